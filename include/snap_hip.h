@@ -1,0 +1,250 @@
+/*
+ * snap_hip.h -- C ABI of libsnap_hip.so: the MI355X (gfx950) kernels behind the
+ * SNAP BEV-fusion + pose-matching hot path.
+ *
+ * The reference (google-research/snap) is pure Python/JAX and exposes NO FFI /
+ * plugin ABI; its boundary is the Flax module API.  This
+ * header is therefore the build-defined boundary a JAX custom-call / XLA FFI
+ * handler (or ctypes, as snap_amd/_lib.py does) would bind.  Each entry point
+ * cites the reference expression (file:line under /root/reference) it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; no torch / C++ types; the caller owns every buffer
+ *     and pre-allocates outputs; the only hidden state is none (no allocation).
+ *   - tensors are row-major, channels-last, contiguous; float = IEEE fp32;
+ *     masks are uint8 (0/1); indices are int32.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no internal sync;
+ *     re-entrant and thread-safe for distinct streams.
+ *   - returns SNAP_OK (0) or a negative SnapStatus; never throws across the ABI.
+ */
+#ifndef SNAP_HIP_H_
+#define SNAP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum SnapStatus {
+  SNAP_OK = 0,
+  SNAP_ERR_BAD_SHAPE = -1,    /* inconsistent / unsupported sizes */
+  SNAP_ERR_UNSUPPORTED = -2,  /* option not implemented */
+  SNAP_ERR_NULL = -3,         /* required pointer is NULL */
+  SNAP_ERR_LAUNCH = -4,       /* hipGetLastError() != hipSuccess after launch */
+  SNAP_ERR_WORKSPACE = -5     /* workspace too small */
+} SnapStatus;
+
+/* Library / device introspection. */
+int snap_abi_version(void);                 /* bumps on any signature change */
+const char* snap_status_string(int status);
+const char* snap_build_arch(void);          /* "gfx950" */
+
+/* ------------------------------------------------------------------------- *
+ * Encoder: implicit-GEMM convolution engine on f32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   replaces flax.linen.Conv / StdConv / Dense as used by
+ *   snap/models/resnet.py:73-132,183-216, snap/models/image_encoder.py:53-94,
+ *   snap/models/layers.py:55-78 (MLP Dense stack) and, with a (H x W x D)-sized
+ *   kernel, the direct rotated-template correlation of
+ *   snap/models/pose_exhaustive_voting.py:86-91.
+ * ------------------------------------------------------------------------- */
+enum { SNAP_PRO_NONE = 0, SNAP_PRO_AFFINE = 1, SNAP_PRO_GN_RELU = 2,
+       SNAP_PRO_RELU_GN = 3, SNAP_PRO_RELU = 4 };
+enum { SNAP_EPI_BIAS = 1, SNAP_EPI_RELU = 2, SNAP_EPI_RESIDUAL = 4,
+       SNAP_EPI_UPSAMPLE2X_ADD = 8, SNAP_EPI_ROWMASK = 16 };
+
+typedef struct SnapConvDesc {
+  int32_t N, H, W, Cin, Cin_stride;   /* input  x[N,H,W,Cin_stride], first Cin used */
+  int32_t KH, KW, stride, pad_t, pad_l;
+  int32_t Ho, Wo, Cout, Cout_stride;  /* output y[N,Ho,Wo,Cout_stride]            */
+  int32_t prologue;                   /* SNAP_PRO_*  applied to every input element
+                                         BEFORE zero padding                       */
+  int32_t epilogue;                   /* OR of SNAP_EPI_*                          */
+  float in_scale, in_shift;           /* SNAP_PRO_AFFINE: x*in_scale + in_shift    */
+} SnapConvDesc;
+
+/* y = epilogue( conv( prologue(x), w ) ).  w is HWIO flattened: [KH*KW*Cin, Cout].
+ * gn_mu/gn_sc: [N, Cin] per-(image, channel) mean and rstd*gamma (from
+ * snap_group_norm_stats_f32); gn_beta: [Cin].  residual: same layout as y.
+ * up_prev: [N, Ho/2, Wo/2, Cout_stride] (bilinear x2, half-pixel centres, edge
+ * clamp == jax.image.resize, image_encoder.py:90).  row_mask: [N*Ho*Wo] uint8.
+ * Unused pointers may be NULL. */
+int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x, const float* w,
+                         float* y, const float* gn_mu, const float* gn_sc,
+                         const float* gn_beta, const float* bias,
+                         const float* residual, const float* up_prev,
+                         const uint8_t* row_mask, void* stream);
+
+/* StdConv weight standardisation over (H,W,I) per output channel, eps inside the
+ * sqrt (resnet.py:34-41,73-79).  w,out: [K, Cout]. */
+int snap_weight_standardize_f32(const float* w, float* out, int32_t K,
+                                int32_t Cout, float eps, void* stream);
+
+/* GroupNorm statistics (resnet.py:46-60): two-pass mean / mean((x-mean)^2) over
+ * (H,W,C/G) per (image, group).  relu_first != 0 computes them on relu(x)
+ * (FPN order, image_encoder.py:80-83).  Outputs mu[N,C], sc[N,C] = rstd*gamma[c].
+ * workspace: snap_group_norm_stats_workspace_bytes(N, HW, C, groups) bytes. */
+size_t snap_group_norm_stats_workspace_bytes(int32_t N, int32_t HW, int32_t C,
+                                             int32_t groups);
+int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, int32_t C,
+                              int32_t C_stride, int32_t groups, float eps,
+                              int32_t relu_first, const float* gamma, float* mu,
+                              float* sc, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* Stand-alone GroupNorm apply (+optional ReLU before/after); used by tests and
+ * for returning normalised tensors.  mode: SNAP_PRO_GN_RELU / SNAP_PRO_RELU_GN. */
+int snap_group_norm_apply_f32(const float* x, float* y, int32_t N, int32_t HW,
+                              int32_t C, const float* mu, const float* sc,
+                              const float* beta, int32_t mode, void* stream);
+
+/* 3x3 / stride 2 / pad 1 max-pool with -inf padding (resnet.py:99). NHWC. */
+int snap_max_pool_3x3s2_f32(const float* x, float* y, int32_t N, int32_t H,
+                            int32_t W, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Lift: voxel -> view projection, top-K view selection, bilinear gather, depth
+ * score interpolation and softmax-weighted multi-view pooling, fused.
+ *   replaces snap/models/streetview_encoder.py:42-178 (k1-k5 of SURVEY 2.2) with
+ *   snap/utils/geometry.py:52-69,198-221,260-280.
+ * ------------------------------------------------------------------------- */
+typedef struct SnapLiftDesc {
+  int32_t B, V, h, w, C;       /* f_images [B,V,h,w,C], C = feature_dim + score bins */
+  int32_t feature_dim;         /* 128 */
+  int32_t num_bins;            /* 32  */
+  int32_t N;                   /* voxels per scene */
+  int32_t K;                   /* 0 => use all V views (interpolate_views_all),
+                                  else top-K selection (V > K)                     */
+  int32_t fisheye;             /* 1: FisheyeCamera, 0: pinhole Camera              */
+  int32_t out_stride;          /* row stride (floats) of `pooled`, >= 2*fd+1, %4==0 */
+  float depth_min, depth_max;  /* depth_min_max                                    */
+  float max_view_distance;     /* < 0: disabled                                    */
+} SnapLiftDesc;
+
+/* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) pad(1) ALREADY scaled to
+ * the feature-map resolution; Rt: [B,V,12] = R row-major (9) then t (3) of
+ * T_view2scene; points: [B,N,3].
+ * pooled: [B,N,out_stride] = mean(fd) | var(fd) | score_max(1) | zero pad;
+ * valid: [B,N] uint8. */
+int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_images,
+                       const float* cam, const float* Rt, const float* points,
+                       float* pooled, uint8_t* valid, void* stream);
+
+/* Debug/parity variant of k1: p2d[B,N,V,2] (ij), vis[B,N,V], depth[B,N,V]. */
+int snap_project_points_f32(int32_t B, int32_t V, int32_t N, int32_t fisheye,
+                            const float* cam, const float* Rt,
+                            const float* points, float* p2d, uint8_t* vis,
+                            float* depth, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * BEV: vertical pooling, modality fusion and matching head.
+ *   replaces snap/models/bev_mapper.py:56-88 (k7), :225-252 (k8), :284-291 +
+ *   snap/models/layers.py:45-52 (k9).
+ * ------------------------------------------------------------------------- */
+enum { SNAP_POOL_MAX = 0, SNAP_POOL_SUM = 1, SNAP_POOL_MEAN = 2 };
+
+/* vol [M, Z, D] + vvalid [M, Z] -> plane [M, D], pvalid [M]. */
+int snap_vertical_pool_f32(const float* vol, const uint8_t* vvalid, float* plane,
+                           uint8_t* pvalid, int64_t M, int32_t Z, int32_t D,
+                           int32_t pooling, void* stream);
+
+/* Fuse `num_planes` modality planes (planes[i] [M,D], valids[i] [M] or NULL=all
+ * valid) with masked max/sum/mean, then matching head: Dense(D->Dm)+bias, L2
+ * normalise (eps), mask.  fused [M,D], fvalid [M], matching [M,Dm] (may be NULL
+ * with Wm NULL). */
+int snap_plane_fuse_match_f32(const float* const* planes,
+                              const uint8_t* const* valids, int32_t num_planes,
+                              int64_t M, int32_t D, int32_t pooling, float* fused,
+                              uint8_t* fvalid, const float* Wm, const float* bm,
+                              int32_t Dm, int32_t normalize, float eps,
+                              float* matching, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Pose: point-vs-map similarity, sampling, scoring, refinement.
+ *   replaces snap/models/bev_localizer.py:157-173 (k10),
+ *   snap/models/pose_estimation.py:126-165 (k11), :49-82 (k12), :168-205 (k13).
+ * ------------------------------------------------------------------------- */
+#define SNAP_SIM_CHUNK 64  /* cells per (max, sum) softmax chunk == one wave64 */
+
+/* sim[B,Nq,XY] = relu(fq . fm) * scale / num_valid[b]  (relu iff clip_negative);
+ * chunk_stats[B,Nq,ceil(XY/64),2] = per-chunk (max, sum exp(x - max)) of the
+ * UN-normalised x = relu(.)*scale: enough to evaluate / sample
+ * prob = softmax_XY(x) / num_valid without a second [B,Nq,XY] tensor.
+ * Optional (may both be NULL): rowstats[B,Nq,2] = (row max, row sum) and
+ * prob[B,Nq,XY] = the full prob_points tensor (needs rowstats).
+ * num_valid: [B] float, already clipped to >= 1 (bev_localizer.py:171). */
+int snap_sim_softmax_f32(const float* fq, const float* fm, int32_t B, int32_t Nq,
+                         int32_t XY, int32_t Dm, float scale,
+                         int32_t clip_negative, const float* num_valid,
+                         float* sim, float* chunk_stats, float* prob,
+                         float* rowstats, void* stream);
+
+/* Draw S correspondences per scene ~ prob_points (iid categorical; counter-based
+ * Philox4x32-10 keyed by (seed, b, s)).  corr[B,S,3] = (n, i, j).
+ * If uniforms != NULL ([B,S,2] in [0,1)), they replace the Philox draws (tests). */
+int snap_ransac_sample_f32(const float* fq, const float* fm,
+                           const float* chunk_stats, int32_t B, int32_t Nq,
+                           int32_t X, int32_t Y, int32_t Dm, float scale,
+                           int32_t clip_negative, int32_t S, uint64_t seed,
+                           const float* uniforms, int32_t* corr, void* stream);
+
+/* corr[B,P*retries*2,3] -> poses[B,P,3] = (angle, tx, ty) of map_t_query:
+ * most distance-consistent retry, 2-point Kabsch (pose_estimation.py:146-165). */
+int snap_poses_from_corr_f32(const int32_t* corr, const float* q_xy, int32_t B,
+                             int32_t Nq, int32_t P, int32_t retries,
+                             float cell_size, float* poses, void* stream);
+
+/* scores[B,P] = sum_n valid_q[b,n] * bilinear(sim[b,n], (R(theta) q_xy[n] + t)/cell)
+ * (pose_estimation.py:63-82).  poses[B,P,3]; map_valid [B,X,Y] only read when
+ * mask_oob != 0.  workspace: snap_pose_score_workspace_bytes(B,Nq,P,X,Y). */
+size_t snap_pose_score_workspace_bytes(int32_t B, int32_t Nq, int32_t P,
+                                       int32_t X, int32_t Y);
+int snap_pose_score_f32(const float* sim, const float* poses, const float* q_xy,
+                        const uint8_t* valid_q, const uint8_t* map_valid,
+                        int32_t B, int32_t Nq, int32_t X, int32_t Y, int32_t P,
+                        float cell_size, int32_t mask_oob, float* scores,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[B,nr*np*np,3] = init[b] o offset(ir,ix,iy)  (pose_estimation.py:178-193).
+ * offs_r[nr] (radians), offs_p[np] (metres). */
+int snap_refine_lattice_f32(const float* init, const float* offs_r,
+                            const float* offs_p, int32_t B, int32_t nr,
+                            int32_t np_, float* out, void* stream);
+
+/* Row-wise argmax with first-index tie-break: idx[B] over scores[B, start:P]. */
+int snap_argmax_rows_f32(const float* scores, int32_t B, int32_t P, int32_t start,
+                         int32_t* idx, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Exhaustive voting: rotated templates + direct correlation.
+ *   replaces snap/models/pose_exhaustive_voting.py:37-69 (k14), :72-104 (k15).
+ * ------------------------------------------------------------------------- */
+/* feat[H,W,D], valid[H,W] (H==W), tfm[R/4,4] = (cos, sin, tx, ty) of
+ * templates_t_grid for the first quadrant of rotations ->
+ * templates[R,H,W,D], tvalid[R,H,W]; also the engine-layout copies
+ * tw[H,W,D,R] (HWIO; R % 4 == 0) and cw[H,W,1,R] = 180-degree-rotated tvalid as
+ * float (the reference's un-flipped mask convolution,
+ * pose_exhaustive_voting.py:97-99); tcount[R] = sum(tvalid[r]). */
+int snap_rotate_templates_f32(const float* feat, const uint8_t* valid,
+                              const float* tfm, int32_t H, int32_t W, int32_t D,
+                              int32_t R, float cell_size, float* templates,
+                              uint8_t* tvalid, float* tw, float* cw,
+                              float* tcount, void* stream);
+
+/* map[H,W,D], mvalid[H,W] -> map_pad[3H-2,3W-2,D] (edge), mvalid_pad[3H-2,3W-2]
+ * (zero padded, as float). */
+int snap_pad_map_f32(const float* map, const uint8_t* mvalid, int32_t H, int32_t W,
+                     int32_t D, float* map_pad, float* mvalid_pad, void* stream);
+
+/* raw[Ho,Wo,Rp], cnt[Ho,Wo,Rp] (engine outputs) -> scores[R,Ho,Wo]:
+ * -inf where cnt <= min_overlap*H*W (if min_overlap >= 0), then / tcount[r]. */
+int snap_template_finalize_f32(const float* raw, const float* cnt,
+                               const float* tcount, int32_t Ho, int32_t Wo,
+                               int32_t R, int32_t Rp, float overlap_threshold,
+                               int32_t use_overlap, float* scores, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SNAP_HIP_H_ */

@@ -1,0 +1,115 @@
+"""Oracle (test infrastructure): BEV mapper (vertical pooling, fusion, matching head).
+
+Restates ``snap/models/bev_mapper.py``.
+"""
+import numpy as np
+
+from oracle import encoder
+from oracle import lift
+
+
+def vertical_pooling(config, features, valid):
+  """bev_mapper.py:56-88 for pooling in {'max', 'sum', 'mean'}.
+
+  features [..., Z, D], valid [..., Z] -> plane features [..., D], valid [...].
+  """
+  dtype = features.dtype
+  valid_any = valid.any(-1)
+  valid_any_or_all = np.where(valid_any[..., None], valid, True)
+  where = valid_any_or_all[..., None]
+  pooling = config['pooling']
+  if pooling == 'max':
+    out = np.where(where, features, -np.inf).max(-2)
+  elif pooling == 'sum':
+    out = np.where(where, features, 0).sum(-2)
+  elif pooling == 'mean':
+    out = np.where(where, features, 0).sum(-2) / where.sum(-2)
+  else:
+    raise NotImplementedError(pooling)
+  out = np.where(valid_any[..., None], out, 0).astype(dtype)
+  return dict(features=out, valid=valid_any)
+
+
+def build_xyz_query(config, grid, scene_t_view, xy_bev=None, z_offset=None):
+  """bev_mapper.py:162-196 (eval path: no random z offset).
+
+  Returns xyz_query [B, X, Y, Z, 3].
+  """
+  t = scene_t_view.t
+  dtype = t.dtype
+  B = t.shape[0]
+  xy = xy_bev
+  if xy is None:
+    xy = grid.index_to_xyz(grid.grid_index()).astype(dtype)
+  if xy.ndim != 4:
+    xy = np.repeat(xy[None], B, axis=0)
+  if z_offset is None:
+    camera_heights = np.median(t[..., -1], axis=-1)
+    height_below_camera = config.get('scene_z_offset', 4.0)
+    z_offset = (camera_heights - height_below_camera).astype(dtype)
+  scene_z_height = config.get('scene_z_height', 12.0)
+  cell = grid.cell_size
+  z = (
+      np.arange(0, scene_z_height, cell).astype(dtype)[None]
+      + z_offset[:, None]
+      + dtype.type(cell / 2)
+  ).astype(dtype)
+  xy_b, z_b = np.broadcast_arrays(
+      xy[:, :, :, None, :], z[:, None, None, :, None]
+  )
+  return np.concatenate([xy_b, z_b[..., :1]], axis=-1).astype(dtype)
+
+
+def fuse_neural_maps(config, planes):
+  """bev_mapper.py:225-252 (modality dropout never fires: train is not forwarded)."""
+  if len(planes) == 1:
+    return planes[0]
+  features = np.stack([p['features'] for p in planes], axis=-2)
+  valid = np.stack([p['valid'] for p in planes], axis=-1)
+  return vertical_pooling(config['modality_fusion'], features, valid)
+
+
+def matching_head(params, config, plane):
+  """bev_mapper.py:284-291."""
+  f = encoder.dense(params['matching_proj'], plane['features'])
+  if config['normalize_matching_features']:
+    f = encoder.normalize(f)
+  f = np.where(plane['valid'][..., None], f, 0).astype(plane['features'].dtype)
+  return dict(features=f, valid=plane['valid'])
+
+
+def bev_mapper(params, config, grid, data):
+  """bev_mapper.py:254-296 (streetview [+ aerial] modalities, eval)."""
+  pred = {}
+  planes = []
+  data = dict(data)
+  if config.get('streetview_encoder') is not None:
+    if 'xyz_query' not in data:
+      data['xyz_query'] = build_xyz_query(
+          config, grid, data['T_view2scene'], data.get('xy_bev'),
+          data.get('z_offset'),
+      )
+    sv = lift.streetview_encoder(
+        params['streetview_encoder'], config['streetview_encoder'], data
+    )
+    vol = sv['feature_volume']
+    sv['vertical_pooling'] = {}
+    sv['feature_plane'] = vertical_pooling(
+        config['pooling'], vol['features'], vol['valid']
+    )
+    pred['streetview'] = sv
+    planes.append(sv['feature_plane'])
+  if config.get('aerial_encoder') is not None and 'rasters' in data:
+    pyr = encoder.image_encoder(
+        params['aerial_encoder'], config['aerial_encoder'],
+        data['rasters']['rgb'],
+    )
+    f = pyr['features'][-1]
+    plane = dict(features=f, valid=np.ones(f.shape[:-1], bool))
+    pred['aerial'] = {'feature_plane': plane}
+    planes.append(plane)
+  pred['bev_features'] = plane = fuse_neural_maps(config, planes)
+  if config.get('matching_dim') is not None:
+    pred['bev_matching'] = matching_head(params, config, plane)
+  pred['_xyz_query'] = data.get('xyz_query')
+  return pred

@@ -1,0 +1,141 @@
+"""ctypes binding of libsnap_hip.so (the C ABI declared in include/snap_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the
+import of :mod:`snap_amd.ops` raises.  Build it with ``make -C snap_amd/csrc`` or
+``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsnap_hip.so')
+
+c_int = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+c_float = ctypes.c_float
+c_size = ctypes.c_size_t
+ptr = ctypes.c_void_p
+
+
+class SnapConvDesc(ctypes.Structure):
+  _fields_ = [
+      ('N', c_int), ('H', c_int), ('W', c_int), ('Cin', c_int),
+      ('Cin_stride', c_int),
+      ('KH', c_int), ('KW', c_int), ('stride', c_int), ('pad_t', c_int),
+      ('pad_l', c_int),
+      ('Ho', c_int), ('Wo', c_int), ('Cout', c_int), ('Cout_stride', c_int),
+      ('prologue', c_int), ('epilogue', c_int),
+      ('in_scale', c_float), ('in_shift', c_float),
+  ]
+
+
+class SnapLiftDesc(ctypes.Structure):
+  _fields_ = [
+      ('B', c_int), ('V', c_int), ('h', c_int), ('w', c_int), ('C', c_int),
+      ('feature_dim', c_int), ('num_bins', c_int), ('N', c_int), ('K', c_int),
+      ('fisheye', c_int), ('out_stride', c_int),
+      ('depth_min', c_float), ('depth_max', c_float),
+      ('max_view_distance', c_float),
+  ]
+
+
+# name -> (restype, argtypes): every symbol include/snap_hip.h declares.
+SIGNATURES = {
+    'snap_abi_version': (c_int, []),
+    'snap_status_string': (ctypes.c_char_p, [c_int]),
+    'snap_build_arch': (ctypes.c_char_p, []),
+    'snap_conv2d_nhwc_f32': (
+        c_int,
+        [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
+         ptr, ptr, ptr],
+    ),
+    'snap_weight_standardize_f32': (c_int, [ptr, ptr, c_int, c_int, c_float, ptr]),
+    'snap_group_norm_stats_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int]),
+    'snap_group_norm_stats_f32': (
+        c_int,
+        [ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr,
+         ptr, c_size, ptr],
+    ),
+    'snap_group_norm_apply_f32': (
+        c_int, [ptr, ptr, c_int, c_int, c_int, ptr, ptr, ptr, c_int, ptr]
+    ),
+    'snap_max_pool_3x3s2_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, ptr]),
+    'snap_lift_pool_f32': (
+        c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]
+    ),
+    'snap_project_points_f32': (
+        c_int, [c_int, c_int, c_int, c_int, ptr, ptr, ptr, ptr, ptr, ptr, ptr]
+    ),
+    'snap_vertical_pool_f32': (
+        c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, c_int, ptr]
+    ),
+    'snap_plane_fuse_match_f32': (
+        c_int,
+        [ptr, ptr, c_int, c_i64, c_int, c_int, ptr, ptr, ptr, ptr, c_int, c_int,
+         c_float, ptr, ptr],
+    ),
+    'snap_sim_softmax_f32': (
+        c_int,
+        [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr,
+         ptr, ptr, ptr],
+    ),
+    'snap_ransac_sample_f32': (
+        c_int,
+        [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+         c_int, c_u64, ptr, ptr, ptr],
+    ),
+    'snap_poses_from_corr_f32': (
+        c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr, ptr]
+    ),
+    'snap_pose_score_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    'snap_pose_score_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float,
+         c_int, ptr, ptr, c_size, ptr],
+    ),
+    'snap_refine_lattice_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, ptr, ptr]),
+    'snap_argmax_rows_f32': (c_int, [ptr, c_int, c_int, c_int, ptr, ptr]),
+    'snap_rotate_templates_f32': (
+        c_int,
+        [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr, ptr, ptr, ptr,
+         ptr, ptr],
+    ),
+    'snap_pad_map_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, ptr, ptr, ptr]),
+    'snap_template_finalize_f32': (
+        c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr]
+    ),
+}
+
+ABI_VERSION = 1
+
+_lib = None
+
+
+def load():
+  """Load libsnap_hip.so and bind every declared symbol; raises if impossible."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f'{LIB_PATH} not found: the HIP extension is not built. '
+        'Run `make -C snap_amd/csrc` (needs hipcc); there is no CPU fallback.'
+    )
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, (restype, argtypes) in SIGNATURES.items():
+    fn = getattr(lib, name)  # AttributeError if the symbol is missing
+    fn.restype = restype
+    fn.argtypes = argtypes
+  if lib.snap_abi_version() != ABI_VERSION:
+    raise RuntimeError(
+        f'libsnap_hip.so ABI {lib.snap_abi_version()} != expected {ABI_VERSION}; rebuild.'
+    )
+  _lib = lib
+  return lib
+
+
+def check(status, what):
+  if status != 0:
+    msg = load().snap_status_string(status).decode()
+    raise RuntimeError(f'{what} failed: {msg} (status {status})')

@@ -1,0 +1,32 @@
+"""BEV localization model config (model part of snap/configs/train_localization.py:21-50).
+
+The data / optimiser / schedule entries of the reference config belong to the
+Scenic training harness, which is out of scope; the few scalar ones a driver needs
+are kept as plain values.
+"""
+from snap_amd.configs import defaults
+from snap_amd.utils.config_dict import ConfigDict
+
+
+def get_config(args_str: None | str = None) -> ConfigDict:
+  args = defaults.parse_argument_string(args_str)
+  model = defaults.bev_localizer()
+  model.filter_points_in_fov = True
+  model.num_pose_samples = 10_000
+  model.num_pose_sampling_retries = 8
+  modalities = args['modalities'].split('+')
+  model.bev_mapper = defaults.bev_mapper(modalities)
+  encoder = defaults.resnet(args['image_encoder'])
+  if defaults.MapModalities.STREETVIEW in modalities:
+    model.bev_mapper.streetview_encoder.image_encoder.encoder = encoder
+  else:
+    query = defaults.bev_mapper(modalities=(defaults.MapModalities.STREETVIEW,))
+    query.streetview_encoder.image_encoder.encoder = encoder
+    dim = query.streetview_encoder.feature_dim
+    query.streetview_encoder.fusion.layers = (dim * 2, dim * 2, dim)
+    model.bev_mapper_query = query
+  return ConfigDict(
+      model_name='bev_localizer', model=model, batch_size=1, rng_seed=0,
+      dtype_str='float32', voxel_size=0.2,
+      lr_configs=dict(base_learning_rate=5e-5), num_training_steps=400_000,
+  )

@@ -1,0 +1,184 @@
+// BEV plane kernels (HBM-bound):
+//   * vertical pooling of the voxel volume into a BEV plane
+//       snap/models/bev_mapper.py:56-88 (max / sum / mean with validity masks)
+//   * modality fusion (same masked reduce over stacked planes) + matching head
+//       snap/models/bev_mapper.py:225-252, :284-291 and layers.normalize
+//       (snap/models/layers.py:45-52), fused in one pass over the planes.
+// A 32-lane half-wave owns one BEV cell; lane q holds channels 4q..4q+3 (one
+// 512-byte coalesced row per voxel for D = 128); per-column reductions run in
+// registers, the L2-norm over the 32 matching channels uses xor-shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXQ = 2;  // up to D = 256 channels (MAXQ * 32 lanes * 4)
+
+__global__ __launch_bounds__(256) void vertical_pool_kernel(
+    const float* __restrict__ vol, const uint8_t* __restrict__ vvalid, float* __restrict__ plane,
+    uint8_t* __restrict__ pvalid, int64_t M, int Z, int D, int pooling) {
+  const int hl = threadIdx.x & 31;
+  const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (m >= M) return;
+  const int nq = D >> 2;
+  const uint8_t* vv = vvalid + m * Z;
+  const float* base = vol + m * Z * D;
+  f32x4 acc[MAXQ];
+  const float init = pooling == SNAP_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{init, init, init, init};
+  int count = 0;
+  for (int z = 0; z < Z; ++z) {
+    if (!vv[z]) continue;  // half-wave uniform
+    ++count;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+      const int q = hl + 32 * i;
+      if (q < nq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)z * D + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[i][e] = pooling == SNAP_POOL_MAX ? fmaxf(acc[i][e], v[e]) : acc[i][e] + v[e];
+      }
+    }
+  }
+  const bool any = count > 0;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int q = hl + 32 * i;
+    if (q < nq) {
+      f32x4 o = acc[i];
+      if (!any) o = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (any && pooling == SNAP_POOL_MEAN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = o[e] / (float)count;
+      }
+      *reinterpret_cast<f32x4*>(plane + m * D + 4 * q) = o;
+    }
+  }
+  if (hl == 0) pvalid[m] = any ? 1 : 0;
+}
+
+struct FuseArgs {
+  const float* planes[4];
+  const uint8_t* valids[4];
+  int num_planes;
+  int64_t M;
+  int D, pooling;
+  float* fused;
+  uint8_t* fvalid;
+  const float* Wm;
+  const float* bm;
+  int Dm, normalize;
+  float eps;
+  float* matching;
+};
+
+__global__ __launch_bounds__(256) void plane_fuse_match_kernel(const FuseArgs a) {
+  const int hl = threadIdx.x & 31;
+  const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (m >= a.M) return;
+  const int nq = a.D >> 2;
+  f32x4 acc[MAXQ];
+  const float init = a.pooling == SNAP_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{init, init, init, init};
+  int count = 0;
+  for (int p = 0; p < a.num_planes; ++p) {
+    const bool v = a.valids[p] ? (a.valids[p][m] != 0) : true;
+    if (!v) continue;
+    ++count;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+      const int q = hl + 32 * i;
+      if (q < nq) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a.planes[p] + m * a.D + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[i][e] = a.pooling == SNAP_POOL_MAX ? fmaxf(acc[i][e], x[e]) : acc[i][e] + x[e];
+      }
+    }
+  }
+  const bool any = count > 0;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    if (!any) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (any && a.pooling == SNAP_POOL_MEAN) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][e] = acc[i][e] / (float)count;
+    }
+    const int q = hl + 32 * i;
+    if (q < nq && a.fused) *reinterpret_cast<f32x4*>(a.fused + m * a.D + 4 * q) = acc[i];
+  }
+  if (hl == 0 && a.fvalid) a.fvalid[m] = any ? 1 : 0;
+  if (!a.matching) return;
+
+  // matching head: lane j computes output channel j (Dm <= 32).
+  const int j = hl;
+  float y = (j < a.Dm) ? a.bm[j] : 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    for (int q = 0; q < 32; ++q) {
+      const int cq = q + 32 * i;
+      if (cq >= nq) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xv = __shfl(acc[i][e], q, 32);
+        if (j < a.Dm) y += xv * a.Wm[(int64_t)(4 * cq + e) * a.Dm + j];
+      }
+    }
+  }
+  if (a.normalize) {
+    float ss = (j < a.Dm) ? y * y : 0.f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 32);
+    const float nrm = sqrtf(ss);
+    const bool invalid = nrm < a.eps;
+    // layers.normalize: y_safe = where(invalid, eps, x); z = x / ||y_safe||.
+    const float denom = invalid ? sqrtf((float)a.Dm) * a.eps : nrm;
+    y = invalid ? 0.f : y / denom;
+  }
+  if (j < a.Dm) a.matching[m * a.Dm + j] = any ? y : 0.f;
+}
+
+}  // namespace
+
+extern "C" int snap_vertical_pool_f32(const float* vol, const uint8_t* vvalid, float* plane,
+                                      uint8_t* pvalid, int64_t M, int32_t Z, int32_t D,
+                                      int32_t pooling, void* stream) {
+  if (!vol || !vvalid || !plane || !pvalid) return SNAP_ERR_NULL;
+  if (M <= 0 || Z <= 0 || D <= 0 || D % 4 != 0 || D > MAXQ * 128) return SNAP_ERR_BAD_SHAPE;
+  if (pooling < SNAP_POOL_MAX || pooling > SNAP_POOL_MEAN) return SNAP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(vertical_pool_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), vol, vvalid, plane, pvalid, M, Z, D,
+                     pooling);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_plane_fuse_match_f32(const float* const* planes, const uint8_t* const* valids,
+                                         int32_t num_planes, int64_t M, int32_t D, int32_t pooling,
+                                         float* fused, uint8_t* fvalid, const float* Wm,
+                                         const float* bm, int32_t Dm, int32_t normalize, float eps,
+                                         float* matching, void* stream) {
+  if (!planes) return SNAP_ERR_NULL;
+  if (num_planes < 1 || num_planes > 4) return SNAP_ERR_UNSUPPORTED;
+  if (M <= 0 || D <= 0 || D % 4 != 0 || D > MAXQ * 128) return SNAP_ERR_BAD_SHAPE;
+  if (pooling < SNAP_POOL_MAX || pooling > SNAP_POOL_MEAN) return SNAP_ERR_UNSUPPORTED;
+  if (matching && (!Wm || !bm)) return SNAP_ERR_NULL;
+  if (matching && (Dm < 1 || Dm > 32)) return SNAP_ERR_UNSUPPORTED;
+  FuseArgs a;
+  for (int i = 0; i < 4; ++i) {
+    a.planes[i] = i < num_planes ? planes[i] : nullptr;
+    a.valids[i] = (i < num_planes && valids) ? valids[i] : nullptr;
+    if (i < num_planes && !a.planes[i]) return SNAP_ERR_NULL;
+  }
+  a.num_planes = num_planes;
+  a.M = M; a.D = D; a.pooling = pooling;
+  a.fused = fused; a.fvalid = fvalid;
+  a.Wm = Wm; a.bm = bm; a.Dm = Dm; a.normalize = normalize; a.eps = eps;
+  a.matching = matching;
+  hipLaunchKernelGGL(plane_fuse_match_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

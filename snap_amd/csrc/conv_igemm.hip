@@ -1,0 +1,393 @@
+// Implicit-GEMM convolution / dense engine on the f32 matrix cores of gfx950.
+//
+//   y[m, co] = epilogue( sum_{kh,kw,ci} prologue(x[n, ho*s+kh-pt, wo*s+kw-pl, ci]) * w[(kh*KW+kw)*Cin+ci, co] )
+//
+// GEMM view: M = N*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin.  One 256-thread
+// workgroup (4 wave64 in a 2x2 arrangement) owns a BM x BN output tile and walks
+// K in BK=16 slabs.  A (im2col rows, gathered on the fly, never materialised) and
+// B (HWIO weights) slabs are staged global -> registers -> LDS with one barrier per
+// slab (register double buffering: the global loads of slab k+1 are in flight
+// while the MFMAs of slab k run).  A is stored K-major in LDS ([BK][BM+2]) so that
+// the v_mfma_f32_32x32x2_f32 operand fetch (lane l: A[i=l&31][k=l>>5]) is a
+// conflict-free ds_read_b32 and the transposing stores hit 32 distinct banks.
+// The f32 MFMA is an exact fmaf chain (cdna_hip_programming.md section 3), so the
+// result is bitwise a k-ordered fp32 dot product: parity-grade numerics.
+//
+// Fusions (all optional): GroupNorm+ReLU / ReLU+GroupNorm / ReLU / affine applied
+// to A while staging (padding zeros are inserted AFTER the prologue, as in the
+// reference where the conv pads the normalised tensor); bias, residual add,
+// bilinear x2 up-sample-add (FPN), ReLU and a row mask in the epilogue.
+//
+// Replaces: flax.linen.Conv / StdConv / Dense call sites of
+// snap/models/resnet.py:83-132,200-215, image_encoder.py:67-94, layers.py:66-77,
+// streetview_encoder.py:228,281, bev_mapper.py:285 and the direct correlation of
+// pose_exhaustive_voting.py:86-91.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  SnapConvDesc d;
+  const float* x;
+  const float* w;
+  float* y;
+  const float* gn_mu;
+  const float* gn_sc;
+  const float* gn_beta;
+  const float* bias;
+  const float* residual;
+  const float* up_prev;
+  const uint8_t* row_mask;
+  int M;       // N*Ho*Wo
+  int K;       // KH*KW*Cin
+  int ctiles;  // ceil(Cin/16)   (VEC path)
+  int nk;      // number of K slabs
+};
+
+constexpr int BK = 16;
+
+__device__ __forceinline__ float apply_pro(float v, int mode, float mu, float sc,
+                                           float beta, float s, float t) {
+  switch (mode) {
+    case SNAP_PRO_AFFINE: return v * s + t;
+    case SNAP_PRO_GN_RELU: return fmaxf((v - mu) * sc + beta, 0.f);
+    case SNAP_PRO_RELU_GN: return (fmaxf(v, 0.f) - mu) * sc + beta;
+    case SNAP_PRO_RELU: return fmaxf(v, 0.f);
+    default: return v;
+  }
+}
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int AS = BM + 2;    // LDS row stride of the K-major A slab
+  constexpr int TM = BM / 64;   // 32x32 MFMA tiles per wave along M
+  constexpr int TN = BN / 64;   // ... along N
+  constexpr int AROWS = BM / 64;          // VEC: float4 rows per thread
+  constexpr int AELEMS = BM / 16;         // SCALAR: scalars per thread
+  constexpr int BQ = BN / 4;              // float4 per B row
+  constexpr int BROWS_PER_PASS = 256 / BQ;
+  constexpr int BPASS = BK / BROWS_PER_PASS;  // float4 per thread for B
+
+  __shared__ float As[2][BK * AS];
+  __shared__ float Bs[2][BK * BN];
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int HoWo = d.Ho * d.Wo;
+  const int mode = d.prologue;
+
+  // ---- per-thread A row bookkeeping -------------------------------------
+  constexpr int NR = VEC ? AROWS : AELEMS;
+  int r_n[NR], r_hb[NR], r_wb[NR];
+  bool r_ok[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int row = VEC ? (tid >> 2) + 64 * i : (tid >> 4) + 16 * i;
+    const int m = m0 + row;
+    r_ok[i] = m < a.M;
+    const int mm = r_ok[i] ? m : 0;
+    const int n = mm / HoWo;
+    const int r = mm - n * HoWo;
+    const int ho = r / d.Wo;
+    const int wo = r - ho * d.Wo;
+    r_n[i] = n;
+    r_hb[i] = ho * d.stride - d.pad_t;
+    r_wb[i] = wo * d.stride - d.pad_l;
+  }
+  const int akq = tid & 3;    // VEC: which float4 of the 16-wide K slab
+  const int akid = tid & 15;  // SCALAR: which k of the slab
+
+  // B loader coordinates
+  const int bcq = tid % BQ;
+  const int bkr = tid / BQ;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging registers
+  f32x4 xa[VEC ? AROWS : 1], xmu[VEC ? AROWS : 1], xsc[VEC ? AROWS : 1], xbeta;
+  bool xin[VEC ? AROWS : 1];
+  float sa[VEC ? 1 : AELEMS], smu[VEC ? 1 : AELEMS], ssc[VEC ? 1 : AELEMS], sbeta = 0.f;
+  bool sin_[VEC ? 1 : AELEMS];
+  f32x4 xb[BPASS];
+  int cur_c = 0;  // channel of element 0 of this thread's quad (VEC)
+
+  // K-slab walk state (VEC): (kpos = kh*KW+kw, ct)
+  int kpos = 0, ct = 0, kh = 0, kw = 0;
+
+  auto load_slab = [&](int kt) {
+    if constexpr (VEC) {
+      const int c = ct * BK + 4 * akq;
+      cur_c = c;
+      const bool cvalid = c < d.Cin;
+      const bool need_gn = (mode == SNAP_PRO_GN_RELU || mode == SNAP_PRO_RELU_GN);
+      if (need_gn && cvalid) {
+        xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + c);
+      } else {
+        xbeta = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int hi = r_hb[i] + kh, wi = r_wb[i] + kw;
+        const bool inb = r_ok[i] && cvalid && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+        xin[i] = inb;
+        if (inb) {
+          const int64_t off = ((int64_t)(r_n[i] * d.H + hi) * d.W + wi) * d.Cin_stride + c;
+          xa[i] = *reinterpret_cast<const f32x4*>(a.x + off);
+          if (need_gn) {
+            const int64_t so = (int64_t)r_n[i] * d.Cin + c;
+            xmu[i] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
+            xsc[i] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
+          }
+        } else {
+          xa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      // B rows of this slab
+      const int wrow0 = kpos * d.Cin + ct * BK;
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p) {
+        const int kr = bkr + p * BROWS_PER_PASS;
+        const int col = n0 + 4 * bcq;
+        const bool ok = (ct * BK + kr) < d.Cin && col < d.Cout;
+        xb[p] = ok ? *reinterpret_cast<const f32x4*>(a.w + (int64_t)(wrow0 + kr) * d.Cout + col)
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const int k = kt * BK + akid;
+      const bool kvalid = k < a.K;
+      const int kk = kvalid ? k : 0;
+      const int kp = kk / d.Cin;
+      const int c = kk - kp * d.Cin;
+      const int skh = kp / d.KW;
+      const int skw = kp - skh * d.KW;
+      const bool need_gn = (mode == SNAP_PRO_GN_RELU || mode == SNAP_PRO_RELU_GN);
+      sbeta = (need_gn && kvalid) ? a.gn_beta[c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < AELEMS; ++i) {
+        const int hi = r_hb[i] + skh, wi = r_wb[i] + skw;
+        const bool inb = r_ok[i] && kvalid && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+        sin_[i] = inb;
+        if (inb) {
+          const int64_t off = ((int64_t)(r_n[i] * d.H + hi) * d.W + wi) * d.Cin_stride + c;
+          sa[i] = a.x[off];
+          if (need_gn) {
+            smu[i] = a.gn_mu[(int64_t)r_n[i] * d.Cin + c];
+            ssc[i] = a.gn_sc[(int64_t)r_n[i] * d.Cin + c];
+          }
+        } else {
+          sa[i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p) {
+        const int kr = bkr + p * BROWS_PER_PASS;
+        const int col = n0 + 4 * bcq;
+        const bool ok = (kt * BK + kr) < a.K && col < d.Cout;
+        xb[p] = ok ? *reinterpret_cast<const f32x4*>(a.w + (int64_t)(kt * BK + kr) * d.Cout + col)
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  auto advance = [&]() {
+    if constexpr (VEC) {
+      if (++ct == a.ctiles) {
+        ct = 0;
+        ++kpos;
+        if (++kw == d.KW) { kw = 0; ++kh; }
+      }
+    }
+  };
+
+  auto store_slab = [&](int buf) {
+    float* as = As[buf];
+    float* bs = Bs[buf];
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int row = (tid >> 2) + 64 * i;
+        f32x4 v = xa[i];
+        if (xin[i]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pv = apply_pro(v[e], mode, xmu[i][e], xsc[i][e], xbeta[e],
+                                       d.in_scale, d.in_shift);
+            v[e] = (cur_c + e < d.Cin) ? pv : 0.f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) as[(4 * akq + e) * AS + row] = v[e];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AELEMS; ++i) {
+        const int row = (tid >> 4) + 16 * i;
+        float v = sa[i];
+        if (sin_[i]) v = apply_pro(v, mode, smu[i], ssc[i], sbeta, d.in_scale, d.in_shift);
+        as[akid * AS + row] = v;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) {
+      const int kr = bkr + p * BROWS_PER_PASS;
+      *reinterpret_cast<f32x4*>(bs + kr * BN + 4 * bcq) = xb[p];
+    }
+  };
+
+  // ---- main loop ---------------------------------------------------------
+  load_slab(0);
+  advance();
+  store_slab(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int kt = 0; kt < a.nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < a.nk;
+    if (more) {
+      load_slab(kt + 1);
+      advance();
+    }
+    const float* as = As[cur];
+    const float* bs = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        av[i] = as[(2 * kk + lhi) * AS + wr * (BM / 2) + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bv[j] = bs[(2 * kk + lhi) * BN + wc * (BN / 2) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_slab(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------
+  const int epi = d.epilogue;
+  const int Hp = d.Ho >> 1, Wp = d.Wo >> 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int m = m0 + wr * (BM / 2) + i * 32 + ri;
+      if (m >= a.M) continue;
+      const bool keep = (epi & SNAP_EPI_ROWMASK) ? (a.row_mask[m] != 0) : true;
+      // bilinear x2 taps of the coarser level (half-pixel centres, edge clamp)
+      int64_t u00 = 0, u01 = 0, u10 = 0, u11 = 0;
+      float wh_lo = 0.f, wh_hi = 0.f, ww_lo = 0.f, ww_hi = 0.f;
+      if (epi & SNAP_EPI_UPSAMPLE2X_ADD) {
+        const int n = m / HoWo;
+        const int rr = m - n * HoWo;
+        const int ho = rr / d.Wo;
+        const int wo = rr - ho * d.Wo;
+        const float sh = (ho + 0.5f) * 0.5f - 0.5f;
+        const float sw = (wo + 0.5f) * 0.5f - 0.5f;
+        const float fh = floorf(sh), fw = floorf(sw);
+        wh_hi = sh - fh; wh_lo = 1.f - wh_hi;
+        ww_hi = sw - fw; ww_lo = 1.f - ww_hi;
+        const int h0 = min(max((int)fh, 0), Hp - 1), h1 = min(max((int)fh + 1, 0), Hp - 1);
+        const int w0 = min(max((int)fw, 0), Wp - 1), w1 = min(max((int)fw + 1, 0), Wp - 1);
+        const int64_t base = (int64_t)n * Hp * Wp;
+        u00 = (base + (int64_t)h0 * Wp + w0) * d.Cout_stride;
+        u01 = (base + (int64_t)h0 * Wp + w1) * d.Cout_stride;
+        u10 = (base + (int64_t)h1 * Wp + w0) * d.Cout_stride;
+        u11 = (base + (int64_t)h1 * Wp + w1) * d.Cout_stride;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+        if (col >= d.Cout) continue;
+        float v = acc[i][j][r];
+        if (epi & SNAP_EPI_BIAS) v += a.bias[col];
+        const int64_t o = (int64_t)m * d.Cout_stride + col;
+        if (epi & SNAP_EPI_RESIDUAL) v += a.residual[o];
+        if (epi & SNAP_EPI_UPSAMPLE2X_ADD) {
+          const float c0 = a.up_prev[u00 + col] * wh_lo + a.up_prev[u10 + col] * wh_hi;
+          const float c1 = a.up_prev[u01 + col] * wh_lo + a.up_prev[u11 + col] * wh_hi;
+          v += c0 * ww_lo + c1 * ww_hi;
+        }
+        if (epi & SNAP_EPI_RELU) v = fmaxf(v, 0.f);
+        a.y[o] = keep ? v : 0.f;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool VEC>
+int launch(const ConvArgs& a, hipStream_t s) {
+  dim3 grid((unsigned)snap_cdiv(a.M, BM), (unsigned)snap_cdiv(a.d.Cout, BN));
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC>), grid, dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+}  // namespace
+
+extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
+                                    const float* w, float* y, const float* gn_mu,
+                                    const float* gn_sc, const float* gn_beta,
+                                    const float* bias, const float* residual,
+                                    const float* up_prev, const uint8_t* row_mask,
+                                    void* stream) {
+  if (!desc || !x || !w || !y) return SNAP_ERR_NULL;
+  const SnapConvDesc& d = *desc;
+  if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 ||
+      d.KW <= 0 || d.stride <= 0 || d.Ho <= 0 || d.Wo <= 0)
+    return SNAP_ERR_BAD_SHAPE;
+  if (d.Cin_stride < d.Cin || d.Cout_stride < d.Cout) return SNAP_ERR_BAD_SHAPE;
+  if (d.Cout % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if ((int64_t)d.N * d.Ho * d.Wo > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  const bool gn = d.prologue == SNAP_PRO_GN_RELU || d.prologue == SNAP_PRO_RELU_GN;
+  if (d.prologue < 0 || d.prologue > SNAP_PRO_RELU) return SNAP_ERR_UNSUPPORTED;
+  if (gn && (!gn_mu || !gn_sc || !gn_beta)) return SNAP_ERR_NULL;
+  if ((d.epilogue & SNAP_EPI_BIAS) && !bias) return SNAP_ERR_NULL;
+  if ((d.epilogue & SNAP_EPI_RESIDUAL) && !residual) return SNAP_ERR_NULL;
+  if ((d.epilogue & SNAP_EPI_ROWMASK) && !row_mask) return SNAP_ERR_NULL;
+  if (d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD) {
+    if (!up_prev) return SNAP_ERR_NULL;
+    if ((d.Ho & 1) || (d.Wo & 1)) return SNAP_ERR_BAD_SHAPE;
+  }
+  ConvArgs a;
+  a.d = d;
+  a.x = x; a.w = w; a.y = y;
+  a.gn_mu = gn_mu; a.gn_sc = gn_sc; a.gn_beta = gn_beta;
+  a.bias = bias; a.residual = residual; a.up_prev = up_prev; a.row_mask = row_mask;
+  a.M = d.N * d.Ho * d.Wo;
+  a.K = d.KH * d.KW * d.Cin;
+  // float4 path: channel runs must be 16-byte addressable.
+  const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
+                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   (!gn || (d.Cin % 4 == 0));
+  if (vec) {
+    a.ctiles = (d.Cin + BK - 1) / BK;
+    a.nk = d.KH * d.KW * a.ctiles;
+  } else {
+    a.ctiles = 0;
+    a.nk = (a.K + BK - 1) / BK;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool narrow = d.Cout <= 64 || (d.Cout % 128 != 0 && d.Cout % 128 <= 64);
+  if (vec) {
+    return narrow ? launch<128, 64, true>(a, s) : launch<128, 128, true>(a, s);
+  }
+  return narrow ? launch<128, 64, false>(a, s) : launch<128, 128, false>(a, s);
+}

@@ -1,0 +1,327 @@
+// Camera-ray lift (voxel-pull): for every voxel centre, project into the views,
+// select the K nearest visible views, bilinearly gather the image features,
+// interpolate the per-observation depth score and pool the observations with
+// score-softmax weights -- ONE pass, nothing intermediate in HBM.
+//
+// Mapping: a 32-lane half-wave owns one voxel.
+//   * projection / visibility: lane v handles view v (V <= 32);
+//   * top-K selection: K argmin rounds over the half-wave with xor-shuffles,
+//     ties towards the lowest view index (== jax.lax.top_k(-dist));
+//   * gather: lane q loads channels 4q..4q+3 of each of the 4 taps
+//     (one 512-byte contiguous row segment per tap for feature_dim = 128);
+//   * softmax / mean / variance over the <= KMAX observations held in registers.
+// Voxels are ordered z-fastest, so consecutive half-waves walk up an image column:
+// the taps of neighbouring voxels share cache lines (L1/L2 reuse).
+//
+// Replaces snap/models/streetview_encoder.py:42-65 (project), :127-138 (select),
+// :69-105 (gather), :109-124 (depth score), :141-178 (pool) and the camera maths
+// of snap/utils/geometry.py:52-69,198-221,260-280.
+#include "common.h"
+
+namespace {
+
+struct LiftArgs {
+  SnapLiftDesc d;
+  const float* f;
+  const float* cam;
+  const float* Rt;
+  const float* pts;
+  float* pooled;
+  uint8_t* valid;
+};
+
+struct Proj {
+  float pi, pj;   // (row, col) coordinates in the feature map, corner origin
+  float depth;
+  float dist;     // distance voxel -> camera centre
+  bool vis;
+};
+
+// One (voxel, view) projection.  cam = wh f c k(3) max_fov pad; Rt = R(9) t(3).
+__device__ __forceinline__ Proj project_one(const float* __restrict__ cam,
+                                            const float* __restrict__ Rt, float px, float py,
+                                            float pz, int fisheye) {
+  const float eps = 1e-3f;
+  // Transform3D.inv: R_inv = R^T, t_inv = -(R^T t); then t_inv + R_inv p.
+  float pv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float r0 = Rt[0 * 3 + i], r1 = Rt[1 * 3 + i], r2 = Rt[2 * 3 + i];
+    const float tinv = -((r0 * Rt[9] + r1 * Rt[10]) + r2 * Rt[11]);
+    pv[i] = tinv + ((r0 * px + r1 * py) + r2 * pz);
+  }
+  Proj o;
+  o.depth = pv[2];
+  bool valid = pv[2] >= eps;
+  const float z = fmaxf(pv[2], eps);
+  float x = pv[0] / z, y = pv[1] / z;
+  if (fisheye) {
+    const float radius2 = x * x + y * y;
+    const bool in_center = radius2 < eps * eps;
+    const float radius = sqrtf(in_center ? eps * eps : radius2);
+    const float theta = atanf(radius);
+    const float t2 = theta * theta;
+    const float offset = (cam[6] * t2 + cam[7] * (t2 * t2)) + cam[8] * (t2 * t2 * t2);
+    float dist = (offset + 1.f) * theta / radius;
+    dist = in_center ? 1.f : dist;
+    x *= dist;
+    y *= dist;
+    valid = valid && (in_center || ((radius < tanf(0.5f * cam[9])) && (dist > 0.f)));
+  }
+  x = x * cam[2] + cam[4];
+  y = y * cam[3] + cam[5];
+  valid = valid && (x >= 0.f) && (x < cam[0]) && (y >= 0.f) && (y < cam[1]);
+  o.pi = y;  // xy -> ij
+  o.pj = x;
+  o.vis = valid;
+  const float dx = px - Rt[9], dy = py - Rt[10], dz = pz - Rt[11];
+  o.dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+  return o;
+}
+
+struct Taps {
+  int i0, i1, j0, j1;
+  float w00, w01, w10, w11;
+};
+
+// selective != 0: streetview_encoder.py:93-105 (clip the point, floor, +1);
+// selective == 0: grids.interpolate_nd / map_coordinates (clip each tap index).
+__device__ __forceinline__ Taps make_taps(float pi, float pj, int h, int w, int selective) {
+  Taps t;
+  float ci = pi - 0.5f, cj = pj - 0.5f;
+  if (selective) {
+    ci = fmaxf(fminf(ci, (float)(h - 1)), 0.f);
+    cj = fmaxf(fminf(cj, (float)(w - 1)), 0.f);
+  }
+  const float fi = floorf(ci), fj = floorf(cj);
+  const float wi1 = ci - fi, wj1 = cj - fj;
+  const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
+  t.i0 = (int)fminf(fmaxf(fi, 0.f), (float)(h - 1));
+  t.i1 = (int)fminf(fmaxf(fi + 1.f, 0.f), (float)(h - 1));
+  t.j0 = (int)fminf(fmaxf(fj, 0.f), (float)(w - 1));
+  t.j1 = (int)fminf(fmaxf(fj + 1.f, 0.f), (float)(w - 1));
+  t.w00 = wi0 * wj0;
+  t.w01 = wi0 * wj1;
+  t.w10 = wi1 * wj0;
+  t.w11 = wi1 * wj1;
+  return t;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
+  const SnapLiftDesc& d = a.d;
+  const int hl = threadIdx.x & 31;
+  const int64_t gv = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int64_t total = (int64_t)d.B * d.N;
+  if (gv >= total) return;  // whole half-wave exits together
+  const int b = (int)(gv / d.N);
+  const int fd = d.feature_dim;
+  const int nq = fd >> 2;
+  const bool all_views = d.K == 0;
+  const int nsel = all_views ? d.V : d.K;
+
+  const float* p = a.pts + gv * 3;
+  const float px = p[0], py = p[1], pz = p[2];
+
+  // ---- k1: lane v projects into view v -----------------------------------
+  Proj pr;
+  pr.pi = pr.pj = pr.depth = 0.f;
+  pr.dist = INFINITY;
+  pr.vis = false;
+  if (hl < d.V) {
+    pr = project_one(a.cam + ((int64_t)b * d.V + hl) * 11, a.Rt + ((int64_t)b * d.V + hl) * 12, px,
+                     py, pz, d.fisheye);
+  }
+  float key_d = (hl < d.V && pr.vis) ? pr.dist : INFINITY;
+  int key_i = (hl < d.V) ? hl : 1000 + hl;
+
+  // ---- k2: selection ---------------------------------------------------------
+  int sel[KMAX];
+  float min_dist = INFINITY;
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    if (r >= nsel) { sel[r] = 0; continue; }
+    if (all_views) {
+      sel[r] = r;
+      continue;
+    }
+    float bd = key_d;
+    int bi = key_i;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float od = __shfl_xor(bd, o, 32);
+      const int oi = __shfl_xor(bi, o, 32);
+      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (r == 0) min_dist = bd;
+    sel[r] = bi;            // bi < V always while r < nsel <= V
+    if (hl == bi) { key_d = INFINITY; key_i = 1000 + hl; }
+  }
+  if (all_views) {
+    float md = key_d;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) md = fminf(md, __shfl_xor(md, o, 32));
+    min_dist = md;
+  }
+
+  // ---- k3/k4: gather selected observations ----------------------------------
+  f32x4 feat[KMAX];
+  float score[KMAX];
+  bool ok[KMAX];
+  bool any = false;
+  const float log_range = logf(d.depth_max / d.depth_min);
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    feat[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    score[r] = 0.f;
+    ok[r] = false;
+    if (r >= nsel) continue;
+    const int v = sel[r];
+    const float pi = __shfl(pr.pi, v, 32);
+    const float pj = __shfl(pr.pj, v, 32);
+    const float depth = __shfl(pr.depth, v, 32);
+    const bool vis = __shfl((int)pr.vis, v, 32) != 0;
+    ok[r] = vis;
+    if (!vis) continue;  // half-wave uniform
+    any = true;
+    const Taps t = make_taps(pi, pj, d.h, d.w, all_views ? 0 : 1);
+    const float* img = a.f + ((int64_t)b * d.V + v) * d.h * d.w * d.C;
+    const float* r00 = img + ((int64_t)t.i0 * d.w + t.j0) * d.C;
+    const float* r01 = img + ((int64_t)t.i0 * d.w + t.j1) * d.C;
+    const float* r10 = img + ((int64_t)t.i1 * d.w + t.j0) * d.C;
+    const float* r11 = img + ((int64_t)t.i1 * d.w + t.j1) * d.C;
+    if (hl < nq) {
+      const f32x4 a00 = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
+      const f32x4 a01 = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
+      const f32x4 a10 = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
+      const f32x4 a11 = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        feat[r][e] = ((t.w00 * a00[e] + t.w01 * a01[e]) + t.w10 * a10[e]) + t.w11 * a11[e];
+    }
+    // depth score: two neighbouring log-depth bins, each bilinearly gathered.
+    const float dc = fminf(fmaxf(depth, d.depth_min), d.depth_max);
+    const float tt = logf(dc / d.depth_min) / log_range;
+    const float index = 0.5f + tt * (float)(d.num_bins - 1);
+    const float c = index - 0.5f;
+    const float fl = floorf(c);
+    const float wb1 = c - fl, wb0 = 1.f - wb1;
+    const int b0 = (int)fminf(fmaxf(fl, 0.f), (float)(d.num_bins - 1));
+    const int b1 = (int)fminf(fmaxf(fl + 1.f, 0.f), (float)(d.num_bins - 1));
+    const int c0 = fd + b0, c1 = fd + b1;
+    const float s0 = ((t.w00 * r00[c0] + t.w01 * r01[c0]) + t.w10 * r10[c0]) + t.w11 * r11[c0];
+    const float s1 = ((t.w00 * r00[c1] + t.w01 * r01[c1]) + t.w10 * r10[c1]) + t.w11 * r11[c1];
+    score[r] = wb0 * s0 + wb1 * s1;
+  }
+
+  // ---- k5: softmax-weighted mean / variance / max score ---------------------
+  float* out = a.pooled + gv * d.out_stride;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, var = {0.f, 0.f, 0.f, 0.f};
+  float smax = 0.f;
+  if (any) {
+    // jax.nn.softmax(..., where=valid, initial=0): shift = max(0, max valid score).
+    float m = 0.f;
+    smax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r)
+      if (ok[r]) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
+    float e[KMAX], den = 0.f;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      e[r] = ok[r] ? expf(score[r] - m) : 0.f;
+      den += e[r];
+    }
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      const float wgt = e[r] / den;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mean[c] += wgt * feat[r][c];
+    }
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      const float wgt = e[r] / den;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float dl = feat[r][c] - mean[c];
+        var[c] += wgt * (dl * dl);
+      }
+    }
+  }
+  if (hl < nq) {
+    *reinterpret_cast<f32x4*>(out + 4 * hl) = mean;
+    *reinterpret_cast<f32x4*>(out + fd + 4 * hl) = var;
+  }
+  if (hl == 0) {
+    out[2 * fd] = smax;
+    for (int c = 2 * fd + 1; c < d.out_stride; ++c) out[c] = 0.f;
+    bool vld = any;
+    if (d.max_view_distance >= 0.f && !all_views) vld = vld && (min_dist <= d.max_view_distance);
+    a.valid[gv] = vld ? 1 : 0;
+  }
+}
+
+__global__ void project_points_kernel(int B, int V, int N, int fisheye,
+                                      const float* __restrict__ cam, const float* __restrict__ Rt,
+                                      const float* __restrict__ pts, float* __restrict__ p2d,
+                                      uint8_t* __restrict__ vis, float* __restrict__ depth) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * N * V;
+  if (i >= total) return;
+  const int v = (int)(i % V);
+  const int64_t bn = i / V;
+  const int b = (int)(bn / N);
+  const float* p = pts + bn * 3;
+  const Proj pr = project_one(cam + ((int64_t)b * V + v) * 11, Rt + ((int64_t)b * V + v) * 12, p[0],
+                              p[1], p[2], fisheye);
+  p2d[i * 2 + 0] = pr.pi;
+  p2d[i * 2 + 1] = pr.pj;
+  vis[i] = pr.vis ? 1 : 0;
+  depth[i] = pr.depth;
+}
+
+}  // namespace
+
+extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_images,
+                                  const float* cam, const float* Rt, const float* points,
+                                  float* pooled, uint8_t* valid, void* stream) {
+  if (!desc || !f_images || !cam || !Rt || !points || !pooled || !valid) return SNAP_ERR_NULL;
+  const SnapLiftDesc& d = *desc;
+  if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.V > 32) return SNAP_ERR_UNSUPPORTED;
+  if (d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0) return SNAP_ERR_UNSUPPORTED;
+  if (d.C != d.feature_dim + d.num_bins || d.C % 4 != 0 || d.num_bins < 1) return SNAP_ERR_BAD_SHAPE;
+  if (d.out_stride < 2 * d.feature_dim + 1 || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;  // K>0 means V > K
+  if (!(d.depth_max > d.depth_min) || !(d.depth_min > 0.f)) return SNAP_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(f_images) & 15) || (reinterpret_cast<uintptr_t>(pooled) & 15))
+    return SNAP_ERR_BAD_SHAPE;
+  const int nsel = d.K == 0 ? d.V : d.K;
+  LiftArgs a{d, f_images, cam, Rt, points, pooled, valid};
+  const int64_t total = (int64_t)d.B * d.N;
+  const dim3 grid((unsigned)snap_cdiv(total, 8));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (nsel <= 1) {
+    hipLaunchKernelGGL(lift_pool_kernel<1>, grid, dim3(256), 0, s, a);
+  } else if (nsel <= 4) {
+    hipLaunchKernelGGL(lift_pool_kernel<4>, grid, dim3(256), 0, s, a);
+  } else if (nsel <= 8) {
+    hipLaunchKernelGGL(lift_pool_kernel<8>, grid, dim3(256), 0, s, a);
+  } else {
+    return SNAP_ERR_UNSUPPORTED;
+  }
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_project_points_f32(int32_t B, int32_t V, int32_t N, int32_t fisheye,
+                                       const float* cam, const float* Rt, const float* points,
+                                       float* p2d, uint8_t* vis, float* depth, void* stream) {
+  if (!cam || !Rt || !points || !p2d || !vis || !depth) return SNAP_ERR_NULL;
+  if (B <= 0 || V <= 0 || N <= 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)B * N * V;
+  hipLaunchKernelGGL(project_points_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), B, V, N, fisheye, cam, Rt, points, p2d, vis,
+                     depth);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

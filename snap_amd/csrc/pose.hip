@@ -1,0 +1,647 @@
+// Pose-likelihood kernels: point-vs-map similarity + softmax statistics (k10),
+// correspondence sampling + 2-point Kabsch (k11), pose scoring with LDS-staged
+// score planes (k12) and the refinement lattice (k13).
+//
+// Replaces snap/models/bev_localizer.py:157-173 and
+// snap/models/pose_estimation.py:49-82,100-165,168-205.
+//
+// Data layout in HBM (per scene b):
+//   fq   [Nq, Dm]      query matching features (L2-normalised, masked)
+//   fm   [X*Y, Dm]     map matching features
+//   sim  [Nq, X*Y]     sim_points, one contiguous X*Y plane per query point
+//   chunk_stats [Nq, ceil(XY/64), 2]  per-64-cell (max, sum exp) of the softmax
+// The prob_points tensor of the reference is never materialised on the product
+// path: its row-softmax is represented by chunk_stats (1/32 of the bytes) and
+// re-evaluated on the fly by the sampler.
+#include "common.h"
+
+namespace {
+
+constexpr int SIM_CH = 64;  // cells per softmax chunk == one wave
+constexpr int SIM_TQ = 64;  // query rows per workgroup tile
+
+// ---------------------------------------------------------------------------
+// k10: similarity.  MODE 0: write sim + chunk stats.  MODE 1: write prob.
+// grid = (ceil(XY/256), ceil(Nq/TQ), B), block = 256 (thread <-> map cell).
+// Each thread keeps its map cell's Dm-vector in registers and streams the TQ
+// query rows (LDS broadcast reads); sim rows are written 1 KiB-coalesced.
+// ---------------------------------------------------------------------------
+template <int DM, int MODE>
+__global__ __launch_bounds__(256) void sim_kernel(
+    const float* __restrict__ fq, const float* __restrict__ fm, int Nq, int XY, float scale,
+    int clip, const float* __restrict__ num_valid, float* __restrict__ sim,
+    float* __restrict__ stats, const float* __restrict__ rowstats, float* __restrict__ prob) {
+  __shared__ float q_s[SIM_TQ * DM];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * SIM_TQ;
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int NC = (XY + SIM_CH - 1) / SIM_CH;
+  const bool cvalid = cell < XY;
+  for (int i = threadIdx.x; i < SIM_TQ * DM; i += 256) {
+    const int r = i / DM;
+    q_s[i] = (n0 + r < Nq) ? fq[((int64_t)b * Nq + n0) * DM + i] : 0.f;
+  }
+  float mv[DM];
+  if (cvalid) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(fm + ((int64_t)b * XY + cell) * DM);
+#pragma unroll
+    for (int k = 0; k < DM / 4; ++k) {
+      const f32x4 t = src[k];
+      mv[4 * k + 0] = t[0]; mv[4 * k + 1] = t[1]; mv[4 * k + 2] = t[2]; mv[4 * k + 3] = t[3];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < DM; ++k) mv[k] = 0.f;
+  }
+  __syncthreads();
+  const float nv = num_valid[b];
+  const int rows = min(SIM_TQ, Nq - n0);
+  for (int r = 0; r < rows; ++r) {
+    const int64_t row = (int64_t)b * Nq + n0 + r;
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < DM; ++k) dot = fmaf(q_s[r * DM + k], mv[k], dot);
+    float x = clip ? fmaxf(dot, 0.f) : dot;
+    x *= scale;
+    if (MODE == 0) {
+      if (cvalid) sim[row * XY + cell] = x / nv;
+      const float m = wave_max(cvalid ? x : -INFINITY);
+      const float s = wave_sum(cvalid ? expf(x - m) : 0.f);
+      if (lane == 0 && chunk < NC) {
+        stats[(row * NC + chunk) * 2 + 0] = m;
+        stats[(row * NC + chunk) * 2 + 1] = s;
+      }
+    } else {
+      const float M = rowstats[row * 2 + 0], T = rowstats[row * 2 + 1];
+      if (cvalid) prob[row * XY + cell] = (expf(x - M) / T) / nv;
+    }
+  }
+}
+
+// one wave per (b, n): row max M and total T = sum_c s_c * exp(m_c - M).
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ stats,
+                                                        int64_t rows, int NC,
+                                                        float* __restrict__ rowstats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* st = stats + row * NC * 2;
+  float m = -INFINITY;
+  for (int c = lane; c < NC; c += 64) m = fmaxf(m, st[2 * c]);
+  m = wave_max(m);
+  float t = 0.f;
+  for (int c = lane; c < NC; c += 64) t += st[2 * c + 1] * expf(st[2 * c] - m);
+  t = wave_sum(t);
+  if (lane == 0) {
+    rowstats[row * 2 + 0] = m;
+    rowstats[row * 2 + 1] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k11a: iid categorical sampling of correspondences ~ prob_points.
+// prob mass is uniform over query points (every row softmax sums to 1), so:
+// n = floor(u1 * Nq); cell ~ softmax row n by two-level inverse CDF:
+// chunk from chunk_stats, then the 64 cells of that chunk re-evaluated.
+// One wave per sample.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t* out) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+template <int DM>
+__global__ __launch_bounds__(256) void ransac_sample_kernel(
+    const float* __restrict__ fq, const float* __restrict__ fm, const float* __restrict__ stats,
+    int Nq, int X, int Y, float scale, int clip, int S, uint64_t seed,
+    const float* __restrict__ uniforms, int32_t* __restrict__ corr) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (s >= S) return;
+  const int XY = X * Y;
+  const int NC = (XY + SIM_CH - 1) / SIM_CH;
+  float u1, u2;
+  if (uniforms) {
+    u1 = uniforms[((int64_t)b * S + s) * 2 + 0];
+    u2 = uniforms[((int64_t)b * S + s) * 2 + 1];
+  } else {
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)s, (uint32_t)b, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+    u1 = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+    u2 = (float)(rnd[1] >> 8) * (1.0f / 16777216.0f);
+  }
+  const int n = min((int)(u1 * (float)Nq), Nq - 1);
+  const int64_t row = (int64_t)b * Nq + n;
+  const float* st = stats + row * NC * 2;
+
+  // level 1: pick the chunk.  lane l owns the contiguous chunk range [l*cpl, (l+1)*cpl).
+  const int cpl = (NC + 63) / 64;
+  const int cb = lane * cpl, ce = min(cb + cpl, NC);
+  float M = -INFINITY;
+  for (int c = cb; c < ce; ++c) M = fmaxf(M, st[2 * c]);
+  M = wave_max(M);
+  float local = 0.f;
+  for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
+  const float incl = wave_scan_incl(local, lane);
+  const float total = __shfl(incl, 63, 64);
+  const float target = u2 * total;
+  unsigned long long bal = __ballot(incl > target && ce > cb);
+  int L;
+  if (bal) {
+    L = __ffsll((long long)bal) - 1;
+  } else {  // rounding: fall back to the last non-empty lane
+    const unsigned long long ne = __ballot(ce > cb);
+    L = 63 - __clzll((long long)ne);
+  }
+  // lane L walks its chunks
+  int cstar = 0;
+  float resid = 0.f;
+  if (lane == L) {
+    float run = incl - local;
+    cstar = ce - 1;
+    resid = 0.f;
+    bool found = false;
+    for (int c = cb; c < ce; ++c) {
+      const float wgt = st[2 * c + 1] * expf(st[2 * c] - M);
+      if (!found && run + wgt > target) {
+        cstar = c;
+        // residual expressed relative to the chunk's own max
+        resid = (target - run) / expf(st[2 * c] - M);
+        found = true;
+      }
+      run += wgt;
+    }
+    if (!found) resid = INFINITY;
+  }
+  cstar = __shfl(cstar, L, 64);
+  resid = __shfl(resid, L, 64);
+  const float mc = st[2 * cstar];
+
+  // level 2: the 64 cells of the chunk.
+  const int cell = cstar * SIM_CH + lane;
+  const bool cvalid = cell < XY;
+  float e = 0.f;
+  if (cvalid) {
+    const f32x4* mp = reinterpret_cast<const f32x4*>(fm + ((int64_t)b * XY + cell) * DM);
+    const f32x4* qp = reinterpret_cast<const f32x4*>(fq + row * DM);
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < DM / 4; ++k) {
+      const f32x4 a = qp[k], c = mp[k];
+      dot = fmaf(a[0], c[0], dot); dot = fmaf(a[1], c[1], dot); dot = fmaf(a[2], c[2], dot); dot = fmaf(a[3], c[3], dot);
+    }
+    float x = clip ? fmaxf(dot, 0.f) : dot;
+    x *= scale;
+    e = expf(x - mc);
+  }
+  const float ci = wave_scan_incl(e, lane);
+  unsigned long long b2 = __ballot(cvalid && ci > resid);
+  int pick;
+  if (b2) {
+    pick = __ffsll((long long)b2) - 1;
+  } else {
+    const unsigned long long nv = __ballot(cvalid);
+    pick = 63 - __clzll((long long)nv);
+  }
+  if (lane == 0) {
+    const int c = cstar * SIM_CH + pick;
+    int32_t* o = corr + ((int64_t)b * S + s) * 3;
+    o[0] = n;
+    o[1] = c / Y;
+    o[2] = c - (c / Y) * Y;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k11b: best-of-retries + 2-point Kabsch (closed form of the 2x2 SVD).
+// ---------------------------------------------------------------------------
+__global__ void poses_from_corr_kernel(const int32_t* __restrict__ corr,
+                                       const float* __restrict__ q_xy, int B, int Nq, int P,
+                                       int retries, float cell, float* __restrict__ poses) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * P) return;
+  const int b = (int)(i / P), p = (int)(i - (int64_t)b * P);
+  const int32_t* cb = corr + ((int64_t)b * P * retries * 2) * 3;
+  float best = INFINITY;
+  float bi0x = 0, bi0y = 0, bi1x = 0, bi1y = 0, bj0x = 0, bj0y = 0, bj1x = 0, bj1y = 0;
+  for (int r = 0; r < retries; ++r) {
+    const int32_t* c0 = cb + ((int64_t)(p * retries + r) * 2 + 0) * 3;
+    const int32_t* c1 = c0 + 3;
+    const float i0x = q_xy[((int64_t)b * Nq + c0[0]) * 2 + 0], i0y = q_xy[((int64_t)b * Nq + c0[0]) * 2 + 1];
+    const float i1x = q_xy[((int64_t)b * Nq + c1[0]) * 2 + 0], i1y = q_xy[((int64_t)b * Nq + c1[0]) * 2 + 1];
+    const float j0x = ((float)c0[1] + 0.5f) * cell, j0y = ((float)c0[2] + 0.5f) * cell;
+    const float j1x = ((float)c1[1] + 0.5f) * cell, j1y = ((float)c1[2] + 0.5f) * cell;
+    float ratio = 0.f;
+    if (retries > 1) {
+      const float dix = i1x - i0x, diy = i1y - i0y, djx = j1x - j0x, djy = j1y - j0y;
+      const float d_i = sqrtf(dix * dix + diy * diy), d_j = sqrtf(djx * djx + djy * djy);
+      ratio = fmaxf(d_i / fmaxf(d_j, 1e-5f), d_j / fmaxf(d_i, 1e-5f));
+    }
+    if (r == 0 || ratio < best) {
+      best = ratio;
+      bi0x = i0x; bi0y = i0y; bi1x = i1x; bi1y = i1y;
+      bj0x = j0x; bj0y = j0y; bj1x = j1x; bj1y = j1y;
+    }
+  }
+  // kabsch_algorithm_2d(j_xy (map), i_xy (query)) -> map_t_query.
+  const float mux = (bj0x + bj1x) * 0.5f, muy = (bj0y + bj1y) * 0.5f;   // map mean
+  const float nux = (bi0x + bi1x) * 0.5f, nuy = (bi0y + bi1y) * 0.5f;   // query mean
+  const float ax = bj1x - bj0x, ay = bj1y - bj0y;                       // map diff
+  const float qx = bi1x - bi0x, qy = bi1y - bi0y;                       // query diff
+  const float dot = ax * qx + ay * qy;
+  const float crs = qx * ay - qy * ax;
+  const float nrm = sqrtf(dot * dot + crs * crs);
+  float c = 1.f, s = 0.f;
+  if (nrm > 0.f) { c = dot / nrm; s = crs / nrm; }
+  const float tx = mux - (c * nux - s * nuy);
+  const float ty = muy - (s * nux + c * nuy);
+  float* o = poses + i * 3;
+  o[0] = atan2f(s, c);
+  o[1] = tx;
+  o[2] = ty;
+}
+
+// ---------------------------------------------------------------------------
+// k12: pose scoring.  grid = (point chunks, pose chunks, B), block = 1024.
+// The score plane sim[b, n] (X*Y fp32, or a row band of it) is staged in LDS once
+// and gathered from there by every pose; each thread keeps PPT poses (cos, sin,
+// t) and their accumulators in registers.  Compulsory HBM traffic: sim read once
+// per pose chunk.  Partial sums per point chunk are reduced in fixed order
+// (deterministic).
+// ---------------------------------------------------------------------------
+constexpr int PS_THREADS = 1024;
+constexpr int PS_LDS_FLOATS = 24 * 1024;  // 96 KiB plane / band buffer
+
+struct ScoreArgs {
+  const float* sim;
+  const float* poses;
+  const float* q_xy;
+  const uint8_t* valid_q;
+  const uint8_t* map_valid;
+  int B, Nq, X, Y, P;
+  float cell;
+  int mask_oob;
+  int points_per_chunk;
+  int RB, NB;      // rows per band, number of bands
+  float* partial;  // [B, NCH, P]
+  const float* table;  // [B, P, 4] = (cos, sin, tx, ty)
+};
+
+__global__ void pose_table_kernel(const float* __restrict__ poses, int64_t total,
+                                  float* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float th = poses[i * 3 + 0];
+  f32x4 t;
+  t[0] = cosf(th); t[1] = sinf(th); t[2] = poses[i * 3 + 1]; t[3] = poses[i * 3 + 2];
+  reinterpret_cast<f32x4*>(table)[i] = t;
+}
+
+template <int PPT, bool MASK, bool BANDS>
+__global__ __launch_bounds__(PS_THREADS) void pose_score_kernel(const ScoreArgs a) {
+  extern __shared__ float plane[];
+  const int b = blockIdx.z;
+  // pose chunk fastest: workgroups sharing the same score planes are dispatched
+  // back to back and hit L2 / Infinity Cache on the re-read.
+  const int chunk = blockIdx.y;
+  const int NCH = gridDim.y;
+  const int p_base = blockIdx.x * (PS_THREADS * PPT);
+  const int tid = threadIdx.x;
+  float pc[PPT], ps[PPT], ptx[PPT], pty[PPT], acc[PPT];
+  bool pok[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    pok[k] = p < a.P;
+    acc[k] = 0.f;
+    // out-of-range slots score pose P-1 again; only the final store is guarded.
+    const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + min(p, a.P - 1)];
+    pc[k] = t[0]; ps[k] = t[1]; ptx[k] = t[2]; pty[k] = t[3];
+  }
+  const int n_begin = chunk * a.points_per_chunk;
+  const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
+  const float Xf = (float)a.X, Yf = (float)a.Y;
+  const uint8_t* mvalid = a.map_valid ? a.map_valid + (int64_t)b * a.X * a.Y : nullptr;
+  for (int n = n_begin; n < n_end; ++n) {
+    if (!a.valid_q[(int64_t)b * a.Nq + n]) continue;  // block-uniform
+    const float qx = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+    const float qy = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+    const float* src = a.sim + ((int64_t)b * a.Nq + n) * a.X * a.Y;
+    const int nbands = BANDS ? a.NB : 1;
+    for (int band = 0; band < nbands; ++band) {
+      const int r0 = band * (a.RB - 1);
+      const int nrows = min(a.RB, a.X - r0);
+      const int nfl = nrows * a.Y;
+      __syncthreads();  // previous consumers done
+      {
+        const float* s0 = src + (int64_t)r0 * a.Y;
+        if (((a.Y & 3) == 0)) {
+          const f32x4* s4 = reinterpret_cast<const f32x4*>(s0);
+          f32x4* d4 = reinterpret_cast<f32x4*>(plane);
+          for (int i = tid; i < (nfl >> 2); i += PS_THREADS) d4[i] = s4[i];
+        } else {
+          for (int i = tid; i < nfl; i += PS_THREADS) plane[i] = s0[i];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        // (j_t_i @ xy) / cell_size  -- Transform2D.transform, geometry.py:137-139
+        const float xm = (pc[k] * qx - ps[k] * qy) + ptx[k];
+        const float ym = (ps[k] * qx + pc[k] * qy) + pty[k];
+        const float u = xm / a.cell, v = ym / a.cell;
+        const float cu = u - 0.5f, cv = v - 0.5f;
+        const float fu = floorf(cu), fv = floorf(cv);
+        const int i0 = (int)fminf(fmaxf(fu, 0.f), Xf - 1.f);
+        bool mine = true;
+        if (BANDS) mine = min(i0 / (a.RB - 1), a.NB - 1) == band;
+        const int i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), Xf - 1.f);
+        const int j0 = (int)fminf(fmaxf(fv, 0.f), Yf - 1.f);
+        const int j1 = (int)fminf(fmaxf(fv + 1.f, 0.f), Yf - 1.f);
+        const float wu1 = cu - fu, wu0 = 1.f - wu1;
+        const float wv1 = cv - fv, wv0 = 1.f - wv1;
+        const int l0 = mine ? (i0 - r0) * a.Y : 0, l1 = mine ? (i1 - r0) * a.Y : 0;
+        const float s00 = plane[l0 + j0], s01 = plane[l0 + j1];
+        const float s10 = plane[l1 + j0], s11 = plane[l1 + j1];
+        const float val =
+            (((wu0 * wv0) * s00 + (wu0 * wv1) * s01) + (wu1 * wv0) * s10) + (wu1 * wv1) * s11;
+        bool ok = mine;
+        if (MASK) {
+          ok = ok && (u >= 0.f) && (u < Xf) && (v >= 0.f) && (v < Yf);
+          ok = ok && mvalid[i0 * a.Y + j0] && mvalid[i0 * a.Y + j1] && mvalid[i1 * a.Y + j0] &&
+               mvalid[i1 * a.Y + j1];
+        }
+        acc[k] += ok ? val : 0.f;
+        // keep the PPT bodies sequential: interleaving them spills (16 live
+        // bilinear contexts); 4 waves/SIMD already hide the LDS latency.
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    if (pok[k]) a.partial[((int64_t)b * NCH + chunk) * a.P + p] = acc[k];
+  }
+}
+
+__global__ void pose_score_reduce_kernel(const float* __restrict__ partial, int NCH, int P,
+                                         int64_t total, float* __restrict__ scores) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*P
+  if (i >= total) return;
+  const int64_t b = i / P, p = i - b * P;
+  float t = 0.f;
+  for (int c = 0; c < NCH; ++c) t += partial[(b * NCH + c) * P + p];
+  scores[i] = t;
+}
+
+inline int score_chunks(int B, int Nq, int pose_chunks) {
+  // aim for >= 512 workgroups overall, at least 8 points per chunk.
+  int nch = (512 + B * pose_chunks - 1) / (B * pose_chunks);
+  nch = nch < 1 ? 1 : nch;
+  const int maxch = (Nq + 7) / 8;
+  if (nch > maxch) nch = maxch;
+  if (nch < 1) nch = 1;
+  return nch;
+}
+constexpr int PS_PPT = 10;
+inline int score_pose_chunks(int P) { return (P + PS_THREADS * PS_PPT - 1) / (PS_THREADS * PS_PPT); }
+
+__global__ void refine_lattice_kernel(const float* __restrict__ init,
+                                      const float* __restrict__ offs_r,
+                                      const float* __restrict__ offs_p, int B, int nr, int np_,
+                                      float* __restrict__ out) {
+  const int64_t per = (int64_t)nr * np_ * np_;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per * B) return;
+  const int b = (int)(i / per);
+  int64_t r = i - (int64_t)b * per;
+  const int iy = (int)(r % np_); r /= np_;
+  const int ix = (int)(r % np_);
+  const int ir = (int)(r / np_);
+  const float th0 = init[b * 3 + 0], tx0 = init[b * 3 + 1], ty0 = init[b * 3 + 2];
+  const float c = cosf(th0), s = sinf(th0);
+  const float ox = offs_p[ix], oy = offs_p[iy];
+  // compose: angle = a0 + a1; t = t0 + R(a0) t1   (geometry.py:141-144)
+  out[i * 3 + 0] = th0 + offs_r[ir];
+  out[i * 3 + 1] = tx0 + (c * ox - s * oy);
+  out[i * 3 + 2] = ty0 + (s * ox + c * oy);
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ scores, int P,
+                                                          int start, int32_t* __restrict__ idx) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const int b = blockIdx.x;
+  const float* row = scores + (int64_t)b * P;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int p = start + threadIdx.x; p < P; p += 256) {
+    const float v = row[p];
+    if (v > best || besti == 0x7fffffff) { best = v; besti = p; }
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = besti;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float ov = bv[threadIdx.x + o];
+      const int oi = bi[threadIdx.x + o];
+      const float mv = bv[threadIdx.x];
+      const int mi = bi[threadIdx.x];
+      if (oi != 0x7fffffff && (mi == 0x7fffffff || ov > mv || (ov == mv && oi < mi))) {
+        bv[threadIdx.x] = ov;
+        bi[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) idx[b] = bi[0] - start;
+}
+
+template <int MODE>
+int launch_sim(int Dm, dim3 grid, hipStream_t s, const float* fq, const float* fm, int Nq, int XY,
+               float scale, int clip, const float* nv, float* sim, float* stats,
+               const float* rowstats, float* prob) {
+  switch (Dm) {
+    case 8: hipLaunchKernelGGL((sim_kernel<8, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
+    case 16: hipLaunchKernelGGL((sim_kernel<16, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
+    case 32: hipLaunchKernelGGL((sim_kernel<32, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
+    case 64: hipLaunchKernelGGL((sim_kernel<64, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
+    default: return SNAP_ERR_UNSUPPORTED;
+  }
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t snap_sim_rowstats_bytes(int32_t B, int32_t Nq) {
+  return (size_t)B * Nq * 2 * sizeof(float);
+}
+
+extern "C" int snap_sim_softmax_f32(const float* fq, const float* fm, int32_t B, int32_t Nq,
+                                    int32_t XY, int32_t Dm, float scale, int32_t clip_negative,
+                                    const float* num_valid, float* sim, float* chunk_stats,
+                                    float* prob, float* rowstats, void* stream) {
+  if (!fq || !fm || !num_valid || !sim || !chunk_stats) return SNAP_ERR_NULL;
+  if (prob && !rowstats) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || XY <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)snap_cdiv(XY, 256), (unsigned)snap_cdiv(Nq, SIM_TQ), (unsigned)B);
+  int rc = launch_sim<0>(Dm, grid, s, fq, fm, Nq, XY, scale, clip_negative, num_valid, sim,
+                         chunk_stats, nullptr, nullptr);
+  if (rc != SNAP_OK) return rc;
+  if (rowstats) {
+    const int64_t rows = (int64_t)B * Nq;
+    const int NC = (XY + SIM_CH - 1) / SIM_CH;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)snap_cdiv(rows, 4)), dim3(256), 0, s,
+                       (const float*)chunk_stats, rows, NC, rowstats);
+    SNAP_CHECK_LAUNCH();
+  }
+  if (prob) {
+    rc = launch_sim<1>(Dm, grid, s, fq, fm, Nq, XY, scale, clip_negative, num_valid, nullptr,
+                       nullptr, rowstats, prob);
+  }
+  return rc;
+}
+
+extern "C" int snap_ransac_sample_f32(const float* fq, const float* fm, const float* chunk_stats,
+                                      int32_t B, int32_t Nq, int32_t X, int32_t Y, int32_t Dm,
+                                      float scale, int32_t clip_negative, int32_t S, uint64_t seed,
+                                      const float* uniforms, int32_t* corr, void* stream) {
+  if (!fq || !fm || !chunk_stats || !corr) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || S <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)snap_cdiv(S, 4), (unsigned)B);
+  switch (Dm) {
+    case 8: hipLaunchKernelGGL(ransac_sample_kernel<8>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
+    case 16: hipLaunchKernelGGL(ransac_sample_kernel<16>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
+    case 32: hipLaunchKernelGGL(ransac_sample_kernel<32>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
+    case 64: hipLaunchKernelGGL(ransac_sample_kernel<64>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
+    default: return SNAP_ERR_UNSUPPORTED;
+  }
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_poses_from_corr_f32(const int32_t* corr, const float* q_xy, int32_t B,
+                                        int32_t Nq, int32_t P, int32_t retries, float cell_size,
+                                        float* poses, void* stream) {
+  if (!corr || !q_xy || !poses) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || P <= 0 || retries <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(poses_from_corr_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), corr, q_xy, B, Nq, P, retries,
+                     cell_size, poses);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" size_t snap_pose_score_workspace_bytes(int32_t B, int32_t Nq, int32_t P, int32_t X,
+                                                  int32_t Y) {
+  (void)X; (void)Y;
+  const int pch = score_pose_chunks(P);
+  const int nch = score_chunks(B, Nq, pch);
+  // pose table (16-byte aligned, first) + per-chunk partial sums.
+  return (size_t)B * P * 4 * sizeof(float) + (size_t)B * nch * P * sizeof(float);
+}
+
+extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const float* q_xy,
+                                   const uint8_t* valid_q, const uint8_t* map_valid, int32_t B,
+                                   int32_t Nq, int32_t X, int32_t Y, int32_t P, float cell_size,
+                                   int32_t mask_oob, float* scores, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (!sim || !poses || !q_xy || !valid_q || !scores || !workspace) return SNAP_ERR_NULL;
+  if (mask_oob && !map_valid) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || P <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (Y > PS_LDS_FLOATS / 2) return SNAP_ERR_UNSUPPORTED;
+  if (workspace_bytes < snap_pose_score_workspace_bytes(B, Nq, P, X, Y)) return SNAP_ERR_WORKSPACE;
+  ScoreArgs a;
+  a.sim = sim; a.poses = poses; a.q_xy = q_xy; a.valid_q = valid_q; a.map_valid = map_valid;
+  a.B = B; a.Nq = Nq; a.X = X; a.Y = Y; a.P = P;
+  a.cell = cell_size; a.mask_oob = mask_oob;
+  const int pch = score_pose_chunks(P);
+  const int nch = score_chunks(B, Nq, pch);
+  a.points_per_chunk = (Nq + nch - 1) / nch;
+  if ((int64_t)X * Y <= PS_LDS_FLOATS) {
+    a.RB = X; a.NB = 1;
+  } else {
+    a.RB = PS_LDS_FLOATS / Y;
+    a.NB = (X - 1 + (a.RB - 1) - 1) / (a.RB - 1);
+  }
+  float* table = static_cast<float*>(workspace);
+  a.table = table;
+  a.partial = table + (size_t)B * P * 4;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return SNAP_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)min((int64_t)a.RB * Y, (int64_t)PS_LDS_FLOATS) * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool bands = a.NB > 1;
+  const void* fn = nullptr;
+  if (mask_oob) fn = bands ? (const void*)&pose_score_kernel<PS_PPT, true, true>
+                           : (const void*)&pose_score_kernel<PS_PPT, true, false>;
+  else fn = bands ? (const void*)&pose_score_kernel<PS_PPT, false, true>
+                  : (const void*)&pose_score_kernel<PS_PPT, false, false>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            PS_LDS_FLOATS * sizeof(float)) != hipSuccess)
+      return SNAP_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(pose_table_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)), dim3(256),
+                     0, s, poses, (int64_t)B * P, table);
+  SNAP_CHECK_LAUNCH();
+  {
+    void* kargs[] = {(void*)&a};
+    if (hipLaunchKernel(fn, dim3(pch, nch, B), dim3(PS_THREADS), kargs, lds, s) != hipSuccess)
+      return SNAP_ERR_LAUNCH;
+  }
+  SNAP_CHECK_LAUNCH();
+  const int64_t total = (int64_t)B * P;
+  hipLaunchKernelGGL(pose_score_reduce_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     s, (const float*)a.partial, nch, P, total, scores);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_refine_lattice_f32(const float* init, const float* offs_r, const float* offs_p,
+                                       int32_t B, int32_t nr, int32_t np_, float* out,
+                                       void* stream) {
+  if (!init || !offs_r || !offs_p || !out) return SNAP_ERR_NULL;
+  if (B <= 0 || nr <= 0 || np_ <= 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)B * nr * np_ * np_;
+  hipLaunchKernelGGL(refine_lattice_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), init, offs_r, offs_p, B, nr, np_, out);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_argmax_rows_f32(const float* scores, int32_t B, int32_t P, int32_t start,
+                                    int32_t* idx, void* stream) {
+  if (!scores || !idx) return SNAP_ERR_NULL;
+  if (B <= 0 || P <= 0 || start < 0 || start >= P) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     scores, P, start, idx);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

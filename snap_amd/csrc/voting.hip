@@ -1,0 +1,162 @@
+// Exhaustive (x, y, theta) voting: rotated query templates, edge-padded map and
+// the -inf / normalisation pass around the direct correlation, which itself runs
+// on the MFMA conv engine (conv_igemm.hip) with the templates as an
+// (H x W x D) -> R filter bank.
+//
+// Replaces snap/models/pose_exhaustive_voting.py:37-69 (sample_query_templates)
+// and the non-GEMM parts of :72-104 (template_matching).
+#include "common.h"
+
+namespace {
+
+// thread <-> (r0, i, j, channel quad); r0 < R/4 (first quadrant of rotations);
+// the other three quadrants are written as rot90 copies, exactly as the
+// reference completes them with jnp.rot90(quarter, k, axes=(2, 1)).
+__global__ void rotate_templates_kernel(const float* __restrict__ feat,
+                                        const uint8_t* __restrict__ valid,
+                                        const float* __restrict__ tfm, int H, int W, int D, int R,
+                                        int Rp, float cell, float* __restrict__ templates,
+                                        uint8_t* __restrict__ tvalid, float* __restrict__ tw,
+                                        float* __restrict__ cw, float* __restrict__ tcount) {
+  const int D4 = D >> 2;
+  const int RQ = R >> 2;
+  const int64_t total = (int64_t)RQ * H * W * D4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % D4);
+  int64_t r = idx / D4;
+  const int sj = (int)(r % W); r /= W;
+  const int si = (int)(r % H);
+  const int r0 = (int)(r / H);
+  const float c = tfm[r0 * 4 + 0], s = tfm[r0 * 4 + 1], tx = tfm[r0 * 4 + 2], ty = tfm[r0 * 4 + 3];
+  // cell centre in metres, transformed, back to cell units.
+  const float gx = ((float)si + 0.5f) * cell, gy = ((float)sj + 0.5f) * cell;
+  const float xm = (c * gx - s * gy) + tx;
+  const float ym = (s * gx + c * gy) + ty;
+  const float u = xm / cell, v = ym / cell;
+  bool ok = (u >= 0.f) && (u < (float)H) && (v >= 0.f) && (v < (float)W);
+  const float cu = u - 0.5f, cv = v - 0.5f;
+  const float fu = floorf(cu), fv = floorf(cv);
+  const float wu1 = cu - fu, wu0 = 1.f - wu1, wv1 = cv - fv, wv0 = 1.f - wv1;
+  const int i0 = (int)fminf(fmaxf(fu, 0.f), (float)(H - 1));
+  const int i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), (float)(H - 1));
+  const int j0 = (int)fminf(fmaxf(fv, 0.f), (float)(W - 1));
+  const int j1 = (int)fminf(fmaxf(fv + 1.f, 0.f), (float)(W - 1));
+  // NaN-mask validity: every tap must be valid, even with zero weight.
+  ok = ok && valid[i0 * W + j0] && valid[i0 * W + j1] && valid[i1 * W + j0] && valid[i1 * W + j1];
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    const f32x4 a00 = *reinterpret_cast<const f32x4*>(feat + ((int64_t)i0 * W + j0) * D + 4 * q);
+    const f32x4 a01 = *reinterpret_cast<const f32x4*>(feat + ((int64_t)i0 * W + j1) * D + 4 * q);
+    const f32x4 a10 = *reinterpret_cast<const f32x4*>(feat + ((int64_t)i1 * W + j0) * D + 4 * q);
+    const f32x4 a11 = *reinterpret_cast<const f32x4*>(feat + ((int64_t)i1 * W + j1) * D + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = (((wu0 * wv0) * a00[e] + (wu0 * wv1) * a01[e]) + (wu1 * wv0) * a10[e]) +
+             (wu1 * wv1) * a11[e];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // destination of source cell (si, sj) under rot90(., k, axes=(2,1)); H == W.
+    int di, dj;
+    if (k == 0) { di = si; dj = sj; }
+    else if (k == 1) { di = sj; dj = H - 1 - si; }
+    else if (k == 2) { di = H - 1 - si; dj = W - 1 - sj; }
+    else { di = H - 1 - sj; dj = si; }
+    const int rr = k * RQ + r0;
+    *reinterpret_cast<f32x4*>(templates + (((int64_t)rr * H + di) * W + dj) * D + 4 * q) = o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      tw[(((int64_t)di * W + dj) * D + 4 * q + e) * Rp + rr] = o[e];
+    if (q == 0) {
+      tvalid[((int64_t)rr * H + di) * W + dj] = ok ? 1 : 0;
+      // count filter = 180-degree rotated mask (un-flipped true convolution).
+      cw[((int64_t)(H - 1 - di) * W + (W - 1 - dj)) * Rp + rr] = ok ? 1.f : 0.f;
+      if (ok) atomicAdd(tcount + rr, 1.f);  // integer-valued: order independent
+    }
+  }
+}
+
+__global__ void pad_map_kernel(const float* __restrict__ map, const uint8_t* __restrict__ mvalid,
+                               int H, int W, int D, float* __restrict__ map_pad,
+                               float* __restrict__ mvalid_pad) {
+  const int D4 = D >> 2;
+  const int Hp = 3 * H - 2, Wp = 3 * W - 2;
+  const int64_t total = (int64_t)Hp * Wp * D4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % D4);
+  int64_t r = idx / D4;
+  const int b = (int)(r % Wp);
+  const int a = (int)(r / Wp);
+  const int si = a - (H - 1), sj = b - (W - 1);
+  const int ci = min(max(si, 0), H - 1), cj = min(max(sj, 0), W - 1);
+  reinterpret_cast<f32x4*>(map_pad)[idx] =
+      *reinterpret_cast<const f32x4*>(map + ((int64_t)ci * W + cj) * D + 4 * q);
+  if (q == 0) {
+    const bool inside = si >= 0 && si < H && sj >= 0 && sj < W;
+    mvalid_pad[(int64_t)a * Wp + b] = (inside && mvalid[ci * W + cj]) ? 1.f : 0.f;
+  }
+}
+
+__global__ void template_finalize_kernel(const float* __restrict__ raw,
+                                         const float* __restrict__ cnt,
+                                         const float* __restrict__ tcount, int Ho, int Wo, int R,
+                                         int Rp, float thr, int use_overlap,
+                                         float* __restrict__ scores) {
+  const int64_t total = (int64_t)R * Ho * Wo;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t ab = idx % ((int64_t)Ho * Wo);
+  const int r = (int)(idx / ((int64_t)Ho * Wo));
+  float v = raw[ab * Rp + r];
+  if (use_overlap && !(cnt[ab * Rp + r] > thr)) v = -INFINITY;
+  scores[idx] = v / tcount[r];
+}
+
+}  // namespace
+
+extern "C" int snap_rotate_templates_f32(const float* feat, const uint8_t* valid,
+                                         const float* tfm, int32_t H, int32_t W, int32_t D,
+                                         int32_t R, float cell_size, float* templates,
+                                         uint8_t* tvalid, float* tw, float* cw, float* tcount,
+                                         void* stream) {
+  if (!feat || !valid || !tfm || !templates || !tvalid || !tw || !cw || !tcount)
+    return SNAP_ERR_NULL;
+  if (H <= 0 || H != W || D <= 0 || D % 4 != 0 || R <= 0 || R % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int Rp = R;  // R % 4 == 0 already
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(tcount, 0, sizeof(float) * R, s) != hipSuccess) return SNAP_ERR_LAUNCH;
+  const int64_t total = (int64_t)(R / 4) * H * W * (D / 4);
+  hipLaunchKernelGGL(rotate_templates_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     s, feat, valid, tfm, H, W, D, R, Rp, cell_size, templates, tvalid, tw, cw,
+                     tcount);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_pad_map_f32(const float* map, const uint8_t* mvalid, int32_t H, int32_t W,
+                                int32_t D, float* map_pad, float* mvalid_pad, void* stream) {
+  if (!map || !mvalid || !map_pad || !mvalid_pad) return SNAP_ERR_NULL;
+  if (H <= 0 || W <= 0 || D <= 0 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)(3 * H - 2) * (3 * W - 2) * (D / 4);
+  hipLaunchKernelGGL(pad_map_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), map, mvalid, H, W, D, map_pad, mvalid_pad);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_template_finalize_f32(const float* raw, const float* cnt, const float* tcount,
+                                          int32_t Ho, int32_t Wo, int32_t R, int32_t Rp,
+                                          float overlap_threshold, int32_t use_overlap,
+                                          float* scores, void* stream) {
+  if (!raw || !tcount || !scores) return SNAP_ERR_NULL;
+  if (use_overlap && !cnt) return SNAP_ERR_NULL;
+  if (Ho <= 0 || Wo <= 0 || R <= 0 || Rp < R) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)R * Ho * Wo;
+  hipLaunchKernelGGL(template_finalize_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), raw, cnt, tcount, Ho, Wo, R, Rp,
+                     overlap_threshold, use_overlap, scores);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

@@ -1,0 +1,114 @@
+"""Module plumbing: a tiny functional module system + the BaseModel contract.
+
+The reference modules are Flax ``nn.Module``s driven as
+``model.init(rngs, batch, train=...)`` / ``model.apply(variables, batch, ...)``
+(snap/trainer.py:147-156,211-218; snap/models/base.py:32-67).  Here a module is a
+plain object with
+
+  * ``init_params(gen, device) -> dict``  -- nested dict of fp32 tensors in the
+    FLAX parameter layout (conv kernels HWIO, Dense kernels (in, out), GroupNorm
+    scale/bias (1,1,1,C)), so a Flax checkpoint maps 1:1 with no transposes;
+  * ``__call__(params, ...)``              -- the forward pass on HIP kernels.
+
+``Module.init`` / ``Module.apply`` adapt that to the Flax calling convention.
+"""
+import math
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import torch
+
+Batch = Dict[str, Any]
+Predictions = Dict[str, Any]
+LossMetricsTuple = Tuple[Dict[str, Any], Dict[str, Any]]
+
+
+class ForwardContext:
+  """Per-``apply`` scratch: caches standardised conv kernels (StdConv) so the map
+  and query passes, which share parameters, standardise each kernel once."""
+
+  def __init__(self):
+    self._wstd = {}
+
+  def standardized(self, kernel, fn):
+    key = kernel.data_ptr()
+    out = self._wstd.get(key)
+    if out is None:
+      out = self._wstd[key] = fn(kernel)
+    return out
+
+
+class Module:
+  """Base class: Flax-style ``init`` / ``apply`` over explicit parameter dicts."""
+
+  def init_params(self, gen: torch.Generator, device) -> Dict[str, Any]:
+    raise NotImplementedError
+
+  def init(self, rngs, *args, device=None, **kwargs):
+    """``model.init(rngs, batch, train=False)`` -> ``{'params': ...}``.
+
+    ``rngs`` may be an int seed, a ``torch.Generator`` or a dict with a 'params'
+    entry holding either (the Flax ``{'params': key, 'sampling': key}`` shape).
+    """
+    if isinstance(rngs, dict):
+      rngs = rngs.get('params', 0)
+    if isinstance(rngs, torch.Generator):
+      gen = rngs
+    else:
+      gen = torch.Generator(device='cpu')
+      gen.manual_seed(int(rngs))
+    if device is None:
+      device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+    return {'params': self.init_params(gen, torch.device(device))}
+
+  def apply(self, variables, *args, rngs=None, mutable=False, **kwargs):
+    """``model.apply({'params': p}, batch, train=..., rngs={'sampling': seed})``.
+
+    Returns ``pred`` or ``(pred, new_state)`` when ``mutable`` is truthy (the
+    model has no mutable collections: GroupNorm only, so ``new_state == {}``).
+    """
+    seed = None
+    if isinstance(rngs, dict):
+      seed = rngs.get('sampling')
+    elif rngs is not None:
+      seed = rngs
+    out = self(variables['params'], *args, rng=seed, **kwargs)
+    if mutable:
+      return out, {}
+    return out
+
+
+# -- initialisers (host side, CPU generator for reproducibility) --------------
+def lecun_normal(gen, shape, fan_in, device):
+  std = 1.0 / math.sqrt(fan_in)
+  return (torch.randn(shape, generator=gen) * std).to(device)
+
+
+def glorot_uniform(gen, shape, fan_in, fan_out, device):
+  lim = math.sqrt(6.0 / (fan_in + fan_out))
+  return ((torch.rand(shape, generator=gen) * 2 - 1) * lim).to(device)
+
+
+def truncated_normal(gen, shape, std, device):
+  t = torch.empty(shape)
+  torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+  # flax variance_scaling divides by the std of the truncated unit normal.
+  return (t * (std / 0.87962566103423978)).to(device)
+
+
+class BaseModel:
+  """Trainer-facing wrapper (snap/models/base.py:32-67)."""
+
+  def __init__(self, config, dataset_meta_data: Dict[str, Any], dtype=torch.float32):
+    self.config = config
+    self.dataset_meta_data = dataset_meta_data
+    self.dtype = dtype
+    self.flax_model = self.build_flax_model()
+
+  def loss_metrics_function(self, pred, batch, model_params=None) -> LossMetricsTuple:
+    raise NotImplementedError('Subclasses must implement metrics.')
+
+  def build_flax_model(self) -> Module:
+    raise NotImplementedError('Subclasses must implement build_flax_model().')
+
+  def default_flax_model_config(self):
+    raise NotImplementedError('Subclasses must implement default_flax_model_config().')

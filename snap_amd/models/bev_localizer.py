@@ -1,0 +1,226 @@
+"""BEV localizer: relative pose between a query view and a map scene.
+
+Mirrors ``snap/models/bev_localizer.py:36-278`` (``build_query_frustum_grid``,
+``BEVLocalizer``, ``BEVLocalizerModel``).
+"""
+import math
+
+import numpy as np
+import torch
+
+from snap_amd import ops
+from snap_amd.configs import defaults as default_configs
+from snap_amd.models import base
+from snap_amd.models import bev_mapper
+from snap_amd.models import pose_estimation
+from snap_amd.models import types
+from snap_amd.utils import geometry
+from snap_amd.utils import grids
+
+
+def build_query_frustum_grid(cell_size, depth, filter_points_in_fov=False, hfov_deg=None):
+  """Gravity-aligned grid bounding the query frustum (bev_localizer.py:36-55).
+
+  Host-side constant (numpy -> fp32 torch on CPU); returns (grid, grid_p_view, q_xy_p).
+  """
+  width = 3 * depth // 2
+  grid = grids.Grid2D.from_extent_meters((width, depth), cell_size)
+  grid_p_view = torch.tensor([width / 2, 0.0], dtype=torch.float32)
+  qgrid_xy_p = grid.index_to_xyz(grid.grid_index().to(torch.float32))
+  q_xy_p = qgrid_xy_p - grid_p_view
+  if filter_points_in_fov:
+    angle = torch.atan2(q_xy_p[..., 0], q_xy_p[..., 1])
+    keep = torch.abs(angle) < math.radians(hfov_deg / 2)
+    q_xy_p = q_xy_p[keep][:, None]
+  return grid, grid_p_view, q_xy_p
+
+
+class BEVLocalizer(base.Module):
+  """Estimate the relative pose between a pair of overlapping scenes."""
+
+  def __init__(self, config, scene_config, grid_map, semantic_map_classes=None,
+               dtype=torch.float32):
+    self.config = config
+    self.scene_config = scene_config
+    self.grid_map = grid_map
+    hfov = (
+        scene_config['streetview_hfov_deg'] if isinstance(scene_config, dict)
+        else scene_config.streetview_hfov_deg
+    )
+    self.grid_query, self.qgrid_p_q, self.q_xy_p = build_query_frustum_grid(
+        grid_map.cell_size, config.query_frustum_depth,
+        config.filter_points_in_fov, hfov,
+    )
+    if self.q_xy_p.dim() != 3 or self.q_xy_p.shape[1] != 1:
+      # the reference squeezes axis 2 of [B,Nq,1,2] (bev_localizer.py:151):
+      # only the FoV-filtered point list is a valid configuration.
+      raise ValueError('filter_points_in_fov=True is required (as in train_localization)')
+    if config.add_confidence_map:
+      raise NotImplementedError('Map confidence is not yet supported.')
+    if config.add_confidence_query:
+      raise NotImplementedError('add_confidence_query (non-default confidence path)')
+    self.bev_mapper = bev_mapper.BEVMapper(
+        config.bev_mapper, grid_map, semantic_map_classes, dtype
+    )
+    self.bev_mapper_query = None
+    if config.bev_mapper_query is not None:
+      self.bev_mapper_query = bev_mapper.BEVMapper(
+          config.bev_mapper_query, grid_map, semantic_map_classes, dtype
+      )
+
+  def init_params(self, gen, device):
+    params = {'bev_mapper': self.bev_mapper.init_params(gen, device)}
+    if self.bev_mapper_query is not None:
+      params['bev_mapper_query'] = self.bev_mapper_query.init_params(gen, device)
+    if self.config.add_temperature:
+      params['temperature'] = torch.tensor(
+          float(self.config.init_temperature), device=device
+      )
+    return params
+
+  def recover_dense_feature_plane(self, plane_sparse):
+    """Sparse FoV point list -> dense query-frustum plane (bev_localizer.py:110-128)."""
+    dev = plane_sparse.features.device
+    D = plane_sparse.features.shape[-1]
+    feats = torch.zeros((*self.grid_query.extent, D), device=dev)
+    valid = torch.zeros(self.grid_query.extent, dtype=torch.bool, device=dev)
+    q_xy_p = self.q_xy_p.squeeze(1).to(dev)
+    idx = self.grid_query.xyz_to_index(q_xy_p + self.qgrid_p_q[:2].to(dev))
+    valid[idx[:, 0], idx[:, 1]] = plane_sparse.valid.reshape(len(idx))
+    feats[idx[:, 0], idx[:, 1]] = plane_sparse.features.reshape(len(idx), -1)
+    return types.FeaturePlane(features=feats, valid=valid)
+
+  def similarity(self, params, f_p_q, plane_map, valid_points, want_prob=False):
+    """bev_localizer.py:157-173: sim_points (+ softmax statistics) on the GPU."""
+    cfg = self.config
+    scale = 1.0
+    if cfg.add_temperature:
+      # exp(temperature): a host scalar (one tiny D2H sync per apply).
+      scale = float(torch.exp(params['temperature'].to(torch.float32)))
+    num_valid = valid_points.sum(-1).clamp(min=1).to(torch.float32)
+    sim, stats, prob, _ = ops.sim_softmax(
+        f_p_q.contiguous(), plane_map.features.contiguous(), scale,
+        bool(cfg.clip_negative_scores), num_valid, want_prob=want_prob,
+    )
+    matching = dict(
+        fq=f_p_q.contiguous(), fm=plane_map.features.contiguous(),
+        chunk_stats=stats, scale=scale, clip=bool(cfg.clip_negative_scores),
+    )
+    return sim, prob, matching
+
+  def __call__(self, params, data, train=False, debug=False, rng=None,
+               pose_samples=None):
+    cfg = self.config
+    ctx = base.ForwardContext()
+    dev = data['query']['images'].device
+    batch_size = len(data['query']['images'])
+    q_xy_p = self.q_xy_p.to(dev)[None].expand(batch_size, -1, -1, -1)
+
+    pred = {}
+    pred['map'] = self.bev_mapper(params['bev_mapper'], data['map'], train, debug, ctx=ctx, rng=rng)
+    mapper_q = self.bev_mapper_query or self.bev_mapper
+    params_q = params['bev_mapper_query'] if self.bev_mapper_query is not None else params['bev_mapper']
+    pred['query'] = mapper_q(
+        params_q, {**data['query'], 'xy_bev': q_xy_p}, train, debug, is_query=True,
+        ctx=ctx, rng=rng,
+    )
+
+    plane_map = pred['map']['bev_matching']
+    plane_q = pred['query']['bev_matching']
+    q_xy_p = q_xy_p.squeeze(2).contiguous()
+    valid_points = plane_q.valid.reshape(batch_size, -1)
+    f_p_q = plane_q.features.reshape(batch_size, -1, plane_q.features.shape[-1])
+
+    sim_points, prob_points, matching = self.similarity(
+        params, f_p_q, plane_map, valid_points, want_prob=debug
+    )
+    if debug:
+      pred['sim_points'] = sim_points
+      pred['prob_points'] = prob_points
+
+    if pose_samples is None:
+      if cfg.num_pose_samples is None:
+        raise ValueError('config.num_pose_samples must be set')
+      m_t_q, corr = pose_estimation.sample_transforms_ransac_batched(
+          rng, matching, q_xy_p, cfg.num_pose_samples,
+          cfg.num_pose_sampling_retries, self.grid_map,
+      )
+      if debug:
+        pred['correspondences'] = corr
+    else:
+      m_t_q = pose_samples
+    m_t_q_gt = data.get('T_query2map')
+    if m_t_q_gt is not None:
+      m_t_q_gt = geometry.Transform2D.from_Transform3D(m_t_q_gt)
+      m_t_q = geometry.Transform2D.cat([m_t_q_gt[:, None], m_t_q], 1)
+    pred['map_t_query_samples'] = m_t_q
+
+    pred['scores_poses'] = scores = pose_estimation.pose_scoring_many_batched(
+        m_t_q, sim_points, q_xy_p, valid_points, plane_map.valid, self.grid_map,
+        cfg.mask_score_out_of_bounds,
+    )
+    start_idx = int(m_t_q_gt is not None)
+    pred['best_index'] = best_idx = ops.argmax_rows(scores, start_idx)
+    bi = torch.arange(batch_size, device=dev)
+    pred['map_t_query'] = m_t_q[bi, best_idx.to(torch.int64) + start_idx]
+
+    if cfg.do_grid_refinement:
+      pred['map_t_query_ransac'] = pred['map_t_query']
+      pred['map_t_query'], pred['scores_grid_refine'] = (
+          pose_estimation.grid_refinement_batched(
+              pred['map_t_query'], sim_points, q_xy_p, valid_points,
+              plane_map.valid, self.grid_map, cfg.mask_score_out_of_bounds,
+          )
+      )
+    return pred
+
+  default_config = staticmethod(default_configs.bev_localizer)
+
+
+class BEVLocalizerModel(base.BaseModel):
+  """Trainer-facing wrapper (bev_localizer.py:228-278)."""
+
+  def build_flax_model(self):
+    meta = self.dataset_meta_data
+    return BEVLocalizer(
+        self.config, meta['build_config'].scene_config, meta['grid'].bev(),
+        meta.get('semantic_map_classes'), self.dtype,
+    )
+
+  @classmethod
+  def default_flax_model_config(cls):
+    return default_configs.bev_localizer()
+
+  def loss_metrics_function(self, pred, data, model_params=None):
+    """NLL over sampled poses + recall metrics (bev_localizer.py:244-278).
+
+    Host-side torch on [B, P] tensors (trivial cost).
+    """
+    scores = pred['scores_poses']
+    m_t_q_gt = geometry.Transform2D.from_Transform3D(data['T_query2map'])
+    samples_t_gt = pred['map_t_query_samples'].inv @ m_t_q_gt[..., None]
+    dr_samples, dt_samples = samples_t_gt.magnitude()
+    if self.config.threshold_remove_accurate_poses is not None:
+      dr_min, dt_min = self.config.threshold_remove_accurate_poses
+      remove = (dr_samples < dr_min) & (dt_samples < dt_min)
+      remove[..., 0] = False
+      scores = torch.where(remove, torch.full_like(scores, -math.inf), scores)
+    nll = -torch.log_softmax(scores, dim=-1)[..., 0]
+    losses = {'localization/nll': nll, 'total': nll}
+    dr, dt = (pred['map_t_query'].inv @ m_t_q_gt).magnitude()
+    metrics = {
+        'loc/err_max_position': dt,
+        'loc/err_max_rotation': dr,
+        'loc/recall_top1': torch.argmax(pred['scores_poses'], dim=-1) == 0,
+    }
+    for t in [0.5, 1, 2, 5]:
+      metrics[f'loc/recall_max_{t}m'] = dt < t
+      metrics[f'loc/recall_max_{t}°'] = dr < t
+    if self.config.add_temperature and model_params is not None:
+      metrics['loc/temperature'] = model_params['temperature'].repeat(len(nll))
+    for dt_thresh, dr_thresh in [(0.5, 1), (1, 2), (2, 4)]:
+      recall = (dr_samples < dr_thresh) & (dt_samples < dt_thresh)
+      metrics[f'loc/recall_samples_{dt_thresh}m_{dr_thresh}°'] = (
+          recall[..., 1:].to(torch.float32).mean(-1)
+      )
+    return losses, metrics

@@ -1,0 +1,105 @@
+"""Image encoder = ResNet-v2 + FPN decoder (``snap/models/image_encoder.py``)."""
+import numpy as np
+import torch
+
+from snap_amd import ops
+from snap_amd.configs import defaults as default_configs
+from snap_amd.models import base
+from snap_amd.models import resnet
+from snap_amd.models import types
+
+
+def pad_to_multiple(images, stride):
+  """image_encoder.py:32-39.  Quirk kept: an already divisible size is padded by a
+  full stride (``pad = stride - size % stride``)."""
+  shape = np.array(images.shape[-3:-1])
+  pad = stride - shape % stride
+  return torch.nn.functional.pad(images, (0, 0, 0, int(pad[1]), 0, int(pad[0])))
+
+
+class FPNDecoder(base.Module):
+  """FPN-like decoder (image_encoder.py:42-94), activation relu + 'bit_resnet' norm.
+
+  Per level: ReLU -> GroupNorm -> 1x1 conv (no bias) [+ bilinear x2 of the coarser
+  level].  ReLU+GN are fused into the conv's operand staging, the up-sample-add
+  into its epilogue: one kernel per level.
+  """
+
+  def __init__(self, output_dim, num_levels, in_dims, dtype=torch.float32):
+    self.output_dim = output_dim
+    self.num_levels = num_levels
+    self.in_dims = in_dims
+
+  def init_params(self, gen, device):
+    params = {}
+    for level, c in enumerate(self.in_dims):
+      params[f'{level}_skip_norm'] = {
+          'scale': torch.ones(1, 1, 1, c, device=device),
+          'bias': torch.zeros(1, 1, 1, c, device=device),
+      }
+      params[f'{level}_skip_conv'] = {
+          'kernel': base.lecun_normal(gen, (1, 1, c, self.output_dim), c, device)
+      }
+    return params
+
+  def __call__(self, params, input_features, train=False):
+    assert len(input_features) == self.num_levels
+    out_features = []
+    f_prev = None
+    for level, f_skip in enumerate(input_features):
+      norm = params[f'{level}_skip_norm']
+      mu, sc = ops.group_norm_stats(f_skip, norm['scale'].reshape(-1), relu_first=True)
+      if f_prev is not None:
+        assert f_skip.shape[-3] == f_prev.shape[-3] * 2, "Image heights don't match."
+        assert f_skip.shape[-2] == f_prev.shape[-2] * 2, "Image widths don't match."
+      f = ops.conv2d(
+          f_skip, params[f'{level}_skip_conv']['kernel'], prologue=ops.PRO_RELU_GN,
+          gn=(mu, sc, norm['bias'].reshape(-1)), up_prev=f_prev,
+      )
+      f_prev = f
+      out_features.append(f)
+    return out_features
+
+
+class ImageEncoder(base.Module):
+  """image_encoder.py:97-144.  Input [N, H, W, 3] in [0, 1]."""
+
+  def __init__(self, config, dtype=torch.float32):
+    self.config = config
+    num_pyr_levels = config.num_pyr_levels
+    if config.encoder_name != 'resnet':
+      raise ValueError(config.encoder_name)
+    self.encoder = resnet.ResNetV2(config.encoder, dtype)
+    if num_pyr_levels is None:
+      num_pyr_levels = len(self.encoder.level_names)
+    self.max_stride = (not config.encoder.skip_root_block) * 2 + num_pyr_levels - 1
+    self.level_names = self.encoder.level_names[:num_pyr_levels][::-1]
+    width = self.encoder.width
+    in_dims = [width * 4 * 2 ** (int(n[5:]) - 1) for n in self.level_names]
+    self.decoder = FPNDecoder(config.output_dim, num_pyr_levels, in_dims, dtype)
+
+  def init_params(self, gen, device):
+    return {
+        'encoder': self.encoder.init_params(gen, device),
+        'decoder': self.decoder.init_params(gen, device),
+    }
+
+  def __call__(self, params, image, train=False, ctx=None, rng=None):
+    image = image.to(torch.float32)
+    input_shape = np.array(image.shape[-3:-1])
+    image_padded = pad_to_multiple(image, 2**self.max_stride).contiguous()
+    padded_shape = np.array(image_padded.shape[-3:-1])
+    encoder_features = self.encoder(params['encoder'], image_padded, train=train, ctx=ctx)
+    skip_features = []
+    for layer_name in self.level_names:
+      _, f = sorted(encoder_features[layer_name].items())[-1]
+      skip_features.append(f)
+    out_features = self.decoder(params['decoder'], skip_features, train=train)
+    strides = [padded_shape / np.array(f.shape[-3:-1]) for f in out_features]
+    crops = []
+    for s, f in zip(strides, out_features):
+      h, w = np.round(np.ceil(input_shape / s)).astype(int)
+      crops.append(f[..., :h, :w, :])
+    return types.FeatureImagePyramid(features=crops, strides=strides)
+
+  default_config = staticmethod(default_configs.image_encoder)

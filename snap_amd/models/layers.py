@@ -1,0 +1,48 @@
+"""Common building blocks (``snap/models/layers.py``): the Dense-stack MLP.
+
+``normalize`` (layers.py:45-52) is fused into bev_ops.hip's matching head;
+``masked_softmax`` / ``masked_mean`` are only used by non-default confidence
+paths of the reference and have no counterpart here.
+"""
+import torch
+
+from snap_amd import ops
+from snap_amd.models import base
+
+
+class MLP(base.Module):
+  """ReLU MLP (layers.py:55-78); every Dense runs on the MFMA conv engine.
+
+  The ReLU between layers is fused into the previous layer's epilogue; an input
+  activation (``apply_input_activation``) is fused into the first layer's
+  operand staging.  ``in_dim`` is the logical input width (the tensor may carry a
+  wider, padded row stride).
+  """
+
+  def __init__(self, config, in_dim, dtype=None):
+    if config.activation != 'relu':
+      raise NotImplementedError(config.activation)
+    self.config = config
+    self.in_dim = in_dim
+
+  def init_params(self, gen, device):
+    params = {}
+    d_in = self.in_dim
+    for i, d in enumerate(self.config.layers):
+      params[f'Dense_{i}'] = {
+          'kernel': base.glorot_uniform(gen, (d_in, d), d_in, d, device),
+          'bias': torch.zeros(d, device=device),
+      }
+      d_in = d
+    return params
+
+  def __call__(self, params, x, train=False, row_mask=None):
+    n = len(self.config.layers)
+    for i in range(n):
+      p = params[f'Dense_{i}']
+      pro = ops.PRO_RELU if (i == 0 and self.config.apply_input_activation) else ops.PRO_NONE
+      x = ops.dense(
+          x, p['kernel'], p['bias'], cin=p['kernel'].shape[0], prologue=pro,
+          relu=(i + 1 < n), row_mask=row_mask if i + 1 == n else None,
+      )
+    return x

@@ -1,0 +1,80 @@
+"""Pose estimation from BEV correspondences (``snap/models/pose_estimation.py``).
+
+Same function names as the reference (``*_batched`` variants operate on a leading
+scene axis); the arithmetic runs in pose.hip.
+"""
+import numpy as np
+import torch
+
+from snap_amd import ops
+from snap_amd.utils import geometry
+
+
+def pose_scoring_many_batched(
+    j_t_i, scores_points_all, i_xy_points, valid_points, valid_j, grid,
+    mask_out_of_bounds,
+):
+  """pose_estimation.py:63-82,208-211.
+
+  j_t_i: Transform2D [B,P]; scores_points_all [B,N,H,W]; i_xy_points [B,N,2];
+  valid_points [B,N]; valid_j [B,H,W].  Returns scores [B,P].
+  """
+  return ops.pose_score(
+      scores_points_all, j_t_i.packed(), i_xy_points.contiguous(),
+      valid_points.contiguous(), valid_j.contiguous(), grid.cell_size,
+      mask_oob=mask_out_of_bounds,
+  )
+
+
+def sample_transforms_ransac_batched(
+    rng, matching, i_xy_p, num_poses, num_retries, grid, uniforms=None,
+):
+  """pose_estimation.py:126-165 (vmapped :224).
+
+  The reference samples flat indices of ``prob_points`` with
+  ``jax.random.choice(p=...)``; here ``matching`` carries what is needed to sample
+  from the same distribution without materialising it:
+  ``dict(fq, fm, chunk_stats, scale, clip)`` as produced by
+  ``BEVLocalizer.similarity``.  ``rng`` is an integer seed (Philox stream).
+  Returns Transform2D [B, num_poses] and the sampled correspondences.
+  """
+  S = num_poses * num_retries * 2
+  corr = ops.ransac_sample(
+      matching['fq'], matching['fm'], matching['chunk_stats'], matching['scale'],
+      matching['clip'], S, seed=0 if rng is None else int(rng), uniforms=uniforms,
+  )
+  poses = ops.poses_from_corr(corr, i_xy_p.contiguous(), num_poses, num_retries, grid.cell_size)
+  return geometry.Transform2D.from_packed(poses), corr
+
+
+def refinement_offsets(device):
+  """The 41 x 41 x 41 (rotation, x, y) lattice of pose_estimation.py:178-184."""
+  delta_p, delta_r, range_p, range_r = 0.2, 0.25, 4, 5
+  offs_r = np.mgrid[slice(-range_r, range_r + delta_r, delta_r)]
+  offs_p = np.mgrid[slice(-range_p, range_p + delta_p, delta_p)]
+  offs_r = torch.tensor(np.deg2rad(offs_r.astype(np.float32)), device=device)
+  offs_p = torch.tensor(offs_p.astype(np.float32), device=device)
+  return offs_r, offs_p
+
+
+def grid_refinement_batched(
+    j_t_i_init, scores_points_all, i_xy_points, valid_points, valid_j, grid,
+    mask_out_of_bounds,
+):
+  """pose_estimation.py:168-205 (vmapped :212-214).
+
+  Returns (Transform2D [B], scores [B, 41, 41, 41]).
+  """
+  dev = scores_points_all.device
+  offs_r, offs_p = refinement_offsets(dev)
+  samples = ops.refine_lattice(j_t_i_init.packed(), offs_r, offs_p)
+  scores = ops.pose_score(
+      scores_points_all, samples, i_xy_points.contiguous(),
+      valid_points.contiguous(), valid_j.contiguous(), grid.cell_size,
+      mask_oob=mask_out_of_bounds,
+  )
+  best = ops.argmax_rows(scores).to(torch.int64)
+  B = samples.shape[0]
+  refined = samples[torch.arange(B, device=dev), best]
+  nr, np_ = offs_r.numel(), offs_p.numel()
+  return geometry.Transform2D.from_packed(refined), scores.reshape(B, nr, np_, np_)

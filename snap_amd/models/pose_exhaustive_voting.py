@@ -1,0 +1,107 @@
+"""Exhaustive (x, y, theta) pose voting (``snap/models/pose_exhaustive_voting.py``).
+
+``template_matching`` is a dense contraction (2*R*(2H-1)(2W-1)*H*W*D flop): it runs
+on the f32-MFMA conv engine with the R rotated templates as an (H x W x D) -> R
+filter bank over the edge-padded map; rotation, padding and the -inf/normalise
+pass are small HIP kernels (voting.hip).
+"""
+import math
+
+import numpy as np
+import torch
+
+from snap_amd import ops
+from snap_amd.models import types
+from snap_amd.utils import geometry
+
+
+def get_grid_center_transform(grid, device=None):
+  """corner_t_center (pose_exhaustive_voting.py:31-34)."""
+  center = torch.tensor((np.asarray(grid.extent_meters) / 2).astype(np.float32), device=device)
+  return geometry.Transform2D(torch.zeros((), device=device), center)
+
+
+def _template_transforms(num_rotations, grid, device):
+  """templates_t_grid = corner_t_center @ rot(theta) @ corner_t_center^-1 (:44-50)."""
+  angles = torch.tensor(
+      np.linspace(0, np.pi * 2, num_rotations, endpoint=False).astype(np.float32)
+  )
+  c = get_grid_center_transform(grid)
+  n = len(angles)
+  corner = geometry.Transform2D(c.angle.expand(n), c.t.expand(n, 2))
+  rot = geometry.Transform2D(angles, torch.zeros(n, 2))
+  t = corner @ rot @ corner.inv
+  tfm = torch.stack([torch.cos(t.angle), torch.sin(t.angle), t.t[:, 0], t.t[:, 1]], -1)
+  return tfm.to(device=device, dtype=torch.float32).contiguous()
+
+
+def sample_query_templates(features, valid, num_rotations, grid, _engine=False):
+  """Rotate a BEV by ``num_rotations`` angles (pose_exhaustive_voting.py:37-69)."""
+  if num_rotations % 4 != 0:
+    raise ValueError('num_rotations must be divisible by 4')
+  if features.shape[0] != features.shape[1]:
+    raise ValueError('the rot90 completion requires a square BEV')
+  tfm = _template_transforms(num_rotations, grid, features.device)
+  out = ops.rotate_templates(
+      features.contiguous(), valid.contiguous(), tfm[: num_rotations // 4].contiguous(),
+      num_rotations, grid.cell_size,
+  )
+  if _engine:
+    return out
+  return out[0], out[1]
+
+
+def _match(tw, cw, tcount, R, q_hw, m, m_valid, min_overlap):
+  H, W = q_hw
+  mp, mvp = ops.pad_map(m.contiguous(), m_valid.contiguous())
+  raw = ops.conv2d(mp[None], tw)[0]                     # [Ho, Wo, R]
+  cnt = None
+  if min_overlap is not None:
+    cnt = ops.conv2d(mvp[None, :, :, None].contiguous(), cw)[0]
+  thr = 0.0 if min_overlap is None else min_overlap * H * W
+  return ops.template_finalize(raw, cnt, tcount, R, thr, use_overlap=min_overlap is not None)
+
+
+def template_matching(q, q_valid, m, m_valid, do_padding=True, min_overlap=0.05):
+  """pose_exhaustive_voting.py:72-104 with explicit templates q [R,H,W,D]."""
+  if not do_padding:
+    raise NotImplementedError('do_padding=False')
+  R, H, W, D = q.shape
+  tw = q.permute(1, 2, 3, 0).contiguous()
+  cw = q_valid.flip(1, 2).permute(1, 2, 0).to(torch.float32)[:, :, None, :].contiguous()
+  tcount = q_valid.sum((-1, -2)).to(torch.float32)
+  return _match(tw, cw, tcount, R, (H, W), m, m_valid, min_overlap)
+
+
+def exhaustive_pose_voting(plane_q, plane_map, num_rotations, grid, conf_q=None):
+  """pose_exhaustive_voting.py:107-124 -> scores [R, 2H-1, 2W-1]."""
+  feats_q = plane_q.features
+  if conf_q is not None:
+    feats_q = feats_q * conf_q[..., None]
+  _, _, tw, cw, tcount = sample_query_templates(
+      feats_q, plane_q.valid, num_rotations, grid, _engine=True
+  )
+  H, W = feats_q.shape[:2]
+  return _match(tw, cw, tcount, num_rotations, (H, W), plane_map.features, plane_map.valid, 0.05)
+
+
+def exhaustive_index_to_tfm(index, grid, num_rotations):
+  """pose_exhaustive_voting.py:127-137 (keeps the reference's +0.5 cell offset)."""
+  index = torch.as_tensor(index)
+  dev = index.device
+  extent = torch.tensor(grid.extent, device=dev)
+  xy_cell = ((index[1:] - extent + 1 + 0.5) * grid.cell_size).to(torch.float32)
+  angle = (index[0] * 2 * math.pi / num_rotations).to(torch.float32)
+  m_t_q_center = geometry.Transform2D(-angle, xy_cell)
+  c = get_grid_center_transform(grid, dev)
+  return c @ m_t_q_center @ c.inv
+
+
+def exhaustive_tfm_to_index(m_t_q_corner, grid, num_rotations):
+  """pose_exhaustive_voting.py:140-149."""
+  dev = m_t_q_corner.t.device
+  c = get_grid_center_transform(grid, dev)
+  m_t_q_center = c.inv @ m_t_q_corner @ c
+  k = (-m_t_q_center.angle / (math.pi * 2) % 1) * num_rotations
+  ij = (m_t_q_center.t / grid.cell_size) + torch.tensor(grid.extent, device=dev) - 1.5
+  return torch.cat([k[..., None], ij], -1)

@@ -1,0 +1,137 @@
+"""BiT ResNet-v2 encoder on the HIP conv engine (``snap/models/resnet.py:34-216``).
+
+Per residual unit the reference runs GroupNorm -> ReLU -> StdConv three times.
+Here GroupNorm+ReLU never materialise: ``group_norm_stats`` reads the activation
+once for (mean, rstd) and the consumer conv applies normalise+ReLU while staging
+its A operand; the residual add is fused in conv3's epilogue.  Kernels keep the
+Flax HWIO layout; StdConv standardisation (fp32, eps 1e-10) is a HIP kernel whose
+result is cached per forward (map and query passes share parameters).
+"""
+import torch
+
+from snap_amd import ops
+from snap_amd.configs import defaults as default_configs
+from snap_amd.models import base
+
+
+def get_block_desc(depth):
+  """resnet.py:158-167."""
+  if isinstance(depth, list):
+    depth = tuple(depth)
+  return {
+      26: [2, 2, 2, 2],
+      50: [3, 4, 6, 3],
+      101: [3, 4, 23, 3],
+      152: [3, 8, 36, 3],
+      200: [3, 24, 36, 3],
+  }.get(depth, depth)
+
+
+def _std(ctx, kernel):
+  return ctx.standardized(kernel, ops.weight_standardize)
+
+
+def _gn(x, p, relu_first=False):
+  mu, sc = ops.group_norm_stats(x, p['scale'].reshape(-1), relu_first=relu_first)
+  return mu, sc, p['bias'].reshape(-1)
+
+
+def residual_unit(ctx, p, x, stride, nmid):
+  """Bottleneck unit (resnet.py:103-132)."""
+  nmid = nmid or x.shape[-1] // 4
+  nout = nmid * 4
+  gn1 = _gn(x, p['gn1'])
+  if x.shape[-1] != nout or stride != 1:
+    residual = ops.conv2d(
+        x, _std(ctx, p['conv_proj']['kernel']), stride=stride,
+        prologue=ops.PRO_GN_RELU, gn=gn1,
+    )
+  else:
+    residual = x
+  y = ops.conv2d(x, _std(ctx, p['conv1']['kernel']), prologue=ops.PRO_GN_RELU, gn=gn1)
+  y = ops.conv2d(
+      y, _std(ctx, p['conv2']['kernel']), stride=stride,
+      padding=((1, 1), (1, 1)), prologue=ops.PRO_GN_RELU, gn=_gn(y, p['gn2']),
+  )
+  y = ops.conv2d(
+      y, _std(ctx, p['conv3']['kernel']), prologue=ops.PRO_GN_RELU,
+      gn=_gn(y, p['gn3']), residual=residual,
+  )
+  return y
+
+
+def _init_unit(gen, device, cin, nmid, stride):
+  nout = nmid * 4
+  def gn(c):
+    return {'scale': torch.ones(1, 1, 1, c, device=device),
+            'bias': torch.zeros(1, 1, 1, c, device=device)}
+  def conv(kh, kw, ci, co):
+    return {'kernel': base.lecun_normal(gen, (kh, kw, ci, co), kh * kw * ci, device)}
+  p = {'gn1': gn(cin), 'conv1': conv(1, 1, cin, nmid), 'gn2': gn(nmid),
+       'conv2': conv(3, 3, nmid, nmid), 'gn3': gn(nmid),
+       'conv3': conv(1, 1, nmid, nout)}
+  if cin != nout or stride != 1:
+    p['conv_proj'] = conv(1, 1, cin, nout)
+  return p
+
+
+class ResNetV2(base.Module):
+  """BiT variant (resnet.py:170-216); returns {stage: {unit: activation}}."""
+
+  def __init__(self, config, dtype=torch.float32):
+    self.config = config
+    self.blocks = get_block_desc(config.depth)
+    if config.limit_num_blocks is not None:
+      self.blocks = self.blocks[: config.limit_num_blocks]
+    self.level_names = [f'stage{i + 1}' for i in range(len(self.blocks))]
+    self.width = int(64 * config.width)
+    if self.width % 32 != 0:
+      raise ValueError('GroupNorm(32) needs the base width to be a multiple of 32')
+
+  def init_params(self, gen, device):
+    w = self.width
+    params = {}
+    if self.config.skip_root_block:
+      params['conv_root'] = {'kernel': base.lecun_normal(gen, (3, 3, 3, w), 27, device)}
+    else:
+      params['root_block'] = {
+          'conv_root': {'kernel': base.lecun_normal(gen, (7, 7, 3, w), 147, device)}
+      }
+    cin = w
+    for i, size in enumerate(self.blocks):
+      nmid = w * 2**i
+      stage = {}
+      for u in range(size):
+        stride = 2 if (u == 0 and i > 0) else 1
+        stage[f'unit{u + 1:02d}'] = _init_unit(gen, device, cin, nmid, stride)
+        cin = nmid * 4
+      params[f'block{i + 1}'] = stage
+    return params
+
+  def __call__(self, params, image, *, train=False, ctx=None, rng=None):
+    ctx = ctx or base.ForwardContext()
+    out = {}
+    # `image * 2 - 1` (resnet.py:199) is fused into the root conv's operand staging.
+    if self.config.skip_root_block:
+      x = ops.conv2d(
+          image, _std(ctx, params['conv_root']['kernel']),
+          padding=((1, 1), (1, 1)), prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0),
+      )
+    else:
+      x = ops.conv2d(
+          image, _std(ctx, params['root_block']['conv_root']['kernel']),
+          stride=2, padding=((3, 3), (3, 3)), prologue=ops.PRO_AFFINE,
+          in_affine=(2.0, -1.0),
+      )
+      x = out['stem'] = ops.max_pool_3x3s2(x)
+    for i, size in enumerate(self.blocks):
+      stage = {}
+      nmid = self.width * 2**i
+      for u in range(size):
+        name = f'unit{u + 1:02d}'
+        stride = 2 if (u == 0 and i > 0) else 1
+        x = stage[name] = residual_unit(ctx, params[f'block{i + 1}'][name], x, stride, nmid)
+      out[f'stage{i + 1}'] = stage
+    return out
+
+  default_config = staticmethod(default_configs.resnet)

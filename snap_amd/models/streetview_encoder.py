@@ -1,0 +1,97 @@
+"""StreetView encoder: per-view image features lifted into a 3-D feature volume.
+
+Mirrors ``snap/models/streetview_encoder.py:181-287``.  The projection, top-K view
+selection, bilinear gather, depth-score interpolation and multi-view pooling of
+the reference (five XLA stages that materialise [B,N,K,160] tensors) are ONE HIP
+kernel here (``ops.lift_pool`` -> lift.hip); the fusion MLP runs on the MFMA conv
+engine with the validity mask fused into its last epilogue.
+"""
+import copy
+
+import torch
+
+from snap_amd import ops
+from snap_amd.configs import defaults as default_configs
+from snap_amd.models import base
+from snap_amd.models import image_encoder
+from snap_amd.models import layers
+from snap_amd.models import types
+
+
+class StreetViewEncoder(base.Module):
+  """Encode a set of posed images into a 3-D feature grid."""
+
+  def __init__(self, config, dtype=torch.float32):
+    if config.pretrained_path is not None:
+      raise NotImplementedError(
+          'pretrained_path: Flax checkpoint loading is out of scope '
+          '(and broken in the reference, streetview_encoder.py:189).'
+      )
+    if not config.do_weighted_fusion:
+      raise NotImplementedError('only do_weighted_fusion=True (the default) is built')
+    if config.fusion_add_minmax or not config.fusion_use_variance:
+      raise NotImplementedError('only mean+variance+max-score fusion (the default) is built')
+    self.config = config
+    self.image_encoder = image_encoder.ImageEncoder(config.image_encoder, dtype)
+    fd = config.feature_dim
+    self.fusion_mlp = layers.MLP(config.fusion, in_dim=2 * fd + 1)
+    proj_config = copy.deepcopy(config.proj_mlp)
+    proj_config.layers = (fd + config.num_scale_bins,)
+    self.proj_mlp = layers.MLP(proj_config, in_dim=config.image_encoder.output_dim)
+
+  def init_params(self, gen, device):
+    return {
+        'image_encoder': self.image_encoder.init_params(gen, device),
+        'proj_mlp': self.proj_mlp.init_params(gen, device),
+        'fusion_mlp': self.fusion_mlp.init_params(gen, device),
+    }
+
+  def __call__(self, params, data, train=False, ctx=None, rng=None):
+    cfg = self.config
+    ctx = ctx or base.ForwardContext()
+    f_image_pyr = data.get('image_feature_pyr')
+    if f_image_pyr is None:
+      images = data['images'].to(torch.float32)
+      B, V = images.shape[:2]
+      # nn.vmap over scenes with shared params == one batch of B*V images
+      # (GroupNorm statistics are per image).
+      pyr = self.image_encoder(
+          params['image_encoder'], images.reshape(B * V, *images.shape[2:]),
+          train, ctx=ctx,
+      )
+      f_image_pyr = types.FeatureImagePyramid(
+          features=[f.reshape(B, V, *f.shape[1:]) for f in pyr.features],
+          strides=pyr.strides,
+      )
+    f_images = f_image_pyr.features[-1]
+    B, V = f_images.shape[:2]
+    feature_stride = f_image_pyr.strides[-1]
+    scale = torch.tensor(
+        (1.0 / feature_stride[::-1]).astype('float32'), device=f_images.device
+    )
+    cameras = data['camera'].scale(scale)
+    scene_t_view = data['T_view2scene']
+    pred = {'image_feature_pyramid': f_image_pyr}
+
+    f_images = self.proj_mlp(params['proj_mlp'], f_images.contiguous(), train)
+    pred['scores_images'] = f_images[..., -cfg.num_scale_bins:]
+
+    xyz = data['xyz_query']
+    xyz_flat = xyz.reshape(len(xyz), -1, 3).contiguous()
+    k_vs = cfg.top_k_view_selection
+    K = k_vs if (k_vs and V > k_vs) else 0
+    pooled, valid = ops.lift_pool(
+        f_images, cameras.packed().to(torch.float32),
+        scene_t_view.packed().to(torch.float32), xyz_flat, K=K,
+        fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
+        num_bins=cfg.num_scale_bins, depth_min_max=cfg.depth_min_max,
+        max_view_distance=cfg.get('max_view_distance'),
+    )
+    f_grid = self.fusion_mlp(params['fusion_mlp'], pooled, train, row_mask=valid)
+    grid_shape = (-1, *xyz.shape[-4:-1])
+    f_grid = f_grid.reshape(*grid_shape, f_grid.shape[-1])
+    valid = valid.reshape(grid_shape)
+    pred['feature_volume'] = types.FeatureVolume(features=f_grid, valid=valid)
+    return pred
+
+  default_config = staticmethod(default_configs.streetview_encoder)

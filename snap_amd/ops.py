@@ -1,0 +1,450 @@
+"""Host-side operator wrappers over the C ABI of libsnap_hip.so.
+
+Every function validates dtype / device / contiguity, allocates the outputs with
+torch (device memory plumbing only) and launches the HIP kernel on torch's
+current stream.  There is no CPU or PyTorch fallback: tensors must live on a
+ROCm device and the shared library must be built, otherwise these raise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from snap_amd import _lib
+
+PRO_NONE, PRO_AFFINE, PRO_GN_RELU, PRO_RELU_GN, PRO_RELU = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_UPSAMPLE2X_ADD, EPI_ROWMASK = 1, 2, 4, 8, 16
+POOLING = {'max': 0, 'sum': 1, 'mean': 2}
+SIM_CHUNK = 64
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+  if t is None:
+    return None
+  return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name):
+  if not isinstance(t, torch.Tensor):
+    raise TypeError(f'{name}: expected a torch.Tensor, got {type(t)}')
+  if not t.is_cuda:
+    raise RuntimeError(
+        f'{name}: tensor is on {t.device}; snap_amd ops run only on a ROCm GPU '
+        '(no CPU fallback).'
+    )
+  if t.dtype != dtype:
+    raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+  if not t.is_contiguous():
+    raise ValueError(f'{name}: tensor must be contiguous')
+  return t
+
+
+def _f32(t, name):
+  return _chk(t, torch.float32, name)
+
+
+def _mask(t, name):
+  if t.dtype == torch.bool:
+    return _chk(t, torch.bool, name)
+  return _chk(t, torch.uint8, name)
+
+
+# ----------------------------------------------------------------------------
+# encoder
+# ----------------------------------------------------------------------------
+def conv2d(
+    x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
+    gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
+    up_prev=None, row_mask=None,
+):
+  """NHWC implicit-GEMM conv on f32 MFMA.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
+
+  gn = (mu [N,Cin], sc [N,Cin], beta [Cin]) for PRO_GN_RELU / PRO_RELU_GN.
+  Returns y [N,Ho,Wo,Cout].
+  """
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(w, 'w')
+  N, H, W, Cs = x.shape
+  KH, KW, Cin, Cout = w.shape
+  if cin is None:
+    cin = Cs
+  if cin != Cin:
+    raise ValueError(f'conv2d: kernel expects Cin={Cin}, input has {cin}')
+  (pt, pb), (pl, pr) = padding
+  Ho = (H + pt + pb - KH) // stride + 1
+  Wo = (W + pl + pr - KW) // stride + 1
+  y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+  epi = 0
+  mu = sc = beta = None
+  if prologue in (PRO_GN_RELU, PRO_RELU_GN):
+    mu, sc, beta = gn
+    _f32(mu, 'gn_mu'); _f32(sc, 'gn_sc'); _f32(beta, 'gn_beta')
+    if mu.numel() != N * Cin or sc.numel() != N * Cin or beta.numel() != Cin:
+      raise ValueError('conv2d: GroupNorm statistics have the wrong size')
+  if bias is not None:
+    _f32(bias, 'bias'); epi |= EPI_BIAS
+    if bias.numel() != Cout:
+      raise ValueError('conv2d: bias size')
+  if relu:
+    epi |= EPI_RELU
+  if residual is not None:
+    _f32(residual, 'residual'); epi |= EPI_RESIDUAL
+    if residual.shape != y.shape:
+      raise ValueError(f'conv2d: residual {tuple(residual.shape)} vs {tuple(y.shape)}')
+  if up_prev is not None:
+    _f32(up_prev, 'up_prev'); epi |= EPI_UPSAMPLE2X_ADD
+    if tuple(up_prev.shape) != (N, Ho // 2, Wo // 2, Cout):
+      raise ValueError('conv2d: up_prev shape')
+  if row_mask is not None:
+    _mask(row_mask, 'row_mask'); epi |= EPI_ROWMASK
+    if row_mask.numel() != N * Ho * Wo:
+      raise ValueError('conv2d: row_mask size')
+  d = _lib.SnapConvDesc(
+      N, H, W, Cin, Cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout, prologue,
+      epi, float(in_affine[0]), float(in_affine[1]),
+  )
+  st = lib.snap_conv2d_nhwc_f32(
+      ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
+      _p(residual), _p(up_prev), _p(row_mask), _stream(),
+  )
+  _lib.check(st, 'snap_conv2d_nhwc_f32')
+  return y
+
+
+def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
+          row_mask=None):
+  """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1)."""
+  lead = x.shape[:-1]
+  M = int(np.prod(lead)) if len(lead) else 1
+  y = conv2d(
+      x.reshape(1, 1, M, x.shape[-1]), kernel.reshape(1, 1, *kernel.shape),
+      cin=cin if cin is not None else kernel.shape[0], prologue=prologue,
+      bias=bias, relu=relu, row_mask=row_mask,
+  )
+  return y.reshape(*lead, kernel.shape[1])
+
+
+def weight_standardize(w, eps=1e-10):
+  """StdConv kernel standardisation.  w [KH,KW,Cin,Cout] -> same shape."""
+  lib = _lib.load()
+  _f32(w, 'w')
+  out = torch.empty_like(w)
+  K = w.shape[0] * w.shape[1] * w.shape[2]
+  st = lib.snap_weight_standardize_f32(_p(w), _p(out), K, w.shape[3], eps, _stream())
+  _lib.check(st, 'snap_weight_standardize_f32')
+  return out
+
+
+def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False):
+  """x [N,H,W,C] -> (mu [N,C], sc [N,C]) with sc = rstd * gamma."""
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(gamma, 'gamma')
+  N, H, W, C = x.shape
+  HW = H * W
+  wsb = lib.snap_group_norm_stats_workspace_bytes(N, HW, C, groups)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=x.device)
+  mu = torch.empty((N, C), dtype=torch.float32, device=x.device)
+  sc = torch.empty((N, C), dtype=torch.float32, device=x.device)
+  st = lib.snap_group_norm_stats_f32(
+      _p(x), N, HW, C, C, groups, eps, int(relu_first), _p(gamma), _p(mu),
+      _p(sc), _p(ws), ws.numel() * 4, _stream(),
+  )
+  _lib.check(st, 'snap_group_norm_stats_f32')
+  return mu, sc
+
+
+def group_norm_apply(x, mu, sc, beta, mode):
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(mu, 'mu'); _f32(sc, 'sc'); _f32(beta, 'beta')
+  N, H, W, C = x.shape
+  y = torch.empty_like(x)
+  st = lib.snap_group_norm_apply_f32(
+      _p(x), _p(y), N, H * W, C, _p(mu), _p(sc), _p(beta), mode, _stream()
+  )
+  _lib.check(st, 'snap_group_norm_apply_f32')
+  return y
+
+
+def max_pool_3x3s2(x):
+  lib = _lib.load()
+  _f32(x, 'x')
+  N, H, W, C = x.shape
+  Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+  y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+  st = lib.snap_max_pool_3x3s2_f32(_p(x), _p(y), N, H, W, C, _stream())
+  _lib.check(st, 'snap_max_pool_3x3s2_f32')
+  return y
+
+
+# ----------------------------------------------------------------------------
+# lift
+# ----------------------------------------------------------------------------
+def pooled_stride(feature_dim):
+  return (2 * feature_dim + 1 + 3) // 4 * 4
+
+
+def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
+              depth_min_max, max_view_distance=None):
+  """Fused k1-k5.  f_images [B,V,h,w,C]; cam [B,V,11]; Rt [B,V,12]; points [B,N,3].
+
+  K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad),
+  valid [B,N] bool.
+  """
+  lib = _lib.load()
+  _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
+  B, V, h, w, C = f_images.shape
+  N = points.shape[1]
+  stride = pooled_stride(feature_dim)
+  pooled = torch.empty((B, N, stride), dtype=torch.float32, device=f_images.device)
+  valid = torch.empty((B, N), dtype=torch.bool, device=f_images.device)
+  d = _lib.SnapLiftDesc(
+      B, V, h, w, C, feature_dim, num_bins, N, K, int(fisheye), stride,
+      float(depth_min_max[0]), float(depth_min_max[1]),
+      -1.0 if max_view_distance is None else float(max_view_distance),
+  )
+  st = lib.snap_lift_pool_f32(
+      ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(pooled),
+      _p(valid), _stream(),
+  )
+  _lib.check(st, 'snap_lift_pool_f32')
+  return pooled, valid
+
+
+def project_points(cam, Rt, points, fisheye):
+  lib = _lib.load()
+  _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
+  B, V = cam.shape[:2]
+  N = points.shape[1]
+  dev = cam.device
+  p2d = torch.empty((B, N, V, 2), dtype=torch.float32, device=dev)
+  vis = torch.empty((B, N, V), dtype=torch.bool, device=dev)
+  depth = torch.empty((B, N, V), dtype=torch.float32, device=dev)
+  st = lib.snap_project_points_f32(
+      B, V, N, int(fisheye), _p(cam), _p(Rt), _p(points), _p(p2d), _p(vis),
+      _p(depth), _stream(),
+  )
+  _lib.check(st, 'snap_project_points_f32')
+  return p2d, vis, depth
+
+
+# ----------------------------------------------------------------------------
+# BEV
+# ----------------------------------------------------------------------------
+def vertical_pool(vol, valid, pooling='max'):
+  """vol [..., Z, D], valid [..., Z] -> plane [..., D], pvalid [...]."""
+  lib = _lib.load()
+  _f32(vol, 'vol'); _mask(valid, 'valid')
+  lead = vol.shape[:-2]
+  Z, D = vol.shape[-2:]
+  M = int(np.prod(lead))
+  plane = torch.empty((*lead, D), dtype=torch.float32, device=vol.device)
+  pvalid = torch.empty(lead, dtype=torch.bool, device=vol.device)
+  st = lib.snap_vertical_pool_f32(
+      _p(vol), _p(valid), _p(plane), _p(pvalid), M, Z, D, POOLING[pooling], _stream()
+  )
+  _lib.check(st, 'snap_vertical_pool_f32')
+  return plane, pvalid
+
+
+def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None,
+                     normalize=True, eps=1e-5, want_fused=True):
+  """Fuse modality planes and apply the matching head.
+
+  planes: list of [..., D]; valids: list of [...] bool or None (all valid).
+  Returns fused [..., D], fvalid [...], matching [..., Dm] (None if Wm is None).
+  """
+  lib = _lib.load()
+  n = len(planes)
+  lead = planes[0].shape[:-1]
+  D = planes[0].shape[-1]
+  M = int(np.prod(lead))
+  dev = planes[0].device
+  for i, p in enumerate(planes):
+    _f32(p, f'planes[{i}]')
+    if p.shape != planes[0].shape:
+      raise ValueError('plane_fuse_match: plane shapes differ')
+  pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in planes])
+  vv = (ctypes.c_void_p * n)(
+      *[None if v is None else _mask(v, 'valid').data_ptr() for v in valids]
+  )
+  fused = torch.empty((*lead, D), dtype=torch.float32, device=dev) if want_fused else None
+  fvalid = torch.empty(lead, dtype=torch.bool, device=dev)
+  matching = None
+  Dm = 0
+  if Wm is not None:
+    _f32(Wm, 'Wm'); _f32(bm, 'bm')
+    Dm = Wm.shape[1]
+    matching = torch.empty((*lead, Dm), dtype=torch.float32, device=dev)
+  st = lib.snap_plane_fuse_match_f32(
+      ctypes.cast(pp, ctypes.c_void_p), ctypes.cast(vv, ctypes.c_void_p), n, M,
+      D, POOLING[pooling], _p(fused), _p(fvalid), _p(Wm), _p(bm), Dm,
+      int(normalize), eps, _p(matching), _stream(),
+  )
+  _lib.check(st, 'snap_plane_fuse_match_f32')
+  return fused, fvalid, matching
+
+
+# ----------------------------------------------------------------------------
+# pose
+# ----------------------------------------------------------------------------
+def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
+                want_rowstats=False):
+  """fq [B,Nq,Dm], fm [B,X,Y,Dm], num_valid [B] float ->
+  sim [B,Nq,X,Y], chunk_stats [B,Nq,NC,2], (prob), (rowstats)."""
+  lib = _lib.load()
+  _f32(fq, 'fq'); _f32(fm, 'fm'); _f32(num_valid, 'num_valid')
+  B, Nq, Dm = fq.shape
+  X, Y = fm.shape[1:3]
+  XY = X * Y
+  NC = (XY + SIM_CHUNK - 1) // SIM_CHUNK
+  dev = fq.device
+  sim = torch.empty((B, Nq, X, Y), dtype=torch.float32, device=dev)
+  stats = torch.empty((B, Nq, NC, 2), dtype=torch.float32, device=dev)
+  prob = torch.empty_like(sim) if want_prob else None
+  rowstats = (
+      torch.empty((B, Nq, 2), dtype=torch.float32, device=dev)
+      if (want_prob or want_rowstats) else None
+  )
+  st = lib.snap_sim_softmax_f32(
+      _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(clip_negative),
+      _p(num_valid), _p(sim), _p(stats), _p(prob), _p(rowstats), _stream(),
+  )
+  _lib.check(st, 'snap_sim_softmax_f32')
+  return sim, stats, prob, rowstats
+
+
+def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
+                  uniforms=None):
+  """Draw S correspondences per scene ~ prob_points.  Returns int32 [B,S,3]."""
+  lib = _lib.load()
+  _f32(fq, 'fq'); _f32(fm, 'fm'); _f32(chunk_stats, 'chunk_stats')
+  B, Nq, Dm = fq.shape
+  X, Y = fm.shape[1:3]
+  if uniforms is not None:
+    _f32(uniforms, 'uniforms')
+    if tuple(uniforms.shape) != (B, S, 2):
+      raise ValueError('ransac_sample: uniforms must be [B,S,2]')
+  corr = torch.empty((B, S, 3), dtype=torch.int32, device=fq.device)
+  st = lib.snap_ransac_sample_f32(
+      _p(fq), _p(fm), _p(chunk_stats), B, Nq, X, Y, Dm, float(scale),
+      int(clip_negative), S, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(uniforms),
+      _p(corr), _stream(),
+  )
+  _lib.check(st, 'snap_ransac_sample_f32')
+  return corr
+
+
+def poses_from_corr(corr, q_xy, P, retries, cell_size):
+  """corr int32 [B,P*retries*2,3], q_xy [B,Nq,2] -> poses [B,P,3] (angle,tx,ty)."""
+  lib = _lib.load()
+  _chk(corr, torch.int32, 'corr'); _f32(q_xy, 'q_xy')
+  B, Nq = q_xy.shape[:2]
+  if corr.shape[1] != P * retries * 2:
+    raise ValueError('poses_from_corr: corr size')
+  poses = torch.empty((B, P, 3), dtype=torch.float32, device=corr.device)
+  st = lib.snap_poses_from_corr_f32(
+      _p(corr), _p(q_xy), B, Nq, P, retries, float(cell_size), _p(poses), _stream()
+  )
+  _lib.check(st, 'snap_poses_from_corr_f32')
+  return poses
+
+
+def pose_score(sim, poses, q_xy, valid_q, map_valid, cell_size, mask_oob=False):
+  """sim [B,Nq,X,Y]; poses [B,P,3]; q_xy [B,Nq,2]; valid_q [B,Nq] -> scores [B,P]."""
+  lib = _lib.load()
+  _f32(sim, 'sim'); _f32(poses, 'poses'); _f32(q_xy, 'q_xy'); _mask(valid_q, 'valid_q')
+  if map_valid is not None:
+    _mask(map_valid, 'map_valid')
+  B, Nq, X, Y = sim.shape
+  P = poses.shape[1]
+  wsb = lib.snap_pose_score_workspace_bytes(B, Nq, P, X, Y)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=sim.device)
+  scores = torch.empty((B, P), dtype=torch.float32, device=sim.device)
+  st = lib.snap_pose_score_f32(
+      _p(sim), _p(poses), _p(q_xy), _p(valid_q), _p(map_valid), B, Nq, X, Y, P,
+      float(cell_size), int(mask_oob), _p(scores), _p(ws), ws.numel() * 4,
+      _stream(),
+  )
+  _lib.check(st, 'snap_pose_score_f32')
+  return scores
+
+
+def refine_lattice(init, offs_r, offs_p):
+  """init [B,3]; offs_r [nr] (rad); offs_p [np] (m) -> [B, nr*np*np, 3]."""
+  lib = _lib.load()
+  _f32(init, 'init'); _f32(offs_r, 'offs_r'); _f32(offs_p, 'offs_p')
+  B = init.shape[0]
+  nr, np_ = offs_r.numel(), offs_p.numel()
+  out = torch.empty((B, nr * np_ * np_, 3), dtype=torch.float32, device=init.device)
+  st = lib.snap_refine_lattice_f32(
+      _p(init), _p(offs_r), _p(offs_p), B, nr, np_, _p(out), _stream()
+  )
+  _lib.check(st, 'snap_refine_lattice_f32')
+  return out
+
+
+def argmax_rows(scores, start=0):
+  """First-index argmax of scores[:, start:] -> int32 [B] (relative to start)."""
+  lib = _lib.load()
+  _f32(scores, 'scores')
+  B, P = scores.shape
+  idx = torch.empty((B,), dtype=torch.int32, device=scores.device)
+  st = lib.snap_argmax_rows_f32(_p(scores), B, P, start, _p(idx), _stream())
+  _lib.check(st, 'snap_argmax_rows_f32')
+  return idx
+
+
+# ----------------------------------------------------------------------------
+# exhaustive voting
+# ----------------------------------------------------------------------------
+def rotate_templates(feat, valid, tfm, num_rotations, cell_size):
+  """feat [H,W,D], valid [H,W], tfm [R/4,4] -> templates [R,H,W,D], tvalid [R,H,W],
+  tw [H,W,D,R], cw [H,W,1,R], tcount [R]."""
+  lib = _lib.load()
+  _f32(feat, 'feat'); _mask(valid, 'valid'); _f32(tfm, 'tfm')
+  H, W, D = feat.shape
+  R = num_rotations
+  dev = feat.device
+  templates = torch.empty((R, H, W, D), dtype=torch.float32, device=dev)
+  tvalid = torch.empty((R, H, W), dtype=torch.bool, device=dev)
+  tw = torch.empty((H, W, D, R), dtype=torch.float32, device=dev)
+  cw = torch.empty((H, W, 1, R), dtype=torch.float32, device=dev)
+  tcount = torch.empty((R,), dtype=torch.float32, device=dev)
+  st = lib.snap_rotate_templates_f32(
+      _p(feat), _p(valid), _p(tfm), H, W, D, R, float(cell_size), _p(templates),
+      _p(tvalid), _p(tw), _p(cw), _p(tcount), _stream(),
+  )
+  _lib.check(st, 'snap_rotate_templates_f32')
+  return templates, tvalid, tw, cw, tcount
+
+
+def pad_map(m, mvalid):
+  lib = _lib.load()
+  _f32(m, 'map'); _mask(mvalid, 'mvalid')
+  H, W, D = m.shape
+  dev = m.device
+  mp = torch.empty((3 * H - 2, 3 * W - 2, D), dtype=torch.float32, device=dev)
+  mvp = torch.empty((3 * H - 2, 3 * W - 2), dtype=torch.float32, device=dev)
+  st = lib.snap_pad_map_f32(_p(m), _p(mvalid), H, W, D, _p(mp), _p(mvp), _stream())
+  _lib.check(st, 'snap_pad_map_f32')
+  return mp, mvp
+
+
+def template_finalize(raw, cnt, tcount, R, threshold, use_overlap=True):
+  """raw, cnt [Ho,Wo,Rp] -> scores [R,Ho,Wo]."""
+  lib = _lib.load()
+  _f32(raw, 'raw'); _f32(tcount, 'tcount')
+  if cnt is not None:
+    _f32(cnt, 'cnt')
+  Ho, Wo, Rp = raw.shape
+  scores = torch.empty((R, Ho, Wo), dtype=torch.float32, device=raw.device)
+  st = lib.snap_template_finalize_f32(
+      _p(raw), _p(cnt), _p(tcount), Ho, Wo, R, Rp, float(threshold),
+      int(use_overlap), _p(scores), _stream(),
+  )
+  _lib.check(st, 'snap_template_finalize_f32')
+  return scores

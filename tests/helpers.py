@@ -1,0 +1,122 @@
+"""Shared test helpers: tiny configs, parameter conversion, comparison reports."""
+import copy
+
+import numpy as np
+import torch
+
+from oracle import geometry as o_geo
+from snap_amd.configs import defaults
+
+
+def tiny_localizer_config(num_pose_samples=64, retries=2, top_k=2, feature_dim=32,
+                          matching_dim=8, num_bins=8, depth=(1, 1), width=0.5,
+                          refine=False, aerial=True):
+  """A BEVLocalizer config small enough for the numpy oracle (seconds)."""
+  cfg = defaults.bev_localizer()
+  cfg.filter_points_in_fov = True
+  cfg.num_pose_samples = num_pose_samples
+  cfg.num_pose_sampling_retries = retries
+  cfg.do_grid_refinement = refine
+  cfg.query_frustum_depth = 3.2
+  mods = ('streetview', 'aerial') if aerial else ('streetview',)
+  cfg.bev_mapper = defaults.bev_mapper(mods)
+  m = cfg.bev_mapper
+  m.matching_dim = matching_dim
+  m.scene_z_height = 2.4
+  m.scene_z_offset = 1.6
+  sv = m.streetview_encoder
+  sv.feature_dim = feature_dim
+  sv.num_scale_bins = num_bins
+  sv.top_k_view_selection = top_k
+  sv.fusion.layers = (2 * feature_dim, feature_dim)
+  sv.depth_min_max = (0.5, 8.0)
+  sv.image_encoder.output_dim = feature_dim
+  sv.image_encoder.encoder.depth = list(depth)
+  sv.image_encoder.encoder.width = width
+  sv.image_encoder.encoder.limit_num_blocks = len(depth)
+  if aerial:
+    a = m.aerial_encoder
+    a.output_dim = feature_dim
+    a.encoder.depth = list(depth)
+    a.encoder.width = width
+    a.encoder.limit_num_blocks = len(depth)
+  return cfg
+
+
+def params_to_numpy(params, dtype=np.float32):
+  if isinstance(params, dict):
+    return {k: params_to_numpy(v, dtype) for k, v in params.items()}
+  return params.detach().cpu().numpy().astype(dtype)
+
+
+def params_to_device(params, device):
+  if isinstance(params, dict):
+    return {k: params_to_device(v, device) for k, v in params.items()}
+  return params.to(device)
+
+
+def scene_to_oracle(scene, dtype=np.float32):
+  """torch scene dict -> numpy dict with oracle camera / transform structs."""
+  def n(t):
+    return t.detach().cpu().numpy().astype(dtype)
+  cam = scene['camera']
+  T = scene['T_view2scene']
+  out = {
+      'images': n(scene['images']),
+      'camera': o_geo.FisheyeCamera(n(cam.wh), n(cam.f), n(cam.c), n(cam.k_radial), n(cam.max_fov)),
+      'T_view2scene': o_geo.Transform3D(n(T.R), n(T.t)),
+  }
+  if 'rasters' in scene:
+    out['rasters'] = {'rgb': n(scene['rasters']['rgb'])}
+  if 'xyz_query' in scene:
+    out['xyz_query'] = n(scene['xyz_query'])
+  return out
+
+
+def batch_to_oracle(batch, dtype=np.float32):
+  out = {'map': scene_to_oracle(batch['map'], dtype), 'query': scene_to_oracle(batch['query'], dtype)}
+  if 'T_query2map' in batch:
+    T = batch['T_query2map']
+    out['T_query2map'] = o_geo.Transform3D(
+        T.R.detach().cpu().numpy().astype(dtype), T.t.detach().cpu().numpy().astype(dtype)
+    )
+  return out
+
+
+def batch_to_device(batch, device):
+  def mv(x):
+    if isinstance(x, dict):
+      return {k: mv(v) for k, v in x.items()}
+    if hasattr(x, 'to'):
+      return x.to(device)
+    return x
+  return mv(batch)
+
+
+def report(name, got, want, atol, rtol=0.0):
+  """Assert closeness with a diagnostic message (max error, location, fraction bad)."""
+  got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+  want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+  assert got.shape == want.shape, f'{name}: shape {got.shape} vs {want.shape}'
+  if got.dtype == bool or want.dtype == bool or got.dtype.kind in 'iu':
+    bad = got != want
+    assert not bad.any(), (
+        f'{name}: {bad.sum()} / {bad.size} mismatches; first at '
+        f'{np.argwhere(bad)[0].tolist()}: got {got[bad][0]} want {want[bad][0]}'
+    )
+    return
+  g = got.astype(np.float64)
+  w = want.astype(np.float64)
+  both_inf = np.isinf(g) & np.isinf(w) & (np.sign(g) == np.sign(w))
+  both_nan = np.isnan(g) & np.isnan(w)
+  err = np.where(both_inf | both_nan, 0.0, np.abs(g - w))
+  err = np.where(np.isnan(err), np.inf, err)
+  tol = atol + rtol * np.abs(np.where(np.isfinite(w), w, 0))
+  bad = err > tol
+  if bad.any():
+    i = np.unravel_index(np.argmax(np.where(np.isfinite(err), err, 1e30)), err.shape)
+    raise AssertionError(
+        f'{name}: {bad.sum()} / {bad.size} beyond tol (atol={atol}, rtol={rtol}); '
+        f'max err {err[i]:.3e} at {tuple(int(k) for k in i)}: got {g[i]:.6e} want {w[i]:.6e}; '
+        f'ref |max| {np.nanmax(np.abs(np.where(np.isfinite(w), w, 0))):.3e}'
+    )
