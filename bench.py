@@ -1,0 +1,315 @@
+"""Benchmark of the SNAP localisation hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one ``BEVLocalizer`` forward (map BEV from 4 StreetView views + aerial,
+query BEV, point-vs-map similarity, RANSAC pose sampling, pose scoring, argmax)
+over one batch of synthetic scenes resident in HBM.  Workload (BASELINE.json
+configs[1], "C2"): 8 scenes per GPU, 4 StreetView views @512 px + aerial tile,
+128x128 BEV (25.6 m @ 0.2 m, 60 height levels), ResNet-50 encoders, 10 000 (+1 GT)
+pose samples x 8 retries.  Scenes are independent: N GPUs = N ranks, each with its
+own 8-scene batch, no data-path collective ("weak" scaling).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings),
+including ``roofline`` (dominant kernel, HIP-event timed inside the timed region)
+and ``cpu_baseline`` (the numpy oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from snap_amd import ops  # noqa: E402
+from snap_amd.configs import train_localization  # noqa: E402
+from snap_amd.data import synthetic  # noqa: E402
+from snap_amd.models import bev_localizer  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+WORKLOADS = {
+    # name: (scenes/GPU, views, image px, grid metres, encoder args, pose samples, retries)
+    'c2': dict(batch=8, views=4, image=512, grid=(25.6, 25.6, 12), tiny=False,
+               desc='C2: 8 scenes/GPU, 4 StreetView views @512px + aerial, 128x128x60 '
+                    'voxel BEV @0.2m, ResNet-50 encoders, 10001 pose hypotheses'),
+    'tiny': dict(batch=2, views=3, image=64, grid=(6.4, 6.4, 12), tiny=True,
+                 desc='tiny plumbing workload (tests only)'),
+}
+
+
+def build(workload, device, rank):
+  w = WORKLOADS[workload]
+  meta = synthetic.meta_data(0.2, w['grid'])
+  if w['tiny']:
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    cfg = helpers.tiny_localizer_config()
+  else:
+    cfg = train_localization.get_config().model
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
+  variables = loc.init(0, device='cpu')
+  variables = {'params': _to(variables['params'], device)}
+  batch = synthetic.make_batch(
+      w['batch'], meta['grid'], w['views'], (w['image'], w['image']), seed=100 + rank,
+      device=device,
+  )
+  return loc, cfg, meta, variables, batch
+
+
+def _to(tree, device):
+  if isinstance(tree, dict):
+    return {k: _to(v, device) for k, v in tree.items()}
+  return tree.to(device)
+
+
+def _sync(device):
+  if device.type == 'cuda':
+    torch.cuda.synchronize()
+
+
+def cpu_baseline(cfg, meta, workload, budget_s=40.0):
+  """Time the numpy oracle (a CPU restatement of the reference algorithm; JAX is
+  not installable offline) on a bounded sample of one scene and extrapolate
+  linearly to a whole scene.  Reported, never optimised against."""
+  from oracle import bev as o_bev
+  from oracle import encoder as o_enc
+  from oracle import geometry as o_geo
+  from oracle import grids as o_grids
+  from oracle import lift as o_lift
+  from oracle import pose as o_pose
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import helpers
+
+  w = WORKLOADS[workload]
+  grid = meta['grid']
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, grid.bev())
+  params = helpers.params_to_numpy(loc.init(0, device='cpu')['params'])
+  batch = synthetic.make_batch(1, grid, w['views'], (w['image'], w['image']), seed=7)
+  ob = helpers.batch_to_oracle(batch)
+  mcfg = cfg.bev_mapper
+  sv_cfg = mcfg.streetview_encoder
+  p_sv = params['bev_mapper']['streetview_encoder']
+  V = w['views']
+  t = {}
+
+  # (1) one StreetView view through R50 + FPN + proj MLP; x (V + 1 query view).
+  t0 = time.perf_counter()
+  pyr = o_enc.image_encoder(p_sv['image_encoder'], sv_cfg.image_encoder, ob['map']['images'][0, :1])
+  f_img = pyr['features'][-1]
+  proj_cfg = dict(layers=(sv_cfg.feature_dim + sv_cfg.num_scale_bins,), apply_input_activation=True)
+  f_img = o_enc.mlp(p_sv['proj_mlp'], proj_cfg, f_img)
+  t['encoder_view'] = time.perf_counter() - t0
+  # (2) aerial tile through its own R50 (stride 1).
+  t0 = time.perf_counter()
+  o_enc.image_encoder(params['bev_mapper']['aerial_encoder'], mcfg.aerial_encoder,
+                      ob['map']['rasters']['rgb'])
+  t['encoder_aerial'] = time.perf_counter() - t0
+  # (3) lift + fusion MLP + vertical pooling on a slab of BEV columns.
+  X, Y = grid.extent[:2]
+  xs = max(1, X // 16)
+  data = dict(ob['map'])
+  xyz = o_bev.build_xyz_query(mcfg, o_grids.Grid2D((X, Y), grid.cell_size), data['T_view2scene'])
+  xyz = xyz[:, :xs]
+  f_all = np.repeat(f_img[None], V, axis=1) if f_img.ndim == 4 else f_img
+  t0 = time.perf_counter()
+  stride = pyr['strides'][-1]
+  cams = data['camera'].scale((1 / stride[::-1]).astype(np.float32))
+  pts = xyz.reshape(1, -1, 3)
+  p2d, vis, depth, _ = o_lift.project_points_to_views(data['T_view2scene'], cams, pts)
+  f_proj = o_lift.interpolate_views_all(f_all, p2d)
+  fd = sv_cfg.feature_dim
+  scores = o_lift.interpolate_depth_score(f_proj[..., fd:], depth, sv_cfg.depth_min_max)
+  pooled, valid = o_lift.pool_multiview_features(f_proj[..., :fd], vis, scores, False, True)
+  vol = o_enc.mlp(p_sv['fusion_mlp'], sv_cfg.fusion, pooled)
+  vol = np.where(valid[..., None], vol, 0).reshape(1, xs, Y, -1, fd)
+  o_bev.vertical_pooling(mcfg.pooling, vol, valid.reshape(1, xs, Y, -1))
+  t['lift_slab'] = time.perf_counter() - t0
+  lift_scale = X / xs
+  # query lift: Nq columns
+  _, _, q_xy = o_pose.build_query_frustum_grid(grid.cell_size, cfg.query_frustum_depth, True, 72.0)
+  Nq = q_xy.shape[0]
+  # (4) similarity + softmax for a slice of the query points.
+  Dm = mcfg.matching_dim
+  rng = np.random.default_rng(0)
+  nq_s = min(Nq, 256)
+  fq = rng.standard_normal((1, nq_s, Dm)).astype(np.float32)
+  fm = rng.standard_normal((1, X, Y, Dm)).astype(np.float32)
+  t0 = time.perf_counter()
+  sim, _ = o_pose.similarity(fq, fm, np.ones((1, nq_s), bool), 2.0, True)
+  t['sim_slice'] = time.perf_counter() - t0
+  # (5) pose scoring: a slice of poses against the slice of points.
+  P = cfg.num_pose_samples + 1
+  p_s = min(P, 512)
+  poses = o_geo.Transform2D(
+      rng.uniform(0, 6.28, p_s).astype(np.float32),
+      rng.uniform(0, X * grid.cell_size, (p_s, 2)).astype(np.float32),
+  )
+  qxy = q_xy[:nq_s, 0].astype(np.float32)
+  t0 = time.perf_counter()
+  o_pose.pose_scoring_many(poses, sim[0], qxy, np.ones(nq_s, bool), np.ones((X, Y), bool),
+                           o_grids.Grid2D((X, Y), grid.cell_size), False)
+  t['score_slice'] = time.perf_counter() - t0
+
+  Z = xyz.shape[3]
+  per_scene = (
+      t['encoder_view'] * (V + 1) + t['encoder_aerial']
+      + t['lift_slab'] * lift_scale * (1 + Nq / (X * Y))
+      + t['sim_slice'] * (Nq / nq_s)
+      + t['score_slice'] * (Nq / nq_s) * (P / p_s)
+  )
+  return {
+      'value': 1.0 / per_scene,
+      'unit': 'scenes/s',
+      'cores': os.cpu_count(),
+      'kind': 'port',
+      'sample': (
+          'numpy oracle (CPU restatement of the reference algorithm; JAX unavailable '
+          f'offline), BLAS-threaded: 1 of {V + 1} views through R50+FPN, the aerial R50, '
+          f'{xs}/{X} of the BEV columns (x{Z} levels) through lift+fusion-MLP+pooling, '
+          f'{nq_s}/{Nq} query points for similarity, {p_s}/{P} poses for scoring; '
+          'per-scene time extrapolated linearly'
+      ),
+      'seconds_measured': round(sum(t.values()), 2),
+      'stage_seconds': {k: round(v, 3) for k, v in t.items()},
+  }
+
+
+def main(argv=None):
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=5)
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+  ap.add_argument('--device', default='cuda')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args(argv)
+
+  rank = int(os.environ.get('RANK', 0))
+  world = int(os.environ.get('WORLD_SIZE', 1))
+  local_rank = int(os.environ.get('LOCAL_RANK', 0))
+  if world != args.gpus:
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+  use_cuda = args.device == 'cuda'
+  if use_cuda:
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+  else:
+    device = torch.device('cpu')
+  if world > 1:
+    dist.init_process_group('nccl' if use_cuda else 'gloo')
+
+  loc, cfg, meta, variables, batch = build(args.workload, device, rank)
+  scenes_per_rank = WORKLOADS[args.workload]['batch']
+
+  def step(i):
+    return loc.apply(variables, batch, train=False, rngs={'sampling': 1000 * rank + i})
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    _sync(device)
+
+  for i in range(args.warmup):
+    step(i)
+  barrier()
+  prof = None
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    if use_cuda and rank == 0 and i == args.steps - 1:
+      prof = ops.KernelProfiler()   # HIP events around every launch of the last step
+      ops.set_profiler(prof)
+    pred = step(args.warmup + i)
+  ops.set_profiler(None)
+  barrier()
+  elapsed = time.perf_counter() - t0
+  t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  elapsed = float(t.item())
+  ms_per_step = 1e3 * elapsed / args.steps
+  value = scenes_per_rank * world * args.steps / elapsed
+
+  out = None
+  if rank == 0:
+    out = {
+        'metric': 'localization_scenes_per_sec',
+        'value': round(value, 3),
+        'unit': 'scenes/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 3),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': WORKLOADS[args.workload]['desc'],
+            'scenes_per_gpu': scenes_per_rank,
+            'global_batch': scenes_per_rank * world,
+            'parallelism': f'scene-sharded x{world}, no data-path collective',
+            'mode': 'inference forward (BEVLocalizer.apply, train=False)',
+        },
+    }
+    if prof is not None:
+      summ = prof.summary()
+      kern = {}
+      for name, s in summ.items():
+        ms = max(s['ms'], 1e-9)
+        kern[name] = {
+            'launches': s['launches'], 'ms': round(ms, 3),
+            'tflops': round(s['flops'] / ms / 1e9, 2),
+            'gbs': round(s['bytes'] / ms / 1e6, 1),
+        }
+      dom = max(summ, key=lambda k: summ[k]['ms'])
+      s = summ[dom]
+      if s['flops'] > 0:
+        ach = s['flops'] / s['ms'] / 1e9
+        out['roofline'] = {
+            'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2),
+            'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4), 'traffic': None,
+            'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
+            'flops_per_step': s['flops'],
+        }
+      else:
+        ach = s['bytes'] / s['ms'] / 1e6
+        out['roofline'] = {
+            'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS,
+            'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+            'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
+        }
+      if 'pose_score' in summ:
+        s = summ['pose_score']
+        ach = s['bytes'] / s['ms'] / 1e6
+        out['roofline_pose_corr'] = {
+            'kernel': 'pose_score', 'bound': 'hbm', 'achieved': round(ach, 1),
+            'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
+            'traffic': None, 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
+            'bytes_per_launch': s['bytes'] / s['launches'],
+        }
+      out['kernels'] = kern
+    if world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']:
+      try:
+        out['cpu_baseline'] = cpu_baseline(cfg, meta, args.workload)
+      except Exception as e:  # the baseline must never take the bench line down
+        out['cpu_baseline'] = {'error': repr(e)}
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+  return out
+
+
+if __name__ == '__main__':
+  main()

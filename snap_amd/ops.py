@@ -22,6 +22,76 @@ def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelProfiler:
+  """HIP-event timing of individual kernel launches on torch's current stream.
+
+  ``bench.py`` installs one for a single step of the timed region to obtain the
+  per-kernel durations behind the ``roofline`` object (events are recorded on the
+  stream the kernels are launched on).  ``flops`` / ``nbytes`` are the ALGORITHMIC
+  figures of DESIGN.md, not measured traffic.
+  """
+
+  def __init__(self):
+    self.records = {}
+
+  def region(self, name, flops=0.0, nbytes=0.0):
+    return _Region(self, name, flops, nbytes)
+
+  def summary(self):
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in self.records.items():
+      ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+      out[name] = dict(
+          launches=len(recs), ms=ms, flops=sum(r[2] for r in recs),
+          bytes=sum(r[3] for r in recs),
+      )
+    return out
+
+
+class _Region:
+
+  def __init__(self, prof, name, flops, nbytes):
+    self.prof, self.name, self.flops, self.nbytes = prof, name, flops, nbytes
+
+  def __enter__(self):
+    self.start = torch.cuda.Event(enable_timing=True)
+    self.start.record()
+
+  def __exit__(self, *exc):
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    self.prof.records.setdefault(self.name, []).append(
+        (self.start, end, self.flops, self.nbytes)
+    )
+
+
+class _NoRegion:
+
+  def __enter__(self):
+    pass
+
+  def __exit__(self, *exc):
+    pass
+
+
+_PROFILER = None
+_NO_REGION = _NoRegion()
+
+
+def set_profiler(prof):
+  """Install (or remove with None) a KernelProfiler; returns the previous one."""
+  global _PROFILER
+  old, _PROFILER = _PROFILER, prof
+  return old
+
+
+def _region(name, flops=0.0, nbytes=0.0):
+  if _PROFILER is None:
+    return _NO_REGION
+  return _PROFILER.region(name, flops, nbytes)
+
+
 def _p(t):
   if t is None:
     return None
@@ -107,10 +177,15 @@ def conv2d(
       N, H, W, Cin, Cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout, prologue,
       epi, float(in_affine[0]), float(in_affine[1]),
   )
-  st = lib.snap_conv2d_nhwc_f32(
-      ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
-      _p(residual), _p(up_prev), _p(row_mask), _stream(),
-  )
+  M = N * Ho * Wo
+  with _region(
+      'conv_igemm', 2.0 * M * KH * KW * Cin * Cout,
+      4.0 * (x.numel() + w.numel() + y.numel()),
+  ):
+    st = lib.snap_conv2d_nhwc_f32(
+        ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
+        _p(residual), _p(up_prev), _p(row_mask), _stream(),
+    )
   _lib.check(st, 'snap_conv2d_nhwc_f32')
   return y
 
@@ -134,7 +209,8 @@ def weight_standardize(w, eps=1e-10):
   _f32(w, 'w')
   out = torch.empty_like(w)
   K = w.shape[0] * w.shape[1] * w.shape[2]
-  st = lib.snap_weight_standardize_f32(_p(w), _p(out), K, w.shape[3], eps, _stream())
+  with _region('weight_standardize', 0.0, 16.0 * w.numel()):
+    st = lib.snap_weight_standardize_f32(_p(w), _p(out), K, w.shape[3], eps, _stream())
   _lib.check(st, 'snap_weight_standardize_f32')
   return out
 
@@ -149,10 +225,11 @@ def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False):
   ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=x.device)
   mu = torch.empty((N, C), dtype=torch.float32, device=x.device)
   sc = torch.empty((N, C), dtype=torch.float32, device=x.device)
-  st = lib.snap_group_norm_stats_f32(
-      _p(x), N, HW, C, C, groups, eps, int(relu_first), _p(gamma), _p(mu),
-      _p(sc), _p(ws), ws.numel() * 4, _stream(),
-  )
+  with _region('group_norm_stats', 0.0, 8.0 * x.numel()):
+    st = lib.snap_group_norm_stats_f32(
+        _p(x), N, HW, C, C, groups, eps, int(relu_first), _p(gamma), _p(mu),
+        _p(sc), _p(ws), ws.numel() * 4, _stream(),
+    )
   _lib.check(st, 'snap_group_norm_stats_f32')
   return mu, sc
 
@@ -206,10 +283,13 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
       float(depth_min_max[0]), float(depth_min_max[1]),
       -1.0 if max_view_distance is None else float(max_view_distance),
   )
-  st = lib.snap_lift_pool_f32(
-      ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(pooled),
-      _p(valid), _stream(),
-  )
+  with _region(
+      'lift_pool', 0.0, 4.0 * (f_images.numel() + points.numel() + pooled.numel())
+  ):
+    st = lib.snap_lift_pool_f32(
+        ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(pooled),
+        _p(valid), _stream(),
+    )
   _lib.check(st, 'snap_lift_pool_f32')
   return pooled, valid
 
@@ -243,9 +323,10 @@ def vertical_pool(vol, valid, pooling='max'):
   M = int(np.prod(lead))
   plane = torch.empty((*lead, D), dtype=torch.float32, device=vol.device)
   pvalid = torch.empty(lead, dtype=torch.bool, device=vol.device)
-  st = lib.snap_vertical_pool_f32(
-      _p(vol), _p(valid), _p(plane), _p(pvalid), M, Z, D, POOLING[pooling], _stream()
-  )
+  with _region('vertical_pool', 0.0, 4.0 * (vol.numel() + plane.numel()) + valid.numel()):
+    st = lib.snap_vertical_pool_f32(
+        _p(vol), _p(valid), _p(plane), _p(pvalid), M, Z, D, POOLING[pooling], _stream()
+    )
   _lib.check(st, 'snap_vertical_pool_f32')
   return plane, pvalid
 
@@ -309,10 +390,14 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
       torch.empty((B, Nq, 2), dtype=torch.float32, device=dev)
       if (want_prob or want_rowstats) else None
   )
-  st = lib.snap_sim_softmax_f32(
-      _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(clip_negative),
-      _p(num_valid), _p(sim), _p(stats), _p(prob), _p(rowstats), _stream(),
-  )
+  with _region(
+      'sim_softmax', 2.0 * B * Nq * XY * Dm,
+      4.0 * (fq.numel() + fm.numel() + sim.numel() + stats.numel()),
+  ):
+    st = lib.snap_sim_softmax_f32(
+        _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(clip_negative),
+        _p(num_valid), _p(sim), _p(stats), _p(prob), _p(rowstats), _stream(),
+    )
   _lib.check(st, 'snap_sim_softmax_f32')
   return sim, stats, prob, rowstats
 
@@ -329,11 +414,12 @@ def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
     if tuple(uniforms.shape) != (B, S, 2):
       raise ValueError('ransac_sample: uniforms must be [B,S,2]')
   corr = torch.empty((B, S, 3), dtype=torch.int32, device=fq.device)
-  st = lib.snap_ransac_sample_f32(
-      _p(fq), _p(fm), _p(chunk_stats), B, Nq, X, Y, Dm, float(scale),
-      int(clip_negative), S, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(uniforms),
-      _p(corr), _stream(),
-  )
+  with _region('ransac_sample', 0.0, 12.0 * B * S):
+    st = lib.snap_ransac_sample_f32(
+        _p(fq), _p(fm), _p(chunk_stats), B, Nq, X, Y, Dm, float(scale),
+        int(clip_negative), S, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(uniforms),
+        _p(corr), _stream(),
+    )
   _lib.check(st, 'snap_ransac_sample_f32')
   return corr
 
@@ -364,11 +450,15 @@ def pose_score(sim, poses, q_xy, valid_q, map_valid, cell_size, mask_oob=False):
   wsb = lib.snap_pose_score_workspace_bytes(B, Nq, P, X, Y)
   ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=sim.device)
   scores = torch.empty((B, P), dtype=torch.float32, device=sim.device)
-  st = lib.snap_pose_score_f32(
-      _p(sim), _p(poses), _p(q_xy), _p(valid_q), _p(map_valid), B, Nq, X, Y, P,
-      float(cell_size), int(mask_oob), _p(scores), _p(ws), ws.numel() * 4,
-      _stream(),
-  )
+  # algorithmic bytes: every VALID query point's score plane read once + poses + scores.
+  with _region(
+      'pose_score', 0.0, 4.0 * (sim.numel() + poses.numel() + scores.numel())
+  ):
+    st = lib.snap_pose_score_f32(
+        _p(sim), _p(poses), _p(q_xy), _p(valid_q), _p(map_valid), B, Nq, X, Y, P,
+        float(cell_size), int(mask_oob), _p(scores), _p(ws), ws.numel() * 4,
+        _stream(),
+    )
   _lib.check(st, 'snap_pose_score_f32')
   return scores
 

@@ -1,0 +1,430 @@
+"""`-m gpu` parity tests: every HIP kernel (through the C ABI) vs the numpy oracle.
+
+Same seeded inputs on both sides; sizes the oracle finishes in seconds.
+Tolerances: bit-exact for masks / indices; fp32 round-off class (<= 1e-4 of the
+tensor's magnitude, stated per test) for floating point -- the north-star bound is
+1e-3 on feature maps.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import oracle_ops
+from snap_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+# SNAP_TEST_DRYRUN=1 (see conftest.py) runs these tests on the CPU against the
+# oracle itself: a self-consistency check of the TEST code, not a parity result.
+DEV = 'cpu' if os.environ.get('SNAP_TEST_DRYRUN') else 'cuda'
+
+
+def rnd(shape, seed, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return (torch.randn(shape, generator=g) * scale)
+
+
+def both(fn_name, args_cpu, kwargs=None, to_gpu=None):
+  """Run ops.<fn> on the GPU and oracle_ops.<fn> on the CPU with the same inputs."""
+  kwargs = kwargs or {}
+  def mv(x):
+    if isinstance(x, torch.Tensor):
+      return x.to(DEV).contiguous()
+    if isinstance(x, (list, tuple)):
+      return type(x)(mv(i) for i in x)
+    return x
+  got = getattr(ops, fn_name)(*mv(args_cpu), **{k: mv(v) for k, v in kwargs.items()})
+  want = getattr(oracle_ops, fn_name)(*args_cpu, **kwargs)
+  if DEV == 'cuda':
+    torch.cuda.synchronize()
+  return got, want
+
+
+# ----------------------------------------------------------------------------
+# conv engine
+# ----------------------------------------------------------------------------
+CONV_CASES = [
+    # name, N,H,W,Cin, KH,KW,Cout, stride, pad
+    ('1x1_64_256', 2, 9, 11, 64, 1, 1, 256, 1, 0),
+    ('1x1_s2_proj', 2, 10, 12, 128, 1, 1, 64, 2, 0),
+    ('3x3_s1', 1, 13, 9, 32, 3, 3, 64, 1, 1),
+    ('3x3_s2', 2, 14, 10, 64, 3, 3, 128, 2, 1),
+    ('7x7_root_scalar', 1, 24, 20, 3, 7, 7, 32, 2, 3),
+    ('3x3_root_scalar', 1, 12, 12, 3, 3, 3, 64, 1, 1),
+    ('1x1_cout160', 1, 8, 8, 128, 1, 1, 160, 1, 0),
+    ('1x1_cin20_ktail', 1, 6, 7, 20, 1, 1, 36, 1, 0),
+    ('big_template', 1, 20, 20, 8, 7, 7, 12, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_plain(case):
+  _, N, H, W, Cin, KH, KW, Cout, stride, pad = case
+  x = rnd((N, H, W, Cin), 1)
+  w = rnd((KH, KW, Cin, Cout), 2, 1.0 / np.sqrt(KH * KW * Cin))
+  kw = dict(stride=stride, padding=((pad, pad), (pad, pad)))
+  got, want = both('conv2d', (x, w), kw)
+  helpers.report('conv ' + case[0], got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_conv_affine_root():
+  x = torch.rand((2, 20, 18, 3), generator=torch.Generator().manual_seed(3))
+  w = rnd((7, 7, 3, 64), 4, 0.1)
+  kw = dict(stride=2, padding=((3, 3), (3, 3)), prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0))
+  got, want = both('conv2d', (x, w), kw)
+  helpers.report('conv affine', got, want, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('mode', [ops.PRO_GN_RELU, ops.PRO_RELU_GN])
+@pytest.mark.parametrize('C', [64, 128, 256])
+def test_gn_stats_and_fused_conv(mode, C):
+  N, H, W = 3, 7, 9
+  x = rnd((N, H, W, C), 5) * 2 + 0.7
+  gamma = rnd((C,), 6) * 0.5 + 1
+  beta = rnd((C,), 7) * 0.2
+  relu_first = mode == ops.PRO_RELU_GN
+  (mu_g, sc_g), (mu_w, sc_w) = both('group_norm_stats', (x, gamma), dict(relu_first=relu_first))
+  helpers.report('gn mu', mu_g, mu_w, atol=1e-5, rtol=1e-5)
+  helpers.report('gn sc', sc_g, sc_w, atol=1e-5, rtol=2e-5)
+  y_g, y_w = both('group_norm_apply', (x, mu_w, sc_w, beta, mode))
+  helpers.report('gn apply', y_g, y_w, atol=1e-5, rtol=1e-5)
+  w = rnd((3, 3, C, 64), 8, 1 / np.sqrt(9 * C))
+  kw = dict(padding=((1, 1), (1, 1)), prologue=mode, gn=(mu_w, sc_w, beta))
+  got, want = both('conv2d', (x, w), kw)
+  helpers.report('conv gn-fused', got, want, atol=3e-5, rtol=1e-5)
+
+
+def test_gn_stats_wide_and_narrow():
+  for C, HW in [(32, (5, 5)), (512, (4, 6)), (1024, (3, 3)), (2048, (2, 3))]:
+    x = rnd((2, *HW, C), 9) + 0.3
+    gamma = torch.ones(C)
+    (mu_g, sc_g), (mu_w, sc_w) = both('group_norm_stats', (x, gamma))
+    helpers.report(f'gn mu C={C}', mu_g, mu_w, atol=1e-5, rtol=1e-5)
+    helpers.report(f'gn sc C={C}', sc_g, sc_w, atol=1e-5, rtol=2e-5)
+
+
+def test_gn_stats_many_slabs():
+  x = rnd((2, 40, 37, 64), 10) + 1.0  # 1480 pixels -> 3 slabs
+  gamma = rnd((64,), 11) + 1
+  (mu_g, sc_g), (mu_w, sc_w) = both('group_norm_stats', (x, gamma))
+  helpers.report('gn mu slabs', mu_g, mu_w, atol=1e-5, rtol=1e-5)
+  helpers.report('gn sc slabs', sc_g, sc_w, atol=1e-5, rtol=2e-5)
+
+
+def test_conv_epilogues():
+  N, H, W, Cin, Cout = 2, 8, 6, 64, 128
+  x = rnd((N, H, W, Cin), 12)
+  w = rnd((1, 1, Cin, Cout), 13, 1 / np.sqrt(Cin))
+  bias = rnd((Cout,), 14)
+  res = rnd((N, H, W, Cout), 15)
+  prev = rnd((N, H // 2, W // 2, Cout), 16)
+  mask = torch.rand((N, H, W), generator=torch.Generator().manual_seed(17)) > 0.4
+  got, want = both('conv2d', (x, w), dict(bias=bias, relu=True))
+  helpers.report('bias+relu', got, want, atol=2e-5, rtol=1e-5)
+  got, want = both('conv2d', (x, w), dict(residual=res))
+  helpers.report('residual', got, want, atol=2e-5, rtol=1e-5)
+  got, want = both('conv2d', (x, w), dict(up_prev=prev))
+  helpers.report('upsample-add', got, want, atol=2e-5, rtol=1e-5)
+  got, want = both('conv2d', (x, w), dict(bias=bias, row_mask=mask))
+  helpers.report('rowmask', got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_dense_padded_k257():
+  """Fusion-MLP shape: K = 257 inside a 260-float row stride."""
+  M, K, Ks, Co = 300, 257, 260, 256
+  x = torch.zeros(M, Ks)
+  x[:, :K] = rnd((M, K), 18)
+  x[:, K:] = 123.0  # garbage in the pad must be ignored
+  w = rnd((K, Co), 19, 1 / np.sqrt(K))
+  b = rnd((Co,), 20)
+  got, want = both('dense', (x, w, b), dict(cin=K, relu=True))
+  helpers.report('dense k257', got, want, atol=2e-5, rtol=1e-5)
+  got, want = both('dense', (x[:, :128].contiguous(), w[:128], b), dict(prologue=ops.PRO_RELU))
+  helpers.report('dense relu-in', got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_weight_standardize_and_maxpool():
+  for shape in [(7, 7, 3, 64), (3, 3, 64, 64), (1, 1, 256, 128), (1, 1, 64, 40)]:
+    w = rnd(shape, 21) * 0.3 + 0.05
+    got, want = both('weight_standardize', (w,))
+    helpers.report(f'wstd {shape}', got, want, atol=2e-5, rtol=1e-5)
+  for shape in [(2, 9, 11, 64), (1, 16, 16, 32)]:
+    x = rnd(shape, 22)
+    got, want = both('max_pool_3x3s2', (x,))
+    helpers.report(f'maxpool {shape}', got, want, atol=0, rtol=0)
+
+
+# ----------------------------------------------------------------------------
+# lift
+# ----------------------------------------------------------------------------
+def _lift_scene(B, V, h, w, fd, nb, N, seed, k_radial=0.02):
+  from snap_amd.data import synthetic
+  from snap_amd.utils import grids
+  g = grids.Grid3D((16, 16, 8), 0.4)
+  batch = synthetic.make_batch(B, g, V, (h * 4, w * 4), seed=seed, with_aerial=False,
+                               with_gt=False, k_radial=k_radial)
+  scene = batch['map']
+  cam = scene['camera'].scale(torch.tensor([0.25, 0.25]))
+  rng = np.random.default_rng(seed)
+  pts = np.stack([rng.uniform(-1, 7.4, (B, N)), rng.uniform(-1, 7.4, (B, N)),
+                  rng.uniform(-1.5, 4.0, (B, N))], -1).astype(np.float32)
+  f = rnd((B, V, h, w, fd + nb), seed + 1)
+  return f, cam.packed(), scene['T_view2scene'].packed(), torch.tensor(pts)
+
+
+@pytest.mark.parametrize('K,V', [(0, 1), (0, 3), (2, 3), (4, 6), (4, 20), (8, 9)])
+def test_lift_pool(K, V):
+  fd, nb = 32, 8
+  f, cam, Rt, pts = _lift_scene(2, V, 12, 16, fd, nb, 4000, seed=30 + V)
+  kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0))
+  (pg, vg), (pw, vw) = both('lift_pool', (f, cam, Rt, pts), kw)
+  assert vw.float().mean() > 0.05, 'test scene has (almost) no visible voxels'
+  # visibility can flip for points within round-off of an image border.
+  mism = (vg.cpu() != vw)
+  assert mism.float().mean() < 2e-3, f'valid mismatch fraction {mism.float().mean()}'
+  keep = ~mism
+  helpers.report('lift pooled', pg.cpu()[keep], pw[keep], atol=2e-4, rtol=1e-4)
+
+
+def test_lift_pool_full_width_and_maxdist():
+  fd, nb = 128, 32
+  f, cam, Rt, pts = _lift_scene(1, 5, 10, 10, fd, nb, 3000, seed=41)
+  kw = dict(K=4, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 32.0),
+            max_view_distance=6.0)
+  (pg, vg), (pw, vw) = both('lift_pool', (f, cam, Rt, pts), kw)
+  mism = (vg.cpu() != vw)
+  assert mism.float().mean() < 2e-3
+  helpers.report('lift pooled fd128', pg.cpu()[~mism], pw[~mism], atol=2e-4, rtol=1e-4)
+
+
+def test_project_points():
+  f, cam, Rt, pts = _lift_scene(2, 4, 12, 16, 8, 4, 5000, seed=50, k_radial=0.05)
+  (p2g, vig, dg), (p2w, viw, dw) = both('project_points', (cam, Rt, pts, True))
+  mism = vig.cpu() != viw
+  assert mism.float().mean() < 1e-3
+  helpers.report('depth', dg, dw, atol=1e-5, rtol=1e-5)
+  vis = viw & ~mism
+  helpers.report('p2d (visible)', p2g.cpu()[vis], p2w[vis], atol=2e-4, rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------
+# BEV
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize('pooling', ['max', 'sum', 'mean'])
+def test_vertical_pool(pooling):
+  vol = rnd((2, 9, 7, 12, 128), 60)
+  valid = torch.rand((2, 9, 7, 12), generator=torch.Generator().manual_seed(61)) > 0.6
+  valid[0, 0] = False  # fully invalid columns
+  (pg, vg), (pw, vw) = both('vertical_pool', (vol, valid, pooling))
+  helpers.report('vpool valid', vg, vw, 0)
+  helpers.report('vpool plane', pg, pw, atol=1e-5, rtol=1e-6)
+
+
+@pytest.mark.parametrize('nplanes', [1, 2])
+def test_plane_fuse_match(nplanes):
+  D, Dm = 128, 32
+  planes = [rnd((2, 11, 13, D), 70 + i) for i in range(nplanes)]
+  valids = [torch.rand((2, 11, 13), generator=torch.Generator().manual_seed(80 + i)) > 0.3
+            for i in range(nplanes)]
+  if nplanes == 2:
+    valids[1] = None
+  planes[0] = planes[0] * valids[0][..., None]
+  Wm = rnd((D, Dm), 75, 0.1)
+  bm = rnd((Dm,), 76, 0.01)
+  (fg, vg, mg), (fw, vw, mw) = both('plane_fuse_match', (planes, valids, 'max', Wm, bm))
+  helpers.report('fuse valid', vg, vw, 0)
+  helpers.report('fused', fg, fw, atol=1e-6)
+  helpers.report('matching', mg, mw, atol=2e-6, rtol=1e-5)
+
+
+def test_matching_zero_norm():
+  D, Dm = 32, 8
+  plane = torch.zeros(1, 4, 4, D)
+  valid = torch.ones(1, 4, 4, dtype=torch.bool)
+  Wm = rnd((D, Dm), 77)
+  bm = torch.zeros(Dm)
+  (_, _, mg), (_, _, mw) = both('plane_fuse_match', ([plane], [valid], 'max', Wm, bm))
+  helpers.report('zero-norm matching', mg, mw, atol=0)
+
+
+# ----------------------------------------------------------------------------
+# pose
+# ----------------------------------------------------------------------------
+def _unit(x):
+  return x / x.norm(dim=-1, keepdim=True)
+
+
+@pytest.mark.parametrize('X,Y,Dm', [(16, 16, 32), (13, 21, 8), (40, 24, 16)])
+def test_sim_softmax(X, Y, Dm):
+  B, Nq = 2, 70
+  fq = _unit(rnd((B, Nq, Dm), 90))
+  fm = _unit(rnd((B, X, Y, Dm), 91))
+  fq[0, 3] = 0  # an invalid (masked) query point
+  nv = torch.tensor([69.0, 70.0])
+  scale = float(np.exp(2.0))
+  got, want = both('sim_softmax', (fq, fm, scale, True, nv), dict(want_prob=True))
+  helpers.report('sim', got[0], want[0], atol=1e-6, rtol=1e-5)
+  helpers.report('chunk max', got[1][..., 0], want[1][..., 0], atol=1e-5, rtol=1e-5)
+  helpers.report('chunk sum', got[1][..., 1], want[1][..., 1], atol=1e-4, rtol=1e-5)
+  helpers.report('prob', got[2], want[2], atol=1e-9, rtol=1e-4)
+  helpers.report('rowstats', got[3], want[3], atol=1e-4, rtol=1e-5)
+
+
+def test_ransac_sample_given_uniforms():
+  B, Nq, X, Y, Dm, S = 2, 40, 24, 20, 16, 600
+  fq = _unit(rnd((B, Nq, Dm), 95))
+  fm = _unit(rnd((B, X, Y, Dm), 96))
+  nv = torch.tensor([40.0, 40.0])
+  scale = float(np.exp(2.5))
+  u = torch.rand((B, S, 2), generator=torch.Generator().manual_seed(97))
+  _, stats, _, _ = ops.sim_softmax(fq.to(DEV), fm.to(DEV), scale, True, nv.to(DEV))
+  got = ops.ransac_sample(fq.to(DEV), fm.to(DEV), stats, scale, True, S, uniforms=u.to(DEV)).cpu()
+  want = oracle_ops.ransac_sample(fq, fm, None, scale, True, S, uniforms=u)
+  assert (got[..., 0] == want[..., 0]).all(), 'query row selection differs'
+  # the cell may differ by CDF round-off: accept if the float64 CDF at the
+  # returned cell brackets the target within 1e-5 of the row mass.
+  bad = 0
+  q64, m64 = fq.double().numpy(), fm.double().numpy()
+  for b in range(B):
+    for s in range(S):
+      if (got[b, s] == want[b, s]).all():
+        continue
+      n = int(got[b, s, 0])
+      x = np.maximum(np.einsum('d,ijd->ij', q64[b, n], m64[b]), 0).reshape(-1) * scale
+      e = np.exp(x - x.max())
+      cdf = np.cumsum(e) / e.sum()
+      cell = int(got[b, s, 1]) * Y + int(got[b, s, 2])
+      lo = cdf[cell - 1] if cell > 0 else 0.0
+      t = float(u[b, s, 1])
+      if not (lo - 1e-5 <= t <= cdf[cell] + 1e-5):
+        bad += 1
+  assert bad == 0, f'{bad} samples outside their CDF bracket'
+
+
+def test_ransac_sample_distribution():
+  """Philox path: empirical cell histogram matches prob (chi-square-like bound)."""
+  B, Nq, X, Y, Dm, S = 1, 6, 8, 8, 8, 60000
+  fq = _unit(rnd((B, Nq, Dm), 98))
+  fm = _unit(rnd((B, X, Y, Dm), 99))
+  nv = torch.tensor([6.0])
+  scale = float(np.exp(2.0))
+  _, stats, prob, _ = ops.sim_softmax(fq.to(DEV), fm.to(DEV), scale, True, nv.to(DEV), want_prob=True)
+  corr = ops.ransac_sample(fq.to(DEV), fm.to(DEV), stats, scale, True, S, seed=1234).cpu().numpy()[0]
+  hist = np.zeros((Nq, X, Y))
+  np.add.at(hist, (corr[:, 0], corr[:, 1], corr[:, 2]), 1)
+  p = prob.cpu().numpy()[0].astype(np.float64)
+  p = p / p.sum()
+  exp = p * S
+  z = (hist - exp) / np.sqrt(exp + 1e-9)
+  assert np.abs(z).max() < 6.0, f'max z-score {np.abs(z).max()}'
+  corr2 = ops.ransac_sample(fq.to(DEV), fm.to(DEV), stats, scale, True, S, seed=1234).cpu().numpy()[0]
+  assert (corr == corr2).all(), 'sampling is not deterministic for a fixed seed'
+
+
+def test_poses_from_corr():
+  B, Nq, P, retries, X, Y = 2, 50, 200, 4, 30, 28
+  rng = np.random.default_rng(100)
+  corr = np.stack([rng.integers(0, Nq, (B, P * retries * 2)),
+                   rng.integers(0, X, (B, P * retries * 2)),
+                   rng.integers(0, Y, (B, P * retries * 2))], -1).astype(np.int32)
+  corr[0, 0] = corr[0, 1]  # degenerate pair (identical correspondences)
+  q_xy = torch.tensor(rng.uniform(-5, 5, (B, Nq, 2)).astype(np.float32))
+  got, want = both('poses_from_corr', (torch.tensor(corr), q_xy, P, retries, 0.2))
+  g, w = got.cpu().numpy(), want.numpy()
+  # degenerate / antipodal cases aside, angle and translation agree.
+  dang = np.abs(np.angle(np.exp(1j * (g[..., 0] - w[..., 0]))))
+  ok = dang < 1e-3
+  assert ok.mean() > 0.98, f'only {ok.mean():.3f} of poses agree'
+  helpers.report('pose t', got.cpu()[..., 1:][torch.tensor(ok)], want[..., 1:][torch.tensor(ok)],
+                 atol=2e-3)
+
+
+@pytest.mark.parametrize('mask_oob', [False, True])
+@pytest.mark.parametrize('X,Y', [(32, 32), (25, 37), (192, 160)])
+def test_pose_score(mask_oob, X, Y):
+  B, Nq, P = 2, 45, 700
+  rng = np.random.default_rng(110)
+  sim = torch.tensor(rng.random((B, Nq, X, Y), dtype=np.float32))
+  cell = 0.2
+  poses = np.stack([rng.uniform(-np.pi, np.pi, (B, P)),
+                    rng.uniform(-0.2 * X * cell, 1.2 * X * cell, (B, P)),
+                    rng.uniform(-0.2 * Y * cell, 1.2 * Y * cell, (B, P))], -1).astype(np.float32)
+  q_xy = torch.tensor(rng.uniform(-2, 2, (B, Nq, 2)).astype(np.float32))
+  valid_q = torch.tensor(rng.random((B, Nq)) > 0.2)
+  map_valid = torch.tensor(rng.random((B, X, Y)) > 0.1)
+  got, want = both('pose_score', (sim, torch.tensor(poses), q_xy, valid_q, map_valid, cell),
+                   dict(mask_oob=mask_oob))
+  helpers.report('pose scores', got, want, atol=2e-4, rtol=1e-5)
+  ig, iw = both('argmax_rows', (want.clone(), 1))
+  helpers.report('argmax', ig, iw, 0)
+
+
+def test_refine_lattice_and_argmax_ties():
+  from snap_amd.models import pose_estimation
+  init = torch.tensor([[0.3, 4.0, 5.0], [-2.0, 1.0, 2.5]])
+  offs_r, offs_p = pose_estimation.refinement_offsets('cpu')
+  assert offs_r.numel() == 41 and offs_p.numel() == 41
+  got, want = both('refine_lattice', (init, offs_r, offs_p))
+  helpers.report('lattice', got, want, atol=2e-6)
+  s = torch.zeros(3, 1000)
+  s[0, 500] = 1; s[0, 700] = 1      # tie -> first index
+  s[1, 999] = 2
+  s[2, :] = -1.0
+  ig, iw = both('argmax_rows', (s, 0))
+  helpers.report('argmax ties', ig, iw, 0)
+  ig, iw = both('argmax_rows', (s, 600))
+  helpers.report('argmax start', ig, iw, 0)
+
+
+# ----------------------------------------------------------------------------
+# exhaustive voting
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize('H,R,D', [(16, 8, 8), (24, 36, 32)])
+def test_rotate_templates_and_matching(H, R, D):
+  from oracle import grids as o_grids
+  from oracle import voting as o_voting
+  from snap_amd.models import pose_exhaustive_voting as pev
+  from snap_amd.models import types
+  from snap_amd.utils import grids
+  cell = 0.25
+  rng = np.random.default_rng(120)
+  fq = rng.standard_normal((H, H, D)).astype(np.float32)
+  vq = rng.random((H, H)) > 0.15
+  fq = fq * vq[..., None]
+  fm = rng.standard_normal((H, H, D)).astype(np.float32)
+  vm = rng.random((H, H)) > 0.1
+  g = grids.Grid2D((H, H), cell)
+  og = o_grids.Grid2D((H, H), cell)
+  t_w, tv_w = o_voting.sample_query_templates(fq, vq, R, og)
+  t_g, tv_g = pev.sample_query_templates(torch.tensor(fq).to(DEV), torch.tensor(vq).to(DEV), R, g)
+  mism = tv_g.cpu().numpy() != tv_w
+  assert mism.mean() < 2e-3, f'template validity mismatch {mism.mean()}'
+  helpers.report('templates', t_g.cpu().numpy()[~mism], t_w[~mism], atol=2e-5)
+  s_w = o_voting.template_matching(t_w, tv_w, fm, vm)
+  s_g = pev.template_matching(torch.tensor(t_w).to(DEV), torch.tensor(tv_w).to(DEV),
+                              torch.tensor(fm).to(DEV), torch.tensor(vm).to(DEV))
+  helpers.report('template scores', s_g, s_w, atol=1e-4, rtol=1e-5)
+  full = pev.exhaustive_pose_voting(
+      types.FeaturePlane(torch.tensor(fq).to(DEV), torch.tensor(vq).to(DEV)),
+      types.FeaturePlane(torch.tensor(fm).to(DEV), torch.tensor(vm).to(DEV)), R, g)
+  if mism.sum() == 0:
+    helpers.report('exhaustive voting', full, s_w, atol=1e-4, rtol=1e-5)
+  assert full.shape == (R, 2 * H - 1, 2 * H - 1)
+
+
+def test_exhaustive_identity_kat():
+  """Known answer: matching a map with itself peaks at (0, H-1, W-1)."""
+  from snap_amd.models import pose_exhaustive_voting as pev
+  from snap_amd.models import types
+  from snap_amd.utils import grids
+  H, D, R = 32, 16, 12
+  rng = np.random.default_rng(130)
+  f = torch.tensor(rng.standard_normal((H, H, D)).astype(np.float32)).to(DEV)
+  v = torch.ones(H, H, dtype=torch.bool, device=DEV)
+  plane = types.FeaturePlane(f, v)
+  s = pev.exhaustive_pose_voting(plane, plane, R, grids.Grid2D((H, H), 0.5))
+  idx = np.unravel_index(int(torch.argmax(s)), s.shape)
+  assert tuple(int(i) for i in idx) == (0, H - 1, H - 1)

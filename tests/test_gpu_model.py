@@ -1,0 +1,93 @@
+"""`-m gpu` end-to-end parity: BEVLocalizer forward on HIP vs the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import geometry as o_geo
+from oracle import grids as o_grids
+from oracle import model as o_model
+from snap_amd.data import synthetic
+from snap_amd.models import bev_localizer
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg, B, V, img, seed, refine=False):
+  dev = torch.device('cuda')
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
+  variables = loc.init(seed, device='cpu')
+  batch = synthetic.make_batch(B, meta['grid'], V, img, seed=seed + 1)
+  pred = loc.apply(
+      {'params': helpers.params_to_device(variables['params'], dev)},
+      helpers.batch_to_device(batch, dev), train=False, rngs={'sampling': 11}, debug=True,
+  )
+  torch.cuda.synchronize()
+  samples = pred['map_t_query_samples']
+  ps = o_geo.Transform2D(samples.angle[:, 1:].cpu().numpy(), samples.t[:, 1:].cpu().numpy())
+  ref = o_model.bev_localizer(
+      helpers.params_to_numpy(variables['params']), cfg, {'streetview_hfov_deg': 72.0},
+      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch),
+      pose_samples=ps, keep_sim=True,
+  )
+  return pred, ref
+
+
+@pytest.mark.parametrize('top_k,V', [(2, 3), (4, 3)])
+def test_localizer_forward_parity(top_k, V):
+  cfg = helpers.tiny_localizer_config(top_k=top_k)
+  pred, ref = _run(cfg, 2, V, (64, 64), seed=0)
+  sv, rsv = pred['map']['streetview'], ref['map']['streetview']
+  # feature maps: north-star tolerance 1e-3 (fp32); observed ~1e-5.
+  helpers.report('image features', sv['image_feature_pyramid'].features[-1],
+                 rsv['image_feature_pyramid']['features'][-1], atol=1e-3)
+  vg = sv['feature_volume'].valid.cpu().numpy()
+  vw = rsv['feature_volume']['valid']
+  mism = vg != vw
+  assert mism.mean() < 2e-3
+  helpers.report('feature volume', sv['feature_volume'].features.cpu().numpy()[~mism],
+                 rsv['feature_volume']['features'][~mism], atol=1e-3)
+  helpers.report('aerial plane', pred['map']['aerial']['feature_plane'].features,
+                 ref['map']['aerial']['feature_plane']['features'], atol=1e-3)
+  helpers.report('map bev_matching', pred['map']['bev_matching'].features,
+                 ref['map']['bev_matching']['features'], atol=1e-3)
+  helpers.report('query bev_matching', pred['query']['bev_matching'].features,
+                 ref['query']['bev_matching']['features'], atol=1e-3)
+  helpers.report('sim_points', pred['sim_points'], ref['_sim_points'], atol=1e-5, rtol=1e-3)
+  helpers.report('scores_poses', pred['scores_poses'], ref['scores_poses'], atol=1e-3, rtol=1e-3)
+  # pose argmax: bit-exact against the oracle.
+  helpers.report('best_index', pred['best_index'], ref['best_index'].astype(np.int32), 0)
+  helpers.report('map_t_query', pred['map_t_query'].packed(),
+                 np.concatenate([ref['map_t_query'].angle[:, None], ref['map_t_query'].t], -1),
+                 atol=1e-6)
+
+
+def test_localizer_grid_refinement_parity():
+  cfg = helpers.tiny_localizer_config(refine=True, num_pose_samples=32)
+  pred, ref = _run(cfg, 1, 3, (64, 64), seed=3)
+  assert pred['scores_grid_refine'].shape == (1, 41, 41, 41)
+  helpers.report('scores_grid_refine', pred['scores_grid_refine'], ref['scores_grid_refine'],
+                 atol=1e-3, rtol=1e-3)
+  got = int(torch.argmax(pred['scores_grid_refine'].reshape(-1)))
+  want = int(np.argmax(ref['scores_grid_refine'].reshape(-1)))
+  assert got == want
+  helpers.report('refined pose', pred['map_t_query'].packed(),
+                 np.concatenate([ref['map_t_query'].angle[:, None], ref['map_t_query'].t], -1),
+                 atol=1e-5)
+
+
+def test_output_pytree_keys():
+  """Key-for-key pytree of bev_localizer.py:130-220 / bev_mapper.py:254-296."""
+  cfg = helpers.tiny_localizer_config(refine=True, num_pose_samples=16)
+  pred, _ = _run(cfg, 1, 3, (64, 64), seed=5)
+  base = {'map', 'query', 'map_t_query_samples', 'scores_poses', 'best_index', 'map_t_query',
+          'map_t_query_ransac', 'scores_grid_refine'}
+  assert base <= set(pred)
+  assert set(pred['map']) == {'streetview', 'aerial', 'bev_features', 'bev_matching'}
+  assert set(pred['query']) == {'streetview', 'bev_features', 'bev_matching'}
+  assert set(pred['map']['streetview']) == {
+      'image_feature_pyramid', 'scores_images', 'feature_volume', 'vertical_pooling',
+      'feature_plane'}
+  assert pred['scores_poses'].shape == (1, 17)
+  assert pred['map_t_query_samples'].shape == (1, 17)
