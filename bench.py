@@ -299,6 +299,10 @@ def main(argv=None):
             'bytes_per_launch': s['bytes'] / s['launches'],
         }
       out['kernels'] = kern
+      dump = os.environ.get('SNAP_BENCH_DUMP')
+      if dump:
+        with open(dump, 'w') as f:
+          json.dump({n: prof.launches(n) for n in summ}, f)
     if world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']:
       try:
         out['cpu_baseline'] = cpu_baseline(cfg, meta, args.workload)

@@ -40,7 +40,7 @@ def build_xyz_query(config, grid, scene_t_view, xy_bev=None, z_offset=None):
   B = t.shape[0]
   xy = xy_bev
   if xy is None:
-    xy = grid.index_to_xyz(grid.grid_index()).astype(dtype)
+    xy = grid.index_to_xyz(grid.grid_index(), dtype)
   if xy.ndim != 4:
     xy = np.repeat(xy[None], B, axis=0)
   if z_offset is None:

@@ -29,8 +29,12 @@ class GridND:
     # snap/utils/grids.py:59-60
     return np.floor(xyz / self.cell_size).astype(int)
 
-  def index_to_xyz(self, idx):
-    # snap/utils/grids.py:62-63 -- half-cell centres.
+  def index_to_xyz(self, idx, dtype=None):
+    # snap/utils/grids.py:62-63 -- half-cell centres.  With `dtype` the arithmetic
+    # itself runs in that precision (JAX evaluates it in fp32 by default).
+    if dtype is not None:
+      dtype = np.dtype(dtype).type
+      return (np.asarray(idx).astype(dtype) + dtype(0.5)) * dtype(self.cell_size)
     return (idx + 0.5) * self.cell_size
 
   @property

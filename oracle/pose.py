@@ -18,7 +18,7 @@ def build_query_frustum_grid(
   width = 3 * depth // 2
   grid = grids.Grid2D.from_extent_meters((width, depth), cell_size)
   grid_p_view = np.array([width / 2, 0.0], dtype)
-  qgrid_xy_p = grid.index_to_xyz(grid.grid_index()).astype(dtype)
+  qgrid_xy_p = grid.index_to_xyz(grid.grid_index(), dtype)
   q_xy_p = qgrid_xy_p - grid_p_view
   if filter_points_in_fov:
     angle = np.arctan2(q_xy_p[..., 0], q_xy_p[..., 1])
@@ -163,7 +163,7 @@ def poses_from_correspondences(indices, i_xy_p, num_poses, num_retries, grid):
   dtype = i_xy_p.dtype
   pool_shape = (num_poses, num_retries, 2, 2)
   i_xy_pool = i_xy_p[indices[..., 0]].reshape(pool_shape)
-  j_xy_pool = grid.index_to_xyz(indices[..., 1:]).astype(dtype).reshape(pool_shape)
+  j_xy_pool = grid.index_to_xyz(indices[..., 1:], dtype).reshape(pool_shape)
   if num_retries > 1:
     d_i = np.linalg.norm(np.diff(i_xy_pool, axis=-2).squeeze(-2), axis=-1)
     d_j = np.linalg.norm(np.diff(j_xy_pool, axis=-2).squeeze(-2), axis=-1)

@@ -32,7 +32,7 @@ def sample_query_templates(features, valid, num_rotations, grid):
   """pose_exhaustive_voting.py:37-69.  features [H,W,D], valid [H,W]."""
   dtype = features.dtype
   templates_t_grid = template_transforms(num_rotations, grid, dtype)
-  grid_xy = grid.index_to_xyz(grid.grid_index()).reshape(-1, 2).astype(dtype)
+  grid_xy = grid.index_to_xyz(grid.grid_index(), dtype).reshape(-1, 2)
   nq = num_rotations // 4
   quarter = []
   t_valid = []

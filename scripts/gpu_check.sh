@@ -28,11 +28,11 @@ for s in $STAGES; do
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
       echo "== smoke =="; tail -5 gpurun_out/smoke.log ;;
     bench)
-      timeout 1200 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1
+      SNAP_BENCH_DUMP=gpurun_out/launches.json timeout 1200 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1
       echo "== bench =="; tail -5 gpurun_out/bench.log ;;
     prof)
       rm -rf gpurun_out/prof
-      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o snap -- \
+      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o snap -- \
         python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline) > gpurun_out/prof.log 2>&1
       echo "== prof =="; tail -3 gpurun_out/prof.log
       f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)

@@ -34,14 +34,21 @@ class KernelProfiler:
   def __init__(self):
     self.records = {}
 
-  def region(self, name, flops=0.0, nbytes=0.0):
-    return _Region(self, name, flops, nbytes)
+  def region(self, name, flops=0.0, nbytes=0.0, tag=None):
+    return _Region(self, name, flops, nbytes, tag)
+
+  def launches(self, name):
+    """Per-launch (tag, ms, flops, bytes) of one kernel family (after a sync)."""
+    torch.cuda.synchronize()
+    return [
+        (r[4], r[0].elapsed_time(r[1]), r[2], r[3]) for r in self.records.get(name, [])
+    ]
 
   def summary(self):
     torch.cuda.synchronize()
     out = {}
     for name, recs in self.records.items():
-      ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+      ms = sum(r[0].elapsed_time(r[1]) for r in recs)
       out[name] = dict(
           launches=len(recs), ms=ms, flops=sum(r[2] for r in recs),
           bytes=sum(r[3] for r in recs),
@@ -51,8 +58,8 @@ class KernelProfiler:
 
 class _Region:
 
-  def __init__(self, prof, name, flops, nbytes):
-    self.prof, self.name, self.flops, self.nbytes = prof, name, flops, nbytes
+  def __init__(self, prof, name, flops, nbytes, tag=None):
+    self.prof, self.name, self.flops, self.nbytes, self.tag = prof, name, flops, nbytes, tag
 
   def __enter__(self):
     self.start = torch.cuda.Event(enable_timing=True)
@@ -62,7 +69,7 @@ class _Region:
     end = torch.cuda.Event(enable_timing=True)
     end.record()
     self.prof.records.setdefault(self.name, []).append(
-        (self.start, end, self.flops, self.nbytes)
+        (self.start, end, self.flops, self.nbytes, self.tag)
     )
 
 
@@ -86,10 +93,10 @@ def set_profiler(prof):
   return old
 
 
-def _region(name, flops=0.0, nbytes=0.0):
+def _region(name, flops=0.0, nbytes=0.0, tag=None):
   if _PROFILER is None:
     return _NO_REGION
-  return _PROFILER.region(name, flops, nbytes)
+  return _PROFILER.region(name, flops, nbytes, tag() if callable(tag) else tag)
 
 
 def _p(t):
@@ -181,6 +188,7 @@ def conv2d(
   with _region(
       'conv_igemm', 2.0 * M * KH * KW * Cin * Cout,
       4.0 * (x.numel() + w.numel() + y.numel()),
+      lambda: f'M{M}_K{KH}x{KW}x{Cin}_N{Cout}_s{stride}_p{prologue}_e{epi}',
   ):
     st = lib.snap_conv2d_nhwc_f32(
         ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),

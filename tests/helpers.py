@@ -120,3 +120,27 @@ def report(name, got, want, atol, rtol=0.0):
         f'max err {err[i]:.3e} at {tuple(int(k) for k in i)}: got {g[i]:.6e} want {w[i]:.6e}; '
         f'ref |max| {np.nanmax(np.abs(np.where(np.isfinite(w), w, 0))):.3e}'
     )
+
+
+def assert_same_argmax(name, got_scores, want_scores, got_index=None, rel=2e-6):
+  """Row-wise argmax parity.
+
+  The kernel's argmax must equal the oracle's.  The only tolerated deviation is an
+  fp32 near-tie: the oracle's score AT the kernel's index must then be within
+  `rel` (a few fp32 ulps of the summed magnitude) of the oracle's maximum -- two
+  different summation orders cannot order such values consistently.
+  """
+  g = got_scores.detach().cpu().numpy() if isinstance(got_scores, torch.Tensor) else np.asarray(got_scores)
+  w = np.asarray(want_scores.detach().cpu().numpy() if isinstance(want_scores, torch.Tensor) else want_scores)
+  gi = np.argmax(g, -1)
+  if got_index is not None:
+    k = got_index.detach().cpu().numpy() if isinstance(got_index, torch.Tensor) else np.asarray(got_index)
+    assert (k == gi).all(), f'{name}: reported index {k} != argmax of reported scores {gi}'
+  wi = np.argmax(w, -1)
+  rows = np.arange(w.shape[0])
+  exact = gi == wi
+  gap = (w[rows, wi] - w[rows, gi]) / np.maximum(np.abs(w[rows, wi]), 1e-30)
+  assert (exact | (gap <= rel)).all(), (
+      f'{name}: argmax {gi} vs oracle {wi}; oracle score gap {gap} exceeds near-tie bound {rel}'
+  )
+  return exact

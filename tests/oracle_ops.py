@@ -308,7 +308,7 @@ def rotate_templates(feat, valid, tfm, num_rotations, cell_size):
   f, v, tf = _np(feat, DTYPE), _np(valid).astype(bool), _np(tfm, DTYPE)
   H, W, D = f.shape
   grid = o_grids.Grid2D((H, W), cell_size)
-  grid_xy = grid.index_to_xyz(grid.grid_index()).reshape(-1, 2).astype(DTYPE)
+  grid_xy = grid.index_to_xyz(grid.grid_index(), DTYPE).reshape(-1, 2)
   quarter, qv = [], []
   for r in range(num_rotations // 4):
     c, s, tx, ty = tf[r]

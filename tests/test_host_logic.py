@@ -1,0 +1,294 @@
+"""CPU tests of the host side: configs, struct maths, the C-ABI surface, the module
+API (driven through the test-only oracle backend) and failure behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import geometry as o_geo
+from oracle import grids as o_grids
+from oracle import model as o_model
+from oracle import pose as o_pose
+from oracle import voting as o_voting
+from snap_amd import _lib
+from snap_amd import models
+from snap_amd import ops
+from snap_amd.configs import defaults
+from snap_amd.configs import eval_localization
+from snap_amd.configs import train_localization
+from snap_amd.data import synthetic
+from snap_amd.models import bev_localizer
+from snap_amd.models import pose_exhaustive_voting as pev
+from snap_amd.utils import geometry
+from snap_amd.utils import grids
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# -- C ABI ---------------------------------------------------------------------------
+def _header_symbols():
+  text = open(os.path.join(ROOT, 'include', 'snap_hip.h')).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return set(re.findall(r'\b(snap_[a-z0-9_]+)\s*\(', text))
+
+
+def test_abi_header_and_binding_agree():
+  assert _header_symbols() == set(_lib.SIGNATURES)
+
+
+def test_abi_library_loads_and_exports_every_symbol():
+  """No compute calls: only dlopen + dlsym + the introspection entry points."""
+  lib = _lib.load()
+  raw = ctypes.CDLL(_lib.LIB_PATH)
+  for name in _header_symbols():
+    assert hasattr(raw, name), f'{name} declared in snap_hip.h but not exported'
+  assert lib.snap_abi_version() == _lib.ABI_VERSION
+  assert lib.snap_build_arch() == b'gfx950'
+  assert lib.snap_status_string(0) == b'ok'
+  assert b'shape' in lib.snap_status_string(-1)
+
+
+def test_ops_fail_loudly_without_gpu():
+  x = torch.zeros(1, 4, 4, 8)
+  w = torch.zeros(1, 1, 8, 8)
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    ops.conv2d(x, w)
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    ops.vertical_pool(torch.zeros(2, 3, 8), torch.ones(2, 3, dtype=torch.bool))
+  with pytest.raises(TypeError):
+    ops.conv2d(np.zeros((1, 4, 4, 8), np.float32), w)
+
+
+def test_missing_library_raises(monkeypatch):
+  monkeypatch.setattr(_lib, '_lib', None)
+  monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libsnap_hip.so')
+  with pytest.raises(RuntimeError, match='not built'):
+    _lib.load()
+
+
+def test_entry_point_argument_validation_codes():
+  """Bad descriptors are rejected with status codes before any launch (CPU-safe)."""
+  lib = _lib.load()
+  d = _lib.SnapConvDesc(1, 4, 4, 8, 8, 1, 1, 1, 0, 0, 4, 4, 6, 6, 0, 0, 1.0, 0.0)  # Cout % 4 != 0
+  one = ctypes.c_void_p(16)
+  assert lib.snap_conv2d_nhwc_f32(ctypes.byref(d), one, one, one, None, None, None, None, None,
+                                  None, None, None) == -1
+  assert lib.snap_conv2d_nhwc_f32(ctypes.byref(d), None, one, one, None, None, None, None, None,
+                                  None, None, None) == -3
+  assert lib.snap_vertical_pool_f32(one, one, one, one, 4, 3, 6, 0, None) == -1   # D % 4
+  assert lib.snap_vertical_pool_f32(one, one, one, one, 4, 3, 8, 7, None) == -2   # pooling
+  assert lib.snap_pose_score_f32(one, one, one, one, None, 1, 4, 8, 8, 10, 0.2, 0, one, one, 0,
+                                 None) == -5                                      # workspace
+
+
+# -- configs ----------------------------------------------------------------------------
+def test_default_config_values_match_reference_defaults():
+  c = defaults.bev_localizer()
+  assert (c.mask_score_out_of_bounds, c.clip_negative_scores, c.add_temperature) == (False, True, True)
+  assert c.init_temperature == 2.0 and c.query_frustum_depth == 16.0
+  assert c.num_pose_samples is None and c.num_pose_sampling_retries == 1
+  m = c.bev_mapper
+  assert (m.scene_z_offset, m.scene_z_height, m.matching_dim) == (4.0, 12.0, 32)
+  assert tuple(m.scene_z_offset_range) == (-2, 2)
+  assert m.pooling.pooling == 'max' and m.modality_fusion.pooling == 'max'
+  sv = m.streetview_encoder
+  assert (sv.feature_dim, sv.num_scale_bins, sv.top_k_view_selection) == (128, 32, 4)
+  assert tuple(sv.depth_min_max) == (1.0, 32.0) and tuple(sv.fusion.layers) == (256, 128)
+  assert sv.proj_mlp.apply_input_activation and sv.do_weighted_fusion
+  assert sv.image_encoder.encoder.depth == 50 and not sv.image_encoder.encoder.skip_root_block
+  assert m.aerial_encoder.encoder.skip_root_block
+  t = train_localization.get_config()
+  assert t.model.num_pose_samples == 10_000 and t.model.num_pose_sampling_retries == 8
+  assert t.model.filter_points_in_fov
+  e = eval_localization.get_config()
+  assert e.model.num_pose_samples == 20_000 and e.model.do_grid_refinement
+  with pytest.raises(AttributeError):
+    c.not_a_key = 1          # locked, like ml_collections
+  with pytest.raises(ValueError):
+    defaults.parse_argument_string('foo=1')
+  assert defaults.parse_argument_string('image_encoder=R101')['image_encoder'] == 'R101'
+  assert defaults.resnet('R152x2').width == 2
+
+
+# -- struct maths vs oracle ----------------------------------------------------------------
+def test_torch_geometry_matches_oracle():
+  rng = np.random.default_rng(0)
+  ang = rng.uniform(-3, 3, (2, 5))
+  tt = rng.standard_normal((2, 5, 2))
+  a = geometry.Transform2D(torch.tensor(ang), torch.tensor(tt))
+  oa = o_geo.Transform2D(ang, tt)
+  pts = rng.standard_normal((2, 5, 7, 2))
+  np.testing.assert_allclose((a @ torch.tensor(pts)).numpy(), oa @ pts, atol=1e-12)
+  np.testing.assert_allclose((a @ a.inv).t.numpy(), 0, atol=1e-12)
+  np.testing.assert_allclose(a.inv.t.numpy(), oa.inv.t, atol=1e-12)
+  dr, dt = a.magnitude()
+  odr, odt = oa.magnitude()
+  np.testing.assert_allclose(dr.numpy(), odr)
+  np.testing.assert_allclose(dt.numpy(), odt)
+  assert a[0].shape == (5,) and a[:, None].shape == (2, 1, 5)
+  assert geometry.Transform2D.from_packed(a.packed()).t.equal(a.t)
+  cam = geometry.FisheyeCamera(
+      torch.tensor([[100.0, 80.0]]), torch.tensor([[60.0, 55.0]]), torch.tensor([[50.0, 40.0]]),
+      torch.tensor([[0.05, -0.01, 0.002]]), torch.tensor([2.0]))
+  ocam = o_geo.FisheyeCamera(*(t.numpy() for t in (cam.wh, cam.f, cam.c, cam.k_radial, cam.max_fov)))
+  p3 = rng.standard_normal((1, 50, 3)) * np.array([2, 2, 4]) + np.array([0, 0, 2])
+  uv, ok = cam.world2image(torch.tensor(p3))
+  ouv, ook = ocam.world2image(p3)
+  np.testing.assert_allclose(uv.numpy(), ouv, atol=1e-9)
+  assert (ok.numpy() == ook).all()
+  assert cam.packed().shape == (1, 11)
+  sc = cam.scale(torch.tensor([0.25, 0.5]))
+  np.testing.assert_allclose(sc.f.numpy(), [[15.0, 27.5]])
+
+
+def test_grids_and_frustum_match_oracle():
+  g = grids.Grid3D.from_extent_meters((24, 32, 12), 0.2)
+  assert g.extent == (120, 160, 60) and g.bev().extent == (120, 160)
+  with pytest.raises(ValueError):
+    grids.Grid2D.from_extent_meters((1.0, 1.05), 0.2)
+  idx = g.bev().grid_index()
+  assert idx.shape == (120, 160, 2)
+  np.testing.assert_allclose(
+      g.bev().index_to_xyz(idx.float()).numpy(),
+      o_grids.Grid2D((120, 160), 0.2).index_to_xyz(o_grids.Grid2D((120, 160), 0.2).grid_index()),
+      atol=1e-5)
+  grid, p, q = bev_localizer.build_query_frustum_grid(0.2, 16.0, True, 72.0)
+  og, op, oq = o_pose.build_query_frustum_grid(0.2, 16.0, True, 72.0)
+  assert grid.extent == og.extent == (120, 80)
+  np.testing.assert_allclose(q.numpy(), oq, atol=1e-6)
+
+
+def test_exhaustive_index_helpers_match_oracle():
+  g = grids.Grid2D((48, 48), 0.5)
+  og = o_grids.Grid2D((48, 48), 0.5)
+  idx = torch.tensor([5, 50, 43])
+  tf = pev.exhaustive_index_to_tfm(idx, g, 36)
+  otf = o_voting.exhaustive_index_to_tfm(idx.numpy(), og, 36)
+  np.testing.assert_allclose(tf.angle.numpy(), otf.angle, atol=1e-6)
+  np.testing.assert_allclose(tf.t.numpy(), otf.t, atol=1e-5)
+  back = pev.exhaustive_tfm_to_index(tf, g, 36)
+  np.testing.assert_allclose(back.numpy(), idx.numpy(), atol=1e-4)
+
+
+# -- module API through the oracle backend ---------------------------------------------------
+def _tiny(refine=False, **kw):
+  cfg = helpers.tiny_localizer_config(refine=refine, **kw)
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  model = models.get_model('bev_localizer')(cfg, meta)
+  return cfg, meta, model
+
+
+def test_model_registry_and_base_model_contract():
+  cfg, meta, model = _tiny()
+  assert isinstance(model.flax_model, bev_localizer.BEVLocalizer)
+  assert model.default_flax_model_config().bev_mapper.matching_dim == 32
+  with pytest.raises(KeyError):
+    models.get_model('semantic_net')
+
+
+def test_param_tree_has_flax_layout():
+  cfg, meta, model = _tiny()
+  p = model.flax_model.init(0, device='cpu')['params']
+  assert set(p) == {'bev_mapper', 'temperature'}
+  bm = p['bev_mapper']
+  assert set(bm) == {'streetview_encoder', 'vertical_pooling', 'aerial_encoder',
+                     'modality_fusion', 'matching_proj'}
+  sv = bm['streetview_encoder']
+  assert set(sv) == {'image_encoder', 'proj_mlp', 'fusion_mlp'}
+  enc = sv['image_encoder']['encoder']
+  assert enc['root_block']['conv_root']['kernel'].shape == (7, 7, 3, 32)      # HWIO
+  u = enc['block1']['unit01']
+  assert set(u) == {'gn1', 'conv1', 'gn2', 'conv2', 'gn3', 'conv3', 'conv_proj'}
+  assert u['gn1']['scale'].shape == (1, 1, 1, 32)
+  assert u['conv2']['kernel'].shape == (3, 3, 32, 32)
+  assert 'conv_root' in bm['aerial_encoder']['encoder']                        # skip_root_block
+  dec = sv['image_encoder']['decoder']
+  assert set(dec) == {'0_skip_norm', '0_skip_conv', '1_skip_norm', '1_skip_conv'}
+  assert sv['fusion_mlp']['Dense_0']['kernel'].shape == (65, 64)               # (in, out)
+  assert sv['proj_mlp']['Dense_0']['kernel'].shape == (32, 40)
+  assert bm['matching_proj']['kernel'].shape == (32, 8)
+  assert float(p['temperature']) == 2.0
+
+
+def test_forward_pytree_and_oracle_agreement(oracle_backend):
+  cfg, meta, model = _tiny(refine=True, num_pose_samples=24)
+  loc = model.flax_model
+  variables = loc.init({'params': 0, 'sampling': 1}, device='cpu')
+  batch = synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=1)
+  pred, state = loc.apply(variables, batch, train=False, rngs={'sampling': 3}, mutable=['batch_stats'],
+                          debug=True)
+  assert state == {}
+  assert {'map', 'query', 'map_t_query_samples', 'scores_poses', 'best_index', 'map_t_query',
+          'map_t_query_ransac', 'scores_grid_refine'} <= set(pred)
+  assert set(pred['map']) == {'streetview', 'aerial', 'bev_features', 'bev_matching'}
+  assert set(pred['query']) == {'streetview', 'bev_features', 'bev_matching'}
+  assert 'xyz_query' in batch['map']                      # input dict side effect (bev_mapper.py:196)
+  assert pred['map']['streetview']['feature_volume'].features.shape == (2, 32, 32, 12, 32)
+  assert pred['query']['bev_matching'].features.shape[0:3:2] == (2, 1)
+  assert pred['scores_poses'].shape == (2, 25) and pred['scores_grid_refine'].shape == (2, 41, 41, 41)
+  assert pred['map_t_query_samples'].shape == (2, 25)
+  # GT pose is prepended at index 0.
+  gt = geometry.Transform2D.from_Transform3D(batch['T_query2map'])
+  assert torch.allclose(pred['map_t_query_samples'].t[:, 0], gt.t)
+
+  samples = pred['map_t_query_samples']
+  ps = o_geo.Transform2D(samples.angle[:, 1:].numpy(), samples.t[:, 1:].numpy())
+  ref = o_model.bev_localizer(
+      helpers.params_to_numpy(variables['params']), cfg, {'streetview_hfov_deg': 72.0},
+      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch), pose_samples=ps)
+  helpers.report('bev_matching', pred['map']['bev_matching'].features,
+                 ref['map']['bev_matching']['features'], atol=2e-5)
+  helpers.report('scores', pred['scores_poses'], ref['scores_poses'], atol=2e-5)
+  helpers.assert_same_argmax('best', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                             got_index=pred['best_index'])
+
+  losses, metrics = model.loss_metrics_function(pred, batch, variables['params'])
+  rl, rm = o_pose.loss_metrics(
+      dict(scores_poses=pred['scores_poses'].numpy(),
+           map_t_query_samples=o_geo.Transform2D(samples.angle.numpy(), samples.t.numpy()),
+           map_t_query=o_geo.Transform2D(pred['map_t_query'].angle.numpy(), pred['map_t_query'].t.numpy())),
+      helpers.batch_to_oracle(batch)['T_query2map'])
+  assert set(losses) == {'localization/nll', 'total'}
+  np.testing.assert_allclose(losses['total'].numpy(), rl['total'], rtol=1e-5)
+  for k, v in rm.items():
+    np.testing.assert_allclose(metrics[k].numpy().astype(np.float64), np.asarray(v, np.float64),
+                               rtol=1e-4, atol=1e-5, err_msg=k)
+  assert 'loc/temperature' in metrics
+
+
+def test_unsupported_configs_raise_like_the_reference():
+  cfg = helpers.tiny_localizer_config()
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  sc = meta['build_config'].scene_config
+  bad = helpers.tiny_localizer_config()
+  bad.add_confidence_map = True
+  with pytest.raises(NotImplementedError):
+    bev_localizer.BEVLocalizer(bad, sc, meta['grid'].bev())
+  bad = helpers.tiny_localizer_config()
+  bad.filter_points_in_fov = False
+  with pytest.raises(ValueError):
+    bev_localizer.BEVLocalizer(bad, sc, meta['grid'].bev())
+  bad = helpers.tiny_localizer_config()
+  bad.bev_mapper.streetview_encoder.image_encoder.encoder_name = 'vit'
+  with pytest.raises(ValueError):
+    bev_localizer.BEVLocalizer(bad, sc, meta['grid'].bev())
+  bad = helpers.tiny_localizer_config()
+  bad.bev_mapper.pooling.pooling = 'bogus'
+  with pytest.raises(NotImplementedError):
+    bev_localizer.BEVLocalizer(bad, sc, meta['grid'].bev())
+
+
+def test_recover_dense_feature_plane(oracle_backend):
+  cfg, meta, model = _tiny()
+  loc = model.flax_model
+  n = loc.q_xy_p.shape[0]
+  from snap_amd.models import types
+  sparse = types.FeaturePlane(torch.arange(n * 3, dtype=torch.float32).reshape(n, 1, 3),
+                              torch.ones(n, 1, dtype=torch.bool))
+  dense = loc.recover_dense_feature_plane(sparse)
+  assert dense.features.shape == (*loc.grid_query.extent, 3)
+  assert int(dense.valid.sum()) == n
