@@ -46,18 +46,19 @@ struct ConvArgs {
 
 constexpr int BK = 16;
 
-__device__ __forceinline__ float apply_pro(float v, int mode, float mu, float sc,
-                                           float beta, float s, float t) {
-  switch (mode) {
-    case SNAP_PRO_AFFINE: return v * s + t;
-    case SNAP_PRO_GN_RELU: return fmaxf((v - mu) * sc + beta, 0.f);
-    case SNAP_PRO_RELU_GN: return (fmaxf(v, 0.f) - mu) * sc + beta;
-    case SNAP_PRO_RELU: return fmaxf(v, 0.f);
-    default: return v;
-  }
+// The prologue is a COMPILE-TIME parameter: a run-time switch here is lowered to a
+// branch tree per staged element and wrecks the schedule of the whole main loop.
+template <int PRO>
+__device__ __forceinline__ float apply_pro(float v, float mu, float sc, float beta, float s,
+                                           float t) {
+  if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
+  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
+  if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
+  if constexpr (PRO == SNAP_PRO_RELU) return fmaxf(v, 0.f);
+  return v;
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, int PRO>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int AS = BM + 2;    // LDS row stride of the K-major A slab
   constexpr int TM = BM / 64;   // 32x32 MFMA tiles per wave along M
@@ -79,12 +80,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int HoWo = d.Ho * d.Wo;
-  const int mode = d.prologue;
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
 
   // ---- per-thread A row bookkeeping -------------------------------------
   constexpr int NR = VEC ? AROWS : AELEMS;
   int r_n[NR], r_hb[NR], r_wb[NR];
   bool r_ok[NR];
+  const float* r_px[NR];   // &x[n, hb, wb, 0]  (may point outside the image: used only when in-bounds)
+  int64_t r_gn[NR];        // n * Cin  (GroupNorm statistics row)
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int row = VEC ? (tid >> 2) + 64 * i : (tid >> 4) + 16 * i;
@@ -98,6 +101,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     r_n[i] = n;
     r_hb[i] = ho * d.stride - d.pad_t;
     r_wb[i] = wo * d.stride - d.pad_l;
+    r_px[i] = a.x + (((int64_t)n * d.H + r_hb[i]) * d.W + r_wb[i]) * d.Cin_stride;
+    r_gn[i] = (int64_t)n * d.Cin;
   }
   const int akq = tid & 3;    // VEC: which float4 of the 16-wide K slab
   const int akid = tid & 15;  // SCALAR: which k of the slab
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   float sa[VEC ? 1 : AELEMS], smu[VEC ? 1 : AELEMS], ssc[VEC ? 1 : AELEMS], sbeta = 0.f;
   bool sin_[VEC ? 1 : AELEMS];
   f32x4 xb[BPASS];
+  bool xbok[BPASS];
   int cur_c = 0;  // channel of element 0 of this thread's quad (VEC)
 
   // K-slab walk state (VEC): (kpos = kh*KW+kw, ct)
@@ -130,27 +136,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       const int c = ct * BK + 4 * akq;
       cur_c = c;
       const bool cvalid = c < d.Cin;
-      const bool need_gn = (mode == SNAP_PRO_GN_RELU || mode == SNAP_PRO_RELU_GN);
-      if (need_gn && cvalid) {
-        xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + c);
-      } else {
-        xbeta = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      // Loads are unconditional from a clamped (always mapped) address; invalid
+      // lanes are zeroed when the slab is stored.  No divergent branches.
+      if constexpr (need_gn) xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
+      // element offset of (kh, kw, c) relative to a row's base pixel
+      const int64_t delta = ((int64_t)kh * d.W + kw) * d.Cin_stride + c;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const int hi = r_hb[i] + kh, wi = r_wb[i] + kw;
         const bool inb = r_ok[i] && cvalid && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
         xin[i] = inb;
-        if (inb) {
-          const int64_t off = ((int64_t)(r_n[i] * d.H + hi) * d.W + wi) * d.Cin_stride + c;
-          xa[i] = *reinterpret_cast<const f32x4*>(a.x + off);
-          if (need_gn) {
-            const int64_t so = (int64_t)r_n[i] * d.Cin + c;
-            xmu[i] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
-            xsc[i] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
-          }
-        } else {
-          xa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* px = inb ? r_px[i] + delta : a.x;
+        xa[i] = *reinterpret_cast<const f32x4*>(px);
+        if constexpr (need_gn) {
+          const int64_t so = inb ? r_gn[i] + c : (int64_t)0;
+          xmu[i] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
+          xsc[i] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
         }
       }
       // B rows of this slab
@@ -160,8 +161,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int kr = bkr + p * BROWS_PER_PASS;
         const int col = n0 + 4 * bcq;
         const bool ok = (ct * BK + kr) < d.Cin && col < d.Cout;
-        xb[p] = ok ? *reinterpret_cast<const f32x4*>(a.w + (int64_t)(wrow0 + kr) * d.Cout + col)
-                   : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int64_t wo = ok ? (int64_t)(wrow0 + kr) * d.Cout + col : (int64_t)0;
+        // NB: nothing may consume the loaded registers before the MFMA block (a
+        // select here would pull the s_waitcnt vmcnt(0) in front of the MFMAs).
+        xb[p] = *reinterpret_cast<const f32x4*>(a.w + wo);
+        xbok[p] = ok;
       }
     } else {
       const int k = kt * BK + akid;
@@ -171,22 +175,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       const int c = kk - kp * d.Cin;
       const int skh = kp / d.KW;
       const int skw = kp - skh * d.KW;
-      const bool need_gn = (mode == SNAP_PRO_GN_RELU || mode == SNAP_PRO_RELU_GN);
-      sbeta = (need_gn && kvalid) ? a.gn_beta[c] : 0.f;
+      sbeta = 0.f;
+      if constexpr (need_gn) sbeta = a.gn_beta[c];
 #pragma unroll
       for (int i = 0; i < AELEMS; ++i) {
         const int hi = r_hb[i] + skh, wi = r_wb[i] + skw;
         const bool inb = r_ok[i] && kvalid && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
         sin_[i] = inb;
-        if (inb) {
-          const int64_t off = ((int64_t)(r_n[i] * d.H + hi) * d.W + wi) * d.Cin_stride + c;
-          sa[i] = a.x[off];
-          if (need_gn) {
-            smu[i] = a.gn_mu[(int64_t)r_n[i] * d.Cin + c];
-            ssc[i] = a.gn_sc[(int64_t)r_n[i] * d.Cin + c];
-          }
-        } else {
-          sa[i] = 0.f;
+        const int64_t sdelta = ((int64_t)skh * d.W + skw) * d.Cin_stride + c;
+        const float* px = inb ? r_px[i] + sdelta : a.x;
+        sa[i] = *px;
+        if constexpr (need_gn) {
+          const int64_t so = inb ? r_gn[i] + c : (int64_t)0;
+          smu[i] = a.gn_mu[so];
+          ssc[i] = a.gn_sc[so];
         }
       }
 #pragma unroll
@@ -194,8 +196,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int kr = bkr + p * BROWS_PER_PASS;
         const int col = n0 + 4 * bcq;
         const bool ok = (kt * BK + kr) < a.K && col < d.Cout;
-        xb[p] = ok ? *reinterpret_cast<const f32x4*>(a.w + (int64_t)(kt * BK + kr) * d.Cout + col)
-                   : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int64_t wo = ok ? (int64_t)(kt * BK + kr) * d.Cout + col : (int64_t)0;
+        // NB: nothing may consume the loaded registers before the MFMA block (a
+        // select here would pull the s_waitcnt vmcnt(0) in front of the MFMAs).
+        xb[p] = *reinterpret_cast<const f32x4*>(a.w + wo);
+        xbok[p] = ok;
       }
     }
   };
@@ -218,13 +223,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       for (int i = 0; i < AROWS; ++i) {
         const int row = (tid >> 2) + 64 * i;
         f32x4 v = xa[i];
-        if (xin[i]) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float pv = apply_pro(v[e], mode, xmu[i][e], xsc[i][e], xbeta[e],
-                                       d.in_scale, d.in_shift);
-            v[e] = (cur_c + e < d.Cin) ? pv : 0.f;
-          }
+        for (int e = 0; e < 4; ++e) {
+          float pv;
+          if constexpr (need_gn)
+            pv = apply_pro<PRO>(v[e], xmu[i][e], xsc[i][e], xbeta[e], d.in_scale, d.in_shift);
+          else
+            pv = apply_pro<PRO>(v[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+          v[e] = (xin[i] && (cur_c + e < d.Cin)) ? pv : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) as[(4 * akq + e) * AS + row] = v[e];
@@ -233,15 +239,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < AELEMS; ++i) {
         const int row = (tid >> 4) + 16 * i;
-        float v = sa[i];
-        if (sin_[i]) v = apply_pro(v, mode, smu[i], ssc[i], sbeta, d.in_scale, d.in_shift);
-        as[akid * AS + row] = v;
+        float pv;
+        if constexpr (need_gn)
+          pv = apply_pro<PRO>(sa[i], smu[i], ssc[i], sbeta, d.in_scale, d.in_shift);
+        else
+          pv = apply_pro<PRO>(sa[i], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+        as[akid * AS + row] = sin_[i] ? pv : 0.f;
       }
     }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p) {
       const int kr = bkr + p * BROWS_PER_PASS;
-      *reinterpret_cast<f32x4*>(bs + kr * BN + 4 * bcq) = xb[p];
+      *reinterpret_cast<f32x4*>(bs + kr * BN + 4 * bcq) =
+          xbok[p] ? xb[p] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
 
@@ -261,20 +271,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
     const float* as = As[cur];
     const float* bs = Bs[cur];
+    // LDS -> register operand fetch runs one k-pair ahead of the MFMAs.
+    float av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i] = as[lhi * AS + wr * (BM / 2) + i * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j] = bs[lhi * BN + wc * (BN / 2) + j * 32 + l31];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float av[TM], bv[TN];
+      const int cu = kk & 1, nx = cu ^ 1;
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        av[i] = as[(2 * kk + lhi) * AS + wr * (BM / 2) + i * 32 + l31];
+        for (int i = 0; i < TM; ++i)
+          av[nx][i] = as[(2 * (kk + 1) + lhi) * AS + wr * (BM / 2) + i * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bv[j] = bs[(2 * kk + lhi) * BN + wc * (BN / 2) + j * 32 + l31];
+        for (int j = 0; j < TN; ++j)
+          bv[nx][j] = bs[(2 * (kk + 1) + lhi) * BN + wc * (BN / 2) + j * 32 + l31];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(av[cu][i], bv[cu][j], acc[i][j], 0, 0, 0);
+    }
+    // Pin the schedule: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
+    // k-pair kk, so the LDS latency hides under 4 x 64 MFMA cycles.
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     if (more) store_slab(cur ^ 1);
     __syncthreads();
@@ -332,12 +359,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, int PRO>
 int launch(const ConvArgs& a, hipStream_t s) {
   dim3 grid((unsigned)snap_cdiv(a.M, BM), (unsigned)snap_cdiv(a.d.Cout, BN));
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
+}
+
+template <int BM, int BN, bool VEC>
+int launch_pro(const ConvArgs& a, hipStream_t s) {
+  switch (a.d.prologue) {
+    case SNAP_PRO_NONE: return launch<BM, BN, VEC, SNAP_PRO_NONE>(a, s);
+    case SNAP_PRO_AFFINE: return launch<BM, BN, VEC, SNAP_PRO_AFFINE>(a, s);
+    case SNAP_PRO_GN_RELU:
+      // the scalar (unaligned / Cin % 4 != 0) path carries no GroupNorm variant.
+      if constexpr (VEC) return launch<BM, BN, VEC, SNAP_PRO_GN_RELU>(a, s);
+      return SNAP_ERR_UNSUPPORTED;
+    case SNAP_PRO_RELU_GN:
+      if constexpr (VEC) return launch<BM, BN, VEC, SNAP_PRO_RELU_GN>(a, s);
+      return SNAP_ERR_UNSUPPORTED;
+    case SNAP_PRO_RELU: return launch<BM, BN, VEC, SNAP_PRO_RELU>(a, s);
+    default: return SNAP_ERR_UNSUPPORTED;
+  }
+}
+
+// Tile choice: the largest tile that still yields >= 2 workgroups per CU; small-M
+// layers (deep stages, few images) fall back to 64x64 tiles to fill the 256 CUs.
+template <bool VEC>
+int launch_tile(const ConvArgs& a, hipStream_t s) {
+  const int64_t M = a.M, N = a.d.Cout;
+  const int64_t kMin = 512;
+  const bool n_wide_ok = N > 64 && !(N % 128 != 0 && N % 128 <= 64);
+  if (n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin)
+    return launch_pro<128, 128, VEC>(a, s);
+  if (snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)
+    return launch_pro<128, 64, VEC>(a, s);
+  if (n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin)
+    return launch_pro<64, 128, VEC>(a, s);
+  return launch_pro<64, 64, VEC>(a, s);
 }
 
 }  // namespace
@@ -385,9 +445,5 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
     a.nk = (a.K + BK - 1) / BK;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool narrow = d.Cout <= 64 || (d.Cout % 128 != 0 && d.Cout % 128 <= 64);
-  if (vec) {
-    return narrow ? launch<128, 64, true>(a, s) : launch<128, 128, true>(a, s);
-  }
-  return narrow ? launch<128, 64, false>(a, s) : launch<128, 128, false>(a, s);
+  return vec ? launch_tile<true>(a, s) : launch_tile<false>(a, s);
 }

@@ -59,94 +59,104 @@ __global__ __launch_bounds__(256) void weight_std_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// GroupNorm statistics.
+// GroupNorm statistics -- ONE pass over the activation.
 // grid = (slabs, N, channel chunks of <=1024); block = 256 threads laid out as
-// QW float4-quads x PW pixels.  PASS 0 accumulates sum(v); PASS 1 accumulates
-// sum((v-mean)^2) with mean from pass 0.  Deterministic: fixed-order LDS trees
-// and a fixed-order slab reduction in the finalize kernels.
+// QW float4-quads x PW pixels.  Every thread accumulates sum(v - p) and
+// sum((v - p)^2) around a per-channel pivot p = v[pixel 0] (a sample of the data, so
+// no catastrophic cancellation); the finalize kernel combines slabs and channels
+// in double precision into the exact two-pass quantities mean and
+// mean((v - mean)^2) of resnet.py:38-40.  Deterministic: fixed-order reductions.
 // ---------------------------------------------------------------------------
-constexpr int GN_PIX_PER_BLOCK = 512;
-
-template <int PASS>
 __global__ __launch_bounds__(256) void gn_partial_kernel(
-    const float* __restrict__ x, int HW, int C, int Cs, int groups, int relu_first,
-    const float* __restrict__ mean /*[N,groups]*/, float* __restrict__ partial /*[N,S,groups]*/) {
-  __shared__ float part[256 * 4];
-  __shared__ float csum[1024];
+    const float* __restrict__ x, int HW, int C, int Cs, int relu_first, int ppb,
+    float* __restrict__ partial /*[N,S,C,2]*/) {
+  __shared__ float part[256 * 8];
   const int S = gridDim.x;
   const int n = blockIdx.y;
   const int cbase = blockIdx.z * 1024;
   const int cchunk = min(C - cbase, 1024);
-  const int QW = cchunk >> 2;        // quads in this chunk (<=256), power of two or 16..256
+  const int QW = cchunk >> 2;
   const int PW = 256 / QW;
   const int tq = threadIdx.x % QW, tp = threadIdx.x / QW;
-  const int cpg = C / groups;
   const int c0 = cbase + 4 * tq;
-  const int p_begin = blockIdx.x * GN_PIX_PER_BLOCK;
-  const int p_end = min(p_begin + GN_PIX_PER_BLOCK, HW);
-  float m[4] = {0.f, 0.f, 0.f, 0.f};
-  if (PASS == 1) {
+  const int p_begin = blockIdx.x * ppb;
+  const int p_end = min(p_begin + ppb, HW);
+  const float* xb = x + ((int64_t)n * HW) * Cs + c0;
+  f32x4 piv = *reinterpret_cast<const f32x4*>(xb);
+  if (relu_first) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) m[e] = mean[n * groups + (c0 + e) / cpg];
+    for (int e = 0; e < 4; ++e) piv[e] = fmaxf(piv[e], 0.f);
   }
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (tp < PW) {
-    const float* xb = x + ((int64_t)n * HW) * Cs + c0;
-    for (int p = p_begin + tp; p < p_end; p += PW) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)p * Cs);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = p_begin + tp; p < p_end; p += PW) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)p * Cs);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = relu_first ? fmaxf(v[e], 0.f) : v[e];
-        if (PASS == 1) { t -= m[e]; t *= t; }
-        acc[e] += t;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const float t = (relu_first ? fmaxf(v[e], 0.f) : v[e]) - piv[e];
+      s1[e] += t;
+      s2[e] += t * t;
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) part[threadIdx.x * 4 + e] = acc[e];
+  for (int e = 0; e < 4; ++e) {
+    part[threadIdx.x * 8 + e] = s1[e];
+    part[threadIdx.x * 8 + 4 + e] = s2[e];
+  }
   __syncthreads();
   // per-channel sums over the PW pixel lanes (fixed order)
   for (int c = threadIdx.x; c < cchunk; c += 256) {
     const int q = c >> 2, e = c & 3;
-    float t = 0.f;
-    for (int pp = 0; pp < PW; ++pp) t += part[(pp * QW + q) * 4 + e];
-    csum[c] = t;
-  }
-  __syncthreads();
-  const int g0 = cbase / cpg;
-  const int ng = cchunk / cpg;
-  for (int g = threadIdx.x; g < ng; g += 256) {
-    float t = 0.f;
-    for (int c = 0; c < cpg; ++c) t += csum[g * cpg + c];
-    partial[((int64_t)n * S + blockIdx.x) * groups + g0 + g] = t;
+    float a1 = 0.f, a2 = 0.f;
+    for (int pp = 0; pp < PW; ++pp) {
+      a1 += part[(pp * QW + q) * 8 + e];
+      a2 += part[(pp * QW + q) * 8 + 4 + e];
+    }
+    float* o = partial + (((int64_t)n * S + blockIdx.x) * C + cbase + c) * 2;
+    o[0] = a1;
+    o[1] = a2;
   }
 }
 
-__global__ void gn_finalize_mean_kernel(const float* __restrict__ partial, int S, int groups,
-                                        float count, float* __restrict__ mean, int total) {
+// one thread per (image, group)
+__global__ void gn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                   int S, int HW, int C, int Cs, int groups, int relu_first,
+                                   float eps, const float* __restrict__ gamma,
+                                   float* __restrict__ mu, float* __restrict__ sc, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*groups
   if (i >= total) return;
   const int n = i / groups, g = i - n * groups;
-  float t = 0.f;
-  for (int s = 0; s < S; ++s) t += partial[((int64_t)n * S + s) * groups + g];
-  mean[i] = t / count;
-}
-
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int S, int groups, int C,
-                                   float count, float eps, const float* __restrict__ mean,
-                                   const float* __restrict__ gamma, float* __restrict__ mu,
-                                   float* __restrict__ sc, int total /*N*C*/) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*C
-  if (i >= total) return;
-  const int n = i / C, c = i - n * C;
-  const int g = c / (C / groups);
-  float t = 0.f;
-  for (int s = 0; s < S; ++s) t += partial[((int64_t)n * S + s) * groups + g];
-  const float var = t / count;
+  const int cpg = C / groups;
+  const double cnt = (double)HW;
+  double sum = 0.0;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    float pv = x[((int64_t)n * HW) * Cs + c];
+    if (relu_first) pv = fmaxf(pv, 0.f);
+    double a1 = 0.0;
+    for (int s = 0; s < S; ++s) a1 += (double)partial[(((int64_t)n * S + s) * C + c) * 2];
+    sum += a1 + cnt * (double)pv;
+  }
+  const double mean = sum / (cnt * cpg);
+  double m2 = 0.0;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    float pv = x[((int64_t)n * HW) * Cs + c];
+    if (relu_first) pv = fmaxf(pv, 0.f);
+    double a1 = 0.0, a2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+      const float* pp = partial + (((int64_t)n * S + s) * C + c) * 2;
+      a1 += (double)pp[0];
+      a2 += (double)pp[1];
+    }
+    const double dl = mean - (double)pv;
+    m2 += a2 - 2.0 * dl * a1 + cnt * dl * dl;
+  }
+  const float meanf = (float)mean;
+  const float var = (float)(m2 / (cnt * cpg));
   // x / sqrt(mean(x^2) + eps): division by the sqrt, as in resnet.py:40.
-  const float rstd = 1.0f / sqrtf(var + eps);
-  mu[i] = mean[n * groups + g];
-  sc[i] = rstd * gamma[c];
+  const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    mu[(int64_t)n * C + c] = meanf;
+    sc[(int64_t)n * C + c] = rstd * gamma[c];
+  }
 }
 
 __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total4,
@@ -203,7 +213,20 @@ __global__ void max_pool_kernel(const float* __restrict__ x, float* __restrict__
   reinterpret_cast<f32x4*>(y)[i] = best;
 }
 
-inline int gn_slabs(int HW) { return (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK; }
+// slabs per image: enough workgroups (>= ~1024) to fill the chip, >= 8 pixels each.
+struct GnPlan { int S, ppb; };
+inline GnPlan gn_plan(int N, int HW, int C) {
+  const int chunks = (C + 1023) / 1024;
+  int S = (1024 + N * chunks - 1) / (N * chunks);
+  const int smax = (HW + 7) / 8;
+  if (S > smax) S = smax;
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  GnPlan p;
+  p.ppb = (HW + S - 1) / S;
+  p.S = (HW + p.ppb - 1) / p.ppb;
+  return p;
+}
 
 }  // namespace
 
@@ -219,9 +242,9 @@ extern "C" int snap_weight_standardize_f32(const float* w, float* out, int32_t K
 
 extern "C" size_t snap_group_norm_stats_workspace_bytes(int32_t N, int32_t HW, int32_t C,
                                                         int32_t groups) {
-  (void)C;
-  const size_t S = (size_t)gn_slabs(HW);
-  return ((size_t)N * S * groups + (size_t)N * groups) * sizeof(float);
+  (void)groups;
+  const GnPlan pl = gn_plan(N, HW, C);
+  return (size_t)N * pl.S * C * 2 * sizeof(float);
 }
 
 extern "C" int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, int32_t C,
@@ -232,34 +255,22 @@ extern "C" int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, 
   if (!x || !gamma || !mu || !sc || !workspace) return SNAP_ERR_NULL;
   if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0) return SNAP_ERR_BAD_SHAPE;
   if (C % 4 != 0 || C_stride % 4 != 0 || C_stride < C) return SNAP_ERR_BAD_SHAPE;
-  // channel chunking: chunks of 1024 channels must hold whole groups and a
-  // power-of-two number of quads dividing 256.
-  const int cpg = C / groups;
   const int nchunks = (C + 1023) / 1024;
-  if (nchunks > 1 && (C % 1024 != 0 || 1024 % cpg != 0)) return SNAP_ERR_BAD_SHAPE;
+  if (nchunks > 1 && C % 1024 != 0) return SNAP_ERR_BAD_SHAPE;
   const int cchunk = nchunks > 1 ? 1024 : C;
   const int QW = cchunk / 4;
   if (256 % QW != 0) return SNAP_ERR_BAD_SHAPE;
   if (workspace_bytes < snap_group_norm_stats_workspace_bytes(N, HW, C, groups))
     return SNAP_ERR_WORKSPACE;
-  const int S = gn_slabs(HW);
+  const GnPlan pl = gn_plan(N, HW, C);
   float* partial = static_cast<float*>(workspace);
-  float* mean = partial + (size_t)N * S * groups;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(S, N, nchunks);
-  const float count = (float)HW * (float)cpg;
-  hipLaunchKernelGGL(gn_partial_kernel<0>, grid, dim3(256), 0, s, x, HW, C, C_stride, groups,
-                     relu_first, (const float*)nullptr, partial);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(pl.S, N, nchunks), dim3(256), 0, s, x, HW, C,
+                     C_stride, relu_first, pl.ppb, partial);
   SNAP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_mean_kernel, dim3((unsigned)snap_cdiv(N * groups, 256)),
-                     dim3(256), 0, s, partial, S, groups, count, mean, N * groups);
-  SNAP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_partial_kernel<1>, grid, dim3(256), 0, s, x, HW, C, C_stride, groups,
-                     relu_first, (const float*)mean, partial);
-  SNAP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv((int64_t)N * C, 256)),
-                     dim3(256), 0, s, partial, S, groups, C, count, eps, (const float*)mean,
-                     gamma, mu, sc, N * C);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv(N * groups, 64)), dim3(64), 0, s,
+                     x, (const float*)partial, pl.S, HW, C, C_stride, groups, relu_first, eps,
+                     gamma, mu, sc, N * groups);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

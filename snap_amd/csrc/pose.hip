@@ -13,6 +13,8 @@
 // The prob_points tensor of the reference is never materialised on the product
 // path: its row-softmax is represented by chunk_stats (1/32 of the bytes) and
 // re-evaluated on the fly by the sampler.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -407,6 +409,98 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_kernel(const ScoreArgs 
   }
 }
 
+// Double-buffered variant for planes that fit twice in LDS (X*Y*4 <= 64 KiB, the
+// 128x128 map): the plane of the NEXT valid query point is streamed HBM -> LDS by
+// the LDS-DMA path (global_load_lds_dwordx4: no VGPR round trip, wave-uniform LDS
+// base + lane*16, i.e. a linear copy) while every thread gathers from the current
+// one; one barrier per point.  This keeps the HBM stream busy during the gather
+// phase -- the kernel's roofline is the single read of sim.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_void_t;
+
+template <int PPT, bool MASK>
+__global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreArgs a) {
+  extern __shared__ float plane[];
+  const int b = blockIdx.z;
+  const int chunk = blockIdx.y;
+  const int NCH = gridDim.y;
+  const int p_base = blockIdx.x * (PS_THREADS * PPT);
+  const int tid = threadIdx.x;
+  const int XY = a.X * a.Y;
+  const int nf4 = XY >> 2;
+  float pc[PPT], ps[PPT], ptx[PPT], pty[PPT], acc[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    acc[k] = 0.f;
+    const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + min(p, a.P - 1)];
+    pc[k] = t[0]; ps[k] = t[1]; ptx[k] = t[2]; pty[k] = t[3];
+  }
+  const int n_begin = chunk * a.points_per_chunk;
+  const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
+  const float Xf = (float)a.X, Yf = (float)a.Y;
+  const uint8_t* vq = a.valid_q + (int64_t)b * a.Nq;
+  const uint8_t* mvalid = a.map_valid ? a.map_valid + (int64_t)b * XY : nullptr;
+
+  auto issue = [&](int n, int buf) {
+    const float* src = a.sim + ((int64_t)b * a.Nq + n) * XY;
+    float* dst = plane + buf * XY;
+    for (int i = tid; i < nf4; i += PS_THREADS) {
+      __builtin_amdgcn_global_load_lds((global_void_t*)(src + 4 * i), (lds_void_t*)(dst + 4 * i),
+                                       16, 0, 0);
+    }
+  };
+  auto next_valid = [&](int n) {
+    while (n < n_end && !vq[n]) ++n;
+    return n;
+  };
+
+  int n = next_valid(n_begin);
+  int buf = 0;
+  if (n < n_end) issue(n, 0);
+  while (n < n_end) {
+    __syncthreads();  // plane n landed (vmcnt(0) + barrier); other buffer is free
+    const int nn = next_valid(n + 1);
+    if (nn < n_end) issue(nn, buf ^ 1);
+    const float* pl = plane + buf * XY;
+    const float qx = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+    const float qy = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float xm = (pc[k] * qx - ps[k] * qy) + ptx[k];
+      const float ym = (ps[k] * qx + pc[k] * qy) + pty[k];
+      const float u = xm / a.cell, v = ym / a.cell;
+      const float cu = u - 0.5f, cv = v - 0.5f;
+      const float fu = floorf(cu), fv = floorf(cv);
+      const int i0 = (int)fminf(fmaxf(fu, 0.f), Xf - 1.f);
+      const int i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), Xf - 1.f);
+      const int j0 = (int)fminf(fmaxf(fv, 0.f), Yf - 1.f);
+      const int j1 = (int)fminf(fmaxf(fv + 1.f, 0.f), Yf - 1.f);
+      const float wu1 = cu - fu, wu0 = 1.f - wu1;
+      const float wv1 = cv - fv, wv0 = 1.f - wv1;
+      const float s00 = pl[i0 * a.Y + j0], s01 = pl[i0 * a.Y + j1];
+      const float s10 = pl[i1 * a.Y + j0], s11 = pl[i1 * a.Y + j1];
+      const float val =
+          (((wu0 * wv0) * s00 + (wu0 * wv1) * s01) + (wu1 * wv0) * s10) + (wu1 * wv1) * s11;
+      bool ok = true;
+      if (MASK) {
+        ok = (u >= 0.f) && (u < Xf) && (v >= 0.f) && (v < Yf);
+        ok = ok && mvalid[i0 * a.Y + j0] && mvalid[i0 * a.Y + j1] && mvalid[i1 * a.Y + j0] &&
+             mvalid[i1 * a.Y + j1];
+      }
+      acc[k] += ok ? val : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    n = nn;
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    if (p < a.P) a.partial[((int64_t)b * NCH + chunk) * a.P + p] = acc[k];
+  }
+}
+
 __global__ void pose_score_reduce_kernel(const float* __restrict__ partial, int NCH, int P,
                                          int64_t total, float* __restrict__ scores) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*P
@@ -598,14 +692,26 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
   const size_t lds = (size_t)min((int64_t)a.RB * Y, (int64_t)PS_LDS_FLOATS) * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bands = a.NB > 1;
+  // double-buffered LDS-DMA variant: two whole planes must fit (2 * XY * 4 <= 128 KiB).
+  static const bool db_enabled = []() {
+    const char* e = getenv("SNAP_POSE_SCORE_DB");
+    return !(e && e[0] == '0');
+  }();
+  const bool use_db = db_enabled && !bands && ((int64_t)X * Y <= 16384) && ((X * Y) % 4 == 0);
   const void* fn = nullptr;
-  if (mask_oob) fn = bands ? (const void*)&pose_score_kernel<PS_PPT, true, true>
+  size_t lds_bytes = lds;
+  if (use_db) {
+    fn = mask_oob ? (const void*)&pose_score_db_kernel<PS_PPT, true>
+                  : (const void*)&pose_score_db_kernel<PS_PPT, false>;
+    lds_bytes = (size_t)2 * X * Y * sizeof(float);
+  } else if (mask_oob) fn = bands ? (const void*)&pose_score_kernel<PS_PPT, true, true>
                            : (const void*)&pose_score_kernel<PS_PPT, true, false>;
   else fn = bands ? (const void*)&pose_score_kernel<PS_PPT, false, true>
                   : (const void*)&pose_score_kernel<PS_PPT, false, false>;
-  if (lds > 64 * 1024) {
+  if (lds_bytes > 64 * 1024) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            PS_LDS_FLOATS * sizeof(float)) != hipSuccess)
+                            (int)(use_db ? 128 * 1024 : PS_LDS_FLOATS * sizeof(float))) !=
+        hipSuccess)
       return SNAP_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(pose_table_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)), dim3(256),
@@ -613,7 +719,7 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
   SNAP_CHECK_LAUNCH();
   {
     void* kargs[] = {(void*)&a};
-    if (hipLaunchKernel(fn, dim3(pch, nch, B), dim3(PS_THREADS), kargs, lds, s) != hipSuccess)
+    if (hipLaunchKernel(fn, dim3(pch, nch, B), dim3(PS_THREADS), kargs, lds_bytes, s) != hipSuccess)
       return SNAP_ERR_LAUNCH;
   }
   SNAP_CHECK_LAUNCH();

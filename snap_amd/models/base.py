@@ -22,19 +22,33 @@ Predictions = Dict[str, Any]
 LossMetricsTuple = Tuple[Dict[str, Any], Dict[str, Any]]
 
 
-class ForwardContext:
-  """Per-``apply`` scratch: caches standardised conv kernels (StdConv) so the map
-  and query passes, which share parameters, standardise each kernel once."""
+import weakref
 
-  def __init__(self):
-    self._wstd = {}
+# id(kernel tensor) -> (weakref to it, tensor._version, standardised copy).
+# StdConv re-standardises its kernel on every call in the reference (it is part of
+# the traced graph); the result only changes when the parameter does, so it is
+# cached until the tensor is modified in place (optimizer step -> _version bump) or
+# dies.  Inference pays the standardisation kernels once.
+_WSTD_CACHE = {}
+
+
+class ForwardContext:
+  """Per-``apply`` scratch + access to the standardised-kernel cache (StdConv)."""
 
   def standardized(self, kernel, fn):
-    key = kernel.data_ptr()
-    out = self._wstd.get(key)
-    if out is None:
-      out = self._wstd[key] = fn(kernel)
+    key = id(kernel)
+    hit = _WSTD_CACHE.get(key)
+    if hit is not None and hit[0]() is kernel and hit[1] == kernel._version:
+      return hit[2]
+    out = fn(kernel)
+    if len(_WSTD_CACHE) > 4096:
+      _WSTD_CACHE.clear()
+    _WSTD_CACHE[key] = (weakref.ref(kernel), kernel._version, out)
     return out
+
+
+def clear_caches():
+  _WSTD_CACHE.clear()
 
 
 class Module:

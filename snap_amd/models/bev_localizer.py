@@ -90,6 +90,36 @@ class BEVLocalizer(base.Module):
     feats[idx[:, 0], idx[:, 1]] = plane_sparse.features.reshape(len(idx), -1)
     return types.FeaturePlane(features=feats, valid=valid)
 
+  def _encode_views_jointly(self, params, data_map, data_query, train, ctx):
+    """Map and query views share the StreetView image encoder (same parameters,
+    per-image GroupNorm): when their image sizes agree, encode all B*(V+1) views in
+    ONE batch (bigger GEMM M, fewer launches) and hand each mapper its slice through
+    the ``image_feature_pyr`` input of StreetViewEncoder (streetview_encoder.py:218)."""
+    sv = self.bev_mapper.streetview_encoder
+    if self.bev_mapper_query is not None or sv is None:
+      return
+    if 'image_feature_pyr' in data_map or 'image_feature_pyr' in data_query:
+      return
+    im, iq = data_map['images'], data_query['images']
+    if im.shape[2:] != iq.shape[2:]:
+      return
+    B, V = im.shape[:2]
+    Vq = iq.shape[1]
+    both = torch.cat(
+        [im.reshape(B * V, *im.shape[2:]), iq.reshape(B * Vq, *iq.shape[2:])], 0
+    ).to(torch.float32)
+    pyr = sv.image_encoder(
+        params['bev_mapper']['streetview_encoder']['image_encoder'], both, train, ctx=ctx
+    )
+    data_map['image_feature_pyr'] = types.FeatureImagePyramid(
+        features=[f[: B * V].reshape(B, V, *f.shape[1:]) for f in pyr.features],
+        strides=pyr.strides,
+    )
+    data_query['image_feature_pyr'] = types.FeatureImagePyramid(
+        features=[f[B * V:].reshape(B, Vq, *f.shape[1:]) for f in pyr.features],
+        strides=pyr.strides,
+    )
+
   def similarity(self, params, f_p_q, plane_map, valid_points, want_prob=False):
     """bev_localizer.py:157-173: sim_points (+ softmax statistics) on the GPU."""
     cfg = self.config
@@ -117,12 +147,16 @@ class BEVLocalizer(base.Module):
     q_xy_p = self.q_xy_p.to(dev)[None].expand(batch_size, -1, -1, -1)
 
     pred = {}
-    pred['map'] = self.bev_mapper(params['bev_mapper'], data['map'], train, debug, ctx=ctx, rng=rng)
+    # shallow copies: the mappers add keys (xyz_query, image_feature_pyr) that must
+    # not leak into the caller's batch (under jax.jit the reference's dict mutation
+    # at bev_mapper.py:196 is likewise invisible to the caller).
+    data_map, data_query = dict(data['map']), {**data['query'], 'xy_bev': q_xy_p}
+    self._encode_views_jointly(params, data_map, data_query, train, ctx)
+    pred['map'] = self.bev_mapper(params['bev_mapper'], data_map, train, debug, ctx=ctx, rng=rng)
     mapper_q = self.bev_mapper_query or self.bev_mapper
     params_q = params['bev_mapper_query'] if self.bev_mapper_query is not None else params['bev_mapper']
     pred['query'] = mapper_q(
-        params_q, {**data['query'], 'xy_bev': q_xy_p}, train, debug, is_query=True,
-        ctx=ctx, rng=rng,
+        params_q, data_query, train, debug, is_query=True, ctx=ctx, rng=rng,
     )
 
     plane_map = pred['map']['bev_matching']

@@ -226,7 +226,7 @@ def test_forward_pytree_and_oracle_agreement(oracle_backend):
           'map_t_query_ransac', 'scores_grid_refine'} <= set(pred)
   assert set(pred['map']) == {'streetview', 'aerial', 'bev_features', 'bev_matching'}
   assert set(pred['query']) == {'streetview', 'bev_features', 'bev_matching'}
-  assert 'xyz_query' in batch['map']                      # input dict side effect (bev_mapper.py:196)
+  assert 'xyz_query' not in batch['map'] and 'image_feature_pyr' not in batch['map']
   assert pred['map']['streetview']['feature_volume'].features.shape == (2, 32, 32, 12, 32)
   assert pred['query']['bev_matching'].features.shape[0:3:2] == (2, 1)
   assert pred['scores_poses'].shape == (2, 25) and pred['scores_grid_refine'].shape == (2, 41, 41, 41)
