@@ -117,45 +117,57 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(
   }
 }
 
-// one thread per (image, group)
-__global__ void gn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
-                                   int S, int HW, int C, int Cs, int groups, int relu_first,
-                                   float eps, const float* __restrict__ gamma,
-                                   float* __restrict__ mu, float* __restrict__ sc, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*groups
+// one wave per (image, group): a flat fp64 reduction over (slab, channel).
+//   T1 = sum a1, T2 = sum a2, U = sum p_c*a1, P1 = sum_c p_c, P2 = sum_c p_c^2
+//   mean = (T1 + HW*P1) / (HW*cpg)
+//   M2   = T2 - 2*mean*T1 + 2*U + HW*(cpg*mean^2 - 2*mean*P1 + P2)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(
+    const float* __restrict__ x, const float* __restrict__ partial, int S, int HW, int C, int Cs,
+    int groups, int relu_first, float eps, const float* __restrict__ gamma,
+    float* __restrict__ mu, float* __restrict__ sc, int total) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // over N*groups
   if (i >= total) return;
   const int n = i / groups, g = i - n * groups;
   const int cpg = C / groups;
+  const int c_lo = g * cpg;
+  const float* xp = x + ((int64_t)n * HW) * Cs + c_lo;
+  double t1 = 0.0, t2 = 0.0, u = 0.0, p1 = 0.0, p2 = 0.0;
+  const int count = S * cpg;
+  for (int e = lane; e < count; e += 64) {
+    const int s = e / cpg, cc = e - s * cpg;
+    float pv = xp[cc];
+    if (relu_first) pv = fmaxf(pv, 0.f);
+    const float* pp = partial + (((int64_t)n * S + s) * C + c_lo + cc) * 2;
+    const double a1 = (double)pp[0];
+    t1 += a1;
+    t2 += (double)pp[1];
+    u += (double)pv * a1;
+  }
+  for (int cc = lane; cc < cpg; cc += 64) {
+    float pv = xp[cc];
+    if (relu_first) pv = fmaxf(pv, 0.f);
+    p1 += (double)pv;
+    p2 += (double)pv * (double)pv;
+  }
+  t1 = wave_sum_f64(t1); t2 = wave_sum_f64(t2); u = wave_sum_f64(u);
+  p1 = wave_sum_f64(p1); p2 = wave_sum_f64(p2);
   const double cnt = (double)HW;
-  double sum = 0.0;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    float pv = x[((int64_t)n * HW) * Cs + c];
-    if (relu_first) pv = fmaxf(pv, 0.f);
-    double a1 = 0.0;
-    for (int s = 0; s < S; ++s) a1 += (double)partial[(((int64_t)n * S + s) * C + c) * 2];
-    sum += a1 + cnt * (double)pv;
-  }
-  const double mean = sum / (cnt * cpg);
-  double m2 = 0.0;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    float pv = x[((int64_t)n * HW) * Cs + c];
-    if (relu_first) pv = fmaxf(pv, 0.f);
-    double a1 = 0.0, a2 = 0.0;
-    for (int s = 0; s < S; ++s) {
-      const float* pp = partial + (((int64_t)n * S + s) * C + c) * 2;
-      a1 += (double)pp[0];
-      a2 += (double)pp[1];
-    }
-    const double dl = mean - (double)pv;
-    m2 += a2 - 2.0 * dl * a1 + cnt * dl * dl;
-  }
+  const double mean = (t1 + cnt * p1) / (cnt * cpg);
+  const double m2 = t2 - 2.0 * mean * t1 + 2.0 * u + cnt * (cpg * mean * mean - 2.0 * mean * p1 + p2);
   const float meanf = (float)mean;
   const float var = (float)(m2 / (cnt * cpg));
   // x / sqrt(mean(x^2) + eps): division by the sqrt, as in resnet.py:40.
   const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    mu[(int64_t)n * C + c] = meanf;
-    sc[(int64_t)n * C + c] = rstd * gamma[c];
+  for (int cc = lane; cc < cpg; cc += 64) {
+    mu[(int64_t)n * C + c_lo + cc] = meanf;
+    sc[(int64_t)n * C + c_lo + cc] = rstd * gamma[c_lo + cc];
   }
 }
 
@@ -268,7 +280,7 @@ extern "C" int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, 
   hipLaunchKernelGGL(gn_partial_kernel, dim3(pl.S, N, nchunks), dim3(256), 0, s, x, HW, C,
                      C_stride, relu_first, pl.ppb, partial);
   SNAP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv(N * groups, 64)), dim3(64), 0, s,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv(N * groups, 4)), dim3(256), 0, s,
                      x, (const float*)partial, pl.S, HW, C, C_stride, groups, relu_first, eps,
                      gamma, mu, sc, N * groups);
   SNAP_CHECK_LAUNCH();

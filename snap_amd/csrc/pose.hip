@@ -321,6 +321,22 @@ __global__ void pose_table_kernel(const float* __restrict__ poses, int64_t total
   reinterpret_cast<f32x4*>(table)[i] = t;
 }
 
+// Same poses as affine maps in CELL units, half-cell shift folded in:
+//   cu = A*qx - B*qy + Cx,  cv = B*qx + A*qy + Cy   with A = cos/cell, B = sin/cell,
+//   Cx = tx/cell - 0.5, Cy = ty/cell - 0.5.
+// (Transform2D.transform followed by "/ cell_size" and the "- 0.5" of interpolate_nd,
+// pose_estimation.py:74 + grids.py:129, re-associated: <= 1 ulp on the coordinate.)
+__global__ void pose_table_cells_kernel(const float* __restrict__ poses, int64_t total,
+                                        float cell, float* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float th = poses[i * 3 + 0];
+  f32x4 t;
+  t[0] = cosf(th) / cell; t[1] = sinf(th) / cell;
+  t[2] = poses[i * 3 + 1] / cell - 0.5f; t[3] = poses[i * 3 + 2] / cell - 0.5f;
+  reinterpret_cast<f32x4*>(table)[i] = t;
+}
+
 template <int PPT, bool MASK, bool BANDS>
 __global__ __launch_bounds__(PS_THREADS) void pose_score_kernel(const ScoreArgs a) {
   extern __shared__ float plane[];
@@ -467,10 +483,8 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
     const float qy = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-      const float xm = (pc[k] * qx - ps[k] * qy) + ptx[k];
-      const float ym = (ps[k] * qx + pc[k] * qy) + pty[k];
-      const float u = xm / a.cell, v = ym / a.cell;
-      const float cu = u - 0.5f, cv = v - 0.5f;
+      const float cu = fmaf(pc[k], qx, fmaf(-ps[k], qy, ptx[k]));
+      const float cv = fmaf(ps[k], qx, fmaf(pc[k], qy, pty[k]));
       const float fu = floorf(cu), fv = floorf(cv);
       const int i0 = (int)fminf(fmaxf(fu, 0.f), Xf - 1.f);
       const int i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), Xf - 1.f);
@@ -484,6 +498,7 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
           (((wu0 * wv0) * s00 + (wu0 * wv1) * s01) + (wu1 * wv0) * s10) + (wu1 * wv1) * s11;
       bool ok = true;
       if (MASK) {
+        const float u = cu + 0.5f, v = cv + 0.5f;
         ok = (u >= 0.f) && (u < Xf) && (v >= 0.f) && (v < Yf);
         ok = ok && mvalid[i0 * a.Y + j0] && mvalid[i0 * a.Y + j1] && mvalid[i1 * a.Y + j0] &&
              mvalid[i1 * a.Y + j1];
@@ -714,8 +729,13 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
         hipSuccess)
       return SNAP_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(pose_table_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)), dim3(256),
-                     0, s, poses, (int64_t)B * P, table);
+  if (use_db) {
+    hipLaunchKernelGGL(pose_table_cells_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)),
+                       dim3(256), 0, s, poses, (int64_t)B * P, cell_size, table);
+  } else {
+    hipLaunchKernelGGL(pose_table_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)),
+                       dim3(256), 0, s, poses, (int64_t)B * P, table);
+  }
   SNAP_CHECK_LAUNCH();
   {
     void* kargs[] = {(void*)&a};
