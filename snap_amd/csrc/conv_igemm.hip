@@ -69,8 +69,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int BROWS_PER_PASS = 256 / BQ;
   constexpr int BPASS = BK / BROWS_PER_PASS;  // float4 per thread for B
 
-  __shared__ float As[2][BK * AS];
-  __shared__ float Bs[2][BK * BN];
+  // one LDS block: the A/B slab ring during the main loop, then the staging buffer
+  // of the epilogue (64 x BN fp32) -- a single __shared__ object by design.
+  constexpr int kSlabFloats = 2 * BK * AS + 2 * BK * BN;
+  constexpr int kStageFloats = 64 * BN;
+  constexpr int kSmemFloats = kSlabFloats > kStageFloats ? kSlabFloats : kStageFloats;
+  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * BK * AS;
 
   const SnapConvDesc& d = a.d;
   const int tid = threadIdx.x;
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   };
 
   auto store_slab = [&](int buf) {
-    float* as = As[buf];
-    float* bs = Bs[buf];
+    float* as = As0 + buf * (BK * AS);
+    float* bs = Bs0 + buf * (BK * BN);
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
@@ -269,8 +275,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       load_slab(kt + 1);
       advance();
     }
-    const float* as = As[cur];
-    const float* bs = Bs[cur];
+    const float* as = As0 + cur * (BK * AS);
+    const float* bs = Bs0 + cur * (BK * BN);
     // LDS -> register operand fetch runs one k-pair ahead of the MFMAs.
     float av[2][TM], bv[2][TN];
 #pragma unroll
@@ -308,20 +314,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue ------------------------------------------------------------
+  // The MFMA C layout gives every lane one column of 16 rows: direct stores would be
+  // 4-byte scattered.  Instead each pass stages 64 rows x BN columns through LDS and
+  // writes them back as float4 rows (512 B contiguous per row for BN = 128); bias,
+  // residual, FPN up-sample-add, ReLU and the row mask are applied on the way out
+  // with float4 loads.  The final __syncthreads of the main loop already fenced the
+  // slab ring, so the buffer can be reused at once.
   const int epi = d.epilogue;
   const int Hp = d.Ho >> 1, Wp = d.Wo >> 1;
+  constexpr int Q = BN / 4;               // float4 per staged row
+  constexpr int PER_THREAD = (64 * Q) / 256;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int h = 0; h < TM; ++h) {
+    if (h > 0) __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const int m = m0 + wr * (BM / 2) + i * 32 + ri;
-      if (m >= a.M) continue;
-      const bool keep = (epi & SNAP_EPI_ROWMASK) ? (a.row_mask[m] != 0) : true;
-      // bilinear x2 taps of the coarser level (half-pixel centres, edge clamp)
-      int64_t u00 = 0, u01 = 0, u10 = 0, u11 = 0;
-      float wh_lo = 0.f, wh_hi = 0.f, ww_lo = 0.f, ww_hi = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        smem[(wr * 32 + ri) * BN + wc * (BN / 2) + j * 32 + l31] = acc[h][j][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PER_THREAD; ++it) {
+      const int idx = tid + 256 * it;
+      const int row = idx / Q, q = idx - row * Q;
+      const int m = m0 + (row >> 5) * (BM / 2) + h * 32 + (row & 31);
+      const int col = n0 + 4 * q;
+      if (m >= a.M || col >= d.Cout) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * BN + 4 * q);
+      const int64_t o = (int64_t)m * d.Cout_stride + col;
+      if (epi & SNAP_EPI_BIAS) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bb[e];
+      }
+      if (epi & SNAP_EPI_RESIDUAL) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rr[e];
+      }
       if (epi & SNAP_EPI_UPSAMPLE2X_ADD) {
+        // bilinear x2 of the coarser level (half-pixel centres, edge clamp)
         const int n = m / HoWo;
         const int rr = m - n * HoWo;
         const int ho = rr / d.Wo;
@@ -329,32 +363,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const float sh = (ho + 0.5f) * 0.5f - 0.5f;
         const float sw = (wo + 0.5f) * 0.5f - 0.5f;
         const float fh = floorf(sh), fw = floorf(sw);
-        wh_hi = sh - fh; wh_lo = 1.f - wh_hi;
-        ww_hi = sw - fw; ww_lo = 1.f - ww_hi;
+        const float wh_hi = sh - fh, wh_lo = 1.f - wh_hi;
+        const float ww_hi = sw - fw, ww_lo = 1.f - ww_hi;
         const int h0 = min(max((int)fh, 0), Hp - 1), h1 = min(max((int)fh + 1, 0), Hp - 1);
         const int w0 = min(max((int)fw, 0), Wp - 1), w1 = min(max((int)fw + 1, 0), Wp - 1);
         const int64_t base = (int64_t)n * Hp * Wp;
-        u00 = (base + (int64_t)h0 * Wp + w0) * d.Cout_stride;
-        u01 = (base + (int64_t)h0 * Wp + w1) * d.Cout_stride;
-        u10 = (base + (int64_t)h1 * Wp + w0) * d.Cout_stride;
-        u11 = (base + (int64_t)h1 * Wp + w1) * d.Cout_stride;
-      }
+        const f32x4 p00 = *reinterpret_cast<const f32x4*>(
+            a.up_prev + (base + (int64_t)h0 * Wp + w0) * d.Cout_stride + col);
+        const f32x4 p01 = *reinterpret_cast<const f32x4*>(
+            a.up_prev + (base + (int64_t)h0 * Wp + w1) * d.Cout_stride + col);
+        const f32x4 p10 = *reinterpret_cast<const f32x4*>(
+            a.up_prev + (base + (int64_t)h1 * Wp + w0) * d.Cout_stride + col);
+        const f32x4 p11 = *reinterpret_cast<const f32x4*>(
+            a.up_prev + (base + (int64_t)h1 * Wp + w1) * d.Cout_stride + col);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wc * (BN / 2) + j * 32 + l31;
-        if (col >= d.Cout) continue;
-        float v = acc[i][j][r];
-        if (epi & SNAP_EPI_BIAS) v += a.bias[col];
-        const int64_t o = (int64_t)m * d.Cout_stride + col;
-        if (epi & SNAP_EPI_RESIDUAL) v += a.residual[o];
-        if (epi & SNAP_EPI_UPSAMPLE2X_ADD) {
-          const float c0 = a.up_prev[u00 + col] * wh_lo + a.up_prev[u10 + col] * wh_hi;
-          const float c1 = a.up_prev[u01 + col] * wh_lo + a.up_prev[u11 + col] * wh_hi;
-          v += c0 * ww_lo + c1 * ww_hi;
+        for (int e = 0; e < 4; ++e) {
+          const float c0 = p00[e] * wh_lo + p10[e] * wh_hi;
+          const float c1 = p01[e] * wh_lo + p11[e] * wh_hi;
+          v[e] += c0 * ww_lo + c1 * ww_hi;
         }
-        if (epi & SNAP_EPI_RELU) v = fmaxf(v, 0.f);
-        a.y[o] = keep ? v : 0.f;
       }
+      if (epi & SNAP_EPI_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if ((epi & SNAP_EPI_ROWMASK) && a.row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(a.y + o) = v;
     }
   }
 }
@@ -414,7 +448,11 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
       d.KW <= 0 || d.stride <= 0 || d.Ho <= 0 || d.Wo <= 0)
     return SNAP_ERR_BAD_SHAPE;
   if (d.Cin_stride < d.Cin || d.Cout_stride < d.Cout) return SNAP_ERR_BAD_SHAPE;
-  if (d.Cout % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.Cout % 4 != 0 || d.Cout_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
+      (reinterpret_cast<uintptr_t>(bias) & 15) || (reinterpret_cast<uintptr_t>(residual) & 15) ||
+      (reinterpret_cast<uintptr_t>(up_prev) & 15))
+    return SNAP_ERR_BAD_SHAPE;
   if ((int64_t)d.N * d.Ho * d.Wo > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   const bool gn = d.prologue == SNAP_PRO_GN_RELU || d.prologue == SNAP_PRO_RELU_GN;
   if (d.prologue < 0 || d.prologue > SNAP_PRO_RELU) return SNAP_ERR_UNSUPPORTED;
