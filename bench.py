@@ -186,8 +186,8 @@ def cpu_baseline(cfg, meta, workload, budget_s=40.0):
 def main(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=5)
-  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
   ap.add_argument('--device', default='cuda')
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -222,15 +222,25 @@ def main(argv=None):
     step(i)
   barrier()
   prof = None
+  marks = []
   t0 = time.perf_counter()
   for i in range(args.steps):
     if use_cuda and rank == 0 and i == args.steps - 1:
       prof = ops.KernelProfiler()   # HIP events around every launch of the last step
       ops.set_profiler(prof)
+    if use_cuda:
+      ev = torch.cuda.Event(enable_timing=True)
+      ev.record()
+      marks.append(ev)
     pred = step(args.warmup + i)
   ops.set_profiler(None)
+  if use_cuda:
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    marks.append(ev)
   barrier()
   elapsed = time.perf_counter() - t0
+  step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
   t = torch.tensor([elapsed], dtype=torch.float64, device=device)
   if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -248,6 +258,10 @@ def main(argv=None):
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3),
+        'step_ms': {
+            'min': round(min(step_ms), 3), 'median': round(float(np.median(step_ms)), 3),
+            'max': round(max(step_ms), 3),
+        } if step_ms else None,
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,

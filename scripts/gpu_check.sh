@@ -28,7 +28,7 @@ for s in $STAGES; do
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
       echo "== smoke =="; tail -5 gpurun_out/smoke.log ;;
     bench)
-      SNAP_BENCH_DUMP=gpurun_out/launches.json timeout 1200 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1
+      SNAP_BENCH_DUMP=gpurun_out/launches.json timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
       echo "== bench =="; tail -5 gpurun_out/bench.log ;;
     prof)
       rm -rf gpurun_out/prof
