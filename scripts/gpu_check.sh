@@ -30,6 +30,9 @@ for s in $STAGES; do
     bench)
       SNAP_BENCH_DUMP=gpurun_out/launches.json timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
       echo "== bench =="; tail -5 gpurun_out/bench.log ;;
+    bench32)
+      SNAP_CONV_BK=32 SNAP_BENCH_DUMP=gpurun_out/launches32.json timeout 1200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench32.log 2>&1
+      echo "== bench BK=32 =="; tail -5 gpurun_out/bench32.log | cut -c1-1500 ;;
     prof)
       rm -rf gpurun_out/prof
       (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o snap -- \

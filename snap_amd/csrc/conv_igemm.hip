@@ -22,6 +22,9 @@
 // snap/models/resnet.py:83-132,200-215, image_encoder.py:67-94, layers.py:66-77,
 // streetview_encoder.py:228,281, bev_mapper.py:285 and the direct correlation of
 // pose_exhaustive_voting.py:86-91.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -44,7 +47,6 @@ struct ConvArgs {
   int nk;      // number of K slabs
 };
 
-constexpr int BK = 16;
 
 // The prologue is a COMPILE-TIME parameter: a run-time switch here is lowered to a
 // branch tree per staged element and wrecks the schedule of the whole main loop.
@@ -58,13 +60,16 @@ __device__ __forceinline__ float apply_pro(float v, float mu, float sc, float be
   return v;
 }
 
-template <int BM, int BN, bool VEC, int PRO>
+template <int BM, int BN, bool VEC, int PRO, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int AS = BM + 2;    // LDS row stride of the K-major A slab
   constexpr int TM = BM / 64;   // 32x32 MFMA tiles per wave along M
   constexpr int TN = BN / 64;   // ... along N
-  constexpr int AROWS = BM / 64;          // VEC: float4 rows per thread
-  constexpr int AELEMS = BM / 16;         // SCALAR: scalars per thread
+  constexpr int QPR = BK / 4;             // VEC: float4 quads per A row of the slab
+  constexpr int RPP = 256 / QPR;          // VEC: rows staged per pass
+  constexpr int AROWS = BM / RPP;         // VEC: float4 rows per thread
+  constexpr int SRPP = 256 / BK;          // SCALAR: rows staged per pass
+  constexpr int AELEMS = BM / SRPP;       // SCALAR: scalars per thread
   constexpr int BQ = BN / 4;              // float4 per B row
   constexpr int BROWS_PER_PASS = 256 / BQ;
   constexpr int BPASS = BK / BROWS_PER_PASS;  // float4 per thread for B
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   int64_t r_gn[NR];        // n * Cin  (GroupNorm statistics row)
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
-    const int row = VEC ? (tid >> 2) + 64 * i : (tid >> 4) + 16 * i;
+    const int row = VEC ? (tid / QPR) + RPP * i : (tid / BK) + SRPP * i;
     const int m = m0 + row;
     r_ok[i] = m < a.M;
     const int mm = r_ok[i] ? m : 0;
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     r_px[i] = a.x + (((int64_t)n * d.H + r_hb[i]) * d.W + r_wb[i]) * d.Cin_stride;
     r_gn[i] = (int64_t)n * d.Cin;
   }
-  const int akq = tid & 3;    // VEC: which float4 of the 16-wide K slab
-  const int akid = tid & 15;  // SCALAR: which k of the slab
+  const int akq = tid % QPR;  // VEC: which float4 of the BK-wide K slab
+  const int akid = tid % BK;  // SCALAR: which k of the slab
 
   // B loader coordinates
   const int bcq = tid % BQ;
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
-        const int row = (tid >> 2) + 64 * i;
+        const int row = (tid / QPR) + RPP * i;
         f32x4 v = xa[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     } else {
 #pragma unroll
       for (int i = 0; i < AELEMS; ++i) {
-        const int row = (tid >> 4) + 16 * i;
+        const int row = (tid / BK) + SRPP * i;
         float pv;
         if constexpr (need_gn)
           pv = apply_pro<PRO>(sa[i], smu[i], ssc[i], sbeta, d.in_scale, d.in_shift);
@@ -393,29 +398,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, bool VEC, int PRO>
-int launch(const ConvArgs& a, hipStream_t s) {
+template <int BM, int BN, bool VEC, int PRO, int BK>
+int launch(ConvArgs a, hipStream_t s) {
+  if (VEC) {
+    a.ctiles = (a.d.Cin + BK - 1) / BK;
+    a.nk = a.d.KH * a.d.KW * a.ctiles;
+  } else {
+    a.ctiles = 0;
+    a.nk = (a.K + BK - 1) / BK;
+  }
   dim3 grid((unsigned)snap_cdiv(a.M, BM), (unsigned)snap_cdiv(a.d.Cout, BN));
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO, BK>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, int BK>
 int launch_pro(const ConvArgs& a, hipStream_t s) {
   switch (a.d.prologue) {
-    case SNAP_PRO_NONE: return launch<BM, BN, VEC, SNAP_PRO_NONE>(a, s);
-    case SNAP_PRO_AFFINE: return launch<BM, BN, VEC, SNAP_PRO_AFFINE>(a, s);
+    case SNAP_PRO_NONE: return launch<BM, BN, VEC, SNAP_PRO_NONE, BK>(a, s);
+    case SNAP_PRO_AFFINE: return launch<BM, BN, VEC, SNAP_PRO_AFFINE, BK>(a, s);
     case SNAP_PRO_GN_RELU:
       // the scalar (unaligned / Cin % 4 != 0) path carries no GroupNorm variant.
-      if constexpr (VEC) return launch<BM, BN, VEC, SNAP_PRO_GN_RELU>(a, s);
+      if constexpr (VEC) return launch<BM, BN, VEC, SNAP_PRO_GN_RELU, BK>(a, s);
       return SNAP_ERR_UNSUPPORTED;
     case SNAP_PRO_RELU_GN:
-      if constexpr (VEC) return launch<BM, BN, VEC, SNAP_PRO_RELU_GN>(a, s);
+      if constexpr (VEC) return launch<BM, BN, VEC, SNAP_PRO_RELU_GN, BK>(a, s);
       return SNAP_ERR_UNSUPPORTED;
-    case SNAP_PRO_RELU: return launch<BM, BN, VEC, SNAP_PRO_RELU>(a, s);
+    case SNAP_PRO_RELU: return launch<BM, BN, VEC, SNAP_PRO_RELU, BK>(a, s);
     default: return SNAP_ERR_UNSUPPORTED;
   }
+}
+
+// K-slab depth of the big tiles (SNAP_CONV_BK=16|32, tuning knob; default set by
+// measurement on MI355X).
+inline int conv_bk() {
+  const char* e = getenv("SNAP_CONV_BK");
+  return (e && atoi(e) == 32) ? 32 : 16;
+}
+
+// SNAP_CONV_TILE=128x128|128x64|64x128|64x64 forces a tile (tests / tuning).
+inline int conv_forced_tile() {
+  const char* e = getenv("SNAP_CONV_TILE");
+  if (!e) return 0;
+  int bm = 0, bn = 0;
+  if (sscanf(e, "%dx%d", &bm, &bn) != 2) return 0;
+  return bm * 1000 + bn;
 }
 
 // Tile choice: the largest tile that still yields >= 2 workgroups per CU; small-M
@@ -425,13 +453,24 @@ int launch_tile(const ConvArgs& a, hipStream_t s) {
   const int64_t M = a.M, N = a.d.Cout;
   const int64_t kMin = 512;
   const bool n_wide_ok = N > 64 && !(N % 128 != 0 && N % 128 <= 64);
-  if (n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin)
-    return launch_pro<128, 128, VEC>(a, s);
-  if (snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)
-    return launch_pro<128, 64, VEC>(a, s);
-  if (n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin)
-    return launch_pro<64, 128, VEC>(a, s);
-  return launch_pro<64, 64, VEC>(a, s);
+  const bool deep = VEC && conv_bk() == 32 && a.d.Cin >= 32;
+  const int forced = conv_forced_tile();
+  if (forced == 128128 || (!forced && n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin)) {
+    if constexpr (VEC) {
+      if (deep) return launch_pro<128, 128, VEC, 32>(a, s);
+    }
+    return launch_pro<128, 128, VEC, 16>(a, s);
+  }
+  if (forced == 128064 || (!forced && snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)) {
+    if constexpr (VEC) {
+      if (deep) return launch_pro<128, 64, VEC, 32>(a, s);
+    }
+    return launch_pro<128, 64, VEC, 16>(a, s);
+  }
+  if (forced == 64128 ||
+      (!forced && n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin))
+    return launch_pro<64, 128, VEC, 16>(a, s);
+  return launch_pro<64, 64, VEC, 16>(a, s);
 }
 
 }  // namespace
@@ -475,13 +514,8 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
   const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
                    ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                    (!gn || (d.Cin % 4 == 0));
-  if (vec) {
-    a.ctiles = (d.Cin + BK - 1) / BK;
-    a.nk = d.KH * d.KW * a.ctiles;
-  } else {
-    a.ctiles = 0;
-    a.nk = (a.K + BK - 1) / BK;
-  }
+  a.ctiles = 0;
+  a.nk = 0;  // set per K-slab depth in launch<>
   hipStream_t s = static_cast<hipStream_t>(stream);
   return vec ? launch_tile<true>(a, s) : launch_tile<false>(a, s);
 }

@@ -70,6 +70,35 @@ def test_conv_plain(case):
   helpers.report('conv ' + case[0], got, want, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('tile', ['128x128', '128x64', '64x128', '64x64'])
+@pytest.mark.parametrize('bk', ['16', '32'])
+def test_conv_every_tile_variant(tile, bk, monkeypatch):
+  """Force each (tile, K-slab depth) instantiation of the engine on shapes with
+  M / N / K tails, a GroupNorm prologue and residual + bias + ReLU epilogues."""
+  monkeypatch.setenv('SNAP_CONV_TILE', tile)
+  monkeypatch.setenv('SNAP_CONV_BK', bk)
+  N, H, W, Cin, Cout = 2, 15, 13, 96, 200
+  x = rnd((N, H, W, Cin), 31) + 0.2
+  w = rnd((3, 3, Cin, Cout), 32, 1 / np.sqrt(9 * Cin))
+  gamma, beta = rnd((Cin,), 33) + 1, rnd((Cin,), 34) * 0.1
+  mu, sc = oracle_ops.group_norm_stats(x, gamma)
+  res = rnd((N, H, W, Cout), 35)
+  bias = rnd((Cout,), 36)
+  kw = dict(padding=((1, 1), (1, 1)), prologue=ops.PRO_GN_RELU, gn=(mu, sc, beta), residual=res,
+            bias=bias, relu=True)
+  got, want = both('conv2d', (x, w), kw)
+  helpers.report(f'conv tile {tile} bk {bk}', got, want, atol=5e-5, rtol=1e-5)
+  xs = rnd((1, 1, 700, 260), 37)
+  ws = rnd((1, 1, 257, 256), 38, 1 / 16.0)
+  got, want = both('conv2d', (xs, ws), dict(cin=257))
+  helpers.report(f'dense k257 tile {tile} bk {bk}', got, want, atol=5e-5, rtol=1e-5)
+  x3 = torch.rand((1, 20, 18, 3), generator=torch.Generator().manual_seed(39))
+  w3 = rnd((7, 7, 3, 64), 40, 0.1)
+  got, want = both('conv2d', (x3, w3), dict(stride=2, padding=((3, 3), (3, 3)),
+                                            prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0)))
+  helpers.report(f'scalar path tile {tile}', got, want, atol=5e-5, rtol=1e-5)
+
+
 def test_conv_affine_root():
   x = torch.rand((2, 20, 18, 3), generator=torch.Generator().manual_seed(3))
   w = rnd((7, 7, 3, 64), 4, 0.1)
