@@ -24,6 +24,9 @@ for s in $STAGES; do
       echo "##### model" >> gpurun_out/tests.log
       timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q --timeout=600 2>&1 | tail -60 >> gpurun_out/tests.log
       echo "== tests (grouped) =="; grep -E "#####|passed|failed|error|Error|assert|beyond|mismatch|Fault|fault|Abort" gpurun_out/tests.log | head -120 ;;
+    extra)
+      timeout 1500 python -m pytest tests/test_golden.py tests/test_gpu_fullsize.py -m gpu -q --timeout=900 2>&1 | tail -60 > gpurun_out/tests_extra.log
+      echo "== golden + full-size =="; tail -40 gpurun_out/tests_extra.log ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
       echo "== smoke =="; tail -5 gpurun_out/smoke.log ;;
