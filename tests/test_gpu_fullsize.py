@@ -62,7 +62,9 @@ def test_pose_score_full_size_properties(X, Y, Nq, P):
   assert ops.argmax_rows(s1).cpu().tolist() == planted
   # exact linearity under a power-of-two scale (fp32 scaling by 2 is exact)
   s2 = ops.pose_score((sim * 2).contiguous(), poses.contiguous(), q_xy, valid_q, mv, cell)
-  assert torch.equal(s2, s1 * 2)
+  big = s1.abs() > 1e-20          # (denormal tap products are not exactly scalable)
+  assert torch.equal(s2[big], (s1 * 2)[big])
+  assert torch.allclose(s2, s1 * 2, rtol=1e-5, atol=1e-30)
   # additivity over a split of the query points
   va = valid_q.clone(); va[:, : Nq // 2] = False
   vb = valid_q & ~va
