@@ -45,6 +45,7 @@ struct ConvArgs {
   int K;       // KH*KW*Cin
   int ctiles;  // ceil(Cin/16)   (VEC path)
   int nk;      // number of K slabs
+  int prio;    // experiment knob: s_setprio(1) around the MFMA block
 };
 
 
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
     const float* as = As0 + cur * (BK * AS);
     const float* bs = Bs0 + cur * (BK * BN);
+    if (a.prio) __builtin_amdgcn_s_setprio(1);
     // LDS -> register operand fetch runs one k-pair ahead of the MFMAs.
     float av[2][TM], bv[2][TN];
 #pragma unroll
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
     if (more) store_slab(cur ^ 1);
     __syncthreads();
   }
@@ -516,6 +519,10 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
                    (!gn || (d.Cin % 4 == 0));
   a.ctiles = 0;
   a.nk = 0;  // set per K-slab depth in launch<>
+  {
+    const char* e = getenv("SNAP_CONV_PRIO");
+    a.prio = (e && e[0] == '1') ? 1 : 0;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   return vec ? launch_tile<true>(a, s) : launch_tile<false>(a, s);
 }
