@@ -194,10 +194,17 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
     const float* r10 = img + ((int64_t)tp[r].i1 * d.w + tp[r].j0) * d.C;
     const float* r11 = img + ((int64_t)tp[r].i1 * d.w + tp[r].j1) * d.C;
     const int ql = (hl < nq) ? hl : 0;
-    tap[r][0] = *reinterpret_cast<const f32x4*>(r00 + 4 * ql);
-    tap[r][1] = *reinterpret_cast<const f32x4*>(r01 + 4 * ql);
-    tap[r][2] = *reinterpret_cast<const f32x4*>(r10 + 4 * ql);
-    tap[r][3] = *reinterpret_cast<const f32x4*>(r11 + 4 * ql);
+    // invisible observations are skipped (half-wave uniform): at C2 a voxel is seen
+    // by ~1-2 of its 4 views, so this halves the gather traffic.
+    if (ok[r]) {
+      tap[r][0] = *reinterpret_cast<const f32x4*>(r00 + 4 * ql);
+      tap[r][1] = *reinterpret_cast<const f32x4*>(r01 + 4 * ql);
+      tap[r][2] = *reinterpret_cast<const f32x4*>(r10 + 4 * ql);
+      tap[r][3] = *reinterpret_cast<const f32x4*>(r11 + 4 * ql);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tap[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // depth score: two neighbouring log-depth bins, each bilinearly gathered.
     const float dc = fminf(fmaxf(depth, d.depth_min), d.depth_max);
     const float tt = logf(dc / d.depth_min) / log_range;
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
     const int b1 = (int)fminf(fmaxf(fl + 1.f, 0.f), (float)(d.num_bins - 1));
     const int st = (hl >> 1) & 3;                 // tap handled by this lane
     const float* rt = st == 0 ? r00 : (st == 1 ? r01 : (st == 2 ? r10 : r11));
-    sval[r] = rt[fd + ((hl & 1) ? b1 : b0)];
+    sval[r] = ok[r] ? rt[fd + ((hl & 1) ? b1 : b0)] : 0.f;
   }
 #pragma unroll
   for (int r = 0; r < KMAX; ++r) {
