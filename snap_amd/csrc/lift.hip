@@ -165,45 +165,39 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
   }
 
   // ---- k3/k4: gather selected observations ----------------------------------
-  // Two stages for memory-level parallelism: (1) issue EVERY load of every selected
-  // view (4 feature taps as float4 per lane + one scalar per lane for the 8 depth-
-  // score values: lane l < 8 fetches tap l>>1 of bin l&1), addresses clamped so the
-  // loads are unconditional; (2) combine.  One memory round trip per voxel instead of
-  // 2 x K serialised ones.
   f32x4 feat[KMAX];
   float score[KMAX];
   bool ok[KMAX];
   bool any = false;
   const float log_range = logf(d.depth_max / d.depth_min);
-  f32x4 tap[KMAX][4];
-  float sval[KMAX];
-  Taps tp[KMAX];
-  float wb1[KMAX];
 #pragma unroll
   for (int r = 0; r < KMAX; ++r) {
-    const int v = (r < nsel) ? sel[r] : 0;
+    feat[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    score[r] = 0.f;
+    ok[r] = false;
+    if (r >= nsel) continue;
+    const int v = sel[r];
     const float pi = __shfl(pr.pi, v, 32);
     const float pj = __shfl(pr.pj, v, 32);
     const float depth = __shfl(pr.depth, v, 32);
-    ok[r] = (r < nsel) && (__shfl((int)pr.vis, v, 32) != 0);
-    any = any || ok[r];
-    tp[r] = make_taps(pi, pj, d.h, d.w, all_views ? 0 : 1);
+    const bool vis = __shfl((int)pr.vis, v, 32) != 0;
+    ok[r] = vis;
+    if (!vis) continue;  // half-wave uniform
+    any = true;
+    const Taps t = make_taps(pi, pj, d.h, d.w, all_views ? 0 : 1);
     const float* img = a.f + ((int64_t)b * d.V + v) * d.h * d.w * d.C;
-    const float* r00 = img + ((int64_t)tp[r].i0 * d.w + tp[r].j0) * d.C;
-    const float* r01 = img + ((int64_t)tp[r].i0 * d.w + tp[r].j1) * d.C;
-    const float* r10 = img + ((int64_t)tp[r].i1 * d.w + tp[r].j0) * d.C;
-    const float* r11 = img + ((int64_t)tp[r].i1 * d.w + tp[r].j1) * d.C;
-    const int ql = (hl < nq) ? hl : 0;
-    // invisible observations are skipped (half-wave uniform): at C2 a voxel is seen
-    // by ~1-2 of its 4 views, so this halves the gather traffic.
-    if (ok[r]) {
-      tap[r][0] = *reinterpret_cast<const f32x4*>(r00 + 4 * ql);
-      tap[r][1] = *reinterpret_cast<const f32x4*>(r01 + 4 * ql);
-      tap[r][2] = *reinterpret_cast<const f32x4*>(r10 + 4 * ql);
-      tap[r][3] = *reinterpret_cast<const f32x4*>(r11 + 4 * ql);
-    } else {
+    const float* r00 = img + ((int64_t)t.i0 * d.w + t.j0) * d.C;
+    const float* r01 = img + ((int64_t)t.i0 * d.w + t.j1) * d.C;
+    const float* r10 = img + ((int64_t)t.i1 * d.w + t.j0) * d.C;
+    const float* r11 = img + ((int64_t)t.i1 * d.w + t.j1) * d.C;
+    if (hl < nq) {
+      const f32x4 a00 = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
+      const f32x4 a01 = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
+      const f32x4 a10 = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
+      const f32x4 a11 = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) tap[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < 4; ++e)
+        feat[r][e] = ((t.w00 * a00[e] + t.w01 * a01[e]) + t.w10 * a10[e]) + t.w11 * a11[e];
     }
     // depth score: two neighbouring log-depth bins, each bilinearly gathered.
     const float dc = fminf(fmaxf(depth, d.depth_min), d.depth_max);
@@ -211,33 +205,13 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
     const float index = 0.5f + tt * (float)(d.num_bins - 1);
     const float c = index - 0.5f;
     const float fl = floorf(c);
-    wb1[r] = c - fl;
+    const float wb1 = c - fl, wb0 = 1.f - wb1;
     const int b0 = (int)fminf(fmaxf(fl, 0.f), (float)(d.num_bins - 1));
     const int b1 = (int)fminf(fmaxf(fl + 1.f, 0.f), (float)(d.num_bins - 1));
-    const int st = (hl >> 1) & 3;                 // tap handled by this lane
-    const float* rt = st == 0 ? r00 : (st == 1 ? r01 : (st == 2 ? r10 : r11));
-    sval[r] = ok[r] ? rt[fd + ((hl & 1) ? b1 : b0)] : 0.f;
-  }
-#pragma unroll
-  for (int r = 0; r < KMAX; ++r) {
-    const Taps& t = tp[r];
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      feat[r][e] = ((t.w00 * tap[r][0][e] + t.w01 * tap[r][1][e]) + t.w10 * tap[r][2][e]) +
-                   t.w11 * tap[r][3][e];
-    // s_bin = ((w00*v00 + w01*v01) + w10*v10) + w11*v11 with the four taps on lanes
-    // bin + {0,2,4,6}; gathered by shuffles so the summation order is the oracle's.
-    const float v00_0 = __shfl(sval[r], 0, 32), v01_0 = __shfl(sval[r], 2, 32);
-    const float v10_0 = __shfl(sval[r], 4, 32), v11_0 = __shfl(sval[r], 6, 32);
-    const float v00_1 = __shfl(sval[r], 1, 32), v01_1 = __shfl(sval[r], 3, 32);
-    const float v10_1 = __shfl(sval[r], 5, 32), v11_1 = __shfl(sval[r], 7, 32);
-    const float s0 = ((t.w00 * v00_0 + t.w01 * v01_0) + t.w10 * v10_0) + t.w11 * v11_0;
-    const float s1 = ((t.w00 * v00_1 + t.w01 * v01_1) + t.w10 * v10_1) + t.w11 * v11_1;
-    score[r] = (1.f - wb1[r]) * s0 + wb1[r] * s1;
-    if (!ok[r]) {
-      feat[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-      score[r] = 0.f;
-    }
+    const int c0 = fd + b0, c1 = fd + b1;
+    const float s0 = ((t.w00 * r00[c0] + t.w01 * r01[c0]) + t.w10 * r10[c0]) + t.w11 * r11[c0];
+    const float s1 = ((t.w00 * r00[c1] + t.w01 * r01[c1]) + t.w10 * r10[c1]) + t.w11 * r11[c1];
+    score[r] = wb0 * s0 + wb1 * s1;
   }
 
   // ---- k5: softmax-weighted mean / variance / max score ---------------------
