@@ -1,0 +1,112 @@
+"""Data-parallel exchange step of the training loop (the only collective of the path).
+
+The reference shards scenes over devices with ``jax.pmap(axis_name='batch')`` and has
+exactly three cross-device operations:
+  * ``jax.lax.pmean(grad, 'batch')``            snap/trainer.py:225-234
+  * the finite flag of ``DynamicScale`` / the non-finite step skip   :223-229,:260-277
+  * ``psum`` of (sum(metric), count) pairs      snap/trainer.py:57-67
+Here: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over xGMI
+on ROCm; "gloo" on CPU for tests).  Gradients are packed into a few large flat fp32
+buckets -- xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring
+all-reduce is per-link bound and wants few, large messages: the ~48 M-parameter
+model is ~193 MB = 3 buckets of 64 MiB.  Inference needs no collective at all.
+"""
+from typing import Dict, Iterable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def _world(group=None):
+  if not (dist.is_available() and dist.is_initialized()):
+    return 1
+  return dist.get_world_size(group)
+
+
+def flatten_tree(tree, prefix=''):
+  """Nested dict of tensors -> list of (name, tensor) in a deterministic order."""
+  out = []
+  if isinstance(tree, dict):
+    for k in sorted(tree):
+      out.extend(flatten_tree(tree[k], f'{prefix}/{k}' if prefix else k))
+  elif tree is not None:
+    out.append((prefix, tree))
+  return out
+
+
+def allreduce_mean_(tensors: Iterable[torch.Tensor], group=None,
+                    bucket_bytes: int = 64 << 20) -> int:
+  """In-place mean over ranks of every tensor (``pmean``), bucketed.
+
+  Returns the number of all-reduce calls issued.  Tensors of one call must share a
+  device; fp32 accumulation (lower-precision grads are up-cast in the bucket).
+  """
+  tensors = [t for t in tensors if t is not None]
+  world = _world(group)
+  if world == 1 or not tensors:
+    return 0
+  calls = 0
+  bucket: List[torch.Tensor] = []
+  size = 0
+
+  def flush():
+    nonlocal bucket, size, calls
+    if not bucket:
+      return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in bucket])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    off = 0
+    for t in bucket:
+      n = t.numel()
+      t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+      off += n
+    calls += 1
+    bucket, size = [], 0
+
+  for t in tensors:
+    nbytes = t.numel() * 4
+    if bucket and size + nbytes > bucket_bytes:
+      flush()
+    bucket.append(t)
+    size += nbytes
+  flush()
+  return calls
+
+
+def allreduce_mean_tree_(grads: Dict, group=None, bucket_bytes: int = 64 << 20) -> int:
+  """``pmean`` of a nested gradient dict (the Flax param tree layout)."""
+  return allreduce_mean_([t for _, t in flatten_tree(grads)], group, bucket_bytes)
+
+
+def all_finite(tensors: Iterable[torch.Tensor], group=None) -> bool:
+  """True iff every element on every rank is finite (trainer.py:260-266)."""
+  tensors = [t for t in tensors if t is not None]
+  ok = torch.ones((), dtype=torch.float32, device=tensors[0].device if tensors else 'cpu')
+  for t in tensors:
+    ok = ok * torch.isfinite(t).all().to(torch.float32)
+  if _world(group) > 1:
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+  return bool(ok.item() > 0)
+
+
+def psum_metric_normalizer(metrics: Dict[str, Tuple[torch.Tensor, torch.Tensor]], group=None):
+  """Sum (sum(metric), count) pairs over ranks (trainer.py:57-67); one collective."""
+  if not metrics:
+    return {}
+  keys = sorted(metrics)
+  flat = torch.stack([
+      torch.stack([metrics[k][0].to(torch.float64).sum(), metrics[k][1].to(torch.float64).sum()])
+      for k in keys
+  ])
+  if _world(group) > 1:
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+  return {k: (flat[i, 0], flat[i, 1]) for i, k in enumerate(keys)}
+
+
+def reduce_batch_metrics(metrics: Dict[str, torch.Tensor], batch_mask: torch.Tensor, group=None):
+  """Per-example metric vectors [B] -> global masked means (trainer.py:57-67,258)."""
+  m = batch_mask.to(torch.float64)
+  pairs = {k: ((v.to(torch.float64) * m).sum(), m.sum()) for k, v in metrics.items()}
+  summed = psum_metric_normalizer(pairs, group)
+  return {k: float(s / torch.clamp(c, min=1.0)) for k, (s, c) in summed.items()}

@@ -51,3 +51,16 @@ def test_bench_rejects_world_size_mismatch():
       env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')},
   )
   assert out.returncode != 0 and 'WORLD_SIZE' in (out.stderr + out.stdout)
+
+
+def test_gradient_and_metric_sync_two_ranks_gloo():
+  """snap_amd.dist: bucketed pmean of a gradient tree, finite flag, metric psum
+  (the exchange step of snap/trainer.py:57-67,225-234,260-277)."""
+  cmd = [
+      sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+      '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+      os.path.join(ROOT, 'tests', 'dist_sync_driver.py'),
+  ]
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-3000:]
+  assert 'DIST_SYNC_OK' in out.stdout
