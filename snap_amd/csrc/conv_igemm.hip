@@ -46,6 +46,7 @@ struct ConvArgs {
   int ctiles;  // ceil(Cin/16)   (VEC path)
   int nk;      // number of K slabs
   int prio;    // experiment knob: s_setprio(1) around the MFMA block
+  int ablate;  // tuning-only: bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads
 };
 
 
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   for (int kt = 0; kt < a.nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < a.nk;
-    if (more) {
+    if (more && !(a.ablate & 1)) {
       load_slab(kt + 1);
       advance();
     }
@@ -317,8 +318,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     if (a.prio) __builtin_amdgcn_s_setprio(0);
-    if (more) store_slab(cur ^ 1);
-    __syncthreads();
+    if (!(a.ablate & 2)) {
+      if (more) store_slab(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------
@@ -522,6 +525,8 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
   {
     const char* e = getenv("SNAP_CONV_PRIO");
     a.prio = (e && e[0] == '1') ? 1 : 0;
+    const char* ab = getenv("SNAP_CONV_ABLATE");   // timing experiments only (wrong results)
+    a.ablate = ab ? atoi(ab) : 0;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   return vec ? launch_tile<true>(a, s) : launch_tile<false>(a, s);
