@@ -46,6 +46,7 @@ struct ConvArgs {
   int ctiles;  // ceil(Cin/16)   (VEC path)
   int nk;      // number of K slabs
   int prio;    // experiment knob: s_setprio(1) around the MFMA block
+  int ncol;    // number of column tiles (set in launch<>)
   int ablate;  // tuning-only: bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads
 };
 
@@ -90,8 +91,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs, each
+  // with a private L2): row-tile r lives on XCD r % 8 and ALL its column tiles run
+  // back to back on that XCD, so the A rows (and 3x3 halos of the next row tile of
+  // the same XCD) are re-read from its L2 instead of HBM.  A pure speed mapping.
+  const int ncol = a.ncol;
+  const int xcd = blockIdx.x & 7;
+  const int seq = blockIdx.x >> 3;
+  const int col_t = seq % ncol;
+  const int row_t = (seq / ncol) * 8 + xcd;
+  if (row_t * BM >= a.M) return;   // padding blocks of the last row group (uniform per block)
+  const int m0 = row_t * BM;
+  const int n0 = col_t * BN;
   const int HoWo = d.Ho * d.Wo;
   constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
 
@@ -413,8 +424,12 @@ int launch(ConvArgs a, hipStream_t s) {
     a.ctiles = 0;
     a.nk = (a.K + BK - 1) / BK;
   }
-  dim3 grid((unsigned)snap_cdiv(a.M, BM), (unsigned)snap_cdiv(a.d.Cout, BN));
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO, BK>), grid, dim3(256), 0, s, a);
+  const int64_t nrow = snap_cdiv(a.M, BM);
+  a.ncol = (int)snap_cdiv(a.d.Cout, BN);
+  const int64_t nblocks = snap_cdiv(nrow, 8) * 8 * a.ncol;
+  if (nblocks > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO, BK>), dim3((unsigned)nblocks), dim3(256),
+                     0, s, a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
