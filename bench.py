@@ -71,6 +71,23 @@ def _to(tree, device):
   return tree.to(device)
 
 
+def _pmc_traffic(kernel, launches, workload):
+  """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+  (profiles/r01_c2_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate
+  passes on this workload, gfx950 x2 read correction applied).  None if unavailable."""
+  if workload != 'c2':
+    return None
+  path = os.path.join(ROOT, 'profiles', 'r01_c2_hbm_traffic.json')
+  try:
+    with open(path) as f:
+      rec = json.load(f)['per_step'].get(kernel)
+  except (OSError, ValueError, KeyError):
+    return None
+  if not rec or not launches:
+    return None
+  return round((rec['hbm_read_bytes'] + rec['hbm_write_bytes']) / launches, 1)
+
+
 def _sync(device):
   if device.type == 'cuda':
     torch.cuda.synchronize()
@@ -292,7 +309,10 @@ def main(argv=None):
         out['roofline'] = {
             'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2),
             'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4), 'traffic': None,
+            'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+            'traffic': _pmc_traffic(dom, s['launches'], args.workload),
+            'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, separate passes; profiles/)',
+            'algorithmic_bytes_per_launch': round(s['bytes'] / s['launches'], 1),
             'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
             'flops_per_step': s['flops'],
         }
@@ -300,7 +320,8 @@ def main(argv=None):
         ach = s['bytes'] / s['ms'] / 1e6
         out['roofline'] = {
             'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS,
-            'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+            'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
+            'traffic': _pmc_traffic(dom, s['launches'], args.workload),
             'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
         }
       if 'pose_score' in summ:
@@ -309,7 +330,8 @@ def main(argv=None):
         out['roofline_pose_corr'] = {
             'kernel': 'pose_score', 'bound': 'hbm', 'achieved': round(ach, 1),
             'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
-            'traffic': None, 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
+            'traffic': _pmc_traffic('pose_score', s['launches'], args.workload),
+            'avg_launch_ms': round(s['ms'] / s['launches'], 4),
             'bytes_per_launch': s['bytes'] / s['launches'],
         }
       out['kernels'] = kern
