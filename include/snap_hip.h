@@ -90,7 +90,8 @@ size_t snap_group_norm_stats_workspace_bytes(int32_t N, int32_t HW, int32_t C,
 int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, int32_t C,
                               int32_t C_stride, int32_t groups, float eps,
                               int32_t relu_first, const float* gamma, float* mu,
-                              float* sc, void* workspace, size_t workspace_bytes,
+                              float* sc, float* rstd /* optional [N,C] */,
+                              void* workspace, size_t workspace_bytes,
                               void* stream);
 
 /* Stand-alone GroupNorm apply (+optional ReLU before/after); used by tests and
@@ -243,6 +244,74 @@ int snap_template_finalize_f32(const float* raw, const float* cnt,
                                const float* tcount, int32_t Ho, int32_t Wo,
                                int32_t R, int32_t Rp, float overlap_threshold,
                                int32_t use_overlap, float* scores, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Training path: vector-Jacobian products of the kernels above.
+ * The reference obtains these from jax.grad over the same call sites
+ * (snap/trainer.py:223-234).  Data-gradients of convs reuse snap_conv2d_nhwc_f32
+ * with the rotated / transposed kernel (host side, snap_amd/autograd.py).
+ * ------------------------------------------------------------------------- */
+/* dw[KH*KW*Cin, Cout] (+)= im2col(prologue(x))^T dy   on f32 MFMA; dy [N,Ho,Wo,Cout]. */
+size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc);
+int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, const float* dy,
+                          float* dw, const float* gn_mu, const float* gn_sc,
+                          const float* gn_beta, int32_t accumulate, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* GroupNorm(+ReLU) backward.  dz: grad w.r.t. the prologue output; add: optional extra
+ * gradient summed into dx (identity-residual branch).  mode: SNAP_PRO_GN_RELU /
+ * SNAP_PRO_RELU_GN.  dgamma/dbeta [C] (+)=. */
+size_t snap_group_norm_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C, int32_t groups);
+int snap_group_norm_bwd_f32(const float* x, const float* dz, const float* add, float* dx,
+                            int32_t N, int32_t HW, int32_t C, int32_t groups,
+                            const float* mu, const float* rstd, const float* gamma,
+                            const float* beta, int32_t mode, float* dgamma, float* dbeta,
+                            int32_t accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+int snap_weight_standardize_bwd_f32(const float* w, const float* dws, float* dw, int32_t K,
+                                    int32_t Cout, float eps, void* stream);
+int snap_max_pool_3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int32_t N,
+                                int32_t H, int32_t W, int32_t C, void* stream);
+/* dprev[N,Hp,Wp,C] = transpose of the bilinear x2 up-sampling applied to dy[N,2Hp,2Wp,C]. */
+int snap_upsample2x_bwd_f32(const float* dy, float* dprev, int32_t N, int32_t Hp, int32_t Wp,
+                            int32_t C, void* stream);
+/* out = dy * [y > 0 iff relu] * row_mask  (epilogue gating; y, row_mask optional). */
+int snap_epilogue_bwd_f32(const float* dy, const float* y, const uint8_t* row_mask, float* out,
+                          int64_t M, int32_t C, int32_t relu, void* stream);
+/* out[C] (+)= column sums of a[M,C]  (bias gradients). */
+size_t snap_colsum_workspace_bytes(int64_t M, int32_t C);
+int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* d f_images[B,V,h,w,C] = VJP of snap_lift_pool_f32 w.r.t. f_images (zeroed inside). */
+int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_images, const float* cam,
+                           const float* Rt, const float* points, const float* dpooled,
+                           float* df_images, void* stream);
+int snap_vertical_pool_bwd_f32(const float* vol, const uint8_t* vvalid, const float* dplane,
+                               float* dvol, int64_t M, int32_t Z, int32_t D, int32_t pooling,
+                               void* stream);
+/* VJP of snap_plane_fuse_match_f32: dplanes[i][M,D] and dy[M,Dm] (gradient w.r.t. the
+ * Dense output, for the kernel / bias gradients via wgrad / colsum). */
+int snap_plane_fuse_match_bwd_f32(const float* const* planes, const uint8_t* const* valids,
+                                  float* const* dplanes, int32_t num_planes, int64_t M,
+                                  int32_t D, int32_t pooling, const float* Wm, const float* bm,
+                                  int32_t Dm, int32_t normalize, float eps,
+                                  const float* dmatching, const float* dfused, float* dy,
+                                  void* stream);
+
+/* VJP of snap_pose_score_f32 w.r.t. sim: dsim[B,Nq,X,Y] (planes <= 96 KiB). */
+size_t snap_pose_score_bwd_workspace_bytes(int32_t B, int32_t P);
+int snap_pose_score_bwd_f32(const float* dscores, const float* poses, const float* q_xy,
+                            const uint8_t* valid_q, const uint8_t* map_valid, int32_t B,
+                            int32_t Nq, int32_t X, int32_t Y, int32_t P, float cell_size,
+                            int32_t mask_oob, float* dsim, void* workspace,
+                            size_t workspace_bytes, void* stream);
+/* In place: dsim <- dsim * [sim > 0 iff clip] * coef[b]; partial[B,num_partial] <- partial
+ * sums of dsim*sim (temperature gradient). */
+int snap_sim_bwd_prepare_f32(float* dsim, const float* sim, int32_t B, int64_t per_scene,
+                             int32_t clip_negative, const float* coef, float* partial,
+                             int32_t num_partial, void* stream);
 
 #ifdef __cplusplus
 }

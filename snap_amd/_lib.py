@@ -55,7 +55,7 @@ SIGNATURES = {
     'snap_group_norm_stats_f32': (
         c_int,
         [ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr,
-         ptr, c_size, ptr],
+         ptr, ptr, c_size, ptr],
     ),
     'snap_group_norm_apply_f32': (
         c_int, [ptr, ptr, c_int, c_int, c_int, ptr, ptr, ptr, c_int, ptr]
@@ -105,9 +105,47 @@ SIGNATURES = {
     'snap_template_finalize_f32': (
         c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr]
     ),
+    # ---- training path ----
+    'snap_conv2d_wgrad_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_conv2d_wgrad_f32': (
+        c_int,
+        [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr],
+    ),
+    'snap_group_norm_bwd_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int]),
+    'snap_group_norm_bwd_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr, ptr, ptr, ptr, c_int, ptr, ptr,
+         c_int, ptr, c_size, ptr],
+    ),
+    'snap_weight_standardize_bwd_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_float, ptr]),
+    'snap_max_pool_3x3s2_bwd_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr]),
+    'snap_upsample2x_bwd_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, ptr]),
+    'snap_epilogue_bwd_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, ptr]),
+    'snap_colsum_workspace_bytes': (c_size, [c_i64, c_int]),
+    'snap_colsum_f32': (c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_size, ptr]),
+    'snap_lift_pool_bwd_f32': (
+        c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]
+    ),
+    'snap_vertical_pool_bwd_f32': (
+        c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, c_int, ptr]
+    ),
+    'snap_plane_fuse_match_bwd_f32': (
+        c_int,
+        [ptr, ptr, ptr, c_int, c_i64, c_int, c_int, ptr, ptr, c_int, c_int, c_float, ptr, ptr,
+         ptr, ptr],
+    ),
+    'snap_pose_score_bwd_workspace_bytes': (c_size, [c_int, c_int]),
+    'snap_pose_score_bwd_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr,
+         c_size, ptr],
+    ),
+    'snap_sim_bwd_prepare_f32': (
+        c_int, [ptr, ptr, c_int, c_i64, c_int, ptr, ptr, c_int, ptr]
+    ),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 

@@ -1,0 +1,334 @@
+"""Differentiable wrappers (torch.autograd.Function) around the HIP kernels.
+
+The reference gets gradients from ``jax.grad`` over the whole model
+(snap/trainer.py:223-234).  Here every forward kernel has a hand-written VJP kernel
+(``snap_amd/ops_bwd.py``); the wrappers only record what the backward needs.  Data
+gradients of convolutions reuse the forward MFMA engine with the rotated /
+transposed kernel; kernel gradients use the transpose-A engine (wgrad.hip).
+
+With ``torch.no_grad()`` (inference) the wrappers reduce to the plain ``ops`` calls.
+"""
+import torch
+import torch.nn.functional as F
+
+from snap_amd import ops
+from snap_amd import ops_bwd
+
+_GN_MODES = (ops.PRO_GN_RELU, ops.PRO_RELU_GN)
+
+
+# ----------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------
+def conv_dgrad(dy, w, x_shape, stride, padding):
+  """d(prologue output) of a conv: transposed convolution through the forward engine.
+
+  dy [N,Ho,Wo,Cout]; w [KH,KW,Cin,Cout]; returns dz [N,H,W,Cin].
+  Stride > 1: dy is zero-dilated first (the few strided layers of the ResNet).
+  """
+  N, H, W, Cin = x_shape
+  KH, KW, _, Cout = w.shape
+  (pt, pb), (pl, pr) = padding
+  if stride > 1:
+    Ho, Wo = dy.shape[1:3]
+    Hd, Wd = (Ho - 1) * stride + 1, (Wo - 1) * stride + 1
+    dyd = torch.zeros((N, Hd, Wd, Cout), dtype=dy.dtype, device=dy.device)
+    dyd[:, ::stride, ::stride] = dy
+    dy = dyd
+  Ho, Wo = dy.shape[1:3]
+  w_rot = w.flip(0, 1).permute(0, 1, 3, 2).contiguous()       # [KH,KW,Cout,Cin]
+  pt2, pl2 = KH - 1 - pt, KW - 1 - pl
+  pb2 = H - Ho - pt2 + KH - 1
+  pr2 = W - Wo - pl2 + KW - 1
+  return ops.conv2d(dy.contiguous(), w_rot, padding=((pt2, pb2), (pl2, pr2)))
+
+
+def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid):
+  """VJP of sim = relu(fq . fm) * scale / num_valid.  `dsim` is overwritten.
+
+  Returns dfq [B,Nq,Dm], dfm [B,X,Y,Dm], dtemperature (scalar tensor, d/dT with
+  scale = exp(T))."""
+  B, Nq, X, Y = sim.shape
+  Dm = fq.shape[-1]
+  XY = X * Y
+  coef = (scale / num_valid).to(torch.float32).contiguous()
+  dtemp = ops_bwd.sim_bwd_prepare_(dsim, sim, clip, coef).sum()
+  dfq = torch.empty_like(fq)
+  dfm = torch.empty_like(fm)
+  for b in range(B):
+    g = dsim[b].reshape(1, 1, Nq, XY)
+    dfq[b] = ops.conv2d(g, fm[b].reshape(1, 1, XY, Dm)).reshape(Nq, Dm)
+    dfm[b] = ops_bwd.conv2d_wgrad(g, fq[b].reshape(1, 1, Nq, Dm).contiguous(),
+                                  (1, 1, XY, Dm)).reshape(X, Y, Dm)
+  return dfq, dfm, dtemp.to(torch.float32)
+
+
+# ----------------------------------------------------------------------------
+# conv / dense
+# ----------------------------------------------------------------------------
+class _FusedConv(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, w, gamma, beta, bias, residual, up_prev, cfg):
+    stride, padding, prologue, in_affine, relu, row_mask, cin = cfg
+    gn = None
+    mu = sc = rstd = None
+    if prologue in _GN_MODES:
+      mu, sc, rstd = ops.group_norm_stats(
+          x, gamma.reshape(-1), relu_first=prologue == ops.PRO_RELU_GN, want_rstd=True
+      )
+      gn = (mu, sc, beta.reshape(-1))
+    y = ops.conv2d(
+        x, w, stride=stride, padding=padding, cin=cin, prologue=prologue, gn=gn,
+        in_affine=in_affine, bias=bias, relu=relu, residual=residual, up_prev=up_prev,
+        row_mask=row_mask,
+    )
+    ctx.cfg = cfg
+    ctx.has = (bias is not None, residual is not None, up_prev is not None)
+    ctx.save_for_backward(x, w, gamma, beta, mu, sc, rstd, y if relu else None, row_mask)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    stride, padding, prologue, in_affine, relu, _, cin = ctx.cfg
+    x, w, gamma, beta, mu, sc, rstd, y, row_mask = ctx.saved_tensors
+    has_bias, has_res, has_up = ctx.has
+    dy = dy.contiguous()
+    if relu or row_mask is not None:
+      dy = ops_bwd.epilogue_bwd(dy, y, row_mask, relu=relu)
+    need = ctx.needs_input_grad
+    gn = (mu, sc, beta.reshape(-1)) if prologue in _GN_MODES else None
+    dw = None
+    if need[1]:
+      dw = ops_bwd.conv2d_wgrad(x, dy, tuple(w.shape), stride=stride, padding=padding,
+                                prologue=prologue, gn=gn, in_affine=in_affine)
+    dbias = ops_bwd.colsum(dy) if (has_bias and need[4]) else None
+    dres = dy if (has_res and need[5]) else None
+    dup = ops_bwd.upsample2x_bwd(dy) if (has_up and need[6]) else None
+    dx = dgamma = dbeta = None
+    if need[0] or (prologue in _GN_MODES and (need[2] or need[3])):
+      N, H, W, Cs = x.shape
+      Cin = w.shape[2]
+      dz = conv_dgrad(dy, w, (N, H, W, Cin), stride, padding)
+      if prologue in _GN_MODES:
+        dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
+            x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), prologue
+        )
+        dgamma = dgamma.reshape(gamma.shape)
+        dbeta = dbeta.reshape(beta.shape)
+      elif prologue == ops.PRO_RELU:
+        xs = x if Cs == Cin else x[..., :Cin].contiguous()
+        dx = ops_bwd.epilogue_bwd(dz, xs, None, relu=True)
+      elif prologue == ops.PRO_AFFINE:
+        dx = dz * in_affine[0]
+      else:
+        dx = dz
+      if Cs != Cin:
+        dx = F.pad(dx, (0, Cs - Cin))
+    return dx, dw, dgamma, dbeta, dbias, dres, dup, None
+
+
+def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=ops.PRO_NONE,
+           gn_params=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
+           up_prev=None, row_mask=None):
+  """Differentiable ``ops.conv2d``.  ``gn_params = (gamma, beta)`` for GN prologues
+  (statistics are computed inside, so the VJP covers them)."""
+  gamma, beta = gn_params if gn_params is not None else (None, None)
+  cfg = (stride, padding, prologue, tuple(in_affine), relu, row_mask, cin)
+  return _FusedConv.apply(x, w, gamma, beta, bias, residual, up_prev, cfg)
+
+
+def dense(x, kernel, bias=None, *, cin=None, prologue=ops.PRO_NONE, relu=False, row_mask=None):
+  lead = x.shape[:-1]
+  M = 1
+  for s in lead:
+    M *= int(s)
+  y = conv2d(
+      x.reshape(1, 1, M, x.shape[-1]), kernel.reshape(1, 1, *kernel.shape),
+      cin=cin if cin is not None else kernel.shape[0], prologue=prologue, bias=bias, relu=relu,
+      row_mask=row_mask,
+  )
+  return y.reshape(*lead, kernel.shape[1])
+
+
+class _WeightStd(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, w):
+    ctx.save_for_backward(w)
+    return ops.weight_standardize(w)
+
+  @staticmethod
+  def backward(ctx, dws):
+    (w,) = ctx.saved_tensors
+    return ops_bwd.weight_standardize_bwd(w, dws.contiguous())
+
+
+def weight_standardize(w):
+  return _WeightStd.apply(w)
+
+
+class _MaxPool(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x):
+    ctx.save_for_backward(x)
+    return ops.max_pool_3x3s2(x)
+
+  @staticmethod
+  def backward(ctx, dy):
+    (x,) = ctx.saved_tensors
+    return ops_bwd.max_pool_3x3s2_bwd(x, dy.contiguous())
+
+
+def max_pool_3x3s2(x):
+  return _MaxPool.apply(x)
+
+
+# ----------------------------------------------------------------------------
+# lift / BEV
+# ----------------------------------------------------------------------------
+class _LiftPool(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, f_images, cam, Rt, points, cfg):
+    K, fisheye, fd, nb, dmm, mvd = cfg
+    pooled, valid = ops.lift_pool(f_images, cam, Rt, points, K=K, fisheye=fisheye, feature_dim=fd,
+                                  num_bins=nb, depth_min_max=dmm, max_view_distance=mvd)
+    ctx.cfg = cfg
+    ctx.save_for_backward(f_images, cam, Rt, points)
+    ctx.mark_non_differentiable(valid)
+    return pooled, valid
+
+  @staticmethod
+  def backward(ctx, dpooled, _dvalid):
+    K, fisheye, fd, nb, dmm, mvd = ctx.cfg
+    f_images, cam, Rt, points = ctx.saved_tensors
+    df = ops_bwd.lift_pool_bwd(f_images, cam, Rt, points, dpooled.contiguous(), K=K,
+                               fisheye=fisheye, feature_dim=fd, num_bins=nb, depth_min_max=dmm,
+                               max_view_distance=mvd)
+    return df, None, None, None, None
+
+
+def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins, depth_min_max,
+              max_view_distance=None):
+  cfg = (K, fisheye, feature_dim, num_bins, tuple(depth_min_max), max_view_distance)
+  return _LiftPool.apply(f_images, cam, Rt, points, cfg)
+
+
+class _VerticalPool(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, vol, valid, pooling):
+    plane, pvalid = ops.vertical_pool(vol, valid, pooling)
+    ctx.pooling = pooling
+    ctx.save_for_backward(vol, valid)
+    ctx.mark_non_differentiable(pvalid)
+    return plane, pvalid
+
+  @staticmethod
+  def backward(ctx, dplane, _dv):
+    vol, valid = ctx.saved_tensors
+    return ops_bwd.vertical_pool_bwd(vol, valid, dplane.contiguous(), ctx.pooling), None, None
+
+
+def vertical_pool(vol, valid, pooling='max'):
+  return _VerticalPool.apply(vol, valid, pooling)
+
+
+class _PlaneFuseMatch(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, Wm, bm, cfg, *planes):
+    valids, pooling, normalize, eps = cfg
+    fused, fvalid, matching = ops.plane_fuse_match(
+        list(planes), list(valids), pooling, Wm, bm, normalize=normalize, eps=eps, want_fused=True
+    )
+    ctx.cfg = cfg
+    ctx.n = len(planes)
+    ctx.save_for_backward(Wm, bm, fused, *planes)
+    ctx.mark_non_differentiable(fvalid)
+    if matching is None:
+      matching = fused.new_zeros(())
+    return fused, fvalid, matching
+
+  @staticmethod
+  def backward(ctx, dfused, _dvalid, dmatching):
+    valids, pooling, normalize, eps = ctx.cfg
+    Wm, bm, fused = ctx.saved_tensors[:3]
+    planes = list(ctx.saved_tensors[3:])
+    has_match = Wm is not None
+    dplanes, dy = ops_bwd.plane_fuse_match_bwd(
+        planes, list(valids), pooling, Wm, bm, normalize, eps,
+        dmatching.contiguous() if has_match else None,
+        dfused.contiguous() if dfused is not None else None,
+    )
+    dW = db = None
+    if has_match:
+      D, Dm = Wm.shape
+      M = fused.numel() // D
+      dW = ops_bwd.conv2d_wgrad(fused.reshape(1, 1, M, D), dy.reshape(1, 1, M, Dm), (1, 1, D, Dm))
+      dW = dW.reshape(D, Dm)
+      db = ops_bwd.colsum(dy)
+    return (dW, db, None, *dplanes)
+
+
+def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None, normalize=True, eps=1e-5,
+                     want_fused=True):
+  cfg = (tuple(valids), pooling, normalize, eps)
+  fused, fvalid, matching = _PlaneFuseMatch.apply(Wm, bm, cfg, *planes)
+  return fused, fvalid, (matching if Wm is not None else None)
+
+
+# ----------------------------------------------------------------------------
+# pose head
+# ----------------------------------------------------------------------------
+class _SimSoftmax(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, fq, fm, temperature, num_valid, clip, want_prob):
+    scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+    sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob)
+    ctx.scale, ctx.clip = scale, clip
+    ctx.save_for_backward(fq, fm, sim, num_valid)
+    ctx.has_t = temperature is not None
+    ctx.mark_non_differentiable(stats)
+    if prob is None:
+      prob = sim.new_zeros(())
+    ctx.mark_non_differentiable(prob)
+    return sim, stats, prob
+
+  @staticmethod
+  def backward(ctx, dsim, _ds, _dp):
+    fq, fm, sim, num_valid = ctx.saved_tensors
+    dfq, dfm, dtemp = similarity_bwd(dsim.contiguous().clone(), sim, fq, fm, ctx.scale, ctx.clip,
+                                     num_valid)
+    return dfq, dfm, (dtemp if ctx.has_t else None), None, None, None
+
+
+def sim_softmax(fq, fm, temperature, clip_negative, num_valid, want_prob=False):
+  """Returns (sim, chunk_stats, prob or None, scale)."""
+  sim, stats, prob = _SimSoftmax.apply(fq, fm, temperature, num_valid, clip_negative, want_prob)
+  scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+  return sim, stats, (prob if want_prob else None), scale
+
+
+class _PoseScore(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, sim, poses, q_xy, valid_q, map_valid, cell, mask_oob):
+    ctx.cfg = (cell, mask_oob, tuple(sim.shape))
+    ctx.save_for_backward(poses, q_xy, valid_q, map_valid)
+    return ops.pose_score(sim, poses, q_xy, valid_q, map_valid, cell, mask_oob=mask_oob)
+
+  @staticmethod
+  def backward(ctx, dscores):
+    cell, mask_oob, shape = ctx.cfg
+    poses, q_xy, valid_q, map_valid = ctx.saved_tensors
+    dsim = ops_bwd.pose_score_bwd(dscores.contiguous(), poses, q_xy, valid_q, map_valid, shape,
+                                  cell, mask_oob=mask_oob)
+    return dsim, None, None, None, None, None, None
+
+
+def pose_score(sim, poses, q_xy, valid_q, map_valid, cell_size, mask_oob=False):
+  return _PoseScore.apply(sim, poses, q_xy, valid_q, map_valid, cell_size, mask_oob)

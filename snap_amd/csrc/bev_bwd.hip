@@ -1,0 +1,522 @@
+// Backward kernels of the lift and BEV stages (training path).
+//   * lift_pool backward: d pooled[B,N,257] -> d f_images[B,V,h,w,C]  (VJP of
+//     streetview_encoder.py:69-178; geometry carries no gradient).  Bilinear taps are
+//     scatter-added with hardware fp32 atomics (the only non-deterministic-order sums
+//     of the training path).
+//   * vertical pooling backward (VJP of bev_mapper.py:56-88; max: equal split among ties,
+//     as jnp.max's VJP does)
+//   * modality fusion + matching head backward (VJP of bev_mapper.py:225-252,284-291,
+//     layers.py:45-52)
+#include "common.h"
+
+namespace {
+
+// ------------------------------- lift ----------------------------------------
+struct LiftBwdArgs {
+  SnapLiftDesc d;
+  const float* f;
+  const float* cam;
+  const float* Rt;
+  const float* pts;
+  const float* dpooled;
+  float* df;
+};
+
+struct ProjB {
+  float pi, pj, depth, dist;
+  bool vis;
+};
+
+__device__ __forceinline__ ProjB project_b(const float* __restrict__ cam,
+                                           const float* __restrict__ Rt, float px, float py,
+                                           float pz, int fisheye) {
+  const float eps = 1e-3f;
+  float pv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float r0 = Rt[0 * 3 + i], r1 = Rt[1 * 3 + i], r2 = Rt[2 * 3 + i];
+    const float tinv = -((r0 * Rt[9] + r1 * Rt[10]) + r2 * Rt[11]);
+    pv[i] = tinv + ((r0 * px + r1 * py) + r2 * pz);
+  }
+  ProjB o;
+  o.depth = pv[2];
+  bool valid = pv[2] >= eps;
+  const float z = fmaxf(pv[2], eps);
+  float x = pv[0] / z, y = pv[1] / z;
+  if (fisheye) {
+    const float radius2 = x * x + y * y;
+    const bool in_center = radius2 < eps * eps;
+    const float radius = sqrtf(in_center ? eps * eps : radius2);
+    const float theta = atanf(radius);
+    const float t2 = theta * theta;
+    const float offset = (cam[6] * t2 + cam[7] * (t2 * t2)) + cam[8] * (t2 * t2 * t2);
+    float dist = (offset + 1.f) * theta / radius;
+    dist = in_center ? 1.f : dist;
+    x *= dist;
+    y *= dist;
+    valid = valid && (in_center || ((radius < tanf(0.5f * cam[9])) && (dist > 0.f)));
+  }
+  x = x * cam[2] + cam[4];
+  y = y * cam[3] + cam[5];
+  valid = valid && (x >= 0.f) && (x < cam[0]) && (y >= 0.f) && (y < cam[1]);
+  o.pi = y;
+  o.pj = x;
+  o.vis = valid;
+  const float dx = px - Rt[9], dy = py - Rt[10], dz = pz - Rt[11];
+  o.dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+  return o;
+}
+
+struct TapsB {
+  int i0, i1, j0, j1;
+  float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ TapsB taps_b(float pi, float pj, int h, int w, int selective) {
+  TapsB t;
+  float ci = pi - 0.5f, cj = pj - 0.5f;
+  if (selective) {
+    ci = fmaxf(fminf(ci, (float)(h - 1)), 0.f);
+    cj = fmaxf(fminf(cj, (float)(w - 1)), 0.f);
+  }
+  const float fi = floorf(ci), fj = floorf(cj);
+  const float wi1 = ci - fi, wj1 = cj - fj;
+  const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
+  t.i0 = (int)fminf(fmaxf(fi, 0.f), (float)(h - 1));
+  t.i1 = (int)fminf(fmaxf(fi + 1.f, 0.f), (float)(h - 1));
+  t.j0 = (int)fminf(fmaxf(fj, 0.f), (float)(w - 1));
+  t.j1 = (int)fminf(fmaxf(fj + 1.f, 0.f), (float)(w - 1));
+  t.w00 = wi0 * wj0;
+  t.w01 = wi0 * wj1;
+  t.w10 = wi1 * wj0;
+  t.w11 = wi1 * wj1;
+  return t;
+}
+
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a) {
+  const SnapLiftDesc& d = a.d;
+  const int hl = threadIdx.x & 31;
+  const int64_t gv = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int64_t total = (int64_t)d.B * d.N;
+  if (gv >= total) return;
+  const int b = (int)(gv / d.N);
+  const int fd = d.feature_dim;
+  const int nq = fd >> 2;
+  const bool all_views = d.K == 0;
+  const int nsel = all_views ? d.V : d.K;
+  const float* p = a.pts + gv * 3;
+  const float px = p[0], py = p[1], pz = p[2];
+
+  ProjB pr;
+  pr.pi = pr.pj = pr.depth = 0.f;
+  pr.dist = INFINITY;
+  pr.vis = false;
+  if (hl < d.V)
+    pr = project_b(a.cam + ((int64_t)b * d.V + hl) * 11, a.Rt + ((int64_t)b * d.V + hl) * 12, px, py,
+                   pz, d.fisheye);
+  float key_d = (hl < d.V && pr.vis) ? pr.dist : INFINITY;
+  int key_i = (hl < d.V) ? hl : 1000 + hl;
+  int sel[KMAX];
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    if (r >= nsel) { sel[r] = 0; continue; }
+    if (all_views) { sel[r] = r; continue; }
+    float bd = key_d;
+    int bi = key_i;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float od = __shfl_xor(bd, o, 32);
+      const int oi = __shfl_xor(bi, o, 32);
+      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    sel[r] = bi;
+    if (hl == bi) { key_d = INFINITY; key_i = 1000 + hl; }
+  }
+
+  // ---- recompute the forward quantities -----------------------------------
+  f32x4 feat[KMAX];
+  float score[KMAX], wb1[KMAX];
+  int bin0[KMAX], bin1[KMAX], view[KMAX];
+  TapsB tp[KMAX];
+  bool ok[KMAX];
+  bool any = false;
+  const float log_range = logf(d.depth_max / d.depth_min);
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    feat[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    score[r] = 0.f; wb1[r] = 0.f; bin0[r] = bin1[r] = 0; view[r] = 0;
+    ok[r] = false;
+    tp[r] = TapsB{0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (r >= nsel) continue;
+    const int v = sel[r];
+    view[r] = v;
+    const float pi = __shfl(pr.pi, v, 32);
+    const float pj = __shfl(pr.pj, v, 32);
+    const float depth = __shfl(pr.depth, v, 32);
+    const bool vis = __shfl((int)pr.vis, v, 32) != 0;
+    ok[r] = vis;
+    if (!vis) continue;
+    any = true;
+    tp[r] = taps_b(pi, pj, d.h, d.w, all_views ? 0 : 1);
+    const TapsB& t = tp[r];
+    const float* img = a.f + ((int64_t)b * d.V + v) * d.h * d.w * d.C;
+    const float* r00 = img + ((int64_t)t.i0 * d.w + t.j0) * d.C;
+    const float* r01 = img + ((int64_t)t.i0 * d.w + t.j1) * d.C;
+    const float* r10 = img + ((int64_t)t.i1 * d.w + t.j0) * d.C;
+    const float* r11 = img + ((int64_t)t.i1 * d.w + t.j1) * d.C;
+    if (hl < nq) {
+      const f32x4 a00 = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
+      const f32x4 a01 = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
+      const f32x4 a10 = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
+      const f32x4 a11 = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        feat[r][e] = ((t.w00 * a00[e] + t.w01 * a01[e]) + t.w10 * a10[e]) + t.w11 * a11[e];
+    }
+    const float dc = fminf(fmaxf(depth, d.depth_min), d.depth_max);
+    const float tt = logf(dc / d.depth_min) / log_range;
+    const float index = 0.5f + tt * (float)(d.num_bins - 1);
+    const float c = index - 0.5f;
+    const float fl = floorf(c);
+    wb1[r] = c - fl;
+    bin0[r] = (int)fminf(fmaxf(fl, 0.f), (float)(d.num_bins - 1));
+    bin1[r] = (int)fminf(fmaxf(fl + 1.f, 0.f), (float)(d.num_bins - 1));
+    const int c0 = fd + bin0[r], c1 = fd + bin1[r];
+    const float s0 = ((t.w00 * r00[c0] + t.w01 * r01[c0]) + t.w10 * r10[c0]) + t.w11 * r11[c0];
+    const float s1 = ((t.w00 * r00[c1] + t.w01 * r01[c1]) + t.w10 * r10[c1]) + t.w11 * r11[c1];
+    score[r] = (1.f - wb1[r]) * s0 + wb1[r] * s1;
+  }
+  if (!any) return;  // pooled == 0 (masked): no gradient
+
+  float m = 0.f, smax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r)
+    if (ok[r]) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
+  float wgt[KMAX], den = 0.f;
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    wgt[r] = ok[r] ? expf(score[r] - m) : 0.f;
+    den += wgt[r];
+  }
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    wgt[r] = wgt[r] / den;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mean[e] += wgt[r] * feat[r][e];
+  }
+
+  // ---- upstream gradients ------------------------------------------------------
+  const float* g = a.dpooled + gv * d.out_stride;
+  f32x4 dmean = {0.f, 0.f, 0.f, 0.f}, dvar = {0.f, 0.f, 0.f, 0.f};
+  if (hl < nq) {
+    dmean = *reinterpret_cast<const f32x4*>(g + 4 * hl);
+    dvar = *reinterpret_cast<const f32x4*>(g + fd + 4 * hl);
+  }
+  const float dsmax = g[2 * fd];
+  int nmax = 0;
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) nmax += (ok[r] && score[r] == smax) ? 1 : 0;
+
+  // d w_k = sum_c f_kc dmean_c + (f_kc - mean_c)^2 dvar_c   (half-wave reduction)
+  float dw[KMAX], dwbar = 0.f;
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    float t = 0.f;
+    if (ok[r]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dl = feat[r][e] - mean[e];
+        t += feat[r][e] * dmean[e] + (dl * dl) * dvar[e];
+      }
+    }
+    dw[r] = half_sum(t);
+    dwbar += wgt[r] * dw[r];
+  }
+#pragma unroll
+  for (int r = 0; r < KMAX; ++r) {
+    if (!ok[r]) continue;
+    const float ds = wgt[r] * (dw[r] - dwbar) + ((score[r] == smax) ? dsmax / (float)nmax : 0.f);
+    const TapsB& t = tp[r];
+    float* img = a.df + ((int64_t)b * d.V + view[r]) * d.h * d.w * d.C;
+    float* r00 = img + ((int64_t)t.i0 * d.w + t.j0) * d.C;
+    float* r01 = img + ((int64_t)t.i0 * d.w + t.j1) * d.C;
+    float* r10 = img + ((int64_t)t.i1 * d.w + t.j0) * d.C;
+    float* r11 = img + ((int64_t)t.i1 * d.w + t.j1) * d.C;
+    if (hl < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float df = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
+        unsafeAtomicAdd(r00 + 4 * hl + e, t.w00 * df);
+        unsafeAtomicAdd(r01 + 4 * hl + e, t.w01 * df);
+        unsafeAtomicAdd(r10 + 4 * hl + e, t.w10 * df);
+        unsafeAtomicAdd(r11 + 4 * hl + e, t.w11 * df);
+      }
+    }
+    // score taps: lanes 0..7 = (tap, bin)
+    if (hl < 8) {
+      const int st = hl >> 1, sb = hl & 1;
+      float* rt = st == 0 ? r00 : (st == 1 ? r01 : (st == 2 ? r10 : r11));
+      const float wt = st == 0 ? t.w00 : (st == 1 ? t.w01 : (st == 2 ? t.w10 : t.w11));
+      const float wbin = sb ? wb1[r] : (1.f - wb1[r]);
+      unsafeAtomicAdd(rt + fd + (sb ? bin1[r] : bin0[r]), wt * wbin * ds);
+    }
+  }
+}
+
+// ------------------------------- vertical pool --------------------------------
+__global__ __launch_bounds__(256) void vertical_pool_bwd_kernel(
+    const float* __restrict__ vol, const uint8_t* __restrict__ vvalid,
+    const float* __restrict__ dplane, float* __restrict__ dvol, int64_t M, int Z, int D,
+    int pooling) {
+  const int hl = threadIdx.x & 31;
+  const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (m >= M) return;
+  const int nq = D >> 2;
+  const uint8_t* vv = vvalid + m * Z;
+  const float* base = vol + m * Z * D;
+  float* dbase = dvol + m * Z * D;
+  for (int q = hl; q < nq; q += 32) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dplane + m * D + 4 * q);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 cnt = {0.f, 0.f, 0.f, 0.f};
+    int nvalid = 0;
+    for (int z = 0; z < Z; ++z) {
+      if (!vv[z]) continue;
+      ++nvalid;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)z * D + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (v[e] > best[e]) { best[e] = v[e]; cnt[e] = 1.f; }
+        else if (v[e] == best[e]) cnt[e] += 1.f;
+      }
+    }
+    for (int z = 0; z < Z; ++z) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (vv[z]) {
+        if (pooling == SNAP_POOL_MAX) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)z * D + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (v[e] == best[e]) ? g[e] / cnt[e] : 0.f;
+        } else if (pooling == SNAP_POOL_SUM) {
+          o = g;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = g[e] / (float)nvalid;
+        }
+      }
+      *reinterpret_cast<f32x4*>(dbase + (int64_t)z * D + 4 * q) = o;
+    }
+  }
+}
+
+// ------------------------------- fuse + matching --------------------------------
+struct FuseBwdArgs {
+  const float* planes[4];
+  const uint8_t* valids[4];
+  float* dplanes[4];
+  int num_planes;
+  int64_t M;
+  int D, pooling;
+  const float* Wm;
+  const float* bm;
+  int Dm, normalize;
+  float eps;
+  const float* dmatching;  // [M,Dm] or null
+  const float* dfused;     // [M,D] or null
+  float* dy;               // [M,Dm] grad w.r.t. the Dense output (pre-normalisation)
+};
+
+constexpr int FB_MAXQ = 2;
+
+__global__ __launch_bounds__(256) void plane_fuse_match_bwd_kernel(const FuseBwdArgs a) {
+  const int hl = threadIdx.x & 31;
+  const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (m >= a.M) return;
+  const int nq = a.D >> 2;
+  // recompute the fused vector and the routing weights
+  f32x4 fused[FB_MAXQ], x[4][FB_MAXQ];
+  bool pv[4];
+  int count = 0;
+  const float init = a.pooling == SNAP_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+  for (int i = 0; i < FB_MAXQ; ++i) fused[i] = f32x4{init, init, init, init};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    pv[p] = false;
+#pragma unroll
+    for (int i = 0; i < FB_MAXQ; ++i) x[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p >= a.num_planes) continue;
+    pv[p] = a.valids[p] ? (a.valids[p][m] != 0) : true;
+    if (!pv[p]) continue;
+    ++count;
+#pragma unroll
+    for (int i = 0; i < FB_MAXQ; ++i) {
+      const int q = hl + 32 * i;
+      if (q < nq) {
+        x[p][i] = *reinterpret_cast<const f32x4*>(a.planes[p] + m * a.D + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          fused[i][e] = a.pooling == SNAP_POOL_MAX ? fmaxf(fused[i][e], x[p][i][e])
+                                                   : fused[i][e] + x[p][i][e];
+      }
+    }
+  }
+  const bool any = count > 0;
+#pragma unroll
+  for (int i = 0; i < FB_MAXQ; ++i) {
+    if (!any) fused[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (any && a.pooling == SNAP_POOL_MEAN) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fused[i][e] = fused[i][e] / (float)count;
+    }
+  }
+  // ---- matching head backward: dy (lane j) ----------------------------------
+  const int j = hl;
+  float dyj = 0.f;
+  if (a.dmatching) {
+    float y = (j < a.Dm) ? a.bm[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < FB_MAXQ; ++i)
+      for (int q = 0; q < 32; ++q) {
+        const int cq = q + 32 * i;
+        if (cq >= nq) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = __shfl(fused[i][e], q, 32);
+          if (j < a.Dm) y += xv * a.Wm[(int64_t)(4 * cq + e) * a.Dm + j];
+        }
+      }
+    const float dz = (j < a.Dm && any) ? a.dmatching[m * a.Dm + j] : 0.f;
+    if (a.normalize) {
+      const float nrm = sqrtf(half_sum((j < a.Dm) ? y * y : 0.f));
+      if (nrm >= a.eps) {
+        const float z = y / nrm;
+        const float zdz = half_sum((j < a.Dm) ? z * dz : 0.f);
+        dyj = (dz - z * zdz) / nrm;
+      }
+    } else {
+      dyj = dz;
+    }
+    if (j < a.Dm) a.dy[m * a.Dm + j] = dyj;
+  }
+  // ---- d fused = Wm dy (+ dfused) and routing to the planes -------------------
+#pragma unroll
+  for (int i = 0; i < FB_MAXQ; ++i) {
+    const int q = hl + 32 * i;
+    f32x4 df = {0.f, 0.f, 0.f, 0.f};
+    if (a.dmatching) {
+      for (int jj = 0; jj < a.Dm; ++jj) {
+        const float dv = __shfl(dyj, jj, 32);
+        if (q < nq) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) df[e] += a.Wm[(int64_t)(4 * q + e) * a.Dm + jj] * dv;
+        }
+      }
+    }
+    if (q >= nq) continue;
+    if (a.dfused && any) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.dfused + m * a.D + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) df[e] += g[e];
+    }
+    f32x4 ties = {0.f, 0.f, 0.f, 0.f};
+    if (a.pooling == SNAP_POOL_MAX) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (pv[p]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ties[e] += (x[p][i][e] == fused[i][e]) ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p >= a.num_planes || !a.dplanes[p]) continue;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (pv[p]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (a.pooling == SNAP_POOL_MAX) o[e] = (x[p][i][e] == fused[i][e]) ? df[e] / ties[e] : 0.f;
+          else if (a.pooling == SNAP_POOL_SUM) o[e] = df[e];
+          else o[e] = df[e] / (float)count;
+        }
+      }
+      *reinterpret_cast<f32x4*>(a.dplanes[p] + m * a.D + 4 * q) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_images,
+                                      const float* cam, const float* Rt, const float* points,
+                                      const float* dpooled, float* df_images, void* stream) {
+  if (!desc || !f_images || !cam || !Rt || !points || !dpooled || !df_images) return SNAP_ERR_NULL;
+  const SnapLiftDesc& d = *desc;
+  if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.V > 32 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0)
+    return SNAP_ERR_UNSUPPORTED;
+  if (d.C != d.feature_dim + d.num_bins || d.C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.out_stride < 2 * d.feature_dim + 1 || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  const int nsel = d.K == 0 ? d.V : d.K;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t bytes = (size_t)d.B * d.V * d.h * d.w * d.C * sizeof(float);
+  if (hipMemsetAsync(df_images, 0, bytes, s) != hipSuccess) return SNAP_ERR_LAUNCH;
+  LiftBwdArgs a{d, f_images, cam, Rt, points, dpooled, df_images};
+  const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
+  if (nsel <= 1) hipLaunchKernelGGL(lift_pool_bwd_kernel<1>, grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL(lift_pool_bwd_kernel<4>, grid, dim3(256), 0, s, a);
+  else if (nsel <= 8) hipLaunchKernelGGL(lift_pool_bwd_kernel<8>, grid, dim3(256), 0, s, a);
+  else return SNAP_ERR_UNSUPPORTED;
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_vertical_pool_bwd_f32(const float* vol, const uint8_t* vvalid,
+                                          const float* dplane, float* dvol, int64_t M, int32_t Z,
+                                          int32_t D, int32_t pooling, void* stream) {
+  if (!vol || !vvalid || !dplane || !dvol) return SNAP_ERR_NULL;
+  if (M <= 0 || Z <= 0 || D <= 0 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (pooling < SNAP_POOL_MAX || pooling > SNAP_POOL_MEAN) return SNAP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(vertical_pool_bwd_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), vol, vvalid, dplane, dvol, M, Z, D, pooling);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_plane_fuse_match_bwd_f32(const float* const* planes,
+                                             const uint8_t* const* valids, float* const* dplanes,
+                                             int32_t num_planes, int64_t M, int32_t D,
+                                             int32_t pooling, const float* Wm, const float* bm,
+                                             int32_t Dm, int32_t normalize, float eps,
+                                             const float* dmatching, const float* dfused, float* dy,
+                                             void* stream) {
+  if (!planes || !dplanes) return SNAP_ERR_NULL;
+  if (num_planes < 1 || num_planes > 4) return SNAP_ERR_UNSUPPORTED;
+  if (M <= 0 || D <= 0 || D % 4 != 0 || D > FB_MAXQ * 128) return SNAP_ERR_BAD_SHAPE;
+  if (pooling < SNAP_POOL_MAX || pooling > SNAP_POOL_MEAN) return SNAP_ERR_UNSUPPORTED;
+  if (dmatching && (!Wm || !bm || !dy)) return SNAP_ERR_NULL;
+  if (dmatching && (Dm < 1 || Dm > 32)) return SNAP_ERR_UNSUPPORTED;
+  FuseBwdArgs a;
+  for (int i = 0; i < 4; ++i) {
+    a.planes[i] = i < num_planes ? planes[i] : nullptr;
+    a.valids[i] = (i < num_planes && valids) ? valids[i] : nullptr;
+    a.dplanes[i] = i < num_planes ? dplanes[i] : nullptr;
+    if (i < num_planes && !a.planes[i]) return SNAP_ERR_NULL;
+  }
+  a.num_planes = num_planes; a.M = M; a.D = D; a.pooling = pooling;
+  a.Wm = Wm; a.bm = bm; a.Dm = Dm; a.normalize = normalize; a.eps = eps;
+  a.dmatching = dmatching; a.dfused = dfused; a.dy = dy;
+  hipLaunchKernelGGL(plane_fuse_match_bwd_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

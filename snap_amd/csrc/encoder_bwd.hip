@@ -1,0 +1,486 @@
+// Backward kernels of the encoder building blocks (training path).
+//   * GroupNorm(+ReLU) backward, both orders (VJP of resnet.py:46-70 fused with the
+//     ReLU of resnet.py:118,125,130 / image_encoder.py:80-83)
+//   * StdConv weight-standardisation backward (VJP of resnet.py:34-41,73-79)
+//   * 3x3/2 max-pool backward (VJP of resnet.py:99)
+//   * bilinear x2 up-sample backward (VJP of image_encoder.py:90)
+//   * epilogue backward (ReLU / row-mask gating of dY) and column sums (bias grads)
+// All reductions are fixed-order (deterministic).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// GroupNorm backward.  z = f(x):  GN_RELU: z = relu(xh*g + b);  RELU_GN: z = xh'*g + b
+// with xh = (x - mu)*rstd (xh' uses relu(x)).  Pass 1: per (n, slab, c) sums of
+//   A = sum dyp, Bs = sum dyp*xh   (dyp = dz gated by the ReLU for GN_RELU).
+// Finalize: per (n, c) totals -> per (n, g) S1 = sum_c g_c A, S2 = sum_c g_c Bs and the
+// parameter gradients d gamma_c = sum_n Bs, d beta_c = sum_n A.
+// Pass 2: dx = rstd * (dyp*g - S1/cnt - xh*S2/cnt)  [* (x>0) for RELU_GN]  (+ add).
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, int HW, int C,
+    const float* __restrict__ mu, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int ppb, float* __restrict__ partial /*[N,S,C,2]*/) {
+  __shared__ float part[256 * 8];
+  const int S = gridDim.x;
+  const int n = blockIdx.y;
+  const int cbase = blockIdx.z * 1024;
+  const int cchunk = min(C - cbase, 1024);
+  const int QW = cchunk >> 2;
+  const int PW = 256 / QW;
+  const int tq = threadIdx.x % QW, tp = threadIdx.x / QW;
+  const int c0 = cbase + 4 * tq;
+  const int p_begin = blockIdx.x * ppb;
+  const int p_end = min(p_begin + ppb, HW);
+  const f32x4 m4 = *reinterpret_cast<const f32x4*>(mu + (int64_t)n * C + c0);
+  const f32x4 r4 = *reinterpret_cast<const f32x4*>(rstd + (int64_t)n * C + c0);
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c0);
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + c0);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t base = ((int64_t)n * HW) * C + c0;
+  for (int p = p_begin + tp; p < p_end; p += PW) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (int64_t)p * C);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(dz + base + (int64_t)p * C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xh, dyp;
+      if (MODE == SNAP_PRO_GN_RELU) {
+        xh = (xv[e] - m4[e]) * r4[e];
+        dyp = (xh * g4[e] + b4[e] > 0.f) ? gv[e] : 0.f;
+      } else {
+        xh = (fmaxf(xv[e], 0.f) - m4[e]) * r4[e];
+        dyp = gv[e];
+      }
+      s1[e] += dyp;
+      s2[e] += dyp * xh;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    part[threadIdx.x * 8 + e] = s1[e];
+    part[threadIdx.x * 8 + 4 + e] = s2[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cchunk; c += 256) {
+    const int q = c >> 2, e = c & 3;
+    float a1 = 0.f, a2 = 0.f;
+    for (int pp = 0; pp < PW; ++pp) {
+      a1 += part[(pp * QW + q) * 8 + e];
+      a2 += part[(pp * QW + q) * 8 + 4 + e];
+    }
+    float* o = partial + (((int64_t)n * S + blockIdx.x) * C + cbase + c) * 2;
+    o[0] = a1;
+    o[1] = a2;
+  }
+}
+
+// thread per (n, c): slab totals -> AB[n,c,2]
+__global__ void gn_bwd_reduce_kernel(const float* __restrict__ partial, int S, int C, int total,
+                                     float* __restrict__ ab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*C
+  if (i >= total) return;
+  const int n = i / C, c = i - n * C;
+  float a1 = 0.f, a2 = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* p = partial + (((int64_t)n * S + s) * C + c) * 2;
+    a1 += p[0];
+    a2 += p[1];
+  }
+  ab[(int64_t)i * 2 + 0] = a1;
+  ab[(int64_t)i * 2 + 1] = a2;
+}
+
+// thread per (n, g): group sums;  thread per c (second launch dimension): param grads
+__global__ void gn_bwd_group_kernel(const float* __restrict__ ab, const float* __restrict__ gamma,
+                                    int N, int C, int groups, float* __restrict__ s12 /*[N,G,2]*/,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpg = C / groups;
+  if (i < N * groups) {
+    const int n = i / groups, g = i - n * groups;
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      t1 += gamma[c] * ab[((int64_t)n * C + c) * 2 + 0];
+      t2 += gamma[c] * ab[((int64_t)n * C + c) * 2 + 1];
+    }
+    s12[(int64_t)i * 2 + 0] = t1;
+    s12[(int64_t)i * 2 + 1] = t2;
+  }
+  if (i < C) {
+    float da = 0.f, db = 0.f;
+    for (int n = 0; n < N; ++n) {
+      da += ab[((int64_t)n * C + i) * 2 + 1];
+      db += ab[((int64_t)n * C + i) * 2 + 0];
+    }
+    dgamma[i] = accumulate ? dgamma[i] + da : da;
+    dbeta[i] = accumulate ? dbeta[i] + db : db;
+  }
+}
+
+template <int MODE>
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                    const float* __restrict__ add, float* __restrict__ dx,
+                                    int64_t total4, int HW, int C, int groups,
+                                    const float* __restrict__ mu, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ s12) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int C4 = C >> 2;
+  const int q = (int)(i % C4);
+  const int n = (int)((i / C4) / HW);
+  const int cpg = C / groups;
+  const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+  const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+  const f32x4 gv = reinterpret_cast<const f32x4*>(dz)[i];
+  const f32x4 m4 = *reinterpret_cast<const f32x4*>(mu + (int64_t)n * C + 4 * q);
+  const f32x4 r4 = *reinterpret_cast<const f32x4*>(rstd + (int64_t)n * C + 4 * q);
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * q);
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + 4 * q);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int g = (4 * q + e) / cpg;
+    const float S1 = s12[((int64_t)n * groups + g) * 2 + 0];
+    const float S2 = s12[((int64_t)n * groups + g) * 2 + 1];
+    float xh, dyp;
+    if (MODE == SNAP_PRO_GN_RELU) {
+      xh = (xv[e] - m4[e]) * r4[e];
+      dyp = (xh * g4[e] + b4[e] > 0.f) ? gv[e] : 0.f;
+    } else {
+      xh = (fmaxf(xv[e], 0.f) - m4[e]) * r4[e];
+      dyp = gv[e];
+    }
+    float d = r4[e] * (dyp * g4[e] - S1 * inv_cnt - xh * (S2 * inv_cnt));
+    if (MODE == SNAP_PRO_RELU_GN) d = xv[e] > 0.f ? d : 0.f;
+    o[e] = d;
+  }
+  if (add) {
+    const f32x4 av = reinterpret_cast<const f32x4*>(add)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += av[e];
+  }
+  reinterpret_cast<f32x4*>(dx)[i] = o;
+}
+
+// ---------------------------------------------------------------------------
+// StdConv backward: ws = (w - mean)/sigma per column;  dw = (dws - mean(dws) - ws*mean(dws*ws))/sigma
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __restrict__ w,
+                                                             const float* __restrict__ dws,
+                                                             float* __restrict__ dw, int K,
+                                                             int Cout, float eps) {
+  __shared__ float red[8][33];
+  __shared__ float stat[4][32];
+  const int tc = threadIdx.x & 31, tk = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tc;
+  const bool ok = col < Cout;
+  auto reduce = [&](float v, int slot, float scale) {
+    red[tk][tc] = v;
+    __syncthreads();
+    if (tk == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += red[i][tc];
+      stat[slot][tc] = t * scale;
+    }
+    __syncthreads();
+  };
+  float s = 0.f;
+  if (ok)
+    for (int k = tk; k < K; k += 8) s += w[(int64_t)k * Cout + col];
+  reduce(s, 0, 1.0f / (float)K);
+  const float mean = stat[0][tc];
+  float q = 0.f;
+  if (ok)
+    for (int k = tk; k < K; k += 8) {
+      const float dl = w[(int64_t)k * Cout + col] - mean;
+      q += dl * dl;
+    }
+  reduce(q, 1, 1.0f / (float)K);
+  const float sigma = sqrtf(stat[1][tc] + eps);
+  float g1 = 0.f, g2 = 0.f;
+  if (ok)
+    for (int k = tk; k < K; k += 8) {
+      const int64_t o = (int64_t)k * Cout + col;
+      const float ws = (w[o] - mean) / sigma;
+      g1 += dws[o];
+      g2 += dws[o] * ws;
+    }
+  reduce(g1, 2, 1.0f / (float)K);
+  reduce(g2, 3, 1.0f / (float)K);
+  const float mg = stat[2][tc], mgw = stat[3][tc];
+  // d sigma carries the eps: sigma^2 = var + eps, so d/dw (1/sigma) uses var/sigma... exact form:
+  // ws = (w-mean)/sigma; dw = (dws - mean(dws) - ws * mean(dws*ws)) / sigma.
+  if (ok)
+    for (int k = tk; k < K; k += 8) {
+      const int64_t o = (int64_t)k * Cout + col;
+      const float ws = (w[o] - mean) / sigma;
+      dw[o] = (dws[o] - mg - ws * mgw) / sigma;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// max-pool 3x3/2 pad 1 backward (gather form; first maximum in window scan order).
+// ---------------------------------------------------------------------------
+__global__ void max_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                    int Wo) {
+  const int64_t total = (int64_t)N * H * W * C;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  int64_t r = i / C;
+  const int wi = (int)(r % W); r /= W;
+  const int hi = (int)(r % H);
+  const int n = (int)(r / H);
+  const float xv = x[i];
+  float g = 0.f;
+  // windows (ho, wo) with ho*2-1 <= hi <= ho*2+1
+  for (int ho = (hi) / 2; ho <= (hi + 1) / 2; ++ho) {
+    if (ho < 0 || ho >= Ho) continue;
+    for (int wo = (wi) / 2; wo <= (wi + 1) / 2; ++wo) {
+      if (wo < 0 || wo >= Wo) continue;
+      // is (hi, wi) the first maximum of window (ho, wo)?
+      bool first = true;
+      for (int dh = 0; dh < 3 && first; ++dh) {
+        const int h2 = ho * 2 - 1 + dh;
+        if (h2 < 0 || h2 >= H) continue;
+        for (int dw = 0; dw < 3; ++dw) {
+          const int w2 = wo * 2 - 1 + dw;
+          if (w2 < 0 || w2 >= W) continue;
+          const float v = x[(((int64_t)n * H + h2) * W + w2) * C + c];
+          const bool before = (h2 < hi) || (h2 == hi && w2 < wi);
+          if (v > xv || (v == xv && before)) { first = false; break; }
+        }
+      }
+      if (first) g += dy[(((int64_t)n * Ho + ho) * Wo + wo) * C + c];
+    }
+  }
+  dx[i] = g;
+}
+
+// ---------------------------------------------------------------------------
+// bilinear x2 up-sample backward: dprev[n,hp,wp,:] = sum over fine pixels whose taps hit it.
+// ---------------------------------------------------------------------------
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dprev,
+                                      int N, int Hp, int Wp, int C) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)N * Hp * Wp * C4;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i % C4);
+  int64_t r = i / C4;
+  const int wp = (int)(r % Wp); r /= Wp;
+  const int hp = (int)(r % Hp);
+  const int n = (int)(r / Hp);
+  const int Ho = 2 * Hp, Wo = 2 * Wp;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int ho = 2 * hp - 2; ho <= 2 * hp + 2; ++ho) {
+    if (ho < 0 || ho >= Ho) continue;
+    const float sh = (ho + 0.5f) * 0.5f - 0.5f;
+    const float fh = floorf(sh);
+    const float wh1 = sh - fh, wh0 = 1.f - wh1;
+    const int h0 = min(max((int)fh, 0), Hp - 1), h1 = min(max((int)fh + 1, 0), Hp - 1);
+    const float wh = (h0 == hp ? wh0 : 0.f) + (h1 == hp ? wh1 : 0.f);
+    if (wh == 0.f) continue;
+    for (int wo = 2 * wp - 2; wo <= 2 * wp + 2; ++wo) {
+      if (wo < 0 || wo >= Wo) continue;
+      const float sw = (wo + 0.5f) * 0.5f - 0.5f;
+      const float fw = floorf(sw);
+      const float ww1 = sw - fw, ww0 = 1.f - ww1;
+      const int w0 = min(max((int)fw, 0), Wp - 1), w1 = min(max((int)fw + 1, 0), Wp - 1);
+      const float ww = (w0 == wp ? ww0 : 0.f) + (w1 == wp ? ww1 : 0.f);
+      if (ww == 0.f) continue;
+      const f32x4 g =
+          *reinterpret_cast<const f32x4*>(dy + (((int64_t)n * Ho + ho) * Wo + wo) * C + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += (wh * ww) * g[e];
+    }
+  }
+  reinterpret_cast<f32x4*>(dprev)[i] = acc;
+}
+
+// dy_lin = dy * [y > 0 if relu] * rowmask  (float4)
+__global__ void epilogue_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                    const uint8_t* __restrict__ row_mask, float* __restrict__ out,
+                                    int64_t total4, int C4, int relu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+  if (row_mask && !row_mask[i / C4]) g = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (relu) {
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+  }
+  reinterpret_cast<f32x4*>(out)[i] = g;
+}
+
+// column sums: partial[s][c] over row slabs, then fixed-order reduce.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int64_t M,
+                                                             int C, int64_t rows_per_block,
+                                                             float* __restrict__ partial) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
+  float t = 0.f;
+  for (int64_t r = r0; r < r1; ++r) t += a[r * C + c];
+  partial[(int64_t)blockIdx.x * C + c] = t;
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int S, int C,
+                                     float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = accumulate ? out[c] : 0.f;
+  for (int s = 0; s < S; ++s) t += partial[(int64_t)s * C + c];
+  out[c] = t;
+}
+
+struct GnPlanB { int S, ppb; };
+inline GnPlanB gn_plan_b(int N, int HW, int C) {
+  const int chunks = (C + 1023) / 1024;
+  int S = (1024 + N * chunks - 1) / (N * chunks);
+  const int smax = (HW + 7) / 8;
+  if (S > smax) S = smax;
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  GnPlanB p;
+  p.ppb = (HW + S - 1) / S;
+  p.S = (HW + p.ppb - 1) / p.ppb;
+  return p;
+}
+inline int colsum_slabs(int64_t M) {
+  int64_t s = (M + 511) / 512;
+  if (s > 2048) s = 2048;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" size_t snap_group_norm_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C,
+                                                      int32_t groups) {
+  const GnPlanB pl = gn_plan_b(N, HW, C);
+  return ((size_t)N * pl.S * C * 2 + (size_t)N * C * 2 + (size_t)N * groups * 2) * sizeof(float);
+}
+
+extern "C" int snap_group_norm_bwd_f32(const float* x, const float* dz, const float* add,
+                                       float* dx, int32_t N, int32_t HW, int32_t C, int32_t groups,
+                                       const float* mu, const float* rstd, const float* gamma,
+                                       const float* beta, int32_t mode, float* dgamma,
+                                       float* dbeta, int32_t accumulate, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  if (!x || !dz || !dx || !mu || !rstd || !gamma || !beta || !dgamma || !dbeta || !workspace)
+    return SNAP_ERR_NULL;
+  if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || C % 4 != 0)
+    return SNAP_ERR_BAD_SHAPE;
+  if (mode != SNAP_PRO_GN_RELU && mode != SNAP_PRO_RELU_GN) return SNAP_ERR_UNSUPPORTED;
+  const int nchunks = (C + 1023) / 1024;
+  if (nchunks > 1 && C % 1024 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int cchunk = nchunks > 1 ? 1024 : C;
+  if (256 % (cchunk / 4) != 0) return SNAP_ERR_BAD_SHAPE;
+  if (workspace_bytes < snap_group_norm_bwd_workspace_bytes(N, HW, C, groups))
+    return SNAP_ERR_WORKSPACE;
+  const GnPlanB pl = gn_plan_b(N, HW, C);
+  float* partial = static_cast<float*>(workspace);
+  float* ab = partial + (size_t)N * pl.S * C * 2;
+  float* s12 = ab + (size_t)N * C * 2;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(pl.S, N, nchunks);
+  if (mode == SNAP_PRO_GN_RELU)
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<SNAP_PRO_GN_RELU>, grid, dim3(256), 0, s, x, dz, HW, C,
+                       mu, rstd, gamma, beta, pl.ppb, partial);
+  else
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<SNAP_PRO_RELU_GN>, grid, dim3(256), 0, s, x, dz, HW, C,
+                       mu, rstd, gamma, beta, pl.ppb, partial);
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)snap_cdiv((int64_t)N * C, 256)),
+                     dim3(256), 0, s, (const float*)partial, pl.S, C, N * C, ab);
+  SNAP_CHECK_LAUNCH();
+  const int work = N * groups > C ? N * groups : C;
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)snap_cdiv(work, 256)), dim3(256), 0, s,
+                     (const float*)ab, gamma, N, C, groups, s12, dgamma, dbeta, accumulate);
+  SNAP_CHECK_LAUNCH();
+  const int64_t total4 = (int64_t)N * HW * (C / 4);
+  if (mode == SNAP_PRO_GN_RELU)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<SNAP_PRO_GN_RELU>, dim3((unsigned)snap_cdiv(total4, 256)),
+                       dim3(256), 0, s, x, dz, add, dx, total4, HW, C, groups, mu, rstd, gamma, beta,
+                       (const float*)s12);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<SNAP_PRO_RELU_GN>, dim3((unsigned)snap_cdiv(total4, 256)),
+                       dim3(256), 0, s, x, dz, add, dx, total4, HW, C, groups, mu, rstd, gamma, beta,
+                       (const float*)s12);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_weight_standardize_bwd_f32(const float* w, const float* dws, float* dw,
+                                               int32_t K, int32_t Cout, float eps, void* stream) {
+  if (!w || !dws || !dw) return SNAP_ERR_NULL;
+  if (K <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((unsigned)snap_cdiv(Cout, 32)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, dws, dw, K, Cout, eps);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_max_pool_3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int32_t N,
+                                           int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!x || !dy || !dx) return SNAP_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return SNAP_ERR_BAD_SHAPE;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * H * W * C;
+  hipLaunchKernelGGL(max_pool_bwd_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, dy, dx, N, H, W, C, Ho, Wo);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_upsample2x_bwd_f32(const float* dy, float* dprev, int32_t N, int32_t Hp,
+                                       int32_t Wp, int32_t C, void* stream) {
+  if (!dy || !dprev) return SNAP_ERR_NULL;
+  if (N <= 0 || Hp <= 0 || Wp <= 0 || C <= 0 || C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)N * Hp * Wp * (C / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dy, dprev, N, Hp, Wp, C);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_epilogue_bwd_f32(const float* dy, const float* y, const uint8_t* row_mask,
+                                     float* out, int64_t M, int32_t C, int32_t relu, void* stream) {
+  if (!dy || !out) return SNAP_ERR_NULL;
+  if (relu && !y) return SNAP_ERR_NULL;
+  if (M <= 0 || C <= 0 || C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total4 = M * (C / 4);
+  hipLaunchKernelGGL(epilogue_bwd_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dy, y, row_mask, out, total4, C / 4, relu);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" size_t snap_colsum_workspace_bytes(int64_t M, int32_t C) {
+  return (size_t)colsum_slabs(M) * C * sizeof(float);
+}
+
+extern "C" int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!a || !out || !workspace) return SNAP_ERR_NULL;
+  if (M <= 0 || C <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (workspace_bytes < snap_colsum_workspace_bytes(M, C)) return SNAP_ERR_WORKSPACE;
+  const int S = colsum_slabs(M);
+  const int64_t rpb = (M + S - 1) / S;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(S, (unsigned)snap_cdiv(C, 256)), dim3(256), 0, s, a,
+                     M, C, rpb, static_cast<float*>(workspace));
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 256)), dim3(256), 0, s,
+                     (const float*)workspace, S, C, out, accumulate);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

@@ -130,7 +130,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const float* __restrict__ x, const float* __restrict__ partial, int S, int HW, int C, int Cs,
     int groups, int relu_first, float eps, const float* __restrict__ gamma,
-    float* __restrict__ mu, float* __restrict__ sc, int total) {
+    float* __restrict__ mu, float* __restrict__ sc, float* __restrict__ rstd_out, int total) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // over N*groups
   if (i >= total) return;
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   for (int cc = lane; cc < cpg; cc += 64) {
     mu[(int64_t)n * C + c_lo + cc] = meanf;
     sc[(int64_t)n * C + c_lo + cc] = rstd * gamma[c_lo + cc];
+    if (rstd_out) rstd_out[(int64_t)n * C + c_lo + cc] = rstd;
   }
 }
 
@@ -262,8 +263,8 @@ extern "C" size_t snap_group_norm_stats_workspace_bytes(int32_t N, int32_t HW, i
 extern "C" int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, int32_t C,
                                          int32_t C_stride, int32_t groups, float eps,
                                          int32_t relu_first, const float* gamma, float* mu,
-                                         float* sc, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
+                                         float* sc, float* rstd, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
   if (!x || !gamma || !mu || !sc || !workspace) return SNAP_ERR_NULL;
   if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0) return SNAP_ERR_BAD_SHAPE;
   if (C % 4 != 0 || C_stride % 4 != 0 || C_stride < C) return SNAP_ERR_BAD_SHAPE;
@@ -282,7 +283,7 @@ extern "C" int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, 
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv(N * groups, 4)), dim3(256), 0, s,
                      x, (const float*)partial, pl.S, HW, C, C_stride, groups, relu_first, eps,
-                     gamma, mu, sc, N * groups);
+                     gamma, mu, sc, rstd, N * groups);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

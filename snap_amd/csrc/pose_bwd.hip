@@ -1,0 +1,180 @@
+// Backward kernels of the pose head (training path):
+//   * pose_score backward: d scores[B,P] -> d sim_points[B,Nq,X,Y]
+//       (VJP of pose_estimation.py:63-82: bilinear scatter of every pose's gradient
+//        into the point's score plane, accumulated in LDS, one plane at a time)
+//   * similarity backward helper: G = d sim * [sim > 0] * scale / num_valid in place
+//       + the temperature gradient sum(d sim * sim)   (VJP of bev_localizer.py:157-173;
+//        prob_points is behind stop_gradient in the reference, :178)
+// The two GEMM-shaped contractions of the similarity VJP (d fq = G fm, d fm = G^T fq)
+// run on the MFMA engines (conv_igemm.hip / wgrad.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int PB_THREADS = 1024;
+constexpr int PB_PPT = 10;
+constexpr int PB_LDS_FLOATS = 24 * 1024;  // 96 KiB accumulator plane
+
+struct ScoreBwdArgs {
+  const float* dscores;   // [B,P]
+  const float* table;     // [B,P,4] (A, B, Cx, Cy) cell-unit affine poses
+  const float* q_xy;      // [B,Nq,2]
+  const uint8_t* valid_q; // [B,Nq]
+  const uint8_t* map_valid;
+  int B, Nq, X, Y, P;
+  int mask_oob;
+  int points_per_chunk;
+  float* dsim;            // [B,Nq,X,Y]
+};
+
+template <bool MASK>
+__global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_kernel(const ScoreBwdArgs a) {
+  extern __shared__ float plane[];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int XY = a.X * a.Y;
+  const float Xf = (float)a.X, Yf = (float)a.Y;
+  const int n_begin = blockIdx.x * a.points_per_chunk;
+  const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
+  const uint8_t* mvalid = a.map_valid ? a.map_valid + (int64_t)b * XY : nullptr;
+  const int passes = (a.P + PB_THREADS * PB_PPT - 1) / (PB_THREADS * PB_PPT);
+  for (int n = n_begin; n < n_end; ++n) {
+    float* dst = a.dsim + ((int64_t)b * a.Nq + n) * XY;
+    if (!a.valid_q[(int64_t)b * a.Nq + n]) {   // block-uniform: zero gradient plane
+      for (int i = tid; i < XY; i += PB_THREADS) dst[i] = 0.f;
+      continue;
+    }
+    for (int i = tid; i < XY; i += PB_THREADS) plane[i] = 0.f;
+    __syncthreads();
+    const float qx = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+    const float qy = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+    for (int ps = 0; ps < passes; ++ps) {
+#pragma unroll
+      for (int k = 0; k < PB_PPT; ++k) {
+        const int p = (ps * PB_PPT + k) * PB_THREADS + tid;
+        if (p >= a.P) continue;
+        const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + p];
+        const float g = a.dscores[(int64_t)b * a.P + p];
+        const float cu = fmaf(t[0], qx, fmaf(-t[1], qy, t[2]));
+        const float cv = fmaf(t[1], qx, fmaf(t[0], qy, t[3]));
+        const float fu = floorf(cu), fv = floorf(cv);
+        const int i0 = (int)fminf(fmaxf(fu, 0.f), Xf - 1.f);
+        const int i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), Xf - 1.f);
+        const int j0 = (int)fminf(fmaxf(fv, 0.f), Yf - 1.f);
+        const int j1 = (int)fminf(fmaxf(fv + 1.f, 0.f), Yf - 1.f);
+        const float wu1 = cu - fu, wu0 = 1.f - wu1;
+        const float wv1 = cv - fv, wv0 = 1.f - wv1;
+        bool ok = true;
+        if (MASK) {
+          const float u = cu + 0.5f, v = cv + 0.5f;
+          ok = (u >= 0.f) && (u < Xf) && (v >= 0.f) && (v < Yf);
+          ok = ok && mvalid[i0 * a.Y + j0] && mvalid[i0 * a.Y + j1] && mvalid[i1 * a.Y + j0] &&
+               mvalid[i1 * a.Y + j1];
+        }
+        if (ok && g != 0.f) {
+          atomicAdd(&plane[i0 * a.Y + j0], (wu0 * wv0) * g);
+          atomicAdd(&plane[i0 * a.Y + j1], (wu0 * wv1) * g);
+          atomicAdd(&plane[i1 * a.Y + j0], (wu1 * wv0) * g);
+          atomicAdd(&plane[i1 * a.Y + j1], (wu1 * wv1) * g);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < XY; i += PB_THREADS) dst[i] = plane[i];
+    __syncthreads();
+  }
+}
+
+// G = dsim * [sim > 0] * coef[b] in place; per-block partial of sum(dsim * sim).
+__global__ __launch_bounds__(256) void sim_bwd_prepare_kernel(float* __restrict__ dsim,
+                                                              const float* __restrict__ sim,
+                                                              int64_t per_scene, int clip,
+                                                              const float* __restrict__ coef,
+                                                              float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int b = blockIdx.y;
+  const int64_t base = (int64_t)b * per_scene;
+  const float cf = coef[b];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_scene;
+       i += (int64_t)gridDim.x * 256) {
+    const float g = dsim[base + i];
+    const float s = sim[base + i];
+    acc += g * s;
+    dsim[base + i] = (!clip || s > 0.f) ? g * cf : 0.f;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ void pose_table_cells_bwd_kernel(const float* __restrict__ poses, int64_t total,
+                                            float cell, float* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float th = poses[i * 3 + 0];
+  f32x4 t;
+  t[0] = cosf(th) / cell; t[1] = sinf(th) / cell;
+  t[2] = poses[i * 3 + 1] / cell - 0.5f; t[3] = poses[i * 3 + 2] / cell - 0.5f;
+  reinterpret_cast<f32x4*>(table)[i] = t;
+}
+
+}  // namespace
+
+extern "C" size_t snap_pose_score_bwd_workspace_bytes(int32_t B, int32_t P) {
+  return (size_t)B * P * 4 * sizeof(float);
+}
+
+extern "C" int snap_pose_score_bwd_f32(const float* dscores, const float* poses, const float* q_xy,
+                                       const uint8_t* valid_q, const uint8_t* map_valid, int32_t B,
+                                       int32_t Nq, int32_t X, int32_t Y, int32_t P,
+                                       float cell_size, int32_t mask_oob, float* dsim,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dscores || !poses || !q_xy || !valid_q || !dsim || !workspace) return SNAP_ERR_NULL;
+  if (mask_oob && !map_valid) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || P <= 0) return SNAP_ERR_BAD_SHAPE;
+  if ((int64_t)X * Y > PB_LDS_FLOATS) return SNAP_ERR_UNSUPPORTED;   // band tiling: forward only
+  if (workspace_bytes < snap_pose_score_bwd_workspace_bytes(B, P)) return SNAP_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return SNAP_ERR_BAD_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* table = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(pose_table_cells_bwd_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)),
+                     dim3(256), 0, s, poses, (int64_t)B * P, cell_size, table);
+  SNAP_CHECK_LAUNCH();
+  ScoreBwdArgs a;
+  a.dscores = dscores; a.table = table; a.q_xy = q_xy; a.valid_q = valid_q; a.map_valid = map_valid;
+  a.B = B; a.Nq = Nq; a.X = X; a.Y = Y; a.P = P; a.mask_oob = mask_oob; a.dsim = dsim;
+  int nch = (512 + B - 1) / B;
+  if (nch > Nq) nch = Nq;
+  a.points_per_chunk = (Nq + nch - 1) / nch;
+  nch = (Nq + a.points_per_chunk - 1) / a.points_per_chunk;
+  const size_t lds = (size_t)X * Y * sizeof(float);
+  const void* fn = mask_oob ? (const void*)&pose_score_bwd_kernel<true>
+                            : (const void*)&pose_score_bwd_kernel<false>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(PB_LDS_FLOATS * sizeof(float))) != hipSuccess)
+      return SNAP_ERR_LAUNCH;
+  }
+  void* kargs[] = {(void*)&a};
+  if (hipLaunchKernel(fn, dim3(nch, B), dim3(PB_THREADS), kargs, lds, s) != hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_sim_bwd_prepare_f32(float* dsim, const float* sim, int32_t B, int64_t per_scene,
+                                        int32_t clip_negative, const float* coef, float* partial,
+                                        int32_t num_partial, void* stream) {
+  if (!dsim || !sim || !coef || !partial) return SNAP_ERR_NULL;
+  if (B <= 0 || per_scene <= 0 || num_partial <= 0 || num_partial > 65535) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sim_bwd_prepare_kernel, dim3(num_partial, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dsim, sim, per_scene, clip_negative, coef,
+                     partial);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

@@ -1,0 +1,339 @@
+// Weight-gradient engine (training path): dW[k, co] = sum_m Z[m, k] * dY[m, co]
+// with Z the implicit im2col of prologue(x) -- the transpose-A companion of
+// conv_igemm.hip on the same f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+// GEMM view: rows = K = KH*KW*Cin (one workgroup owns BKT consecutive input channels
+// of ONE (kh, kw) tap), cols = Cout (BN per workgroup), reduction over the M = N*Ho*Wo
+// output pixels in slabs of 16, split over gridDim.y chunks of M whose partial tiles
+// are summed by a second, fixed-order kernel (deterministic; no float atomics).
+// Both operands are staged row-major ([16 m][BKT] and [16 m][BN]): the loader writes
+// float4 rows straight to LDS and both MFMA operand fetches are conflict-free
+// ds_read_b32 over consecutive lanes -- no transpose anywhere.
+//
+// Used for: every conv / Dense kernel gradient (VJP of snap/models/resnet.py StdConv,
+// image_encoder.py skip convs, layers.py Dense), d fm = G^T fq of the similarity VJP
+// (bev_localizer.py:157) and the matching-head kernel gradient (bev_mapper.py:285).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  SnapConvDesc d;
+  const float* x;
+  const float* dy;
+  float* partial;  // [S, K, Cout]
+  const float* gn_mu;
+  const float* gn_sc;
+  const float* gn_beta;
+  int M, K;
+  int ctiles;      // channel tiles per (kh,kw) tap
+  int ncol;        // Cout tiles
+  int slabs_per_chunk;
+};
+
+template <int PRO>
+__device__ __forceinline__ float wg_pro(float v, float mu, float sc, float beta, float s, float t) {
+  if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
+  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
+  if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
+  if constexpr (PRO == SNAP_PRO_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+template <int BKT, int BN, bool VEC, int PRO>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  constexpr int RS = 16;                   // reduction slab (output pixels)
+  constexpr int TM = BKT / 64, TN = BN / 64;
+  constexpr int ZQ = BKT / 4;              // float4 per Z row
+  constexpr int ZRPP = 256 / ZQ;           // Z rows per pass
+  constexpr int ZPASS = RS / ZRPP;
+  constexpr int DQ = BN / 4;
+  constexpr int DRPP = 256 / DQ;
+  constexpr int DPASS = RS / DRPP;
+  constexpr int ZELEMS = (RS * BKT) / 256;  // scalar path: elements per thread
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  __shared__ __attribute__((aligned(16))) float smem[2 * RS * BKT + 2 * RS * BN];
+  float* const Zs0 = smem;
+  float* const Ds0 = smem + 2 * RS * BKT;
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int kt = blockIdx.x / a.ncol, col_t = blockIdx.x - kt * a.ncol;
+  const int kpos = kt / a.ctiles, ct = kt - kpos * a.ctiles;
+  const int kh = kpos / d.KW, kw = kpos - kh * d.KW;
+  const int c0 = ct * BKT;
+  const int n0 = col_t * BN;
+  const int HoWo = d.Ho * d.Wo;
+  const int64_t m_begin = (int64_t)blockIdx.y * a.slabs_per_chunk * RS;
+  const int64_t m_end = min((int64_t)a.M, m_begin + (int64_t)a.slabs_per_chunk * RS);
+  const int nslab = (int)((m_end - m_begin + RS - 1) / RS);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 zr[VEC ? ZPASS : 1], zmu[VEC ? ZPASS : 1], zsc[VEC ? ZPASS : 1], zbeta;
+  bool zin[VEC ? ZPASS : 1];
+  float se[VEC ? 1 : ZELEMS], smu[VEC ? 1 : ZELEMS], ssc[VEC ? 1 : ZELEMS], sbeta[VEC ? 1 : ZELEMS];
+  bool sin_[VEC ? 1 : ZELEMS];
+  f32x4 dr[DPASS];
+  bool din[DPASS];
+  const int zq = tid % ZQ, zrow0 = tid / ZQ;
+  const int dq = tid % DQ, drow0 = tid / DQ;
+  const int zc = c0 + 4 * zq;  // VEC: first channel of this thread's quad
+  if constexpr (VEC && need_gn) {
+    zbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (zc < d.Cin ? zc : 0));
+  }
+
+  auto load_slab = [&](int sl) {
+    const int64_t ms = m_begin + (int64_t)sl * RS;
+    if constexpr (VEC) {
+#pragma unroll
+      for (int p = 0; p < ZPASS; ++p) {
+        const int64_t m = ms + zrow0 + p * ZRPP;
+        const bool mok = m < m_end;
+        const int mm = mok ? (int)m : 0;
+        const int n = mm / HoWo;
+        const int r = mm - n * HoWo;
+        const int ho = r / d.Wo, wo = r - ho * d.Wo;
+        const int hi = ho * d.stride - d.pad_t + kh, wi = wo * d.stride - d.pad_l + kw;
+        const bool inb = mok && zc < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+        zin[p] = inb;
+        const int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + zc : (int64_t)0;
+        zr[p] = *reinterpret_cast<const f32x4*>(a.x + off);
+        if constexpr (need_gn) {
+          const int64_t so = inb ? (int64_t)n * d.Cin + zc : (int64_t)0;
+          zmu[p] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
+          zsc[p] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < ZELEMS; ++e) {
+        const int idx = tid + 256 * e;           // over RS x BKT
+        const int rr = idx / BKT, cc = idx - rr * BKT;
+        const int64_t m = ms + rr;
+        const bool mok = m < m_end;
+        const int mm = mok ? (int)m : 0;
+        const int n = mm / HoWo;
+        const int r = mm - n * HoWo;
+        const int ho = r / d.Wo, wo = r - ho * d.Wo;
+        const int hi = ho * d.stride - d.pad_t + kh, wi = wo * d.stride - d.pad_l + kw;
+        const int c = c0 + cc;
+        const bool inb = mok && c < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+        sin_[e] = inb;
+        const int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + c : (int64_t)0;
+        se[e] = a.x[off];
+        if constexpr (need_gn) {
+          const int64_t so = inb ? (int64_t)n * d.Cin + c : (int64_t)0;
+          smu[e] = a.gn_mu[so];
+          ssc[e] = a.gn_sc[so];
+          sbeta[e] = a.gn_beta[inb ? c : 0];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p) {
+      const int64_t m = ms + drow0 + p * DRPP;
+      const int col = n0 + 4 * dq;
+      const bool ok = m < m_end && col < d.Cout;
+      din[p] = ok;
+      dr[p] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? m * d.Cout_stride + col : (int64_t)0));
+    }
+  };
+
+  auto store_slab = [&](int buf) {
+    float* zs = Zs0 + buf * (RS * BKT);
+    float* ds = Ds0 + buf * (RS * BN);
+    if constexpr (VEC) {
+#pragma unroll
+      for (int p = 0; p < ZPASS; ++p) {
+        f32x4 v = zr[p];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pv;
+          if constexpr (need_gn)
+            pv = wg_pro<PRO>(v[e], zmu[p][e], zsc[p][e], zbeta[e], d.in_scale, d.in_shift);
+          else
+            pv = wg_pro<PRO>(v[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+          v[e] = (zin[p] && (zc + e < d.Cin)) ? pv : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(zs + (zrow0 + p * ZRPP) * BKT + 4 * zq) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < ZELEMS; ++e) {
+        const int idx = tid + 256 * e;
+        float pv;
+        if constexpr (need_gn)
+          pv = wg_pro<PRO>(se[e], smu[e], ssc[e], sbeta[e], d.in_scale, d.in_shift);
+        else
+          pv = wg_pro<PRO>(se[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+        zs[idx] = sin_[e] ? pv : 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p)
+      *reinterpret_cast<f32x4*>(ds + (drow0 + p * DRPP) * BN + 4 * dq) =
+          din[p] ? dr[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  if (nslab > 0) {
+    load_slab(0);
+    store_slab(0);
+  }
+  __syncthreads();
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int cur = sl & 1;
+    const bool more = sl + 1 < nslab;
+    if (more) load_slab(sl + 1);
+    const float* zs = Zs0 + cur * (RS * BKT);
+    const float* ds = Ds0 + cur * (RS * BN);
+#pragma unroll
+    for (int kk = 0; kk < RS / 2; ++kk) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = zs[(2 * kk + lhi) * BKT + wr * (BKT / 2) + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = ds[(2 * kk + lhi) * BN + wc * (BN / 2) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_slab(cur ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> workspace [chunk][K][Cout]
+  float* out = a.partial + (int64_t)blockIdx.y * a.K * d.Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int c = c0 + wr * (BKT / 2) + i * 32 + ri;
+      if (c >= d.Cin) continue;
+      const int64_t krow = (int64_t)kpos * d.Cin + c;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+        if (col < d.Cout) out[krow * d.Cout + col] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t total,
+                                    float* __restrict__ dw, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float t = accumulate ? dw[i] : 0.f;
+  for (int s = 0; s < S; ++s) t += partial[(int64_t)s * total + i];
+  dw[i] = t;
+}
+
+struct WgPlan { int bkt, bn, ctiles, ncol, S, slabs_per_chunk; };
+
+inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
+  WgPlan p;
+  p.bkt = (vec && d.Cin > 64) ? 128 : 64;
+  p.bn = d.Cout > 64 ? 128 : 64;
+  p.ctiles = (d.Cin + p.bkt - 1) / p.bkt;
+  p.ncol = (d.Cout + p.bn - 1) / p.bn;
+  const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+  // the M split is sized on 64-channel tiles so that it (and the workspace) does not
+  // depend on which loader variant runs.
+  const int64_t tiles = (int64_t)d.KH * d.KW * ((d.Cin + 63) / 64) * p.ncol;
+  int64_t S = (1024 + tiles - 1) / tiles;
+  const int64_t smax = (M + 255) / 256;   // >= 16 slabs per chunk
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  const int64_t slabs = (M + 15) / 16;
+  p.slabs_per_chunk = (int)((slabs + S - 1) / S);
+  p.S = (int)((slabs + p.slabs_per_chunk - 1) / p.slabs_per_chunk);
+  return p;
+}
+
+template <int BKT, int BN, bool VEC, int PRO>
+int wg_launch(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
+  const dim3 grid((unsigned)(a.d.KH * a.d.KW * p.ctiles * p.ncol), (unsigned)p.S);
+  hipLaunchKernelGGL((wgrad_kernel<BKT, BN, VEC, PRO>), grid, dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+template <int BKT, int BN, bool VEC>
+int wg_launch_pro(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
+  switch (a.d.prologue) {
+    case SNAP_PRO_NONE: return wg_launch<BKT, BN, VEC, SNAP_PRO_NONE>(a, p, s);
+    case SNAP_PRO_AFFINE: return wg_launch<BKT, BN, VEC, SNAP_PRO_AFFINE>(a, p, s);
+    case SNAP_PRO_GN_RELU:
+      if constexpr (VEC) return wg_launch<BKT, BN, VEC, SNAP_PRO_GN_RELU>(a, p, s);
+      return SNAP_ERR_UNSUPPORTED;
+    case SNAP_PRO_RELU_GN:
+      if constexpr (VEC) return wg_launch<BKT, BN, VEC, SNAP_PRO_RELU_GN>(a, p, s);
+      return SNAP_ERR_UNSUPPORTED;
+    case SNAP_PRO_RELU: return wg_launch<BKT, BN, VEC, SNAP_PRO_RELU>(a, p, s);
+    default: return SNAP_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc) {
+  if (!desc) return 0;
+  const WgPlan p = wg_plan(*desc, true);
+  return (size_t)p.S * desc->KH * desc->KW * desc->Cin * desc->Cout * sizeof(float);
+}
+
+extern "C" int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, const float* dy,
+                                     float* dw, const float* gn_mu, const float* gn_sc,
+                                     const float* gn_beta, int32_t accumulate, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (!desc || !x || !dy || !dw || !workspace) return SNAP_ERR_NULL;
+  const SnapConvDesc& d = *desc;
+  if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 || d.KW <= 0 ||
+      d.stride <= 0 || d.Ho <= 0 || d.Wo <= 0)
+    return SNAP_ERR_BAD_SHAPE;
+  if (d.Cin_stride < d.Cin || d.Cout_stride < d.Cout || d.Cout % 4 != 0 || d.Cout_stride % 4 != 0)
+    return SNAP_ERR_BAD_SHAPE;
+  if ((int64_t)d.N * d.Ho * d.Wo > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return SNAP_ERR_BAD_SHAPE;
+  const bool gn = d.prologue == SNAP_PRO_GN_RELU || d.prologue == SNAP_PRO_RELU_GN;
+  if (gn && (!gn_mu || !gn_sc || !gn_beta)) return SNAP_ERR_NULL;
+  if (workspace_bytes < snap_conv2d_wgrad_workspace_bytes(desc)) return SNAP_ERR_WORKSPACE;
+  const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
+                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (!gn || (d.Cin % 4 == 0));
+  const WgPlan p = wg_plan(d, vec);
+  WgradArgs a;
+  a.d = d;
+  a.x = x; a.dy = dy; a.partial = static_cast<float*>(workspace);
+  a.gn_mu = gn_mu; a.gn_sc = gn_sc; a.gn_beta = gn_beta;
+  a.M = d.N * d.Ho * d.Wo;
+  a.K = d.KH * d.KW * d.Cin;
+  a.ctiles = p.ctiles; a.ncol = p.ncol; a.slabs_per_chunk = p.slabs_per_chunk;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  if (vec) {
+    if (p.bkt == 128) rc = p.bn == 128 ? wg_launch_pro<128, 128, true>(a, p, s) : wg_launch_pro<128, 64, true>(a, p, s);
+    else rc = p.bn == 128 ? wg_launch_pro<64, 128, true>(a, p, s) : wg_launch_pro<64, 64, true>(a, p, s);
+  } else {
+    rc = p.bn == 128 ? wg_launch_pro<64, 128, false>(a, p, s) : wg_launch_pro<64, 64, false>(a, p, s);
+  }
+  if (rc != SNAP_OK) return rc;
+  const int64_t total = (int64_t)a.K * d.Cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0, s,
+                     (const float*)a.partial, p.S, total, dw, accumulate);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

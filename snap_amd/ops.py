@@ -223,8 +223,8 @@ def weight_standardize(w, eps=1e-10):
   return out
 
 
-def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False):
-  """x [N,H,W,C] -> (mu [N,C], sc [N,C]) with sc = rstd * gamma."""
+def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False, want_rstd=False):
+  """x [N,H,W,C] -> (mu [N,C], sc [N,C]) with sc = rstd * gamma (+ rstd [N,C])."""
   lib = _lib.load()
   _f32(x, 'x'); _f32(gamma, 'gamma')
   N, H, W, C = x.shape
@@ -233,12 +233,15 @@ def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False):
   ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=x.device)
   mu = torch.empty((N, C), dtype=torch.float32, device=x.device)
   sc = torch.empty((N, C), dtype=torch.float32, device=x.device)
+  rstd = torch.empty((N, C), dtype=torch.float32, device=x.device) if want_rstd else None
   with _region('group_norm_stats', 0.0, 8.0 * x.numel()):
     st = lib.snap_group_norm_stats_f32(
         _p(x), N, HW, C, C, groups, eps, int(relu_first), _p(gamma), _p(mu),
-        _p(sc), _p(ws), ws.numel() * 4, _stream(),
+        _p(sc), _p(rstd), _p(ws), ws.numel() * 4, _stream(),
     )
   _lib.check(st, 'snap_group_norm_stats_f32')
+  if want_rstd:
+    return mu, sc, rstd
   return mu, sc
 
 

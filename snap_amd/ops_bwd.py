@@ -1,0 +1,215 @@
+"""Host-side wrappers of the backward (training-path) entry points of the C ABI.
+
+Same conventions as :mod:`snap_amd.ops`: GPU tensors only, no fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from snap_amd import _lib
+from snap_amd import ops
+from snap_amd.ops import _f32, _mask, _p, _region, _stream, POOLING
+
+
+def _conv_desc(x_shape, w_shape, stride, padding, prologue, in_affine, cs=None):
+  N, H, W, Cs = x_shape
+  KH, KW, Cin, Cout = w_shape
+  (pt, pb), (pl, pr) = padding
+  Ho = (H + pt + pb - KH) // stride + 1
+  Wo = (W + pl + pr - KW) // stride + 1
+  return _lib.SnapConvDesc(
+      N, H, W, Cin, Cs if cs is None else cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout,
+      prologue, 0, float(in_affine[0]), float(in_affine[1]),
+  ), (N, Ho, Wo, Cout)
+
+
+def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue=ops.PRO_NONE,
+                 gn=None, in_affine=(1.0, 0.0)):
+  """dw [KH,KW,Cin,Cout] = im2col(prologue(x))^T dy  (MFMA; deterministic split-M)."""
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(dy, 'dy')
+  d, yshape = _conv_desc(x.shape, w_shape, stride, padding, prologue, in_affine)
+  if tuple(dy.shape) != yshape:
+    raise ValueError(f'conv2d_wgrad: dy {tuple(dy.shape)} vs {yshape}')
+  mu = sc = beta = None
+  if prologue in (ops.PRO_GN_RELU, ops.PRO_RELU_GN):
+    mu, sc, beta = gn
+  wsb = lib.snap_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=x.device)
+  dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+  KH, KW, Cin, Cout = w_shape
+  M = yshape[0] * yshape[1] * yshape[2]
+  with _region('conv_wgrad', 2.0 * M * KH * KW * Cin * Cout, 4.0 * (x.numel() + dy.numel())):
+    st = lib.snap_conv2d_wgrad_f32(
+        ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(mu), _p(sc), _p(beta), 0, _p(ws),
+        ws.numel() * 4, _stream(),
+    )
+  _lib.check(st, 'snap_conv2d_wgrad_f32')
+  return dw
+
+
+def group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, *, groups=32, add=None):
+  """VJP of the fused GroupNorm(+ReLU) prologue.  Returns dx, dgamma, dbeta."""
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(dz, 'dz'); _f32(mu, 'mu'); _f32(rstd, 'rstd')
+  N, H, W, C = x.shape
+  wsb = lib.snap_group_norm_bwd_workspace_bytes(N, H * W, C, groups)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=x.device)
+  dx = torch.empty_like(x)
+  dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+  dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+  with _region('group_norm_bwd', 0.0, 16.0 * x.numel()):
+    st = lib.snap_group_norm_bwd_f32(
+        _p(x), _p(dz), _p(add), _p(dx), N, H * W, C, groups, _p(mu), _p(rstd), _p(gamma),
+        _p(beta), mode, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel() * 4, _stream(),
+    )
+  _lib.check(st, 'snap_group_norm_bwd_f32')
+  return dx, dgamma, dbeta
+
+
+def weight_standardize_bwd(w, dws, eps=1e-10):
+  lib = _lib.load()
+  _f32(w, 'w'); _f32(dws, 'dws')
+  dw = torch.empty_like(w)
+  K = w.shape[0] * w.shape[1] * w.shape[2]
+  st = lib.snap_weight_standardize_bwd_f32(_p(w), _p(dws), _p(dw), K, w.shape[3], eps, _stream())
+  _lib.check(st, 'snap_weight_standardize_bwd_f32')
+  return dw
+
+
+def max_pool_3x3s2_bwd(x, dy):
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(dy, 'dy')
+  N, H, W, C = x.shape
+  dx = torch.empty_like(x)
+  st = lib.snap_max_pool_3x3s2_bwd_f32(_p(x), _p(dy), _p(dx), N, H, W, C, _stream())
+  _lib.check(st, 'snap_max_pool_3x3s2_bwd_f32')
+  return dx
+
+
+def upsample2x_bwd(dy):
+  lib = _lib.load()
+  _f32(dy, 'dy')
+  N, Ho, Wo, C = dy.shape
+  dprev = torch.empty((N, Ho // 2, Wo // 2, C), dtype=torch.float32, device=dy.device)
+  st = lib.snap_upsample2x_bwd_f32(_p(dy), _p(dprev), N, Ho // 2, Wo // 2, C, _stream())
+  _lib.check(st, 'snap_upsample2x_bwd_f32')
+  return dprev
+
+
+def epilogue_bwd(dy, y=None, row_mask=None, relu=False):
+  """dy gated by the forward epilogue: * [y > 0] (ReLU) * row_mask."""
+  lib = _lib.load()
+  _f32(dy, 'dy')
+  C = dy.shape[-1]
+  M = dy.numel() // C
+  out = torch.empty_like(dy)
+  st = lib.snap_epilogue_bwd_f32(_p(dy), _p(y), _p(row_mask), _p(out), M, C, int(relu), _stream())
+  _lib.check(st, 'snap_epilogue_bwd_f32')
+  return out
+
+
+def colsum(a):
+  """Column sums of a [..., C] -> [C]  (bias gradients)."""
+  lib = _lib.load()
+  _f32(a, 'a')
+  C = a.shape[-1]
+  M = a.numel() // C
+  wsb = lib.snap_colsum_workspace_bytes(M, C)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=a.device)
+  out = torch.empty(C, dtype=torch.float32, device=a.device)
+  st = lib.snap_colsum_f32(_p(a), M, C, _p(out), 0, _p(ws), ws.numel() * 4, _stream())
+  _lib.check(st, 'snap_colsum_f32')
+  return out
+
+
+def lift_pool_bwd(f_images, cam, Rt, points, dpooled, *, K, fisheye, feature_dim, num_bins,
+                  depth_min_max, max_view_distance=None):
+  lib = _lib.load()
+  _f32(f_images, 'f_images'); _f32(dpooled, 'dpooled')
+  B, V, h, w, C = f_images.shape
+  N = points.shape[1]
+  d = _lib.SnapLiftDesc(
+      B, V, h, w, C, feature_dim, num_bins, N, K, int(fisheye), dpooled.shape[-1],
+      float(depth_min_max[0]), float(depth_min_max[1]),
+      -1.0 if max_view_distance is None else float(max_view_distance),
+  )
+  df = torch.empty_like(f_images)
+  with _region('lift_pool_bwd', 0.0, 4.0 * (f_images.numel() * 2 + dpooled.numel())):
+    st = lib.snap_lift_pool_bwd_f32(
+        ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(dpooled), _p(df), _stream()
+    )
+  _lib.check(st, 'snap_lift_pool_bwd_f32')
+  return df
+
+
+def vertical_pool_bwd(vol, valid, dplane, pooling='max'):
+  lib = _lib.load()
+  _f32(vol, 'vol'); _mask(valid, 'valid'); _f32(dplane, 'dplane')
+  Z, D = vol.shape[-2:]
+  M = vol.numel() // (Z * D)
+  dvol = torch.empty_like(vol)
+  st = lib.snap_vertical_pool_bwd_f32(
+      _p(vol), _p(valid), _p(dplane), _p(dvol), M, Z, D, POOLING[pooling], _stream()
+  )
+  _lib.check(st, 'snap_vertical_pool_bwd_f32')
+  return dvol
+
+
+def plane_fuse_match_bwd(planes, valids, pooling, Wm, bm, normalize, eps, dmatching, dfused=None):
+  """Returns (dplanes list, dy [M,Dm] or None)."""
+  lib = _lib.load()
+  n = len(planes)
+  D = planes[0].shape[-1]
+  M = planes[0].numel() // D
+  dev = planes[0].device
+  dplanes = [torch.empty_like(p) for p in planes]
+  pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in planes])
+  vv = (ctypes.c_void_p * n)(*[None if v is None else _mask(v, 'valid').data_ptr() for v in valids])
+  dp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in dplanes])
+  dy = None
+  Dm = 0
+  if dmatching is not None:
+    _f32(dmatching, 'dmatching')
+    Dm = Wm.shape[1]
+    dy = torch.empty((M, Dm), dtype=torch.float32, device=dev)
+  st = lib.snap_plane_fuse_match_bwd_f32(
+      ctypes.cast(pp, ctypes.c_void_p), ctypes.cast(vv, ctypes.c_void_p),
+      ctypes.cast(dp, ctypes.c_void_p), n, M, D, POOLING[pooling], _p(Wm), _p(bm), Dm,
+      int(normalize), eps, _p(dmatching), _p(dfused), _p(dy), _stream(),
+  )
+  _lib.check(st, 'snap_plane_fuse_match_bwd_f32')
+  return dplanes, dy
+
+
+def pose_score_bwd(dscores, poses, q_xy, valid_q, map_valid, sim_shape, cell_size, mask_oob=False):
+  lib = _lib.load()
+  _f32(dscores, 'dscores'); _f32(poses, 'poses'); _f32(q_xy, 'q_xy'); _mask(valid_q, 'valid_q')
+  B, Nq, X, Y = sim_shape
+  P = poses.shape[1]
+  wsb = lib.snap_pose_score_bwd_workspace_bytes(B, P)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=poses.device)
+  dsim = torch.empty(sim_shape, dtype=torch.float32, device=poses.device)
+  with _region('pose_score_bwd', 0.0, 4.0 * dsim.numel()):
+    st = lib.snap_pose_score_bwd_f32(
+        _p(dscores), _p(poses), _p(q_xy), _p(valid_q), _p(map_valid), B, Nq, X, Y, P,
+        float(cell_size), int(mask_oob), _p(dsim), _p(ws), ws.numel() * 4, _stream(),
+    )
+  _lib.check(st, 'snap_pose_score_bwd_f32')
+  return dsim
+
+
+def sim_bwd_prepare_(dsim, sim, clip_negative, coef):
+  """In place G = dsim * [sim>0] * coef[b]; returns sum(dsim * sim) per scene [B]."""
+  lib = _lib.load()
+  _f32(dsim, 'dsim'); _f32(sim, 'sim'); _f32(coef, 'coef')
+  B = dsim.shape[0]
+  per_scene = dsim.numel() // B
+  nparts = 512
+  partial = torch.empty((B, nparts), dtype=torch.float32, device=dsim.device)
+  st = lib.snap_sim_bwd_prepare_f32(
+      _p(dsim), _p(sim), B, per_scene, int(clip_negative), _p(coef), _p(partial), nparts, _stream()
+  )
+  _lib.check(st, 'snap_sim_bwd_prepare_f32')
+  return partial.to(torch.float64).sum(-1)

@@ -1,0 +1,330 @@
+"""`-m gpu` gradient parity: every backward HIP kernel vs torch autograd (CPU, fp64)
+of a plain torch restatement of the same op (the fp reference for floating-point
+kernels), on the same seeded inputs and cotangents."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers
+import oracle_ops
+from snap_amd import ops
+from snap_amd import ops_bwd
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rnd(shape, seed, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return torch.randn(shape, generator=g) * scale
+
+
+def G(t):
+  return t.to(DEV).contiguous()
+
+
+# -- torch references (float64, differentiable) ---------------------------------------
+def ref_gn(x, gamma, beta, groups, relu_first, relu_after):
+  N, H, W, C = x.shape
+  v = torch.relu(x) if relu_first else x
+  g = v.reshape(N, H * W, groups, C // groups)
+  mean = g.mean((1, 3), keepdim=True)
+  var = ((g - mean) ** 2).mean((1, 3), keepdim=True)
+  y = ((g - mean) / torch.sqrt(var + 1e-5)).reshape(N, H, W, C) * gamma + beta
+  return torch.relu(y) if relu_after else y
+
+
+def ref_conv(z, w, stride, pad):
+  y = F.conv2d(z.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=stride, padding=pad)
+  return y.permute(0, 2, 3, 1)
+
+
+# -- wgrad / dgrad -----------------------------------------------------------------------
+WG_CASES = [
+    ('1x1', 2, 9, 7, 64, 1, 128, 1, 0, ops.PRO_NONE),
+    ('3x3_gn', 2, 10, 9, 64, 3, 64, 1, 1, ops.PRO_GN_RELU),
+    ('3x3_s2_gn', 2, 12, 10, 128, 3, 128, 2, 1, ops.PRO_GN_RELU),
+    ('1x1_relu_gn', 1, 8, 8, 256, 1, 32, 1, 0, ops.PRO_RELU_GN),
+    ('dense_k257', 1, 1, 500, 257, 1, 256, 1, 0, ops.PRO_NONE),
+    ('root_affine', 1, 18, 16, 3, 7, 32, 2, 3, ops.PRO_AFFINE),
+    ('1x1_relu', 1, 6, 6, 128, 1, 160, 1, 0, ops.PRO_RELU),
+    ('big_m', 4, 40, 40, 64, 1, 256, 1, 0, ops.PRO_GN_RELU),
+]
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_conv_wgrad(case):
+  _, N, H, W, Cin, k, Cout, stride, pad, pro = case
+  cs = 260 if Cin == 257 else Cin
+  x = torch.zeros(N, H, W, cs)
+  x[..., :Cin] = rnd((N, H, W, Cin), 1) + 0.1
+  w = rnd((k, k, Cin, Cout), 2, 1 / math.sqrt(k * k * Cin))
+  gamma, beta = rnd((Cin,), 3) * 0.3 + 1, rnd((Cin,), 4) * 0.2
+  Ho = (H + 2 * pad - k) // stride + 1
+  Wo = (W + 2 * pad - k) // stride + 1
+  dy = rnd((N, Ho, Wo, Cout), 5)
+  xd = x[..., :Cin].double()
+  if pro == ops.PRO_GN_RELU:
+    z = ref_gn(xd, gamma.double(), beta.double(), 32, False, True)
+  elif pro == ops.PRO_RELU_GN:
+    z = ref_gn(xd, gamma.double(), beta.double(), 32, True, False)
+  elif pro == ops.PRO_AFFINE:
+    z = xd * 2 - 1
+  elif pro == ops.PRO_RELU:
+    z = torch.relu(xd)
+  else:
+    z = xd
+  wd = w.double().requires_grad_(True)
+  ref_conv(z, wd, stride, pad).backward(dy.double())
+  gn = None
+  if pro in (ops.PRO_GN_RELU, ops.PRO_RELU_GN):
+    mu, sc = oracle_ops.group_norm_stats(x[..., :Cin].contiguous(), gamma,
+                                         relu_first=pro == ops.PRO_RELU_GN)
+    gn = (G(mu), G(sc), G(beta))
+  got = ops_bwd.conv2d_wgrad(G(x), G(dy), tuple(w.shape), stride=stride,
+                             padding=((pad, pad), (pad, pad)), prologue=pro, gn=gn,
+                             in_affine=(2.0, -1.0) if pro == ops.PRO_AFFINE else (1.0, 0.0))
+  ref = wd.grad
+  helpers.report('wgrad ' + case[0], got, ref.float(), atol=2e-4 * float(ref.abs().max()) + 1e-5)
+
+
+@pytest.mark.parametrize('k,stride,pad', [(1, 1, 0), (3, 1, 1), (3, 2, 1), (1, 2, 0)])
+def test_conv_dgrad_via_engine(k, stride, pad):
+  from snap_amd import autograd as ag
+  N, H, W, Cin, Cout = 2, 11, 10, 64, 128
+  x = rnd((N, H, W, Cin), 6).double().requires_grad_(True)
+  w = rnd((k, k, Cin, Cout), 7, 1 / math.sqrt(k * k * Cin))
+  y = ref_conv(x, w.double(), stride, pad)
+  dy = rnd(tuple(y.shape), 8)
+  y.backward(dy.double())
+  got = ag.conv_dgrad(G(dy), G(w), (N, H, W, Cin), stride, ((pad, pad), (pad, pad)))
+  helpers.report(f'dgrad k{k} s{stride}', got, x.grad.float(), atol=3e-5, rtol=1e-5)
+
+
+# -- GroupNorm backward -------------------------------------------------------------------
+@pytest.mark.parametrize('mode', [ops.PRO_GN_RELU, ops.PRO_RELU_GN])
+@pytest.mark.parametrize('C,HW', [(64, (9, 7)), (256, (5, 6)), (2048, (3, 2))])
+def test_group_norm_bwd(mode, C, HW):
+  N = 3
+  x = rnd((N, *HW, C), 10) * 1.5 + 0.4
+  gamma, beta = rnd((C,), 11) * 0.3 + 1, rnd((C,), 12) * 0.2
+  dz = rnd((N, *HW, C), 13)
+  add = rnd((N, *HW, C), 14)
+  xd = x.double().requires_grad_(True)
+  gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+  z = ref_gn(xd, gd, bd, 32, mode == ops.PRO_RELU_GN, mode == ops.PRO_GN_RELU)
+  z.backward(dz.double())
+  mu, sc, rstd = ops.group_norm_stats(G(x), G(gamma), relu_first=mode == ops.PRO_RELU_GN,
+                                      want_rstd=True)
+  dx, dgamma, dbeta = ops_bwd.group_norm_bwd(G(x), G(dz), mu, rstd, G(gamma), G(beta), mode,
+                                             add=G(add))
+  helpers.report('gn dx', dx, (xd.grad + add.double()).float(), atol=3e-5, rtol=1e-4)
+  helpers.report('gn dgamma', dgamma, gd.grad.float(), atol=2e-4, rtol=1e-4)
+  helpers.report('gn dbeta', dbeta, bd.grad.float(), atol=2e-4, rtol=1e-4)
+
+
+def test_small_backward_ops():
+  # weight standardisation
+  w = rnd((3, 3, 16, 24), 20) * 0.3 + 0.1
+  dws = rnd((3, 3, 16, 24), 21)
+  wd = w.double().requires_grad_(True)
+  u = wd - wd.mean((0, 1, 2), keepdim=True)
+  (u / torch.sqrt((u * u).mean((0, 1, 2), keepdim=True) + 1e-10)).backward(dws.double())
+  helpers.report('wstd bwd', ops_bwd.weight_standardize_bwd(G(w), G(dws)), wd.grad.float(),
+                 atol=1e-4, rtol=1e-4)
+  # max pool
+  x = rnd((2, 9, 11, 8), 22)
+  xd = x.double().requires_grad_(True)
+  y = F.max_pool2d(xd.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+  dy = rnd(tuple(y.shape), 23)
+  y.backward(dy.double())
+  helpers.report('maxpool bwd', ops_bwd.max_pool_3x3s2_bwd(G(x), G(dy)), xd.grad.float(), atol=1e-6)
+  # bilinear x2 transpose
+  p = rnd((2, 5, 4, 8), 24).double().requires_grad_(True)
+  up = F.interpolate(p.permute(0, 3, 1, 2), scale_factor=2, mode='bilinear', align_corners=False)
+  dyu = rnd((2, 10, 8, 8), 25)
+  up.permute(0, 2, 3, 1).backward(dyu.double())
+  helpers.report('upsample bwd', ops_bwd.upsample2x_bwd(G(dyu)), p.grad.float(), atol=1e-5)
+  # epilogue gate + column sums
+  dy2, y2 = rnd((300, 64), 26), rnd((300, 64), 27)
+  mask = torch.rand(300, generator=torch.Generator().manual_seed(28)) > 0.3
+  ref = dy2 * (y2 > 0) * mask[:, None]
+  helpers.report('epilogue bwd', ops_bwd.epilogue_bwd(G(dy2), G(y2), G(mask), relu=True), ref, atol=0)
+  a = rnd((5000, 96), 29)
+  helpers.report('colsum', ops_bwd.colsum(G(a)), a.double().sum(0).float(), atol=2e-4)
+
+
+# -- lift / BEV ------------------------------------------------------------------------------
+@pytest.mark.parametrize('K,V', [(0, 3), (2, 4)])
+def test_lift_pool_bwd(K, V):
+  """Reference: torch autograd through a differentiable restatement that takes the
+  projection geometry (taps, weights, visibility) from the numpy oracle."""
+  import test_gpu_kernels as tk
+  from oracle import lift as o_lift
+  fd, nb = 16, 4
+  f, cam, Rt, pts = tk._lift_scene(1, V, 10, 12, fd, nb, 1500, seed=60 + V)
+  kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0))
+  stride = ops.pooled_stride(fd)
+  dpooled = rnd((1, 1500, stride), 61)
+  dpooled[..., 2 * fd + 1:] = 0
+  # torch restatement (float64)
+  cams = oracle_ops.unpack_cameras(cam, True)
+  T = oracle_ops.unpack_transforms(Rt)
+  p2d, vis, depth, _ = o_lift.project_points_to_views(T, cams, pts.numpy())
+  if K > 0:
+    idx, _ = o_lift.view_selection(pts.numpy(), T, vis, K)
+    p2d, vis, depth = (o_lift.gather_batched_observations(a, idx) for a in (p2d, vis, depth))
+  else:
+    idx = np.broadcast_to(np.arange(V), vis.shape).copy()
+  fdbl = f.double().requires_grad_(True)
+  h, w = f.shape[2:4]
+  pt = torch.tensor(p2d[0]).double() - 0.5                     # [N,Kv,2]
+  if K > 0:
+    pt = torch.minimum(torch.maximum(pt, torch.zeros(2, dtype=torch.float64)),
+                       torch.tensor([h - 1.0, w - 1.0], dtype=torch.float64))
+  lo = torch.floor(pt)
+  w1 = pt - lo
+  w0 = 1 - w1
+  i0 = lo[..., 0].long().clamp(0, h - 1); i1 = (lo[..., 0].long() + 1).clamp(0, h - 1)
+  j0 = lo[..., 1].long().clamp(0, w - 1); j1 = (lo[..., 1].long() + 1).clamp(0, w - 1)
+  vi = torch.tensor(idx[0]).long()
+  img = fdbl[0]
+  val = ((w0[..., 0] * w0[..., 1])[..., None] * img[vi, i0, j0]
+         + (w0[..., 0] * w1[..., 1])[..., None] * img[vi, i0, j1]
+         + (w1[..., 0] * w0[..., 1])[..., None] * img[vi, i1, j0]
+         + (w1[..., 0] * w1[..., 1])[..., None] * img[vi, i1, j1])   # [N,Kv,C]
+  feats, scales = val[..., :fd], val[..., fd:]
+  dpt = torch.tensor(depth[0]).double().clamp(1.0, 16.0)
+  tt = torch.log(dpt / 1.0) / math.log(16.0)
+  c = (0.5 + tt * (nb - 1)) - 0.5
+  fl = torch.floor(c)
+  wb = c - fl
+  b0 = fl.long().clamp(0, nb - 1); b1 = (fl.long() + 1).clamp(0, nb - 1)
+  score = (1 - wb) * torch.gather(scales, -1, b0[..., None])[..., 0] + wb * torch.gather(
+      scales, -1, b1[..., None])[..., 0]
+  visb = torch.tensor(vis[0])
+  anyv = visb.any(-1)
+  sm = torch.where(visb, score, torch.full_like(score, -math.inf))
+  wgt = torch.softmax(torch.where(anyv[:, None], sm, torch.zeros_like(sm)), -1)
+  wgt = torch.where(visb, wgt, torch.zeros_like(wgt))
+  mean = (wgt[..., None] * feats).sum(1)
+  var = (wgt[..., None] * (feats - mean[:, None]) ** 2).sum(1)
+  smax = torch.where(anyv, sm.max(-1).values, torch.zeros_like(anyv, dtype=torch.float64))
+  pooled = torch.cat([mean, var, smax[:, None]], -1) * anyv[:, None]
+  pooled.backward(dpooled[0, :, : 2 * fd + 1].double())
+  got = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
+  ref = fdbl.grad.float()
+  helpers.report('lift bwd', got, ref, atol=2e-4 * float(ref.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize('pooling', ['max', 'sum', 'mean'])
+def test_vertical_pool_bwd(pooling):
+  vol = rnd((2, 6, 5, 7, 32), 70)
+  valid = torch.rand((2, 6, 5, 7), generator=torch.Generator().manual_seed(71)) > 0.5
+  valid[0, 0] = False
+  dplane = rnd((2, 6, 5, 32), 72)
+  vd = vol.double().requires_grad_(True)
+  anyv = valid.any(-1)
+  if pooling == 'max':
+    out = torch.where(valid[..., None], vd, torch.full_like(vd, -math.inf)).amax(-2)
+    out = torch.where(anyv[..., None], out, torch.zeros_like(out))
+  else:
+    out = (vd * valid[..., None]).sum(-2)
+    if pooling == 'mean':
+      out = out / valid.sum(-1).clamp(min=1)[..., None]
+  out.backward(dplane.double())
+  got = ops_bwd.vertical_pool_bwd(G(vol), G(valid), G(dplane), pooling)
+  helpers.report('vpool bwd ' + pooling, got, vd.grad.float(), atol=1e-6)
+
+
+@pytest.mark.parametrize('nplanes', [1, 2])
+def test_plane_fuse_match_bwd(nplanes):
+  D, Dm, M = 64, 16, 140
+  planes = [rnd((M, D), 80 + i) for i in range(nplanes)]
+  valids = [torch.rand(M, generator=torch.Generator().manual_seed(90 + i)) > 0.3 for i in range(nplanes)]
+  if nplanes == 2:
+    valids[1] = None
+  planes[0] = planes[0] * valids[0][:, None]
+  Wm, bm = rnd((D, Dm), 85, 0.2), rnd((Dm,), 86, 0.05)
+  dmat = rnd((M, Dm), 87)
+  pd = [p.double().requires_grad_(True) for p in planes]
+  Wd, bd = Wm.double().requires_grad_(True), bm.double().requires_grad_(True)
+  vs = torch.stack([torch.ones(M, dtype=torch.bool) if v is None else v for v in valids], -1)
+  st = torch.stack(pd, -2)
+  anyv = vs.any(-1)
+  fused = torch.where(vs[..., None], st, torch.full_like(st, -math.inf)).amax(-2)
+  fused = torch.where(anyv[:, None], fused, torch.zeros_like(fused))
+  y = fused @ Wd + bd
+  z = y / y.norm(dim=-1, keepdim=True)
+  (z * anyv[:, None]).backward(dmat.double())
+  dplanes, dy = ops_bwd.plane_fuse_match_bwd([G(p) for p in planes],
+                                             [None if v is None else G(v) for v in valids], 'max',
+                                             G(Wm), G(bm), True, 1e-5, G(dmat))
+  for i in range(nplanes):
+    helpers.report(f'dplane{i}', dplanes[i], pd[i].grad.float(), atol=2e-5, rtol=1e-4)
+  fused_g, _, _ = ops.plane_fuse_match([G(p) for p in planes],
+                                       [None if v is None else G(v) for v in valids], 'max',
+                                       G(Wm), G(bm))
+  dW = ops_bwd.conv2d_wgrad(fused_g.reshape(1, 1, M, D), dy.reshape(1, 1, M, Dm), (1, 1, D, Dm))
+  helpers.report('dWm', dW.reshape(D, Dm), Wd.grad.float(), atol=1e-4, rtol=1e-4)
+  helpers.report('dbm', ops_bwd.colsum(dy), bd.grad.float(), atol=1e-4, rtol=1e-4)
+
+
+# -- pose head --------------------------------------------------------------------------------
+@pytest.mark.parametrize('mask_oob', [False, True])
+def test_pose_score_bwd(mask_oob):
+  B, Nq, X, Y, P = 2, 30, 24, 20, 300
+  rng = np.random.default_rng(100)
+  sim = torch.tensor(rng.random((B, Nq, X, Y), dtype=np.float32))
+  cell = 0.25
+  poses = torch.tensor(np.stack([rng.uniform(-3, 3, (B, P)), rng.uniform(-1, X * cell + 1, (B, P)),
+                                 rng.uniform(-1, Y * cell + 1, (B, P))], -1).astype(np.float32))
+  q_xy = torch.tensor(rng.uniform(-1.5, 1.5, (B, Nq, 2)).astype(np.float32))
+  valid_q = torch.tensor(rng.random((B, Nq)) > 0.2)
+  mv = torch.tensor(rng.random((B, X, Y)) > 0.1)
+  dscores = rnd((B, P), 101)
+  sd = sim.double().requires_grad_(True)
+  c, s = torch.cos(poses[..., 0].double()), torch.sin(poses[..., 0].double())
+  qx, qy = q_xy[..., 0].double(), q_xy[..., 1].double()
+  u = (c[:, :, None] * qx[:, None] - s[:, :, None] * qy[:, None] + poses[..., 1].double()[:, :, None]) / cell
+  v = (s[:, :, None] * qx[:, None] + c[:, :, None] * qy[:, None] + poses[..., 2].double()[:, :, None]) / cell
+  cu, cv = u - 0.5, v - 0.5
+  fu, fv = torch.floor(cu), torch.floor(cv)
+  wu1, wv1 = cu - fu, cv - fv
+  i0 = fu.long().clamp(0, X - 1); i1 = (fu.long() + 1).clamp(0, X - 1)
+  j0 = fv.long().clamp(0, Y - 1); j1 = (fv.long() + 1).clamp(0, Y - 1)
+  bi = torch.arange(B)[:, None, None]
+  ni = torch.arange(Nq)[None, None, :]
+  val = ((1 - wu1) * (1 - wv1) * sd[bi, ni, i0, j0] + (1 - wu1) * wv1 * sd[bi, ni, i0, j1]
+         + wu1 * (1 - wv1) * sd[bi, ni, i1, j0] + wu1 * wv1 * sd[bi, ni, i1, j1])
+  ok = valid_q[:, None, :].expand(B, P, Nq)
+  if mask_oob:
+    inb = (u >= 0) & (u < X) & (v >= 0) & (v < Y)
+    tv = mv[bi, i0, j0] & mv[bi, i0, j1] & mv[bi, i1, j0] & mv[bi, i1, j1]
+    ok = ok & inb & tv
+  (val * ok).sum(-1).backward(dscores.double())
+  got = ops_bwd.pose_score_bwd(G(dscores), G(poses), G(q_xy), G(valid_q), G(mv), tuple(sim.shape),
+                               cell, mask_oob=mask_oob)
+  helpers.report('pose_score bwd', got, sd.grad.float(), atol=2e-4, rtol=1e-4)
+
+
+def test_similarity_bwd():
+  from snap_amd import autograd as ag
+  B, Nq, X, Y, Dm = 2, 50, 12, 16, 32
+  fq = F.normalize(rnd((B, Nq, Dm), 110), dim=-1)
+  fm = F.normalize(rnd((B, X, Y, Dm), 111), dim=-1)
+  nv = torch.tensor([48.0, 50.0])
+  temp = torch.tensor(2.0)
+  dsim = rnd((B, Nq, X, Y), 112)
+  fqd, fmd, td = (t.double().requires_grad_(True) for t in (fq, fm, temp))
+  sim = torch.relu(torch.einsum('bnd,bijd->bnij', fqd, fmd)) * torch.exp(td) / nv.double()[:, None, None, None]
+  sim.backward(dsim.double())
+  simg, _, _, _ = ops.sim_softmax(G(fq), G(fm), float(torch.exp(temp)), True, G(nv))
+  dfq, dfm, dtemp = ag.similarity_bwd(G(dsim).clone(), simg, G(fq), G(fm), float(torch.exp(temp)),
+                                      True, G(nv))
+  helpers.report('dfq', dfq, fqd.grad.float(), atol=2e-5, rtol=1e-4)
+  helpers.report('dfm', dfm, fmd.grad.float(), atol=2e-5, rtol=1e-4)
+  assert abs(float(dtemp) - float(td.grad)) < 1e-3 * max(1.0, abs(float(td.grad)))
