@@ -47,6 +47,14 @@ class ForwardContext:
     return out
 
 
+def needs_grad(*tensors):
+  """True when autograd must record this op: grad mode is on and some input needs it.
+  Inference (plain parameter tensors / torch.no_grad()) takes the direct `ops` path."""
+  if not torch.is_grad_enabled():
+    return False
+  return any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
 def clear_caches():
   _WSTD_CACHE.clear()
 

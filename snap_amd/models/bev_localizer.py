@@ -8,6 +8,7 @@ import math
 import numpy as np
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
@@ -123,19 +124,18 @@ class BEVLocalizer(base.Module):
   def similarity(self, params, f_p_q, plane_map, valid_points, want_prob=False):
     """bev_localizer.py:157-173: sim_points (+ softmax statistics) on the GPU."""
     cfg = self.config
-    scale = 1.0
-    if cfg.add_temperature:
-      # exp(temperature): a host scalar (one tiny D2H sync per apply).
-      scale = float(torch.exp(params['temperature'].to(torch.float32)))
+    temperature = params['temperature'] if cfg.add_temperature else None
     num_valid = valid_points.sum(-1).clamp(min=1).to(torch.float32)
-    sim, stats, prob, _ = ops.sim_softmax(
-        f_p_q.contiguous(), plane_map.features.contiguous(), scale,
-        bool(cfg.clip_negative_scores), num_valid, want_prob=want_prob,
-    )
-    matching = dict(
-        fq=f_p_q.contiguous(), fm=plane_map.features.contiguous(),
-        chunk_stats=stats, scale=scale, clip=bool(cfg.clip_negative_scores),
-    )
+    fq, fm = f_p_q.contiguous(), plane_map.features.contiguous()
+    clip = bool(cfg.clip_negative_scores)
+    if base.needs_grad(fq, fm, temperature):
+      sim, stats, prob, scale = ag.sim_softmax(fq, fm, temperature, clip, num_valid, want_prob)
+    else:
+      # exp(temperature): a host scalar (one tiny D2H sync per apply).
+      scale = 1.0 if temperature is None else float(torch.exp(temperature.to(torch.float32)))
+      sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob)
+    # the sampler sees stop_gradient(prob_points) (bev_localizer.py:178): detached inputs.
+    matching = dict(fq=fq.detach(), fm=fm.detach(), chunk_stats=stats, scale=scale, clip=clip)
     return sim, prob, matching
 
   def __call__(self, params, data, train=False, debug=False, rng=None,

@@ -4,6 +4,7 @@ Mirrors ``snap/models/bev_mapper.py:40-296`` (``VerticalPooling``, ``BEVMapper``
 """
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
@@ -25,7 +26,8 @@ class VerticalPooling(base.Module):
     return {}
 
   def __call__(self, params, feature_volume):
-    plane, valid = ops.vertical_pool(
+    vp = ag.vertical_pool if base.needs_grad(feature_volume.features) else ops.vertical_pool
+    plane, valid = vp(
         feature_volume.features.contiguous(), feature_volume.valid.contiguous(),
         self.config.pooling,
     )
@@ -169,8 +171,12 @@ class BEVMapper(base.Module):
         self.modality_fusion.config.pooling if self.modality_fusion is not None else 'max'
     )
     single = len(feature_planes) == 1
-    fused, fvalid, matching = ops.plane_fuse_match(
-        [p.features for p in feature_planes],
+    feats = [p.features for p in feature_planes]
+    pfm = ops.plane_fuse_match
+    if base.needs_grad(*feats, *( [mp['kernel'], mp['bias']] if has_match else [])):
+      pfm = ag.plane_fuse_match
+    fused, fvalid, matching = pfm(
+        feats,
         [p.valid for p in feature_planes],
         pooling,
         mp['kernel'] if has_match else None,

@@ -2,6 +2,7 @@
 import numpy as np
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
@@ -48,14 +49,19 @@ class FPNDecoder(base.Module):
     f_prev = None
     for level, f_skip in enumerate(input_features):
       norm = params[f'{level}_skip_norm']
-      mu, sc = ops.group_norm_stats(f_skip, norm['scale'].reshape(-1), relu_first=True)
+      kernel = params[f'{level}_skip_conv']['kernel']
       if f_prev is not None:
         assert f_skip.shape[-3] == f_prev.shape[-3] * 2, "Image heights don't match."
         assert f_skip.shape[-2] == f_prev.shape[-2] * 2, "Image widths don't match."
-      f = ops.conv2d(
-          f_skip, params[f'{level}_skip_conv']['kernel'], prologue=ops.PRO_RELU_GN,
-          gn=(mu, sc, norm['bias'].reshape(-1)), up_prev=f_prev,
-      )
+      if base.needs_grad(f_skip, kernel, norm['scale'], f_prev):
+        f = ag.conv2d(f_skip, kernel, prologue=ops.PRO_RELU_GN,
+                      gn_params=(norm['scale'], norm['bias']), up_prev=f_prev)
+      else:
+        mu, sc = ops.group_norm_stats(f_skip, norm['scale'].reshape(-1), relu_first=True)
+        f = ops.conv2d(
+            f_skip, kernel, prologue=ops.PRO_RELU_GN,
+            gn=(mu, sc, norm['bias'].reshape(-1)), up_prev=f_prev,
+        )
       f_prev = f
       out_features.append(f)
     return out_features

@@ -6,6 +6,7 @@ paths of the reference and have no counterpart here.
 """
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.models import base
 
@@ -41,7 +42,8 @@ class MLP(base.Module):
     for i in range(n):
       p = params[f'Dense_{i}']
       pro = ops.PRO_RELU if (i == 0 and self.config.apply_input_activation) else ops.PRO_NONE
-      x = ops.dense(
+      fn = ag.dense if base.needs_grad(x, p['kernel'], p['bias']) else ops.dense
+      x = fn(
           x, p['kernel'], p['bias'], cin=p['kernel'].shape[0], prologue=pro,
           relu=(i + 1 < n), row_mask=row_mask if i + 1 == n else None,
       )

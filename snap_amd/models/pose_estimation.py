@@ -6,6 +6,7 @@ scene axis); the arithmetic runs in pose.hip.
 import numpy as np
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.utils import geometry
 
@@ -19,8 +20,9 @@ def pose_scoring_many_batched(
   j_t_i: Transform2D [B,P]; scores_points_all [B,N,H,W]; i_xy_points [B,N,2];
   valid_points [B,N]; valid_j [B,H,W].  Returns scores [B,P].
   """
-  return ops.pose_score(
-      scores_points_all, j_t_i.packed(), i_xy_points.contiguous(),
+  score = ag.pose_score if (torch.is_grad_enabled() and scores_points_all.requires_grad) else ops.pose_score
+  return score(
+      scores_points_all, j_t_i.packed().detach(), i_xy_points.contiguous(),
       valid_points.contiguous(), valid_j.contiguous(), grid.cell_size,
       mask_oob=mask_out_of_bounds,
   )

@@ -9,6 +9,7 @@ result is cached per forward (map and query passes share parameters).
 """
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
@@ -28,7 +29,18 @@ def get_block_desc(depth):
 
 
 def _std(ctx, kernel):
+  if base.needs_grad(kernel):
+    return ag.weight_standardize(kernel)     # training: differentiable, never cached
   return ctx.standardized(kernel, ops.weight_standardize)
+
+
+def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, **kw):
+  """GroupNorm -> ReLU -> StdConv.  Training: one autograd node (statistics inside);
+  inference: `gn_stats` may be shared between the convs reading the same input."""
+  w = _std(ctx, kernel)
+  if base.needs_grad(x, w, gn_p['scale'], gn_p['bias']):
+    return ag.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn_params=(gn_p['scale'], gn_p['bias']), **kw)
+  return ops.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn=gn_stats or _gn(x, gn_p), **kw)
 
 
 def _gn(x, p, relu_first=False):
@@ -40,23 +52,15 @@ def residual_unit(ctx, p, x, stride, nmid):
   """Bottleneck unit (resnet.py:103-132)."""
   nmid = nmid or x.shape[-1] // 4
   nout = nmid * 4
-  gn1 = _gn(x, p['gn1'])
+  train = base.needs_grad(x, p['conv1']['kernel'])
+  gn1 = None if train else _gn(x, p['gn1'])     # shared by conv_proj and conv1
   if x.shape[-1] != nout or stride != 1:
-    residual = ops.conv2d(
-        x, _std(ctx, p['conv_proj']['kernel']), stride=stride,
-        prologue=ops.PRO_GN_RELU, gn=gn1,
-    )
+    residual = _conv_gn(ctx, x, p['conv_proj']['kernel'], p['gn1'], gn1, stride=stride)
   else:
     residual = x
-  y = ops.conv2d(x, _std(ctx, p['conv1']['kernel']), prologue=ops.PRO_GN_RELU, gn=gn1)
-  y = ops.conv2d(
-      y, _std(ctx, p['conv2']['kernel']), stride=stride,
-      padding=((1, 1), (1, 1)), prologue=ops.PRO_GN_RELU, gn=_gn(y, p['gn2']),
-  )
-  y = ops.conv2d(
-      y, _std(ctx, p['conv3']['kernel']), prologue=ops.PRO_GN_RELU,
-      gn=_gn(y, p['gn3']), residual=residual,
-  )
+  y = _conv_gn(ctx, x, p['conv1']['kernel'], p['gn1'], gn1)
+  y = _conv_gn(ctx, y, p['conv2']['kernel'], p['gn2'], stride=stride, padding=((1, 1), (1, 1)))
+  y = _conv_gn(ctx, y, p['conv3']['kernel'], p['gn3'], residual=residual)
   return y
 
 
@@ -113,17 +117,16 @@ class ResNetV2(base.Module):
     out = {}
     # `image * 2 - 1` (resnet.py:199) is fused into the root conv's operand staging.
     if self.config.skip_root_block:
-      x = ops.conv2d(
-          image, _std(ctx, params['conv_root']['kernel']),
-          padding=((1, 1), (1, 1)), prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0),
-      )
+      w = _std(ctx, params['conv_root']['kernel'])
+      conv = ag.conv2d if base.needs_grad(w) else ops.conv2d
+      x = conv(image, w, padding=((1, 1), (1, 1)), prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0))
     else:
-      x = ops.conv2d(
-          image, _std(ctx, params['root_block']['conv_root']['kernel']),
-          stride=2, padding=((3, 3), (3, 3)), prologue=ops.PRO_AFFINE,
-          in_affine=(2.0, -1.0),
-      )
-      x = out['stem'] = ops.max_pool_3x3s2(x)
+      w = _std(ctx, params['root_block']['conv_root']['kernel'])
+      conv = ag.conv2d if base.needs_grad(w) else ops.conv2d
+      x = conv(image, w, stride=2, padding=((3, 3), (3, 3)), prologue=ops.PRO_AFFINE,
+               in_affine=(2.0, -1.0))
+      pool = ag.max_pool_3x3s2 if base.needs_grad(x) else ops.max_pool_3x3s2
+      x = out['stem'] = pool(x)
     for i, size in enumerate(self.blocks):
       stage = {}
       nmid = self.width * 2**i

@@ -10,6 +10,7 @@ import copy
 
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
@@ -80,7 +81,8 @@ class StreetViewEncoder(base.Module):
     xyz_flat = xyz.reshape(len(xyz), -1, 3).contiguous()
     k_vs = cfg.top_k_view_selection
     K = k_vs if (k_vs and V > k_vs) else 0
-    pooled, valid = ops.lift_pool(
+    lift = ag.lift_pool if base.needs_grad(f_images) else ops.lift_pool
+    pooled, valid = lift(
         f_images, cameras.packed().to(torch.float32),
         scene_t_view.packed().to(torch.float32), xyz_flat, K=K,
         fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,

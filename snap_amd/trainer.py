@@ -1,0 +1,111 @@
+"""Data-parallel training step of the localisation model.
+
+Semantics of ``snap/trainer.py:165-295`` (``train_step``): per-rank loss =
+masked mean of ``losses['total']``; gradients averaged over ranks (``pmean``);
+optional global-norm clipping; Adam; the update is SKIPPED when any gradient is
+non-finite on any rank; metrics reduced as (sum, count) pairs.  The Scenic loop
+around it (data, checkpoints, logging) is out of scope; this module is the step a
+driver calls.  One process per GPU; the exchange goes through ``snap_amd.dist``
+(RCCL over xGMI under backend "nccl").
+"""
+import dataclasses
+import math
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+
+from snap_amd import dist as sdist
+
+
+def flatten_params(tree, prefix=''):
+  return sdist.flatten_tree(tree, prefix)
+
+
+def make_lr_fn(base_lr: float, num_steps: int, start_decay_step: Optional[int] = None) -> Callable:
+  """'constant * cosine_decay' with the decay starting at `start_decay_step`
+  (snap/configs/train_localization.py:87-92: half-way, one cosine cycle)."""
+  start = num_steps // 2 if start_decay_step is None else start_decay_step
+  cycle = max(num_steps - start, 1)
+
+  def lr_fn(step: int) -> float:
+    progress = max(0, step - start) / cycle
+    return base_lr * 0.5 * (1.0 + math.cos(math.pi * (progress % 1.0)))
+
+  return lr_fn
+
+
+@dataclasses.dataclass
+class TrainState:
+  params: Dict[str, Any]
+  m: List[torch.Tensor]
+  v: List[torch.Tensor]
+  global_step: int = 0
+  rng: int = 0
+
+  @classmethod
+  def create(cls, params, rng=0):
+    leaves = [t for _, t in flatten_params(params)]
+    return cls(params=params, m=[torch.zeros_like(t) for t in leaves],
+               v=[torch.zeros_like(t) for t in leaves], global_step=0, rng=rng)
+
+
+def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+  """optax.adam (bias-corrected, eps outside the sqrt); in place on `leaves`."""
+  torch._foreach_mul_(m, b1)
+  torch._foreach_add_(m, grads, alpha=1 - b1)
+  torch._foreach_mul_(v, b2)
+  torch._foreach_addcmul_(v, grads, grads, value=1 - b2)
+  c1 = 1 - b1 ** step
+  c2 = 1 - b2 ** step
+  denom = torch._foreach_sqrt(v)
+  torch._foreach_div_(denom, math.sqrt(c2))
+  torch._foreach_add_(denom, eps)
+  torch._foreach_addcdiv_(leaves, m, denom, value=-lr / c1)
+
+
+def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_norm=None,
+               group=None, debug=False):
+  """One optimisation step.  Returns (state, metrics, training_logs)."""
+  named = flatten_params(state.params)
+  leaves = [t for _, t in named]
+  for t in leaves:
+    t.requires_grad_(True)
+    t.grad = None
+  state.rng += 1
+  rank = torch.distributed.get_rank(group) if sdist._world(group) > 1 else 0
+  sampling_rng = state.rng * 7919 + rank            # bind the stream to the device
+  with torch.enable_grad():
+    pred = model.flax_model.apply(
+        {'params': state.params}, batch, train=True, rngs={'sampling': sampling_rng},
+        mutable=False, debug=debug,
+    )
+    losses, metrics = model.loss_metrics_function(pred, batch, state.params)
+    mask = batch['batch_mask'].to(losses['total'].dtype)
+    loss = (losses['total'] * mask).sum() / mask.sum().clamp(min=1)
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+  grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
+  for t in leaves:
+    t.requires_grad_(False)
+  sdist.allreduce_mean_(grads, group)                 # jax.lax.pmean(grad, 'batch')
+  logs = {}
+  if max_grad_norm is not None:
+    gn = torch.sqrt(sum((g * g).sum() for g in grads))
+    factor = torch.clamp(max_grad_norm / (gn + 1e-6), max=1.0)
+    grads = [g * factor for g in grads]
+  is_fin = sdist.all_finite(grads, group)
+  logs['l2_grads'] = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+  lr = lr_fn(state.global_step)
+  logs['learning_rate'] = lr
+  logs['is_finite'] = is_fin
+  if is_fin:                                           # otherwise: skip the update
+    with torch.no_grad():
+      _adam_update_(leaves, grads, state.m, state.v, state.global_step + 1, lr)
+  with torch.no_grad():
+    logs['l2_params'] = float(torch.sqrt(sum((t.double() ** 2).sum() for t in leaves)))
+    per_example = {k: v.detach().to(torch.float32) for k, v in metrics.items()}
+    for k, v in losses.items():
+      per_example[f'loss/{k}'] = v.detach()
+    reduced = sdist.reduce_batch_metrics(per_example, batch['batch_mask'], group)
+  state.global_step += 1
+  logs['loss'] = float(loss.detach())
+  return state, reduced, logs
