@@ -23,7 +23,8 @@ _GN_MODES = (ops.PRO_GN_RELU, ops.PRO_RELU_GN)
 def conv_dgrad(dy, w, x_shape, stride, padding):
   """d(prologue output) of a conv: transposed convolution through the forward engine.
 
-  dy [N,Ho,Wo,Cout]; w [KH,KW,Cin,Cout]; returns dz [N,H,W,Cin].
+  dy [N,Ho,Wo,Cout]; w [KH,KW,Cin,Cout]; returns dz [N,H,W,roundup(Cin,4)] (channels
+  past Cin are zero).
   Stride > 1: dy is zero-dilated first (the few strided layers of the ResNet).
   """
   N, H, W, Cin = x_shape
@@ -36,7 +37,10 @@ def conv_dgrad(dy, w, x_shape, stride, padding):
     dyd[:, ::stride, ::stride] = dy
     dy = dyd
   Ho, Wo = dy.shape[1:3]
-  w_rot = w.flip(0, 1).permute(0, 1, 3, 2).contiguous()       # [KH,KW,Cout,Cin]
+  w_rot = w.flip(0, 1).permute(0, 1, 3, 2)                    # [KH,KW,Cout,Cin]
+  if Cin % 4:                                                  # engine writes 4-channel groups:
+    w_rot = F.pad(w_rot, (0, 4 - Cin % 4))                     # extra channels come out as exact zeros
+  w_rot = w_rot.contiguous()
   pt2, pl2 = KH - 1 - pt, KW - 1 - pl
   pb2 = H - Ho - pt2 + KH - 1
   pr2 = W - Wo - pl2 + KW - 1
@@ -110,6 +114,9 @@ class _FusedConv(torch.autograd.Function):
       N, H, W, Cs = x.shape
       Cin = w.shape[2]
       dz = conv_dgrad(dy, w, (N, H, W, Cin), stride, padding)
+      if dz.shape[-1] > Cs:
+        dz = dz[..., :Cs].contiguous()
+      Cin = dz.shape[-1]                                       # zero-padded channel count
       if prologue in _GN_MODES:
         dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
             x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), prologue

@@ -328,3 +328,25 @@ def test_similarity_bwd():
   helpers.report('dfq', dfq, fqd.grad.float(), atol=2e-5, rtol=1e-4)
   helpers.report('dfm', dfm, fmd.grad.float(), atol=2e-5, rtol=1e-4)
   assert abs(float(dtemp) - float(td.grad)) < 1e-3 * max(1.0, abs(float(td.grad)))
+
+
+@pytest.mark.parametrize('cin,cs,pro', [(65, 68, ops.PRO_NONE), (33, 36, ops.PRO_RELU), (65, 65, ops.PRO_NONE)])
+def test_dense_autograd_ragged_channels(cin, cs, pro):
+  """Dense over the first `cin` of `cs` stored channels (the fusion-MLP input is
+  mean|var|score = 2D+1 wide): dx must be zero past cin, dw/dbias match torch."""
+  from snap_amd import autograd as ag
+  M, Cout = 300, 64
+  x = rnd((M, cs), 120)
+  w = rnd((cin, Cout), 121, 1 / math.sqrt(cin))
+  b = rnd((Cout,), 122)
+  dy = rnd((M, Cout), 123)
+  xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+  z = xd[:, :cin]
+  z = torch.relu(z) if pro == ops.PRO_RELU else z
+  torch.relu(z @ wd + bd).backward(dy.double())
+  xg, wg, bg = (G(t).requires_grad_(True) for t in (x, w, b))
+  y = ag.dense(xg, wg, bg, cin=cin, prologue=pro, relu=True)
+  y.backward(G(dy))
+  helpers.report('dx', xg.grad, xd.grad.float(), atol=3e-5, rtol=1e-5)
+  helpers.report('dw', wg.grad, wd.grad.float(), atol=2e-4, rtol=1e-5)
+  helpers.report('db', bg.grad, bd.grad.float(), atol=2e-4, rtol=1e-5)

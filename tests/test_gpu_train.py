@@ -80,6 +80,8 @@ def test_end_to_end_gradients_match_finite_differences():
       flat[idx] = old
     fd = (lp - lm) / (2 * eps)
     rel = abs(fd - ga) / max(abs(fd), abs(ga), 1e-6)
+    print(f'[fd] {name:90s} analytic={ga:+.5e} fd={fd:+.5e} rel={rel:.3e}')
+    assert abs(ga) > 1e-5, (name, ga)              # the probe must be a live parameter
     if rel > 0.08:
       bad.append((name, ga, fd, rel))
   assert not bad, bad
