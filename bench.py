@@ -41,6 +41,9 @@ WORKLOADS = {
     'c2': dict(batch=8, views=4, image=512, grid=(25.6, 25.6, 12), tiny=False,
                desc='C2: 8 scenes/GPU, 4 StreetView views @512px + aerial, 128x128x60 '
                     'voxel BEV @0.2m, ResNet-50 encoders, 10001 pose hypotheses'),
+    'c3': dict(batch=4, views=4, image=512, grid=(25.6, 25.6, 12), tiny=False,
+               desc='C3: train_localization default model, batch_size 32 over 8 GPUs = 4 scenes/GPU, '
+                    '4 StreetView views @512px + aerial, 128x128x60 voxel BEV, ResNet-50 encoders'),
     'tiny': dict(batch=2, views=3, image=64, grid=(6.4, 6.4, 12), tiny=True,
                  desc='tiny plumbing workload (tests only)'),
 }
@@ -208,6 +211,9 @@ def main(argv=None):
   ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
   ap.add_argument('--device', default='cuda')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                  help='infer: BEVLocalizer forward (the headline metric); train: one '
+                       'snap_amd.trainer.train_step (fwd + bwd + grad all-reduce + Adam)')
   args = ap.parse_args(argv)
 
   rank = int(os.environ.get('RANK', 0))
@@ -227,8 +233,22 @@ def main(argv=None):
   loc, cfg, meta, variables, batch = build(args.workload, device, rank)
   scenes_per_rank = WORKLOADS[args.workload]['batch']
 
-  def step(i):
-    return loc.apply(variables, batch, train=False, rngs={'sampling': 1000 * rank + i})
+  if args.mode == 'train':
+    from snap_amd import models, trainer
+    model = models.get_model('bev_localizer')(cfg, meta)
+    tcfg = train_localization.get_config()
+    lr_fn = trainer.make_lr_fn(tcfg.lr_configs['base_learning_rate'], tcfg.num_training_steps)
+    state = trainer.TrainState.create(variables['params'], rng=1000 * rank)
+    last_logs = {}
+
+    def step(i):
+      nonlocal state
+      state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn)
+      last_logs.update(logs)
+      return logs
+  else:
+    def step(i):
+      return loc.apply(variables, batch, train=False, rngs={'sampling': 1000 * rank + i})
 
   def barrier():
     if world > 1:
@@ -268,7 +288,7 @@ def main(argv=None):
   out = None
   if rank == 0:
     out = {
-        'metric': 'localization_scenes_per_sec',
+        'metric': 'localization_scenes_per_sec' if args.mode == 'infer' else 'train_scenes_per_sec',
         'value': round(value, 3),
         'unit': 'scenes/s',
         'n_gpus': world,
@@ -288,8 +308,10 @@ def main(argv=None):
             'workload': WORKLOADS[args.workload]['desc'],
             'scenes_per_gpu': scenes_per_rank,
             'global_batch': scenes_per_rank * world,
-            'parallelism': f'scene-sharded x{world}, no data-path collective',
-            'mode': 'inference forward (BEVLocalizer.apply, train=False)',
+            'parallelism': (f'scene-sharded x{world}, no data-path collective' if args.mode == 'infer'
+                            else f'dp{world}: scene-sharded, RCCL gradient all-reduce'),
+            'mode': ('inference forward (BEVLocalizer.apply, train=False)' if args.mode == 'infer' else
+                     'train_step: forward + backward + gradient all-reduce + Adam (fp32)'),
         },
     }
     if prof is not None:
@@ -339,7 +361,10 @@ def main(argv=None):
       if dump:
         with open(dump, 'w') as f:
           json.dump({n: prof.launches(n) for n in summ}, f)
-    if world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']:
+    if args.mode == 'train':
+      out['train_logs'] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in last_logs.items()}
+    if (world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']
+        and args.mode == 'infer'):
       try:
         out['cpu_baseline'] = cpu_baseline(cfg, meta, args.workload)
       except Exception as e:  # the baseline must never take the bench line down

@@ -36,6 +36,12 @@ for s in $STAGES; do
     bench32)
       SNAP_CONV_BK=32 SNAP_BENCH_DUMP=gpurun_out/launches32.json timeout 1200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench32.log 2>&1
       echo "== bench BK=32 =="; tail -5 gpurun_out/bench32.log | cut -c1-1500 ;;
+    train)
+      timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_backward.py -m gpu -q --timeout=600 2>&1 | tail -40 > gpurun_out/tests_train.log
+      echo "== train tests =="; tail -5 gpurun_out/tests_train.log ;;
+    benchtrain)
+      SNAP_BENCH_DUMP=gpurun_out/launches_train.json timeout 1200 python bench.py --mode train --workload c3 --steps 8 --warmup 2 > gpurun_out/bench_train.log 2>&1
+      echo "== bench train =="; tail -5 gpurun_out/bench_train.log | cut -c1-3000 ;;
     prof)
       rm -rf gpurun_out/prof
       (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o snap -- \
