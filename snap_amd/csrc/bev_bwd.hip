@@ -108,7 +108,6 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
   if (gv >= total) return;
   const int b = (int)(gv / d.N);
   const int fd = d.feature_dim;
-  const int nq = fd >> 2;
   const bool all_views = d.K == 0;
   const int nsel = all_views ? d.V : d.K;
   const float* p = a.pts + gv * 3;
@@ -171,14 +170,11 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
     const float* r01 = img + ((int64_t)t.i0 * d.w + t.j1) * d.C;
     const float* r10 = img + ((int64_t)t.i1 * d.w + t.j0) * d.C;
     const float* r11 = img + ((int64_t)t.i1 * d.w + t.j1) * d.C;
-    if (hl < nq) {
-      const f32x4 a00 = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
-      const f32x4 a01 = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
-      const f32x4 a10 = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
-      const f32x4 a11 = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        feat[r][e] = ((t.w00 * a00[e] + t.w01 * a01[e]) + t.w10 * a10[e]) + t.w11 * a11[e];
+    for (int e = 0; e < 4; ++e) {
+      const int c = hl + 32 * e;  // lane owns channels hl, hl+32, ..: every access below is
+      if (c < fd)                 // one contiguous 128-byte line per half-wave
+        feat[r][e] = ((t.w00 * r00[c] + t.w01 * r01[c]) + t.w10 * r10[c]) + t.w11 * r11[c];
     }
     const float dc = fminf(fmaxf(depth, d.depth_min), d.depth_max);
     const float tt = logf(dc / d.depth_min) / log_range;
@@ -216,9 +212,10 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
   // ---- upstream gradients ------------------------------------------------------
   const float* g = a.dpooled + gv * d.out_stride;
   f32x4 dmean = {0.f, 0.f, 0.f, 0.f}, dvar = {0.f, 0.f, 0.f, 0.f};
-  if (hl < nq) {
-    dmean = *reinterpret_cast<const f32x4*>(g + 4 * hl);
-    dvar = *reinterpret_cast<const f32x4*>(g + fd + 4 * hl);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = hl + 32 * e;
+    if (c < fd) { dmean[e] = g[c]; dvar[e] = g[fd + c]; }
   }
   const float dsmax = g[2 * fd];
   int nmax = 0;
@@ -250,15 +247,15 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
     float* r01 = img + ((int64_t)t.i0 * d.w + t.j1) * d.C;
     float* r10 = img + ((int64_t)t.i1 * d.w + t.j0) * d.C;
     float* r11 = img + ((int64_t)t.i1 * d.w + t.j1) * d.C;
-    if (hl < nq) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float df = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
-        unsafeAtomicAdd(r00 + 4 * hl + e, t.w00 * df);
-        unsafeAtomicAdd(r01 + 4 * hl + e, t.w01 * df);
-        unsafeAtomicAdd(r10 + 4 * hl + e, t.w10 * df);
-        unsafeAtomicAdd(r11 + 4 * hl + e, t.w11 * df);
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int c = hl + 32 * e;
+      if (c >= fd) continue;
+      const float df = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
+      unsafeAtomicAdd(r00 + c, t.w00 * df);
+      unsafeAtomicAdd(r01 + c, t.w01 * df);
+      unsafeAtomicAdd(r10 + c, t.w10 * df);
+      unsafeAtomicAdd(r11 + c, t.w11 * df);
     }
     // score taps: lanes 0..7 = (tap, bin)
     if (hl < 8) {

@@ -434,7 +434,13 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_kernel(const ScoreArgs 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void global_void_t;
 
-template <int PPT, bool MASK>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int PS_DB_MAX_POINTS = 1024;  // valid points of one chunk staged in LDS
+
+// YC: compile-time row length (0 = run time).  The 2x2 footprint is two ds_read2_b32 off
+// ONE address (offsets {0,1} and {YC,YC+1}); each lands as a (col j, col j+1) register
+// pair, so the coordinate and row-lerp arithmetic is packed f32 (v_pk_fma/v_pk_add).
+template <int PPT, bool MASK, int YC>
 __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreArgs a) {
   extern __shared__ float plane[];
   const int b = blockIdx.z;
@@ -442,19 +448,24 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
   const int NCH = gridDim.y;
   const int p_base = blockIdx.x * (PS_THREADS * PPT);
   const int tid = threadIdx.x;
-  const int XY = a.X * a.Y;
+  const int Y = YC ? YC : a.Y;
+  const int XY = a.X * Y;
   const int nf4 = XY >> 2;
-  float pc[PPT], ps[PPT], ptx[PPT], pty[PPT], acc[PPT];
+  f32x2 pcs[PPT], rot[PPT], pt[PPT];
+  float acc[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int p = p_base + k * PS_THREADS + tid;
     acc[k] = 0.f;
     const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + min(p, a.P - 1)];
-    pc[k] = t[0]; ps[k] = t[1]; ptx[k] = t[2]; pty[k] = t[3];
+    pcs[k] = f32x2{t[0], t[1]};
+    rot[k] = f32x2{-t[1], t[0]};
+    pt[k] = f32x2{t[2], t[3]};
   }
   const int n_begin = chunk * a.points_per_chunk;
   const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
-  const float Xf = (float)a.X, Yf = (float)a.Y;
+  const float Xf = (float)a.X, Yf = (float)Y;
+  const f32x2 lim1 = {Xf - 1.f, Yf - 1.f}, lim2 = {Xf - 2.f, Yf - 2.f}, zero2 = {0.f, 0.f};
   const uint8_t* vq = a.valid_q + (int64_t)b * a.Nq;
   const uint8_t* mvalid = a.map_valid ? a.map_valid + (int64_t)b * XY : nullptr;
 
@@ -466,47 +477,69 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
                                        16, 0, 0);
     }
   };
-  auto next_valid = [&](int n) {
-    while (n < n_end && !vq[n]) ++n;
-    return n;
-  };
-
-  int n = next_valid(n_begin);
+  // The chunk's valid points, compacted (ascending) into LDS up front: the plane loop
+  // then touches global memory ONLY through the LDS-DMA stream, so the vmcnt(0) at the
+  // top of an iteration waits for exactly the plane it is about to read and the next
+  // plane's DMA flies under the arithmetic (any other global load inside the loop would
+  // sit behind the in-order vmcnt and serialise load and compute).
+  __shared__ int pt_n[PS_DB_MAX_POINTS];
+  __shared__ float pt_x[PS_DB_MAX_POINTS], pt_y[PS_DB_MAX_POINTS];
+  __shared__ int pt_count;
+  if (tid < 64) {
+    int count = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+      const int n = n0 + tid;
+      const bool v = n < n_end && vq[n] != 0;
+      const unsigned long long m = __ballot(v);
+      if (v) {
+        const int slot = count + __popcll(m & ((1ull << tid) - 1ull));
+        pt_n[slot] = n;
+        pt_x[slot] = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+        pt_y[slot] = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+      }
+      count += __popcll(m);
+    }
+    if (tid == 0) pt_count = count;
+  }
+  __syncthreads();
+  const int count = pt_count;
   int buf = 0;
-  if (n < n_end) issue(n, 0);
-  while (n < n_end) {
-    __syncthreads();  // plane n landed (vmcnt(0) + barrier); other buffer is free
-    const int nn = next_valid(n + 1);
-    if (nn < n_end) issue(nn, buf ^ 1);
+  if (count > 0) issue(pt_n[0], 0);
+  for (int i = 0; i < count; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // plane i landed for every wave; the other buffer is free
+    if (i + 1 < count) issue(pt_n[i + 1], buf ^ 1);
     const float* pl = plane + buf * XY;
-    const float qx = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
-    const float qy = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+    const float qx = pt_x[i], qy = pt_y[i];
+    const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy};
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-      const float cu = fmaf(pc[k], qx, fmaf(-ps[k], qy, ptx[k]));
-      const float cv = fmaf(ps[k], qx, fmaf(pc[k], qy, pty[k]));
-      const float fu = floorf(cu), fv = floorf(cv);
-      const int i0 = (int)fminf(fmaxf(fu, 0.f), Xf - 1.f);
-      const int i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), Xf - 1.f);
-      const int j0 = (int)fminf(fmaxf(fv, 0.f), Yf - 1.f);
-      const int j1 = (int)fminf(fmaxf(fv + 1.f, 0.f), Yf - 1.f);
-      const float wu1 = cu - fu, wu0 = 1.f - wu1;
-      const float wv1 = cv - fv, wv0 = 1.f - wv1;
-      const float s00 = pl[i0 * a.Y + j0], s01 = pl[i0 * a.Y + j1];
-      const float s10 = pl[i1 * a.Y + j0], s11 = pl[i1 * a.Y + j1];
-      const float val =
-          (((wu0 * wv0) * s00 + (wu0 * wv1) * s01) + (wu1 * wv0) * s10) + (wu1 * wv1) * s11;
+      // 'nearest' extension == sampling at the clamped coordinate; the cell is capped
+      // at X-2 (weight 1 there) so the 2x2 footprint always lies inside the plane.
+      const f32x2 r = __builtin_elementwise_fma(pcs[k], qx2, __builtin_elementwise_fma(rot[k], qy2, pt[k]));
+      const f32x2 c = __builtin_elementwise_min(__builtin_elementwise_max(r, zero2), lim1);
+      const f32x2 f = __builtin_elementwise_min(f32x2{floorf(c.x), floorf(c.y)}, lim2);
+      const f32x2 w = c - f;
+      const int base = (int)fmaf(f.x, Yf, f.y);
+      const float* q = pl + base;
+      const f32x2 s0 = {q[0], q[1]};          // one ds_read2_b32 each: (row i, cols j,j+1)
+      const f32x2 s1 = {q[Y], q[Y + 1]};
+      const f32x2 t = __builtin_elementwise_fma(f32x2{w.x, w.x}, s1 - s0, s0);
+      const float val = fmaf(w.y, t.y - t.x, t.x);
       bool ok = true;
       if (MASK) {
-        const float u = cu + 0.5f, v = cv + 0.5f;
+        const float u = r.x + 0.5f, v = r.y + 0.5f;
         ok = (u >= 0.f) && (u < Xf) && (v >= 0.f) && (v < Yf);
-        ok = ok && mvalid[i0 * a.Y + j0] && mvalid[i0 * a.Y + j1] && mvalid[i1 * a.Y + j0] &&
-             mvalid[i1 * a.Y + j1];
+        const float gu = floorf(r.x), gv = floorf(r.y);
+        const int i0 = (int)fminf(fmaxf(gu, 0.f), Xf - 1.f);
+        const int i1 = (int)fminf(fmaxf(gu + 1.f, 0.f), Xf - 1.f);
+        const int j0 = (int)fminf(fmaxf(gv, 0.f), Yf - 1.f);
+        const int j1 = (int)fminf(fmaxf(gv + 1.f, 0.f), Yf - 1.f);
+        ok = ok && mvalid[i0 * Y + j0] && mvalid[i0 * Y + j1] && mvalid[i1 * Y + j0] &&
+             mvalid[i1 * Y + j1];
       }
       acc[k] += ok ? val : 0.f;
-      __builtin_amdgcn_sched_barrier(0);
     }
-    n = nn;
     buf ^= 1;
   }
 #pragma unroll
@@ -532,6 +565,8 @@ inline int score_chunks(int B, int Nq, int pose_chunks) {
   nch = nch < 1 ? 1 : nch;
   const int maxch = (Nq + 7) / 8;
   if (nch > maxch) nch = maxch;
+  const int minch = (Nq + PS_DB_MAX_POINTS - 1) / PS_DB_MAX_POINTS;  // LDS point list of the db kernel
+  if (nch < minch) nch = minch;
   if (nch < 1) nch = 1;
   return nch;
 }
@@ -712,12 +747,17 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
     const char* e = getenv("SNAP_POSE_SCORE_DB");
     return !(e && e[0] == '0');
   }();
-  const bool use_db = db_enabled && !bands && ((int64_t)X * Y <= 16384) && ((X * Y) % 4 == 0);
+  const bool use_db = db_enabled && !bands && ((int64_t)X * Y <= 16384) && ((X * Y) % 4 == 0) &&
+                      X >= 2 && Y >= 2;
   const void* fn = nullptr;
   size_t lds_bytes = lds;
   if (use_db) {
-    fn = mask_oob ? (const void*)&pose_score_db_kernel<PS_PPT, true>
-                  : (const void*)&pose_score_db_kernel<PS_PPT, false>;
+    if (Y == 128)
+      fn = mask_oob ? (const void*)&pose_score_db_kernel<PS_PPT, true, 128>
+                    : (const void*)&pose_score_db_kernel<PS_PPT, false, 128>;
+    else
+      fn = mask_oob ? (const void*)&pose_score_db_kernel<PS_PPT, true, 0>
+                    : (const void*)&pose_score_db_kernel<PS_PPT, false, 0>;
     lds_bytes = (size_t)2 * X * Y * sizeof(float);
   } else if (mask_oob) fn = bands ? (const void*)&pose_score_kernel<PS_PPT, true, true>
                            : (const void*)&pose_score_kernel<PS_PPT, true, false>;
