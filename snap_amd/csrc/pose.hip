@@ -435,7 +435,12 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void global_void_t;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float uniform_f(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 constexpr int PS_DB_MAX_POINTS = 1024;  // valid points of one chunk staged in LDS
+constexpr int PS_DB_ROUNDS = 5;           // 16-byte DMA chunks per thread per plane (max)
+constexpr int PS_DB_PLANE_BYTES = PS_DB_ROUNDS * PS_THREADS * 16 - 12 * 1024;  // 68 KiB padded plane
 
 // YC: compile-time row length (0 = run time).  The 2x2 footprint is two ds_read2_b32 off
 // ONE address (offsets {0,1} and {YC,YC+1}); each lands as a (col j, col j+1) register
@@ -450,8 +455,16 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
   const int tid = threadIdx.x;
   const int Y = YC ? YC : a.Y;
   const int XY = a.X * Y;
-  const int nf4 = XY >> 2;
-  f32x2 pcs[PPT], rot[PPT], pt[PPT];
+  // LDS rows are padded by one 16-byte chunk (stride S = Y + 4 floats): bank(i, j) =
+  // (4 i + j) mod 32, so samples clamped to the first / last COLUMN (out-of-map poses:
+  // a large share of RANSAC hypotheses) spread over 8 banks instead of all hitting one.
+  // The DMA writes LDS contiguously but each lane may fetch any global chunk, so the pad
+  // costs one duplicate chunk per row and no extra instructions.
+  const int S = Y + 4;
+  const int CRP = (Y >> 2) + 1;            // chunks per padded row
+  const int nchunks = a.X * CRP;
+  const int PLANE = a.X * S;               // floats per LDS plane
+  f32x2 pcs[PPT], pt[PPT];
   float acc[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
@@ -459,22 +472,33 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
     acc[k] = 0.f;
     const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + min(p, a.P - 1)];
     pcs[k] = f32x2{t[0], t[1]};
-    rot[k] = f32x2{-t[1], t[0]};
     pt[k] = f32x2{t[2], t[3]};
   }
   const int n_begin = chunk * a.points_per_chunk;
   const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
   const float Xf = (float)a.X, Yf = (float)Y;
+  const float Sf = (float)S;
   const f32x2 lim1 = {Xf - 1.f, Yf - 1.f}, lim2 = {Xf - 2.f, Yf - 2.f}, zero2 = {0.f, 0.f};
   const uint8_t* vq = a.valid_q + (int64_t)b * a.Nq;
   const uint8_t* mvalid = a.map_valid ? a.map_valid + (int64_t)b * XY : nullptr;
 
+  // global float offset of the chunk this thread fetches in DMA round k (plane-invariant)
+  int goff[PS_DB_ROUNDS];
+#pragma unroll
+  for (int k = 0; k < PS_DB_ROUNDS; ++k) {
+    const int c = min(k * PS_THREADS + tid, nchunks - 1);
+    const int row = c / CRP;
+    goff[k] = row * Y + 4 * min(c - row * CRP, CRP - 2);
+  }
   auto issue = [&](int n, int buf) {
     const float* src = a.sim + ((int64_t)b * a.Nq + n) * XY;
-    float* dst = plane + buf * XY;
-    for (int i = tid; i < nf4; i += PS_THREADS) {
-      __builtin_amdgcn_global_load_lds((global_void_t*)(src + 4 * i), (lds_void_t*)(dst + 4 * i),
-                                       16, 0, 0);
+    float* dst = plane + buf * PLANE;
+#pragma unroll
+    for (int k = 0; k < PS_DB_ROUNDS; ++k) {
+      const int c = k * PS_THREADS + tid;
+      if (c < nchunks)
+        __builtin_amdgcn_global_load_lds((global_void_t*)(src + goff[k]),
+                                         (lds_void_t*)(dst + 4 * c), 16, 0, 0);
     }
   };
   // The chunk's valid points, compacted (ascending) into LDS up front: the plane loop
@@ -505,41 +529,87 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
   const int count = pt_count;
   int buf = 0;
   if (count > 0) issue(pt_n[0], 0);
+
+  // One sample = coords() (pure VALU, needs only the pose and the point) + gather()
+  // (two ds_read2_b32 + lerp).  The loop is software-pipelined across the barrier: the
+  // coordinates of the first G poses for plane i+1 are computed at the end of iteration
+  // i, so every wave fires LDS reads right after the barrier instead of all 16 waves
+  // doing address arithmetic while the LDS sits idle.
+  struct Coord { f32x2 w; int off; f32x2 r; };
+  auto coords = [&](int k, float qx, float qy) {
+    // 'nearest' extension == sampling at the clamped coordinate; the cell is capped at
+    // X-2 (weight 1 there) so the 2x2 footprint always lies inside the plane.
+    const f32x2 qx2 = {qx, qx}, qyn = {-qy, qy};
+    Coord o;
+    o.r = __builtin_elementwise_fma(pcs[k], qx2, __builtin_elementwise_fma(pcs[k].yx, qyn, pt[k]));
+    const f32x2 c = __builtin_elementwise_min(__builtin_elementwise_max(o.r, zero2), lim1);
+    const f32x2 f = __builtin_elementwise_min(f32x2{floorf(c.x), floorf(c.y)}, lim2);
+    o.w = c - f;
+    o.off = (int)fmaf(f.x, Sf, f.y);
+    return o;
+  };
+  struct Taps { f32x2 s0, s1; };
+  auto fetch = [&](const Coord& o, const float* pl) {
+    const float* q = pl + o.off;
+    Taps t;
+    t.s0 = f32x2{q[0], q[1]};  // one ds_read2_b32 each: (row i, cols j,j+1)
+    t.s1 = f32x2{q[S], q[S + 1]};
+    return t;
+  };
+  auto blend = [&](int k, const Coord& o, const Taps& tp) {
+    const f32x2 t = __builtin_elementwise_fma(f32x2{o.w.x, o.w.x}, tp.s1 - tp.s0, tp.s0);
+    const float val = fmaf(o.w.y, t.y - t.x, t.x);
+    bool ok = true;
+    if (MASK) {
+      const float u = o.r.x + 0.5f, v = o.r.y + 0.5f;
+      ok = (u >= 0.f) && (u < Xf) && (v >= 0.f) && (v < Yf);
+      const float gu = floorf(o.r.x), gv = floorf(o.r.y);
+      const int i0 = (int)fminf(fmaxf(gu, 0.f), Xf - 1.f);
+      const int i1 = (int)fminf(fmaxf(gu + 1.f, 0.f), Xf - 1.f);
+      const int j0 = (int)fminf(fmaxf(gv, 0.f), Yf - 1.f);
+      const int j1 = (int)fminf(fmaxf(gv + 1.f, 0.f), Yf - 1.f);
+      ok = ok && mvalid[i0 * Y + j0] && mvalid[i0 * Y + j1] && mvalid[i1 * Y + j0] &&
+           mvalid[i1 * Y + j1];
+    }
+    acc[k] += ok ? val : 0.f;
+  };
+  constexpr int G = PPT / 2;
+  Coord pre[G];
+  {
+    const float qx = count > 0 ? pt_x[0] : 0.f, qy = count > 0 ? pt_y[0] : 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) pre[k] = coords(k, qx, qy);
+  }
   for (int i = 0; i < count; ++i) {
+    const int inext = min(i + 1, count - 1);
+    const float qx = uniform_f(pt_x[i]), qy = uniform_f(pt_y[i]);  // wave-uniform: keep in SGPRs
+    const float nqx = uniform_f(pt_x[inext]), nqy = uniform_f(pt_y[inext]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // plane i landed for every wave; the other buffer is free
     if (i + 1 < count) issue(pt_n[i + 1], buf ^ 1);
-    const float* pl = plane + buf * XY;
-    const float qx = pt_x[i], qy = pt_y[i];
-    const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy};
+    const float* pl = plane + buf * PLANE;
+    // group 0 reads go out back to back (addresses were ready before the barrier); group
+    // 1's coordinates are computed under their latency.  Same again for group 1 with the
+    // next plane's group-0 coordinates as the cover.
+    Taps tp[G];
+    Coord c1[PPT - G];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      // 'nearest' extension == sampling at the clamped coordinate; the cell is capped
-      // at X-2 (weight 1 there) so the 2x2 footprint always lies inside the plane.
-      const f32x2 r = __builtin_elementwise_fma(pcs[k], qx2, __builtin_elementwise_fma(rot[k], qy2, pt[k]));
-      const f32x2 c = __builtin_elementwise_min(__builtin_elementwise_max(r, zero2), lim1);
-      const f32x2 f = __builtin_elementwise_min(f32x2{floorf(c.x), floorf(c.y)}, lim2);
-      const f32x2 w = c - f;
-      const int base = (int)fmaf(f.x, Yf, f.y);
-      const float* q = pl + base;
-      const f32x2 s0 = {q[0], q[1]};          // one ds_read2_b32 each: (row i, cols j,j+1)
-      const f32x2 s1 = {q[Y], q[Y + 1]};
-      const f32x2 t = __builtin_elementwise_fma(f32x2{w.x, w.x}, s1 - s0, s0);
-      const float val = fmaf(w.y, t.y - t.x, t.x);
-      bool ok = true;
-      if (MASK) {
-        const float u = r.x + 0.5f, v = r.y + 0.5f;
-        ok = (u >= 0.f) && (u < Xf) && (v >= 0.f) && (v < Yf);
-        const float gu = floorf(r.x), gv = floorf(r.y);
-        const int i0 = (int)fminf(fmaxf(gu, 0.f), Xf - 1.f);
-        const int i1 = (int)fminf(fmaxf(gu + 1.f, 0.f), Xf - 1.f);
-        const int j0 = (int)fminf(fmaxf(gv, 0.f), Yf - 1.f);
-        const int j1 = (int)fminf(fmaxf(gv + 1.f, 0.f), Yf - 1.f);
-        ok = ok && mvalid[i0 * Y + j0] && mvalid[i0 * Y + j1] && mvalid[i1 * Y + j0] &&
-             mvalid[i1 * Y + j1];
-      }
-      acc[k] += ok ? val : 0.f;
-    }
+    for (int k = 0; k < G; ++k) tp[k] = fetch(pre[k], pl);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = G; k < PPT; ++k) c1[k - G] = coords(k, qx, qy);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < G; ++k) blend(k, pre[k], tp[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = G; k < PPT; ++k) tp[k - G] = fetch(c1[k - G], pl);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < G; ++k) pre[k] = coords(k, nqx, nqy);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = G; k < PPT; ++k) blend(k, c1[k - G], tp[k - G]);
     buf ^= 1;
   }
 #pragma unroll
@@ -555,6 +625,7 @@ __global__ void pose_score_reduce_kernel(const float* __restrict__ partial, int 
   if (i >= total) return;
   const int64_t b = i / P, p = i - b * P;
   float t = 0.f;
+#pragma unroll 8
   for (int c = 0; c < NCH; ++c) t += partial[(b * NCH + c) * P + p];
   scores[i] = t;
 }
@@ -747,8 +818,8 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
     const char* e = getenv("SNAP_POSE_SCORE_DB");
     return !(e && e[0] == '0');
   }();
-  const bool use_db = db_enabled && !bands && ((int64_t)X * Y <= 16384) && ((X * Y) % 4 == 0) &&
-                      X >= 2 && Y >= 2;
+  const bool use_db = db_enabled && !bands && (Y % 4 == 0) && X >= 2 && Y >= 2 &&
+                      ((int64_t)X * (Y + 4) * 4 <= PS_DB_PLANE_BYTES);
   const void* fn = nullptr;
   size_t lds_bytes = lds;
   if (use_db) {
@@ -758,14 +829,14 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
     else
       fn = mask_oob ? (const void*)&pose_score_db_kernel<PS_PPT, true, 0>
                     : (const void*)&pose_score_db_kernel<PS_PPT, false, 0>;
-    lds_bytes = (size_t)2 * X * Y * sizeof(float);
+    lds_bytes = (size_t)2 * X * (Y + 4) * sizeof(float);
   } else if (mask_oob) fn = bands ? (const void*)&pose_score_kernel<PS_PPT, true, true>
                            : (const void*)&pose_score_kernel<PS_PPT, true, false>;
   else fn = bands ? (const void*)&pose_score_kernel<PS_PPT, false, true>
                   : (const void*)&pose_score_kernel<PS_PPT, false, false>;
   if (lds_bytes > 64 * 1024) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(use_db ? 128 * 1024 : PS_LDS_FLOATS * sizeof(float))) !=
+                            (int)(use_db ? 2 * PS_DB_PLANE_BYTES : PS_LDS_FLOATS * sizeof(float))) !=
         hipSuccess)
       return SNAP_ERR_LAUNCH;
   }
