@@ -314,6 +314,17 @@ def main(argv=None):
                      'train_step: forward + backward + gradient all-reduce + Adam (fp32)'),
         },
     }
+    if args.mode == 'infer':
+      # share of voxels seen by at least one camera: the fusion MLP multiplies only those
+      # rows (the others are masked to zero by the reference too), so the step time
+      # depends on it -- stated here so the number can be judged against the data.
+      try:
+        out['config']['observed_voxel_fraction'] = {
+            k: round(float(pred[k]['streetview']['feature_volume'].valid.float().mean()), 4)
+            for k in ('map', 'query')
+        }
+      except (KeyError, TypeError, AttributeError):
+        pass
     if prof is not None:
       summ = prof.summary()
       kern = {}

@@ -76,6 +76,32 @@ int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x, const float* 
                          const float* residual, const float* up_prev,
                          const uint8_t* row_mask, void* stream);
 
+/* Row-indexed variant for masked voxel lists (the fusion MLP of
+ * streetview_encoder.py:281 runs over every voxel and the result is then masked by
+ * visibility; unobserved voxels never reach any output, so only the observed rows are
+ * multiplied).  rows_in: GEMM row m reads output pixel rows_in[m] of x; rows_out: GEMM
+ * row m is stored to row rows_out[m] of y; row_count: DEVICE scalar with the number of
+ * rows (<= N*Ho*Wo, the launch bound) -- no host synchronisation.  Any may be NULL.
+ * Only SNAP_EPI_BIAS / SNAP_EPI_RELU epilogues.  */
+int snap_conv2d_nhwc_rows_f32(const SnapConvDesc* desc, const float* x, const float* w,
+                              float* y, const float* gn_mu, const float* gn_sc,
+                              const float* gn_beta, const float* bias,
+                              const float* residual, const float* up_prev,
+                              const uint8_t* row_mask, const int32_t* rows_in,
+                              const int32_t* rows_out, const int32_t* row_count,
+                              void* stream);
+
+/* Ascending list of the rows with mask != 0: index[0..count) (stable order,
+ * deterministic), count written to *count (device).  index must hold M entries. */
+size_t snap_compact_rows_workspace_bytes(int64_t M);
+int snap_compact_rows_u8(const uint8_t* mask, int64_t M, int32_t* index, int32_t* count,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* y[m, 0..C) = value for every row with mask[m] == 0 (the masked voxels of a volume
+ * whose observed rows were written through rows_out).  C % 4 == 0. */
+int snap_fill_masked_rows_f32(float* y, const uint8_t* mask, int64_t M, int32_t C,
+                              float value, void* stream);
+
 /* StdConv weight standardisation over (H,W,I) per output channel, eps inside the
  * sqrt (resnet.py:34-41,73-79).  w,out: [K, Cout]. */
 int snap_weight_standardize_f32(const float* w, float* out, int32_t K,

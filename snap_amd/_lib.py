@@ -50,6 +50,14 @@ SIGNATURES = {
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
          ptr, ptr, ptr],
     ),
+    'snap_conv2d_nhwc_rows_f32': (
+        c_int,
+        [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
+         ptr, ptr, ptr, ptr, ptr, ptr],
+    ),
+    'snap_compact_rows_workspace_bytes': (c_size, [c_i64]),
+    'snap_compact_rows_u8': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_size, ptr]),
+    'snap_fill_masked_rows_f32': (c_int, [ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_weight_standardize_f32': (c_int, [ptr, ptr, c_int, c_int, c_float, ptr]),
     'snap_group_norm_stats_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int]),
     'snap_group_norm_stats_f32': (
@@ -145,7 +153,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -41,7 +41,10 @@ struct ConvArgs {
   const float* residual;
   const float* up_prev;
   const uint8_t* row_mask;
-  int M;       // N*Ho*Wo
+  const int32_t* rows_in;    // optional: GEMM row m reads output pixel rows_in[m]
+  const int32_t* rows_out;   // optional: GEMM row m is written to y row rows_out[m]
+  const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
+  int M;       // N*Ho*Wo  (upper bound of the row count when row_count is set)
   int K;       // KH*KW*Cin
   int ctiles;  // ceil(Cin/16)   (VEC path)
   int nk;      // number of K slabs
@@ -100,7 +103,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int seq = blockIdx.x >> 3;
   const int col_t = seq % ncol;
   const int row_t = (seq / ncol) * 8 + xcd;
-  if (row_t * BM >= a.M) return;   // padding blocks of the last row group (uniform per block)
+  // Row-indexed mode (compacted voxel lists): the launch covers the worst case M and the
+  // workgroups past the device-side count leave at once.
+  const int Meff = a.row_count ? min(*a.row_count, a.M) : a.M;
+  if (row_t * BM >= Meff) return;  // padding blocks of the last row group (uniform per block)
   const int m0 = row_t * BM;
   const int n0 = col_t * BN;
   const int HoWo = d.Ho * d.Wo;
@@ -116,8 +122,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   for (int i = 0; i < NR; ++i) {
     const int row = VEC ? (tid / QPR) + RPP * i : (tid / BK) + SRPP * i;
     const int m = m0 + row;
-    r_ok[i] = m < a.M;
-    const int mm = r_ok[i] ? m : 0;
+    r_ok[i] = m < Meff;
+    int mm = r_ok[i] ? m : 0;
+    if (a.rows_in) mm = a.rows_in[mm];
     const int n = mm / HoWo;
     const int r = mm - n * HoWo;
     const int ho = r / d.Wo;
@@ -363,9 +370,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       const int row = idx / Q, q = idx - row * Q;
       const int m = m0 + (row >> 5) * (BM / 2) + h * 32 + (row & 31);
       const int col = n0 + 4 * q;
-      if (m >= a.M || col >= d.Cout) continue;
+      if (m >= Meff || col >= d.Cout) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * BN + 4 * q);
-      const int64_t o = (int64_t)m * d.Cout_stride + col;
+      const int64_t o = (int64_t)(a.rows_out ? a.rows_out[m] : m) * d.Cout_stride + col;
       if (epi & SNAP_EPI_BIAS) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + col);
 #pragma unroll
@@ -502,7 +509,21 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
                                     const float* bias, const float* residual,
                                     const float* up_prev, const uint8_t* row_mask,
                                     void* stream) {
+  return snap_conv2d_nhwc_rows_f32(desc, x, w, y, gn_mu, gn_sc, gn_beta, bias, residual, up_prev,
+                                   row_mask, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int snap_conv2d_nhwc_rows_f32(const SnapConvDesc* desc, const float* x,
+                                         const float* w, float* y, const float* gn_mu,
+                                         const float* gn_sc, const float* gn_beta,
+                                         const float* bias, const float* residual,
+                                         const float* up_prev, const uint8_t* row_mask,
+                                         const int32_t* rows_in, const int32_t* rows_out,
+                                         const int32_t* row_count, void* stream) {
   if (!desc || !x || !w || !y) return SNAP_ERR_NULL;
+  if ((rows_in || rows_out) &&
+      (desc->epilogue & (SNAP_EPI_RESIDUAL | SNAP_EPI_UPSAMPLE2X_ADD | SNAP_EPI_ROWMASK)))
+    return SNAP_ERR_UNSUPPORTED;  // row-indexed launches carry bias / ReLU only
   const SnapConvDesc& d = *desc;
   if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 ||
       d.KW <= 0 || d.stride <= 0 || d.Ho <= 0 || d.Wo <= 0)
@@ -529,6 +550,7 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
   a.x = x; a.w = w; a.y = y;
   a.gn_mu = gn_mu; a.gn_sc = gn_sc; a.gn_beta = gn_beta;
   a.bias = bias; a.residual = residual; a.up_prev = up_prev; a.row_mask = row_mask;
+  a.rows_in = rows_in; a.rows_out = rows_out; a.row_count = row_count;
   a.M = d.N * d.Ho * d.Wo;
   a.K = d.KH * d.KW * d.Cin;
   // float4 path: channel runs must be 16-byte addressable.

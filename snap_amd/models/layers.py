@@ -39,6 +39,10 @@ class MLP(base.Module):
 
   def __call__(self, params, x, train=False, row_mask=None):
     n = len(self.config.layers)
+    grad = any(base.needs_grad(x, params[f'Dense_{i}']['kernel'], params[f'Dense_{i}']['bias'])
+               for i in range(n))
+    if row_mask is not None and not grad and row_mask.numel() >= self.COMPACT_MIN_ROWS:
+      return self._masked_rows(params, x, row_mask)
     for i in range(n):
       p = params[f'Dense_{i}']
       pro = ops.PRO_RELU if (i == 0 and self.config.apply_input_activation) else ops.PRO_NONE
@@ -48,3 +52,26 @@ class MLP(base.Module):
           relu=(i + 1 < n), row_mask=row_mask if i + 1 == n else None,
       )
     return x
+
+  # Below this many rows the three tiny compaction launches cost more than they save.
+  COMPACT_MIN_ROWS = 1 << 16
+
+  def _masked_rows(self, params, x, row_mask):
+    """Inference path for a row-masked MLP: rows with mask == 0 come out as zeros whatever
+    the MLP computes (streetview_encoder.py:281-283), so only the listed rows are
+    multiplied.  Bitwise the same values as the dense path on the kept rows."""
+    n = len(self.config.layers)
+    lead = x.shape[:-1]
+    M = row_mask.numel()
+    index, count = ops.compact_rows(row_mask)
+    h = x.reshape(M, x.shape[-1])
+    for i in range(n):
+      p = params[f'Dense_{i}']
+      pro = ops.PRO_RELU if (i == 0 and self.config.apply_input_activation) else ops.PRO_NONE
+      last = i + 1 == n
+      h = ops.dense(
+          h, p['kernel'], p['bias'], cin=p['kernel'].shape[0], prologue=pro, relu=not last,
+          rows_in=index if i == 0 else None, rows_out=index if last else None, row_count=count,
+      )
+    ops.fill_masked_rows_(h, row_mask)
+    return h.reshape(*lead, h.shape[-1])

@@ -41,7 +41,8 @@ class KernelProfiler:
     """Per-launch (tag, ms, flops, bytes) of one kernel family (after a sync)."""
     torch.cuda.synchronize()
     return [
-        (r[4], r[0].elapsed_time(r[1]), r[2], r[3]) for r in self.records.get(name, [])
+        (r[4], r[0].elapsed_time(r[1]), _num(r[2]), _num(r[3]))
+        for r in self.records.get(name, [])
     ]
 
   def summary(self):
@@ -50,10 +51,15 @@ class KernelProfiler:
     for name, recs in self.records.items():
       ms = sum(r[0].elapsed_time(r[1]) for r in recs)
       out[name] = dict(
-          launches=len(recs), ms=ms, flops=sum(r[2] for r in recs),
-          bytes=sum(r[3] for r in recs),
+          launches=len(recs), ms=ms, flops=sum(_num(r[2]) for r in recs),
+          bytes=sum(_num(r[3]) for r in recs),
       )
     return out
+
+
+def _num(v):
+  """flops / bytes may be callables resolved after the sync (device-side row counts)."""
+  return float(v()) if callable(v) else v
 
 
 class _Region:
@@ -136,11 +142,13 @@ def _mask(t, name):
 def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
-    up_prev=None, row_mask=None,
+    up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
 ):
   """NHWC implicit-GEMM conv on f32 MFMA.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
   gn = (mu [N,Cin], sc [N,Cin], beta [Cin]) for PRO_GN_RELU / PRO_RELU_GN.
+  rows_in / rows_out (int32 [M]) + row_count (int32 [1], device): row-indexed launch
+  over a compacted row list (see ``compact_rows``); ``out`` supplies the destination.
   Returns y [N,Ho,Wo,Cout].
   """
   lib = _lib.load()
@@ -154,7 +162,15 @@ def conv2d(
   (pt, pb), (pl, pr) = padding
   Ho = (H + pt + pb - KH) // stride + 1
   Wo = (W + pl + pr - KW) // stride + 1
-  y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+  if out is None:
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+  else:
+    y = _f32(out, 'out')
+    if y.numel() != N * Ho * Wo * Cout:
+      raise ValueError('conv2d: out has the wrong size')
+  for t, nm in ((rows_in, 'rows_in'), (rows_out, 'rows_out'), (row_count, 'row_count')):
+    if t is not None:
+      _chk(t, torch.int32, nm)
   epi = 0
   mu = sc = beta = None
   if prologue in (PRO_GN_RELU, PRO_RELU_GN):
@@ -185,30 +201,68 @@ def conv2d(
       epi, float(in_affine[0]), float(in_affine[1]),
   )
   M = N * Ho * Wo
+  kflops = 2.0 * KH * KW * Cin * Cout
+  if row_count is None:
+    flops = kflops * M
+    nbytes = 4.0 * (x.numel() + w.numel() + y.numel())
+  else:  # resolved after the sync: only the listed rows are multiplied / moved
+    flops = lambda: kflops * int(row_count.item())
+    nbytes = lambda: 4.0 * (int(row_count.item()) * (Cin + Cout) + w.numel())
   with _region(
-      'conv_igemm', 2.0 * M * KH * KW * Cin * Cout,
-      4.0 * (x.numel() + w.numel() + y.numel()),
-      lambda: f'M{M}_K{KH}x{KW}x{Cin}_N{Cout}_s{stride}_p{prologue}_e{epi}',
+      'conv_igemm', flops, nbytes,
+      lambda: f'M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}_s{stride}'
+              f'_p{prologue}_e{epi}',
   ):
-    st = lib.snap_conv2d_nhwc_f32(
+    st = lib.snap_conv2d_nhwc_rows_f32(
         ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
-        _p(residual), _p(up_prev), _p(row_mask), _stream(),
+        _p(residual), _p(up_prev), _p(row_mask), _p(rows_in), _p(rows_out), _p(row_count),
+        _stream(),
     )
-  _lib.check(st, 'snap_conv2d_nhwc_f32')
+  _lib.check(st, 'snap_conv2d_nhwc_rows_f32')
   return y
 
 
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
-          row_mask=None):
+          row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None):
   """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1)."""
   lead = x.shape[:-1]
   M = int(np.prod(lead)) if len(lead) else 1
   y = conv2d(
       x.reshape(1, 1, M, x.shape[-1]), kernel.reshape(1, 1, *kernel.shape),
       cin=cin if cin is not None else kernel.shape[0], prologue=prologue,
-      bias=bias, relu=relu, row_mask=row_mask,
+      bias=bias, relu=relu, row_mask=row_mask, rows_in=rows_in, rows_out=rows_out,
+      row_count=row_count, out=None if out is None else out.reshape(1, 1, M, kernel.shape[1]),
   )
   return y.reshape(*lead, kernel.shape[1])
+
+
+def compact_rows(mask):
+  """mask [...] (bool/uint8) -> (index int32 [M] -- first `count` entries valid, ascending --
+  and count int32 [1]); everything stays on the device."""
+  lib = _lib.load()
+  _mask(mask, 'mask')
+  M = mask.numel()
+  wsb = lib.snap_compact_rows_workspace_bytes(M)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.int32, device=mask.device)
+  index = torch.empty(M, dtype=torch.int32, device=mask.device)
+  count = torch.empty(1, dtype=torch.int32, device=mask.device)
+  st = lib.snap_compact_rows_u8(_p(mask), M, _p(index), _p(count), _p(ws), ws.numel() * 4,
+                                _stream())
+  _lib.check(st, 'snap_compact_rows_u8')
+  return index, count
+
+
+def fill_masked_rows_(y, mask, value=0.0):
+  """In place: y[m, :] = value where mask[m] == 0.  y [..., C]."""
+  lib = _lib.load()
+  _f32(y, 'y'); _mask(mask, 'mask')
+  C = y.shape[-1]
+  M = y.numel() // C
+  if mask.numel() != M:
+    raise ValueError('fill_masked_rows_: mask size')
+  st = lib.snap_fill_masked_rows_f32(_p(y), _p(mask), M, C, float(value), _stream())
+  _lib.check(st, 'snap_fill_masked_rows_f32')
+  return y
 
 
 def weight_standardize(w, eps=1e-10):

@@ -457,3 +457,50 @@ def test_exhaustive_identity_kat():
   s = pev.exhaustive_pose_voting(plane, plane, R, grids.Grid2D((H, H), 0.5))
   idx = np.unravel_index(int(torch.argmax(s)), s.shape)
   assert tuple(int(i) for i in idx) == (0, H - 1, H - 1)
+
+
+# ---------------------------------------------------------------------------
+# masked-row compaction (row-indexed fusion MLP)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('M,p', [(1, 1.0), (17, 0.5), (4096, 0.0), (4097, 1.0), (100003, 0.6),
+                                 (1 << 20, 0.03)])
+def test_compact_rows_matches_nonzero(M, p):
+  g = torch.Generator().manual_seed(M)
+  mask = (torch.rand(M, generator=g) < p)
+  index, count = ops.compact_rows(mask.cuda())
+  want = torch.nonzero(mask).flatten().to(torch.int32)
+  assert int(count.item()) == want.numel()
+  assert torch.equal(index[: want.numel()].cpu(), want)
+  # unaligned view (the 16-byte fast path must not be taken blindly)
+  if M > 5:
+    sub = mask.cuda()[3:]                                    # data_ptr off by 3 bytes
+    index, count = ops.compact_rows(sub)
+    want = torch.nonzero(mask[3:]).flatten().to(torch.int32)
+    assert int(count.item()) == want.numel()
+    assert torch.equal(index[: want.numel()].cpu(), want)
+
+
+@pytest.mark.parametrize('layers_,in_dim,stride', [((64, 32), 65, 68), ((128,), 257, 260), ((256, 128), 257, 260)])
+def test_masked_row_mlp_is_bitwise_the_dense_mlp(layers_, in_dim, stride, monkeypatch):
+  from snap_amd.models import layers
+  from snap_amd.utils import config_dict
+  cfg = config_dict.ConfigDict(dict(layers=layers_, activation='relu', apply_input_activation=False))
+  mlp = layers.MLP(cfg, in_dim=in_dim)
+  gen = torch.Generator().manual_seed(5)
+  params = helpers.params_to_device(mlp.init_params(gen, 'cpu'), 'cuda')
+  for i in range(len(layers_)):
+    params[f'Dense_{i}']['bias'] = torch.randn(layers_[i], generator=gen).cuda()
+  M = 70001
+  x = torch.randn(M, stride, generator=gen).cuda()
+  mask = (torch.rand(M, generator=gen) < 0.6).cuda()
+  dense = mlp(params, x, row_mask=mask)                      # M < COMPACT_MIN_ROWS: dense path
+  monkeypatch.setattr(layers.MLP, 'COMPACT_MIN_ROWS', 0)
+  compact = mlp(params, x, row_mask=mask)
+  assert torch.equal(dense, compact)
+  assert bool((compact[~mask] == 0).all())
+  # all rows masked / none masked
+  for m in (torch.zeros(M, dtype=torch.bool).cuda(), torch.ones(M, dtype=torch.bool).cuda()):
+    monkeypatch.setattr(layers.MLP, 'COMPACT_MIN_ROWS', 1 << 30)
+    d = mlp(params, x, row_mask=m)
+    monkeypatch.setattr(layers.MLP, 'COMPACT_MIN_ROWS', 0)
+    assert torch.equal(d, mlp(params, x, row_mask=m))
