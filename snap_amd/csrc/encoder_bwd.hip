@@ -173,10 +173,12 @@ __global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dws,
                                                              float* __restrict__ dw, int K,
                                                              int Cout, float eps) {
-  __shared__ float red[8][33];
-  __shared__ float stat[4][32];
-  const int tc = threadIdx.x & 31, tk = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + tc;
+  // same geometry as the forward kernel (encoder_ops.hip): 8 columns x 32 k-slices.
+  constexpr int COLS = 8, SLICES = 256 / COLS;
+  __shared__ float red[SLICES][COLS + 1];
+  __shared__ float stat[4][COLS];
+  const int tc = threadIdx.x % COLS, tk = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + tc;
   const bool ok = col < Cout;
   auto reduce = [&](float v, int slot, float scale) {
     red[tk][tc] = v;
@@ -184,19 +186,19 @@ __global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __rest
     if (tk == 0) {
       float t = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t += red[i][tc];
+      for (int i = 0; i < SLICES; ++i) t += red[i][tc];
       stat[slot][tc] = t * scale;
     }
     __syncthreads();
   };
   float s = 0.f;
   if (ok)
-    for (int k = tk; k < K; k += 8) s += w[(int64_t)k * Cout + col];
+    for (int k = tk; k < K; k += SLICES) s += w[(int64_t)k * Cout + col];
   reduce(s, 0, 1.0f / (float)K);
   const float mean = stat[0][tc];
   float q = 0.f;
   if (ok)
-    for (int k = tk; k < K; k += 8) {
+    for (int k = tk; k < K; k += SLICES) {
       const float dl = w[(int64_t)k * Cout + col] - mean;
       q += dl * dl;
     }
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __rest
   const float sigma = sqrtf(stat[1][tc] + eps);
   float g1 = 0.f, g2 = 0.f;
   if (ok)
-    for (int k = tk; k < K; k += 8) {
+    for (int k = tk; k < K; k += SLICES) {
       const int64_t o = (int64_t)k * Cout + col;
       const float ws = (w[o] - mean) / sigma;
       g1 += dws[o];
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __rest
   // d sigma carries the eps: sigma^2 = var + eps, so d/dw (1/sigma) uses var/sigma... exact form:
   // ws = (w-mean)/sigma; dw = (dws - mean(dws) - ws * mean(dws*ws)) / sigma.
   if (ok)
-    for (int k = tk; k < K; k += 8) {
+    for (int k = tk; k < K; k += SLICES) {
       const int64_t o = (int64_t)k * Cout + col;
       const float ws = (w[o] - mean) / sigma;
       dw[o] = (dws[o] - mg - ws * mgw) / sigma;
@@ -423,7 +425,7 @@ extern "C" int snap_weight_standardize_bwd_f32(const float* w, const float* dws,
                                                int32_t K, int32_t Cout, float eps, void* stream) {
   if (!w || !dws || !dw) return SNAP_ERR_NULL;
   if (K <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((unsigned)snap_cdiv(Cout, 32)), dim3(256), 0,
+  hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((unsigned)snap_cdiv(Cout, 8)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, dws, dw, K, Cout, eps);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;

@@ -12,32 +12,37 @@ namespace {
 
 // ---------------------------------------------------------------------------
 // Weight standardisation: w[K, Cout], statistics over K per column.
-// block = 32 columns x 8 k-slices.
+// block = WS_COLS columns x WS_SLICES k-slices.  Narrow column groups keep the grid
+// large (Cout/8 workgroups) and the serial K walk short (K/32 steps): these tensors are
+// tiny and the kernel is pure latency.
 // ---------------------------------------------------------------------------
+constexpr int WS_COLS = 8;
+constexpr int WS_SLICES = 256 / WS_COLS;
+
 __global__ __launch_bounds__(256) void weight_std_kernel(const float* __restrict__ w,
                                                          float* __restrict__ out, int K,
                                                          int Cout, float eps) {
-  __shared__ float red[8][33];
-  __shared__ float stat[2][32];
-  const int tc = threadIdx.x & 31, tk = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + tc;
+  __shared__ float red[WS_SLICES][WS_COLS + 1];
+  __shared__ float stat[2][WS_COLS];
+  const int tc = threadIdx.x % WS_COLS, tk = threadIdx.x / WS_COLS;
+  const int col = blockIdx.x * WS_COLS + tc;
   const bool ok = col < Cout;
   float s = 0.f;
   if (ok)
-    for (int k = tk; k < K; k += 8) s += w[(int64_t)k * Cout + col];
+    for (int k = tk; k < K; k += WS_SLICES) s += w[(int64_t)k * Cout + col];
   red[tk][tc] = s;
   __syncthreads();
   if (tk == 0) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i][tc];
+    for (int i = 0; i < WS_SLICES; ++i) t += red[i][tc];
     stat[0][tc] = t / (float)K;
   }
   __syncthreads();
   const float mean = stat[0][tc];
   float q = 0.f;
   if (ok)
-    for (int k = tk; k < K; k += 8) {
+    for (int k = tk; k < K; k += WS_SLICES) {
       const float dlt = w[(int64_t)k * Cout + col] - mean;
       q += dlt * dlt;
     }
@@ -46,13 +51,13 @@ __global__ __launch_bounds__(256) void weight_std_kernel(const float* __restrict
   if (tk == 0) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i][tc];
+    for (int i = 0; i < WS_SLICES; ++i) t += red[i][tc];
     stat[1][tc] = sqrtf(t / (float)K + eps);
   }
   __syncthreads();
   const float denom = stat[1][tc];
   if (ok)
-    for (int k = tk; k < K; k += 8) {
+    for (int k = tk; k < K; k += WS_SLICES) {
       const int64_t o = (int64_t)k * Cout + col;
       out[o] = (w[o] - mean) / denom;
     }
@@ -247,7 +252,7 @@ extern "C" int snap_weight_standardize_f32(const float* w, float* out, int32_t K
                                            float eps, void* stream) {
   if (!w || !out) return SNAP_ERR_NULL;
   if (K <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(weight_std_kernel, dim3((unsigned)snap_cdiv(Cout, 32)), dim3(256), 0,
+  hipLaunchKernelGGL(weight_std_kernel, dim3((unsigned)snap_cdiv(Cout, WS_COLS)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, out, K, Cout, eps);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;

@@ -63,9 +63,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int wr = wid >> 1, wc = wid & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int kt = blockIdx.x / a.ncol, col_t = blockIdx.x - kt * a.ncol;
-  const int kpos = kt / a.ctiles, ct = kt - kpos * a.ctiles;
+  // VEC: a tile is BKT channels of ONE (kh, kw) tap.  Scalar path (Cin < 4 or unaligned,
+  // i.e. the 7x7x3 root conv): a tile is BKT consecutive rows of the FLAT k = (kh*KW+kw)*Cin+c
+  // axis, so its 147 rows fill 3 tiles instead of 49 tiles that are 95 % padding.
+  const int kpos = VEC ? kt / a.ctiles : 0, ct = VEC ? kt - kpos * a.ctiles : 0;
   const int kh = kpos / d.KW, kw = kpos - kh * d.KW;
   const int c0 = ct * BKT;
+  const int k0 = kt * BKT;  // scalar path: first flat k of the tile
   const int n0 = col_t * BN;
   const int HoWo = d.Ho * d.Wo;
   const int64_t m_begin = (int64_t)blockIdx.y * a.slabs_per_chunk * RS;
@@ -89,6 +93,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int zq = tid % ZQ, zrow0 = tid / ZQ;
   const int dq = tid % DQ, drow0 = tid / DQ;
   const int zc = c0 + 4 * zq;  // VEC: first channel of this thread's quad
+  // scalar path: (kh, kw, c) of each of this thread's slab elements (slab-invariant)
+  int ekh[VEC ? 1 : ZELEMS], ekw[VEC ? 1 : ZELEMS], ec[VEC ? 1 : ZELEMS];
+  bool ekok[VEC ? 1 : ZELEMS];
+  if constexpr (!VEC) {
+#pragma unroll
+    for (int e = 0; e < ZELEMS; ++e) {
+      const int idx = tid + 256 * e;
+      const int k = k0 + (idx % BKT);
+      ekok[e] = k < a.K;
+      const int kk = ekok[e] ? k : 0;
+      const int kp = kk / d.Cin;
+      ec[e] = kk - kp * d.Cin;
+      ekh[e] = kp / d.KW;
+      ekw[e] = kp - ekh[e] * d.KW;
+    }
+  }
   if constexpr (VEC && need_gn) {
     zbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (zc < d.Cin ? zc : 0));
   }
@@ -119,16 +139,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < ZELEMS; ++e) {
         const int idx = tid + 256 * e;           // over RS x BKT
-        const int rr = idx / BKT, cc = idx - rr * BKT;
+        const int rr = idx / BKT;
         const int64_t m = ms + rr;
         const bool mok = m < m_end;
         const int mm = mok ? (int)m : 0;
         const int n = mm / HoWo;
         const int r = mm - n * HoWo;
         const int ho = r / d.Wo, wo = r - ho * d.Wo;
-        const int hi = ho * d.stride - d.pad_t + kh, wi = wo * d.stride - d.pad_l + kw;
-        const int c = c0 + cc;
-        const bool inb = mok && c < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+        const int hi = ho * d.stride - d.pad_t + ekh[e], wi = wo * d.stride - d.pad_l + ekw[e];
+        const int c = ec[e];
+        const bool inb = mok && ekok[e] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
         sin_[e] = inb;
         const int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + c : (int64_t)0;
         se[e] = a.x[off];
@@ -222,8 +242,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
       const int c = c0 + wr * (BKT / 2) + i * 32 + ri;
-      if (c >= d.Cin) continue;
-      const int64_t krow = (int64_t)kpos * d.Cin + c;
+      int64_t krow;
+      if constexpr (VEC) {
+        if (c >= d.Cin) continue;
+        krow = (int64_t)kpos * d.Cin + c;
+      } else {
+        krow = k0 + wr * (BKT / 2) + i * 32 + ri;
+        if (krow >= a.K) continue;
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wc * (BN / 2) + j * 32 + l31;
@@ -241,7 +267,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, in
   dw[i] = t;
 }
 
-struct WgPlan { int bkt, bn, ctiles, ncol, S, slabs_per_chunk; };
+struct WgPlan { int bkt, bn, ctiles, ncol, ktiles, S, slabs_per_chunk; };
 
 inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
   WgPlan p;
@@ -250,9 +276,12 @@ inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
   p.ctiles = (d.Cin + p.bkt - 1) / p.bkt;
   p.ncol = (d.Cout + p.bn - 1) / p.bn;
   const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
-  // the M split is sized on 64-channel tiles so that it (and the workspace) does not
-  // depend on which loader variant runs.
-  const int64_t tiles = (int64_t)d.KH * d.KW * ((d.Cin + 63) / 64) * p.ncol;
+  // row tiles: per-tap channel tiles (VEC) or flat-k tiles (scalar path)
+  p.ktiles = vec ? d.KH * d.KW * p.ctiles : (d.KH * d.KW * d.Cin + p.bkt - 1) / p.bkt;
+  // the M split of the VEC plan is sized on 64-channel tiles so that it (and the
+  // workspace) does not depend on BKT.
+  const int64_t tiles = vec ? (int64_t)d.KH * d.KW * ((d.Cin + 63) / 64) * p.ncol
+                            : (int64_t)p.ktiles * p.ncol;
   int64_t S = (1024 + tiles - 1) / tiles;
   const int64_t smax = (M + 255) / 256;   // >= 16 slabs per chunk
   if (S > smax) S = smax;
@@ -265,7 +294,7 @@ inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
 
 template <int BKT, int BN, bool VEC, int PRO>
 int wg_launch(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
-  const dim3 grid((unsigned)(a.d.KH * a.d.KW * p.ctiles * p.ncol), (unsigned)p.S);
+  const dim3 grid((unsigned)(p.ktiles * p.ncol), (unsigned)p.S);
   hipLaunchKernelGGL((wgrad_kernel<BKT, BN, VEC, PRO>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
@@ -291,8 +320,9 @@ int wg_launch_pro(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
 
 extern "C" size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc) {
   if (!desc) return 0;
-  const WgPlan p = wg_plan(*desc, true);
-  return (size_t)p.S * desc->KH * desc->KW * desc->Cin * desc->Cout * sizeof(float);
+  // the loader variant depends on the pointer alignment seen at launch: size for both.
+  const int S = max(wg_plan(*desc, true).S, wg_plan(*desc, false).S);
+  return (size_t)S * desc->KH * desc->KW * desc->Cin * desc->Cout * sizeof(float);
 }
 
 extern "C" int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, const float* dy,

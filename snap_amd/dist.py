@@ -82,9 +82,12 @@ def allreduce_mean_tree_(grads: Dict, group=None, bucket_bytes: int = 64 << 20) 
 def all_finite(tensors: Iterable[torch.Tensor], group=None) -> bool:
   """True iff every element on every rank is finite (trainer.py:260-266)."""
   tensors = [t for t in tensors if t is not None]
-  ok = torch.ones((), dtype=torch.float32, device=tensors[0].device if tensors else 'cpu')
-  for t in tensors:
-    ok = ok * torch.isfinite(t).all().to(torch.float32)
+  if tensors:
+    # max|.| per tensor in one multi-tensor launch; inf / nan propagate into the max.
+    peak = torch.stack(torch._foreach_norm(tensors, float('inf')))
+    ok = torch.isfinite(peak).all().to(torch.float32)
+  else:
+    ok = torch.ones((), dtype=torch.float32)
   if _world(group) > 1:
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
   return bool(ok.item() > 0)

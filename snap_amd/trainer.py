@@ -63,6 +63,11 @@ def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
   torch._foreach_addcdiv_(leaves, m, denom, value=-lr / c1)
 
 
+def _global_norm(tensors):
+  """sqrt(sum ||t||^2): one multi-tensor launch + a tiny fp64 reduction."""
+  return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)).double())
+
+
 def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_norm=None,
                group=None, debug=False):
   """One optimisation step.  Returns (state, metrics, training_logs)."""
@@ -89,11 +94,11 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   sdist.allreduce_mean_(grads, group)                 # jax.lax.pmean(grad, 'batch')
   logs = {}
   if max_grad_norm is not None:
-    gn = torch.sqrt(sum((g * g).sum() for g in grads))
+    gn = _global_norm(grads)
     factor = torch.clamp(max_grad_norm / (gn + 1e-6), max=1.0)
-    grads = [g * factor for g in grads]
+    torch._foreach_mul_(grads, factor)
   is_fin = sdist.all_finite(grads, group)
-  logs['l2_grads'] = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+  logs['l2_grads'] = float(_global_norm(grads))
   lr = lr_fn(state.global_step)
   logs['learning_rate'] = lr
   logs['is_finite'] = is_fin
@@ -101,7 +106,7 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
     with torch.no_grad():
       _adam_update_(leaves, grads, state.m, state.v, state.global_step + 1, lr)
   with torch.no_grad():
-    logs['l2_params'] = float(torch.sqrt(sum((t.double() ** 2).sum() for t in leaves)))
+    logs['l2_params'] = float(_global_norm(leaves))
     per_example = {k: v.detach().to(torch.float32) for k, v in metrics.items()}
     for k, v in losses.items():
       per_example[f'loss/{k}'] = v.detach()
