@@ -211,6 +211,10 @@ def main(argv=None):
   ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
   ap.add_argument('--device', default='cuda')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--dist-backend', default=None,
+                  help='testing only: override the process-group backend (default nccl = RCCL)')
+  ap.add_argument('--share-gpu', action='store_true',
+                  help='testing only: every rank uses GPU 0 (multi-process plumbing check on a 1-GPU box)')
   ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                   help='infer: BEVLocalizer forward (the headline metric); train: one '
                        'snap_amd.trainer.train_step (fwd + bwd + grad all-reduce + Adam)')
@@ -223,12 +227,13 @@ def main(argv=None):
     raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
   use_cuda = args.device == 'cuda'
   if use_cuda:
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
   else:
     device = torch.device('cpu')
   if world > 1:
-    dist.init_process_group('nccl' if use_cuda else 'gloo')
+    dist.init_process_group(args.dist_backend or ('nccl' if use_cuda else 'gloo'))
 
   loc, cfg, meta, variables, batch = build(args.workload, device, rank)
   scenes_per_rank = WORKLOADS[args.workload]['batch']
