@@ -111,9 +111,11 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
   const SnapLiftDesc& d = a.d;
   const int hl = threadIdx.x & 31;
-  // Blocks walk the voxel range in dispatch (round-robin over XCDs) order.  A
-  // contiguous eighth per XCD was measured SLOWER (6.6 vs 5.7 ms at C2): visibility
-  // varies over the scene, so contiguous slabs unbalance the XCDs.
+  // Blocks walk the voxel range in dispatch (round-robin over XCDs) order.  Measured
+  // alternatives at C2 (5.7 ms): a contiguous eighth per XCD is SLOWER (6.6 ms, visibility
+  // varies over the scene and unbalances the XCDs); XCD-owned chunks of 8..480 workgroups
+  // (whole columns per L2) change nothing (5.7-5.8 ms) although they remove most of the
+  // L2 over-fetch -- the kernel is bound by the tap gathers through L1, not by L2 misses.
   const int64_t gv = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   const int64_t total = (int64_t)d.B * d.N;
   if (gv >= total) return;  // whole half-wave exits together
