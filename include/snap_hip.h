@@ -76,20 +76,43 @@ int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x, const float* 
                          const float* residual, const float* up_prev,
                          const uint8_t* row_mask, void* stream);
 
-/* Row-indexed variant for masked voxel lists (the fusion MLP of
- * streetview_encoder.py:281 runs over every voxel and the result is then masked by
- * visibility; unobserved voxels never reach any output, so only the observed rows are
- * multiplied).  rows_in: GEMM row m reads output pixel rows_in[m] of x; rows_out: GEMM
- * row m is stored to row rows_out[m] of y; row_count: DEVICE scalar with the number of
- * rows (<= N*Ho*Wo, the launch bound) -- no host synchronisation.  Any may be NULL.
- * Only SNAP_EPI_BIAS / SNAP_EPI_RELU epilogues.  */
-int snap_conv2d_nhwc_rows_f32(const SnapConvDesc* desc, const float* x, const float* w,
-                              float* y, const float* gn_mu, const float* gn_sc,
-                              const float* gn_beta, const float* bias,
-                              const float* residual, const float* up_prev,
-                              const uint8_t* row_mask, const int32_t* rows_in,
-                              const int32_t* rows_out, const int32_t* row_count,
-                              void* stream);
+/* Optional extras of a conv launch (all may be NULL / 0):
+ *  - row-indexed launch over a masked voxel list (the fusion MLP of
+ *    streetview_encoder.py:281 runs over every voxel and the result is then masked by
+ *    visibility; unobserved voxels never reach any output, so only the observed rows are
+ *    multiplied).  rows_in: GEMM row m reads output pixel rows_in[m] of x; rows_out: GEMM
+ *    row m is stored to row rows_out[m] of y; row_count: DEVICE scalar with the number of
+ *    rows (<= N*Ho*Wo, the launch bound) -- no host synchronisation.  Only
+ *    SNAP_EPI_BIAS / SNAP_EPI_RELU epilogues.
+ *  - gn_partial: the epilogue also emits per-(image, row tile, channel) sums of y and y^2
+ *    (of relu(y) if gn_partial_relu), from which snap_group_norm_stats_from_partial_f32
+ *    produces the GroupNorm statistics the NEXT layer's fused prologue needs
+ *    (resnet.py:46-60) without re-reading y.  Size: snap_conv2d_gn_partial_bytes(desc);
+ *    0 means "not available for this shape" (Ho*Wo smaller than a row tile).  */
+typedef struct SnapConvExtras {
+  const int32_t* rows_in;
+  const int32_t* rows_out;
+  const int32_t* row_count;
+  float* gn_partial;
+  size_t gn_partial_bytes;
+  int32_t gn_partial_relu;
+} SnapConvExtras;
+
+int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,
+                            float* y, const float* gn_mu, const float* gn_sc,
+                            const float* gn_beta, const float* bias,
+                            const float* residual, const float* up_prev,
+                            const uint8_t* row_mask, const SnapConvExtras* extras,
+                            void* stream);
+size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc);
+int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc);   /* row-tile height the launch uses */
+
+/* mu / sc (/ rstd) [N, C] from a conv launch's gn_partial.  tile_rows =
+ * snap_conv2d_tile_rows(desc of that launch); HW = Ho*Wo of its output. */
+int snap_group_norm_stats_from_partial_f32(const float* partial, int32_t N, int32_t HW,
+                                           int32_t C, int32_t groups, float eps,
+                                           int32_t tile_rows, const float* gamma, float* mu,
+                                           float* sc, float* rstd, void* stream);
 
 /* Ascending list of the rows with mask != 0: index[0..count) (stable order,
  * deterministic), count written to *count (device).  index must hold M entries. */

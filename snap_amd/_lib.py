@@ -30,6 +30,13 @@ class SnapConvDesc(ctypes.Structure):
   ]
 
 
+class SnapConvExtras(ctypes.Structure):
+  _fields_ = [
+      ('rows_in', ptr), ('rows_out', ptr), ('row_count', ptr), ('gn_partial', ptr),
+      ('gn_partial_bytes', c_size), ('gn_partial_relu', c_int),
+  ]
+
+
 class SnapLiftDesc(ctypes.Structure):
   _fields_ = [
       ('B', c_int), ('V', c_int), ('h', c_int), ('w', c_int), ('C', c_int),
@@ -50,10 +57,15 @@ SIGNATURES = {
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
          ptr, ptr, ptr],
     ),
-    'snap_conv2d_nhwc_rows_f32': (
+    'snap_conv2d_nhwc_ex_f32': (
         c_int,
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
-         ptr, ptr, ptr, ptr, ptr, ptr],
+         ptr, ptr, ctypes.POINTER(SnapConvExtras), ptr],
+    ),
+    'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_group_norm_stats_from_partial_f32': (
+        c_int, [ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr, ptr]
     ),
     'snap_compact_rows_workspace_bytes': (c_size, [c_i64]),
     'snap_compact_rows_u8': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_size, ptr]),
@@ -153,7 +165,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

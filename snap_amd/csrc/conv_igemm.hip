@@ -44,6 +44,9 @@ struct ConvArgs {
   const int32_t* rows_in;    // optional: GEMM row m reads output pixel rows_in[m]
   const int32_t* rows_out;   // optional: GEMM row m is written to y row rows_out[m]
   const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
+  float* gn_partial;         // optional: per-(image, row tile, channel) sums of y and y^2
+  int gn_relu;               // ... of relu(y) (FPN order)
+  int gn_slabs;              // row tiles per image in gn_partial (= HoWo / BM + 2)
   int M;       // N*Ho*Wo  (upper bound of the row count when row_count is set)
   int K;       // KH*KW*Cin
   int ctiles;  // ceil(Cin/16)   (VEC path)
@@ -353,6 +356,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int Hp = d.Ho >> 1, Wp = d.Wo >> 1;
   constexpr int Q = BN / 4;               // float4 per staged row
   constexpr int PER_THREAD = (64 * Q) / 256;
+  // GroupNorm statistics of the OUTPUT (consumed by the next layer's fused GN prologue):
+  // every thread owns 4 fixed columns (256 % Q == 0), accumulates sum / sum of squares of
+  // what it stores, split by image (a tile of BM <= HoWo rows touches at most two).
+  const bool want_stats = a.gn_partial != nullptr;
+  const int n_first = m0 / HoWo;
+  const int m_split = (n_first + 1) * HoWo;   // first row of the second image
+  float gs1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float gs2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int h = 0; h < TM; ++h) {
     if (h > 0) __syncthreads();
@@ -418,6 +429,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       }
       if ((epi & SNAP_EPI_ROWMASK) && a.row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(a.y + o) = v;
+      if (want_stats) {
+        const int sl = m >= m_split ? 1 : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = a.gn_relu ? fmaxf(v[e], 0.f) : v[e];
+          gs1[sl][e] += t;
+          gs2[sl][e] += t * t;
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    // fixed-order reduction over the 256/Q row groups through LDS, then one writer per
+    // (image slot, column): deterministic.
+    constexpr int RG = 256 / Q;
+    __syncthreads();
+    const int q = tid % Q, rg = tid / Q;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 0] = gs1[sl][e];
+        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 1] = gs2[sl][e];
+      }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int sl = i / BN, c = i - sl * BN;
+      const int col = n0 + c;
+      const int n = n_first + sl;
+      // slot 1 exists only if the tile reaches into the next image
+      const bool live = col < d.Cout && n < d.N && (sl == 0 || (m0 + BM > m_split && m_split < Meff));
+      if (!live) continue;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        t1 += smem[((r * 2 + sl) * BN + c) * 2 + 0];
+        t2 += smem[((r * 2 + sl) * BN + c) * 2 + 1];
+      }
+      const int slab = row_t - (int)(((int64_t)n * HoWo) / BM);
+      float* o = a.gn_partial + (((int64_t)n * a.gn_slabs + slab) * d.Cout + col) * 2;
+      o[0] = t1;
+      o[1] = t2;
     }
   }
 }
@@ -433,6 +486,7 @@ int launch(ConvArgs a, hipStream_t s) {
   }
   const int64_t nrow = snap_cdiv(a.M, BM);
   a.ncol = (int)snap_cdiv(a.d.Cout, BN);
+  a.gn_slabs = (a.d.Ho * a.d.Wo) / BM + 2;
   const int64_t nblocks = snap_cdiv(nrow, 8) * 8 * a.ncol;
   if (nblocks > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO, BK>), dim3((unsigned)nblocks), dim3(256),
@@ -476,28 +530,37 @@ inline int conv_forced_tile() {
 
 // Tile choice: the largest tile that still yields >= 2 workgroups per CU; small-M
 // layers (deep stages, few images) fall back to 64x64 tiles to fill the 256 CUs.
-template <bool VEC>
-int launch_tile(const ConvArgs& a, hipStream_t s) {
-  const int64_t M = a.M, N = a.d.Cout;
+struct TileChoice { int bm, bn; };
+inline TileChoice choose_tile(int64_t M, int64_t N) {
   const int64_t kMin = 512;
   const bool n_wide_ok = N > 64 && !(N % 128 != 0 && N % 128 <= 64);
-  const bool deep = VEC && conv_bk() == 32 && a.d.Cin >= 32;
   const int forced = conv_forced_tile();
-  if (forced == 128128 || (!forced && n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin)) {
+  if (forced == 128128 || (!forced && n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin))
+    return {128, 128};
+  if (forced == 128064 || (!forced && snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)) return {128, 64};
+  if (forced == 64128 ||
+      (!forced && n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin))
+    return {64, 128};
+  return {64, 64};
+}
+
+template <bool VEC>
+int launch_tile(const ConvArgs& a, hipStream_t s) {
+  const TileChoice t = choose_tile(a.M, a.d.Cout);
+  const bool deep = VEC && conv_bk() == 32 && a.d.Cin >= 32;
+  if (t.bm == 128 && t.bn == 128) {
     if constexpr (VEC) {
       if (deep) return launch_pro<128, 128, VEC, 32>(a, s);
     }
     return launch_pro<128, 128, VEC, 16>(a, s);
   }
-  if (forced == 128064 || (!forced && snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)) {
+  if (t.bm == 128) {
     if constexpr (VEC) {
       if (deep) return launch_pro<128, 64, VEC, 32>(a, s);
     }
     return launch_pro<128, 64, VEC, 16>(a, s);
   }
-  if (forced == 64128 ||
-      (!forced && n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin))
-    return launch_pro<64, 128, VEC, 16>(a, s);
+  if (t.bn == 128) return launch_pro<64, 128, VEC, 16>(a, s);
   return launch_pro<64, 64, VEC, 16>(a, s);
 }
 
@@ -509,21 +572,45 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
                                     const float* bias, const float* residual,
                                     const float* up_prev, const uint8_t* row_mask,
                                     void* stream) {
-  return snap_conv2d_nhwc_rows_f32(desc, x, w, y, gn_mu, gn_sc, gn_beta, bias, residual, up_prev,
-                                   row_mask, nullptr, nullptr, nullptr, stream);
+  return snap_conv2d_nhwc_ex_f32(desc, x, w, y, gn_mu, gn_sc, gn_beta, bias, residual, up_prev,
+                                 row_mask, nullptr, stream);
 }
 
-extern "C" int snap_conv2d_nhwc_rows_f32(const SnapConvDesc* desc, const float* x,
-                                         const float* w, float* y, const float* gn_mu,
-                                         const float* gn_sc, const float* gn_beta,
-                                         const float* bias, const float* residual,
-                                         const float* up_prev, const uint8_t* row_mask,
-                                         const int32_t* rows_in, const int32_t* rows_out,
-                                         const int32_t* row_count, void* stream) {
+extern "C" size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc) {
+  if (!desc) return 0;
+  const SnapConvDesc& d = *desc;
+  const int64_t HoWo = (int64_t)d.Ho * d.Wo;
+  const TileChoice t = choose_tile((int64_t)d.N * HoWo, d.Cout);
+  if (HoWo < t.bm) return 0;  // a tile would straddle more than two images: not produced
+  return (size_t)d.N * (HoWo / t.bm + 2) * d.Cout * 2 * sizeof(float);
+}
+
+extern "C" int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc) {
+  if (!desc) return 0;
+  return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout).bm;
+}
+
+extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
+                                       const float* w, float* y, const float* gn_mu,
+                                       const float* gn_sc, const float* gn_beta,
+                                       const float* bias, const float* residual,
+                                       const float* up_prev, const uint8_t* row_mask,
+                                       const SnapConvExtras* ex, void* stream) {
   if (!desc || !x || !w || !y) return SNAP_ERR_NULL;
+  const int32_t* rows_in = ex ? ex->rows_in : nullptr;
+  const int32_t* rows_out = ex ? ex->rows_out : nullptr;
+  const int32_t* row_count = ex ? ex->row_count : nullptr;
+  float* gn_partial = ex ? ex->gn_partial : nullptr;
   if ((rows_in || rows_out) &&
       (desc->epilogue & (SNAP_EPI_RESIDUAL | SNAP_EPI_UPSAMPLE2X_ADD | SNAP_EPI_ROWMASK)))
     return SNAP_ERR_UNSUPPORTED;  // row-indexed launches carry bias / ReLU only
+  if (gn_partial) {
+    if (rows_in || rows_out || row_count) return SNAP_ERR_UNSUPPORTED;
+    if (desc->Cout_stride != desc->Cout) return SNAP_ERR_UNSUPPORTED;
+    if (ex->gn_partial_bytes < snap_conv2d_gn_partial_bytes(desc) ||
+        snap_conv2d_gn_partial_bytes(desc) == 0)
+      return SNAP_ERR_WORKSPACE;
+  }
   const SnapConvDesc& d = *desc;
   if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 ||
       d.KW <= 0 || d.stride <= 0 || d.Ho <= 0 || d.Wo <= 0)
@@ -551,6 +638,9 @@ extern "C" int snap_conv2d_nhwc_rows_f32(const SnapConvDesc* desc, const float* 
   a.gn_mu = gn_mu; a.gn_sc = gn_sc; a.gn_beta = gn_beta;
   a.bias = bias; a.residual = residual; a.up_prev = up_prev; a.row_mask = row_mask;
   a.rows_in = rows_in; a.rows_out = rows_out; a.row_count = row_count;
+  a.gn_partial = gn_partial;
+  a.gn_relu = ex ? ex->gn_partial_relu : 0;
+  a.gn_slabs = 0;
   a.M = d.N * d.Ho * d.Wo;
   a.K = d.KH * d.KW * d.Cin;
   // float4 path: channel runs must be 16-byte addressable.

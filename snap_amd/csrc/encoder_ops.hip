@@ -132,30 +132,38 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// tile_rows > 0: `partial` comes from the conv engine's epilogue (conv_igemm.hip): plain
+// sums (pivot 0) per row tile of `tile_rows` output pixels, S = HW / tile_rows + 2 slots
+// per image of which only the tiles overlapping the image are live; x is not read.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const float* __restrict__ x, const float* __restrict__ partial, int S, int HW, int C, int Cs,
     int groups, int relu_first, float eps, const float* __restrict__ gamma,
-    float* __restrict__ mu, float* __restrict__ sc, float* __restrict__ rstd_out, int total) {
+    float* __restrict__ mu, float* __restrict__ sc, float* __restrict__ rstd_out, int total,
+    int tile_rows) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // over N*groups
   if (i >= total) return;
   const int n = i / groups, g = i - n * groups;
   const int cpg = C / groups;
   const int c_lo = g * cpg;
-  const float* xp = x + ((int64_t)n * HW) * Cs + c_lo;
+  const bool tiled = tile_rows > 0;
+  const float* xp = tiled ? nullptr : x + ((int64_t)n * HW) * Cs + c_lo;
   double t1 = 0.0, t2 = 0.0, u = 0.0, p1 = 0.0, p2 = 0.0;
-  const int count = S * cpg;
+  int live = S;
+  if (tiled)
+    live = (int)((((int64_t)(n + 1) * HW - 1) / tile_rows) - (((int64_t)n * HW) / tile_rows)) + 1;
+  const int count = live * cpg;
   for (int e = lane; e < count; e += 64) {
     const int s = e / cpg, cc = e - s * cpg;
-    float pv = xp[cc];
-    if (relu_first) pv = fmaxf(pv, 0.f);
+    float pv = tiled ? 0.f : xp[cc];
+    if (relu_first && !tiled) pv = fmaxf(pv, 0.f);
     const float* pp = partial + (((int64_t)n * S + s) * C + c_lo + cc) * 2;
     const double a1 = (double)pp[0];
     t1 += a1;
     t2 += (double)pp[1];
     u += (double)pv * a1;
   }
-  for (int cc = lane; cc < cpg; cc += 64) {
+  for (int cc = lane; cc < cpg && !tiled; cc += 64) {
     float pv = xp[cc];
     if (relu_first) pv = fmaxf(pv, 0.f);
     p1 += (double)pv;
@@ -288,7 +296,23 @@ extern "C" int snap_group_norm_stats_f32(const float* x, int32_t N, int32_t HW, 
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv(N * groups, 4)), dim3(256), 0, s,
                      x, (const float*)partial, pl.S, HW, C, C_stride, groups, relu_first, eps,
-                     gamma, mu, sc, rstd, N * groups);
+                     gamma, mu, sc, rstd, N * groups, 0);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_group_norm_stats_from_partial_f32(const float* partial, int32_t N, int32_t HW,
+                                                      int32_t C, int32_t groups, float eps,
+                                                      int32_t tile_rows, const float* gamma,
+                                                      float* mu, float* sc, float* rstd,
+                                                      void* stream) {
+  if (!partial || !gamma || !mu || !sc) return SNAP_ERR_NULL;
+  if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0) return SNAP_ERR_BAD_SHAPE;
+  if (tile_rows <= 0 || HW < tile_rows) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv(N * groups, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const float*)nullptr, partial,
+                     HW / tile_rows + 2, HW, C, C, groups, 0, eps, gamma, mu, sc, rstd, N * groups,
+                     tile_rows);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -34,13 +34,15 @@ def _std(ctx, kernel):
   return ctx.standardized(kernel, ops.weight_standardize)
 
 
-def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, **kw):
+def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, emit=True, **kw):
   """GroupNorm -> ReLU -> StdConv.  Training: one autograd node (statistics inside);
   inference: `gn_stats` may be shared between the convs reading the same input."""
   w = _std(ctx, kernel)
   if base.needs_grad(x, w, gn_p['scale'], gn_p['bias']):
     return ag.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn_params=(gn_p['scale'], gn_p['bias']), **kw)
-  return ops.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn=gn_stats or _gn(x, gn_p), **kw)
+  # the output feeds the next GroupNorm: its statistics come out of this conv's epilogue
+  return ops.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn=gn_stats or _gn(x, gn_p),
+                    emit_gn_stats='raw' if emit else None, **kw)
 
 
 def _gn(x, p, relu_first=False):
@@ -55,7 +57,7 @@ def residual_unit(ctx, p, x, stride, nmid):
   train = base.needs_grad(x, p['conv1']['kernel'])
   gn1 = None if train else _gn(x, p['gn1'])     # shared by conv_proj and conv1
   if x.shape[-1] != nout or stride != 1:
-    residual = _conv_gn(ctx, x, p['conv_proj']['kernel'], p['gn1'], gn1, stride=stride)
+    residual = _conv_gn(ctx, x, p['conv_proj']['kernel'], p['gn1'], gn1, emit=False, stride=stride)
   else:
     residual = x
   y = _conv_gn(ctx, x, p['conv1']['kernel'], p['gn1'], gn1)
@@ -119,7 +121,9 @@ class ResNetV2(base.Module):
     if self.config.skip_root_block:
       w = _std(ctx, params['conv_root']['kernel'])
       conv = ag.conv2d if base.needs_grad(w) else ops.conv2d
-      x = conv(image, w, padding=((1, 1), (1, 1)), prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0))
+      kw = {} if conv is ag.conv2d else {'emit_gn_stats': 'raw'}
+      x = conv(image, w, padding=((1, 1), (1, 1)), prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0),
+               **kw)
     else:
       w = _std(ctx, params['root_block']['conv_root']['kernel'])
       conv = ag.conv2d if base.needs_grad(w) else ops.conv2d

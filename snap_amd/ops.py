@@ -111,6 +111,10 @@ def _p(t):
   return ctypes.c_void_p(t.data_ptr())
 
 
+def _pv(t):
+  return None if t is None else t.data_ptr()
+
+
 def _chk(t, dtype, name):
   if not isinstance(t, torch.Tensor):
     raise TypeError(f'{name}: expected a torch.Tensor, got {type(t)}')
@@ -143,12 +147,16 @@ def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
+    emit_gn_stats=None,
 ):
   """NHWC implicit-GEMM conv on f32 MFMA.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
   gn = (mu [N,Cin], sc [N,Cin], beta [Cin]) for PRO_GN_RELU / PRO_RELU_GN.
   rows_in / rows_out (int32 [M]) + row_count (int32 [1], device): row-indexed launch
   over a compacted row list (see ``compact_rows``); ``out`` supplies the destination.
+  emit_gn_stats = 'raw' | 'relu': the epilogue also emits the partial sums from which
+  ``group_norm_stats(y, ...)`` (same ``relu_first``) builds its result without re-reading
+  y; they travel as ``y._snap_gn_partial``.  Ignored where the shape does not allow it.
   Returns y [N,Ho,Wo,Cout].
   """
   lib = _lib.load()
@@ -201,6 +209,16 @@ def conv2d(
       epi, float(in_affine[0]), float(in_affine[1]),
   )
   M = N * Ho * Wo
+  ex = None
+  partial = None
+  if rows_in is not None or rows_out is not None or row_count is not None:
+    ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0)
+  elif emit_gn_stats is not None:
+    pbytes = lib.snap_conv2d_gn_partial_bytes(ctypes.byref(d))
+    if pbytes:
+      partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
+      ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
+                               int(emit_gn_stats == 'relu'))
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -213,12 +231,14 @@ def conv2d(
       lambda: f'M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}_s{stride}'
               f'_p{prologue}_e{epi}',
   ):
-    st = lib.snap_conv2d_nhwc_rows_f32(
+    st = lib.snap_conv2d_nhwc_ex_f32(
         ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
-        _p(residual), _p(up_prev), _p(row_mask), _p(rows_in), _p(rows_out), _p(row_count),
+        _p(residual), _p(up_prev), _p(row_mask), None if ex is None else ctypes.byref(ex),
         _stream(),
     )
-  _lib.check(st, 'snap_conv2d_nhwc_rows_f32')
+  _lib.check(st, 'snap_conv2d_nhwc_ex_f32')
+  if partial is not None:
+    y._snap_gn_partial = (partial, lib.snap_conv2d_tile_rows(ctypes.byref(d)), emit_gn_stats == 'relu')
   return y
 
 
@@ -277,6 +297,9 @@ def weight_standardize(w, eps=1e-10):
   return out
 
 
+USE_FUSED_GN_STATS = True   # tests flip it to compare against the stand-alone kernel
+
+
 def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False, want_rstd=False):
   """x [N,H,W,C] -> (mu [N,C], sc [N,C]) with sc = rstd * gamma (+ rstd [N,C])."""
   lib = _lib.load()
@@ -288,6 +311,16 @@ def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False, want_rs
   mu = torch.empty((N, C), dtype=torch.float32, device=x.device)
   sc = torch.empty((N, C), dtype=torch.float32, device=x.device)
   rstd = torch.empty((N, C), dtype=torch.float32, device=x.device) if want_rstd else None
+  fused = getattr(x, '_snap_gn_partial', None)
+  if fused is not None and fused[2] == bool(relu_first) and groups == 32 and USE_FUSED_GN_STATS:
+    partial, tile_rows, _ = fused        # emitted by the conv that produced x
+    with _region('group_norm_stats', 0.0, 4.0 * partial.numel()):
+      st = lib.snap_group_norm_stats_from_partial_f32(
+          _p(partial), N, HW, C, groups, eps, tile_rows, _p(gamma), _p(mu), _p(sc), _p(rstd),
+          _stream(),
+      )
+    _lib.check(st, 'snap_group_norm_stats_from_partial_f32')
+    return (mu, sc, rstd) if want_rstd else (mu, sc)
   with _region('group_norm_stats', 0.0, 8.0 * x.numel()):
     st = lib.snap_group_norm_stats_f32(
         _p(x), N, HW, C, C, groups, eps, int(relu_first), _p(gamma), _p(mu),

@@ -504,3 +504,44 @@ def test_masked_row_mlp_is_bitwise_the_dense_mlp(layers_, in_dim, stride, monkey
     d = mlp(params, x, row_mask=m)
     monkeypatch.setattr(layers.MLP, 'COMPACT_MIN_ROWS', 0)
     assert torch.equal(d, mlp(params, x, row_mask=m))
+
+
+# ---------------------------------------------------------------------------
+# GroupNorm statistics emitted by the producing conv's epilogue
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,relu', [
+    (3, 17, 19, 64, 128, 1, False),     # HW = 323: row tiles straddle images
+    (2, 34, 34, 64, 64, 3, False),      # BN = 64 tiles
+    (5, 16, 16, 128, 256, 1, True),     # HW = 256 = 2 tiles exactly; FPN order
+    (1, 40, 40, 32, 512, 1, False),
+    (40, 12, 12, 64, 256, 1, False),    # HW = 144: >= tile (64x.. tiles) many images
+    (8, 64, 64, 64, 256, 1, False),     # 128x128 tiles
+    (20, 70, 70, 64, 64, 3, True),      # 128x64 tiles, HW = 4900 straddles
+])
+def test_gn_stats_from_conv_epilogue(N, H, W, Cin, Cout, k, relu):
+  g = torch.Generator().manual_seed(N * 1000 + Cout)
+  x = torch.randn(N, H, W, Cin, generator=g).cuda()
+  w = (torch.randn(k, k, Cin, Cout, generator=g) / np.sqrt(k * k * Cin)).cuda()
+  res = torch.randn(N, H, W, Cout, generator=g).cuda() + 0.7
+  gamma = (torch.rand(Cout, generator=g) + 0.5).cuda()
+  pad = ((k // 2, k // 2), (k // 2, k // 2))
+  y = ops.conv2d(x, w, padding=pad, residual=res, emit_gn_stats='relu' if relu else 'raw')
+  assert hasattr(y, '_snap_gn_partial'), 'shape should support fused statistics'
+  mu_f, sc_f, rs_f = ops.group_norm_stats(y, gamma, relu_first=relu, want_rstd=True)
+  ops.USE_FUSED_GN_STATS = False
+  try:
+    mu_s, sc_s, rs_s = ops.group_norm_stats(y, gamma, relu_first=relu, want_rstd=True)
+  finally:
+    ops.USE_FUSED_GN_STATS = True
+  helpers.report('mu', mu_f, mu_s, atol=2e-6, rtol=2e-6)
+  helpers.report('sc', sc_f, sc_s, atol=1e-6, rtol=5e-6)
+  helpers.report('rstd', rs_f, rs_s, atol=1e-6, rtol=5e-6)
+  # and against the oracle's two-pass definition in fp64
+  v = torch.relu(y) if relu else y
+  vg = v.double().reshape(N, H * W, 32, Cout // 32)
+  mean = vg.mean((1, 3))
+  var = ((vg - mean[:, None, :, None]) ** 2).mean((1, 3))
+  want_mu = mean[:, :, None].expand(N, 32, Cout // 32).reshape(N, Cout)
+  want_rs = (1 / torch.sqrt(var + 1e-5))[:, :, None].expand(N, 32, Cout // 32).reshape(N, Cout)
+  helpers.report('mu vs fp64', mu_f, want_mu.float(), atol=2e-6, rtol=2e-6)
+  helpers.report('rstd vs fp64', rs_f, want_rs.float(), atol=1e-6, rtol=5e-6)
