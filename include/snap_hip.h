@@ -130,6 +130,22 @@ int snap_fill_masked_rows_f32(float* y, const uint8_t* mask, int64_t M, int32_t 
 int snap_weight_standardize_f32(const float* w, float* out, int32_t K,
                                 int32_t Cout, float eps, void* stream);
 
+/* All StdConv kernels of an encoder in one launch (training standardises ~53 kernels per
+ * encoder every step; one launch per kernel is pure launch latency).  `items` is a DEVICE
+ * array; item i owns workgroups [block_begin, block_begin + ceil(Cout / 8)); items sorted
+ * by block_begin; total_blocks = sum.  Forward: out = standardise(w) (dws unused).
+ * Backward (snap_weight_standardize_bwd_multi_f32): out = d w given dws = d standardise(w). */
+typedef struct SnapWstdItem {
+  const float* w;
+  const float* dws;
+  float* out;
+  int32_t K, Cout, block_begin, reserved;
+} SnapWstdItem;
+int snap_weight_standardize_multi_f32(const SnapWstdItem* items, int32_t n_items,
+                                      int32_t total_blocks, float eps, void* stream);
+int snap_weight_standardize_bwd_multi_f32(const SnapWstdItem* items, int32_t n_items,
+                                          int32_t total_blocks, float eps, void* stream);
+
 /* GroupNorm statistics (resnet.py:46-60): two-pass mean / mean((x-mean)^2) over
  * (H,W,C/G) per (image, group).  relu_first != 0 computes them on relu(x)
  * (FPN order, image_encoder.py:80-83).  Outputs mu[N,C], sc[N,C] = rstd*gamma[c].

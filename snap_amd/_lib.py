@@ -71,6 +71,8 @@ SIGNATURES = {
     'snap_compact_rows_u8': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_size, ptr]),
     'snap_fill_masked_rows_f32': (c_int, [ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_weight_standardize_f32': (c_int, [ptr, ptr, c_int, c_int, c_float, ptr]),
+    'snap_weight_standardize_multi_f32': (c_int, [ptr, c_int, c_int, c_float, ptr]),
+    'snap_weight_standardize_bwd_multi_f32': (c_int, [ptr, c_int, c_int, c_float, ptr]),
     'snap_group_norm_stats_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int]),
     'snap_group_norm_stats_f32': (
         c_int,

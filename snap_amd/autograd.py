@@ -74,7 +74,7 @@ class _FusedConv(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, gamma, beta, bias, residual, up_prev, cfg):
-    stride, padding, prologue, in_affine, relu, row_mask, cin = cfg
+    stride, padding, prologue, in_affine, relu, row_mask, cin, emit = cfg
     gn = None
     mu = sc = rstd = None
     if prologue in _GN_MODES:
@@ -85,7 +85,7 @@ class _FusedConv(torch.autograd.Function):
     y = ops.conv2d(
         x, w, stride=stride, padding=padding, cin=cin, prologue=prologue, gn=gn,
         in_affine=in_affine, bias=bias, relu=relu, residual=residual, up_prev=up_prev,
-        row_mask=row_mask,
+        row_mask=row_mask, emit_gn_stats=emit,
     )
     ctx.cfg = cfg
     ctx.has = (bias is not None, residual is not None, up_prev is not None)
@@ -94,7 +94,7 @@ class _FusedConv(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, dy):
-    stride, padding, prologue, in_affine, relu, _, cin = ctx.cfg
+    stride, padding, prologue, in_affine, relu, _, cin, _ = ctx.cfg
     x, w, gamma, beta, mu, sc, rstd, y, row_mask = ctx.saved_tensors
     has_bias, has_res, has_up = ctx.has
     dy = dy.contiguous()
@@ -137,11 +137,11 @@ class _FusedConv(torch.autograd.Function):
 
 def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=ops.PRO_NONE,
            gn_params=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
-           up_prev=None, row_mask=None):
+           up_prev=None, row_mask=None, emit_gn_stats=None):
   """Differentiable ``ops.conv2d``.  ``gn_params = (gamma, beta)`` for GN prologues
   (statistics are computed inside, so the VJP covers them)."""
   gamma, beta = gn_params if gn_params is not None else (None, None)
-  cfg = (stride, padding, prologue, tuple(in_affine), relu, row_mask, cin)
+  cfg = (stride, padding, prologue, tuple(in_affine), relu, row_mask, cin, emit_gn_stats)
   return _FusedConv.apply(x, w, gamma, beta, bias, residual, up_prev, cfg)
 
 
@@ -173,6 +173,31 @@ class _WeightStd(torch.autograd.Function):
 
 def weight_standardize(w):
   return _WeightStd.apply(w)
+
+
+class _WeightStdMulti(torch.autograd.Function):
+  """All StdConv kernels of an encoder: one launch forward, one backward."""
+
+  @staticmethod
+  def forward(ctx, *ws):
+    ctx.save_for_backward(*ws)
+    return tuple(ops.weight_standardize_multi(list(ws)))
+
+  @staticmethod
+  def backward(ctx, *dwss):
+    ws = ctx.saved_tensors
+    live = [i for i, g in enumerate(dwss) if g is not None]
+    out = [None] * len(ws)
+    if live:
+      dws = ops.weight_standardize_bwd_multi([ws[i] for i in live],
+                                             [dwss[i].contiguous() for i in live])
+      for i, g in zip(live, dws):
+        out[i] = g
+    return tuple(out)
+
+
+def weight_standardize_multi(ws):
+  return _WeightStdMulti.apply(*ws)
 
 
 class _MaxPool(torch.autograd.Function):

@@ -169,16 +169,16 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 // ---------------------------------------------------------------------------
 // StdConv backward: ws = (w - mean)/sigma per column;  dw = (dws - mean(dws) - ws*mean(dws*ws))/sigma
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __restrict__ w,
-                                                             const float* __restrict__ dws,
-                                                             float* __restrict__ dw, int K,
-                                                             int Cout, float eps) {
+__device__ __forceinline__ void weight_std_bwd_body(const float* __restrict__ w,
+                                                    const float* __restrict__ dws,
+                                                    float* __restrict__ dw, int K, int Cout,
+                                                    float eps, int blk) {
   // same geometry as the forward kernel (encoder_ops.hip): 8 columns x 32 k-slices.
   constexpr int COLS = 8, SLICES = 256 / COLS;
   __shared__ float red[SLICES][COLS + 1];
   __shared__ float stat[4][COLS];
   const int tc = threadIdx.x % COLS, tk = threadIdx.x / COLS;
-  const int col = blockIdx.x * COLS + tc;
+  const int col = blk * COLS + tc;
   const bool ok = col < Cout;
   auto reduce = [&](float v, int slot, float scale) {
     red[tk][tc] = v;
@@ -223,6 +223,24 @@ __global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __rest
       const float ws = (w[o] - mean) / sigma;
       dw[o] = (dws[o] - mg - ws * mgw) / sigma;
     }
+}
+
+__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __restrict__ w,
+                                                             const float* __restrict__ dws,
+                                                             float* __restrict__ dw, int K,
+                                                             int Cout, float eps) {
+  weight_std_bwd_body(w, dws, dw, K, Cout, eps, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void weight_std_bwd_multi_kernel(
+    const SnapWstdItem* __restrict__ items, int n_items, float eps) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SnapWstdItem it = items[lo];
+  weight_std_bwd_body(it.w, it.dws, it.out, it.K, it.Cout, eps, blockIdx.x - it.block_begin);
 }
 
 // ---------------------------------------------------------------------------
@@ -427,6 +445,17 @@ extern "C" int snap_weight_standardize_bwd_f32(const float* w, const float* dws,
   if (K <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((unsigned)snap_cdiv(Cout, 8)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, dws, dw, K, Cout, eps);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_weight_standardize_bwd_multi_f32(const SnapWstdItem* items, int32_t n_items,
+                                                     int32_t total_blocks, float eps,
+                                                     void* stream) {
+  if (!items) return SNAP_ERR_NULL;
+  if (n_items <= 0 || total_blocks <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(weight_std_bwd_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, n_items, eps);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -19,13 +19,13 @@ namespace {
 constexpr int WS_COLS = 8;
 constexpr int WS_SLICES = 256 / WS_COLS;
 
-__global__ __launch_bounds__(256) void weight_std_kernel(const float* __restrict__ w,
-                                                         float* __restrict__ out, int K,
-                                                         int Cout, float eps) {
+__device__ __forceinline__ void weight_std_body(const float* __restrict__ w,
+                                                float* __restrict__ out, int K, int Cout,
+                                                float eps, int blk) {
   __shared__ float red[WS_SLICES][WS_COLS + 1];
   __shared__ float stat[2][WS_COLS];
   const int tc = threadIdx.x % WS_COLS, tk = threadIdx.x / WS_COLS;
-  const int col = blockIdx.x * WS_COLS + tc;
+  const int col = blk * WS_COLS + tc;
   const bool ok = col < Cout;
   float s = 0.f;
   if (ok)
@@ -61,6 +61,25 @@ __global__ __launch_bounds__(256) void weight_std_kernel(const float* __restrict
       const int64_t o = (int64_t)k * Cout + col;
       out[o] = (w[o] - mean) / denom;
     }
+}
+
+__global__ __launch_bounds__(256) void weight_std_kernel(const float* __restrict__ w,
+                                                         float* __restrict__ out, int K,
+                                                         int Cout, float eps) {
+  weight_std_body(w, out, K, Cout, eps, blockIdx.x);
+}
+
+// every StdConv kernel of an encoder in ONE launch: workgroup -> (item, column group) by
+// binary search over the items' first-workgroup table.
+__global__ __launch_bounds__(256) void weight_std_multi_kernel(const SnapWstdItem* __restrict__ items,
+                                                               int n_items, float eps) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SnapWstdItem it = items[lo];
+  weight_std_body(it.w, it.out, it.K, it.Cout, eps, blockIdx.x - it.block_begin);
 }
 
 // ---------------------------------------------------------------------------
@@ -262,6 +281,17 @@ extern "C" int snap_weight_standardize_f32(const float* w, float* out, int32_t K
   if (K <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(weight_std_kernel, dim3((unsigned)snap_cdiv(Cout, WS_COLS)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, out, K, Cout, eps);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_weight_standardize_multi_f32(const SnapWstdItem* items, int32_t n_items,
+                                                 int32_t total_blocks, float eps,
+                                                 void* stream) {
+  if (!items) return SNAP_ERR_NULL;
+  if (n_items <= 0 || total_blocks <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(weight_std_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, n_items, eps);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

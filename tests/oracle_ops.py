@@ -64,7 +64,8 @@ def _prologue(x, prologue, gn, in_affine, cin):
 
 def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
            gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
-           up_prev=None, row_mask=None):
+           up_prev=None, row_mask=None, emit_gn_stats=None):
+  # emit_gn_stats: a speed hint of the HIP path (statistics out of the epilogue); no-op here.
   xn, wn = _np(x, DTYPE), _np(w, DTYPE)
   cin = wn.shape[2] if cin is None else cin
   xn = _prologue(xn, prologue, gn, in_affine, cin)
