@@ -88,7 +88,8 @@ int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x, const float* 
  *    (of relu(y) if gn_partial_relu), from which snap_group_norm_stats_from_partial_f32
  *    produces the GroupNorm statistics the NEXT layer's fused prologue needs
  *    (resnet.py:46-60) without re-reading y.  Size: snap_conv2d_gn_partial_bytes(desc);
- *    0 means "not available for this shape" (Ho*Wo smaller than a row tile).  */
+ *    0 means "not available for this shape" (Ho*Wo smaller than a row tile); a launch that
+ *    emits statistics never splits K.  */
 typedef struct SnapConvExtras {
   const int32_t* rows_in;
   const int32_t* rows_out;
@@ -96,6 +97,8 @@ typedef struct SnapConvExtras {
   float* gn_partial;
   size_t gn_partial_bytes;
   int32_t gn_partial_relu;
+  void* workspace;            /* split-K scratch: snap_conv2d_workspace_bytes(desc) (may be 0) */
+  size_t workspace_bytes;
 } SnapConvExtras;
 
 int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,
@@ -104,6 +107,11 @@ int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const floa
                             const float* residual, const float* up_prev,
                             const uint8_t* row_mask, const SnapConvExtras* extras,
                             void* stream);
+/* Scratch for split-K launches (small-M / deep-K layers that cannot fill 256 CUs with output
+ * tiles: slices of K go to extra workgroups, partial tiles are summed in fixed order by a
+ * second kernel that also applies the epilogue -- deterministic).  0 = the shape does not
+ * split.  Without a workspace the launch simply does not split. */
+size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc);
 size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc);
 int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc);   /* row-tile height the launch uses */
 

@@ -34,6 +34,7 @@ class SnapConvExtras(ctypes.Structure):
   _fields_ = [
       ('rows_in', ptr), ('rows_out', ptr), ('row_count', ptr), ('gn_partial', ptr),
       ('gn_partial_bytes', c_size), ('gn_partial_relu', c_int),
+      ('workspace', ptr), ('workspace_bytes', c_size),
   ]
 
 
@@ -63,6 +64,7 @@ SIGNATURES = {
          ptr, ptr, ctypes.POINTER(SnapConvExtras), ptr],
     ),
     'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_conv2d_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
     'snap_group_norm_stats_from_partial_f32': (
         c_int, [ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr, ptr]

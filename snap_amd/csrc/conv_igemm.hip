@@ -44,6 +44,11 @@ struct ConvArgs {
   const int32_t* rows_in;    // optional: GEMM row m reads output pixel rows_in[m]
   const int32_t* rows_out;   // optional: GEMM row m is written to y row rows_out[m]
   const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
+  float* kpartial;           // split-K: [ksplit][M][Cout] raw partial tiles (workspace)
+  size_t kpartial_bytes;
+  int ksplit;                // number of K splits (1 = none)
+  int slabs_per_split;
+  int tiles_per_split;       // workgroups of one split (multiple of 8)
   float* gn_partial;         // optional: per-(image, row tile, channel) sums of y and y^2
   int gn_relu;               // ... of relu(y) (FPN order)
   int gn_slabs;              // row tiles per image in gn_partial (= HoWo / BM + 2)
@@ -101,9 +106,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   // with a private L2): row-tile r lives on XCD r % 8 and ALL its column tiles run
   // back to back on that XCD, so the A rows (and 3x3 halos of the next row tile of
   // the same XCD) are re-read from its L2 instead of HBM.  A pure speed mapping.
+  // split-K (small-M, deep-K layers that cannot fill 256 CUs with output tiles): the
+  // outermost grid dimension walks slices of the K slabs; partial tiles go to a workspace
+  // and a second kernel sums them in fixed order and applies the epilogue.
   const int ncol = a.ncol;
-  const int xcd = blockIdx.x & 7;
-  const int seq = blockIdx.x >> 3;
+  const int split = a.ksplit > 1 ? blockIdx.x / a.tiles_per_split : 0;
+  const int bid = a.ksplit > 1 ? blockIdx.x - split * a.tiles_per_split : blockIdx.x;
+  const int xcd = bid & 7;
+  const int seq = bid >> 3;
   const int col_t = seq % ncol;
   const int row_t = (seq / ncol) * 8 + xcd;
   // Row-indexed mode (compacted voxel lists): the launch covers the worst case M and the
@@ -162,8 +172,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   bool xbok[BPASS];
   int cur_c = 0;  // channel of element 0 of this thread's quad (VEC)
 
+  const int kt_begin = a.ksplit > 1 ? split * a.slabs_per_split : 0;
+  const int kt_end = a.ksplit > 1 ? min(a.nk, kt_begin + a.slabs_per_split) : a.nk;
   // K-slab walk state (VEC): (kpos = kh*KW+kw, ct)
   int kpos = 0, ct = 0, kh = 0, kw = 0;
+  if (VEC && kt_begin > 0) {
+    kpos = kt_begin / a.ctiles;
+    ct = kt_begin - kpos * a.ctiles;
+    kh = kpos / d.KW;
+    kw = kpos - kh * d.KW;
+  }
 
   auto load_slab = [&](int kt) {
     if constexpr (VEC) {
@@ -290,15 +308,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   };
 
   // ---- main loop ---------------------------------------------------------
-  load_slab(0);
+  load_slab(kt_begin);
   advance();
   store_slab(0);
   __syncthreads();
 
   const int l31 = lane & 31, lhi = lane >> 5;
-  for (int kt = 0; kt < a.nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < a.nk;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
     if (more && !(a.ablate & 1)) {
       load_slab(kt + 1);
       advance();
@@ -383,6 +401,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       const int col = n0 + 4 * q;
       if (m >= Meff || col >= d.Cout) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * BN + 4 * q);
+      if (a.ksplit > 1) {  // raw partial tile; the epilogue runs in splitk_reduce_kernel
+        *reinterpret_cast<f32x4*>(a.kpartial + ((int64_t)split * a.M + m) * d.Cout + col) = v;
+        continue;
+      }
       const int64_t o = (int64_t)(a.rows_out ? a.rows_out[m] : m) * d.Cout_stride + col;
       if (epi & SNAP_EPI_BIAS) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + col);
@@ -475,6 +497,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+    const float* __restrict__ partial, int S, int64_t M, int Cout, int Cout_stride, int epi,
+    const float* __restrict__ bias, const float* __restrict__ residual,
+    const uint8_t* __restrict__ row_mask, float* __restrict__ y) {
+  const int Q = Cout >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * Q) return;
+  const int64_t m = i / Q;
+  const int col = 4 * (int)(i - m * Q);
+  f32x4 v = *reinterpret_cast<const f32x4*>(partial + m * Cout + col);
+  for (int s = 1; s < S; ++s) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * M + m) * Cout + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += t[e];
+  }
+  const int64_t o = m * Cout_stride + col;
+  if (epi & SNAP_EPI_BIAS) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bb[e];
+  }
+  if (epi & SNAP_EPI_RESIDUAL) {
+    const f32x4 rr = *reinterpret_cast<const f32x4*>(residual + o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+  }
+  if (epi & SNAP_EPI_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if ((epi & SNAP_EPI_ROWMASK) && row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+  *reinterpret_cast<f32x4*>(y + o) = v;
+}
+
+// split-K heuristic: launches with at most splitk_max_tiles() output tiles (1.5 per CU)
+// are split into about splitk_target() workgroups.  Measured in one box (C2 inference /
+// C3 train step): off 59.75 / 162.5 ms; tiles<=128 59.96 / 159.9; tiles<=384, target 768
+// 59.34 / 157.8; tiles<=256, target 1024 59.55 / 158.4.
+// SNAP_CONV_SPLITK=<target> (0 disables), SNAP_CONV_SPLITK_TILES=<max tiles>.
+inline int64_t splitk_max_tiles() {
+  static const int t = []() {
+    const char* e = getenv("SNAP_CONV_SPLITK_TILES");
+    return e ? atoi(e) : 384;
+  }();
+  return t;
+}
+inline int splitk_target() {
+  static const int t = []() {
+    const char* e = getenv("SNAP_CONV_SPLITK");
+    return e ? atoi(e) : 768;
+  }();
+  return t;
+}
+
 template <int BM, int BN, bool VEC, int PRO, int BK>
 int launch(ConvArgs a, hipStream_t s) {
   if (VEC) {
@@ -487,11 +563,37 @@ int launch(ConvArgs a, hipStream_t s) {
   const int64_t nrow = snap_cdiv(a.M, BM);
   a.ncol = (int)snap_cdiv(a.d.Cout, BN);
   a.gn_slabs = (a.d.Ho * a.d.Wo) / BM + 2;
-  const int64_t nblocks = snap_cdiv(nrow, 8) * 8 * a.ncol;
+  int64_t nblocks = snap_cdiv(nrow, 8) * 8 * a.ncol;
   if (nblocks > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  // split-K decision (needs a caller-provided workspace; plain epilogues only)
+  a.ksplit = 1;
+  a.tiles_per_split = (int)nblocks;
+  a.slabs_per_split = a.nk;
+  const int64_t tiles = nrow * a.ncol;
+  const int target = splitk_target();
+  if (a.kpartial && target > 0 && tiles <= splitk_max_tiles() && a.nk >= 16 && !a.rows_in &&
+      !a.rows_out && !a.row_count && !a.gn_partial &&
+      !(a.d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) {
+    int64_t S = (target + tiles - 1) / tiles;
+    S = S < a.nk / 8 ? S : a.nk / 8;                       // >= 8 slabs per split
+    const int64_t fit = (int64_t)(a.kpartial_bytes / ((size_t)a.M * a.d.Cout * sizeof(float)));
+    S = S < fit ? S : fit;
+    if (S >= 2) {
+      a.slabs_per_split = (int)((a.nk + S - 1) / S);
+      a.ksplit = (a.nk + a.slabs_per_split - 1) / a.slabs_per_split;
+      nblocks *= a.ksplit;
+    }
+  }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO, BK>), dim3((unsigned)nblocks), dim3(256),
                      0, s, a);
   SNAP_CHECK_LAUNCH();
+  if (a.ksplit > 1) {
+    const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
+                       (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.Cout_stride,
+                       a.d.epilogue, a.bias, a.residual, a.row_mask, a.y);
+    SNAP_CHECK_LAUNCH();
+  }
   return SNAP_OK;
 }
 
@@ -585,6 +687,21 @@ extern "C" size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc) {
   return (size_t)d.N * (HoWo / t.bm + 2) * d.Cout * 2 * sizeof(float);
 }
 
+extern "C" size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc) {
+  if (!desc) return 0;
+  const SnapConvDesc& d = *desc;
+  const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+  const TileChoice t = choose_tile(M, d.Cout);
+  const int64_t tiles = snap_cdiv(M, t.bm) * snap_cdiv((int64_t)d.Cout, t.bn);
+  const int target = splitk_target();
+  const int64_t nk = (int64_t)d.KH * d.KW * ((d.Cin + 15) / 16);
+  if (target <= 0 || tiles > splitk_max_tiles() || nk < 16 || (d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) return 0;
+  int64_t S = (target + tiles - 1) / tiles;
+  S = S < nk / 8 ? S : nk / 8;
+  if (S < 2) return 0;
+  return (size_t)S * M * d.Cout * sizeof(float);
+}
+
 extern "C" int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc) {
   if (!desc) return 0;
   return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout).bm;
@@ -640,6 +757,10 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.rows_in = rows_in; a.rows_out = rows_out; a.row_count = row_count;
   a.gn_partial = gn_partial;
   a.gn_relu = ex ? ex->gn_partial_relu : 0;
+  a.kpartial = ex ? static_cast<float*>(ex->workspace) : nullptr;
+  a.kpartial_bytes = ex ? ex->workspace_bytes : 0;
+  if (reinterpret_cast<uintptr_t>(a.kpartial) & 15) a.kpartial = nullptr;
+  a.ksplit = 1; a.slabs_per_split = 0; a.tiles_per_split = 0;
   a.gn_slabs = 0;
   a.M = d.N * d.Ho * d.Wo;
   a.K = d.KH * d.KW * d.Cin;

@@ -211,14 +211,20 @@ def conv2d(
   M = N * Ho * Wo
   ex = None
   partial = None
+  kws = None
   if rows_in is not None or rows_out is not None or row_count is not None:
-    ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0)
-  elif emit_gn_stats is not None:
-    pbytes = lib.snap_conv2d_gn_partial_bytes(ctypes.byref(d))
-    if pbytes:
-      partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
-      ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
-                               int(emit_gn_stats == 'relu'))
+    ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0)
+  else:
+    wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if USE_SPLITK else 0
+    if wbytes:   # small-M / deep-K layer: split K (its statistics are cheap to take after)
+      kws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
+      ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes)
+    elif emit_gn_stats is not None:
+      pbytes = lib.snap_conv2d_gn_partial_bytes(ctypes.byref(d))
+      if pbytes:
+        partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
+        ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
+                                 int(emit_gn_stats == 'relu'), None, 0)
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -335,7 +341,8 @@ def weight_standardize_bwd_multi(ws, dwss, eps=1e-10):
   return outs
 
 
-USE_FUSED_GN_STATS = True   # tests flip it to compare against the stand-alone kernel
+USE_FUSED_GN_STATS = True
+USE_SPLITK = True           # tests flip it: split-K vs single-pass launches   # tests flip it to compare against the stand-alone kernel
 
 
 def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False, want_rstd=False):

@@ -525,7 +525,11 @@ def test_gn_stats_from_conv_epilogue(N, H, W, Cin, Cout, k, relu):
   res = torch.randn(N, H, W, Cout, generator=g).cuda() + 0.7
   gamma = (torch.rand(Cout, generator=g) + 0.5).cuda()
   pad = ((k // 2, k // 2), (k // 2, k // 2))
-  y = ops.conv2d(x, w, padding=pad, residual=res, emit_gn_stats='relu' if relu else 'raw')
+  ops.USE_SPLITK = False      # small test shapes would otherwise take the split-K route
+  try:
+    y = ops.conv2d(x, w, padding=pad, residual=res, emit_gn_stats='relu' if relu else 'raw')
+  finally:
+    ops.USE_SPLITK = True
   assert hasattr(y, '_snap_gn_partial'), 'shape should support fused statistics'
   mu_f, sc_f, rs_f = ops.group_norm_stats(y, gamma, relu_first=relu, want_rstd=True)
   ops.USE_FUSED_GN_STATS = False
@@ -545,3 +549,42 @@ def test_gn_stats_from_conv_epilogue(N, H, W, Cin, Cout, k, relu):
   want_rs = (1 / torch.sqrt(var + 1e-5))[:, :, None].expand(N, 32, Cout // 32).reshape(N, Cout)
   helpers.report('mu vs fp64', mu_f, want_mu.float(), atol=2e-6, rtol=2e-6)
   helpers.report('rstd vs fp64', rs_f, want_rs.float(), atol=1e-6, rtol=5e-6)
+
+
+# ---------------------------------------------------------------------------
+# split-K launches of the conv engine (small-M / deep-K layers)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,stride,kind', [
+    (1, 17, 17, 512, 512, 3, 1, 'gn_res'),     # the deep ResNet stage shape
+    (2, 9, 9, 2048, 512, 1, 1, 'plain'),
+    (1, 1, 4652, 16384, 32, 1, 1, 'plain'),    # similarity backward (d fq)
+    (2, 20, 20, 256, 64, 3, 2, 'bias_relu'),
+    (1, 12, 12, 67, 128, 3, 1, 'plain'),       # scalar (Cin % 4 != 0) loader
+    (3, 8, 8, 1024, 256, 1, 1, 'mask'),
+])
+def test_conv_split_k_matches_single_pass(N, H, W, Cin, Cout, k, stride, kind):
+  g = torch.Generator().manual_seed(Cin + Cout)
+  x = torch.randn(N, H, W, Cin, generator=g).cuda()
+  w = (torch.randn(k, k, Cin, Cout, generator=g) / np.sqrt(k * k * Cin)).cuda()
+  pad = ((k // 2, k // 2), (k // 2, k // 2))
+  Ho = (H + 2 * (k // 2) - k) // stride + 1
+  Wo = (W + 2 * (k // 2) - k) // stride + 1
+  kw = dict(stride=stride, padding=pad)
+  if kind == 'gn_res':
+    gamma = (torch.rand(Cin, generator=g) + 0.5).cuda()
+    beta = torch.randn(Cin, generator=g).cuda()
+    mu, sc = ops.group_norm_stats(x, gamma)
+    kw.update(prologue=ops.PRO_GN_RELU, gn=(mu, sc, beta),
+              residual=torch.randn(N, Ho, Wo, Cout, generator=g).cuda())
+  elif kind == 'bias_relu':
+    kw.update(bias=torch.randn(Cout, generator=g).cuda(), relu=True)
+  elif kind == 'mask':
+    kw.update(row_mask=(torch.rand(N * Ho * Wo, generator=g) < 0.5).cuda())
+  lib = ops._lib.load()
+  split = ops.conv2d(x, w, **kw)
+  ops.USE_SPLITK = False
+  try:
+    single = ops.conv2d(x, w, **kw)
+  finally:
+    ops.USE_SPLITK = True
+  helpers.report('split-K vs single pass', split, single, atol=3e-5, rtol=1e-5)
