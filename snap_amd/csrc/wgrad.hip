@@ -217,18 +217,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     if (more) load_slab(sl + 1);
     const float* zs = Zs0 + cur * (RS * BKT);
     const float* ds = Ds0 + cur * (RS * BN);
+    // LDS -> register operand fetch runs one k-pair ahead of the MFMAs (as in conv_igemm.hip).
+    float av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i] = zs[lhi * BKT + wr * (BKT / 2) + i * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j] = ds[lhi * BN + wc * (BN / 2) + j * 32 + l31];
 #pragma unroll
     for (int kk = 0; kk < RS / 2; ++kk) {
-      float av[TM], bv[TN];
+      const int cu = kk & 1, nx = cu ^ 1;
+      if (kk + 1 < RS / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = zs[(2 * kk + lhi) * BKT + wr * (BKT / 2) + i * 32 + l31];
+        for (int i = 0; i < TM; ++i)
+          av[nx][i] = zs[(2 * (kk + 1) + lhi) * BKT + wr * (BKT / 2) + i * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = ds[(2 * kk + lhi) * BN + wc * (BN / 2) + j * 32 + l31];
+        for (int j = 0; j < TN; ++j)
+          bv[nx][j] = ds[(2 * (kk + 1) + lhi) * BN + wc * (BN / 2) + j * 32 + l31];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cu][i], bv[cu][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+    for (int kk = 0; kk < RS / 2; ++kk) {
+      if (kk + 1 < RS / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     if (more) store_slab(cur ^ 1);
     __syncthreads();
