@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 rm -rf gpurun_out/pmc
 R=$PWD
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $1 --output-format csv -d "$R/gpurun_out/pmc" -o pmc -- \
-  python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline) > gpurun_out/pmc.log 2>&1
+  python "$R/bench.py" ${BENCH_ARGS:---steps 1 --warmup 1 --no-cpu-baseline}) > gpurun_out/pmc.log 2>&1
 tail -3 gpurun_out/pmc.log
 ls gpurun_out/pmc
 python - <<'PY'

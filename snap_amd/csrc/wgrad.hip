@@ -113,6 +113,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     zbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (zc < d.Cin ? zc : 0));
   }
 
+  // (image, ho, wo) of each Z row this thread stages, advanced by RS rows per slab: the
+  // reduction walks M, so a per-slab m -> (n, ho, wo) decode would cost two integer
+  // divisions per row per slab (more VALU time than the loads themselves).
+  constexpr int NZ = VEC ? ZPASS : ZELEMS;
+  int rn[NZ], rho[NZ], rwo[NZ];
+#pragma unroll
+  for (int p = 0; p < NZ; ++p) {
+    const int64_t m = m_begin + (VEC ? zrow0 + p * ZRPP : (tid + 256 * p) / BKT);
+    const int mm = (int)min(m, (int64_t)a.M - 1);
+    rn[p] = mm / HoWo;
+    const int r = mm - rn[p] * HoWo;
+    rho[p] = r / d.Wo;
+    rwo[p] = r - rho[p] * d.Wo;
+  }
+  auto advance_rows = [&]() {
+#pragma unroll
+    for (int p = 0; p < NZ; ++p) {
+      rwo[p] += RS;
+      while (rwo[p] >= d.Wo) { rwo[p] -= d.Wo; ++rho[p]; }
+      while (rho[p] >= d.Ho) { rho[p] -= d.Ho; ++rn[p]; }
+    }
+  };
+
   auto load_slab = [&](int sl) {
     const int64_t ms = m_begin + (int64_t)sl * RS;
     if constexpr (VEC) {
@@ -120,10 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       for (int p = 0; p < ZPASS; ++p) {
         const int64_t m = ms + zrow0 + p * ZRPP;
         const bool mok = m < m_end;
-        const int mm = mok ? (int)m : 0;
-        const int n = mm / HoWo;
-        const int r = mm - n * HoWo;
-        const int ho = r / d.Wo, wo = r - ho * d.Wo;
+        const int n = rn[p], ho = rho[p], wo = rwo[p];   // walked incrementally (no divisions)
         const int hi = ho * d.stride - d.pad_t + kh, wi = wo * d.stride - d.pad_l + kw;
         const bool inb = mok && zc < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
         zin[p] = inb;
@@ -142,10 +162,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int rr = idx / BKT;
         const int64_t m = ms + rr;
         const bool mok = m < m_end;
-        const int mm = mok ? (int)m : 0;
-        const int n = mm / HoWo;
-        const int r = mm - n * HoWo;
-        const int ho = r / d.Wo, wo = r - ho * d.Wo;
+        const int n = rn[e], ho = rho[e], wo = rwo[e];
         const int hi = ho * d.stride - d.pad_t + ekh[e], wi = wo * d.stride - d.pad_l + ekw[e];
         const int c = ec[e];
         const bool inb = mok && ekok[e] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
@@ -208,13 +225,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
   if (nslab > 0) {
     load_slab(0);
+    advance_rows();
     store_slab(0);
   }
   __syncthreads();
   for (int sl = 0; sl < nslab; ++sl) {
     const int cur = sl & 1;
     const bool more = sl + 1 < nslab;
-    if (more) load_slab(sl + 1);
+    if (more) {
+      load_slab(sl + 1);
+      advance_rows();
+    }
     const float* zs = Zs0 + cur * (RS * BKT);
     const float* ds = Ds0 + cur * (RS * BN);
     // LDS -> register operand fetch runs one k-pair ahead of the MFMAs (as in conv_igemm.hip).
