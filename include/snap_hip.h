@@ -331,6 +331,15 @@ int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, const float*
                           const float* gn_beta, int32_t accumulate, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Row-list variant for the masked fusion MLP (flat [1,1,M,C] Dense layout only): reduction
+ * row m reads x row rows_z[m] and dy row rows_dy[m]; only the first *row_count (device
+ * scalar) rows exist.  Any of the three may be NULL. */
+int snap_conv2d_wgrad_rows_f32(const SnapConvDesc* desc, const float* x, const float* dy,
+                               float* dw, const float* gn_mu, const float* gn_sc,
+                               const float* gn_beta, int32_t accumulate, void* workspace,
+                               size_t workspace_bytes, const int32_t* rows_z,
+                               const int32_t* rows_dy, const int32_t* row_count, void* stream);
+
 /* GroupNorm(+ReLU) backward.  dz: grad w.r.t. the prologue output; add: optional extra
  * gradient summed into dx (identity-residual branch).  mode: SNAP_PRO_GN_RELU /
  * SNAP_PRO_RELU_GN.  dgamma/dbeta [C] (+)=. */
@@ -356,6 +365,10 @@ int snap_epilogue_bwd_f32(const float* dy, const float* y, const uint8_t* row_ma
 size_t snap_colsum_workspace_bytes(int64_t M, int32_t C);
 int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* ... over the listed rows only: sum_{m < *row_count} a[rows[m], :]  (rows / row_count may be NULL). */
+int snap_colsum_rows_f32(const float* a, int64_t M, int32_t C, const int32_t* rows,
+                         const int32_t* row_count, float* out, int32_t accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* d f_images[B,V,h,w,C] = VJP of snap_lift_pool_f32 w.r.t. f_images (zeroed inside). */
 int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_images, const float* cam,

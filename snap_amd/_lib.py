@@ -135,6 +135,12 @@ SIGNATURES = {
         c_int,
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr],
     ),
+    'snap_conv2d_wgrad_rows_f32': (
+        c_int,
+        [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr, ptr,
+         ptr, ptr],
+    ),
+    'snap_colsum_rows_f32': (c_int, [ptr, c_i64, c_int, ptr, ptr, ptr, c_int, ptr, c_size, ptr]),
     'snap_group_norm_bwd_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int]),
     'snap_group_norm_bwd_f32': (
         c_int,

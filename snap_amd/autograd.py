@@ -158,6 +158,88 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=ops.PRO_NONE, relu=False, 
   return y.reshape(*lead, kernel.shape[1])
 
 
+class _MaskedRowsMLP(torch.autograd.Function):
+  """ReLU MLP over the rows with mask != 0 only; masked rows of the output are zero.
+
+  Same function as the dense MLP with ``row_mask`` on its last layer (the reference,
+  streetview_encoder.py:281-283) -- the masked rows carry no gradient to the parameters
+  or the input -- but every GEMM (forward, data gradient, kernel gradient) walks the
+  device-side row list, so unobserved voxels cost nothing.
+  """
+
+  @staticmethod
+  def forward(ctx, x, mask, relu_input, *wb):
+    n = len(wb) // 2
+    M = mask.numel()
+    index, count = ops.compact_rows(mask)
+    pro0 = ops.PRO_RELU if relu_input else ops.PRO_NONE
+    acts = []
+    h = x.reshape(M, x.shape[-1])
+    for i in range(n):
+      W, b = wb[2 * i], wb[2 * i + 1]
+      last = i + 1 == n
+      h = ops.dense(h, W, b, cin=W.shape[0], prologue=pro0 if i == 0 else ops.PRO_NONE,
+                    relu=not last, rows_in=index if i == 0 else None,
+                    rows_out=index if last else None, row_count=count)
+      if not last:
+        acts.append(h)
+    ops.fill_masked_rows_(h, mask)
+    ctx.relu_input = relu_input
+    ctx.n = n
+    ctx.xshape = x.shape
+    ctx.save_for_backward(x, mask, index, count, *acts, *[wb[2 * i] for i in range(n)])
+    return h.reshape(*x.shape[:-1], h.shape[-1])
+
+  @staticmethod
+  def backward(ctx, dy):
+    n = ctx.n
+    saved = ctx.saved_tensors
+    x, mask, index, count = saved[:4]
+    acts = saved[4:4 + n - 1]
+    Ws = saved[4 + n - 1:]
+    M = mask.numel()
+    Cs = x.shape[-1]
+    x2 = x.reshape(M, Cs)
+    g = dy.contiguous().reshape(M, dy.shape[-1])
+    grads = [None] * (2 * n)
+    dx = None
+    for i in reversed(range(n)):
+      last = i + 1 == n
+      W = Ws[i]
+      cin, cout = W.shape
+      if not last:                      # ReLU gate of this layer's output (compact rows)
+        g = ops_bwd.epilogue_bwd(g, acts[i], None, relu=True)
+      rows_dy = index if last else None
+      inp = x2 if i == 0 else acts[i - 1]
+      pro = ops.PRO_RELU if (i == 0 and ctx.relu_input) else ops.PRO_NONE
+      if ctx.needs_input_grad[3 + 2 * i]:
+        grads[2 * i] = ops_bwd.conv2d_wgrad(
+            inp.reshape(1, 1, M, inp.shape[-1]), g.reshape(1, 1, M, cout), (1, 1, cin, cout),
+            prologue=pro, rows_z=index if i == 0 else None, rows_dy=rows_dy, row_count=count,
+        ).reshape(cin, cout)
+      if ctx.needs_input_grad[4 + 2 * i]:
+        grads[2 * i + 1] = ops_bwd.colsum(g, rows=rows_dy, row_count=count)
+      if i > 0 or ctx.needs_input_grad[0]:
+        width = Cs if i == 0 else cin               # d input row width (x keeps its padded stride)
+        Wt = W.t()
+        if width != cin:
+          Wt = F.pad(Wt, (0, width - cin))
+        Wt = Wt.contiguous()
+        gi = ops.dense(g, Wt, None, cin=cout, rows_in=rows_dy,
+                       rows_out=index if i == 0 else None, row_count=count)
+        if i == 0:
+          ops.fill_masked_rows_(gi, mask)
+          if ctx.relu_input:
+            gi = ops_bwd.epilogue_bwd(gi, x2, None, relu=True)
+          dx = gi.reshape(ctx.xshape)
+        g = gi
+    return (dx, None, None, *grads)
+
+
+def masked_rows_mlp(x, mask, relu_input, weights_and_biases):
+  return _MaskedRowsMLP.apply(x, mask, relu_input, *weights_and_biases)
+
+
 class _WeightStd(torch.autograd.Function):
 
   @staticmethod

@@ -343,13 +343,20 @@ __global__ void epilogue_bwd_kernel(const float* __restrict__ dy, const float* _
 // column sums: partial[s][c] over row slabs, then fixed-order reduce.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int64_t M,
                                                              int C, int64_t rows_per_block,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial,
+                                                             const int32_t* __restrict__ rows,
+                                                             const int32_t* __restrict__ row_count) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
+  const int64_t Meff = row_count ? min((int64_t)*row_count, M) : M;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = min(M, r0 + rows_per_block);
+  const int64_t r1 = min(Meff, r0 + rows_per_block);
   float t = 0.f;
-  for (int64_t r = r0; r < r1; ++r) t += a[r * C + c];
+  if (rows) {
+    for (int64_t r = r0; r < r1; ++r) t += a[(int64_t)rows[r] * C + c];
+  } else {
+    for (int64_t r = r0; r < r1; ++r) t += a[r * C + c];
+  }
   partial[(int64_t)blockIdx.x * C + c] = t;
 }
 __global__ void colsum_reduce_kernel(const float* __restrict__ partial, int S, int C,
@@ -501,6 +508,13 @@ extern "C" size_t snap_colsum_workspace_bytes(int64_t M, int32_t C) {
 
 extern "C" int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
                                void* workspace, size_t workspace_bytes, void* stream) {
+  return snap_colsum_rows_f32(a, M, C, nullptr, nullptr, out, accumulate, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int snap_colsum_rows_f32(const float* a, int64_t M, int32_t C, const int32_t* rows,
+                                    const int32_t* row_count, float* out, int32_t accumulate,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!a || !out || !workspace) return SNAP_ERR_NULL;
   if (M <= 0 || C <= 0) return SNAP_ERR_BAD_SHAPE;
   if (workspace_bytes < snap_colsum_workspace_bytes(M, C)) return SNAP_ERR_WORKSPACE;
@@ -508,7 +522,7 @@ extern "C" int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out,
   const int64_t rpb = (M + S - 1) / S;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(S, (unsigned)snap_cdiv(C, 256)), dim3(256), 0, s, a,
-                     M, C, rpb, static_cast<float*>(workspace));
+                     M, C, rpb, static_cast<float*>(workspace), rows, row_count);
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 256)), dim3(256), 0, s,
                      (const float*)workspace, S, C, out, accumulate);

@@ -31,6 +31,9 @@ struct WgradArgs {
   int ctiles;      // channel tiles per (kh,kw) tap
   int ncol;        // Cout tiles
   int slabs_per_chunk;
+  const int32_t* rows_z;     // optional: reduction row m reads x row rows_z[m] (flat 1x1 only)
+  const int32_t* rows_dy;    // optional: ... and dy row rows_dy[m]
+  const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
 };
 
 template <int PRO>
@@ -72,9 +75,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int k0 = kt * BKT;  // scalar path: first flat k of the tile
   const int n0 = col_t * BN;
   const int HoWo = d.Ho * d.Wo;
-  const int64_t m_begin = (int64_t)blockIdx.y * a.slabs_per_chunk * RS;
-  const int64_t m_end = min((int64_t)a.M, m_begin + (int64_t)a.slabs_per_chunk * RS);
-  const int nslab = (int)((m_end - m_begin + RS - 1) / RS);
+  const int64_t Meff = a.row_count ? min((int64_t)*a.row_count, (int64_t)a.M) : (int64_t)a.M;
+  // with a device-side row count the chunks are re-cut over the rows that exist, so every
+  // workgroup keeps an equal share (the launch was sized for the upper bound M)
+  const int64_t spc = a.row_count ? (((Meff + RS - 1) / RS) + gridDim.y - 1) / gridDim.y
+                                  : (int64_t)a.slabs_per_chunk;
+  const int64_t m_begin = (int64_t)blockIdx.y * spc * RS;
+  const int64_t m_end = min(Meff, m_begin + spc * RS);
+  const int nslab = m_end > m_begin ? (int)((m_end - m_begin + RS - 1) / RS) : 0;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -147,7 +155,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int hi = ho * d.stride - d.pad_t + kh, wi = wo * d.stride - d.pad_l + kw;
         const bool inb = mok && zc < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
         zin[p] = inb;
-        const int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + zc : (int64_t)0;
+        int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + zc : (int64_t)0;
+        if (a.rows_z)  // row list over a flat [1,1,M,C] tensor
+          off = inb ? (int64_t)a.rows_z[m] * d.Cin_stride + zc : (int64_t)0;
         zr[p] = *reinterpret_cast<const f32x4*>(a.x + off);
         if constexpr (need_gn) {
           const int64_t so = inb ? (int64_t)n * d.Cin + zc : (int64_t)0;
@@ -167,7 +177,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int c = ec[e];
         const bool inb = mok && ekok[e] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
         sin_[e] = inb;
-        const int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + c : (int64_t)0;
+        int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + c : (int64_t)0;
+        if (a.rows_z) off = inb ? (int64_t)a.rows_z[m] * d.Cin_stride + c : (int64_t)0;
         se[e] = a.x[off];
         if constexpr (need_gn) {
           const int64_t so = inb ? (int64_t)n * d.Cin + c : (int64_t)0;
@@ -183,7 +194,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       const int col = n0 + 4 * dq;
       const bool ok = m < m_end && col < d.Cout;
       din[p] = ok;
-      dr[p] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? m * d.Cout_stride + col : (int64_t)0));
+      const int64_t drow = (ok && a.rows_dy) ? (int64_t)a.rows_dy[m] : m;
+      dr[p] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? drow * d.Cout_stride + col : (int64_t)0));
     }
   };
 
@@ -366,7 +378,22 @@ extern "C" int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, c
                                      float* dw, const float* gn_mu, const float* gn_sc,
                                      const float* gn_beta, int32_t accumulate, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  return snap_conv2d_wgrad_rows_f32(desc, x, dy, dw, gn_mu, gn_sc, gn_beta, accumulate, workspace,
+                                    workspace_bytes, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int snap_conv2d_wgrad_rows_f32(const SnapConvDesc* desc, const float* x,
+                                          const float* dy, float* dw, const float* gn_mu,
+                                          const float* gn_sc, const float* gn_beta,
+                                          int32_t accumulate, void* workspace,
+                                          size_t workspace_bytes, const int32_t* rows_z,
+                                          const int32_t* rows_dy, const int32_t* row_count,
+                                          void* stream) {
   if (!desc || !x || !dy || !dw || !workspace) return SNAP_ERR_NULL;
+  if ((rows_z || rows_dy) && !(desc->KH == 1 && desc->KW == 1 && desc->stride == 1 &&
+                               desc->N == 1 && desc->H == 1 && desc->pad_t == 0 &&
+                               desc->pad_l == 0))
+    return SNAP_ERR_UNSUPPORTED;  // row lists address a flat [1,1,M,C] (Dense) layout
   const SnapConvDesc& d = *desc;
   if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 || d.KW <= 0 ||
       d.stride <= 0 || d.Ho <= 0 || d.Wo <= 0)
@@ -389,6 +416,7 @@ extern "C" int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, c
   a.M = d.N * d.Ho * d.Wo;
   a.K = d.KH * d.KW * d.Cin;
   a.ctiles = p.ctiles; a.ncol = p.ncol; a.slabs_per_chunk = p.slabs_per_chunk;
+  a.rows_z = rows_z; a.rows_dy = rows_dy; a.row_count = row_count;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (vec) {

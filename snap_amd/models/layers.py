@@ -41,8 +41,14 @@ class MLP(base.Module):
     n = len(self.config.layers)
     grad = any(base.needs_grad(x, params[f'Dense_{i}']['kernel'], params[f'Dense_{i}']['bias'])
                for i in range(n))
-    if row_mask is not None and not grad and row_mask.numel() >= self.COMPACT_MIN_ROWS:
-      return self._masked_rows(params, x, row_mask)
+    if row_mask is not None and row_mask.numel() >= self.COMPACT_MIN_ROWS:
+      if not grad:
+        return self._masked_rows(params, x, row_mask)
+      if all(params[f'Dense_{i}']['kernel'].shape[1] % 4 == 0 for i in range(n)):
+        wb = []
+        for i in range(n):
+          wb += [params[f'Dense_{i}']['kernel'], params[f'Dense_{i}']['bias']]
+        return ag.masked_rows_mlp(x, row_mask, bool(self.config.apply_input_activation), wb)
     for i in range(n):
       p = params[f'Dense_{i}']
       pro = ops.PRO_RELU if (i == 0 and self.config.apply_input_activation) else ops.PRO_NONE

@@ -25,13 +25,18 @@ def _conv_desc(x_shape, w_shape, stride, padding, prologue, in_affine, cs=None):
 
 
 def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue=ops.PRO_NONE,
-                 gn=None, in_affine=(1.0, 0.0)):
-  """dw [KH,KW,Cin,Cout] = im2col(prologue(x))^T dy  (MFMA; deterministic split-M)."""
+                 gn=None, in_affine=(1.0, 0.0), rows_z=None, rows_dy=None, row_count=None):
+  """dw [KH,KW,Cin,Cout] = im2col(prologue(x))^T dy  (MFMA; deterministic split-M).
+
+  rows_z / rows_dy / row_count: row lists over flat [1,1,M,C] operands (masked MLP)."""
   lib = _lib.load()
   _f32(x, 'x'); _f32(dy, 'dy')
   d, yshape = _conv_desc(x.shape, w_shape, stride, padding, prologue, in_affine)
   if tuple(dy.shape) != yshape:
     raise ValueError(f'conv2d_wgrad: dy {tuple(dy.shape)} vs {yshape}')
+  for t, nm in ((rows_z, 'rows_z'), (rows_dy, 'rows_dy'), (row_count, 'row_count')):
+    if t is not None:
+      ops._chk(t, torch.int32, nm)
   mu = sc = beta = None
   if prologue in (ops.PRO_GN_RELU, ops.PRO_RELU_GN):
     mu, sc, beta = gn
@@ -40,12 +45,14 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
   KH, KW, Cin, Cout = w_shape
   M = yshape[0] * yshape[1] * yshape[2]
-  with _region('conv_wgrad', 2.0 * M * KH * KW * Cin * Cout, 4.0 * (x.numel() + dy.numel())):
-    st = lib.snap_conv2d_wgrad_f32(
+  kfl = 2.0 * KH * KW * Cin * Cout
+  flops = kfl * M if row_count is None else (lambda: kfl * int(row_count.item()))
+  with _region('conv_wgrad', flops, 4.0 * (x.numel() + dy.numel())):
+    st = lib.snap_conv2d_wgrad_rows_f32(
         ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(mu), _p(sc), _p(beta), 0, _p(ws),
-        ws.numel() * 4, _stream(),
+        ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), _stream(),
     )
-  _lib.check(st, 'snap_conv2d_wgrad_f32')
+  _lib.check(st, 'snap_conv2d_wgrad_rows_f32')
   return dw
 
 
@@ -110,8 +117,8 @@ def epilogue_bwd(dy, y=None, row_mask=None, relu=False):
   return out
 
 
-def colsum(a):
-  """Column sums of a [..., C] -> [C]  (bias gradients)."""
+def colsum(a, rows=None, row_count=None):
+  """Column sums of a [..., C] -> [C]  (bias gradients); optionally over a row list."""
   lib = _lib.load()
   _f32(a, 'a')
   C = a.shape[-1]
@@ -119,8 +126,9 @@ def colsum(a):
   wsb = lib.snap_colsum_workspace_bytes(M, C)
   ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=a.device)
   out = torch.empty(C, dtype=torch.float32, device=a.device)
-  st = lib.snap_colsum_f32(_p(a), M, C, _p(out), 0, _p(ws), ws.numel() * 4, _stream())
-  _lib.check(st, 'snap_colsum_f32')
+  st = lib.snap_colsum_rows_f32(_p(a), M, C, _p(rows), _p(row_count), _p(out), 0, _p(ws),
+                                ws.numel() * 4, _stream())
+  _lib.check(st, 'snap_colsum_rows_f32')
   return out
 
 

@@ -350,3 +350,45 @@ def test_dense_autograd_ragged_channels(cin, cs, pro):
   helpers.report('dx', xg.grad, xd.grad.float(), atol=3e-5, rtol=1e-5)
   helpers.report('dw', wg.grad, wd.grad.float(), atol=2e-4, rtol=1e-5)
   helpers.report('db', bg.grad, bd.grad.float(), atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize('layers_,in_dim,stride,relu_in', [((64, 32), 65, 68, False), ((128,), 257, 260, False),
+                                                            ((256, 128), 257, 260, True)])
+def test_masked_rows_mlp_gradients_match_dense_path(layers_, in_dim, stride, relu_in, monkeypatch):
+  """Row-list MLP (observed voxels only) vs the dense autograd MLP with the row mask on its
+  last layer: same outputs, same parameter / input gradients (summation order aside)."""
+  from snap_amd.models import layers
+  from snap_amd.utils import config_dict
+  cfg = config_dict.ConfigDict(dict(layers=layers_, activation='relu', apply_input_activation=relu_in))
+  mlp = layers.MLP(cfg, in_dim=in_dim)
+  gen = torch.Generator().manual_seed(11)
+  params = helpers.params_to_device(mlp.init_params(gen, 'cpu'), 'cuda')
+  for i in range(len(layers_)):
+    params[f'Dense_{i}']['bias'] = torch.randn(layers_[i], generator=gen).cuda()
+  M = 70001
+  x = torch.randn(M, stride, generator=gen).cuda()
+  mask = (torch.rand(M, generator=gen) < 0.6).cuda()
+  dy = torch.randn(M, layers_[-1], generator=gen).cuda()
+
+  def run(min_rows):
+    monkeypatch.setattr(layers.MLP, 'COMPACT_MIN_ROWS', min_rows)
+    leaves = [x.clone().requires_grad_(True)]
+    p = {}
+    for i in range(len(layers_)):
+      k = params[f'Dense_{i}']['kernel'].clone().requires_grad_(True)
+      b = params[f'Dense_{i}']['bias'].clone().requires_grad_(True)
+      p[f'Dense_{i}'] = {'kernel': k, 'bias': b}
+      leaves += [k, b]
+    y = mlp(p, leaves[0], train=True, row_mask=mask)
+    y.backward(dy)
+    return y.detach(), [t.grad for t in leaves]
+
+  y_d, g_d = run(1 << 30)     # dense autograd path
+  y_c, g_c = run(0)           # row-list path
+  assert torch.equal(y_d, y_c)
+  names = ['dx'] + [f'd{n}{i}' for i in range(len(layers_)) for n in ('W', 'b')]
+  for nm, a, b in zip(names, g_c, g_d):
+    scale = float(b.abs().max())
+    helpers.report(nm, a, b, atol=2e-5 * max(scale, 1.0), rtol=1e-4)
+  # masked rows receive exactly zero input gradient
+  assert bool((g_c[0][~mask] == 0).all())
