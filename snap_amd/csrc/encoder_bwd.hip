@@ -83,10 +83,11 @@ __global__ void gn_bwd_reduce_kernel(const float* __restrict__ partial, int S, i
   if (i >= total) return;
   const int n = i / C, c = i - n * C;
   float a1 = 0.f, a2 = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float* p = partial + (((int64_t)n * S + s) * C + c) * 2;
-    a1 += p[0];
-    a2 += p[1];
+#pragma unroll 8
+  for (int s = 0; s < S; ++s) {   // unrolled: 8 independent loads in flight (pure latency)
+    const float2 p = *reinterpret_cast<const float2*>(partial + (((int64_t)n * S + s) * C + c) * 2);
+    a1 += p.x;
+    a2 += p.y;
   }
   ab[(int64_t)i * 2 + 0] = a1;
   ab[(int64_t)i * 2 + 1] = a2;
@@ -359,13 +360,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
   partial[(int64_t)blockIdx.x * C + c] = t;
 }
-__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int S, int C,
-                                     float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float t = accumulate ? out[c] : 0.f;
-  for (int s = 0; s < S; ++s) t += partial[(int64_t)s * C + c];
-  out[c] = t;
+// 32 columns x 8 slab groups per workgroup; fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial,
+                                                            int S, int C, float* __restrict__ out,
+                                                            int accumulate) {
+  __shared__ float red[8][33];
+  const int tc = threadIdx.x & 31, tg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tc;
+  float t = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int s = tg; s < S; s += 8) t += partial[(int64_t)s * C + c];
+  }
+  red[tg][tc] = t;
+  __syncthreads();
+  if (tg == 0 && c < C) {
+    float r = accumulate ? out[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += red[i][tc];
+    out[c] = r;
+  }
 }
 
 struct GnPlanB { int S, ppb; };
@@ -524,7 +538,7 @@ extern "C" int snap_colsum_rows_f32(const float* a, int64_t M, int32_t C, const 
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(S, (unsigned)snap_cdiv(C, 256)), dim3(256), 0, s, a,
                      M, C, rpb, static_cast<float*>(workspace), rows, row_count);
   SNAP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 32)), dim3(256), 0, s,
                      (const float*)workspace, S, C, out, accumulate);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;

@@ -312,6 +312,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, in
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   float t = accumulate ? dw[i] : 0.f;
+#pragma unroll 8
   for (int s = 0; s < S; ++s) t += partial[(int64_t)s * total + i];
   dw[i] = t;
 }
