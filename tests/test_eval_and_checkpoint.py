@@ -1,0 +1,99 @@
+"""Host logic of the evaluator contract and the checkpoint converter (CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from snap_amd import evaluator
+from snap_amd.utils import checkpoint
+from snap_amd.utils import geometry
+
+
+def _rot_z(a):
+  c, s = np.cos(a), np.sin(a)
+  R = np.zeros(a.shape + (3, 3))
+  R[..., 0, 0], R[..., 0, 1], R[..., 1, 0], R[..., 1, 1], R[..., 2, 2] = c, -s, s, c, 1
+  return R
+
+
+def test_compute_distance_view_to_map_picks_the_closest_translation():
+  rng = np.random.default_rng(0)
+  B, V = 3, 5
+  aq, am = rng.uniform(-3, 3, B), rng.uniform(-3, 3, (B, V))
+  tq, tm = rng.normal(size=(B, 3)), rng.normal(size=(B, V, 3))
+  q = geometry.Transform3D(torch.tensor(_rot_z(aq)), torch.tensor(tq))
+  m = geometry.Transform3D(torch.tensor(_rot_z(am)), torch.tensor(tm))
+  dr, dt = evaluator.compute_distance_view_to_map(q, m)
+  d = np.linalg.norm(tm - tq[:, None], axis=-1)          # |R_q^T (t_m - t_q)| = |t_m - t_q|
+  j = d.argmin(-1)
+  np.testing.assert_allclose(dt.numpy(), d.min(-1), rtol=1e-12)
+  da = np.abs((am[np.arange(B), j] - aq + np.pi) % (2 * np.pi) - np.pi)
+  np.testing.assert_allclose(dr.numpy(), np.rad2deg(da), atol=1e-6)
+
+
+def test_compute_recall_curve():
+  errors = np.array([0.1, 0.4, 0.6, 2.5, 7.0])
+  th, rec = evaluator.compute_recall(errors, 5.0)
+  assert th.shape == rec.shape == (100,) and th[0] == 0 and th[-1] == 5.0
+  assert rec[0] == 0.0 and rec[-1] == 80.0
+  assert np.all(np.diff(rec) >= 0)
+  k = np.searchsorted(th, 0.5)
+  assert rec[k] == 40.0                                   # strict '<' at the threshold grid
+
+
+def test_eval_dump_round_trip(tmp_path):
+  results = {'error_max_meter': np.arange(4.0), 'recall_top1': np.array([1.0, 0, 1, 1])}
+  evaluator.write_eval_dump(tmp_path / 'e', results, {'a': 1, 'b': {'c': 2}}, compressed=True)
+  got, cfg = evaluator.read_eval_dump(tmp_path / 'e')
+  assert cfg == {'a': 1, 'b': {'c': 2}}
+  assert set(got) == set(results)
+  for k in results:
+    np.testing.assert_array_equal(got[k], results[k])
+
+
+def test_flatten_unflatten_and_find_nested_dict():
+  tree = {'opt': {'x': torch.zeros(1)},
+          'params': {'bev_mapper': {'matching_proj': {'kernel': torch.ones(2, 3)}, 'enc': {'k': torch.zeros(2)}},
+                     'temperature': torch.tensor(2.0)}}
+  flat = checkpoint.flatten(tree)
+  assert list(flat) == ['opt/x', 'params/bev_mapper/enc/k', 'params/bev_mapper/matching_proj/kernel',
+                        'params/temperature']
+  back = checkpoint.unflatten(flat)
+  assert checkpoint.flatten(back).keys() == flat.keys()
+  sub = checkpoint.find_nested_dict(tree, 'bev_mapper')
+  assert sub is tree['params']['bev_mapper']
+  assert checkpoint.find_nested_dict(tree, 'nope') is None
+  with pytest.raises(ValueError):
+    checkpoint.unflatten({'a': 1, 'a/b': 2})
+
+
+def test_checkpoint_npz_round_trip_of_the_model_tree(tmp_path):
+  import helpers
+  from snap_amd import models
+  from snap_amd.data import synthetic
+  cfg = helpers.tiny_localizer_config()
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  model = models.get_model('bev_localizer')(cfg, meta)
+  params = model.flax_model.init(0, device='cpu')['params']
+  path = os.path.join(tmp_path, 'ckpt.npz')
+  checkpoint.save_npz(path, {'params': params})
+  other = model.flax_model.init(1, device='cpu')['params']           # different values, same tree
+  loaded = checkpoint.load_pretrained(other, path)
+  fa, fb = checkpoint.flatten(params), checkpoint.flatten(loaded)
+  assert fa.keys() == fb.keys()
+  assert all(torch.equal(fa[k], fb[k]) for k in fa)
+  # Flax names / layouts of the reference
+  assert 'bev_mapper/streetview_encoder/fusion_mlp/Dense_0/kernel' in fa
+  assert fa['bev_mapper/matching_proj/kernel'].shape[1] == cfg.bev_mapper.matching_dim
+  # sub-tree restore, as BEVMapper.load_pretrained_variables does with 'bev_mapper'
+  sub = checkpoint.load_pretrained(other['bev_mapper'], path, scope='bev_mapper')
+  assert torch.equal(checkpoint.flatten(sub)['matching_proj/kernel'], fa['bev_mapper/matching_proj/kernel'])
+  # strictness: a wrong shape and a missing leaf are errors
+  bad = checkpoint.unflatten({**fa, 'temperature': torch.zeros(2)})
+  with pytest.raises(ValueError):
+    checkpoint.load_into(other, bad)
+  fewer = checkpoint.unflatten({k: v for k, v in fa.items() if k != 'temperature'})
+  with pytest.raises(KeyError):
+    checkpoint.load_into(other, fewer)
+  assert torch.equal(checkpoint.load_into(other, fewer, strict=False)['temperature'], other['temperature'])

@@ -91,3 +91,33 @@ def test_output_pytree_keys():
       'feature_plane'}
   assert pred['scores_poses'].shape == (1, 17)
   assert pred['map_t_query_samples'].shape == (1, 17)
+
+
+def test_evaluator_contract_on_tiny_model(tmp_path):
+  """eval_step / eval_on_batches / dump round trip (snap/evaluator.py:57-109,205-238)."""
+  from snap_amd import evaluator
+  from snap_amd import models
+  dev = torch.device('cuda')
+  cfg = helpers.tiny_localizer_config(num_pose_samples=64, retries=2)
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  model = models.get_model('bev_localizer')(cfg, meta)
+  params = helpers.params_to_device(model.flax_model.init(0, device='cpu')['params'], dev)
+  batches = []
+  for s in (1, 2):
+    b = helpers.batch_to_device(synthetic.make_batch(3, meta['grid'], 2, (64, 64), seed=s), dev)
+    b['batch_mask'] = torch.tensor([True, s == 1, True], device=dev)
+    batches.append(b)
+  res = evaluator.eval_on_batches(model, params, batches, rng=7)
+  want = {'error_max_meter', 'error_max_deg', 'recall_top1', 'pose_score_max', 'overlap',
+          'time_delta_days', 'closest_map_view_meter', 'closest_map_view_deg', 'loss'}
+  assert set(res) == want
+  assert all(v.shape == (5,) for v in res.values())               # 3 + 2 valid examples
+  for k in want - {'overlap', 'time_delta_days'}:                  # dataset-only fields are NaN
+    assert np.isfinite(res[k]).all(), k
+  assert set(np.unique(res['recall_top1'])) <= {0.0, 1.0}
+  assert (res['closest_map_view_meter'] >= 0).all() and (res['error_max_deg'] <= 180).all()
+  evaluator.write_eval_dump(tmp_path / 'osaka', res, cfg)
+  back, _ = evaluator.read_eval_dump(tmp_path / 'osaka')
+  np.testing.assert_array_equal(back['loss'], res['loss'])
+  th, rec = evaluator.compute_recall(res['error_max_meter'], 5.0)
+  assert rec[-1] == 100.0 * np.mean(res['error_max_meter'] < 5.0)
