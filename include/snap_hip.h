@@ -318,6 +318,24 @@ int snap_template_finalize_f32(const float* raw, const float* cnt,
                                int32_t R, int32_t Rp, float overlap_threshold,
                                int32_t use_overlap, float* scores, void* stream);
 
+/* Confidence-weighted vertical pooling: the 'softmax' / 'weighted' modes of VerticalPooling
+ * (bev_mapper.py:63-78).  score_z = vol[m,z,:] . w + bias[0] (log_sigmoid of it when
+ * log_sigmoid_scores != 0, i.e. 'weighted'); weights = softmax over the valid levels (all
+ * levels if none is valid, then zeroed), plane = sum_z weights_z vol[m,z,:], zero where no
+ * level is valid.  scores / weights: [M, Z] (pred['scores'], pred['weights']).  Z <= 64,
+ * D <= 128.  Backward: d vol from d plane (scores / weights outputs carry no gradient here),
+ * plus per-workgroup partial rows [rows, D + 4] of (d w | d bias at column D) whose column
+ * sums (snap_colsum_f32) are d w and d bias; rows = snap_vertical_pool_conf_bwd_partial_rows(M). */
+int snap_vertical_pool_conf_f32(const float* vol, const uint8_t* vvalid, const float* w,
+                                const float* bias, int64_t M, int32_t Z, int32_t D,
+                                int32_t log_sigmoid_scores, float* plane, uint8_t* pvalid,
+                                float* scores, float* weights, void* stream);
+size_t snap_vertical_pool_conf_bwd_partial_rows(int64_t M);
+int snap_vertical_pool_conf_bwd_f32(const float* vol, const uint8_t* vvalid, const float* w,
+                                    const float* bias, const float* weights, const float* dplane,
+                                    int64_t M, int32_t Z, int32_t D, int32_t log_sigmoid_scores,
+                                    float* dvol, float* dw_partial, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Training path: vector-Jacobian products of the kernels above.
  * The reference obtains these from jax.grad over the same call sites

@@ -8,17 +8,47 @@ from oracle import encoder
 from oracle import lift
 
 
-def vertical_pooling(config, features, valid):
-  """bev_mapper.py:56-88 for pooling in {'max', 'sum', 'mean'}.
+def log_sigmoid(x):
+  """jax.nn.log_sigmoid = -softplus(-x), evaluated stably."""
+  return np.minimum(x, 0) - np.log1p(np.exp(-np.abs(x)))
 
-  features [..., Z, D], valid [..., Z] -> plane features [..., D], valid [...].
+
+def masked_softmax(x, where, axis=-1):
+  """jax.nn.softmax(x, where=where, initial=0, axis): max over the selected entries and the
+  initial value 0; sum over the selected entries; unselected outputs are 0."""
+  shift = np.maximum(np.max(np.where(where, x, -np.inf), axis=axis, keepdims=True), 0)
+  e = np.where(where, np.exp(x - shift), 0)
+  return e / e.sum(axis, keepdims=True)
+
+
+def vertical_pooling(config, features, valid, params=None):
+  """bev_mapper.py:56-88.
+
+  features [..., Z, D], valid [..., Z] -> plane features [..., D], valid [...]
+  (+ 'scores' / 'weights' [..., Z] for the 'softmax' / 'weighted' modes).  ``params``:
+  {'confidence_head': {'kernel' [D,1], 'bias' [1]}} or {'fusion_mlp': ...} ('mlp').
   """
   dtype = features.dtype
   valid_any = valid.any(-1)
   valid_any_or_all = np.where(valid_any[..., None], valid, True)
   where = valid_any_or_all[..., None]
   pooling = config['pooling']
-  if pooling == 'max':
+  extra = {}
+  if pooling in ('weighted', 'softmax'):
+    head = params['confidence_head']
+    scores = (features @ head['kernel'].astype(dtype))[..., 0] + head['bias'].astype(dtype)[0]
+    if pooling == 'weighted':
+      scores = log_sigmoid(scores)
+    weights = masked_softmax(scores, valid_any_or_all, axis=-1)
+    weights = np.where(valid, weights, 0).astype(dtype)
+    out = (features * weights[..., None]).sum(-2)
+    extra = dict(scores=scores.astype(dtype), weights=weights)
+  elif pooling == 'mlp':
+    from oracle import encoder as o_enc
+    f = np.where(valid[..., None], features, 0)
+    f = f.reshape(*f.shape[:-2], -1)
+    out = o_enc.mlp(params['fusion_mlp'], config['mlp'], f)
+  elif pooling == 'max':
     out = np.where(where, features, -np.inf).max(-2)
   elif pooling == 'sum':
     out = np.where(where, features, 0).sum(-2)
@@ -27,7 +57,7 @@ def vertical_pooling(config, features, valid):
   else:
     raise NotImplementedError(pooling)
   out = np.where(valid_any[..., None], out, 0).astype(dtype)
-  return dict(features=out, valid=valid_any)
+  return dict(features=out, valid=valid_any, **extra)
 
 
 def build_xyz_query(config, grid, scene_t_view, xy_bev=None, z_offset=None):

@@ -129,6 +129,13 @@ SIGNATURES = {
     'snap_template_finalize_f32': (
         c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr]
     ),
+    'snap_vertical_pool_conf_f32': (
+        c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, c_int, ptr, ptr, ptr, ptr, ptr]
+    ),
+    'snap_vertical_pool_conf_bwd_partial_rows': (c_size, [c_i64]),
+    'snap_vertical_pool_conf_bwd_f32': (
+        c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_int, c_int, c_int, ptr, ptr, ptr]
+    ),
     # ---- training path ----
     'snap_conv2d_wgrad_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_wgrad_f32': (

@@ -350,6 +350,33 @@ def vertical_pool(vol, valid, pooling='max'):
   return _VerticalPool.apply(vol, valid, pooling)
 
 
+class _VerticalPoolConf(torch.autograd.Function):
+  """'softmax' / 'weighted' VerticalPooling.  The scores / weights outputs are diagnostic
+  (pred['scores'], pred['weights']; nothing in the localisation loss reads them) and are
+  returned without gradient."""
+
+  @staticmethod
+  def forward(ctx, vol, valid, w, bias, log_sig):
+    plane, pvalid, scores, weights = ops.vertical_pool_conf(vol, valid, w.reshape(-1).contiguous(),
+                                                            bias, log_sig)
+    ctx.log_sig = log_sig
+    ctx.wshape = w.shape
+    ctx.save_for_backward(vol, valid, w, bias, weights)
+    ctx.mark_non_differentiable(pvalid, scores, weights)
+    return plane, pvalid, scores, weights
+
+  @staticmethod
+  def backward(ctx, dplane, _dv, _ds, _dw):
+    vol, valid, w, bias, weights = ctx.saved_tensors
+    dvol, dw, db = ops_bwd.vertical_pool_conf_bwd(
+        vol, valid, w.reshape(-1).contiguous(), bias, weights, dplane.contiguous(), ctx.log_sig)
+    return dvol, None, dw.reshape(ctx.wshape), db, None
+
+
+def vertical_pool_conf(vol, valid, w, bias, log_sigmoid_scores):
+  return _VerticalPoolConf.apply(vol, valid, w, bias, log_sigmoid_scores)
+
+
 class _PlaneFuseMatch(torch.autograd.Function):
 
   @staticmethod

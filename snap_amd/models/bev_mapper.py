@@ -9,29 +9,67 @@ from snap_amd import ops
 from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
 from snap_amd.models import image_encoder
+from snap_amd.models import layers
 from snap_amd.models import streetview_encoder
 from snap_amd.models import types
 
 
 class VerticalPooling(base.Module):
-  """Masked reduce over the vertical (or modality) axis (bev_mapper.py:40-88)."""
+  """Masked reduce over the vertical (or modality) axis (bev_mapper.py:40-88).
 
-  def __init__(self, config, dtype=torch.float32):
-    if config.pooling not in ('max', 'sum', 'mean'):
-      # 'weighted' / 'softmax' / 'mlp' are non-default variants (SURVEY 8f rank 4).
+  'max' / 'sum' / 'mean': one masked-reduce kernel.  'softmax' / 'weighted': a Dense(1)
+  confidence head + masked softmax over the levels + weighted sum, ONE kernel that reads the
+  volume once (bev_conf_pool.hip).  'mlp': masked volume flattened over (Z, D) -> MLP on the
+  conv engine; needs ``num_levels`` and ``feature_dim`` (Flax infers them at init).
+  """
+
+  def __init__(self, config, dtype=torch.float32, num_levels=None, feature_dim=None):
+    if config.pooling not in ('max', 'sum', 'mean', 'softmax', 'weighted', 'mlp'):
       raise NotImplementedError(config.pooling)
     self.config = config
+    self.feature_dim = feature_dim
+    self.fusion_mlp = None
+    if config.pooling == 'mlp':
+      if num_levels is None or feature_dim is None:
+        raise ValueError("pooling='mlp' needs num_levels and feature_dim")
+      self.fusion_mlp = layers.MLP(config.mlp, in_dim=num_levels * feature_dim)
+    elif config.pooling in ('softmax', 'weighted') and feature_dim is None:
+      raise ValueError(f"pooling='{config.pooling}' needs feature_dim")
 
   def init_params(self, gen, device):
+    if self.config.pooling in ('softmax', 'weighted'):
+      d = self.feature_dim
+      return {'confidence_head': {
+          'kernel': base.lecun_normal(gen, (d, 1), d, device),
+          'bias': torch.zeros(1, device=device),
+      }}
+    if self.config.pooling == 'mlp':
+      return {'fusion_mlp': self.fusion_mlp.init_params(gen, device)}
     return {}
 
   def __call__(self, params, feature_volume):
-    vp = ag.vertical_pool if base.needs_grad(feature_volume.features) else ops.vertical_pool
-    plane, valid = vp(
-        feature_volume.features.contiguous(), feature_volume.valid.contiguous(),
-        self.config.pooling,
-    )
-    return {'plane': types.FeaturePlane(features=plane, valid=valid)}
+    pooling = self.config.pooling
+    feats = feature_volume.features.contiguous()
+    valid = feature_volume.valid.contiguous()
+    if pooling in ('softmax', 'weighted'):
+      head = params['confidence_head']
+      fn = (ag.vertical_pool_conf if base.needs_grad(feats, head['kernel'], head['bias'])
+            else ops.vertical_pool_conf)
+      w = head['kernel'] if fn is ag.vertical_pool_conf else head['kernel'].reshape(-1).contiguous()
+      plane, pvalid, scores, weights = fn(feats, valid, w, head['bias'], pooling == 'weighted')
+      return {'scores': scores, 'weights': weights,
+              'plane': types.FeaturePlane(features=plane, valid=pvalid)}
+    if pooling == 'mlp':
+      Z, D = feats.shape[-2:]
+      lead = feats.shape[:-2]
+      masked = feats * valid[..., None].to(feats.dtype)                  # where(valid, f, 0)
+      flat = masked.reshape(*lead, Z * D)
+      pvalid = valid.any(-1)
+      out = self.fusion_mlp(params['fusion_mlp'], flat, row_mask=pvalid.contiguous())
+      return {'plane': types.FeaturePlane(features=out, valid=pvalid)}
+    vp = ag.vertical_pool if base.needs_grad(feats) else ops.vertical_pool
+    plane, pvalid = vp(feats, valid, pooling)
+    return {'plane': types.FeaturePlane(features=plane, valid=pvalid)}
 
 
 def _median_lower_upper_mean(x):
@@ -57,7 +95,12 @@ class BEVMapper(base.Module):
       self.streetview_encoder = streetview_encoder.StreetViewEncoder(
           config.streetview_encoder, dtype
       )
-      self.vertical_pooling = VerticalPooling(config.pooling, dtype)
+      cell = grid.cell_size if hasattr(grid, 'cell_size') else None
+      num_levels = None if cell is None else len(torch.arange(0, config.scene_z_height, cell))
+      self.vertical_pooling = VerticalPooling(
+          config.pooling, dtype, num_levels=num_levels,
+          feature_dim=config.streetview_encoder.feature_dim,
+      )
       feature_dimensions.append(config.streetview_encoder.feature_dim)
     if config.aerial_encoder is not None:
       self.aerial_encoder = image_encoder.ImageEncoder(config.aerial_encoder, dtype)
@@ -69,6 +112,10 @@ class BEVMapper(base.Module):
     elif len(feature_dimensions) > 1:
       if not all(d == feature_dimensions[0] for d in feature_dimensions):
         raise ValueError(f'Encoder have different output dimensions: {feature_dimensions}')
+      if config.modality_fusion.pooling not in ('max', 'sum', 'mean'):
+        raise NotImplementedError(
+            f'modality_fusion.pooling={config.modality_fusion.pooling}: only max/sum/mean are '
+            'fused with the matching head (plane_fuse_match)')
       self.modality_fusion = VerticalPooling(config.modality_fusion, dtype)
     self.feature_dim = feature_dimensions[0]
     if config.bev_net is not None:
@@ -80,7 +127,7 @@ class BEVMapper(base.Module):
     params = {}
     if self.streetview_encoder is not None:
       params['streetview_encoder'] = self.streetview_encoder.init_params(gen, device)
-      params['vertical_pooling'] = {}
+      params['vertical_pooling'] = self.vertical_pooling.init_params(gen, device)
     if self.aerial_encoder is not None:
       params['aerial_encoder'] = self.aerial_encoder.init_params(gen, device)
     if self.modality_fusion is not None:
@@ -133,7 +180,8 @@ class BEVMapper(base.Module):
     if 'xyz_query' not in data:
       data['xyz_query'] = self.build_xyz_query(data, train, is_query, rng)
     pred = self.streetview_encoder(params['streetview_encoder'], data, train=train, ctx=ctx)
-    pred['vertical_pooling'] = self.vertical_pooling({}, pred['feature_volume'])
+    pred['vertical_pooling'] = self.vertical_pooling(
+        params.get('vertical_pooling', {}), pred['feature_volume'])
     pred['feature_plane'] = pred['vertical_pooling'].pop('plane')
     return pred
 

@@ -474,6 +474,27 @@ def vertical_pool(vol, valid, pooling='max'):
   return plane, pvalid
 
 
+def vertical_pool_conf(vol, valid, w, bias, log_sigmoid_scores):
+  """'softmax' / 'weighted' VerticalPooling.  vol [..., Z, D]; valid [..., Z]; w [D] (or
+  [D,1]); bias [1] -> plane [..., D], valid_any [...], scores [..., Z], weights [..., Z]."""
+  lib = _lib.load()
+  _f32(vol, 'vol'); _mask(valid, 'valid'); _f32(w, 'w'); _f32(bias, 'bias')
+  Z, D = vol.shape[-2:]
+  lead = vol.shape[:-2]
+  M = vol.numel() // (Z * D)
+  plane = torch.empty((*lead, D), dtype=torch.float32, device=vol.device)
+  pvalid = torch.empty(lead, dtype=torch.bool, device=vol.device)
+  scores = torch.empty((*lead, Z), dtype=torch.float32, device=vol.device)
+  weights = torch.empty((*lead, Z), dtype=torch.float32, device=vol.device)
+  with _region('vertical_pool', 0.0, 4.0 * (vol.numel() + plane.numel())):
+    st = lib.snap_vertical_pool_conf_f32(
+        _p(vol), _p(valid), _p(w), _p(bias), M, Z, D, int(log_sigmoid_scores), _p(plane),
+        _p(pvalid), _p(scores), _p(weights), _stream(),
+    )
+  _lib.check(st, 'snap_vertical_pool_conf_f32')
+  return plane, pvalid, scores, weights
+
+
 def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None,
                      normalize=True, eps=1e-5, want_fused=True):
   """Fuse modality planes and apply the matching head.

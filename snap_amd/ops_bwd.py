@@ -221,3 +221,21 @@ def sim_bwd_prepare_(dsim, sim, clip_negative, coef):
   )
   _lib.check(st, 'snap_sim_bwd_prepare_f32')
   return partial.to(torch.float64).sum(-1)
+
+
+def vertical_pool_conf_bwd(vol, valid, w, bias, weights, dplane, log_sigmoid_scores):
+  """Returns (dvol, dw [D], dbias [1])."""
+  lib = _lib.load()
+  _f32(vol, 'vol'); _mask(valid, 'valid'); _f32(weights, 'weights'); _f32(dplane, 'dplane')
+  Z, D = vol.shape[-2:]
+  M = vol.numel() // (Z * D)
+  rows = lib.snap_vertical_pool_conf_bwd_partial_rows(M)
+  partial = torch.empty((rows, D + 4), dtype=torch.float32, device=vol.device)
+  dvol = torch.empty_like(vol)
+  st = lib.snap_vertical_pool_conf_bwd_f32(
+      _p(vol), _p(valid), _p(w), _p(bias), _p(weights), _p(dplane), M, Z, D,
+      int(log_sigmoid_scores), _p(dvol), _p(partial), _stream(),
+  )
+  _lib.check(st, 'snap_vertical_pool_conf_bwd_f32')
+  sums = colsum(partial)
+  return dvol, sums[:D].contiguous(), sums[D:D + 1].contiguous()

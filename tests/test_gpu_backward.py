@@ -392,3 +392,34 @@ def test_masked_rows_mlp_gradients_match_dense_path(layers_, in_dim, stride, rel
     helpers.report(nm, a, b, atol=2e-5 * max(scale, 1.0), rtol=1e-4)
   # masked rows receive exactly zero input gradient
   assert bool((g_c[0][~mask] == 0).all())
+
+
+@pytest.mark.parametrize('mode', ['softmax', 'weighted'])
+def test_vertical_pool_conf_bwd(mode):
+  from snap_amd import autograd as ag
+  g = torch.Generator().manual_seed(140)
+  lead, Z, D = (2, 5, 4), 60, 128
+  vol = torch.randn(*lead, Z, D, generator=g)
+  valid = torch.rand(*lead, Z, generator=g) < 0.5
+  valid[0, 0, 0] = False
+  valid[1, 2, 3] = True
+  w = torch.randn(D, 1, generator=g) * 0.3
+  b = torch.randn(1, generator=g)
+  dplane = torch.randn(*lead, D, generator=g)
+  vd, wd, bd = (t.double().requires_grad_(True) for t in (vol, w, b))
+  s = (vd @ wd)[..., 0] + bd[0]
+  if mode == 'weighted':
+    s = F.logsigmoid(s)
+  any_ = valid.any(-1, keepdim=True)
+  where = torch.where(any_, valid, torch.ones_like(valid))
+  p = torch.softmax(s.masked_fill(~where, -float('inf')), -1)
+  p = torch.where(valid, p, torch.zeros_like(p))
+  plane = (vd * p[..., None]).sum(-2) * any_.double()
+  plane.backward(dplane.double())
+  vg, wg, bg = (G(t).requires_grad_(True) for t in (vol, w, b))
+  out, pv, sc, wt = ag.vertical_pool_conf(vg, G(valid), wg, bg, mode == 'weighted')
+  helpers.report('plane', out, plane.detach().float(), atol=2e-5, rtol=2e-5)
+  out.backward(G(dplane))
+  helpers.report('dvol', vg.grad, vd.grad.float(), atol=2e-5, rtol=1e-4)
+  helpers.report('dw', wg.grad, wd.grad.float(), atol=2e-4, rtol=1e-4)
+  helpers.report('db', bg.grad, bd.grad.float(), atol=2e-4, rtol=1e-4)

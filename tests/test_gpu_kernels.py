@@ -588,3 +588,55 @@ def test_conv_split_k_matches_single_pass(N, H, W, Cin, Cout, k, stride, kind):
   finally:
     ops.USE_SPLITK = True
   helpers.report('split-K vs single pass', split, single, atol=3e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------
+# VerticalPooling: 'softmax' / 'weighted' / 'mlp' modes
+# ---------------------------------------------------------------------------
+def _volume(seed, lead=(2, 9, 7), Z=60, D=128):
+  g = torch.Generator().manual_seed(seed)
+  vol = torch.randn(*lead, Z, D, generator=g)
+  valid = torch.rand(*lead, Z, generator=g) < 0.55
+  valid[0, 0, 0] = False          # a column without any valid level
+  valid[0, 0, 1] = True           # a fully valid column
+  valid[0, 1, 0] = False
+  valid[0, 1, 0, Z // 3] = True   # exactly one valid level
+  return vol, valid, g
+
+
+@pytest.mark.parametrize('mode', ['softmax', 'weighted'])
+@pytest.mark.parametrize('Z,D', [(60, 128), (12, 32)])
+def test_vertical_pool_confidence_modes(mode, Z, D):
+  from oracle import bev as o_bev
+  vol, valid, g = _volume(31, Z=Z, D=D)
+  w = torch.randn(D, 1, generator=g) * 0.3
+  b = torch.randn(1, generator=g)
+  want = o_bev.vertical_pooling({'pooling': mode}, vol.numpy(), valid.numpy(),
+                                {'confidence_head': {'kernel': w.numpy(), 'bias': b.numpy()}})
+  plane, pvalid, scores, weights = ops.vertical_pool_conf(
+      vol.cuda(), valid.cuda(), w.reshape(-1).cuda(), b.cuda(), mode == 'weighted')
+  helpers.report('valid', pvalid, want['valid'], 0)
+  helpers.report('scores', scores, want['scores'], atol=2e-5, rtol=1e-5)
+  helpers.report('weights', weights, want['weights'], atol=2e-6, rtol=2e-5)
+  helpers.report('plane', plane, want['features'], atol=2e-5, rtol=2e-5)
+  assert float(plane[0, 0, 0].abs().max()) == 0.0
+  assert abs(float(weights[0, 1, 0].sum()) - 1.0) < 1e-6 and float(weights[0, 1, 0, Z // 3]) == 1.0
+
+
+def test_vertical_pooling_module_modes_match_oracle():
+  """The module-level API for every pooling mode, incl. 'mlp' (flatten (Z, D) -> MLP)."""
+  from oracle import bev as o_bev
+  from snap_amd.models import bev_mapper, types
+  from snap_amd.utils import config_dict
+  vol, valid, g = _volume(32, lead=(1, 6, 5), Z=12, D=32)
+  fv = types.FeatureVolume(features=vol.cuda(), valid=valid.cuda())
+  mlp_cfg = dict(layers=(64, 32), activation='relu', apply_input_activation=False)
+  for mode in ('max', 'sum', 'mean', 'softmax', 'weighted', 'mlp'):
+    cfg = config_dict.ConfigDict(dict(pooling=mode, mlp=mlp_cfg))
+    vp = bev_mapper.VerticalPooling(cfg, num_levels=12, feature_dim=32)
+    params = vp.init_params(torch.Generator().manual_seed(3), 'cpu')
+    pred = vp(helpers.params_to_device(params, 'cuda'), fv)
+    want = o_bev.vertical_pooling(cfg.to_dict(), vol.numpy(), valid.numpy(), helpers.params_to_numpy(params))
+    helpers.report(f'{mode} plane', pred['plane'].features, want['features'], atol=3e-5, rtol=3e-5)
+    helpers.report(f'{mode} valid', pred['plane'].valid, want['valid'], 0)
+    assert ('weights' in pred) == (mode in ('softmax', 'weighted'))
