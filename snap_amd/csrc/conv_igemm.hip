@@ -75,7 +75,7 @@ __device__ __forceinline__ float apply_pro(float v, float mu, float sc, float be
 }
 
 template <int BM, int BN, bool VEC, int PRO, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   constexpr int AS = BM + 2;    // LDS row stride of the K-major A slab
   constexpr int TM = BM / 64;   // 32x32 MFMA tiles per wave along M
   constexpr int TN = BN / 64;   // ... along N
@@ -497,6 +497,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+// Two entry points over one body.  Variants WITHOUT a GroupNorm prologue fit 128 VGPRs
+// and are held to 4 waves per SIMD (measured +3-4 % on the big Dense layers: more waves to
+// cover the global-load latency); the GroupNorm variants carry the statistics operands
+// and would spill at that budget, so they keep the default allocation (3 waves).
+template <int BM, int BN, bool VEC, int PRO, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  conv_igemm_body<BM, BN, VEC, PRO, BK>(a);
+}
+template <int BM, int BN, bool VEC, int PRO, int BK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv_igemm_kernel_occ4(const ConvArgs a) {
+  conv_igemm_body<BM, BN, VEC, PRO, BK>(a);
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(
     const float* __restrict__ partial, int S, int64_t M, int Cout, int Cout_stride, int epi,
     const float* __restrict__ bias, const float* __restrict__ residual,
@@ -584,8 +598,14 @@ int launch(ConvArgs a, hipStream_t s) {
       nblocks *= a.ksplit;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO, BK>), dim3((unsigned)nblocks), dim3(256),
-                     0, s, a);
+  constexpr bool kGn = PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN;
+  if constexpr (!kGn && BK == 16 && (VEC || BM * BN < 128 * 128)) {  // (scalar 128x128 would spill)
+    hipLaunchKernelGGL((conv_igemm_kernel_occ4<BM, BN, VEC, PRO, BK>), dim3((unsigned)nblocks),
+                       dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, VEC, PRO, BK>), dim3((unsigned)nblocks),
+                       dim3(256), 0, s, a);
+  }
   SNAP_CHECK_LAUNCH();
   if (a.ksplit > 1) {
     const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
