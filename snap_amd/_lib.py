@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsnap_hip.so')
+# SNAP_HIP_LIB: alternative build of the same ABI (A/B experiments); default = in-tree.
+LIB_PATH = os.environ.get('SNAP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libsnap_hip.so')
 
 c_int = ctypes.c_int32
 c_i64 = ctypes.c_int64
