@@ -196,8 +196,9 @@ typedef struct SnapLiftDesc {
   float max_view_distance;     /* < 0: disabled                                    */
 } SnapLiftDesc;
 
-/* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) pad(1) ALREADY scaled to
- * the feature-map resolution; Rt: [B,V,12] = R row-major (9) then t (3) of
+/* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) tan(max_fov/2)(1) ALREADY scaled to
+ * the feature-map resolution (the last entry is read by the fisheye path instead of
+ * evaluating tanf per voxel and view: geometry.py:262 `radius < tan(0.5 * max_fov)`); Rt: [B,V,12] = R row-major (9) then t (3) of
  * T_view2scene; points: [B,N,3].
  * pooled: [B,N,out_stride] = mean(fd) | var(fd) | score_max(1) | zero pad;
  * valid: [B,N] uint8. */

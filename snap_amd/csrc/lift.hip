@@ -66,7 +66,7 @@ __device__ __forceinline__ Proj project_one(const float* __restrict__ cam,
     dist = in_center ? 1.f : dist;
     x *= dist;
     y *= dist;
-    valid = valid && (in_center || ((radius < tanf(0.5f * cam[9])) && (dist > 0.f)));
+    valid = valid && (in_center || ((radius < cam[10]) && (dist > 0.f)));
   }
   x = x * cam[2] + cam[4];
   y = y * cam[3] + cam[5];

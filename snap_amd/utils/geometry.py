@@ -281,7 +281,9 @@ class FisheyeCamera(Camera):
     return p2d, visible & valid & self.in_image(p2d)
 
   def packed(self):
-    pad = torch.zeros(*self.shape, 1, dtype=self.wh.dtype, device=self.wh.device)
+    """[..., 11] = wh f c k_radial max_fov tan(max_fov / 2): the last entry saves the lift
+    kernels a tanf per (voxel, view)."""
+    tan_half = torch.tan(0.5 * self.max_fov)[..., None]
     return torch.cat(
-        [self.wh, self.f, self.c, self.k_radial, self.max_fov[..., None], pad], -1
+        [self.wh, self.f, self.c, self.k_radial, self.max_fov[..., None], tan_half], -1
     ).contiguous()
