@@ -110,6 +110,12 @@ SIGNATURES = {
         [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
          c_int, c_u64, ptr, ptr, ptr],
     ),
+    'snap_ransac_sample_workspace_bytes': (c_size, [c_int, c_int]),
+    'snap_ransac_sample_ws_f32': (
+        c_int,
+        [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+         c_int, c_u64, ptr, ptr, ptr, c_size, ptr],
+    ),
     'snap_poses_from_corr_f32': (
         c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr, ptr]
     ),

@@ -133,11 +133,36 @@ __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
   return v;
 }
 
+// one wave per (b, n): the row maximum M and, per lane l, the inclusive prefix over lanes of
+// the mass of lane l's chunk range (w_c = s_c * exp(m_c - M)) -- exactly the quantities the
+// sampler used to rebuild per SAMPLE (2 passes over the row's statistics, 2 x cpl expf, a
+// wave max and a wave scan).  ~34 samples share a row at C2; with this table a sample reads 64
+// floats and only the selected lane re-evaluates its own chunks.  Bit-identical samples.
+__global__ __launch_bounds__(256) void chunk_prefix_kernel(const float* __restrict__ stats,
+                                                           int64_t rows, int NC,
+                                                           float* __restrict__ lane_incl,
+                                                           float* __restrict__ rowmax) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* st = stats + row * NC * 2;
+  const int cpl = (NC + 63) / 64;
+  const int cb = lane * cpl, ce = min(cb + cpl, NC);
+  float M = -INFINITY;
+  for (int c = cb; c < ce; ++c) M = fmaxf(M, st[2 * c]);
+  M = wave_max(M);
+  float local = 0.f;
+  for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
+  lane_incl[row * 64 + lane] = wave_scan_incl(local, lane);
+  if (lane == 0) rowmax[row] = M;
+}
+
 template <int DM>
 __global__ __launch_bounds__(256) void ransac_sample_kernel(
     const float* __restrict__ fq, const float* __restrict__ fm, const float* __restrict__ stats,
     int Nq, int X, int Y, float scale, int clip, int S, uint64_t seed,
-    const float* __restrict__ uniforms, int32_t* __restrict__ corr) {
+    const float* __restrict__ uniforms, int32_t* __restrict__ corr,
+    const float* __restrict__ lane_incl, const float* __restrict__ rowmax) {
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -161,12 +186,18 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
   // level 1: pick the chunk.  lane l owns the contiguous chunk range [l*cpl, (l+1)*cpl).
   const int cpl = (NC + 63) / 64;
   const int cb = lane * cpl, ce = min(cb + cpl, NC);
-  float M = -INFINITY;
-  for (int c = cb; c < ce; ++c) M = fmaxf(M, st[2 * c]);
-  M = wave_max(M);
-  float local = 0.f;
-  for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
-  const float incl = wave_scan_incl(local, lane);
+  float M, local = 0.f, incl;
+  const bool table = lane_incl != nullptr;
+  if (table) {                   // per-row prefix table (chunk_prefix_kernel)
+    M = rowmax[row];
+    incl = lane_incl[row * 64 + lane];
+  } else {
+    M = -INFINITY;
+    for (int c = cb; c < ce; ++c) M = fmaxf(M, st[2 * c]);
+    M = wave_max(M);
+    for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
+    incl = wave_scan_incl(local, lane);
+  }
   const float total = __shfl(incl, 63, 64);
   const float target = u2 * total;
   unsigned long long bal = __ballot(incl > target && ce > cb);
@@ -181,6 +212,8 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
   int cstar = 0;
   float resid = 0.f;
   if (lane == L) {
+    if (table)                   // only the selected lane re-evaluates its own chunk masses
+      for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
     float run = incl - local;
     cstar = ce - 1;
     resid = 0.f;
@@ -747,15 +780,40 @@ extern "C" int snap_ransac_sample_f32(const float* fq, const float* fm, const fl
                                       int32_t B, int32_t Nq, int32_t X, int32_t Y, int32_t Dm,
                                       float scale, int32_t clip_negative, int32_t S, uint64_t seed,
                                       const float* uniforms, int32_t* corr, void* stream) {
+  return snap_ransac_sample_ws_f32(fq, fm, chunk_stats, B, Nq, X, Y, Dm, scale, clip_negative, S,
+                                   seed, uniforms, corr, nullptr, 0, stream);
+}
+
+extern "C" size_t snap_ransac_sample_workspace_bytes(int32_t B, int32_t Nq) {
+  return (size_t)B * Nq * 65 * sizeof(float);   // 64 lane prefixes + the row maximum
+}
+
+extern "C" int snap_ransac_sample_ws_f32(const float* fq, const float* fm, const float* chunk_stats,
+                                         int32_t B, int32_t Nq, int32_t X, int32_t Y, int32_t Dm,
+                                         float scale, int32_t clip_negative, int32_t S,
+                                         uint64_t seed, const float* uniforms, int32_t* corr,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
   if (!fq || !fm || !chunk_stats || !corr) return SNAP_ERR_NULL;
   if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || S <= 0) return SNAP_ERR_BAD_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  float* lane_incl = nullptr;
+  float* rowmax = nullptr;
+  if (workspace) {
+    if (workspace_bytes < snap_ransac_sample_workspace_bytes(B, Nq)) return SNAP_ERR_WORKSPACE;
+    const int64_t rows = (int64_t)B * Nq;
+    lane_incl = static_cast<float*>(workspace);
+    rowmax = lane_incl + rows * 64;
+    const int NC = (X * Y + SIM_CH - 1) / SIM_CH;
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)snap_cdiv(rows, 4)), dim3(256), 0, s,
+                       chunk_stats, rows, NC, lane_incl, rowmax);
+    SNAP_CHECK_LAUNCH();
+  }
   const dim3 grid((unsigned)snap_cdiv(S, 4), (unsigned)B);
   switch (Dm) {
-    case 8: hipLaunchKernelGGL(ransac_sample_kernel<8>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
-    case 16: hipLaunchKernelGGL(ransac_sample_kernel<16>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
-    case 32: hipLaunchKernelGGL(ransac_sample_kernel<32>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
-    case 64: hipLaunchKernelGGL(ransac_sample_kernel<64>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr); break;
+    case 8: hipLaunchKernelGGL(ransac_sample_kernel<8>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
+    case 16: hipLaunchKernelGGL(ransac_sample_kernel<16>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
+    case 32: hipLaunchKernelGGL(ransac_sample_kernel<32>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
+    case 64: hipLaunchKernelGGL(ransac_sample_kernel<64>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
     default: return SNAP_ERR_UNSUPPORTED;
   }
   SNAP_CHECK_LAUNCH();

@@ -567,8 +567,9 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
 
 
 def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
-                  uniforms=None):
-  """Draw S correspondences per scene ~ prob_points.  Returns int32 [B,S,3]."""
+                  uniforms=None, row_table=True):
+  """Draw S correspondences per scene ~ prob_points.  Returns int32 [B,S,3].
+  row_table=False takes the table-free path (same samples; tests compare the two)."""
   lib = _lib.load()
   _f32(fq, 'fq'); _f32(fm, 'fm'); _f32(chunk_stats, 'chunk_stats')
   B, Nq, Dm = fq.shape
@@ -578,13 +579,17 @@ def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
     if tuple(uniforms.shape) != (B, S, 2):
       raise ValueError('ransac_sample: uniforms must be [B,S,2]')
   corr = torch.empty((B, S, 3), dtype=torch.int32, device=fq.device)
+  ws = None
+  if row_table:
+    ws = torch.empty(lib.snap_ransac_sample_workspace_bytes(B, Nq) // 4, dtype=torch.float32,
+                     device=fq.device)
   with _region('ransac_sample', 0.0, 12.0 * B * S):
-    st = lib.snap_ransac_sample_f32(
+    st = lib.snap_ransac_sample_ws_f32(
         _p(fq), _p(fm), _p(chunk_stats), B, Nq, X, Y, Dm, float(scale),
         int(clip_negative), S, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(uniforms),
-        _p(corr), _stream(),
+        _p(corr), _p(ws), 0 if ws is None else ws.numel() * 4, _stream(),
     )
-  _lib.check(st, 'snap_ransac_sample_f32')
+  _lib.check(st, 'snap_ransac_sample_ws_f32')
   return corr
 
 

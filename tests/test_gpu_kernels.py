@@ -640,3 +640,21 @@ def test_vertical_pooling_module_modes_match_oracle():
     helpers.report(f'{mode} plane', pred['plane'].features, want['features'], atol=3e-5, rtol=3e-5)
     helpers.report(f'{mode} valid', pred['plane'].valid, want['valid'], 0)
     assert ('weights' in pred) == (mode in ('softmax', 'weighted'))
+
+
+@pytest.mark.parametrize('X,Y,Nq', [(24, 20, 40), (128, 128, 300), (9, 7, 5)])
+def test_ransac_row_table_gives_identical_samples(X, Y, Nq):
+  """The per-row prefix table is a pure speed path: same correspondences, bit for bit."""
+  B, Dm, S = 2, 32, 4000
+  fq = _unit(rnd((B, Nq, Dm), 195)).to(DEV)
+  fm = _unit(rnd((B, X, Y, Dm), 196)).to(DEV)
+  nv = torch.full((B,), float(Nq)).to(DEV)
+  scale = float(np.exp(2.0))
+  _, stats, _, _ = ops.sim_softmax(fq, fm, scale, True, nv)
+  a = ops.ransac_sample(fq, fm, stats, scale, True, S, seed=77, row_table=True)
+  b = ops.ransac_sample(fq, fm, stats, scale, True, S, seed=77, row_table=False)
+  assert torch.equal(a, b)
+  u = torch.rand((B, S, 2), generator=torch.Generator().manual_seed(5)).to(DEV)
+  a = ops.ransac_sample(fq, fm, stats, scale, True, S, uniforms=u, row_table=True)
+  b = ops.ransac_sample(fq, fm, stats, scale, True, S, uniforms=u, row_table=False)
+  assert torch.equal(a, b)
