@@ -19,6 +19,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int SIM_CH = 64;  // cells per softmax chunk == one wave
 constexpr int SIM_TQ = 64;  // query rows per workgroup tile
 
@@ -41,43 +43,53 @@ __global__ __launch_bounds__(256) void sim_kernel(
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int NC = (XY + SIM_CH - 1) / SIM_CH;
   const bool cvalid = cell < XY;
+  // query rows staged K-MAJOR ([k][row]) so that two consecutive rows of one k are an
+  // aligned 8-byte pair: the dot products of TWO rows advance with one v_pk_fma_f32.
   for (int i = threadIdx.x; i < SIM_TQ * DM; i += 256) {
-    const int r = i / DM;
-    q_s[i] = (n0 + r < Nq) ? fq[((int64_t)b * Nq + n0) * DM + i] : 0.f;
+    const int r = i / DM, k = i - r * DM;
+    q_s[k * SIM_TQ + r] = (n0 + r < Nq) ? fq[((int64_t)b * Nq + n0) * DM + i] : 0.f;
   }
-  float mv[DM];
+  f32x2 mv[DM];
   if (cvalid) {
     const f32x4* src = reinterpret_cast<const f32x4*>(fm + ((int64_t)b * XY + cell) * DM);
 #pragma unroll
     for (int k = 0; k < DM / 4; ++k) {
       const f32x4 t = src[k];
-      mv[4 * k + 0] = t[0]; mv[4 * k + 1] = t[1]; mv[4 * k + 2] = t[2]; mv[4 * k + 3] = t[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mv[4 * k + e] = f32x2{t[e], t[e]};
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < DM; ++k) mv[k] = 0.f;
+    for (int k = 0; k < DM; ++k) mv[k] = f32x2{0.f, 0.f};
   }
   __syncthreads();
   const float nv = num_valid[b];
   const int rows = min(SIM_TQ, Nq - n0);
-  for (int r = 0; r < rows; ++r) {
-    const int64_t row = (int64_t)b * Nq + n0 + r;
-    float dot = 0.f;
+  for (int r0 = 0; r0 < rows; r0 += 2) {
+    f32x2 dot2 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < DM; ++k) dot = fmaf(q_s[r * DM + k], mv[k], dot);
-    float x = clip ? fmaxf(dot, 0.f) : dot;
-    x *= scale;
-    if (MODE == 0) {
-      if (cvalid) sim[row * XY + cell] = x / nv;
-      const float m = wave_max(cvalid ? x : -INFINITY);
-      const float s = wave_sum(cvalid ? expf(x - m) : 0.f);
-      if (lane == 0 && chunk < NC) {
-        stats[(row * NC + chunk) * 2 + 0] = m;
-        stats[(row * NC + chunk) * 2 + 1] = s;
+    for (int k = 0; k < DM; ++k)   // per component the same k-ordered fmaf chain as before
+      dot2 = __builtin_elementwise_fma(*reinterpret_cast<const f32x2*>(q_s + k * SIM_TQ + r0), mv[k], dot2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = r0 + h;
+      if (r >= rows) break;
+      const int64_t row = (int64_t)b * Nq + n0 + r;
+      const float dot = h ? dot2.y : dot2.x;
+      float x = clip ? fmaxf(dot, 0.f) : dot;
+      x *= scale;
+      if (MODE == 0) {
+        if (cvalid) sim[row * XY + cell] = x / nv;
+        const float m = wave_max(cvalid ? x : -INFINITY);
+        const float s = wave_sum(cvalid ? expf(x - m) : 0.f);
+        if (lane == 0 && chunk < NC) {
+          stats[(row * NC + chunk) * 2 + 0] = m;
+          stats[(row * NC + chunk) * 2 + 1] = s;
+        }
+      } else {
+        const float M = rowstats[row * 2 + 0], T = rowstats[row * 2 + 1];
+        if (cvalid) prob[row * XY + cell] = (expf(x - M) / T) / nv;
       }
-    } else {
-      const float M = rowstats[row * 2 + 0], T = rowstats[row * 2 + 1];
-      if (cvalid) prob[row * XY + cell] = (expf(x - M) / T) / nv;
     }
   }
 }
@@ -467,7 +479,6 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_kernel(const ScoreArgs 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void global_void_t;
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float uniform_f(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
