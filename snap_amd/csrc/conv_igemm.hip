@@ -58,7 +58,7 @@ struct ConvArgs {
   int nk;      // number of K slabs
   int prio;    // experiment knob: s_setprio(1) around the MFMA block
   int ncol;    // number of column tiles (set in launch<>)
-  int ablate;  // tuning-only: bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads
+  int ablate;  // tuning-only: bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
 };
 
 
@@ -183,6 +183,24 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     kw = kpos - kh * d.KW;
   }
 
+  // Per-tap state of the VEC loader: whether row i's (kh, kw) tap is inside the image and the
+  // pointer to its channel 0.  Recomputed only when the walk moves to the next tap (once per
+  // Cin/BK slabs; never again for 1x1 convs) instead of in every slab.
+  const float* tap_px[VEC ? AROWS : 1];
+  bool tap_in[VEC ? AROWS : 1];
+  auto set_tap = [&]() {
+    if constexpr (VEC) {
+      const int64_t delta = ((int64_t)kh * d.W + kw) * d.Cin_stride;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int hi = r_hb[i] + kh, wi = r_wb[i] + kw;
+        tap_in[i] = r_ok[i] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+        tap_px[i] = r_px[i] + delta;
+      }
+    }
+  };
+  set_tap();
+
   auto load_slab = [&](int kt) {
     if constexpr (VEC) {
       const int c = ct * BK + 4 * akq;
@@ -191,14 +209,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
       // Loads are unconditional from a clamped (always mapped) address; invalid
       // lanes are zeroed when the slab is stored.  No divergent branches.
       if constexpr (need_gn) xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
-      // element offset of (kh, kw, c) relative to a row's base pixel
-      const int64_t delta = ((int64_t)kh * d.W + kw) * d.Cin_stride + c;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
-        const int hi = r_hb[i] + kh, wi = r_wb[i] + kw;
-        const bool inb = r_ok[i] && cvalid && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+        // (kh, kw) bounds test and tap pointer are per-TAP state (set_tap), not per slab
+        const bool inb = tap_in[i] && cvalid;
         xin[i] = inb;
-        const float* px = inb ? r_px[i] + delta : a.x;
+        const float* px = inb ? tap_px[i] + c : a.x;
         xa[i] = *reinterpret_cast<const f32x4*>(px);
         if constexpr (need_gn) {
           const int64_t so = inb ? r_gn[i] + c : (int64_t)0;
@@ -263,6 +279,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         ct = 0;
         ++kpos;
         if (++kw == d.KW) { kw = 0; ++kh; }
+        set_tap();
       }
     }
   };
@@ -359,7 +376,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     if (a.prio) __builtin_amdgcn_s_setprio(0);
     if (!(a.ablate & 2)) {
       if (more) store_slab(cur ^ 1);
-      __syncthreads();
+      if (!(a.ablate & 8)) __syncthreads();   // bit3: keep the stores, drop only the barrier
     }
   }
 

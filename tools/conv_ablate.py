@@ -18,7 +18,7 @@ for name, N, H, W, Cin, k, Cout in shapes:
   w = torch.randn(k, k, Cin, Cout, device='cuda') * 0.05
   mu = torch.zeros(N, Cin, device='cuda'); sc = torch.ones(N, Cin, device='cuda'); beta = torch.zeros(Cin, device='cuda')
   for pro in (0, 2):
-    for ab in (0, 1, 2, 3, 7):
+    for ab in (0, 1, 2, 8, 9, 3):
       os.environ['SNAP_CONV_ABLATE'] = str(ab)
       pad = ((k // 2, k // 2), (k // 2, k // 2))
       kw = dict(padding=pad, prologue=pro, gn=(mu, sc, beta) if pro else None)
