@@ -264,6 +264,11 @@ def main(argv=None):
 
   for i in range(args.warmup):
     step(i)
+  # a generational GC pass over the Python heap in the middle of the loop costs 100+ ms
+  # (seen as one 280 ms step in an otherwise 56 ms run): collect now, pause it while timing
+  import gc
+  gc.collect()
+  gc.disable()
   barrier()
   prof = None
   marks = []
@@ -284,6 +289,7 @@ def main(argv=None):
     marks.append(ev)
   barrier()
   elapsed = time.perf_counter() - t0
+  gc.enable()
   step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
   t = torch.tensor([elapsed], dtype=torch.float64, device=device)
   if world > 1:
@@ -304,7 +310,7 @@ def main(argv=None):
         'ms_per_step': round(ms_per_step, 3),
         'step_ms': {
             'min': round(min(step_ms), 3), 'median': round(float(np.median(step_ms)), 3),
-            'max': round(max(step_ms), 3),
+            'max': round(max(step_ms), 3), 'argmax': int(np.argmax(step_ms)),
         } if step_ms else None,
         'higher_is_better': True,
         'scaling': 'weak',
