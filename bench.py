@@ -262,8 +262,15 @@ def main(argv=None):
       dist.barrier()
     _sync(device)
 
+  # Warm-up and timed steps follow the SAME allocation pattern (result dropped before the next
+  # step starts): the caching allocator then reaches its steady state in the first warm-up
+  # step.  Holding the previous result across a step made the allocator fetch fresh 7.5 GiB
+  # segments in the middle of the timed loop (hipMalloc of that size: ~200 ms, seen as one
+  # 280 ms step in an otherwise 56 ms run).
+  pred = None
   for i in range(args.warmup):
-    step(i)
+    pred = None
+    pred = step(i)
   # a generational GC pass over the Python heap in the middle of the loop costs 100+ ms
   # (seen as one 280 ms step in an otherwise 56 ms run): collect now, pause it while timing
   import gc
@@ -281,6 +288,7 @@ def main(argv=None):
       ev = torch.cuda.Event(enable_timing=True)
       ev.record()
       marks.append(ev)
+    pred = None
     pred = step(args.warmup + i)
   ops.set_profiler(None)
   if use_cuda:

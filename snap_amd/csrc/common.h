@@ -18,6 +18,7 @@
 static inline int64_t snap_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Wave-level reductions over all 64 lanes; the (bitwise identical) result lands in every

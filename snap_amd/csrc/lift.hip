@@ -16,6 +16,8 @@
 // Replaces snap/models/streetview_encoder.py:42-65 (project), :127-138 (select),
 // :69-105 (gather), :109-124 (depth score), :141-178 (pool) and the camera maths
 // of snap/utils/geometry.py:52-69,198-221,260-280.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -82,6 +84,7 @@ __device__ __forceinline__ Proj project_one(const float* __restrict__ cam,
 struct Taps {
   int i0, i1, j0, j1;
   float w00, w01, w10, w11;
+  float wi1, wj1;   // the 1-D weights the four products are built from
 };
 
 // selective != 0: streetview_encoder.py:93-105 (clip the point, floor, +1);
@@ -104,6 +107,8 @@ __device__ __forceinline__ Taps make_taps(float pi, float pj, int h, int w, int 
   t.w01 = wi0 * wj1;
   t.w10 = wi1 * wj0;
   t.w11 = wi1 * wj1;
+  t.wi1 = wi1;
+  t.wj1 = wj1;
   return t;
 }
 
@@ -265,6 +270,211 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Batched variant (nsel <= 4): a half-wave owns 32 CONSECUTIVE voxels.
+//   phase A  lane j <-> voxel j: project it into the views, select, and build the tap record
+//            of each selected view (tap offset, clamp flags, 1-D weights, depth bins) -- the scalar
+//            per-voxel geometry now runs once per voxel on a full lane set instead of once per
+//            voxel with 4 of 32 lanes doing useful work (it was ~60 % of the kernel's VALU
+//            issue; the kernel is VALU-bound, PMC r01).  Records go to LDS (32 B each).
+//   phase B  for each of the 32 voxels: lane q <-> channels 4q..4q+3: broadcast-read the
+//            records, gather the taps, pool.  Same arithmetic as lift_pool_kernel, same bits.
+// ---------------------------------------------------------------------------
+constexpr int LB_REC = 8;    // dwords per (voxel, slot) record: o00 | packed | wi1 | wj1 | wb1
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a) {
+  __shared__ __attribute__((aligned(16))) int recs[8][32][KMAX][LB_REC];
+  __shared__ float hdr[8][32][2];   // (scene, min_dist) per voxel
+  const SnapLiftDesc& d = a.d;
+  const int hl = threadIdx.x & 31;
+  const int hw = threadIdx.x >> 5;
+  const int64_t total = (int64_t)d.B * d.N;
+  const int64_t gv0 = ((int64_t)blockIdx.x * 8 + hw) * 32;
+  const int fd = d.feature_dim;
+  const int nq = fd >> 2;
+  const bool all_views = d.K == 0;
+  const int nsel = all_views ? d.V : d.K;
+  const float log_range = logf(d.depth_max / d.depth_min);
+
+  // ---------------- phase A: lane = voxel ----------------
+  {
+    const int64_t gv = gv0 + hl;
+    const bool live = gv < total;
+    const int b = live ? (int)(gv / d.N) : 0;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (live) {
+      const float* p = a.pts + gv * 3;
+      px = p[0]; py = p[1]; pz = p[2];
+    }
+    // selected views, ascending (visible distance, view index); invisible views never
+    // contribute (ok = false in the pooling), so only visible ones are kept.
+    float kd[KMAX], kpi[KMAX], kpj[KMAX], kdep[KMAX];
+    int kv[KMAX];
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) { kd[r] = INFINITY; kpi[r] = kpj[r] = kdep[r] = 0.f; kv[r] = -1; }
+    float min_dist = INFINITY;
+    for (int v = 0; v < d.V; ++v) {
+      const Proj pr = project_one(a.cam + ((int64_t)b * d.V + v) * 11,
+                                  a.Rt + ((int64_t)b * d.V + v) * 12, px, py, pz, d.fisheye);
+      const bool vis = live && pr.vis;
+      if (all_views) {
+        // slot v <-> view v
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r)
+          if (r == v) { kv[r] = vis ? v : -1; kpi[r] = pr.pi; kpj[r] = pr.pj; kdep[r] = pr.depth; }
+        if (vis) min_dist = fminf(min_dist, pr.dist);
+      } else if (vis) {
+        // stable insertion (strict <): equal distances keep the lower view index first
+        float cd = pr.dist, cpi = pr.pi, cpj = pr.pj, cdep = pr.depth;
+        int cv = v;
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) {
+          if (r < nsel && cd < kd[r]) {
+            const float td = kd[r], tpi = kpi[r], tpj = kpj[r], tdep = kdep[r];
+            const int tv = kv[r];
+            kd[r] = cd; kpi[r] = cpi; kpj[r] = cpj; kdep[r] = cdep; kv[r] = cv;
+            cd = td; cpi = tpi; cpj = tpj; cdep = tdep; cv = tv;
+          }
+        }
+      }
+    }
+    if (!all_views) min_dist = kd[0];
+    hdr[hw][hl][0] = __int_as_float(b);
+    hdr[hw][hl][1] = min_dist;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      int* rec = recs[hw][hl][r];
+      if (r >= nsel || kv[r] < 0) { rec[1] = -1; continue; }
+      const Taps t = make_taps(kpi[r], kpj[r], d.h, d.w, all_views ? 0 : 1);
+      // depth score: two neighbouring log-depth bins
+      const float dc = fminf(fmaxf(kdep[r], d.depth_min), d.depth_max);
+      const float tt = logf(dc / d.depth_min) / log_range;
+      const float index = 0.5f + tt * (float)(d.num_bins - 1);
+      const float c = index - 0.5f;
+      const float fl = floorf(c);
+      const int b0 = (int)fminf(fmaxf(fl, 0.f), (float)(d.num_bins - 1));
+      const int b1 = (int)fminf(fmaxf(fl + 1.f, 0.f), (float)(d.num_bins - 1));
+      rec[0] = (t.i0 * d.w + t.j0) * d.C;
+      rec[1] = kv[r] | ((t.i1 != t.i0) << 8) | ((t.j1 != t.j0) << 9) | (b0 << 10) | (b1 << 18);
+      rec[2] = __float_as_int(t.wi1);
+      rec[3] = __float_as_int(t.wj1);
+      rec[4] = __float_as_int(c - fl);
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase B: lane = channel quad ----------------
+  const int64_t vstride = (int64_t)d.h * d.w * d.C;
+  for (int j = 0; j < 32; ++j) {
+    const int64_t gv = gv0 + j;
+    if (gv >= total) break;   // half-wave uniform
+    const int b = __float_as_int(hdr[hw][j][0]);
+    const float min_dist = hdr[hw][j][1];
+    f32x4 feat[KMAX];
+    float score[KMAX];
+    bool ok[KMAX];
+    bool any = false;
+    // pass 1: issue the tap loads of EVERY visible slot before any of them is consumed, so
+    // a voxel has up to 4 x (4 rows + 8 bin scalars) loads in flight instead of one slot's.
+    f32x4 t00[KMAX], t01[KMAX], t10[KMAX], t11[KMAX];
+    float sb[KMAX][8];
+    float wi1s[KMAX], wj1s[KMAX], wb1s[KMAX];
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      ok[r] = false;
+      t00[r] = t01[r] = t10[r] = t11[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sb[r][e] = 0.f;
+      wi1s[r] = wj1s[r] = wb1s[r] = 0.f;
+      if (r >= nsel) continue;
+      const int* rec = recs[hw][j][r];
+      const i32x4 q4 = *reinterpret_cast<const i32x4*>(rec);   // o00 | packed | wi1 | wj1
+      const int pk = q4[1];
+      if (pk < 0) continue;    // half-wave uniform
+      ok[r] = true;
+      any = true;
+      const int v = pk & 0xff;
+      wi1s[r] = __int_as_float(q4[2]);
+      wj1s[r] = __int_as_float(q4[3]);
+      wb1s[r] = __int_as_float(rec[4]);
+      const int dj = ((pk >> 9) & 1) * d.C, di = ((pk >> 8) & 1) * d.w * d.C;
+      const float* r00 = a.f + ((int64_t)b * d.V + v) * vstride + q4[0];
+      const float* r01 = r00 + dj;
+      const float* r10 = r00 + di;
+      const float* r11 = r10 + dj;
+      if (hl < nq) {
+        t00[r] = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
+        t01[r] = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
+        t10[r] = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
+        t11[r] = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
+      }
+      const int c0 = fd + ((pk >> 10) & 0xff), c1 = fd + ((pk >> 18) & 0xff);
+      sb[r][0] = r00[c0]; sb[r][1] = r01[c0]; sb[r][2] = r10[c0]; sb[r][3] = r11[c0];
+      sb[r][4] = r00[c1]; sb[r][5] = r01[c1]; sb[r][6] = r10[c1]; sb[r][7] = r11[c1];
+    }
+    // pass 2: blend
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      feat[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      score[r] = 0.f;
+      if (!ok[r]) continue;
+      const float wi1 = wi1s[r], wj1 = wj1s[r];
+      const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
+      const float w00 = wi0 * wj0, w01 = wi0 * wj1, w10 = wi1 * wj0, w11 = wi1 * wj1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        feat[r][e] = ((w00 * t00[r][e] + w01 * t01[r][e]) + w10 * t10[r][e]) + w11 * t11[r][e];
+      const float wb1 = wb1s[r], wb0 = 1.f - wb1;
+      const float s0 = ((w00 * sb[r][0] + w01 * sb[r][1]) + w10 * sb[r][2]) + w11 * sb[r][3];
+      const float s1 = ((w00 * sb[r][4] + w01 * sb[r][5]) + w10 * sb[r][6]) + w11 * sb[r][7];
+      score[r] = wb0 * s0 + wb1 * s1;
+    }
+    float* out = a.pooled + gv * d.out_stride;
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, var = {0.f, 0.f, 0.f, 0.f};
+    float smax = 0.f;
+    if (any) {
+      float m = 0.f;
+      smax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (ok[r]) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
+      float e[KMAX], den = 0.f;
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r) {
+        e[r] = ok[r] ? expf(score[r] - m) : 0.f;
+        den += e[r];
+      }
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r) {
+        const float wgt = e[r] / den;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mean[c] += wgt * feat[r][c];
+      }
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r) {
+        const float wgt = e[r] / den;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float dl = feat[r][c] - mean[c];
+          var[c] += wgt * (dl * dl);
+        }
+      }
+    }
+    if (hl < nq) {
+      *reinterpret_cast<f32x4*>(out + 4 * hl) = mean;
+      *reinterpret_cast<f32x4*>(out + fd + 4 * hl) = var;
+    }
+    if (hl == 0) {
+      out[2 * fd] = smax;
+      for (int c = 2 * fd + 1; c < d.out_stride; ++c) out[c] = 0.f;
+      bool vld = any;
+      if (d.max_view_distance >= 0.f && !all_views) vld = vld && (min_dist <= d.max_view_distance);
+      a.valid[gv] = vld ? 1 : 0;
+    }
+  }
+}
+
 __global__ void project_points_kernel(int B, int V, int N, int fisheye,
                                       const float* __restrict__ cam, const float* __restrict__ Rt,
                                       const float* __restrict__ pts, float* __restrict__ p2d,
@@ -305,7 +515,16 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   const int64_t total = (int64_t)d.B * d.N;
   const dim3 grid((unsigned)snap_cdiv(total, 8));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (nsel <= 1) {
+  static const bool batched = []() {
+    const char* e = getenv("SNAP_LIFT_BATCHED");   // 0 = one voxel per half-wave (v1 kernel)
+    return !(e && e[0] == '0');
+  }();
+  const dim3 bgrid((unsigned)snap_cdiv(total, 256));   // 8 half-waves x 32 voxels
+  if (batched && nsel <= 1) {
+    hipLaunchKernelGGL(lift_pool_batched_kernel<1>, bgrid, dim3(256), 0, s, a);
+  } else if (batched && nsel <= 4) {
+    hipLaunchKernelGGL(lift_pool_batched_kernel<4>, bgrid, dim3(256), 0, s, a);
+  } else if (nsel <= 1) {
     hipLaunchKernelGGL(lift_pool_kernel<1>, grid, dim3(256), 0, s, a);
   } else if (nsel <= 4) {
     hipLaunchKernelGGL(lift_pool_kernel<4>, grid, dim3(256), 0, s, a);
