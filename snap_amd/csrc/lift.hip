@@ -371,69 +371,57 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
     if (gv >= total) break;   // half-wave uniform
     const int b = __float_as_int(hdr[hw][j][0]);
     const float min_dist = hdr[hw][j][1];
+    // Per visible slot: gather + blend right away (16 live tap registers, not 64: occupancy
+    // matters more here than loads in flight per wave).  Nothing is zero-initialised and every
+    // use is guarded by ok[r]; voxels seen by ONE view skip the softmax (weight e/e == 1
+    // exactly: mean = f, var = 0, same bits) -- the common case.
     f32x4 feat[KMAX];
     float score[KMAX];
     bool ok[KMAX];
-    bool any = false;
-    // pass 1: issue the tap loads of EVERY visible slot before any of them is consumed, so
-    // a voxel has up to 4 x (4 rows + 8 bin scalars) loads in flight instead of one slot's.
-    f32x4 t00[KMAX], t01[KMAX], t10[KMAX], t11[KMAX];
-    float sb[KMAX][8];
-    float wi1s[KMAX], wj1s[KMAX], wb1s[KMAX];
+    int nvis = 0;
 #pragma unroll
     for (int r = 0; r < KMAX; ++r) {
       ok[r] = false;
-      t00[r] = t01[r] = t10[r] = t11[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sb[r][e] = 0.f;
-      wi1s[r] = wj1s[r] = wb1s[r] = 0.f;
       if (r >= nsel) continue;
       const int* rec = recs[hw][j][r];
       const i32x4 q4 = *reinterpret_cast<const i32x4*>(rec);   // o00 | packed | wi1 | wj1
       const int pk = q4[1];
       if (pk < 0) continue;    // half-wave uniform
       ok[r] = true;
-      any = true;
+      ++nvis;
       const int v = pk & 0xff;
-      wi1s[r] = __int_as_float(q4[2]);
-      wj1s[r] = __int_as_float(q4[3]);
-      wb1s[r] = __int_as_float(rec[4]);
+      const float wi1 = __int_as_float(q4[2]), wj1 = __int_as_float(q4[3]);
+      const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
+      const float w00 = wi0 * wj0, w01 = wi0 * wj1, w10 = wi1 * wj0, w11 = wi1 * wj1;
       const int dj = ((pk >> 9) & 1) * d.C, di = ((pk >> 8) & 1) * d.w * d.C;
       const float* r00 = a.f + ((int64_t)b * d.V + v) * vstride + q4[0];
       const float* r01 = r00 + dj;
       const float* r10 = r00 + di;
       const float* r11 = r10 + dj;
       if (hl < nq) {
-        t00[r] = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
-        t01[r] = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
-        t10[r] = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
-        t11[r] = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
+        const f32x4 a00 = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
+        const f32x4 a01 = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
+        const f32x4 a10 = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
+        const f32x4 a11 = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          feat[r][e] = ((w00 * a00[e] + w01 * a01[e]) + w10 * a10[e]) + w11 * a11[e];
       }
+      const float wb1 = __int_as_float(rec[4]), wb0 = 1.f - wb1;
       const int c0 = fd + ((pk >> 10) & 0xff), c1 = fd + ((pk >> 18) & 0xff);
-      sb[r][0] = r00[c0]; sb[r][1] = r01[c0]; sb[r][2] = r10[c0]; sb[r][3] = r11[c0];
-      sb[r][4] = r00[c1]; sb[r][5] = r01[c1]; sb[r][6] = r10[c1]; sb[r][7] = r11[c1];
-    }
-    // pass 2: blend
-#pragma unroll
-    for (int r = 0; r < KMAX; ++r) {
-      feat[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-      score[r] = 0.f;
-      if (!ok[r]) continue;
-      const float wi1 = wi1s[r], wj1 = wj1s[r];
-      const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
-      const float w00 = wi0 * wj0, w01 = wi0 * wj1, w10 = wi1 * wj0, w11 = wi1 * wj1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        feat[r][e] = ((w00 * t00[r][e] + w01 * t01[r][e]) + w10 * t10[r][e]) + w11 * t11[r][e];
-      const float wb1 = wb1s[r], wb0 = 1.f - wb1;
-      const float s0 = ((w00 * sb[r][0] + w01 * sb[r][1]) + w10 * sb[r][2]) + w11 * sb[r][3];
-      const float s1 = ((w00 * sb[r][4] + w01 * sb[r][5]) + w10 * sb[r][6]) + w11 * sb[r][7];
+      const float s0 = ((w00 * r00[c0] + w01 * r01[c0]) + w10 * r10[c0]) + w11 * r11[c0];
+      const float s1 = ((w00 * r00[c1] + w01 * r01[c1]) + w10 * r10[c1]) + w11 * r11[c1];
       score[r] = wb0 * s0 + wb1 * s1;
     }
     float* out = a.pooled + gv * d.out_stride;
     f32x4 mean = {0.f, 0.f, 0.f, 0.f}, var = {0.f, 0.f, 0.f, 0.f};
     float smax = 0.f;
-    if (any) {
+    if (nvis == 1) {          // half-wave uniform
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (ok[r]) { mean = feat[r]; smax = score[r]; }
+    } else if (nvis > 1) {
+      // jax.nn.softmax(..., where=valid, initial=0): shift = max(0, max valid score).
       float m = 0.f;
       smax = -INFINITY;
 #pragma unroll
@@ -442,22 +430,25 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
       float e[KMAX], den = 0.f;
 #pragma unroll
       for (int r = 0; r < KMAX; ++r) {
-        e[r] = ok[r] ? expf(score[r] - m) : 0.f;
-        den += e[r];
+        e[r] = 0.f;
+        if (ok[r]) e[r] = expf(score[r] - m);
+        den += e[r];             // (+0 for the invisible slots: same sum as the masked form)
+      }
+      float wgt[KMAX];
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r) {
+        if (!ok[r]) continue;
+        wgt[r] = e[r] / den;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mean[c] += wgt[r] * feat[r][c];
       }
 #pragma unroll
       for (int r = 0; r < KMAX; ++r) {
-        const float wgt = e[r] / den;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mean[c] += wgt * feat[r][c];
-      }
-#pragma unroll
-      for (int r = 0; r < KMAX; ++r) {
-        const float wgt = e[r] / den;
+        if (!ok[r]) continue;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float dl = feat[r][c] - mean[c];
-          var[c] += wgt * (dl * dl);
+          var[c] += wgt[r] * (dl * dl);
         }
       }
     }
@@ -468,7 +459,7 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
     if (hl == 0) {
       out[2 * fd] = smax;
       for (int c = 2 * fd + 1; c < d.out_stride; ++c) out[c] = 0.f;
-      bool vld = any;
+      bool vld = nvis > 0;
       if (d.max_view_distance >= 0.f && !all_views) vld = vld && (min_dist <= d.max_view_distance);
       a.valid[gv] = vld ? 1 : 0;
     }
