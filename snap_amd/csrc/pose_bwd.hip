@@ -85,6 +85,91 @@ __global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_kernel(const ScoreB
   }
 }
 
+// Fast path (P <= PB_THREADS * PB_PPT, no validity mask): every thread keeps its 10 poses and
+// their cotangents in registers for the whole point loop (the general kernel re-reads the 200 KB
+// pose table from L2 for every point), samples with the forward kernel's clamped-coordinate
+// formulation (pose.hip: identical derivative; the zero-weight taps of clamped samples are
+// skipped) and keeps the four CORNER cells -- where every sample that leaves the map in both
+// directions lands, thousands per plane -- in registers instead of serialising LDS atomics on
+// one address; they are reduced per wave (DPP) and added once per plane.
+typedef float bf32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_fast_kernel(const ScoreBwdArgs a) {
+  extern __shared__ float plane[];
+  __shared__ float corner[4];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int Y = a.Y;
+  const int XY = a.X * Y;
+  const float Xf = (float)a.X, Yf = (float)Y;
+  const int n_begin = blockIdx.x * a.points_per_chunk;
+  const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
+  float pc[PB_PPT], ps[PB_PPT], ptx[PB_PPT], pty[PB_PPT], g[PB_PPT];
+#pragma unroll
+  for (int k = 0; k < PB_PPT; ++k) {
+    const int p = k * PB_THREADS + tid;
+    const bool live = p < a.P;
+    const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + (live ? p : 0)];
+    pc[k] = t[0]; ps[k] = t[1]; ptx[k] = t[2]; pty[k] = t[3];
+    g[k] = live ? a.dscores[(int64_t)b * a.P + p] : 0.f;
+  }
+  for (int n = n_begin; n < n_end; ++n) {
+    float* dst = a.dsim + ((int64_t)b * a.Nq + n) * XY;
+    if (!a.valid_q[(int64_t)b * a.Nq + n]) {   // block-uniform: zero gradient plane
+      for (int i = tid; i < XY; i += PB_THREADS) dst[i] = 0.f;
+      continue;
+    }
+    for (int i = tid; i < XY; i += PB_THREADS) plane[i] = 0.f;
+    if (tid < 4) corner[tid] = 0.f;
+    __syncthreads();
+    const float qx = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+    const float qy = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+    float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;   // corner cells (0,0) (0,Y-1) (X-1,0) (X-1,Y-1)
+#pragma unroll
+    for (int k = 0; k < PB_PPT; ++k) {
+      const float gk = g[k];
+      const float ru = fmaf(pc[k], qx, fmaf(-ps[k], qy, ptx[k]));
+      const float rv = fmaf(ps[k], qx, fmaf(pc[k], qy, pty[k]));
+      const bool ulo = ru <= 0.f, uhi = ru >= Xf - 1.f;
+      const bool vlo = rv <= 0.f, vhi = rv >= Yf - 1.f;
+      if ((ulo || uhi) && (vlo || vhi)) {       // clamped in both directions: one corner cell
+        if (ulo && vlo) c00 += gk;
+        else if (ulo) c01 += gk;
+        else if (vlo) c10 += gk;
+        else c11 += gk;
+        continue;
+      }
+      if (gk == 0.f) continue;
+      const float cu = fminf(fmaxf(ru, 0.f), Xf - 1.f), cv = fminf(fmaxf(rv, 0.f), Yf - 1.f);
+      const float fu = fminf(floorf(cu), Xf - 2.f), fv = fminf(floorf(cv), Yf - 2.f);
+      const float wu = cu - fu, wv = cv - fv;
+      float* q = plane + (int)fmaf(fu, Yf, fv);
+      const float g0 = (1.f - wu) * gk, g1 = wu * gk;
+      const float w00 = g0 * (1.f - wv), w01 = g0 * wv, w10 = g1 * (1.f - wv), w11 = g1 * wv;
+      if (w00 != 0.f) atomicAdd(q, w00);
+      if (w01 != 0.f) atomicAdd(q + 1, w01);
+      if (w10 != 0.f) atomicAdd(q + Y, w10);
+      if (w11 != 0.f) atomicAdd(q + Y + 1, w11);
+    }
+    c00 = wave_sum(c00); c01 = wave_sum(c01); c10 = wave_sum(c10); c11 = wave_sum(c11);
+    if (lane == 0) {
+      atomicAdd(&corner[0], c00); atomicAdd(&corner[1], c01);
+      atomicAdd(&corner[2], c10); atomicAdd(&corner[3], c11);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      plane[0] += corner[0];
+      plane[Y - 1] += corner[1];
+      plane[(a.X - 1) * Y] += corner[2];
+      plane[(a.X - 1) * Y + Y - 1] += corner[3];
+    }
+    __syncthreads();
+    for (int i = tid; i < XY; i += PB_THREADS) dst[i] = plane[i];
+    __syncthreads();
+  }
+}
+
 // G = dsim * [sim > 0] * coef[b] in place; per-block partial of sum(dsim * sim).
 __global__ __launch_bounds__(256) void sim_bwd_prepare_kernel(float* __restrict__ dsim,
                                                               const float* __restrict__ sim,
@@ -153,8 +238,10 @@ extern "C" int snap_pose_score_bwd_f32(const float* dscores, const float* poses,
   a.points_per_chunk = (Nq + nch - 1) / nch;
   nch = (Nq + a.points_per_chunk - 1) / a.points_per_chunk;
   const size_t lds = (size_t)X * Y * sizeof(float);
-  const void* fn = mask_oob ? (const void*)&pose_score_bwd_kernel<true>
-                            : (const void*)&pose_score_bwd_kernel<false>;
+  const bool fast = !mask_oob && P <= PB_THREADS * PB_PPT && X >= 2 && Y >= 2;
+  const void* fn = fast ? (const void*)&pose_score_bwd_fast_kernel
+                        : (mask_oob ? (const void*)&pose_score_bwd_kernel<true>
+                                    : (const void*)&pose_score_bwd_kernel<false>);
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(PB_LDS_FLOATS * sizeof(float))) != hipSuccess)
