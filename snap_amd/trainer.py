@@ -69,8 +69,12 @@ def _global_norm(tensors):
 
 
 def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_norm=None,
-               group=None, debug=False):
-  """One optimisation step.  Returns (state, metrics, training_logs)."""
+               group=None, debug=False, overlap_allreduce=True):
+  """One optimisation step.  Returns (state, metrics, training_logs).
+
+  With more than one rank and ``overlap_allreduce`` the gradient buckets are all-reduced
+  while the backward pass is still running (``dist.OverlappedGradReducer``); otherwise one
+  bucketed all-reduce follows the backward pass.  Same averaged gradients either way."""
   named = flatten_params(state.params)
   leaves = [t for _, t in named]
   for t in leaves:
@@ -87,11 +91,17 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
     losses, metrics = model.loss_metrics_function(pred, batch, state.params)
     mask = batch['batch_mask'].to(losses['total'].dtype)
     loss = (losses['total'] * mask).sum() / mask.sum().clamp(min=1)
-    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-  grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
+    if sdist._world(group) > 1 and overlap_allreduce:
+      reducer = sdist.OverlappedGradReducer(leaves, group).attach()
+      loss.backward()                                  # buckets go out as their grads land
+      grads = reducer.finish()                         # jax.lax.pmean(grad, 'batch')
+    else:
+      grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+      grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
+      sdist.allreduce_mean_(grads, group)              # jax.lax.pmean(grad, 'batch')
   for t in leaves:
     t.requires_grad_(False)
-  sdist.allreduce_mean_(grads, group)                 # jax.lax.pmean(grad, 'batch')
+    t.grad = None
   logs = {}
   if max_grad_norm is not None:
     gn = _global_norm(grads)

@@ -33,6 +33,17 @@ def main():
   red = sdist.reduce_batch_metrics(metrics, mask)
   # rank0: err 1,3 (both valid); rank1: err 2,(6 masked) -> (1+3+2)/3
   assert abs(red['err'] - 2.0) < 1e-9 and abs(red['hit'] - 2.0 / 3.0) < 1e-9
+  # overlapped reducer: hooks fire during backward(), buckets are reduced asynchronously
+  leaves = [(b.clone() * 0 + 1.0).requires_grad_(True) for b in base[:4]]
+  unused = torch.ones(3, requires_grad=True)                 # never reaches the loss
+  red = sdist.OverlappedGradReducer(leaves + [unused], bucket_bytes=4096).attach()
+  loss = sum(((rank + 1) * b * l).sum() for b, l in zip(base[:4], leaves))
+  loss.backward()
+  avg = red.finish()
+  for b, gavg in zip(base[:4], avg):
+    assert torch.allclose(gavg, b * scale, atol=1e-6)
+  assert float(avg[4].abs().max()) == 0.0 and all(l.grad is None for l in leaves)
+  assert red.calls == len(red.buckets) >= 2, (red.calls, len(red.buckets))
   if rank == 0:
     print('DIST_SYNC_OK', calls)
   dist.barrier()
