@@ -663,6 +663,137 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_db_kernel(const ScoreAr
   }
 }
 
+// Banded variant for planes that do not fit LDS (256x256 maps of the eval path, BASELINE
+// configs[3]): the plane of a point streams through LDS in NB bands of RB rows (+1 halo row)
+// with the same LDS-DMA double buffering, padded rows and LDS point list as the whole-plane
+// kernel; the clamped coordinates / weights of the thread's 10 poses are computed once per
+// point and kept in registers across its bands, every band then costs a membership test, two
+// ds_read2_b32 and the lerp.  No validity mask (MASK launches take the older band kernel).
+template <int PPT>
+__global__ __launch_bounds__(PS_THREADS) void pose_score_band_db_kernel(const ScoreArgs a) {
+  extern __shared__ float plane[];
+  const int b = blockIdx.z;
+  const int chunk = blockIdx.y;
+  const int NCH = gridDim.y;
+  const int p_base = blockIdx.x * (PS_THREADS * PPT);
+  const int tid = threadIdx.x;
+  const int Y = a.Y;
+  const int XY = a.X * Y;
+  const int S = Y + 4;
+  const int CRP = (Y >> 2) + 1;
+  const int RB = a.RB, NB = a.NB;          // band rows (without the halo row), band count
+  const int PLANE = (RB + 1) * S;          // floats per LDS band buffer
+  f32x2 pcs[PPT], pt[PPT];
+  float acc[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    acc[k] = 0.f;
+    const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + min(p, a.P - 1)];
+    pcs[k] = f32x2{t[0], t[1]};
+    pt[k] = f32x2{t[2], t[3]};
+  }
+  const int n_begin = chunk * a.points_per_chunk;
+  const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
+  const float Xf = (float)a.X, Yf = (float)Y, Sf = (float)S;
+  const f32x2 lim1 = {Xf - 1.f, Yf - 1.f}, lim2 = {Xf - 2.f, Yf - 2.f}, zero2 = {0.f, 0.f};
+  const uint8_t* vq = a.valid_q + (int64_t)b * a.Nq;
+
+  // chunk -> global float offset inside a band (band-invariant; rows past the band end are
+  // masked by the chunk count of the band)
+  int goff[PS_DB_ROUNDS];
+#pragma unroll
+  for (int k = 0; k < PS_DB_ROUNDS; ++k) {
+    const int c = k * PS_THREADS + tid;
+    const int row = c / CRP;
+    goff[k] = row * Y + 4 * min(c - row * CRP, CRP - 2);
+  }
+  auto issue = [&](int n, int band, int buf) {
+    const int r0 = band * RB;
+    const int rows = min(RB + 1, a.X - r0);
+    const int nchunks = rows * CRP;
+    const float* src = a.sim + ((int64_t)b * a.Nq + n) * XY + (int64_t)r0 * Y;
+    float* dst = plane + buf * PLANE;
+#pragma unroll
+    for (int k = 0; k < PS_DB_ROUNDS; ++k) {
+      const int c = k * PS_THREADS + tid;
+      if (c < nchunks)
+        __builtin_amdgcn_global_load_lds((global_void_t*)(src + goff[k]),
+                                         (lds_void_t*)(dst + 4 * c), 16, 0, 0);
+    }
+  };
+  __shared__ int pt_n[PS_DB_MAX_POINTS];
+  __shared__ float pt_x[PS_DB_MAX_POINTS], pt_y[PS_DB_MAX_POINTS];
+  __shared__ int pt_count;
+  if (tid < 64) {
+    int count = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+      const int n = n0 + tid;
+      const bool v = n < n_end && vq[n] != 0;
+      const unsigned long long m = __ballot(v);
+      if (v) {
+        const int slot = count + __popcll(m & ((1ull << tid) - 1ull));
+        pt_n[slot] = n;
+        pt_x[slot] = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+        pt_y[slot] = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+      }
+      count += __popcll(m);
+    }
+    if (tid == 0) pt_count = count;
+  }
+  __syncthreads();
+  const int count = pt_count;
+  const int steps = count * NB;            // (point, band) pairs, band fastest
+  int buf = 0;
+  if (steps > 0) issue(pt_n[0], 0, 0);
+  float wu[PPT], wv[PPT];
+  int off[PPT];   // cell offset in full-plane padded rows; its row = off / S (fv < Y < S)
+  int i = 0, band = 0;
+  for (int t = 0; t < steps; ++t) {
+    if (band == 0) {
+      // per-point state of the 10 poses: cell row, lerp weights, offset in full-plane rows
+      const float qx = uniform_f(pt_x[i]), qy = uniform_f(pt_y[i]);
+      const f32x2 qx2 = {qx, qx}, qyn = {-qy, qy};
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const f32x2 r = __builtin_elementwise_fma(pcs[k], qx2, __builtin_elementwise_fma(pcs[k].yx, qyn, pt[k]));
+        const f32x2 c = __builtin_elementwise_min(__builtin_elementwise_max(r, zero2), lim1);
+        const f32x2 f = __builtin_elementwise_min(f32x2{floorf(c.x), floorf(c.y)}, lim2);
+        wu[k] = c.x - f.x;
+        wv[k] = c.y - f.y;
+        off[k] = (int)fmaf(f.x, Sf, f.y);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // band t landed for every wave; the other buffer is free
+    {
+      int ni = i, nb = band + 1;
+      if (nb == NB) { nb = 0; ++ni; }
+      if (t + 1 < steps) issue(pt_n[ni], nb, buf ^ 1);
+    }
+    const float* pl = plane + buf * PLANE;
+    const int shift = band * RB * S;         // band rows [band*RB, band*RB + RB)
+    const int span = RB * S;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const bool in = (unsigned)(off[k] - shift) < (unsigned)span;
+      const float* q = pl + (in ? off[k] - shift : 0);
+      const f32x2 s0 = {q[0], q[1]};
+      const f32x2 s1 = {q[S], q[S + 1]};
+      const f32x2 tt = __builtin_elementwise_fma(f32x2{wu[k], wu[k]}, s1 - s0, s0);
+      const float val = fmaf(wv[k], tt.y - tt.x, tt.x);
+      acc[k] += in ? val : 0.f;
+    }
+    buf ^= 1;
+    if (++band == NB) { band = 0; ++i; }
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    if (p < a.P) a.partial[((int64_t)b * NCH + chunk) * a.P + p] = acc[k];
+  }
+}
+
 __global__ void pose_score_reduce_kernel(const float* __restrict__ partial, int NCH, int P,
                                          int64_t total, float* __restrict__ scores) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*P
@@ -686,6 +817,7 @@ inline int score_chunks(int B, int Nq, int pose_chunks) {
   return nch;
 }
 constexpr int PS_PPT = 10;
+constexpr int PS_BAND_PPT = 8;   // the banded kernel keeps per-pose sampling state in registers
 inline int score_pose_chunks(int P) { return (P + PS_THREADS * PS_PPT - 1) / (PS_THREADS * PS_PPT); }
 
 __global__ void refine_lattice_kernel(const float* __restrict__ init,
@@ -889,9 +1021,18 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
   }();
   const bool use_db = db_enabled && !bands && (Y % 4 == 0) && X >= 2 && Y >= 2 &&
                       ((int64_t)X * (Y + 4) * 4 <= PS_DB_PLANE_BYTES);
+  // banded double-buffered variant: a plane that does not fit streams through in row bands
+  const int band_rows = (int)(PS_DB_PLANE_BYTES / ((size_t)(Y + 4) * sizeof(float))) - 1;
+  const bool use_band_db = db_enabled && !use_db && !mask_oob && (Y % 4 == 0) && X >= 2 &&
+                           Y >= 2 && band_rows >= 1 && X > band_rows;
   const void* fn = nullptr;
   size_t lds_bytes = lds;
-  if (use_db) {
+  if (use_band_db) {
+    a.RB = band_rows;
+    a.NB = (X - 1 + band_rows - 1) / band_rows;     // cell rows 0 .. X-2
+    fn = (const void*)&pose_score_band_db_kernel<PS_BAND_PPT>;
+    lds_bytes = (size_t)2 * (band_rows + 1) * (Y + 4) * sizeof(float);
+  } else if (use_db) {
     if (Y == 128)
       fn = mask_oob ? (const void*)&pose_score_db_kernel<PS_PPT, true, 128>
                     : (const void*)&pose_score_db_kernel<PS_PPT, false, 128>;
@@ -905,11 +1046,12 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
                   : (const void*)&pose_score_kernel<PS_PPT, false, false>;
   if (lds_bytes > 64 * 1024) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(use_db ? 2 * PS_DB_PLANE_BYTES : PS_LDS_FLOATS * sizeof(float))) !=
+                            (int)((use_db || use_band_db) ? 2 * PS_DB_PLANE_BYTES
+                                                          : PS_LDS_FLOATS * sizeof(float))) !=
         hipSuccess)
       return SNAP_ERR_LAUNCH;
   }
-  if (use_db) {
+  if (use_db || use_band_db) {
     hipLaunchKernelGGL(pose_table_cells_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)),
                        dim3(256), 0, s, poses, (int64_t)B * P, cell_size, table);
   } else {
@@ -919,7 +1061,10 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
   SNAP_CHECK_LAUNCH();
   {
     void* kargs[] = {(void*)&a};
-    if (hipLaunchKernel(fn, dim3(pch, nch, B), dim3(PS_THREADS), kargs, lds_bytes, s) != hipSuccess)
+    // (the banded kernel carries 8 poses per thread; the point chunking and the partial buffer
+    // layout [B, nch, P] are the same)
+    const int gx = use_band_db ? (P + PS_THREADS * PS_BAND_PPT - 1) / (PS_THREADS * PS_BAND_PPT) : pch;
+    if (hipLaunchKernel(fn, dim3(gx, nch, B), dim3(PS_THREADS), kargs, lds_bytes, s) != hipSuccess)
       return SNAP_ERR_LAUNCH;
   }
   SNAP_CHECK_LAUNCH();

@@ -372,7 +372,7 @@ def test_poses_from_corr():
 
 
 @pytest.mark.parametrize('mask_oob', [False, True])
-@pytest.mark.parametrize('X,Y', [(32, 32), (25, 37), (192, 160)])
+@pytest.mark.parametrize('X,Y', [(32, 32), (25, 37), (192, 160), (131, 260)])   # the last two: row bands
 def test_pose_score(mask_oob, X, Y):
   B, Nq, P = 2, 45, 700
   rng = np.random.default_rng(110)
