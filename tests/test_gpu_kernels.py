@@ -658,3 +658,40 @@ def test_ransac_row_table_gives_identical_samples(X, Y, Nq):
   a = ops.ransac_sample(fq, fm, stats, scale, True, S, uniforms=u, row_table=True)
   b = ops.ransac_sample(fq, fm, stats, scale, True, S, uniforms=u, row_table=False)
   assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------
+# degenerate inputs
+# ---------------------------------------------------------------------------
+def test_pose_score_without_valid_points_is_zero():
+  B, Nq, X, Y, P = 1, 70, 128, 128, 300
+  g = torch.Generator().manual_seed(1)
+  sim = torch.rand(B, Nq, X, Y, generator=g).to(DEV)
+  poses = torch.rand(B, P, 3, generator=g).to(DEV)
+  q_xy = torch.rand(B, Nq, 2, generator=g).to(DEV)
+  none = torch.zeros(B, Nq, dtype=torch.bool, device=DEV)
+  s = ops.pose_score(sim, poses, q_xy, none, None, 0.2)
+  assert float(s.abs().max()) == 0.0
+  one = none.clone()
+  one[0, 37] = True                       # exactly one valid point
+  s1 = ops.pose_score(sim, poses, q_xy, one, None, 0.2)
+  want = oracle_ops.pose_score(sim.cpu(), poses.cpu(), q_xy.cpu(), one.cpu(), None, 0.2)
+  helpers.report('one valid point', s1, want, atol=1e-6, rtol=1e-6)
+
+
+def test_lift_with_nothing_visible():
+  """All voxels far above every (horizontally looking) camera: pooled rows are zero, nothing
+  is valid, and the masked-row MLP on top of it returns zeros (empty row list)."""
+  fd, nb = 32, 8
+  f, cam, Rt, pts = _lift_scene(1, 3, 12, 16, fd, nb, 70000, seed=77)
+  pts = pts.clone()
+  pts[..., 2] = 500.0                     # straight up: outside every vertical field of view
+  pooled, valid = ops.lift_pool(f.to(DEV), cam.to(DEV), Rt.to(DEV), pts.to(DEV), K=2, fisheye=True,
+                                feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0))
+  assert not bool(valid.any()) and float(pooled.abs().max()) == 0.0
+  index, count = ops.compact_rows(valid)
+  assert int(count.item()) == 0
+  w = torch.randn(pooled.shape[-1], 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+  y = ops.dense(pooled.reshape(-1, pooled.shape[-1]), w, None, rows_in=index, rows_out=index, row_count=count)
+  ops.fill_masked_rows_(y, valid.reshape(-1))
+  assert float(y.abs().max()) == 0.0
