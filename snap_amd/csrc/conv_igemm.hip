@@ -74,7 +74,13 @@ __device__ __forceinline__ float apply_pro(float v, float mu, float sc, float be
   return v;
 }
 
-template <int BM, int BN, bool VEC, int PRO, int BK>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void cglobal_void_t;
+
+// zero source for LDS-DMA lanes whose tap / channel / row is out of range
+__device__ __attribute__((aligned(64))) const float kZeroChunk[16] = {0.f};
+
+template <int BM, int BN, bool VEC, int PRO, int BK, bool DMA = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   constexpr int AS = BM + 2;    // LDS row stride of the K-major A slab
   constexpr int TM = BM / 64;   // 32x32 MFMA tiles per wave along M
@@ -90,7 +96,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 
   // one LDS block: the A/B slab ring during the main loop, then the staging buffer
   // of the epilogue (64 x BN fp32) -- a single __shared__ object by design.
-  constexpr int kSlabFloats = 2 * BK * AS + 2 * BK * BN;
+  constexpr int kDmaStages = 3;
+  constexpr int kSlabFloats = DMA ? kDmaStages * (BK * BM + BK * BN) : 2 * BK * AS + 2 * BK * BN;
   constexpr int kStageFloats = 64 * BN;
   constexpr int kSmemFloats = kSlabFloats > kStageFloats ? kSlabFloats : kStageFloats;
   __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
@@ -325,12 +332,84 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   };
 
   // ---- main loop ---------------------------------------------------------
+  const int l31 = lane & 31, lhi = lane >> 5;
+  if constexpr (DMA) {
+    // LDS-DMA pipeline (prologues without per-(image, channel) operands: NONE / RELU).
+    // Both operands go global -> LDS by global_load_lds, three stages deep, no staging
+    // registers and no store phase: the wave only issues 4 DMA instructions per slab and
+    // runs MFMAs.  A stage = [row][16 k] with the 16-byte k-quads XOR-swizzled by
+    // (row >> 2) & 3: four lanes fetch one row's contiguous 64 bytes (coalesced) and the
+    // operand fetch is a conflict-free ds_read_b128 per 32-row block and lane group; lane
+    // group g consumes k = 8g .. 8g+7 of the slab, so MFMA j pairs k = j with k = 8 + j (B rows
+    // are read to match; the fp32 sum of a slab is re-associated, nothing else changes).
+    static_assert(VEC && BK == 16 && (PRO == SNAP_PRO_NONE || PRO == SNAP_PRO_RELU), "DMA path");
+    constexpr int A_ST = BK * BM, B_ST = BK * BN;
+    float* const Ad = smem;
+    float* const Bd = smem + kDmaStages * A_ST;
+    const int nslab = kt_end - kt_begin;
+    auto issue = [&](int stage) {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int row = (tid / QPR) + RPP * i;
+        const int q = akq ^ ((row >> 2) & 3);            // logical k-quad held by this slot
+        const int c = ct * BK + 4 * q;
+        const bool ok = tap_in[i] && c < d.Cin;          // (Cin % 4 == 0 on the VEC path)
+        const float* src = ok ? tap_px[i] + c : kZeroChunk;
+        __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                         (lds_void_t*)(Ad + stage * A_ST + 4 * (tid + 256 * i)), 16, 0, 0);
+      }
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p) {
+        const int kr = bkr + p * BROWS_PER_PASS;
+        const int col = n0 + 4 * bcq;
+        const bool ok = (ct * BK + kr) < d.Cin && col < d.Cout;
+        const float* src = ok ? a.w + ((int64_t)(kpos * d.Cin + ct * BK + kr) * d.Cout + col) : kZeroChunk;
+        __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                         (lds_void_t*)(Bd + stage * B_ST + 4 * (tid + 256 * p)), 16, 0, 0);
+      }
+    };
+    if (nslab > 0) { issue(0); advance(); }
+    if (nslab > 1) { issue(1); advance(); }
+    for (int t = 0; t < nslab; ++t) {
+      if (t + 1 < nslab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AROWS + BPASS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // slab t landed for every wave; stage (t+2)%3 (slab t-1) is free
+      if (t + 2 < nslab) { issue((t + 2) % kDmaStages); advance(); }
+      const float* as = Ad + (t % kDmaStages) * A_ST;
+      const float* bs = Bd + (t % kDmaStages) * B_ST;
+      f32x4 av[TM][2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int R = wr * (BM / 2) + i * 32 + l31;
+          const int pq = (lhi * 2 + h) ^ ((R >> 2) & 3);
+          av[i][h] = *reinterpret_cast<const f32x4*>(as + 4 * (R * 4 + pq));
+          if constexpr (PRO == SNAP_PRO_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[i][h][e] = fmaxf(av[i][h][e], 0.f);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < BK / 2; ++j) {
+        float bv[TN];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+          bv[jn] = bs[(8 * lhi + j) * BN + wc * (BN / 2) + jn * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j >> 2][j & 3], bv[jn], acc[i][jn], 0, 0, 0);
+      }
+    }
+    __syncthreads();     // the epilogue reuses the ring
+  } else {
   load_slab(kt_begin);
   advance();
   store_slab(0);
   __syncthreads();
 
-  const int l31 = lane & 31, lhi = lane >> 5;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
@@ -378,6 +457,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
       if (more) store_slab(cur ^ 1);
       if (!(a.ablate & 8)) __syncthreads();   // bit3: keep the stores, drop only the barrier
     }
+  }
+
   }
 
   // ---- epilogue ------------------------------------------------------------
@@ -527,6 +608,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void conv_igemm_kernel_occ4(const ConvArgs a) {
   conv_igemm_body<BM, BN, VEC, PRO, BK>(a);
 }
+template <int BM, int BN, int PRO>
+__global__ __launch_bounds__(256) void conv_igemm_kernel_dma(const ConvArgs a) {
+  conv_igemm_body<BM, BN, true, PRO, 16, true>(a);
+}
+
+// SNAP_CONV_DMA=0 keeps the register-staged loader for the NONE / RELU prologues too
+inline bool conv_dma_enabled() {
+  static const bool on = []() {
+    const char* e = getenv("SNAP_CONV_DMA");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(
     const float* __restrict__ partial, int S, int64_t M, int Cout, int Cout_stride, int epi,
@@ -616,7 +710,17 @@ int launch(ConvArgs a, hipStream_t s) {
     }
   }
   constexpr bool kGn = PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN;
-  if constexpr (!kGn && BK == 16 && (VEC || BM * BN < 128 * 128)) {  // (scalar 128x128 would spill)
+  constexpr bool kDmaOk = VEC && BK == 16 && (PRO == SNAP_PRO_NONE || PRO == SNAP_PRO_RELU);
+  bool launched = false;
+  if constexpr (kDmaOk) {
+    if (conv_dma_enabled()) {
+      hipLaunchKernelGGL((conv_igemm_kernel_dma<BM, BN, PRO>), dim3((unsigned)nblocks), dim3(256), 0,
+                         s, a);
+      launched = true;
+    }
+  }
+  if (launched) {
+  } else if constexpr (!kGn && BK == 16 && (VEC || BM * BN < 128 * 128)) {  // (scalar 128x128 would spill)
     hipLaunchKernelGGL((conv_igemm_kernel_occ4<BM, BN, VEC, PRO, BK>), dim3((unsigned)nblocks),
                        dim3(256), 0, s, a);
   } else {
