@@ -390,17 +390,29 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             for (int e = 0; e < 4; ++e) av[i][h][e] = fmaxf(av[i][h][e], 0.f);
           }
         }
+      // B operand fetch runs one k-pair ahead of the MFMAs (pinned below)
+      float bv[2][TN];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bv[0][jn] = bs[(8 * lhi) * BN + wc * (BN / 2) + jn * 32 + l31];
 #pragma unroll
       for (int j = 0; j < BK / 2; ++j) {
-        float bv[TN];
+        const int cu = j & 1, nx = cu ^ 1;
+        if (j + 1 < BK / 2) {
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-          bv[jn] = bs[(8 * lhi + j) * BN + wc * (BN / 2) + jn * 32 + l31];
+          for (int jn = 0; jn < TN; ++jn)
+            bv[nx][jn] = bs[(8 * lhi + j + 1) * BN + wc * (BN / 2) + jn * 32 + l31];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int jn = 0; jn < TN; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j >> 2][j & 3], bv[jn], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j >> 2][j & 3], bv[cu][jn], acc[i][jn], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + TN, 0);   // A quads + first B pair
+#pragma unroll
+      for (int j = 0; j < BK / 2; ++j) {
+        if (j + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
       }
     }
     __syncthreads();     // the epilogue reuses the ring
