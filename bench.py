@@ -34,6 +34,7 @@ from snap_amd.data import synthetic  # noqa: E402
 from snap_amd.models import bev_localizer  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA dense peak
+PEAK_MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (train --precision bf16: operands staged from f32 HBM tensors)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 WORKLOADS = {
@@ -217,6 +218,10 @@ def main(argv=None):
                   help='testing only: override the process-group backend (default nccl = RCCL)')
   ap.add_argument('--share-gpu', action='store_true',
                   help='testing only: every rank uses GPU 0 (multi-process plumbing check on a 1-GPU box)')
+  ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+                  help="train mode only: 'bf16' rounds the conv / dense operands to bf16 (f32 "
+                       "accumulate) -- the analogue of the reference's float16 train config; the "
+                       "inference headline always runs the exact f32 path")
   ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                   help='infer: BEVLocalizer forward (the headline metric); train: one '
                        'snap_amd.trainer.train_step (fwd + bwd + grad all-reduce + Adam)')
@@ -250,7 +255,8 @@ def main(argv=None):
 
     def step(i):
       nonlocal state
-      state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn)
+      state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn,
+                                          precision=args.precision)
       last_logs.update(logs)
       return logs
   else:
@@ -323,7 +329,8 @@ def main(argv=None):
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': ('f32' if (args.mode == 'infer' or args.precision == 'f32')
+                  else 'bf16 GEMM operands, f32 accumulate / parameters / optimizer'),
         'data': 'synthetic',
         'config': {
             'workload': WORKLOADS[args.workload]['desc'],
@@ -332,7 +339,7 @@ def main(argv=None):
             'parallelism': (f'scene-sharded x{world}, no data-path collective' if args.mode == 'infer'
                             else f'dp{world}: scene-sharded, RCCL gradient all-reduce'),
             'mode': ('inference forward (BEVLocalizer.apply, train=False)' if args.mode == 'infer' else
-                     'train_step: forward + backward + gradient all-reduce + Adam (fp32)'),
+                     f'train_step: forward + backward + gradient all-reduce + Adam ({args.precision})'),
         },
     }
     if args.mode == 'infer':
@@ -360,10 +367,11 @@ def main(argv=None):
       s = summ[dom]
       if s['flops'] > 0:
         ach = s['flops'] / s['ms'] / 1e9
+        peak = PEAK_MFMA_BF16_TFLOPS if dom.endswith('bf16') else PEAK_MFMA_F32_TFLOPS
         out['roofline'] = {
             'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2),
-            'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+            'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(ach / peak, 4),
             'traffic': _pmc_traffic(dom, s['launches'], args.workload),
             'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, separate passes; profiles/)',
             'algorithmic_bytes_per_launch': round(s['bytes'] / s['launches'], 1),

@@ -99,6 +99,8 @@ typedef struct SnapConvExtras {
   int32_t gn_partial_relu;
   void* workspace;            /* split-K scratch: snap_conv2d_workspace_bytes(desc) (may be 0) */
   size_t workspace_bytes;
+  const void* w_bf16;         /* non-NULL selects the bf16-operand engine (see below) */
+  size_t w_bf16_bytes;
 } SnapConvExtras;
 
 int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,
@@ -107,6 +109,19 @@ int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const floa
                             const float* residual, const float* up_prev,
                             const uint8_t* row_mask, const SnapConvExtras* extras,
                             void* stream);
+/* Training-precision engine: the analogue of the reference's float16 train config
+ * (snap/configs/train_localization.py:25).  Tensors stay f32 in memory; the prologue runs in
+ * f32, then both operands are rounded to bf16 (round-to-nearest-even) and multiplied on the
+ * bf16 matrix cores with f32 accumulation; epilogue in f32.  The caller packs the weights
+ * once per launch (or per step) with snap_conv2d_pack_weights_bf16 -- out is
+ * [Cout][taps][roundup(Cin, 8)] bf16, taps = KH*KW -- and passes them as extras->w_bf16; `w`
+ * is still required (shapes the bf16 engine does not carry -- Cin < 4, unaligned channel
+ * rows -- run on the exact f32 engine instead).  All fusions, row-indexed launches, GroupNorm
+ * partial sums and split-K behave as on the f32 engine. */
+size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, int32_t Cout);
+int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
+                                  void* out, size_t out_bytes, void* stream);
+
 /* Scratch for split-K launches (small-M / deep-K layers that cannot fill 256 CUs with output
  * tiles: slices of K go to extra workgroups, partial tiles are summed in fixed order by a
  * second kernel that also applies the epilogue -- deterministic).  0 = the shape does not
@@ -368,6 +383,18 @@ int snap_conv2d_wgrad_rows_f32(const SnapConvDesc* desc, const float* x, const f
                                const float* gn_beta, int32_t accumulate, void* workspace,
                                size_t workspace_bytes, const int32_t* rows_z,
                                const int32_t* rows_dy, const int32_t* row_count, void* stream);
+/* The same with a choice of arithmetic: SNAP_MATH_F32 (exact f32 matrix cores) or
+ * SNAP_MATH_BF16 (both operands rounded to bf16 after the f32 prologue, f32 accumulate: the
+ * training-precision engine, see snap_conv2d_pack_weights_bf16).  Shapes the bf16 engine does
+ * not carry (Cin < 4, unaligned channel rows) run in f32. */
+#define SNAP_MATH_F32 0
+#define SNAP_MATH_BF16 1
+int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x, const float* dy,
+                             float* dw, const float* gn_mu, const float* gn_sc,
+                             const float* gn_beta, int32_t accumulate, void* workspace,
+                             size_t workspace_bytes, const int32_t* rows_z,
+                             const int32_t* rows_dy, const int32_t* row_count, int32_t math,
+                             void* stream);
 
 /* GroupNorm(+ReLU) backward.  dz: grad w.r.t. the prologue output; add: optional extra
  * gradient summed into dx (identity-residual branch).  mode: SNAP_PRO_GN_RELU /

@@ -36,6 +36,20 @@ def conv2d(x, kernel, strides=(1, 1), padding=((0, 0), (0, 0)), bias=None):
   return out.astype(x.dtype)
 
 
+def bf16_round(x):
+  """float32 -> nearest bfloat16 (ties to even), returned as float32.
+
+  The training-precision conv engine multiplies bf16-rounded operands with f32
+  accumulation (the build's analogue of the reference's ``dtype='float16'`` train
+  config, ``snap/configs/train_localization.py:25``); this is the rounding step of
+  its restatement.
+  """
+  u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+  r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000))
+  out = r.view(np.float32)
+  return np.where(np.isfinite(x), out, np.asarray(x, dtype=np.float32))
+
+
 def same_padding(size, k, s):
   """XLA 'SAME' padding for one spatial dim."""
   out = -(-size // s)

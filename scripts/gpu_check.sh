@@ -42,10 +42,13 @@ for s in $STAGES; do
     benchtrain)
       SNAP_BENCH_DUMP=gpurun_out/launches_train.json timeout 1200 python bench.py --mode train --workload c3 --steps 8 --warmup 2 > gpurun_out/bench_train.log 2>&1
       echo "== bench train =="; tail -5 gpurun_out/bench_train.log | cut -c1-3000 ;;
+    benchtrainbf16)
+      SNAP_BENCH_DUMP=gpurun_out/launches_train_bf16.json timeout 1200 python bench.py --mode train --workload c3 --precision bf16 --steps 8 --warmup 2 > gpurun_out/bench_train_bf16.log 2>&1
+      echo "== bench train bf16 =="; tail -5 gpurun_out/bench_train_bf16.log | cut -c1-3000 ;;
     proftrain)
       rm -rf gpurun_out/proftrain
       (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/proftrain" -o snap -- \
-        python "$OLDPWD/bench.py" --mode train --workload c3 --steps 2 --warmup 1) > gpurun_out/proftrain.log 2>&1
+        python "$OLDPWD/bench.py" --mode train --workload c3 --steps 2 --warmup 1 ${TRAIN_ARGS:-}) > gpurun_out/proftrain.log 2>&1
       echo "== prof train =="; tail -2 gpurun_out/proftrain.log | cut -c1-300
       f=$(find gpurun_out/proftrain -name '*kernel_stats.csv' | head -1)
       [ -n "$f" ] && head -40 "$f" | cut -c1-220 ;;

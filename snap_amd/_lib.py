@@ -36,6 +36,7 @@ class SnapConvExtras(ctypes.Structure):
       ('rows_in', ptr), ('rows_out', ptr), ('row_count', ptr), ('gn_partial', ptr),
       ('gn_partial_bytes', c_size), ('gn_partial_relu', c_int),
       ('workspace', ptr), ('workspace_bytes', c_size),
+      ('w_bf16', ptr), ('w_bf16_bytes', c_size),
   ]
 
 
@@ -67,6 +68,8 @@ SIGNATURES = {
     'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_conv2d_packed_weights_bytes': (c_size, [c_int, c_int, c_int]),
+    'snap_conv2d_pack_weights_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_group_norm_stats_from_partial_f32': (
         c_int, [ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr, ptr]
     ),
@@ -154,6 +157,11 @@ SIGNATURES = {
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr, ptr,
          ptr, ptr],
     ),
+    'snap_conv2d_wgrad_ex_f32': (
+        c_int,
+        [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr, ptr,
+         ptr, c_int, ptr],
+    ),
     'snap_colsum_rows_f32': (c_int, [ptr, c_i64, c_int, ptr, ptr, ptr, c_int, ptr, c_size, ptr]),
     'snap_group_norm_bwd_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int]),
     'snap_group_norm_bwd_f32': (
@@ -189,7 +197,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

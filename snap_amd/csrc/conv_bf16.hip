@@ -1,0 +1,335 @@
+// Implicit-GEMM convolution / dense engine with bf16 operands and f32 accumulation
+// (v_mfma_f32_32x32x16_bf16) -- the training-precision analogue of the reference's float16
+// train config (snap/configs/train_localization.py:25, trainer.py:391 DynamicScale); the
+// exact-f32 engine of conv_igemm.hip stays the inference / parity path.
+//
+// Same GEMM view, fusions, tile order, split-K and epilogue as conv_igemm.hip (shared through
+// conv_common.h).  What differs is the operand pipeline:
+//   * tensors stay f32 in HBM.  A (im2col rows) is gathered global -> registers, the fused
+//     prologue runs in f32, the result is rounded to bf16 (v_cvt_pk_bf16_f32, RNE) and stored
+//     as [row][32 k] (64 B per row, 16-byte k-octets XOR-swizzled by (row >> 2) & 3): one
+//     conflict-free ds_read_b128 fetches a lane's 8 consecutive k of the MFMA A fragment.
+//   * B comes from a bf16 copy of the weights packed [Cout][tap][cin8] (k contiguous per
+//     output channel, snap_conv2d_pack_weights_bf16) and goes global -> LDS by LDS-DMA with the
+//     same swizzle applied on the source side: no registers, no conversion, no store phase.
+//   * one K slab = 32 k = two MFMA k-steps; double-buffered LDS, one barrier per slab.
+// Products of bf16 values are exact in f32, so the result equals an f32-accumulated dot product
+// of the rounded operands (up to summation order): the parity tests compare against exactly
+// that restatement.
+#include "conv_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int PRO>
+__device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
+  constexpr int BK = 32;
+  constexpr int TM = BM / 64;
+  constexpr int TN = BN / 64;
+  constexpr int QPR = BK / 4;             // float4 quads per A row of the slab
+  constexpr int RPP = 256 / QPR;          // rows staged per pass
+  constexpr int AROWS = BM / RPP;         // float4 per thread for A
+  constexpr int BPIECES = (BN * 4) / 256; // 16-byte DMA pieces per thread for B (BN cols x 4 octets)
+  constexpr int A_ST = BM * 16;           // floats per A stage (64 B per row)
+  constexpr int B_ST = BN * 16;
+  constexpr int kSlabFloats = 2 * (A_ST + B_ST);
+  constexpr int kStageFloats = 64 * BN;
+  constexpr int kSmemFloats = kSlabFloats > kStageFloats ? kSlabFloats : kStageFloats;
+  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
+  char* const Ab = reinterpret_cast<char*>(smem);
+  char* const Bb = reinterpret_cast<char*>(smem + 2 * A_ST);
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  // tile order / split-K / row-indexed mode: as conv_igemm.hip
+  const int ncol = a.ncol;
+  const int split = a.ksplit > 1 ? blockIdx.x / a.tiles_per_split : 0;
+  const int bid = a.ksplit > 1 ? blockIdx.x - split * a.tiles_per_split : blockIdx.x;
+  const int xcd = bid & 7;
+  const int seq = bid >> 3;
+  const int col_t = seq % ncol;
+  const int row_t = (seq / ncol) * 8 + xcd;
+  const int Meff = a.row_count ? min(*a.row_count, a.M) : a.M;
+  if (row_t * BM >= Meff) return;
+  const int m0 = row_t * BM;
+  const int n0 = col_t * BN;
+  const int HoWo = d.Ho * d.Wo;
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+
+  int r_hb[AROWS], r_wb[AROWS];
+  bool r_ok[AROWS];
+  const float* r_px[AROWS];
+  int64_t r_gn[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    const int row = (tid / QPR) + RPP * i;
+    const int m = m0 + row;
+    r_ok[i] = m < Meff;
+    int mm = r_ok[i] ? m : 0;
+    if (a.rows_in) mm = a.rows_in[mm];
+    const int n = mm / HoWo;
+    const int r = mm - n * HoWo;
+    const int ho = r / d.Wo;
+    const int wo = r - ho * d.Wo;
+    r_hb[i] = ho * d.stride - d.pad_t;
+    r_wb[i] = wo * d.stride - d.pad_l;
+    r_px[i] = a.x + (((int64_t)n * d.H + r_hb[i]) * d.W + r_wb[i]) * d.Cin_stride;
+    r_gn[i] = (int64_t)n * d.Cin;
+  }
+  const int akq = tid % QPR;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 xa[AROWS], xmu[AROWS], xsc[AROWS], xbeta;
+  bool xin[AROWS];
+  int cur_c = 0;
+
+  const int taps = d.KH * d.KW;
+  const int kt_begin = a.ksplit > 1 ? split * a.slabs_per_split : 0;
+  const int kt_end = a.ksplit > 1 ? min(a.nk, kt_begin + a.slabs_per_split) : a.nk;
+  int kpos = 0, ct = 0, kh = 0, kw = 0;
+  if (kt_begin > 0) {
+    kpos = kt_begin / a.ctiles;
+    ct = kt_begin - kpos * a.ctiles;
+    kh = kpos / d.KW;
+    kw = kpos - kh * d.KW;
+  }
+  const float* tap_px[AROWS];
+  bool tap_in[AROWS];
+  auto set_tap = [&]() {
+    const int64_t delta = ((int64_t)kh * d.W + kw) * d.Cin_stride;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int hi = r_hb[i] + kh, wi = r_wb[i] + kw;
+      tap_in[i] = r_ok[i] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+      tap_px[i] = r_px[i] + delta;
+    }
+  };
+  set_tap();
+
+  auto load_a = [&]() {
+    const int c = ct * BK + 4 * akq;
+    cur_c = c;
+    const bool cvalid = c < d.Cin;
+    if constexpr (need_gn) xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const bool inb = tap_in[i] && cvalid;
+      xin[i] = inb;
+      const float* px = inb ? tap_px[i] + c : a.x;
+      xa[i] = *reinterpret_cast<const f32x4*>(px);
+      if constexpr (need_gn) {
+        const int64_t so = inb ? r_gn[i] + c : (int64_t)0;
+        xmu[i] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
+        xsc[i] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
+      }
+    }
+  };
+  const __bf16* const wt = static_cast<const __bf16*>(a.w_bf16);
+  auto issue_b = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < BPIECES; ++p) {
+      const int slot = tid + 256 * p;
+      const int col = slot >> 2;
+      const int oct = (slot & 3) ^ ((col >> 2) & 3);    // logical k-octet held by this slot
+      const int kc = ct * BK + 8 * oct;
+      const bool ok = kc < a.cin8 && (n0 + col) < d.Cout;
+      const void* src = ok ? static_cast<const void*>(wt + ((int64_t)(n0 + col) * taps + kpos) * a.cin8 + kc)
+                           : static_cast<const void*>(kZeroChunk);
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                       (lds_void_t*)(Bb + buf * (B_ST * 4) + 16 * slot), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    if (++ct == a.ctiles) {
+      ct = 0;
+      ++kpos;
+      if (++kw == d.KW) { kw = 0; ++kh; }
+      set_tap();
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int row = (tid / QPR) + RPP * i;
+      f32x4 v = xa[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pv;
+        if constexpr (need_gn)
+          pv = apply_pro<PRO>(v[e], xmu[i][e], xsc[i][e], xbeta[e], d.in_scale, d.in_shift);
+        else
+          pv = apply_pro<PRO>(v[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+        v[e] = (xin[i] && (cur_c + e < d.Cin)) ? pv : 0.f;
+      }
+      const bf16x4 b = __builtin_convertvector(v, bf16x4);
+      const int oct = (akq >> 1) ^ ((row >> 2) & 3);
+      *reinterpret_cast<bf16x4*>(Ab + buf * (A_ST * 4) + row * 64 + oct * 16 + (akq & 1) * 8) = b;
+    }
+  };
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  if (kt_begin < kt_end) {
+    load_a();
+    issue_b(0);
+    advance();
+    store_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) {
+      load_a();
+      issue_b(cur ^ 1);
+      advance();
+    }
+    const char* as = Ab + cur * (A_ST * 4);
+    const char* bs = Bb + cur * (B_ST * 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int R = wr * (BM / 2) + i * 32 + l31;
+        av[i] = *reinterpret_cast<const bf16x8*>(as + R * 64 + (((2 * s + lhi) ^ ((R >> 2) & 3)) * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int C = wc * (BN / 2) + j * 32 + l31;
+        bv[j] = *reinterpret_cast<const bf16x8*>(bs + C * 64 + (((2 * s + lhi) ^ ((C >> 2) & 3)) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_a(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the B octets of slab kt+1 landed
+    __syncthreads();
+  }
+
+  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
+}
+
+template <int BM, int BN, int PRO>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs a) {
+  conv_bf16_body<BM, BN, PRO>(a);
+}
+
+template <int BM, int BN, int PRO>
+int launch(ConvArgs a, hipStream_t s) {
+  constexpr int BK = 32;
+  a.ctiles = (a.d.Cin + BK - 1) / BK;
+  a.nk = a.d.KH * a.d.KW * a.ctiles;
+  const int64_t nrow = snap_cdiv(a.M, BM);
+  a.ncol = (int)snap_cdiv(a.d.Cout, BN);
+  a.gn_slabs = (a.d.Ho * a.d.Wo) / BM + 2;
+  int64_t nblocks = snap_cdiv(nrow, 8) * 8 * a.ncol;
+  if (nblocks > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  a.ksplit = 1;
+  a.tiles_per_split = (int)nblocks;
+  a.slabs_per_split = a.nk;
+  const int64_t tiles = nrow * a.ncol;
+  const int target = splitk_target();
+  if (a.kpartial && target > 0 && tiles <= splitk_max_tiles() && a.nk >= 8 && !a.rows_in &&
+      !a.rows_out && !a.row_count && !a.gn_partial &&
+      !(a.d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) {
+    int64_t S = (target + tiles - 1) / tiles;
+    S = S < a.nk / 4 ? S : a.nk / 4;                        // >= 4 slabs (128 k) per split
+    const int64_t fit = (int64_t)(a.kpartial_bytes / ((size_t)a.M * a.d.Cout * sizeof(float)));
+    S = S < fit ? S : fit;
+    if (S >= 2) {
+      a.slabs_per_split = (int)((a.nk + S - 1) / S);
+      a.ksplit = (a.nk + a.slabs_per_split - 1) / a.slabs_per_split;
+      nblocks *= a.ksplit;
+    }
+  }
+  hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  if (a.ksplit > 1) {
+    const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
+                       (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.Cout_stride,
+                       a.d.epilogue, a.bias, a.residual, a.row_mask, a.y);
+    SNAP_CHECK_LAUNCH();
+  }
+  return SNAP_OK;
+}
+
+template <int BM, int BN>
+int launch_pro(const ConvArgs& a, hipStream_t s) {
+  switch (a.d.prologue) {
+    case SNAP_PRO_NONE: return launch<BM, BN, SNAP_PRO_NONE>(a, s);
+    case SNAP_PRO_AFFINE: return launch<BM, BN, SNAP_PRO_AFFINE>(a, s);
+    case SNAP_PRO_GN_RELU: return launch<BM, BN, SNAP_PRO_GN_RELU>(a, s);
+    case SNAP_PRO_RELU_GN: return launch<BM, BN, SNAP_PRO_RELU_GN>(a, s);
+    case SNAP_PRO_RELU: return launch<BM, BN, SNAP_PRO_RELU>(a, s);
+    default: return SNAP_ERR_UNSUPPORTED;
+  }
+}
+
+// w [taps*Cin, Cout] f32 -> out [Cout][taps][cin8] bf16 (RNE), channels Cin..cin8 zero.
+// One 32 x 32 (k x n) tile per workgroup through LDS: coalesced along n on the way in,
+// along k on the way out.
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(
+    const float* __restrict__ w, __bf16* __restrict__ out, int taps, int Cin, int cin8, int Cout) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32, t = blockIdx.z;
+#pragma unroll
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, n = n0 + tx;
+    tile[j][tx] = (c < Cin && n < Cout) ? w[((int64_t)t * Cin + c) * Cout + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = ty; j < 32; j += 8) {
+    const int n = n0 + j, c = c0 + tx;
+    if (n < Cout && c < cin8) out[((int64_t)n * taps + t) * cin8 + c] = (__bf16)tile[tx][j];
+  }
+}
+
+}  // namespace
+
+int snapconv::launch_bf16(ConvArgs a, hipStream_t s) {
+  const TileChoice t = choose_tile(a.M, a.d.Cout);
+  if (t.bm == 128 && t.bn == 128) return launch_pro<128, 128>(a, s);
+  if (t.bm == 128) return launch_pro<128, 64>(a, s);
+  if (t.bn == 128) return launch_pro<64, 128>(a, s);
+  return launch_pro<64, 64>(a, s);
+}
+
+extern "C" size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, int32_t Cout) {
+  if (taps <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const size_t cin8 = ((size_t)Cin + 7) / 8 * 8;
+  return (size_t)Cout * taps * cin8 * 2;
+}
+
+extern "C" int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin,
+                                             int32_t Cout, void* out, size_t out_bytes,
+                                             void* stream) {
+  if (!w || !out) return SNAP_ERR_NULL;
+  if (taps <= 0 || Cin <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (out_bytes < snap_conv2d_packed_weights_bytes(taps, Cin, Cout)) return SNAP_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(out) & 15) return SNAP_ERR_BAD_SHAPE;
+  const int cin8 = (Cin + 7) / 8 * 8;
+  const dim3 grid((unsigned)snap_cdiv(cin8, 32), (unsigned)snap_cdiv(Cout, 32), (unsigned)taps);
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w, static_cast<__bf16*>(out), taps, Cin, cin8, Cout);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

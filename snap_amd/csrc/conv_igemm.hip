@@ -22,63 +22,9 @@
 // snap/models/resnet.py:83-132,200-215, image_encoder.py:67-94, layers.py:66-77,
 // streetview_encoder.py:228,281, bev_mapper.py:285 and the direct correlation of
 // pose_exhaustive_voting.py:86-91.
-#include <stdio.h>
-#include <stdlib.h>
-
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
-
-struct ConvArgs {
-  SnapConvDesc d;
-  const float* x;
-  const float* w;
-  float* y;
-  const float* gn_mu;
-  const float* gn_sc;
-  const float* gn_beta;
-  const float* bias;
-  const float* residual;
-  const float* up_prev;
-  const uint8_t* row_mask;
-  const int32_t* rows_in;    // optional: GEMM row m reads output pixel rows_in[m]
-  const int32_t* rows_out;   // optional: GEMM row m is written to y row rows_out[m]
-  const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
-  float* kpartial;           // split-K: [ksplit][M][Cout] raw partial tiles (workspace)
-  size_t kpartial_bytes;
-  int ksplit;                // number of K splits (1 = none)
-  int slabs_per_split;
-  int tiles_per_split;       // workgroups of one split (multiple of 8)
-  float* gn_partial;         // optional: per-(image, row tile, channel) sums of y and y^2
-  int gn_relu;               // ... of relu(y) (FPN order)
-  int gn_slabs;              // row tiles per image in gn_partial (= HoWo / BM + 2)
-  int M;       // N*Ho*Wo  (upper bound of the row count when row_count is set)
-  int K;       // KH*KW*Cin
-  int ctiles;  // ceil(Cin/16)   (VEC path)
-  int nk;      // number of K slabs
-  int prio;    // experiment knob: s_setprio(1) around the MFMA block
-  int ncol;    // number of column tiles (set in launch<>)
-  int ablate;  // tuning-only: bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
-};
-
-
-// The prologue is a COMPILE-TIME parameter: a run-time switch here is lowered to a
-// branch tree per staged element and wrecks the schedule of the whole main loop.
-template <int PRO>
-__device__ __forceinline__ float apply_pro(float v, float mu, float sc, float beta, float s,
-                                           float t) {
-  if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
-  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
-  if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
-  if constexpr (PRO == SNAP_PRO_RELU) return fmaxf(v, 0.f);
-  return v;
-}
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void cglobal_void_t;
-
-// zero source for LDS-DMA lanes whose tap / channel / row is out of range
-__device__ __attribute__((aligned(64))) const float kZeroChunk[16] = {0.f};
 
 template <int BM, int BN, bool VEC, int PRO, int BK, bool DMA = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
@@ -473,139 +419,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 
   }
 
-  // ---- epilogue ------------------------------------------------------------
-  // The MFMA C layout gives every lane one column of 16 rows: direct stores would be
-  // 4-byte scattered.  Instead each pass stages 64 rows x BN columns through LDS and
-  // writes them back as float4 rows (512 B contiguous per row for BN = 128); bias,
-  // residual, FPN up-sample-add, ReLU and the row mask are applied on the way out
-  // with float4 loads.  The final __syncthreads of the main loop already fenced the
-  // slab ring, so the buffer can be reused at once.
-  const int epi = d.epilogue;
-  const int Hp = d.Ho >> 1, Wp = d.Wo >> 1;
-  constexpr int Q = BN / 4;               // float4 per staged row
-  constexpr int PER_THREAD = (64 * Q) / 256;
-  // GroupNorm statistics of the OUTPUT (consumed by the next layer's fused GN prologue):
-  // every thread owns 4 fixed columns (256 % Q == 0), accumulates sum / sum of squares of
-  // what it stores, split by image (a tile of BM <= HoWo rows touches at most two).
-  const bool want_stats = a.gn_partial != nullptr;
-  const int n_first = m0 / HoWo;
-  const int m_split = (n_first + 1) * HoWo;   // first row of the second image
-  float gs1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  float gs2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-  for (int h = 0; h < TM; ++h) {
-    if (h > 0) __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        smem[(wr * 32 + ri) * BN + wc * (BN / 2) + j * 32 + l31] = acc[h][j][r];
-      }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < PER_THREAD; ++it) {
-      const int idx = tid + 256 * it;
-      const int row = idx / Q, q = idx - row * Q;
-      const int m = m0 + (row >> 5) * (BM / 2) + h * 32 + (row & 31);
-      const int col = n0 + 4 * q;
-      if (m >= Meff || col >= d.Cout) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * BN + 4 * q);
-      if (a.ksplit > 1) {  // raw partial tile; the epilogue runs in splitk_reduce_kernel
-        *reinterpret_cast<f32x4*>(a.kpartial + ((int64_t)split * a.M + m) * d.Cout + col) = v;
-        continue;
-      }
-      const int64_t o = (int64_t)(a.rows_out ? a.rows_out[m] : m) * d.Cout_stride + col;
-      if (epi & SNAP_EPI_BIAS) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bb[e];
-      }
-      if (epi & SNAP_EPI_RESIDUAL) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += rr[e];
-      }
-      if (epi & SNAP_EPI_UPSAMPLE2X_ADD) {
-        // bilinear x2 of the coarser level (half-pixel centres, edge clamp)
-        const int n = m / HoWo;
-        const int rr = m - n * HoWo;
-        const int ho = rr / d.Wo;
-        const int wo = rr - ho * d.Wo;
-        const float sh = (ho + 0.5f) * 0.5f - 0.5f;
-        const float sw = (wo + 0.5f) * 0.5f - 0.5f;
-        const float fh = floorf(sh), fw = floorf(sw);
-        const float wh_hi = sh - fh, wh_lo = 1.f - wh_hi;
-        const float ww_hi = sw - fw, ww_lo = 1.f - ww_hi;
-        const int h0 = min(max((int)fh, 0), Hp - 1), h1 = min(max((int)fh + 1, 0), Hp - 1);
-        const int w0 = min(max((int)fw, 0), Wp - 1), w1 = min(max((int)fw + 1, 0), Wp - 1);
-        const int64_t base = (int64_t)n * Hp * Wp;
-        const f32x4 p00 = *reinterpret_cast<const f32x4*>(
-            a.up_prev + (base + (int64_t)h0 * Wp + w0) * d.Cout_stride + col);
-        const f32x4 p01 = *reinterpret_cast<const f32x4*>(
-            a.up_prev + (base + (int64_t)h0 * Wp + w1) * d.Cout_stride + col);
-        const f32x4 p10 = *reinterpret_cast<const f32x4*>(
-            a.up_prev + (base + (int64_t)h1 * Wp + w0) * d.Cout_stride + col);
-        const f32x4 p11 = *reinterpret_cast<const f32x4*>(
-            a.up_prev + (base + (int64_t)h1 * Wp + w1) * d.Cout_stride + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float c0 = p00[e] * wh_lo + p10[e] * wh_hi;
-          const float c1 = p01[e] * wh_lo + p11[e] * wh_hi;
-          v[e] += c0 * ww_lo + c1 * ww_hi;
-        }
-      }
-      if (epi & SNAP_EPI_RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if ((epi & SNAP_EPI_ROWMASK) && a.row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(a.y + o) = v;
-      if (want_stats) {
-        const int sl = m >= m_split ? 1 : 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = a.gn_relu ? fmaxf(v[e], 0.f) : v[e];
-          gs1[sl][e] += t;
-          gs2[sl][e] += t * t;
-        }
-      }
-    }
-  }
-  if (want_stats) {
-    // fixed-order reduction over the 256/Q row groups through LDS, then one writer per
-    // (image slot, column): deterministic.
-    constexpr int RG = 256 / Q;
-    __syncthreads();
-    const int q = tid % Q, rg = tid / Q;
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 0] = gs1[sl][e];
-        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 1] = gs2[sl][e];
-      }
-    __syncthreads();
-    for (int i = tid; i < 2 * BN; i += 256) {
-      const int sl = i / BN, c = i - sl * BN;
-      const int col = n0 + c;
-      const int n = n_first + sl;
-      // slot 1 exists only if the tile reaches into the next image
-      const bool live = col < d.Cout && n < d.N && (sl == 0 || (m0 + BM > m_split && m_split < Meff));
-      if (!live) continue;
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < RG; ++r) {
-        t1 += smem[((r * 2 + sl) * BN + c) * 2 + 0];
-        t2 += smem[((r * 2 + sl) * BN + c) * 2 + 1];
-      }
-      const int slab = row_t - (int)(((int64_t)n * HoWo) / BM);
-      float* o = a.gn_partial + (((int64_t)n * a.gn_slabs + slab) * d.Cout + col) * 2;
-      o[0] = t1;
-      o[1] = t2;
-    }
-  }
+  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
+
 
 // Two entry points over one body.  Variants WITHOUT a GroupNorm prologue fit 128 VGPRs
 // and are held to 4 waves per SIMD (measured +3-4 % on the big Dense layers: more waves to
@@ -634,59 +450,6 @@ inline bool conv_dma_enabled() {
   return on;
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(
-    const float* __restrict__ partial, int S, int64_t M, int Cout, int Cout_stride, int epi,
-    const float* __restrict__ bias, const float* __restrict__ residual,
-    const uint8_t* __restrict__ row_mask, float* __restrict__ y) {
-  const int Q = Cout >> 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * Q) return;
-  const int64_t m = i / Q;
-  const int col = 4 * (int)(i - m * Q);
-  f32x4 v = *reinterpret_cast<const f32x4*>(partial + m * Cout + col);
-  for (int s = 1; s < S; ++s) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * M + m) * Cout + col);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += t[e];
-  }
-  const int64_t o = m * Cout_stride + col;
-  if (epi & SNAP_EPI_BIAS) {
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += bb[e];
-  }
-  if (epi & SNAP_EPI_RESIDUAL) {
-    const f32x4 rr = *reinterpret_cast<const f32x4*>(residual + o);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += rr[e];
-  }
-  if (epi & SNAP_EPI_RELU) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-  }
-  if ((epi & SNAP_EPI_ROWMASK) && row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-  *reinterpret_cast<f32x4*>(y + o) = v;
-}
-
-// split-K heuristic: launches with at most splitk_max_tiles() output tiles (1.5 per CU)
-// are split into about splitk_target() workgroups.  Measured in one box (C2 inference /
-// C3 train step): off 59.75 / 162.5 ms; tiles<=128 59.96 / 159.9; tiles<=384, target 768
-// 59.34 / 157.8; tiles<=256, target 1024 59.55 / 158.4.
-// SNAP_CONV_SPLITK=<target> (0 disables), SNAP_CONV_SPLITK_TILES=<max tiles>.
-inline int64_t splitk_max_tiles() {
-  static const int t = []() {
-    const char* e = getenv("SNAP_CONV_SPLITK_TILES");
-    return e ? atoi(e) : 384;
-  }();
-  return t;
-}
-inline int splitk_target() {
-  static const int t = []() {
-    const char* e = getenv("SNAP_CONV_SPLITK");
-    return e ? atoi(e) : 768;
-  }();
-  return t;
-}
 
 template <int BM, int BN, bool VEC, int PRO, int BK>
 int launch(ConvArgs a, hipStream_t s) {
@@ -774,30 +537,6 @@ inline int conv_bk() {
   return (e && atoi(e) == 32) ? 32 : 16;
 }
 
-// SNAP_CONV_TILE=128x128|128x64|64x128|64x64 forces a tile (tests / tuning).
-inline int conv_forced_tile() {
-  const char* e = getenv("SNAP_CONV_TILE");
-  if (!e) return 0;
-  int bm = 0, bn = 0;
-  if (sscanf(e, "%dx%d", &bm, &bn) != 2) return 0;
-  return bm * 1000 + bn;
-}
-
-// Tile choice: the largest tile that still yields >= 2 workgroups per CU; small-M
-// layers (deep stages, few images) fall back to 64x64 tiles to fill the 256 CUs.
-struct TileChoice { int bm, bn; };
-inline TileChoice choose_tile(int64_t M, int64_t N) {
-  const int64_t kMin = 512;
-  const bool n_wide_ok = N > 64 && !(N % 128 != 0 && N % 128 <= 64);
-  const int forced = conv_forced_tile();
-  if (forced == 128128 || (!forced && n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin))
-    return {128, 128};
-  if (forced == 128064 || (!forced && snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)) return {128, 64};
-  if (forced == 64128 ||
-      (!forced && n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin))
-    return {64, 128};
-  return {64, 64};
-}
 
 template <bool VEC>
 int launch_tile(const ConvArgs& a, hipStream_t s) {
@@ -930,5 +669,15 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
     a.ablate = ab ? atoi(ab) : 0;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // bf16-operand engine (training precision): needs the packed bf16 weights and the float4
+  // loader's alignment; anything else runs on the (more precise) f32 engine below.
+  a.w_bf16 = ex ? ex->w_bf16 : nullptr;
+  a.cin8 = (d.Cin + 7) / 8 * 8;
+  if (a.w_bf16 && vec) {
+    if (ex->w_bf16_bytes < snap_conv2d_packed_weights_bytes(d.KH * d.KW, d.Cin, d.Cout))
+      return SNAP_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(a.w_bf16) & 15) return SNAP_ERR_BAD_SHAPE;
+    return snapconv::launch_bf16(a, s);
+  }
   return vec ? launch_tile<true>(a, s) : launch_tile<false>(a, s);
 }

@@ -13,37 +13,9 @@
 // Used for: every conv / Dense kernel gradient (VJP of snap/models/resnet.py StdConv,
 // image_encoder.py skip convs, layers.py Dense), d fm = G^T fq of the similarity VJP
 // (bev_localizer.py:157) and the matching-head kernel gradient (bev_mapper.py:285).
-#include <stdlib.h>
-
-#include "common.h"
+#include "wgrad_common.h"
 
 namespace {
-
-struct WgradArgs {
-  SnapConvDesc d;
-  const float* x;
-  const float* dy;
-  float* partial;  // [S, K, Cout]
-  const float* gn_mu;
-  const float* gn_sc;
-  const float* gn_beta;
-  int M, K;
-  int ctiles;      // channel tiles per (kh,kw) tap
-  int ncol;        // Cout tiles
-  int slabs_per_chunk;
-  const int32_t* rows_z;     // optional: reduction row m reads x row rows_z[m] (flat 1x1 only)
-  const int32_t* rows_dy;    // optional: ... and dy row rows_dy[m]
-  const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
-};
-
-template <int PRO>
-__device__ __forceinline__ float wg_pro(float v, float mu, float sc, float beta, float s, float t) {
-  if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
-  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
-  if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
-  if constexpr (PRO == SNAP_PRO_RELU) return fmaxf(v, 0.f);
-  return v;
-}
 
 template <int BKT, int BN, bool VEC, int PRO>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
@@ -317,31 +289,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, in
   dw[i] = t;
 }
 
-struct WgPlan { int bkt, bn, ctiles, ncol, ktiles, S, slabs_per_chunk; };
-
-inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
-  WgPlan p;
-  p.bkt = (vec && d.Cin > 64) ? 128 : 64;
-  p.bn = d.Cout > 64 ? 128 : 64;
-  p.ctiles = (d.Cin + p.bkt - 1) / p.bkt;
-  p.ncol = (d.Cout + p.bn - 1) / p.bn;
-  const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
-  // row tiles: per-tap channel tiles (VEC) or flat-k tiles (scalar path)
-  p.ktiles = vec ? d.KH * d.KW * p.ctiles : (d.KH * d.KW * d.Cin + p.bkt - 1) / p.bkt;
-  // the M split of the VEC plan is sized on 64-channel tiles so that it (and the
-  // workspace) does not depend on BKT.
-  const int64_t tiles = vec ? (int64_t)d.KH * d.KW * ((d.Cin + 63) / 64) * p.ncol
-                            : (int64_t)p.ktiles * p.ncol;
-  int64_t S = (1024 + tiles - 1) / tiles;
-  const int64_t smax = (M + 255) / 256;   // >= 16 slabs per chunk
-  if (S > smax) S = smax;
-  if (S < 1) S = 1;
-  const int64_t slabs = (M + 15) / 16;
-  p.slabs_per_chunk = (int)((slabs + S - 1) / S);
-  p.S = (int)((slabs + p.slabs_per_chunk - 1) / p.slabs_per_chunk);
-  return p;
-}
-
 template <int BKT, int BN, bool VEC, int PRO>
 int wg_launch(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
   const dim3 grid((unsigned)(p.ktiles * p.ncol), (unsigned)p.S);
@@ -390,6 +337,18 @@ extern "C" int snap_conv2d_wgrad_rows_f32(const SnapConvDesc* desc, const float*
                                           size_t workspace_bytes, const int32_t* rows_z,
                                           const int32_t* rows_dy, const int32_t* row_count,
                                           void* stream) {
+  return snap_conv2d_wgrad_ex_f32(desc, x, dy, dw, gn_mu, gn_sc, gn_beta, accumulate, workspace,
+                                  workspace_bytes, rows_z, rows_dy, row_count, SNAP_MATH_F32, stream);
+}
+
+extern "C" int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x,
+                                        const float* dy, float* dw, const float* gn_mu,
+                                        const float* gn_sc, const float* gn_beta,
+                                        int32_t accumulate, void* workspace,
+                                        size_t workspace_bytes, const int32_t* rows_z,
+                                        const int32_t* rows_dy, const int32_t* row_count,
+                                        int32_t math, void* stream) {
+  if (math != SNAP_MATH_F32 && math != SNAP_MATH_BF16) return SNAP_ERR_UNSUPPORTED;
   if (!desc || !x || !dy || !dw || !workspace) return SNAP_ERR_NULL;
   if ((rows_z || rows_dy) && !(desc->KH == 1 && desc->KW == 1 && desc->stride == 1 &&
                                desc->N == 1 && desc->H == 1 && desc->pad_t == 0 &&
@@ -420,7 +379,9 @@ extern "C" int snap_conv2d_wgrad_rows_f32(const SnapConvDesc* desc, const float*
   a.rows_z = rows_z; a.rows_dy = rows_dy; a.row_count = row_count;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
-  if (vec) {
+  if (vec && math == SNAP_MATH_BF16) {
+    rc = snapwg::launch_bf16(a, p, s);
+  } else if (vec) {
     if (p.bkt == 128) rc = p.bn == 128 ? wg_launch_pro<128, 128, true>(a, p, s) : wg_launch_pro<128, 64, true>(a, p, s);
     else rc = p.bn == 128 ? wg_launch_pro<64, 128, true>(a, p, s) : wg_launch_pro<64, 64, true>(a, p, s);
   } else {

@@ -1,0 +1,227 @@
+// Weight-gradient engine with bf16 operands and f32 accumulation
+// (v_mfma_f32_32x32x16_bf16): dW[k, co] = sum_m bf16(Z[m, k]) * bf16(dY[m, co]) -- the
+// training-precision companion of conv_bf16.hip (reference analogue: the float16 train
+// config, snap/configs/train_localization.py:25); wgrad.hip stays the exact path.
+//
+// Same tiling, M split and fixed-order reduction as wgrad.hip.  The reduction runs over the
+// output pixels m, so both MFMA fragments need 8 CONSECUTIVE m of one channel / one output
+// column: the loader transposes in registers.  A thread owns one channel quad and 4
+// consecutive rows m (lane % 8 picks the row group, lane / 8 the quad: every row is read in
+// 128-byte runs), applies the prologue in f32, rounds, and writes each channel's 4 values as
+// one ds_write_b64 into a [channel][32 m] image with an 80-byte row stride -- 5 x 16 bytes,
+// so both the 8-byte transposing stores and the ds_read_b128 fragment fetches are
+// conflict-free without a swizzle.
+#include "wgrad_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int BKT, int BN, int PRO>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
+  constexpr int RS = 32;                   // reduction slab (output pixels) = two MFMA k-steps
+  constexpr int RSB = 80;                  // LDS row stride in bytes (32 bf16 + 16 B pad)
+  constexpr int TM = BKT / 64, TN = BN / 64;
+  constexpr int ZQ = BKT / 4, DQ = BN / 4; // float4 quads per row
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  constexpr int Z_ST = BKT * RSB, D_ST = BN * RSB;   // bytes per stage
+  __shared__ __attribute__((aligned(16))) char smem[2 * Z_ST + 2 * D_ST];
+  char* const Zs0 = smem;
+  char* const Ds0 = smem + 2 * Z_ST;
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int kt = blockIdx.x / a.ncol, col_t = blockIdx.x - kt * a.ncol;
+  const int kpos = kt / a.ctiles, ct = kt - kpos * a.ctiles;
+  const int kh = kpos / d.KW, kw = kpos - kh * d.KW;
+  const int c0 = ct * BKT;
+  const int n0 = col_t * BN;
+  const int HoWo = d.Ho * d.Wo;
+  const int64_t Meff = a.row_count ? min((int64_t)*a.row_count, (int64_t)a.M) : (int64_t)a.M;
+  // chunk of the M axis owned by this workgroup (the plan counts 16-row slabs)
+  const int64_t rpc = a.row_count ? ((((Meff + 15) / 16) + gridDim.y - 1) / gridDim.y) * 16
+                                  : (int64_t)a.slabs_per_chunk * 16;
+  const int64_t m_begin = (int64_t)blockIdx.y * rpc;
+  const int64_t m_end = min(Meff, m_begin + rpc);
+  const int nslab = m_end > m_begin ? (int)((m_end - m_begin + RS - 1) / RS) : 0;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // loader coordinates: row group (4 consecutive m) and quad
+  const int mg = tid & 7;
+  const int quad = tid >> 3;                  // 0..31
+  const bool z_on = quad < ZQ, d_on = quad < DQ;
+  const int zc = c0 + 4 * quad;
+  const int dcol = n0 + 4 * quad;
+  f32x4 zr[4], zmu[4], zsc[4], zbeta = {0.f, 0.f, 0.f, 0.f};
+  bool zin[4];
+  f32x4 dr[4];
+  bool din[4];
+  if constexpr (need_gn) {
+    zbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + ((z_on && zc < d.Cin) ? zc : 0));
+  }
+
+  int rn[4], rho[4], rwo[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int64_t m = m_begin + 4 * mg + p;
+    const int mm = (int)min(m, (int64_t)a.M - 1);
+    rn[p] = mm / HoWo;
+    const int r = mm - rn[p] * HoWo;
+    rho[p] = r / d.Wo;
+    rwo[p] = r - rho[p] * d.Wo;
+  }
+  auto advance_rows = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      rwo[p] += RS;
+      while (rwo[p] >= d.Wo) { rwo[p] -= d.Wo; ++rho[p]; }
+      while (rho[p] >= d.Ho) { rho[p] -= d.Ho; ++rn[p]; }
+    }
+  };
+
+  auto load_slab = [&](int sl) {
+    const int64_t ms = m_begin + (int64_t)sl * RS + 4 * mg;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t m = ms + p;
+      const bool mok = m < m_end;
+      const int n = rn[p], ho = rho[p], wo = rwo[p];
+      const int hi = ho * d.stride - d.pad_t + kh, wi = wo * d.stride - d.pad_l + kw;
+      const bool inb = mok && z_on && zc < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+      zin[p] = inb;
+      int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + zc : (int64_t)0;
+      if (a.rows_z) off = inb ? (int64_t)a.rows_z[m] * d.Cin_stride + zc : (int64_t)0;
+      zr[p] = *reinterpret_cast<const f32x4*>(a.x + off);
+      if constexpr (need_gn) {
+        const int64_t so = inb ? (int64_t)n * d.Cin + zc : (int64_t)0;
+        zmu[p] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
+        zsc[p] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
+      }
+      const bool ok = mok && d_on && dcol < d.Cout;
+      din[p] = ok;
+      const int64_t drow = (ok && a.rows_dy) ? (int64_t)a.rows_dy[m] : m;
+      dr[p] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? drow * d.Cout_stride + dcol : (int64_t)0));
+    }
+  };
+
+  auto store_slab = [&](int buf) {
+    char* zs = Zs0 + buf * Z_ST;
+    char* ds = Ds0 + buf * D_ST;
+    f32x4 zv[4], dv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pv;
+        if constexpr (need_gn)
+          pv = wg_pro<PRO>(zr[p][e], zmu[p][e], zsc[p][e], zbeta[e], d.in_scale, d.in_shift);
+        else
+          pv = wg_pro<PRO>(zr[p][e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+        zv[p][e] = (zin[p] && (zc + e < d.Cin)) ? pv : 0.f;
+      }
+      dv[p] = din[p] ? dr[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (z_on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 t = {zv[0][e], zv[1][e], zv[2][e], zv[3][e]};   // 4 consecutive m of channel e
+        *reinterpret_cast<bf16x4*>(zs + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, bf16x4);
+      }
+    }
+    if (d_on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 t = {dv[0][e], dv[1][e], dv[2][e], dv[3][e]};
+        *reinterpret_cast<bf16x4*>(ds + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, bf16x4);
+      }
+    }
+  };
+
+  if (nslab > 0) {
+    load_slab(0);
+    advance_rows();
+    store_slab(0);
+  }
+  __syncthreads();
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int cur = sl & 1;
+    const bool more = sl + 1 < nslab;
+    if (more) {
+      load_slab(sl + 1);
+      advance_rows();
+    }
+    const char* zs = Zs0 + cur * Z_ST;
+    const char* ds = Ds0 + cur * D_ST;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        av[i] = *reinterpret_cast<const bf16x8*>(zs + (wr * (BKT / 2) + i * 32 + l31) * RSB + (2 * s + lhi) * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bv[j] = *reinterpret_cast<const bf16x8*>(ds + (wc * (BN / 2) + j * 32 + l31) * RSB + (2 * s + lhi) * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_slab(cur ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> workspace [chunk][K][Cout]
+  float* out = a.partial + (int64_t)blockIdx.y * a.K * d.Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int c = c0 + wr * (BKT / 2) + i * 32 + ri;
+      if (c >= d.Cin) continue;
+      const int64_t krow = (int64_t)kpos * d.Cin + c;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+        if (col < d.Cout) out[krow * d.Cout + col] = acc[i][j][r];
+      }
+    }
+}
+
+template <int BKT, int BN, int PRO>
+int wg_launch(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
+  const dim3 grid((unsigned)(p.ktiles * p.ncol), (unsigned)p.S);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO>), grid, dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+template <int BKT, int BN>
+int wg_launch_pro(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
+  switch (a.d.prologue) {
+    case SNAP_PRO_NONE: return wg_launch<BKT, BN, SNAP_PRO_NONE>(a, p, s);
+    case SNAP_PRO_AFFINE: return wg_launch<BKT, BN, SNAP_PRO_AFFINE>(a, p, s);
+    case SNAP_PRO_GN_RELU: return wg_launch<BKT, BN, SNAP_PRO_GN_RELU>(a, p, s);
+    case SNAP_PRO_RELU_GN: return wg_launch<BKT, BN, SNAP_PRO_RELU_GN>(a, p, s);
+    case SNAP_PRO_RELU: return wg_launch<BKT, BN, SNAP_PRO_RELU>(a, p, s);
+    default: return SNAP_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+
+int snapwg::launch_bf16(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
+  if (p.bkt == 128) return p.bn == 128 ? wg_launch_pro<128, 128>(a, p, s) : wg_launch_pro<128, 64>(a, p, s);
+  return p.bn == 128 ? wg_launch_pro<64, 128>(a, p, s) : wg_launch_pro<64, 64>(a, p, s);
+}

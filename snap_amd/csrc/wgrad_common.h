@@ -1,0 +1,76 @@
+// Shared pieces of the weight-gradient engines (wgrad.hip: exact f32; wgrad_bf16.hip: bf16
+// operands / f32 accumulate): launch arguments, the fused prologues and the launch plan.
+#ifndef SNAP_CSRC_WGRAD_COMMON_H_
+#define SNAP_CSRC_WGRAD_COMMON_H_
+
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace snapwg {
+
+struct WgradArgs {
+  SnapConvDesc d;
+  const float* x;
+  const float* dy;
+  float* partial;  // [S, K, Cout]
+  const float* gn_mu;
+  const float* gn_sc;
+  const float* gn_beta;
+  int M, K;
+  int ctiles;      // channel tiles per (kh,kw) tap
+  int ncol;        // Cout tiles
+  int slabs_per_chunk;
+  const int32_t* rows_z;     // optional: reduction row m reads x row rows_z[m] (flat 1x1 only)
+  const int32_t* rows_dy;    // optional: ... and dy row rows_dy[m]
+  const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
+};
+
+struct WgPlan { int bkt, bn, ctiles, ncol, ktiles, S, slabs_per_chunk; };
+
+inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
+  WgPlan p;
+  p.bkt = (vec && d.Cin > 64) ? 128 : 64;
+  p.bn = d.Cout > 64 ? 128 : 64;
+  p.ctiles = (d.Cin + p.bkt - 1) / p.bkt;
+  p.ncol = (d.Cout + p.bn - 1) / p.bn;
+  const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+  // row tiles: per-tap channel tiles (VEC) or flat-k tiles (scalar path)
+  p.ktiles = vec ? d.KH * d.KW * p.ctiles : (d.KH * d.KW * d.Cin + p.bkt - 1) / p.bkt;
+  // the M split of the VEC plan is sized on 64-channel tiles so that it (and the
+  // workspace) does not depend on BKT.
+  const int64_t tiles = vec ? (int64_t)d.KH * d.KW * ((d.Cin + 63) / 64) * p.ncol
+                            : (int64_t)p.ktiles * p.ncol;
+  int64_t S = (1024 + tiles - 1) / tiles;
+  const int64_t smax = (M + 255) / 256;   // >= 16 slabs per chunk
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  const int64_t slabs = (M + 15) / 16;
+  p.slabs_per_chunk = (int)((slabs + S - 1) / S);
+  p.S = (int)((slabs + p.slabs_per_chunk - 1) / p.slabs_per_chunk);
+  return p;
+}
+
+
+// bf16-operand engine (wgrad_bf16.hip); `a` / `p` prepared by snap_conv2d_wgrad_ex_f32
+int launch_bf16(const WgradArgs& a, const WgPlan& p, hipStream_t s);
+
+}  // namespace snapwg
+
+namespace {
+using snapwg::WgradArgs;
+using snapwg::WgPlan;
+using snapwg::wg_plan;
+
+template <int PRO>
+__device__ __forceinline__ float wg_pro(float v, float mu, float sc, float beta, float s, float t) {
+  if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
+  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
+  if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
+  if constexpr (PRO == SNAP_PRO_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+}  // namespace
+
+#endif  // SNAP_CSRC_WGRAD_COMMON_H_

@@ -147,9 +147,12 @@ def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
-    emit_gn_stats=None,
+    emit_gn_stats=None, math=None,
 ):
-  """NHWC implicit-GEMM conv on f32 MFMA.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
+  """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
+
+  math = 'f32' (exact f32 MFMA, the parity path) | 'bf16' (operands rounded to bf16 after the
+  f32 prologue, f32 accumulate: the training-precision engine); None = ``MATMUL_PRECISION``.
 
   gn = (mu [N,Cin], sc [N,Cin], beta [Cin]) for PRO_GN_RELU / PRO_RELU_GN.
   rows_in / rows_out (int32 [M]) + row_count (int32 [1], device): row-indexed launch
@@ -213,18 +216,31 @@ def conv2d(
   partial = None
   kws = None
   if rows_in is not None or rows_out is not None or row_count is not None:
-    ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0)
+    ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0,
+                             None, 0)
   else:
     wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if USE_SPLITK else 0
     if wbytes:   # small-M / deep-K layer: split K (its statistics are cheap to take after)
       kws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
-      ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes)
+      ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes, None, 0)
     elif emit_gn_stats is not None:
       pbytes = lib.snap_conv2d_gn_partial_bytes(ctypes.byref(d))
       if pbytes:
         partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
         ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
-                                 int(emit_gn_stats == 'relu'), None, 0)
+                                 int(emit_gn_stats == 'relu'), None, 0, None, 0)
+  math = MATMUL_PRECISION if math is None else math
+  if math not in ('f32', 'bf16'):
+    raise ValueError(f'conv2d: math={math!r}')
+  family = 'conv_igemm'
+  wpk = None
+  if math == 'bf16' and Cs % 4 == 0 and Cin >= 4:
+    wpk = pack_weights_bf16(w)
+    if ex is None:
+      ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
+    ex.w_bf16 = wpk.data_ptr()
+    ex.w_bf16_bytes = wpk.numel() * 2
+    family = 'conv_bf16'
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -233,7 +249,7 @@ def conv2d(
     flops = lambda: kflops * int(row_count.item())
     nbytes = lambda: 4.0 * (int(row_count.item()) * (Cin + Cout) + w.numel())
   with _region(
-      'conv_igemm', flops, nbytes,
+      family, flops, nbytes,
       lambda: f'M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}_s{stride}'
               f'_p{prologue}_e{epi}',
   ):
@@ -248,8 +264,20 @@ def conv2d(
   return y
 
 
+def pack_weights_bf16(w):
+  """w [KH,KW,Cin,Cout] f32 -> the bf16 engine's weight image [Cout][KH*KW][roundup(Cin,8)]."""
+  lib = _lib.load()
+  _f32(w, 'w')
+  KH, KW, Cin, Cout = w.shape
+  nbytes = lib.snap_conv2d_packed_weights_bytes(KH * KW, Cin, Cout)
+  out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+  st = lib.snap_conv2d_pack_weights_bf16(_p(w), KH * KW, Cin, Cout, _p(out), nbytes, _stream())
+  _lib.check(st, 'snap_conv2d_pack_weights_bf16')
+  return out
+
+
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
-          row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None):
+          row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None):
   """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1)."""
   lead = x.shape[:-1]
   M = int(np.prod(lead)) if len(lead) else 1
@@ -258,6 +286,7 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
       cin=cin if cin is not None else kernel.shape[0], prologue=prologue,
       bias=bias, relu=relu, row_mask=row_mask, rows_in=rows_in, rows_out=rows_out,
       row_count=row_count, out=None if out is None else out.reshape(1, 1, M, kernel.shape[1]),
+      math=math,
   )
   return y.reshape(*lead, kernel.shape[1])
 
@@ -342,6 +371,10 @@ def weight_standardize_bwd_multi(ws, dwss, eps=1e-10):
 
 
 USE_FUSED_GN_STATS = True
+# 'f32': every conv / dense runs on the exact f32 matrix-core path (inference, parity).
+# 'bf16': operands rounded to bf16, f32 accumulate -- the training-precision analogue of the
+# reference's float16 train config (train_localization.py:25); set by the trainer.
+MATMUL_PRECISION = 'f32'
 USE_SPLITK = True           # tests flip it: split-K vs single-pass launches   # tests flip it to compare against the stand-alone kernel
 
 

@@ -25,10 +25,15 @@ def _conv_desc(x_shape, w_shape, stride, padding, prologue, in_affine, cs=None):
 
 
 def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue=ops.PRO_NONE,
-                 gn=None, in_affine=(1.0, 0.0), rows_z=None, rows_dy=None, row_count=None):
+                 gn=None, in_affine=(1.0, 0.0), rows_z=None, rows_dy=None, row_count=None,
+                 math=None):
   """dw [KH,KW,Cin,Cout] = im2col(prologue(x))^T dy  (MFMA; deterministic split-M).
 
-  rows_z / rows_dy / row_count: row lists over flat [1,1,M,C] operands (masked MLP)."""
+  rows_z / rows_dy / row_count: row lists over flat [1,1,M,C] operands (masked MLP).
+  math: 'f32' | 'bf16' (None = ``ops.MATMUL_PRECISION``), as ``ops.conv2d``."""
+  math = ops.MATMUL_PRECISION if math is None else math
+  if math not in ('f32', 'bf16'):
+    raise ValueError(f'conv2d_wgrad: math={math!r}')
   lib = _lib.load()
   _f32(x, 'x'); _f32(dy, 'dy')
   d, yshape = _conv_desc(x.shape, w_shape, stride, padding, prologue, in_affine)
@@ -47,12 +52,13 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   M = yshape[0] * yshape[1] * yshape[2]
   kfl = 2.0 * KH * KW * Cin * Cout
   flops = kfl * M if row_count is None else (lambda: kfl * int(row_count.item()))
-  with _region('conv_wgrad', flops, 4.0 * (x.numel() + dy.numel())):
-    st = lib.snap_conv2d_wgrad_rows_f32(
+  bf16 = math == 'bf16' and x.shape[-1] % 4 == 0 and Cin >= 4
+  with _region('conv_wgrad_bf16' if bf16 else 'conv_wgrad', flops, 4.0 * (x.numel() + dy.numel())):
+    st = lib.snap_conv2d_wgrad_ex_f32(
         ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(mu), _p(sc), _p(beta), 0, _p(ws),
-        ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), _stream(),
+        ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), int(bf16), _stream(),
     )
-  _lib.check(st, 'snap_conv2d_wgrad_rows_f32')
+  _lib.check(st, 'snap_conv2d_wgrad_ex_f32')
   return dw
 
 

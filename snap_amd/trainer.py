@@ -15,6 +15,7 @@ from typing import Any, Callable, Dict, List, Optional
 import torch
 
 from snap_amd import dist as sdist
+from snap_amd import ops
 
 
 def flatten_params(tree, prefix=''):
@@ -69,8 +70,14 @@ def _global_norm(tensors):
 
 
 def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_norm=None,
-               group=None, debug=False, overlap_allreduce=True):
+               group=None, debug=False, overlap_allreduce=True, precision='f32'):
   """One optimisation step.  Returns (state, metrics, training_logs).
+
+  precision: 'f32' -- every conv / dense (forward, dgrad, wgrad) on the exact f32 matrix
+  cores; 'bf16' -- their operands are rounded to bf16 with f32 accumulation (the analogue of
+  the reference's ``dtype='float16'`` train config, train_localization.py:25, trainer.py:391;
+  bf16 keeps the f32 exponent range, so no DynamicScale loss scaling is needed).  Parameters,
+  gradients, Adam state, GroupNorm statistics and all non-GEMM kernels stay f32.
 
   With more than one rank and ``overlap_allreduce`` the gradient buckets are all-reduced
   while the backward pass is still running (``dist.OverlappedGradReducer``); otherwise one
@@ -83,22 +90,15 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   state.rng += 1
   rank = torch.distributed.get_rank(group) if sdist._world(group) > 1 else 0
   sampling_rng = state.rng * 7919 + rank            # bind the stream to the device
-  with torch.enable_grad():
-    pred = model.flax_model.apply(
-        {'params': state.params}, batch, train=True, rngs={'sampling': sampling_rng},
-        mutable=False, debug=debug,
-    )
-    losses, metrics = model.loss_metrics_function(pred, batch, state.params)
-    mask = batch['batch_mask'].to(losses['total'].dtype)
-    loss = (losses['total'] * mask).sum() / mask.sum().clamp(min=1)
-    if sdist._world(group) > 1 and overlap_allreduce:
-      reducer = sdist.OverlappedGradReducer(leaves, group).attach()
-      loss.backward()                                  # buckets go out as their grads land
-      grads = reducer.finish()                         # jax.lax.pmean(grad, 'batch')
-    else:
-      grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-      grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
-      sdist.allreduce_mean_(grads, group)              # jax.lax.pmean(grad, 'batch')
+  if precision not in ('f32', 'bf16'):
+    raise ValueError(f'train_step: precision={precision!r}')
+  prev_precision = ops.MATMUL_PRECISION
+  ops.MATMUL_PRECISION = precision      # read by the backward thread too (module global)
+  try:
+    grads, loss, losses, metrics = _forward_backward(state, batch, model, leaves, sampling_rng,
+                                                     group, debug, overlap_allreduce)
+  finally:
+    ops.MATMUL_PRECISION = prev_precision
   for t in leaves:
     t.requires_grad_(False)
     t.grad = None
@@ -124,3 +124,24 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   state.global_step += 1
   logs['loss'] = float(loss.detach())
   return state, reduced, logs
+
+
+def _forward_backward(state, batch, model, leaves, sampling_rng, group, debug, overlap_allreduce):
+  """Loss + (all-reduced) gradients of one batch."""
+  with torch.enable_grad():
+    pred = model.flax_model.apply(
+        {'params': state.params}, batch, train=True, rngs={'sampling': sampling_rng},
+        mutable=False, debug=debug,
+    )
+    losses, metrics = model.loss_metrics_function(pred, batch, state.params)
+    mask = batch['batch_mask'].to(losses['total'].dtype)
+    loss = (losses['total'] * mask).sum() / mask.sum().clamp(min=1)
+    if sdist._world(group) > 1 and overlap_allreduce:
+      reducer = sdist.OverlappedGradReducer(leaves, group).attach()
+      loss.backward()                                  # buckets go out as their grads land
+      grads = reducer.finish()                         # jax.lax.pmean(grad, 'batch')
+    else:
+      grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+      grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
+      sdist.allreduce_mean_(grads, group)              # jax.lax.pmean(grad, 'batch')
+  return grads, loss, losses, metrics

@@ -64,12 +64,21 @@ def _prologue(x, prologue, gn, in_affine, cin):
 
 def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
            gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
-           up_prev=None, row_mask=None, emit_gn_stats=None):
+           up_prev=None, row_mask=None, emit_gn_stats=None, math=None):
   # emit_gn_stats: a speed hint of the HIP path (statistics out of the epilogue); no-op here.
+  # math='bf16': both operands rounded to bf16 after the f32 prologue, products summed in
+  # float64 (the engine accumulates in f32: the test tolerance covers the summation order).
   xn, wn = _np(x, DTYPE), _np(w, DTYPE)
   cin = wn.shape[2] if cin is None else cin
+  cs = xn.shape[-1]
   xn = _prologue(xn, prologue, gn, in_affine, cin)
-  y = o_enc.conv2d(xn, wn, (stride, stride), padding)
+  if math == 'bf16' and cs % 4 == 0 and cin >= 4:   # (other shapes run on the f32 engine)
+    xn = o_enc.bf16_round(xn.astype(np.float32)).astype(np.float64)
+    wn = o_enc.bf16_round(wn.astype(np.float32)).astype(np.float64)
+    y = o_enc.conv2d(xn, wn, (stride, stride), padding).astype(DTYPE)
+    xn = None
+  if xn is not None:
+    y = o_enc.conv2d(xn, wn, (stride, stride), padding)
   if bias is not None:
     y = y + _np(bias, DTYPE)
   if residual is not None:

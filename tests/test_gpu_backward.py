@@ -91,6 +91,56 @@ def test_conv_wgrad(case):
   helpers.report('wgrad ' + case[0], got, ref.float(), atol=2e-4 * float(ref.abs().max()) + 1e-5)
 
 
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_conv_wgrad_bf16(case):
+  """bf16-operand wgrad engine vs the restatement that rounds prologue(x) and dy to bf16
+  (oracle/encoder.py:bf16_round) and accumulates exactly; fp32 round-off class tolerance."""
+  from oracle import encoder as o_enc
+  _, N, H, W, Cin, k, Cout, stride, pad, pro = case
+  cs = 260 if Cin == 257 else Cin
+  x = torch.zeros(N, H, W, cs)
+  x[..., :Cin] = rnd((N, H, W, Cin), 1) + 0.1
+  gamma, beta = rnd((Cin,), 3) * 0.3 + 1, rnd((Cin,), 4) * 0.2
+  Ho = (H + 2 * pad - k) // stride + 1
+  Wo = (W + 2 * pad - k) // stride + 1
+  dy = rnd((N, Ho, Wo, Cout), 5)
+  gn = gn_cpu = None
+  if pro in (ops.PRO_GN_RELU, ops.PRO_RELU_GN):
+    mu, sc = oracle_ops.group_norm_stats(x[..., :Cin].contiguous(), gamma,
+                                         relu_first=pro == ops.PRO_RELU_GN)
+    gn = (G(mu), G(sc), G(beta))
+    gn_cpu = (mu, sc, beta)
+  aff = (2.0, -1.0) if pro == ops.PRO_AFFINE else (1.0, 0.0)
+  z32 = oracle_ops._prologue(x.numpy().astype(np.float32), pro, gn_cpu, aff, Cin)
+  bf16_path = cs % 4 == 0 and Cin >= 4
+  rz = o_enc.bf16_round(z32) if bf16_path else z32
+  rdy = o_enc.bf16_round(dy.numpy()) if bf16_path else dy.numpy()
+  wd = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+  ref_conv(torch.from_numpy(rz).double(), wd, stride, pad).backward(torch.from_numpy(rdy).double())
+  got = ops_bwd.conv2d_wgrad(G(x), G(dy), (k, k, Cin, Cout), stride=stride,
+                             padding=((pad, pad), (pad, pad)), prologue=pro, gn=gn,
+                             in_affine=aff, math='bf16')
+  ref = wd.grad
+  helpers.report('wgrad bf16 ' + case[0], got, ref.float(), atol=2e-5 * float(ref.abs().max()) + 1e-5)
+
+
+def test_conv_wgrad_bf16_rows():
+  """Row lists + device-side row count on the bf16 wgrad engine."""
+  from oracle import encoder as o_enc
+  M, Cin, Cout = 5000, 260, 128
+  x = rnd((M, Cin), 71)
+  dy = rnd((M, Cout), 72)
+  mask = torch.rand(M, generator=torch.Generator().manual_seed(73)) > 0.55
+  index, count = ops.compact_rows(G(mask))
+  got = ops_bwd.conv2d_wgrad(G(x).reshape(1, 1, M, Cin), G(dy).reshape(1, 1, M, Cout),
+                             (1, 1, 257, Cout), rows_z=index, rows_dy=index, row_count=count,
+                             math='bf16')
+  zr = o_enc.bf16_round(x.numpy()[mask.numpy()][:, :257]).astype(np.float64)
+  dr = o_enc.bf16_round(dy.numpy()[mask.numpy()]).astype(np.float64)
+  ref = torch.from_numpy(zr.T @ dr).float().reshape(1, 1, 257, Cout)
+  helpers.report('wgrad bf16 rows', got, ref, atol=2e-5 * float(ref.abs().max()) + 1e-5)
+
+
 @pytest.mark.parametrize('k,stride,pad', [(1, 1, 0), (3, 1, 1), (3, 2, 1), (1, 2, 0)])
 def test_conv_dgrad_via_engine(k, stride, pad):
   from snap_amd import autograd as ag

@@ -99,6 +99,103 @@ def test_conv_every_tile_variant(tile, bk, monkeypatch):
   helpers.report(f'scalar path tile {tile}', got, want, atol=5e-5, rtol=1e-5)
 
 
+# bf16-operand engine (training precision): compared with the restatement that rounds both
+# operands to bf16 after the f32 prologue (oracle/encoder.py:bf16_round); what is left is the
+# f32 accumulation order, so the tolerance stays in the fp32 round-off class.
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_bf16_plain(case):
+  _, N, H, W, Cin, KH, KW, Cout, stride, pad = case
+  x = rnd((N, H, W, Cin), 1)
+  w = rnd((KH, KW, Cin, Cout), 2, 1.0 / np.sqrt(KH * KW * Cin))
+  kw = dict(stride=stride, padding=((pad, pad), (pad, pad)), math='bf16')
+  got, want = both('conv2d', (x, w), kw)
+  helpers.report('conv bf16 ' + case[0], got, want, atol=3e-5, rtol=1e-5)
+  # ... and it is NOT the f32 result (the engine really ran in bf16) where the shape allows it
+  if Cin >= 4 and Cin % 4 == 0 and DEV == 'cuda':
+    exact = oracle_ops.conv2d(x, w, stride=stride, padding=((pad, pad), (pad, pad)))
+    assert (got.cpu() - exact).abs().max() > 1e-4
+
+
+@pytest.mark.parametrize('tile', ['128x128', '128x64', '64x128', '64x64'])
+def test_conv_bf16_every_tile_variant(tile, monkeypatch):
+  monkeypatch.setenv('SNAP_CONV_TILE', tile)
+  N, H, W, Cin, Cout = 2, 15, 13, 96, 200
+  x = rnd((N, H, W, Cin), 31) + 0.2
+  w = rnd((3, 3, Cin, Cout), 32, 1 / np.sqrt(9 * Cin))
+  gamma, beta = rnd((Cin,), 33) + 1, rnd((Cin,), 34) * 0.1
+  res = rnd((N, H, W, Cout), 35)
+  bias = rnd((Cout,), 36)
+  for pro, relu_first in ((ops.PRO_GN_RELU, False), (ops.PRO_RELU_GN, True)):
+    mu, sc = oracle_ops.group_norm_stats(x, gamma, relu_first=relu_first)
+    kw = dict(padding=((1, 1), (1, 1)), prologue=pro, gn=(mu, sc, beta), residual=res,
+              bias=bias, relu=True, math='bf16')
+    got, want = both('conv2d', (x, w), kw)
+    helpers.report(f'conv bf16 tile {tile} pro {pro}', got, want, atol=5e-5, rtol=1e-5)
+  xs = rnd((1, 1, 700, 260), 37)
+  ws = rnd((1, 1, 257, 256), 38, 1 / 16.0)
+  got, want = both('conv2d', (xs, ws), dict(cin=257, prologue=ops.PRO_RELU, math='bf16'))
+  helpers.report(f'dense bf16 k257 tile {tile}', got, want, atol=5e-5, rtol=1e-5)
+  x2 = rnd((2, 11, 9, 40), 41)
+  w2 = rnd((3, 3, 40, 72), 42, 1 / np.sqrt(360))
+  prev = rnd((2, 3, 3, 72), 43)
+  got, want = both('conv2d', (x2, w2), dict(stride=2, padding=((1, 1), (1, 1)), up_prev=None,
+                                            prologue=ops.PRO_AFFINE, in_affine=(0.5, 0.25),
+                                            math='bf16'))
+  helpers.report(f'conv bf16 s2 affine tile {tile}', got, want, atol=5e-5, rtol=1e-5)
+  x3 = rnd((2, 6, 6, 64), 44)
+  w3 = rnd((1, 1, 64, 72), 45, 1 / 8.0)
+  got, want = both('conv2d', (x3, w3), dict(up_prev=prev, math='bf16'))
+  helpers.report(f'conv bf16 upsample-add tile {tile}', got, want, atol=5e-5, rtol=1e-5)
+
+
+def test_conv_bf16_rows_gnstats_splitk():
+  """Row-indexed launches, GroupNorm partial sums and split-K on the bf16 engine."""
+  g = torch.Generator().manual_seed(50)
+  M, Cin, Cout = 3000, 260, 256
+  x = rnd((M, Cin), 51)
+  w = rnd((257, Cout), 52, 1 / 16.0)
+  bias = rnd((Cout,), 53)
+  mask = torch.rand(M, generator=g) > 0.6
+  want = oracle_ops.dense(x, w, bias, cin=257, relu=True)
+  want_rows = want[mask]
+  index, count = ops.compact_rows(mask.to(DEV))
+  out = torch.zeros(M, Cout, device=DEV)
+  ops.dense(x.to(DEV), w.to(DEV), bias.to(DEV), cin=257, relu=True, rows_in=index, rows_out=index,
+            row_count=count, out=out, math='bf16')
+  want_b = oracle_ops.conv2d(x.reshape(1, 1, M, Cin), w.reshape(1, 1, 257, Cout), cin=257, bias=bias,
+                             relu=True, math='bf16').reshape(M, Cout)
+  helpers.report('bf16 row-indexed dense', out[mask.to(DEV)], want_b[mask], atol=5e-5, rtol=1e-5)
+  assert float(out[~mask.to(DEV)].abs().max()) == 0.0
+  del want_rows
+  # statistics out of the epilogue == statistics of the produced tensor
+  N, H, W, C1, C2 = 2, 24, 20, 64, 128
+  xi = rnd((N, H, W, C1), 54)
+  wi = rnd((3, 3, C1, C2), 55, 1 / 24.0)
+  gamma = rnd((C2,), 56) + 1
+  ops.USE_SPLITK = False     # (a launch that splits K takes its statistics afterwards)
+  try:
+    y = ops.conv2d(xi.to(DEV), wi.to(DEV), padding=((1, 1), (1, 1)), emit_gn_stats='raw', math='bf16')
+  finally:
+    ops.USE_SPLITK = True
+  assert hasattr(y, '_snap_gn_partial')
+  mu_f, sc_f = ops.group_norm_stats(y, gamma.to(DEV))
+  mu_w, sc_w = oracle_ops.group_norm_stats(y.cpu(), gamma)
+  helpers.report('bf16 fused gn mu', mu_f, mu_w, atol=1e-5, rtol=1e-5)
+  helpers.report('bf16 fused gn sc', sc_f, sc_w, atol=1e-5, rtol=5e-5)
+  # split-K (deep K, few tiles) against the single-pass launch
+  xs = rnd((2, 8, 8, 512), 57)
+  ws = rnd((3, 3, 512, 128), 58, 1 / np.sqrt(9 * 512))
+  kw = dict(padding=((1, 1), (1, 1)), math='bf16')
+  got, want = both('conv2d', (xs, ws), kw)
+  helpers.report('bf16 split-K', got, want, atol=5e-5, rtol=1e-5)
+  ops.USE_SPLITK = False
+  try:
+    single = ops.conv2d(xs.to(DEV), ws.to(DEV), **kw)
+  finally:
+    ops.USE_SPLITK = True
+  helpers.report('bf16 split-K vs single pass', got, single.cpu(), atol=2e-5, rtol=1e-5)
+
+
 def test_conv_affine_root():
   x = torch.rand((2, 20, 18, 3), generator=torch.Generator().manual_seed(3))
   w = rnd((7, 7, 3, 64), 4, 0.1)
