@@ -45,6 +45,10 @@ WORKLOADS = {
     'c3': dict(batch=4, views=4, image=512, grid=(25.6, 25.6, 12), tiny=False,
                desc='C3: train_localization default model, batch_size 32 over 8 GPUs = 4 scenes/GPU, '
                     '4 StreetView views @512px + aerial, 128x128x60 voxel BEV, ResNet-50 encoders'),
+    'c5': dict(batch=4, views=4, image=512, grid=(25.6, 25.6, 12), tiny=False, vit=True,
+               desc='C5: ViT-B/16 StreetView image encoder (bf16 matrix-core GEMMs + fused attention; '
+                    'not in the reference: build-only), ResNet-50 aerial, 128x128x60 voxel BEV, '
+                    'batch 32 over 8 GPUs = 4 scenes/GPU, forward'),
     'tiny': dict(batch=2, views=3, image=64, grid=(6.4, 6.4, 12), tiny=True,
                  desc='tiny plumbing workload (tests only)'),
 }
@@ -59,6 +63,11 @@ def build(workload, device, rank):
     cfg = helpers.tiny_localizer_config()
   else:
     cfg = train_localization.get_config().model
+    if w.get('vit'):
+      from snap_amd.configs import defaults
+      vcfg = defaults.image_encoder('vit')
+      vcfg.output_dim = cfg.bev_mapper.streetview_encoder.image_encoder.output_dim
+      cfg.bev_mapper.streetview_encoder.image_encoder = vcfg
   loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
   variables = loc.init(0, device='cpu')
   variables = {'params': _to(variables['params'], device)}
@@ -329,7 +338,8 @@ def main(argv=None):
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': ('f32' if (args.mode == 'infer' or args.precision == 'f32')
+        'dtype': ('bf16 ViT GEMMs + attention (f32 accumulate), f32 elsewhere' if WORKLOADS[args.workload].get('vit')
+                  else 'f32' if (args.mode == 'infer' or args.precision == 'f32')
                   else 'bf16 GEMM operands, f32 accumulate / parameters / optimizer'),
         'data': 'synthetic',
         'config': {
@@ -404,7 +414,7 @@ def main(argv=None):
     if args.mode == 'train':
       out['train_logs'] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in last_logs.items()}
     if (world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']
-        and args.mode == 'infer'):
+        and not WORKLOADS[args.workload].get('vit') and args.mode == 'infer'):
       try:
         out['cpu_baseline'] = cpu_baseline(cfg, meta, args.workload)
       except Exception as e:  # the baseline must never take the bench line down

@@ -52,7 +52,8 @@ const char* snap_build_arch(void);          /* "gfx950" */
 enum { SNAP_PRO_NONE = 0, SNAP_PRO_AFFINE = 1, SNAP_PRO_GN_RELU = 2,
        SNAP_PRO_RELU_GN = 3, SNAP_PRO_RELU = 4 };
 enum { SNAP_EPI_BIAS = 1, SNAP_EPI_RELU = 2, SNAP_EPI_RESIDUAL = 4,
-       SNAP_EPI_UPSAMPLE2X_ADD = 8, SNAP_EPI_ROWMASK = 16 };
+       SNAP_EPI_UPSAMPLE2X_ADD = 8, SNAP_EPI_ROWMASK = 16,
+       SNAP_EPI_GELU = 32 /* tanh-approximated GELU (ViT MLP), applied where ReLU is */ };
 
 typedef struct SnapConvDesc {
   int32_t N, H, W, Cin, Cin_stride;   /* input  x[N,H,W,Cin_stride], first Cin used */
@@ -121,6 +122,18 @@ int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const floa
 size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, int32_t Cout);
 int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
                                   void* out, size_t out_bytes, void* stream);
+
+/* ViT encoder pieces (BASELINE.json configs[4]; the reference itself has no ViT --
+ * snap/models/image_encoder.py:103 -- so these follow the published ViT block).
+ * snap_layer_norm_f32: y[m,:] = (x[m,:] - mean) * rsqrt(var + eps) * gamma + beta over the C
+ * channels of each of the M rows (biased variance); C % 4 == 0, C <= 1024.
+ * snap_attention_bf16_f32: multi-head self-attention softmax(scale * Q K^T) V on the bf16
+ * matrix cores (f32 softmax statistics and accumulation).  qkv [B, N, 3, H, D] f32 (the fused
+ * QKV projection's output), out [B, N, H*D] f32; D must be 64. */
+int snap_layer_norm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                        int64_t M, int32_t C, float eps, void* stream);
+int snap_attention_bf16_f32(const float* qkv, float* out, int32_t B, int32_t N, int32_t H,
+                            int32_t D, float scale, void* stream);
 
 /* Scratch for split-K launches (small-M / deep-K layers that cannot fill 256 CUs with output
  * tiles: slices of K go to extra workgroups, partial tiles are summed in fixed order by a

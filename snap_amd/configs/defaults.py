@@ -60,7 +60,27 @@ def resnet(name: str = 'R50') -> ConfigDict:
   return cfg
 
 
-def image_encoder() -> ConfigDict:
+def vit(name: str = 'B/16') -> ConfigDict:
+  """ViT encoder (``encoder_name='vit'``): not in the reference (image_encoder.py:103);
+  BASELINE.json configs[4].  Sizes of the published variants."""
+  variants = {
+      'Ti/16': dict(hidden_size=192, num_layers=12, num_heads=3, mlp_dim=768),
+      'S/16': dict(hidden_size=384, num_layers=12, num_heads=6, mlp_dim=1536),
+      'B/16': dict(hidden_size=768, num_layers=12, num_heads=12, mlp_dim=3072),
+  }
+  if name not in variants:
+    raise ValueError(f'Unknown ViT name: {name}')
+  return ConfigDict(
+      patch_size=16, posemb_grid=(32, 32), matmul_precision='bf16', **variants[name],
+  ).lock()
+
+
+def image_encoder(encoder_name: str = 'resnet') -> ConfigDict:
+  if encoder_name == 'vit':
+    return ConfigDict(
+        encoder_name='vit', encoder=vit(), output_dim=128,
+        num_pyr_levels=config_dict.placeholder(int),
+    ).lock()
   return ConfigDict(
       encoder_name='resnet', encoder=resnet(), output_dim=128,
       num_pyr_levels=config_dict.placeholder(int),

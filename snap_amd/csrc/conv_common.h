@@ -71,6 +71,13 @@ typedef const __attribute__((address_space(1))) void cglobal_void_t;
 // zero source for LDS-DMA lanes whose tap / channel / row is out of range
 __device__ __attribute__((aligned(64))) const float kZeroChunk[16] = {0.f};
 
+// tanh-approximated GELU (flax.linen.gelu default): 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)),
+// u = sqrt(2/pi) (x + 0.044715 x^3)
+__device__ __forceinline__ float snap_gelu_tanh(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
 // ---- epilogue ------------------------------------------------------------
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / 64][BN / 64],
@@ -169,6 +176,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
+      if (epi & SNAP_EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = snap_gelu_tanh(v[e]);
+      }
       if ((epi & SNAP_EPI_ROWMASK) && a.row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(a.y + o) = v;
       if (want_stats) {
@@ -246,6 +257,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   if (epi & SNAP_EPI_RELU) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (epi & SNAP_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = snap_gelu_tanh(v[e]);
   }
   if ((epi & SNAP_EPI_ROWMASK) && row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
   *reinterpret_cast<f32x4*>(y + o) = v;

@@ -8,6 +8,7 @@ from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
 from snap_amd.models import resnet
 from snap_amd.models import types
+from snap_amd.models import vit
 
 
 def pad_to_multiple(images, stride):
@@ -73,6 +74,11 @@ class ImageEncoder(base.Module):
   def __init__(self, config, dtype=torch.float32):
     self.config = config
     num_pyr_levels = config.num_pyr_levels
+    self.is_vit = config.encoder_name == 'vit'
+    if self.is_vit:   # build-only extension (BASELINE.json configs[4]); not in the reference
+      self.encoder = vit.ViTEncoder(config.encoder, config.output_dim, dtype)
+      self.decoder = None
+      return
     if config.encoder_name != 'resnet':
       raise ValueError(config.encoder_name)
     self.encoder = resnet.ResNetV2(config.encoder, dtype)
@@ -85,6 +91,8 @@ class ImageEncoder(base.Module):
     self.decoder = FPNDecoder(config.output_dim, num_pyr_levels, in_dims, dtype)
 
   def init_params(self, gen, device):
+    if self.is_vit:
+      return {'encoder': self.encoder.init_params(gen, device)}
     return {
         'encoder': self.encoder.init_params(gen, device),
         'decoder': self.decoder.init_params(gen, device),
@@ -93,6 +101,13 @@ class ImageEncoder(base.Module):
   def __call__(self, params, image, train=False, ctx=None, rng=None):
     image = image.to(torch.float32)
     input_shape = np.array(image.shape[-3:-1])
+    if self.is_vit:   # one level at the patch stride
+      patch = self.config.encoder.patch_size
+      padded = vit.pad_to_patch(image, patch)
+      f = self.encoder(params['encoder'], padded, train=train, ctx=ctx)
+      h, w = np.ceil(input_shape / patch).astype(int)
+      return types.FeatureImagePyramid(
+          features=[f[..., :h, :w, :]], strides=[np.array([patch, patch], dtype=np.float64)])
     image_padded = pad_to_multiple(image, 2**self.max_stride).contiguous()
     padded_shape = np.array(image_padded.shape[-3:-1])
     encoder_features = self.encoder(params['encoder'], image_padded, train=train, ctx=ctx)

@@ -13,7 +13,7 @@ import torch
 from snap_amd import _lib
 
 PRO_NONE, PRO_AFFINE, PRO_GN_RELU, PRO_RELU_GN, PRO_RELU = 0, 1, 2, 3, 4
-EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_UPSAMPLE2X_ADD, EPI_ROWMASK = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_UPSAMPLE2X_ADD, EPI_ROWMASK, EPI_GELU = 1, 2, 4, 8, 16, 32
 POOLING = {'max': 0, 'sum': 1, 'mean': 2}
 SIM_CHUNK = 64
 
@@ -147,7 +147,7 @@ def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
-    emit_gn_stats=None, math=None,
+    emit_gn_stats=None, math=None, gelu=False,
 ):
   """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
@@ -195,6 +195,8 @@ def conv2d(
       raise ValueError('conv2d: bias size')
   if relu:
     epi |= EPI_RELU
+  if gelu:                                   # tanh-approximated GELU (ViT MLP)
+    epi |= EPI_GELU
   if residual is not None:
     _f32(residual, 'residual'); epi |= EPI_RESIDUAL
     if residual.shape != y.shape:
@@ -277,7 +279,8 @@ def pack_weights_bf16(w):
 
 
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
-          row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None):
+          row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None,
+          gelu=False, residual=None):
   """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1)."""
   lead = x.shape[:-1]
   M = int(np.prod(lead)) if len(lead) else 1
@@ -286,9 +289,39 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
       cin=cin if cin is not None else kernel.shape[0], prologue=prologue,
       bias=bias, relu=relu, row_mask=row_mask, rows_in=rows_in, rows_out=rows_out,
       row_count=row_count, out=None if out is None else out.reshape(1, 1, M, kernel.shape[1]),
-      math=math,
+      math=math, gelu=gelu,
+      residual=None if residual is None else residual.reshape(1, 1, M, kernel.shape[1]),
   )
   return y.reshape(*lead, kernel.shape[1])
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+  """LayerNorm over the last axis (flax.linen.LayerNorm: biased variance, eps inside the sqrt)."""
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(gamma, 'gamma'); _f32(beta, 'beta')
+  C = x.shape[-1]
+  M = x.numel() // C
+  y = torch.empty_like(x)
+  with _region('layer_norm', 0.0, 8.0 * x.numel()):
+    st = lib.snap_layer_norm_f32(_p(x), _p(gamma), _p(beta), _p(y), M, C, float(eps), _stream())
+  _lib.check(st, 'snap_layer_norm_f32')
+  return y
+
+
+def attention(qkv, scale=None):
+  """Multi-head self-attention on the bf16 matrix cores.  qkv [B, N, 3, H, 64] (fused QKV
+  projection output, f32) -> [B, N, H*64] f32 = softmax(scale * Q K^T) V per head."""
+  lib = _lib.load()
+  _f32(qkv, 'qkv')
+  B, N, three, H, D = qkv.shape
+  if three != 3:
+    raise ValueError('attention: qkv must be [B, N, 3, H, D]')
+  scale = D ** -0.5 if scale is None else float(scale)
+  out = torch.empty((B, N, H * D), dtype=torch.float32, device=qkv.device)
+  with _region('attention', 4.0 * B * H * N * N * D, 4.0 * (qkv.numel() + out.numel())):
+    st = lib.snap_attention_bf16_f32(_p(qkv), _p(out), B, N, H, D, scale, _stream())
+  _lib.check(st, 'snap_attention_bf16_f32')
+  return out
 
 
 def compact_rows(mask):

@@ -18,6 +18,7 @@ from oracle import geometry as o_geo
 from oracle import grids as o_grids
 from oracle import lift as o_lift
 from oracle import pose as o_pose
+from oracle import vit as o_vit
 
 PRO_NONE, PRO_AFFINE, PRO_GN_RELU, PRO_RELU_GN, PRO_RELU = 0, 1, 2, 3, 4
 SIM_CHUNK = 64
@@ -64,7 +65,7 @@ def _prologue(x, prologue, gn, in_affine, cin):
 
 def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
            gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
-           up_prev=None, row_mask=None, emit_gn_stats=None, math=None):
+           up_prev=None, row_mask=None, emit_gn_stats=None, math=None, gelu=False):
   # emit_gn_stats: a speed hint of the HIP path (statistics out of the epilogue); no-op here.
   # math='bf16': both operands rounded to bf16 after the f32 prologue, products summed in
   # float64 (the engine accumulates in f32: the test tolerance covers the summation order).
@@ -87,20 +88,32 @@ def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_N
     y = y + o_enc.resize_bilinear_x2(_np(up_prev, DTYPE))
   if relu:
     y = np.maximum(y, 0)
+  if gelu:
+    y = o_vit.gelu_tanh(y)
   if row_mask is not None:
     y = np.where(_np(row_mask).reshape(*y.shape[:-1], 1), y, 0)
   return _t(y, x)
 
 
-def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False, row_mask=None):
+def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False, row_mask=None,
+          math=None, gelu=False, residual=None):
   lead = x.shape[:-1]
   M = int(np.prod(lead)) if len(lead) else 1
   y = conv2d(
       x.reshape(1, 1, M, x.shape[-1]), kernel.reshape(1, 1, *kernel.shape),
       cin=cin if cin is not None else kernel.shape[0], prologue=prologue, bias=bias,
-      relu=relu, row_mask=row_mask,
+      relu=relu, row_mask=row_mask, math=math, gelu=gelu,
+      residual=None if residual is None else residual.reshape(1, 1, M, kernel.shape[1]),
   )
   return y.reshape(*lead, kernel.shape[1])
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+  return _t(o_vit.layer_norm(_np(x, DTYPE), _np(gamma, DTYPE), _np(beta, DTYPE), eps), x)
+
+
+def attention(qkv, scale=None, bf16_operands=True):
+  return _t(o_vit.attention(_np(qkv, np.float64), scale, bf16_operands).astype(DTYPE), qkv)
 
 
 def weight_standardize(w, eps=1e-10):

@@ -792,3 +792,42 @@ def test_lift_with_nothing_visible():
   y = ops.dense(pooled.reshape(-1, pooled.shape[-1]), w, None, rows_in=index, rows_out=index, row_count=count)
   ops.fill_masked_rows_(y, valid.reshape(-1))
   assert float(y.abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------
+# ViT encoder pieces (BASELINE.json configs[4]; no reference implementation exists, the oracle
+# is the published architecture in float64 -- oracle/vit.py)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize('M,C', [(37, 768), (5, 192), (130, 1024), (9, 64)])
+def test_layer_norm(M, C):
+  x = rnd((M, C), 201) * 1.7 + 0.3
+  gamma, beta = rnd((C,), 202) * 0.3 + 1, rnd((C,), 203) * 0.2
+  got, want = both('layer_norm', (x, gamma, beta))
+  helpers.report(f'layer_norm {M}x{C}', got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_dense_gelu_and_residual_epilogues():
+  x = rnd((300, 192), 204)
+  w = rnd((192, 256), 205, 1 / np.sqrt(192))
+  b = rnd((256,), 206)
+  res = rnd((300, 256), 207)
+  got, want = both('dense', (x, w, b), dict(gelu=True))
+  helpers.report('dense + gelu', got, want, atol=2e-5, rtol=1e-5)
+  got, want = both('dense', (x, w, b), dict(residual=res))
+  helpers.report('dense + residual', got, want, atol=2e-5, rtol=1e-5)
+  got, want = both('dense', (x, w, b), dict(gelu=True, math='bf16'))
+  helpers.report('dense + gelu bf16', got, want, atol=5e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('B,N,H', [(2, 200, 3), (1, 1024, 2), (3, 64, 1), (1, 129, 12)])
+def test_attention(B, N, H):
+  """softmax(q k^T / 8) v on the bf16 matrix cores vs float64 on the bf16-rounded operands.
+  Tolerance: 4e-3 of the value range (the kernel also rounds its probabilities to bf16,
+  relative error 2^-9 each, averaged by the softmax)."""
+  qkv = rnd((B, N, 3, H, 64), 210 + N)
+  qkv[:, :, 0] *= 2.0                                  # sharper softmax than unit variance
+  got, want = both('attention', (qkv,))
+  scale = float(qkv[:, :, 2].abs().max())
+  helpers.report(f'attention B{B} N{N} H{H}', got, want, atol=4e-3 * scale, rtol=0)
+  exact = oracle_ops.attention(qkv, bf16_operands=False)
+  helpers.report(f'attention vs exact f64 B{B} N{N} H{H}', got, exact, atol=2e-2 * scale, rtol=0)

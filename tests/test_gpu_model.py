@@ -121,3 +121,66 @@ def test_evaluator_contract_on_tiny_model(tmp_path):
   np.testing.assert_array_equal(back['loss'], res['loss'])
   th, rec = evaluator.compute_recall(res['error_max_meter'], 5.0)
   assert rec[-1] == 100.0 * np.mean(res['error_max_meter'] < 5.0)
+
+
+def _tiny_vit_config():
+  from snap_amd.configs import defaults
+  cfg = defaults.image_encoder('vit')
+  cfg.encoder.hidden_size = 128
+  cfg.encoder.num_heads = 2
+  cfg.encoder.num_layers = 2
+  cfg.encoder.mlp_dim = 256
+  cfg.encoder.posemb_grid = (4, 4)
+  cfg.output_dim = 32
+  return cfg
+
+
+@pytest.mark.parametrize('precision,tol', [('f32', 3e-3), ('bf16', 3e-2)])
+def test_vit_encoder_matches_oracle(precision, tol):
+  """encoder_name='vit' (BASELINE.json configs[4]; no reference ViT exists): the HIP forward
+  vs the float64 numpy restatement of the published architecture, same weights.  Tolerances
+  relative to the feature range: f32 GEMMs leave only the bf16 attention products; with bf16
+  GEMM operands everything is bf16-class."""
+  import numpy as np
+  from oracle import vit as o_vit
+  from snap_amd.models import image_encoder
+  cfg = _tiny_vit_config()
+  cfg.encoder.matmul_precision = precision
+  enc = image_encoder.ImageEncoder(cfg)
+  params = enc.init_params(torch.Generator().manual_seed(3), 'cpu')
+  g = torch.Generator().manual_seed(4)
+  for name in ('bias',):                                   # non-trivial biases / norms
+    params['encoder']['embedding'][name] = torch.randn(128, generator=g) * 0.1
+  img = torch.rand((3, 64, 40, 3), generator=g)           # 40 -> padded to 48: grid 4 x 3
+  pyr = enc(helpers.params_to_device(params, 'cuda'), img.cuda())
+  got = pyr.features[0].cpu().numpy()
+  assert got.shape == (3, 4, 3, 32) and list(pyr.strides[0]) == [16, 16]
+
+  def to_np(t):
+    return {k: to_np(v) for k, v in t.items()} if isinstance(t, dict) else t.numpy().astype(np.float64)
+  ocfg = dict(cfg.encoder.to_dict())
+  padded = np.pad(img.numpy().astype(np.float64), ((0, 0), (0, 0), (0, 8), (0, 0)))
+  want = o_vit.vit_encoder(to_np(params['encoder']), ocfg, padded)[:, :4, :3]
+  err = float(np.abs(got - want).max()) / float(np.abs(want).max())
+  print(f'vit encoder {precision}: max err / range = {err:.2e}')
+  assert err < tol, err
+
+
+def test_localizer_runs_with_vit_streetview_encoder():
+  """The whole localisation path with a (tiny) ViT as the StreetView image encoder."""
+  dev = torch.device('cuda')
+  cfg = helpers.tiny_localizer_config(num_pose_samples=48, retries=2)
+  vit_cfg = _tiny_vit_config()
+  vit_cfg.output_dim = cfg.bev_mapper.streetview_encoder.image_encoder.output_dim
+  cfg.bev_mapper.streetview_encoder.image_encoder = vit_cfg
+  from snap_amd import models
+  from snap_amd.data import synthetic
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  model = models.get_model('bev_localizer')(cfg, meta)
+  variables = model.flax_model.init(0, device='cpu')
+  params = helpers.params_to_device(variables['params'], dev)
+  batch = helpers.batch_to_device(synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=1), dev)
+  pred = model.flax_model.apply({'params': params}, batch, train=False, rngs={'sampling': 5})
+  assert bool(torch.isfinite(pred['scores_poses']).all())
+  f = pred['map']['streetview']['image_feature_pyramid'].features[-1]
+  assert f.shape[-3:-1] == (4, 4)

@@ -273,7 +273,7 @@ def test_unsupported_configs_raise_like_the_reference():
   with pytest.raises(ValueError):
     bev_localizer.BEVLocalizer(bad, sc, meta['grid'].bev())
   bad = helpers.tiny_localizer_config()
-  bad.bev_mapper.streetview_encoder.image_encoder.encoder_name = 'vit'
+  bad.bev_mapper.streetview_encoder.image_encoder.encoder_name = 'swin'   # ('vit' is a build extension)
   with pytest.raises(ValueError):
     bev_localizer.BEVLocalizer(bad, sc, meta['grid'].bev())
   bad = helpers.tiny_localizer_config()

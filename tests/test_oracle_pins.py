@@ -273,3 +273,36 @@ def test_pool_multiview_all_invalid_is_zero():
   np.testing.assert_allclose(stats[0, :4], 1)       # mean of ones
   np.testing.assert_allclose(stats[0, 4:8], 0, atol=1e-15)  # variance
   np.testing.assert_allclose(stats[0, 8], 0.1)      # max valid score
+
+
+def test_vit_oracle_against_independent_torch_implementations():
+  """The reference has no ViT (image_encoder.py:103), so oracle/vit.py cannot be pinned to it
+  ("parity unpinned" in its header); its primitives are pinned here to torch's own
+  implementations of the same published operators."""
+  import torch
+  from oracle import vit as o_vit
+  rng = np.random.default_rng(0)
+  p = rng.standard_normal((1, 16, 8))
+  t = torch.nn.functional.interpolate(
+      torch.from_numpy(p).reshape(1, 4, 4, 8).permute(0, 3, 1, 2), size=(4, 3), mode='bilinear',
+      align_corners=False).permute(0, 2, 3, 1).reshape(1, 12, 8).numpy()
+  np.testing.assert_allclose(o_vit.resize_posemb(p, (4, 4), (4, 3)), t, atol=1e-12)
+  qkv = rng.standard_normal((2, 10, 3, 2, 64))
+  tq = torch.from_numpy(qkv)
+  ref = torch.nn.functional.scaled_dot_product_attention(
+      tq[:, :, 0].permute(0, 2, 1, 3), tq[:, :, 1].permute(0, 2, 1, 3),
+      tq[:, :, 2].permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(2, 10, 128).numpy()
+  np.testing.assert_allclose(o_vit.attention(qkv), ref, atol=1e-12)
+  x = rng.standard_normal((5, 64))
+  np.testing.assert_allclose(
+      o_vit.gelu_tanh(x), torch.nn.functional.gelu(torch.from_numpy(x), approximate='tanh').numpy(),
+      atol=1e-12)
+  g, b = rng.standard_normal(64), rng.standard_normal(64)
+  np.testing.assert_allclose(
+      o_vit.layer_norm(x, g, b),
+      torch.nn.functional.layer_norm(torch.from_numpy(x), (64,), torch.from_numpy(g),
+                                     torch.from_numpy(b), eps=1e-6).numpy(), atol=1e-12)
+  # bf16 rounding restatement == torch's float32 -> bfloat16 conversion
+  from oracle import encoder as o_enc
+  v = (rng.standard_normal(4096) * 3.3).astype(np.float32)
+  np.testing.assert_array_equal(o_enc.bf16_round(v), torch.from_numpy(v).to(torch.bfloat16).float().numpy())
