@@ -134,6 +134,23 @@ int snap_layer_norm_f32(const float* x, const float* gamma, const float* beta, f
                         int64_t M, int32_t C, float eps, void* stream);
 int snap_attention_bf16_f32(const float* qkv, float* out, int32_t B, int32_t N, int32_t H,
                             int32_t D, float scale, void* stream);
+/* Training path of the ViT pieces.  snap_attention_lse_bf16_f32 also returns lse [B, H, N], the
+ * base-2 log-sum-exp of the scaled scores; snap_attention_bwd_bf16_f32 turns (qkv, out, dout,
+ * lse) into dqkv (same layout as qkv; delta [B, H, N] is scratch) with two atomic-free kernels
+ * on the bf16 matrix cores.  snap_layer_norm_bwd_f32: dx, dgamma, dbeta (fixed-order column
+ * sums; workspace from snap_layer_norm_bwd_workspace_bytes).  snap_gelu[_bwd]_f32: tanh-form
+ * GELU and its VJP over n (% 4 == 0) elements (the training path keeps the pre-activation). */
+int snap_attention_lse_bf16_f32(const float* qkv, float* out, float* lse, int32_t B, int32_t N,
+                                int32_t H, int32_t D, float scale, void* stream);
+int snap_attention_bwd_bf16_f32(const float* qkv, const float* out, const float* dout,
+                                const float* lse, float* delta, float* dqkv, int32_t B, int32_t N,
+                                int32_t H, int32_t D, float scale, void* stream);
+size_t snap_layer_norm_bwd_workspace_bytes(int64_t M, int32_t C);
+int snap_layer_norm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx,
+                            float* dgamma, float* dbeta, int64_t M, int32_t C, float eps,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int snap_gelu_f32(const float* x, float* y, int64_t n, void* stream);
+int snap_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 
 /* Scratch for split-K launches (small-M / deep-K layers that cannot fill 256 CUs with output
  * tiles: slices of K go to extra workgroups, partial tiles are summed in fixed order by a

@@ -70,6 +70,14 @@ SIGNATURES = {
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
     'snap_layer_norm_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_attention_bf16_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
+    'snap_attention_lse_bf16_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
+    'snap_attention_bwd_bf16_f32': (
+        c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
+    'snap_layer_norm_bwd_workspace_bytes': (c_size, [c_i64, c_int]),
+    'snap_layer_norm_bwd_f32': (
+        c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr, c_size, ptr]),
+    'snap_gelu_f32': (c_int, [ptr, ptr, c_i64, ptr]),
+    'snap_gelu_bwd_f32': (c_int, [ptr, ptr, ptr, c_i64, ptr]),
     'snap_conv2d_packed_weights_bytes': (c_size, [c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_group_norm_stats_from_partial_f32': (

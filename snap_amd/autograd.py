@@ -145,7 +145,8 @@ def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=ops.P
   return _FusedConv.apply(x, w, gamma, beta, bias, residual, up_prev, cfg)
 
 
-def dense(x, kernel, bias=None, *, cin=None, prologue=ops.PRO_NONE, relu=False, row_mask=None):
+def dense(x, kernel, bias=None, *, cin=None, prologue=ops.PRO_NONE, relu=False, row_mask=None,
+          residual=None):
   lead = x.shape[:-1]
   M = 1
   for s in lead:
@@ -154,8 +155,67 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=ops.PRO_NONE, relu=False, 
       x.reshape(1, 1, M, x.shape[-1]), kernel.reshape(1, 1, *kernel.shape),
       cin=cin if cin is not None else kernel.shape[0], prologue=prologue, bias=bias, relu=relu,
       row_mask=row_mask,
+      residual=None if residual is None else residual.reshape(1, 1, M, kernel.shape[1]),
   )
   return y.reshape(*lead, kernel.shape[1])
+
+
+# ----------------------------------------------------------------------------
+# ViT pieces (vit_ops.hip / vit_bwd.hip)
+# ----------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, eps):
+    ctx.eps = eps
+    ctx.save_for_backward(x, gamma)
+    return ops.layer_norm(x, gamma, beta, eps)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, gamma = ctx.saved_tensors
+    dx, dgamma, dbeta = ops_bwd.layer_norm_bwd(x, dy.contiguous(), gamma, ctx.eps)
+    return dx, dgamma, dbeta, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+  return _LayerNorm.apply(x.contiguous(), gamma, beta, eps)
+
+
+class _Gelu(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x):
+    ctx.save_for_backward(x)
+    return ops.gelu(x)
+
+  @staticmethod
+  def backward(ctx, dy):
+    (x,) = ctx.saved_tensors
+    return ops_bwd.gelu_bwd(x, dy.contiguous())
+
+
+def gelu(x):
+  return _Gelu.apply(x.contiguous())
+
+
+class _Attention(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, qkv, scale):
+    out, lse = ops.attention(qkv, scale, want_lse=True)
+    ctx.scale = scale
+    ctx.save_for_backward(qkv, out, lse)
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    qkv, out, lse = ctx.saved_tensors
+    return ops_bwd.attention_bwd(qkv, out, dout.contiguous(), lse, ctx.scale), None
+
+
+def attention(qkv, scale=None):
+  return _Attention.apply(qkv.contiguous(), scale)
 
 
 class _MaskedRowsMLP(torch.autograd.Function):

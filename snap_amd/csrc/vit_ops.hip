@@ -76,6 +76,7 @@ constexpr int AT_VS = 136;      // V^T row stride in LDS, bytes (128 + 8: b64 re
 struct AttnArgs {
   const float* qkv;   // [B, N, 3, H, 64]
   float* out;         // [B, N, H * 64]
+  float* lse;         // optional [B, H, N]: base-2 log-sum-exp of the scaled scores (for the VJP)
   int B, N, H;
   float scale_log2e;  // softmax scale * log2(e)
 };
@@ -220,6 +221,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
+  if (a.lse && lhi == 0 && q0 + l31 < a.N)
+    a.lse[((int64_t)b * a.H + h) * a.N + q0 + l31] = m_run + log2f(l_tot);
   // transpose through LDS (each wave its own [32 queries][64 d] patch, 68-float rows), then
   // 256-byte row stores
   float* stage = reinterpret_cast<float*>(smem) + wid * (AT_QW * 68);
@@ -260,6 +263,12 @@ extern "C" int snap_layer_norm_f32(const float* x, const float* gamma, const flo
 
 extern "C" int snap_attention_bf16_f32(const float* qkv, float* out, int32_t B, int32_t N,
                                        int32_t H, int32_t D, float scale, void* stream) {
+  return snap_attention_lse_bf16_f32(qkv, out, nullptr, B, N, H, D, scale, stream);
+}
+
+extern "C" int snap_attention_lse_bf16_f32(const float* qkv, float* out, float* lse, int32_t B,
+                                           int32_t N, int32_t H, int32_t D, float scale,
+                                           void* stream) {
   if (!qkv || !out) return SNAP_ERR_NULL;
   if (B <= 0 || N <= 0 || H <= 0) return SNAP_ERR_BAD_SHAPE;
   if (D != AT_D) return SNAP_ERR_UNSUPPORTED;
@@ -267,7 +276,7 @@ extern "C" int snap_attention_bf16_f32(const float* qkv, float* out, int32_t B, 
     return SNAP_ERR_BAD_SHAPE;
   if (B > 65535 || H > 65535) return SNAP_ERR_BAD_SHAPE;
   AttnArgs a;
-  a.qkv = qkv; a.out = out; a.B = B; a.N = N; a.H = H;
+  a.qkv = qkv; a.out = out; a.lse = lse; a.B = B; a.N = N; a.H = H;
   a.scale_log2e = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)snap_cdiv(N, 4 * AT_QW), (unsigned)H, (unsigned)B);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -2,7 +2,7 @@
 
 The reference has no ViT (``snap/models/image_encoder.py:103`` raises for anything but
 'resnet'); this is the published ViT block with the big_vision / scenic parameter tree (see
-``oracle/vit.py``), forward only this round.  Every Dense runs on the conv engine (bf16
+``oracle/vit.py``), forward and hand-written backward.  Every Dense runs on the conv engine (bf16
 operands by default -- ``config.matmul_precision``), LayerNorm and the fused-softmax attention
 are the kernels of ``csrc/vit_ops.hip``; bias, GELU and the residual adds ride in the GEMM
 epilogues.
@@ -10,6 +10,7 @@ epilogues.
 import numpy as np
 import torch
 
+from snap_amd import autograd as ag
 from snap_amd import ops
 from snap_amd.models import base
 
@@ -64,9 +65,40 @@ class ViTEncoder(base.Module):
     p = torch.nn.functional.interpolate(p, size=tuple(grid), mode='bilinear', align_corners=False)
     return p.permute(0, 2, 3, 1).reshape(1, grid[0] * grid[1], -1).contiguous()
 
+  def _forward_train(self, params, image):
+    """Differentiable path (hand-written VJP kernels through ``snap_amd.autograd``).  The GEMM
+    precision follows ``ops.MATMUL_PRECISION`` (``trainer.train_step(precision=...)``); GELU
+    runs as its own kernel so that the pre-activation is kept for the backward."""
+    cfg = self.config
+    C, H = cfg.hidden_size, cfg.num_heads
+    D = C // H
+    p = cfg.patch_size
+    emb = params['embedding']
+    x = ag.conv2d(image.contiguous(), emb['kernel'], stride=p, prologue=ops.PRO_AFFINE,
+                  in_affine=(2.0, -1.0), bias=emb['bias'])
+    N, h, w, _ = x.shape
+    x = (x.reshape(N, h * w, C) + self._posemb(params['pos_embedding'], (h, w))).contiguous()
+    for i in range(cfg.num_layers):
+      blk = params['Transformer'][f'encoderblock_{i}']
+      att = blk['MultiHeadDotProductAttention_0']
+      wqkv = torch.cat([att[n]['kernel'].reshape(C, C) for n in ('query', 'key', 'value')], dim=1)
+      bqkv = torch.cat([att[n]['bias'].reshape(C) for n in ('query', 'key', 'value')])
+      y = ag.layer_norm(x, blk['LayerNorm_0']['scale'], blk['LayerNorm_0']['bias'])
+      qkv = ag.dense(y, wqkv.contiguous(), bqkv).reshape(N, h * w, 3, H, D)
+      a = ag.attention(qkv)
+      x = ag.dense(a, att['out']['kernel'].reshape(C, C), att['out']['bias'], residual=x)
+      y = ag.layer_norm(x, blk['LayerNorm_1']['scale'], blk['LayerNorm_1']['bias'])
+      mlp = blk['MlpBlock_0']
+      y = ag.gelu(ag.dense(y, mlp['Dense_0']['kernel'], mlp['Dense_0']['bias']))
+      x = ag.dense(y, mlp['Dense_1']['kernel'], mlp['Dense_1']['bias'], residual=x)
+    norm = params['Transformer']['encoder_norm']
+    x = ag.layer_norm(x, norm['scale'], norm['bias'])
+    x = ag.dense(x, params['proj']['kernel'], params['proj']['bias'])
+    return x.reshape(N, h, w, self.output_dim)
+
   def __call__(self, params, image, train=False, ctx=None):
-    if train and base.needs_grad(image, params['proj']['kernel']):
-      raise NotImplementedError('ViT encoder: forward only (no backward kernels yet)')
+    if base.needs_grad(image, params['proj']['kernel'], params['embedding']['kernel']):
+      return self._forward_train(params, image)
     cfg = self.config
     math = cfg.get('matmul_precision', 'bf16')
     C, H = cfg.hidden_size, cfg.num_heads

@@ -308,9 +308,10 @@ def layer_norm(x, gamma, beta, eps=1e-6):
   return y
 
 
-def attention(qkv, scale=None):
+def attention(qkv, scale=None, want_lse=False):
   """Multi-head self-attention on the bf16 matrix cores.  qkv [B, N, 3, H, 64] (fused QKV
-  projection output, f32) -> [B, N, H*64] f32 = softmax(scale * Q K^T) V per head."""
+  projection output, f32) -> [B, N, H*64] f32 = softmax(scale * Q K^T) V per head.
+  want_lse: also return the base-2 log-sum-exp of the scaled scores [B, H, N] (for the VJP)."""
   lib = _lib.load()
   _f32(qkv, 'qkv')
   B, N, three, H, D = qkv.shape
@@ -318,10 +319,22 @@ def attention(qkv, scale=None):
     raise ValueError('attention: qkv must be [B, N, 3, H, D]')
   scale = D ** -0.5 if scale is None else float(scale)
   out = torch.empty((B, N, H * D), dtype=torch.float32, device=qkv.device)
+  lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
   with _region('attention', 4.0 * B * H * N * N * D, 4.0 * (qkv.numel() + out.numel())):
-    st = lib.snap_attention_bf16_f32(_p(qkv), _p(out), B, N, H, D, scale, _stream())
-  _lib.check(st, 'snap_attention_bf16_f32')
-  return out
+    st = lib.snap_attention_lse_bf16_f32(_p(qkv), _p(out), _p(lse), B, N, H, D, scale, _stream())
+  _lib.check(st, 'snap_attention_lse_bf16_f32')
+  return (out, lse) if want_lse else out
+
+
+def gelu(x):
+  """tanh-form GELU as a stand-alone kernel (training path: the pre-activation is kept)."""
+  lib = _lib.load()
+  _f32(x, 'x')
+  y = torch.empty_like(x)
+  with _region('gelu', 0.0, 8.0 * x.numel()):
+    st = lib.snap_gelu_f32(_p(x), _p(y), x.numel(), _stream())
+  _lib.check(st, 'snap_gelu_f32')
+  return y
 
 
 def compact_rows(mask):

@@ -245,3 +245,46 @@ def vertical_pool_conf_bwd(vol, valid, w, bias, weights, dplane, log_sigmoid_sco
   _lib.check(st, 'snap_vertical_pool_conf_bwd_f32')
   sums = colsum(partial)
   return dvol, sums[:D].contiguous(), sums[D:D + 1].contiguous()
+
+
+def layer_norm_bwd(x, dy, gamma, eps=1e-6):
+  """VJP of ``ops.layer_norm``: dx, dgamma, dbeta (deterministic column sums)."""
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(dy, 'dy'); _f32(gamma, 'gamma')
+  C = x.shape[-1]
+  M = x.numel() // C
+  wsb = lib.snap_layer_norm_bwd_workspace_bytes(M, C)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=x.device)
+  dx = torch.empty_like(x)
+  dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+  dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+  with _region('layer_norm_bwd', 0.0, 12.0 * x.numel()):
+    st = lib.snap_layer_norm_bwd_f32(_p(x), _p(dy), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), M, C,
+                                     float(eps), _p(ws), ws.numel() * 4, _stream())
+  _lib.check(st, 'snap_layer_norm_bwd_f32')
+  return dx, dgamma, dbeta
+
+
+def gelu_bwd(x, dy):
+  lib = _lib.load()
+  _f32(x, 'x'); _f32(dy, 'dy')
+  dx = torch.empty_like(x)
+  with _region('gelu_bwd', 0.0, 12.0 * x.numel()):
+    st = lib.snap_gelu_bwd_f32(_p(x), _p(dy), _p(dx), x.numel(), _stream())
+  _lib.check(st, 'snap_gelu_bwd_f32')
+  return dx
+
+
+def attention_bwd(qkv, out, dout, lse, scale=None):
+  """VJP of ``ops.attention`` w.r.t. qkv (bf16 matrix cores, two atomic-free kernels)."""
+  lib = _lib.load()
+  _f32(qkv, 'qkv'); _f32(out, 'out'); _f32(dout, 'dout'); _f32(lse, 'lse')
+  B, N, _, H, D = qkv.shape
+  scale = D ** -0.5 if scale is None else float(scale)
+  dqkv = torch.empty_like(qkv)
+  delta = torch.empty_like(lse)
+  with _region('attention_bwd', 10.0 * B * H * N * N * D, 8.0 * qkv.numel()):
+    st = lib.snap_attention_bwd_bf16_f32(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv),
+                                         B, N, H, D, scale, _stream())
+  _lib.check(st, 'snap_attention_bwd_bf16_f32')
+  return dqkv

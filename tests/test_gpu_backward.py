@@ -473,3 +473,54 @@ def test_vertical_pool_conf_bwd(mode):
   helpers.report('dvol', vg.grad, vd.grad.float(), atol=2e-5, rtol=1e-4)
   helpers.report('dw', wg.grad, wd.grad.float(), atol=2e-4, rtol=1e-4)
   helpers.report('db', bg.grad, bd.grad.float(), atol=2e-4, rtol=1e-4)
+
+
+# -- ViT pieces (no reference ViT exists; fp reference = torch fp64 autograd of the published ops) --
+@pytest.mark.parametrize('M,C', [(70, 768), (33, 192), (5, 1024)])
+def test_layer_norm_bwd(M, C):
+  x = rnd((M, C), 301) * 1.3 + 0.2
+  gamma, beta = rnd((C,), 302) * 0.3 + 1, rnd((C,), 303) * 0.1
+  dy = rnd((M, C), 304)
+  xd, gd, bd = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+  F.layer_norm(xd, (C,), gd, bd, eps=1e-6).backward(dy.double())
+  dx, dgamma, dbeta = ops_bwd.layer_norm_bwd(G(x), G(dy), G(gamma))
+  helpers.report('ln dx', dx, xd.grad.float(), atol=2e-5, rtol=1e-4)
+  helpers.report('ln dgamma', dgamma, gd.grad.float(), atol=1e-4, rtol=1e-4)
+  helpers.report('ln dbeta', dbeta, bd.grad.float(), atol=1e-4, rtol=1e-4)
+
+
+def test_gelu_fwd_bwd():
+  x = rnd((257, 64), 305) * 2.5
+  dy = rnd((257, 64), 306)
+  xd = x.double().requires_grad_(True)
+  y = F.gelu(xd, approximate='tanh')
+  y.backward(dy.double())
+  helpers.report('gelu', ops.gelu(G(x)), y.detach().float(), atol=2e-6, rtol=1e-5)
+  helpers.report('gelu bwd', ops_bwd.gelu_bwd(G(x), G(dy)), xd.grad.float(), atol=5e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('B,N,H', [(2, 200, 2), (1, 512, 3), (1, 65, 1)])
+def test_attention_bwd(B, N, H):
+  """dqkv of the bf16 attention VJP vs torch fp64 autograd of softmax(q k^T / 8) v on the
+  bf16-rounded operands.  bf16-class tolerance: 2e-2 of each gradient's range (P, dS and dO are
+  rounded to bf16 before their matrix-core products)."""
+  from oracle import encoder as o_enc
+  qkv = rnd((B, N, 3, H, 64), 310 + N)
+  qkv[:, :, 0] *= 1.5
+  dout = rnd((B, N, H * 64), 311 + N)
+  out, lse = ops.attention(G(qkv), want_lse=True)
+  dqkv = ops_bwd.attention_bwd(G(qkv), out, G(dout), lse)
+  r = torch.from_numpy(o_enc.bf16_round(qkv.numpy())).double().requires_grad_(True)
+  q, k, v = (r[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+  ref = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+  ref.backward(dout.double())
+  helpers.report('attention fwd (lse path)', out, ref.detach().float(),
+                 atol=1e-2 * float(ref.detach().abs().max()), rtol=0)
+  for i, name in enumerate(('dq', 'dk', 'dv')):
+    want = r.grad[:, :, i].float()
+    helpers.report(f'attention {name} B{B} N{N} H{H}', dqkv[:, :, i], want,
+                   atol=2e-2 * float(want.abs().max()), rtol=0)
+  # the saved statistic: base-2 log-sum-exp of the scaled scores
+  s = torch.einsum('bhqd,bhkd->bhqk', q, k).detach() * 0.125
+  want_lse = torch.logsumexp(s, -1) / math.log(2.0)
+  helpers.report('attention lse', lse, want_lse.float(), atol=2e-2, rtol=0)

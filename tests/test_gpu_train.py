@@ -162,3 +162,75 @@ def test_bf16_training_precision_tracks_f32():
     losses.append(logs['loss'])
   assert ops.MATMUL_PRECISION == 'f32'                # restored after every step
   assert min(losses[3:]) < losses[0], losses
+
+
+def test_vit_encoder_gradients_match_torch_autograd():
+  """encoder_name='vit' training path: d loss / d theta of the hand-written VJP chain (f32 GEMMs,
+  bf16 attention) vs torch fp64 autograd of a plain torch restatement of the same tiny ViT."""
+  import torch.nn.functional as F
+  from snap_amd.configs import defaults
+  from snap_amd.models import image_encoder
+  cfg = defaults.image_encoder('vit')
+  cfg.encoder.hidden_size = 128
+  cfg.encoder.num_heads = 2
+  cfg.encoder.num_layers = 2
+  cfg.encoder.mlp_dim = 256
+  cfg.encoder.posemb_grid = (4, 4)
+  cfg.output_dim = 32
+  enc = image_encoder.ImageEncoder(cfg)
+  params = enc.init_params(torch.Generator().manual_seed(5), 'cpu')
+  g = torch.Generator().manual_seed(6)
+  img = torch.rand((2, 64, 48, 3), generator=g)
+  cot = torch.randn((2, 4, 3, 32), generator=g)
+  leaves = dict(trainer.flatten_params(params))
+
+  def ref_forward(P, image):
+    C, H, D = 128, 2, 64
+    x = F.conv2d((image * 2 - 1).permute(0, 3, 1, 2), P['encoder/embedding/kernel'].permute(3, 2, 0, 1),
+                 P['encoder/embedding/bias'], stride=16).permute(0, 2, 3, 1)
+    N, h, w, _ = x.shape
+    pe = P['encoder/pos_embedding'].reshape(1, 4, 4, C).permute(0, 3, 1, 2)
+    pe = F.interpolate(pe, size=(h, w), mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
+    x = x.reshape(N, h * w, C) + pe.reshape(1, h * w, C)
+    for i in range(2):
+      pre = f'encoder/Transformer/encoderblock_{i}/'
+      y = F.layer_norm(x, (C,), P[pre + 'LayerNorm_0/scale'], P[pre + 'LayerNorm_0/bias'], eps=1e-6)
+      att = pre + 'MultiHeadDotProductAttention_0/'
+      q, k, v = ((y @ P[att + n + '/kernel'].reshape(C, C) + P[att + n + '/bias'].reshape(C))
+                 .reshape(N, h * w, H, D).permute(0, 2, 1, 3) for n in ('query', 'key', 'value'))
+      a = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(N, h * w, C)
+      x = x + a @ P[att + 'out/kernel'].reshape(C, C) + P[att + 'out/bias']
+      y = F.layer_norm(x, (C,), P[pre + 'LayerNorm_1/scale'], P[pre + 'LayerNorm_1/bias'], eps=1e-6)
+      y = F.gelu(y @ P[pre + 'MlpBlock_0/Dense_0/kernel'] + P[pre + 'MlpBlock_0/Dense_0/bias'], approximate='tanh')
+      x = x + y @ P[pre + 'MlpBlock_0/Dense_1/kernel'] + P[pre + 'MlpBlock_0/Dense_1/bias']
+    x = F.layer_norm(x, (C,), P['encoder/Transformer/encoder_norm/scale'],
+                     P['encoder/Transformer/encoder_norm/bias'], eps=1e-6)
+    x = x @ P['encoder/proj/kernel'] + P['encoder/proj/bias']
+    return x.reshape(N, h, w, -1)
+
+  P64 = {k: v.double().requires_grad_(True) for k, v in leaves.items()}
+  ref = ref_forward(P64, img.double())
+  (ref * cot.double()).sum().backward()
+
+  gparams = helpers.params_to_device(params, 'cuda')
+  gleaves = dict(trainer.flatten_params(gparams))
+  for t in gleaves.values():
+    t.requires_grad_(True)
+  pyr = enc(gparams, img.cuda(), train=True)
+  got = pyr.features[0]
+  helpers.report('vit train-path forward', got, ref.detach().float(), atol=5e-3 * float(ref.abs().max()), rtol=0)
+  grads = torch.autograd.grad((got * cot.cuda()).sum(), list(gleaves.values()), allow_unused=True)
+  bad = []
+  for (name, _), gv in zip(gleaves.items(), grads):
+    want = P64[name].grad
+    assert gv is not None, name
+    scale = float(want.abs().max())
+    if name.endswith('key/bias'):
+      # exactly zero in exact arithmetic (the softmax is invariant to a key bias): the kernel's
+      # value is the sum of the bf16 rounding residues of dK over all tokens -- judged against
+      # the size of the query-bias gradient of the same block, not against ~1e-17
+      scale = float(P64[name.replace('key/bias', 'query/bias')].grad.abs().max())
+    err = float((gv.cpu().double() - want).abs().max()) / max(scale, 1e-6)
+    if err > 3e-2:
+      bad.append((name, err))
+  assert not bad, bad
