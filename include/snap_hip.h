@@ -123,6 +123,22 @@ size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, int32_t Cout)
 int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
                                   void* out, size_t out_bytes, void* stream);
 
+/* Semantic-raster embedding (snap/models/semantic_raster_encoder.py:63-79).  rasters [M, N]
+ * uint8 (bool); idx_road / idx_other: HOST arrays with the raster channels of the mutually
+ * exclusive surfel-road classes and of the independent binary classes (<= 32 each);
+ * table_road [nr, E], table_other [2*no, E]; out [M, (1 + no) * E]:
+ * [table_road[argmax road bits] | table_other[j + bit_j] for j < no]  (the reference's row
+ * indexing, :72-75).  E % 4 == 0.  snap_semantic_onehot_f32 writes the [M, KP] one-hot matrix
+ * (column c < nr: road label c; column nr + 2j + b: class j has bit b; KP % 4 == 0) whose
+ * transpose times d out (snap_conv2d_wgrad_f32) gives the table gradients deterministically. */
+int snap_semantic_embed_f32(const uint8_t* rasters, int64_t M, int32_t N, const int32_t* idx_road,
+                            int32_t nr, const int32_t* idx_other, int32_t no,
+                            const float* table_road, const float* table_other, int32_t E,
+                            float* out, void* stream);
+int snap_semantic_onehot_f32(const uint8_t* rasters, int64_t M, int32_t N, const int32_t* idx_road,
+                             int32_t nr, const int32_t* idx_other, int32_t no, float* onehot,
+                             int32_t KP, void* stream);
+
 /* ViT encoder pieces (BASELINE.json configs[4]; the reference itself has no ViT --
  * snap/models/image_encoder.py:103 -- so these follow the published ViT block).
  * snap_layer_norm_f32: y[m,:] = (x[m,:] - mean) * rsqrt(var + eps) * gamma + beta over the C

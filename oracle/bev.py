@@ -109,7 +109,8 @@ def matching_head(params, config, plane):
 
 
 def bev_mapper(params, config, grid, data):
-  """bev_mapper.py:254-296 (streetview [+ aerial] modalities, eval)."""
+  """bev_mapper.py:254-296 (streetview [+ aerial] [+ semantic] modalities, eval).  The raster
+  class names of the semantic modality travel as ``config['_semantic_map_classes']``."""
   pred = {}
   planes = []
   data = dict(data)
@@ -138,8 +139,42 @@ def bev_mapper(params, config, grid, data):
     plane = dict(features=f, valid=np.ones(f.shape[:-1], bool))
     pred['aerial'] = {'feature_plane': plane}
     planes.append(plane)
+  if config.get('semantic_encoder') is not None and 'rasters' in data:
+    # bev_mapper.py:214-223,273-278 (no semantic rasters for query images)
+    pyr = semantic_raster_encoder(
+        params['semantic_encoder'], config['semantic_encoder'],
+        config['_semantic_map_classes'], data['rasters']['semantics'],
+    )
+    f = pyr['features'][-1]
+    plane = dict(features=f, valid=np.ones(f.shape[:-1], bool))
+    pred['semantic'] = {'feature_plane': plane}
+    planes.append(plane)
   pred['bev_features'] = plane = fuse_neural_maps(config, planes)
   if config.get('matching_dim') is not None:
     pred['bev_matching'] = matching_head(params, config, plane)
   pred['_xyz_query'] = data.get('xyz_query')
   return pred
+
+
+# snap/data/types.py:35-42
+SURFEL_ROAD_CLASSES = ('crosswalk', 'sidewalk', 'pavedroad', 'stopline', 'line', 'otherlanemarking')
+
+
+def semantic_raster_embed(params, raster_classes, rasters, dtype=np.float32):
+  """semantic_raster_encoder.py:33-46,63-79: rasters [..., N] bool -> [..., (1 + n_other) * E]."""
+  idx_road = [i for i, c in enumerate(raster_classes) if c in SURFEL_ROAD_CLASSES]
+  idx_other = [i for i, c in enumerate(raster_classes) if c not in SURFEL_ROAD_CLASSES]
+  t_road = params['embeddings_surfel_road']['embedding']
+  t_other = params['embeddings_other_classes']['embedding']
+  label_road = np.argmax(rasters[..., idx_road], axis=-1)                 # :65-66
+  f_road = t_road[label_road]                                               # :67
+  labels_other = np.arange(len(idx_other)) + rasters[..., idx_other].astype(int)   # :70-72 (sic)
+  f_other = t_other[labels_other]                                           # :73
+  f_other = f_other.reshape(*f_other.shape[:-2], -1)                        # :75
+  return np.concatenate([f_road, f_other], axis=-1).astype(dtype)          # :77
+
+
+def semantic_raster_encoder(params, config, raster_classes, rasters):
+  f = semantic_raster_embed(params, raster_classes, rasters,
+                            params['embeddings_surfel_road']['embedding'].dtype)
+  return encoder.image_encoder(params['encoder'], config['encoder'], f)      # :78

@@ -68,6 +68,9 @@ SIGNATURES = {
     'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_semantic_embed_f32': (
+        c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, ptr, c_int, ptr, ptr]),
+    'snap_semantic_onehot_f32': (c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, c_int, ptr]),
     'snap_layer_norm_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_attention_bf16_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_attention_lse_bf16_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),

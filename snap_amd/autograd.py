@@ -160,6 +160,40 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=ops.PRO_NONE, relu=False, 
   return y.reshape(*lead, kernel.shape[1])
 
 
+class _SemanticEmbed(torch.autograd.Function):
+  """Embedding lookups of the semantic rasters; table gradients = one-hot^T @ dy on the
+  deterministic wgrad engine (exact f32), then the few rows are regrouped on the host."""
+
+  @staticmethod
+  def forward(ctx, rasters, table_road, table_other, idx_road, idx_other):
+    ctx.idx = (tuple(idx_road), tuple(idx_other))
+    ctx.save_for_backward(rasters)
+    ctx.shapes = (tuple(table_road.shape), tuple(table_other.shape))
+    return ops.semantic_embed(rasters, idx_road, idx_other, table_road, table_other)
+
+  @staticmethod
+  def backward(ctx, dy):
+    (rasters,) = ctx.saved_tensors
+    idx_road, idx_other = ctx.idx
+    nr, no = len(idx_road), len(idx_other)
+    E = ctx.shapes[0][1]
+    onehot = ops.semantic_onehot(rasters, idx_road, idx_other)
+    M, KP = onehot.shape
+    W = dy.shape[-1]
+    G = ops_bwd.conv2d_wgrad(onehot.reshape(1, 1, M, KP), dy.contiguous().reshape(1, 1, M, W),
+                             (1, 1, KP, W), math='f32').reshape(KP, W)
+    d_road = G[:nr, :E].contiguous()
+    d_other = torch.zeros(ctx.shapes[1], dtype=G.dtype, device=G.device)
+    for j in range(no):
+      for b in (0, 1):      # class j with bit b read row j + b (semantic_raster_encoder.py:72-75)
+        d_other[j + b] += G[nr + 2 * j + b, E * (1 + j):E * (2 + j)]
+    return None, d_road, d_other, None, None
+
+
+def semantic_embed(rasters, idx_road, idx_other, table_road, table_other):
+  return _SemanticEmbed.apply(rasters, table_road, table_other, tuple(idx_road), tuple(idx_other))
+
+
 # ----------------------------------------------------------------------------
 # ViT pieces (vit_ops.hip / vit_bwd.hip)
 # ----------------------------------------------------------------------------

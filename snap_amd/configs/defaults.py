@@ -93,6 +93,17 @@ def aerial_encoder() -> ConfigDict:
   return cfg
 
 
+def semantic_raster_encoder() -> ConfigDict:
+  """defaults.py:191-198."""
+  encoder = image_encoder()
+  encoder.encoder.skip_root_block = True
+  encoder.encoder.depth = 26
+  encoder.encoder.width = 2
+  encoder.encoder.pretrained_path = None
+  encoder.encoder.limit_num_blocks = 4
+  return ConfigDict(encoder=encoder, embedding_dim=8).lock()
+
+
 def streetview_encoder() -> ConfigDict:
   dim = 128
   fusion = mlp()
@@ -137,9 +148,7 @@ def bev_mapper(
     elif m == MapModalities.AERIAL:
       cfg.aerial_encoder = aerial_encoder()
     else:
-      # The semantic-raster modality is outside the streetview+aerial hot path
-      # (SURVEY.md section 2.1 #20).
-      raise NotImplementedError(f'modality {m.value} is out of scope')
+      cfg.semantic_encoder = semantic_raster_encoder()
   return cfg.lock()
 
 

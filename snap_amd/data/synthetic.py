@@ -35,9 +35,13 @@ def make_cameras(B, V, image_size, k_radial=0.0, max_fov_deg=115.0):
   return wh, f, c, k, fov
 
 
+SURFEL_ROAD_CLASSES = ('crosswalk', 'sidewalk', 'pavedroad', 'stopline', 'line', 'otherlanemarking')
+
+
 def make_batch(
     batch_size, grid: grids.Grid3D, num_views, image_size, query_image_size=None,
     seed=0, device='cpu', with_aerial=True, with_gt=True, k_radial=0.0,
+    semantic_classes=None,
 ):
   """Returns a batch dict: map / query scenes + planted T_query2map."""
   rng = np.random.default_rng(seed)
@@ -65,6 +69,17 @@ def make_batch(
   }
   if with_aerial:
     map_scene['rasters'] = {'rgb': t(rng.random((B, X, Y, 3), dtype=np.float32))}
+  if semantic_classes:
+    # boolean rasters [B, X, Y, N] (loader.py:150-158): random blobs per class; the surfel-road
+    # classes are made mutually exclusive as in the data (semantic_raster_encoder.py:33-35)
+    srng = np.random.default_rng(seed + 977)     # own stream: the other fields stay unchanged
+    sem = srng.random((B, X, Y, len(semantic_classes))) < 0.3
+    road = [i for i, c in enumerate(semantic_classes) if c in SURFEL_ROAD_CLASSES]
+    if road:
+      pick = srng.integers(0, len(road) + 1, (B, X, Y))
+      for k, i in enumerate(road):
+        sem[..., i] = pick == k
+    map_scene.setdefault('rasters', {})['semantics'] = torch.as_tensor(sem).to(device)
 
   # query: one view at the origin of its gravity-aligned frame, looking along +y.
   R_q = _yaw_camera_rotation(np.full((B, 1), np.pi / 2))

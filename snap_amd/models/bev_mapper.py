@@ -10,6 +10,7 @@ from snap_amd.configs import defaults as default_configs
 from snap_amd.models import base
 from snap_amd.models import image_encoder
 from snap_amd.models import layers
+from snap_amd.models import semantic_raster_encoder
 from snap_amd.models import streetview_encoder
 from snap_amd.models import types
 
@@ -106,7 +107,9 @@ class BEVMapper(base.Module):
       self.aerial_encoder = image_encoder.ImageEncoder(config.aerial_encoder, dtype)
       feature_dimensions.append(config.aerial_encoder.output_dim)
     if config.semantic_encoder is not None:
-      raise NotImplementedError('semantic modality is out of scope (SURVEY 2.1 #20)')
+      self.semantic_encoder = semantic_raster_encoder.SemanticRasterEncoder(
+          config.semantic_encoder, semantic_map_classes, dtype)
+      feature_dimensions.append(config.semantic_encoder.encoder.output_dim)
     if not feature_dimensions:
       raise ValueError('Need to create at least one input encoder.')
     elif len(feature_dimensions) > 1:
@@ -130,6 +133,8 @@ class BEVMapper(base.Module):
       params['vertical_pooling'] = self.vertical_pooling.init_params(gen, device)
     if self.aerial_encoder is not None:
       params['aerial_encoder'] = self.aerial_encoder.init_params(gen, device)
+    if self.semantic_encoder is not None:
+      params['semantic_encoder'] = self.semantic_encoder.init_params(gen, device)
     if self.modality_fusion is not None:
       params['modality_fusion'] = {}
     if self.config.matching_dim is not None:
@@ -194,6 +199,16 @@ class BEVMapper(base.Module):
     )
     return {'feature_plane': plane}
 
+  def encode_semantics(self, params, semantic_raster, train=False, ctx=None):
+    """bev_mapper.py:214-223."""
+    pyramid = self.semantic_encoder(params['semantic_encoder'], semantic_raster, train=train, ctx=ctx)
+    features = pyramid.features[-1].contiguous()      # highest-resolution level
+    plane = types.FeaturePlane(
+        features=features,
+        valid=torch.ones(features.shape[:-1], dtype=torch.bool, device=features.device),
+    )
+    return {'feature_plane': plane}
+
   def __call__(self, params, data, train=False, debug=False, is_query=False,
                ctx=None, rng=None):
     cfg = self.config
@@ -208,6 +223,10 @@ class BEVMapper(base.Module):
     if self.aerial_encoder is not None and 'rasters' in data:
       pred['aerial'] = self.encode_aerial(params, data['rasters']['rgb'], train=train, ctx=ctx)
       feature_planes.append(pred['aerial']['feature_plane'])
+    if self.semantic_encoder is not None and 'rasters' in data:
+      # (there are no semantic rasters for query images, bev_mapper.py:273-278)
+      pred['semantic'] = self.encode_semantics(params, data['rasters']['semantics'], train=train, ctx=ctx)
+      feature_planes.append(pred['semantic']['feature_plane'])
     if not feature_planes:
       raise ValueError('No map encoder given.')
 

@@ -71,7 +71,7 @@ class FPNDecoder(base.Module):
 class ImageEncoder(base.Module):
   """image_encoder.py:97-144.  Input [N, H, W, 3] in [0, 1]."""
 
-  def __init__(self, config, dtype=torch.float32):
+  def __init__(self, config, dtype=torch.float32, in_channels=3):
     self.config = config
     num_pyr_levels = config.num_pyr_levels
     self.is_vit = config.encoder_name == 'vit'
@@ -81,7 +81,7 @@ class ImageEncoder(base.Module):
       return
     if config.encoder_name != 'resnet':
       raise ValueError(config.encoder_name)
-    self.encoder = resnet.ResNetV2(config.encoder, dtype)
+    self.encoder = resnet.ResNetV2(config.encoder, dtype, in_channels=in_channels)
     if num_pyr_levels is None:
       num_pyr_levels = len(self.encoder.level_names)
     self.max_stride = (not config.encoder.skip_root_block) * 2 + num_pyr_levels - 1

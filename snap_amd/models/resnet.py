@@ -97,8 +97,9 @@ def _init_unit(gen, device, cin, nmid, stride):
 class ResNetV2(base.Module):
   """BiT variant (resnet.py:170-216); returns {stage: {unit: activation}}."""
 
-  def __init__(self, config, dtype=torch.float32):
+  def __init__(self, config, dtype=torch.float32, in_channels=3):
     self.config = config
+    self.in_channels = in_channels   # (Flax infers it at init; 3 for images)
     self.blocks = get_block_desc(config.depth)
     if config.limit_num_blocks is not None:
       self.blocks = self.blocks[: config.limit_num_blocks]
@@ -111,10 +112,12 @@ class ResNetV2(base.Module):
     w = self.width
     params = {}
     if self.config.skip_root_block:
-      params['conv_root'] = {'kernel': base.lecun_normal(gen, (3, 3, 3, w), 27, device)}
+      c = self.in_channels
+      params['conv_root'] = {'kernel': base.lecun_normal(gen, (3, 3, c, w), 9 * c, device)}
     else:
+      c = self.in_channels
       params['root_block'] = {
-          'conv_root': {'kernel': base.lecun_normal(gen, (7, 7, 3, w), 147, device)}
+          'conv_root': {'kernel': base.lecun_normal(gen, (7, 7, c, w), 49 * c, device)}
       }
     cin = w
     for i, size in enumerate(self.blocks):

@@ -295,6 +295,43 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
   return y.reshape(*lead, kernel.shape[1])
 
 
+def semantic_embed(rasters, idx_road, idx_other, table_road, table_other):
+  """rasters [..., N] bool -> [..., (1 + len(idx_other)) * E] (semantic_raster_encoder.py:63-79)."""
+  lib = _lib.load()
+  _mask(rasters, 'rasters'); _f32(table_road, 'table_road'); _f32(table_other, 'table_other')
+  N = rasters.shape[-1]
+  M = rasters.numel() // N
+  E = table_road.shape[1]
+  nr, no = len(idx_road), len(idx_other)
+  if tuple(table_road.shape) != (nr, E) or tuple(table_other.shape) != (2 * no, E):
+    raise ValueError('semantic_embed: table shapes')
+  ir = (ctypes.c_int32 * max(nr, 1))(*idx_road)
+  io = (ctypes.c_int32 * max(no, 1))(*idx_other)
+  out = torch.empty((*rasters.shape[:-1], (1 + no) * E), dtype=torch.float32, device=rasters.device)
+  st = lib.snap_semantic_embed_f32(_p(rasters), M, N, ctypes.cast(ir, ctypes.c_void_p), nr,
+                                   ctypes.cast(io, ctypes.c_void_p), no, _p(table_road),
+                                   _p(table_other), E, _p(out), _stream())
+  _lib.check(st, 'snap_semantic_embed_f32')
+  return out
+
+
+def semantic_onehot(rasters, idx_road, idx_other):
+  """[M, KP] one-hot matrix of the embedding rows each pixel reads (KP = roundup(nr + 2 no, 4))."""
+  lib = _lib.load()
+  _mask(rasters, 'rasters')
+  N = rasters.shape[-1]
+  M = rasters.numel() // N
+  nr, no = len(idx_road), len(idx_other)
+  KP = (nr + 2 * no + 3) // 4 * 4
+  ir = (ctypes.c_int32 * max(nr, 1))(*idx_road)
+  io = (ctypes.c_int32 * max(no, 1))(*idx_other)
+  onehot = torch.empty((M, KP), dtype=torch.float32, device=rasters.device)
+  st = lib.snap_semantic_onehot_f32(_p(rasters), M, N, ctypes.cast(ir, ctypes.c_void_p), nr,
+                                    ctypes.cast(io, ctypes.c_void_p), no, _p(onehot), KP, _stream())
+  _lib.check(st, 'snap_semantic_onehot_f32')
+  return onehot
+
+
 def layer_norm(x, gamma, beta, eps=1e-6):
   """LayerNorm over the last axis (flax.linen.LayerNorm: biased variance, eps inside the sqrt)."""
   lib = _lib.load()

@@ -67,7 +67,11 @@ def scene_to_oracle(scene, dtype=np.float32):
       'T_view2scene': o_geo.Transform3D(n(T.R), n(T.t)),
   }
   if 'rasters' in scene:
-    out['rasters'] = {'rgb': n(scene['rasters']['rgb'])}
+    out['rasters'] = {}
+    if 'rgb' in scene['rasters']:
+      out['rasters']['rgb'] = n(scene['rasters']['rgb'])
+    if 'semantics' in scene['rasters']:
+      out['rasters']['semantics'] = scene['rasters']['semantics'].detach().cpu().numpy().astype(bool)
   if 'xyz_query' in scene:
     out['xyz_query'] = n(scene['xyz_query'])
   return out

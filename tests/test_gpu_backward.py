@@ -524,3 +524,27 @@ def test_attention_bwd(B, N, H):
   s = torch.einsum('bhqd,bhkd->bhqk', q, k).detach() * 0.125
   want_lse = torch.logsumexp(s, -1) / math.log(2.0)
   helpers.report('attention lse', lse, want_lse.float(), atol=2e-2, rtol=0)
+
+
+def test_semantic_embed_table_gradients():
+  """d tables of the semantic-raster embedding (one-hot^T @ dy on the wgrad engine) vs torch
+  autograd of the indexing expression of semantic_raster_encoder.py:63-79."""
+  from snap_amd import autograd as ag
+  g = torch.Generator().manual_seed(41)
+  N, nr, no, E = 7, 3, 4, 8
+  idx_road, idx_other = [0, 2, 5], [1, 3, 4, 6]
+  rasters = torch.rand((2, 11, 9, N), generator=g) < 0.5
+  t_road = torch.randn((nr, E), generator=g)
+  t_other = torch.randn((2 * no, E), generator=g)
+  dy = torch.randn((2, 11, 9, (1 + no) * E), generator=g)
+  tr, to = t_road.double().requires_grad_(True), t_other.double().requires_grad_(True)
+  label = torch.argmax(rasters[..., idx_road].int(), dim=-1)
+  f_road = tr[label]
+  lab_o = torch.arange(no) + rasters[..., idx_other].long()
+  f_other = to[lab_o].reshape(2, 11, 9, no * E)
+  (torch.cat([f_road, f_other], -1) * dy.double()).sum().backward()
+  a, b = G(t_road).requires_grad_(True), G(t_other).requires_grad_(True)
+  out = ag.semantic_embed(G(rasters), idx_road, idx_other, a, b)
+  ga, gb = torch.autograd.grad((out * G(dy)).sum(), [a, b])
+  helpers.report('d table_road', ga, tr.grad.float(), atol=1e-4, rtol=1e-5)
+  helpers.report('d table_other', gb, to.grad.float(), atol=1e-4, rtol=1e-5)

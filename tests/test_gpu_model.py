@@ -184,3 +184,69 @@ def test_localizer_runs_with_vit_streetview_encoder():
   assert bool(torch.isfinite(pred['scores_poses']).all())
   f = pred['map']['streetview']['image_feature_pyramid'].features[-1]
   assert f.shape[-3:-1] == (4, 4)
+
+
+SEM_CLASSES = ('sidewalk', 'buildings_raw', 'pavedroad', 'crosswalk', 'trees', 'poles')
+
+
+def _semantic_config():
+  from snap_amd.configs import defaults
+  cfg = helpers.tiny_localizer_config(top_k=2)
+  sem = defaults.semantic_raster_encoder()
+  sem.embedding_dim = 4
+  sem.encoder.output_dim = cfg.bev_mapper.aerial_encoder.output_dim
+  sem.encoder.encoder.depth = [1, 1]
+  sem.encoder.encoder.width = 0.5
+  sem.encoder.encoder.limit_num_blocks = 2
+  cfg.bev_mapper.semantic_encoder = sem
+  return cfg
+
+
+def test_semantic_embed_kernel_matches_oracle():
+  from oracle import bev as o_bev
+  from snap_amd import ops
+  g = torch.Generator().manual_seed(31)
+  rasters = torch.rand((2, 9, 7, len(SEM_CLASSES)), generator=g) < 0.4
+  rasters[0, 0, 0] = False                                   # no class set at all
+  t_road = torch.randn((3, 8), generator=g)
+  t_other = torch.randn((6, 8), generator=g)
+  idx_road = [i for i, c in enumerate(SEM_CLASSES) if c in o_bev.SURFEL_ROAD_CLASSES]
+  idx_other = [i for i, c in enumerate(SEM_CLASSES) if c not in o_bev.SURFEL_ROAD_CLASSES]
+  got = ops.semantic_embed(rasters.cuda(), idx_road, idx_other, t_road.cuda(), t_other.cuda())
+  want = o_bev.semantic_raster_embed(
+      {'embeddings_surfel_road': {'embedding': t_road.numpy()},
+       'embeddings_other_classes': {'embedding': t_other.numpy()}}, SEM_CLASSES, rasters.numpy())
+  helpers.report('semantic embed', got, want, atol=0.0)       # a pure gather: bit-exact
+
+
+def test_localizer_parity_with_semantic_modality():
+  """StreetView + aerial + semantic-raster modality (bev_mapper.py:125-129,214-223,273-278)."""
+  from snap_amd.data import synthetic
+  from snap_amd.models import bev_localizer
+  from oracle import geometry as o_geo, grids as o_grids, model as o_model
+  cfg = _semantic_config()
+  dev = torch.device('cuda')
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev(),
+                                   semantic_map_classes=SEM_CLASSES)
+  variables = loc.init(3, device='cpu')
+  assert 'semantic_encoder' in variables['params']['bev_mapper']
+  batch = synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=4, semantic_classes=SEM_CLASSES)
+  pred = loc.apply({'params': helpers.params_to_device(variables['params'], dev)},
+                   helpers.batch_to_device(batch, dev), train=False, rngs={'sampling': 11}, debug=True)
+  samples = pred['map_t_query_samples']
+  ps = o_geo.Transform2D(samples.angle[:, 1:].cpu().numpy(), samples.t[:, 1:].cpu().numpy())
+  ocfg = cfg.to_dict()
+  ocfg['bev_mapper']['_semantic_map_classes'] = SEM_CLASSES
+  ref = o_model.bev_localizer(
+      helpers.params_to_numpy(variables['params']), ocfg, {'streetview_hfov_deg': 72.0},
+      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch),
+      pose_samples=ps, keep_sim=True)
+  helpers.report('semantic plane', pred['map']['semantic']['feature_plane'].features,
+                 ref['map']['semantic']['feature_plane']['features'], atol=1e-3)
+  helpers.report('map bev_matching (3 modalities)', pred['map']['bev_matching'].features,
+                 ref['map']['bev_matching']['features'], atol=1e-3)
+  helpers.report('scores_poses', pred['scores_poses'], ref['scores_poses'], atol=1e-3, rtol=1e-3)
+  helpers.assert_same_argmax('best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                             got_index=pred['best_index'])
+  assert 'semantic' not in pred['query']
