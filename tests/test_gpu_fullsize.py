@@ -174,3 +174,56 @@ def test_c2_forward_is_deterministic_and_sane():
   assert int(p1['best_index'].max()) < 10000 and int(p1['best_index'].min()) >= 0
   p3 = loc.apply(variables, batch, rngs={'sampling': 10})
   assert not torch.equal(p1['map_t_query_samples'].t[:, 1:], p3['map_t_query_samples'].t[:, 1:])
+
+
+def test_bf16_engines_full_size_properties():
+  """bf16-operand conv / wgrad engines at the fusion-MLP size of the C3 step (1 M voxel rows,
+  K = 257 of a 260-wide row, N = 256): scaling the input by a power of two commutes with the
+  bf16 rounding and with every f32 product and sum, so the result must scale bit-exactly; the
+  weight gradient of an all-ones dy is the (bf16-rounded) column sum of x, checked against
+  torch on the rounded values; and a launch is run-to-run deterministic."""
+  from snap_amd import ops_bwd
+  g = torch.Generator(device=DEV).manual_seed(7)
+  M, Cs, K, N = 1 << 20, 260, 257, 256
+  x = torch.randn((1, 1, M, Cs), device=DEV, generator=g)
+  w = torch.randn((1, 1, K, N), device=DEV, generator=g) / 16
+  b = torch.randn((N,), device=DEV, generator=g)
+  y1 = ops.conv2d(x, w, cin=K, math='bf16')
+  y2 = ops.conv2d(x * 4.0, w, cin=K, math='bf16')
+  assert torch.equal(y1 * 4.0, y2)
+  assert torch.equal(y1, ops.conv2d(x, w, cin=K, math='bf16'))
+  yb = ops.conv2d(x, w, cin=K, bias=b, relu=True, math='bf16')
+  assert torch.equal(yb, torch.relu(y1 + b))
+  exact = ops.conv2d(x[:, :, :4096], w, cin=K)                       # f32 engine, first rows
+  err = (y1[:, :, :4096] - exact).abs().max() / exact.abs().max()
+  assert 1e-5 < float(err) < 2e-2, float(err)                         # bf16-class, and really bf16
+  dy = torch.ones((1, 1, M, N), device=DEV)
+  dw = ops_bwd.conv2d_wgrad(x, dy, (1, 1, K, N), math='bf16')
+  want = x[0, 0, :, :K].to(torch.bfloat16).double().sum(0)
+  got = dw[0, 0, :, 0].double()
+  assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max()) + 0.5   # f32 sums of 1M terms
+  assert torch.equal(dw[0, 0, :, 0], dw[0, 0, :, N - 1])              # every column sees the same sum
+  assert torch.equal(dw, ops_bwd.conv2d_wgrad(x, dy, (1, 1, K, N), math='bf16'))
+
+
+def test_attention_full_size_properties():
+  """ViT-B/16 attention at the C5 size (20 images x 1024 tokens x 12 heads): softmax rows sum to
+  one, so a per-head constant V comes back exactly as that constant (whatever Q and K are); a
+  one-hot-sharp softmax (one dominant key per query) returns that key's V row; deterministic."""
+  g = torch.Generator(device=DEV).manual_seed(9)
+  B, N, H, D = 20, 1024, 12, 64
+  qkv = torch.randn((B, N, 3, H, D), device=DEV, generator=g)
+  const = torch.randn((H, D), device=DEV, generator=g).to(torch.bfloat16).float()   # bf16-exact values
+  qkv[:, :, 2] = const
+  out = ops.attention(qkv)
+  assert torch.equal(out, ops.attention(qkv))
+  want = const.reshape(1, 1, H * D).expand(B, N, H * D)
+  assert float((out - want).abs().max()) <= 8e-3 * float(const.abs().max())   # P rounded to bf16: sum(P) = 1 +- 2^-8
+  # sharp softmax: q_i = 64 * k_perm(i), unit-norm keys -> key perm(i) wins by a wide margin
+  k = torch.nn.functional.normalize(torch.randn((B, N, H, D), device=DEV, generator=g), dim=-1)
+  perm = torch.randperm(N, device=DEV, generator=g)
+  v = torch.randn((B, N, H, D), device=DEV, generator=g)
+  qkv2 = torch.stack([k[:, perm] * 512.0, k, v], dim=2).contiguous()
+  out2 = ops.attention(qkv2).reshape(B, N, H, D)
+  want2 = v[:, perm].to(torch.bfloat16).float()
+  assert float((out2 - want2).abs().max()) <= 2e-2 * float(v.abs().max())
