@@ -380,6 +380,14 @@ int snap_rotate_templates_f32(const float* feat, const uint8_t* valid,
 
 /* map[H,W,D], mvalid[H,W] -> map_pad[3H-2,3W-2,D] (edge), mvalid_pad[3H-2,3W-2]
  * (zero padded, as float). */
+/* Shift-stacked filter bank for the exhaustive correlation: tw [H, W, D, R] (HWIO) ->
+ * tws [H+S-1, W+S-1, D, R*S*S], tws[i', j', d, (r*S + sa)*S + sb] = tw[i'-sa, j'-sb, d, r]
+ * (zero outside).  A stride-S snap_conv2d over the padded map with tws computes, at output
+ * pixel (a4, b4) and channel (r, sa, sb), exactly the direct-form output (r, S a4 + sa,
+ * S b4 + sb) of pose_exhaustive_voting.py:86-91 -- same products, full 64-wide GEMM tiles
+ * instead of R = 36 columns. */
+int snap_stack_templates_f32(const float* tw, float* tws, int32_t H, int32_t W, int32_t D,
+                             int32_t R, int32_t S, void* stream);
 int snap_pad_map_f32(const float* map, const uint8_t* mvalid, int32_t H, int32_t W,
                      int32_t D, float* map_pad, float* mvalid_pad, void* stream);
 

@@ -135,6 +135,39 @@ extern "C" int snap_rotate_templates_f32(const float* feat, const uint8_t* valid
   return SNAP_OK;
 }
 
+// Shift-stacked filter bank: tws[i', j', d, (r*S + sa)*S + sb] = tw[i'-sa, j'-sb, d, r] (0 outside).
+// A stride-S correlation with it yields, per output pixel (a4, b4), the S x S block of direct-form
+// outputs (S a4 + sa, S b4 + sb) of every template: the GEMM's N grows from R (36: 56 % of a
+// 64-wide tile) to R S^2 (576 = 9 full tiles), M shrinks by S^2, K grows by ((H+S-1)(W+S-1))/(HW).
+__global__ __launch_bounds__(256) void stack_templates_kernel(
+    const float* __restrict__ tw, float* __restrict__ tws, int H, int W, int D, int R, int S) {
+  const int RS = R * S * S;
+  const int64_t total = (int64_t)(H + S - 1) * (W + S - 1) * D * RS;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i % RS);
+  int64_t t = i / RS;
+  const int d = (int)(t % D); t /= D;
+  const int jp = (int)(t % (W + S - 1));
+  const int ip = (int)(t / (W + S - 1));
+  const int sb = n % S, sa = (n / S) % S, r = n / (S * S);
+  const int ii = ip - sa, jj = jp - sb;
+  tws[i] = (ii >= 0 && ii < H && jj >= 0 && jj < W)
+               ? tw[(((int64_t)ii * W + jj) * D + d) * R + r] : 0.f;
+}
+
+extern "C" int snap_stack_templates_f32(const float* tw, float* tws, int32_t H, int32_t W,
+                                        int32_t D, int32_t R, int32_t S, void* stream) {
+  if (!tw || !tws) return SNAP_ERR_NULL;
+  if (H <= 0 || W <= 0 || D <= 0 || R <= 0 || S < 1 || S > 8) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)(H + S - 1) * (W + S - 1) * D * R * S * S;
+  if (snap_cdiv(total, 256) > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(stack_templates_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), tw, tws, H, W, D, R, S);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
 extern "C" int snap_pad_map_f32(const float* map, const uint8_t* mvalid, int32_t H, int32_t W,
                                 int32_t D, float* map_pad, float* mvalid_pad, void* stream) {
   if (!map || !mvalid || !map_pad || !mvalid_pad) return SNAP_ERR_NULL;

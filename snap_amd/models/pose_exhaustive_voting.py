@@ -51,10 +51,34 @@ def sample_query_templates(features, valid, num_rotations, grid, _engine=False):
   return out[0], out[1]
 
 
+# Shift-stacking factor of the correlation GEMM (0 / 1 = plain direct form).  With R = 36 templates
+# the GEMM has 36 output columns -- 56 % of a 64-wide MFMA tile; stacking the S x S shifted copies
+# of every template as extra filters (and striding the correlation by S) gives R S^2 = 576 columns
+# = 9 full tiles for 2.4 % more multiply-adds: the same products, summed in the same k order.
+STACK_SHIFT = 4
+STACK_MIN_CELLS = 64 * 64      # below this the plain form is already launch-bound
+
+
+def _correlate(mp, tw, R, q_hw):
+  H, W = q_hw
+  S = STACK_SHIFT
+  Ho, Wo = mp.shape[0] - H + 1, mp.shape[1] - W + 1
+  if S <= 1 or H * W < STACK_MIN_CELLS or (R * S * S) % 4:
+    return ops.conv2d(mp[None], tw)[0]                  # [Ho, Wo, R]
+  tws = ops.stack_templates(tw, S)
+  A4, B4 = -(-Ho // S), -(-Wo // S)
+  pb = max(0, S * (A4 - 1) + (H + S - 1) - mp.shape[0])  # zero rows only cropped outputs can see
+  pr = max(0, S * (B4 - 1) + (W + S - 1) - mp.shape[1])
+  raw4 = ops.conv2d(mp[None], tws, stride=S, padding=((0, pb), (0, pr)))[0]   # [A4, B4, R*S*S]
+  del tws
+  raw = raw4.reshape(A4, B4, R, S, S).permute(0, 3, 1, 4, 2).reshape(A4 * S, B4 * S, R)
+  return raw[:Ho, :Wo].contiguous()
+
+
 def _match(tw, cw, tcount, R, q_hw, m, m_valid, min_overlap):
   H, W = q_hw
   mp, mvp = ops.pad_map(m.contiguous(), m_valid.contiguous())
-  raw = ops.conv2d(mp[None], tw)[0]                     # [Ho, Wo, R]
+  raw = _correlate(mp, tw, R, q_hw)                     # [Ho, Wo, R]
   cnt = None
   if min_overlap is not None:
     cnt = ops.conv2d(mvp[None, :, :, None].contiguous(), cw)[0]

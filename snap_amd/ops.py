@@ -332,6 +332,17 @@ def semantic_onehot(rasters, idx_road, idx_other):
   return onehot
 
 
+def stack_templates(tw, S):
+  """tw [H, W, D, R] -> shift-stacked filter bank [H+S-1, W+S-1, D, R*S*S] (see snap_hip.h)."""
+  lib = _lib.load()
+  _f32(tw, 'tw')
+  H, W, D, R = tw.shape
+  tws = torch.empty((H + S - 1, W + S - 1, D, R * S * S), dtype=torch.float32, device=tw.device)
+  st = lib.snap_stack_templates_f32(_p(tw), _p(tws), H, W, D, R, S, _stream())
+  _lib.check(st, 'snap_stack_templates_f32')
+  return tws
+
+
 def layer_norm(x, gamma, beta, eps=1e-6):
   """LayerNorm over the last axis (flax.linen.LayerNorm: biased variance, eps inside the sqrt)."""
   lib = _lib.load()

@@ -541,6 +541,30 @@ def test_rotate_templates_and_matching(H, R, D):
   assert full.shape == (R, 2 * H - 1, 2 * H - 1)
 
 
+@pytest.mark.parametrize('H,R,D,S', [(16, 8, 8, 4), (24, 36, 32, 4), (24, 36, 32, 3), (20, 12, 16, 2)])
+def test_template_matching_shift_stacked(H, R, D, S, monkeypatch):
+  """The shift-stacked form of the correlation GEMM (R S^2 filters, stride S) is the direct form
+  re-tiled: compared with the oracle and with the plain path (same products and k order; only
+  the split-K partition can differ), incl. output sizes that S does not divide."""
+  from oracle import voting as o_voting
+  from snap_amd.models import pose_exhaustive_voting as pev
+  rng = np.random.default_rng(140 + S)
+  t = rng.standard_normal((R, H, H, D)).astype(np.float32)
+  tv = rng.random((R, H, H)) > 0.2
+  t = t * tv[..., None]
+  fm = rng.standard_normal((H, H, D)).astype(np.float32)
+  vm = rng.random((H, H)) > 0.1
+  args = [torch.tensor(a).to(DEV) for a in (t, tv, fm, vm)]
+  monkeypatch.setattr(pev, 'STACK_SHIFT', 1)
+  plain = pev.template_matching(*args)
+  monkeypatch.setattr(pev, 'STACK_SHIFT', S)
+  monkeypatch.setattr(pev, 'STACK_MIN_CELLS', 0)
+  stacked = pev.template_matching(*args)
+  want = o_voting.template_matching(t, tv, fm, vm)
+  helpers.report(f'stacked S={S} vs oracle', stacked, want, atol=1e-4, rtol=1e-5)
+  helpers.report(f'stacked S={S} vs plain', stacked, plain, atol=2e-5, rtol=1e-6)
+
+
 def test_exhaustive_identity_kat():
   """Known answer: matching a map with itself peaks at (0, H-1, W-1)."""
   from snap_amd.models import pose_exhaustive_voting as pev
