@@ -152,6 +152,26 @@ def bev_mapper(
   return cfg.lock()
 
 
+def semantic_net() -> ConfigDict:
+  """defaults.py:286-342."""
+  return ConfigDict(
+      bev_mapper=bev_mapper(), decoder_type='mlp', decoder_dim=128, mlp_num_layers=2,
+      resnet_num_units=8, apply_random_flip=False,
+      area_classes=('crosswalk', 'sidewalk', 'road', 'terrain', 'building'),
+      area_frequencies=(
+          ('crosswalk', 0.036434), ('sidewalk', 0.226553), ('road', 0.446990),
+          ('terrain', 0.085374), ('building', 0.204649),
+      ),
+      object_classes_exclusive=('fence', 'pole', 'tree'),
+      object_classes_independent=('traffic_sign', 'traffic_light', 'street_light'),
+      object_frequencies=(
+          ('fence', 0.006257), ('pole', 0.001172), ('tree', 0.001924),
+          ('traffic_sign', 0.000960), ('traffic_light', 0.000559),
+          ('street_light', 0.000738), ('void', 0.988391),
+      ),
+  ).lock()
+
+
 def bev_localizer() -> ConfigDict:
   return ConfigDict(
       bev_mapper=bev_mapper(),

@@ -1,7 +1,7 @@
 """Top-level register of models (``snap/models/__init__.py:25-40``).
 
-Only the localisation model is on the hot path; ``occupancy_net`` and
-``semantic_net`` of the reference are out of scope.
+The localisation model is the hot path; ``semantic_net`` reuses its
+BEV mapper; ``occupancy_net`` of the reference is out of scope.
 """
 import importlib
 
@@ -9,6 +9,7 @@ BASEPATH = 'snap_amd.models.{}'
 
 MODELS = {
     'bev_localizer': ('bev_localizer', 'BEVLocalizerModel'),
+    'semantic_net': ('semantic_net', 'SemanticNetModel'),
 }
 
 
@@ -19,5 +20,5 @@ def get_class(modulename, classname):
 def get_model(name):
   """Get a top-level model class by name."""
   if name not in MODELS:
-    raise KeyError(f'model {name!r} is not part of the localisation hot path')
+    raise KeyError(f'model {name!r} is not built (bev_localizer, semantic_net)')
   return get_class(*MODELS[name])

@@ -250,3 +250,47 @@ def test_localizer_parity_with_semantic_modality():
   helpers.assert_same_argmax('best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
                              got_index=pred['best_index'])
   assert 'semantic' not in pred['query']
+
+
+@pytest.mark.parametrize('decoder', ['mlp', 'resnet_stage'])
+def test_semantic_net_forward_parity(decoder):
+  """SemanticNet (semantic_net.py:123-199): BEV mapper + decoder -> logits, vs the oracle."""
+  from oracle import semantic_net as o_sem
+  from snap_amd import models
+  model_cls = models.get_model('semantic_net')
+  cfg = model_cls.default_flax_model_config()
+  cfg.bev_mapper = helpers.tiny_localizer_config(top_k=2).bev_mapper
+  cfg.decoder_type = decoder
+  cfg.decoder_dim = 128 if decoder == 'resnet_stage' else 64
+  cfg.resnet_num_units = 2
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  meta['semantic_classes_gt'] = ('crosswalk', 'sidewalk', 'road', 'terrain', 'building', 'fence',
+                                 'pole', 'tree', 'traffic_sign', 'traffic_light', 'street_light')
+  model = model_cls(cfg, meta)
+  net = model.flax_model
+  variables = net.init(5, device='cpu')
+  batch = synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=6)
+  dev = torch.device('cuda')
+  pred = net.apply({'params': helpers.params_to_device(variables['params'], dev)},
+                   helpers.batch_to_device(batch, dev), train=False)
+  ref = o_sem.semantic_net(helpers.params_to_numpy(variables['params']), cfg.to_dict(),
+                           o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch))
+  for k in ('logits_areas', 'logits_objects_exclusive', 'logits_objects_independent'):
+    helpers.report(f'{decoder} {k}', pred[k], ref[k], atol=1e-3)
+  assert pred['logits_areas'].shape[-1] == 5 and pred['logits_objects_exclusive'].shape[-1] == 4
+  # loss + gradients through the whole net (training path)
+  g = torch.Generator().manual_seed(7)
+  gt = torch.rand((2, *pred['logits_areas'].shape[1:3], len(meta['semantic_classes_gt'])), generator=g) < 0.3
+  data = helpers.batch_to_device(batch, dev)
+  data['map']['rasters']['gt_semantics'] = gt.to(dev)
+  from snap_amd import trainer
+  params = helpers.params_to_device(variables['params'], dev)
+  leaves = [t for _, t in trainer.flatten_params(params)]
+  for t in leaves:
+    t.requires_grad_(True)
+  with torch.enable_grad():
+    p2 = net.apply({'params': params}, data, train=True, rngs={'sampling': 3})
+    losses, metrics = model.loss_metrics_function(p2, data)
+    grads = torch.autograd.grad(losses['total'].mean(), leaves, allow_unused=True)
+  assert all(g_ is not None and bool(torch.isfinite(g_).all()) for g_ in grads)
+  assert 'semantics/accuracy' in metrics and float(losses['total'].mean()) > 0

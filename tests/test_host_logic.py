@@ -186,8 +186,9 @@ def test_model_registry_and_base_model_contract():
   cfg, meta, model = _tiny()
   assert isinstance(model.flax_model, bev_localizer.BEVLocalizer)
   assert model.default_flax_model_config().bev_mapper.matching_dim == 32
+  assert models.get_model('semantic_net').__name__ == 'SemanticNetModel'
   with pytest.raises(KeyError):
-    models.get_model('semantic_net')
+    models.get_model('occupancy_net')
 
 
 def test_param_tree_has_flax_layout():
@@ -292,3 +293,46 @@ def test_recover_dense_feature_plane(oracle_backend):
   dense = loc.recover_dense_feature_plane(sparse)
   assert dense.features.shape == (*loc.grid_query.extent, 3)
   assert int(dense.valid.sum()) == n
+
+
+def test_semantic_net_losses_match_the_oracle():
+  """SemanticNetModel.loss_metrics_function (host-side torch) vs the numpy restatement of
+  semantic_net.py:38-111,225-343 on random logits / masks (runs on the CPU: no kernels)."""
+  from oracle import semantic_net as o_sem
+  from snap_amd import models
+  from snap_amd.data import synthetic
+  from snap_amd.models import types
+  gt_classes = ('crosswalk', 'sidewalk', 'road', 'terrain', 'building', 'fence', 'pole', 'tree',
+                'traffic_sign', 'traffic_light', 'street_light', 'line', 'stopline')
+  map_classes = ('sidewalk', 'buildings_raw', 'tree', 'pavedroad')
+  model_cls = models.get_model('semantic_net')
+  cfg = model_cls.default_flax_model_config()
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  meta['semantic_classes_gt'] = gt_classes
+  meta['semantic_map_classes'] = None          # (no semantic INPUT modality in the default config)
+  model = model_cls(cfg, meta)
+  model.dataset_meta_data = dict(meta, semantic_map_classes=map_classes)
+  g = torch.Generator().manual_seed(0)
+  B, H, W = 3, 9, 7
+  pred = {
+      'bev_features': types.FeaturePlane(features=torch.zeros(B, H, W, 4),
+                                         valid=torch.rand((B, H, W), generator=g) > 0.2),
+      'logits_areas': torch.randn((B, H, W, 5), generator=g) * 2,
+      'logits_objects_exclusive': torch.randn((B, H, W, 4), generator=g) * 2,
+      'logits_objects_independent': torch.randn((B, H, W, 3), generator=g) * 2,
+  }
+  pred['bev_features'].valid[2] = False        # an empty mask: masked_mean must return 0, not NaN
+  rasters = {'gt_semantics': torch.rand((B, H, W, len(gt_classes)), generator=g) < 0.3,
+             'semantics': torch.rand((B, H, W, len(map_classes)), generator=g) < 0.5}
+  losses, metrics = model.loss_metrics_function(pred, {'map': {'rasters': rasters}})
+  opred = {k: (v.numpy() if k != 'bev_features' else {'valid': v.valid.numpy()}) for k, v in pred.items()}
+  olosses, ometrics = o_sem.loss_metrics(
+      opred, cfg.to_dict(), gt_classes, map_classes, {k: v.numpy() for k, v in rasters.items()})
+  assert set(losses) == set(olosses) and set(metrics) == set(ometrics)
+  for k in losses:
+    np.testing.assert_allclose(losses[k].numpy(), olosses[k], rtol=2e-5, atol=1e-6, err_msg=k)
+  for k in metrics:
+    np.testing.assert_allclose(metrics[k].numpy(), ometrics[k], rtol=2e-5, atol=1e-6, err_msg=k)
+  assert np.isfinite(losses['total'].numpy()).all() and float(losses['total'][2]) == 0.0
+  packed = model.pack_evaluation_metrics(metrics, losses, {'map': {'rasters': rasters}}, pred)
+  assert 'gt_counts/road' in packed and 'loss' in packed

@@ -306,3 +306,23 @@ def test_vit_oracle_against_independent_torch_implementations():
   from oracle import encoder as o_enc
   v = (rng.standard_normal(4096) * 3.3).astype(np.float32)
   np.testing.assert_array_equal(o_enc.bf16_round(v), torch.from_numpy(v).to(torch.bfloat16).float().numpy())
+
+
+def test_semantic_net_cross_entropies_against_torch():
+  """oracle/semantic_net.py's log-softmax / sigmoid cross-entropies == torch.nn.functional's
+  (the published definitions optax implements, semantic_net.py:65,98)."""
+  import torch
+  from oracle import semantic_net as o_sem
+  rng = np.random.default_rng(3)
+  logits = rng.standard_normal((2, 5, 4, 6)) * 3
+  labels = rng.integers(0, 6, (2, 5, 4))
+  valid = np.ones((2, 5, 4), bool)
+  nll, _ = o_sem.multiclass_crossentropy_metrics(logits, labels, valid, list('abcdef'), None)
+  ref = F.cross_entropy(torch.from_numpy(logits).reshape(-1, 6), torch.from_numpy(labels).reshape(-1),
+                        reduction='none').reshape(2, -1).mean(-1).numpy()
+  np.testing.assert_allclose(nll, ref, rtol=1e-12)
+  gt = rng.random((2, 5, 4, 6)) < 0.4
+  nll, _ = o_sem.binary_crossentropy_metrics(logits, gt, valid, list('abcdef'), None)
+  ref = F.binary_cross_entropy_with_logits(torch.from_numpy(logits), torch.from_numpy(gt).double(),
+                                           reduction='none').mean(-1).reshape(2, -1).mean(-1).numpy()
+  np.testing.assert_allclose(nll, ref, rtol=1e-12)
