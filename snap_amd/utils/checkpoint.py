@@ -102,3 +102,28 @@ def load_pretrained(template: Dict[str, Any], path, scope: Optional[str] = None,
       raise ValueError(f'No parameters for {scope} in {path}')
     params = sub
   return load_into(template, params, **kw)
+
+
+def load_bit_resnet(template: Dict[str, Any], path, **kw) -> Dict[str, Any]:
+  """BiT ResNet-v2 checkpoint (``.npz``) -> the encoder sub-tree, as ``ResNetV2.load_pretrained_
+  variables`` (``snap/models/resnet.py:223-233``) does through ``big_vision``'s ``load_params``.
+
+  ``big_vision`` is not part of the reference; what its loader does for these files is: read
+  the ``'a/b/c' -> array`` entries, rebuild the tree, and (for trainer checkpoints) unwrap a
+  ``params/`` or ``opt/target/`` prefix.  The BiT parameter tree IS the reference's
+  (``root_block/conv_root/kernel``, ``block{i}/unit{jj}/{conv1,conv2,conv3,conv_proj}/kernel``,
+  ``.../gn{1,2,3}/{scale,bias}`` with shape (1,1,1,C)), so leaves map 1:1.  The classification
+  head of the checkpoint (``norm-pre-head``, ``head``) has no counterpart and is dropped; a
+  leaf the encoder needs but the file lacks raises.  ``template`` = ``ResNetV2.init_params``."""
+  with np.load(path, allow_pickle=False) as z:
+    flat = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+  for prefix in ('opt/target/', 'params/'):
+    if flat and all(k.startswith(prefix) for k in flat):
+      flat = {k[len(prefix):]: v for k, v in flat.items()}
+  want = set(flatten(template))
+  dropped = sorted(k for k in flat if k not in want)
+  not_head = [k for k in dropped if k.split('/')[0] not in ('head', 'norm-pre-head')]
+  if not_head:
+    raise KeyError(f'unexpected (non-head) entries in {path}: {not_head[:5]}')
+  source = unflatten({k: v for k, v in flat.items() if k in want})
+  return load_into(template, source, strict=True, **kw)

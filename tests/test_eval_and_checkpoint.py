@@ -97,3 +97,36 @@ def test_checkpoint_npz_round_trip_of_the_model_tree(tmp_path):
   with pytest.raises(KeyError):
     checkpoint.load_into(other, fewer)
   assert torch.equal(checkpoint.load_into(other, fewer, strict=False)['temperature'], other['temperature'])
+
+
+def test_bit_resnet_npz_loads_into_the_encoder_tree(tmp_path):
+  """resnet.py:223-233: a BiT-style .npz (flat 'a/b/c' names, optional trainer prefix, a
+  classification head the encoder does not have) restores 1:1 into ResNetV2's tree."""
+  from snap_amd.configs import defaults
+  from snap_amd.models import resnet
+  cfg = defaults.resnet()
+  cfg.depth = [1, 1]
+  cfg.width = 0.5
+  cfg.limit_num_blocks = 2
+  enc = resnet.ResNetV2(cfg)
+  template = enc.init_params(torch.Generator().manual_seed(0), 'cpu')
+  src = enc.init_params(torch.Generator().manual_seed(1), 'cpu')
+  flat = {k: v.numpy() for k, v in checkpoint.flatten(src).items()}
+  flat['head/kernel'] = np.zeros((8, 10), np.float32)
+  flat['head/bias'] = np.zeros((10,), np.float32)
+  flat['norm-pre-head/scale'] = np.ones((1, 1, 1, 8), np.float32)
+  for prefix in ('', 'params/', 'opt/target/'):
+    path = tmp_path / f'bit{len(prefix)}.npz'
+    np.savez(path, **{prefix + k: v for k, v in flat.items()})
+    got = checkpoint.load_bit_resnet(template, path)
+    for (ka, a), (kb, b) in zip(checkpoint.flatten(got).items(), checkpoint.flatten(src).items()):
+      assert ka == kb and torch.equal(a, b)
+  bad = dict(flat)
+  del bad['block1/unit01/conv1/kernel']
+  np.savez(tmp_path / 'bad.npz', **bad)
+  with pytest.raises(KeyError):
+    checkpoint.load_bit_resnet(template, tmp_path / 'bad.npz')
+  bad = dict(flat, **{'block9/unit01/conv1/kernel': np.zeros((1, 1, 4, 4), np.float32)})
+  np.savez(tmp_path / 'bad2.npz', **bad)
+  with pytest.raises(KeyError):
+    checkpoint.load_bit_resnet(template, tmp_path / 'bad2.npz')
