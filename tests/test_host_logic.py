@@ -336,3 +336,50 @@ def test_semantic_net_losses_match_the_oracle():
   assert np.isfinite(losses['total'].numpy()).all() and float(losses['total'][2]) == 0.0
   packed = model.pack_evaluation_metrics(metrics, losses, {'map': {'rasters': rasters}}, pred)
   assert 'gt_counts/road' in packed and 'loss' in packed
+
+
+def test_reference_batch_adapter():
+  """snap_amd.data.adapter: a batch in the reference's loader schema (numpy leaves, struct
+  objects or field dicts, optional pmap axis) becomes the batch the models consume."""
+  import types as pytypes
+  from snap_amd.data import adapter
+  from snap_amd.data import synthetic
+  from snap_amd.utils import geometry
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  ours = synthetic.make_batch(4, meta['grid'], 3, (32, 32), seed=0)
+
+  def np_struct(s, as_object):
+    fields = {f: getattr(s, f).numpy() for f in s._fields}
+    return pytypes.SimpleNamespace(**fields) if as_object else fields
+
+  def ref_scene(scene, as_object):
+    return {'images': scene['images'].numpy(), 'camera': np_struct(scene['camera'], as_object),
+            'T_view2scene': np_struct(scene['T_view2scene'], as_object),
+            **({'rasters': {k: v.numpy() for k, v in scene['rasters'].items()}} if 'rasters' in scene else {}),
+            'scene_id': ['a', 'b', 'c', 'd']}
+
+  for as_object in (True, False):
+    ref = {'map': ref_scene(ours['map'], as_object), 'query': ref_scene(ours['query'], as_object),
+           'T_query2map': np_struct(ours['T_query2map'], as_object),
+           'batch_mask': np.array([1, 1, 1, 0], bool), 'pair_id': np.arange(4)}
+    got = adapter.from_reference_batch(ref)
+    assert isinstance(got['map']['camera'], geometry.FisheyeCamera)
+    assert torch.equal(got['map']['images'], ours['map']['images'])
+    assert torch.equal(got['map']['camera'].k_radial, ours['map']['camera'].k_radial)
+    assert torch.equal(got['query']['T_view2scene'].R, ours['query']['T_view2scene'].R)
+    assert torch.equal(got['T_query2map'].t, ours['T_query2map'].t)
+    assert got['batch_mask'].tolist() == [True, True, True, False]
+    assert got['map']['scene_id'] == ['a', 'b', 'c', 'd'] and 'pair_id' in got
+  # pmap layout [D, B/D, ...]
+  def split(x):
+    return x.reshape(2, 2, *x.shape[1:])
+  refp = {'query': {'images': split(ours['query']['images'].numpy()),
+                    'camera': {f: split(getattr(ours['query']['camera'], f).numpy())
+                               for f in ours['query']['camera']._fields},
+                    'T_view2scene': {'R': split(ours['query']['T_view2scene'].R.numpy()),
+                                     't': split(ours['query']['T_view2scene'].t.numpy())}}}
+  merged = adapter.from_reference_batch(refp, device_axis='merge')
+  assert torch.equal(merged['query']['images'], ours['query']['images'])
+  shard1 = adapter.from_reference_batch(refp, device_axis=1)
+  assert torch.equal(shard1['query']['images'], ours['query']['images'][2:])
+  assert shard1['batch_mask'].shape == (2,)
