@@ -148,6 +148,23 @@ def test_conv_bf16_every_tile_variant(tile, monkeypatch):
   helpers.report(f'conv bf16 upsample-add tile {tile}', got, want, atol=5e-5, rtol=1e-5)
 
 
+def test_conv_bf16_degenerate_shapes():
+  """One output pixel, one image row, K smaller than a slab, Cout = 4, an all-masked row list."""
+  for (N, H, W, Cin, k, Cout, pad) in [(1, 1, 1, 8, 1, 4, 0), (1, 1, 5, 4, 1, 8, 0), (1, 3, 3, 12, 3, 4, 1)]:
+    x = rnd((N, H, W, Cin), 60 + Cin)
+    w = rnd((k, k, Cin, Cout), 61, 1 / np.sqrt(k * k * Cin))
+    got, want = both('conv2d', (x, w), dict(padding=((pad, pad), (pad, pad)), math='bf16'))
+    helpers.report(f'conv bf16 tiny {N}x{H}x{W}x{Cin}', got, want, atol=3e-5, rtol=1e-5)
+  M = 70000
+  x = rnd((M, 64), 62)
+  w = rnd((64, 32), 63, 1 / 8.0)
+  mask = torch.zeros(M, dtype=torch.bool)
+  index, count = ops.compact_rows(mask.to(DEV))
+  out = torch.full((M, 32), 7.0, device=DEV)
+  ops.dense(x.to(DEV), w.to(DEV), rows_in=index, rows_out=index, row_count=count, out=out, math='bf16')
+  assert int(count.item()) == 0 and float(out.min()) == 7.0      # nothing written
+
+
 def test_conv_bf16_rows_gnstats_splitk():
   """Row-indexed launches, GroupNorm partial sums and split-K on the bf16 engine."""
   g = torch.Generator().manual_seed(50)
@@ -822,7 +839,7 @@ def test_lift_with_nothing_visible():
 # ViT encoder pieces (BASELINE.json configs[4]; no reference implementation exists, the oracle
 # is the published architecture in float64 -- oracle/vit.py)
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize('M,C', [(37, 768), (5, 192), (130, 1024), (9, 64)])
+@pytest.mark.parametrize('M,C', [(37, 768), (5, 192), (130, 1024), (9, 64), (1, 4)])
 def test_layer_norm(M, C):
   x = rnd((M, C), 201) * 1.7 + 0.3
   gamma, beta = rnd((C,), 202) * 0.3 + 1, rnd((C,), 203) * 0.2
@@ -843,7 +860,7 @@ def test_dense_gelu_and_residual_epilogues():
   helpers.report('dense + gelu bf16', got, want, atol=5e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize('B,N,H', [(2, 200, 3), (1, 1024, 2), (3, 64, 1), (1, 129, 12)])
+@pytest.mark.parametrize('B,N,H', [(2, 200, 3), (1, 1024, 2), (3, 64, 1), (1, 129, 12), (2, 1, 1), (1, 7, 2)])
 def test_attention(B, N, H):
   """softmax(q k^T / 8) v on the bf16 matrix cores vs float64 on the bf16-rounded operands.
   Tolerance: 4e-3 of the value range (the kernel also rounds its probabilities to bf16,
