@@ -140,6 +140,8 @@ class ResNetV2(base.Module):
       pre = dict(getattr(ctx, 'pre_std', None) or {})
       pre.update({id(k): s for k, s in zip(kernels, ag.weight_standardize_multi(kernels))})
       ctx.pre_std = pre
+    else:   # inference: one launch for all StdConv kernels of this encoder
+      ctx.standardize_all(kernels, ops.weight_standardize_multi)
     # `image * 2 - 1` (resnet.py:199) is fused into the root conv's operand staging.
     if self.config.skip_root_block:
       w = _std(ctx, params['conv_root']['kernel'])

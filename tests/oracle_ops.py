@@ -120,6 +120,10 @@ def weight_standardize(w, eps=1e-10):
   return _t(o_enc.standardize(_np(w, DTYPE), (0, 1, 2), eps), w)
 
 
+def weight_standardize_multi(ws, eps=1e-10):
+  return [weight_standardize(w, eps) for w in ws]
+
+
 def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False):
   xn = _np(x, DTYPE)
   if relu_first:
@@ -371,7 +375,7 @@ def template_finalize(raw, cnt, tcount, R, threshold, use_overlap=True):
 
 
 ALL_OPS = [
-    'conv2d', 'dense', 'weight_standardize', 'group_norm_stats', 'group_norm_apply',
+    'conv2d', 'dense', 'weight_standardize', 'weight_standardize_multi', 'group_norm_stats', 'group_norm_apply',
     'max_pool_3x3s2', 'pooled_stride', 'lift_pool', 'project_points', 'vertical_pool',
     'plane_fuse_match', 'sim_softmax', 'ransac_sample', 'poses_from_corr', 'pose_score',
     'refine_lattice', 'argmax_rows', 'rotate_templates', 'pad_map', 'template_finalize',
