@@ -388,6 +388,10 @@ int snap_rotate_templates_f32(const float* feat, const uint8_t* valid,
  * instead of R = 36 columns. */
 int snap_stack_templates_f32(const float* tw, float* tws, int32_t H, int32_t W, int32_t D,
                              int32_t R, int32_t S, void* stream);
+/* The same bank from the [R, H, W, D] template tensor of snap_rotate_templates_f32 (whose `tw`
+ * output may then be NULL: the r-fastest HWIO copy is only needed by the unstacked path). */
+int snap_stack_templates_rhwd_f32(const float* templates, float* tws, int32_t H, int32_t W,
+                                  int32_t D, int32_t R, int32_t S, void* stream);
 int snap_pad_map_f32(const float* map, const uint8_t* mvalid, int32_t H, int32_t W,
                      int32_t D, float* map_pad, float* mvalid_pad, void* stream);
 

@@ -72,6 +72,7 @@ SIGNATURES = {
         c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, ptr, c_int, ptr, ptr]),
     'snap_semantic_onehot_f32': (c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, c_int, ptr]),
     'snap_stack_templates_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
+    'snap_stack_templates_rhwd_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
     'snap_layer_norm_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_attention_bf16_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_attention_lse_bf16_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),

@@ -65,15 +65,32 @@ __global__ void rotate_templates_kernel(const float* __restrict__ feat,
     else { di = H - 1 - sj; dj = si; }
     const int rr = k * RQ + r0;
     *reinterpret_cast<f32x4*>(templates + (((int64_t)rr * H + di) * W + dj) * D + 4 * q) = o;
+    if (tw) {     // HWIO filter bank of the plain path (r fastest: 4-byte scattered stores)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      tw[(((int64_t)di * W + dj) * D + 4 * q + e) * Rp + rr] = o[e];
+      for (int e = 0; e < 4; ++e)
+        tw[(((int64_t)di * W + dj) * D + 4 * q + e) * Rp + rr] = o[e];
+    }
     if (q == 0) {
       tvalid[((int64_t)rr * H + di) * W + dj] = ok ? 1 : 0;
       // count filter = 180-degree rotated mask (un-flipped true convolution).
       cw[((int64_t)(H - 1 - di) * W + (W - 1 - dj)) * Rp + rr] = ok ? 1.f : 0.f;
-      if (ok) atomicAdd(tcount + rr, 1.f);  // integer-valued: order independent
     }
+  }
+  // tcount[r] = number of valid cells of template r (integer-valued: order independent).  One
+  // atomic per WAVE and quadrant instead of one per cell: 36 addresses took 2 M serialised
+  // atomics at 256^2 (9 ms).  r0 is wave-uniform except where a wave straddles two rotations.
+  const bool mine = (q == 0) && ok;
+  const int r0_first = __builtin_amdgcn_readfirstlane(r0);
+  const bool uniform = __all(r0 == r0_first);
+  if (uniform) {
+    const int n = __popcll(__ballot(mine));
+    if ((threadIdx.x & 63) == 0 && n > 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(tcount + k * RQ + r0_first, (float)n);
+    }
+  } else if (mine) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(tcount + k * RQ + r0, 1.f);
   }
 }
 
@@ -121,7 +138,7 @@ extern "C" int snap_rotate_templates_f32(const float* feat, const uint8_t* valid
                                          int32_t R, float cell_size, float* templates,
                                          uint8_t* tvalid, float* tw, float* cw, float* tcount,
                                          void* stream) {
-  if (!feat || !valid || !tfm || !templates || !tvalid || !tw || !cw || !tcount)
+  if (!feat || !valid || !tfm || !templates || !tvalid || !cw || !tcount)   // (tw may be NULL)
     return SNAP_ERR_NULL;
   if (H <= 0 || H != W || D <= 0 || D % 4 != 0 || R <= 0 || R % 4 != 0) return SNAP_ERR_BAD_SHAPE;
   const int Rp = R;  // R % 4 == 0 already
@@ -154,6 +171,38 @@ __global__ __launch_bounds__(256) void stack_templates_kernel(
   const int ii = ip - sa, jj = jp - sb;
   tws[i] = (ii >= 0 && ii < H && jj >= 0 && jj < W)
                ? tw[(((int64_t)ii * W + jj) * D + d) * R + r] : 0.f;
+}
+
+// the same from the [R, H, W, D] template tensor (what rotate_templates writes coalesced), so
+// the large-map path never materialises the r-fastest HWIO bank
+__global__ __launch_bounds__(256) void stack_templates_rhwd_kernel(
+    const float* __restrict__ templates, float* __restrict__ tws, int H, int W, int D, int R, int S) {
+  const int RS = R * S * S;
+  const int64_t total = (int64_t)(H + S - 1) * (W + S - 1) * D * RS;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i % RS);
+  int64_t t = i / RS;
+  const int d = (int)(t % D); t /= D;
+  const int jp = (int)(t % (W + S - 1));
+  const int ip = (int)(t / (W + S - 1));
+  const int sb = n % S, sa = (n / S) % S, r = n / (S * S);
+  const int ii = ip - sa, jj = jp - sb;
+  tws[i] = (ii >= 0 && ii < H && jj >= 0 && jj < W)
+               ? templates[(((int64_t)r * H + ii) * W + jj) * D + d] : 0.f;
+}
+
+extern "C" int snap_stack_templates_rhwd_f32(const float* templates, float* tws, int32_t H,
+                                             int32_t W, int32_t D, int32_t R, int32_t S,
+                                             void* stream) {
+  if (!templates || !tws) return SNAP_ERR_NULL;
+  if (H <= 0 || W <= 0 || D <= 0 || R <= 0 || S < 1 || S > 8) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)(H + S - 1) * (W + S - 1) * D * R * S * S;
+  if (snap_cdiv(total, 256) > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(stack_templates_rhwd_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), templates, tws, H, W, D, R, S);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
 }
 
 extern "C" int snap_stack_templates_f32(const float* tw, float* tws, int32_t H, int32_t W,

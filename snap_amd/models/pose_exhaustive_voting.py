@@ -42,9 +42,11 @@ def sample_query_templates(features, valid, num_rotations, grid, _engine=False):
   if features.shape[0] != features.shape[1]:
     raise ValueError('the rot90 completion requires a square BEV')
   tfm = _template_transforms(num_rotations, grid, features.device)
+  H, W = features.shape[:2]
   out = ops.rotate_templates(
       features.contiguous(), valid.contiguous(), tfm[: num_rotations // 4].contiguous(),
       num_rotations, grid.cell_size,
+      want_tw=_engine and not _stacked(num_rotations, (H, W)),   # (the stacked path reads `templates`)
   )
   if _engine:
     return out
@@ -59,13 +61,21 @@ STACK_SHIFT = 4
 STACK_MIN_CELLS = 64 * 64      # below this the plain form is already launch-bound
 
 
-def _correlate(mp, tw, R, q_hw):
+def _stacked(R, q_hw):
+  S = STACK_SHIFT
+  return S > 1 and q_hw[0] * q_hw[1] >= STACK_MIN_CELLS and (R * S * S) % 4 == 0
+
+
+def _correlate(mp, tw, R, q_hw, templates=None):
+  """``tw`` [H,W,D,R] and / or ``templates`` [R,H,W,D]: the same filter bank in two layouts."""
   H, W = q_hw
   S = STACK_SHIFT
   Ho, Wo = mp.shape[0] - H + 1, mp.shape[1] - W + 1
-  if S <= 1 or H * W < STACK_MIN_CELLS or (R * S * S) % 4:
+  if not _stacked(R, q_hw):
+    if tw is None:
+      tw = templates.permute(1, 2, 3, 0).contiguous()
     return ops.conv2d(mp[None], tw)[0]                  # [Ho, Wo, R]
-  tws = ops.stack_templates(tw, S)
+  tws = ops.stack_templates(templates, S, 'rhwd') if templates is not None else ops.stack_templates(tw, S)
   A4, B4 = -(-Ho // S), -(-Wo // S)
   pb = max(0, S * (A4 - 1) + (H + S - 1) - mp.shape[0])  # zero rows only cropped outputs can see
   pr = max(0, S * (B4 - 1) + (W + S - 1) - mp.shape[1])
@@ -75,10 +85,10 @@ def _correlate(mp, tw, R, q_hw):
   return raw[:Ho, :Wo].contiguous()
 
 
-def _match(tw, cw, tcount, R, q_hw, m, m_valid, min_overlap):
+def _match(tw, cw, tcount, R, q_hw, m, m_valid, min_overlap, templates=None):
   H, W = q_hw
   mp, mvp = ops.pad_map(m.contiguous(), m_valid.contiguous())
-  raw = _correlate(mp, tw, R, q_hw)                     # [Ho, Wo, R]
+  raw = _correlate(mp, tw, R, q_hw, templates)          # [Ho, Wo, R]
   cnt = None
   if min_overlap is not None:
     cnt = ops.conv2d(mvp[None, :, :, None].contiguous(), cw)[0]
@@ -91,10 +101,9 @@ def template_matching(q, q_valid, m, m_valid, do_padding=True, min_overlap=0.05)
   if not do_padding:
     raise NotImplementedError('do_padding=False')
   R, H, W, D = q.shape
-  tw = q.permute(1, 2, 3, 0).contiguous()
   cw = q_valid.flip(1, 2).permute(1, 2, 0).to(torch.float32)[:, :, None, :].contiguous()
   tcount = q_valid.sum((-1, -2)).to(torch.float32)
-  return _match(tw, cw, tcount, R, (H, W), m, m_valid, min_overlap)
+  return _match(None, cw, tcount, R, (H, W), m, m_valid, min_overlap, templates=q.contiguous())
 
 
 def exhaustive_pose_voting(plane_q, plane_map, num_rotations, grid, conf_q=None):
@@ -102,11 +111,12 @@ def exhaustive_pose_voting(plane_q, plane_map, num_rotations, grid, conf_q=None)
   feats_q = plane_q.features
   if conf_q is not None:
     feats_q = feats_q * conf_q[..., None]
-  _, _, tw, cw, tcount = sample_query_templates(
+  templates, _, tw, cw, tcount = sample_query_templates(
       feats_q, plane_q.valid, num_rotations, grid, _engine=True
   )
   H, W = feats_q.shape[:2]
-  return _match(tw, cw, tcount, num_rotations, (H, W), plane_map.features, plane_map.valid, 0.05)
+  return _match(tw, cw, tcount, num_rotations, (H, W), plane_map.features, plane_map.valid, 0.05,
+                templates=templates)
 
 
 def exhaustive_index_to_tfm(index, grid, num_rotations):

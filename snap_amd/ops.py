@@ -332,14 +332,20 @@ def semantic_onehot(rasters, idx_road, idx_other):
   return onehot
 
 
-def stack_templates(tw, S):
-  """tw [H, W, D, R] -> shift-stacked filter bank [H+S-1, W+S-1, D, R*S*S] (see snap_hip.h)."""
+def stack_templates(tw, S, layout='hwdr'):
+  """tw [H, W, D, R] (layout 'hwdr') or templates [R, H, W, D] ('rhwd') -> shift-stacked filter
+  bank [H+S-1, W+S-1, D, R*S*S] (see snap_hip.h)."""
   lib = _lib.load()
   _f32(tw, 'tw')
-  H, W, D, R = tw.shape
+  if layout == 'hwdr':
+    H, W, D, R = tw.shape
+    fn, name = lib.snap_stack_templates_f32, 'snap_stack_templates_f32'
+  else:
+    R, H, W, D = tw.shape
+    fn, name = lib.snap_stack_templates_rhwd_f32, 'snap_stack_templates_rhwd_f32'
   tws = torch.empty((H + S - 1, W + S - 1, D, R * S * S), dtype=torch.float32, device=tw.device)
-  st = lib.snap_stack_templates_f32(_p(tw), _p(tws), H, W, D, R, S, _stream())
-  _lib.check(st, 'snap_stack_templates_f32')
+  st = fn(_p(tw), _p(tws), H, W, D, R, S, _stream())
+  _lib.check(st, name)
   return tws
 
 
@@ -787,9 +793,9 @@ def argmax_rows(scores, start=0):
 # ----------------------------------------------------------------------------
 # exhaustive voting
 # ----------------------------------------------------------------------------
-def rotate_templates(feat, valid, tfm, num_rotations, cell_size):
+def rotate_templates(feat, valid, tfm, num_rotations, cell_size, want_tw=True):
   """feat [H,W,D], valid [H,W], tfm [R/4,4] -> templates [R,H,W,D], tvalid [R,H,W],
-  tw [H,W,D,R], cw [H,W,1,R], tcount [R]."""
+  tw [H,W,D,R] (None unless want_tw), cw [H,W,1,R], tcount [R]."""
   lib = _lib.load()
   _f32(feat, 'feat'); _mask(valid, 'valid'); _f32(tfm, 'tfm')
   H, W, D = feat.shape
@@ -797,7 +803,7 @@ def rotate_templates(feat, valid, tfm, num_rotations, cell_size):
   dev = feat.device
   templates = torch.empty((R, H, W, D), dtype=torch.float32, device=dev)
   tvalid = torch.empty((R, H, W), dtype=torch.bool, device=dev)
-  tw = torch.empty((H, W, D, R), dtype=torch.float32, device=dev)
+  tw = torch.empty((H, W, D, R), dtype=torch.float32, device=dev) if want_tw else None
   cw = torch.empty((H, W, 1, R), dtype=torch.float32, device=dev)
   tcount = torch.empty((R,), dtype=torch.float32, device=dev)
   st = lib.snap_rotate_templates_f32(
