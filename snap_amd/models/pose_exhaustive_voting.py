@@ -85,13 +85,38 @@ def _correlate(mp, tw, R, q_hw, templates=None):
   return raw[:Ho, :Wo].contiguous()
 
 
+def _overlap_count(mvp, cw, R, q_hw):
+  """cnt[a, b, r] = sum_ij cw[i, j, r] * mvp[a+i, b+j]  (pose_exhaustive_voting.py:93-101).
+
+  Plain form: a 1-channel correlation on the f32 engine's scalar path.  Large maps with
+  W % 32 == 0: the template columns are folded into 32 input channels (j = 32 t + c) and the
+  output columns into 32 images (b = 32 bq + br), X[br][row, col, c] = mvp[row, 32 col + br + c],
+  which makes it a KH x (W/32) conv with Cin = 32 -- run on the bf16 engine.  EXACT: both
+  operands are 0 / 1 (exact in bf16), every product is 0 / 1 and the f32 accumulator counts at
+  most H W < 2^24 of them, so the result is the same integers."""
+  H, W = q_hw
+  if not _stacked(R, q_hw) or W % 32:
+    return ops.conv2d(mvp[None, :, :, None].contiguous(), cw)[0]
+  Hp, Wp = mvp.shape
+  Ho, Wo = Hp - H + 1, Wp - W + 1
+  nbq = -(-Wo // 32)                       # output column groups
+  ncol = nbq + W // 32 - 1                 # decimated columns a group can touch
+  need = 32 * (ncol - 1) + 31 + 31 + 1     # widest index + 1
+  mv = torch.nn.functional.pad(mvp, (0, max(0, need - Wp)))
+  win = mv.unfold(1, 32, 1)[:, :32 * ncol]                       # win[row, s, c] = mv[row, s + c]
+  X = win.reshape(Hp, ncol, 32, 32).permute(2, 0, 1, 3).contiguous()   # [br, row, col, c]
+  wq = cw.reshape(H, W // 32, 32, R)                               # [i, t, c, r], j = 32 t + c
+  out = ops.conv2d(X, wq, math='bf16')                             # [32, Ho, nbq, R]
+  return out.permute(1, 2, 0, 3).reshape(Ho, nbq * 32, R)[:, :Wo].contiguous()
+
+
 def _match(tw, cw, tcount, R, q_hw, m, m_valid, min_overlap, templates=None):
   H, W = q_hw
   mp, mvp = ops.pad_map(m.contiguous(), m_valid.contiguous())
   raw = _correlate(mp, tw, R, q_hw, templates)          # [Ho, Wo, R]
   cnt = None
   if min_overlap is not None:
-    cnt = ops.conv2d(mvp[None, :, :, None].contiguous(), cw)[0]
+    cnt = _overlap_count(mvp, cw, R, q_hw)
   thr = 0.0 if min_overlap is None else min_overlap * H * W
   return ops.template_finalize(raw, cnt, tcount, R, thr, use_overlap=min_overlap is not None)
 

@@ -582,6 +582,25 @@ def test_template_matching_shift_stacked(H, R, D, S, monkeypatch):
   helpers.report(f'stacked S={S} vs plain', stacked, plain, atol=2e-5, rtol=1e-6)
 
 
+def test_overlap_count_on_the_bf16_engine_is_exact(monkeypatch):
+  """The 0/1 overlap-count correlation folded onto the bf16 engine (W % 32 == 0 maps) returns the
+  same integers as the f32 scalar path -- bit for bit."""
+  from snap_amd.models import pose_exhaustive_voting as pev
+  H = W = 64
+  R = 8
+  g = torch.Generator().manual_seed(150)
+  cw = (torch.rand((H, W, 1, R), generator=g) < 0.8).float().to(DEV)
+  mv = (torch.rand((H, W), generator=g) < 0.9)
+  mp, mvp = ops.pad_map(torch.zeros((H, W, 4), device=DEV), mv.to(DEV))
+  monkeypatch.setattr(pev, 'STACK_MIN_CELLS', 1 << 30)
+  plain = pev._overlap_count(mvp, cw, R, (H, W))
+  monkeypatch.setattr(pev, 'STACK_MIN_CELLS', 0)
+  folded = pev._overlap_count(mvp, cw, R, (H, W))
+  assert plain.shape == folded.shape == (2 * H - 1, 2 * W - 1, R)
+  assert torch.equal(plain, folded)
+  assert float(plain.max()) > 1000          # real counts, not zeros
+
+
 def test_exhaustive_identity_kat():
   """Known answer: matching a map with itself peaks at (0, H-1, W-1)."""
   from snap_amd.models import pose_exhaustive_voting as pev
