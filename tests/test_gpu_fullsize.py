@@ -176,6 +176,39 @@ def test_c2_forward_is_deterministic_and_sane():
   assert not torch.equal(p1['map_t_query_samples'].t[:, 1:], p3['map_t_query_samples'].t[:, 1:])
 
 
+def test_reference_default_shapes_forward():
+  """The reference's own default scene (SURVEY REF): 120 x 160 x 60 voxels (24 x 32 x 12 m at
+  0.2 m -- a NON-square map), V = 20 views -> top-K = 4 view selection, 4652 frustum points,
+  10 001 pose hypotheses x 8 retries; eval config adds the 41^3 refinement lattice."""
+  from snap_amd.configs import eval_localization
+  cfg = train_localization.get_config().model
+  meta = synthetic.meta_data(0.2, (24, 32, 12))
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
+  variables = loc.init(0, device=DEV)
+  batch = synthetic.make_batch(1, meta['grid'], 20, (256, 256), seed=11, device=DEV)
+  p1 = loc.apply(variables, batch, rngs={'sampling': 3})
+  assert p1['scores_poses'].shape == (1, 10001) and bool(torch.isfinite(p1['scores_poses']).all())
+  vol = p1['map']['streetview']['feature_volume']
+  assert vol.features.shape == (1, 120, 160, 60, 128)
+  assert 0.05 < float(vol.valid.float().mean()) < 1.0
+  assert float(vol.features[~vol.valid].abs().max()) == 0.0
+  assert p1['query']['bev_matching'].features.shape[1] == 4652
+  p2 = loc.apply(variables, batch, rngs={'sampling': 3})
+  assert torch.equal(p1['scores_poses'], p2['scores_poses'])
+  # eval config: more hypotheses + grid refinement around the best pose
+  import copy
+  ecfg = copy.deepcopy(cfg)
+  ecfg.update(eval_localization.get_config().model)      # (the eval config overrides the train model config)
+  assert ecfg.num_pose_samples == 20_000 and ecfg.do_grid_refinement
+  eloc = bev_localizer.BEVLocalizer(ecfg, meta['build_config'].scene_config, meta['grid'].bev())
+  pe = eloc.apply(variables, batch, rngs={'sampling': 3})
+  assert pe['scores_grid_refine'].shape == (1, 41, 41, 41)
+  assert bool(torch.isfinite(pe['map_t_query'].t).all())
+  # refinement can only improve on the RANSAC winner's score (the lattice contains offset 0)
+  best_ransac = pe['scores_poses'][:, 1:].max(dim=1).values
+  assert bool((pe['scores_grid_refine'].reshape(1, -1).max(dim=1).values >= best_ransac - 1e-4).all())
+
+
 def test_bf16_engines_full_size_properties():
   """bf16-operand conv / wgrad engines at the fusion-MLP size of the C3 step (1 M voxel rows,
   K = 257 of a 260-wide row, N = 256): scaling the input by a power of two commutes with the
