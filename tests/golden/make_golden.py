@@ -118,6 +118,28 @@ def main():
   scores = o_voting.template_matching(templates, tvalid, m, mvv)
   save('voting', q=q, q_valid=qv, m=m, m_valid=mvv, templates=templates, tvalid=tvalid, scores=scores)
 
+  # (xi) later additions: bf16-operand conv (rounded-operand restatement), ViT pieces, semantic embed.
+  xb = t(f32(2, 6, 5, 40) + 0.2)
+  wb = t(f32(3, 3, 40, 24) / 19)
+  gam, bet = t(f32(40) * 0.3 + 1), t(f32(40) * 0.1)
+  mub, scb = oracle_ops.group_norm_stats(xb, gam, groups=8)
+  yb = oracle_ops.conv2d(xb, wb, padding=((1, 1), (1, 1)), prologue=2, gn=(mub, scb, bet), math='bf16')
+  xd = t(f32(50, 36)); wd = t(f32(33, 16) / 6); bd = t(f32(16))
+  yd = oracle_ops.dense(xd, wd, bd, cin=33, gelu=True, math='bf16')
+  save('bf16', x=xb, w=wb, beta=bet, mu=mub, sc=scb, y=yb, xd=xd, wd=wd, bd=bd, yd=yd)
+
+  xl = t(f32(11, 192) * 1.4 + 0.3)
+  gl, bl = t(f32(192) * 0.3 + 1), t(f32(192) * 0.2)
+  yl = oracle_ops.layer_norm(xl, gl, bl)
+  qkv = t(f32(2, 70, 3, 2, 64))
+  att = oracle_ops.attention(qkv)
+  save('vit', x=xl, gamma=gl, beta=bl, y=yl, qkv=qkv, att=att)
+
+  ras = t(rng.random((2, 6, 5, 7)) < 0.4)
+  t_road, t_other = t(f32(3, 8)), t(f32(8, 8))
+  emb = oracle_ops.semantic_embed(ras, [0, 2, 5], [1, 3, 4, 6], t_road, t_other)
+  save('semantic', rasters=ras, table_road=t_road, table_other=t_other, out=emb)
+
 
 if __name__ == '__main__':
   main()

@@ -108,6 +108,16 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False, row_
   return y.reshape(*lead, kernel.shape[1])
 
 
+def semantic_embed(rasters, idx_road, idx_other, table_road, table_other):
+  r = _np(rasters).astype(bool)
+  tr, to = _np(table_road, DTYPE), _np(table_other, DTYPE)
+  label = np.argmax(r[..., list(idx_road)], axis=-1)
+  f_road = tr[label]
+  lab_o = np.arange(len(idx_other)) + r[..., list(idx_other)].astype(int)
+  f_other = to[lab_o].reshape(*r.shape[:-1], -1)
+  return _t(np.concatenate([f_road, f_other], -1), table_road)
+
+
 def layer_norm(x, gamma, beta, eps=1e-6):
   return _t(o_vit.layer_norm(_np(x, DTYPE), _np(gamma, DTYPE), _np(beta, DTYPE), eps), x)
 
