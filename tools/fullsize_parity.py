@@ -1,0 +1,101 @@
+"""One FULL-SIZE scene of the headline workload (C2: 4 views @512 px + aerial, 128x128x60 voxels,
+ResNet-50 encoders, 10 001 pose hypotheses x 8 retries) through the HIP path and through the
+numpy oracle on the host cores; prints one JSON line with the deviations and the argmax check.
+
+  python tools/fullsize_parity.py [--out profiles/r01_c2_fullsize_parity.json]
+
+The oracle needs minutes of CPU time at this size, which is why the pytest suites compare at
+reduced sizes and check the full size through properties; this is the direct comparison, run
+once per round on the GPU box (the pose samples drawn by the HIP sampler are injected into
+the oracle: JAX's / numpy's RNG streams cannot match Philox).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import helpers  # noqa: E402
+from oracle import geometry as o_geo  # noqa: E402
+from oracle import grids as o_grids  # noqa: E402
+from oracle import model as o_model  # noqa: E402
+from snap_amd.configs import train_localization  # noqa: E402
+from snap_amd.data import synthetic  # noqa: E402
+from snap_amd.models import bev_localizer  # noqa: E402
+
+
+def rel(got, want):
+  got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+  return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--out', default=None)
+  ap.add_argument('--views', type=int, default=4)
+  ap.add_argument('--image', type=int, default=512)
+  args = ap.parse_args()
+  dev = torch.device('cuda')
+  cfg = train_localization.get_config().model
+  meta = synthetic.meta_data(0.2, (25.6, 25.6, 12))
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
+  variables = loc.init(0, device='cpu')
+  batch = synthetic.make_batch(1, meta['grid'], args.views, (args.image, args.image), seed=21)
+  t0 = time.perf_counter()
+  pred = loc.apply({'params': helpers.params_to_device(variables['params'], dev)},
+                   helpers.batch_to_device(batch, dev), train=False, rngs={'sampling': 11}, debug=True)
+  torch.cuda.synchronize()
+  t_hip = time.perf_counter() - t0
+  samples = pred['map_t_query_samples']
+  ps = o_geo.Transform2D(samples.angle[:, 1:].cpu().numpy(), samples.t[:, 1:].cpu().numpy())
+  t0 = time.perf_counter()
+  ref = o_model.bev_localizer(
+      helpers.params_to_numpy(variables['params']), cfg, {'streetview_hfov_deg': 72.0},
+      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch),
+      pose_samples=ps, keep_sim=False)
+  t_cpu = time.perf_counter() - t0
+  sv, rsv = pred['map']['streetview'], ref['map']['streetview']
+  vg = sv['feature_volume'].valid.cpu().numpy()
+  vw = rsv['feature_volume']['valid']
+  mism = vg != vw
+  scores_g = pred['scores_poses'].cpu().numpy()
+  scores_w = ref['scores_poses']
+  gi, wi = int(np.argmax(scores_g[0, 1:])), int(np.argmax(scores_w[0, 1:]))
+  out = {
+      'workload': f'one C2 scene: {args.views} views @{args.image}px + aerial, 128x128x60 voxels, R50, '
+                  f'{scores_g.shape[1] - 1} pose hypotheses',
+      'image_features_rel_err': rel(sv['image_feature_pyramid'].features[-1],
+                                    rsv['image_feature_pyramid']['features'][-1]),
+      'voxel_validity_mismatch_fraction': float(mism.mean()),
+      'feature_volume_rel_err': rel(sv['feature_volume'].features.cpu().numpy()[~mism],
+                                    rsv['feature_volume']['features'][~mism]),
+      'aerial_plane_rel_err': rel(pred['map']['aerial']['feature_plane'].features,
+                                  ref['map']['aerial']['feature_plane']['features']),
+      'map_bev_matching_max_abs_err': float(np.abs(pred['map']['bev_matching'].features.cpu().numpy()
+                                                   - ref['map']['bev_matching']['features']).max()),
+      'query_bev_matching_max_abs_err': float(np.abs(pred['query']['bev_matching'].features.cpu().numpy()
+                                                     - ref['query']['bev_matching']['features']).max()),
+      'scores_poses_rel_err': rel(scores_g, scores_w),
+      'pose_argmax_hip': gi, 'pose_argmax_oracle': wi, 'pose_argmax_equal': gi == wi,
+      'oracle_score_gap_at_hip_argmax': float((scores_w[0, 1 + wi] - scores_w[0, 1 + gi])
+                                              / max(abs(scores_w[0, 1 + wi]), 1e-30)),
+      'tolerance': 'north star: feature maps within 1e-3 (unit-norm matching features: absolute), pose argmax identical',
+      'hip_seconds_incl_first_call': round(t_hip, 2), 'oracle_seconds': round(t_cpu, 1),
+      'host_cores': os.cpu_count(),
+  }
+  line = json.dumps(out)
+  print(line)
+  if args.out:
+    with open(args.out, 'w') as f:
+      f.write(line + '\n')
+
+
+if __name__ == '__main__':
+  main()
