@@ -41,9 +41,14 @@ def main():
   ap.add_argument('--out', default=None)
   ap.add_argument('--views', type=int, default=4)
   ap.add_argument('--image', type=int, default=512)
+  ap.add_argument('--eval', action='store_true',
+                  help='eval_localization.py overrides: 20 000 hypotheses + the 41^3 refinement lattice')
   args = ap.parse_args()
   dev = torch.device('cuda')
   cfg = train_localization.get_config().model
+  if args.eval:
+    from snap_amd.configs import eval_localization
+    cfg.update(eval_localization.get_config().model)
   meta = synthetic.meta_data(0.2, (25.6, 25.6, 12))
   loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
   variables = loc.init(0, device='cpu')
@@ -90,6 +95,16 @@ def main():
       'hip_seconds_incl_first_call': round(t_hip, 2), 'oracle_seconds': round(t_cpu, 1),
       'host_cores': os.cpu_count(),
   }
+  if args.eval:
+    lat_g = pred['scores_grid_refine'].cpu().numpy()
+    lat_w = ref['scores_grid_refine']
+    out['refine_lattice_rel_err'] = rel(lat_g, lat_w)
+    out['refine_argmax_hip'] = int(np.argmax(lat_g[0]))
+    out['refine_argmax_oracle'] = int(np.argmax(lat_w[0]))
+    out['refine_argmax_equal'] = out['refine_argmax_hip'] == out['refine_argmax_oracle']
+    tg, tw = pred['map_t_query'], ref['map_t_query']
+    out['refined_pose_abs_err'] = [float(abs(float(tg.angle[0]) - float(tw.angle[0]))),
+                                   float(np.abs(tg.t[0].cpu().numpy() - tw.t[0]).max())]
   line = json.dumps(out)
   print(line)
   if args.out:
