@@ -213,6 +213,54 @@ def test_conv_bf16_rows_gnstats_splitk():
   helpers.report('bf16 split-K vs single pass', got, single.cpu(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16'])
+def test_conv_random_shapes_fuzz(math):
+  """24 seeded random (shape, stride, padding, prologue, epilogue) combinations per engine vs the
+  oracle: odd sizes, Cin / Cout off the tile multiples, asymmetric padding, every fusion."""
+  rng = np.random.default_rng(2025 if math == 'f32' else 2026)
+  for it in range(24):
+    N = int(rng.integers(1, 4))
+    k = int(rng.choice([1, 1, 3, 3, 5]))
+    stride = int(rng.choice([1, 1, 2]))
+    H, W = int(rng.integers(k, 23)), int(rng.integers(k, 23))
+    Cin = int(rng.choice([4, 8, 12, 20, 32, 36, 64, 100, 132]))
+    Cs = Cin + int(rng.choice([0, 0, 4]))                       # padded row stride
+    Cout = int(rng.choice([4, 8, 28, 64, 68, 132, 200]))
+    pt, pb, pl, pr = (int(v) for v in rng.integers(0, k, 4))
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    if Ho < 1 or Wo < 1:
+      continue
+    x = torch.zeros((N, H, W, Cs))
+    x[..., :Cin] = rnd((N, H, W, Cin), 1000 + it) + 0.1
+    w = rnd((k, k, Cin, Cout), 2000 + it, 1.0 / np.sqrt(k * k * Cin))
+    pro = int(rng.choice([ops.PRO_NONE, ops.PRO_RELU, ops.PRO_AFFINE, ops.PRO_GN_RELU, ops.PRO_RELU_GN]))
+    kw = dict(stride=stride, padding=((pt, pb), (pl, pr)), cin=Cin, prologue=pro, math=math)
+    if pro in (ops.PRO_GN_RELU, ops.PRO_RELU_GN):
+      if Cin % 4:
+        continue
+      groups = 4 if Cin % 32 else 32
+      gamma, beta = rnd((Cin,), 3000 + it) * 0.3 + 1, rnd((Cin,), 4000 + it) * 0.1
+      mu, sc = oracle_ops.group_norm_stats(x[..., :Cin].contiguous(), gamma, groups=groups,
+                                           relu_first=pro == ops.PRO_RELU_GN)
+      kw['gn'] = (mu, sc, beta)
+    if pro == ops.PRO_AFFINE:
+      kw['in_affine'] = (float(rng.uniform(0.5, 2)), float(rng.uniform(-1, 1)))
+    if rng.random() < 0.5:
+      kw['bias'] = rnd((Cout,), 5000 + it)
+    if rng.random() < 0.4:
+      kw['relu'] = True
+    if rng.random() < 0.4:
+      kw['residual'] = rnd((N, Ho, Wo, Cout), 6000 + it)
+    if rng.random() < 0.3:
+      kw['row_mask'] = torch.rand((N, Ho, Wo), generator=torch.Generator().manual_seed(7000 + it)) > 0.3
+    got, want = both('conv2d', (x, w), kw)
+    scale = max(1.0, float(want.abs().max()))
+    helpers.report(f'fuzz {math} #{it} N{N} {H}x{W} k{k} s{stride} Cin{Cin}/{Cs} Cout{Cout} pro{pro} '
+                   f'{sorted(set(kw) - {"stride", "padding", "cin", "prologue", "math"})}',
+                   got, want, atol=4e-5 * scale, rtol=1e-5)
+
+
 def test_conv_affine_root():
   x = torch.rand((2, 20, 18, 3), generator=torch.Generator().manual_seed(3))
   w = rnd((7, 7, 3, 64), 4, 0.1)
