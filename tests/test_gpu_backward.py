@@ -141,6 +141,49 @@ def test_conv_wgrad_bf16_rows():
   helpers.report('wgrad bf16 rows', got, ref, atol=2e-5 * float(ref.abs().max()) + 1e-5)
 
 
+@pytest.mark.parametrize('math_', ['f32', 'bf16'])
+def test_conv_wgrad_and_dgrad_random_shapes_fuzz(math_):
+  """16 seeded random (shape, stride, padding, prologue) combinations per engine: kernel and data
+  gradients vs torch fp64 autograd of the plain restatement (operands rounded to bf16 first for
+  the bf16 engine, so the tolerance stays in the f32 round-off class)."""
+  from oracle import encoder as o_enc
+  from snap_amd import autograd as ag
+  rng = np.random.default_rng(3030 if math_ == 'f32' else 3031)
+  for it in range(16):
+    N = int(rng.integers(1, 3))
+    k = int(rng.choice([1, 3]))
+    stride = int(rng.choice([1, 1, 2]))
+    pad = int(rng.integers(0, k))
+    H, W = int(rng.integers(k + 1, 15)), int(rng.integers(k + 1, 15))
+    Cin = int(rng.choice([4, 8, 36, 64, 100, 132]))
+    Cout = int(rng.choice([4, 28, 64, 132]))
+    pro = int(rng.choice([ops.PRO_NONE, ops.PRO_RELU, ops.PRO_AFFINE]))
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    x = rnd((N, H, W, Cin), 100 + it) + 0.1
+    w = rnd((k, k, Cin, Cout), 200 + it, 1 / math.sqrt(k * k * Cin))
+    dy = rnd((N, Ho, Wo, Cout), 300 + it)
+    aff = (1.5, -0.25) if pro == ops.PRO_AFFINE else (1.0, 0.0)
+    z32 = oracle_ops._prologue(x.numpy(), pro, None, aff, Cin)
+    rnd_ = o_enc.bf16_round if math_ == 'bf16' else (lambda a: a)
+    zd = torch.from_numpy(rnd_(z32)).double()
+    wd = torch.from_numpy(rnd_(w.numpy())).double().requires_grad_(True)
+    zd.requires_grad_(True)
+    ref_conv(zd, wd, stride, pad).backward(torch.from_numpy(rnd_(dy.numpy())).double())
+    tag = f'fuzz {math_} #{it} N{N} {H}x{W} k{k} s{stride} p{pad} Cin{Cin} Cout{Cout} pro{pro}'
+    dw = ops_bwd.conv2d_wgrad(G(x), G(dy), tuple(w.shape), stride=stride, padding=((pad, pad), (pad, pad)),
+                              prologue=pro, in_affine=aff, math=math_)
+    want = wd.grad.float()
+    helpers.report('wgrad ' + tag, dw, want, atol=3e-5 * float(want.abs().max()) + 1e-6)
+    ops.MATMUL_PRECISION = math_
+    try:
+      dz = ag.conv_dgrad(G(dy), G(w), (N, H, W, Cin), stride, ((pad, pad), (pad, pad)))
+    finally:
+      ops.MATMUL_PRECISION = 'f32'
+    wantz = zd.grad.float()
+    helpers.report('dgrad ' + tag, dz[..., :Cin], wantz, atol=3e-5 * float(wantz.abs().max()) + 1e-6)
+
+
 @pytest.mark.parametrize('k,stride,pad', [(1, 1, 0), (3, 1, 1), (3, 2, 1), (1, 2, 0)])
 def test_conv_dgrad_via_engine(k, stride, pad):
   from snap_amd import autograd as ag
