@@ -106,6 +106,39 @@ def _sync(device):
     torch.cuda.synchronize()
 
 
+def cpu_baseline_full_scene(cfg, meta, workload):
+  """The numpy oracle on ONE WHOLE scene of the workload, end to end (encoders, lift, fusion MLP,
+  pooling, fusion, similarity, scoring of all P hypotheses): no extrapolation.  ~23 s on the 256
+  host cores of the GPU box (BLAS-threaded), inside the 10-30 s the contract asks for."""
+  from oracle import geometry as o_geo
+  from oracle import grids as o_grids
+  from oracle import model as o_model
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import helpers
+  w = WORKLOADS[workload]
+  grid = meta['grid']
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, grid.bev())
+  params = helpers.params_to_numpy(loc.init(0, device='cpu')['params'])
+  batch = synthetic.make_batch(1, grid, w['views'], (w['image'], w['image']), seed=7)
+  ob = helpers.batch_to_oracle(batch)
+  rng = np.random.default_rng(0)
+  P = cfg.num_pose_samples
+  X, Y = grid.extent[:2]
+  ps = o_geo.Transform2D(rng.uniform(0, 6.28, (1, P)).astype(np.float32),
+                         rng.uniform(0, X * grid.cell_size, (1, P, 2)).astype(np.float32))
+  t0 = time.perf_counter()
+  o_model.bev_localizer(params, cfg, {'streetview_hfov_deg': 72.0}, o_grids.Grid2D((X, Y), grid.cell_size),
+                        ob, pose_samples=ps)
+  dt = time.perf_counter() - t0
+  return {
+      'value': 1.0 / dt, 'unit': 'scenes/s', 'cores': os.cpu_count(), 'kind': 'port',
+      'sample': ('numpy oracle (CPU restatement of the reference algorithm; JAX unavailable offline), '
+                 f'BLAS-threaded: ONE WHOLE scene of the workload end to end ({w["views"]} views + query + aerial, '
+                 f'{X}x{Y}x60 voxels, {P + 1} pose hypotheses), no extrapolation'),
+      'seconds_measured': round(dt, 2),
+  }
+
+
 def cpu_baseline(cfg, meta, workload, budget_s=40.0):
   """Time the numpy oracle (a CPU restatement of the reference algorithm; JAX is
   not installable offline) on a bounded sample of one scene and extrapolate
@@ -416,7 +449,10 @@ def main(argv=None):
     if (world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']
         and not WORKLOADS[args.workload].get('vit') and args.mode == 'infer'):
       try:
-        out['cpu_baseline'] = cpu_baseline(cfg, meta, args.workload)
+        # a whole scene where the host is big enough to finish it in ~20-30 s (the GPU box: 256
+        # cores); the bounded-sample estimate elsewhere
+        fn = cpu_baseline_full_scene if (os.cpu_count() or 1) >= 64 else cpu_baseline
+        out['cpu_baseline'] = fn(cfg, meta, args.workload)
       except Exception as e:  # the baseline must never take the bench line down
         out['cpu_baseline'] = {'error': repr(e)}
     print(json.dumps(out), flush=True)
