@@ -58,6 +58,73 @@ __global__ __launch_bounds__(256) void vertical_pool_kernel(
   if (hl == 0) pvalid[m] = any ? 1 : 0;
 }
 
+// Z <= 64: ONE WAVE per column.  The validity bytes of the column become a wave-uniform 64-bit
+// mask (one ballot), so the walk over the valid levels has no data-dependent branches; the two
+// half-waves take alternate valid levels and each keeps two row loads in flight (four 512-byte
+// rows per wave instead of one per half-wave), then the halves are combined.  max: identical
+// values; sum / mean: the same terms, associated as (even levels) + (odd levels).
+__global__ __launch_bounds__(256) void vertical_pool_wave_kernel(
+    const float* __restrict__ vol, const uint8_t* __restrict__ vvalid, float* __restrict__ plane,
+    uint8_t* __restrict__ pvalid, int64_t M, int Z, int D, int pooling) {
+  const int lane = threadIdx.x & 63;
+  const int hl = lane & 31, half = lane >> 5;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int nq = D >> 2;
+  unsigned long long mask = __ballot(lane < Z && vvalid[m * Z + lane] != 0);
+  const int count = __popcll(mask);
+  const float* base = vol + m * Z * D;
+  const bool is_max = pooling == SNAP_POOL_MAX;
+  f32x4 acc[MAXQ];
+  const float init = is_max ? -INFINITY : 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{init, init, init, init};
+  while (mask) {
+    // next four valid levels: z[0], z[2] -> half 0; z[1], z[3] -> half 1
+    int z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      z[k] = mask ? (int)__builtin_ctzll(mask) : -1;
+      mask &= mask - 1;                    // (0 stays 0)
+    }
+    const int za = half ? z[1] : z[0], zb = half ? z[3] : z[2];
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+      const int q = hl + 32 * i;
+      if (q < nq) {
+        f32x4 va = f32x4{init, init, init, init}, vb = va;
+        if (za >= 0) va = *reinterpret_cast<const f32x4*>(base + (int64_t)za * D + 4 * q);
+        if (zb >= 0) vb = *reinterpret_cast<const f32x4*>(base + (int64_t)zb * D + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[i][e] = is_max ? fmaxf(acc[i][e], va[e]) : acc[i][e] + va[e];
+          acc[i][e] = is_max ? fmaxf(acc[i][e], vb[e]) : acc[i][e] + vb[e];
+        }
+      }
+    }
+  }
+  const bool any = count > 0;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int q = hl + 32 * i;
+    f32x4 o = acc[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float other = __shfl_xor(o[e], 32);
+      o[e] = is_max ? fmaxf(o[e], other) : o[e] + other;
+    }
+    if (q < nq && half == 0) {
+      if (!any) o = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (any && pooling == SNAP_POOL_MEAN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = o[e] / (float)count;
+      }
+      *reinterpret_cast<f32x4*>(plane + m * D + 4 * q) = o;
+    }
+  }
+  if (lane == 0) pvalid[m] = any ? 1 : 0;
+}
+
 struct FuseArgs {
   const float* planes[4];
   const uint8_t* valids[4];
@@ -148,9 +215,15 @@ extern "C" int snap_vertical_pool_f32(const float* vol, const uint8_t* vvalid, f
   if (!vol || !vvalid || !plane || !pvalid) return SNAP_ERR_NULL;
   if (M <= 0 || Z <= 0 || D <= 0 || D % 4 != 0 || D > MAXQ * 128) return SNAP_ERR_BAD_SHAPE;
   if (pooling < SNAP_POOL_MAX || pooling > SNAP_POOL_MEAN) return SNAP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(vertical_pool_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), vol, vvalid, plane, pvalid, M, Z, D,
-                     pooling);
+  if (Z <= 64) {
+    hipLaunchKernelGGL(vertical_pool_wave_kernel, dim3((unsigned)snap_cdiv(M, 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), vol, vvalid, plane, pvalid, M, Z, D,
+                       pooling);
+  } else {
+    hipLaunchKernelGGL(vertical_pool_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), vol, vvalid, plane, pvalid, M, Z, D,
+                       pooling);
+  }
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

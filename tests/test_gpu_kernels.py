@@ -404,11 +404,15 @@ def test_project_points():
 # ----------------------------------------------------------------------------
 # BEV
 # ----------------------------------------------------------------------------
+@pytest.mark.parametrize('Z,D', [(12, 128), (60, 128), (64, 32), (1, 256), (70, 128)])
 @pytest.mark.parametrize('pooling', ['max', 'sum', 'mean'])
-def test_vertical_pool(pooling):
-  vol = rnd((2, 9, 7, 12, 128), 60)
-  valid = torch.rand((2, 9, 7, 12), generator=torch.Generator().manual_seed(61)) > 0.6
+def test_vertical_pool(pooling, Z, D):
+  """Z <= 64: the wave-per-column kernel (alternate levels per half-wave); Z = 70: the
+  half-wave-per-column kernel."""
+  vol = rnd((2, 9, 7, Z, D), 60)
+  valid = torch.rand((2, 9, 7, Z), generator=torch.Generator().manual_seed(61)) > 0.6
   valid[0, 0] = False  # fully invalid columns
+  valid[1, 1] = True   # fully valid columns
   (pg, vg), (pw, vw) = both('vertical_pool', (vol, valid, pooling))
   helpers.report('vpool valid', vg, vw, 0)
   helpers.report('vpool plane', pg, pw, atol=1e-5, rtol=1e-6)
