@@ -380,6 +380,47 @@ def test_lift_pool(K, V):
   helpers.report('lift pooled', pg.cpu()[keep], pw[keep], atol=2e-4, rtol=1e-4)
 
 
+def test_lift_and_pose_score_random_configs_fuzz():
+  """12 seeded random lift configurations (views, top-K, feature / bin widths, map sizes, radial
+  distortion, depth ranges, max view distance, N off the 32-voxel batches) and 12 pose-scoring
+  configurations (plane sizes on both kernels, P, Nq, masks) vs the oracle."""
+  rng = np.random.default_rng(4040)
+  for it in range(12):
+    V = int(rng.integers(1, 9))
+    K = 0 if V == 1 or rng.random() < 0.4 else int(rng.integers(1, min(V, 8)))
+    if K >= V:
+      K = 0
+    fd = int(rng.choice([8, 32, 64, 128]))
+    nb = int(rng.choice([4, 8, 32]))
+    h, w = int(rng.integers(6, 20)), int(rng.integers(6, 20))
+    N = int(rng.integers(33, 3000))
+    f, cam, Rt, pts = _lift_scene(int(rng.integers(1, 3)), V, h, w, fd, nb, N, seed=500 + it,
+                                  k_radial=float(rng.choice([0.0, 0.02, 0.08])))
+    dmin = float(rng.choice([0.5, 1.0]))
+    kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(dmin, dmin * float(rng.choice([8, 32]))))
+    if K and rng.random() < 0.4:
+      kw['max_view_distance'] = float(rng.uniform(3, 8))
+    (pg, vg), (pw, vw) = both('lift_pool', (f, cam, Rt, pts), kw)
+    mism = (vg.cpu() != vw)
+    assert mism.float().mean() < 4e-3, f'lift fuzz #{it}: valid mismatch {mism.float().mean()} ({kw}, V={V})'
+    helpers.report(f'lift fuzz #{it} V{V} K{K} fd{fd} nb{nb} {h}x{w} N{N}', pg.cpu()[~mism], pw[~mism],
+                   atol=2e-4, rtol=1e-4)
+  for it in range(12):
+    X, Y = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+    B, Nq, P = int(rng.integers(1, 3)), int(rng.integers(1, 90)), int(rng.integers(1, 900))
+    cell = float(rng.choice([0.2, 0.25, 0.5]))
+    sim = torch.tensor(rng.random((B, Nq, X, Y), dtype=np.float32))
+    poses = np.stack([rng.uniform(-np.pi, np.pi, (B, P)),
+                      rng.uniform(-0.3 * X * cell, 1.3 * X * cell, (B, P)),
+                      rng.uniform(-0.3 * Y * cell, 1.3 * Y * cell, (B, P))], -1).astype(np.float32)
+    q_xy = torch.tensor(rng.uniform(-3, 3, (B, Nq, 2)).astype(np.float32))
+    valid_q = torch.tensor(rng.random((B, Nq)) > 0.2)
+    map_valid = torch.tensor(rng.random((B, X, Y)) > 0.1) if rng.random() < 0.7 else None
+    oob = bool(rng.random() < 0.5) and map_valid is not None     # (masking needs the map validity)
+    got, want = both('pose_score', (sim, torch.tensor(poses), q_xy, valid_q, map_valid, cell), dict(mask_oob=oob))
+    helpers.report(f'pose_score fuzz #{it} {X}x{Y} B{B} Nq{Nq} P{P} oob{oob}', got, want, atol=2e-4, rtol=1e-5)
+
+
 def test_lift_pool_full_width_and_maxdist():
   fd, nb = 128, 32
   f, cam, Rt, pts = _lift_scene(1, 5, 10, 10, fd, nb, 3000, seed=41)
