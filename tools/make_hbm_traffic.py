@@ -21,7 +21,7 @@ FAMILIES = [
     ('pose_score_db_kernel', 'pose_score'), ('pose_score_kernel', 'pose_score'),
     ('pose_table', 'pose_score'), ('pose_score_reduce', 'pose_score'),
     ('lift_pool_batched_kernel', 'lift_pool'), ('lift_pool_kernel', 'lift_pool'),
-    ('vertical_pool_kernel', 'vertical_pool'),
+    ('vertical_pool_kernel', 'vertical_pool'), ('vertical_pool_wave_kernel', 'vertical_pool'),
     ('gn_partial_kernel', 'group_norm_stats'), ('gn_finalize_kernel', 'group_norm_stats'),
     ('sim_kernel', 'sim_softmax'), ('row_stats_kernel', 'sim_softmax'),
     ('ransac_sample_kernel', 'ransac_sample'), ('chunk_prefix_kernel', 'ransac_sample'), ('weight_std', 'weight_standardize'),
