@@ -50,6 +50,37 @@ class TrainState:
                v=[torch.zeros_like(t) for t in leaves], global_step=0, rng=rng)
 
 
+def save_train_state(path, state: TrainState) -> None:
+  """Checkpoint for resume (the reference: ``train_utils.save_checkpoint`` of the Flax TrainState,
+  ``trainer.py:594-602``): parameters under ``params/...`` (Flax names, so the file doubles as a
+  pretrained checkpoint for ``checkpoint.load_pretrained``), Adam moments under ``opt/m|v/...``,
+  step and sampling rng as 0-d arrays."""
+  from snap_amd.utils import checkpoint
+  names = [n for n, _ in flatten_params(state.params)]
+  tree = {
+      'params': state.params,
+      'opt': {'m': checkpoint.unflatten(dict(zip(names, state.m))),
+              'v': checkpoint.unflatten(dict(zip(names, state.v)))},
+      'global_step': torch.tensor(state.global_step, dtype=torch.int64),
+      'rng': torch.tensor(state.rng, dtype=torch.int64),
+  }
+  checkpoint.save_npz(path, tree)
+
+
+def load_train_state(path, template: TrainState) -> TrainState:
+  """Restore a ``save_train_state`` file into the structure (names, shapes, devices) of
+  ``template`` (``trainer.py:437-440``: ``restore_checkpoint(workdir, train_state)``)."""
+  from snap_amd.utils import checkpoint
+  tree = checkpoint.load_npz(path)
+  names = [n for n, _ in flatten_params(template.params)]
+  params = checkpoint.load_into(template.params, tree['params'])
+  tmpl_m = checkpoint.unflatten(dict(zip(names, template.m)))
+  m = checkpoint.load_into(tmpl_m, tree['opt']['m'])
+  v = checkpoint.load_into(tmpl_m, tree['opt']['v'])
+  return TrainState(params=params, m=[t for _, t in flatten_params(m)], v=[t for _, t in flatten_params(v)],
+                    global_step=int(tree['global_step']), rng=int(tree['rng']))
+
+
 def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
   """optax.adam (bias-corrected, eps outside the sqrt); in place on `leaves`."""
   torch._foreach_mul_(m, b1)
