@@ -196,7 +196,12 @@ def psum_metric_normalizer(metrics: Dict[str, Tuple[torch.Tensor, torch.Tensor]]
 
 def reduce_batch_metrics(metrics: Dict[str, torch.Tensor], batch_mask: torch.Tensor, group=None):
   """Per-example metric vectors [B] -> global masked means (trainer.py:57-67,258)."""
-  m = batch_mask.to(torch.float64)
-  pairs = {k: ((v.to(torch.float64) * m).sum(), m.sum()) for k, v in metrics.items()}
+  # metric_mask = batch_mask * isfinite(v): a non-finite value (e.g. on a padding example)
+  # leaves both the sum and the count (trainer.py:57-67), instead of NaN * 0 = NaN.
+  pairs = {}
+  for k, v in metrics.items():
+    v = v.to(torch.float64)
+    keep = batch_mask.to(torch.bool) & torch.isfinite(v)
+    pairs[k] = (torch.where(keep, v, torch.zeros_like(v)).sum(), keep.to(torch.float64).sum())
   summed = psum_metric_normalizer(pairs, group)
   return {k: float(s / torch.clamp(c, min=1.0)) for k, (s, c) in summed.items()}

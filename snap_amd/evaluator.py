@@ -61,9 +61,13 @@ def eval_step(params, batch, *, rng, model) -> Dict[str, torch.Tensor]:
   pred = model.flax_model.apply({'params': params}, batch, train=False, mutable=False,
                                 debug=False, rngs={'sampling': rng})
   losses, metrics = model.loss_metrics_function(pred, batch, params)
-  if type(model).__name__ != 'BEVLocalizerModel':
-    raise ValueError(f'No packing function for model {type(model).__name__}.')
-  return pack_localization_metrics(metrics, losses, batch, pred)
+  # evaluator.py:100-108: the localizer packs here, other models pack themselves.
+  from snap_amd.models import bev_localizer
+  if isinstance(model, bev_localizer.BEVLocalizerModel):
+    return pack_localization_metrics(metrics, losses, batch, pred)
+  if hasattr(model, 'pack_evaluation_metrics'):
+    return model.pack_evaluation_metrics(metrics, losses, batch, pred)
+  raise ValueError(f'No packing function for model {type(model).__name__}.')
 
 
 def eval_on_batches(model, params, batches: Iterable[Dict[str, Any]], rng: int = 0) -> Dict[str, np.ndarray]:

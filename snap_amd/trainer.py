@@ -41,6 +41,7 @@ class TrainState:
   m: List[torch.Tensor]
   v: List[torch.Tensor]
   global_step: int = 0
+  opt_count: int = 0      # optimizer updates actually applied (skipped steps do not count)
   rng: int = 0
 
   @classmethod
@@ -62,6 +63,7 @@ def save_train_state(path, state: TrainState) -> None:
       'opt': {'m': checkpoint.unflatten(dict(zip(names, state.m))),
               'v': checkpoint.unflatten(dict(zip(names, state.v)))},
       'global_step': torch.tensor(state.global_step, dtype=torch.int64),
+      'opt_count': torch.tensor(state.opt_count, dtype=torch.int64),
       'rng': torch.tensor(state.rng, dtype=torch.int64),
   }
   checkpoint.save_npz(path, tree)
@@ -78,7 +80,8 @@ def load_train_state(path, template: TrainState) -> TrainState:
   m = checkpoint.load_into(tmpl_m, tree['opt']['m'])
   v = checkpoint.load_into(tmpl_m, tree['opt']['v'])
   return TrainState(params=params, m=[t for _, t in flatten_params(m)], v=[t for _, t in flatten_params(v)],
-                    global_step=int(tree['global_step']), rng=int(tree['rng']))
+                    global_step=int(tree['global_step']), rng=int(tree['rng']),
+                    opt_count=int(tree.get('opt_count', tree['global_step'])))
 
 
 def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
@@ -140,12 +143,15 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
     torch._foreach_mul_(grads, factor)
   is_fin = sdist.all_finite(grads, group)
   logs['l2_grads'] = float(_global_norm(grads))
-  lr = lr_fn(state.global_step)
+  # The reference restores the whole opt_state on a skipped step, optax's step and schedule
+  # counts included (trainer.py:269-276): bias correction and schedule follow opt_count.
+  lr = lr_fn(state.opt_count)
   logs['learning_rate'] = lr
   logs['is_finite'] = is_fin
   if is_fin:                                           # otherwise: skip the update
     with torch.no_grad():
-      _adam_update_(leaves, grads, state.m, state.v, state.global_step + 1, lr)
+      _adam_update_(leaves, grads, state.m, state.v, state.opt_count + 1, lr)
+    state.opt_count += 1
   with torch.no_grad():
     logs['l2_params'] = float(_global_norm(leaves))
     per_example = {k: v.detach().to(torch.float32) for k, v in metrics.items()}
@@ -165,8 +171,11 @@ def _forward_backward(state, batch, model, leaves, sampling_rng, group, debug, o
         mutable=False, debug=debug,
     )
     losses, metrics = model.loss_metrics_function(pred, batch, state.params)
-    mask = batch['batch_mask'].to(losses['total'].dtype)
-    loss = (losses['total'] * mask).sum() / mask.sum().clamp(min=1)
+    # mean(where=batch_mask) (trainer.py:221): a non-finite loss on a padding example must
+    # not reach the sum (NaN * 0 = NaN), so select instead of multiplying.
+    mask = batch['batch_mask'].to(torch.bool)
+    total = losses['total']
+    loss = torch.where(mask, total, torch.zeros_like(total)).sum() / mask.sum().clamp(min=1)
     if sdist._world(group) > 1 and overlap_allreduce:
       reducer = sdist.OverlappedGradReducer(leaves, group).attach()
       loss.backward()                                  # buckets go out as their grads land

@@ -9,6 +9,7 @@ then ``misc.find_nested_dict(state['params'], 'bev_mapper')``; ``resnet.py:223-2
 for checkpoints exchanged as ``.npz`` files of ``'a/b/c' -> array`` entries (what
 ``flax.traverse_util.flatten_dict(params, sep='/')`` + ``np.savez`` produces).
 """
+import os
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -57,7 +58,14 @@ def find_nested_dict(tree: Dict[str, Any], target_key: str) -> Optional[Dict[str
 def save_npz(path, params: Dict[str, Any]) -> None:
   flat = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
           for k, v in flatten(params).items()}
-  np.savez(path, **flat)
+  # Written through an open handle (np.savez would append '.npz' to a bare path, so the
+  # file would not be found again under the name the caller used) and renamed into place,
+  # so a crash mid-save cannot corrupt the only resume checkpoint.
+  path = os.fspath(path)
+  tmp = f'{path}.tmp.{os.getpid()}'
+  with open(tmp, 'wb') as f:
+    np.savez(f, **flat)
+  os.replace(tmp, path)
 
 
 def load_npz(path) -> Dict[str, Any]:

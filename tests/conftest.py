@@ -14,13 +14,6 @@ def pytest_configure(config):
   config.addinivalue_line(
       'markers', 'gpu: needs a ROCm GPU (run on the MI355X box with `-m gpu`)'
   )
-  if os.environ.get('SNAP_TEST_DRYRUN'):
-    # Developer aid: exercise the `-m gpu` TEST CODE on a CPU-only machine by
-    # pointing snap_amd.ops at the oracle (results prove nothing about the kernels).
-    import oracle_ops
-    from snap_amd import ops
-    for name in oracle_ops.ALL_OPS:
-      setattr(ops, name, getattr(oracle_ops, name))
 
 
 @pytest.fixture

@@ -8,6 +8,11 @@ from oracle import geometry as o_geo
 from snap_amd.configs import defaults
 
 
+# Device the `-m gpu` tests run on.  Always the GPU inside the suite; only the developer
+# plugin tools/dryrun_plugin.py (never loaded by tests/, bench.py or the driver) rebinds it.
+DEVICE = 'cuda'
+
+
 def tiny_localizer_config(num_pose_samples=64, retries=2, top_k=2, feature_dim=32,
                           matching_dim=8, num_bins=8, depth=(1, 1), width=0.5,
                           refine=False, aerial=True):

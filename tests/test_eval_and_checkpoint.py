@@ -150,14 +150,53 @@ def test_train_state_checkpoint_round_trip(tmp_path):
   for t in state.m + state.v:
     t.copy_(torch.randn(t.shape, generator=g))
   state.global_step = 123
-  path = tmp_path / 'state.npz'
+  state.opt_count = 120                     # three skipped (non-finite) steps
+  path = tmp_path / 'state'                 # no suffix: must load back under the same name
   trainer.save_train_state(path, state)
   fresh = trainer.TrainState.create(model.flax_model.init(5, device='cpu')['params'])
   back = trainer.load_train_state(path, fresh)
-  assert back.global_step == 123 and back.rng == 17
+  assert back.global_step == 123 and back.rng == 17 and back.opt_count == 120
+  assert os.listdir(tmp_path) == ['state']  # written atomically, no stray temp / '.npz' twin
   for (na, a), (nb, b) in zip(trainer.flatten_params(state.params), trainer.flatten_params(back.params)):
     assert na == nb and torch.equal(a, b)
   assert all(torch.equal(a, b) for a, b in zip(state.m, back.m))
   assert all(torch.equal(a, b) for a, b in zip(state.v, back.v))
   sub = checkpoint.load_pretrained(fresh.params['bev_mapper'], path, scope='bev_mapper')
   assert torch.equal(checkpoint.flatten(sub)['matching_proj/kernel'], state.params['bev_mapper']['matching_proj']['kernel'])
+
+
+def test_masked_metric_reduction_drops_non_finite_examples():
+  """trainer.py:57-67: metric_mask = batch_mask * isfinite(value); a NaN on a padding example
+  (or on a real one) leaves both the sum and the count instead of poisoning the mean."""
+  from snap_amd import dist as sdist
+  v = torch.tensor([1.0, float('nan'), 3.0, float('inf')])
+  out = sdist.reduce_batch_metrics({'a': v, 'b': torch.tensor([1.0, 2.0, 3.0, 4.0])},
+                                   torch.tensor([True, False, True, True]))
+  assert out['a'] == 2.0            # NaN row masked out, inf row dropped as non-finite
+  assert out['b'] == pytest.approx(8.0 / 3.0)
+
+
+def test_eval_step_dispatches_on_the_model(monkeypatch):
+  """evaluator.py:100-108: the localizer is packed by the evaluator, any other model by its own
+  pack_evaluation_metrics; a model with neither raises."""
+  class _Flax:
+    def apply(self, *a, **k):
+      return {'x': torch.zeros(1)}
+
+  class _Sem:
+    flax_model = _Flax()
+    def loss_metrics_function(self, pred, batch, params):
+      return {'total': torch.ones(1)}, {'m': torch.zeros(1)}
+    def pack_evaluation_metrics(self, metrics, losses, batch, pred):
+      return {**metrics, 'loss': losses['total']}
+
+  out = evaluator.eval_step({}, {}, rng=0, model=_Sem())
+  assert set(out) == {'m', 'loss'}
+
+  class _Other(_Sem):
+    pack_evaluation_metrics = None
+  other = _Other()
+  del _Other.pack_evaluation_metrics
+  monkeypatch.delattr(_Sem, 'pack_evaluation_metrics')
+  with pytest.raises(ValueError):
+    evaluator.eval_step({}, {}, rng=0, model=other)

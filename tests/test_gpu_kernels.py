@@ -17,9 +17,7 @@ from snap_amd import ops
 
 pytestmark = pytest.mark.gpu
 
-# SNAP_TEST_DRYRUN=1 (see conftest.py) runs these tests on the CPU against the
-# oracle itself: a self-consistency check of the TEST code, not a parity result.
-DEV = 'cpu' if os.environ.get('SNAP_TEST_DRYRUN') else 'cuda'
+DEV = helpers.DEVICE
 
 
 def rnd(shape, seed, scale=1.0):
