@@ -100,8 +100,10 @@ typedef struct SnapConvExtras {
   int32_t gn_partial_relu;
   void* workspace;            /* split-K scratch: snap_conv2d_workspace_bytes(desc) (may be 0) */
   size_t workspace_bytes;
-  const void* w_bf16;         /* non-NULL selects the bf16-operand engine (see below) */
+  const void* w_bf16;         /* non-NULL selects a bf16 matrix-core engine (see below) */
   size_t w_bf16_bytes;
+  int32_t w_split_parts;      /* 0: w_bf16 = rounded weights (training-precision engine);
+                                 2 | 3: w_bf16 = split weights (f32-grade split-bf16 engine) */
 } SnapConvExtras;
 
 int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,
@@ -122,6 +124,22 @@ int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const floa
 size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, int32_t Cout);
 int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
                                   void* out, size_t out_bytes, void* stream);
+/* f32-grade engine on the bf16 matrix cores (inference / parity path; replaces the same
+ * flax.linen.Conv / Dense calls: resnet.py:73-132, image_encoder.py:67-94, layers.py:55-78).
+ * Each f32 operand is split into `parts` bf16 values (hi = bf16(v), then bf16 of the exact f32
+ * residual, ...); a*b is the f32-accumulated sum of the part products above the f32 rounding
+ * level: parts = 2 -> a_lo b_hi + a_hi b_lo + a_hi b_hi (relative error ~2^-17 per product),
+ * parts = 3 -> six products (operands exact to 24 bits, ~2^-24 per product: the accuracy class
+ * of an f32 fmaf chain).  The caller splits the weights with
+ * snap_conv2d_pack_weights_split_bf16 -- out is [parts][Cout][taps][roundup(Cin, 8)] bf16 --
+ * and passes them as extras->w_bf16 with extras->w_split_parts = parts; activations are split
+ * on the fly after the f32 prologue.  Fusions, row-indexed launches, GroupNorm partial sums
+ * and split-K as on the f32 engine; shapes it does not carry (Cin < 4, unaligned channel rows)
+ * run on the exact f32 engine. */
+size_t snap_conv2d_packed_weights_split_bytes(int32_t taps, int32_t Cin, int32_t Cout,
+                                              int32_t parts);
+int snap_conv2d_pack_weights_split_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
+                                        int32_t parts, void* out, size_t out_bytes, void* stream);
 
 /* Semantic-raster embedding (snap/models/semantic_raster_encoder.py:63-79).  rasters [M, N]
  * uint8 (bool); idx_road / idx_other: HOST arrays with the raster channels of the mutually

@@ -36,7 +36,7 @@ class SnapConvExtras(ctypes.Structure):
       ('rows_in', ptr), ('rows_out', ptr), ('row_count', ptr), ('gn_partial', ptr),
       ('gn_partial_bytes', c_size), ('gn_partial_relu', c_int),
       ('workspace', ptr), ('workspace_bytes', c_size),
-      ('w_bf16', ptr), ('w_bf16_bytes', c_size),
+      ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int),
   ]
 
 
@@ -85,6 +85,8 @@ SIGNATURES = {
     'snap_gelu_bwd_f32': (c_int, [ptr, ptr, ptr, c_i64, ptr]),
     'snap_conv2d_packed_weights_bytes': (c_size, [c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
+    'snap_conv2d_packed_weights_split_bytes': (c_size, [c_int, c_int, c_int, c_int]),
+    'snap_conv2d_pack_weights_split_bf16': (c_int, [ptr, c_int, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_group_norm_stats_from_partial_f32': (
         c_int, [ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr, ptr]
     ),
@@ -212,7 +214,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 

@@ -46,6 +46,9 @@ struct ConvArgs {
 
 // bf16-operand engine (conv_bf16.hip); `a` validated by snap_conv2d_nhwc_ex_f32
 int launch_bf16(ConvArgs a, hipStream_t s);
+// split-bf16 engine (conv_split.hip): `parts` = 2 (three products) or 3 (six products);
+// a.w_bf16 then holds [parts][Cout][taps][cin8]
+int launch_split(ConvArgs a, int parts, hipStream_t s);
 
 }  // namespace snapconv
 

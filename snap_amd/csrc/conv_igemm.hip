@@ -674,10 +674,13 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.w_bf16 = ex ? ex->w_bf16 : nullptr;
   a.cin8 = (d.Cin + 7) / 8 * 8;
   if (a.w_bf16 && vec) {
-    if (ex->w_bf16_bytes < snap_conv2d_packed_weights_bytes(d.KH * d.KW, d.Cin, d.Cout))
+    const int parts = ex->w_split_parts;
+    if (parts < 0 || parts == 1 || parts > 3) return SNAP_ERR_UNSUPPORTED;
+    if (ex->w_bf16_bytes < (size_t)(parts ? parts : 1) *
+                               snap_conv2d_packed_weights_bytes(d.KH * d.KW, d.Cin, d.Cout))
       return SNAP_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(a.w_bf16) & 15) return SNAP_ERR_BAD_SHAPE;
-    return snapconv::launch_bf16(a, s);
+    return parts ? snapconv::launch_split(a, parts, s) : snapconv::launch_bf16(a, s);
   }
   return vec ? launch_tile<true>(a, s) : launch_tile<false>(a, s);
 }

@@ -151,8 +151,10 @@ def conv2d(
 ):
   """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
-  math = 'f32' (exact f32 MFMA, the parity path) | 'bf16' (operands rounded to bf16 after the
-  f32 prologue, f32 accumulate: the training-precision engine); None = ``MATMUL_PRECISION``.
+  math = 'f32' (exact f32 MFMA) | 'bf16x6' / 'bf16x3' (f32-grade split-bf16 engine: every
+  operand split into 3 / 2 bf16 parts after the f32 prologue, 6 / 3 part products accumulated in
+  f32 -- ~2^-24 / ~2^-17 relative error per product) | 'bf16' (operands rounded to bf16, f32
+  accumulate: the training-precision engine); None = ``MATMUL_PRECISION``.
 
   gn = (mu [N,Cin], sc [N,Cin], beta [Cin]) for PRO_GN_RELU / PRO_RELU_GN.
   rows_in / rows_out (int32 [M]) + row_count (int32 [1], device): row-indexed launch
@@ -232,17 +234,21 @@ def conv2d(
         ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
                                  int(emit_gn_stats == 'relu'), None, 0, None, 0)
   math = MATMUL_PRECISION if math is None else math
-  if math not in ('f32', 'bf16'):
+  if math not in ('f32', 'bf16', 'bf16x3', 'bf16x6'):
     raise ValueError(f'conv2d: math={math!r}')
   family = 'conv_igemm'
   wpk = None
-  if math == 'bf16' and Cs % 4 == 0 and Cin >= 4:
-    wpk = pack_weights_bf16(w)
+  if math != 'f32' and Cs % 4 == 0 and Cin >= 4:
+    parts = SPLIT_PARTS.get(math, 0)
+    wpk = getattr(w, '_snap_packed', {}).get(math)   # split / rounded once by the caller
+    if wpk is None:
+      wpk = pack_weights_split_bf16(w, parts) if parts else pack_weights_bf16(w)
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.w_bf16 = wpk.data_ptr()
     ex.w_bf16_bytes = wpk.numel() * 2
-    family = 'conv_bf16'
+    ex.w_split_parts = parts
+    family = 'conv_split' if parts else 'conv_bf16'
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -275,6 +281,23 @@ def pack_weights_bf16(w):
   out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
   st = lib.snap_conv2d_pack_weights_bf16(_p(w), KH * KW, Cin, Cout, _p(out), nbytes, _stream())
   _lib.check(st, 'snap_conv2d_pack_weights_bf16')
+  return out
+
+
+SPLIT_PARTS = {'bf16x3': 2, 'bf16x6': 3}
+
+
+def pack_weights_split_bf16(w, parts):
+  """w [KH,KW,Cin,Cout] f32 -> the split engine's image [parts][Cout][KH*KW][roundup(Cin,8)]
+  (part 0 = bf16(w), part p = bf16 of the exact f32 residual of parts < p)."""
+  lib = _lib.load()
+  _f32(w, 'w')
+  KH, KW, Cin, Cout = w.shape
+  nbytes = lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts)
+  out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+  st = lib.snap_conv2d_pack_weights_split_bf16(_p(w), KH * KW, Cin, Cout, parts, _p(out), nbytes,
+                                               _stream())
+  _lib.check(st, 'snap_conv2d_pack_weights_split_bf16')
   return out
 
 

@@ -146,6 +146,124 @@ def test_conv_bf16_every_tile_variant(tile, monkeypatch):
   helpers.report(f'conv bf16 upsample-add tile {tile}', got, want, atol=5e-5, rtol=1e-5)
 
 
+# split-bf16 engine (f32-grade accuracy on the bf16 matrix cores): compared with the EXACT conv of
+# the f32 operands, like the f32 engine.  'bf16x6' (3 parts, 6 products) is held to the f32
+# engine's own tolerance; 'bf16x3' (2 parts, 3 products, ~2^-17 per product) to 1e-4.
+SPLIT_TOL = {'bf16x6': 2e-5, 'bf16x3': 1e-4}
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_split_plain(case, math):
+  _, N, H, W, Cin, KH, KW, Cout, stride, pad = case
+  x = rnd((N, H, W, Cin), 1)
+  w = rnd((KH, KW, Cin, Cout), 2, 1.0 / np.sqrt(KH * KW * Cin))
+  kw = dict(stride=stride, padding=((pad, pad), (pad, pad)), math=math)
+  got, want = both('conv2d', (x, w), kw)
+  helpers.report(f'conv {math} ' + case[0], got, want, atol=SPLIT_TOL[math], rtol=1e-5)
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('tile', ['128x128', '128x64', '64x128', '64x64'])
+def test_conv_split_every_tile_variant(tile, math, monkeypatch):
+  monkeypatch.setenv('SNAP_CONV_TILE', tile)
+  tol = 2.5 * SPLIT_TOL[math]
+  N, H, W, Cin, Cout = 2, 15, 13, 96, 200
+  x = rnd((N, H, W, Cin), 31) + 0.2
+  w = rnd((3, 3, Cin, Cout), 32, 1 / np.sqrt(9 * Cin))
+  gamma, beta = rnd((Cin,), 33) + 1, rnd((Cin,), 34) * 0.1
+  res = rnd((N, H, W, Cout), 35)
+  bias = rnd((Cout,), 36)
+  for pro, relu_first in ((ops.PRO_GN_RELU, False), (ops.PRO_RELU_GN, True)):
+    mu, sc = oracle_ops.group_norm_stats(x, gamma, relu_first=relu_first)
+    kw = dict(padding=((1, 1), (1, 1)), prologue=pro, gn=(mu, sc, beta), residual=res,
+              bias=bias, relu=True, math=math)
+    got, want = both('conv2d', (x, w), kw)
+    helpers.report(f'conv {math} tile {tile} pro {pro}', got, want, atol=tol, rtol=1e-5)
+  xs = rnd((1, 1, 700, 260), 37)
+  ws = rnd((1, 1, 257, 256), 38, 1 / 16.0)
+  got, want = both('conv2d', (xs, ws), dict(cin=257, prologue=ops.PRO_RELU, math=math))
+  helpers.report(f'dense {math} k257 tile {tile}', got, want, atol=tol, rtol=1e-5)
+  x2 = rnd((2, 11, 9, 40), 41)
+  w2 = rnd((3, 3, 40, 72), 42, 1 / np.sqrt(360))
+  prev = rnd((2, 3, 3, 72), 43)
+  got, want = both('conv2d', (x2, w2), dict(stride=2, padding=((1, 1), (1, 1)),
+                                            prologue=ops.PRO_AFFINE, in_affine=(0.5, 0.25),
+                                            math=math))
+  helpers.report(f'conv {math} s2 affine tile {tile}', got, want, atol=tol, rtol=1e-5)
+  x3 = rnd((2, 6, 6, 64), 44)
+  w3 = rnd((1, 1, 64, 72), 45, 1 / 8.0)
+  got, want = both('conv2d', (x3, w3), dict(up_prev=prev, math=math))
+  helpers.report(f'conv {math} upsample-add tile {tile}', got, want, atol=tol, rtol=1e-5)
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3'])
+def test_conv_split_rows_gnstats_splitk_and_scales(math):
+  """Row-indexed launches, GroupNorm partial sums, split-K, degenerate shapes and operand
+  magnitudes far from 1 (the split is exponent-agnostic: power-of-two scaling is exact)."""
+  tol = 2.5 * SPLIT_TOL[math]
+  g = torch.Generator().manual_seed(50)
+  M, Cin, Cout = 3000, 260, 256
+  x = rnd((M, Cin), 51)
+  w = rnd((257, Cout), 52, 1 / 16.0)
+  bias = rnd((Cout,), 53)
+  mask = torch.rand(M, generator=g) > 0.6
+  want = oracle_ops.dense(x, w, bias, cin=257, relu=True)
+  index, count = ops.compact_rows(mask.to(DEV))
+  out = torch.zeros(M, Cout, device=DEV)
+  ops.dense(x.to(DEV), w.to(DEV), bias.to(DEV), cin=257, relu=True, rows_in=index, rows_out=index,
+            row_count=count, out=out, math=math)
+  helpers.report(f'{math} row-indexed dense', out[mask.to(DEV)], want[mask], atol=tol, rtol=1e-5)
+  assert float(out[~mask.to(DEV)].abs().max()) == 0.0
+  N, H, W, C1, C2 = 2, 24, 20, 64, 128
+  xi = rnd((N, H, W, C1), 54)
+  wi = rnd((3, 3, C1, C2), 55, 1 / 24.0)
+  gamma = rnd((C2,), 56) + 1
+  ops.USE_SPLITK = False
+  try:
+    y = ops.conv2d(xi.to(DEV), wi.to(DEV), padding=((1, 1), (1, 1)), emit_gn_stats='raw', math=math)
+  finally:
+    ops.USE_SPLITK = True
+  assert hasattr(y, '_snap_gn_partial')
+  mu_f, sc_f = ops.group_norm_stats(y, gamma.to(DEV))
+  mu_w, sc_w = oracle_ops.group_norm_stats(y.cpu(), gamma)
+  helpers.report(f'{math} fused gn mu', mu_f, mu_w, atol=1e-5, rtol=1e-5)
+  helpers.report(f'{math} fused gn sc', sc_f, sc_w, atol=1e-5, rtol=5e-5)
+  xs = rnd((2, 8, 8, 512), 57)
+  ws = rnd((3, 3, 512, 128), 58, 1 / np.sqrt(9 * 512))
+  kw = dict(padding=((1, 1), (1, 1)), math=math)
+  got, want = both('conv2d', (xs, ws), kw)
+  helpers.report(f'{math} split-K', got, want, atol=tol, rtol=1e-5)
+  for (N, H, W, Cin, k, Cout, pad) in [(1, 1, 1, 8, 1, 4, 0), (1, 1, 5, 4, 1, 8, 0), (1, 3, 3, 12, 3, 4, 1)]:
+    x = rnd((N, H, W, Cin), 60 + Cin)
+    w = rnd((k, k, Cin, Cout), 61, 1 / np.sqrt(k * k * Cin))
+    got, want = both('conv2d', (x, w), dict(padding=((pad, pad), (pad, pad)), math=math))
+    helpers.report(f'conv {math} tiny {N}x{H}x{W}x{Cin}', got, want, atol=tol, rtol=1e-5)
+  # scaling both operands by powers of two scales the result exactly (bit for bit)
+  xa = rnd((1, 9, 9, 32), 70)
+  wa = rnd((3, 3, 32, 64), 71, 0.1)
+  base = ops.conv2d(xa.to(DEV), wa.to(DEV), padding=((1, 1), (1, 1)), math=math)
+  big = ops.conv2d((xa * 2.0 ** 40).to(DEV), (wa * 2.0 ** -70).to(DEV), padding=((1, 1), (1, 1)), math=math)
+  assert torch.equal(big, base * 2.0 ** -30)
+
+
+def test_conv_split_accuracy_class():
+  """The split engines against float64 on a deep reduction (K = 4608), next to the exact f32
+  engine: 'bf16x6' must sit in the f32 engine's error class (<= 2x its rms error), 'bf16x3'
+  within 2^-15 of the product scale."""
+  x = rnd((2, 20, 20, 512), 80)
+  w = rnd((3, 3, 512, 256), 81, 1 / np.sqrt(9 * 512))
+  exact = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(),
+                                     padding=1).permute(0, 2, 3, 1)
+  errs = {}
+  for math in ('f32', 'bf16x6', 'bf16x3'):
+    y = ops.conv2d(x.to(DEV), w.to(DEV), padding=((1, 1), (1, 1)), math=math).cpu().double()
+    errs[math] = float((y - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt())
+  print('relative rms error vs float64:', errs)
+  assert errs['bf16x6'] <= 2.0 * errs['f32'] + 1e-8
+  assert errs['bf16x3'] <= 2.0 ** -15
+
+
 def test_conv_bf16_degenerate_shapes():
   """One output pixel, one image row, K smaller than a slab, Cout = 4, an all-masked row list."""
   for (N, H, W, Cin, k, Cout, pad) in [(1, 1, 1, 8, 1, 4, 0), (1, 1, 5, 4, 1, 8, 0), (1, 3, 3, 12, 3, 4, 1)]:

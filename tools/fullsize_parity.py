@@ -36,36 +36,7 @@ def rel(got, want):
   return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--out', default=None)
-  ap.add_argument('--views', type=int, default=4)
-  ap.add_argument('--image', type=int, default=512)
-  ap.add_argument('--eval', action='store_true',
-                  help='eval_localization.py overrides: 20 000 hypotheses + the 41^3 refinement lattice')
-  args = ap.parse_args()
-  dev = torch.device('cuda')
-  cfg = train_localization.get_config().model
-  if args.eval:
-    from snap_amd.configs import eval_localization
-    cfg.update(eval_localization.get_config().model)
-  meta = synthetic.meta_data(0.2, (25.6, 25.6, 12))
-  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
-  variables = loc.init(0, device='cpu')
-  batch = synthetic.make_batch(1, meta['grid'], args.views, (args.image, args.image), seed=21)
-  t0 = time.perf_counter()
-  pred = loc.apply({'params': helpers.params_to_device(variables['params'], dev)},
-                   helpers.batch_to_device(batch, dev), train=False, rngs={'sampling': 11}, debug=True)
-  torch.cuda.synchronize()
-  t_hip = time.perf_counter() - t0
-  samples = pred['map_t_query_samples']
-  ps = o_geo.Transform2D(samples.angle[:, 1:].cpu().numpy(), samples.t[:, 1:].cpu().numpy())
-  t0 = time.perf_counter()
-  ref = o_model.bev_localizer(
-      helpers.params_to_numpy(variables['params']), cfg, {'streetview_hfov_deg': 72.0},
-      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch),
-      pose_samples=ps, keep_sim=False)
-  t_cpu = time.perf_counter() - t0
+def compare(pred, ref, args, t_hip, t_cpu):
   sv, rsv = pred['map']['streetview'], ref['map']['streetview']
   vg = sv['feature_volume'].valid.cpu().numpy()
   vw = rsv['feature_volume']['valid']
@@ -105,6 +76,59 @@ def main():
     tg, tw = pred['map_t_query'], ref['map_t_query']
     out['refined_pose_abs_err'] = [float(abs(float(tg.angle[0]) - float(tw.angle[0]))),
                                    float(np.abs(tg.t[0].cpu().numpy() - tw.t[0]).max())]
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--out', default=None)
+  ap.add_argument('--views', type=int, default=4)
+  ap.add_argument('--image', type=int, default=512)
+  ap.add_argument('--math', default='f32',
+                  help="comma list of conv engines: f32 | bf16x6 | bf16x3 (ops.MATMUL_PRECISION)")
+  ap.add_argument('--eval', action='store_true',
+                  help='eval_localization.py overrides: 20 000 hypotheses + the 41^3 refinement lattice')
+  args = ap.parse_args()
+  dev = torch.device('cuda')
+  cfg = train_localization.get_config().model
+  if args.eval:
+    from snap_amd.configs import eval_localization
+    cfg.update(eval_localization.get_config().model)
+  meta = synthetic.meta_data(0.2, (25.6, 25.6, 12))
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
+  variables = loc.init(0, device='cpu')
+  batch = synthetic.make_batch(1, meta['grid'], args.views, (args.image, args.image), seed=21)
+  from snap_amd import ops
+  params_dev = helpers.params_to_device(variables['params'], dev)
+  batch_dev = helpers.batch_to_device(batch, dev)
+  maths = args.math.split(',')
+  preds, t_hip = {}, {}
+  inject = None
+  for math in maths:
+    ops.MATMUL_PRECISION = math
+    t0 = time.perf_counter()
+    # every engine scores the SAME hypotheses (those the first engine's sampler drew), so that
+    # one oracle run checks all of them
+    preds[math] = loc.apply({'params': params_dev}, batch_dev, train=False, rngs={'sampling': 11},
+                            debug=True, pose_samples=inject)
+    torch.cuda.synchronize()
+    t_hip[math] = time.perf_counter() - t0
+    if inject is None:
+      smp = preds[math]['map_t_query_samples']
+      from snap_amd.utils import geometry as _geo
+      inject = _geo.Transform2D(smp.angle[:, 1:].contiguous(), smp.t[:, 1:].contiguous())
+  ops.MATMUL_PRECISION = 'f32'
+  ps = o_geo.Transform2D(inject.angle.cpu().numpy(), inject.t.cpu().numpy())
+  t0 = time.perf_counter()
+  ref = o_model.bev_localizer(
+      helpers.params_to_numpy(variables['params']), cfg, {'streetview_hfov_deg': 72.0},
+      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch),
+      pose_samples=ps, keep_sim=False)
+  t_cpu = time.perf_counter() - t0
+  results = {}
+  for math in maths:
+    results[math] = compare(preds[math], ref, args, t_hip[math], t_cpu)
+  out = results[maths[0]] if len(maths) == 1 else {'per_math': results}
   line = json.dumps(out)
   print(line)
   if args.out:
