@@ -131,7 +131,8 @@ int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin, int
  * level: parts = 2 -> a_lo b_hi + a_hi b_lo + a_hi b_hi (relative error ~2^-17 per product),
  * parts = 3 -> six products (operands exact to 24 bits, ~2^-24 per product: the accuracy class
  * of an f32 fmaf chain).  The caller splits the weights with
- * snap_conv2d_pack_weights_split_bf16 -- out is [parts][Cout][taps][roundup(Cin, 8)] bf16 --
+ * snap_conv2d_pack_weights_split_bf16 -- out is the engine's own tile-major image
+ * ([Cout/128][taps][Cin/16][parts][128][16] bf16, zero padded; an opaque blob to the caller) --
  * and passes them as extras->w_bf16 with extras->w_split_parts = parts; activations are split
  * on the fly after the f32 prologue.  Fusions, row-indexed launches, GroupNorm partial sums
  * and split-K as on the f32 engine; shapes it does not carry (Cin < 4, unaligned channel rows)

@@ -676,9 +676,11 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   if (a.w_bf16 && vec) {
     const int parts = ex->w_split_parts;
     if (parts < 0 || parts == 1 || parts > 3) return SNAP_ERR_UNSUPPORTED;
-    if (ex->w_bf16_bytes < (size_t)(parts ? parts : 1) *
-                               snap_conv2d_packed_weights_bytes(d.KH * d.KW, d.Cin, d.Cout))
-      return SNAP_ERR_WORKSPACE;
+    const size_t need = parts ? snap_conv2d_packed_weights_split_bytes(d.KH * d.KW, d.Cin, d.Cout, parts)
+                              : snap_conv2d_packed_weights_bytes(d.KH * d.KW, d.Cin, d.Cout);
+    if (need == 0) return SNAP_ERR_UNSUPPORTED;
+    if (ex->w_bf16_bytes < need) return SNAP_ERR_WORKSPACE;
+    if (parts) a.cin8 = (d.Cin + 15) / 16 * 16;   // split image: channel axis padded to the slab
     if (reinterpret_cast<uintptr_t>(a.w_bf16) & 15) return SNAP_ERR_BAD_SHAPE;
     return parts ? snapconv::launch_split(a, parts, s) : snapconv::launch_bf16(a, s);
   }

@@ -18,9 +18,9 @@
 //   * A (im2col rows): global -> registers (float4), fused prologue in f32, split into NS bf16
 //     images, each stored as [row][16 k] (32 B per row; the two 16-byte k-octets XOR-swizzled by
 //     (row >> 3) & 1 so the MFMA fragment fetch -- one ds_read_b128 per lane -- is conflict-free).
-//   * B: the weights are split once by snap_conv2d_pack_weights_split_bf16 into
-//     [part][Cout][tap][cin8] bf16 and go global -> LDS by LDS-DMA (no registers, no VALU), with
-//     the swizzle applied on the source side.
+//   * B: the weights are split once by snap_conv2d_pack_weights_split_bf16 into an image laid out
+//     as the LDS stages ([column tile][tap][channel tile][part][column][16 k], swizzle applied at
+//     rest) and go global -> LDS by LDS-DMA as contiguous 1 KB runs (no registers, no VALU).
 //   * one K slab = 16 k = one MFMA k-step of NS(NS+1)/2 products per 32x32 tile; double-buffered
 //     LDS, one barrier per slab (96 MFMA-cycles x TM x TN at NS = 3 between barriers).
 #include "conv_common.h"
@@ -30,21 +30,43 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Four f32 -> NS x four bf16 (packed two per dword).  Each part is one v_cvt_pk_bf16_f32 (RNE)
+// per element PAIR; the value it represents is recovered by a shift / mask of the packed dword
+// and subtracted exactly in f32 (3 VALU per element and part instead of the 4 the generic
+// vector conversion costs).
 template <int NS>
-__device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&out)[NS]) {
+__device__ __forceinline__ void split_bf16(const f32x4& v, u32x2 (&out)[NS]) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x4 r = v;
 #pragma unroll
   for (int p = 0; p < NS; ++p) {
-    out[p] = __builtin_convertvector(r, bf16x4);            // v_cvt_pk_bf16_f32, RNE
-    if (p + 1 < NS) {
-      const f32x4 back = __builtin_convertvector(out[p], f32x4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = r[e] - back[e];    // exact
+    for (int h = 0; h < 2; ++h) {
+      const f32x2 pr = {r[2 * h], r[2 * h + 1]};
+      const bf16x2 b = __builtin_convertvector(pr, bf16x2);
+      unsigned u;
+      __builtin_memcpy(&u, &b, 4);
+      out[p][h] = u;
+      if (p + 1 < NS) {
+        r[2 * h] = r[2 * h] - __uint_as_float(u << 16);               // exact
+        r[2 * h + 1] = r[2 * h + 1] - __uint_as_float(u & 0xffff0000u);
+      }
     }
   }
 }
 
-template <int BM, int BN, int PRO, int NS>
+// GNT: the GroupNorm operands (mean, rstd*gamma per (image, channel); beta per channel) of the
+// slab's 16 channels come from a small LDS table instead of two float4 global loads per staged
+// ROW: a row tile of BM <= Ho*Wo pixels touches at most two images, so 20 lanes fetch
+// [mu n0 | sc n0 | mu n1 | sc n1 | beta] (320 B) by LDS-DMA two slabs ahead (3-deep ring; the
+// slab's closing barrier publishes it).  Per-row statistics loads were 2/3 of the bytes the
+// vector-memory path moved per slab (they hit L1, but the path itself delivers 64 B/clk/CU).
+// TAIL: Cin is not a multiple of 4 (the 257-channel fusion MLP): the last channel quad needs a
+// per-element mask; otherwise one flag per 16-byte chunk does.
+template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL>
 __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   constexpr int BK = 16;
   constexpr int TM = BM / 64;
@@ -61,9 +83,13 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   constexpr int kSlabBytes = 2 * (A_ST + B_ST);
   constexpr int kStageBytes = 64 * BN * 4;
   constexpr int kSmemBytes = kSlabBytes > kStageBytes ? kSlabBytes : kStageBytes;
-  __shared__ __attribute__((aligned(16))) float smem[kSmemBytes / 4];
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  constexpr bool gn_tab = need_gn && GNT;
+  constexpr int kGnRing = 320;            // bytes per table
+  __shared__ __attribute__((aligned(16))) float smem[(kSmemBytes + (gn_tab ? 3 * kGnRing : 0)) / 4];
   char* const Ab = reinterpret_cast<char*>(smem);
   char* const Bb = Ab + 2 * A_ST;
+  char* const Gt = Ab + kSmemBytes;
 
   const SnapConvDesc& d = a.d;
   const int tid = threadIdx.x;
@@ -83,12 +109,14 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   const int m0 = row_t * BM;
   const int n0 = col_t * BN;
   const int HoWo = d.Ho * d.Wo;
-  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  const int n_first = m0 / HoWo;
+  const int m_split = (n_first + 1) * HoWo;   // first row of the tile's second image
 
   int r_hb[AROWS], r_wb[AROWS];
   bool r_ok[AROWS];
   const float* r_px[AROWS];
   int64_t r_gn[AROWS];
+  int r_slot[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int row = (tid / QPR) + RPP * i;
@@ -104,6 +132,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     r_wb[i] = wo * d.stride - d.pad_l;
     r_px[i] = a.x + (((int64_t)n * d.H + r_hb[i]) * d.W + r_wb[i]) * d.Cin_stride;
     r_gn[i] = (int64_t)n * d.Cin;
+    r_slot[i] = m >= m_split ? 1 : 0;
   }
   const int akq = tid % QPR;
 
@@ -146,39 +175,64 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     const int c = ct * BK + 4 * akq;
     cur_c = c;
     const bool cvalid = c < d.Cin;
-    if constexpr (need_gn) xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
+    if constexpr (need_gn && !gn_tab)
+      xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const bool inb = tap_in[i] && cvalid;
       xin[i] = inb;
       const float* px = inb ? tap_px[i] + c : a.x;
       xa[i] = *reinterpret_cast<const f32x4*>(px);
-      if constexpr (need_gn) {
+      if constexpr (need_gn && !gn_tab) {
         const int64_t so = inb ? r_gn[i] + c : (int64_t)0;
         xmu[i] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
         xsc[i] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
       }
     }
   };
-  const __bf16* const wt = static_cast<const __bf16*>(a.w_bf16);
-  const int64_t part_stride = (int64_t)d.Cout * taps * a.cin8;
+  // B: the packed weights are stored in exactly the order the LDS stage wants them --
+  // [column tile of 128][tap][channel tile][part][column][two swizzled k-octets] -- so one slab of
+  // one column tile is ONE contiguous block of NS * 4 KB and a wave's DMA instruction reads 1 KB of
+  // consecutive bytes (8 L2 requests of 128 B instead of 32 of 32 B with a k-contiguous layout:
+  // the L2 request rate, not its byte rate, bounded the loop).  The block of the next slab is
+  // the next NS * 4 KB: the (tap, channel tile) walk of the K loop is the storage order.
+  const char* const wt = static_cast<const char*>(a.w_bf16);
+  const int64_t col_tile_bytes = (int64_t)taps * a.ctiles * (NS * 4096);
+  const char* bsrc[BPIECES];
+#pragma unroll
+  for (int p = 0; p < BPIECES; ++p) {
+    const int slot = tid + 256 * p;
+    const int part = slot / (2 * BN);
+    const int rem = slot - part * (2 * BN);
+    const int gcol = n0 + (rem >> 1);                          // (padded columns hold zeros)
+    bsrc[p] = wt + (gcol >> 7) * col_tile_bytes + (int64_t)kt_begin * (NS * 4096) +
+              (part < NS ? part : 0) * 4096 + (gcol & 127) * 32 + (rem & 1) * 16;
+  }
   auto issue_b = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < BPIECES; ++p) {
       const int slot = tid + 256 * p;
       if (BSLOTS % 256 != 0 && slot >= BSLOTS) break;       // wave-uniform (BSLOTS % 64 == 0)
-      const int part = slot / (2 * BN);
-      const int rem = slot - part * (2 * BN);
-      const int col = rem >> 1;
-      const int oct = (rem & 1) ^ ((col >> 3) & 1);         // logical k-octet held by this slot
-      const int kc = ct * BK + 8 * oct;
-      const bool ok = kc < a.cin8 && (n0 + col) < d.Cout;
-      const void* src =
-          ok ? static_cast<const void*>(wt + part * part_stride +
-                                        ((int64_t)(n0 + col) * taps + kpos) * a.cin8 + kc)
-             : static_cast<const void*>(kZeroChunk);
-      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)bsrc[p],
                                        (lds_void_t*)(Bb + buf * B_ST + 16 * slot), 16, 0, 0);
+      bsrc[p] += NS * 4096;
+    }
+  };
+  // GroupNorm table of channel tile `ctile` -> ring slot `ring` (lanes 0..19 of wave 0)
+  const int n_second = min(n_first + 1, d.N - 1);
+  auto issue_gn = [&](int ring, int ctile) {
+    if constexpr (gn_tab) {
+      if (tid < 20) {
+        const int seg = tid >> 2;
+        const int c = ctile * BK + 4 * (tid & 3);
+        const float* base = seg == 4 ? a.gn_beta
+                                     : ((seg & 1) ? a.gn_sc : a.gn_mu) +
+                                           (int64_t)(seg >= 2 ? n_second : n_first) * d.Cin;
+        const void* src = c < d.Cin ? static_cast<const void*>(base + c)
+                                    : static_cast<const void*>(kZeroChunk);
+        __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                         (lds_void_t*)(Gt + ring * kGnRing + 16 * tid), 16, 0, 0);
+      }
     }
   };
   auto advance = [&]() {
@@ -189,11 +243,17 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
       set_tap();
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int buf, int ring) {
+    const float* const tb = reinterpret_cast<const float*>(Gt + ring * kGnRing);
+    if constexpr (gn_tab) xbeta = *reinterpret_cast<const f32x4*>(tb + 64 + 4 * akq);
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int row = (tid / QPR) + RPP * i;
       f32x4 v = xa[i];
+      if constexpr (gn_tab) {
+        xmu[i] = *reinterpret_cast<const f32x4*>(tb + r_slot[i] * 32 + 4 * akq);
+        xsc[i] = *reinterpret_cast<const f32x4*>(tb + r_slot[i] * 32 + 16 + 4 * akq);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float pv;
@@ -201,33 +261,51 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
           pv = apply_pro<PRO>(v[e], xmu[i][e], xsc[i][e], xbeta[e], d.in_scale, d.in_shift);
         else
           pv = apply_pro<PRO>(v[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
-        v[e] = (xin[i] && (cur_c + e < d.Cin)) ? pv : 0.f;
+        if constexpr (TAIL)
+          v[e] = (xin[i] && (cur_c + e < d.Cin)) ? pv : 0.f;
+        else
+          v[e] = xin[i] ? pv : 0.f;
       }
-      bf16x4 parts[NS];
+      u32x2 parts[NS];
       split_bf16<NS>(v, parts);
       const int oct = (akq >> 1) ^ ((row >> 3) & 1);
       char* dst = Ab + buf * A_ST + row * 32 + oct * 16 + (akq & 1) * 8;
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x4*>(dst + p * A_PART) = parts[p];
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<u32x2*>(dst + p * A_PART) = parts[p];
     }
   };
 
   const int l31 = lane & 31, lhi = lane >> 5;
+  int g_ct = ct;                 // channel tile of the next table to fetch
+  auto next_gct = [&]() { if (++g_ct == a.ctiles) g_ct = 0; };
+  int ring_cur = 0;              // ring slot of the slab being multiplied
   if (kt_begin < kt_end) {
+    if constexpr (gn_tab) {
+      issue_gn(0, g_ct); next_gct();
+      issue_gn(1, g_ct); next_gct();
+    }
     load_a();
     issue_b(0);
     advance();
-    store_a(0);
+    if constexpr (gn_tab) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();           // tables of slabs 0 and 1 visible to every wave
+    }
+    store_a(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
+    const int ring_next = ring_cur == 2 ? 0 : ring_cur + 1;
     if (more) {
       load_a();
       issue_b(cur ^ 1);
       advance();
+      if constexpr (gn_tab) {
+        if (kt + 2 < kt_end) { issue_gn(ring_next == 2 ? 0 : ring_next + 1, g_ct); next_gct(); }
+      }
     }
     const char* as = Ab + cur * A_ST;
     const char* bs = Bb + cur * B_ST;
@@ -264,17 +342,35 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
       SNAP_SPLIT_PRODUCT(0, 0)
     }
 #undef SNAP_SPLIT_PRODUCT
-    if (more) store_a(cur ^ 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the B octets of slab kt+1 landed
+    if (more) store_a(cur ^ 1, ring_next);
+    ring_cur = ring_next;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B octets of slab kt+1 (+ table kt+2) landed
     __syncthreads();
   }
 
   conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
-template <int BM, int BN, int PRO, int NS>
+// ---------------------------------------------------------------------------------------------
+// Deep-pipelined variant (the one every large launch takes): ALL operands travel global -> LDS
+// by LDS-DMA, D slabs ahead of the matrix cores.
+//   * A: the raw f32 im2col chunks (16 B = 4 channels of one pixel) land in a D-stage ring; the
+//     thread that issued a chunk later reads the SAME chunk back (its own vmcnt covers it -- no
+//     barrier), applies the f32 prologue, splits it and writes the NS bf16 images the MFMA
+//     fragments are fetched from (double-buffered, published by the slab's closing barrier).
+//     Out-of-image taps / channel tails fetch a zero chunk and are forced to zero AFTER the
+//     prologue (the reference pads the normalised tensor).
+//   * B: split weights, (D+1)-stage ring.
+//   * GroupNorm operands of the slab's 16 channels: a 320-byte table per WAVE (20 lanes, one DMA;
+//     private copies keep it inside the wave's own vmcnt ordering), D-stage ring.  Needs a row
+//     tile inside <= 2 images (BM <= Ho*Wo); other launches take conv_split_body above.
+// With one slab in flight (the register-staged body) a wave waited out a full memory round trip
+// per 16-k slab: the loop ran at ~30 % of the matrix-pipe rate whatever the product count.
+// (Holding NS = 2 to 128 registers for four workgroups per CU was measured: 1x1 layers +10 %,
+// 3x3 layers -10 %; left at the natural three.)
+template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL>
 __global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
-  conv_split_body<BM, BN, PRO, NS>(a);
+  conv_split_body<BM, BN, PRO, NS, GNT, TAIL>(a);
 }
 
 template <int BM, int BN, int PRO, int NS>
@@ -305,7 +401,17 @@ int launch(ConvArgs a, hipStream_t s) {
       nblocks *= a.ksplit;
     }
   }
-  hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  // the LDS statistics table needs "a row tile touches at most two images"
+  const bool table_ok = !need_gn || (a.d.Ho * a.d.Wo >= BM && !a.rows_in);
+  const bool tail = (a.d.Cin & 3) != 0;
+  const dim3 grid((unsigned)nblocks);
+  if (need_gn && table_ok)           // (GroupNorm operands are per channel QUAD: Cin % 4 == 0)
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, need_gn, false>), grid, dim3(256), 0, s, a);
+  else if (tail)
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, false, true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, false, false>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
   if (a.ksplit > 1) {
     const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
@@ -338,11 +444,14 @@ int launch_tile(const ConvArgs& a, hipStream_t s) {
   return launch_pro<64, 64, NS>(a, s);
 }
 
-// w [taps*Cin, Cout] f32 -> out [parts][Cout][taps][cin8] bf16: part 0 = bf16(w) (RNE), part p =
-// bf16 of the exact f32 residual left by parts 0..p-1; channels Cin..cin8 zero.  One 32 x 32
-// (k x n) tile per workgroup through LDS: coalesced along n on the way in, along k on the way out.
+// w [taps*Cin, Cout] f32 -> the split engine's weight image
+//   out[column tile of 128][tap][channel tile of 16][part][column 0..127][16 k] bf16,
+// the two 8-k octets of a column swapped where (column >> 3) & 1 (the LDS swizzle, applied at
+// rest); part 0 = bf16(w) (RNE), part p = bf16 of the exact f32 residual left by parts < p;
+// channels >= Cin and columns >= Cout are zero.  One 32 x 32 (k x n) tile per workgroup through
+// LDS: coalesced along n on the way in, 64 B runs on the way out.
 __global__ __launch_bounds__(256) void pack_weights_split_kernel(
-    const float* __restrict__ w, __bf16* __restrict__ out, int taps, int Cin, int cin8, int Cout,
+    const float* __restrict__ w, __bf16* __restrict__ out, int taps, int Cin, int ctiles, int Cout,
     int parts) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -353,18 +462,19 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(
     tile[j][tx] = (c < Cin && n < Cout) ? w[((int64_t)t * Cin + c) * Cout + n] : 0.f;
   }
   __syncthreads();
-  const int64_t part_stride = (int64_t)Cout * taps * cin8;
 #pragma unroll
   for (int j = ty; j < 32; j += 8) {
-    const int n = n0 + j, c = c0 + tx;
-    if (n < Cout && c < cin8) {
-      float r = tile[tx][j];
-      __bf16* o = out + ((int64_t)n * taps + t) * cin8 + c;
-      for (int p = 0; p < parts; ++p) {
-        const __bf16 b = (__bf16)r;
-        o[p * part_stride] = b;
-        r -= (float)b;
-      }
+    const int n = n0 + j, c = c0 + tx;          // n < padded Cout, c < 16 * ctiles by the grid
+    if (c >= 16 * ctiles) continue;
+    const int col = n & 127, k = c & 15;
+    const int oct = (k >> 3) ^ ((col >> 3) & 1);
+    const int64_t blk = ((int64_t)(n >> 7) * taps + t) * ctiles + (c >> 4);
+    __bf16* o = out + blk * ((int64_t)parts * 2048) + col * 16 + oct * 8 + (k & 7);
+    float r = tile[tx][j];
+    for (int p = 0; p < parts; ++p) {
+      const __bf16 b = (__bf16)r;
+      o[p * 2048] = b;
+      r -= (float)b;
     }
   }
 }
@@ -379,8 +489,12 @@ int snapconv::launch_split(ConvArgs a, int parts, hipStream_t s) {
 
 extern "C" size_t snap_conv2d_packed_weights_split_bytes(int32_t taps, int32_t Cin, int32_t Cout,
                                                          int32_t parts) {
-  if (parts < 1 || parts > 3) return 0;
-  return (size_t)parts * snap_conv2d_packed_weights_bytes(taps, Cin, Cout);
+  if (parts < 1 || parts > 3 || taps <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const size_t cin16 = ((size_t)Cin + 15) / 16 * 16;
+  const size_t cout128 = ((size_t)Cout + 127) / 128 * 128;
+  const size_t elems = (size_t)parts * cout128 * taps * cin16;
+  if (elems >= ((size_t)1 << 33)) return 0;   // (template banks of the exhaustive voting: f32 engine)
+  return elems * 2;
 }
 
 extern "C" int snap_conv2d_pack_weights_split_bf16(const float* w, int32_t taps, int32_t Cin,
@@ -389,12 +503,15 @@ extern "C" int snap_conv2d_pack_weights_split_bf16(const float* w, int32_t taps,
   if (!w || !out) return SNAP_ERR_NULL;
   if (taps <= 0 || Cin <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
   if (parts < 1 || parts > 3) return SNAP_ERR_UNSUPPORTED;
-  if (out_bytes < snap_conv2d_packed_weights_split_bytes(taps, Cin, Cout, parts)) return SNAP_ERR_WORKSPACE;
+  const size_t need = snap_conv2d_packed_weights_split_bytes(taps, Cin, Cout, parts);
+  if (need == 0) return SNAP_ERR_UNSUPPORTED;
+  if (out_bytes < need) return SNAP_ERR_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(out) & 15) return SNAP_ERR_BAD_SHAPE;
-  const int cin8 = (Cin + 7) / 8 * 8;
-  const dim3 grid((unsigned)snap_cdiv(cin8, 32), (unsigned)snap_cdiv(Cout, 32), (unsigned)taps);
+  const int ctiles = (Cin + 15) / 16;
+  const int cout128 = (Cout + 127) / 128 * 128;
+  const dim3 grid((unsigned)snap_cdiv(16 * ctiles, 32), (unsigned)(cout128 / 32), (unsigned)taps);
   hipLaunchKernelGGL(pack_weights_split_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
-                     w, static_cast<__bf16*>(out), taps, Cin, cin8, Cout, parts);
+                     w, static_cast<__bf16*>(out), taps, Cin, ctiles, Cout, parts);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -41,6 +41,8 @@ class ForwardContext:
 
   def __init__(self):
     self._std = {}
+    from snap_amd import ops
+    ops.PACK_EPOCH += 1        # bf16 weight images are per apply (see ops._packed_weights)
 
   def _lookup(self, kernel):
     hit = self._std.get(id(kernel))

@@ -238,17 +238,17 @@ def conv2d(
     raise ValueError(f'conv2d: math={math!r}')
   family = 'conv_igemm'
   wpk = None
+  parts = SPLIT_PARTS.get(math, 0)
+  if parts and lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts) == 0:
+    math = 'f32'     # weight image beyond the split engine's 32-bit offsets (template banks)
   if math != 'f32' and Cs % 4 == 0 and Cin >= 4:
-    parts = SPLIT_PARTS.get(math, 0)
-    wpk = getattr(w, '_snap_packed', {}).get(math)   # split / rounded once by the caller
-    if wpk is None:
-      wpk = pack_weights_split_bf16(w, parts) if parts else pack_weights_bf16(w)
+    wpk = _packed_weights(w, math, parts)
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.w_bf16 = wpk.data_ptr()
     ex.w_bf16_bytes = wpk.numel() * 2
     ex.w_split_parts = parts
-    family = 'conv_split' if parts else 'conv_bf16'
+    family = f'conv_split_{math}' if parts else 'conv_bf16'
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -285,6 +285,33 @@ def pack_weights_bf16(w):
 
 
 SPLIT_PARTS = {'bf16x3': 2, 'bf16x6': 3}
+# Bumped by every ``ForwardContext`` (= every ``apply``): the bf16 weight images are prepared
+# once per apply and tensor (the map and query passes of one apply share them), never carried
+# from one apply / timed step to the next -- like the StdConv standardisation.
+PACK_EPOCH = 0
+
+
+def _packed_weights(w, math, parts):
+  """The engine's weight image of ``w`` for this apply: an explicit ``w._snap_packed[math]``
+  (tools) wins; otherwise packed at first use and remembered on the tensor for the current
+  ``PACK_EPOCH`` while the tensor is not modified in place."""
+  slot = getattr(w, '_snap_packed', None)
+  if slot is not None:
+    hit = slot.get(math)
+    if hit is not None:
+      if not isinstance(hit, tuple):
+        return hit
+      if hit[0] == PACK_EPOCH and hit[1] == w._version:
+        return hit[2]
+  wpk = pack_weights_split_bf16(w, parts) if parts else pack_weights_bf16(w)
+  if slot is None:
+    slot = {}
+    try:
+      w._snap_packed = slot
+    except AttributeError:
+      return wpk
+  slot[math] = (PACK_EPOCH, w._version, wpk)
+  return wpk
 
 
 def pack_weights_split_bf16(w, parts):
