@@ -153,3 +153,62 @@ def assert_same_argmax(name, got_scores, want_scores, got_index=None, rel=2e-6):
       f'{name}: argmax {gi} vs oracle {wi}; oracle score gap {gap} exceeds near-tie bound {rel}'
   )
   return exact
+
+
+def assert_validity_mismatches_on_borders(name, got_valid, want_valid, scene, xyz_query, stride,
+                                          tol=2e-4, max_view_distance=None):
+  """Boolean voxel validity must equal the oracle's EXCEPT where a float64 re-projection shows the
+  voxel sitting on a visibility boundary of some view: within `tol` feature-map pixels of an image
+  edge, within `tol` of the near plane (z = eps), or within `tol` (relative) of the fisheye FoV
+  limit -- the only places where two correct fp32 evaluations of streetview_encoder.py:42-65 may
+  disagree.  `scene` is the oracle-side scene dict (camera, T_view2scene); `xyz_query` [B,...,3];
+  `stride` = (sy, sx) of the feature level the lift samples.  Returns the mismatch count."""
+  got = np.asarray(got_valid.detach().cpu().numpy() if hasattr(got_valid, 'detach') else got_valid, bool)
+  want = np.asarray(want_valid, bool)
+  assert got.shape == want.shape, f'{name}: shape {got.shape} vs {want.shape}'
+  mism = got != want
+  n = int(mism.sum())
+  if n == 0:
+    return 0
+  B = got.shape[0]
+  f8 = lambda a: np.asarray(a, np.float64)
+  cam, T = scene['camera'], scene['T_view2scene']
+  cam64 = o_geo.FisheyeCamera(f8(cam.wh), f8(cam.f), f8(cam.c), f8(cam.k_radial), f8(cam.max_fov))
+  cam64 = cam64.scale(1.0 / f8(stride)[::-1])
+  R, t = f8(T.R), f8(T.t)
+  pts = f8(xyz_query).reshape(B, -1, 3)
+  flat = mism.reshape(B, -1)
+  worst = 0.0
+  for b in range(B):
+    idx = np.nonzero(flat[b])[0]
+    if len(idx) == 0:
+      continue
+    p = pts[b, idx]                                             # [n, 3]
+    pv = np.einsum('vji,vnj->vni', R[b], p[None] - t[b][:, None])   # R^T (p - t): [V, n, 3]
+    z = pv[..., 2]
+    zc = np.clip(z, cam64.eps, None)
+    xy = pv[..., :2] / zc[..., None]
+    radius = np.sqrt((xy ** 2).sum(-1))
+    theta = np.arctan(np.maximum(radius, 1e-12))
+    k = cam64.k_radial[b][:, None, :]
+    offset = sum(k[..., i] * theta ** (2 * (i + 1)) for i in range(3))
+    dist = np.where(radius < cam64.eps, 1.0, (offset + 1) * theta / np.maximum(radius, 1e-12))
+    uv = xy * dist[..., None] * cam64.f[b][:, None, :] + cam64.c[b][:, None, :]
+    wh = cam64.wh[b][:, None, :]
+    lim = np.tan(0.5 * cam64.max_fov[b])[:, None]
+    margin = np.minimum.reduce([
+        np.abs(uv[..., 0]), np.abs(uv[..., 0] - wh[..., 0]),
+        np.abs(uv[..., 1]), np.abs(uv[..., 1] - wh[..., 1]),
+        np.abs(z - cam64.eps) * 1e3,                           # near plane, in units of eps
+        np.abs(radius - lim) / np.maximum(lim, 1e-12) * 1e2,   # FoV limit (relative, scaled)
+    ])                                                         # [V, n]
+    m = margin.min(0)
+    if max_view_distance is not None:
+      d = np.sqrt(((p[None] - t[b][:, None]) ** 2).sum(-1))    # [V, n]
+      m = np.minimum(m, np.abs(d - max_view_distance).min(0))
+    worst = max(worst, float(m.max()))
+  print(f'[parity] {name:38s} validity mismatches {n} of {got.size}, farthest from a visibility '
+        f'boundary: {worst:.2e} (tol {tol:.0e})')
+  assert worst <= tol, (f'{name}: a voxel whose validity differs from the oracle is {worst:.3e} away '
+                        f'from every visibility boundary (tol {tol})')
+  return n

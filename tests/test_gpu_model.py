@@ -13,17 +13,25 @@ from snap_amd.models import bev_localizer
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg, B, V, img, seed, refine=False):
-  dev = torch.device('cuda')
-  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+def _run(cfg, B, V, img, seed, refine=False, math='f32', extent=(6.4, 6.4, 12), want_batch=False):
+  """One BEVLocalizer forward on the GPU (conv / dense engine `math`) and through the oracle."""
+  from snap_amd import ops
+  dev = torch.device(helpers.DEVICE)
+  meta = synthetic.meta_data(0.2, extent)
   loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
   variables = loc.init(seed, device='cpu')
   batch = synthetic.make_batch(B, meta['grid'], V, img, seed=seed + 1)
-  pred = loc.apply(
-      {'params': helpers.params_to_device(variables['params'], dev)},
-      helpers.batch_to_device(batch, dev), train=False, rngs={'sampling': 11}, debug=True,
-  )
-  torch.cuda.synchronize()
+  prev = ops.MATMUL_PRECISION
+  ops.MATMUL_PRECISION = math
+  try:
+    pred = loc.apply(
+        {'params': helpers.params_to_device(variables['params'], dev)},
+        helpers.batch_to_device(batch, dev), train=False, rngs={'sampling': 11}, debug=True,
+    )
+    if dev.type == 'cuda':
+      torch.cuda.synchronize()
+  finally:
+    ops.MATMUL_PRECISION = prev
   samples = pred['map_t_query_samples']
   ps = o_geo.Transform2D(samples.angle[:, 1:].cpu().numpy(), samples.t[:, 1:].cpu().numpy())
   ref = o_model.bev_localizer(
@@ -31,13 +39,27 @@ def _run(cfg, B, V, img, seed, refine=False):
       o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch),
       pose_samples=ps, keep_sim=True,
   )
+  if want_batch:
+    return pred, ref, helpers.batch_to_oracle(batch), meta
   return pred, ref
 
 
+def _check_validity(name, pred_side, ref_side, scene, cfg):
+  """Voxel validity: identical to the oracle except on visibility boundaries (see helper)."""
+  sv, rsv = pred_side['streetview'], ref_side['streetview']
+  stride = np.asarray(rsv['image_feature_pyramid']['strides'][-1]).reshape(-1, 2)[0]
+  xyz = ref_side.get('_xyz_query')
+  return helpers.assert_validity_mismatches_on_borders(
+      name, sv['feature_volume'].valid, rsv['feature_volume']['valid'], scene, xyz, stride,
+      max_view_distance=cfg.bev_mapper.streetview_encoder.get('max_view_distance'))
+
+
+# every engine the bench can select must hold the same parity bar
+@pytest.mark.parametrize('math', ['f32', 'bf16x6', 'bf16x3'])
 @pytest.mark.parametrize('top_k,V', [(2, 3), (4, 3)])
-def test_localizer_forward_parity(top_k, V):
+def test_localizer_forward_parity(top_k, V, math):
   cfg = helpers.tiny_localizer_config(top_k=top_k)
-  pred, ref = _run(cfg, 2, V, (64, 64), seed=0)
+  pred, ref, ob, _ = _run(cfg, 2, V, (64, 64), seed=0, math=math, want_batch=True)
   sv, rsv = pred['map']['streetview'], ref['map']['streetview']
   # feature maps: north-star tolerance 1e-3 (fp32); observed ~1e-5.
   helpers.report('image features', sv['image_feature_pyramid'].features[-1],
@@ -45,7 +67,8 @@ def test_localizer_forward_parity(top_k, V):
   vg = sv['feature_volume'].valid.cpu().numpy()
   vw = rsv['feature_volume']['valid']
   mism = vg != vw
-  assert mism.mean() < 2e-3
+  _check_validity('map voxel validity', pred['map'], ref['map'], ob['map'], cfg)
+  _check_validity('query voxel validity', pred['query'], ref['query'], ob['query'], cfg)
   helpers.report('feature volume', sv['feature_volume'].features.cpu().numpy()[~mism],
                  rsv['feature_volume']['features'][~mism], atol=1e-3)
   helpers.report('aerial plane', pred['map']['aerial']['feature_plane'].features,

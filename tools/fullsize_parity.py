@@ -79,6 +79,56 @@ def compare(pred, ref, args, t_hip, t_cpu):
   return out
 
 
+def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
+  """HIP forward of one C2 scene per engine in `maths` + ONE oracle run; returns
+  {'per_math': {engine: deviations}, 'pred': {engine: pred}, 'ref': oracle pred, ...}."""
+  from snap_amd import ops
+  from snap_amd.utils import geometry as _geo
+  dev = torch.device('cuda')
+  cfg = train_localization.get_config().model
+  if eval_mode:
+    from snap_amd.configs import eval_localization
+    cfg.update(eval_localization.get_config().model)
+  meta = synthetic.meta_data(0.2, (25.6, 25.6, 12))
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
+  variables = loc.init(0, device='cpu')
+  batch = synthetic.make_batch(1, meta['grid'], views, (image, image), seed=seed)
+  params_dev = helpers.params_to_device(variables['params'], dev)
+  batch_dev = helpers.batch_to_device(batch, dev)
+  preds, t_hip = {}, {}
+  inject = None
+  prev = ops.MATMUL_PRECISION
+  try:
+    for math in maths:
+      ops.MATMUL_PRECISION = math
+      t0 = time.perf_counter()
+      # every engine scores the SAME hypotheses (those the first engine's sampler drew), so that
+      # one oracle run checks all of them
+      preds[math] = loc.apply({'params': params_dev}, batch_dev, train=False, rngs={'sampling': 11},
+                              debug=True, pose_samples=inject)
+      torch.cuda.synchronize()
+      t_hip[math] = time.perf_counter() - t0
+      if inject is None:
+        smp = preds[math]['map_t_query_samples']
+        inject = _geo.Transform2D(smp.angle[:, 1:].contiguous(), smp.t[:, 1:].contiguous())
+  finally:
+    ops.MATMUL_PRECISION = prev
+  ps = o_geo.Transform2D(inject.angle.cpu().numpy(), inject.t.cpu().numpy())
+  t0 = time.perf_counter()
+  ob = helpers.batch_to_oracle(batch)
+  ref = o_model.bev_localizer(
+      helpers.params_to_numpy(variables['params']), cfg, {'streetview_hfov_deg': 72.0},
+      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), ob, pose_samples=ps, keep_sim=False)
+  t_cpu = time.perf_counter() - t0
+
+  class _A:   # the fields compare() reads
+    pass
+  args = _A()
+  args.views, args.image, args.eval = views, image, eval_mode
+  results = {m: compare(preds[m], ref, args, t_hip[m], t_cpu) for m in maths}
+  return {'per_math': results, 'pred': preds, 'ref': ref, 'oracle_batch': ob, 'cfg': cfg}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--out', default=None)
@@ -89,46 +139,9 @@ def main():
   ap.add_argument('--eval', action='store_true',
                   help='eval_localization.py overrides: 20 000 hypotheses + the 41^3 refinement lattice')
   args = ap.parse_args()
-  dev = torch.device('cuda')
-  cfg = train_localization.get_config().model
-  if args.eval:
-    from snap_amd.configs import eval_localization
-    cfg.update(eval_localization.get_config().model)
-  meta = synthetic.meta_data(0.2, (25.6, 25.6, 12))
-  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
-  variables = loc.init(0, device='cpu')
-  batch = synthetic.make_batch(1, meta['grid'], args.views, (args.image, args.image), seed=21)
-  from snap_amd import ops
-  params_dev = helpers.params_to_device(variables['params'], dev)
-  batch_dev = helpers.batch_to_device(batch, dev)
   maths = args.math.split(',')
-  preds, t_hip = {}, {}
-  inject = None
-  for math in maths:
-    ops.MATMUL_PRECISION = math
-    t0 = time.perf_counter()
-    # every engine scores the SAME hypotheses (those the first engine's sampler drew), so that
-    # one oracle run checks all of them
-    preds[math] = loc.apply({'params': params_dev}, batch_dev, train=False, rngs={'sampling': 11},
-                            debug=True, pose_samples=inject)
-    torch.cuda.synchronize()
-    t_hip[math] = time.perf_counter() - t0
-    if inject is None:
-      smp = preds[math]['map_t_query_samples']
-      from snap_amd.utils import geometry as _geo
-      inject = _geo.Transform2D(smp.angle[:, 1:].contiguous(), smp.t[:, 1:].contiguous())
-  ops.MATMUL_PRECISION = 'f32'
-  ps = o_geo.Transform2D(inject.angle.cpu().numpy(), inject.t.cpu().numpy())
-  t0 = time.perf_counter()
-  ref = o_model.bev_localizer(
-      helpers.params_to_numpy(variables['params']), cfg, {'streetview_hfov_deg': 72.0},
-      o_grids.Grid2D(meta['grid'].extent[:2], 0.2), helpers.batch_to_oracle(batch),
-      pose_samples=ps, keep_sim=False)
-  t_cpu = time.perf_counter() - t0
-  results = {}
-  for math in maths:
-    results[math] = compare(preds[math], ref, args, t_hip[math], t_cpu)
-  out = results[maths[0]] if len(maths) == 1 else {'per_math': results}
+  res = run(maths, args.views, args.image, args.eval)
+  out = res['per_math'][maths[0]] if len(maths) == 1 else {'per_math': res['per_math']}
   line = json.dumps(out)
   print(line)
   if args.out:
