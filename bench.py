@@ -57,6 +57,11 @@ WORKLOADS = {
                desc='C5: ViT-B/16 StreetView image encoder (bf16 matrix-core GEMMs + fused attention; '
                     'not in the reference: build-only), ResNet-50 aerial, 128x128x60 voxel BEV, '
                     'batch 32 over 8 GPUs = 4 scenes/GPU, forward'),
+    'c4': dict(batch=1, c4=True, tiny=False,
+               desc='C4: eval_localization pose-estimation path on a 256x256 BEV map (D = 32): exhaustive '
+                    '(x, y, theta) voting with 36 yaw hypotheses (rotated templates + direct correlation, '
+                    '[36, 511, 511] scores) + point-vs-map similarity for the 4652 frustum points + scoring '
+                    'of 20 001 pose hypotheses + the 41^3 refinement lattice; one scene per step'),
     'tiny': dict(batch=2, views=3, image=64, grid=(6.4, 6.4, 12), tiny=True,
                  desc='tiny plumbing workload (tests only)'),
 }
@@ -84,6 +89,59 @@ def build(workload, device, rank):
       device=device,
   )
   return loc, cfg, meta, variables, batch
+
+
+def build_c4(device, rank):
+  """Synthetic 256^2 planes for the eval pose-estimation path (unit-norm random
+  features smoothed with a 2-cell Gaussian so that the correlation peak is unique)."""
+  import math
+  from snap_amd.models import pose_exhaustive_voting as pev
+  from snap_amd.models import pose_estimation
+  from snap_amd.models import types
+  from snap_amd.utils import geometry, grids
+  H, D, R, P, cell = 256, 32, 36, 20001, 0.2
+  g = torch.Generator(device='cpu').manual_seed(300 + rank)
+
+  def plane():
+    f = torch.randn(1, D, H, H, generator=g)
+    k = torch.exp(-(torch.arange(-6, 7).float() ** 2) / (2 * 2.0 ** 2))
+    k = k / k.sum()
+    f = torch.nn.functional.conv2d(f, k.reshape(1, 1, 13, 1).expand(D, 1, 13, 1), padding=(6, 0), groups=D)
+    f = torch.nn.functional.conv2d(f, k.reshape(1, 1, 1, 13).expand(D, 1, 1, 13), padding=(0, 6), groups=D)
+    f = torch.nn.functional.normalize(f[0].permute(1, 2, 0), dim=-1)
+    return f.contiguous().to(device)
+
+  fm, fqp = plane(), plane()
+  ones = torch.ones(H, H, dtype=torch.bool, device=device)
+  grid = grids.Grid2D((H, H), cell)
+  _, _, q_xy_p = bev_localizer.build_query_frustum_grid(cell, 16.0, True, 72.0)
+  q_xy = q_xy_p[:, 0].to(device)[None].contiguous()                    # [1, 4652, 2]
+  Nq = q_xy.shape[1]
+  fq = torch.nn.functional.normalize(torch.randn(1, Nq, D, generator=g), dim=-1).to(device)
+  poses = torch.stack([torch.rand(1, P, generator=g) * 2 * math.pi,
+                       torch.rand(1, P, generator=g) * H * cell,
+                       torch.rand(1, P, generator=g) * H * cell], -1).to(device).contiguous()
+  vq = torch.ones(1, Nq, dtype=torch.bool, device=device)
+  nv = torch.full((1,), float(Nq), device=device)
+  scale = math.exp(2.0)
+
+  # SURVEY 8(d): k15 direct-form flops and algorithmic bytes at 256^2, R = 36, Dm = 32
+  algo = dict(voting_flops=2.0 * R * (2 * H - 1) ** 2 * H * H * D,
+              voting_bytes=4.0 * (R * H * H * D + H * H * D + R * (2 * H - 1) ** 2) + (R * H * H + H * H),
+              scoring_bytes=4.0 * Nq * H * H)
+
+  def step(i):
+    # (the outer region times the WHOLE voting call: rotate, pad, stack, correlate, count, finalize)
+    with ops._region('exhaustive_voting_total', algo['voting_flops'], algo['voting_bytes']):
+      votes = pev.exhaustive_pose_voting(types.FeaturePlane(fqp, ones), types.FeaturePlane(fm, ones), R, grid)
+    sim, _, _, _ = ops.sim_softmax(fq, fm[None], scale, True, nv)
+    scores = ops.pose_score(sim, poses, q_xy, vq, ones[None], cell)
+    best = ops.argmax_rows(scores).to(torch.int64)
+    init = geometry.Transform2D.from_packed(poses[torch.arange(1, device=device), best])
+    refined, lattice = pose_estimation.grid_refinement_batched(init, sim, q_xy, vq, ones[None], grid, False)
+    return dict(votes=votes, scores_poses=scores, map_t_query=refined, scores_grid_refine=lattice)
+
+  return step, algo
 
 
 def _to(tree, device):
@@ -296,7 +354,14 @@ def main(argv=None):
   if world > 1:
     dist.init_process_group(args.dist_backend or ('nccl' if use_cuda else 'gloo'))
 
-  loc, cfg, meta, variables, batch = build(args.workload, device, rank)
+  is_c4 = bool(WORKLOADS[args.workload].get('c4'))
+  if is_c4:
+    if args.mode != 'infer':
+      raise SystemExit('--workload c4 is an inference (eval) path')
+    c4_step, c4_algo = build_c4(device, rank)
+    loc = cfg = meta = variables = batch = None
+  else:
+    loc, cfg, meta, variables, batch = build(args.workload, device, rank)
   scenes_per_rank = WORKLOADS[args.workload]['batch']
 
   if args.mode == 'train':
@@ -313,6 +378,9 @@ def main(argv=None):
                                           precision=args.precision)
       last_logs.update(logs)
       return logs
+  elif is_c4:
+    ops.MATMUL_PRECISION = args.math     # the correlation runs on the selected conv engine
+    step = c4_step
   else:
     ops.MATMUL_PRECISION = args.math
 
@@ -396,11 +464,12 @@ def main(argv=None):
             'global_batch': scenes_per_rank * world,
             'parallelism': (f'scene-sharded x{world}, no data-path collective' if args.mode == 'infer'
                             else f'dp{world}: scene-sharded, RCCL gradient all-reduce'),
-            'mode': ('inference forward (BEVLocalizer.apply, train=False)' if args.mode == 'infer' else
+            'mode': ('exhaustive voting + similarity + pose scoring + grid refinement (eval path)' if is_c4 else
+                     'inference forward (BEVLocalizer.apply, train=False)' if args.mode == 'infer' else
                      f'train_step: forward + backward + gradient all-reduce + Adam ({args.precision})'),
         },
     }
-    if args.mode == 'infer':
+    if args.mode == 'infer' and not is_c4:
       # share of voxels seen by at least one camera: the fusion MLP multiplies only those
       # rows (the others are masked to zero by the reference too), so the step time
       # depends on it -- stated here so the number can be judged against the data.
@@ -421,7 +490,7 @@ def main(argv=None):
             'tflops': round(s['flops'] / ms / 1e9, 2),
             'gbs': round(s['bytes'] / ms / 1e6, 1),
         }
-      dom = max(summ, key=lambda k: summ[k]['ms'])
+      dom = max((k for k in summ if k != 'exhaustive_voting_total'), key=lambda k: summ[k]['ms'])
       s = summ[dom]
       if s['flops'] > 0:
         ach = s['flops'] / s['ms'] / 1e9
@@ -462,6 +531,29 @@ def main(argv=None):
             'bytes_per_launch': s['bytes'] / s['launches'],
         }
       out['kernels'] = kern
+      if is_c4:
+        # the direct-form correlation is MFMA-bound (AI ~ 1e5 flop/B); report BOTH the
+        # matrix-core fraction on its direct-form flops and the HBM fraction its algorithmic bytes
+        # would need (what an FFT formulation would be held to)
+        conv = [n for n in summ if n.startswith('conv_')]
+        vms = summ.get('exhaustive_voting_total', {}).get('ms', 0.0)
+        kern.pop('exhaustive_voting_total', None)
+        if vms > 0:
+          nprod = max([SPLIT_PRODUCTS.get(n, 0) for n in conv] + [0])
+          peak = PEAK_MFMA_BF16_TFLOPS / nprod if nprod else PEAK_MFMA_F32_TFLOPS
+          ach = c4_algo['voting_flops'] / vms / 1e9
+          out['roofline'] = {
+              'kernel': 'exhaustive_voting (templates + correlation engine ' + '/'.join(conv) + ')',
+              'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+              'frac': round(ach / peak, 4), 'traffic': None, 'ms': round(vms, 3),
+              'formulation': 'direct form (as the reference: jax.scipy.signal.convolve), shift-stacked',
+              'flops_direct_form': c4_algo['voting_flops'],
+          }
+          gbs = c4_algo['voting_bytes'] / vms / 1e6
+          out['roofline_voting_hbm'] = {
+              'kernel': 'exhaustive_voting', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
+              'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5), 'algorithmic_bytes': c4_algo['voting_bytes'],
+              'note': 'algorithmic bytes of SURVEY 8(d); only a frequency-domain formulation is HBM-bound'}
       dump = os.environ.get('SNAP_BENCH_DUMP')
       if dump:
         with open(dump, 'w') as f:
@@ -469,7 +561,7 @@ def main(argv=None):
     if args.mode == 'train':
       out['train_logs'] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in last_logs.items()}
     if (world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']
-        and not WORKLOADS[args.workload].get('vit') and args.mode == 'infer'):
+        and not WORKLOADS[args.workload].get('vit') and args.mode == 'infer' and not is_c4):
       try:
         # a whole scene where the host is big enough to finish it in ~20-30 s (the GPU box: 256
         # cores); the bounded-sample estimate elsewhere

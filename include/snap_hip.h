@@ -142,6 +142,21 @@ size_t snap_conv2d_packed_weights_split_bytes(int32_t taps, int32_t Cin, int32_t
 int snap_conv2d_pack_weights_split_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
                                         int32_t parts, void* out, size_t out_bytes, void* stream);
 
+/* Generic N-D grid operators (snap/utils/grids.py:116-153); n = 1..3 leading grid axes.
+ * snap_interpolate_nd_f32: array [size..., D], points [K, n] in corner-origin coordinates (cell
+ * centres at k + 0.5), optional valid_array [size...] -> values [K, D], valid [K]:
+ * jax.scipy.ndimage.map_coordinates(order=1, mode='nearest') per channel after the -0.5 shift
+ * (:129-130); valid = 0 <= p < size on every axis AND no tap -- not even a zero-weight one --
+ * is invalid (the 0 * NaN mask of :131-136).  `size` is a HOST array.
+ * snap_expectation_nd_f32: pdf [rows, size...] -> out [rows, n] = sum_cells index(cell) pdf(cell)
+ * (:148-153; deterministic fixed-order sums).  argmax_nd (:140-145) = snap_argmax_rows_f32 over
+ * the flattened grid + GridND.id_to_index on the host side. */
+int snap_interpolate_nd_f32(const float* array, const int32_t* size, int32_t n, int32_t D,
+                            const uint8_t* valid_array, const float* points, int64_t K,
+                            float* values, uint8_t* valid, void* stream);
+int snap_expectation_nd_f32(const float* pdf, int64_t rows, const int32_t* size, int32_t n,
+                            float* out, void* stream);
+
 /* Semantic-raster embedding (snap/models/semantic_raster_encoder.py:63-79).  rasters [M, N]
  * uint8 (bool); idx_road / idx_other: HOST arrays with the raster channels of the mutually
  * exclusive surfel-road classes and of the independent binary classes (<= 32 each);
@@ -335,6 +350,22 @@ int snap_sim_softmax_f32(const float* fq, const float* fm, int32_t B, int32_t Nq
                          float* sim, float* chunk_stats, float* prob,
                          float* rowstats, void* stream);
 
+/* add_confidence_query (bev_localizer.py:165-168): the 1 / num_valid normalisation of sim (and
+ * prob) is replaced by per-point weights row_weight[B, Nq] = layers.masked_softmax(bev_confidence
+ * of the query points, valid points).  row_weight == NULL is snap_sim_softmax_f32. */
+int snap_sim_softmax_weighted_f32(const float* fq, const float* fm, int32_t B, int32_t Nq,
+                                  int32_t XY, int32_t Dm, float scale, int32_t clip_negative,
+                                  const float* num_valid, const float* row_weight, float* sim,
+                                  float* chunk_stats, float* prob, float* rowstats, void* stream);
+/* layers.masked_softmax over the last axis (snap/models/layers.py:38-43: an all-false mask acts
+ * as all-true) of x [B, N] + its inclusive CDF (the sampler's distribution over query points). */
+int snap_masked_softmax_rows_f32(const float* x, const uint8_t* mask, int32_t B, int32_t N,
+                                 float* weights, float* cdf, void* stream);
+/* bev_confidence = where(valid, log_sigmoid(features . w + bias), 0)  (Dense(1) head of the BEV
+ * plane, bev_mapper.py:154-157,292-295).  features [M, D], D % 4 == 0; valid may be NULL. */
+int snap_confidence_head_f32(const float* features, const uint8_t* valid, const float* w, float bias,
+                             int64_t M, int32_t D, float* out, void* stream);
+
 /* Draw S correspondences per scene ~ prob_points (iid categorical; counter-based
  * Philox4x32-10 keyed by (seed, b, s)).  corr[B,S,3] = (n, i, j).
  * If uniforms != NULL ([B,S,2] in [0,1)), they replace the Philox draws (tests). */
@@ -348,6 +379,13 @@ int snap_ransac_sample_f32(const float* fq, const float* fm,
  * prefix of the chunk masses is built once per row instead of once per sample (~34 samples
  * share a row at the default sizes).  Bit-identical output. */
 size_t snap_ransac_sample_workspace_bytes(int32_t B, int32_t Nq);
+/* ... with row_cdf [B, Nq] (inclusive, from snap_masked_softmax_rows_f32) the query point of a
+ * sample is drawn from that distribution instead of uniformly (confidence-weighted prob_points). */
+int snap_ransac_sample_rows_f32(const float* fq, const float* fm, const float* chunk_stats,
+                                const float* row_cdf, int32_t B, int32_t Nq, int32_t X, int32_t Y,
+                                int32_t Dm, float scale, int32_t clip_negative, int32_t S,
+                                uint64_t seed, const float* uniforms, int32_t* corr,
+                                void* workspace, size_t workspace_bytes, void* stream);
 int snap_ransac_sample_ws_f32(const float* fq, const float* fm, const float* chunk_stats,
                               int32_t B, int32_t Nq, int32_t X, int32_t Y, int32_t Dm,
                               float scale, int32_t clip_negative, int32_t S, uint64_t seed,

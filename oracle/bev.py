@@ -21,6 +21,15 @@ def masked_softmax(x, where, axis=-1):
   return e / e.sum(axis, keepdims=True)
 
 
+def layers_masked_softmax(x, mask, axis=-1):
+  """snap/models/layers.py:38-43: an all-false mask acts as all-true; masked entries -> -inf."""
+  valid = mask.any(axis=axis, keepdims=True)
+  mask = np.where(valid, mask, True)
+  xm = np.where(mask, x, -np.inf)
+  e = np.exp(xm - xm.max(axis=axis, keepdims=True))
+  return e / e.sum(axis=axis, keepdims=True)
+
+
 def vertical_pooling(config, features, valid, params=None):
   """bev_mapper.py:56-88.
 
@@ -152,6 +161,12 @@ def bev_mapper(params, config, grid, data):
   pred['bev_features'] = plane = fuse_neural_maps(config, planes)
   if config.get('matching_dim') is not None:
     pred['bev_matching'] = matching_head(params, config, plane)
+  if config.get('add_confidence'):
+    # bev_mapper.py:292-295
+    head = params['confidence_head']['layers_0']
+    scores = (plane['features'] @ head['kernel'])[..., 0] + head['bias'][0]
+    conf = log_sigmoid(scores.astype(np.float32))
+    pred['bev_confidence'] = np.where(plane['valid'], conf, 0).astype(np.float32)
   pred['_xyz_query'] = data.get('xyz_query')
   return pred
 

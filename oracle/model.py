@@ -61,9 +61,15 @@ def bev_localizer(params, config, scene_config, grid_map, data,
   f_p_q = plane_q['features'].reshape(B, -1, plane_q['features'].shape[-1])
 
   temperature = params['temperature'] if config['add_temperature'] else None
+  conf_weights = None
+  if config.get('add_confidence_query'):
+    # bev_localizer.py:165-168
+    conf_p = pred['query']['bev_confidence'].reshape(B, -1)
+    conf_weights = bev.layers_masked_softmax(conf_p, valid_points, -1)[..., None, None]
+    pred['_conf_weights'] = conf_weights[..., 0, 0]
   sim, prob = pose.similarity(
       f_p_q, plane_map['features'], valid_points, temperature,
-      config['clip_negative_scores'],
+      config['clip_negative_scores'], conf_weights,
   )
   if keep_sim:
     pred['_sim_points'] = sim

@@ -68,6 +68,8 @@ SIGNATURES = {
     'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_interpolate_nd_f32': (c_int, [ptr, ptr, c_int, c_int, ptr, ptr, c_i64, ptr, ptr, ptr]),
+    'snap_expectation_nd_f32': (c_int, [ptr, c_i64, ptr, c_int, ptr, ptr]),
     'snap_semantic_embed_f32': (
         c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, ptr, c_int, ptr, ptr]),
     'snap_semantic_onehot_f32': (c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, c_int, ptr]),
@@ -124,6 +126,18 @@ SIGNATURES = {
         c_int,
         [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr,
          ptr, ptr, ptr],
+    ),
+    'snap_sim_softmax_weighted_f32': (
+        c_int,
+        [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr,
+         ptr, ptr, ptr],
+    ),
+    'snap_masked_softmax_rows_f32': (c_int, [ptr, ptr, c_int, c_int, ptr, ptr, ptr]),
+    'snap_confidence_head_f32': (c_int, [ptr, ptr, ptr, c_float, c_i64, c_int, ptr, ptr]),
+    'snap_ransac_sample_rows_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+         c_int, c_u64, ptr, ptr, ptr, c_size, ptr],
     ),
     'snap_ransac_sample_f32': (
         c_int,

@@ -255,3 +255,44 @@ extern "C" int snap_plane_fuse_match_f32(const float* const* planes, const uint8
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// Confidence head of the BEV plane (snap/models/bev_mapper.py:154-157,292-295):
+//   bev_confidence = where(valid, log_sigmoid(Dense(1)(features)), 0)
+// One half-wave per cell (float4 per lane, D <= 128 ... any multiple of 4 by striding),
+// log_sigmoid(s) = min(s, 0) - log1p(exp(-|s|))  (== -softplus(-s), stable).
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void confidence_head_kernel(
+    const float* __restrict__ f, const uint8_t* __restrict__ valid, const float* __restrict__ w,
+    float bias, int64_t M, int D, float* __restrict__ out) {
+  const int hl = threadIdx.x & 31;
+  const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (m >= M) return;
+  float acc = 0.f;
+  for (int c = 4 * hl; c < D; c += 128) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(f + m * D + c);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+    acc += ((x[0] * ww[0] + x[1] * ww[1]) + x[2] * ww[2]) + x[3] * ww[3];
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 32);
+  if (hl == 0) {
+    const float s = acc + bias;
+    const float ls = fminf(s, 0.f) - log1pf(expf(-fabsf(s)));
+    out[m] = (valid == nullptr || valid[m]) ? ls : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int snap_confidence_head_f32(const float* features, const uint8_t* valid, const float* w,
+                                        float bias, int64_t M, int32_t D, float* out, void* stream) {
+  if (!features || !w || !out) return SNAP_ERR_NULL;
+  if (M <= 0 || D <= 0 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(features) | reinterpret_cast<uintptr_t>(w)) & 15) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(confidence_head_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), features, valid, w, bias, M, D, out);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

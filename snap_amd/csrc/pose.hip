@@ -34,7 +34,8 @@ template <int DM, int MODE>
 __global__ __launch_bounds__(256) void sim_kernel(
     const float* __restrict__ fq, const float* __restrict__ fm, int Nq, int XY, float scale,
     int clip, const float* __restrict__ num_valid, float* __restrict__ sim,
-    float* __restrict__ stats, const float* __restrict__ rowstats, float* __restrict__ prob) {
+    float* __restrict__ stats, const float* __restrict__ rowstats, float* __restrict__ prob,
+    const float* __restrict__ row_weight) {
   __shared__ float q_s[SIM_TQ * DM];
   const int b = blockIdx.z;
   const int n0 = blockIdx.y * SIM_TQ;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void sim_kernel(
   }
   __syncthreads();
   const float nv = num_valid[b];
+  const float rnv = 1.0f / nv;      // sim = x * (1 / num_valid): one rounding away from x / num_valid
   const int rows = min(SIM_TQ, Nq - n0);
   for (int r0 = 0; r0 < rows; r0 += 2) {
     f32x2 dot2 = {0.f, 0.f};
@@ -78,8 +80,11 @@ __global__ __launch_bounds__(256) void sim_kernel(
       const float dot = h ? dot2.y : dot2.x;
       float x = clip ? fmaxf(dot, 0.f) : dot;
       x *= scale;
+      // bev_localizer.py:165-172: confidence weights (masked softmax over the query points)
+      // replace the 1 / num_valid normalisation when add_confidence_query is set
+      const float wrow = row_weight ? row_weight[row] : rnv;
       if (MODE == 0) {
-        if (cvalid) sim[row * XY + cell] = x / nv;
+        if (cvalid) sim[row * XY + cell] = x * wrow;
         const float m = wave_max(cvalid ? x : -INFINITY);
         const float s = wave_sum(cvalid ? expf(x - m) : 0.f);
         if (lane == 0 && chunk < NC) {
@@ -88,9 +93,208 @@ __global__ __launch_bounds__(256) void sim_kernel(
         }
       } else {
         const float M = rowstats[row * 2 + 0], T = rowstats[row * 2 + 1];
-        if (cvalid) prob[row * XY + cell] = (expf(x - M) / T) / nv;
+        if (cvalid) prob[row * XY + cell] = row_weight ? (expf(x - M) / T) * wrow : (expf(x - M) / T) / nv;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k10 on the f32 matrix cores (MODE 0 of the kernel above: sim + chunk statistics).
+// D[n, cell] = sum_k fq[n, k] fm[cell, k] as 32x32x2 f32 MFMAs (each the exact k-ordered fmaf
+// chain the VALU kernel runs, so sim and the sampler's re-evaluation keep their bits).
+// grid as above; a wave owns the 64 cells of one softmax chunk (B operand, held in registers for
+// the whole tile) and the tile's 64 query rows (A operand): 2 x 2 tiles of 32 x 32, DM / 2 MFMAs
+// each.  Neither operand touches LDS: lane (l31, lhi) of an MFMA holds element k = 2 j + lhi of
+// row / column l31, picked out of the lane's own contiguous DM-vector.  Epilogue straight from the
+// accumulators: a register holds, per half-wave, 32 consecutive cells of one query row -> one
+// 128-byte line per half-wave and store; the chunk's (max, sum exp) pair is a half-wave
+// reduction (4 DPP row rotates + one cross-row exchange).
+// The VALU kernel was bound by its packed-FMA issue (97 % VALU busy, 1.65 ms at C2 for a
+// 2.44 GB write that the HBM can take in 0.4 ms).
+// ---------------------------------------------------------------------------
+template <int DM>
+__device__ __forceinline__ void sim_load_operand(const float* __restrict__ row, bool valid, int lhi,
+                                                 float (&out)[DM / 2]) {
+  if (!valid) {
+#pragma unroll
+    for (int j = 0; j < DM / 2; ++j) out[j] = 0.f;
+    return;
+  }
+  const f32x4* src = reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+  for (int q = 0; q < DM / 4; ++q) {
+    const f32x4 t = src[q];
+    out[2 * q] = lhi ? t[1] : t[0];
+    out[2 * q + 1] = lhi ? t[3] : t[2];
+  }
+}
+
+__device__ __forceinline__ float half_wave_max(float v) {
+  v = fmaxf(v, snap_dpp<0x128>(v));
+  v = fmaxf(v, snap_dpp<0x124>(v));
+  v = fmaxf(v, snap_dpp<0x122>(v));
+  v = fmaxf(v, snap_dpp<0x121>(v));
+  return fmaxf(v, __shfl_xor(v, 16, 64));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += snap_dpp<0x128>(v);
+  v += snap_dpp<0x124>(v);
+  v += snap_dpp<0x122>(v);
+  v += snap_dpp<0x121>(v);
+  return v + __shfl_xor(v, 16, 64);
+}
+
+template <int DM>
+__global__ __launch_bounds__(256) void sim_mfma_kernel(
+    const float* __restrict__ fq, const float* __restrict__ fm, int Nq, int XY, float scale,
+    int clip, const float* __restrict__ num_valid, float* __restrict__ sim,
+    float* __restrict__ stats, const float* __restrict__ row_weight) {
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * SIM_TQ;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int chunk = blockIdx.x * 4 + wave;
+  const int cell0 = chunk * SIM_CH;
+  const int NC = (XY + SIM_CH - 1) / SIM_CH;
+  if (cell0 >= XY) return;                      // (whole wave; no barrier in this kernel)
+  float bq[2][DM / 2], aq[2][DM / 2];
+  bool cv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int cell = cell0 + 32 * t + l31;
+    cv[t] = cell < XY;
+    sim_load_operand<DM>(fm + ((int64_t)b * XY + (cv[t] ? cell : 0)) * DM, cv[t], lhi, bq[t]);
+    const int row = n0 + 32 * t + l31;
+    sim_load_operand<DM>(fq + ((int64_t)b * Nq + (row < Nq ? row : 0)) * DM, row < Nq, lhi, aq[t]);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < DM / 2; ++j)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ti][j], bq[tj][j], acc[ti][tj], 0, 0, 0);
+  // Epilogue through a per-wave LDS tile (32 rows x 64 cells, one ti at a time): the MFMA C
+  // layout gives a lane ONE cell of 16 rows -- 64 dword stores per tile, and narrow stores are
+  // issue-bound.  Staged, 16 lanes own one query row's 64 cells as float4: a wave store covers
+  // four 256-byte row segments with dwordx4 (8 stores per ti instead of 32), and the chunk's
+  // (max, sum exp) is a reduction inside one 16-lane DPP row.
+  __shared__ __attribute__((aligned(16))) float stage[4][32][64 + 4];   // +4: rows 4 apart hit distinct banks
+  float (*st)[64 + 4] = stage[wave];
+  const float rnv = 1.0f / num_valid[b];   // as the VALU kernel: the two stay bit-identical
+  const int sub = lane >> 4;            // row within a 4-row pass
+  const int c4 = (lane & 15) * 4;       // first of the lane's 4 cells
+  const int ncell = XY - cell0;         // live cells of this chunk (>= 1)
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        st[(r & 3) + 8 * (r >> 2) + 4 * lhi][32 * tj + l31] = acc[ti][tj][r];   // MFMA C layout
+    // (the tile is private to the wave: LDS ops of one wave complete in order, no barrier)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int rr = 4 * p + sub;
+      const int n = n0 + 32 * ti + rr;
+      const bool live = n < Nq;
+      const int64_t row = (int64_t)b * Nq + (live ? n : 0);
+      const float wrow = row_weight ? row_weight[row] : rnv;
+      f32x4 x = *reinterpret_cast<const f32x4*>(&st[rr][c4]);
+      float m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (clip) x[e] = fmaxf(x[e], 0.f);
+        x[e] *= scale;
+        if (c4 + e < ncell) m = fmaxf(m, x[e]);
+      }
+      m = fmaxf(m, snap_dpp<0x128>(m));
+      m = fmaxf(m, snap_dpp<0x124>(m));
+      m = fmaxf(m, snap_dpp<0x122>(m));
+      m = fmaxf(m, snap_dpp<0x121>(m));
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c4 + e < ncell) sum += __expf(x[e] - m);   // v_exp_f32: ~1e-6 relative on the chunk mass
+      sum += snap_dpp<0x128>(sum);
+      sum += snap_dpp<0x124>(sum);
+      sum += snap_dpp<0x122>(sum);
+      sum += snap_dpp<0x121>(sum);
+      if (live) {
+        float* o = sim + row * XY + cell0 + c4;
+        if (c4 + 3 < ncell && ((XY & 3) == 0)) {
+          *reinterpret_cast<f32x4*>(o) = f32x4{x[0] * wrow, x[1] * wrow, x[2] * wrow, x[3] * wrow};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c4 + e < ncell) o[e] = x[e] * wrow;
+        }
+        if ((lane & 15) == 0) {
+          stats[(row * NC + chunk) * 2 + 0] = m;
+          stats[(row * NC + chunk) * 2 + 1] = sum;
+        }
+      }
+    }
+  }
+}
+
+// layers.masked_softmax over the query points (snap/models/layers.py:38-43) + its inclusive CDF
+// (the sampler's row distribution).  One workgroup per scene; fixed-order sums.
+__global__ __launch_bounds__(256) void masked_softmax_rows_kernel(
+    const float* __restrict__ x, const uint8_t* __restrict__ mask, int N, float* __restrict__ w,
+    float* __restrict__ cdf) {
+  __shared__ float red[256];
+  __shared__ int any_s;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* xr = x + (int64_t)b * N;
+  const uint8_t* mr = mask + (int64_t)b * N;
+  const int seg = (N + 255) / 256;
+  const int i0 = min(t * seg, N), i1 = min(i0 + seg, N);
+  int any = 0;
+  for (int i = i0; i < i1; ++i) any |= mr[i];
+  if (t == 0) any_s = 0;
+  __syncthreads();
+  if (any) atomicOr(&any_s, 1);
+  __syncthreads();
+  const bool all = any_s == 0;                 // nothing valid: the mask becomes all-true
+  float m = -INFINITY;
+  for (int i = i0; i < i1; ++i)
+    if (all || mr[i]) m = fmaxf(m, xr[i]);
+  red[t] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  float loc = 0.f;
+  for (int i = i0; i < i1; ++i) loc += (all || mr[i]) ? expf(xr[i] - m) : 0.f;
+  red[t] = loc;
+  __syncthreads();
+  // inclusive scan of the 256 segment sums (Hillis-Steele, fixed order)
+  for (int o = 1; o < 256; o <<= 1) {
+    const float add = t >= o ? red[t - o] : 0.f;
+    __syncthreads();
+    red[t] += add;
+    __syncthreads();
+  }
+  const float total = red[255];
+  float run = red[t] - loc;
+  for (int i = i0; i < i1; ++i) {
+    const float e = (all || mr[i]) ? expf(xr[i] - m) : 0.f;
+    run += e;
+    w[(int64_t)b * N + i] = e / total;
+    cdf[(int64_t)b * N + i] = run / total;
   }
 }
 
@@ -174,7 +378,8 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     const float* __restrict__ fq, const float* __restrict__ fm, const float* __restrict__ stats,
     int Nq, int X, int Y, float scale, int clip, int S, uint64_t seed,
     const float* __restrict__ uniforms, int32_t* __restrict__ corr,
-    const float* __restrict__ lane_incl, const float* __restrict__ rowmax) {
+    const float* __restrict__ lane_incl, const float* __restrict__ rowmax,
+    const float* __restrict__ row_cdf) {
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -191,7 +396,21 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     u1 = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
     u2 = (float)(rnd[1] >> 8) * (1.0f / 16777216.0f);
   }
-  const int n = min((int)(u1 * (float)Nq), Nq - 1);
+  int n;
+  if (row_cdf) {
+    // rows carry the confidence weights as mass (bev_localizer.py:165-168): first n whose
+    // inclusive CDF exceeds u1 * total (wave-uniform binary search)
+    const float* cdf = row_cdf + (int64_t)b * Nq;
+    const float tgt = u1 * cdf[Nq - 1];
+    int lo = 0, hi = Nq - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] > tgt) hi = mid; else lo = mid + 1;
+    }
+    n = lo;
+  } else {
+    n = min((int)(u1 * (float)Nq), Nq - 1);
+  }
   const int64_t row = (int64_t)b * Nq + n;
   const float* st = stats + row * NC * 2;
 
@@ -875,12 +1094,12 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 template <int MODE>
 int launch_sim(int Dm, dim3 grid, hipStream_t s, const float* fq, const float* fm, int Nq, int XY,
                float scale, int clip, const float* nv, float* sim, float* stats,
-               const float* rowstats, float* prob) {
+               const float* rowstats, float* prob, const float* row_weight) {
   switch (Dm) {
-    case 8: hipLaunchKernelGGL((sim_kernel<8, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
-    case 16: hipLaunchKernelGGL((sim_kernel<16, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
-    case 32: hipLaunchKernelGGL((sim_kernel<32, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
-    case 64: hipLaunchKernelGGL((sim_kernel<64, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob); break;
+    case 8: hipLaunchKernelGGL((sim_kernel<8, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob, row_weight); break;
+    case 16: hipLaunchKernelGGL((sim_kernel<16, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob, row_weight); break;
+    case 32: hipLaunchKernelGGL((sim_kernel<32, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob, row_weight); break;
+    case 64: hipLaunchKernelGGL((sim_kernel<64, MODE>), grid, dim3(256), 0, s, fq, fm, Nq, XY, scale, clip, nv, sim, stats, rowstats, prob, row_weight); break;
     default: return SNAP_ERR_UNSUPPORTED;
   }
   SNAP_CHECK_LAUNCH();
@@ -897,13 +1116,43 @@ extern "C" int snap_sim_softmax_f32(const float* fq, const float* fm, int32_t B,
                                     int32_t XY, int32_t Dm, float scale, int32_t clip_negative,
                                     const float* num_valid, float* sim, float* chunk_stats,
                                     float* prob, float* rowstats, void* stream) {
+  return snap_sim_softmax_weighted_f32(fq, fm, B, Nq, XY, Dm, scale, clip_negative, num_valid,
+                                       nullptr, sim, chunk_stats, prob, rowstats, stream);
+}
+
+extern "C" int snap_sim_softmax_weighted_f32(const float* fq, const float* fm, int32_t B,
+                                             int32_t Nq, int32_t XY, int32_t Dm, float scale,
+                                             int32_t clip_negative, const float* num_valid,
+                                             const float* row_weight, float* sim,
+                                             float* chunk_stats, float* prob, float* rowstats,
+                                             void* stream) {
   if (!fq || !fm || !num_valid || !sim || !chunk_stats) return SNAP_ERR_NULL;
   if (prob && !rowstats) return SNAP_ERR_NULL;
   if (B <= 0 || Nq <= 0 || XY <= 0) return SNAP_ERR_BAD_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)snap_cdiv(XY, 256), (unsigned)snap_cdiv(Nq, SIM_TQ), (unsigned)B);
-  int rc = launch_sim<0>(Dm, grid, s, fq, fm, Nq, XY, scale, clip_negative, num_valid, sim,
-                         chunk_stats, nullptr, nullptr);
+  const char* env = getenv("SNAP_SIM_MFMA");    // 0 = the VALU kernel (tests compare the two)
+  const bool use_mfma = !(env && env[0] == '0');
+  const bool aligned = ((reinterpret_cast<uintptr_t>(fq) | reinterpret_cast<uintptr_t>(fm)) & 15) == 0;
+  int rc = SNAP_OK;
+  if (use_mfma && aligned && (Dm == 8 || Dm == 16 || Dm == 32 || Dm == 64)) {
+#define SNAP_SIM_MFMA_CASE(D)                                                                     \
+  case D:                                                                                         \
+    hipLaunchKernelGGL(sim_mfma_kernel<D>, grid, dim3(256), 0, s, fq, fm, Nq, XY, scale,          \
+                       clip_negative, num_valid, sim, chunk_stats, row_weight);                   \
+    break;
+    switch (Dm) {
+      SNAP_SIM_MFMA_CASE(8)
+      SNAP_SIM_MFMA_CASE(16)
+      SNAP_SIM_MFMA_CASE(32)
+      SNAP_SIM_MFMA_CASE(64)
+    }
+#undef SNAP_SIM_MFMA_CASE
+    SNAP_CHECK_LAUNCH();
+  } else {
+    rc = launch_sim<0>(Dm, grid, s, fq, fm, Nq, XY, scale, clip_negative, num_valid, sim,
+                       chunk_stats, nullptr, nullptr, row_weight);
+  }
   if (rc != SNAP_OK) return rc;
   if (rowstats) {
     const int64_t rows = (int64_t)B * Nq;
@@ -914,7 +1163,7 @@ extern "C" int snap_sim_softmax_f32(const float* fq, const float* fm, int32_t B,
   }
   if (prob) {
     rc = launch_sim<1>(Dm, grid, s, fq, fm, Nq, XY, scale, clip_negative, num_valid, nullptr,
-                       nullptr, rowstats, prob);
+                       nullptr, rowstats, prob, row_weight);
   }
   return rc;
 }
@@ -936,6 +1185,18 @@ extern "C" int snap_ransac_sample_ws_f32(const float* fq, const float* fm, const
                                          float scale, int32_t clip_negative, int32_t S,
                                          uint64_t seed, const float* uniforms, int32_t* corr,
                                          void* workspace, size_t workspace_bytes, void* stream) {
+  return snap_ransac_sample_rows_f32(fq, fm, chunk_stats, nullptr, B, Nq, X, Y, Dm, scale,
+                                     clip_negative, S, seed, uniforms, corr, workspace,
+                                     workspace_bytes, stream);
+}
+
+extern "C" int snap_ransac_sample_rows_f32(const float* fq, const float* fm,
+                                           const float* chunk_stats, const float* row_cdf,
+                                           int32_t B, int32_t Nq, int32_t X, int32_t Y,
+                                           int32_t Dm, float scale, int32_t clip_negative,
+                                           int32_t S, uint64_t seed, const float* uniforms,
+                                           int32_t* corr, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
   if (!fq || !fm || !chunk_stats || !corr) return SNAP_ERR_NULL;
   if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || S <= 0) return SNAP_ERR_BAD_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -953,12 +1214,22 @@ extern "C" int snap_ransac_sample_ws_f32(const float* fq, const float* fm, const
   }
   const dim3 grid((unsigned)snap_cdiv(S, 4), (unsigned)B);
   switch (Dm) {
-    case 8: hipLaunchKernelGGL(ransac_sample_kernel<8>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
-    case 16: hipLaunchKernelGGL(ransac_sample_kernel<16>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
-    case 32: hipLaunchKernelGGL(ransac_sample_kernel<32>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
-    case 64: hipLaunchKernelGGL(ransac_sample_kernel<64>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax); break;
+    case 8: hipLaunchKernelGGL(ransac_sample_kernel<8>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
+    case 16: hipLaunchKernelGGL(ransac_sample_kernel<16>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
+    case 32: hipLaunchKernelGGL(ransac_sample_kernel<32>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
+    case 64: hipLaunchKernelGGL(ransac_sample_kernel<64>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
     default: return SNAP_ERR_UNSUPPORTED;
   }
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_masked_softmax_rows_f32(const float* x, const uint8_t* mask, int32_t B,
+                                            int32_t N, float* weights, float* cdf, void* stream) {
+  if (!x || !mask || !weights || !cdf) return SNAP_ERR_NULL;
+  if (B <= 0 || N <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(masked_softmax_rows_kernel, dim3((unsigned)B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, mask, N, weights, cdf);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

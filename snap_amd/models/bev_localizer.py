@@ -58,8 +58,8 @@ class BEVLocalizer(base.Module):
       raise ValueError('filter_points_in_fov=True is required (as in train_localization)')
     if config.add_confidence_map:
       raise NotImplementedError('Map confidence is not yet supported.')
-    if config.add_confidence_query:
-      raise NotImplementedError('add_confidence_query (non-default confidence path)')
+    if config.add_confidence_query or config.add_confidence_map:
+      config.bev_mapper.add_confidence = True      # as the reference's setup (bev_localizer.py:90-91)
     self.bev_mapper = bev_mapper.BEVMapper(
         config.bev_mapper, grid_map, semantic_map_classes, dtype
     )
@@ -121,21 +121,30 @@ class BEVLocalizer(base.Module):
         strides=pyr.strides,
     )
 
-  def similarity(self, params, f_p_q, plane_map, valid_points, want_prob=False):
-    """bev_localizer.py:157-173: sim_points (+ softmax statistics) on the GPU."""
+  def similarity(self, params, f_p_q, plane_map, valid_points, want_prob=False, conf_p=None):
+    """bev_localizer.py:157-173: sim_points (+ softmax statistics) on the GPU.  ``conf_p`` [B,Nq]:
+    query-point confidences (add_confidence_query, :165-168): their masked softmax weights
+    replace the 1 / num_valid normalisation and become the sampler's point distribution."""
     cfg = self.config
     temperature = params['temperature'] if cfg.add_temperature else None
     num_valid = valid_points.sum(-1).clamp(min=1).to(torch.float32)
     fq, fm = f_p_q.contiguous(), plane_map.features.contiguous()
     clip = bool(cfg.clip_negative_scores)
+    weights = row_cdf = None
+    if conf_p is not None:
+      if base.needs_grad(fq, fm, temperature, conf_p):
+        raise NotImplementedError('add_confidence_query: no backward kernels yet (inference only)')
+      weights, row_cdf = ops.masked_softmax_rows(conf_p.contiguous(), valid_points.contiguous())
     if base.needs_grad(fq, fm, temperature):
       sim, stats, prob, scale = ag.sim_softmax(fq, fm, temperature, clip, num_valid, want_prob)
     else:
       # exp(temperature): a host scalar (one tiny D2H sync per apply).
       scale = 1.0 if temperature is None else float(torch.exp(temperature.to(torch.float32)))
-      sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob)
+      sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob,
+                                            row_weight=weights)
     # the sampler sees stop_gradient(prob_points) (bev_localizer.py:178): detached inputs.
-    matching = dict(fq=fq.detach(), fm=fm.detach(), chunk_stats=stats, scale=scale, clip=clip)
+    matching = dict(fq=fq.detach(), fm=fm.detach(), chunk_stats=stats, scale=scale, clip=clip,
+                    row_cdf=row_cdf)
     return sim, prob, matching
 
   def __call__(self, params, data, train=False, debug=False, rng=None,
@@ -165,8 +174,11 @@ class BEVLocalizer(base.Module):
     valid_points = plane_q.valid.reshape(batch_size, -1)
     f_p_q = plane_q.features.reshape(batch_size, -1, plane_q.features.shape[-1])
 
+    conf_p = None
+    if cfg.add_confidence_query:
+      conf_p = pred['query']['bev_confidence'].reshape(batch_size, -1)
     sim_points, prob_points, matching = self.similarity(
-        params, f_p_q, plane_map, valid_points, want_prob=debug
+        params, f_p_q, plane_map, valid_points, want_prob=debug, conf_p=conf_p
     )
     if debug:
       pred['sim_points'] = sim_points

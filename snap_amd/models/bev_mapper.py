@@ -123,8 +123,6 @@ class BEVMapper(base.Module):
     self.feature_dim = feature_dimensions[0]
     if config.bev_net is not None:
       raise NotImplementedError('BEV network not yet implemented')
-    if config.add_confidence:
-      raise NotImplementedError('add_confidence (non-default confidence head)')
 
   def init_params(self, gen, device):
     params = {}
@@ -145,6 +143,12 @@ class BEVMapper(base.Module):
           'kernel': base.truncated_normal(gen, (self.feature_dim, dm), std, device),
           'bias': torch.zeros(dm, device=device),
       }
+    if self.config.add_confidence:
+      # nn.Sequential([nn.Dense(1)]) (bev_mapper.py:154-157): Flax names the layer 'layers_0'
+      params['confidence_head'] = {'layers_0': {
+          'kernel': base.lecun_normal(gen, (self.feature_dim, 1), self.feature_dim, device),
+          'bias': torch.zeros(1, device=device),
+      }}
     return params
 
   def build_xyz_query(self, data, train, is_query, rng=None):
@@ -258,6 +262,14 @@ class BEVMapper(base.Module):
     pred['bev_features'] = plane
     if has_match:
       pred['bev_matching'] = types.FeaturePlane(features=matching, valid=plane.valid)
+    if cfg.add_confidence:
+      # bev_mapper.py:292-295: where(valid, log_sigmoid(Dense(1)(features)), 0)
+      head = params['confidence_head']['layers_0']
+      if base.needs_grad(plane.features, head['kernel'], head['bias']):
+        raise NotImplementedError('add_confidence: the confidence head has no backward kernel yet')
+      pred['bev_confidence'] = ops.confidence_head(
+          plane.features.contiguous(), plane.valid.contiguous(),
+          head['kernel'].reshape(-1).contiguous(), float(head['bias'].reshape(-1)[0]))
     return pred
 
   default_config = staticmethod(default_configs.bev_mapper)

@@ -720,11 +720,16 @@ def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None,
 # pose
 # ----------------------------------------------------------------------------
 def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
-                want_rowstats=False):
+                want_rowstats=False, row_weight=None):
   """fq [B,Nq,Dm], fm [B,X,Y,Dm], num_valid [B] float ->
-  sim [B,Nq,X,Y], chunk_stats [B,Nq,NC,2], (prob), (rowstats)."""
+  sim [B,Nq,X,Y], chunk_stats [B,Nq,NC,2], (prob), (rowstats).  row_weight [B,Nq]: per-point
+  confidence weights that replace the 1 / num_valid normalisation (add_confidence_query)."""
   lib = _lib.load()
   _f32(fq, 'fq'); _f32(fm, 'fm'); _f32(num_valid, 'num_valid')
+  if row_weight is not None:
+    _f32(row_weight, 'row_weight')
+    if tuple(row_weight.shape) != tuple(fq.shape[:2]):
+      raise ValueError('sim_softmax: row_weight must be [B, Nq]')
   B, Nq, Dm = fq.shape
   X, Y = fm.shape[1:3]
   XY = X * Y
@@ -741,16 +746,45 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
       'sim_softmax', 2.0 * B * Nq * XY * Dm,
       4.0 * (fq.numel() + fm.numel() + sim.numel() + stats.numel()),
   ):
-    st = lib.snap_sim_softmax_f32(
+    st = lib.snap_sim_softmax_weighted_f32(
         _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(clip_negative),
-        _p(num_valid), _p(sim), _p(stats), _p(prob), _p(rowstats), _stream(),
+        _p(num_valid), _p(row_weight), _p(sim), _p(stats), _p(prob), _p(rowstats), _stream(),
     )
-  _lib.check(st, 'snap_sim_softmax_f32')
+  _lib.check(st, 'snap_sim_softmax_weighted_f32')
   return sim, stats, prob, rowstats
 
 
+def masked_softmax_rows(x, mask):
+  """layers.masked_softmax over the last axis of x [B, N] (layers.py:38-43) -> (weights, inclusive
+  CDF), both [B, N]."""
+  lib = _lib.load()
+  _f32(x, 'x'); _mask(mask, 'mask')
+  B, N = x.shape
+  w = torch.empty_like(x)
+  cdf = torch.empty_like(x)
+  st = lib.snap_masked_softmax_rows_f32(_p(x), _p(mask), B, N, _p(w), _p(cdf), _stream())
+  _lib.check(st, 'snap_masked_softmax_rows_f32')
+  return w, cdf
+
+
+def confidence_head(features, valid, kernel, bias):
+  """where(valid, log_sigmoid(features @ kernel + bias), 0): features [..., D], kernel [D] ->
+  [...] (bev_mapper.py:292-295)."""
+  lib = _lib.load()
+  _f32(features, 'features'); _f32(kernel, 'kernel')
+  if valid is not None:
+    _mask(valid, 'valid')
+  D = features.shape[-1]
+  M = features.numel() // D
+  out = torch.empty(features.shape[:-1], dtype=torch.float32, device=features.device)
+  st = lib.snap_confidence_head_f32(_p(features), _p(valid), _p(kernel), float(bias), M, D, _p(out),
+                                    _stream())
+  _lib.check(st, 'snap_confidence_head_f32')
+  return out
+
+
 def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
-                  uniforms=None, row_table=True):
+                  uniforms=None, row_table=True, row_cdf=None):
   """Draw S correspondences per scene ~ prob_points.  Returns int32 [B,S,3].
   row_table=False takes the table-free path (same samples; tests compare the two)."""
   lib = _lib.load()
@@ -767,12 +801,12 @@ def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
     ws = torch.empty(lib.snap_ransac_sample_workspace_bytes(B, Nq) // 4, dtype=torch.float32,
                      device=fq.device)
   with _region('ransac_sample', 0.0, 12.0 * B * S):
-    st = lib.snap_ransac_sample_ws_f32(
-        _p(fq), _p(fm), _p(chunk_stats), B, Nq, X, Y, Dm, float(scale),
+    st = lib.snap_ransac_sample_rows_f32(
+        _p(fq), _p(fm), _p(chunk_stats), _p(row_cdf), B, Nq, X, Y, Dm, float(scale),
         int(clip_negative), S, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(uniforms),
         _p(corr), _p(ws), 0 if ws is None else ws.numel() * 4, _stream(),
     )
-  _lib.check(st, 'snap_ransac_sample_ws_f32')
+  _lib.check(st, 'snap_ransac_sample_rows_f32')
   return corr
 
 
@@ -838,6 +872,47 @@ def argmax_rows(scores, start=0):
   st = lib.snap_argmax_rows_f32(_p(scores), B, P, start, _p(idx), _stream())
   _lib.check(st, 'snap_argmax_rows_f32')
   return idx
+
+
+# ----------------------------------------------------------------------------
+# generic grid operators (snap/utils/grids.py:116-153)
+# ----------------------------------------------------------------------------
+def interpolate_nd(array, points, valid_array=None):
+  """array [s_0..s_{n-1}, D], points [K, n] (corner-origin coordinates) -> values [K, D],
+  valid [K] (grids.py:116-137: linear, 'nearest' extension, zero-weight-invalid-tap rule)."""
+  lib = _lib.load()
+  _f32(array, 'array'); _f32(points, 'points')
+  K, n = points.shape
+  if array.dim() != n + 1 or not 1 <= n <= 3:
+    raise ValueError(f'interpolate_nd: array {tuple(array.shape)} vs points [K, {n}]')
+  D = array.shape[-1]
+  size = (ctypes.c_int32 * n)(*array.shape[:n])
+  if valid_array is not None:
+    _mask(valid_array, 'valid_array')
+    if tuple(valid_array.shape) != tuple(array.shape[:n]):
+      raise ValueError('interpolate_nd: valid_array shape')
+  values = torch.empty((K, D), dtype=torch.float32, device=array.device)
+  valid = torch.empty((K,), dtype=torch.bool, device=array.device)
+  st = lib.snap_interpolate_nd_f32(_p(array), size, n, D, _p(valid_array), _p(points), K,
+                                   _p(values), _p(valid), _stream())
+  _lib.check(st, 'snap_interpolate_nd_f32')
+  return values, valid
+
+
+def expectation_nd(pdf, extent):
+  """pdf [..., *extent] -> expected (fractional) index [..., n] (grids.py:148-153)."""
+  lib = _lib.load()
+  _f32(pdf, 'pdf')
+  n = len(extent)
+  if tuple(pdf.shape[-n:]) != tuple(extent) or not 1 <= n <= 3:
+    raise ValueError(f'expectation_nd: pdf {tuple(pdf.shape)} vs extent {tuple(extent)}')
+  lead = pdf.shape[:-n]
+  rows = int(np.prod(lead)) if len(lead) else 1
+  size = (ctypes.c_int32 * n)(*extent)
+  out = torch.empty((rows, n), dtype=torch.float32, device=pdf.device)
+  st = lib.snap_expectation_nd_f32(_p(pdf), rows, size, n, _p(out), _stream())
+  _lib.check(st, 'snap_expectation_nd_f32')
+  return out.reshape(*lead, n)
 
 
 # ----------------------------------------------------------------------------

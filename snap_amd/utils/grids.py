@@ -1,8 +1,8 @@
 """Regular grids (host-side index maths), mirroring ``snap/utils/grids.py:33-106``.
 
-``interpolate_nd`` of the reference (:116-137) has no host-side counterpart here:
-every interpolation of the hot path runs inside a HIP kernel (lift.hip, pose.hip,
-voting.hip).
+``interpolate_nd`` / ``argmax_nd`` / ``expectation_nd`` (:116-153) are thin wrappers over
+stand-alone HIP entry points (grid_ops.hip); inside the hot path the same interpolation is
+fused into lift.hip / pose.hip / voting.hip.
 """
 import dataclasses
 from typing import Tuple
@@ -66,3 +66,30 @@ class Grid3D(GridND):
 
   def bev(self) -> Grid2D:
     return Grid2D(self.extent[:2], self.cell_size)
+
+
+def interpolate_nd(array, points, valid_array=None, order=1, mode='nearest'):
+  """snap/utils/grids.py:116-137.  array [..., D] over an N-D grid, points [K, N] in
+  corner-origin coordinates -> (values [K, D], valid [K]).  Only the reference's own
+  ``order=1, mode='nearest'`` combination exists (it never calls any other)."""
+  if order != 1 or mode != 'nearest':
+    raise NotImplementedError("interpolate_nd: only order=1, mode='nearest' (the reference's call)")
+  from snap_amd import ops
+  return ops.interpolate_nd(array.contiguous(), points.contiguous(),
+                            None if valid_array is None else valid_array.contiguous())
+
+
+def argmax_nd(scores, grid: GridND):
+  """snap/utils/grids.py:140-145: index [..., N] of the (first) maximum over the grid axes."""
+  from snap_amd import ops
+  n = len(grid.extent)
+  lead = scores.shape[:-n]
+  flat = scores.reshape(-1, int(np.prod(scores.shape[-n:]))).contiguous()
+  ids = ops.argmax_rows(flat).to(torch.int64)
+  return grid.id_to_index(ids).reshape(*lead, n)
+
+
+def expectation_nd(pdf, grid: GridND):
+  """snap/utils/grids.py:148-153: expected index of an N-D probability tensor."""
+  from snap_amd import ops
+  return ops.expectation_nd(pdf.contiguous(), grid.extent)

@@ -242,9 +242,12 @@ def _raw_sim(fq, fm, scale, clip):
 
 
 def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
-                want_rowstats=False):
+                want_rowstats=False, row_weight=None):
   q, m = _np(fq, DTYPE), _np(fm, DTYPE)
   nv = _np(num_valid, DTYPE)[:, None, None, None]
+  if row_weight is not None:      # confidence weights replace 1 / num_valid (bev_localizer.py:165-172)
+    nv = 1.0 / np.maximum(_np(row_weight, DTYPE), 1e-38)[:, :, None, None]
+    nv = np.where(_np(row_weight, DTYPE)[:, :, None, None] > 0, nv, np.inf)
   x = _raw_sim(q, m, scale, clip_negative)
   B, Nq, X, Y = x.shape
   XY = X * Y
@@ -266,7 +269,7 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
   return _t(x / nv, fq), _t(stats, fq), prob, rowstats
 
 
-def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0, uniforms=None):
+def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0, uniforms=None, row_cdf=None):
   """Two-level inverse-CDF sampler in float64 (same scheme as pose.hip)."""
   q, m = _np(fq, np.float64), _np(fm, np.float64)
   B, Nq, _ = q.shape
@@ -278,6 +281,9 @@ def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0, uniforms
   corr = np.zeros((B, S, 3), np.int32)
   for b in range(B):
     n = np.minimum((u[b, :, 0].astype(np.float32) * np.float32(Nq)).astype(np.int64), Nq - 1)
+    if row_cdf is not None:
+      c = _np(row_cdf, np.float64)[b]
+      n = np.minimum(np.searchsorted(c, u[b, :, 0] * c[-1], side='right'), Nq - 1)
     for s in range(S):
       x = np.einsum('d,ijd->ij', q[b, n[s]], m[b])
       if clip_negative:

@@ -625,6 +625,27 @@ def test_sim_softmax(X, Y, Dm):
   helpers.report('rowstats', got[3], want[3], atol=1e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize('Dm', [8, 32])
+def test_sim_softmax_mfma_kernel_keeps_the_valu_kernels_bits(Dm, monkeypatch):
+  """The matrix-core similarity kernel runs the same k-ordered fmaf chain as the VALU kernel it
+  replaces (v_mfma_f32_32x32x2_f32 is an exact f32 chain): sim must agree bit for bit -- the
+  sampler re-evaluates the selected chunk with that chain -- and the chunk statistics up to the
+  order of their 64-term sums.  Ragged sizes: Nq and X*Y not multiples of the 64 x 256 tile."""
+  B, Nq, X, Y = 2, 150, 27, 23
+  fq = _unit(rnd((B, Nq, Dm), 190)).to(DEV)
+  fm = _unit(rnd((B, X, Y, Dm), 191)).to(DEV)
+  nv = torch.tensor([149.0, 150.0], device=DEV)
+  scale = float(np.exp(2.0))
+  for clip in (True, False):
+    monkeypatch.setenv('SNAP_SIM_MFMA', '0')
+    sim_v, st_v, _, _ = ops.sim_softmax(fq, fm, scale, clip, nv)
+    monkeypatch.setenv('SNAP_SIM_MFMA', '1')
+    sim_m, st_m, _, _ = ops.sim_softmax(fq, fm, scale, clip, nv)
+    assert torch.equal(sim_m, sim_v)
+    assert torch.equal(st_m[..., 0], st_v[..., 0])
+    assert torch.allclose(st_m[..., 1], st_v[..., 1], rtol=1e-5, atol=0)
+
+
 def test_ransac_sample_given_uniforms():
   B, Nq, X, Y, Dm, S = 2, 40, 24, 20, 16, 600
   fq = _unit(rnd((B, Nq, Dm), 95))
@@ -1100,3 +1121,126 @@ def test_attention(B, N, H):
   helpers.report(f'attention B{B} N{N} H{H}', got, want, atol=4e-3 * scale, rtol=0)
   exact = oracle_ops.attention(qkv, bf16_operands=False)
   helpers.report(f'attention vs exact f64 B{B} N{N} H{H}', got, exact, atol=2e-2 * scale, rtol=0)
+
+
+# ----------------------------------------------------------------------------
+# generic grid operators (snap/utils/grids.py:116-153)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize('shape,D', [((9,), 3), ((7, 5), 1), ((6, 8), 5), ((4, 5, 3), 2)])
+@pytest.mark.parametrize('with_valid', [False, True])
+def test_interpolate_nd_matches_the_oracle(shape, D, with_valid):
+  from oracle import grids as o_grids
+  from snap_amd.utils import grids as g
+  n = len(shape)
+  rng = np.random.default_rng(7 + n + D)
+  arr = rng.standard_normal((*shape, D)).astype(np.float32)
+  K = 400
+  pts = rng.uniform(-1.5, np.asarray(shape) + 1.5, (K, n)).astype(np.float32)
+  # exact grid lines / centres / borders: zero-weight taps and the in-bounds test
+  pts[:40] = np.round(pts[:40] * 2) / 2
+  pts[40] = 0.0
+  pts[41] = np.asarray(shape, np.float32)               # == size: out of bounds
+  pts[42] = np.nextafter(np.asarray(shape, np.float32), 0).astype(np.float32)
+  va = (rng.uniform(size=shape) > 0.25) if with_valid else None
+  want_v, want_ok = o_grids.interpolate_nd(arr, pts, va)
+  got_v, got_ok = g.interpolate_nd(torch.from_numpy(arr).to(DEV), torch.from_numpy(pts).to(DEV),
+                                   None if va is None else torch.from_numpy(va).to(DEV))
+  assert np.array_equal(got_ok.cpu().numpy(), want_ok)
+  helpers.report(f'interpolate_nd {shape}x{D}', got_v, want_v, atol=2e-6, rtol=1e-6)
+  with pytest.raises(NotImplementedError):
+    g.interpolate_nd(torch.from_numpy(arr).to(DEV), torch.from_numpy(pts).to(DEV), order=0)
+
+
+def test_argmax_nd_and_expectation_nd():
+  from snap_amd.utils import grids as g
+  rng = np.random.default_rng(11)
+  for extent in ((17,), (6, 9), (5, 4, 7)):
+    grid = g.GridND(tuple(extent), 0.5)
+    sc = rng.standard_normal((3, 2, *extent)).astype(np.float32)
+    flat = sc.reshape(3, 2, -1)
+    flat[0, 0, 5] = flat[0, 0, 11] = flat.max() + 1.0          # a tie: the FIRST index wins
+    want = np.stack(np.unravel_index(np.argmax(flat, -1), extent), -1)
+    got = g.argmax_nd(torch.from_numpy(sc).to(DEV), grid)
+    assert np.array_equal(got.cpu().numpy(), want)
+    pdf = np.exp(sc)
+    pdf /= pdf.reshape(3, 2, -1).sum(-1).reshape(3, 2, *([1] * len(extent)))
+    idx = np.stack(np.meshgrid(*[np.arange(e) for e in extent], indexing='ij'), -1)
+    want_e = (idx * pdf[..., None].astype(np.float64)).sum(tuple(range(2, 2 + len(extent))))
+    got_e = g.expectation_nd(torch.from_numpy(pdf.astype(np.float32)).to(DEV), grid)
+    assert got_e.shape == (3, 2, len(extent))
+    helpers.report(f'expectation_nd {extent}', got_e, want_e.astype(np.float32), atol=1e-4, rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------
+# confidence-weighted matching (bev_mapper.py:154-157,292-295; bev_localizer.py:165-168)
+# ----------------------------------------------------------------------------
+def test_confidence_head_and_masked_softmax_rows():
+  from oracle import bev as o_bev
+  rng = np.random.default_rng(21)
+  f = rng.standard_normal((2, 9, 7, 128)).astype(np.float32)
+  v = rng.uniform(size=(2, 9, 7)) > 0.3
+  w = (rng.standard_normal(128) / 11).astype(np.float32)
+  b = 0.37
+  got = ops.confidence_head(torch.from_numpy(f).to(DEV), torch.from_numpy(v).to(DEV),
+                            torch.from_numpy(w).to(DEV), b)
+  want = np.where(v, o_bev.log_sigmoid((f @ w + np.float32(b)).astype(np.float32)), 0)
+  helpers.report('confidence head', got, want, atol=2e-6, rtol=1e-5)
+  x = (rng.standard_normal((3, 1000)) * 3).astype(np.float32)
+  m = rng.uniform(size=(3, 1000)) > 0.4
+  m[1] = False                                        # nothing valid: behaves as all-true
+  wgt, cdf = ops.masked_softmax_rows(torch.from_numpy(x).to(DEV), torch.from_numpy(m).to(DEV))
+  want_w = o_bev.layers_masked_softmax(x.astype(np.float64), m, -1)
+  helpers.report('masked softmax rows', wgt, want_w.astype(np.float32), atol=1e-8, rtol=2e-5)
+  helpers.report('masked softmax cdf', cdf, np.cumsum(want_w, -1).astype(np.float32), atol=2e-6, rtol=2e-5)
+  assert float(wgt[0][~torch.from_numpy(m[0]).to(DEV)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('mfma', ['1', '0'])
+def test_sim_softmax_with_confidence_weights(mfma, monkeypatch):
+  from oracle import pose as o_pose
+  monkeypatch.setenv('SNAP_SIM_MFMA', mfma)
+  B, Nq, X, Y, Dm = 2, 70, 13, 21, 32
+  fq = _unit(rnd((B, Nq, Dm), 290))
+  fm = _unit(rnd((B, X, Y, Dm), 291))
+  g = torch.Generator().manual_seed(292)
+  wts = torch.softmax(torch.randn(B, Nq, generator=g), -1)
+  wts[0, 5] = 0.0
+  nv = torch.tensor([70.0, 70.0])
+  scale = float(np.exp(2.0))
+  sim, stats, prob, _ = ops.sim_softmax(fq.to(DEV), fm.to(DEV), scale, True, nv.to(DEV), want_prob=True,
+                                        row_weight=wts.to(DEV).contiguous())
+  want_sim, want_prob = o_pose.similarity(fq.numpy(), fm.numpy(), np.ones((B, Nq), bool), 2.0, True,
+                                          wts.numpy()[..., None, None])
+  helpers.report('weighted sim', sim, want_sim, atol=1e-7, rtol=1e-5)
+  helpers.report('weighted prob', prob, want_prob, atol=1e-10, rtol=1e-4)
+  # the chunk statistics describe the UN-weighted row softmax: unchanged by the weights
+  _, stats0, _, _ = ops.sim_softmax(fq.to(DEV), fm.to(DEV), scale, True, nv.to(DEV))
+  assert torch.equal(stats, stats0)
+
+
+def test_ransac_sample_rows_follow_the_confidence_cdf():
+  B, Nq, X, Y, Dm, S = 2, 50, 12, 10, 16, 4000
+  fq = _unit(rnd((B, Nq, Dm), 295)).to(DEV)
+  fm = _unit(rnd((B, X, Y, Dm), 296)).to(DEV)
+  nv = torch.full((B,), float(Nq), device=DEV)
+  scale = float(np.exp(2.0))
+  conf = rnd((B, Nq), 297).to(DEV) * 2
+  mask = torch.ones(B, Nq, dtype=torch.bool, device=DEV)
+  mask[:, ::3] = False
+  w, cdf = ops.masked_softmax_rows(conf.contiguous(), mask)
+  _, stats, _, _ = ops.sim_softmax(fq, fm, scale, True, nv, row_weight=w)
+  u = torch.rand((B, S, 2), generator=torch.Generator().manual_seed(298)).to(DEV)
+  corr = ops.ransac_sample(fq, fm, stats, scale, True, S, uniforms=u, row_cdf=cdf)
+  # injected uniforms: the selected row is exactly the inverse CDF of u1
+  want_rows = torch.searchsorted(cdf, (u[..., 0] * cdf[:, -1:]).contiguous(), right=True).clamp(max=Nq - 1)
+  assert torch.equal(corr[..., 0].long(), want_rows)
+  assert not bool((~mask)[torch.arange(B, device=DEV)[:, None], corr[..., 0].long()].any())   # never a masked point
+  # Philox draws: row frequencies follow the weights (z-score on every valid row)
+  S2 = 200000
+  c2 = ops.ransac_sample(fq, fm, stats, scale, True, S2, seed=9, row_cdf=cdf)
+  for bb in range(B):
+    cnt = torch.bincount(c2[bb, :, 0].long(), minlength=Nq).double().cpu().numpy()
+    p = w[bb].double().cpu().numpy()
+    z = (cnt - S2 * p) / np.sqrt(np.maximum(S2 * p * (1 - p), 1e-9))
+    assert np.abs(z[p > 0]).max() < 5.0
+    assert cnt[p == 0].sum() == 0

@@ -84,6 +84,24 @@ def test_localizer_forward_parity(top_k, V, math):
                              got_index=pred['best_index'])
 
 
+def test_localizer_with_query_confidence_parity():
+  """add_confidence_query (bev_localizer.py:165-168 + the Dense(1) head of bev_mapper.py:154-157):
+  log-sigmoid confidences, masked-softmax point weights instead of 1 / num_valid, parity of the
+  weighted similarity / scores / argmax with the oracle."""
+  cfg = helpers.tiny_localizer_config(top_k=2)
+  cfg.add_confidence_query = True
+  pred, ref = _run(cfg, 2, 3, (64, 64), seed=8)
+  assert cfg.bev_mapper.add_confidence                      # set by the localizer, as the reference's setup
+  helpers.report('query bev_confidence', pred['query']['bev_confidence'], ref['query']['bev_confidence'],
+                 atol=1e-4, rtol=1e-4)
+  assert float(pred['query']['bev_confidence'].max()) <= 0.0
+  helpers.report('sim_points (weighted)', pred['sim_points'], ref['_sim_points'], atol=1e-6, rtol=2e-3)
+  helpers.report('prob_points (weighted)', pred['prob_points'], ref['_prob_points'], atol=1e-9, rtol=2e-3)
+  helpers.report('scores_poses', pred['scores_poses'], ref['scores_poses'], atol=1e-4, rtol=2e-3)
+  helpers.assert_same_argmax('best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                             got_index=pred['best_index'])
+
+
 def test_localizer_grid_refinement_parity():
   cfg = helpers.tiny_localizer_config(refine=True, num_pose_samples=32)
   pred, ref = _run(cfg, 1, 3, (64, 64), seed=3)
