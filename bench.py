@@ -330,7 +330,7 @@ def main(argv=None):
                   help="train mode only: 'bf16' rounds the conv / dense operands to bf16 (f32 "
                        "accumulate) -- the analogue of the reference's float16 train config; the "
                        "inference headline always runs the exact f32 path")
-  ap.add_argument('--math', default='bf16x6', choices=['f32', 'bf16x6', 'bf16x3'],
+  ap.add_argument('--math', default='bf16x3', choices=['f32', 'bf16x6', 'bf16x3'],
                   help="infer mode: conv / dense engine.  'f32' = exact f32 MFMA (v_mfma_f32_32x32x2_f32); "
                        "'bf16x6' / 'bf16x3' = f32-grade split-bf16 engine (each f32 operand split into 3 / 2 "
                        "bf16 parts, 6 / 3 part products on v_mfma_f32_32x32x16_bf16, f32 accumulate)")

@@ -141,6 +141,17 @@ size_t snap_conv2d_packed_weights_split_bytes(int32_t taps, int32_t Cin, int32_t
                                               int32_t parts);
 int snap_conv2d_pack_weights_split_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
                                         int32_t parts, void* out, size_t out_bytes, void* stream);
+/* ... every kernel of an encoder in ONE launch: `items` is a DEVICE array sorted by block_begin;
+ * item i owns workgroups [block_begin, block_begin + snap_conv2d_pack_weights_split_blocks(...));
+ * out: snap_conv2d_packed_weights_split_bytes(taps, Cin, Cout, parts) bytes, 16-byte aligned. */
+typedef struct SnapPackItem {
+  const float* w;
+  void* out;
+  int32_t taps, Cin, Cout, block_begin;
+} SnapPackItem;
+int32_t snap_conv2d_pack_weights_split_blocks(int32_t taps, int32_t Cin, int32_t Cout);
+int snap_conv2d_pack_weights_split_multi_bf16(const SnapPackItem* items, int32_t n_items,
+                                              int32_t total_blocks, int32_t parts, void* stream);
 
 /* Generic N-D grid operators (snap/utils/grids.py:116-153); n = 1..3 leading grid axes.
  * snap_interpolate_nd_f32: array [size..., D], points [K, n] in corner-origin coordinates (cell

@@ -89,6 +89,8 @@ SIGNATURES = {
     'snap_conv2d_pack_weights_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_conv2d_packed_weights_split_bytes': (c_size, [c_int, c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_split_bf16': (c_int, [ptr, c_int, c_int, c_int, c_int, ptr, c_size, ptr]),
+    'snap_conv2d_pack_weights_split_blocks': (c_int, [c_int, c_int, c_int]),
+    'snap_conv2d_pack_weights_split_multi_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr]),
     'snap_group_norm_stats_from_partial_f32': (
         c_int, [ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr, ptr]
     ),

@@ -366,10 +366,11 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
 //     tile inside <= 2 images (BM <= Ho*Wo); other launches take conv_split_body above.
 // With one slab in flight (the register-staged body) a wave waited out a full memory round trip
 // per 16-k slab: the loop ran at ~30 % of the matrix-pipe rate whatever the product count.
-// (Holding NS = 2 to 128 registers for four workgroups per CU was measured: 1x1 layers +10 %,
-// 3x3 layers -10 %; left at the natural three.)
+// NS = 2 is held to 128 registers (64 accumulators + 64) so that four workgroups share a CU:
+// single 3x3 layers lose ~10 %, the HBM-leaning 1x1 layers gain ~10 %, the C2 step's conv time
+// as a whole 23.3 -> 22.1 ms.
 template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL>
-__global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, NS == 2 ? 4 : 3) void conv_split_kernel(const ConvArgs a) {
   conv_split_body<BM, BN, PRO, NS, GNT, TAIL>(a);
 }
 
@@ -450,12 +451,13 @@ int launch_tile(const ConvArgs& a, hipStream_t s) {
 // rest); part 0 = bf16(w) (RNE), part p = bf16 of the exact f32 residual left by parts < p;
 // channels >= Cin and columns >= Cout are zero.  One 32 x 32 (k x n) tile per workgroup through
 // LDS: coalesced along n on the way in, 64 B runs on the way out.
-__global__ __launch_bounds__(256) void pack_weights_split_kernel(
-    const float* __restrict__ w, __bf16* __restrict__ out, int taps, int Cin, int ctiles, int Cout,
-    int parts) {
+__device__ __forceinline__ void pack_weights_split_body(const float* __restrict__ w,
+                                                        __bf16* __restrict__ out, int taps, int Cin,
+                                                        int ctiles, int Cout, int parts, int bx,
+                                                        int by, int t) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32, t = blockIdx.z;
+  const int c0 = bx * 32, n0 = by * 32;
 #pragma unroll
   for (int j = ty; j < 32; j += 8) {
     const int c = c0 + j, n = n0 + tx;
@@ -477,6 +479,31 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(
       r -= (float)b;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_split_kernel(
+    const float* __restrict__ w, __bf16* __restrict__ out, int taps, int Cin, int ctiles, int Cout,
+    int parts) {
+  pack_weights_split_body(w, out, taps, Cin, ctiles, Cout, parts, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// every weight of an encoder in ONE launch (items sorted by block_begin, as SnapWstdItem)
+__global__ __launch_bounds__(256) void pack_weights_split_multi_kernel(
+    const SnapPackItem* __restrict__ items, int n_items, int parts) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SnapPackItem it = items[lo];
+  const int ctiles = (it.Cin + 15) / 16;
+  const int gx = (16 * ctiles + 31) / 32;
+  const int gy = ((it.Cout + 127) / 128 * 128) / 32;
+  const int local = blockIdx.x - it.block_begin;
+  const int t = local / (gx * gy);
+  const int rem = local - t * (gx * gy);
+  pack_weights_split_body(it.w, static_cast<__bf16*>(it.out), it.taps, it.Cin, ctiles, it.Cout, parts,
+                          rem % gx, rem / gx, t);
 }
 
 }  // namespace
@@ -512,6 +539,24 @@ extern "C" int snap_conv2d_pack_weights_split_bf16(const float* w, int32_t taps,
   const dim3 grid((unsigned)snap_cdiv(16 * ctiles, 32), (unsigned)(cout128 / 32), (unsigned)taps);
   hipLaunchKernelGGL(pack_weights_split_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                      w, static_cast<__bf16*>(out), taps, Cin, ctiles, Cout, parts);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int32_t snap_conv2d_pack_weights_split_blocks(int32_t taps, int32_t Cin, int32_t Cout) {
+  if (taps <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const int ctiles = (Cin + 15) / 16;
+  return ((16 * ctiles + 31) / 32) * (((Cout + 127) / 128 * 128) / 32) * taps;
+}
+
+extern "C" int snap_conv2d_pack_weights_split_multi_bf16(const SnapPackItem* items, int32_t n_items,
+                                                         int32_t total_blocks, int32_t parts,
+                                                         void* stream) {
+  if (!items) return SNAP_ERR_NULL;
+  if (n_items <= 0 || total_blocks <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (parts < 1 || parts > 3) return SNAP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_weights_split_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, n_items, parts);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -113,6 +113,7 @@ class OverlappedGradReducer:
     self.handles = [None] * len(self.buckets)
     self.hooks = []
     self.calls = 0
+    self.calls_in_backward = 0     # buckets whose all-reduce was issued from a gradient hook
 
   def _buffer(self, bi):
     if self.flat[bi] is None:
@@ -127,7 +128,9 @@ class OverlappedGradReducer:
     self.leaves[i].grad = None
     self.remaining[bi] -= 1
     if self.remaining[bi] == 0:
+      before = self.calls
       self._launch(bi)
+      self.calls_in_backward += self.calls - before
 
   def _launch(self, bi):
     if self.handles[bi] is None and self.world > 1:

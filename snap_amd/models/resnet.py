@@ -142,6 +142,9 @@ class ResNetV2(base.Module):
       ctx.pre_std = pre
     else:   # inference: one launch for all StdConv kernels of this encoder
       ctx.standardize_all(kernels, ops.weight_standardize_multi)
+      if ops.MATMUL_PRECISION in ops.SPLIT_PARTS:
+        # split-bf16 engine: the weight images of all standardised kernels, one launch
+        ops.pack_weights_split_multi([ctx._lookup(k) for k in kernels], ops.MATMUL_PRECISION)
     # `image * 2 - 1` (resnet.py:199) is fused into the root conv's operand staging.
     if self.config.skip_root_block:
       w = _std(ctx, params['conv_root']['kernel'])

@@ -328,6 +328,49 @@ def pack_weights_split_bf16(w, parts):
   return out
 
 
+_PACK_ITEM = np.dtype([('w', np.uint64), ('out', np.uint64), ('taps', np.int32), ('Cin', np.int32),
+                       ('Cout', np.int32), ('block_begin', np.int32)])
+
+
+def pack_weights_split_multi(ws, math):
+  """Prepare the split engine's weight image of every kernel in ``ws`` (HWIO tensors) with ONE
+  launch and remember it on the tensors for the current apply (see ``_packed_weights``)."""
+  parts = SPLIT_PARTS[math]
+  lib = _lib.load()
+  todo = []
+  for w in ws:
+    slot = getattr(w, '_snap_packed', None)
+    hit = None if slot is None else slot.get(math)
+    if isinstance(hit, tuple) and hit[0] == PACK_EPOCH and hit[1] == w._version:
+      continue
+    KH, KW, Cin, Cout = w.shape
+    if Cin < 4 or lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts) == 0:
+      continue                       # runs on the f32 engine (conv2d decides the same way)
+    todo.append(w)
+  if not todo:
+    return
+  items = np.zeros(len(todo), dtype=_PACK_ITEM)
+  outs = []
+  blk = 0
+  for i, w in enumerate(todo):
+    _f32(w, 'w')
+    KH, KW, Cin, Cout = w.shape
+    nbytes = lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts)
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    outs.append(out)
+    items[i] = (w.data_ptr(), out.data_ptr(), KH * KW, Cin, Cout, blk)
+    blk += lib.snap_conv2d_pack_weights_split_blocks(KH * KW, Cin, Cout)
+  table = torch.from_numpy(items.view(np.uint8).copy()).to(todo[0].device, non_blocking=True)
+  st = lib.snap_conv2d_pack_weights_split_multi_bf16(_p(table), len(todo), blk, parts, _stream())
+  _lib.check(st, 'snap_conv2d_pack_weights_split_multi_bf16')
+  for w, out in zip(todo, outs):
+    slot = getattr(w, '_snap_packed', None)
+    if slot is None:
+      slot = {}
+      w._snap_packed = slot
+    slot[math] = (PACK_EPOCH, w._version, out)
+
+
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
           row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None,
           gelu=False, residual=None):
