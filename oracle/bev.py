@@ -99,13 +99,14 @@ def build_xyz_query(config, grid, scene_t_view, xy_bev=None, z_offset=None):
   return np.concatenate([xy_b, z_b[..., :1]], axis=-1).astype(dtype)
 
 
-def fuse_neural_maps(config, planes):
+def fuse_neural_maps(config, planes, params=None):
   """bev_mapper.py:225-252 (modality dropout never fires: train is not forwarded)."""
   if len(planes) == 1:
     return planes[0]
   features = np.stack([p['features'] for p in planes], axis=-2)
   valid = np.stack([p['valid'] for p in planes], axis=-1)
-  return vertical_pooling(config['modality_fusion'], features, valid)
+  out = vertical_pooling(config['modality_fusion'], features, valid, params)
+  return dict(features=out['features'], valid=out['valid'])
 
 
 def matching_head(params, config, plane):
@@ -158,7 +159,7 @@ def bev_mapper(params, config, grid, data):
     plane = dict(features=f, valid=np.ones(f.shape[:-1], bool))
     pred['semantic'] = {'feature_plane': plane}
     planes.append(plane)
-  pred['bev_features'] = plane = fuse_neural_maps(config, planes)
+  pred['bev_features'] = plane = fuse_neural_maps(config, planes, params.get('modality_fusion'))
   if config.get('matching_dim') is not None:
     pred['bev_matching'] = matching_head(params, config, plane)
   if config.get('add_confidence'):

@@ -115,11 +115,12 @@ class BEVMapper(base.Module):
     elif len(feature_dimensions) > 1:
       if not all(d == feature_dimensions[0] for d in feature_dimensions):
         raise ValueError(f'Encoder have different output dimensions: {feature_dimensions}')
-      if config.modality_fusion.pooling not in ('max', 'sum', 'mean'):
-        raise NotImplementedError(
-            f'modality_fusion.pooling={config.modality_fusion.pooling}: only max/sum/mean are '
-            'fused with the matching head (plane_fuse_match)')
-      self.modality_fusion = VerticalPooling(config.modality_fusion, dtype)
+      # max / sum / mean are fused with the matching head in one kernel (plane_fuse_match); the
+      # learned modes ('softmax' / 'weighted' / 'mlp', bev_mapper.py:63-78 reused at :250-252)
+      # pool the stacked planes with the same kernels as the vertical pooling
+      self.modality_fusion = VerticalPooling(
+          config.modality_fusion, dtype, num_levels=len(feature_dimensions),
+          feature_dim=feature_dimensions[0])
     self.feature_dim = feature_dimensions[0]
     if config.bev_net is not None:
       raise NotImplementedError('BEV network not yet implemented')
@@ -134,7 +135,7 @@ class BEVMapper(base.Module):
     if self.semantic_encoder is not None:
       params['semantic_encoder'] = self.semantic_encoder.init_params(gen, device)
     if self.modality_fusion is not None:
-      params['modality_fusion'] = {}
+      params['modality_fusion'] = self.modality_fusion.init_params(gen, device)
     if self.config.matching_dim is not None:
       dm = self.config.matching_dim
       # variance_scaling(1/sqrt(dm), 'fan_in', 'truncated_normal') (bev_mapper.py:145-153)
@@ -241,7 +242,16 @@ class BEVMapper(base.Module):
     pooling = (
         self.modality_fusion.config.pooling if self.modality_fusion is not None else 'max'
     )
+    if len(feature_planes) > 1 and pooling not in ('max', 'sum', 'mean'):
+      # learned modality fusion: VerticalPooling over the stacked planes (bev_mapper.py:246-252)
+      stacked = types.FeatureVolume(
+          features=torch.stack([p.features for p in feature_planes], dim=-2).contiguous(),
+          valid=torch.stack([p.valid for p in feature_planes], dim=-1).contiguous())
+      feature_planes = [self.modality_fusion(params['modality_fusion'], stacked)['plane']]
+      pooling = 'max'                 # (one plane left: the fused kernel only adds the matching head)
     single = len(feature_planes) == 1
+    if single:
+      pooling = 'max'                   # nothing to fuse (fuse_neural_maps returns the plane, :230-231)
     feats = [p.features for p in feature_planes]
     pfm = ops.plane_fuse_match
     if base.needs_grad(*feats, *( [mp['kernel'], mp['bias']] if has_match else [])):

@@ -50,6 +50,20 @@ def sample_transforms_ransac_batched(
   return geometry.Transform2D.from_packed(poses), corr
 
 
+def sample_transforms_random(rng, num, grid, device=None):
+  """pose_estimation.py:85-97: ``num`` poses uniform in angle and within 2/3 of the grid extent
+  around its centre, expressed in the corner frame.  ``rng``: int seed or torch.Generator (CPU);
+  the draws come from torch's generator (JAX's threefry stream cannot be reproduced)."""
+  gen = rng if isinstance(rng, torch.Generator) else torch.Generator(device='cpu').manual_seed(int(rng))
+  angle = torch.rand(num, generator=gen) * (2 * np.pi)
+  size = torch.tensor(np.asarray(grid.extent_meters, np.float32))
+  t_max = size * 2 / 3
+  translation = (torch.rand(num, 2, generator=gen) * 2 - 1) * t_max
+  centre = geometry.Transform2D(angle.to(device), translation.to(device))
+  corner_t_center = geometry.Transform2D(torch.zeros((), device=device), (size / 2).to(device))
+  return corner_t_center @ centre @ corner_t_center.inv
+
+
 def refinement_offsets(device):
   """The 41 x 41 x 41 (rotation, x, y) lattice of pose_estimation.py:178-184."""
   delta_p, delta_r, range_p, range_r = 0.2, 0.25, 4, 5

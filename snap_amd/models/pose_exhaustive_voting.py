@@ -123,11 +123,20 @@ def _match(tw, cw, tcount, R, q_hw, m, m_valid, min_overlap, templates=None):
 
 def template_matching(q, q_valid, m, m_valid, do_padding=True, min_overlap=0.05):
   """pose_exhaustive_voting.py:72-104 with explicit templates q [R,H,W,D]."""
-  if not do_padding:
-    raise NotImplementedError('do_padding=False')
   R, H, W, D = q.shape
   cw = q_valid.flip(1, 2).permute(1, 2, 0).to(torch.float32)[:, :, None, :].contiguous()
   tcount = q_valid.sum((-1, -2)).to(torch.float32)
+  if not do_padding:
+    # :82-86: no edge padding and jax.scipy.signal.convolve(mode='full') == the same
+    # cross-correlation over the map extended by ZEROS.  The reference's overlap test pads the
+    # validity mask regardless of do_padding (:93-96), which gives it a [4H-3, 4W-3] count
+    # against [2H-1, 2W-1] scores: only min_overlap=None is a working combination there.
+    if min_overlap is not None:
+      raise ValueError('template_matching(do_padding=False) needs min_overlap=None '
+                       '(the reference\'s shapes disagree otherwise)')
+    mp = torch.nn.functional.pad(m, (0, 0, W - 1, W - 1, H - 1, H - 1)).contiguous()
+    raw = _correlate(mp, None, R, (H, W), q.contiguous())
+    return ops.template_finalize(raw, None, tcount, R, 0.0, use_overlap=False)
   return _match(None, cw, tcount, R, (H, W), m, m_valid, min_overlap, templates=q.contiguous())
 
 

@@ -1244,3 +1244,31 @@ def test_ransac_sample_rows_follow_the_confidence_cdf():
     z = (cnt - S2 * p) / np.sqrt(np.maximum(S2 * p * (1 - p), 1e-9))
     assert np.abs(z[p > 0]).max() < 5.0
     assert cnt[p == 0].sum() == 0
+
+
+def test_template_matching_without_padding_is_the_zero_extended_correlation():
+  """pose_exhaustive_voting.py:82-91 with do_padding=False: jax.scipy.signal.convolve(mode='full')
+  of the flipped templates == the cross-correlation over the map extended by zeros; checked
+  against scipy.signal.convolve(method='direct') itself."""
+  import scipy.signal
+  from snap_amd.models import pose_exhaustive_voting as pev
+  rng = np.random.default_rng(31)
+  R, H, D = 8, 12, 4
+  q = rng.standard_normal((R, H, H, D)).astype(np.float32)
+  qv = rng.uniform(size=(R, H, H)) > 0.2
+  q = q * qv[..., None]
+  m = rng.standard_normal((H, H, D)).astype(np.float32)
+  mv = np.ones((H, H), bool)
+  got = pev.template_matching(torch.from_numpy(q).to(DEV), torch.from_numpy(qv).to(DEV),
+                              torch.from_numpy(m).to(DEV), torch.from_numpy(mv).to(DEV),
+                              do_padding=False, min_overlap=None)
+  want = np.zeros((R, 2 * H - 1, 2 * H - 1))
+  for r in range(R):
+    for d in range(D):
+      want[r] += scipy.signal.convolve(q[r, ::-1, ::-1, d].astype(np.float64), m[..., d].astype(np.float64),
+                                       mode='full', method='direct')
+    want[r] /= qv[r].sum()
+  helpers.report('template matching, no padding', got, want.astype(np.float32), atol=2e-5, rtol=1e-5)
+  with pytest.raises(ValueError):
+    pev.template_matching(torch.from_numpy(q).to(DEV), torch.from_numpy(qv).to(DEV),
+                          torch.from_numpy(m).to(DEV), torch.from_numpy(mv).to(DEV), do_padding=False)

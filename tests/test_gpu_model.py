@@ -102,6 +102,23 @@ def test_localizer_with_query_confidence_parity():
                              got_index=pred['best_index'])
 
 
+@pytest.mark.parametrize('pooling', ['softmax', 'weighted'])
+def test_learned_modality_fusion_parity(pooling):
+  """modality_fusion.pooling = 'softmax' / 'weighted' (bev_mapper.py:246-252 reuses
+  VerticalPooling, :63-78, over the stacked StreetView / aerial planes)."""
+  cfg = helpers.tiny_localizer_config(top_k=2)
+  cfg.bev_mapper.modality_fusion.pooling = pooling
+  pred, ref = _run(cfg, 2, 3, (64, 64), seed=9)
+  helpers.report(f'bev_features ({pooling} fusion)', pred['map']['bev_features'].features,
+                 ref['map']['bev_features']['features'], atol=1e-3)
+  assert np.array_equal(pred['map']['bev_features'].valid.cpu().numpy(), ref['map']['bev_features']['valid'])
+  helpers.report('map bev_matching', pred['map']['bev_matching'].features,
+                 ref['map']['bev_matching']['features'], atol=1e-3)
+  helpers.report('scores_poses', pred['scores_poses'], ref['scores_poses'], atol=1e-3, rtol=1e-3)
+  helpers.assert_same_argmax('best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                             got_index=pred['best_index'])
+
+
 def test_localizer_grid_refinement_parity():
   cfg = helpers.tiny_localizer_config(refine=True, num_pose_samples=32)
   pred, ref = _run(cfg, 1, 3, (64, 64), seed=3)

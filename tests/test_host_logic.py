@@ -383,3 +383,24 @@ def test_reference_batch_adapter():
   shard1 = adapter.from_reference_batch(refp, device_axis=1)
   assert torch.equal(shard1['query']['images'], ours['query']['images'][2:])
   assert shard1['batch_mask'].shape == (2,)
+
+
+def test_sample_transforms_random_is_uniform_in_the_corner_frame():
+  """pose_estimation.py:85-97: uniform angles, translations within 2/3 of the extent around the
+  grid CENTRE, returned in the corner frame (corner_t_center @ T @ corner_t_center^-1)."""
+  import torch
+  from snap_amd.models import pose_estimation
+  from snap_amd.utils import geometry, grids
+  grid = grids.Grid2D((120, 160), 0.2)
+  tf = pose_estimation.sample_transforms_random(7, 5000, grid, device='cpu')
+  assert tf.angle.shape == (5000,) and tf.t.shape == (5000, 2)
+  size = torch.tensor([24.0, 32.0])
+  c = geometry.Transform2D(torch.zeros(()), size / 2)
+  centre = c.inv @ tf @ c
+  ang = torch.remainder(centre.angle, 2 * np.pi)
+  assert float(ang.min()) >= 0 and float(ang.max()) < 2 * np.pi + 1e-5
+  assert abs(float(ang.mean()) - np.pi) < 0.15
+  lim = size * 2 / 3
+  assert bool((centre.t.abs() <= lim + 1e-3).all()) and float(centre.t.abs().max()) > 0.9 * float(lim.min())
+  again = pose_estimation.sample_transforms_random(7, 5000, grid, device='cpu')
+  assert torch.equal(again.t, tf.t) and torch.equal(again.angle, tf.angle)
