@@ -354,6 +354,8 @@ def main(argv=None):
   if world > 1:
     dist.init_process_group(args.dist_backend or ('nccl' if use_cuda else 'gloo'))
 
+  if not use_cuda:
+    args.math = 'f32'        # (--device cpu exists for the gloo plumbing test only: oracle backend)
   is_c4 = bool(WORKLOADS[args.workload].get('c4'))
   if is_c4:
     if args.mode != 'infer':
