@@ -171,7 +171,12 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   };
   set_tap();
 
+  // a.ablate (SNAP_CONV_ABLATE, timing experiments only -- wrong results): bit0 no A loads,
+  // bit1 no B DMA, bit2 no MFMAs, bit3 no prologue / split math, bit4 no A LDS stores, bit5 no
+  // fragment fetches
+  const int ablate = a.ablate;
   auto load_a = [&]() {
+    if (ablate & 1) return;
     const int c = ct * BK + 4 * akq;
     cur_c = c;
     const bool cvalid = c < d.Cin;
@@ -209,6 +214,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
               (part < NS ? part : 0) * 4096 + (gcol & 127) * 32 + (rem & 1) * 16;
   }
   auto issue_b = [&](int buf) {
+    if (ablate & 2) return;
 #pragma unroll
     for (int p = 0; p < BPIECES; ++p) {
       const int slot = tid + 256 * p;
@@ -244,6 +250,18 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     }
   };
   auto store_a = [&](int buf, int ring) {
+    if (ablate & 16) return;
+    if (ablate & 8) {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int row = (tid / QPR) + RPP * i;
+        char* dst = Ab + buf * A_ST + row * 32 + (akq >> 1) * 16 + (akq & 1) * 8;
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          *reinterpret_cast<u32x2*>(dst + p * A_PART) = u32x2{__float_as_uint(xa[i][0]), __float_as_uint(xa[i][1])};
+      }
+      return;
+    }
     const float* const tb = reinterpret_cast<const float*>(Gt + ring * kGnRing);
     if constexpr (gn_tab) xbeta = *reinterpret_cast<const f32x4*>(tb + 64 + 4 * akq);
 #pragma unroll
@@ -310,25 +328,37 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     const char* as = Ab + cur * A_ST;
     const char* bs = Bb + cur * B_ST;
     bf16x8 av[TM][NS], bv[TN][NS];
+    if (!(ablate & 32)) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int R = wr * (BM / 2) + i * 32 + l31;
-      const char* p0 = as + R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
+      for (int i = 0; i < TM; ++i) {
+        const int R = wr * (BM / 2) + i * 32 + l31;
+        const char* p0 = as + R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(p0 + p * A_PART);
-    }
+        for (int p = 0; p < NS; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(p0 + p * A_PART);
+      }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int C = wc * (BN / 2) + j * 32 + l31;
-      const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+      for (int j = 0; j < TN; ++j) {
+        const int C = wc * (BN / 2) + j * 32 + l31;
+        const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(p0 + p * B_PART);
+        for (int p = 0; p < NS; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(p0 + p * B_PART);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) asm volatile("" : "=v"(av[i][p]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) asm volatile("" : "=v"(bv[j][p]));
     }
     // smallest terms first; the four (i, j) accumulators interleave so that two MFMAs on the
     // same accumulator are TM*TN issues apart
 #define SNAP_SPLIT_PRODUCT(PA, PB)                                                          \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA], bv[j][PB], acc[i][j], 0, 0, 0);
+    if (!(ablate & 4)) {
     if constexpr (NS == 3) {
       SNAP_SPLIT_PRODUCT(2, 0)
       SNAP_SPLIT_PRODUCT(0, 2)
@@ -340,6 +370,16 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
       SNAP_SPLIT_PRODUCT(1, 0)
       SNAP_SPLIT_PRODUCT(0, 1)
       SNAP_SPLIT_PRODUCT(0, 0)
+    }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) asm volatile("" ::"v"(av[i][p]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) asm volatile("" ::"v"(bv[j][p]));
     }
 #undef SNAP_SPLIT_PRODUCT
     if (more) store_a(cur ^ 1, ring_next);
