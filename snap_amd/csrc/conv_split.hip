@@ -174,7 +174,10 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   // a.ablate (SNAP_CONV_ABLATE, timing experiments only -- wrong results): bit0 no A loads,
   // bit1 no B DMA, bit2 no MFMAs, bit3 no prologue / split math, bit4 no A LDS stores, bit5 no
   // fragment fetches
-  const int ablate = a.ablate;
+#ifndef SNAP_CONV_SPLIT_ABLATE
+#define SNAP_CONV_SPLIT_ABLATE 0     // build with EXTRA=-DSNAP_CONV_SPLIT_ABLATE=1 (an alt library:
+#endif                               // the hooks cost registers, 11 spilled VGPRs at 4 waves / SIMD)
+  const int ablate = SNAP_CONV_SPLIT_ABLATE ? a.ablate : 0;
   auto load_a = [&]() {
     if (ablate & 1) return;
     const int c = ct * BK + 4 * akq;

@@ -1,5 +1,8 @@
 """Ablation timing of the split-bf16 conv engine on one layer (tuning only; results are wrong
 with any bit set): python tools/conv_ablate_split.py <layer index> <math>.
+Needs a library built with the hooks compiled in:
+  make -C snap_amd/csrc OUT=../lib/alt/libsnap_hip.so OBJDIR=../lib/alt/obj EXTRA=-DSNAP_CONV_SPLIT_ABLATE=1
+  SNAP_HIP_LIB=snap_amd/lib/alt/libsnap_hip.so python tools/conv_ablate_split.py 6 bf16x3
 Bits (SNAP_CONV_ABLATE): 1 no A loads, 2 no B DMA, 4 no MFMAs, 8 no prologue/split math,
 16 no A LDS stores, 32 no fragment fetches."""
 import os
