@@ -156,12 +156,16 @@ def _pmc_traffic(kernel, launches, workload):
   passes on this workload, gfx950 x2 read correction applied).  None if unavailable."""
   if workload != 'c2':
     return None
-  path = os.path.join(ROOT, 'profiles', 'r01_c2_hbm_traffic.json')
-  try:
-    with open(path) as f:
-      rec = json.load(f)['per_step'].get(kernel)
-  except (OSError, ValueError, KeyError):
-    return None
+  fam = 'conv_split' if kernel.startswith('conv_split') else kernel
+  rec = None
+  for name in ('r02_c2_hbm_traffic.json', 'r01_c2_hbm_traffic.json'):   # newest round first
+    try:
+      with open(os.path.join(ROOT, 'profiles', name)) as f:
+        rec = json.load(f)['per_step'].get(fam)
+    except (OSError, ValueError, KeyError):
+      rec = None
+    if rec:
+      break
   if not rec or not launches:
     return None
   return round((rec['hbm_read_bytes'] + rec['hbm_write_bytes']) / launches, 1)

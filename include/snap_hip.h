@@ -390,6 +390,16 @@ int snap_ransac_sample_f32(const float* fq, const float* fm,
  * prefix of the chunk masses is built once per row instead of once per sample (~34 samples
  * share a row at the default sizes).  Bit-identical output. */
 size_t snap_ransac_sample_workspace_bytes(int32_t B, int32_t Nq);
+/* ... with sim [B, Nq, X*Y] (the tensor snap_sim_softmax*_f32 wrote) and row_unscale [B, Nq]
+ * (num_valid[b], or 1 / row_weight[b, n]: x = sim * row_unscale) the selected chunk's 64 scores
+ * are READ (256 contiguous bytes) instead of re-evaluated from 8 KB of map features; both NULL =
+ * re-evaluate.  Same distribution; the scores agree to one rounding. */
+int snap_ransac_sample_sim_f32(const float* fq, const float* fm, const float* chunk_stats,
+                               const float* row_cdf, const float* sim, const float* row_unscale,
+                               int32_t B, int32_t Nq, int32_t X, int32_t Y, int32_t Dm, float scale,
+                               int32_t clip_negative, int32_t S, uint64_t seed,
+                               const float* uniforms, int32_t* corr, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* ... with row_cdf [B, Nq] (inclusive, from snap_masked_softmax_rows_f32) the query point of a
  * sample is drawn from that distribution instead of uniformly (confidence-weighted prob_points). */
 int snap_ransac_sample_rows_f32(const float* fq, const float* fm, const float* chunk_stats,

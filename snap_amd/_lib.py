@@ -136,6 +136,11 @@ SIGNATURES = {
     ),
     'snap_masked_softmax_rows_f32': (c_int, [ptr, ptr, c_int, c_int, ptr, ptr, ptr]),
     'snap_confidence_head_f32': (c_int, [ptr, ptr, ptr, c_float, c_i64, c_int, ptr, ptr]),
+    'snap_ransac_sample_sim_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+         c_int, c_u64, ptr, ptr, ptr, c_size, ptr],
+    ),
     'snap_ransac_sample_rows_f32': (
         c_int,
         [ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int,

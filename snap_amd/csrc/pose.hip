@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     int Nq, int X, int Y, float scale, int clip, int S, uint64_t seed,
     const float* __restrict__ uniforms, int32_t* __restrict__ corr,
     const float* __restrict__ lane_incl, const float* __restrict__ rowmax,
-    const float* __restrict__ row_cdf) {
+    const float* __restrict__ row_cdf, const float* __restrict__ sim,
+    const float* __restrict__ row_unscale) {
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -469,7 +470,13 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
   const int cell = cstar * SIM_CH + lane;
   const bool cvalid = cell < XY;
   float e = 0.f;
-  if (cvalid) {
+  if (cvalid && sim) {
+    // the chunk's scores were written by the similarity kernel: 256 contiguous bytes of sim
+    // (x = sim * num_valid, or sim / weight, to within one rounding) instead of re-evaluating 64
+    // dot products from 8 KB of map features -- the sampler was bound by that L2 traffic
+    // (10.8 GB per C2 step, 1.75 ms)
+    e = expf(sim[row * (int64_t)XY + cell] * row_unscale[row] - mc);
+  } else if (cvalid) {
     const f32x4* mp = reinterpret_cast<const f32x4*>(fm + ((int64_t)b * XY + cell) * DM);
     const f32x4* qp = reinterpret_cast<const f32x4*>(fq + row * DM);
     float dot = 0.f;
@@ -1197,7 +1204,20 @@ extern "C" int snap_ransac_sample_rows_f32(const float* fq, const float* fm,
                                            int32_t S, uint64_t seed, const float* uniforms,
                                            int32_t* corr, void* workspace, size_t workspace_bytes,
                                            void* stream) {
+  return snap_ransac_sample_sim_f32(fq, fm, chunk_stats, row_cdf, nullptr, nullptr, B, Nq, X, Y, Dm,
+                                    scale, clip_negative, S, seed, uniforms, corr, workspace,
+                                    workspace_bytes, stream);
+}
+
+extern "C" int snap_ransac_sample_sim_f32(const float* fq, const float* fm,
+                                          const float* chunk_stats, const float* row_cdf,
+                                          const float* sim, const float* row_unscale, int32_t B,
+                                          int32_t Nq, int32_t X, int32_t Y, int32_t Dm, float scale,
+                                          int32_t clip_negative, int32_t S, uint64_t seed,
+                                          const float* uniforms, int32_t* corr, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   if (!fq || !fm || !chunk_stats || !corr) return SNAP_ERR_NULL;
+  if ((sim == nullptr) != (row_unscale == nullptr)) return SNAP_ERR_NULL;
   if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || S <= 0) return SNAP_ERR_BAD_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* lane_incl = nullptr;
@@ -1214,10 +1234,10 @@ extern "C" int snap_ransac_sample_rows_f32(const float* fq, const float* fm,
   }
   const dim3 grid((unsigned)snap_cdiv(S, 4), (unsigned)B);
   switch (Dm) {
-    case 8: hipLaunchKernelGGL(ransac_sample_kernel<8>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
-    case 16: hipLaunchKernelGGL(ransac_sample_kernel<16>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
-    case 32: hipLaunchKernelGGL(ransac_sample_kernel<32>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
-    case 64: hipLaunchKernelGGL(ransac_sample_kernel<64>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf); break;
+    case 8: hipLaunchKernelGGL(ransac_sample_kernel<8>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf, sim, row_unscale); break;
+    case 16: hipLaunchKernelGGL(ransac_sample_kernel<16>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf, sim, row_unscale); break;
+    case 32: hipLaunchKernelGGL(ransac_sample_kernel<32>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf, sim, row_unscale); break;
+    case 64: hipLaunchKernelGGL(ransac_sample_kernel<64>, grid, dim3(256), 0, s, fq, fm, chunk_stats, Nq, X, Y, scale, clip_negative, S, seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf, sim, row_unscale); break;
     default: return SNAP_ERR_UNSUPPORTED;
   }
   SNAP_CHECK_LAUNCH();

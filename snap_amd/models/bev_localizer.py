@@ -143,8 +143,13 @@ class BEVLocalizer(base.Module):
       sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob,
                                             row_weight=weights)
     # the sampler sees stop_gradient(prob_points) (bev_localizer.py:178): detached inputs.
+    # x = sim * row_unscale: lets the sampler read the selected chunk's scores back from sim
+    if weights is not None:
+      row_unscale = torch.where(weights > 0, 1.0 / weights.clamp(min=1e-38), torch.zeros_like(weights))
+    else:
+      row_unscale = num_valid[:, None].expand(-1, fq.shape[1]).contiguous()
     matching = dict(fq=fq.detach(), fm=fm.detach(), chunk_stats=stats, scale=scale, clip=clip,
-                    row_cdf=row_cdf)
+                    row_cdf=row_cdf, sim=sim.detach(), row_unscale=row_unscale.contiguous())
     return sim, prob, matching
 
   def __call__(self, params, data, train=False, debug=False, rng=None,

@@ -44,7 +44,8 @@ def sample_transforms_ransac_batched(
   corr = ops.ransac_sample(
       matching['fq'], matching['fm'], matching['chunk_stats'], matching['scale'],
       matching['clip'], S, seed=0 if rng is None else int(rng), uniforms=uniforms,
-      row_cdf=matching.get('row_cdf'),
+      row_cdf=matching.get('row_cdf'), sim=matching.get('sim'),
+      row_unscale=matching.get('row_unscale'),
   )
   poses = ops.poses_from_corr(corr, i_xy_p.contiguous(), num_poses, num_retries, grid.cell_size)
   return geometry.Transform2D.from_packed(poses), corr

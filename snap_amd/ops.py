@@ -827,7 +827,7 @@ def confidence_head(features, valid, kernel, bias):
 
 
 def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
-                  uniforms=None, row_table=True, row_cdf=None):
+                  uniforms=None, row_table=True, row_cdf=None, sim=None, row_unscale=None):
   """Draw S correspondences per scene ~ prob_points.  Returns int32 [B,S,3].
   row_table=False takes the table-free path (same samples; tests compare the two)."""
   lib = _lib.load()
@@ -844,12 +844,16 @@ def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0,
     ws = torch.empty(lib.snap_ransac_sample_workspace_bytes(B, Nq) // 4, dtype=torch.float32,
                      device=fq.device)
   with _region('ransac_sample', 0.0, 12.0 * B * S):
-    st = lib.snap_ransac_sample_rows_f32(
-        _p(fq), _p(fm), _p(chunk_stats), _p(row_cdf), B, Nq, X, Y, Dm, float(scale),
-        int(clip_negative), S, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(uniforms),
+    if sim is not None:
+      _f32(sim, 'sim'); _f32(row_unscale, 'row_unscale')
+      if sim.numel() != B * Nq * X * Y or tuple(row_unscale.shape) != (B, Nq):
+        raise ValueError('ransac_sample: sim must be [B,Nq,X,Y], row_unscale [B,Nq]')
+    st = lib.snap_ransac_sample_sim_f32(
+        _p(fq), _p(fm), _p(chunk_stats), _p(row_cdf), _p(sim), _p(row_unscale), B, Nq, X, Y, Dm,
+        float(scale), int(clip_negative), S, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(uniforms),
         _p(corr), _p(ws), 0 if ws is None else ws.numel() * 4, _stream(),
     )
-  _lib.check(st, 'snap_ransac_sample_rows_f32')
+  _lib.check(st, 'snap_ransac_sample_sim_f32')
   return corr
 
 

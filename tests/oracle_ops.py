@@ -269,7 +269,8 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
   return _t(x / nv, fq), _t(stats, fq), prob, rowstats
 
 
-def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0, uniforms=None, row_cdf=None):
+def ransac_sample(fq, fm, chunk_stats, scale, clip_negative, S, seed=0, uniforms=None, row_cdf=None,
+                  sim=None, row_unscale=None):
   """Two-level inverse-CDF sampler in float64 (same scheme as pose.hip)."""
   q, m = _np(fq, np.float64), _np(fm, np.float64)
   B, Nq, _ = q.shape

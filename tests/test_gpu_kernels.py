@@ -1272,3 +1272,29 @@ def test_template_matching_without_padding_is_the_zero_extended_correlation():
   with pytest.raises(ValueError):
     pev.template_matching(torch.from_numpy(q).to(DEV), torch.from_numpy(qv).to(DEV),
                           torch.from_numpy(m).to(DEV), torch.from_numpy(mv).to(DEV), do_padding=False)
+
+
+def test_ransac_sample_reading_the_chunk_scores_from_sim():
+  """The sampler may read the selected chunk's 64 scores from the sim tensor (x = sim * num_valid,
+  one rounding away from the re-evaluated dot products) instead of recomputing them: same
+  distribution, and with injected uniforms the same correspondences except where a CDF step falls
+  inside that rounding."""
+  B, Nq, X, Y, Dm, S = 2, 90, 24, 20, 32, 20000
+  fq = _unit(rnd((B, Nq, Dm), 395)).to(DEV)
+  fm = _unit(rnd((B, X, Y, Dm), 396)).to(DEV)
+  nv = torch.tensor([88.0, 90.0], device=DEV)
+  scale = float(np.exp(2.0))
+  sim, stats, _, _ = ops.sim_softmax(fq, fm, scale, True, nv)
+  u = torch.rand((B, S, 2), generator=torch.Generator().manual_seed(397)).to(DEV)
+  a = ops.ransac_sample(fq, fm, stats, scale, True, S, uniforms=u)
+  unscale = nv[:, None].expand(B, Nq).contiguous()
+  b = ops.ransac_sample(fq, fm, stats, scale, True, S, uniforms=u, sim=sim, row_unscale=unscale)
+  assert torch.equal(a[..., 0], b[..., 0])
+  same = (a == b).all(-1).float().mean()
+  assert float(same) > 0.999, float(same)
+  # where they differ, they differ by ONE cell within the chunk (a CDF boundary)
+  diff = (a != b).any(-1)
+  if bool(diff.any()):
+    ca = a[diff][:, 1].long() * Y + a[diff][:, 2].long()
+    cb = b[diff][:, 1].long() * Y + b[diff][:, 2].long()
+    assert int((ca - cb).abs().max()) <= 1

@@ -17,13 +17,14 @@ import sys
 
 # kernel-name substring -> bench.py kernel family (the KernelProfiler region names)
 FAMILIES = [
-    ('conv_igemm_kernel', 'conv_igemm'), ('splitk_reduce_kernel', 'conv_igemm'),
+    ('conv_igemm_kernel', 'conv_igemm'), ('conv_split_kernel', 'conv_split'), ('splitk_reduce_kernel', 'conv_split'),
+    ('pack_weights_split', 'pack_weights'),
     ('pose_score_db_kernel', 'pose_score'), ('pose_score_kernel', 'pose_score'),
     ('pose_table', 'pose_score'), ('pose_score_reduce', 'pose_score'),
     ('lift_pool_batched_kernel', 'lift_pool'), ('lift_pool_kernel', 'lift_pool'),
     ('vertical_pool_kernel', 'vertical_pool'), ('vertical_pool_wave_kernel', 'vertical_pool'),
     ('gn_partial_kernel', 'group_norm_stats'), ('gn_finalize_kernel', 'group_norm_stats'),
-    ('sim_kernel', 'sim_softmax'), ('row_stats_kernel', 'sim_softmax'),
+    ('sim_kernel', 'sim_softmax'), ('sim_mfma_kernel', 'sim_softmax'), ('row_stats_kernel', 'sim_softmax'),
     ('ransac_sample_kernel', 'ransac_sample'), ('chunk_prefix_kernel', 'ransac_sample'), ('weight_std', 'weight_standardize'),
     ('plane_fuse_match', 'plane_fuse_match'), ('max_pool_kernel', 'max_pool'),
     ('count_rows_kernel', 'compact_rows'), ('scan_blocks_kernel', 'compact_rows'),
@@ -70,7 +71,7 @@ def main():
           'bytes = WRITE_SIZE x 1024. per_step = bytes of ONE bench step per kernel family '
           '(tools/make_hbm_traffic.py).')
   json.dump({'_note': note, 'kernels': kernels, 'per_step': per_step}, open(out, 'w'), indent=1)
-  for fam in ('conv_igemm', 'pose_score', 'lift_pool', 'sim_softmax'):
+  for fam in ('conv_igemm', 'conv_split', 'pose_score', 'lift_pool', 'sim_softmax'):
     if fam in per_step:
       print(fam, {k: f'{v / 1e9:.3f} GB' for k, v in per_step[fam].items()})
 
