@@ -300,14 +300,21 @@ typedef struct SnapLiftDesc {
   int32_t out_stride;          /* row stride (floats) of `pooled`, >= 2*fd+1, %4==0 */
   float depth_min, depth_max;  /* depth_min_max                                    */
   float max_view_distance;     /* < 0: disabled                                    */
+  /* fusion options of pool_multiview_features (streetview_encoder.py:141-178); the reference
+   * default is weighted = 1, use_variance = 1, add_minmax = 0 */
+  int32_t weighted;            /* do_weighted_fusion: depth-score softmax weights + the
+                                  score_max channel; 0: plain mean / variance (scores = None),
+                                  f_images carries no score bins (C = feature_dim)  */
+  int32_t use_variance;        /* fusion_use_variance                              */
+  int32_t add_minmax;          /* fusion_add_minmax: + max, min over the valid views */
 } SnapLiftDesc;
 
 /* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) tan(max_fov/2)(1) ALREADY scaled to
  * the feature-map resolution (the last entry is read by the fisheye path instead of
  * evaluating tanf per voxel and view: geometry.py:262 `radius < tan(0.5 * max_fov)`); Rt: [B,V,12] = R row-major (9) then t (3) of
  * T_view2scene; points: [B,N,3].
- * pooled: [B,N,out_stride] = mean(fd) | var(fd) | score_max(1) | zero pad;
- * valid: [B,N] uint8. */
+ * pooled: [B,N,out_stride] = mean(fd) | var(fd)? | max(fd), min(fd)? | score_max(1)? | zero pad
+ * (default options: mean | var | score_max);  valid: [B,N] uint8. */
 int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_images,
                        const float* cam, const float* Rt, const float* points,
                        float* pooled, uint8_t* valid, void* stream);

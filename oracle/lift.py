@@ -187,13 +187,15 @@ def streetview_encoder(params, config, data):
   scene_t_view = data['T_view2scene']
   pred = {'image_feature_pyramid': f_image_pyr}
 
-  assert config['do_weighted_fusion'], 'only the default path is restated'
-  proj_config = dict(
-      layers=(config['feature_dim'] + config['num_scale_bins'],),
-      apply_input_activation=config['proj_mlp']['apply_input_activation'],
-  )
-  f_images = encoder.mlp(params['proj_mlp'], proj_config, f_images)
-  pred['scores_images'] = f_images[..., -config['num_scale_bins']:]
+  weighted = bool(config['do_weighted_fusion'])
+  assert weighted or config.get('depth_mlp') is None, 'depth_mlp fusion is not restated'
+  if weighted:
+    proj_config = dict(
+        layers=(config['feature_dim'] + config['num_scale_bins'],),
+        apply_input_activation=config['proj_mlp']['apply_input_activation'],
+    )
+    f_images = encoder.mlp(params['proj_mlp'], proj_config, f_images)
+    pred['scores_images'] = f_images[..., -config['num_scale_bins']:]
 
   xyz = data['xyz_query']
   xyz_flat = xyz.reshape(len(xyz), -1, 3)
@@ -215,10 +217,13 @@ def streetview_encoder(params, config, data):
     min_distance = None
 
   fd = config['feature_dim']
-  f_proj, scores_scales = f_proj[..., :fd], f_proj[..., fd:]
-  scores_proj = interpolate_depth_score(
-      scores_scales, depth, config['depth_min_max']
-  )
+  if weighted:
+    f_proj, scores_scales = f_proj[..., :fd], f_proj[..., fd:]
+    scores_proj = interpolate_depth_score(
+        scores_scales, depth, config['depth_min_max']
+    )
+  else:
+    scores_proj = None      # streetview_encoder.py:261-262
   f_pooled, valid = pool_multiview_features(
       f_proj,
       visible,

@@ -47,6 +47,7 @@ class SnapLiftDesc(ctypes.Structure):
       ('fisheye', c_int), ('out_stride', c_int),
       ('depth_min', c_float), ('depth_max', c_float),
       ('max_view_distance', c_float),
+      ('weighted', c_int), ('use_variance', c_int), ('add_minmax', c_int),
   ]
 
 

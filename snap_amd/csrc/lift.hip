@@ -112,6 +112,101 @@ __device__ __forceinline__ Taps make_taps(float pi, float pj, int h, int w, int 
   return t;
 }
 
+// Pooling for the NON-default fusion options of pool_multiview_features
+// (streetview_encoder.py:141-178): unweighted statistics (scores = None: plain mean / variance over
+// the valid views, no score channel), fusion_use_variance = False, fusion_add_minmax = True.
+// Row layout: mean | var? | max, min? | score_max?  (the default kernels keep their own
+// specialised code: mean | var | score_max).
+template <int KMAX>
+__device__ __forceinline__ void pool_generic(const SnapLiftDesc& d, const f32x4 (&feat)[KMAX],
+                                             const float (&score)[KMAX], const bool (&ok)[KMAX],
+                                             int nvis, int hl, float* out) {
+  const int fd = d.feature_dim;
+  const int nq = fd >> 2;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, var = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mx = {0.f, 0.f, 0.f, 0.f}, mn = {0.f, 0.f, 0.f, 0.f};
+  float smax = 0.f;
+  if (nvis > 0) {
+    float wgt[KMAX];
+    if (d.weighted) {
+      float m = 0.f;
+      smax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (ok[r]) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
+      float den = 0.f;
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r) {
+        wgt[r] = ok[r] ? expf(score[r] - m) : 0.f;
+        den += wgt[r];
+      }
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r) wgt[r] = wgt[r] / den;
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (ok[r])
+#pragma unroll
+          for (int c = 0; c < 4; ++c) mean[c] += wgt[r] * feat[r][c];
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (ok[r])
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float dl = feat[r][c] - mean[c];
+            var[c] += wgt[r] * (dl * dl);
+          }
+    } else {
+      // jnp.mean / jnp.var(where=valid): sums over the valid views divided by their count
+      const float cnt = (float)nvis;
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (ok[r])
+#pragma unroll
+          for (int c = 0; c < 4; ++c) mean[c] += feat[r][c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mean[c] = mean[c] / cnt;
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (ok[r])
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float dl = feat[r][c] - mean[c];
+            var[c] += dl * dl;
+          }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) var[c] = var[c] / cnt;
+    }
+    mx = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mn = f32x4{INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r)
+      if (ok[r])
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          mx[c] = fmaxf(mx[c], feat[r][c]);
+          mn[c] = fminf(mn[c], feat[r][c]);
+        }
+  }
+  int off = 0;
+  if (hl < nq) *reinterpret_cast<f32x4*>(out + 4 * hl) = mean;
+  off += fd;
+  if (d.use_variance) {
+    if (hl < nq) *reinterpret_cast<f32x4*>(out + off + 4 * hl) = var;
+    off += fd;
+  }
+  if (d.add_minmax) {
+    if (hl < nq) {
+      *reinterpret_cast<f32x4*>(out + off + 4 * hl) = mx;
+      *reinterpret_cast<f32x4*>(out + off + fd + 4 * hl) = mn;
+    }
+    off += 2 * fd;
+  }
+  if (hl == 0) {
+    if (d.weighted) out[off++] = smax;
+    for (int c = off; c < d.out_stride; ++c) out[c] = 0.f;
+  }
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
   const SnapLiftDesc& d = a.d;
@@ -209,6 +304,7 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
       for (int e = 0; e < 4; ++e)
         feat[r][e] = ((t.w00 * a00[e] + t.w01 * a01[e]) + t.w10 * a10[e]) + t.w11 * a11[e];
     }
+    if (!d.weighted) continue;           // (scores = None: no depth-score bins in f_images)
     // depth score: two neighbouring log-depth bins, each bilinearly gathered.
     const float dc = fminf(fmaxf(depth, d.depth_min), d.depth_max);
     const float tt = logf(dc / d.depth_min) / log_range;
@@ -226,6 +322,18 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
 
   // ---- k5: softmax-weighted mean / variance / max score ---------------------
   float* out = a.pooled + gv * d.out_stride;
+  if (!(d.weighted && d.use_variance && !d.add_minmax)) {      // non-default fusion options
+    int nvis = 0;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) nvis += ok[r] ? 1 : 0;
+    pool_generic<KMAX>(d, feat, score, ok, nvis, hl, out);
+    if (hl == 0) {
+      bool vld = any;
+      if (d.max_view_distance >= 0.f && !all_views) vld = vld && (min_dist <= d.max_view_distance);
+      a.valid[gv] = vld ? 1 : 0;
+    }
+    return;
+  }
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, var = {0.f, 0.f, 0.f, 0.f};
   float smax = 0.f;
   if (any) {
@@ -495,8 +603,11 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
   if (d.V > 32) return SNAP_ERR_UNSUPPORTED;
   if (d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0) return SNAP_ERR_UNSUPPORTED;
-  if (d.C != d.feature_dim + d.num_bins || d.C % 4 != 0 || d.num_bins < 1) return SNAP_ERR_BAD_SHAPE;
-  if (d.out_stride < 2 * d.feature_dim + 1 || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const bool dflt = d.weighted && d.use_variance && !d.add_minmax;
+  const int bins = d.weighted ? d.num_bins : 0;
+  if (d.C != d.feature_dim + bins || d.C % 4 != 0 || (d.weighted && d.num_bins < 1)) return SNAP_ERR_BAD_SHAPE;
+  const int chans = d.feature_dim * (1 + (d.use_variance ? 1 : 0) + (d.add_minmax ? 2 : 0)) + (d.weighted ? 1 : 0);
+  if (d.out_stride < chans || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
   if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;  // K>0 means V > K
   if (!(d.depth_max > d.depth_min) || !(d.depth_min > 0.f)) return SNAP_ERR_BAD_SHAPE;
   if ((reinterpret_cast<uintptr_t>(f_images) & 15) || (reinterpret_cast<uintptr_t>(pooled) & 15))
@@ -511,9 +622,9 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
     return !(e && e[0] == '0');
   }();
   const dim3 bgrid((unsigned)snap_cdiv(total, 256));   // 8 half-waves x 32 voxels
-  if (batched && nsel <= 1) {
+  if (dflt && batched && nsel <= 1) {
     hipLaunchKernelGGL(lift_pool_batched_kernel<1>, bgrid, dim3(256), 0, s, a);
-  } else if (batched && nsel <= 4) {
+  } else if (dflt && batched && nsel <= 4) {
     hipLaunchKernelGGL(lift_pool_batched_kernel<4>, bgrid, dim3(256), 0, s, a);
   } else if (nsel <= 1) {
     hipLaunchKernelGGL(lift_pool_kernel<1>, grid, dim3(256), 0, s, a);

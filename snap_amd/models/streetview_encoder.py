@@ -28,24 +28,32 @@ class StreetViewEncoder(base.Module):
           'pretrained_path: Flax checkpoint loading is out of scope '
           '(and broken in the reference, streetview_encoder.py:189).'
       )
-    if not config.do_weighted_fusion:
-      raise NotImplementedError('only do_weighted_fusion=True (the default) is built')
-    if config.fusion_add_minmax or not config.fusion_use_variance:
-      raise NotImplementedError('only mean+variance+max-score fusion (the default) is built')
+    if not config.do_weighted_fusion and config.depth_mlp is not None:
+      raise NotImplementedError('depth_mlp fusion (a per-observation MLP, streetview_encoder.py:263-267)')
     self.config = config
     self.image_encoder = image_encoder.ImageEncoder(config.image_encoder, dtype)
     fd = config.feature_dim
-    self.fusion_mlp = layers.MLP(config.fusion, in_dim=2 * fd + 1)
-    proj_config = copy.deepcopy(config.proj_mlp)
-    proj_config.layers = (fd + config.num_scale_bins,)
-    self.proj_mlp = layers.MLP(proj_config, in_dim=config.image_encoder.output_dim)
+    self.weighted = bool(config.do_weighted_fusion)
+    self.default_fusion = (self.weighted and bool(config.fusion_use_variance)
+                           and not config.fusion_add_minmax)
+    self.fusion_mlp = layers.MLP(config.fusion, in_dim=ops.pooled_channels(
+        fd, self.weighted, bool(config.fusion_use_variance), bool(config.fusion_add_minmax)))
+    self.proj_mlp = None
+    if self.weighted:
+      # fusion features and depth scores from one linear layer (streetview_encoder.py:207-213)
+      proj_config = copy.deepcopy(config.proj_mlp)
+      proj_config.layers = (fd + config.num_scale_bins,)
+      self.proj_mlp = layers.MLP(proj_config, in_dim=config.image_encoder.output_dim)
+    elif config.image_encoder.output_dim != fd:
+      raise ValueError('do_weighted_fusion=False: the image features are pooled as they are, '
+                       'image_encoder.output_dim must equal feature_dim')
 
   def init_params(self, gen, device):
-    return {
-        'image_encoder': self.image_encoder.init_params(gen, device),
-        'proj_mlp': self.proj_mlp.init_params(gen, device),
-        'fusion_mlp': self.fusion_mlp.init_params(gen, device),
-    }
+    params = {'image_encoder': self.image_encoder.init_params(gen, device)}
+    if self.proj_mlp is not None:
+      params['proj_mlp'] = self.proj_mlp.init_params(gen, device)
+    params['fusion_mlp'] = self.fusion_mlp.init_params(gen, device)
+    return params
 
   def __call__(self, params, data, train=False, ctx=None, rng=None):
     cfg = self.config
@@ -74,20 +82,31 @@ class StreetViewEncoder(base.Module):
     scene_t_view = data['T_view2scene']
     pred = {'image_feature_pyramid': f_image_pyr}
 
-    f_images = self.proj_mlp(params['proj_mlp'], f_images.contiguous(), train)
-    pred['scores_images'] = f_images[..., -cfg.num_scale_bins:]
+    if self.weighted:
+      f_images = self.proj_mlp(params['proj_mlp'], f_images.contiguous(), train)
+      pred['scores_images'] = f_images[..., -cfg.num_scale_bins:]
+    else:
+      f_images = f_images.contiguous()
 
     xyz = data['xyz_query']
     xyz_flat = xyz.reshape(len(xyz), -1, 3).contiguous()
     k_vs = cfg.top_k_view_selection
     K = k_vs if (k_vs and V > k_vs) else 0
-    lift = ag.lift_pool if base.needs_grad(f_images) else ops.lift_pool
+    kw = dict(K=K, fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
+              num_bins=cfg.num_scale_bins, depth_min_max=cfg.depth_min_max,
+              max_view_distance=cfg.get('max_view_distance'))
+    if base.needs_grad(f_images):
+      if not self.default_fusion:
+        raise NotImplementedError('non-default fusion options have no backward kernel yet')
+      lift = ag.lift_pool
+    else:
+      lift = ops.lift_pool
+      if not self.default_fusion:
+        kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
+                  add_minmax=bool(cfg.fusion_add_minmax))
     pooled, valid = lift(
         f_images, cameras.packed().to(torch.float32),
-        scene_t_view.packed().to(torch.float32), xyz_flat, K=K,
-        fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
-        num_bins=cfg.num_scale_bins, depth_min_max=cfg.depth_min_max,
-        max_view_distance=cfg.get('max_view_distance'),
+        scene_t_view.packed().to(torch.float32), xyz_flat, **kw,
     )
     f_grid = self.fusion_mlp(params['fusion_mlp'], pooled, train, row_mask=valid)
     grid_shape = (-1, *xyz.shape[-4:-1])

@@ -629,28 +629,36 @@ def max_pool_3x3s2(x):
 # ----------------------------------------------------------------------------
 # lift
 # ----------------------------------------------------------------------------
-def pooled_stride(feature_dim):
-  return (2 * feature_dim + 1 + 3) // 4 * 4
+def pooled_channels(feature_dim, weighted=True, use_variance=True, add_minmax=False):
+  """Channels of the pooled statistics: mean | var? | max, min? | score_max?
+  (pool_multiview_features, streetview_encoder.py:141-178)."""
+  return feature_dim * (1 + int(use_variance) + 2 * int(add_minmax)) + int(weighted)
+
+
+def pooled_stride(feature_dim, weighted=True, use_variance=True, add_minmax=False):
+  return (pooled_channels(feature_dim, weighted, use_variance, add_minmax) + 3) // 4 * 4
 
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
-              depth_min_max, max_view_distance=None):
+              depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
+              add_minmax=False):
   """Fused k1-k5.  f_images [B,V,h,w,C]; cam [B,V,11]; Rt [B,V,12]; points [B,N,3].
 
-  K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad),
-  valid [B,N] bool.
+  K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad by default;
+  see ``pooled_channels`` for the other fusion options), valid [B,N] bool.
   """
   lib = _lib.load()
   _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
   B, V, h, w, C = f_images.shape
   N = points.shape[1]
-  stride = pooled_stride(feature_dim)
+  stride = pooled_stride(feature_dim, weighted, use_variance, add_minmax)
   pooled = torch.empty((B, N, stride), dtype=torch.float32, device=f_images.device)
   valid = torch.empty((B, N), dtype=torch.bool, device=f_images.device)
   d = _lib.SnapLiftDesc(
-      B, V, h, w, C, feature_dim, num_bins, N, K, int(fisheye), stride,
+      B, V, h, w, C, feature_dim, num_bins if weighted else 0, N, K, int(fisheye), stride,
       float(depth_min_max[0]), float(depth_min_max[1]),
       -1.0 if max_view_distance is None else float(max_view_distance),
+      int(weighted), int(use_variance), int(add_minmax),
   )
   with _region(
       'lift_pool', 0.0, 4.0 * (f_images.numel() + points.numel() + pooled.numel())

@@ -148,6 +148,7 @@ def lift_pool_bwd(f_images, cam, Rt, points, dpooled, *, K, fisheye, feature_dim
       B, V, h, w, C, feature_dim, num_bins, N, K, int(fisheye), dpooled.shape[-1],
       float(depth_min_max[0]), float(depth_min_max[1]),
       -1.0 if max_view_distance is None else float(max_view_distance),
+      1, 1, 0,            # (the VJP exists for the default fusion options only)
   )
   df = torch.empty_like(f_images)
   with _region('lift_pool_bwd', 0.0, 4.0 * (f_images.numel() * 2 + dpooled.numel())):

@@ -159,8 +159,9 @@ def max_pool_3x3s2(x):
 
 
 # -- lift ------------------------------------------------------------------------
-def pooled_stride(feature_dim):
-  return (2 * feature_dim + 1 + 3) // 4 * 4
+def pooled_stride(feature_dim, weighted=True, use_variance=True, add_minmax=False):
+  ch = feature_dim * (1 + int(use_variance) + 2 * int(add_minmax)) + int(weighted)
+  return (ch + 3) // 4 * 4
 
 
 def unpack_cameras(cam, fisheye):
@@ -176,7 +177,8 @@ def unpack_transforms(Rt):
 
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
-              depth_min_max, max_view_distance=None):
+              depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
+              add_minmax=False):
   f = _np(f_images, DTYPE)
   cams = unpack_cameras(cam, fisheye)
   T = unpack_transforms(Rt)
@@ -192,11 +194,11 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   else:
     f_proj = o_lift.interpolate_views_all(f, p2d)
   feats, scales = f_proj[..., :feature_dim], f_proj[..., feature_dim:]
-  scores = o_lift.interpolate_depth_score(scales, depth, depth_min_max)
-  pooled, valid = o_lift.pool_multiview_features(feats, vis, scores, False, True)
+  scores = o_lift.interpolate_depth_score(scales, depth, depth_min_max) if weighted else None
+  pooled, valid = o_lift.pool_multiview_features(feats, vis, scores, add_minmax, use_variance)
   if max_view_distance is not None and min_distance is not None:
     valid = valid & (min_distance <= max_view_distance)
-  stride = pooled_stride(feature_dim)
+  stride = (pooled.shape[-1] + 3) // 4 * 4
   out = np.zeros(pooled.shape[:-1] + (stride,), pooled.dtype)
   out[..., : pooled.shape[-1]] = pooled
   return _t(out, f_images), _t(valid, f_images)

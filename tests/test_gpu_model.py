@@ -119,6 +119,26 @@ def test_learned_modality_fusion_parity(pooling):
                              got_index=pred['best_index'])
 
 
+def test_unweighted_minmax_fusion_parity():
+  """do_weighted_fusion=False (no proj_mlp, plain mean / variance over the views, no score
+  channel) + fusion_add_minmax=True: streetview_encoder.py:141-178,259-262."""
+  cfg = helpers.tiny_localizer_config(top_k=2)
+  sv = cfg.bev_mapper.streetview_encoder
+  sv.do_weighted_fusion = False
+  sv.fusion_add_minmax = True
+  pred, ref, ob, _ = _run(cfg, 2, 3, (64, 64), seed=10, want_batch=True)
+  assert 'scores_images' not in pred['map']['streetview']
+  _check_validity('map voxel validity', pred['map'], ref['map'], ob['map'], cfg)
+  vol, rvol = pred['map']['streetview']['feature_volume'], ref['map']['streetview']['feature_volume']
+  both = vol.valid.cpu().numpy() == rvol['valid']
+  helpers.report('feature volume (unweighted + minmax)', vol.features.cpu().numpy()[both],
+                 rvol['features'][both], atol=1e-3)
+  helpers.report('map bev_matching', pred['map']['bev_matching'].features,
+                 ref['map']['bev_matching']['features'], atol=1e-3)
+  helpers.assert_same_argmax('best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                             got_index=pred['best_index'])
+
+
 def test_localizer_grid_refinement_parity():
   cfg = helpers.tiny_localizer_config(refine=True, num_pose_samples=32)
   pred, ref = _run(cfg, 1, 3, (64, 64), seed=3)
