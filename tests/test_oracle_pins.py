@@ -13,6 +13,7 @@ import scipy.signal as sig
 import torch
 import torch.nn.functional as F
 
+from oracle import bev as o_bev
 from oracle import encoder as o_enc
 from oracle import geometry as o_geo
 from oracle import grids as o_grids
@@ -326,3 +327,75 @@ def test_semantic_net_cross_entropies_against_torch():
   ref = F.binary_cross_entropy_with_logits(torch.from_numpy(logits), torch.from_numpy(gt).double(),
                                            reduction='none').mean(-1).reshape(2, -1).mean(-1).numpy()
   np.testing.assert_allclose(nll, ref, rtol=1e-12)
+
+
+# -- pins the oracle does not generate itself (closed forms / hand arithmetic) -----------------
+def test_lift_of_an_affine_feature_field_is_the_field_at_the_projected_point():
+  """Bilinear interpolation reproduces an affine function exactly, so lifting an image whose
+  channel c is a_c * i + b_c * j + c_c must return that function evaluated at the projected
+  (continuous, half-pixel-centred) coordinate -- a closed form independent of any tap logic
+  (streetview_encoder.py:69-76, grids.py:116-137)."""
+  rng = np.random.default_rng(3)
+  B, V, h, w, D, N = 1, 2, 12, 16, 3, 200
+  a, b, c = rng.standard_normal((3, D))
+  ii, jj = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing='ij')   # pixel centres
+  img = (a * ii[..., None] + b * jj[..., None] + c).astype(np.float64)
+  f_images = np.broadcast_to(img, (B, V, h, w, D)).copy()
+  # interior points only (1 px away from the border: no clamped taps)
+  p2d = np.stack([rng.uniform(1.0, h - 1.0, (B, N, V)), rng.uniform(1.0, w - 1.0, (B, N, V))], -1)
+  got = o_lift.interpolate_views_all(f_images, p2d)
+  want = a * p2d[..., 0:1] + b * p2d[..., 1:2] + c
+  np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+  # the selective branch (top-K gather) follows the same closed form
+  idx = np.stack([rng.integers(0, V, (B, N)) for _ in range(2)], -1)
+  p_sel = np.take_along_axis(p2d, idx[..., None], axis=2)
+  got_s = o_lift.interpolate_views_selective(f_images, p_sel, idx)
+  np.testing.assert_allclose(got_s, a * p_sel[..., 0:1] + b * p_sel[..., 1:2] + c, rtol=0, atol=1e-12)
+
+
+def test_two_view_softmax_pooling_by_hand():
+  """pool_multiview_features (streetview_encoder.py:141-178) on numbers small enough to do by
+  hand: two valid views with scores 0.5 and 1.5, features (1, 2) and (3, 6).
+  softmax weights: e^0.5 / (e^0.5 + e^1.5) = 1 / (1 + e) and e / (1 + e)."""
+  e = np.e
+  w0, w1 = 1 / (1 + e), e / (1 + e)
+  feats = np.array([[[1.0, 2.0], [3.0, 6.0], [100.0, -100.0]]])       # third view is invalid
+  valid = np.array([[True, True, False]])
+  scores = np.array([[0.5, 1.5, 9.0]])
+  stats, ok = o_lift.pool_multiview_features(feats, valid, scores, add_minmax=True, use_variance=True)
+  mean = np.array([w0 * 1 + w1 * 3, w0 * 2 + w1 * 6])
+  var = np.array([w0 * (1 - mean[0]) ** 2 + w1 * (3 - mean[0]) ** 2,
+                  w0 * (2 - mean[1]) ** 2 + w1 * (6 - mean[1]) ** 2])
+  want = np.concatenate([mean, var, [3.0, 6.0], [1.0, 2.0], [1.5]])    # mean | var | max | min | score_max
+  assert ok.tolist() == [True]
+  np.testing.assert_allclose(stats[0], want, rtol=1e-13)
+  # no valid view at all: zeros and valid = False (the double-where keeps it finite)
+  stats0, ok0 = o_lift.pool_multiview_features(feats, np.array([[False, False, False]]), scores, True, True)
+  assert ok0.tolist() == [False] and not np.any(stats0)
+  # unweighted (scores = None): plain mean / population variance over the valid views
+  s2, _ = o_lift.pool_multiview_features(feats, valid, None, add_minmax=False, use_variance=True)
+  np.testing.assert_allclose(s2[0], [2.0, 4.0, 1.0, 4.0], rtol=1e-13)
+
+
+def test_softmax_where_initial_semantics():
+  """jax.nn.softmax(x, where=w, initial=0): JAX computes
+      unnormalized = exp(x - max(x, where=w, initial=0));  result = unnormalized / sum(unnormalized, where=w)
+  (jax/_src/nn/functions.py: `x_max = jnp.max(x, axis, where=where, initial=initial, keepdims=True)`),
+  i.e. the shift is max(0, max over the selected entries) -- mathematically the plain softmax over
+  the selected entries, numerically a different (never larger-than-needed) shift.  All-negative
+  scores therefore use shift 0.  KAT on both the view-pooling and the vertical-pooling restatement."""
+  x = np.array([-3.0, -1.0, -2.0, 50.0])
+  w = np.array([True, True, True, False])
+  want = np.exp(x[:3]) / np.exp(x[:3]).sum()            # shift 0 == plain softmax
+  got = o_bev.masked_softmax(x, w)
+  np.testing.assert_allclose(got[:3], want, rtol=1e-14)
+  assert got[3] == 0.0
+  # a positive maximum shifts by it (no overflow at large scores)
+  x2 = np.array([700.0, 699.0, -5.0])
+  got2 = o_bev.masked_softmax(x2, np.array([True, True, False]))
+  np.testing.assert_allclose(got2[:2], [1 / (1 + np.exp(-1.0)), np.exp(-1.0) / (1 + np.exp(-1.0))], rtol=1e-14)
+  # the same rule inside pool_multiview_features: weights of two all-negative scores
+  feats = np.array([[[1.0], [2.0]]])
+  stats, _ = o_lift.pool_multiview_features(feats, np.array([[True, True]]), np.array([[-2.0, -1.0]]), False, False)
+  wgt = np.exp([-2.0, -1.0]) / np.exp([-2.0, -1.0]).sum()
+  np.testing.assert_allclose(stats[0], [wgt[0] * 1 + wgt[1] * 2, -1.0], rtol=1e-14)
