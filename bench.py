@@ -35,7 +35,7 @@ from snap_amd.models import bev_localizer  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (train --precision bf16: operands staged from f32 HBM tensors)
-SPLIT_PRODUCTS = {'conv_split_bf16x6': 6, 'conv_split_bf16x3': 3}
+SPLIT_PRODUCTS = {'conv_split_bf16x6': 6, 'conv_split_bf16x3': 3, 'mlp2_pool_bf16x3': 3}
 INFER_DTYPE = {
     'f32': 'f32',
     'bf16x6': 'f32 (tensors, accumulation, every non-GEMM op); conv / dense products f32-grade on the bf16 '
@@ -67,7 +67,7 @@ WORKLOADS = {
 }
 
 
-def build(workload, device, rank):
+def build(workload, device, rank, materialize_volume=True):
   w = WORKLOADS[workload]
   meta = synthetic.meta_data(0.2, w['grid'])
   if w['tiny']:
@@ -81,6 +81,7 @@ def build(workload, device, rank):
       vcfg = defaults.image_encoder('vit')
       vcfg.output_dim = cfg.bev_mapper.streetview_encoder.image_encoder.output_dim
       cfg.bev_mapper.streetview_encoder.image_encoder = vcfg
+  cfg.bev_mapper.materialize_volume = bool(materialize_volume)
   loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
   variables = loc.init(0, device='cpu')
   variables = {'params': _to(variables['params'], device)}
@@ -338,6 +339,10 @@ def main(argv=None):
                   help="infer mode: conv / dense engine.  'f32' = exact f32 MFMA (v_mfma_f32_32x32x2_f32); "
                        "'bf16x6' / 'bf16x3' = f32-grade split-bf16 engine (each f32 operand split into 3 / 2 "
                        "bf16 parts, 6 / 3 part products on v_mfma_f32_32x32x16_bf16, f32 accumulate)")
+  ap.add_argument('--materialize-volume', action='store_true',
+                  help='infer mode: also write the dense [B, X, Y, Z, D] StreetView feature volume (an '
+                       'intermediate the localisation outputs do not need; under jit the reference drops it '
+                       'as dead code).  Default: only its vertical max, the BEV plane, is produced')
   ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                   help='infer: BEVLocalizer forward (the headline metric); train: one '
                        'snap_amd.trainer.train_step (fwd + bwd + grad all-reduce + Adam)')
@@ -367,7 +372,9 @@ def main(argv=None):
     c4_step, c4_algo = build_c4(device, rank)
     loc = cfg = meta = variables = batch = None
   else:
-    loc, cfg, meta, variables, batch = build(args.workload, device, rank)
+    loc, cfg, meta, variables, batch = build(
+        args.workload, device, rank,
+        materialize_volume=args.materialize_volume or args.mode != 'infer')
   scenes_per_rank = WORKLOADS[args.workload]['batch']
 
   if args.mode == 'train':
@@ -473,6 +480,8 @@ def main(argv=None):
             'mode': ('exhaustive voting + similarity + pose scoring + grid refinement (eval path)' if is_c4 else
                      'inference forward (BEVLocalizer.apply, train=False)' if args.mode == 'infer' else
                      f'train_step: forward + backward + gradient all-reduce + Adam ({args.precision})'),
+            'feature_volume': ('n/a' if is_c4 else 'materialized' if (args.materialize_volume or args.mode != 'infer')
+                               else 'not materialized: fusion MLP + vertical max pooling fused, plane only'),
         },
     }
     if args.mode == 'infer' and not is_c4:

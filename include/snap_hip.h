@@ -234,6 +234,28 @@ size_t snap_compact_rows_workspace_bytes(int64_t M);
 int snap_compact_rows_u8(const uint8_t* mask, int64_t M, int32_t* index, int32_t* count,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fusion MLP + vertical max pooling in one kernel (mlp_pool.hip) --------------------
+ * The two Dense layers of StreetViewEncoder.fusion_mlp (streetview_encoder.py:279-286,
+ * layers.py:55-78: Dense(H) -> relu -> Dense(D)) over the rows listed in `rows`, followed by
+ * VerticalPooling('max') (bev_mapper.py:78-88) over the Z levels of a column:
+ *   plane[col, :] = max over listed rows m with rows[m] / Z == col of Dense1(relu(Dense0(x[rows[m]])))
+ *   pvalid[col]   = the column has a listed row;  plane = 0 where it has none.
+ * Neither the hidden activations nor the [.., Z, D] feature volume are written.  Arithmetic:
+ * the split-bf16 engine with 2 parts ("bf16x3"); the plane equals, bit for bit, the one
+ * snap_conv2d_nhwc_ex_f32 (w_split_parts = 2) x 2 + snap_fill_masked_rows_f32 +
+ * snap_vertical_pool_f32 produce.
+ *   x [*, x_stride] f32 (Cin <= x_stride, x_stride % 4 == 0); rows / row_count from
+ *   snap_compact_rows_u8 (ascending); M = upper bound of the row count;
+ *   w0_split = snap_conv2d_pack_weights_split_bf16(W0 [Cin, H], taps 1, parts 2);
+ *   w1_split = the same packing of W1 [H, D];  H % 32 == 0, H <= 256; D % 4 == 0, D <= 128;
+ *   relu_in: MLP.apply_input_activation;  plane [ncols, D], pvalid [ncols]. */
+int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                           const int32_t* rows, const int32_t* row_count,
+                           const void* w0_split, size_t w0_bytes, const float* b0, int32_t H,
+                           const void* w1_split, size_t w1_bytes, const float* b1, int32_t D,
+                           int32_t relu_in, int32_t Z, int64_t ncols, float* plane,
+                           uint8_t* pvalid, void* stream);
+
 /* y[m, 0..C) = value for every row with mask[m] == 0 (the masked voxels of a volume
  * whose observed rows were written through rows_out).  C % 4 == 0. */
 int snap_fill_masked_rows_f32(float* y, const uint8_t* mask, int64_t M, int32_t C,

@@ -97,6 +97,8 @@ SIGNATURES = {
     ),
     'snap_compact_rows_workspace_bytes': (c_size, [c_i64]),
     'snap_compact_rows_u8': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_size, ptr]),
+    'snap_mlp2_pool_max_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, ptr, c_int,
+                                       ptr, c_size, ptr, c_int, c_int, c_int, c_i64, ptr, ptr, ptr]),
     'snap_fill_masked_rows_f32': (c_int, [ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_weight_standardize_f32': (c_int, [ptr, ptr, c_int, c_int, c_float, ptr]),
     'snap_weight_standardize_multi_f32': (c_int, [ptr, c_int, c_int, c_float, ptr]),
@@ -236,7 +238,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 

@@ -140,6 +140,7 @@ def bev_mapper(
       bev_net=config_dict.placeholder(ConfigDict),
       matching_dim=32, normalize_matching_features=True, add_confidence=False,
       apply_modality_dropout=True, pretrained_path=config_dict.placeholder(str),
+      materialize_volume=True,      # (not a reference key) False: only the pooled plane is needed
   )
   for m in modalities:
     m = MapModalities(m)

@@ -1,0 +1,397 @@
+// Fusion MLP + vertical max pooling of the StreetView encoder in ONE kernel: the two Dense layers
+// of StreetViewEncoder.fusion_mlp (snap/models/streetview_encoder.py:279-286, layers.py:55-78)
+// followed by VerticalPooling('max') (snap/models/bev_mapper.py:78-88), for the observed voxels
+// only.  Neither the hidden activations ([rows, 256] f32, written and re-read by the unfused
+// chain) nor the dense feature volume ([B, X, Y, Z, D], written, zero-filled, re-read by the
+// pooling) touch memory: the kernel reads the lift's `pooled` rows once and writes the plane.
+//
+// Arithmetic = the split-bf16 engine at NS = 2 ("bf16x3", conv_split.hip): f32 operands split
+// into hi + lo bf16 parts, three part products per MAC on v_mfma_f32_32x32x16_bf16, f32
+// accumulation, the same slab order and the same product order per accumulator -- the plane is
+// bitwise what conv_split + fill_masked_rows + vertical_pool produce.
+//
+// One workgroup (4 waves) = 128 rows of the compacted row list (snap_compact_rows_u8: observed
+// voxels in (b, x, y, z) order, so a column's levels are consecutive rows).  Each WAVE owns 32
+// rows and ALL hidden columns, and both GEMMs are computed TRANSPOSED (weights as the first MFMA
+// operand, rows as the second), so that an accumulator lane holds ONE row and 16 hidden columns:
+//   GEMM0  hidden^T[256 x 32 rows] = W0^T x^T      x: global -> registers -> split -> LDS
+//                                                  W0: packed image -> LDS by LDS-DMA (as conv_split)
+//   GEMM1  out^T[128 x 32 rows]    = W1^T relu(hidden + b0)^T
+//          the second operand comes STRAIGHT FROM THE GEMM0 ACCUMULATORS (bias, ReLU, split in
+//          registers): lane (row, half) of accumulator tile t holds hidden columns
+//          32t + 8q + 4 half + {0..3}, q = 0..3; k-step s of the tile takes q = 2s, 2s+1, and one
+//          v_permlane32_swap per register exchanges the middle quads of the two half-waves so
+//          that half 0 holds k = 0..7 and half 1 holds k = 8..15 of the slab -- the MFMA operand
+//          order of the unfused engine.  W1 (the same packed image) streams through a 3-slot
+//          LDS ring by LDS-DMA.
+//   max    out (+ b1) -> LDS, a scan down the rows per output channel with a flush at every
+//          column change -> float atomic max into the plane (prefilled with -inf; max is
+//          order-independent, so the result is deterministic); a finalize pass turns untouched
+//          columns into zeros / valid = 0 (the reference's where(any valid, max, 0)).
+#include "conv_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpPoolArgs {
+  const float* x;          // [*, x_stride] f32 rows (the lift's pooled statistics)
+  int64_t x_stride;
+  int Cin;                 // logical input width (257)
+  const int32_t* rows;     // compacted row list
+  const int32_t* row_count;
+  int M;                   // upper bound of the row count
+  const char* w0;          // split image of W0 [Cin, H] (snap_conv2d_pack_weights_split_bf16, parts 2)
+  int ctiles0;
+  const float* b0;
+  int H;
+  const char* w1;          // split image of W1 [H, D] (same packing, D <= 128: one column tile)
+  const float* b1;
+  int D;
+  int Z;                   // levels per column: column id = row / Z
+  float* plane;            // [ncols, D]
+};
+
+// hi / lo bf16 parts of four f32 (as conv_split.hip: one v_cvt_pk per pair, exact residual)
+__device__ __forceinline__ void split2(const f32x4& v, u32x2& hi, u32x2& lo) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x2 pr = {v[2 * h], v[2 * h + 1]};
+    const bf16x2 b = __builtin_convertvector(pr, bf16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &b, 4);
+    hi[h] = u;
+    const f32x2 rs = {pr[0] - __uint_as_float(u << 16), pr[1] - __uint_as_float(u & 0xffff0000u)};
+    const bf16x2 bl = __builtin_convertvector(rs, bf16x2);
+    __builtin_memcpy(&u, &bl, 4);
+    lo[h] = u;
+  }
+}
+
+__device__ __forceinline__ void atomic_max_f32(float* p, float v) {
+  const unsigned u = __float_as_uint(v);
+  if (u >> 31)
+    atomicMin(reinterpret_cast<unsigned*>(p), u);        // negative: larger float = smaller bits
+  else
+    atomicMax(reinterpret_cast<int*>(p), (int)u);
+}
+
+template <int N0, bool RELU_IN>
+__global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
+  constexpr int BM = 128, N1 = 128;
+  constexpr int T0 = N0 / 32, T1 = N1 / 32;
+  constexpr int A_PART = BM * 32, A_ST = 2 * A_PART;          // 8 KB per stage
+  constexpr int B0_ST = (N0 / 128) * 8192;                    // 16 KB per stage at N0 = 256
+  constexpr int kB0 = 2 * A_ST;
+  constexpr int kRing = 16384;                                // one W1 stage = two 16-k slabs
+  constexpr int kBias = 3 * kRing;                            // b0 [N0] | b1 [N1]
+  static_assert(kB0 + 2 * B0_ST <= kBias, "GEMM0 stages overlap the bias table");
+  __shared__ __attribute__((aligned(16))) float smem[16384];  // 64 KB
+  char* const sm = reinterpret_cast<char*>(smem);
+  float* const bias0 = reinterpret_cast<float*>(sm + kBias);
+  float* const bias1 = bias0 + N0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Meff = min(*a.row_count, a.M);
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= Meff) return;
+
+  for (int i = tid; i < N0 + N1; i += 256)
+    bias0[i] = i < N0 ? (i < a.H ? a.b0[i] : 0.f) : (i - N0 < a.D ? a.b1[i - N0] : 0.f);
+
+  // ---- GEMM0: A staging as conv_split_body (4 threads per row, 2 rows per thread) --------------
+  const int akq = tid & 3;
+  const float* r_px[2];
+  bool r_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + (tid >> 2) + 64 * i;
+    r_ok[i] = m < Meff;
+    r_px[i] = a.x + (int64_t)a.rows[r_ok[i] ? m : m0] * a.x_stride;
+  }
+  f32x4 xa[2];
+  bool xin[2];
+  int cur_c = 0;
+  auto load_a = [&](int ct) {
+    const int c = ct * 16 + 4 * akq;
+    cur_c = c;
+    const bool cvalid = c < a.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      xin[i] = r_ok[i] && cvalid;
+      xa[i] = *reinterpret_cast<const f32x4*>(xin[i] ? r_px[i] + c : a.x);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (tid >> 2) + 64 * i;
+      f32x4 v = xa[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = RELU_IN ? fmaxf(v[e], 0.f) : v[e];
+        v[e] = (xin[i] && cur_c + e < a.Cin) ? pv : 0.f;
+      }
+      u32x2 hi, lo;
+      split2(v, hi, lo);
+      const int oct = (akq >> 1) ^ ((row >> 3) & 1);
+      char* dst = sm + buf * A_ST + row * 32 + oct * 16 + (akq & 1) * 8;
+      *reinterpret_cast<u32x2*>(dst) = hi;
+      *reinterpret_cast<u32x2*>(dst + A_PART) = lo;
+    }
+  };
+  // W0 slab s: per column tile of 128 one contiguous 8 KB block [part][column][32 B]
+  constexpr int B0_PIECES = B0_ST / 16 / 256;
+  auto issue_b0 = [&](int buf, int s) {
+#pragma unroll
+    for (int p = 0; p < B0_PIECES; ++p) {
+      const int slot = tid + 256 * p;
+      const int j = slot >> 9;
+      const char* src = a.w0 + ((int64_t)j * a.ctiles0 + s) * 8192 + (slot & 511) * 16;
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                       (lds_void_t*)(sm + kB0 + buf * B0_ST + 16 * slot), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc0[T0];
+#pragma unroll
+  for (int t = 0; t < T0; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
+
+  load_a(0);
+  issue_b0(0, 0);
+  store_a(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int R = 32 * wid + l31;                                   // this lane's row of the tile
+  const int a_off = R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
+  const int w_off = l31 * 32 + ((lhi ^ ((l31 >> 3) & 1)) * 16);   // column 32 t' + l31 of a 128-tile
+  const int nk0 = a.ctiles0;
+  for (int kt = 0; kt < nk0; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk0;
+    if (more) {
+      load_a(kt + 1);
+      issue_b0(cur ^ 1, kt + 1);
+    }
+    const char* as = sm + cur * A_ST + a_off;
+    const char* bs = sm + kB0 + cur * B0_ST + w_off;
+    const bf16x8 x_hi = *reinterpret_cast<const bf16x8*>(as);
+    const bf16x8 x_lo = *reinterpret_cast<const bf16x8*>(as + A_PART);
+#pragma unroll
+    for (int g = 0; g < T0 / 4; ++g) {
+      bf16x8 w_hi[4], w_lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * g + j;
+        const char* p0 = bs + (t >> 2) * 8192 + (t & 3) * 1024;
+        w_hi[j] = *reinterpret_cast<const bf16x8*>(p0);
+        w_lo[j] = *reinterpret_cast<const bf16x8*>(p0 + 4096);
+      }
+      // per accumulator: x_lo w_hi, x_hi w_lo, x_hi w_hi (conv_split's order at NS = 2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc0[4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], x_lo, acc0[4 * g + j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc0[4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[j], x_hi, acc0[4 * g + j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc0[4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], x_hi, acc0[4 * g + j], 0, 0, 0);
+    }
+    if (more) store_a(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- GEMM1: W1 stages (two slabs = 16 KB each) through a 3-slot ring over the GEMM0 stages ----
+  const int nst = a.H >> 5;                                       // stages = accumulator tiles in use
+  auto issue_b1 = [&](int g) {
+    const char* src = a.w1 + (int64_t)g * kRing + tid * 16;
+    char* dst = sm + (g % 3) * kRing + tid * 16;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + 4096 * p),
+                                       (lds_void_t*)(dst + 4096 * p), 16, 0, 0);
+  };
+  issue_b1(0);
+  if (nst > 1) issue_b1(1);
+
+  f32x16 acc1[T1];
+#pragma unroll
+  for (int t = 0; t < T1; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+
+#pragma unroll
+  for (int g = 0; g < T0; ++g) {
+    if (g < nst) {
+      if (g + 1 < nst)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // stage g landed, g + 1 in flight
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (g + 2 < nst) issue_b1(g + 2);                           // slot of stage g - 1: drained
+      const char* ws = sm + (g % 3) * kRing + w_off;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        // relu(hidden + b0) of this lane's row, hidden columns 32 g + 16 s + {4 lhi + 0..3, 8 + 4 lhi + 0..3}
+        f32x4 v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias0 + 32 * g + 16 * s + 8 * q + 4 * lhi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(acc0[g][8 * s + 4 * q + e] + bb[e], 0.f);
+        }
+        // half 0: columns 0-3 | 8-11, half 1: 4-7 | 12-15  ->  half 0: 0-7, half 1: 8-15
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0][e]),
+                                                           __float_as_uint(v[1][e]), false, false);
+          v[0][e] = __uint_as_float(sw[0]);
+          v[1][e] = __uint_as_float(sw[1]);
+        }
+        u32x2 h0, l0, h1, l1;
+        split2(v[0], h0, l0);
+        split2(v[1], h1, l1);
+        const u32x4 hh = {h0[0], h0[1], h1[0], h1[1]};
+        const u32x4 ll = {l0[0], l0[1], l1[0], l1[1]};
+        bf16x8 h_hi, h_lo;
+        __builtin_memcpy(&h_hi, &hh, 16);
+        __builtin_memcpy(&h_lo, &ll, 16);
+        bf16x8 w_hi[T1], w_lo[T1];
+#pragma unroll
+        for (int j = 0; j < T1; ++j) {
+          const char* p0 = ws + s * 8192 + j * 1024;
+          w_hi[j] = *reinterpret_cast<const bf16x8*>(p0);
+          w_lo[j] = *reinterpret_cast<const bf16x8*>(p0 + 4096);
+        }
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_lo, acc1[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[j], h_hi, acc1[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_hi, acc1[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- + b1, stage [128 rows][128 channels] (float4 quads XOR-swizzled by the row) -------------
+#pragma unroll
+  for (int j = 0; j < T1; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias1 + 32 * j + 8 * q + 4 * lhi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc1[j][4 * q + e] += bb[e];
+    }
+  __syncthreads();                                                // ring and bias table drained
+#pragma unroll
+  for (int j = 0; j < T1; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int quad = (8 * j + 2 * q + lhi) ^ (R & 31);
+      *reinterpret_cast<f32x4*>(smem + R * N1 + 4 * quad) =
+          f32x4{acc1[j][4 * q], acc1[j][4 * q + 1], acc1[j][4 * q + 2], acc1[j][4 * q + 3]};
+    }
+  __syncthreads();
+
+  // ---- segmented max down the rows: thread = (channel, half of the tile) ------------------------
+  const int c = tid & 127;
+  const int h = tid >> 7;                                         // wave-uniform (two waves per half)
+  const int my = m0 + 64 * h + lane;
+  const int cid = my < Meff ? a.rows[my] / a.Z : -1;
+  int cur = -1;
+  float run = -INFINITY;
+  const bool live = c < a.D;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int cr = __builtin_amdgcn_readlane(cid, r);
+    if (cr != cur) {
+      if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
+      cur = cr;
+      run = -INFINITY;
+    }
+    const int row = 64 * h + r;
+    run = fmaxf(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
+  }
+  if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
+}
+
+// plane prefilled with -inf -> where(any level valid, max, 0) + the validity byte
+__global__ __launch_bounds__(256) void mlp2_pool_finalize_kernel(float* __restrict__ plane,
+                                                                 uint8_t* __restrict__ pvalid,
+                                                                 int64_t ncols, int D) {
+  const int Q = D >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncols * Q) return;
+  const int64_t col = i / Q;
+  f32x4* p = reinterpret_cast<f32x4*>(plane) + i;
+  f32x4 v = *p;
+  const bool any = v[0] != -INFINITY;
+  if (!any) *p = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (i - col * Q == 0) pvalid[col] = any ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, int64_t n4, float v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) reinterpret_cast<f32x4*>(p)[i] = f32x4{v, v, v, v};
+}
+
+}  // namespace
+
+extern "C" int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                                      const int32_t* rows, const int32_t* row_count,
+                                      const void* w0_split, size_t w0_bytes, const float* b0,
+                                      int32_t H, const void* w1_split, size_t w1_bytes,
+                                      const float* b1, int32_t D, int32_t relu_in, int32_t Z,
+                                      int64_t ncols, float* plane, uint8_t* pvalid, void* stream) {
+  if (!x || !rows || !row_count || !w0_split || !b0 || !w1_split || !b1 || !plane || !pvalid)
+    return SNAP_ERR_NULL;
+  if (M <= 0 || M > 0x7fffffffLL || Cin <= 0 || x_stride < Cin || x_stride % 4 != 0 || Z <= 0 ||
+      ncols <= 0 || ncols * Z > 0x7fffffffLL)
+    return SNAP_ERR_BAD_SHAPE;
+  if (H <= 0 || H % 32 != 0 || H > 256 || D <= 0 || D % 4 != 0 || D > 128) return SNAP_ERR_UNSUPPORTED;
+  if (w0_bytes < snap_conv2d_packed_weights_split_bytes(1, Cin, H, 2) ||
+      w1_bytes < snap_conv2d_packed_weights_split_bytes(1, H, D, 2))
+    return SNAP_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w0_split) |
+       reinterpret_cast<uintptr_t>(w1_split) | reinterpret_cast<uintptr_t>(plane)) & 15)
+    return SNAP_ERR_BAD_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n4 = ncols * (D / 4);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s, plane, n4,
+                     -INFINITY);
+  SNAP_CHECK_LAUNCH();
+  MlpPoolArgs a;
+  a.x = x; a.x_stride = x_stride; a.Cin = Cin;
+  a.rows = rows; a.row_count = row_count; a.M = (int)M;
+  a.w0 = static_cast<const char*>(w0_split); a.ctiles0 = (Cin + 15) / 16; a.b0 = b0; a.H = H;
+  a.w1 = static_cast<const char*>(w1_split); a.b1 = b1; a.D = D;
+  a.Z = Z; a.plane = plane;
+  const dim3 grid((unsigned)snap_cdiv(M, 128));
+  if (H <= 128) {
+    if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<128, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp2_pool_kernel<128, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<256, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp2_pool_kernel<256, false>), grid, dim3(256), 0, s, a);
+  }
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mlp2_pool_finalize_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s,
+                     plane, pvalid, ncols, D);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

@@ -189,7 +189,16 @@ class BEVMapper(base.Module):
   def encode_streetview(self, params, data, train, is_query, ctx=None, rng=None):
     if 'xyz_query' not in data:
       data['xyz_query'] = self.build_xyz_query(data, train, is_query, rng)
-    pred = self.streetview_encoder(params['streetview_encoder'], data, train=train, ctx=ctx)
+    # materialize_volume=False (an option of this implementation; under jit the reference's
+    # unused feature volume is dead code too): with max pooling the fusion MLP and the pooling
+    # run as one kernel and only the plane is written
+    pool_max = (not self.config.get('materialize_volume', True)
+                and self.vertical_pooling.config.pooling == 'max')
+    pred = self.streetview_encoder(params['streetview_encoder'], data, train=train, ctx=ctx,
+                                   pool_max=pool_max)
+    if 'feature_plane' in pred:
+      pred['vertical_pooling'] = {}
+      return pred
     pred['vertical_pooling'] = self.vertical_pooling(
         params.get('vertical_pooling', {}), pred['feature_volume'])
     pred['feature_plane'] = pred['vertical_pooling'].pop('plane')

@@ -55,7 +55,22 @@ class StreetViewEncoder(base.Module):
     params['fusion_mlp'] = self.fusion_mlp.init_params(gen, device)
     return params
 
-  def __call__(self, params, data, train=False, ctx=None, rng=None):
+  def _fused_pool_ok(self, params, pooled):
+    """The fusion MLP + vertical max pooling run as ONE kernel (ops.mlp2_pool_max) when nothing
+    needs gradients, the conv engine in use is the one the kernel is written for and the MLP
+    has the two-layer shape of the reference's configs."""
+    layers_ = tuple(self.config.fusion.layers)
+    if len(layers_) != 2 or ops.MATMUL_PRECISION != 'bf16x3':
+      return False
+    p = params['fusion_mlp']
+    if base.needs_grad(pooled, *(p[f'Dense_{i}'][k] for i in range(2) for k in ('kernel', 'bias'))):
+      return False
+    return ops.mlp2_pool_supported(self.fusion_mlp.in_dim, layers_[0], layers_[1])
+
+  def __call__(self, params, data, train=False, ctx=None, rng=None, pool_max=False):
+    """``pool_max``: the caller only needs the vertical max of the feature volume
+    (BEVMapper with ``pooling='max'`` and ``materialize_volume=False``); when the fused kernel
+    applies, ``pred['feature_plane']`` is returned and ``feature_volume.features`` is None."""
     cfg = self.config
     ctx = ctx or base.ForwardContext()
     f_image_pyr = data.get('image_feature_pyr')
@@ -108,8 +123,20 @@ class StreetViewEncoder(base.Module):
         f_images, cameras.packed().to(torch.float32),
         scene_t_view.packed().to(torch.float32), xyz_flat, **kw,
     )
-    f_grid = self.fusion_mlp(params['fusion_mlp'], pooled, train, row_mask=valid)
     grid_shape = (-1, *xyz.shape[-4:-1])
+    if pool_max and self._fused_pool_ok(params, pooled):
+      p = params['fusion_mlp']
+      plane, pvalid = ops.mlp2_pool_max(
+          pooled.reshape(-1, pooled.shape[-1]), valid.reshape(-1),
+          p['Dense_0']['kernel'], p['Dense_0']['bias'], p['Dense_1']['kernel'], p['Dense_1']['bias'],
+          cin=self.fusion_mlp.in_dim, Z=grid_shape[-1],
+          relu_in=bool(cfg.fusion.apply_input_activation))
+      pred['feature_volume'] = types.FeatureVolume(features=None, valid=valid.reshape(grid_shape))
+      pred['feature_plane'] = types.FeaturePlane(
+          features=plane.reshape(*grid_shape[:-1], plane.shape[-1]),
+          valid=pvalid.reshape(grid_shape[:-1]))
+      return pred
+    f_grid = self.fusion_mlp(params['fusion_mlp'], pooled, train, row_mask=valid)
     f_grid = f_grid.reshape(*grid_shape, f_grid.shape[-1])
     valid = valid.reshape(grid_shape)
     pred['feature_volume'] = types.FeatureVolume(features=f_grid, valid=valid)

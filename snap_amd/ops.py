@@ -500,6 +500,44 @@ def compact_rows(mask):
   return index, count
 
 
+def mlp2_pool_supported(cin, hidden, out_dim):
+  """Shapes the fused fusion-MLP + vertical-max-pool kernel takes (mlp_pool.hip)."""
+  return hidden % 32 == 0 and hidden <= 256 and out_dim % 4 == 0 and out_dim <= 128 and cin >= 4
+
+
+def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False):
+  """Fusion MLP (Dense -> relu -> Dense) over the rows with row_mask != 0 + max over the Z
+  levels of every column, in one kernel on the bf16x3 engine (streetview_encoder.py:279-286 +
+  bev_mapper.py:78-88).  x [M, Cs] (M = columns * Z, level fastest), row_mask [M];
+  w0 [cin, H], w1 [H, D] -> plane [M / Z, D] f32, pvalid [M / Z] bool.  The hidden activations
+  and the [M, D] volume are never written."""
+  lib = _lib.load()
+  _f32(x, 'x'); _mask(row_mask, 'row_mask')
+  for t, n in ((w0, 'w0'), (b0, 'b0'), (w1, 'w1'), (b1, 'b1')):
+    _f32(t, n)
+  M, Cs = x.shape
+  H, D = w1.shape
+  if M % Z != 0 or row_mask.numel() != M or tuple(w0.shape) != (cin, H):
+    raise ValueError('mlp2_pool_max: shapes')
+  if not mlp2_pool_supported(cin, H, D):
+    raise ValueError(f'mlp2_pool_max: unsupported widths {cin} -> {H} -> {D}')
+  index, count = compact_rows(row_mask)
+  w0p = pack_weights_split_bf16(w0.reshape(1, 1, cin, H), 2)
+  w1p = pack_weights_split_bf16(w1.reshape(1, 1, H, D), 2)
+  ncols = M // Z
+  plane = torch.empty(ncols, D, dtype=torch.float32, device=x.device)
+  pvalid = torch.empty(ncols, dtype=torch.bool, device=x.device)
+  kflops = 2.0 * (cin * H + H * D)
+  with _region('mlp2_pool_bf16x3', lambda: kflops * int(count.item()),
+               lambda: 4.0 * (int(count.item()) * cin + plane.numel()),
+               lambda: f'M{M}r_K{cin}_H{H}_N{D}_Z{Z}'):
+    st = lib.snap_mlp2_pool_max_f32(
+        _p(x), M, cin, Cs, _p(index), _p(count), _p(w0p), w0p.numel() * 2, _p(b0), H,
+        _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), Z, ncols, _p(plane), _p(pvalid), _stream())
+  _lib.check(st, 'snap_mlp2_pool_max_f32')
+  return plane, pvalid
+
+
 def fill_masked_rows_(y, mask, value=0.0):
   """In place: y[m, :] = value where mask[m] == 0.  y [..., C]."""
   lib = _lib.load()

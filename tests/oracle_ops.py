@@ -217,6 +217,22 @@ def vertical_pool(vol, valid, pooling='max'):
   return _t(out['features'], vol), _t(out['valid'], vol)
 
 
+def mlp2_pool_supported(cin, hidden, out_dim):
+  return True
+
+
+def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False):
+  xx = _np(x, DTYPE)[:, :cin]
+  if relu_in:
+    xx = np.maximum(xx, 0)
+  hid = np.maximum(xx @ _np(w0, DTYPE) + _np(b0, DTYPE), 0)
+  vol = hid @ _np(w1, DTYPE) + _np(b1, DTYPE)
+  m = _np(row_mask).astype(bool)
+  vol = np.where(m[:, None], vol, 0).reshape(-1, Z, vol.shape[-1])
+  out = o_bev.vertical_pooling({'pooling': 'max'}, vol, m.reshape(-1, Z))
+  return _t(out['features'], x), _t(out['valid'], x)
+
+
 def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None, normalize=True,
                      eps=1e-5, want_fused=True):
   feats = np.stack([_np(p, DTYPE) for p in planes], axis=-2)

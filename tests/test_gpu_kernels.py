@@ -601,6 +601,51 @@ def test_vertical_pool(pooling, Z, D):
   helpers.report('vpool plane', pg, pw, atol=1e-5, rtol=1e-6)
 
 
+MLP_POOL_CASES = [
+    # cin, stride, H, D, Z, columns, relu_in
+    (257, 260, 256, 128, 60, 37, False),     # the reference's fusion MLP / 12 m column at 0.2 m
+    (257, 260, 256, 128, 60, 300, True),     # several row tiles, columns straddling them
+    (65, 68, 64, 32, 12, 50, False),         # the tiny test models (feature_dim 32)
+    (129, 132, 128, 64, 7, 91, False),
+    (33, 36, 96, 20, 64, 9, True),           # H not a multiple of 64, D < 32
+]
+
+
+@pytest.mark.parametrize('cin,stride,H,D,Z,ncols,relu_in', MLP_POOL_CASES)
+def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
+  """Fused fusion MLP + vertical max pooling vs the oracle, and BIT-EXACT against the unfused
+  chain on the same engine (conv_split bf16x3 x 2 -> fill_masked_rows -> vertical_pool)."""
+  M = ncols * Z
+  g = torch.Generator().manual_seed(900 + cin + ncols)
+  x = torch.randn(M, stride, generator=g)
+  x[:, cin:] = 0
+  mask = torch.rand(M, generator=g) > 0.4
+  mask.view(ncols, Z)[0] = False               # an unobserved column
+  mask.view(ncols, Z)[1] = True                # a fully observed one
+  mask.view(ncols, Z)[2] = False
+  mask.view(ncols, Z)[2, Z // 2] = True        # a single level
+  w0 = torch.randn(cin, H, generator=g) / cin ** 0.5
+  b0 = torch.randn(H, generator=g) * 0.1
+  w1 = torch.randn(H, D, generator=g) / H ** 0.5
+  b1 = torch.randn(D, generator=g) * 0.1
+  kw = dict(cin=cin, Z=Z, relu_in=relu_in)
+  (pg, vg), (pw, vw) = both('mlp2_pool_max', (x, mask, w0, b0, w1, b1), kw)
+  helpers.report('mlp2_pool valid', vg, vw, 0)
+  helpers.report('mlp2_pool plane', pg, pw, atol=1e-4, rtol=1e-4)   # bf16x3 class (~1e-5 observed)
+  assert float(pg[0].abs().max()) == 0.0
+  # the unfused chain, same arithmetic
+  xd, md = x.to(DEV), mask.to(DEV)
+  pro = ops.PRO_RELU if relu_in else ops.PRO_NONE
+  index, count = ops.compact_rows(md)          # (what layers.MLP._masked_rows launches)
+  hid = ops.dense(xd, w0.to(DEV), b0.to(DEV), cin=cin, prologue=pro, relu=True, math='bf16x3',
+                  rows_in=index, row_count=count)
+  vol = ops.dense(hid, w1.to(DEV), b1.to(DEV), math='bf16x3', rows_out=index, row_count=count)
+  ops.fill_masked_rows_(vol, md)
+  plane, pvalid = ops.vertical_pool(vol.reshape(ncols, Z, D), md.reshape(ncols, Z), 'max')
+  assert torch.equal(pvalid, vg)
+  assert torch.equal(plane, pg), float((plane - pg).abs().max())
+
+
 @pytest.mark.parametrize('nplanes', [1, 2])
 def test_plane_fuse_match(nplanes):
   D, Dm = 128, 32

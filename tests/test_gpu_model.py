@@ -84,6 +84,28 @@ def test_localizer_forward_parity(top_k, V, math):
                              got_index=pred['best_index'])
 
 
+def test_localizer_without_feature_volume():
+  """bev_mapper.materialize_volume = False on the bf16x3 engine: the fusion MLP and the vertical
+  max pooling run as one kernel (ops.mlp2_pool_max); the plane is bit-identical to the unfused
+  chain's and everything downstream holds the same parity bar."""
+  cfg = helpers.tiny_localizer_config(top_k=2)
+  full, ref, ob, _ = _run(cfg, 2, 3, (64, 64), seed=4, math='bf16x3', want_batch=True)
+  cfg.bev_mapper.materialize_volume = False
+  pred, _ = _run(cfg, 2, 3, (64, 64), seed=4, math='bf16x3')
+  for side in ('map', 'query'):
+    sv = pred[side]['streetview']
+    assert sv['feature_volume'].features is None
+    _check_validity(f'{side} voxel validity', pred[side], ref[side], ob[side], cfg)
+    fp, fp_full = sv['feature_plane'], full[side]['streetview']['feature_plane']
+    assert torch.equal(fp.valid, fp_full.valid)
+    assert torch.equal(fp.features, fp_full.features), float((fp.features - fp_full.features).abs().max())
+    helpers.report(f'{side} bev_matching', pred[side]['bev_matching'].features,
+                   ref[side]['bev_matching']['features'], atol=1e-3)
+  helpers.report('scores_poses', pred['scores_poses'], ref['scores_poses'], atol=1e-3, rtol=1e-3)
+  helpers.assert_same_argmax('best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                             got_index=pred['best_index'])
+
+
 def test_localizer_with_query_confidence_parity():
   """add_confidence_query (bev_localizer.py:165-168 + the Dense(1) head of bev_mapper.py:154-157):
   log-sigmoid confidences, masked-softmax point weights instead of 1 / num_valid, parity of the
