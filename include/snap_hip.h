@@ -329,6 +329,11 @@ typedef struct SnapLiftDesc {
                                   f_images carries no score bins (C = feature_dim)  */
   int32_t use_variance;        /* fusion_use_variance                              */
   int32_t add_minmax;          /* fusion_add_minmax: + max, min over the valid views */
+  /* traversal hint (results do not depend on it): the N points of a scene are the voxel
+   * centres of an [N / (grid_y * grid_z), grid_y, grid_z] grid, level fastest
+   * (bev_mapper.py:162-196); the kernel then walks 8 x 8 blocks of columns per XCD so that a
+   * block's image taps stay in that XCD's L2.  0, 0 = unstructured points (query frustum). */
+  int32_t grid_y, grid_z;
 } SnapLiftDesc;
 
 /* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) tan(max_fov/2)(1) ALREADY scaled to

@@ -116,6 +116,8 @@ class StreetViewEncoder(base.Module):
       lift = ag.lift_pool
     else:
       lift = ops.lift_pool
+      if xyz.dim() == 5:                     # [B, X, Y, Z, 3]: a voxel grid (traversal hint)
+        kw.update(grid_yz=tuple(xyz.shape[2:4]))
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))

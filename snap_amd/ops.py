@@ -679,11 +679,13 @@ def pooled_stride(feature_dim, weighted=True, use_variance=True, add_minmax=Fals
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
-              add_minmax=False):
+              add_minmax=False, grid_yz=None):
   """Fused k1-k5.  f_images [B,V,h,w,C]; cam [B,V,11]; Rt [B,V,12]; points [B,N,3].
 
   K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad by default;
   see ``pooled_channels`` for the other fusion options), valid [B,N] bool.
+  ``grid_yz`` = (Y, Z): the points are the voxel centres of an [X, Y, Z] grid, level fastest --
+  a traversal hint (8 x 8 column blocks per XCD), the results do not depend on it.
   """
   lib = _lib.load()
   _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
@@ -698,6 +700,8 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
       -1.0 if max_view_distance is None else float(max_view_distance),
       int(weighted), int(use_variance), int(add_minmax),
   )
+  if grid_yz is not None and N % (int(grid_yz[0]) * int(grid_yz[1])) == 0:
+    d.grid_y, d.grid_z = int(grid_yz[0]), int(grid_yz[1])
   with _region(
       'lift_pool', 0.0, 4.0 * (f_images.numel() + points.numel() + pooled.numel())
   ):

@@ -574,6 +574,21 @@ def test_lift_pool_full_width_and_maxdist():
   helpers.report('lift pooled fd128', pg.cpu()[~mism], pw[~mism], atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('X,Y,Z,K,V', [(11, 13, 7, 0, 3), (16, 8, 60, 0, 4), (9, 24, 60, 2, 5), (8, 8, 3, 0, 1)])
+def test_lift_bev_tiled_traversal_is_a_pure_reordering(X, Y, Z, K, V):
+  """grid_yz: the 8 x 8-column-block traversal (one block per XCD at a time) writes the same
+  rows, bit for bit, as the linear voxel order -- grids that are not multiples of the block,
+  blocks whose voxel count is not a multiple of a workgroup's 256."""
+  fd, nb = 128, 32
+  f, cam, Rt, pts = _lift_scene(2, V, 12, 16, fd, nb, X * Y * Z, seed=300 + X)
+  kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0))
+  args = [t.to(DEV) for t in (f, cam, Rt, pts)]
+  p0, v0 = ops.lift_pool(*args, **kw)
+  p1, v1 = ops.lift_pool(*args, grid_yz=(Y, Z), **kw)
+  assert v0.float().mean() > 0.05
+  assert torch.equal(v0, v1) and torch.equal(p0, p1)
+
+
 def test_project_points():
   f, cam, Rt, pts = _lift_scene(2, 4, 12, 16, 8, 4, 5000, seed=50, k_radial=0.05)
   (p2g, vig, dg), (p2w, viw, dw) = both('project_points', (cam, Rt, pts, True))

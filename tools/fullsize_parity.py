@@ -50,8 +50,13 @@ def compare(pred, ref, args, t_hip, t_cpu):
       'image_features_rel_err': rel(sv['image_feature_pyramid'].features[-1],
                                     rsv['image_feature_pyramid']['features'][-1]),
       'voxel_validity_mismatch_fraction': float(mism.mean()),
-      'feature_volume_rel_err': rel(sv['feature_volume'].features.cpu().numpy()[~mism],
-                                    rsv['feature_volume']['features'][~mism]),
+      # (engine '<math>+plane': the volume is not materialised -- its vertical max is compared)
+      'feature_volume_rel_err': (None if sv['feature_volume'].features is None else
+                                 rel(sv['feature_volume'].features.cpu().numpy()[~mism],
+                                     rsv['feature_volume']['features'][~mism])),
+      'streetview_plane_rel_err': rel(sv['feature_plane'].features, rsv['feature_plane']['features']),
+      'streetview_plane_valid_equal': bool(np.array_equal(sv['feature_plane'].valid.cpu().numpy(),
+                                                          rsv['feature_plane']['valid'])),
       'aerial_plane_rel_err': rel(pred['map']['aerial']['feature_plane'].features,
                                   ref['map']['aerial']['feature_plane']['features']),
       'map_bev_matching_max_abs_err': float(np.abs(pred['map']['bev_matching'].features.cpu().numpy()
@@ -81,7 +86,9 @@ def compare(pred, ref, args, t_hip, t_cpu):
 
 def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
   """HIP forward of one C2 scene per engine in `maths` + ONE oracle run; returns
-  {'per_math': {engine: deviations}, 'pred': {engine: pred}, 'ref': oracle pred, ...}."""
+  {'per_math': {engine: deviations}, 'pred': {engine: pred}, 'ref': oracle pred, ...}.
+  An engine name may carry '+plane': bev_mapper.materialize_volume = False (on bf16x3 the fusion
+  MLP and the vertical max pooling then run as one kernel, ops.mlp2_pool_max)."""
   from snap_amd import ops
   from snap_amd.utils import geometry as _geo
   dev = torch.device('cuda')
@@ -100,7 +107,8 @@ def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
   prev = ops.MATMUL_PRECISION
   try:
     for math in maths:
-      ops.MATMUL_PRECISION = math
+      ops.MATMUL_PRECISION = math.split('+')[0]
+      cfg.bev_mapper.materialize_volume = not math.endswith('+plane')
       t0 = time.perf_counter()
       # every engine scores the SAME hypotheses (those the first engine's sampler drew), so that
       # one oracle run checks all of them
@@ -113,6 +121,7 @@ def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
         inject = _geo.Transform2D(smp.angle[:, 1:].contiguous(), smp.t[:, 1:].contiguous())
   finally:
     ops.MATMUL_PRECISION = prev
+    cfg.bev_mapper.materialize_volume = True
   ps = o_geo.Transform2D(inject.angle.cpu().numpy(), inject.t.cpu().numpy())
   t0 = time.perf_counter()
   ob = helpers.batch_to_oracle(batch)
