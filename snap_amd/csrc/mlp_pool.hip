@@ -22,8 +22,9 @@
 //          32t + 8q + 4 half + {0..3}, q = 0..3; k-step s of the tile takes q = 2s, 2s+1, and one
 //          v_permlane32_swap per register exchanges the middle quads of the two half-waves so
 //          that half 0 holds k = 0..7 and half 1 holds k = 8..15 of the slab -- the MFMA operand
-//          order of the unfused engine.  W1 (the same packed image) streams through a 3-slot
-//          LDS ring by LDS-DMA.
+//          order of the unfused engine.  The fragments are built in place of the accumulators
+//          before the loop; W1 (the same packed image) streams through an eight-slot LDS ring,
+//          one k-step per slot, up to seven in flight.
 //   max    out (+ b1) -> LDS, a scan down the rows per output channel with a flush at every
 //          column change -> float atomic max into the plane (prefilled with -inf; max is
 //          order-independent, so the result is deterministic); a finalize pass turns untouched
@@ -87,10 +88,9 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   constexpr int A_PART = BM * 32, A_ST = 2 * A_PART;          // 8 KB per stage
   constexpr int B0_ST = (N0 / 128) * 8192;                    // 16 KB per stage at N0 = 256
   constexpr int kB0 = 2 * A_ST;
-  constexpr int kRing = 16384;                                // one W1 stage = two 16-k slabs
-  constexpr int kBias = 3 * kRing;                            // b0 [N0] | b1 [N1]
+  constexpr int kBias = 65536;                                // b0 [N0] | b1 [N1] behind the 64 KB
   static_assert(kB0 + 2 * B0_ST <= kBias, "GEMM0 stages overlap the bias table");
-  __shared__ __attribute__((aligned(16))) float smem[16384];  // 64 KB
+  __shared__ __attribute__((aligned(16))) float smem[16384 + N0 + N1];   // 65.5 KB (two per CU)
   char* const sm = reinterpret_cast<char*>(smem);
   float* const bias0 = reinterpret_cast<float*>(sm + kBias);
   float* const bias1 = bias0 + N0;
@@ -119,7 +119,11 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   f32x4 xa[2];
   bool xin[2];
   int cur_c = 0;
+#ifndef SNAP_MLP_POOL_ABLATE
+#define SNAP_MLP_POOL_ABLATE 0     // timing experiments only (wrong results): 1 = no A loads,
+#endif                             // 2 = no A loads / split / LDS stores, 4 = no GEMM1, 8 = no max scan
   auto load_a = [&](int ct) {
+    if (SNAP_MLP_POOL_ABLATE & 3) { cur_c = 0; xa[0] = xa[1] = f32x4{1.f, 1.f, 1.f, 1.f}; xin[0] = xin[1] = true; return; }
     const int c = ct * 16 + 4 * akq;
     cur_c = c;
     const bool cvalid = c < a.Cin;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
     }
   };
   auto store_a = [&](int buf) {
+    if (SNAP_MLP_POOL_ABLATE & 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (tid >> 2) + 64 * i;
@@ -159,6 +164,21 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
                                        (lds_void_t*)(sm + kB0 + buf * B0_ST + 16 * slot), 16, 0, 0);
     }
   };
+
+  // W1 k-step ks (8 KB: [part][column][32 B]) -> slot (ks + 6) & 7 of an eight-slot ring over the
+  // first 64 KB.  A stage is consumed in 12 MFMAs (~0.2 us) but takes ~1 us to arrive, so up to
+  // seven k-steps are kept in flight; slots 6, 7 lie behind the GEMM0 stages: k-steps 0 and 1
+  // travel while GEMM0 runs.
+  auto issue_b1 = [&](int ks) {
+    const char* src = a.w1 + (int64_t)ks * 8192 + tid * 16;
+    char* dst = sm + ((ks + 6) & 7) * 8192 + tid * 16;
+    __builtin_amdgcn_global_load_lds((cglobal_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + 4096), (lds_void_t*)(dst + 4096), 16, 0, 0);
+  };
+  if (!(SNAP_MLP_POOL_ABLATE & 4)) {
+    issue_b1(0);
+    issue_b1(1);                                                  // (H >= 32: two k-steps exist)
+  }
 
   f32x16 acc0[T0];
 #pragma unroll
@@ -213,19 +233,45 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
     __syncthreads();
   }
 
-  // ---- GEMM1: W1 stages (two slabs = 16 KB each) through a 3-slot ring over the GEMM0 stages ----
-  const int nst = a.H >> 5;                                       // stages = accumulator tiles in use
-  auto issue_b1 = [&](int g) {
-    const char* src = a.w1 + (int64_t)g * kRing + tid * 16;
-    char* dst = sm + (g % 3) * kRing + tid * 16;
+  // ---- hidden = relu(acc0 + b0) -> the GEMM1 operand fragments, IN PLACE (16 accumulator
+  // registers of a tile become 2 k-steps x (hi, lo) x 4 registers), while the first W1 stages
+  // travel.  Keeping this VALU chain out of the GEMM1 loop leaves that loop LDS reads + MFMAs only.
+  const int nks = a.H >> 4;                                       // 16-k steps of GEMM1
+  const bool run1 = !(SNAP_MLP_POOL_ABLATE & 4);
+  if (run1) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + 4096 * p),
-                                       (lds_void_t*)(dst + 4096 * p), 16, 0, 0);
-  };
-  issue_b1(0);
-  if (nst > 1) issue_b1(1);
+    for (int k = 2; k < 8; ++k)
+      if (k < nks) issue_b1(k);                                   // (k-steps 0, 1: issued at the start)
+  }
+  u32x4 f_hi[T0][2], f_lo[T0][2];
+#pragma unroll
+  for (int t = 0; t < T0; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // this lane's row, hidden columns 32 t + 16 s + {4 lhi + 0..3, 8 + 4 lhi + 0..3}
+      f32x4 v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias0 + 32 * t + 16 * s + 8 * q + 4 * lhi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(acc0[t][8 * s + 4 * q + e] + bb[e], 0.f);
+      }
+      // half 0: columns 0-3 | 8-11, half 1: 4-7 | 12-15  ->  half 0: 0-7, half 1: 8-15
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0][e]),
+                                                         __float_as_uint(v[1][e]), false, false);
+        v[0][e] = __uint_as_float(sw[0]);
+        v[1][e] = __uint_as_float(sw[1]);
+      }
+      u32x2 h0, l0, h1, l1;
+      split2(v[0], h0, l0);
+      split2(v[1], h1, l1);
+      f_hi[t][s] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      f_lo[t][s] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
 
+  // ---- GEMM1: one k-step per ring slot -----------------------------------------------------------
   f32x16 acc1[T1];
 #pragma unroll
   for (int t = 0; t < T1; ++t)
@@ -233,58 +279,45 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
     for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
 
 #pragma unroll
-  for (int g = 0; g < T0; ++g) {
-    if (g < nst) {
-      if (g + 1 < nst)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // stage g landed, g + 1 in flight
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (g + 2 < nst) issue_b1(g + 2);                           // slot of stage g - 1: drained
-      const char* ws = sm + (g % 3) * kRing + w_off;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        // relu(hidden + b0) of this lane's row, hidden columns 32 g + 16 s + {4 lhi + 0..3, 8 + 4 lhi + 0..3}
-        f32x4 v[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias0 + 32 * g + 16 * s + 8 * q + 4 * lhi);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(acc0[g][8 * s + 4 * q + e] + bb[e], 0.f);
+  for (int ks = 0; ks < 2 * T0; ++ks) {
+    if (ks < nks && run1) {
+      // wait for k-step ks; issued so far: 2 .. ks + 6, so ks + 1 .. min(ks + 6, nks - 1) may
+      // stay in flight, two DMA instructions each (k-steps 0, 1 were drained by GEMM0's waits)
+      if (ks >= 2) {
+        const int younger = min(ks + 6, nks - 1) - ks;
+        switch (younger) {
+          case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
-        // half 0: columns 0-3 | 8-11, half 1: 4-7 | 12-15  ->  half 0: 0-7, half 1: 8-15
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0][e]),
-                                                           __float_as_uint(v[1][e]), false, false);
-          v[0][e] = __uint_as_float(sw[0]);
-          v[1][e] = __uint_as_float(sw[1]);
-        }
-        u32x2 h0, l0, h1, l1;
-        split2(v[0], h0, l0);
-        split2(v[1], h1, l1);
-        const u32x4 hh = {h0[0], h0[1], h1[0], h1[1]};
-        const u32x4 ll = {l0[0], l0[1], l1[0], l1[1]};
-        bf16x8 h_hi, h_lo;
-        __builtin_memcpy(&h_hi, &hh, 16);
-        __builtin_memcpy(&h_lo, &ll, 16);
-        bf16x8 w_hi[T1], w_lo[T1];
-#pragma unroll
-        for (int j = 0; j < T1; ++j) {
-          const char* p0 = ws + s * 8192 + j * 1024;
-          w_hi[j] = *reinterpret_cast<const bf16x8*>(p0);
-          w_lo[j] = *reinterpret_cast<const bf16x8*>(p0 + 4096);
-        }
-#pragma unroll
-        for (int j = 0; j < T1; ++j)
-          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_lo, acc1[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < T1; ++j)
-          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[j], h_hi, acc1[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < T1; ++j)
-          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_hi, acc1[j], 0, 0, 0);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // every wave is past k-step ks - 1: its slot takes k-step ks + 7
+      if (ks >= 1 && ks + 7 < nks) issue_b1(ks + 7);
+      const char* ws = sm + ((ks + 6) & 7) * 8192 + w_off;
+      bf16x8 h_hi, h_lo;
+      __builtin_memcpy(&h_hi, &f_hi[ks >> 1][ks & 1], 16);
+      __builtin_memcpy(&h_lo, &f_lo[ks >> 1][ks & 1], 16);
+      bf16x8 w_hi[T1], w_lo[T1];
+#pragma unroll
+      for (int j = 0; j < T1; ++j) {
+        const char* p0 = ws + j * 1024;
+        w_hi[j] = *reinterpret_cast<const bf16x8*>(p0);
+        w_lo[j] = *reinterpret_cast<const bf16x8*>(p0 + 4096);
+      }
+#pragma unroll
+      for (int j = 0; j < T1; ++j)
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_lo, acc1[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < T1; ++j)
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[j], h_hi, acc1[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < T1; ++j)
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_hi, acc1[j], 0, 0, 0);
     }
   }
 
@@ -315,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   const int cid = my < Meff ? a.rows[my] / a.Z : -1;
   int cur = -1;
   float run = -INFINITY;
-  const bool live = c < a.D;
+  const bool live = c < a.D && !(SNAP_MLP_POOL_ABLATE & 8);
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
     const int cr = __builtin_amdgcn_readlane(cid, r);
