@@ -31,6 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Four f32 -> NS x four bf16 (packed two per dword).  Each part is one v_cvt_pk_bf16_f32 (RNE)
 // per element PAIR; the value it represents is recovered by a shift / mask of the packed dword
@@ -394,24 +395,299 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Deep-pipelined variant (the one every large launch takes): ALL operands travel global -> LDS
-// by LDS-DMA, D slabs ahead of the matrix cores.
-//   * A: the raw f32 im2col chunks (16 B = 4 channels of one pixel) land in a D-stage ring; the
-//     thread that issued a chunk later reads the SAME chunk back (its own vmcnt covers it -- no
-//     barrier), applies the f32 prologue, splits it and writes the NS bf16 images the MFMA
-//     fragments are fetched from (double-buffered, published by the slab's closing barrier).
-//     Out-of-image taps / channel tails fetch a zero chunk and are forced to zero AFTER the
-//     prologue (the reference pads the normalised tensor).
-//   * B: split weights, (D+1)-stage ring.
-//   * GroupNorm operands of the slab's 16 channels: a 320-byte table per WAVE (20 lanes, one DMA;
-//     private copies keep it inside the wave's own vmcnt ordering), D-stage ring.  Needs a row
-//     tile inside <= 2 images (BM <= Ho*Wo); other launches take conv_split_body above.
-// With one slab in flight (the register-staged body) a wave waited out a full memory round trip
-// per 16-k slab: the loop ran at ~30 % of the matrix-pipe rate whatever the product count.
 // NS = 2 is held to 128 registers (64 accumulators + 64) so that four workgroups share a CU:
 // single 3x3 layers lose ~10 %, the HBM-leaning 1x1 layers gain ~10 %, the C2 step's conv time
 // as a whole 23.3 -> 22.1 ms.
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 with the input staged ONCE per channel tile ("halo" body).
+// The im2col body above fetches, normalises and splits every input pixel nine times (once per
+// tap); its loop spends 41 % of its time on those loads and 16 % on the conversion
+// (tools/conv_ablate_split.py).  Here the K loop runs channel tile OUTER, tap INNER: per channel
+// tile the BM + 2W + 2 consecutive pixels (flattened (n, y, x) order) that the tile's nine taps
+// touch are fetched, normalised (GroupNorm table of at most two images) and split ONCE into an
+// LDS stage; tap (kh, kw) of output row r reads stage row r + kh W + kw.  A tap that falls
+// outside the image would read the wrapped neighbour: the fragment is replaced by zeros per lane
+// (the reference pads the NORMALISED tensor with zeros).  2.1x (W = 68) ... 1.3x (W = 17) one
+// tap's worth of loads per channel tile instead of 9x.  Taken for W <= 79 (a stage of at most
+// 288 rows, three workgroups per CU); at W = 128 / 136 the 3.1x stage and two workgroups per CU
+// measured SLOWER than the im2col body (0.34 vs 0.29 ms, stage 1 of the C2 encoders).
+// Measured at C2: 17 x 17 x 512 0.30 -> 0.20 ms, 34 x 34 x 256 0.225 -> 0.165, 68 x 68 x 128
+// 0.23 -> 0.22, the conv family 15.4 -> 14.55 ms per step.  (Draining the stage loads at tap 0,
+// two instead of three workgroups per CU, __syncthreads instead of the fence-less barrier: all
+// within the run-to-run noise.)  Same tile order, weight image,
+// accumulation order per channel... NOT the same k order as the im2col body (tap-major there,
+// channel-tile-major here): results differ in the last bits, not in the error class.
+// Epilogue, row tiling and GroupNorm statistics of the output: unchanged (conv_epilogue).
+template <int BN, int PRO, int NS, int HPMAX>
+__device__ __forceinline__ void conv3x3_halo_body(const ConvArgs& a) {
+  constexpr int BM = 128, BK = 16;
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int NPER = (HPMAX * 4 + 255) / 256;     // float4 per thread and channel tile
+  constexpr int H_PART = HPMAX * 32;                // bytes per part image of a halo stage
+  constexpr int H_ST = NS * H_PART;
+  constexpr int B_PART = BN * 32;
+  constexpr int B_ST = NS * B_PART;
+  constexpr int BSLOTS = NS * BN * 2;
+  constexpr int BPIECES = (BSLOTS + 255) / 256;
+  constexpr int kSlabBytes = 2 * (H_ST + B_ST);
+  constexpr int kStageBytes = 64 * BN * 4;
+  constexpr int kSmemBytes = kSlabBytes > kStageBytes ? kSlabBytes : kStageBytes;
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  constexpr int kGnRing = 320;
+  __shared__ __attribute__((aligned(16))) float smem[(kSmemBytes + (need_gn ? 2 * kGnRing : 0)) / 4];
+  char* const Hb = reinterpret_cast<char*>(smem);
+  char* const Bb = Hb + 2 * H_ST;
+  char* const Gt = Hb + kSmemBytes;
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int ncol = a.ncol;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int seq = bid >> 3;
+  const int col_t = seq % ncol;
+  const int row_t = (seq / ncol) * 8 + xcd;
+  const int Meff = a.M;
+  if (row_t * BM >= Meff) return;
+  const int m0 = row_t * BM;
+  const int n0 = col_t * BN;
+  const int W = d.W, HW = d.H * d.W;
+  const int n_first = m0 / HW;
+  const int m_split = (n_first + 1) * HW;
+  const int n_second = min(n_first + 1, d.N - 1);
+  const int halo0 = m0 - W - 1;                       // flattened pixel of stage row 0
+  const int HP = BM + 2 * W + 2;                      // stage rows in use (<= HPMAX)
+
+  // per output row of this lane (two row tiles): 9-bit mask of the taps inside the image
+  int tapmask[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wr * 64 + i * 32 + l31;
+    int mk = 0;
+    if (m < Meff) {
+      const int r = m % HW;
+      const int y = r / W, x = r - y * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < d.H && xx >= 0 && xx < W) mk |= 1 << t;
+      }
+    }
+    tapmask[i] = mk;
+  }
+
+  // halo staging: float4 f = tid + 256 j -> stage row f >> 2, channel quad f & 3
+  // (addresses and flags are recomputed per channel tile: keeping them costs the registers that
+  // decide between two and three workgroups per CU)
+  const int Mtot = d.N * HW;
+  auto halo_ok_row = [&](int hp) {
+    const int mp = halo0 + hp;
+    return hp < HP && mp >= 0 && mp < Mtot;
+  };
+  f32x4 xa[NPER];
+  auto load_halo = [&](int ct) {
+#pragma unroll
+    for (int j = 0; j < NPER; ++j) {
+      const int f = tid + 256 * j;
+      const int hp = f >> 2;
+      const bool ok = halo_ok_row(hp);
+      const float* px = a.x + ((int64_t)(ok ? halo0 + hp : 0) * d.Cin_stride + 4 * (f & 3) + ct * BK);
+      xa[j] = *reinterpret_cast<const f32x4*>(ok ? px : a.x);
+    }
+  };
+  auto issue_gn = [&](int ring, int ct) {
+    if constexpr (need_gn) {
+      if (tid < 20) {
+        const int seg = tid >> 2;
+        const int c = ct * BK + 4 * (tid & 3);
+        const float* base = seg == 4 ? a.gn_beta
+                                     : ((seg & 1) ? a.gn_sc : a.gn_mu) +
+                                           (int64_t)(seg >= 2 ? n_second : n_first) * d.Cin;
+        __builtin_amdgcn_global_load_lds((cglobal_void_t*)(base + c),
+                                         (lds_void_t*)(Gt + ring * kGnRing + 16 * tid), 16, 0, 0);
+      }
+    }
+  };
+  auto store_halo = [&](int buf, int ring) {
+    const float* const tb = reinterpret_cast<const float*>(Gt + ring * kGnRing);
+#pragma unroll
+    for (int j = 0; j < NPER; ++j) {
+      const int f = tid + 256 * j;
+      const int hp = f >> 2, q = f & 3;
+      if (NPER * 256 > HPMAX * 4 && hp >= HPMAX) continue;
+      f32x4 v = xa[j];
+      f32x4 mu = {0.f, 0.f, 0.f, 0.f}, sc = mu, be = mu;
+      const bool ok = halo_ok_row(hp);
+      if constexpr (need_gn) {
+        const int slot = halo0 + hp >= m_split ? 1 : 0;
+        mu = *reinterpret_cast<const f32x4*>(tb + slot * 32 + 4 * q);
+        sc = *reinterpret_cast<const f32x4*>(tb + slot * 32 + 16 + 4 * q);
+        be = *reinterpret_cast<const f32x4*>(tb + 64 + 4 * q);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = apply_pro<PRO>(v[e], mu[e], sc[e], be[e], d.in_scale, d.in_shift);
+        v[e] = ok ? pv : 0.f;
+      }
+      u32x2 parts[NS];
+      split_bf16<NS>(v, parts);
+      const int oct = (q >> 1) ^ ((hp >> 3) & 1);
+      char* dst = Hb + buf * H_ST + hp * 32 + oct * 16 + (q & 1) * 8;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<u32x2*>(dst + p * H_PART) = parts[p];
+    }
+  };
+
+  // B: slab (tap, ct) of column tile n0 / 128 = block (tap * ctiles + ct) of the packed image
+  const char* const wt = static_cast<const char*>(a.w_bf16);
+  const int ctiles = a.ctiles;
+  const int64_t col_tile_bytes = (int64_t)9 * ctiles * (NS * 4096);
+  const char* bbase[BPIECES];
+#pragma unroll
+  for (int p = 0; p < BPIECES; ++p) {
+    const int slot = tid + 256 * p;
+    const int part = slot / (2 * BN);
+    const int rem = slot - part * (2 * BN);
+    const int gcol = n0 + (rem >> 1);
+    bbase[p] = wt + (gcol >> 7) * col_tile_bytes + (part < NS ? part : 0) * 4096 + (gcol & 127) * 32 +
+               (rem & 1) * 16;
+  }
+  auto issue_b = [&](int buf, int ct, int t) {
+    const int64_t off = ((int64_t)t * ctiles + ct) * (NS * 4096);
+#pragma unroll
+    for (int p = 0; p < BPIECES; ++p) {
+      const int slot = tid + 256 * p;
+      if (BSLOTS % 256 != 0 && slot >= BSLOTS) break;
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(bbase[p] + off),
+                                       (lds_void_t*)(Bb + buf * B_ST + 16 * slot), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: table + halo of channel tile 0, weights of slab (0, tap 0)
+  issue_gn(0, 0);
+  load_halo(0);
+  issue_b(0, 0, 0);
+  if constexpr (need_gn) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  store_halo(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int bcur = 0;
+  for (int ct = 0; ct < ctiles; ++ct) {
+    const int hb = ct & 1;
+    const bool more_ct = ct + 1 < ctiles;
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      const bool last = !more_ct && t == 8;
+      const bool fetch = t == 0 && more_ct;
+      if (fetch) issue_gn(hb ^ 1, ct + 1);
+      if (!last) issue_b(bcur ^ 1, t == 8 ? ct + 1 : ct, t == 8 ? 0 : t + 1);
+      if (fetch) {
+        // the next channel tile's pixels: issued AFTER this slab's DMAs (compiler barrier) so that
+        // the slab-closing wait can leave exactly these NPER loads in flight
+        asm volatile("" ::: "memory");
+        load_halo(ct + 1);
+        asm volatile("" ::: "memory");
+      }
+      const int kh = t / 3, kw = t - 3 * kh;
+      const int toff = kh * W + kw;
+      const char* hs = Hb + hb * H_ST;
+      const char* bs = Bb + bcur * B_ST;
+      bf16x8 av[TM][NS], bv[TN][NS];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int h = wr * 64 + i * 32 + l31 + toff;
+        const char* p0 = hs + h * 32 + ((lhi ^ ((h >> 3) & 1)) * 16);
+        const bool in = (tapmask[i] >> t) & 1;
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          u32x4 raw = *reinterpret_cast<const u32x4*>(p0 + p * H_PART);
+          if (!in) raw = u32x4{0u, 0u, 0u, 0u};
+          __builtin_memcpy(&av[i][p], &raw, 16);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int C = wc * (BN / 2) + j * 32 + l31;
+        const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(p0 + p * B_PART);
+      }
+#define SNAP_SPLIT_PRODUCT(PA, PB)                                                          \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA], bv[j][PB], acc[i][j], 0, 0, 0);
+      if constexpr (NS == 3) {
+        SNAP_SPLIT_PRODUCT(2, 0)
+        SNAP_SPLIT_PRODUCT(0, 2)
+        SNAP_SPLIT_PRODUCT(1, 1)
+        SNAP_SPLIT_PRODUCT(1, 0)
+        SNAP_SPLIT_PRODUCT(0, 1)
+        SNAP_SPLIT_PRODUCT(0, 0)
+      } else {
+        SNAP_SPLIT_PRODUCT(1, 0)
+        SNAP_SPLIT_PRODUCT(0, 1)
+        SNAP_SPLIT_PRODUCT(0, 0)
+      }
+#undef SNAP_SPLIT_PRODUCT
+      // the next channel tile's pixels (fetched during tap 0) -> the other halo stage: nobody
+      // reads it before the barrier that closes tap 8
+      if (t == 2 && more_ct) store_halo(hb ^ 1, hb ^ 1);
+      if (fetch)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      bcur ^= 1;
+    }
+  }
+  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, 0);
+}
+
+template <int BN, int PRO, int NS, int HPMAX>
+__global__ __launch_bounds__(256, NS == 2 ? 3 : 2) void conv3x3_halo_kernel(const ConvArgs a) {
+  conv3x3_halo_body<BN, PRO, NS, HPMAX>(a);
+}
+
+// the halo body takes: 3x3, stride 1, pad 1, whole 16-channel tiles, plain row order, no split-K,
+// images at least as large as the stage (BM + 2W + 2 pixels: the stage then touches <= 2 images)
+inline bool halo_ok(const ConvArgs& a) {
+  static const bool on = []() {
+    const char* e = getenv("SNAP_CONV_HALO");     // 0 = im2col body for every 3x3
+    return !(e && e[0] == '0');
+  }();
+  const SnapConvDesc& d = a.d;
+  const int hp = 128 + 2 * d.W + 2;
+  return on && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 &&
+         d.Ho == d.H && d.Wo == d.W && d.Cin % 16 == 0 && !a.rows_in && !a.rows_out &&
+         !a.row_count && a.ksplit == 1 && hp <= 288 && d.H * d.W >= hp &&
+         (int64_t)d.N * d.H * d.W * d.Cin_stride < 0x7fffffffLL &&
+         (d.prologue == SNAP_PRO_GN_RELU || d.prologue == SNAP_PRO_NONE);
+}
+
+template <int BN, int PRO, int NS>
+void launch_halo(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  const int hp = 128 + 2 * a.d.W + 2;
+  if (hp <= 208)
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, PRO, NS, 208>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, PRO, NS, 288>), grid, dim3(256), 0, s, a);
+}
+
 template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL>
 __global__ __launch_bounds__(256, NS == 2 ? 4 : 3) void conv_split_kernel(const ConvArgs a) {
   conv_split_body<BM, BN, PRO, NS, GNT, TAIL>(a);
@@ -450,6 +726,13 @@ int launch(ConvArgs a, hipStream_t s) {
   const bool table_ok = !need_gn || (a.d.Ho * a.d.Wo >= BM && !a.rows_in);
   const bool tail = (a.d.Cin & 3) != 0;
   const dim3 grid((unsigned)nblocks);
+  if constexpr (BM == 128 && (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_NONE)) {
+    if (halo_ok(a)) {
+      launch_halo<BN, PRO, NS>(a, grid, s);
+      SNAP_CHECK_LAUNCH();
+      return SNAP_OK;
+    }
+  }
   if (need_gn && table_ok)           // (GroupNorm operands are per channel QUAD: Cin % 4 == 0)
     hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, need_gn, false>), grid, dim3(256), 0, s, a);
   else if (tail)

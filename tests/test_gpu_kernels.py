@@ -247,6 +247,50 @@ def test_conv_split_rows_gnstats_splitk_and_scales(math):
   assert torch.equal(big, base * 2.0 ** -30)
 
 
+HALO_CASES = [
+    # N, H, W, Cin, Cout, GroupNorm prologue, epilogue extras
+    (2, 34, 34, 64, 64, True, False),       # stage-3 width, BN = 64
+    (3, 20, 40, 32, 200, False, True),      # plain prologue, bias + residual + relu, ragged Cout
+    (1, 136, 136, 16, 64, True, False),     # stage-1 width: the largest stage (402 rows)
+    (2, 68, 68, 48, 128, True, True),       # stage-2 width
+    (1, 16, 143, 16, 32, False, False),     # widest image the stage holds (416 rows)
+    (5, 12, 12, 32, 128, True, False),      # image == stage size (130 + 2 W = 154 > 144: im2col body)
+    (4, 13, 13, 32, 128, True, False),      # 169 pixels >= 156: several images per row tile
+]
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('N,H,W,Cin,Cout,gn,extras', HALO_CASES)
+def test_conv_split_halo_3x3(N, H, W, Cin, Cout, gn, extras, math):
+  """3x3 / stride 1 / pad 1 on the halo body (input staged once per channel tile, taps read
+  shifted rows of the stage; out-of-image taps masked per lane), incl. tiles that straddle
+  images, GroupNorm tables of two images, the fused output statistics."""
+  tol = 2.5 * SPLIT_TOL[math]
+  x = rnd((N, H, W, Cin), 500 + W) + 0.1
+  w = rnd((3, 3, Cin, Cout), 501, 1 / np.sqrt(9 * Cin))
+  kw = dict(padding=((1, 1), (1, 1)), math=math)
+  if gn:
+    gamma, beta = rnd((Cin,), 502) + 1, rnd((Cin,), 503) * 0.1
+    mu, sc = oracle_ops.group_norm_stats(x, gamma, groups=min(32, Cin // 2))
+    kw.update(prologue=ops.PRO_GN_RELU, gn=(mu, sc, beta))
+  if extras:
+    kw.update(residual=rnd((N, H, W, Cout), 504), bias=rnd((Cout,), 505), relu=True)
+  ops.USE_SPLITK = False
+  try:
+    got, want = both('conv2d', (x, w), kw)
+    helpers.report(f'halo conv {math} {N}x{H}x{W}x{Cin}->{Cout}', got, want, atol=tol, rtol=1e-5)
+    if not extras and Cout % 32 == 0:
+      gkw = {k: (tuple(t.to(DEV) for t in v) if k == 'gn' else v) for k, v in kw.items()}
+      y = ops.conv2d(x.to(DEV), w.to(DEV), emit_gn_stats='raw', **gkw)
+      g2 = rnd((Cout,), 506) + 1
+      mu_f, sc_f = ops.group_norm_stats(y, g2.to(DEV))
+      mu_w, sc_w = oracle_ops.group_norm_stats(y.cpu(), g2)
+      helpers.report('halo fused gn mu', mu_f, mu_w, atol=1e-5, rtol=1e-5)
+      helpers.report('halo fused gn sc', sc_f, sc_w, atol=1e-5, rtol=5e-5)
+  finally:
+    ops.USE_SPLITK = True
+
+
 def test_conv_split_accuracy_class():
   """The split engines against float64 on a deep reduction (K = 4608), next to the exact f32
   engine: 'bf16x6' must sit in the f32 engine's error class (<= 2x its rms error), 'bf16x3'
