@@ -157,7 +157,8 @@ def _pmc_traffic(kernel, launches, workload):
   passes on this workload, gfx950 x2 read correction applied).  None if unavailable."""
   if workload != 'c2':
     return None
-  fam = 'conv_split' if kernel.startswith('conv_split') else kernel
+  fam = ('conv_split' if kernel.startswith('conv_split') else
+         'mlp2_pool' if kernel.startswith('mlp2_pool') else kernel)
   rec = None
   for name in ('r02_c2_hbm_traffic.json', 'r01_c2_hbm_traffic.json'):   # newest round first
     try:

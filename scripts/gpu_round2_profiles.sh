@@ -12,6 +12,8 @@ tail -1 $O/bench_bf16x3.log > $O/r02_c2_bench_bf16x3.json
 for m in bf16x6 f32; do
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --math $m 2>/dev/null | tail -1 > $O/r02_c2_bench_$m.json
 done
+# (the default engine with the dense feature volume written: the unfused MLP -> fill -> pool chain)
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --materialize-volume 2>/dev/null | tail -1 > $O/r02_c2_bench_bf16x3_volume.json
 # 2. rocprofv3 kernel stats of the same command
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o snap -- \
   python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline) > $O/prof.log 2>&1
@@ -46,8 +48,8 @@ done
   python "$R/bench.py" --workload c4 --steps 2 --warmup 1) > $O/prof_c4.log 2>&1
 cp $O/prof_c4/snap_kernel_stats.csv $O/r02_c4_kernel_stats.csv 2>/dev/null
 # 6. whole-scene parity of every engine (one oracle run) + the eval variant on the default engine
-timeout 400 python tools/fullsize_parity.py --math f32,bf16x6,bf16x3 --out $O/r02_c2_fullsize_parity.json > $O/parity.log 2>&1
-timeout 400 python tools/fullsize_parity.py --math bf16x3 --eval --out $O/r02_c2_fullsize_parity_eval.json > $O/parity_eval.log 2>&1
+timeout 400 python tools/fullsize_parity.py --math f32,bf16x6,bf16x3,bf16x3+plane --out $O/r02_c2_fullsize_parity.json > $O/parity.log 2>&1
+timeout 400 python tools/fullsize_parity.py --math bf16x3+plane --eval --out $O/r02_c2_fullsize_parity_eval.json > $O/parity_eval.log 2>&1
 # 7. training step (C3) and the ViT workload (C5)
 timeout 300 python bench.py --mode train --workload c3 --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/r02_c3_train_bench.json
 timeout 300 python bench.py --mode train --workload c3 --precision bf16 --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/r02_c3_train_bf16_bench.json

@@ -17,7 +17,9 @@ import sys
 
 # kernel-name substring -> bench.py kernel family (the KernelProfiler region names)
 FAMILIES = [
-    ('conv_igemm_kernel', 'conv_igemm'), ('conv_split_kernel', 'conv_split'), ('splitk_reduce_kernel', 'conv_split'),
+    ('conv_igemm_kernel', 'conv_igemm'), ('conv_split_kernel', 'conv_split'), ('conv3x3_halo_kernel', 'conv_split'),
+    ('splitk_reduce_kernel', 'conv_split'),
+    ('mlp2_pool_kernel', 'mlp2_pool'), ('mlp2_pool_finalize_kernel', 'mlp2_pool'), ('fill_f32_kernel', 'mlp2_pool'),
     ('pack_weights_split', 'pack_weights'),
     ('pose_score_db_kernel', 'pose_score'), ('pose_score_kernel', 'pose_score'),
     ('pose_table', 'pose_score'), ('pose_score_reduce', 'pose_score'),
