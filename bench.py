@@ -151,11 +151,11 @@ def _to(tree, device):
   return tree.to(device)
 
 
-def _pmc_traffic(kernel, launches, workload):
+def _pmc_traffic(kernel, launches, workload, default_config=True):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
   (profiles/r01_c2_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate
   passes on this workload, gfx950 x2 read correction applied).  None if unavailable."""
-  if workload != 'c2':
+  if workload != 'c2' or not default_config:     # (the counter passes ran the default configuration)
     return None
   fam = ('conv_split' if kernel.startswith('conv_split') else
          'mlp2_pool' if kernel.startswith('mlp2_pool') else kernel)
@@ -506,6 +506,7 @@ def main(argv=None):
             'tflops': round(s['flops'] / ms / 1e9, 2),
             'gbs': round(s['bytes'] / ms / 1e6, 1),
         }
+      default_cfg = (args.mode == 'infer' and args.math == 'bf16x3' and not args.materialize_volume)
       dom = max((k for k in summ if k != 'exhaustive_voting_total'), key=lambda k: summ[k]['ms'])
       s = summ[dom]
       if s['flops'] > 0:
@@ -518,7 +519,7 @@ def main(argv=None):
             'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2),
             'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(ach / peak, 4),
-            'traffic': _pmc_traffic(dom, s['launches'], args.workload),
+            'traffic': _pmc_traffic(dom, s['launches'], args.workload, default_cfg),
             'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, separate passes; profiles/)',
             'algorithmic_bytes_per_launch': round(s['bytes'] / s['launches'], 1),
             'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
@@ -533,7 +534,7 @@ def main(argv=None):
         out['roofline'] = {
             'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS,
             'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
-            'traffic': _pmc_traffic(dom, s['launches'], args.workload),
+            'traffic': _pmc_traffic(dom, s['launches'], args.workload, default_cfg),
             'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
         }
       if 'pose_score' in summ:
@@ -542,7 +543,7 @@ def main(argv=None):
         out['roofline_pose_corr'] = {
             'kernel': 'pose_score', 'bound': 'hbm', 'achieved': round(ach, 1),
             'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
-            'traffic': _pmc_traffic('pose_score', s['launches'], args.workload),
+            'traffic': _pmc_traffic('pose_score', s['launches'], args.workload, default_cfg),
             'avg_launch_ms': round(s['ms'] / s['launches'], 4),
             'bytes_per_launch': s['bytes'] / s['launches'],
         }

@@ -165,6 +165,7 @@ class BEVLocalizer(base.Module):
     # not leak into the caller's batch (under jax.jit the reference's dict mutation
     # at bev_mapper.py:196 is likewise invisible to the caller).
     data_map, data_query = dict(data['map']), {**data['query'], 'xy_bev': q_xy_p}
+    self.bev_mapper.start_aerial(params['bev_mapper'], data_map, train, ctx)   # (second stream)
     self._encode_views_jointly(params, data_map, data_query, train, ctx)
     pred['map'] = self.bev_mapper(params['bev_mapper'], data_map, train, debug, ctx=ctx, rng=rng)
     mapper_q = self.bev_mapper_query or self.bev_mapper

@@ -204,6 +204,32 @@ class BEVMapper(base.Module):
     pred['feature_plane'] = pred['vertical_pooling'].pop('plane')
     return pred
 
+  def start_aerial(self, params, data, train=False, ctx=None):
+    """Inference: launch the aerial encoder on a second HIP stream NOW, so that it runs next to
+    the StreetView chain it does not depend on (``__call__`` joins it before the fusion).  The
+    encoder's deep stages are launches of a few dozen workgroups; on their own stream they fill
+    compute units the StreetView kernels leave idle instead of serialising behind them."""
+    if self.aerial_encoder is None or 'rasters' not in data or train or not ops.OVERLAP_AERIAL:
+      return
+    rgb = data['rasters']['rgb']
+    if not rgb.is_cuda:
+      return
+
+    def leaves(t):
+      if isinstance(t, dict):
+        for v in t.values():
+          yield from leaves(v)
+      else:
+        yield t
+    if base.needs_grad(rgb, *leaves(params['aerial_encoder'])):
+      return
+    main, side = torch.cuda.current_stream(), ops.side_stream()
+    side.wait_stream(main)                      # the inputs were produced on the main stream
+    with torch.cuda.stream(side):
+      pred = self.encode_aerial(params, rgb, train=train, ctx=ctx)
+      done = side.record_event()
+    data['_aerial_async'] = (pred, done)
+
   def encode_aerial(self, params, aerial_rgb, train=False, ctx=None):
     pyramid = self.aerial_encoder(params['aerial_encoder'], aerial_rgb, train=train, ctx=ctx)
     features = pyramid.features[-1].contiguous()
@@ -235,7 +261,16 @@ class BEVMapper(base.Module):
       )
       feature_planes.append(pred['streetview']['feature_plane'])
     if self.aerial_encoder is not None and 'rasters' in data:
-      pred['aerial'] = self.encode_aerial(params, data['rasters']['rgb'], train=train, ctx=ctx)
+      pending = data.pop('_aerial_async', None)
+      if pending is not None:                   # started by start_aerial on the side stream
+        pred['aerial'], done = pending
+        main = torch.cuda.current_stream()
+        main.wait_event(done)
+        plane = pred['aerial']['feature_plane']
+        plane.features.record_stream(main)
+        plane.valid.record_stream(main)
+      else:
+        pred['aerial'] = self.encode_aerial(params, data['rasters']['rgb'], train=train, ctx=ctx)
       feature_planes.append(pred['aerial']['feature_plane'])
     if self.semantic_encoder is not None and 'rasters' in data:
       # (there are no semantic rasters for query images, bev_mapper.py:273-278)

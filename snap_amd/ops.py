@@ -6,6 +6,7 @@ current stream.  There is no CPU or PyTorch fallback: tensors must live on a
 ROCm device and the shared library must be built, otherwise these raise.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -20,6 +21,20 @@ SIM_CHUNK = 64
 
 def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# A second HIP stream for work that does not depend on the main chain (the aerial encoder runs
+# next to the StreetView encoder: its deep stages are launches of 19-73 workgroups on a 256-CU
+# part).  SNAP_OVERLAP_AERIAL=0 keeps everything on one stream.
+OVERLAP_AERIAL = os.environ.get('SNAP_OVERLAP_AERIAL', '1') != '0'
+_SIDE_STREAM = None
+
+
+def side_stream():
+  global _SIDE_STREAM
+  if _SIDE_STREAM is None:
+    _SIDE_STREAM = torch.cuda.Stream()
+  return _SIDE_STREAM
 
 
 class KernelProfiler:
