@@ -334,6 +334,11 @@ typedef struct SnapLiftDesc {
    * (bev_mapper.py:162-196); the kernel then walks 8 x 8 blocks of columns per XCD so that a
    * block's image taps stay in that XCD's L2.  0, 0 = unstructured points (query frustum). */
   int32_t grid_y, grid_z;
+  /* 1: rows of `pooled` whose voxel no view sees are NOT written (their `valid` byte is 0;
+   * the default options' batched kernel only) -- for consumers that read the rows of valid
+   * voxels only (snap_mlp2_pool_max_f32, row-indexed conv launches).  0: zeros, as the
+   * reference's pool_multiview_features returns. */
+  int32_t valid_rows_only;
 } SnapLiftDesc;
 
 /* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) tan(max_fov/2)(1) ALREADY scaled to

@@ -48,7 +48,7 @@ class SnapLiftDesc(ctypes.Structure):
       ('depth_min', c_float), ('depth_max', c_float),
       ('max_view_distance', c_float),
       ('weighted', c_int), ('use_variance', c_int), ('add_minmax', c_int),
-      ('grid_y', c_int), ('grid_z', c_int),
+      ('grid_y', c_int), ('grid_z', c_int), ('valid_rows_only', c_int),
   ]
 
 
@@ -239,7 +239,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 

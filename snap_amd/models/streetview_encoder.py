@@ -55,7 +55,7 @@ class StreetViewEncoder(base.Module):
     params['fusion_mlp'] = self.fusion_mlp.init_params(gen, device)
     return params
 
-  def _fused_pool_ok(self, params, pooled):
+  def _fused_pool_ok(self, params, f_images):
     """The fusion MLP + vertical max pooling run as ONE kernel (ops.mlp2_pool_max) when nothing
     needs gradients, the conv engine in use is the one the kernel is written for and the MLP
     has the two-layer shape of the reference's configs."""
@@ -63,7 +63,7 @@ class StreetViewEncoder(base.Module):
     if len(layers_) != 2 or ops.MATMUL_PRECISION != 'bf16x3':
       return False
     p = params['fusion_mlp']
-    if base.needs_grad(pooled, *(p[f'Dense_{i}'][k] for i in range(2) for k in ('kernel', 'bias'))):
+    if base.needs_grad(f_images, *(p[f'Dense_{i}'][k] for i in range(2) for k in ('kernel', 'bias'))):
       return False
     return ops.mlp2_pool_supported(self.fusion_mlp.in_dim, layers_[0], layers_[1])
 
@@ -110,6 +110,7 @@ class StreetViewEncoder(base.Module):
     kw = dict(K=K, fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
               num_bins=cfg.num_scale_bins, depth_min_max=cfg.depth_min_max,
               max_view_distance=cfg.get('max_view_distance'))
+    fused = False
     if base.needs_grad(f_images):
       if not self.default_fusion:
         raise NotImplementedError('non-default fusion options have no backward kernel yet')
@@ -118,6 +119,9 @@ class StreetViewEncoder(base.Module):
       lift = ops.lift_pool
       if xyz.dim() == 5:                     # [B, X, Y, Z, 3]: a voxel grid (traversal hint)
         kw.update(grid_yz=tuple(xyz.shape[2:4]))
+      fused = pool_max and self.default_fusion and self._fused_pool_ok(params, f_images)
+      if fused:                              # the fused kernel reads the rows of valid voxels only
+        kw.update(valid_rows_only=True)
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))
@@ -126,7 +130,7 @@ class StreetViewEncoder(base.Module):
         scene_t_view.packed().to(torch.float32), xyz_flat, **kw,
     )
     grid_shape = (-1, *xyz.shape[-4:-1])
-    if pool_max and self._fused_pool_ok(params, pooled):
+    if fused:
       p = params['fusion_mlp']
       plane, pvalid = ops.mlp2_pool_max(
           pooled.reshape(-1, pooled.shape[-1]), valid.reshape(-1),

@@ -694,13 +694,15 @@ def pooled_stride(feature_dim, weighted=True, use_variance=True, add_minmax=Fals
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
-              add_minmax=False, grid_yz=None):
+              add_minmax=False, grid_yz=None, valid_rows_only=False):
   """Fused k1-k5.  f_images [B,V,h,w,C]; cam [B,V,11]; Rt [B,V,12]; points [B,N,3].
 
   K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad by default;
   see ``pooled_channels`` for the other fusion options), valid [B,N] bool.
   ``grid_yz`` = (Y, Z): the points are the voxel centres of an [X, Y, Z] grid, level fastest --
   a traversal hint (8 x 8 column blocks per XCD), the results do not depend on it.
+  ``valid_rows_only``: rows of voxels no view sees are left unwritten (uninitialised memory) --
+  only for consumers that read the rows of valid voxels.
   """
   lib = _lib.load()
   _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
@@ -717,6 +719,7 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   )
   if grid_yz is not None and N % (int(grid_yz[0]) * int(grid_yz[1])) == 0:
     d.grid_y, d.grid_z = int(grid_yz[0]), int(grid_yz[1])
+  d.valid_rows_only = int(bool(valid_rows_only))
   with _region(
       'lift_pool', 0.0, 4.0 * (f_images.numel() + points.numel() + pooled.numel())
   ):

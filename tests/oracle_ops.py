@@ -178,7 +178,7 @@ def unpack_transforms(Rt):
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
-              add_minmax=False, grid_yz=None):
+              add_minmax=False, grid_yz=None, valid_rows_only=False):
   f = _np(f_images, DTYPE)
   cams = unpack_cameras(cam, fisheye)
   T = unpack_transforms(Rt)

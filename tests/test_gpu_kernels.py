@@ -631,6 +631,9 @@ def test_lift_bev_tiled_traversal_is_a_pure_reordering(X, Y, Z, K, V):
   p1, v1 = ops.lift_pool(*args, grid_yz=(Y, Z), **kw)
   assert v0.float().mean() > 0.05
   assert torch.equal(v0, v1) and torch.equal(p0, p1)
+  # valid_rows_only: the rows of voxels some view sees are the same bits; the others are not written
+  p2, v2 = ops.lift_pool(*args, grid_yz=(Y, Z), valid_rows_only=True, **kw)
+  assert torch.equal(v2, v0) and torch.equal(p2[v0], p0[v0])
 
 
 def test_project_points():
