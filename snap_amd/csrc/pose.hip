@@ -146,7 +146,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 }
 
 template <int DM>
-__global__ __launch_bounds__(256) void sim_mfma_kernel(
+__global__ __launch_bounds__(256, DM <= 32 ? 4 : 2) void sim_mfma_kernel(
     const float* __restrict__ fq, const float* __restrict__ fm, int Nq, int XY, float scale,
     int clip, const float* __restrict__ num_valid, float* __restrict__ sim,
     float* __restrict__ stats, const float* __restrict__ row_weight) {
@@ -169,20 +169,9 @@ __global__ __launch_bounds__(256) void sim_mfma_kernel(
     const int row = n0 + 32 * t + l31;
     sim_load_operand<DM>(fq + ((int64_t)b * Nq + (row < Nq ? row : 0)) * DM, row < Nq, lhi, aq[t]);
   }
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-  for (int j = 0; j < DM / 2; ++j)
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ti][j], bq[tj][j], acc[ti][tj], 0, 0, 0);
+#ifndef SNAP_SIM_ABLATE
+#define SNAP_SIM_ABLATE 0          // timing experiments only: 1 no sim stores, 2 no MFMAs, 4 no exp
+#endif
   // Epilogue through a per-wave LDS tile (32 rows x 64 cells, one ti at a time): the MFMA C
   // layout gives a lane ONE cell of 16 rows -- 64 dword stores per tile, and narrow stores are
   // issue-bound.  Staged, 16 lanes own one query row's 64 cells as float4: a wave store covers
@@ -194,13 +183,27 @@ __global__ __launch_bounds__(256) void sim_mfma_kernel(
   const int sub = lane >> 4;            // row within a 4-row pass
   const int c4 = (lane & 15) * 4;       // first of the lane's 4 cells
   const int ncell = XY - cell0;         // live cells of this chunk (>= 1)
+  // One 32-row half at a time: the stores of half 0 drain while the matrix pipe works on half 1
+  // (measured: the contraction costs 0.46 ms and the stores 0.38 ms of the kernel's 1.17 ms when
+  // all MFMAs run first -- they did not overlap), and the kernel holds 32 accumulator registers
+  // instead of 64 (one more wave per SIMD).
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < ((SNAP_SIM_ABLATE & 2) ? 1 : DM / 2); ++j)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        acc[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ti][j], bq[tj][j], acc[tj], 0, 0, 0);
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        st[(r & 3) + 8 * (r >> 2) + 4 * lhi][32 * tj + l31] = acc[ti][tj][r];   // MFMA C layout
+        st[(r & 3) + 8 * (r >> 2) + 4 * lhi][32 * tj + l31] = acc[tj][r];   // MFMA C layout
     // (the tile is private to the wave: LDS ops of one wave complete in order, no barrier)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -224,14 +227,15 @@ __global__ __launch_bounds__(256) void sim_mfma_kernel(
       float sum = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (c4 + e < ncell) sum += __expf(x[e] - m);   // v_exp_f32: ~1e-6 relative on the chunk mass
+        if (c4 + e < ncell) sum += (SNAP_SIM_ABLATE & 4) ? (x[e] - m) : __expf(x[e] - m);   // v_exp_f32: ~1e-6 relative on the chunk mass
       sum += snap_dpp<0x128>(sum);
       sum += snap_dpp<0x124>(sum);
       sum += snap_dpp<0x122>(sum);
       sum += snap_dpp<0x121>(sum);
       if (live) {
         float* o = sim + row * XY + cell0 + c4;
-        if (c4 + 3 < ncell && ((XY & 3) == 0)) {
+        if (SNAP_SIM_ABLATE & 1) {
+        } else if (c4 + 3 < ncell && ((XY & 3) == 0)) {
           *reinterpret_cast<f32x4*>(o) = f32x4{x[0] * wrow, x[1] * wrow, x[2] * wrow, x[3] * wrow};
         } else {
 #pragma unroll

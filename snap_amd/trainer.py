@@ -36,6 +36,37 @@ def make_lr_fn(base_lr: float, num_steps: int, start_decay_step: Optional[int] =
 
 
 @dataclasses.dataclass
+class DynamicScale:
+  """Dynamic loss scaling, the state machine of ``flax.training.dynamic_scale.DynamicScale``
+  that the reference attaches to float16 runs (``trainer.py:223-229``: the loss is multiplied
+  by ``scale`` before differentiation, the gradients divided by it; ``trainer.py:391``:
+  ``DynamicScale(minimum_scale=256)``).  A non-finite gradient halves the scale (not below
+  ``minimum_scale``) and the step is skipped; ``growth_interval`` consecutive finite steps
+  double it.  The scale is a power of two, so scaling is exact in f32 / bf16 arithmetic: with
+  this framework's bf16-operand precision (f32 exponent range) it changes nothing but the
+  overflow behaviour -- it exists so that a float16-style training recipe ports unchanged."""
+  growth_factor: float = 2.0
+  backoff_factor: float = 0.5
+  growth_interval: int = 2000
+  fin_steps: int = 0
+  scale: float = 65536.0
+  minimum_scale: Optional[float] = None
+
+  def update(self, is_finite: bool) -> 'DynamicScale':
+    f32_max = 3.4028234663852886e38
+    if is_finite:
+      grow = self.fin_steps == self.growth_interval
+      scale = min(self.scale * self.growth_factor, f32_max) if grow else self.scale
+      fin_steps = 0 if grow else self.fin_steps + 1
+    else:
+      scale = self.scale * self.backoff_factor
+      if self.minimum_scale is not None:
+        scale = max(scale, self.minimum_scale)
+      fin_steps = 0
+    return dataclasses.replace(self, scale=scale, fin_steps=fin_steps)
+
+
+@dataclasses.dataclass
 class TrainState:
   params: Dict[str, Any]
   m: List[torch.Tensor]
@@ -43,12 +74,14 @@ class TrainState:
   global_step: int = 0
   opt_count: int = 0      # optimizer updates actually applied (skipped steps do not count)
   rng: int = 0
+  dynamic_scale: Optional[DynamicScale] = None   # (train_state.dynamic_scale, trainer.py:223)
 
   @classmethod
-  def create(cls, params, rng=0):
+  def create(cls, params, rng=0, dynamic_scale=None):
     leaves = [t for _, t in flatten_params(params)]
     return cls(params=params, m=[torch.zeros_like(t) for t in leaves],
-               v=[torch.zeros_like(t) for t in leaves], global_step=0, rng=rng)
+               v=[torch.zeros_like(t) for t in leaves], global_step=0, rng=rng,
+               dynamic_scale=dynamic_scale)
 
 
 def save_train_state(path, state: TrainState) -> None:
@@ -66,6 +99,9 @@ def save_train_state(path, state: TrainState) -> None:
       'opt_count': torch.tensor(state.opt_count, dtype=torch.int64),
       'rng': torch.tensor(state.rng, dtype=torch.int64),
   }
+  if state.dynamic_scale is not None:
+    tree['dynamic_scale'] = {'scale': torch.tensor(state.dynamic_scale.scale, dtype=torch.float64),
+                             'fin_steps': torch.tensor(state.dynamic_scale.fin_steps, dtype=torch.int64)}
   checkpoint.save_npz(path, tree)
 
 
@@ -79,9 +115,13 @@ def load_train_state(path, template: TrainState) -> TrainState:
   tmpl_m = checkpoint.unflatten(dict(zip(names, template.m)))
   m = checkpoint.load_into(tmpl_m, tree['opt']['m'])
   v = checkpoint.load_into(tmpl_m, tree['opt']['v'])
+  ds = template.dynamic_scale
+  if ds is not None and 'dynamic_scale' in tree:
+    ds = dataclasses.replace(ds, scale=float(tree['dynamic_scale']['scale']),
+                             fin_steps=int(tree['dynamic_scale']['fin_steps']))
   return TrainState(params=params, m=[t for _, t in flatten_params(m)], v=[t for _, t in flatten_params(v)],
                     global_step=int(tree['global_step']), rng=int(tree['rng']),
-                    opt_count=int(tree.get('opt_count', tree['global_step'])))
+                    opt_count=int(tree.get('opt_count', tree['global_step'])), dynamic_scale=ds)
 
 
 def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
@@ -128,9 +168,10 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
     raise ValueError(f'train_step: precision={precision!r}')
   prev_precision = ops.MATMUL_PRECISION
   ops.MATMUL_PRECISION = precision      # read by the backward thread too (module global)
+  loss_scale = state.dynamic_scale.scale if state.dynamic_scale is not None else None
   try:
     grads, loss, losses, metrics = _forward_backward(state, batch, model, leaves, sampling_rng,
-                                                     group, debug, overlap_allreduce)
+                                                     group, debug, overlap_allreduce, loss_scale)
   finally:
     ops.MATMUL_PRECISION = prev_precision
   for t in leaves:
@@ -142,6 +183,9 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
     factor = torch.clamp(max_grad_norm / (gn + 1e-6), max=1.0)
     torch._foreach_mul_(grads, factor)
   is_fin = sdist.all_finite(grads, group)
+  if state.dynamic_scale is not None:
+    state.dynamic_scale = state.dynamic_scale.update(is_fin)
+    logs['loss_scale'] = state.dynamic_scale.scale
   logs['l2_grads'] = float(_global_norm(grads))
   # The reference restores the whole opt_state on a skipped step, optax's step and schedule
   # counts included (trainer.py:269-276): bias correction and schedule follow opt_count.
@@ -163,8 +207,10 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   return state, reduced, logs
 
 
-def _forward_backward(state, batch, model, leaves, sampling_rng, group, debug, overlap_allreduce):
-  """Loss + (all-reduced) gradients of one batch."""
+def _forward_backward(state, batch, model, leaves, sampling_rng, group, debug, overlap_allreduce,
+                      loss_scale=None):
+  """Loss + (all-reduced) gradients of one batch.  ``loss_scale``: DynamicScale -- differentiate
+  loss * scale, return the gradients divided by it (dynamic_scale.value_and_grad)."""
   with torch.enable_grad():
     pred = model.flax_model.apply(
         {'params': state.params}, batch, train=True, rngs={'sampling': sampling_rng},
@@ -176,12 +222,15 @@ def _forward_backward(state, batch, model, leaves, sampling_rng, group, debug, o
     mask = batch['batch_mask'].to(torch.bool)
     total = losses['total']
     loss = torch.where(mask, total, torch.zeros_like(total)).sum() / mask.sum().clamp(min=1)
+    objective = loss if loss_scale is None else loss * loss_scale
     if sdist._world(group) > 1 and overlap_allreduce:
       reducer = sdist.OverlappedGradReducer(leaves, group).attach()
-      loss.backward()                                  # buckets go out as their grads land
+      objective.backward()                             # buckets go out as their grads land
       grads = reducer.finish()                         # jax.lax.pmean(grad, 'batch')
     else:
-      grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+      grads = torch.autograd.grad(objective, leaves, allow_unused=True)
       grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
       sdist.allreduce_mean_(grads, group)              # jax.lax.pmean(grad, 'batch')
+    if loss_scale is not None:
+      torch._foreach_mul_(grads, 1.0 / loss_scale)
   return grads, loss, losses, metrics

@@ -200,3 +200,27 @@ def test_eval_step_dispatches_on_the_model(monkeypatch):
   monkeypatch.delattr(_Sem, 'pack_evaluation_metrics')
   with pytest.raises(ValueError):
     evaluator.eval_step({}, {}, rng=0, model=other)
+
+
+def test_dynamic_scale_state_machine_and_checkpoint(tmp_path):
+  """flax.training.dynamic_scale.DynamicScale's update rule (used by the reference for float16
+  runs, trainer.py:391) and its round trip through save / load_train_state."""
+  from snap_amd import trainer
+  ds = trainer.DynamicScale(growth_interval=2, minimum_scale=256.0, scale=1024.0)
+  seq = []
+  for fin in (True, True, True, True, False, False, False, True):
+    ds = ds.update(fin)
+    seq.append((ds.scale, ds.fin_steps))
+  assert seq == [(1024.0, 1), (1024.0, 2), (2048.0, 0), (2048.0, 1), (1024.0, 0), (512.0, 0),
+                 (256.0, 0), (256.0, 1)]
+  assert trainer.DynamicScale(scale=256.0, minimum_scale=256.0).update(False).scale == 256.0
+  assert trainer.DynamicScale(scale=3e38, growth_interval=0).update(True).scale <= 3.4028234663852886e38
+  params = {'a': {'kernel': torch.ones(3, 2)}, 'b': {'bias': torch.zeros(2)}}
+  st = trainer.TrainState.create(params, rng=4, dynamic_scale=ds)
+  path = str(tmp_path / 'state.npz')
+  trainer.save_train_state(path, st)
+  tmpl = trainer.TrainState.create({'a': {'kernel': torch.zeros(3, 2)}, 'b': {'bias': torch.zeros(2)}},
+                                   dynamic_scale=trainer.DynamicScale(growth_interval=2, minimum_scale=256.0))
+  back = trainer.load_train_state(path, tmpl)
+  assert back.dynamic_scale.scale == 256.0 and back.dynamic_scale.fin_steps == 1
+  assert back.dynamic_scale.growth_interval == 2 and back.rng == 4

@@ -121,6 +121,36 @@ def test_non_finite_gradients_skip_the_update():
   assert all(same)
 
 
+def test_dynamic_scale_is_exact_and_backs_off():
+  """TrainState.dynamic_scale (trainer.py:223-229, 391): the scale is a power of two, so the
+  scaled-and-unscaled gradients -- hence the updated parameters -- equal the unscaled step's
+  up to the lift's float atomics; a non-finite gradient halves the scale (not below
+  minimum_scale) and skips the update; growth after `growth_interval` finite steps."""
+  model, params, batch = _setup(seed=6)
+  plain = trainer.TrainState.create(copy.deepcopy(params), rng=1)
+  scaled = trainer.TrainState.create(copy.deepcopy(params), rng=1,
+                                     dynamic_scale=trainer.DynamicScale(growth_interval=1, minimum_scale=256.0))
+  plain, _, la = trainer.train_step(plain, batch, model=model, lr_fn=lambda s: 1e-3)
+  scaled, _, lb = trainer.train_step(scaled, batch, model=model, lr_fn=lambda s: 1e-3)
+  assert lb['is_finite'] and lb['loss_scale'] == 65536.0 and scaled.dynamic_scale.fin_steps == 1
+  assert abs(la['loss'] - lb['loss']) <= 1e-6 * abs(la['loss'])
+  assert abs(la['l2_grads'] - lb['l2_grads']) <= 1e-4 * la['l2_grads']
+  for (n, a), (_, b) in zip(trainer.flatten_params(plain.params), trainer.flatten_params(scaled.params)):
+    assert torch.allclose(a, b, rtol=0, atol=3e-6), n          # (|update| <= lr = 1e-3 per element)
+  scaled, _, lb = trainer.train_step(scaled, batch, model=model, lr_fn=lambda s: 1e-3)
+  assert lb['loss_scale'] == 131072.0 and scaled.dynamic_scale.fin_steps == 0     # grown
+  bad = dict(batch)
+  q = dict(batch['query'])
+  q['images'] = q['images'].clone()
+  q['images'][0, 0, 0, 0, 0] = float('nan')
+  bad['query'] = q
+  before = copy.deepcopy(scaled.params)
+  scaled, _, lb = trainer.train_step(scaled, bad, model=model, lr_fn=lambda s: 1e-3)
+  assert not lb['is_finite'] and lb['loss_scale'] == 65536.0
+  assert all(torch.equal(a, b) for (_, a), (_, b) in
+             zip(trainer.flatten_params(before), trainer.flatten_params(scaled.params)))
+
+
 def test_bf16_training_precision_tracks_f32():
   """precision='bf16' (bf16 GEMM operands, f32 accumulate -- the analogue of the reference's
   float16 train config): same loss to ~1 %, gradients pointing the same way as the exact
