@@ -537,6 +537,15 @@ def main(argv=None):
             'traffic': _pmc_traffic(dom, s['launches'], args.workload, default_cfg),
             'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
         }
+      if dom.startswith('conv_split') and out['roofline'].get('traffic'):
+        # the same family against the HBM roofline: most of its launches are 1x1 convolutions with
+        # short reductions, which run at the memory system's pace, not the matrix pipe's
+        tb = out['roofline']['traffic'] * s['launches']
+        gbs = tb / s['ms'] / 1e6
+        out['roofline_conv_hbm'] = {
+            'kernel': dom, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic_bytes_per_step': tb,
+            'note': 'HBM-side bytes of the family (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/) / its time'}
       if 'pose_score' in summ:
         s = summ['pose_score']
         ach = s['bytes'] / s['ms'] / 1e6
