@@ -248,13 +248,16 @@ int snap_compact_rows_u8(const uint8_t* mask, int64_t M, int32_t* index, int32_t
  *   snap_compact_rows_u8 (ascending); M = upper bound of the row count;
  *   w0_split = snap_conv2d_pack_weights_split_bf16(W0 [Cin, H], taps 1, parts 2);
  *   w1_split = the same packing of W1 [H, D];  H % 32 == 0, H <= 256; D % 4 == 0, D <= 128;
- *   relu_in: MLP.apply_input_activation;  plane [ncols, D], pvalid [ncols]. */
+ *   relu_in: MLP.apply_input_activation;  plane [ncols, D], pvalid [ncols].
+ *   x_split = 1: x holds the rows pre-split (SnapLiftDesc.out_split: [slab][hi | lo][16] bf16,
+ *   x_stride still in floats); the A operand then travels global -> LDS by LDS-DMA.  Same
+ *   results bit for bit; relu_in must be 0. */
 int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
                            const int32_t* rows, const int32_t* row_count,
                            const void* w0_split, size_t w0_bytes, const float* b0, int32_t H,
                            const void* w1_split, size_t w1_bytes, const float* b1, int32_t D,
-                           int32_t relu_in, int32_t Z, int64_t ncols, float* plane,
-                           uint8_t* pvalid, void* stream);
+                           int32_t relu_in, int32_t x_split, int32_t Z, int64_t ncols,
+                           float* plane, uint8_t* pvalid, void* stream);
 
 /* y[m, 0..C) = value for every row with mask[m] == 0 (the masked voxels of a volume
  * whose observed rows were written through rows_out).  C % 4 == 0. */
@@ -339,6 +342,11 @@ typedef struct SnapLiftDesc {
    * voxels only (snap_mlp2_pool_max_f32, row-indexed conv launches).  0: zeros, as the
    * reference's pool_multiview_features returns. */
   int32_t valid_rows_only;
+  /* 1: `pooled` rows are written pre-split for the split-bf16 engines instead of as f32:
+   * row = [ceil(channels / 16) slabs][hi | lo][16] bf16 (64 B per slab; hi = bf16(v) RNE,
+   * lo = bf16(v - hi)), out_stride (in floats) >= 16 * slabs -- what snap_mlp2_pool_max_f32
+   * takes with x_split = 1.  Default fusion options, <= 4 selected views, feature_dim % 8 == 0. */
+  int32_t out_split;
 } SnapLiftDesc;
 
 /* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) tan(max_fov/2)(1) ALREADY scaled to

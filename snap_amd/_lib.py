@@ -48,7 +48,7 @@ class SnapLiftDesc(ctypes.Structure):
       ('depth_min', c_float), ('depth_max', c_float),
       ('max_view_distance', c_float),
       ('weighted', c_int), ('use_variance', c_int), ('add_minmax', c_int),
-      ('grid_y', c_int), ('grid_z', c_int), ('valid_rows_only', c_int),
+      ('grid_y', c_int), ('grid_z', c_int), ('valid_rows_only', c_int), ('out_split', c_int),
   ]
 
 
@@ -99,7 +99,7 @@ SIGNATURES = {
     'snap_compact_rows_workspace_bytes': (c_size, [c_i64]),
     'snap_compact_rows_u8': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_size, ptr]),
     'snap_mlp2_pool_max_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, ptr, c_int,
-                                       ptr, c_size, ptr, c_int, c_int, c_int, c_i64, ptr, ptr, ptr]),
+                                       ptr, c_size, ptr, c_int, c_int, c_int, c_int, c_i64, ptr, ptr, ptr]),
     'snap_fill_masked_rows_f32': (c_int, [ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_weight_standardize_f32': (c_int, [ptr, ptr, c_int, c_int, c_float, ptr]),
     'snap_weight_standardize_multi_f32': (c_int, [ptr, c_int, c_int, c_float, ptr]),
@@ -239,7 +239,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 

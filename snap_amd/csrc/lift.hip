@@ -396,6 +396,24 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int LB_REC = 8;    // dwords per (voxel, slot) record: o00 | packed | wi1 | wj1 | wb1
 
+// hi / lo bf16 parts of four f32, two per dword (the split of conv_split.hip / mlp_pool.hip)
+__device__ __forceinline__ void split_row_quad(const f32x4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x2 pr = {v[2 * h], v[2 * h + 1]};
+    const bf16x2 b = __builtin_convertvector(pr, bf16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &b, 4);
+    hi[h] = u;
+    const f32x2 rs = {pr[0] - __uint_as_float(u << 16), pr[1] - __uint_as_float(u & 0xffff0000u)};
+    const bf16x2 bl = __builtin_convertvector(rs, bf16x2);
+    __builtin_memcpy(&u, &bl, 4);
+    lo[h] = u;
+  }
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a) {
   __shared__ __attribute__((aligned(16))) int recs[8][32][KMAX][LB_REC];
@@ -608,12 +626,44 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
     // (valid_rows_only: a voxel no view sees gets its validity byte, not its 1 KB row of zeros --
     // for consumers that read the rows of valid voxels only, 40 % of the map's voxels at C2)
     const bool write_row = nvis > 0 || !d.valid_rows_only;
-    if (hl < nq && write_row) {
+    if (d.out_split) {
+      // the row as the split-bf16 engines stage it: [16-channel slab][hi | lo][16] bf16, 64 B per
+      // slab (hi = bf16(v), lo = bf16(v - hi): the consumer's own split, done here once) -- the
+      // fused MLP / pool kernel then moves it global -> LDS by LDS-DMA without touching a register
+      char* orow = reinterpret_cast<char*>(out);
+      // lanes 2i / 2i+1 hold channels k..k+3 / k+4..k+7 of one 16-byte chunk: the even lane
+      // collects both hi halves, the odd lane both lo halves (one exchange), and each writes
+      // ONE 16-byte chunk per statistic instead of two 8-byte halves
+      {
+        const bool odd = hl & 1;
+        const f32x4 stat[2] = {mean, var};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          unsigned hi[2], lo[2];
+          split_row_quad(stat[t], hi, lo);
+          const unsigned g0 = __shfl_xor(odd ? hi[0] : lo[0], 1);
+          const unsigned g1 = __shfl_xor(odd ? hi[1] : lo[1], 1);
+          const uint4 chunk = odd ? uint4{g0, g1, lo[0], lo[1]} : uint4{hi[0], hi[1], g0, g1};
+          const int c = t * fd + 4 * (hl & ~1);          // first channel of the chunk
+          if (hl < nq && write_row)
+            *reinterpret_cast<uint4*>(orow + (c >> 4) * 64 + (odd ? 32 : 0) + (c & 15) * 2) = chunk;
+        }
+      }
+      if (hl == 0 && write_row) {           // (2 fd % 16 == 0: score_max opens a slab of its own)
+        unsigned hi[2], lo[2];
+        split_row_quad(f32x4{smax, 0.f, 0.f, 0.f}, hi, lo);
+        uint4* ps = reinterpret_cast<uint4*>(orow + ((2 * fd) >> 4) * 64);
+        ps[0] = uint4{hi[0], 0u, 0u, 0u};
+        ps[1] = uint4{0u, 0u, 0u, 0u};
+        ps[2] = uint4{lo[0], 0u, 0u, 0u};
+        ps[3] = uint4{0u, 0u, 0u, 0u};
+      }
+    } else if (hl < nq && write_row) {
       *reinterpret_cast<f32x4*>(out + 4 * hl) = mean;
       *reinterpret_cast<f32x4*>(out + fd + 4 * hl) = var;
     }
     if (hl == 0) {
-      if (write_row) {
+      if (write_row && !d.out_split) {
         out[2 * fd] = smax;
         for (int c = 2 * fd + 1; c < d.out_stride; ++c) out[c] = 0.f;
       }
@@ -658,6 +708,11 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   if (d.C != d.feature_dim + bins || d.C % 4 != 0 || (d.weighted && d.num_bins < 1)) return SNAP_ERR_BAD_SHAPE;
   const int chans = d.feature_dim * (1 + (d.use_variance ? 1 : 0) + (d.add_minmax ? 2 : 0)) + (d.weighted ? 1 : 0);
   if (d.out_stride < chans || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.out_split) {      // default options' batched kernel only; whole slabs; score_max on a slab boundary
+    const int nsel_ = d.K == 0 ? d.V : d.K;
+    if (!dflt || nsel_ > 4 || d.feature_dim % 8 != 0 || d.out_stride < ((chans + 15) / 16) * 16)
+      return SNAP_ERR_UNSUPPORTED;
+  }
   if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;  // K>0 means V > K
   if (!(d.depth_max > d.depth_min) || !(d.depth_min > 0.f)) return SNAP_ERR_BAD_SHAPE;
   if ((reinterpret_cast<uintptr_t>(f_images) & 15) || (reinterpret_cast<uintptr_t>(pooled) & 15))

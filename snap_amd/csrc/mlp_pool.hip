@@ -81,7 +81,7 @@ __device__ __forceinline__ void atomic_max_f32(float* p, float v) {
     atomicMax(reinterpret_cast<int*>(p), (int)u);
 }
 
-template <int N0, bool RELU_IN>
+template <int N0, bool RELU_IN, bool XSPLIT>
 __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   constexpr int BM = 128, N1 = 128;
   constexpr int T0 = N0 / 32, T1 = N1 / 32;
@@ -186,27 +186,52 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
 
-  load_a(0);
-  issue_b0(0, 0);
-  store_a(0);
+  // XSPLIT: the rows arrive pre-split ([slab][hi | lo][16] bf16, 64 B per row and slab: the lift's
+  // out_split format) and go global -> LDS by LDS-DMA: no staging registers, no VALU, no LDS stores.
+  // Stage layout [row][4 x 16 B] = hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15, the chunk index XOR-ed
+  // with (row >> 1) & 3 (eight consecutive rows then hit eight distinct 16-byte bank groups); the
+  // DMA writes LDS lane-contiguously, so each lane FETCHES the global chunk its slot holds.
+  const char* xs_px[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 2) + 64 * i;
+    const int c = (tid & 3) ^ ((row >> 1) & 3);
+    xs_px[i] = r_ok[i] ? reinterpret_cast<const char*>(r_px[i]) + c * 16
+                       : reinterpret_cast<const char*>(kZeroChunk);
+  }
+  auto issue_a = [&](int buf, int s_) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(xs_px[i] + (r_ok[i] ? s_ * 64 : 0)),
+                                       (lds_void_t*)(sm + buf * A_ST + (tid + 256 * i) * 16), 16, 0, 0);
+  };
+  if constexpr (XSPLIT) {
+    issue_a(0, 0);
+    issue_b0(0, 0);
+  } else {
+    load_a(0);
+    issue_b0(0, 0);
+    store_a(0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int R = 32 * wid + l31;                                   // this lane's row of the tile
-  const int a_off = R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
+  const int a_off = XSPLIT ? R * 64 + ((lhi ^ ((R >> 1) & 3)) * 16)
+                           : R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
+  const int a_lo_off = XSPLIT ? R * 64 + (((2 + lhi) ^ ((R >> 1) & 3)) * 16) : a_off + A_PART;
   const int w_off = l31 * 32 + ((lhi ^ ((l31 >> 3) & 1)) * 16);   // column 32 t' + l31 of a 128-tile
   const int nk0 = a.ctiles0;
   for (int kt = 0; kt < nk0; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk0;
     if (more) {
-      load_a(kt + 1);
+      if constexpr (XSPLIT) issue_a(cur ^ 1, kt + 1); else load_a(kt + 1);
       issue_b0(cur ^ 1, kt + 1);
     }
-    const char* as = sm + cur * A_ST + a_off;
     const char* bs = sm + kB0 + cur * B0_ST + w_off;
-    const bf16x8 x_hi = *reinterpret_cast<const bf16x8*>(as);
-    const bf16x8 x_lo = *reinterpret_cast<const bf16x8*>(as + A_PART);
+    const bf16x8 x_hi = *reinterpret_cast<const bf16x8*>(sm + cur * A_ST + a_off);
+    const bf16x8 x_lo = *reinterpret_cast<const bf16x8*>(sm + cur * A_ST + a_lo_off);
 #pragma unroll
     for (int g = 0; g < T0 / 4; ++g) {
       bf16x8 w_hi[4], w_lo[4];
@@ -228,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
       for (int j = 0; j < 4; ++j)
         acc0[4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], x_hi, acc0[4 * g + j], 0, 0, 0);
     }
-    if (more) store_a(cur ^ 1);
+    if constexpr (!XSPLIT) {
+      if (more) store_a(cur ^ 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -389,14 +416,16 @@ extern "C" int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, in
                                       const int32_t* rows, const int32_t* row_count,
                                       const void* w0_split, size_t w0_bytes, const float* b0,
                                       int32_t H, const void* w1_split, size_t w1_bytes,
-                                      const float* b1, int32_t D, int32_t relu_in, int32_t Z,
-                                      int64_t ncols, float* plane, uint8_t* pvalid, void* stream) {
+                                      const float* b1, int32_t D, int32_t relu_in, int32_t x_split,
+                                      int32_t Z, int64_t ncols, float* plane, uint8_t* pvalid,
+                                      void* stream) {
   if (!x || !rows || !row_count || !w0_split || !b0 || !w1_split || !b1 || !plane || !pvalid)
     return SNAP_ERR_NULL;
   if (M <= 0 || M > 0x7fffffffLL || Cin <= 0 || x_stride < Cin || x_stride % 4 != 0 || Z <= 0 ||
       ncols <= 0 || ncols * Z > 0x7fffffffLL)
     return SNAP_ERR_BAD_SHAPE;
   if (H <= 0 || H % 32 != 0 || H > 256 || D <= 0 || D % 4 != 0 || D > 128) return SNAP_ERR_UNSUPPORTED;
+  if (x_split && (relu_in || x_stride < ((Cin + 15) / 16) * 16)) return SNAP_ERR_UNSUPPORTED;
   if (w0_bytes < snap_conv2d_packed_weights_split_bytes(1, Cin, H, 2) ||
       w1_bytes < snap_conv2d_packed_weights_split_bytes(1, H, D, 2))
     return SNAP_ERR_WORKSPACE;
@@ -416,11 +445,13 @@ extern "C" int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, in
   a.Z = Z; a.plane = plane;
   const dim3 grid((unsigned)snap_cdiv(M, 128));
   if (H <= 128) {
-    if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<128, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mlp2_pool_kernel<128, false>), grid, dim3(256), 0, s, a);
+    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true>), grid, dim3(256), 0, s, a);
+    else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<128, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp2_pool_kernel<128, false, false>), grid, dim3(256), 0, s, a);
   } else {
-    if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<256, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mlp2_pool_kernel<256, false>), grid, dim3(256), 0, s, a);
+    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<256, false, true>), grid, dim3(256), 0, s, a);
+    else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<256, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp2_pool_kernel<256, false, false>), grid, dim3(256), 0, s, a);
   }
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(mlp2_pool_finalize_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s,

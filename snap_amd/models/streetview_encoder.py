@@ -110,7 +110,7 @@ class StreetViewEncoder(base.Module):
     kw = dict(K=K, fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
               num_bins=cfg.num_scale_bins, depth_min_max=cfg.depth_min_max,
               max_view_distance=cfg.get('max_view_distance'))
-    fused = False
+    fused = split = False
     if base.needs_grad(f_images):
       if not self.default_fusion:
         raise NotImplementedError('non-default fusion options have no backward kernel yet')
@@ -120,8 +120,10 @@ class StreetViewEncoder(base.Module):
       if xyz.dim() == 5:                     # [B, X, Y, Z, 3]: a voxel grid (traversal hint)
         kw.update(grid_yz=tuple(xyz.shape[2:4]))
       fused = pool_max and self.default_fusion and self._fused_pool_ok(params, f_images)
-      if fused:                              # the fused kernel reads the rows of valid voxels only
-        kw.update(valid_rows_only=True)
+      split = (fused and ops.POOLED_SPLIT and not cfg.fusion.apply_input_activation
+               and cfg.feature_dim % 8 == 0 and (K or V) <= 4)
+      if fused:                              # the fused kernel reads the rows of valid voxels only,
+        kw.update(valid_rows_only=True, out_split=split)   # pre-split: its A operand goes by LDS-DMA
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))
@@ -136,7 +138,7 @@ class StreetViewEncoder(base.Module):
           pooled.reshape(-1, pooled.shape[-1]), valid.reshape(-1),
           p['Dense_0']['kernel'], p['Dense_0']['bias'], p['Dense_1']['kernel'], p['Dense_1']['bias'],
           cin=self.fusion_mlp.in_dim, Z=grid_shape[-1],
-          relu_in=bool(cfg.fusion.apply_input_activation))
+          relu_in=bool(cfg.fusion.apply_input_activation), x_split=split)
       pred['feature_volume'] = types.FeatureVolume(features=None, valid=valid.reshape(grid_shape))
       pred['feature_plane'] = types.FeaturePlane(
           features=plane.reshape(*grid_shape[:-1], plane.shape[-1]),

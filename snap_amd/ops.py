@@ -27,6 +27,8 @@ def _stream():
 # next to the StreetView encoder: its deep stages are launches of 19-73 workgroups on a 256-CU
 # part).  SNAP_OVERLAP_AERIAL=0 keeps everything on one stream.
 OVERLAP_AERIAL = os.environ.get('SNAP_OVERLAP_AERIAL', '1') != '0'
+# the lift hands `pooled` to the fused MLP / pool kernel pre-split (LDS-DMA A operand); 0: as f32 rows
+POOLED_SPLIT = os.environ.get('SNAP_POOLED_SPLIT', '1') != '0'
 _SIDE_STREAM = None
 
 
@@ -520,12 +522,14 @@ def mlp2_pool_supported(cin, hidden, out_dim):
   return hidden % 32 == 0 and hidden <= 256 and out_dim % 4 == 0 and out_dim <= 128 and cin >= 4
 
 
-def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False):
+def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False):
   """Fusion MLP (Dense -> relu -> Dense) over the rows with row_mask != 0 + max over the Z
   levels of every column, in one kernel on the bf16x3 engine (streetview_encoder.py:279-286 +
   bev_mapper.py:78-88).  x [M, Cs] (M = columns * Z, level fastest), row_mask [M];
   w0 [cin, H], w1 [H, D] -> plane [M / Z, D] f32, pvalid [M / Z] bool.  The hidden activations
-  and the [M, D] volume are never written."""
+  and the [M, D] volume are never written.  ``x_split``: x holds the rows pre-split
+  (``lift_pool(out_split=True)``: [16-channel slab][hi | lo][16] bf16 in an f32 container); same
+  bits, the kernel's A operand then travels by LDS-DMA."""
   lib = _lib.load()
   _f32(x, 'x'); _mask(row_mask, 'row_mask')
   for t, n in ((w0, 'w0'), (b0, 'b0'), (w1, 'w1'), (b1, 'b1')):
@@ -548,7 +552,8 @@ def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False):
                lambda: f'M{M}r_K{cin}_H{H}_N{D}_Z{Z}'):
     st = lib.snap_mlp2_pool_max_f32(
         _p(x), M, cin, Cs, _p(index), _p(count), _p(w0p), w0p.numel() * 2, _p(b0), H,
-        _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), Z, ncols, _p(plane), _p(pvalid), _stream())
+        _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), int(bool(x_split)), Z, ncols, _p(plane),
+        _p(pvalid), _stream())
   _lib.check(st, 'snap_mlp2_pool_max_f32')
   return plane, pvalid
 
@@ -694,7 +699,7 @@ def pooled_stride(feature_dim, weighted=True, use_variance=True, add_minmax=Fals
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
-              add_minmax=False, grid_yz=None, valid_rows_only=False):
+              add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False):
   """Fused k1-k5.  f_images [B,V,h,w,C]; cam [B,V,11]; Rt [B,V,12]; points [B,N,3].
 
   K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad by default;
@@ -702,13 +707,17 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   ``grid_yz`` = (Y, Z): the points are the voxel centres of an [X, Y, Z] grid, level fastest --
   a traversal hint (8 x 8 column blocks per XCD), the results do not depend on it.
   ``valid_rows_only``: rows of voxels no view sees are left unwritten (uninitialised memory) --
-  only for consumers that read the rows of valid voxels.
+  only for consumers that read the rows of valid voxels.  ``out_split``: rows are written
+  pre-split for the split-bf16 engines ([16-channel slab][hi | lo][16] bf16, returned in an f32
+  container of 16 * slabs floats per row) -- ``mlp2_pool_max(x_split=True)`` takes them.
   """
   lib = _lib.load()
   _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
   B, V, h, w, C = f_images.shape
   N = points.shape[1]
   stride = pooled_stride(feature_dim, weighted, use_variance, add_minmax)
+  if out_split:
+    stride = (pooled_channels(feature_dim, weighted, use_variance, add_minmax) + 15) // 16 * 16
   pooled = torch.empty((B, N, stride), dtype=torch.float32, device=f_images.device)
   valid = torch.empty((B, N), dtype=torch.bool, device=f_images.device)
   d = _lib.SnapLiftDesc(
@@ -720,6 +729,7 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   if grid_yz is not None and N % (int(grid_yz[0]) * int(grid_yz[1])) == 0:
     d.grid_y, d.grid_z = int(grid_yz[0]), int(grid_yz[1])
   d.valid_rows_only = int(bool(valid_rows_only))
+  d.out_split = int(bool(out_split))
   with _region(
       'lift_pool', 0.0, 4.0 * (f_images.numel() + points.numel() + pooled.numel())
   ):

@@ -178,7 +178,7 @@ def unpack_transforms(Rt):
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
-              add_minmax=False, grid_yz=None, valid_rows_only=False):
+              add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False):
   f = _np(f_images, DTYPE)
   cams = unpack_cameras(cam, fisheye)
   T = unpack_transforms(Rt)
@@ -221,7 +221,7 @@ def mlp2_pool_supported(cin, hidden, out_dim):
   return True
 
 
-def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False):
+def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False):
   xx = _np(x, DTYPE)[:, :cin]
   if relu_in:
     xx = np.maximum(xx, 0)

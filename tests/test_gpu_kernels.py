@@ -634,6 +634,17 @@ def test_lift_bev_tiled_traversal_is_a_pure_reordering(X, Y, Z, K, V):
   # valid_rows_only: the rows of voxels some view sees are the same bits; the others are not written
   p2, v2 = ops.lift_pool(*args, grid_yz=(Y, Z), valid_rows_only=True, **kw)
   assert torch.equal(v2, v0) and torch.equal(p2[v0], p0[v0])
+  # out_split: the same rows as [slab][hi | lo][16] bf16 -- hi + lo reproduces the split of the f32 row
+  if K == 0 or K <= 4:
+    p3, v3 = ops.lift_pool(*args, grid_yz=(Y, Z), out_split=True, **kw)
+    ks = (2 * fd + 1 + 15) // 16
+    parts = p3.view(torch.int32).view(torch.int16).view(torch.bfloat16).reshape(*p3.shape[:2], ks, 2, 16)
+    ref = torch.zeros(*p0.shape[:2], ks * 16, device=p0.device)
+    ref[..., :2 * fd + 1] = p0[..., :2 * fd + 1]
+    hi = ref.bfloat16()
+    lo = (ref - hi.float()).bfloat16()
+    assert torch.equal(v3, v0)
+    assert torch.equal(parts[..., 0, :].reshape(*ref.shape), hi) and torch.equal(parts[..., 1, :].reshape(*ref.shape), lo)
 
 
 def test_project_points():
@@ -706,6 +717,19 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
   plane, pvalid = ops.vertical_pool(vol.reshape(ncols, Z, D), md.reshape(ncols, Z), 'max')
   assert torch.equal(pvalid, vg)
   assert torch.equal(plane, pg), float((plane - pg).abs().max())
+  if not relu_in:
+    # the rows handed over pre-split ([slab][hi | lo][16] bf16, the lift's out_split format): same bits
+    ks = (cin + 15) // 16
+    xp = torch.zeros(M, ks * 16)
+    xp[:, :cin] = x[:, :cin]
+    hi = xp.bfloat16()
+    lo = (xp - hi.float()).bfloat16()
+    rows = torch.stack([hi.view(M, ks, 16), lo.view(M, ks, 16)], dim=2).contiguous()      # [M, ks, 2, 16]
+    xs = rows.view(torch.int16).view(M, ks * 32).view(torch.float32).contiguous()           # f32 container
+    assert xs.shape == (M, ks * 16)
+    ps, vs = ops.mlp2_pool_max(xs.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
+                               cin=cin, Z=Z, x_split=True)
+    assert torch.equal(vs, vg) and torch.equal(ps, pg), float((ps - pg).abs().max())
 
 
 @pytest.mark.parametrize('nplanes', [1, 2])
