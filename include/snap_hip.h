@@ -415,6 +415,16 @@ int snap_sim_softmax_weighted_f32(const float* fq, const float* fm, int32_t B, i
                                   int32_t XY, int32_t Dm, float scale, int32_t clip_negative,
                                   const float* num_valid, const float* row_weight, float* sim,
                                   float* chunk_stats, float* prob, float* rowstats, void* stream);
+/* The same sim / chunk_stats with the Nq x XY x Dm contraction on the bf16 matrix cores at f32
+ * grade: fq / fm are split into `parts` bf16 parts per element (3: six products per MAC, ~2^-24
+ * per product -- the arithmetic of the conv engine's 'bf16x6'; 2: three products, ~2^-17) into
+ * `workspace` first.  Dm in {16, 32, 64}.  (prob / rowstats: use snap_sim_softmax_weighted_f32.) */
+size_t snap_sim_split_workspace_bytes(int32_t B, int32_t Nq, int32_t XY, int32_t Dm, int32_t parts);
+int snap_sim_softmax_split_f32(const float* fq, const float* fm, int32_t B, int32_t Nq, int32_t XY,
+                               int32_t Dm, float scale, int32_t clip_negative,
+                               const float* num_valid, const float* row_weight, int32_t parts,
+                               float* sim, float* chunk_stats, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* layers.masked_softmax over the last axis (snap/models/layers.py:38-43: an all-false mask acts
  * as all-true) of x [B, N] + its inclusive CDF (the sampler's distribution over query points). */
 int snap_masked_softmax_rows_f32(const float* x, const uint8_t* mask, int32_t B, int32_t N,

@@ -138,6 +138,9 @@ SIGNATURES = {
         [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr,
          ptr, ptr, ptr],
     ),
+    'snap_sim_split_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    'snap_sim_softmax_split_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr,
+                                           c_int, ptr, ptr, ptr, c_size, ptr]),
     'snap_masked_softmax_rows_f32': (c_int, [ptr, ptr, c_int, c_int, ptr, ptr, ptr]),
     'snap_confidence_head_f32': (c_int, [ptr, ptr, ptr, c_float, c_i64, c_int, ptr, ptr]),
     'snap_ransac_sample_sim_f32': (
@@ -239,7 +242,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 

@@ -251,6 +251,157 @@ __global__ __launch_bounds__(256, DM <= 32 ? 4 : 2) void sim_mfma_kernel(
   }
 }
 
+// ---- the same similarity with the contraction on the BF16 matrix cores, f32-grade -------------
+// f32 MFMAs cost 0.46 ms of the kernel above at C2 (39 GFLOP at half the f32 matrix peak).  Here
+// fq / fm are split once into NS bf16 parts per element (hi = bf16(v), mid = bf16(v - hi), lo =
+// bf16(v - hi - mid): conv_split.hip's arithmetic; NS = 3 keeps 24 significand bits per operand,
+// six part products per MAC, error ~2^-24 per product -- inside the f32 chain's own rounding) by
+// sim_presplit_kernel, and the tile is NS (NS + 1) / 2 x DM / 16 v_mfma_f32_32x32x16_bf16 per
+// 32 x 32 block instead of DM / 2 f32 MFMAs: 2.7 x fewer matrix cycles at NS = 3.  Same epilogue.
+typedef __bf16 sim_bf16x8 __attribute__((ext_vector_type(8)));
+
+// x [R, DM] f32 -> [R][NS][DM] bf16
+template <int NS>
+__global__ __launch_bounds__(256) void sim_presplit_kernel(const float* __restrict__ x, int64_t n,
+                                                           int DM, __bf16* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = i / DM;
+  const int k = (int)(i - r * DM);
+  float v = x[i];
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    const __bf16 b = (__bf16)v;
+    out[(r * NS + p) * DM + k] = b;
+    v -= (float)b;
+  }
+}
+
+template <int DM, int NS>
+__global__ __launch_bounds__(256, 3) void sim_split_kernel(
+    const __bf16* __restrict__ fqs, const __bf16* __restrict__ fms, int Nq, int XY, float scale,
+    int clip, const float* __restrict__ num_valid, float* __restrict__ sim,
+    float* __restrict__ stats, const float* __restrict__ row_weight) {
+  constexpr int KS = DM / 16;
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * SIM_TQ;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int chunk = blockIdx.x * 4 + wave;
+  const int cell0 = chunk * SIM_CH;
+  const int NC = (XY + SIM_CH - 1) / SIM_CH;
+  if (cell0 >= XY) return;
+  // B operand (map cells), both 32-cell tiles, kept for both row halves
+  sim_bf16x8 bq[2][KS][NS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int cell = cell0 + 32 * t + l31;
+    const bool cv = cell < XY;
+    const __bf16* src = fms + ((int64_t)b * XY + (cv ? cell : 0)) * (NS * DM) + 8 * lhi;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        bq[t][s][p] = *reinterpret_cast<const sim_bf16x8*>(src + p * DM + 16 * s);
+        if (!cv) bq[t][s][p] = sim_bf16x8{};
+      }
+  }
+  __shared__ __attribute__((aligned(16))) float stage[4][32][64 + 4];
+  float (*st)[64 + 4] = stage[wave];
+  const float rnv = 1.0f / num_valid[b];
+  const int sub = lane >> 4;
+  const int c4 = (lane & 15) * 4;
+  const int ncell = XY - cell0;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    sim_bf16x8 aq[KS][NS];
+    {
+      const int row = n0 + 32 * ti + l31;
+      const bool rv = row < Nq;
+      const __bf16* src = fqs + ((int64_t)b * Nq + (rv ? row : 0)) * (NS * DM) + 8 * lhi;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          aq[s][p] = *reinterpret_cast<const sim_bf16x8*>(src + p * DM + 16 * s);
+          if (!rv) aq[s][p] = sim_bf16x8{};
+        }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#define SNAP_SIM_PRODUCT(PA, PB)                                                               \
+  _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)                                               \
+      acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s][PA], bq[tj][s][PB], acc[tj], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if constexpr (NS == 3) {               // smallest terms first, as conv_split.hip
+        SNAP_SIM_PRODUCT(2, 0)
+        SNAP_SIM_PRODUCT(0, 2)
+        SNAP_SIM_PRODUCT(1, 1)
+        SNAP_SIM_PRODUCT(1, 0)
+        SNAP_SIM_PRODUCT(0, 1)
+        SNAP_SIM_PRODUCT(0, 0)
+      } else {
+        SNAP_SIM_PRODUCT(1, 0)
+        SNAP_SIM_PRODUCT(0, 1)
+        SNAP_SIM_PRODUCT(0, 0)
+      }
+    }
+#undef SNAP_SIM_PRODUCT
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        st[(r & 3) + 8 * (r >> 2) + 4 * lhi][32 * tj + l31] = acc[tj][r];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int rr = 4 * p + sub;
+      const int n = n0 + 32 * ti + rr;
+      const bool live = n < Nq;
+      const int64_t row = (int64_t)b * Nq + (live ? n : 0);
+      const float wrow = row_weight ? row_weight[row] : rnv;
+      f32x4 x = *reinterpret_cast<const f32x4*>(&st[rr][c4]);
+      float m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (clip) x[e] = fmaxf(x[e], 0.f);
+        x[e] *= scale;
+        if (c4 + e < ncell) m = fmaxf(m, x[e]);
+      }
+      m = fmaxf(m, snap_dpp<0x128>(m));
+      m = fmaxf(m, snap_dpp<0x124>(m));
+      m = fmaxf(m, snap_dpp<0x122>(m));
+      m = fmaxf(m, snap_dpp<0x121>(m));
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c4 + e < ncell) sum += __expf(x[e] - m);
+      sum += snap_dpp<0x128>(sum);
+      sum += snap_dpp<0x124>(sum);
+      sum += snap_dpp<0x122>(sum);
+      sum += snap_dpp<0x121>(sum);
+      if (live) {
+        float* o = sim + row * XY + cell0 + c4;
+        if (c4 + 3 < ncell && ((XY & 3) == 0)) {
+          *reinterpret_cast<f32x4*>(o) = f32x4{x[0] * wrow, x[1] * wrow, x[2] * wrow, x[3] * wrow};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c4 + e < ncell) o[e] = x[e] * wrow;
+        }
+        if ((lane & 15) == 0) {
+          stats[(row * NC + chunk) * 2 + 0] = m;
+          stats[(row * NC + chunk) * 2 + 1] = sum;
+        }
+      }
+    }
+  }
+}
+
 // layers.masked_softmax over the query points (snap/models/layers.py:38-43) + its inclusive CDF
 // (the sampler's row distribution).  One workgroup per scene; fixed-order sums.
 __global__ __launch_bounds__(256) void masked_softmax_rows_kernel(
@@ -1177,6 +1328,49 @@ extern "C" int snap_sim_softmax_weighted_f32(const float* fq, const float* fm, i
                        nullptr, rowstats, prob, row_weight);
   }
   return rc;
+}
+
+extern "C" size_t snap_sim_split_workspace_bytes(int32_t B, int32_t Nq, int32_t XY, int32_t Dm,
+                                                 int32_t parts) {
+  if (B <= 0 || Nq <= 0 || XY <= 0 || Dm <= 0 || parts < 2 || parts > 3) return 0;
+  return ((size_t)B * Nq + (size_t)B * XY) * parts * Dm * sizeof(__bf16);
+}
+
+extern "C" int snap_sim_softmax_split_f32(const float* fq, const float* fm, int32_t B, int32_t Nq,
+                                          int32_t XY, int32_t Dm, float scale, int32_t clip_negative,
+                                          const float* num_valid, const float* row_weight,
+                                          int32_t parts, float* sim, float* chunk_stats,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!fq || !fm || !num_valid || !sim || !chunk_stats || !workspace) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || XY <= 0) return SNAP_ERR_BAD_SHAPE;
+  if ((Dm != 16 && Dm != 32 && Dm != 64) || (parts != 2 && parts != 3)) return SNAP_ERR_UNSUPPORTED;
+  if (workspace_bytes < snap_sim_split_workspace_bytes(B, Nq, XY, Dm, parts)) return SNAP_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return SNAP_ERR_BAD_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  __bf16* fqs = static_cast<__bf16*>(workspace);
+  __bf16* fms = fqs + (size_t)B * Nq * parts * Dm;
+  const int64_t nq = (int64_t)B * Nq * Dm, nm = (int64_t)B * XY * Dm;
+  if (parts == 3) {
+    hipLaunchKernelGGL(sim_presplit_kernel<3>, dim3((unsigned)snap_cdiv(nq, 256)), dim3(256), 0, s, fq, nq, Dm, fqs);
+    hipLaunchKernelGGL(sim_presplit_kernel<3>, dim3((unsigned)snap_cdiv(nm, 256)), dim3(256), 0, s, fm, nm, Dm, fms);
+  } else {
+    hipLaunchKernelGGL(sim_presplit_kernel<2>, dim3((unsigned)snap_cdiv(nq, 256)), dim3(256), 0, s, fq, nq, Dm, fqs);
+    hipLaunchKernelGGL(sim_presplit_kernel<2>, dim3((unsigned)snap_cdiv(nm, 256)), dim3(256), 0, s, fm, nm, Dm, fms);
+  }
+  SNAP_CHECK_LAUNCH();
+  const dim3 grid((unsigned)snap_cdiv(XY, 256), (unsigned)snap_cdiv(Nq, SIM_TQ), (unsigned)B);
+#define SNAP_SIM_SPLIT_CASE(D, P)                                                                  \
+  hipLaunchKernelGGL((sim_split_kernel<D, P>), grid, dim3(256), 0, s, (const __bf16*)fqs,          \
+                     (const __bf16*)fms, Nq, XY, scale, clip_negative, num_valid, sim, chunk_stats, \
+                     row_weight)
+  if (parts == 3) {
+    if (Dm == 16) SNAP_SIM_SPLIT_CASE(16, 3); else if (Dm == 32) SNAP_SIM_SPLIT_CASE(32, 3); else SNAP_SIM_SPLIT_CASE(64, 3);
+  } else {
+    if (Dm == 16) SNAP_SIM_SPLIT_CASE(16, 2); else if (Dm == 32) SNAP_SIM_SPLIT_CASE(32, 2); else SNAP_SIM_SPLIT_CASE(64, 2);
+  }
+#undef SNAP_SIM_SPLIT_CASE
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
 }
 
 extern "C" int snap_ransac_sample_f32(const float* fq, const float* fm, const float* chunk_stats,

@@ -841,10 +841,13 @@ def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None,
 # pose
 # ----------------------------------------------------------------------------
 def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
-                want_rowstats=False, row_weight=None):
+                want_rowstats=False, row_weight=None, math=None):
   """fq [B,Nq,Dm], fm [B,X,Y,Dm], num_valid [B] float ->
   sim [B,Nq,X,Y], chunk_stats [B,Nq,NC,2], (prob), (rowstats).  row_weight [B,Nq]: per-point
-  confidence weights that replace the 1 / num_valid normalisation (add_confidence_query)."""
+  confidence weights that replace the 1 / num_valid normalisation (add_confidence_query).
+  math: 'f32' -- the contraction as the exact k-ordered fmaf chain (f32 MFMA); 'bf16x6' / 'bf16x3'
+  -- on the bf16 matrix cores with 3 / 2-part split operands (f32 grade / ~2^-17 per product).
+  None: 'f32' while ``MATMUL_PRECISION`` is 'f32', else 'bf16x6'."""
   lib = _lib.load()
   _f32(fq, 'fq'); _f32(fm, 'fm'); _f32(num_valid, 'num_valid')
   if row_weight is not None:
@@ -863,6 +866,19 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
       torch.empty((B, Nq, 2), dtype=torch.float32, device=dev)
       if (want_prob or want_rowstats) else None
   )
+  if math is None:
+    math = 'f32' if MATMUL_PRECISION == 'f32' else 'bf16x6'
+  parts = SPLIT_PARTS.get(math, 0)
+  if parts and not (want_prob or want_rowstats) and Dm in (16, 32, 64):
+    wsb = lib.snap_sim_split_workspace_bytes(B, Nq, XY, Dm, parts)
+    ws = torch.empty(wsb // 2, dtype=torch.bfloat16, device=dev)
+    with _region('sim_softmax', 2.0 * B * Nq * XY * Dm,
+                 4.0 * (fq.numel() + fm.numel() + sim.numel() + stats.numel())):
+      st = lib.snap_sim_softmax_split_f32(
+          _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(clip_negative), _p(num_valid),
+          _p(row_weight), parts, _p(sim), _p(stats), _p(ws), wsb, _stream())
+    _lib.check(st, 'snap_sim_softmax_split_f32')
+    return sim, stats, None, None
   with _region(
       'sim_softmax', 2.0 * B * Nq * XY * Dm,
       4.0 * (fq.numel() + fm.numel() + sim.numel() + stats.numel()),

@@ -260,7 +260,7 @@ def _raw_sim(fq, fm, scale, clip):
 
 
 def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
-                want_rowstats=False, row_weight=None):
+                want_rowstats=False, row_weight=None, math=None):
   q, m = _np(fq, DTYPE), _np(fm, DTYPE)
   nv = _np(num_valid, DTYPE)[:, None, None, None]
   if row_weight is not None:      # confidence weights replace 1 / num_valid (bev_localizer.py:165-172)

@@ -803,6 +803,30 @@ def test_sim_softmax_mfma_kernel_keeps_the_valu_kernels_bits(Dm, monkeypatch):
     assert torch.allclose(st_m[..., 1], st_v[..., 1], rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize('math,tol', [('bf16x6', 2e-6), ('bf16x3', 6e-5)])
+@pytest.mark.parametrize('X,Y,Dm,Nq', [(16, 16, 32, 70), (27, 23, 16, 150), (40, 24, 64, 33)])
+def test_sim_softmax_split_bf16(X, Y, Dm, Nq, math, tol):
+  """The contraction on the bf16 matrix cores with split operands: vs the oracle and vs the exact
+  f32 kernel (bf16x6 keeps 24 significand bits per operand: the difference to the f32 chain is
+  rounding-order level), incl. ragged tiles, a zero query row, confidence weights."""
+  B = 2
+  fq = _unit(rnd((B, Nq, Dm), 290))
+  fm = _unit(rnd((B, X, Y, Dm), 291))
+  fq[0, 3] = 0
+  nv = torch.tensor([float(Nq - 1), float(Nq)])
+  scale = float(np.exp(2.0))
+  got, want = both('sim_softmax', (fq, fm, scale, True, nv), dict(math=math))
+  helpers.report(f'sim {math}', got[0], want[0], atol=tol / 10, rtol=tol)
+  helpers.report(f'chunk max {math}', got[1][..., 0], want[1][..., 0], atol=tol * 10, rtol=tol)
+  helpers.report(f'chunk sum {math}', got[1][..., 1], want[1][..., 1], atol=1e-3, rtol=10 * tol)
+  exact = ops.sim_softmax(fq.to(DEV), fm.to(DEV), scale, True, nv.to(DEV), math='f32')
+  assert float((got[0] - exact[0]).abs().max()) <= tol * float(exact[0].abs().max())
+  w = torch.rand(B, Nq, generator=torch.Generator().manual_seed(5)) + 0.1
+  w = (w / w.sum(-1, keepdim=True)).contiguous()
+  gw, ww = both('sim_softmax', (fq, fm, scale, False, nv), dict(math=math, row_weight=w))
+  helpers.report(f'weighted sim {math}', gw[0], ww[0], atol=tol / 10, rtol=tol)
+
+
 def test_ransac_sample_given_uniforms():
   B, Nq, X, Y, Dm, S = 2, 40, 24, 20, 16, 600
   fq = _unit(rnd((B, Nq, Dm), 95))
