@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(const float* __restri
   for (int c = cb; c < ce; ++c) M = fmaxf(M, st[2 * c]);
   M = wave_max(M);
   float local = 0.f;
-  for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
+  for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * __expf(st[2 * c] - M);
   lane_incl[row * 64 + lane] = wave_scan_incl(local, lane);
   if (lane == 0) rowmax[row] = M;
 }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     M = -INFINITY;
     for (int c = cb; c < ce; ++c) M = fmaxf(M, st[2 * c]);
     M = wave_max(M);
-    for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
+    for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * __expf(st[2 * c] - M);
     incl = wave_scan_incl(local, lane);
   }
   const float total = __shfl(incl, 63, 64);
@@ -600,17 +600,17 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
   float resid = 0.f;
   if (lane == L) {
     if (table)                   // only the selected lane re-evaluates its own chunk masses
-      for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * expf(st[2 * c] - M);
+      for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * __expf(st[2 * c] - M);
     float run = incl - local;
     cstar = ce - 1;
     resid = 0.f;
     bool found = false;
     for (int c = cb; c < ce; ++c) {
-      const float wgt = st[2 * c + 1] * expf(st[2 * c] - M);
+      const float wgt = st[2 * c + 1] * __expf(st[2 * c] - M);
       if (!found && run + wgt > target) {
         cstar = c;
         // residual expressed relative to the chunk's own max
-        resid = (target - run) / expf(st[2 * c] - M);
+        resid = (target - run) / __expf(st[2 * c] - M);
         found = true;
       }
       run += wgt;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     // (x = sim * num_valid, or sim / weight, to within one rounding) instead of re-evaluating 64
     // dot products from 8 KB of map features -- the sampler was bound by that L2 traffic
     // (10.8 GB per C2 step, 1.75 ms)
-    e = expf(sim[row * (int64_t)XY + cell] * row_unscale[row] - mc);
+    e = __expf(sim[row * (int64_t)XY + cell] * row_unscale[row] - mc);
   } else if (cvalid) {
     const f32x4* mp = reinterpret_cast<const f32x4*>(fm + ((int64_t)b * XY + cell) * DM);
     const f32x4* qp = reinterpret_cast<const f32x4*>(fq + row * DM);
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     }
     float x = clip ? fmaxf(dot, 0.f) : dot;
     x *= scale;
-    e = expf(x - mc);
+    e = __expf(x - mc);
   }
   const float ci = wave_scan_incl(e, lane);
   unsigned long long b2 = __ballot(cvalid && ci > resid);
