@@ -359,6 +359,21 @@ int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_images,
                        const float* cam, const float* Rt, const float* points,
                        float* pooled, uint8_t* valid, void* stream);
 
+/* depth_mlp fusion (streetview_encoder.py:263-267; do_weighted_fusion = False, so desc->weighted
+ * = 0 and C = feature_dim): the lift in two passes around a per-observation MLP.
+ *   observations: obs [B, N, S, fd + 4] = bilinear features | log10(clip(depth, 0.1, 100)) |
+ *     unit ray in the camera frame (zero where the view does not see the point), S = K (top-K
+ *     order) or V (view order); obs_feat [B, N, S, fd] = the features alone (the residual the
+ *     caller adds the MLP output to); valid [B, N] as snap_lift_pool_f32.
+ *   pool: pool_multiview_features(obs_feat', visible, scores = None, add_minmax, use_variance)
+ *     of the corrected observations obs_feat' [B, N, S, fd] -> pooled [B, N, out_stride], valid. */
+int snap_lift_observations_f32(const SnapLiftDesc* desc, const float* f_images, const float* cam,
+                               const float* Rt, const float* points, float* obs, float* obs_feat,
+                               uint8_t* valid, void* stream);
+int snap_lift_pool_observations_f32(const SnapLiftDesc* desc, const float* cam, const float* Rt,
+                                    const float* points, const float* obs_feat, float* pooled,
+                                    uint8_t* valid, void* stream);
+
 /* Debug/parity variant of k1: p2d[B,N,V,2] (ij), vis[B,N,V], depth[B,N,V]. */
 int snap_project_points_f32(int32_t B, int32_t V, int32_t N, int32_t fisheye,
                             const float* cam, const float* Rt,

@@ -188,7 +188,6 @@ def streetview_encoder(params, config, data):
   pred = {'image_feature_pyramid': f_image_pyr}
 
   weighted = bool(config['do_weighted_fusion'])
-  assert weighted or config.get('depth_mlp') is None, 'depth_mlp fusion is not restated'
   if weighted:
     proj_config = dict(
         layers=(config['feature_dim'] + config['num_scale_bins'],),
@@ -224,6 +223,12 @@ def streetview_encoder(params, config, data):
     )
   else:
     scores_proj = None      # streetview_encoder.py:261-262
+    if config.get('depth_mlp') is not None:
+      # streetview_encoder.py:263-267: a per-observation MLP on [features, log10 depth, ray]
+      log_depth = np.log10(np.clip(depth, 0.1, 100)).astype(dtype)
+      rays_v = np.where(visible[..., None], rays, 0).astype(dtype)
+      f_proj_depth = np.concatenate([f_proj, log_depth[..., None], rays_v], -1)
+      f_proj = f_proj + encoder.mlp(params['depth_mlp'], config['depth_mlp'], f_proj_depth)
   f_pooled, valid = pool_multiview_features(
       f_proj,
       visible,

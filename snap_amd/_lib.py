@@ -117,6 +117,8 @@ SIGNATURES = {
     'snap_lift_pool_f32': (
         c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]
     ),
+    'snap_lift_observations_f32': (c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
+    'snap_lift_pool_observations_f32': (c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
     'snap_project_points_f32': (
         c_int, [c_int, c_int, c_int, c_int, ptr, ptr, ptr, ptr, ptr, ptr, ptr]
     ),
@@ -242,7 +244,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 

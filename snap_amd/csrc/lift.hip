@@ -36,6 +36,10 @@ struct LiftArgs {
   const float* pts;
   float* pooled;
   uint8_t* valid;
+  // depth_mlp fusion (streetview_encoder.py:263-267), generic kernel only:
+  float* obs_out;        // [B*N, nsel, fd + 4]: per-observation features | log10 depth | ray(3)
+  float* obs_feat;       // [B*N, nsel, fd]: the features alone (the MLP's residual operand)
+  const float* obs_in;   // [B*N, nsel, fd]: observations to pool instead of gathering them
 };
 
 struct Proj {
@@ -43,6 +47,7 @@ struct Proj {
   float depth;
   float dist;     // distance voxel -> camera centre
   bool vis;
+  float vx, vy;   // camera-frame x, y (z = depth): the viewing ray of the observation
 };
 
 // One (voxel, view) projection.  cam = wh f c k(3) max_fov pad; Rt = R(9) t(3).
@@ -59,6 +64,8 @@ __device__ __forceinline__ Proj project_one(const float* __restrict__ cam,
     pv[i] = tinv + ((r0 * px + r1 * py) + r2 * pz);
   }
   Proj o;
+  o.vx = pv[0];
+  o.vy = pv[1];
   o.depth = pv[2];
   bool valid = pv[2] >= eps;
   const float z = fmaxf(pv[2], eps);
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
 
   // ---- k1: lane v projects into view v -----------------------------------
   Proj pr;
-  pr.pi = pr.pj = pr.depth = 0.f;
+  pr.pi = pr.pj = pr.depth = pr.vx = pr.vy = 0.f;
   pr.dist = INFINITY;
   pr.vis = false;
   if (hl < d.V) {
@@ -293,8 +300,25 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
     const float depth = __shfl(pr.depth, v, 32);
     const bool vis = __shfl((int)pr.vis, v, 32) != 0;
     ok[r] = vis;
+    if (a.obs_out) {
+      // depth_mlp input: log10(clip(depth, 0.1, 100)) and the unit viewing ray in the camera
+      // frame, zero where the view does not see the point (streetview_encoder.py:264-266)
+      const float vx = __shfl(pr.vx, v, 32), vy = __shfl(pr.vy, v, 32);
+      if (hl == 0) {
+        const float nrm = fmaxf(sqrtf((vx * vx + vy * vy) + depth * depth), 1e-5f);
+        float* o = a.obs_out + (gv * nsel + r) * (int64_t)(fd + 4) + fd;
+        o[0] = log10f(fminf(fmaxf(depth, 0.1f), 100.f));
+        o[1] = vis ? vx / nrm : 0.f;
+        o[2] = vis ? vy / nrm : 0.f;
+        o[3] = vis ? depth / nrm : 0.f;
+      }
+    }
     if (!vis) continue;  // half-wave uniform
     any = true;
+    if (a.obs_in) {        // pooling pass of the depth_mlp fusion: the observation is given
+      if (hl < nq) feat[r] = *reinterpret_cast<const f32x4*>(a.obs_in + (gv * nsel + r) * (int64_t)fd + 4 * hl);
+      continue;
+    }
     const Taps t = make_taps(pi, pj, d.h, d.w, all_views ? 0 : 1);
     const float* img = a.f + ((int64_t)b * d.V + v) * d.h * d.w * d.C;
     const float* r00 = img + ((int64_t)t.i0 * d.w + t.j0) * d.C;
@@ -326,6 +350,20 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
     score[r] = wb0 * s0 + wb1 * s1;
   }
 
+  if (a.obs_out) {         // gathering pass of the depth_mlp fusion: observations out, no pooling
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      if (r >= nsel || hl >= nq) continue;
+      *reinterpret_cast<f32x4*>(a.obs_out + (gv * nsel + r) * (int64_t)(fd + 4) + 4 * hl) = feat[r];
+      *reinterpret_cast<f32x4*>(a.obs_feat + (gv * nsel + r) * (int64_t)fd + 4 * hl) = feat[r];
+    }
+    if (hl == 0) {
+      bool vld = any;
+      if (d.max_view_distance >= 0.f && !all_views) vld = vld && (min_dist <= d.max_view_distance);
+      a.valid[gv] = vld ? 1 : 0;
+    }
+    return;
+  }
   // ---- k5: softmax-weighted mean / variance / max score ---------------------
   float* out = a.pooled + gv * d.out_stride;
   if (!(d.weighted && d.use_variance && !d.add_minmax)) {      // non-default fusion options
@@ -722,7 +760,7 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
     const char* e = getenv("SNAP_LIFT_XCD_GROUP");
     return e ? atoi(e) : 64;
   }();
-  LiftArgs a{xcd_group, 0, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid};
+  LiftArgs a{xcd_group, 0, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr};
   const int64_t total = (int64_t)d.B * d.N;
   if (total > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   if (d.grid_y < 0 || d.grid_z < 0 || (d.grid_y > 0) != (d.grid_z > 0)) return SNAP_ERR_BAD_SHAPE;
@@ -765,6 +803,48 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   }
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
+}
+
+// depth_mlp fusion (streetview_encoder.py:263-267, do_weighted_fusion = False): the observations
+// leave the lift un-pooled, a per-observation MLP corrects them, a second pass pools them.
+static int launch_obs(const SnapLiftDesc& d, const float* f_images, const float* cam, const float* Rt,
+                      const float* points, float* pooled, uint8_t* valid, float* obs_out,
+                      float* obs_feat, const float* obs_in, hipStream_t s) {
+  if (d.B <= 0 || d.V <= 0 || d.V > 32 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.weighted || d.out_split || d.valid_rows_only) return SNAP_ERR_UNSUPPORTED;
+  if (d.feature_dim <= 0 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.C != d.feature_dim)
+    return SNAP_ERR_BAD_SHAPE;
+  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  if ((int64_t)d.B * d.N > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  const int nsel = d.K == 0 ? d.V : d.K;
+  if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
+  LiftArgs a{0, 0, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, obs_out, obs_feat, obs_in};
+  const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
+  if (nsel <= 1) hipLaunchKernelGGL(lift_pool_kernel<1>, grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL(lift_pool_kernel<4>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(lift_pool_kernel<8>, grid, dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_lift_observations_f32(const SnapLiftDesc* desc, const float* f_images,
+                                          const float* cam, const float* Rt, const float* points,
+                                          float* obs, float* obs_feat, uint8_t* valid, void* stream) {
+  if (!desc || !f_images || !cam || !Rt || !points || !obs || !obs_feat || !valid) return SNAP_ERR_NULL;
+  return launch_obs(*desc, f_images, cam, Rt, points, nullptr, valid, obs, obs_feat, nullptr,
+                    static_cast<hipStream_t>(stream));
+}
+
+extern "C" int snap_lift_pool_observations_f32(const SnapLiftDesc* desc, const float* cam,
+                                               const float* Rt, const float* points,
+                                               const float* obs_feat, float* pooled, uint8_t* valid,
+                                               void* stream) {
+  if (!desc || !cam || !Rt || !points || !obs_feat || !pooled || !valid) return SNAP_ERR_NULL;
+  const SnapLiftDesc& d = *desc;
+  const int chans = d.feature_dim * (1 + (d.use_variance ? 1 : 0) + (d.add_minmax ? 2 : 0));
+  if (d.out_stride < chans || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  return launch_obs(d, obs_feat /* (never read) */, cam, Rt, points, pooled, valid, nullptr, nullptr,
+                    obs_feat, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int snap_project_points_f32(int32_t B, int32_t V, int32_t N, int32_t fisheye,

@@ -28,8 +28,6 @@ class StreetViewEncoder(base.Module):
           'pretrained_path: Flax checkpoint loading is out of scope '
           '(and broken in the reference, streetview_encoder.py:189).'
       )
-    if not config.do_weighted_fusion and config.depth_mlp is not None:
-      raise NotImplementedError('depth_mlp fusion (a per-observation MLP, streetview_encoder.py:263-267)')
     self.config = config
     self.image_encoder = image_encoder.ImageEncoder(config.image_encoder, dtype)
     fd = config.feature_dim
@@ -47,11 +45,20 @@ class StreetViewEncoder(base.Module):
     elif config.image_encoder.output_dim != fd:
       raise ValueError('do_weighted_fusion=False: the image features are pooled as they are, '
                        'image_encoder.output_dim must equal feature_dim')
+    # per-observation correction MLP on [features, log10 depth, viewing ray]
+    # (streetview_encoder.py:214-216, 263-267; only without the weighted fusion)
+    self.depth_mlp = None
+    if not self.weighted and config.depth_mlp is not None:
+      if tuple(config.depth_mlp.layers)[-1] != fd:
+        raise ValueError('depth_mlp must map back to feature_dim (its output is added to the features)')
+      self.depth_mlp = layers.MLP(config.depth_mlp, in_dim=fd + 4)
 
   def init_params(self, gen, device):
     params = {'image_encoder': self.image_encoder.init_params(gen, device)}
     if self.proj_mlp is not None:
       params['proj_mlp'] = self.proj_mlp.init_params(gen, device)
+    if self.depth_mlp is not None:
+      params['depth_mlp'] = self.depth_mlp.init_params(gen, device)
     params['fusion_mlp'] = self.fusion_mlp.init_params(gen, device)
     return params
 
@@ -127,10 +134,13 @@ class StreetViewEncoder(base.Module):
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))
-    pooled, valid = lift(
-        f_images, cameras.packed().to(torch.float32),
-        scene_t_view.packed().to(torch.float32), xyz_flat, **kw,
-    )
+    if self.depth_mlp is not None:
+      pooled, valid = self._lift_with_depth_mlp(params, f_images, cameras, scene_t_view, xyz_flat, K, train)
+    else:
+      pooled, valid = lift(
+          f_images, cameras.packed().to(torch.float32),
+          scene_t_view.packed().to(torch.float32), xyz_flat, **kw,
+      )
     grid_shape = (-1, *xyz.shape[-4:-1])
     if fused:
       p = params['fusion_mlp']
@@ -149,5 +159,29 @@ class StreetViewEncoder(base.Module):
     valid = valid.reshape(grid_shape)
     pred['feature_volume'] = types.FeatureVolume(features=f_grid, valid=valid)
     return pred
+
+  def _lift_with_depth_mlp(self, params, f_images, cameras, scene_t_view, xyz_flat, K, train):
+    """streetview_encoder.py:263-267: the observations leave the lift un-pooled
+    (ops.lift_observations), a per-observation MLP on [features, log10 depth, ray] is added to
+    them (conv engine, residual epilogue), a second pass pools them (ops.lift_pool_observations)."""
+    cfg = self.config
+    p = params['depth_mlp']
+    n = len(cfg.depth_mlp.layers)
+    if base.needs_grad(f_images, *(p[f'Dense_{i}'][k] for i in range(n) for k in ('kernel', 'bias'))):
+      raise NotImplementedError('depth_mlp fusion has no backward kernels yet')
+    cam, Rt = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
+    common = dict(K=K, fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
+                  max_view_distance=cfg.get('max_view_distance'))
+    obs, feat, _ = ops.lift_observations(f_images, cam, Rt, xyz_flat, **common)
+    h = obs
+    for i in range(n):
+      d = p[f'Dense_{i}']
+      pro = ops.PRO_RELU if (i == 0 and cfg.depth_mlp.apply_input_activation) else ops.PRO_NONE
+      last = i + 1 == n
+      h = ops.dense(h, d['kernel'], d['bias'], cin=d['kernel'].shape[0], prologue=pro,
+                    relu=not last, residual=feat if last else None)
+    return ops.lift_pool_observations(
+        h, tuple(f_images.shape), cam, Rt, xyz_flat, use_variance=bool(cfg.fusion_use_variance),
+        add_minmax=bool(cfg.fusion_add_minmax), **common)
 
   default_config = staticmethod(default_configs.streetview_encoder)

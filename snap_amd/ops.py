@@ -741,6 +741,54 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   return pooled, valid
 
 
+def _obs_desc(f_shape, N, K, fisheye, feature_dim, max_view_distance, use_variance, add_minmax, stride):
+  B, V, h, w, C = f_shape
+  return _lib.SnapLiftDesc(
+      B, V, h, w, C, feature_dim, 0, N, K, int(fisheye), stride, 1.0, 2.0,
+      -1.0 if max_view_distance is None else float(max_view_distance),
+      0, int(use_variance), int(add_minmax))
+
+
+def lift_observations(f_images, cam, Rt, points, *, K, fisheye, feature_dim, max_view_distance=None):
+  """First pass of the depth_mlp fusion (streetview_encoder.py:263-267): per-observation features,
+  un-pooled.  f_images [B,V,h,w,fd] -> obs [B,N,S,fd+4] (features | log10 depth | unit ray),
+  obs_feat [B,N,S,fd], valid [B,N]; S = K (top-K order) or V."""
+  lib = _lib.load()
+  _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
+  B, V, h, w, C = f_images.shape
+  if C != feature_dim:
+    raise ValueError('lift_observations: f_images must carry feature_dim channels')
+  N = points.shape[1]
+  S = K if K else V
+  obs = torch.empty((B, N, S, feature_dim + 4), dtype=torch.float32, device=f_images.device)
+  feat = torch.empty((B, N, S, feature_dim), dtype=torch.float32, device=f_images.device)
+  valid = torch.empty((B, N), dtype=torch.bool, device=f_images.device)
+  d = _obs_desc(f_images.shape, N, K, fisheye, feature_dim, max_view_distance, True, False, 0)
+  with _region('lift_pool', 0.0, 4.0 * (f_images.numel() + obs.numel() + feat.numel())):
+    st = lib.snap_lift_observations_f32(ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points),
+                                        _p(obs), _p(feat), _p(valid), _stream())
+  _lib.check(st, 'snap_lift_observations_f32')
+  return obs, feat, valid
+
+
+def lift_pool_observations(obs_feat, f_shape, cam, Rt, points, *, K, fisheye, feature_dim,
+                           max_view_distance=None, use_variance=True, add_minmax=False):
+  """Second pass: pool_multiview_features(obs_feat, visible, None, add_minmax, use_variance)
+  (streetview_encoder.py:141-178) -> pooled [B,N,stride], valid [B,N]."""
+  lib = _lib.load()
+  _f32(obs_feat, 'obs_feat'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
+  B, N = points.shape[:2]
+  stride = pooled_stride(feature_dim, False, use_variance, add_minmax)
+  pooled = torch.empty((B, N, stride), dtype=torch.float32, device=obs_feat.device)
+  valid = torch.empty((B, N), dtype=torch.bool, device=obs_feat.device)
+  d = _obs_desc(f_shape, N, K, fisheye, feature_dim, max_view_distance, use_variance, add_minmax, stride)
+  with _region('lift_pool', 0.0, 4.0 * (obs_feat.numel() + pooled.numel())):
+    st = lib.snap_lift_pool_observations_f32(ctypes.byref(d), _p(cam), _p(Rt), _p(points),
+                                             _p(obs_feat), _p(pooled), _p(valid), _stream())
+  _lib.check(st, 'snap_lift_pool_observations_f32')
+  return pooled, valid
+
+
 def project_points(cam, Rt, points, fisheye):
   lib = _lib.load()
   _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')

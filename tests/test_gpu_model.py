@@ -161,6 +161,32 @@ def test_unweighted_minmax_fusion_parity():
                              got_index=pred['best_index'])
 
 
+@pytest.mark.parametrize('top_k,V', [(2, 3), (4, 3)])
+def test_depth_mlp_fusion_parity(top_k, V):
+  """do_weighted_fusion=False + depth_mlp (streetview_encoder.py:214-216, 263-267): the
+  observations leave the lift un-pooled, a per-observation MLP on [features, log10 depth, viewing
+  ray] is added to them, then the plain mean / variance pooling.  Top-K (V > K) and all-views
+  branches."""
+  from snap_amd.configs import defaults
+  cfg = helpers.tiny_localizer_config(top_k=top_k)
+  sv = cfg.bev_mapper.streetview_encoder
+  sv.do_weighted_fusion = False
+  dm = defaults.mlp()
+  dm.layers = (24, sv.feature_dim)
+  sv.depth_mlp = dm
+  pred, ref, ob, _ = _run(cfg, 2, V, (64, 64), seed=12, want_batch=True)
+  _check_validity('map voxel validity', pred['map'], ref['map'], ob['map'], cfg)
+  vol, rvol = pred['map']['streetview']['feature_volume'], ref['map']['streetview']['feature_volume']
+  both = vol.valid.cpu().numpy() == rvol['valid']
+  helpers.report('feature volume (depth_mlp)', vol.features.cpu().numpy()[both], rvol['features'][both],
+                 atol=1e-3)
+  helpers.report('map bev_matching', pred['map']['bev_matching'].features,
+                 ref['map']['bev_matching']['features'], atol=1e-3)
+  helpers.report('scores_poses', pred['scores_poses'], ref['scores_poses'], atol=1e-3, rtol=1e-3)
+  helpers.assert_same_argmax('best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                             got_index=pred['best_index'])
+
+
 def test_localizer_grid_refinement_parity():
   cfg = helpers.tiny_localizer_config(refine=True, num_pose_samples=32)
   pred, ref = _run(cfg, 1, 3, (64, 64), seed=3)
