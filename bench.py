@@ -323,8 +323,8 @@ def cpu_baseline(cfg, meta, workload, budget_s=40.0):
 def main(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
   ap.add_argument('--device', default='cuda')
   ap.add_argument('--no-cpu-baseline', action='store_true')
