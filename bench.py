@@ -332,7 +332,7 @@ def main(argv=None):
                   help='testing only: override the process-group backend (default nccl = RCCL)')
   ap.add_argument('--share-gpu', action='store_true',
                   help='testing only: every rank uses GPU 0 (multi-process plumbing check on a 1-GPU box)')
-  ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+  ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16x3', 'bf16x6'],
                   help="train mode only: 'bf16' rounds the conv / dense operands to bf16 (f32 "
                        "accumulate) -- the analogue of the reference's float16 train config; the "
                        "inference headline always runs the exact f32 path")
@@ -470,6 +470,7 @@ def main(argv=None):
         'dtype': ('bf16 ViT GEMMs + attention (f32 accumulate), f32 elsewhere' if WORKLOADS[args.workload].get('vit')
                   else INFER_DTYPE[args.math] if args.mode == 'infer'
                   else 'f32' if args.precision == 'f32'
+                  else INFER_DTYPE[args.precision] + '; kernel gradients on the exact f32 engine' if args.precision in INFER_DTYPE
                   else 'bf16 GEMM operands, f32 accumulate / parameters / optimizer'),
         'data': 'synthetic',
         'config': {

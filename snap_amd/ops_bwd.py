@@ -32,6 +32,8 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   rows_z / rows_dy / row_count: row lists over flat [1,1,M,C] operands (masked MLP).
   math: 'f32' | 'bf16' (None = ``ops.MATMUL_PRECISION``), as ``ops.conv2d``."""
   math = ops.MATMUL_PRECISION if math is None else math
+  if math in ops.SPLIT_PARTS:
+    math = 'f32'         # the split engine has no weight-gradient kernel: exact f32 (trainer 'bf16x3')
   if math not in ('f32', 'bf16'):
     raise ValueError(f'conv2d_wgrad: math={math!r}')
   lib = _lib.load()

@@ -167,7 +167,7 @@ def test_bf16_training_precision_tracks_f32():
   pose_samples = geometry.Transform2D(s.angle[:, 1:].contiguous(), s.t[:, 1:].contiguous())
   leaves = dict(trainer.flatten_params(params))
   out = {}
-  for precision in ('f32', 'bf16'):
+  for precision in ('f32', 'bf16', 'bf16x3'):
     for t in leaves.values():
       t.requires_grad_(True)
     ops.MATMUL_PRECISION = precision
@@ -180,6 +180,11 @@ def test_bf16_training_precision_tracks_f32():
       t.requires_grad_(False)
     out[precision] = (float(loss), torch.cat([g.reshape(-1) for g in grads]))
   (l32, g32), (l16, g16) = out['f32'], out['bf16']
+  # 'bf16x3': forward / data gradients on the f32-grade split engine, kernel gradients exact
+  lx3, gx3 = out['bf16x3']
+  assert abs(lx3 - l32) <= 2e-4 * abs(l32) + 1e-5, (l32, lx3)
+  cos3 = float(torch.dot(g32, gx3) / (g32.norm() * gx3.norm()))
+  assert cos3 > 0.9995 and 0.99 < float(gx3.norm() / g32.norm()) < 1.01, cos3
   assert l32 != l16                                   # the bf16 engines really ran
   assert abs(l16 - l32) <= 2e-2 * abs(l32) + 1e-3, (l32, l16)
   cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
