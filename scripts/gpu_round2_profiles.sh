@@ -53,6 +53,7 @@ timeout 400 python tools/fullsize_parity.py --math bf16x3+plane --eval --out $O/
 # 7. training step (C3) and the ViT workload (C5)
 timeout 300 python bench.py --mode train --workload c3 --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/r02_c3_train_bench.json
 timeout 300 python bench.py --mode train --workload c3 --precision bf16 --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/r02_c3_train_bf16_bench.json
+timeout 300 python bench.py --mode train --workload c3 --precision bf16x3 --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/r02_c3_train_bf16x3_bench.json
 timeout 300 python bench.py --workload c5 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/r02_c5_vit_bench.json
 rm -rf $O/prof $O/prof_c4 $O/pmcs1 $O/pmcs2 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 ls -la $O
