@@ -587,7 +587,8 @@ _WSTD_ITEM = np.dtype([('w', '<u8'), ('dws', '<u8'), ('out', '<u8'), ('K', '<i4'
                        ('block_begin', '<i4'), ('reserved', '<i4')])   # == SnapWstdItem
 
 
-def _wstd_table(ws, dwss, outs):
+def _wstd_table(ws, dwss, outs, cols=8):
+  """cols: output columns per workgroup of the kernel the table is for (forward 32, backward 8)."""
   items = np.zeros(len(ws), dtype=_WSTD_ITEM)
   blk = 0
   for i, w in enumerate(ws):
@@ -595,7 +596,7 @@ def _wstd_table(ws, dwss, outs):
     K = w.shape[0] * w.shape[1] * w.shape[2]
     items[i] = (w.data_ptr(), 0 if dwss is None else _f32(dwss[i], 'dws').data_ptr(),
                 outs[i].data_ptr(), K, w.shape[3], blk, 0)
-    blk += (w.shape[3] + 7) // 8
+    blk += (w.shape[3] + cols - 1) // cols
   table = torch.from_numpy(items.view(np.uint8).copy()).to(ws[0].device, non_blocking=True)
   return table, blk
 
@@ -604,7 +605,7 @@ def weight_standardize_multi(ws, eps=1e-10):
   """``weight_standardize`` of a list of HWIO kernels in ONE launch."""
   lib = _lib.load()
   outs = [torch.empty_like(w) for w in ws]
-  table, blocks = _wstd_table(ws, None, outs)
+  table, blocks = _wstd_table(ws, None, outs, cols=32)
   with _region('weight_standardize', 0.0, 16.0 * sum(w.numel() for w in ws)):
     st = lib.snap_weight_standardize_multi_f32(_p(table), len(ws), blocks, eps, _stream())
   _lib.check(st, 'snap_weight_standardize_multi_f32')
