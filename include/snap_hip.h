@@ -104,6 +104,10 @@ typedef struct SnapConvExtras {
   size_t w_bf16_bytes;
   int32_t w_split_parts;      /* 0: w_bf16 = rounded weights (training-precision engine);
                                  2 | 3: w_bf16 = split weights (f32-grade split-bf16 engine) */
+  int32_t w_split_root;       /* 1: the 7 x 7 / stride 2 / pad 3 root convolution (resnet.py:200-205)
+                                 of an RGB image stored with 4 floats per pixel (Cin = 3,
+                                 Cin_stride = 4): w_bf16 = snap_conv2d_pack_weights_split_root_bf16,
+                                 a K slab = 4 consecutive pixels of one kernel row */
 } SnapConvExtras;
 
 int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,
@@ -121,6 +125,10 @@ int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const floa
  * is still required (shapes the bf16 engine does not carry -- Cin < 4, unaligned channel
  * rows -- run on the exact f32 engine instead).  All fusions, row-indexed launches, GroupNorm
  * partial sums and split-K behave as on the f32 engine. */
+size_t snap_conv2d_packed_weights_split_root_bytes(int32_t Cout, int32_t parts);
+int snap_conv2d_pack_weights_split_root_bf16(const float* w /* [7,7,3,Cout] */, int32_t Cout,
+                                             int32_t parts, void* out, size_t out_bytes,
+                                             void* stream);
 size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, int32_t Cout);
 int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
                                   void* out, size_t out_bytes, void* stream);

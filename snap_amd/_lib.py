@@ -36,7 +36,7 @@ class SnapConvExtras(ctypes.Structure):
       ('rows_in', ptr), ('rows_out', ptr), ('row_count', ptr), ('gn_partial', ptr),
       ('gn_partial_bytes', c_size), ('gn_partial_relu', c_int),
       ('workspace', ptr), ('workspace_bytes', c_size),
-      ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int),
+      ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
   ]
 
 
@@ -90,6 +90,8 @@ SIGNATURES = {
     'snap_conv2d_packed_weights_bytes': (c_size, [c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_conv2d_packed_weights_split_bytes': (c_size, [c_int, c_int, c_int, c_int]),
+    'snap_conv2d_packed_weights_split_root_bytes': (c_size, [c_int, c_int]),
+    'snap_conv2d_pack_weights_split_root_bf16': (c_int, [ptr, c_int, c_int, ptr, c_size, ptr]),
     'snap_conv2d_pack_weights_split_bf16': (c_int, [ptr, c_int, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_conv2d_pack_weights_split_blocks': (c_int, [c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_split_multi_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr]),
@@ -244,7 +246,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 

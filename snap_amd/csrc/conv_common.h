@@ -49,6 +49,8 @@ int launch_bf16(ConvArgs a, hipStream_t s);
 // split-bf16 engine (conv_split.hip): `parts` = 2 (three products) or 3 (six products);
 // a.w_bf16 then holds [parts][Cout][taps][cin8]
 int launch_split(ConvArgs a, int parts, hipStream_t s);
+// ... the 7 x 7 / stride 2 root convolution of a 4-floats-per-pixel RGB image (root weight image)
+int launch_split_root(ConvArgs a, int parts, hipStream_t s);
 
 }  // namespace snapconv
 

@@ -673,6 +673,15 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   // loader's alignment; anything else runs on the (more precise) f32 engine below.
   a.w_bf16 = ex ? ex->w_bf16 : nullptr;
   a.cin8 = (d.Cin + 7) / 8 * 8;
+  if (a.w_bf16 && ex->w_split_root) {        // RGB root convolution on the split engine
+    const int parts = ex->w_split_parts;
+    if (ex->w_bf16_bytes < snap_conv2d_packed_weights_split_root_bytes(d.Cout, parts) ||
+        snap_conv2d_packed_weights_split_root_bytes(d.Cout, parts) == 0)
+      return SNAP_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(a.w_bf16) | reinterpret_cast<uintptr_t>(x)) & 15) return SNAP_ERR_BAD_SHAPE;
+    a.cin8 = 16;
+    return snapconv::launch_split_root(a, parts, s);
+  }
   if (a.w_bf16 && vec) {
     const int parts = ex->w_split_parts;
     if (parts < 0 || parts == 1 || parts > 3) return SNAP_ERR_UNSUPPORTED;

@@ -67,7 +67,13 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, u32x2 (&out)[NS]) {
 // vector-memory path moved per slab (they hit L1, but the path itself delivers 64 B/clk/CU).
 // TAIL: Cin is not a multiple of 4 (the 257-channel fusion MLP): the last channel quad needs a
 // per-element mask; otherwise one flag per 16-byte chunk does.
-template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL>
+// ROOT: the 7 x 7 / stride 2 / pad 3 root convolution of an RGB image stored with FOUR floats per
+// pixel (RGB + a zero): a K slab is then 4 consecutive pixels x 4 floats of one kernel row, i.e.
+// 16 CONTIGUOUS floats, and the kernel row's 7 taps are two slabs (kw = 0..3 and 4..7, tap 7 and
+// channel 3 carry zero weights: snap_conv2d_pack_weights_split_root_bf16).  The launch sets KW = 2
+// "virtual taps" per kernel row; a thread's quad IS one pixel, so bounds are per thread.  K = 14 x
+// 16 = 224 for 147 real products -- against Cin = 3 padded to a 16-k slab PER TAP (49 slabs).
+template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool ROOT = false>
 __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   constexpr int BK = 16;
   constexpr int TM = BM / 64;
@@ -162,10 +168,10 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   const float* tap_px[AROWS];
   bool tap_in[AROWS];
   auto set_tap = [&]() {
-    const int64_t delta = ((int64_t)kh * d.W + kw) * d.Cin_stride;
+    const int64_t delta = ((int64_t)kh * d.W + (ROOT ? 4 * kw : kw)) * d.Cin_stride;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int hi = r_hb[i] + kh, wi = r_wb[i] + kw;
+      const int hi = r_hb[i] + kh, wi = r_wb[i] + (ROOT ? 4 * kw + (tid % QPR) : kw);
       tap_in[i] = r_ok[i] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
       tap_px[i] = r_px[i] + delta;
     }
@@ -183,7 +189,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     if (ablate & 1) return;
     const int c = ct * BK + 4 * akq;
     cur_c = c;
-    const bool cvalid = c < d.Cin;
+    const bool cvalid = ROOT || c < d.Cin;
     if constexpr (need_gn && !gn_tab)
       xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
 #pragma unroll
@@ -693,6 +699,11 @@ __global__ __launch_bounds__(256, NS == 2 ? 4 : 3) void conv_split_kernel(const 
   conv_split_body<BM, BN, PRO, NS, GNT, TAIL>(a);
 }
 
+template <int BN, int PRO, int NS>
+__global__ __launch_bounds__(256, NS == 2 ? 4 : 3) void conv_split_root_kernel(const ConvArgs a) {
+  conv_split_body<128, BN, PRO, NS, false, false, true>(a);
+}
+
 template <int BM, int BN, int PRO, int NS>
 int launch(ConvArgs a, hipStream_t s) {
   constexpr int BK = 16;
@@ -832,7 +843,67 @@ __global__ __launch_bounds__(256) void pack_weights_split_multi_kernel(
                           rem % gx, rem / gx, t);
 }
 
+// w [7, 7, 3, Cout] f32 -> the ROOT image [column tile of 128][14 slabs = (kh, kw group of 4)][part]
+// [column][16 k], k = 4 (kw - 4 group) + channel; tap kw = 7 and channel 3 are zero
+__global__ __launch_bounds__(256) void pack_weights_split_root_kernel(const float* __restrict__ w,
+                                                                      __bf16* __restrict__ out,
+                                                                      int Cout, int cout128, int parts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;            // over [14 slabs][cout128][16 k]
+  if (i >= 14 * cout128 * 16) return;
+  const int k = i & 15;
+  const int n = (i >> 4) % cout128;
+  const int t = i / (16 * cout128);
+  const int kh = t >> 1, kw = 4 * (t & 1) + (k >> 2), c = k & 3;
+  float r = (kw < 7 && c < 3 && n < Cout) ? w[((kh * 7 + kw) * 3 + c) * Cout + n] : 0.f;
+  const int col = n & 127;
+  const int oct = (k >> 3) ^ ((col >> 3) & 1);
+  __bf16* o = out + ((int64_t)(n >> 7) * 14 + t) * ((int64_t)parts * 2048) + col * 16 + oct * 8 + (k & 7);
+  for (int p = 0; p < parts; ++p) {
+    const __bf16 b = (__bf16)r;
+    o[p * 2048] = b;
+    r -= (float)b;
+  }
+}
+
 }  // namespace
+
+namespace {
+template <int BN, int NS>
+int launch_root_pro(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  if (a.d.prologue == SNAP_PRO_AFFINE)
+    hipLaunchKernelGGL((conv_split_root_kernel<BN, SNAP_PRO_AFFINE, NS>), grid, dim3(256), 0, s, a);
+  else if (a.d.prologue == SNAP_PRO_NONE)
+    hipLaunchKernelGGL((conv_split_root_kernel<BN, SNAP_PRO_NONE, NS>), grid, dim3(256), 0, s, a);
+  else
+    return SNAP_ERR_UNSUPPORTED;
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+}  // namespace
+
+// 7 x 7 / stride 2 / pad 3 over x [N, H, W, 4] (Cin = 3), weights in the root image
+int snapconv::launch_split_root(ConvArgs a, int parts, hipStream_t s) {
+  const SnapConvDesc& d = a.d;
+  if (d.KH != 7 || d.KW != 7 || d.stride != 2 || d.pad_t != 3 || d.pad_l != 3 || d.Cin != 3 ||
+      d.Cin_stride != 4 || a.rows_in || a.rows_out || a.row_count || a.gn_partial)
+    return SNAP_ERR_UNSUPPORTED;
+  a.d.KW = 2;                      // two 4-pixel slabs per kernel row
+  a.ctiles = 1;
+  a.nk = 14;
+  a.ksplit = 1;
+  a.slabs_per_split = a.nk;
+  const bool wide = d.Cout > 64;
+  const int bn = wide ? 128 : 64;
+  a.ncol = (int)snap_cdiv(d.Cout, bn);
+  a.gn_slabs = (d.Ho * d.Wo) / 128 + 2;
+  const int64_t nblocks = snap_cdiv(snap_cdiv(a.M, 128), 8) * 8 * a.ncol;
+  if (nblocks > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  a.tiles_per_split = (int)nblocks;
+  const dim3 grid((unsigned)nblocks);
+  if (parts == 2) return wide ? launch_root_pro<128, 2>(a, grid, s) : launch_root_pro<64, 2>(a, grid, s);
+  if (parts == 3) return wide ? launch_root_pro<128, 3>(a, grid, s) : launch_root_pro<64, 3>(a, grid, s);
+  return SNAP_ERR_UNSUPPORTED;
+}
 
 int snapconv::launch_split(ConvArgs a, int parts, hipStream_t s) {
   if (parts == 2) return launch_tile<2>(a, s);
@@ -883,6 +954,26 @@ extern "C" int snap_conv2d_pack_weights_split_multi_bf16(const SnapPackItem* ite
   if (parts < 1 || parts > 3) return SNAP_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(pack_weights_split_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), items, n_items, parts);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" size_t snap_conv2d_packed_weights_split_root_bytes(int32_t Cout, int32_t parts) {
+  if (parts < 2 || parts > 3 || Cout <= 0) return 0;
+  return (size_t)parts * ((Cout + 127) / 128 * 128) * 14 * 16 * 2;
+}
+
+extern "C" int snap_conv2d_pack_weights_split_root_bf16(const float* w, int32_t Cout, int32_t parts,
+                                                        void* out, size_t out_bytes, void* stream) {
+  if (!w || !out) return SNAP_ERR_NULL;
+  const size_t need = snap_conv2d_packed_weights_split_root_bytes(Cout, parts);
+  if (need == 0) return SNAP_ERR_UNSUPPORTED;
+  if (out_bytes < need) return SNAP_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(out) & 15) return SNAP_ERR_BAD_SHAPE;
+  const int cout128 = (Cout + 127) / 128 * 128;
+  hipLaunchKernelGGL(pack_weights_split_root_kernel, dim3((unsigned)snap_cdiv(14 * cout128 * 16, 256)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), w, static_cast<__bf16*>(out),
+                     Cout, cout128, parts);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

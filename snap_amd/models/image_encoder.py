@@ -11,12 +11,14 @@ from snap_amd.models import types
 from snap_amd.models import vit
 
 
-def pad_to_multiple(images, stride):
+def pad_to_multiple(images, stride, channel_pad=0):
   """image_encoder.py:32-39.  Quirk kept: an already divisible size is padded by a
-  full stride (``pad = stride - size % stride``)."""
+  full stride (``pad = stride - size % stride``).  ``channel_pad``: extra zero channels appended
+  in the same copy (an RGB image stored with 4 floats per pixel lets the split-bf16 engine take
+  the root convolution: ops.conv2d, ``cin=3``)."""
   shape = np.array(images.shape[-3:-1])
   pad = stride - shape % stride
-  return torch.nn.functional.pad(images, (0, 0, 0, int(pad[1]), 0, int(pad[0])))
+  return torch.nn.functional.pad(images, (0, int(channel_pad), 0, int(pad[1]), 0, int(pad[0])))
 
 
 class FPNDecoder(base.Module):
@@ -108,7 +110,10 @@ class ImageEncoder(base.Module):
       h, w = np.ceil(input_shape / patch).astype(int)
       return types.FeatureImagePyramid(
           features=[f[..., :h, :w, :]], strides=[np.array([patch, patch], dtype=np.float64)])
-    image_padded = pad_to_multiple(image, 2**self.max_stride).contiguous()
+    # (inference on a split-bf16 engine: RGB + one zero float per pixel -- see pad_to_multiple)
+    rgb4 = (image.shape[-1] == 3 and ops.MATMUL_PRECISION in ops.SPLIT_PARTS
+            and not base.needs_grad(image) and not train)
+    image_padded = pad_to_multiple(image, 2**self.max_stride, channel_pad=1 if rgb4 else 0).contiguous()
     padded_shape = np.array(image_padded.shape[-3:-1])
     encoder_features = self.encoder(params['encoder'], image_padded, train=train, ctx=ctx)
     skip_features = []

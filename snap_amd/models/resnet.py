@@ -146,16 +146,20 @@ class ResNetV2(base.Module):
         # split-bf16 engine: the weight images of all standardised kernels, one launch
         ops.pack_weights_split_multi([ctx._lookup(k) for k in kernels], ops.MATMUL_PRECISION)
     # `image * 2 - 1` (resnet.py:199) is fused into the root conv's operand staging.
+    # (the image may carry padding channels: image_encoder.pad_to_multiple(channel_pad=...))
+    w_root = params['conv_root' if self.config.skip_root_block else 'root_block']
+    w_root = w_root['kernel'] if self.config.skip_root_block else w_root['conv_root']['kernel']
+    cin_kw = {'cin': w_root.shape[2]} if image.shape[-1] != w_root.shape[2] else {}
     if self.config.skip_root_block:
       w = _std(ctx, params['conv_root']['kernel'])
       conv = ag.conv2d if base.needs_grad(w) else ops.conv2d
       x = conv(image, w, padding=((1, 1), (1, 1)), prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0),
-               emit_gn_stats='raw')
+               emit_gn_stats='raw', **cin_kw)
     else:
       w = _std(ctx, params['root_block']['conv_root']['kernel'])
       conv = ag.conv2d if base.needs_grad(w) else ops.conv2d
       x = conv(image, w, stride=2, padding=((3, 3), (3, 3)), prologue=ops.PRO_AFFINE,
-               in_affine=(2.0, -1.0))
+               in_affine=(2.0, -1.0), **cin_kw)
       pool = ag.max_pool_3x3s2 if base.needs_grad(x) else ops.max_pool_3x3s2
       x = out['stem'] = pool(x)
     for i, size in enumerate(self.blocks):

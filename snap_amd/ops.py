@@ -258,7 +258,21 @@ def conv2d(
   parts = SPLIT_PARTS.get(math, 0)
   if parts and lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts) == 0:
     math = 'f32'     # weight image beyond the split engine's 32-bit offsets (template banks)
-  if math != 'f32' and Cs % 4 == 0 and Cin >= 4:
+  # the RGB root convolution (7 x 7 / stride 2 / pad 3) of an image stored with 4 floats per pixel
+  # runs on the split engine with its own weight image (a K slab = 4 pixels of a kernel row)
+  root = (parts and (KH, KW, stride, Cin, Cs) == (7, 7, 2, 3, 4) and (pt, pl) == (3, 3)
+          and prologue in (PRO_NONE, PRO_AFFINE) and rows_in is None and rows_out is None
+          and row_count is None and partial is None)
+  if root:
+    wpk = _packed_weights(w, math + '/root', parts)
+    if ex is None:
+      ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
+    ex.w_bf16 = wpk.data_ptr()
+    ex.w_bf16_bytes = wpk.numel() * 2
+    ex.w_split_parts = parts
+    ex.w_split_root = 1
+    family = f'conv_split_{math}'
+  elif math != 'f32' and Cs % 4 == 0 and Cin >= 4:
     wpk = _packed_weights(w, math, parts)
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
@@ -320,7 +334,10 @@ def _packed_weights(w, math, parts):
         return hit
       if hit[0] == PACK_EPOCH and hit[1] == w._version:
         return hit[2]
-  wpk = pack_weights_split_bf16(w, parts) if parts else pack_weights_bf16(w)
+  if math.endswith('/root'):
+    wpk = pack_weights_split_root_bf16(w, parts)
+  else:
+    wpk = pack_weights_split_bf16(w, parts) if parts else pack_weights_bf16(w)
   if slot is None:
     slot = {}
     try:
@@ -342,6 +359,21 @@ def pack_weights_split_bf16(w, parts):
   st = lib.snap_conv2d_pack_weights_split_bf16(_p(w), KH * KW, Cin, Cout, parts, _p(out), nbytes,
                                                _stream())
   _lib.check(st, 'snap_conv2d_pack_weights_split_bf16')
+  return out
+
+
+def pack_weights_split_root_bf16(w, parts):
+  """w [7,7,3,Cout] f32 -> the split engine's ROOT image ([Cout/128][14 slabs = (kh, group of 4
+  kw)][parts][128][16 k = 4 kw x (RGB + 0)])."""
+  lib = _lib.load()
+  _f32(w, 'w')
+  if tuple(w.shape[:3]) != (7, 7, 3):
+    raise ValueError('pack_weights_split_root_bf16: w must be [7, 7, 3, Cout]')
+  Cout = w.shape[3]
+  nbytes = lib.snap_conv2d_packed_weights_split_root_bytes(Cout, parts)
+  out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+  st = lib.snap_conv2d_pack_weights_split_root_bf16(_p(w), Cout, parts, _p(out), nbytes, _stream())
+  _lib.check(st, 'snap_conv2d_pack_weights_split_root_bf16')
   return out
 
 

@@ -291,6 +291,25 @@ def test_conv_split_halo_3x3(N, H, W, Cin, Cout, gn, extras, math):
     ops.USE_SPLITK = True
 
 
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('N,H,W,Cout,affine', [(2, 64, 64, 64, True), (1, 96, 80, 32, False), (3, 32, 32, 160, True)])
+def test_conv_split_rgb_root(N, H, W, Cout, affine, math):
+  """The 7 x 7 / stride 2 / pad 3 root convolution of an RGB image stored with 4 floats per pixel
+  (cin = 3): on the split engine a K slab is 4 consecutive pixels of one kernel row (root weight
+  image, 14 slabs); the 4th float of a pixel and the 8th tap of a row meet zero weights."""
+  x = torch.rand((N, H, W, 4), generator=torch.Generator().manual_seed(900 + W))
+  x[..., 3] = 0.37                                  # (must not matter)
+  w = rnd((7, 7, 3, Cout), 901, 1 / np.sqrt(147))
+  kw = dict(stride=2, padding=((3, 3), (3, 3)), cin=3, math=math)
+  if affine:
+    kw.update(prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0))
+  got, want = both('conv2d', (x, w), kw)
+  assert got.shape == (N, H // 2, W // 2, Cout)
+  helpers.report(f'rgb root {math} {N}x{H}x{W}->{Cout}', got, want, atol=2.5 * SPLIT_TOL[math], rtol=1e-5)
+  exact = ops.conv2d(x.to(DEV), w.to(DEV), **{**kw, 'math': 'f32'})
+  assert float((got - exact).abs().max()) <= 2.5 * SPLIT_TOL[math] * float(exact.abs().max())
+
+
 def test_conv_split_accuracy_class():
   """The split engines against float64 on a deep reduction (K = 4608), next to the exact f32
   engine: 'bf16x6' must sit in the f32 engine's error class (<= 2x its rms error), 'bf16x3'
