@@ -108,11 +108,6 @@ typedef struct SnapConvExtras {
                                  of an RGB image stored with 4 floats per pixel (Cin = 3,
                                  Cin_stride = 4): w_bf16 = snap_conv2d_pack_weights_split_root_bf16,
                                  a K slab = 4 consecutive pixels of one kernel row */
-  float* gn_partial2;         /* with gn_partial (gn_partial_relu = 0): a second buffer of the same
-                                 size that receives the partial sums of relu(y) -- for an output
-                                 read by a GroupNorm->ReLU layer AND a ReLU->GroupNorm layer (the
-                                 last unit of a ResNet stage: next stage / FPN level) */
-  size_t gn_partial2_bytes;
 } SnapConvExtras;
 
 int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,

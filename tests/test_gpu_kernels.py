@@ -310,24 +310,6 @@ def test_conv_split_rgb_root(N, H, W, Cout, affine, math):
   assert float((got - exact).abs().max()) <= 2.5 * SPLIT_TOL[math] * float(exact.abs().max())
 
 
-@pytest.mark.parametrize('math', ['f32', 'bf16x3'])
-def test_conv_emits_both_groupnorm_statistics(math):
-  """emit_gn_stats='both': the statistics of y (GroupNorm -> ReLU readers) and of relu(y)
-  (ReLU -> GroupNorm readers, the FPN levels) out of ONE epilogue; tiles straddling images."""
-  N, H, W, Cin, Cout = 3, 37, 29, 64, 128
-  x = rnd((N, H, W, Cin), 950)
-  w = rnd((1, 1, Cin, Cout), 951, 1 / 8.0)
-  res = rnd((N, H, W, Cout), 952)
-  y = ops.conv2d(x.to(DEV), w.to(DEV), residual=res.to(DEV), emit_gn_stats='both', math=math)
-  assert hasattr(y, '_snap_gn_partial') and hasattr(y, '_snap_gn_partial_relu')
-  gamma = rnd((Cout,), 953) + 1
-  for relu_first in (False, True):
-    mu_f, sc_f = ops.group_norm_stats(y, gamma.to(DEV), relu_first=relu_first)
-    mu_w, sc_w = oracle_ops.group_norm_stats(y.cpu(), gamma, relu_first=relu_first)
-    helpers.report(f'both stats mu relu_first={relu_first}', mu_f, mu_w, atol=1e-5, rtol=1e-5)
-    helpers.report(f'both stats sc relu_first={relu_first}', sc_f, sc_w, atol=1e-5, rtol=5e-5)
-
-
 def test_conv_split_accuracy_class():
   """The split engines against float64 on a deep reduction (K = 4608), next to the exact f32
   engine: 'bf16x6' must sit in the f32 engine's error class (<= 2x its rms error), 'bf16x3'
