@@ -537,7 +537,10 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     const float* __restrict__ row_cdf, const float* __restrict__ sim,
     const float* __restrict__ row_unscale) {
   const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // one wave = one correspondence: everything that depends only on (scene, sample) is wave-uniform.
+  // readfirstlane tells the compiler so: the Philox rounds, the row / chunk bookkeeping and the
+  // address arithmetic then run on the scalar unit instead of 64-wide on the (saturated) VALU
+  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int b = blockIdx.y;
   if (s >= S) return;
   const int XY = X * Y;
@@ -567,6 +570,7 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
   } else {
     n = min((int)(u1 * (float)Nq), Nq - 1);
   }
+  n = __builtin_amdgcn_readfirstlane(n);
   const int64_t row = (int64_t)b * Nq + n;
   const float* st = stats + row * NC * 2;
 
@@ -595,30 +599,45 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
     const unsigned long long ne = __ballot(ce > cb);
     L = 63 - __clzll((long long)ne);
   }
-  // lane L walks its chunks
-  int cstar = 0;
-  float resid = 0.f;
-  if (lane == L) {
-    if (table)                   // only the selected lane re-evaluates its own chunk masses
-      for (int c = cb; c < ce; ++c) local += st[2 * c + 1] * __expf(st[2 * c] - M);
-    float run = incl - local;
-    cstar = ce - 1;
-    resid = 0.f;
-    bool found = false;
-    for (int c = cb; c < ce; ++c) {
-      const float wgt = st[2 * c + 1] * __expf(st[2 * c] - M);
-      if (!found && run + wgt > target) {
-        cstar = c;
-        // residual expressed relative to the chunk's own max
-        resid = (target - run) / __expf(st[2 * c] - M);
-        found = true;
+  // the chunks of lane L: lane i evaluates the mass of chunk cbL + i (one exp per lane, side by
+  // side), then the walk runs over those values in the same order and with the same additions as
+  // a serial walk by lane L would
+  L = __builtin_amdgcn_readfirstlane(L);
+  const int cbL = L * cpl, ceL = min(cbL + cpl, NC);
+  const int nL = ceL - cbL;                                 // 1 .. cpl chunks (uniform)
+  const float inclL = __shfl(incl, L, 64);
+  float localL = __shfl(local, L, 64);
+  float run = 0.f;
+  int cstar = ceL - 1;
+  float resid = INFINITY;
+  bool found = false;
+  // (pass 0 re-sums lane L's chunk masses when only the table's prefix is known; pass 1 walks)
+  for (int pass = table ? 0 : 1; pass < 2; ++pass) {
+    if (pass == 1) run = inclL - localL;
+    float acc = 0.f;
+    for (int base = 0; base < nL; base += 64) {             // (nL <= 64 up to 512 x 512 maps)
+      float ex = 0.f, wgt = 0.f;
+      if (base + lane < nL) {
+        ex = __expf(st[2 * (cbL + base + lane)] - M);
+        wgt = st[2 * (cbL + base + lane) + 1] * ex;
       }
-      run += wgt;
+      const int m = min(64, nL - base);
+      for (int i = 0; i < m; ++i) {
+        const float wi = __shfl(wgt, i, 64);
+        if (pass == 0) {
+          acc += wi;
+        } else {
+          if (!found && run + wi > target) {
+            cstar = cbL + base + i;
+            resid = (target - run) / __shfl(ex, i, 64);     // relative to the chunk's own max
+            found = true;
+          }
+          run += wi;
+        }
+      }
     }
-    if (!found) resid = INFINITY;
+    if (pass == 0) localL = acc;
   }
-  cstar = __shfl(cstar, L, 64);
-  resid = __shfl(resid, L, 64);
   const float mc = st[2 * cstar];
 
   // level 2: the 64 cells of the chunk.
