@@ -681,6 +681,147 @@ __global__ __launch_bounds__(256) void ransac_sample_kernel(
   }
 }
 
+// The same draw for the common configuration (per-row prefix table + chunk scores read from sim),
+// NQ correspondences per wave in lock step.  One correspondence is three DEPENDENT memory round
+// trips (row table -> chunk statistics -> the chunk's 64 scores) and ~450 instructions: with one
+// per wave the kernel ran at the pace of those round trips (32 waves per CU / ~5 us each = the
+// measured 0.8 ms for 1.28 M correspondences at C2).  Here the NQ chains of a wave are issued
+// phase by phase, so each round trip serves NQ correspondences.  Same arithmetic per
+// correspondence, in the same order: identical samples.
+template <int NQ>
+__global__ __launch_bounds__(256) void ransac_sample_fast_kernel(
+    const float* __restrict__ stats, int Nq, int X, int Y, int S, uint64_t seed,
+    const float* __restrict__ uniforms, int32_t* __restrict__ corr,
+    const float* __restrict__ lane_incl, const float* __restrict__ rowmax,
+    const float* __restrict__ row_cdf, const float* __restrict__ sim,
+    const float* __restrict__ row_unscale) {
+  const int lane = threadIdx.x & 63;
+  const int s0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * NQ);
+  const int b = blockIdx.y;
+  if (s0 >= S) return;
+  const int XY = X * Y;
+  const int NC = (XY + SIM_CH - 1) / SIM_CH;
+  const int cpl = (NC + 63) / 64;                           // <= 64 (checked by the launcher)
+  const int cb = lane * cpl, ce = min(cb + cpl, NC);
+  bool live[NQ];
+  int n[NQ];
+  float u2[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int s = s0 + q;
+    live[q] = s < S;
+    float u1;
+    if (uniforms) {
+      u1 = live[q] ? uniforms[((int64_t)b * S + s) * 2 + 0] : 0.f;
+      u2[q] = live[q] ? uniforms[((int64_t)b * S + s) * 2 + 1] : 0.f;
+    } else {
+      uint32_t rnd[4];
+      philox4x32_10((uint32_t)s, (uint32_t)b, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+      u1 = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+      u2[q] = (float)(rnd[1] >> 8) * (1.0f / 16777216.0f);
+    }
+    if (row_cdf) {
+      const float* cdf = row_cdf + (int64_t)b * Nq;
+      const float tgt = u1 * cdf[Nq - 1];
+      int lo = 0, hi = Nq - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > tgt) hi = mid; else lo = mid + 1;
+      }
+      n[q] = lo;
+    } else {
+      n[q] = min((int)(u1 * (float)Nq), Nq - 1);
+    }
+    n[q] = __builtin_amdgcn_readfirstlane(n[q]);
+  }
+  // round trip 1: the row's maximum, its per-lane inclusive prefix, its un-scale factor
+  float M[NQ], incl[NQ], ru[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int64_t row = (int64_t)b * Nq + n[q];
+    M[q] = rowmax[row];
+    incl[q] = lane_incl[row * 64 + lane];
+    ru[q] = row_unscale[row];
+  }
+  // level 1: the lane whose chunk range holds the target; round trip 2: that range's statistics
+  int cbL[NQ], nL[NQ];
+  float target[NQ], inclL[NQ], sm[NQ], ss[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float total = __shfl(incl[q], 63, 64);
+    target[q] = u2[q] * total;
+    const unsigned long long bal = __ballot(incl[q] > target[q] && ce > cb);
+    int L;
+    if (bal) {
+      L = __ffsll((long long)bal) - 1;
+    } else {
+      const unsigned long long ne = __ballot(ce > cb);
+      L = 63 - __clzll((long long)ne);
+    }
+    L = __builtin_amdgcn_readfirstlane(L);
+    cbL[q] = L * cpl;
+    nL[q] = min(cbL[q] + cpl, NC) - cbL[q];
+    inclL[q] = __shfl(incl[q], L, 64);
+    const float* st = stats + ((int64_t)b * Nq + n[q]) * NC * 2;
+    sm[q] = ss[q] = 0.f;
+    if (lane < nL[q]) {
+      sm[q] = st[2 * (cbL[q] + lane)];
+      ss[q] = st[2 * (cbL[q] + lane) + 1];
+    }
+  }
+  // the walk over lane L's chunks (masses side by side, additions in the serial order);
+  // round trip 3: the selected chunk's 64 scores
+  int cstar[NQ];
+  float resid[NQ], mc[NQ], x[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float ex = lane < nL[q] ? __expf(sm[q] - M[q]) : 0.f;
+    const float wgt = ss[q] * ex;
+    float localL = 0.f;
+    for (int i = 0; i < nL[q]; ++i) localL += __shfl(wgt, i, 64);
+    float run = inclL[q] - localL;
+    int cs = cbL[q] + nL[q] - 1;
+    float rs = INFINITY;
+    bool found = false;
+    for (int i = 0; i < nL[q]; ++i) {
+      const float wi = __shfl(wgt, i, 64);
+      if (!found && run + wi > target[q]) {
+        cs = cbL[q] + i;
+        rs = (target[q] - run) / __shfl(ex, i, 64);
+        found = true;
+      }
+      run += wi;
+    }
+    cstar[q] = cs;
+    resid[q] = rs;
+    mc[q] = __shfl(sm[q], cs - cbL[q], 64);
+    const int cell = cs * SIM_CH + lane;
+    x[q] = (cell < XY && live[q]) ? sim[((int64_t)b * Nq + n[q]) * XY + cell] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int cell = cstar[q] * SIM_CH + lane;
+    const bool cvalid = cell < XY;
+    const float e = cvalid ? __expf(x[q] * ru[q] - mc[q]) : 0.f;
+    const float ci = wave_scan_incl(e, lane);
+    const unsigned long long b2 = __ballot(cvalid && ci > resid[q]);
+    int pick;
+    if (b2) {
+      pick = __ffsll((long long)b2) - 1;
+    } else {
+      const unsigned long long nv = __ballot(cvalid);
+      pick = 63 - __clzll((long long)nv);
+    }
+    if (lane == 0 && live[q]) {
+      const int c = cstar[q] * SIM_CH + pick;
+      int32_t* o = corr + ((int64_t)b * S + s0 + q) * 3;
+      o[0] = n[q];
+      o[1] = c / Y;
+      o[2] = c - (c / Y) * Y;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k11b: best-of-retries + 2-point Kabsch (closed form of the 2x2 SVD).
 // ---------------------------------------------------------------------------
@@ -1448,6 +1589,19 @@ extern "C" int snap_ransac_sample_sim_f32(const float* fq, const float* fm,
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)snap_cdiv(rows, 4)), dim3(256), 0, s,
                        chunk_stats, rows, NC, lane_incl, rowmax);
     SNAP_CHECK_LAUNCH();
+  }
+  {
+    const int NC = (X * Y + SIM_CH - 1) / SIM_CH;
+    const char* e = getenv("SNAP_RANSAC_FAST");          // 0 = one correspondence per wave
+    if (lane_incl && sim && row_unscale && (NC + 63) / 64 <= 64 && !(e && e[0] == '0')) {
+      constexpr int NQ = 4;
+      const dim3 fgrid((unsigned)snap_cdiv(S, 4 * NQ), (unsigned)B);
+      hipLaunchKernelGGL(ransac_sample_fast_kernel<NQ>, fgrid, dim3(256), 0, s, chunk_stats, Nq, X, Y, S,
+                         seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf,
+                         sim, row_unscale);
+      SNAP_CHECK_LAUNCH();
+      return SNAP_OK;
+    }
   }
   const dim3 grid((unsigned)snap_cdiv(S, 4), (unsigned)B);
   switch (Dm) {

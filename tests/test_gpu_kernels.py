@@ -1498,3 +1498,24 @@ def test_ransac_sample_reading_the_chunk_scores_from_sim():
     ca = a[diff][:, 1].long() * Y + a[diff][:, 2].long()
     cb = b[diff][:, 1].long() * Y + b[diff][:, 2].long()
     assert int((ca - cb).abs().max()) <= 1
+
+
+@pytest.mark.parametrize('X,Y,Nq,S', [(24, 20, 90, 20001), (128, 128, 300, 4003), (256, 256, 64, 1000)])
+def test_ransac_four_per_wave_kernel_draws_the_same_samples(X, Y, Nq, S, monkeypatch):
+  """The sampler kernel that runs four correspondences per wave in lock step (table + sim path)
+  is a scheduling change only: bit-identical correspondences, with the generator and with
+  injected uniforms, sample counts that are not multiples of the 16 per workgroup."""
+  B, Dm = 2, 32
+  fq = _unit(rnd((B, Nq, Dm), 495)).to(DEV)
+  fm = _unit(rnd((B, X, Y, Dm), 496)).to(DEV)
+  nv = torch.tensor([float(Nq - 2), float(Nq)], device=DEV)
+  scale = float(np.exp(2.0))
+  sim, stats, _, _ = ops.sim_softmax(fq, fm, scale, True, nv)
+  unscale = nv[:, None].expand(B, Nq).contiguous()
+  u = torch.rand((B, S, 2), generator=torch.Generator().manual_seed(497)).to(DEV)
+  for kw in (dict(uniforms=u), dict(seed=1234)):
+    monkeypatch.setenv('SNAP_RANSAC_FAST', '0')
+    a = ops.ransac_sample(fq, fm, stats, scale, True, S, sim=sim, row_unscale=unscale, **kw)
+    monkeypatch.setenv('SNAP_RANSAC_FAST', '1')
+    b = ops.ransac_sample(fq, fm, stats, scale, True, S, sim=sim, row_unscale=unscale, **kw)
+    assert torch.equal(a, b)
