@@ -147,10 +147,23 @@ def main():
                   help="comma list of conv engines: f32 | bf16x6 | bf16x3 (ops.MATMUL_PRECISION)")
   ap.add_argument('--eval', action='store_true',
                   help='eval_localization.py overrides: 20 000 hypotheses + the 41^3 refinement lattice')
+  ap.add_argument('--seeds', default='21',
+                  help='comma list of scene seeds (one oracle run each); more than one: a summary per seed')
   args = ap.parse_args()
   maths = args.math.split(',')
-  res = run(maths, args.views, args.image, args.eval)
-  out = res['per_math'][maths[0]] if len(maths) == 1 else {'per_math': res['per_math']}
+  seeds = [int(x) for x in args.seeds.split(',')]
+  if len(seeds) > 1:
+    keys = ('image_features_rel_err', 'streetview_plane_rel_err', 'map_bev_matching_max_abs_err',
+            'scores_poses_rel_err', 'voxel_validity_mismatch_fraction', 'pose_argmax_equal',
+            'refine_argmax_equal')
+    out = {'workload': 'one C2 scene per seed', 'per_seed': {}}
+    for sd in seeds:
+      res = run(maths, args.views, args.image, args.eval, seed=sd)
+      out['per_seed'][str(sd)] = {m: {k: r[k] for k in keys if k in r} for m, r in res['per_math'].items()}
+    out['all_argmax_equal'] = all(r['pose_argmax_equal'] for s_ in out['per_seed'].values() for r in s_.values())
+  else:
+    res = run(maths, args.views, args.image, args.eval, seed=seeds[0])
+    out = res['per_math'][maths[0]] if len(maths) == 1 else {'per_math': res['per_math']}
   line = json.dumps(out)
   print(line)
   if args.out:
