@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
 //   phase B  for each of the 32 voxels: lane q <-> channels 4q..4q+3: broadcast-read the
 //            records, gather the taps, pool.  Same arithmetic as lift_pool_kernel, same bits.
 // ---------------------------------------------------------------------------
-constexpr int LB_REC = 8;    // dwords per (voxel, slot) record: o00 | packed | wi1 | wj1 | wb1
+constexpr int LB_REC = 8;    // dwords per (voxel, slot) record: tap byte offset | packed | wi1 | wj1 | wb1
 
 // hi / lo bf16 parts of four f32, two per dword (the split of conv_split.hip / mlp_pool.hip)
 __device__ __forceinline__ void split_row_quad(const f32x4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
@@ -452,10 +452,15 @@ __device__ __forceinline__ void split_row_quad(const f32x4& v, unsigned (&hi)[2]
   }
 }
 
-template <int KMAX>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pair_lo(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 pair_hi(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
+
+// FD128: feature_dim == 128, every lane of the half-wave owns a channel quad (no lane guards)
+template <int KMAX, bool FD128>
 __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a) {
   __shared__ __attribute__((aligned(16))) int recs[8][32][KMAX][LB_REC];
-  __shared__ float hdr[8][32][4];   // (scene, min_dist, voxel index or -1) per voxel
+  __shared__ float hdr[8][32][4];   // (-, min_dist, voxel index or -1, visible observations) per voxel
   const SnapLiftDesc& d = a.d;
   const int hl = threadIdx.x & 31;
   const int hw = threadIdx.x >> 5;
@@ -548,13 +553,17 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
       }
     }
     if (!all_views) min_dist = kd[0];
-    hdr[hw][hl][0] = __int_as_float(b);
     hdr[hw][hl][1] = min_dist;
     hdr[hw][hl][2] = __int_as_float((int)gv);       // (B * N < 2^31, checked by the launcher)
+    // The records of the visible observations are written to slots 0 .. nvis-1 in slot order
+    // (the selective insertion already leaves them there; with all views, holes are closed):
+    // skipped slots contribute nothing to any sum, so the pooled bits do not change, and phase B
+    // needs one count per voxel instead of a flag per slot.
+    int nvis = 0;
 #pragma unroll
     for (int r = 0; r < KMAX; ++r) {
-      int* rec = recs[hw][hl][r];
-      if (r >= nsel || kv[r] < 0) { rec[1] = -1; continue; }
+      if (r >= nsel || kv[r] < 0) continue;
+      int* rec = recs[hw][hl][nvis++];
       const Taps t = make_taps(kpi[r], kpj[r], d.h, d.w, all_views ? 0 : 1);
       // depth score: two neighbouring log-depth bins
       const float dc = fminf(fmaxf(kdep[r], d.depth_min), d.depth_max);
@@ -564,103 +573,116 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
       const float fl = floorf(c);
       const int b0 = (int)fminf(fmaxf(fl, 0.f), (float)(d.num_bins - 1));
       const int b1 = (int)fminf(fmaxf(fl + 1.f, 0.f), (float)(d.num_bins - 1));
-      rec[0] = (t.i0 * d.w + t.j0) * d.C;
+      rec[0] = (int)(((((uint32_t)b * d.V + kv[r]) * d.h + t.i0) * d.w + t.j0) * ((uint32_t)d.C * 4u));
       rec[1] = kv[r] | ((t.i1 != t.i0) << 8) | ((t.j1 != t.j0) << 9) | (b0 << 10) | (b1 << 18);
       rec[2] = __float_as_int(t.wi1);
       rec[3] = __float_as_int(t.wj1);
       rec[4] = __float_as_int(c - fl);
     }
+    hdr[hw][hl][3] = __int_as_float(nvis);
   }
   __syncthreads();
 
   // ---------------- phase B: lane = channel quad ----------------
-  const int64_t vstride = (int64_t)d.h * d.w * d.C;
+  // The kernel is VALU-bound (PMC r02: VALU 72 % busy), so phase B spends as few instructions
+  // per voxel as the arithmetic allows: tap addresses are 32-bit byte offsets from the (scalar)
+  // base of f_images (one v_add each, saddr-form loads; the launcher checks the tensor is
+  // < 4 GB), the eight depth-score loads are issued BEFORE the four feature loads (one wait for
+  // the twelve, not two round trips), and the four channels of a lane are blended / pooled as
+  // two packed pairs (v_pk_mul_f32 / v_pk_add_f32: same IEEE operations, same bits).
+  const char* fb = reinterpret_cast<const char*>(a.f);
+  const uint32_t Cb = (uint32_t)d.C * 4u, Wb = (uint32_t)d.w * Cb, fdb = (uint32_t)fd * 4u;
+  const uint32_t lane_off = 16u * hl;
   for (int j = 0; j < 32; ++j) {
     const int64_t gv = __float_as_int(hdr[hw][j][2]);
     if (gv < 0) continue;     // half-wave uniform
-    const int b = __float_as_int(hdr[hw][j][0]);
     const float min_dist = hdr[hw][j][1];
+    const int nvis = __float_as_int(hdr[hw][j][3]);     // half-wave uniform
     // Per visible slot: gather + blend right away (16 live tap registers, not 64: occupancy
     // matters more here than loads in flight per wave).  Nothing is zero-initialised and every
-    // use is guarded by ok[r]; voxels seen by ONE view skip the softmax (weight e/e == 1
+    // use is guarded by r < nvis; voxels seen by ONE view skip the softmax (weight e/e == 1
     // exactly: mean = f, var = 0, same bits) -- the common case.
-    f32x4 feat[KMAX];
+    f32x2 feat[KMAX][2];
     float score[KMAX];
-    bool ok[KMAX];
-    int nvis = 0;
 #pragma unroll
     for (int r = 0; r < KMAX; ++r) {
-      ok[r] = false;
-      if (r >= nsel) continue;
+      if (r >= nvis) continue;   // (nvis <= nsel <= KMAX)
       const int* rec = recs[hw][j][r];
-      const i32x4 q4 = *reinterpret_cast<const i32x4*>(rec);   // o00 | packed | wi1 | wj1
+      const i32x4 q4 = *reinterpret_cast<const i32x4*>(rec);   // byte offset | packed | wi1 | wj1
       const int pk = q4[1];
-      if (pk < 0) continue;    // half-wave uniform
-      ok[r] = true;
-      ++nvis;
-      const int v = pk & 0xff;
       const float wi1 = __int_as_float(q4[2]), wj1 = __int_as_float(q4[3]);
       const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
       const float w00 = wi0 * wj0, w01 = wi0 * wj1, w10 = wi1 * wj0, w11 = wi1 * wj1;
-      const int dj = ((pk >> 9) & 1) * d.C, di = ((pk >> 8) & 1) * d.w * d.C;
-      const float* r00 = a.f + ((int64_t)b * d.V + v) * vstride + q4[0];
-      const float* r01 = r00 + dj;
-      const float* r10 = r00 + di;
-      const float* r11 = r10 + dj;
-      if (hl < nq) {
-        const f32x4 a00 = *reinterpret_cast<const f32x4*>(r00 + 4 * hl);
-        const f32x4 a01 = *reinterpret_cast<const f32x4*>(r01 + 4 * hl);
-        const f32x4 a10 = *reinterpret_cast<const f32x4*>(r10 + 4 * hl);
-        const f32x4 a11 = *reinterpret_cast<const f32x4*>(r11 + 4 * hl);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          feat[r][e] = ((w00 * a00[e] + w01 * a01[e]) + w10 * a10[e]) + w11 * a11[e];
+      const uint32_t o00 = (uint32_t)q4[0];
+      const uint32_t o01 = o00 + ((pk >> 9) & 1 ? Cb : 0u);
+      const uint32_t o10 = o00 + ((pk >> 8) & 1 ? Wb : 0u);
+      const uint32_t o11 = o10 + (o01 - o00);
+      const uint32_t c0 = fdb + ((pk >> 10) & 0xff) * 4u, c1 = fdb + ((pk >> 18) & 0xff) * 4u;
+      const float t00 = *reinterpret_cast<const float*>(fb + (o00 + c0));
+      const float t01 = *reinterpret_cast<const float*>(fb + (o01 + c0));
+      const float t10 = *reinterpret_cast<const float*>(fb + (o10 + c0));
+      const float t11 = *reinterpret_cast<const float*>(fb + (o11 + c0));
+      const float u00 = *reinterpret_cast<const float*>(fb + (o00 + c1));
+      const float u01 = *reinterpret_cast<const float*>(fb + (o01 + c1));
+      const float u10 = *reinterpret_cast<const float*>(fb + (o10 + c1));
+      const float u11 = *reinterpret_cast<const float*>(fb + (o11 + c1));
+      if (FD128 || hl < nq) {
+        const f32x4 a00 = *reinterpret_cast<const f32x4*>(fb + (o00 + lane_off));
+        const f32x4 a01 = *reinterpret_cast<const f32x4*>(fb + (o01 + lane_off));
+        const f32x4 a10 = *reinterpret_cast<const f32x4*>(fb + (o10 + lane_off));
+        const f32x4 a11 = *reinterpret_cast<const f32x4*>(fb + (o11 + lane_off));
+        const f32x2 p00 = {w00, w00}, p01 = {w01, w01}, p10 = {w10, w10}, p11 = {w11, w11};
+        feat[r][0] = ((p00 * pair_lo(a00) + p01 * pair_lo(a01)) + p10 * pair_lo(a10)) + p11 * pair_lo(a11);
+        feat[r][1] = ((p00 * pair_hi(a00) + p01 * pair_hi(a01)) + p10 * pair_hi(a10)) + p11 * pair_hi(a11);
       }
       const float wb1 = __int_as_float(rec[4]), wb0 = 1.f - wb1;
-      const int c0 = fd + ((pk >> 10) & 0xff), c1 = fd + ((pk >> 18) & 0xff);
-      const float s0 = ((w00 * r00[c0] + w01 * r01[c0]) + w10 * r10[c0]) + w11 * r11[c0];
-      const float s1 = ((w00 * r00[c1] + w01 * r01[c1]) + w10 * r10[c1]) + w11 * r11[c1];
+      const float s0 = ((w00 * t00 + w01 * t01) + w10 * t10) + w11 * t11;
+      const float s1 = ((w00 * u00 + w01 * u01) + w10 * u10) + w11 * u11;
       score[r] = wb0 * s0 + wb1 * s1;
     }
     float* out = a.pooled + gv * d.out_stride;
-    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, var = {0.f, 0.f, 0.f, 0.f};
+    f32x2 mean2[2] = {{0.f, 0.f}, {0.f, 0.f}}, var2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     float smax = 0.f;
     if (nvis == 1) {          // half-wave uniform
-#pragma unroll
-      for (int r = 0; r < KMAX; ++r)
-        if (ok[r]) { mean = feat[r]; smax = score[r]; }
+      mean2[0] = feat[0][0];
+      mean2[1] = feat[0][1];
+      smax = score[0];
     } else if (nvis > 1) {
       // jax.nn.softmax(..., where=valid, initial=0): shift = max(0, max valid score).
       float m = 0.f;
       smax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < KMAX; ++r)
-        if (ok[r]) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
+        if (r < nvis) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
       float e[KMAX], den = 0.f;
 #pragma unroll
       for (int r = 0; r < KMAX; ++r) {
-        e[r] = 0.f;
-        if (ok[r]) e[r] = expf(score[r] - m);
-        den += e[r];             // (+0 for the invisible slots: same sum as the masked form)
+        if (r >= nvis) continue;
+        e[r] = expf(score[r] - m);
+        den += e[r];             // (the invisible slots of the masked form add +0: same sum)
       }
       float wgt[KMAX];
 #pragma unroll
       for (int r = 0; r < KMAX; ++r) {
-        if (!ok[r]) continue;
+        if (r >= nvis) continue;
         wgt[r] = e[r] / den;
+        const f32x2 w2 = {wgt[r], wgt[r]};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mean[c] += wgt[r] * feat[r][c];
+        for (int h = 0; h < 2; ++h) mean2[h] += w2 * feat[r][h];
       }
 #pragma unroll
       for (int r = 0; r < KMAX; ++r) {
-        if (!ok[r]) continue;
+        if (r >= nvis) continue;
+        const f32x2 w2 = {wgt[r], wgt[r]};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float dl = feat[r][c] - mean[c];
-          var[c] += wgt[r] * (dl * dl);
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 dl = feat[r][h] - mean2[h];
+          var2[h] += w2 * (dl * dl);
         }
       }
     }
+    const f32x4 mean = {mean2[0][0], mean2[0][1], mean2[1][0], mean2[1][1]};
+    const f32x4 var = {var2[0][0], var2[0][1], var2[1][0], var2[1][1]};
     // (valid_rows_only: a voxel no view sees gets its validity byte, not its 1 KB row of zeros --
     // for consumers that read the rows of valid voxels only, 40 % of the map's voxels at C2)
     const bool write_row = nvis > 0 || !d.valid_rows_only;
@@ -677,13 +699,17 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
         const f32x4 stat[2] = {mean, var};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          unsigned hi[2], lo[2];
-          split_row_quad(stat[t], hi, lo);
-          const unsigned g0 = __shfl_xor(odd ? hi[0] : lo[0], 1);
-          const unsigned g1 = __shfl_xor(odd ? hi[1] : lo[1], 1);
-          const uint4 chunk = odd ? uint4{g0, g1, lo[0], lo[1]} : uint4{hi[0], hi[1], g0, g1};
+          uint4 chunk = {0u, 0u, 0u, 0u};
+          if (t == 0 || nvis > 1) {          // (one observation: the variance is exactly 0)
+            unsigned hi[2], lo[2];
+            split_row_quad(stat[t], hi, lo);
+            // (lane ^ 1 by DPP quad_perm [1, 0, 3, 2]: one VALU move each, no LDS permute)
+            const unsigned g0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hi[0] : lo[0]), 0xB1, 0xf, 0xf, true);
+            const unsigned g1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hi[1] : lo[1]), 0xB1, 0xf, 0xf, true);
+            chunk = odd ? uint4{g0, g1, lo[0], lo[1]} : uint4{hi[0], hi[1], g0, g1};
+          }
           const int c = t * fd + 4 * (hl & ~1);          // first channel of the chunk
-          if (hl < nq && write_row)
+          if ((FD128 || hl < nq) && write_row)
             *reinterpret_cast<uint4*>(orow + (c >> 4) * 64 + (odd ? 32 : 0) + (c & 15) * 2) = chunk;
         }
       }
@@ -696,7 +722,7 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
         ps[2] = uint4{lo[0], 0u, 0u, 0u};
         ps[3] = uint4{0u, 0u, 0u, 0u};
       }
-    } else if (hl < nq && write_row) {
+    } else if ((FD128 || hl < nq) && write_row) {
       *reinterpret_cast<f32x4*>(out + 4 * hl) = mean;
       *reinterpret_cast<f32x4*>(out + fd + 4 * hl) = var;
     }
@@ -748,7 +774,8 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   if (d.out_stride < chans || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
   if (d.out_split) {      // default options' batched kernel only; whole slabs; score_max on a slab boundary
     const int nsel_ = d.K == 0 ? d.V : d.K;
-    if (!dflt || nsel_ > 4 || d.feature_dim % 8 != 0 || d.out_stride < ((chans + 15) / 16) * 16)
+    if (!dflt || nsel_ > 4 || d.feature_dim % 8 != 0 || d.out_stride < ((chans + 15) / 16) * 16 ||
+        (int64_t)d.B * d.V * d.h * d.w * d.C * 4 >= (1LL << 32))
       return SNAP_ERR_UNSUPPORTED;
   }
   if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;  // K>0 means V > K
@@ -788,10 +815,15 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
     a.tiles_total = (int64_t)d.B * a.tiles_x * a.tiles_y;
     bgrid = dim3((unsigned)(snap_cdiv(a.tiles_total, 8) * 8 * a.tile_cpt));
   }
-  if (dflt && batched && nsel <= 1) {
-    hipLaunchKernelGGL(lift_pool_batched_kernel<1>, bgrid, dim3(256), 0, s, a);
-  } else if (dflt && batched && nsel <= 4) {
-    hipLaunchKernelGGL(lift_pool_batched_kernel<4>, bgrid, dim3(256), 0, s, a);
+  // (the batched kernels address the taps by 32-bit byte offsets: f_images < 4 GB)
+  const bool small = (int64_t)d.B * d.V * d.h * d.w * d.C * 4 < (1LL << 32);
+  const bool fd128 = d.feature_dim == 128;
+  if (dflt && batched && small && nsel <= 1) {
+    if (fd128) hipLaunchKernelGGL((lift_pool_batched_kernel<1, true>), bgrid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lift_pool_batched_kernel<1, false>), bgrid, dim3(256), 0, s, a);
+  } else if (dflt && batched && small && nsel <= 4) {
+    if (fd128) hipLaunchKernelGGL((lift_pool_batched_kernel<4, true>), bgrid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lift_pool_batched_kernel<4, false>), bgrid, dim3(256), 0, s, a);
   } else if (nsel <= 1) {
     hipLaunchKernelGGL(lift_pool_kernel<1>, grid, dim3(256), 0, s, a);
   } else if (nsel <= 4) {
