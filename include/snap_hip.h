@@ -241,6 +241,10 @@ int snap_group_norm_stats_from_partial_f32(const float* partial, int32_t N, int3
 size_t snap_compact_rows_workspace_bytes(int64_t M);
 int snap_compact_rows_u8(const uint8_t* mask, int64_t M, int32_t* index, int32_t* count,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same list for the rows with lo <= mask[m] <= hi (classed masks: SnapLiftDesc.class_rows). */
+int snap_compact_rows_range_u8(const uint8_t* mask, int64_t M, int32_t lo, int32_t hi,
+                               int32_t* index, int32_t* count, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ---- fusion MLP + vertical max pooling in one kernel (mlp_pool.hip) --------------------
  * The two Dense layers of StreetViewEncoder.fusion_mlp (streetview_encoder.py:279-286,
@@ -266,6 +270,20 @@ int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, int32_t x_str
                            const void* w1_split, size_t w1_bytes, const float* b1, int32_t D,
                            int32_t relu_in, int32_t x_split, int32_t Z, int64_t ncols,
                            float* plane, uint8_t* pvalid, void* stream);
+/* Two row classes into ONE plane: `rows` as above, and `rows_z` (may be NULL) whose rows are
+ * exactly zero over the 16-channel slabs [zero_slab_lo, zero_slab_lo + zero_slabs) of the
+ * first Dense layer's input and need not hold them in memory (single-observation rows of a
+ * lift with SnapLiftDesc.class_rows: the variance slabs).  Those slabs are not read and not
+ * multiplied for that class -- a product with +0 leaves an f32 accumulator unchanged, so the
+ * plane equals the one-list result bit for bit; max is order-independent across the two. */
+int snap_mlp2_pool_max_classes_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                                   const int32_t* rows, const int32_t* row_count,
+                                   const int32_t* rows_z, const int32_t* row_count_z,
+                                   int32_t zero_slab_lo, int32_t zero_slabs,
+                                   const void* w0_split, size_t w0_bytes, const float* b0, int32_t H,
+                                   const void* w1_split, size_t w1_bytes, const float* b1, int32_t D,
+                                   int32_t relu_in, int32_t x_split, int32_t Z, int64_t ncols,
+                                   float* plane, uint8_t* pvalid, void* stream);
 
 /* y[m, 0..C) = value for every row with mask[m] == 0 (the masked voxels of a volume
  * whose observed rows were written through rows_out).  C % 4 == 0. */
@@ -356,6 +374,15 @@ typedef struct SnapLiftDesc {
    * lo = bf16(v - hi)), out_stride (in floats) >= 16 * slabs -- what snap_mlp2_pool_max_f32
    * takes with x_split = 1.  Default fusion options, <= 4 selected views, feature_dim % 8 == 0. */
   int32_t out_split;
+  /* 1 (with out_split; feature_dim % 16 == 0): rows are CLASSED by their number of visible
+   * observations -- valid[] = 0 invalid, 1 one observation, 2 several -- and a one-observation
+   * row does not write its variance slabs (slabs feature_dim/16 .. 2 feature_dim/16 - 1: the
+   * weighted variance of a single observation is exactly 0; 72 % of the observed voxels of a
+   * four-view map and every voxel of the query).  The consumer lists the two classes
+   * separately (snap_compact_rows_range_u8) and skips those slabs for the first
+   * (snap_mlp2_pool_max_classes_f32): 47 % fewer bytes written and re-read for such a row, same
+   * plane bits (products with +0 leave an accumulator unchanged). */
+  int32_t class_rows;
 } SnapLiftDesc;
 
 /* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) tan(max_fov/2)(1) ALREADY scaled to

@@ -49,6 +49,7 @@ class SnapLiftDesc(ctypes.Structure):
       ('max_view_distance', c_float),
       ('weighted', c_int), ('use_variance', c_int), ('add_minmax', c_int),
       ('grid_y', c_int), ('grid_z', c_int), ('valid_rows_only', c_int), ('out_split', c_int),
+      ('class_rows', c_int),
   ]
 
 
@@ -100,6 +101,10 @@ SIGNATURES = {
     ),
     'snap_compact_rows_workspace_bytes': (c_size, [c_i64]),
     'snap_compact_rows_u8': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_size, ptr]),
+    'snap_compact_rows_range_u8': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, ptr]),
+    'snap_mlp2_pool_max_classes_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, ptr, c_int, c_int,
+                                               ptr, c_size, ptr, c_int, ptr, c_size, ptr, c_int, c_int,
+                                               c_int, c_int, c_i64, ptr, ptr, ptr]),
     'snap_mlp2_pool_max_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, ptr, c_int,
                                        ptr, c_size, ptr, c_int, c_int, c_int, c_int, c_i64, ptr, ptr, ptr]),
     'snap_fill_masked_rows_f32': (c_int, [ptr, ptr, c_i64, c_int, c_float, ptr]),
@@ -246,7 +251,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 

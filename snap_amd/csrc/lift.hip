@@ -709,7 +709,9 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
             chunk = odd ? uint4{g0, g1, lo[0], lo[1]} : uint4{hi[0], hi[1], g0, g1};
           }
           const int c = t * fd + 4 * (hl & ~1);          // first channel of the chunk
-          if ((FD128 || hl < nq) && write_row)
+          // (class_rows: the variance slabs of a single-observation row are all zero, the
+          //  consumer skips them -- they are not written)
+          if ((FD128 || hl < nq) && write_row && !(t == 1 && d.class_rows && nvis == 1))
             *reinterpret_cast<uint4*>(orow + (c >> 4) * 64 + (odd ? 32 : 0) + (c & 15) * 2) = chunk;
         }
       }
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
       }
       bool vld = nvis > 0;
       if (d.max_view_distance >= 0.f && !all_views) vld = vld && (min_dist <= d.max_view_distance);
-      a.valid[gv] = vld ? 1 : 0;
+      a.valid[gv] = vld ? (d.class_rows && nvis > 1 ? 2 : 1) : 0;
     }
   }
 }
@@ -778,6 +780,7 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
         (int64_t)d.B * d.V * d.h * d.w * d.C * 4 >= (1LL << 32))
       return SNAP_ERR_UNSUPPORTED;
   }
+  if (d.class_rows && (!d.out_split || d.feature_dim % 16 != 0)) return SNAP_ERR_UNSUPPORTED;
   if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;  // K>0 means V > K
   if (!(d.depth_max > d.depth_min) || !(d.depth_min > 0.f)) return SNAP_ERR_BAD_SHAPE;
   if ((reinterpret_cast<uintptr_t>(f_images) & 15) || (reinterpret_cast<uintptr_t>(pooled) & 15))
@@ -818,10 +821,11 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   // (the batched kernels address the taps by 32-bit byte offsets: f_images < 4 GB)
   const bool small = (int64_t)d.B * d.V * d.h * d.w * d.C * 4 < (1LL << 32);
   const bool fd128 = d.feature_dim == 128;
-  if (dflt && batched && small && nsel <= 1) {
+  const bool use_b = (batched || d.out_split) && dflt && small;   // (out_split exists there only)
+  if (use_b && nsel <= 1) {
     if (fd128) hipLaunchKernelGGL((lift_pool_batched_kernel<1, true>), bgrid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((lift_pool_batched_kernel<1, false>), bgrid, dim3(256), 0, s, a);
-  } else if (dflt && batched && small && nsel <= 4) {
+  } else if (use_b && nsel <= 4) {
     if (fd128) hipLaunchKernelGGL((lift_pool_batched_kernel<4, true>), bgrid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((lift_pool_batched_kernel<4, false>), bgrid, dim3(256), 0, s, a);
   } else if (nsel <= 1) {

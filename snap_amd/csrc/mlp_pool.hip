@@ -53,6 +53,9 @@ struct MlpPoolArgs {
   int D;
   int Z;                   // levels per column: column id = row / Z
   float* plane;            // [ncols, D]
+  // GEMM0 slabs [skip_lo, skip_lo + skip_n) are not visited: the listed rows hold exact zeros
+  // there (and may not have written them): single-observation rows, SnapLiftDesc.class_rows
+  int skip_lo, skip_n;
 };
 
 // hi / lo bf16 parts of four f32 (as conv_split.hip: one v_cvt_pk per pair, exact residual)
@@ -205,12 +208,13 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
       __builtin_amdgcn_global_load_lds((cglobal_void_t*)(xs_px[i] + (r_ok[i] ? s_ * 64 : 0)),
                                        (lds_void_t*)(sm + buf * A_ST + (tid + 256 * i) * 16), 16, 0, 0);
   };
+  const int s_first = a.skip_lo > 0 ? 0 : a.skip_n;
   if constexpr (XSPLIT) {
-    issue_a(0, 0);
-    issue_b0(0, 0);
+    issue_a(0, s_first);
+    issue_b0(0, s_first);
   } else {
-    load_a(0);
-    issue_b0(0, 0);
+    load_a(s_first);
+    issue_b0(0, s_first);
     store_a(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -221,13 +225,14 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
                            : R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
   const int a_lo_off = XSPLIT ? R * 64 + (((2 + lhi) ^ ((R >> 1) & 3)) * 16) : a_off + A_PART;
   const int w_off = l31 * 32 + ((lhi ^ ((l31 >> 3) & 1)) * 16);   // column 32 t' + l31 of a 128-tile
-  const int nk0 = a.ctiles0;
+  const int nk0 = a.ctiles0 - a.skip_n;
   for (int kt = 0; kt < nk0; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk0;
     if (more) {
-      if constexpr (XSPLIT) issue_a(cur ^ 1, kt + 1); else load_a(kt + 1);
-      issue_b0(cur ^ 1, kt + 1);
+      const int sn = kt + 1 < a.skip_lo ? kt + 1 : kt + 1 + a.skip_n;    // the next visited slab
+      if constexpr (XSPLIT) issue_a(cur ^ 1, sn); else load_a(sn);
+      issue_b0(cur ^ 1, sn);
     }
     const char* bs = sm + kB0 + cur * B0_ST + w_off;
     const bf16x8 x_hi = *reinterpret_cast<const bf16x8*>(sm + cur * A_ST + a_off);
@@ -412,15 +417,10 @@ __global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, in
 
 }  // namespace
 
-extern "C" int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
-                                      const int32_t* rows, const int32_t* row_count,
-                                      const void* w0_split, size_t w0_bytes, const float* b0,
-                                      int32_t H, const void* w1_split, size_t w1_bytes,
-                                      const float* b1, int32_t D, int32_t relu_in, int32_t x_split,
-                                      int32_t Z, int64_t ncols, float* plane, uint8_t* pvalid,
-                                      void* stream) {
-  if (!x || !rows || !row_count || !w0_split || !b0 || !w1_split || !b1 || !plane || !pvalid)
-    return SNAP_ERR_NULL;
+static int mlp2_pool_check(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                           const void* w0_split, size_t w0_bytes, int32_t H, const void* w1_split,
+                           size_t w1_bytes, int32_t D, int32_t relu_in, int32_t x_split, int32_t Z,
+                           int64_t ncols, const float* plane) {
   if (M <= 0 || M > 0x7fffffffLL || Cin <= 0 || x_stride < Cin || x_stride % 4 != 0 || Z <= 0 ||
       ncols <= 0 || ncols * Z > 0x7fffffffLL)
     return SNAP_ERR_BAD_SHAPE;
@@ -432,19 +432,12 @@ extern "C" int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, in
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w0_split) |
        reinterpret_cast<uintptr_t>(w1_split) | reinterpret_cast<uintptr_t>(plane)) & 15)
     return SNAP_ERR_BAD_SHAPE;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t n4 = ncols * (D / 4);
-  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s, plane, n4,
-                     -INFINITY);
-  SNAP_CHECK_LAUNCH();
-  MlpPoolArgs a;
-  a.x = x; a.x_stride = x_stride; a.Cin = Cin;
-  a.rows = rows; a.row_count = row_count; a.M = (int)M;
-  a.w0 = static_cast<const char*>(w0_split); a.ctiles0 = (Cin + 15) / 16; a.b0 = b0; a.H = H;
-  a.w1 = static_cast<const char*>(w1_split); a.b1 = b1; a.D = D;
-  a.Z = Z; a.plane = plane;
-  const dim3 grid((unsigned)snap_cdiv(M, 128));
-  if (H <= 128) {
+  return SNAP_OK;
+}
+
+static void mlp2_pool_launch(const MlpPoolArgs& a, int relu_in, int x_split, hipStream_t s) {
+  const dim3 grid((unsigned)snap_cdiv(a.M, 128));
+  if (a.H <= 128) {
     if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true>), grid, dim3(256), 0, s, a);
     else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<128, true, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((mlp2_pool_kernel<128, false, false>), grid, dim3(256), 0, s, a);
@@ -453,9 +446,61 @@ extern "C" int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, in
     else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<256, true, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((mlp2_pool_kernel<256, false, false>), grid, dim3(256), 0, s, a);
   }
+}
+
+extern "C" int snap_mlp2_pool_max_classes_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                                              const int32_t* rows, const int32_t* row_count,
+                                              const int32_t* rows_z, const int32_t* row_count_z,
+                                              int32_t zero_slab_lo, int32_t zero_slabs,
+                                              const void* w0_split, size_t w0_bytes, const float* b0,
+                                              int32_t H, const void* w1_split, size_t w1_bytes,
+                                              const float* b1, int32_t D, int32_t relu_in,
+                                              int32_t x_split, int32_t Z, int64_t ncols, float* plane,
+                                              uint8_t* pvalid, void* stream) {
+  if (!x || !rows || !row_count || !w0_split || !b0 || !w1_split || !b1 || !plane || !pvalid)
+    return SNAP_ERR_NULL;
+  if ((rows_z == nullptr) != (row_count_z == nullptr)) return SNAP_ERR_NULL;
+  const int st = mlp2_pool_check(x, M, Cin, x_stride, w0_split, w0_bytes, H, w1_split, w1_bytes, D,
+                                 relu_in, x_split, Z, ncols, plane);
+  if (st != SNAP_OK) return st;
+  const int ctiles0 = (Cin + 15) / 16;
+  if (rows_z && (zero_slab_lo < 0 || zero_slabs <= 0 || zero_slab_lo + zero_slabs > ctiles0 ||
+                 zero_slabs >= ctiles0))
+    return SNAP_ERR_BAD_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n4 = ncols * (D / 4);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s, plane, n4,
+                     -INFINITY);
   SNAP_CHECK_LAUNCH();
+  MlpPoolArgs a;
+  a.x = x; a.x_stride = x_stride; a.Cin = Cin;
+  a.rows = rows; a.row_count = row_count; a.M = (int)M;
+  a.w0 = static_cast<const char*>(w0_split); a.ctiles0 = ctiles0; a.b0 = b0; a.H = H;
+  a.w1 = static_cast<const char*>(w1_split); a.b1 = b1; a.D = D;
+  a.Z = Z; a.plane = plane;
+  a.skip_lo = ctiles0; a.skip_n = 0;
+  mlp2_pool_launch(a, relu_in, x_split, s);
+  SNAP_CHECK_LAUNCH();
+  if (rows_z) {           // the rows that are zero over [zero_slab_lo, +zero_slabs): same plane (max)
+    a.rows = rows_z; a.row_count = row_count_z;
+    a.skip_lo = zero_slab_lo; a.skip_n = zero_slabs;
+    mlp2_pool_launch(a, relu_in, x_split, s);
+    SNAP_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(mlp2_pool_finalize_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s,
                      plane, pvalid, ncols, D);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
+}
+
+extern "C" int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                                      const int32_t* rows, const int32_t* row_count,
+                                      const void* w0_split, size_t w0_bytes, const float* b0,
+                                      int32_t H, const void* w1_split, size_t w1_bytes,
+                                      const float* b1, int32_t D, int32_t relu_in, int32_t x_split,
+                                      int32_t Z, int64_t ncols, float* plane, uint8_t* pvalid,
+                                      void* stream) {
+  return snap_mlp2_pool_max_classes_f32(x, M, Cin, x_stride, rows, row_count, nullptr, nullptr, 0, 0,
+                                        w0_split, w0_bytes, b0, H, w1_split, w1_bytes, b1, D, relu_in,
+                                        x_split, Z, ncols, plane, pvalid, stream);
 }

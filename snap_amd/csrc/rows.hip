@@ -15,9 +15,9 @@ constexpr int CR_PER_THREAD = 16;  // mask bytes per thread (one 16-byte load)
 constexpr int CR_BLOCK_ROWS = CR_THREADS * CR_PER_THREAD;
 
 __device__ __forceinline__ int load_flags(const uint8_t* __restrict__ mask, int64_t base, int64_t M,
-                                          uint32_t* bits) {
-  // returns the number of set flags among mask[base .. base+16) (bounds-checked);
-  // *bits has bit e set when mask[base+e] != 0.
+                                          uint32_t lo, uint32_t span, uint32_t* bits) {
+  // returns the number of selected bytes among mask[base .. base+16) (bounds-checked);
+  // *bits has bit e set when lo <= mask[base+e] <= lo + span  (1, 254: mask != 0).
   uint32_t b = 0;
   if (base + CR_PER_THREAD <= M && ((reinterpret_cast<uintptr_t>(mask + base) & 15) == 0)) {
     const uint4 v = *reinterpret_cast<const uint4*>(mask + base);
@@ -26,11 +26,11 @@ __device__ __forceinline__ int load_flags(const uint8_t* __restrict__ mask, int6
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if ((w[i] >> (8 * j)) & 0xffu) b |= 1u << (4 * i + j);
+        if ((((w[i] >> (8 * j)) & 0xffu) - lo) <= span) b |= 1u << (4 * i + j);
   } else {
 #pragma unroll
     for (int e = 0; e < CR_PER_THREAD; ++e)
-      if (base + e < M && mask[base + e]) b |= 1u << e;
+      if (base + e < M && ((uint32_t)mask[base + e] - lo) <= span) b |= 1u << e;
   }
   *bits = b;
   return __popc(b);
@@ -59,11 +59,11 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
 }
 
 __global__ __launch_bounds__(CR_THREADS) void count_rows_kernel(const uint8_t* __restrict__ mask,
-                                                                int64_t M,
+                                                                int64_t M, uint32_t lo, uint32_t span,
                                                                 int32_t* __restrict__ block_count) {
   const int64_t base = ((int64_t)blockIdx.x * CR_THREADS + threadIdx.x) * CR_PER_THREAD;
   uint32_t bits;
-  const int c = load_flags(mask, base, M, &bits);
+  const int c = load_flags(mask, base, M, lo, span, &bits);
   int total;
   block_exclusive_scan(c, &total);
   if (threadIdx.x == 0) block_count[blockIdx.x] = total;
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(CR_THREADS) void scan_blocks_kernel(int32_t* __rest
 }
 
 __global__ __launch_bounds__(CR_THREADS) void write_rows_kernel(const uint8_t* __restrict__ mask,
-                                                                int64_t M,
+                                                                int64_t M, uint32_t lo, uint32_t span,
                                                                 const int32_t* __restrict__ block_off,
                                                                 int32_t* __restrict__ index) {
   const int64_t base = ((int64_t)blockIdx.x * CR_THREADS + threadIdx.x) * CR_PER_THREAD;
   uint32_t bits;
-  const int c = load_flags(mask, base, M, &bits);
+  const int c = load_flags(mask, base, M, lo, span, &bits);
   int total;
   int pos = block_off[blockIdx.x] + block_exclusive_scan(c, &total);
 #pragma unroll
@@ -122,22 +122,29 @@ extern "C" size_t snap_compact_rows_workspace_bytes(int64_t M) {
   return (size_t)(snap_cdiv(M, CR_BLOCK_ROWS) + 1) * sizeof(int32_t);
 }
 
-extern "C" int snap_compact_rows_u8(const uint8_t* mask, int64_t M, int32_t* index, int32_t* count,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int snap_compact_rows_range_u8(const uint8_t* mask, int64_t M, int32_t lo, int32_t hi,
+                                          int32_t* index, int32_t* count, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   if (!mask || !index || !count || !workspace) return SNAP_ERR_NULL;
-  if (M <= 0 || M > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  if (M <= 0 || M > 0x7fffffffLL || lo < 0 || hi > 255 || lo > hi) return SNAP_ERR_BAD_SHAPE;
   if (workspace_bytes < snap_compact_rows_workspace_bytes(M)) return SNAP_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nblocks = (int)snap_cdiv(M, CR_BLOCK_ROWS);
   int32_t* bc = static_cast<int32_t*>(workspace);
-  hipLaunchKernelGGL(count_rows_kernel, dim3(nblocks), dim3(CR_THREADS), 0, s, mask, M, bc);
+  const uint32_t ulo = (uint32_t)lo, span = (uint32_t)(hi - lo);
+  hipLaunchKernelGGL(count_rows_kernel, dim3(nblocks), dim3(CR_THREADS), 0, s, mask, M, ulo, span, bc);
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(CR_THREADS), 0, s, bc, nblocks, count);
   SNAP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(write_rows_kernel, dim3(nblocks), dim3(CR_THREADS), 0, s, mask, M,
+  hipLaunchKernelGGL(write_rows_kernel, dim3(nblocks), dim3(CR_THREADS), 0, s, mask, M, ulo, span,
                      (const int32_t*)bc, index);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
+}
+
+extern "C" int snap_compact_rows_u8(const uint8_t* mask, int64_t M, int32_t* index, int32_t* count,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return snap_compact_rows_range_u8(mask, M, 1, 255, index, count, workspace, workspace_bytes, stream);
 }
 
 extern "C" int snap_fill_masked_rows_f32(float* y, const uint8_t* mask, int64_t M, int32_t C,

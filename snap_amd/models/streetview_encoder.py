@@ -117,7 +117,7 @@ class StreetViewEncoder(base.Module):
     kw = dict(K=K, fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
               num_bins=cfg.num_scale_bins, depth_min_max=cfg.depth_min_max,
               max_view_distance=cfg.get('max_view_distance'))
-    fused = split = False
+    fused = split = classed = False
     if base.needs_grad(f_images):
       if not self.default_fusion:
         raise NotImplementedError('non-default fusion options have no backward kernel yet')
@@ -131,24 +131,30 @@ class StreetViewEncoder(base.Module):
                and cfg.feature_dim % 8 == 0 and (K or V) <= 4)
       if fused:                              # the fused kernel reads the rows of valid voxels only,
         kw.update(valid_rows_only=True, out_split=split)   # pre-split: its A operand goes by LDS-DMA
+        # rows classed by their number of observations: one observation (most voxels of a map,
+        # every voxel of the query) = zero variance, neither written nor read nor multiplied
+        classed = split and ops.CLASS_ROWS and cfg.feature_dim % 16 == 0
+        kw.update(class_rows=classed)
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))
     if self.depth_mlp is not None:
       pooled, valid = self._lift_with_depth_mlp(params, f_images, cameras, scene_t_view, xyz_flat, K, train)
     else:
-      pooled, valid = lift(
+      pooled, valid, *classes = lift(
           f_images, cameras.packed().to(torch.float32),
           scene_t_view.packed().to(torch.float32), xyz_flat, **kw,
       )
     grid_shape = (-1, *xyz.shape[-4:-1])
     if fused:
       p = params['fusion_mlp']
+      nvar = cfg.feature_dim // 16                      # (the variance slabs follow the mean's)
       plane, pvalid = ops.mlp2_pool_max(
-          pooled.reshape(-1, pooled.shape[-1]), valid.reshape(-1),
+          pooled.reshape(-1, pooled.shape[-1]), (classes[0] if classed else valid).reshape(-1),
           p['Dense_0']['kernel'], p['Dense_0']['bias'], p['Dense_1']['kernel'], p['Dense_1']['bias'],
           cin=self.fusion_mlp.in_dim, Z=grid_shape[-1],
-          relu_in=bool(cfg.fusion.apply_input_activation), x_split=split)
+          relu_in=bool(cfg.fusion.apply_input_activation), x_split=split,
+          zero_slabs=(nvar, nvar) if classed else None)
       pred['feature_volume'] = types.FeatureVolume(features=None, valid=valid.reshape(grid_shape))
       pred['feature_plane'] = types.FeaturePlane(
           features=plane.reshape(*grid_shape[:-1], plane.shape[-1]),

@@ -29,6 +29,8 @@ def _stream():
 OVERLAP_AERIAL = os.environ.get('SNAP_OVERLAP_AERIAL', '1') != '0'
 # the lift hands `pooled` to the fused MLP / pool kernel pre-split (LDS-DMA A operand); 0: as f32 rows
 POOLED_SPLIT = os.environ.get('SNAP_POOLED_SPLIT', '1') != '0'
+# ... and classed by their number of observations (single-observation rows carry no variance slabs); 0: off
+CLASS_ROWS = os.environ.get('SNAP_CLASS_ROWS', '1') != '0'
 _SIDE_STREAM = None
 
 
@@ -533,9 +535,10 @@ def gelu(x):
   return y
 
 
-def compact_rows(mask):
+def compact_rows(mask, lo=1, hi=255):
   """mask [...] (bool/uint8) -> (index int32 [M] -- first `count` entries valid, ascending --
-  and count int32 [1]); everything stays on the device."""
+  and count int32 [1]) of the rows with lo <= mask <= hi (default: mask != 0); everything stays
+  on the device."""
   lib = _lib.load()
   _mask(mask, 'mask')
   M = mask.numel()
@@ -543,9 +546,9 @@ def compact_rows(mask):
   ws = torch.empty(wsb // 4 + 4, dtype=torch.int32, device=mask.device)
   index = torch.empty(M, dtype=torch.int32, device=mask.device)
   count = torch.empty(1, dtype=torch.int32, device=mask.device)
-  st = lib.snap_compact_rows_u8(_p(mask), M, _p(index), _p(count), _p(ws), ws.numel() * 4,
-                                _stream())
-  _lib.check(st, 'snap_compact_rows_u8')
+  st = lib.snap_compact_rows_range_u8(_p(mask), M, int(lo), int(hi), _p(index), _p(count), _p(ws),
+                                      ws.numel() * 4, _stream())
+  _lib.check(st, 'snap_compact_rows_range_u8')
   return index, count
 
 
@@ -554,14 +557,19 @@ def mlp2_pool_supported(cin, hidden, out_dim):
   return hidden % 32 == 0 and hidden <= 256 and out_dim % 4 == 0 and out_dim <= 128 and cin >= 4
 
 
-def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False):
+def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False,
+                  zero_slabs=None):
   """Fusion MLP (Dense -> relu -> Dense) over the rows with row_mask != 0 + max over the Z
   levels of every column, in one kernel on the bf16x3 engine (streetview_encoder.py:279-286 +
   bev_mapper.py:78-88).  x [M, Cs] (M = columns * Z, level fastest), row_mask [M];
   w0 [cin, H], w1 [H, D] -> plane [M / Z, D] f32, pvalid [M / Z] bool.  The hidden activations
   and the [M, D] volume are never written.  ``x_split``: x holds the rows pre-split
   (``lift_pool(out_split=True)``: [16-channel slab][hi | lo][16] bf16 in an f32 container); same
-  bits, the kernel's A operand then travels by LDS-DMA."""
+  bits, the kernel's A operand then travels by LDS-DMA.  ``zero_slabs`` = (first, count):
+  row_mask is a CLASS per row (uint8, ``lift_pool(class_rows=True)``): rows of class 1 are exactly
+  zero over those 16-channel slabs (and did not write them), rows of class >= 2 are complete --
+  two row lists into one plane, the zero slabs of the first neither read nor multiplied; the same
+  plane bit for bit."""
   lib = _lib.load()
   _f32(x, 'x'); _mask(row_mask, 'row_mask')
   for t, n in ((w0, 'w0'), (b0, 'b0'), (w1, 'w1'), (b1, 'b1')):
@@ -572,21 +580,36 @@ def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split
     raise ValueError('mlp2_pool_max: shapes')
   if not mlp2_pool_supported(cin, H, D):
     raise ValueError(f'mlp2_pool_max: unsupported widths {cin} -> {H} -> {D}')
-  index, count = compact_rows(row_mask)
+  if zero_slabs is None:
+    index, count = compact_rows(row_mask)
+    index_z = count_z = None
+    zlo = zn = 0
+  else:
+    if row_mask.dtype != torch.uint8:
+      raise ValueError('mlp2_pool_max: zero_slabs needs the uint8 row classes')
+    zlo, zn = int(zero_slabs[0]), int(zero_slabs[1])
+    index, count = compact_rows(row_mask, 2, 255)
+    index_z, count_z = compact_rows(row_mask, 1, 1)
   w0p = pack_weights_split_bf16(w0.reshape(1, 1, cin, H), 2)
   w1p = pack_weights_split_bf16(w1.reshape(1, 1, H, D), 2)
   ncols = M // Z
   plane = torch.empty(ncols, D, dtype=torch.float32, device=x.device)
   pvalid = torch.empty(ncols, dtype=torch.bool, device=x.device)
   kflops = 2.0 * (cin * H + H * D)
-  with _region('mlp2_pool_bf16x3', lambda: kflops * int(count.item()),
-               lambda: 4.0 * (int(count.item()) * cin + plane.numel()),
+  kflops_z = 2.0 * ((cin - 16 * zn) * H + H * D)
+
+  def rows_():
+    return int(count.item()), (int(count_z.item()) if count_z is not None else 0)
+
+  with _region('mlp2_pool_bf16x3', lambda: kflops * rows_()[0] + kflops_z * rows_()[1],
+               lambda: 4.0 * (rows_()[0] * cin + rows_()[1] * (cin - 16 * zn) + plane.numel()),
                lambda: f'M{M}r_K{cin}_H{H}_N{D}_Z{Z}'):
-    st = lib.snap_mlp2_pool_max_f32(
-        _p(x), M, cin, Cs, _p(index), _p(count), _p(w0p), w0p.numel() * 2, _p(b0), H,
+    st = lib.snap_mlp2_pool_max_classes_f32(
+        _p(x), M, cin, Cs, _p(index), _p(count), _p(index_z) if index_z is not None else None,
+        _p(count_z) if count_z is not None else None, zlo, zn, _p(w0p), w0p.numel() * 2, _p(b0), H,
         _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), int(bool(x_split)), Z, ncols, _p(plane),
         _p(pvalid), _stream())
-  _lib.check(st, 'snap_mlp2_pool_max_f32')
+  _lib.check(st, 'snap_mlp2_pool_max_classes_f32')
   return plane, pvalid
 
 
@@ -732,7 +755,8 @@ def pooled_stride(feature_dim, weighted=True, use_variance=True, add_minmax=Fals
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
-              add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False):
+              add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False,
+              class_rows=False):
   """Fused k1-k5.  f_images [B,V,h,w,C]; cam [B,V,11]; Rt [B,V,12]; points [B,N,3].
 
   K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad by default;
@@ -743,6 +767,9 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   only for consumers that read the rows of valid voxels.  ``out_split``: rows are written
   pre-split for the split-bf16 engines ([16-channel slab][hi | lo][16] bf16, returned in an f32
   container of 16 * slabs floats per row) -- ``mlp2_pool_max(x_split=True)`` takes them.
+  ``class_rows`` (with out_split): a third result, classes [B,N] uint8 = 0 invalid / 1 one visible
+  observation / 2 several, and rows of class 1 do not write their (all-zero) variance slabs --
+  ``mlp2_pool_max(zero_slabs=(fd / 16, fd / 16))`` takes the classes as its row mask.
   """
   lib = _lib.load()
   _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
@@ -752,7 +779,7 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   if out_split:
     stride = (pooled_channels(feature_dim, weighted, use_variance, add_minmax) + 15) // 16 * 16
   pooled = torch.empty((B, N, stride), dtype=torch.float32, device=f_images.device)
-  valid = torch.empty((B, N), dtype=torch.bool, device=f_images.device)
+  valid = torch.empty((B, N), dtype=torch.uint8 if class_rows else torch.bool, device=f_images.device)
   d = _lib.SnapLiftDesc(
       B, V, h, w, C, feature_dim, num_bins if weighted else 0, N, K, int(fisheye), stride,
       float(depth_min_max[0]), float(depth_min_max[1]),
@@ -763,6 +790,7 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
     d.grid_y, d.grid_z = int(grid_yz[0]), int(grid_yz[1])
   d.valid_rows_only = int(bool(valid_rows_only))
   d.out_split = int(bool(out_split))
+  d.class_rows = int(bool(class_rows))
   with _region(
       'lift_pool', 0.0, 4.0 * (f_images.numel() + points.numel() + pooled.numel())
   ):
@@ -771,6 +799,8 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
         _p(valid), _stream(),
     )
   _lib.check(st, 'snap_lift_pool_f32')
+  if class_rows:
+    return pooled, valid != 0, valid
   return pooled, valid
 
 

@@ -664,6 +664,17 @@ def test_lift_bev_tiled_traversal_is_a_pure_reordering(X, Y, Z, K, V):
     lo = (ref - hi.float()).bfloat16()
     assert torch.equal(v3, v0)
     assert torch.equal(parts[..., 0, :].reshape(*ref.shape), hi) and torch.equal(parts[..., 1, :].reshape(*ref.shape), lo)
+    # class_rows: valid[] becomes 0 / 1 (one visible observation) / 2 (several); a class-1 row has
+    # an all-zero variance and does not write those slabs -- everything else is the same bits
+    p4, v4, c4 = ops.lift_pool(*args, grid_yz=(Y, Z), out_split=True, class_rows=True, **kw)
+    assert torch.equal(v4, v0) and torch.equal(c4 != 0, v0) and int(c4.max()) <= 2
+    one, many = c4 == 1, c4 == 2
+    assert int(one.sum()) > 0 and (V == 1 or int(many.sum()) > 0)
+    p4s, p3s = (t.reshape(*t.shape[:2], ks, 16) for t in (p4, p3))
+    nv = fd // 16
+    assert torch.equal(p4s[many], p3s[many])
+    assert torch.equal(p4s[one][:, :nv], p3s[one][:, :nv]) and torch.equal(p4s[one][:, 2 * nv:], p3s[one][:, 2 * nv:])
+    assert float(p3s[one][:, nv:2 * nv].abs().max()) == 0.0      # (the slabs that are skipped ARE zero)
 
 
 def test_project_points():
@@ -749,6 +760,26 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
     ps, vs = ops.mlp2_pool_max(xs.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
                                cin=cin, Z=Z, x_split=True)
     assert torch.equal(vs, vg) and torch.equal(ps, pg), float((ps - pg).abs().max())
+    # two row classes into one plane: class-1 rows are zero over a slab range and hold GARBAGE
+    # there (never read, never multiplied); the plane is the one-list plane of the zeroed rows
+    zlo, zn = (ks - 1) // 2, (ks - 1) // 2
+    cls = md.to(torch.uint8) * (1 + (torch.rand(M, generator=g) > 0.5).to(torch.uint8)).to(DEV)
+    xz = xp.clone()
+    xz[(cls == 1).cpu(), 16 * zlo:16 * (zlo + zn)] = 0
+    want, vwant = ops.mlp2_pool_max(xz.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
+                                    cin=cin, Z=Z)
+    xg = xz.clone()
+    xg[(cls == 1).cpu(), 16 * zlo:16 * (zlo + zn)] = float('nan')
+    got, vgot = ops.mlp2_pool_max(xg.to(DEV), cls, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
+                                  cin=cin, Z=Z, zero_slabs=(zlo, zn))
+    assert torch.equal(vgot, vwant) and torch.equal(got, want), float((got - want).abs().max())
+    hi = xg.bfloat16()
+    lo = (xg - hi.float()).bfloat16()
+    rows = torch.stack([hi.view(M, ks, 16), lo.view(M, ks, 16)], dim=2).contiguous()
+    xs = rows.view(torch.int16).view(M, ks * 32).view(torch.float32).contiguous()
+    got, vgot = ops.mlp2_pool_max(xs.to(DEV), cls, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
+                                  cin=cin, Z=Z, x_split=True, zero_slabs=(zlo, zn))
+    assert torch.equal(vgot, vwant) and torch.equal(got, want), float((got - want).abs().max())
 
 
 @pytest.mark.parametrize('nplanes', [1, 2])
