@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void lift_pool_kernel(const LiftArgs a) {
 //   phase B  for each of the 32 voxels: lane q <-> channels 4q..4q+3: broadcast-read the
 //            records, gather the taps, pool.  Same arithmetic as lift_pool_kernel, same bits.
 // ---------------------------------------------------------------------------
-constexpr int LB_REC = 8;    // dwords per (voxel, slot) record: tap byte offset | packed | wi1 | wj1 | wb1
+constexpr int LB_REC = 4;    // dwords per (voxel, slot) record: tap byte offset | packed | wi1 | wj1  (+ wb1 apart)
 
 // hi / lo bf16 parts of four f32, two per dword (the split of conv_split.hip / mlp_pool.hip)
 __device__ __forceinline__ void split_row_quad(const f32x4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
@@ -452,15 +452,26 @@ __device__ __forceinline__ void split_row_quad(const f32x4& v, unsigned (&hi)[2]
   }
 }
 
+#ifndef SNAP_LIFT_ABLATE
+#define SNAP_LIFT_ABLATE 0     // timing experiments only (wrong results): 1 = no row stores (and what
+#endif                         // feeds them: dead code), 2 = no feature loads, 4 = rows stored into a 4 MB
+                               // window (every instruction stays, no HBM write traffic)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pair_lo(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f32x2 pair_hi(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
 
 // FD128: feature_dim == 128, every lane of the half-wave owns a channel quad (no lane guards)
 template <int KMAX, bool FD128>
-__global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a) {
+__global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kernel(const LiftArgs a) {
+  // 24 KB of LDS at KMAX = 4 (records 16 + bin weights 4 + headers 4): six workgroups per CU, and
+  // the launch bound keeps the registers at six waves per SIMD too (8-dword records, 36 KB: four
+  // waves per SIMD whatever the register count -- measured: no difference, the kernel is bound
+  // by VALU issue, not by the round trips)
   __shared__ __attribute__((aligned(16))) int recs[8][32][KMAX][LB_REC];
+  __shared__ float wbs[8][32][KMAX];
   __shared__ float hdr[8][32][4];   // (-, min_dist, voxel index or -1, visible observations) per voxel
+  __shared__ int cls_cnt[4][KMAX + 2];
+  __shared__ uint8_t order[256];
   const SnapLiftDesc& d = a.d;
   const int hl = threadIdx.x & 31;
   const int hw = threadIdx.x >> 5;
@@ -563,7 +574,8 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
 #pragma unroll
     for (int r = 0; r < KMAX; ++r) {
       if (r >= nsel || kv[r] < 0) continue;
-      int* rec = recs[hw][hl][nvis++];
+      int* rec = recs[hw][hl][nvis];
+      float* wbp = &wbs[hw][hl][nvis++];
       const Taps t = make_taps(kpi[r], kpj[r], d.h, d.w, all_views ? 0 : 1);
       // depth score: two neighbouring log-depth bins
       const float dc = fminf(fmaxf(kdep[r], d.depth_min), d.depth_max);
@@ -577,9 +589,34 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
       rec[1] = kv[r] | ((t.i1 != t.i0) << 8) | ((t.j1 != t.j0) << 9) | (b0 << 10) | (b1 << 18);
       rec[2] = __float_as_int(t.wi1);
       rec[3] = __float_as_int(t.wj1);
-      rec[4] = __float_as_int(c - fl);
+      *wbp = c - fl;
     }
     hdr[hw][hl][3] = __int_as_float(nvis);
+    // The two half-waves of a wave walk their voxels in lock step, so a wave pays for the longer
+    // of the two paths (no observation / one / several + softmax: ~30 / ~160 / ~400 instructions);
+    // in voxel order 36 % of the pairs of a four-view map contain a several-observation voxel.
+    // The workgroup's 256 voxels are therefore ordered by observation count (counting sort:
+    // ballots per wave, wave totals through LDS) and iteration j of half-wave hw takes entry
+    // 8 j + hw of that order: the two halves of a wave get NEIGHBOURS of the sorted list, i.e.
+    // voxels of the same class except at the few class boundaries.  Rows are independent, so
+    // the bits do not change.
+    const int key = live ? nvis : KMAX + 1;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < KMAX + 2; ++c) {
+      const unsigned long long m = __ballot(key == c);
+      if (key == c) rank = __popcll(m & ((1ull << ln) - 1ull));
+      if (ln == 0) cls_cnt[wv][c] = __popcll(m);
+    }
+    __syncthreads();
+    int pos = rank;
+#pragma unroll
+    for (int c = 0; c < KMAX + 2; ++c)
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (c < key || (c == key && w < wv)) pos += cls_cnt[w][c];
+    order[pos] = (uint8_t)threadIdx.x;
   }
   __syncthreads();
 
@@ -594,10 +631,12 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
   const uint32_t Cb = (uint32_t)d.C * 4u, Wb = (uint32_t)d.w * Cb, fdb = (uint32_t)fd * 4u;
   const uint32_t lane_off = 16u * hl;
   for (int j = 0; j < 32; ++j) {
-    const int64_t gv = __float_as_int(hdr[hw][j][2]);
-    if (gv < 0) continue;     // half-wave uniform
-    const float min_dist = hdr[hw][j][1];
-    const int nvis = __float_as_int(hdr[hw][j][3]);     // half-wave uniform
+    const int v = order[8 * j + hw];                    // (half-wave uniform, like all of its fields)
+    const float* vh = &hdr[0][0][0] + 4 * v;
+    const int64_t gv = __float_as_int(vh[2]);
+    if (gv < 0) continue;
+    const float min_dist = vh[1];
+    const int nvis = __float_as_int(vh[3]);
     // Per visible slot: gather + blend right away (16 live tap registers, not 64: occupancy
     // matters more here than loads in flight per wave).  Nothing is zero-initialised and every
     // use is guarded by r < nvis; voxels seen by ONE view skip the softmax (weight e/e == 1
@@ -607,7 +646,7 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
 #pragma unroll
     for (int r = 0; r < KMAX; ++r) {
       if (r >= nvis) continue;   // (nvis <= nsel <= KMAX)
-      const int* rec = recs[hw][j][r];
+      const int* rec = &recs[0][0][0][0] + (v * KMAX + r) * LB_REC;
       const i32x4 q4 = *reinterpret_cast<const i32x4*>(rec);   // byte offset | packed | wi1 | wj1
       const int pk = q4[1];
       const float wi1 = __int_as_float(q4[2]), wj1 = __int_as_float(q4[3]);
@@ -627,20 +666,28 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
       const float u10 = *reinterpret_cast<const float*>(fb + (o10 + c1));
       const float u11 = *reinterpret_cast<const float*>(fb + (o11 + c1));
       if (FD128 || hl < nq) {
+#if SNAP_LIFT_ABLATE & 2
+        const f32x4 a00 = {w00, w01, w10, w11}, a01 = a00, a10 = a00, a11 = a00;
+#else
         const f32x4 a00 = *reinterpret_cast<const f32x4*>(fb + (o00 + lane_off));
         const f32x4 a01 = *reinterpret_cast<const f32x4*>(fb + (o01 + lane_off));
         const f32x4 a10 = *reinterpret_cast<const f32x4*>(fb + (o10 + lane_off));
         const f32x4 a11 = *reinterpret_cast<const f32x4*>(fb + (o11 + lane_off));
+#endif
         const f32x2 p00 = {w00, w00}, p01 = {w01, w01}, p10 = {w10, w10}, p11 = {w11, w11};
         feat[r][0] = ((p00 * pair_lo(a00) + p01 * pair_lo(a01)) + p10 * pair_lo(a10)) + p11 * pair_lo(a11);
         feat[r][1] = ((p00 * pair_hi(a00) + p01 * pair_hi(a01)) + p10 * pair_hi(a10)) + p11 * pair_hi(a11);
       }
-      const float wb1 = __int_as_float(rec[4]), wb0 = 1.f - wb1;
+      const float wb1 = (&wbs[0][0][0])[v * KMAX + r], wb0 = 1.f - wb1;
       const float s0 = ((w00 * t00 + w01 * t01) + w10 * t10) + w11 * t11;
       const float s1 = ((w00 * u00 + w01 * u01) + w10 * u10) + w11 * u11;
       score[r] = wb0 * s0 + wb1 * s1;
     }
+#if SNAP_LIFT_ABLATE & 4
+    float* out = a.pooled + (gv & 4095) * d.out_stride;     // (all rows into 4 MB: no HBM writes)
+#else
     float* out = a.pooled + gv * d.out_stride;
+#endif
     f32x2 mean2[2] = {{0.f, 0.f}, {0.f, 0.f}}, var2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     float smax = 0.f;
     if (nvis == 1) {          // half-wave uniform
@@ -685,7 +732,11 @@ __global__ __launch_bounds__(256) void lift_pool_batched_kernel(const LiftArgs a
     const f32x4 var = {var2[0][0], var2[0][1], var2[1][0], var2[1][1]};
     // (valid_rows_only: a voxel no view sees gets its validity byte, not its 1 KB row of zeros --
     // for consumers that read the rows of valid voxels only, 40 % of the map's voxels at C2)
+#if SNAP_LIFT_ABLATE & 1
+    const bool write_row = false;
+#else
     const bool write_row = nvis > 0 || !d.valid_rows_only;
+#endif
     if (d.out_split) {
       // the row as the split-bf16 engines stage it: [16-channel slab][hi | lo][16] bf16, 64 B per
       // slab (hi = bf16(v), lo = bf16(v - hi): the consumer's own split, done here once) -- the
