@@ -204,6 +204,48 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   }
 }
 
+// The tiled case (statistics emitted by a conv epilogue) with a WORKGROUP per (image, group):
+// the one-wave-per-group form above walks up to ~1000 partial sums in 16 dependent rounds of
+// loads on a grid of N * groups / 4 workgroups (a 256-CU part mostly idle, ~7-12 us per launch,
+// ~100 launches per forward pass); here every thread takes <= 4 of them and the waves' totals
+// are combined in fixed order (deterministic).
+__global__ __launch_bounds__(256) void gn_finalize_tiled_kernel(
+    const float* __restrict__ partial, int S, int HW, int C, int groups, float eps,
+    const float* __restrict__ gamma, float* __restrict__ mu, float* __restrict__ sc,
+    float* __restrict__ rstd_out, int tile_rows) {
+  __shared__ double wsum[4][2];
+  const int i = blockIdx.x;                 // over N * groups
+  const int n = i / groups, g = i - n * groups;
+  const int cpg = C / groups;
+  const int c_lo = g * cpg;
+  const int live = (int)((((int64_t)(n + 1) * HW - 1) / tile_rows) - (((int64_t)n * HW) / tile_rows)) + 1;
+  const int count = live * cpg;
+  double t1 = 0.0, t2 = 0.0;
+  for (int e = threadIdx.x; e < count; e += 256) {
+    const int s = e / cpg, cc = e - s * cpg;
+    const float* pp = partial + (((int64_t)n * S + s) * C + c_lo + cc) * 2;
+    t1 += (double)pp[0];
+    t2 += (double)pp[1];
+  }
+  t1 = wave_sum_f64(t1);
+  t2 = wave_sum_f64(t2);
+  if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6][0] = t1; wsum[threadIdx.x >> 6][1] = t2; }
+  __syncthreads();
+  t1 = ((wsum[0][0] + wsum[1][0]) + wsum[2][0]) + wsum[3][0];
+  t2 = ((wsum[0][1] + wsum[1][1]) + wsum[2][1]) + wsum[3][1];
+  const double cnt = (double)HW;
+  const double mean = t1 / (cnt * cpg);
+  const double m2 = t2 - 2.0 * mean * t1 + cnt * (cpg * mean * mean);
+  const float meanf = (float)mean;
+  const float var = (float)(m2 / (cnt * cpg));
+  const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
+  for (int cc = threadIdx.x; cc < cpg; cc += 256) {
+    mu[(int64_t)n * C + c_lo + cc] = meanf;
+    sc[(int64_t)n * C + c_lo + cc] = rstd * gamma[c_lo + cc];
+    if (rstd_out) rstd_out[(int64_t)n * C + c_lo + cc] = rstd;
+  }
+}
+
 __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total4,
                                 int HW, int C, const float* __restrict__ mu,
                                 const float* __restrict__ sc, const float* __restrict__ beta,
@@ -339,10 +381,9 @@ extern "C" int snap_group_norm_stats_from_partial_f32(const float* partial, int3
   if (!partial || !gamma || !mu || !sc) return SNAP_ERR_NULL;
   if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0) return SNAP_ERR_BAD_SHAPE;
   if (tile_rows <= 0 || HW < tile_rows) return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)snap_cdiv(N * groups, 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), (const float*)nullptr, partial,
-                     HW / tile_rows + 2, HW, C, C, groups, 0, eps, gamma, mu, sc, rstd, N * groups,
-                     tile_rows);
+  hipLaunchKernelGGL(gn_finalize_tiled_kernel, dim3((unsigned)(N * groups)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), partial, HW / tile_rows + 2, HW, C, groups, eps,
+                     gamma, mu, sc, rstd, tile_rows);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
