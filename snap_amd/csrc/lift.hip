@@ -27,6 +27,7 @@ struct LiftArgs {
   // BEV-tiled traversal (d.grid_y > 0): the voxels of an 8 x 8 block of columns (all levels) are
   // the unit an XCD works on
   int tile_cpt;      // 256-voxel chunks per tile (0 = linear order)
+  int tile_log;      // log2 of the tile's side in columns
   int tiles_x, tiles_y;
   int64_t tiles_total;
   SnapLiftDesc d;
@@ -503,8 +504,9 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
     const int Z = d.grid_z, GY = d.grid_y, GX = d.N / (GY * Z);
     const int l = chunk * 256 + hw * 32 + hl;
     const int col = l / Z, z = l - col * Z;
-    const int X = tx * 8 + (col >> 3), Y = ty * 8 + (col & 7);
-    const bool in = col < 64 && X < GX && Y < GY;
+    const int tl = a.tile_log, ts = 1 << tl;
+    const int X = tx * ts + (col >> tl), Y = ty * ts + (col & (ts - 1));
+    const bool in = col < ts * ts && X < GX && Y < GY;
     my_gv = in ? (((int64_t)b * GX + X) * GY + Y) * Z + z : -1;
   } else {
     if (a.xcd_group > 0) {
@@ -841,7 +843,7 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
     const char* e = getenv("SNAP_LIFT_XCD_GROUP");
     return e ? atoi(e) : 64;
   }();
-  LiftArgs a{xcd_group, 0, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr};
+  LiftArgs a{xcd_group, 0, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr};
   const int64_t total = (int64_t)d.B * d.N;
   if (total > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   if (d.grid_y < 0 || d.grid_z < 0 || (d.grid_y > 0) != (d.grid_z > 0)) return SNAP_ERR_BAD_SHAPE;
@@ -863,9 +865,16 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   }();
   if (bev_tiles && d.grid_y > 0) {
     const int GX = d.N / (d.grid_y * d.grid_z);
-    a.tile_cpt = (64 * d.grid_z + 255) / 256;
-    a.tiles_x = (GX + 7) / 8;
-    a.tiles_y = (d.grid_y + 7) / 8;
+    static const int tile_log = []() {
+      const char* e = getenv("SNAP_LIFT_TILE_LOG");    // tile side = 2^n columns (default 8)
+      const int v = e ? atoi(e) : 3;
+      return v < 1 ? 1 : (v > 5 ? 5 : v);
+    }();
+    const int ts = 1 << tile_log;
+    a.tile_log = tile_log;
+    a.tile_cpt = (ts * ts * d.grid_z + 255) / 256;
+    a.tiles_x = (GX + ts - 1) / ts;
+    a.tiles_y = (d.grid_y + ts - 1) / ts;
     a.tiles_total = (int64_t)d.B * a.tiles_x * a.tiles_y;
     bgrid = dim3((unsigned)(snap_cdiv(a.tiles_total, 8) * 8 * a.tile_cpt));
   }
@@ -905,7 +914,7 @@ static int launch_obs(const SnapLiftDesc& d, const float* f_images, const float*
   if ((int64_t)d.B * d.N > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   const int nsel = d.K == 0 ? d.V : d.K;
   if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
-  LiftArgs a{0, 0, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, obs_out, obs_feat, obs_in};
+  LiftArgs a{0, 0, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, obs_out, obs_feat, obs_in};
   const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
   if (nsel <= 1) hipLaunchKernelGGL(lift_pool_kernel<1>, grid, dim3(256), 0, s, a);
   else if (nsel <= 4) hipLaunchKernelGGL(lift_pool_kernel<4>, grid, dim3(256), 0, s, a);
