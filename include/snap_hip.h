@@ -108,6 +108,15 @@ typedef struct SnapConvExtras {
                                  of an RGB image stored with 4 floats per pixel (Cin = 3,
                                  Cin_stride = 4): w_bf16 = snap_conv2d_pack_weights_split_root_bf16,
                                  a K slab = 4 consecutive pixels of one kernel row */
+  float* gn_partial2;         /* with gn_partial (gn_partial_relu = 0): a second buffer of the same
+                                 size that MAY receive the partial sums of relu(y) -- for an output
+                                 read by a GroupNorm->ReLU layer AND a ReLU->GroupNorm layer (the
+                                 last unit of a ResNet stage: next stage / FPN level).  A request,
+                                 honoured by one kernel variant (split-bf16 engine, GroupNorm->ReLU
+                                 prologue, 128 x 128 tiles): */
+  size_t gn_partial2_bytes;
+  int32_t gn_partial2_done;   /* OUT: 1 if gn_partial2 was written by this launch, else 0 (take
+                                 snap_group_norm_stats_f32 for the second statistic) */
 } SnapConvExtras;
 
 int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,

@@ -37,6 +37,7 @@ class SnapConvExtras(ctypes.Structure):
       ('gn_partial_bytes', c_size), ('gn_partial_relu', c_int),
       ('workspace', ptr), ('workspace_bytes', c_size),
       ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
+      ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
   ]
 
 
@@ -251,7 +252,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 

@@ -31,6 +31,8 @@ struct ConvArgs {
   int slabs_per_split;
   int tiles_per_split;       // workgroups of one split (multiple of 8)
   float* gn_partial;         // optional: per-(image, row tile, channel) sums of y and y^2
+  float* gn_partial2;        // optional, with gn_partial (gn_relu = 0): the same sums of relu(y)
+  int32_t* gn_partial2_done; // HOST pointer (launcher only): 1 when the launch emits gn_partial2
   int gn_relu;               // ... of relu(y) (FPN order)
   int gn_slabs;              // row tiles per image in gn_partial (= HoWo / BM + 2)
   int M;       // N*Ho*Wo  (upper bound of the row count when row_count is set)
@@ -84,7 +86,7 @@ __device__ __forceinline__ float snap_gelu_tanh(float x) {
 }
 
 // ---- epilogue ------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, bool DUAL = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / 64][BN / 64],
                                               float* smem, int m0, int n0, int Meff, int row_t,
                                               int split) {
@@ -114,6 +116,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
   const int m_split = (n_first + 1) * HoWo;   // first row of the second image
   float gs1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float gs2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // a tensor read by a GroupNorm -> ReLU layer AND a ReLU -> GroupNorm layer (the last unit of a
+  // ResNet stage: next stage / FPN level) gets both statistics out of the one epilogue
+  // (DUAL is a template flag of the one kernel variant that is launched for such layers: as a
+  //  run-time option it cost every conv kernel 20 registers)
+  const bool want_relu_too = DUAL && want_stats;
+  float hs1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float hs2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int h = 0; h < TM; ++h) {
     if (h > 0) __syncthreads();
@@ -194,6 +203,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
           const float t = a.gn_relu ? fmaxf(v[e], 0.f) : v[e];
           gs1[sl][e] += t;
           gs2[sl][e] += t * t;
+          if constexpr (DUAL) {
+            const float r = fmaxf(v[e], 0.f);
+            hs1[sl][e] += r;
+            hs2[sl][e] += r * r;
+          }
         }
       }
     }
@@ -202,14 +216,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     // fixed-order reduction over the 256/Q row groups through LDS, then one writer per
     // (image slot, column): deterministic.
     constexpr int RG = 256 / Q;
-    __syncthreads();
     const int q = tid % Q, rg = tid / Q;
+    for (int pass = 0; pass < (want_relu_too ? 2 : 1); ++pass) {
+    float* const dst_partial = pass ? a.gn_partial2 : a.gn_partial;
+    __syncthreads();
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 0] = gs1[sl][e];
-        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 1] = gs2[sl][e];
+        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 0] = pass ? hs1[sl][e] : gs1[sl][e];
+        smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 1] = pass ? hs2[sl][e] : gs2[sl][e];
       }
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
@@ -226,9 +242,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
         t2 += smem[((r * 2 + sl) * BN + c) * 2 + 1];
       }
       const int slab = row_t - (int)(((int64_t)n * HoWo) / BM);
-      float* o = a.gn_partial + (((int64_t)n * a.gn_slabs + slab) * d.Cout + col) * 2;
+      float* o = dst_partial + (((int64_t)n * a.gn_slabs + slab) * d.Cout + col) * 2;
       o[0] = t1;
       o[1] = t2;
+    }
     }
   }
 }

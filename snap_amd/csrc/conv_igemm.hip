@@ -649,6 +649,15 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.rows_in = rows_in; a.rows_out = rows_out; a.row_count = row_count;
   a.gn_partial = gn_partial;
   a.gn_relu = ex ? ex->gn_partial_relu : 0;
+  a.gn_partial2 = nullptr;
+  a.gn_partial2_done = nullptr;
+  if (gn_partial && ex->gn_partial2) {
+    if (a.gn_relu || ex->gn_partial2_bytes < snap_conv2d_gn_partial_bytes(desc)) return SNAP_ERR_WORKSPACE;
+    a.gn_partial2 = ex->gn_partial2;
+    // (an output field of the caller's struct: set by the engine that honours the request)
+    a.gn_partial2_done = const_cast<int32_t*>(&ex->gn_partial2_done);
+    *a.gn_partial2_done = 0;
+  }
   a.kpartial = ex ? static_cast<float*>(ex->workspace) : nullptr;
   a.kpartial_bytes = ex ? ex->workspace_bytes : 0;
   if (reinterpret_cast<uintptr_t>(a.kpartial) & 15) a.kpartial = nullptr;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, u32x2 (&out)[NS]) {
 // channel 3 carry zero weights: snap_conv2d_pack_weights_split_root_bf16).  The launch sets KW = 2
 // "virtual taps" per kernel row; a thread's quad IS one pixel, so bounds are per thread.  K = 14 x
 // 16 = 224 for 147 real products -- against Cin = 3 padded to a 16-k slab PER TAP (49 slabs).
-template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool ROOT = false>
+template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool ROOT = false, bool DUAL = false>
 __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   constexpr int BK = 16;
   constexpr int TM = BM / 64;
@@ -398,7 +398,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     __syncthreads();
   }
 
-  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
+  conv_epilogue<BM, BN, DUAL>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
 // NS = 2 is held to 128 registers (64 accumulators + 64) so that four workgroups share a CU:
@@ -694,9 +694,9 @@ void launch_halo(const ConvArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((conv3x3_halo_kernel<BN, PRO, NS, 288>), grid, dim3(256), 0, s, a);
 }
 
-template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL>
+template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool DUAL = false>
 __global__ __launch_bounds__(256, NS == 2 ? 4 : 3) void conv_split_kernel(const ConvArgs a) {
-  conv_split_body<BM, BN, PRO, NS, GNT, TAIL>(a);
+  conv_split_body<BM, BN, PRO, NS, GNT, TAIL, false, DUAL>(a);
 }
 
 template <int BN, int PRO, int NS>
@@ -740,6 +740,20 @@ int launch(ConvArgs a, hipStream_t s) {
   if constexpr (BM == 128 && (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_NONE)) {
     if (halo_ok(a)) {
       launch_halo<BN, PRO, NS>(a, grid, s);
+      SNAP_CHECK_LAUNCH();
+      return SNAP_OK;
+    }
+  }
+  // statistics of y AND of relu(y) (ConvArgs.gn_partial2): one kernel variant, the shape of the
+  // closing 1 x 1 conv of a ResNet stage; anywhere else the second buffer is left alone and
+  // *gn_partial2_done stays 0 (the caller then takes the stand-alone statistics pass)
+  bool dual = false;
+  if constexpr (BM == 128 && BN == 128 && PRO == SNAP_PRO_GN_RELU)
+    dual = a.gn_partial2 != nullptr && a.gn_partial != nullptr && table_ok && a.ksplit == 1;
+  if (a.gn_partial2_done) *a.gn_partial2_done = dual ? 1 : 0;
+  if constexpr (BM == 128 && BN == 128 && PRO == SNAP_PRO_GN_RELU) {
+    if (dual) {
+      hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, true, false, true>), grid, dim3(256), 0, s, a);
       SNAP_CHECK_LAUNCH();
       return SNAP_OK;
     }

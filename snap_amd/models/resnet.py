@@ -48,14 +48,17 @@ def _kernels(tree, out):
 
 def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, emit=True, **kw):
   """GroupNorm -> ReLU -> StdConv.  Training: one autograd node (statistics inside);
-  inference: `gn_stats` may be shared between the convs reading the same input."""
+  inference: `gn_stats` may be shared between the convs reading the same input.
+  emit: True -> the statistics of the output come out of the epilogue ('both': also those of
+  relu(output), for an FPN level that reads it ReLU -> GroupNorm)."""
   w = _std(ctx, kernel)
+  mode = None if not emit else ('both' if emit == 'both' else 'raw')
   if base.needs_grad(x, w, gn_p['scale'], gn_p['bias']):
     return ag.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn_params=(gn_p['scale'], gn_p['bias']),
                      emit_gn_stats='raw' if emit else None, **kw)
   # the output feeds the next GroupNorm: its statistics come out of this conv's epilogue
   return ops.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn=gn_stats or _gn(x, gn_p),
-                    emit_gn_stats='raw' if emit else None, **kw)
+                    emit_gn_stats=mode, **kw)
 
 
 def _gn(x, p, relu_first=False):
@@ -63,8 +66,9 @@ def _gn(x, p, relu_first=False):
   return mu, sc, p['bias'].reshape(-1)
 
 
-def residual_unit(ctx, p, x, stride, nmid):
-  """Bottleneck unit (resnet.py:103-132)."""
+def residual_unit(ctx, p, x, stride, nmid, last_of_stage=False):
+  """Bottleneck unit (resnet.py:103-132).  last_of_stage: the output is also an FPN level's
+  input (ReLU -> GroupNorm): the closing conv emits both kinds of statistics."""
   nmid = nmid or x.shape[-1] // 4
   nout = nmid * 4
   train = base.needs_grad(x, p['conv1']['kernel'])
@@ -75,7 +79,8 @@ def residual_unit(ctx, p, x, stride, nmid):
     residual = x
   y = _conv_gn(ctx, x, p['conv1']['kernel'], p['gn1'], gn1)
   y = _conv_gn(ctx, y, p['conv2']['kernel'], p['gn2'], stride=stride, padding=((1, 1), (1, 1)))
-  y = _conv_gn(ctx, y, p['conv3']['kernel'], p['gn3'], residual=residual)
+  y = _conv_gn(ctx, y, p['conv3']['kernel'], p['gn3'], residual=residual,
+               emit='both' if (last_of_stage and ops.GN_STATS_BOTH) else True)
   return y
 
 
@@ -168,7 +173,8 @@ class ResNetV2(base.Module):
       for u in range(size):
         name = f'unit{u + 1:02d}'
         stride = 2 if (u == 0 and i > 0) else 1
-        x = stage[name] = residual_unit(ctx, params[f'block{i + 1}'][name], x, stride, nmid)
+        x = stage[name] = residual_unit(ctx, params[f'block{i + 1}'][name], x, stride, nmid,
+                                        last_of_stage=u + 1 == size)
       out[f'stage{i + 1}'] = stage
     return out
 

@@ -178,9 +178,11 @@ def conv2d(
   gn = (mu [N,Cin], sc [N,Cin], beta [Cin]) for PRO_GN_RELU / PRO_RELU_GN.
   rows_in / rows_out (int32 [M]) + row_count (int32 [1], device): row-indexed launch
   over a compacted row list (see ``compact_rows``); ``out`` supplies the destination.
-  emit_gn_stats = 'raw' | 'relu': the epilogue also emits the partial sums from which
+  emit_gn_stats = 'raw' | 'relu' | 'both': the epilogue also emits the partial sums from which
   ``group_norm_stats(y, ...)`` (same ``relu_first``) builds its result without re-reading
-  y; they travel as ``y._snap_gn_partial``.  Ignored where the shape does not allow it.
+  y; they travel as ``y._snap_gn_partial`` ('both' = 'raw' plus, where the engine has the kernel
+  variant -- split-bf16, GroupNorm -> ReLU prologue, 128 x 128 tiles --, those of relu(y) as
+  ``y._snap_gn_partial_relu``).  Ignored where the shape does not allow it.
   Returns y [N,Ho,Wo,Cout].
   """
   lib = _lib.load()
@@ -236,7 +238,7 @@ def conv2d(
   )
   M = N * Ho * Wo
   ex = None
-  partial = None
+  partial = partial2 = None
   kws = None
   if rows_in is not None or rows_out is not None or row_count is not None:
     ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0,
@@ -252,6 +254,11 @@ def conv2d(
         partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
         ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
                                  int(emit_gn_stats == 'relu'), None, 0, None, 0)
+        if emit_gn_stats == 'both' and (MATMUL_PRECISION if math is None else math) in SPLIT_PARTS:
+          # the statistics of y AND of relu(y): a request (SnapConvExtras.gn_partial2_done)
+          partial2 = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
+          ex.gn_partial2 = partial2.data_ptr()
+          ex.gn_partial2_bytes = pbytes
   math = MATMUL_PRECISION if math is None else math
   if math not in ('f32', 'bf16', 'bf16x3', 'bf16x6'):
     raise ValueError(f'conv2d: math={math!r}')
@@ -302,6 +309,8 @@ def conv2d(
   _lib.check(st, 'snap_conv2d_nhwc_ex_f32')
   if partial is not None:
     y._snap_gn_partial = (partial, lib.snap_conv2d_tile_rows(ctypes.byref(d)), emit_gn_stats == 'relu')
+    if partial2 is not None and ex.gn_partial2_done:
+      y._snap_gn_partial_relu = (partial2, y._snap_gn_partial[1], True)
   return y
 
 
@@ -678,6 +687,8 @@ def weight_standardize_bwd_multi(ws, dwss, eps=1e-10):
 
 
 USE_FUSED_GN_STATS = True
+# the last unit of a ResNet stage emits the statistics of relu(y) too (its FPN level reads them)
+GN_STATS_BOTH = os.environ.get('SNAP_GN_STATS_BOTH', '1') != '0'
 # 'f32': every conv / dense runs on the exact f32 matrix-core path (inference, parity).
 # 'bf16': operands rounded to bf16, f32 accumulate -- the training-precision analogue of the
 # reference's float16 train config (train_localization.py:25); set by the trainer.
@@ -697,6 +708,8 @@ def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False, want_rs
   sc = torch.empty((N, C), dtype=torch.float32, device=x.device)
   rstd = torch.empty((N, C), dtype=torch.float32, device=x.device) if want_rstd else None
   fused = getattr(x, '_snap_gn_partial', None)
+  if fused is not None and fused[2] != bool(relu_first):
+    fused = getattr(x, '_snap_gn_partial_relu', None) if relu_first else None
   if fused is not None and fused[2] == bool(relu_first) and groups == 32 and USE_FUSED_GN_STATS:
     partial, tile_rows, _ = fused        # emitted by the conv that produced x
     with _region('group_norm_stats', 0.0, 4.0 * partial.numel()):

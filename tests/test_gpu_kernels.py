@@ -310,6 +310,37 @@ def test_conv_split_rgb_root(N, H, W, Cout, affine, math):
   assert float((got - exact).abs().max()) <= 2.5 * SPLIT_TOL[math] * float(exact.abs().max())
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x3', 'bf16x6'])
+def test_conv_emits_both_groupnorm_statistics(math):
+  """emit_gn_stats='both' (the closing 1 x 1 conv of a ResNet stage): the statistics of y
+  (GroupNorm -> ReLU readers) and of relu(y) (ReLU -> GroupNorm readers, the FPN levels) out of
+  ONE epilogue on the split engines (a dedicated kernel variant; row tiles straddling images);
+  a request the engine does not honour (f32) silently leaves the second statistic to the
+  stand-alone pass."""
+  N, H, W, Cin, Cout = 3, 97, 120, 64, 256      # 273 x 2 tiles of 128 x 128 (the engine's choice)
+  x = rnd((N, H, W, Cin), 950)
+  w = rnd((1, 1, Cin, Cout), 951, 1 / 8.0)
+  res = rnd((N, H, W, Cout), 952)
+  g_in = rnd((Cin,), 954) + 1
+  b_in = rnd((Cin,), 955)
+  xd = x.to(DEV)
+  mu, sc = ops.group_norm_stats(xd, g_in.to(DEV))
+  kw = dict(prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)), residual=res.to(DEV), math=math)
+  y = ops.conv2d(xd, w.to(DEV), emit_gn_stats='both', **kw)
+  y_raw = ops.conv2d(xd, w.to(DEV), emit_gn_stats='raw', **kw)
+  assert torch.equal(y, y_raw)
+  assert hasattr(y, '_snap_gn_partial')
+  assert hasattr(y, '_snap_gn_partial_relu') == (math != 'f32')
+  (mu_a, sc_a), (mu_b, sc_b) = (ops.group_norm_stats(t, g_in.new_ones(Cout).to(DEV)) for t in (y, y_raw))
+  assert torch.equal(mu_a, mu_b) and torch.equal(sc_a, sc_b)      # (the first statistic: unchanged)
+  gamma = rnd((Cout,), 953) + 1
+  for relu_first in (False, True):
+    mu_f, sc_f = ops.group_norm_stats(y, gamma.to(DEV), relu_first=relu_first)
+    mu_w, sc_w = oracle_ops.group_norm_stats(y.cpu(), gamma, relu_first=relu_first)
+    helpers.report(f'both stats mu relu_first={relu_first}', mu_f, mu_w, atol=1e-5, rtol=1e-5)
+    helpers.report(f'both stats sc relu_first={relu_first}', sc_f, sc_w, atol=1e-5, rtol=5e-5)
+
+
 def test_conv_split_accuracy_class():
   """The split engines against float64 on a deep reduction (K = 4608), next to the exact f32
   engine: 'bf16x6' must sit in the f32 engine's error class (<= 2x its rms error), 'bf16x3'
