@@ -178,9 +178,25 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
     __builtin_amdgcn_global_load_lds((cglobal_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + 4096), (lds_void_t*)(dst + 4096), 16, 0, 0);
   };
+#ifndef SNAP_MLP_POOL_PAIRS
+#define SNAP_MLP_POOL_PAIRS 1      // 1: GEMM1 takes TWO k-steps per barrier (four 16 KB ring slots); 0: one (eight 8 KB slots)
+#endif
+  // pair p = k-steps 2p, 2p + 1 (16 KB) -> slot (p + 3) & 3 of a four-slot ring over the same 64 KB:
+  // pair 0 lands behind the GEMM0 stages (it travels while GEMM0 runs), as k-steps 0 and 1 did
+  auto issue_b1_pair = [&](int p) {
+    const char* src = a.w1 + (int64_t)p * 16384 + tid * 16;
+    char* dst = sm + ((p + 3) & 3) * 16384 + tid * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + 4096 * q), (lds_void_t*)(dst + 4096 * q), 16, 0, 0);
+  };
   if (!(SNAP_MLP_POOL_ABLATE & 4)) {
-    issue_b1(0);
-    issue_b1(1);                                                  // (H >= 32: two k-steps exist)
+    if (SNAP_MLP_POOL_PAIRS) {
+      issue_b1_pair(0);
+    } else {
+      issue_b1(0);
+      issue_b1(1);                                                // (H >= 32: two k-steps exist)
+    }
   }
 
   f32x16 acc0[T0];
@@ -270,10 +286,17 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   // travel.  Keeping this VALU chain out of the GEMM1 loop leaves that loop LDS reads + MFMAs only.
   const int nks = a.H >> 4;                                       // 16-k steps of GEMM1
   const bool run1 = !(SNAP_MLP_POOL_ABLATE & 4);
+  const int npairs = nks >> 1;                                    // (H % 32 == 0)
   if (run1) {
+    if (SNAP_MLP_POOL_PAIRS) {
 #pragma unroll
-    for (int k = 2; k < 8; ++k)
-      if (k < nks) issue_b1(k);                                   // (k-steps 0, 1: issued at the start)
+      for (int p = 1; p < 4; ++p)
+        if (p < npairs) issue_b1_pair(p);                         // (pair 0: issued at the start)
+    } else {
+#pragma unroll
+      for (int k = 2; k < 8; ++k)
+        if (k < nks) issue_b1(k);                                 // (k-steps 0, 1: issued at the start)
+    }
   }
   u32x4 f_hi[T0][2], f_lo[T0][2];
 #pragma unroll
@@ -310,8 +333,55 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
 
+  // One barrier per k-step leaves 12 MFMAs (0.16 us) between two barriers, and the ablation puts
+  // GEMM1 at 1.3 of the kernel's 3.3 ms for 192 of a single-observation tile's 408 MFMAs: the
+  // loop pays a barrier + the LDS latency of the operand fetch per k-step.  Two k-steps per
+  // barrier (the same 32 operand registers, reloaded between the two) halve that.
+#pragma unroll
+  for (int pr = 0; pr < T0; ++pr) {
+    if (!SNAP_MLP_POOL_PAIRS) break;
+    if (pr < npairs && run1) {
+      // wait for pair pr; issued so far: 1 .. pr + 2, so pr + 1 .. min(pr + 2, npairs - 1) may stay
+      // in flight, four DMA instructions each (pair 0 was drained by GEMM0's waits)
+      if (pr >= 1) {
+        const int younger = min(pr + 2, npairs - 1) - pr;
+        switch (younger) {
+          case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // every wave is past pair pr - 1: its slot takes pair pr + 3
+      if (pr >= 1 && pr + 3 < npairs) issue_b1_pair(pr + 3);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const char* ws = sm + ((pr + 3) & 3) * 16384 + sub * 8192 + w_off;
+        bf16x8 h_hi, h_lo;
+        __builtin_memcpy(&h_hi, &f_hi[pr][sub], 16);
+        __builtin_memcpy(&h_lo, &f_lo[pr][sub], 16);
+        bf16x8 w_hi[T1], w_lo[T1];
+#pragma unroll
+        for (int j = 0; j < T1; ++j) {
+          const char* p0 = ws + j * 1024;
+          w_hi[j] = *reinterpret_cast<const bf16x8*>(p0);
+          w_lo[j] = *reinterpret_cast<const bf16x8*>(p0 + 4096);
+        }
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_lo, acc1[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[j], h_hi, acc1[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_hi, acc1[j], 0, 0, 0);
+      }
+    }
+  }
 #pragma unroll
   for (int ks = 0; ks < 2 * T0; ++ks) {
+    if (SNAP_MLP_POOL_PAIRS) break;
     if (ks < nks && run1) {
       // wait for k-step ks; issued so far: 2 .. ks + 6, so ks + 1 .. min(ks + 6, nks - 1) may
       // stay in flight, two DMA instructions each (k-steps 0, 1 were drained by GEMM0's waits)
