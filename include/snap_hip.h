@@ -299,6 +299,16 @@ int snap_mlp2_pool_max_classes_f32(const float* x, int64_t M, int32_t Cin, int32
 int snap_fill_masked_rows_f32(float* y, const uint8_t* mask, int64_t M, int32_t C,
                               float value, void* stream);
 
+/* pad_to_multiple (image_encoder.py:32-39) and optional zero channels in one pass:
+ * x [N, H, W, C] -> y [N, H + pad_h, W + pad_w, C + pad_c], zeros bottom / right / extra channels. */
+int snap_pad_image_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad_h,
+                       int32_t pad_w, int32_t pad_c, float* y, void* stream);
+
+/* Voxel-centre query points (bev_mapper.py:162-196): out [B, XY, Z, 3] = (xy[b, c, :], z[b, k]);
+ * xy [XY, 2] (xy_batched = 0) or [B, XY, 2]; z [B, Z] (level heights per scene). */
+int snap_voxel_points_f32(const float* xy, int32_t xy_batched, const float* z, int32_t B, int32_t XY,
+                          int32_t Z, float* out, void* stream);
+
 /* StdConv weight standardisation over (H,W,I) per output channel, eps inside the
  * sqrt (resnet.py:34-41,73-79).  w,out: [K, Cout]. */
 int snap_weight_standardize_f32(const float* w, float* out, int32_t K,

@@ -108,6 +108,8 @@ SIGNATURES = {
                                                c_int, c_int, c_i64, ptr, ptr, ptr]),
     'snap_mlp2_pool_max_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, ptr, c_int,
                                        ptr, c_size, ptr, c_int, c_int, c_int, c_int, c_i64, ptr, ptr, ptr]),
+    'snap_pad_image_f32': (c_int, [ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ptr, ptr]),
+    'snap_voxel_points_f32': (c_int, [ptr, c_int, ptr, c_int, c_int, c_int, ptr, ptr]),
     'snap_fill_masked_rows_f32': (c_int, [ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_weight_standardize_f32': (c_int, [ptr, ptr, c_int, c_int, c_float, ptr]),
     'snap_weight_standardize_multi_f32': (c_int, [ptr, c_int, c_int, c_float, ptr]),
@@ -252,7 +254,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 

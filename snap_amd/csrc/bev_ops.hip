@@ -296,3 +296,37 @@ extern "C" int snap_confidence_head_f32(const float* features, const uint8_t* va
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
+
+// Voxel-centre query points (bev_mapper.py:162-196): xyz[b, x, y, k] = (xy[b or 0, x, y, :], z[b, k]).
+// The small factors (the BEV cell centres, the per-scene level heights) are computed by the host
+// module exactly as the reference does; this is the broadcast into [B, X, Y, Z, 3] in one pass.
+namespace {
+__global__ __launch_bounds__(256) void voxel_points_kernel(const float* __restrict__ xy, int64_t xy_bstride,
+                                                           const float* __restrict__ z, int64_t total,
+                                                           int XY, int Z, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // voxel (b, xy, k), level fastest
+  if (i >= total) return;
+  const int k = (int)(i % Z);
+  const int64_t t = i / Z;
+  const int c = (int)(t % XY);
+  const int64_t b = t / XY;
+  const float* p = xy + b * xy_bstride + (int64_t)c * 2;
+  float* o = out + i * 3;
+  o[0] = p[0];
+  o[1] = p[1];
+  o[2] = z[b * Z + k];
+}
+}  // namespace
+
+extern "C" int snap_voxel_points_f32(const float* xy, int32_t xy_batched, const float* z, int32_t B,
+                                     int32_t XY, int32_t Z, float* out, void* stream) {
+  if (!xy || !z || !out) return SNAP_ERR_NULL;
+  if (B <= 0 || XY <= 0 || Z <= 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)B * XY * Z;
+  hipLaunchKernelGGL(voxel_points_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), xy, xy_batched ? (int64_t)XY * 2 : 0, z, total, XY, Z,
+                     out);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+

@@ -412,3 +412,52 @@ extern "C" int snap_max_pool_3x3s2_f32(const float* x, float* y, int32_t N, int3
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
+
+// pad_to_multiple (image_encoder.py:32-39) + optional zero channels in ONE pass: x [N, H, W, C] ->
+// y [N, H + ph, W + pw, C + cp], zeros at the bottom / right / in the extra channels (what
+// jnp.pad does; torch's F.pad takes a fill launch and a strided copy for it).
+namespace {
+template <int CO>
+__global__ __launch_bounds__(256) void pad_image_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        int64_t total, int H, int W, int C, int Ho,
+                                                        int Wo, int Co) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // output pixel
+  if (i >= total) return;
+  const int wo = (int)(i % Wo);
+  const int64_t t = i / Wo;
+  const int ho = (int)(t % Ho);
+  const int64_t n = t / Ho;
+  const bool in = ho < H && wo < W;
+  const float* src = x + ((n * H + ho) * W + wo) * C;
+  if constexpr (CO == 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (in) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) v[c] = src[c];
+    }
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  } else {
+    float* dst = y + i * Co;
+    for (int c = 0; c < Co; ++c) dst[c] = (in && c < C) ? src[c] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int snap_pad_image_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
+                                  int32_t pad_h, int32_t pad_w, int32_t pad_c, float* y, void* stream) {
+  if (!x || !y) return SNAP_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad_h < 0 || pad_w < 0 || pad_c < 0) return SNAP_ERR_BAD_SHAPE;
+  const int Ho = H + pad_h, Wo = W + pad_w, Co = C + pad_c;
+  const int64_t total = (int64_t)N * Ho * Wo;
+  if (total * Co > 0x7fffffff0LL) return SNAP_ERR_BAD_SHAPE;
+  const dim3 grid((unsigned)snap_cdiv(total, 256));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (Co == 4 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+    hipLaunchKernelGGL(pad_image_kernel<4>, grid, dim3(256), 0, s, x, y, total, H, W, C, Ho, Wo, Co);
+  else
+    hipLaunchKernelGGL(pad_image_kernel<0>, grid, dim3(256), 0, s, x, y, total, H, W, C, Ho, Wo, Co);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+

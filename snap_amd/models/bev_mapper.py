@@ -181,6 +181,10 @@ class BEVMapper(base.Module):
         + cell / 2
     )
     B, X, Y = xy.shape[:3]
+    if t.is_cuda and t.dtype == torch.float32 and ops.NATIVE_GLUE and not base.needs_grad(z, xy):
+      # (xy: an expanded view when the grid is shared by the scenes -- hand over its base)
+      xy_c = xy[0].contiguous() if xy.stride(0) == 0 else xy.contiguous()
+      return ops.voxel_points(xy_c, z.contiguous())                              # one pass
     xyz = torch.empty(B, X, Y, nz, 3, dtype=t.dtype, device=t.device)
     xyz[..., :2] = xy[:, :, :, None, :]
     xyz[..., 2] = z[:, None, None, :]

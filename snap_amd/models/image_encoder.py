@@ -18,6 +18,9 @@ def pad_to_multiple(images, stride, channel_pad=0):
   the root convolution: ops.conv2d, ``cin=3``)."""
   shape = np.array(images.shape[-3:-1])
   pad = stride - shape % stride
+  if (images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+      and not base.needs_grad(images) and ops.NATIVE_GLUE):
+    return ops.pad_image(images, int(pad[0]), int(pad[1]), int(channel_pad))     # one pass
   return torch.nn.functional.pad(images, (0, int(channel_pad), 0, int(pad[1]), 0, int(pad[0])))
 
 

@@ -31,6 +31,8 @@ OVERLAP_AERIAL = os.environ.get('SNAP_OVERLAP_AERIAL', '1') != '0'
 POOLED_SPLIT = os.environ.get('SNAP_POOLED_SPLIT', '1') != '0'
 # ... and classed by their number of observations (single-observation rows carry no variance slabs); 0: off
 CLASS_ROWS = os.environ.get('SNAP_CLASS_ROWS', '1') != '0'
+# image padding and the voxel-centre grid as one native pass each instead of torch fill + strided copies; 0: torch
+NATIVE_GLUE = os.environ.get('SNAP_NATIVE_GLUE', '1') != '0'
 _SIDE_STREAM = None
 
 
@@ -740,6 +742,35 @@ def group_norm_apply(x, mu, sc, beta, mode):
   )
   _lib.check(st, 'snap_group_norm_apply_f32')
   return y
+
+
+def pad_image(x, pad_h, pad_w, pad_c=0):
+  """x [..., H, W, C] -> [..., H + pad_h, W + pad_w, C + pad_c], zeros at the bottom / right / in
+  the extra channels, one pass (pad_to_multiple, image_encoder.py:32-39)."""
+  lib = _lib.load()
+  _f32(x, 'x')
+  *lead, H, W, C = x.shape
+  N = int(np.prod(lead)) if lead else 1
+  y = torch.empty((*lead, H + pad_h, W + pad_w, C + pad_c), dtype=torch.float32, device=x.device)
+  st = lib.snap_pad_image_f32(_p(x), N, H, W, C, int(pad_h), int(pad_w), int(pad_c), _p(y), _stream())
+  _lib.check(st, 'snap_pad_image_f32')
+  return y
+
+
+def voxel_points(xy, z):
+  """xy [X, Y, 2] or [B, X, Y, 2] (BEV cell centres), z [B, Z] (level heights per scene) ->
+  [B, X, Y, Z, 3] voxel centres (bev_mapper.py:162-196), one pass."""
+  lib = _lib.load()
+  _f32(xy, 'xy'); _f32(z, 'z')
+  B, Z = z.shape
+  X, Y = xy.shape[-3:-1]
+  batched = xy.dim() == 4
+  if xy.shape[-1] != 2 or (batched and xy.shape[0] != B):
+    raise ValueError('voxel_points: shapes')
+  out = torch.empty((B, X, Y, Z, 3), dtype=torch.float32, device=z.device)
+  st = lib.snap_voxel_points_f32(_p(xy), int(batched), _p(z), B, X * Y, Z, _p(out), _stream())
+  _lib.check(st, 'snap_voxel_points_f32')
+  return out
 
 
 def max_pool_3x3s2(x):

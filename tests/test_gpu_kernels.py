@@ -708,6 +708,27 @@ def test_lift_bev_tiled_traversal_is_a_pure_reordering(X, Y, Z, K, V):
     assert float(p3s[one][:, nv:2 * nv].abs().max()) == 0.0      # (the slabs that are skipped ARE zero)
 
 
+@pytest.mark.parametrize('shape,ph,pw,pc', [((5, 37, 29, 3), 27, 3, 1), ((2, 3, 16, 16, 3), 16, 16, 1),
+                                            ((3, 20, 31, 5), 12, 1, 0), ((1, 8, 8, 4), 0, 0, 0)])
+def test_pad_image_is_torch_pad(shape, ph, pw, pc):
+  """pad_to_multiple (+ zero channels) in one pass == torch.nn.functional.pad, bit for bit."""
+  x = rnd(shape, 1200 + ph).to(DEV)
+  want = torch.nn.functional.pad(x, (0, pc, 0, pw, 0, ph))
+  got = ops.pad_image(x, ph, pw, pc)
+  assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.parametrize('batched', [False, True])
+def test_voxel_points_is_the_broadcast(batched):
+  B, X, Y, Z = 3, 7, 5, 11
+  xy = rnd((B, X, Y, 2) if batched else (X, Y, 2), 1300).to(DEV)
+  z = rnd((B, Z), 1301).to(DEV)
+  want = torch.empty(B, X, Y, Z, 3, device=DEV)
+  want[..., :2] = (xy if batched else xy[None].expand(B, X, Y, 2))[:, :, :, None, :]
+  want[..., 2] = z[:, None, None, :]
+  assert torch.equal(ops.voxel_points(xy, z), want)
+
+
 def test_project_points():
   f, cam, Rt, pts = _lift_scene(2, 4, 12, 16, 8, 4, 5000, seed=50, k_radial=0.05)
   (p2g, vig, dg), (p2w, viw, dw) = both('project_points', (cam, Rt, pts, True))
