@@ -176,9 +176,34 @@ def unpack_transforms(Rt):
   return o_geo.Transform3D(r[..., :9].reshape(*r.shape[:-1], 3, 3), r[..., 9:12])
 
 
+def _split_rows(rows):
+  """[..., C] f32 -> the split-bf16 hand-over layout of SnapLiftDesc.out_split in an f32 container:
+  [..., ceil(C / 16) slabs][hi | lo][16] bf16 (hi = bf16(v) RNE, lo = bf16(v - hi))."""
+  import torch
+  t = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.float32))
+  C = t.shape[-1]
+  ks = (C + 15) // 16
+  pad = torch.zeros(*t.shape[:-1], ks * 16)
+  pad[..., :C] = t
+  hi = pad.bfloat16()
+  lo = (pad - hi.float()).bfloat16()
+  both = torch.stack([hi.reshape(*t.shape[:-1], ks, 16), lo.reshape(*t.shape[:-1], ks, 16)], dim=-2)
+  return both.contiguous().view(torch.int16).reshape(*t.shape[:-1], ks * 32).view(torch.float32).numpy()
+
+
+def _unsplit_rows(x):
+  """inverse of _split_rows (hi + lo; the residual below the second part is dropped)."""
+  import torch
+  t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))
+  ks = t.shape[-1] // 16
+  parts = t.view(torch.int16).view(torch.bfloat16).reshape(*t.shape[:-1], ks, 2, 16).float()
+  return (parts[..., 0, :] + parts[..., 1, :]).reshape(*t.shape[:-1], ks * 16).numpy()
+
+
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
-              add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False):
+              add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False,
+              class_rows=False):
   f = _np(f_images, DTYPE)
   cams = unpack_cameras(cam, fisheye)
   T = unpack_transforms(Rt)
@@ -198,9 +223,22 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   pooled, valid = o_lift.pool_multiview_features(feats, vis, scores, add_minmax, use_variance)
   if max_view_distance is not None and min_distance is not None:
     valid = valid & (min_distance <= max_view_distance)
-  stride = (pooled.shape[-1] + 3) // 4 * 4
-  out = np.zeros(pooled.shape[:-1] + (stride,), pooled.dtype)
-  out[..., : pooled.shape[-1]] = pooled
+  nvis = vis.sum(-1)
+  if out_split:
+    # the hand-over format of the fused MLP / pool kernel; what the kernel does not write is NaN here
+    out = _split_rows(pooled).copy()
+    if class_rows:
+      nv = feature_dim // 16
+      out[nvis == 1, 16 * nv:32 * nv] = np.nan       # single observation: the variance slabs
+  else:
+    stride = (pooled.shape[-1] + 3) // 4 * 4
+    out = np.zeros(pooled.shape[:-1] + (stride,), pooled.dtype)
+    out[..., : pooled.shape[-1]] = pooled
+  if valid_rows_only:
+    out[nvis == 0] = np.nan
+  if class_rows:
+    classes = np.where(valid, np.where(nvis > 1, 2, 1), 0).astype(np.uint8)
+    return _t(out, f_images), _t(valid, f_images), _t(classes, f_images, dtype=torch.uint8)
   return _t(out, f_images), _t(valid, f_images)
 
 
@@ -221,13 +259,22 @@ def mlp2_pool_supported(cin, hidden, out_dim):
   return True
 
 
-def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False):
-  xx = _np(x, DTYPE)[:, :cin]
+def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False,
+                  zero_slabs=None):
+  xx = _np(x, DTYPE)
+  if x_split:
+    xx = _unsplit_rows(xx)
+  xx = xx[:, :cin].copy()
+  m = _np(row_mask)
+  if zero_slabs is not None:      # row classes: class 1 is exactly zero over the slab range
+    lo, n = zero_slabs
+    xx[m == 1, 16 * lo:16 * (lo + n)] = 0
+  m = m.astype(bool)
+  xx[~m] = 0                       # (rows the lift did not write)
   if relu_in:
     xx = np.maximum(xx, 0)
   hid = np.maximum(xx @ _np(w0, DTYPE) + _np(b0, DTYPE), 0)
   vol = hid @ _np(w1, DTYPE) + _np(b1, DTYPE)
-  m = _np(row_mask).astype(bool)
   vol = np.where(m[:, None], vol, 0).reshape(-1, Z, vol.shape[-1])
   out = o_bev.vertical_pooling({'pooling': 'max'}, vol, m.reshape(-1, Z))
   return _t(out['features'], x), _t(out['valid'], x)
@@ -411,7 +458,7 @@ def template_finalize(raw, cnt, tcount, R, threshold, use_overlap=True):
 
 ALL_OPS = [
     'conv2d', 'dense', 'weight_standardize', 'weight_standardize_multi', 'group_norm_stats', 'group_norm_apply',
-    'max_pool_3x3s2', 'pooled_stride', 'lift_pool', 'project_points', 'vertical_pool',
+    'max_pool_3x3s2', 'pooled_stride', 'lift_pool', 'project_points', 'vertical_pool', 'mlp2_pool_max',
     'plane_fuse_match', 'sim_softmax', 'ransac_sample', 'poses_from_corr', 'pose_score',
     'refine_lattice', 'argmax_rows', 'rotate_templates', 'pad_map', 'template_finalize',
 ]

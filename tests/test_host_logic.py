@@ -261,6 +261,46 @@ def test_forward_pytree_and_oracle_agreement(oracle_backend):
   assert 'loc/temperature' in metrics
 
 
+def test_fused_plane_path_host_plumbing(oracle_backend, monkeypatch):
+  """materialize_volume=False on a split engine: the module hands the lift's rows to the fused
+  MLP / pool op pre-split, only for observed voxels, CLASSED by observation count (single-observation
+  rows without their variance slabs) -- checked here on the CPU through the oracle twins of the ops
+  (what the kernels leave unwritten is NaN in the twins): same BEV planes as the reference path."""
+  from snap_amd import ops
+  cfg, meta, model = _tiny(num_pose_samples=12)
+  loc = model.flax_model
+  variables = loc.init({'params': 0, 'sampling': 1}, device='cpu')
+  batch = synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=1)
+  ref = loc.apply(variables, batch, train=False, rngs={'sampling': 3})
+  seen = {}
+  lift = ops.lift_pool
+
+  def spy(*a, **kw):
+    out = lift(*a, **kw)
+    seen.setdefault('kw', []).append({k: kw.get(k) for k in ('valid_rows_only', 'out_split', 'class_rows')})
+    if kw.get('class_rows'):
+      seen['classes'] = out[2]
+    return out
+
+  monkeypatch.setattr(ops, 'lift_pool', spy)
+  monkeypatch.setattr(ops, 'MATMUL_PRECISION', 'bf16x3')
+  monkeypatch.setattr(ops, 'pack_weights_split_multi', lambda *a, **k: None)
+  cfg2 = helpers.tiny_localizer_config()
+  cfg2.num_pose_samples = 12
+  cfg2.bev_mapper.materialize_volume = False
+  loc2 = bev_localizer.BEVLocalizer(cfg2, meta['build_config'].scene_config, meta['grid'].bev())
+  batch = synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=1)
+  got = loc2.apply(variables, batch, train=False, rngs={'sampling': 3})
+  assert all(k == {'valid_rows_only': True, 'out_split': True, 'class_rows': True} for k in seen['kw'])
+  assert set(np.unique(seen['classes'].numpy())) <= {0, 1, 2} and int((seen['classes'] == 1).sum()) > 0
+  assert got['map']['streetview']['feature_volume'].features is None
+  for side in ('map', 'query'):
+    helpers.report(f'{side} bev_matching (fused, classed)', got[side]['bev_matching'].features,
+                   ref[side]['bev_matching'].features, atol=2e-5)
+    assert torch.equal(got[side]['bev_matching'].valid, ref[side]['bev_matching'].valid)
+  helpers.report('scores (fused, classed)', got['scores_poses'], ref['scores_poses'], atol=2e-5)
+
+
 def test_unsupported_configs_raise_like_the_reference():
   cfg = helpers.tiny_localizer_config()
   meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
