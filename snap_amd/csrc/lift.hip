@@ -487,8 +487,11 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
   // covers most of every view -- far more than a 4 MB L2 holds.  Instead an XCD walks the
   // chunks of ONE 8 x 8 block of columns (1.6 m square, all levels: 15 chunks at Z = 60) before
   // it moves on; the block's footprint in a view is a narrow vertical band.  Measured at C2
-  // (rocprofv3 FETCH_SIZE): 12.7 -> 8.8 GB fetched per step, kernel time unchanged (3.3 ms):
-  // the kernel is not bound by the fabric reads.  (Giving each XCD one contiguous run of tiles
+  // (rocprofv3 FETCH_SIZE): 12.7 -> 8.8 GB fetched per step, kernel time unchanged (3.3 ms) AT
+  // THE TIME: the kernel was bound by VALU issue.  At the end of round 2 (leaner phase B, class
+  // ordering, 2.8 ms) it moves 8.8 GB of L2 misses + 5.1 GB of writes at 4.9 TB/s and IS bound
+  // by them; tile sides of 4 / 16 columns, XCD-owned adjacent tile columns and fewer resident
+  // workgroups were all slower.  (Giving each XCD one contiguous run of tiles
   // -- a whole scene -- was slower, 4.1 ms: the eight L2s then see very different loads.)
   int64_t lb = blockIdx.x;
   int64_t my_gv;                    // phase A: this lane's voxel (-1: none)
