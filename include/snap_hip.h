@@ -117,7 +117,34 @@ typedef struct SnapConvExtras {
   size_t gn_partial2_bytes;
   int32_t gn_partial2_done;   /* OUT: 1 if gn_partial2 was written by this launch, else 0 (take
                                  snap_group_norm_stats_f32 for the second statistic) */
+  int32_t x_presplit;         /* 1: `x` is NOT f32 but the pre-split image of the (already normalised)
+                                 input, [N*H*W][Cin/16][hi 16 | lo 16] bf16 as written by
+                                 snap_gn_norm_split_f32 / snap_presplit_f32; needs w_split_parts = 2,
+                                 prologue NONE, Cin % 16 == 0, no row lists.  Both operands then
+                                 travel by LDS-DMA (conv_ps.hip); sizes come from the
+                                 snap_conv2d_presplit_* queries below instead of the plain ones */
+  int32_t ps_tile;            /* ... 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles (tuning) */
+  int32_t ps_res_init;        /* ... 1 = a residual is loaded into the accumulators before the K loop
+                                 (r + p1 + p2 + ... instead of (p1 + p2 + ...) + r) */
 } SnapConvExtras;
+/* Pre-split launches (extras->x_presplit): row tile, GroupNorm partial-sum bytes and split-K
+ * workspace bytes of the launch `desc` + `ps_tile` describes (the counterparts of
+ * snap_conv2d_tile_rows / _gn_partial_bytes / _workspace_bytes). */
+int32_t snap_conv2d_presplit_tile_rows(const SnapConvDesc* desc, int32_t ps_tile);
+size_t snap_conv2d_presplit_gn_partial_bytes(const SnapConvDesc* desc, int32_t ps_tile);
+size_t snap_conv2d_presplit_workspace_bytes(const SnapConvDesc* desc, int32_t ps_tile);
+/* GroupNorm -> ReLU (resnet.py:34-60,117-130) of a conv output y [N, HW, C] whose partial sums
+ * came out of the producing conv's epilogue (extras->gn_partial, row tile `tile_rows`), written
+ * ONCE in the pre-split format: out [N*HW][C/16][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] bf16
+ * (N*HW*C*4 bytes), hi = bf16(v), lo = bf16(v - hi).  Replaces the statistics finalize launch of
+ * that tensor AND the normalise / split work of every consumer tile; mu / sc (optional, both or
+ * neither): the statistics as snap_group_norm_stats_from_partial_f32 defines them.  C % 16 == 0,
+ * C <= 2048, groups a power of two <= 64. */
+int snap_gn_norm_split_f32(const float* y, const float* partial, int32_t N, int32_t HW, int32_t C,
+                           int32_t groups, float eps, int32_t tile_rows, const float* gamma,
+                           const float* beta, void* out, float* mu, float* sc, void* stream);
+/* The plain two-part split of x [rows, C] f32 into the same format (C % 16 == 0). */
+int snap_presplit_f32(const float* x, int64_t rows, int32_t C, void* out, void* stream);
 
 int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x, const float* w,
                             float* y, const float* gn_mu, const float* gn_sc,

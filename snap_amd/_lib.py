@@ -38,6 +38,7 @@ class SnapConvExtras(ctypes.Structure):
       ('workspace', ptr), ('workspace_bytes', c_size),
       ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
       ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
+      ('x_presplit', c_int), ('ps_tile', c_int), ('ps_res_init', c_int),
   ]
 
 
@@ -72,6 +73,12 @@ SIGNATURES = {
     'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_conv2d_presplit_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
+    'snap_conv2d_presplit_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
+    'snap_conv2d_presplit_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
+    'snap_gn_norm_split_f32': (
+        c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr, ptr, ptr]),
+    'snap_presplit_f32': (c_int, [ptr, c_i64, c_int, ptr, ptr]),
     'snap_interpolate_nd_f32': (c_int, [ptr, ptr, c_int, c_int, ptr, ptr, c_i64, ptr, ptr, ptr]),
     'snap_expectation_nd_f32': (c_int, [ptr, c_i64, ptr, c_int, ptr, ptr]),
     'snap_semantic_embed_f32': (

@@ -44,6 +44,9 @@ struct ConvArgs {
   int ablate;  // tuning-only: bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])
   int cin8;            // ... channel count rounded up to 8
+  const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
+  int ps_tile;         // ... 0 = automatic tile, 1 = 128 rows, 2 = 256 rows
+  int ps_res_init;     // ... 1 = the residual is loaded into the accumulators before the K loop
 };
 
 // bf16-operand engine (conv_bf16.hip); `a` validated by snap_conv2d_nhwc_ex_f32
@@ -53,6 +56,12 @@ int launch_bf16(ConvArgs a, hipStream_t s);
 int launch_split(ConvArgs a, int parts, hipStream_t s);
 // ... the 7 x 7 / stride 2 root convolution of a 4-floats-per-pixel RGB image (root weight image)
 int launch_split_root(ConvArgs a, int parts, hipStream_t s);
+// pre-split engine (conv_ps.hip): a.x_ps = the input already normalised and split in two bf16
+// parts (snap_gn_norm_split_f32 / snap_presplit_f32), a.w_bf16 = the split weight image (parts = 2)
+int launch_ps(ConvArgs a, hipStream_t s);
+struct PsTile { int bm, bn, nt; };
+PsTile ps_choose_tile(int64_t M, int64_t N, int force);
+int ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t kpartial_bytes);
 
 }  // namespace snapconv
 
@@ -86,11 +95,15 @@ __device__ __forceinline__ float snap_gelu_tanh(float x) {
 }
 
 // ---- epilogue ------------------------------------------------------------
-template <int BM, int BN, bool DUAL = false>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / 64][BN / 64],
+// NT threads = NT / 64 waves laid out (NT / 128) x 2; SKIP_RES: the residual already sits in the
+// accumulators (conv_ps.hip loads it there before the K loop)
+template <int BM, int BN, bool DUAL = false, int NT = 256, bool SKIP_RES = false>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
+                                              f32x16 (&acc)[BM / (NT / 4)][BN / 64],
                                               float* smem, int m0, int n0, int Meff, int row_t,
                                               int split) {
-  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int WR = NT / 128;                // wave rows
+  constexpr int TM = BM / (32 * WR), TN = BN / 64;
   const SnapConvDesc& d = a.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -107,9 +120,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
   const int epi = d.epilogue;
   const int Hp = d.Ho >> 1, Wp = d.Wo >> 1;
   constexpr int Q = BN / 4;               // float4 per staged row
-  constexpr int PER_THREAD = (64 * Q) / 256;
+  constexpr int PER_THREAD = (32 * WR * Q) / NT;
   // GroupNorm statistics of the OUTPUT (consumed by the next layer's fused GN prologue):
-  // every thread owns 4 fixed columns (256 % Q == 0), accumulates sum / sum of squares of
+  // every thread owns 4 fixed columns (NT % Q == 0), accumulates sum / sum of squares of
   // what it stores, split by image (a tile of BM <= HoWo rows touches at most two).
   const bool want_stats = a.gn_partial != nullptr;
   const int n_first = m0 / HoWo;
@@ -136,9 +149,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PER_THREAD; ++it) {
-      const int idx = tid + 256 * it;
+      const int idx = tid + NT * it;
       const int row = idx / Q, q = idx - row * Q;
-      const int m = m0 + (row >> 5) * (BM / 2) + h * 32 + (row & 31);
+      const int m = m0 + (row >> 5) * (BM / WR) + h * 32 + (row & 31);
       const int col = n0 + 4 * q;
       if (m >= Meff || col >= d.Cout) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * BN + 4 * q);
@@ -152,7 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bb[e];
       }
-      if (epi & SNAP_EPI_RESIDUAL) {
+      if (!SKIP_RES && (epi & SNAP_EPI_RESIDUAL)) {
         const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + o);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += rr[e];
@@ -215,7 +228,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
   if (want_stats) {
     // fixed-order reduction over the 256/Q row groups through LDS, then one writer per
     // (image slot, column): deterministic.
-    constexpr int RG = 256 / Q;
+    constexpr int RG = NT / Q;
     const int q = tid % Q, rg = tid / Q;
     for (int pass = 0; pass < (want_relu_too ? 2 : 1); ++pass) {
     float* const dst_partial = pass ? a.gn_partial2 : a.gn_partial;
@@ -228,7 +241,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
         smem[((rg * 2 + sl) * BN + 4 * q + e) * 2 + 1] = pass ? hs2[sl][e] : gs2[sl][e];
       }
     __syncthreads();
-    for (int i = tid; i < 2 * BN; i += 256) {
+    for (int i = tid; i < 2 * BN; i += NT) {
       const int sl = i / BN, c = i - sl * BN;
       const int col = n0 + c;
       const int n = n_first + sl;

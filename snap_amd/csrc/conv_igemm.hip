@@ -599,6 +599,32 @@ extern "C" int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc) {
   return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout).bm;
 }
 
+// ---- pre-split launches (conv_ps.hip) ---------------------------------------------------------
+extern "C" int32_t snap_conv2d_presplit_tile_rows(const SnapConvDesc* desc, int32_t ps_tile) {
+  if (!desc) return 0;
+  return snapconv::ps_choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, ps_tile).bm;
+}
+
+extern "C" size_t snap_conv2d_presplit_gn_partial_bytes(const SnapConvDesc* desc, int32_t ps_tile) {
+  if (!desc) return 0;
+  const SnapConvDesc& d = *desc;
+  const int64_t HoWo = (int64_t)d.Ho * d.Wo;
+  const snapconv::PsTile t = snapconv::ps_choose_tile((int64_t)d.N * HoWo, d.Cout, ps_tile);
+  if (HoWo < t.bm) return 0;
+  return (size_t)d.N * (HoWo / t.bm + 2) * d.Cout * 2 * sizeof(float);
+}
+
+extern "C" size_t snap_conv2d_presplit_workspace_bytes(const SnapConvDesc* desc, int32_t ps_tile) {
+  if (!desc) return 0;
+  const SnapConvDesc& d = *desc;
+  if (d.Cin % 16 != 0 || (d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) return 0;
+  const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+  const snapconv::PsTile t = snapconv::ps_choose_tile(M, d.Cout, ps_tile);
+  const int64_t nk = (int64_t)d.KH * d.KW * (d.Cin / 16);
+  const int S = snapconv::ps_ksplit(M, d.Cout, nk, t.bm, t.bn, (size_t)-1);
+  return S >= 2 ? (size_t)S * M * d.Cout * sizeof(float) : 0;
+}
+
 extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
                                        const float* w, float* y, const float* gn_mu,
                                        const float* gn_sc, const float* gn_beta,
@@ -613,12 +639,14 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   if ((rows_in || rows_out) &&
       (desc->epilogue & (SNAP_EPI_RESIDUAL | SNAP_EPI_UPSAMPLE2X_ADD | SNAP_EPI_ROWMASK)))
     return SNAP_ERR_UNSUPPORTED;  // row-indexed launches carry bias / ReLU only
+  const bool presplit = ex && ex->x_presplit;
+  const size_t gn_need = !gn_partial ? 0
+                         : presplit  ? snap_conv2d_presplit_gn_partial_bytes(desc, ex->ps_tile)
+                                     : snap_conv2d_gn_partial_bytes(desc);
   if (gn_partial) {
     if (rows_in || rows_out || row_count) return SNAP_ERR_UNSUPPORTED;
     if (desc->Cout_stride != desc->Cout) return SNAP_ERR_UNSUPPORTED;
-    if (ex->gn_partial_bytes < snap_conv2d_gn_partial_bytes(desc) ||
-        snap_conv2d_gn_partial_bytes(desc) == 0)
-      return SNAP_ERR_WORKSPACE;
+    if (ex->gn_partial_bytes < gn_need || gn_need == 0) return SNAP_ERR_WORKSPACE;
   }
   const SnapConvDesc& d = *desc;
   if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 ||
@@ -652,7 +680,7 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.gn_partial2 = nullptr;
   a.gn_partial2_done = nullptr;
   if (gn_partial && ex->gn_partial2) {
-    if (a.gn_relu || ex->gn_partial2_bytes < snap_conv2d_gn_partial_bytes(desc)) return SNAP_ERR_WORKSPACE;
+    if (a.gn_relu || ex->gn_partial2_bytes < gn_need) return SNAP_ERR_WORKSPACE;
     a.gn_partial2 = ex->gn_partial2;
     // (an output field of the caller's struct: set by the engine that honours the request)
     a.gn_partial2_done = const_cast<int32_t*>(&ex->gn_partial2_done);
@@ -682,6 +710,22 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   // loader's alignment; anything else runs on the (more precise) f32 engine below.
   a.w_bf16 = ex ? ex->w_bf16 : nullptr;
   a.cin8 = (d.Cin + 7) / 8 * 8;
+  a.x_ps = nullptr;
+  a.ps_tile = 0;
+  a.ps_res_init = 0;
+  if (presplit) {                            // both operands pre-split: conv_ps.hip
+    if (!a.w_bf16 || ex->w_split_parts != 2 || ex->w_split_root) return SNAP_ERR_UNSUPPORTED;
+    const size_t need = snap_conv2d_packed_weights_split_bytes(d.KH * d.KW, d.Cin, d.Cout, 2);
+    if (need == 0) return SNAP_ERR_UNSUPPORTED;
+    if (ex->w_bf16_bytes < need) return SNAP_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(a.w_bf16) | reinterpret_cast<uintptr_t>(x)) & 15) return SNAP_ERR_BAD_SHAPE;
+    a.x_ps = x;
+    a.x = nullptr;
+    a.ps_tile = ex->ps_tile;
+    a.ps_res_init = ex->ps_res_init;
+    a.cin8 = d.Cin;
+    return snapconv::launch_ps(a, s);
+  }
   if (a.w_bf16 && ex->w_split_root) {        // RGB root convolution on the split engine
     const int parts = ex->w_split_parts;
     if (ex->w_bf16_bytes < snap_conv2d_packed_weights_split_root_bytes(d.Cout, parts) ||

@@ -46,16 +46,23 @@ def _kernels(tree, out):
   return out
 
 
-def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, emit=True, **kw):
+def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, emit=True, presplit=False, **kw):
   """GroupNorm -> ReLU -> StdConv.  Training: one autograd node (statistics inside);
   inference: `gn_stats` may be shared between the convs reading the same input.
   emit: True -> the statistics of the output come out of the epilogue ('both': also those of
-  relu(output), for an FPN level that reads it ReLU -> GroupNorm)."""
+  relu(output), for an FPN level that reads it ReLU -> GroupNorm).
+  presplit: x has this one consumer (the 3x3 / closing 1x1 conv of a unit): where the engine
+  allows, GroupNorm -> ReLU -> split is ONE pass over x (``ops.gn_norm_split``, which also stands
+  in for the statistics finalize launch) and the conv runs on the pre-split engine."""
   w = _std(ctx, kernel)
   mode = None if not emit else ('both' if emit == 'both' else 'raw')
   if base.needs_grad(x, w, gn_p['scale'], gn_p['bias']):
     return ag.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn_params=(gn_p['scale'], gn_p['bias']),
                      emit_gn_stats='raw' if emit else None, **kw)
+  if presplit and gn_stats is None and w.shape[2] % 16 == 0:
+    xs = ops.gn_norm_split(x, gn_p['scale'].reshape(-1), gn_p['bias'].reshape(-1))
+    if xs is not None:
+      return ops.conv2d(xs, w, emit_gn_stats=mode, **kw)
   # the output feeds the next GroupNorm: its statistics come out of this conv's epilogue
   return ops.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn=gn_stats or _gn(x, gn_p),
                     emit_gn_stats=mode, **kw)
@@ -78,8 +85,9 @@ def residual_unit(ctx, p, x, stride, nmid, last_of_stage=False):
   else:
     residual = x
   y = _conv_gn(ctx, x, p['conv1']['kernel'], p['gn1'], gn1)
-  y = _conv_gn(ctx, y, p['conv2']['kernel'], p['gn2'], stride=stride, padding=((1, 1), (1, 1)))
-  y = _conv_gn(ctx, y, p['conv3']['kernel'], p['gn3'], residual=residual,
+  y = _conv_gn(ctx, y, p['conv2']['kernel'], p['gn2'], stride=stride, padding=((1, 1), (1, 1)),
+               presplit=True)
+  y = _conv_gn(ctx, y, p['conv3']['kernel'], p['gn3'], residual=residual, presplit=True,
                emit='both' if (last_of_stage and ops.GN_STATS_BOTH) else True)
   return y
 

@@ -164,13 +164,82 @@ def _mask(t, name):
 # ----------------------------------------------------------------------------
 # encoder
 # ----------------------------------------------------------------------------
+class PreSplit:
+  """An activation [N, H, W, C] (C % 16 == 0) already normalised and split into two bf16 parts:
+  ``data`` = [N*H*W][C/16][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] (the bytes of the f32 tensor,
+  re-arranged per 16-channel block).  ``conv2d`` multiplies it on the pre-split engine
+  (conv_ps.hip: both operands by LDS-DMA, no normalise / split work in the K loop)."""
+
+  def __init__(self, data, shape):
+    self.data = data
+    self.shape = tuple(shape)
+    self.device = data.device
+
+  def numel(self):
+    return int(np.prod(self.shape))
+
+
+# The 3x3 and the closing 1x1 convolution of a bottleneck unit read their input through
+# ``gn_norm_split`` (one pass that also replaces the statistics finalize launch) when the engine
+# is 'bf16x3'.  Tools flip these for A/B runs.
+USE_PRESPLIT = True
+PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
+PS_TILE = 0              # 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles
+
+
+def gn_norm_split(y, gamma, beta, *, groups=32, eps=1e-5, want_stats=False):
+  """relu(GroupNorm(y)) of a conv output that carries its fused partial sums, written once in the
+  pre-split format -> ``PreSplit`` (or None where the pre-split engine does not apply: another
+  engine, no fused statistics, C % 16 != 0)."""
+  fused = getattr(y, '_snap_gn_partial', None)
+  N, H, W, C = y.shape
+  if (not USE_PRESPLIT or MATMUL_PRECISION != 'bf16x3' or fused is None or fused[2] or groups != 32
+      or C % 16 or C > 2048 or not USE_FUSED_GN_STATS):
+    return None
+  lib = _lib.load()
+  _f32(y, 'y'); _f32(gamma, 'gamma'); _f32(beta, 'beta')
+  partial, tile_rows, _ = fused
+  out = torch.empty(y.numel() * 2, dtype=torch.bfloat16, device=y.device)
+  mu = sc = None
+  if want_stats:
+    mu = torch.empty((N, C), dtype=torch.float32, device=y.device)
+    sc = torch.empty((N, C), dtype=torch.float32, device=y.device)
+  with _region('gn_norm_split', 0.0, 8.0 * y.numel()):
+    st = lib.snap_gn_norm_split_f32(_p(y), _p(partial), N, H * W, C, groups, eps, tile_rows,
+                                    _p(gamma), _p(beta), _p(out), _p(mu), _p(sc), _stream())
+  _lib.check(st, 'snap_gn_norm_split_f32')
+  ps = PreSplit(out, (N, H, W, C))
+  if want_stats:
+    ps.stats = (mu, sc)
+  return ps
+
+
+def presplit(x):
+  """The plain two-part split of x [..., C] f32 (C % 16 == 0) -> ``PreSplit``."""
+  lib = _lib.load()
+  _f32(x, 'x')
+  C = x.shape[-1]
+  rows = x.numel() // C
+  out = torch.empty(x.numel() * 2, dtype=torch.bfloat16, device=x.device)
+  with _region('presplit', 0.0, 8.0 * x.numel()):
+    st = lib.snap_presplit_f32(_p(x), rows, C, _p(out), _stream())
+  _lib.check(st, 'snap_presplit_f32')
+  shape = tuple(x.shape) if x.dim() == 4 else (1,) * (4 - x.dim()) + tuple(x.shape)
+  return PreSplit(out, shape)
+
+
 def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
-    emit_gn_stats=None, math=None, gelu=False,
+    emit_gn_stats=None, math=None, gelu=False, res_init=None, ps_tile=None,
 ):
   """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
+
+  x may be a ``PreSplit`` (``gn_norm_split`` / ``presplit``): the launch then runs on the
+  pre-split engine -- 'bf16x3' arithmetic, prologue NONE, no row lists; ``res_init`` (default
+  ``PS_RES_INIT``) loads ``residual`` into the accumulators before the K loop, ``ps_tile``
+  (default ``PS_TILE``) forces a row tile.
 
   math = 'f32' (exact f32 MFMA) | 'bf16x6' / 'bf16x3' (f32-grade split-bf16 engine: every
   operand split into 3 / 2 bf16 parts after the f32 prologue, 6 / 3 part products accumulated in
@@ -188,8 +257,19 @@ def conv2d(
   Returns y [N,Ho,Wo,Cout].
   """
   lib = _lib.load()
-  _f32(x, 'x'); _f32(w, 'w')
-  N, H, W, Cs = x.shape
+  ps = isinstance(x, PreSplit)
+  if ps:
+    if (prologue != PRO_NONE or rows_in is not None or rows_out is not None or row_count is not None
+        or math not in (None, 'bf16x3')):
+      raise ValueError('conv2d: a PreSplit input takes prologue NONE, no row lists, math bf16x3')
+    math = 'bf16x3'
+    xs, x = x, x.data
+    _chk(x, torch.bfloat16, 'x')
+    N, H, W, Cs = xs.shape
+  else:
+    _f32(x, 'x')
+    N, H, W, Cs = x.shape
+  _f32(w, 'w')
   KH, KW, Cin, Cout = w.shape
   if cin is None:
     cin = Cs
@@ -246,12 +326,17 @@ def conv2d(
     ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0,
                              None, 0)
   else:
-    wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if USE_SPLITK else 0
+    pst = (PS_TILE if ps_tile is None else int(ps_tile)) if ps else 0
+    if ps:
+      wbytes = lib.snap_conv2d_presplit_workspace_bytes(ctypes.byref(d), pst) if USE_SPLITK else 0
+    else:
+      wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if USE_SPLITK else 0
     if wbytes:   # small-M / deep-K layer: split K (its statistics are cheap to take after)
       kws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes, None, 0)
     elif emit_gn_stats is not None:
-      pbytes = lib.snap_conv2d_gn_partial_bytes(ctypes.byref(d))
+      pbytes = (lib.snap_conv2d_presplit_gn_partial_bytes(ctypes.byref(d), pst) if ps
+                else lib.snap_conv2d_gn_partial_bytes(ctypes.byref(d)))
       if pbytes:
         partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
         ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
@@ -271,9 +356,11 @@ def conv2d(
     math = 'f32'     # weight image beyond the split engine's 32-bit offsets (template banks)
   # the RGB root convolution (7 x 7 / stride 2 / pad 3) of an image stored with 4 floats per pixel
   # runs on the split engine with its own weight image (a K slab = 4 pixels of a kernel row)
+  if ps and (parts != 2 or Cin % 16):
+    raise ValueError('conv2d: the pre-split engine needs Cin % 16 == 0 and a two-part weight image')
   root = (parts and (KH, KW, stride, Cin, Cs) == (7, 7, 2, 3, 4) and (pt, pl) == (3, 3)
           and prologue in (PRO_NONE, PRO_AFFINE) and rows_in is None and rows_out is None
-          and row_count is None and partial is None)
+          and row_count is None and partial is None and not ps)
   if root:
     wpk = _packed_weights(w, math + '/root', parts)
     if ex is None:
@@ -291,17 +378,22 @@ def conv2d(
     ex.w_bf16_bytes = wpk.numel() * 2
     ex.w_split_parts = parts
     family = f'conv_split_{math}' if parts else 'conv_bf16'
+    if ps:
+      ex.x_presplit = 1
+      ex.ps_tile = pst
+      ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
-    nbytes = 4.0 * (x.numel() + w.numel() + y.numel())
+    nbytes = 4.0 * ((xs.numel() if ps else x.numel()) + w.numel() + y.numel()
+                    + (residual.numel() if residual is not None else 0))
   else:  # resolved after the sync: only the listed rows are multiplied / moved
     flops = lambda: kflops * int(row_count.item())
     nbytes = lambda: 4.0 * (int(row_count.item()) * (Cin + Cout) + w.numel())
   with _region(
       family, flops, nbytes,
-      lambda: f'M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}_s{stride}'
-              f'_p{prologue}_e{epi}',
+      lambda: f'{"PS_" if ps else ""}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
+              f'_s{stride}_p{prologue}_e{epi}',
   ):
     st = lib.snap_conv2d_nhwc_ex_f32(
         ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
@@ -310,7 +402,9 @@ def conv2d(
     )
   _lib.check(st, 'snap_conv2d_nhwc_ex_f32')
   if partial is not None:
-    y._snap_gn_partial = (partial, lib.snap_conv2d_tile_rows(ctypes.byref(d)), emit_gn_stats == 'relu')
+    tile_rows = (lib.snap_conv2d_presplit_tile_rows(ctypes.byref(d), pst) if ps
+                 else lib.snap_conv2d_tile_rows(ctypes.byref(d)))
+    y._snap_gn_partial = (partial, tile_rows, emit_gn_stats == 'relu')
     if partial2 is not None and ex.gn_partial2_done:
       y._snap_gn_partial_relu = (partial2, y._snap_gn_partial[1], True)
   return y
