@@ -34,26 +34,37 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Timing-only ablations (alt builds: scripts/build_alt.sh; WRONG results): bit0 no DMA inside the
+// loop, bit1 no fragment fetches, bit3 no MFMAs
+#ifndef SNAP_PS_ABLATE
+#define SNAP_PS_ABLATE 0
+#endif
+#ifndef SNAP_PS_STAGGER
+#define SNAP_PS_STAGGER 1     // 512-thread tiles: the two waves of a SIMD issue their DMA pieces at different points of the stage
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NT, int NST, bool RES_INIT, bool DUAL>
+// KS = 16-k steps per ring stage (one barrier per stage), NST = ring depth in stages
+template <int BM, int BN, int NT, int KS, int NST, bool RES_INIT, bool DUAL>
 __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
   constexpr int NS = 2;
   constexpr int WR = NT / 128;
   constexpr int TM = BM / (32 * WR), TN = BN / 64;
   static_assert(BM * 2 == NT, "a thread owns one A row and one octet position");
-  static_assert(TM == 2, "64-row wave blocks");
+  static_assert(TM == 2 && BN % 64 == 0, "64-row wave blocks, 32-column MFMA tiles");
   constexpr int A_PART = BM * 32, B_PART = BN * 32;
   constexpr int A_ST = NS * A_PART, B_ST = NS * B_PART;
-  constexpr int ST = A_ST + B_ST;
-  constexpr int BSLOTS = NS * BN * 2;
-  static_assert(BSLOTS % NT == 0, "whole B pieces per thread");
-  constexpr int BPIECES = BSLOTS / NT;
-  constexpr int PIECES = NS + BPIECES;            // DMA instructions per thread and k-step
-  static_assert(NST >= 3 && NST <= 4, "ring depth");
+  constexpr int ST1 = A_ST + B_ST;                // one k-step
+  constexpr int ST = KS * ST1;                    // one stage
+  constexpr int BSLOTS1 = NS * BN * 2;            // 16-byte B pieces of one k-step
+  static_assert((KS * BSLOTS1) % NT == 0, "whole B pieces per thread and stage");
+  constexpr int BP = KS * BSLOTS1 / NT;
+  constexpr int PIECES = NS * KS + BP;            // DMA instructions per thread and stage
+  static_assert(NST >= 2 && NST <= 4, "ring depth");
   constexpr int kRing = NST * ST;
   constexpr int kStageBytes = 32 * WR * BN * 4;   // epilogue: staged output rows
   constexpr int kStatBytes = NT * 16 * 4;         // epilogue: statistics reduce
@@ -84,11 +95,27 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
   const int64_t pixb = (int64_t)ctiles * 64;      // bytes per pixel of x_ps
 
   // ---- this thread's A row ----------------------------------------------------------------
+  // Both operands are fetched with BUFFER loads (buffer_load_dwordx4 ... lds): a scalar resource +
+  // one 32-bit byte offset per lane instead of a 64-bit address pair, and a lane whose tap lies
+  // outside the image (or whose row lies beyond M) passes an out-of-range offset and receives
+  // ZEROS from the range check -- no select against a zero chunk, no 64-bit VALU in the loop.
   const int arow = tid >> 1;
   const int koct = (tid & 1) ^ ((arow >> 3) & 1);
   const bool r_ok = m0 + arow < Meff;
+  // Offsets are taken from the (tap 0, 0) pixel of the tile's first row -- the pixel index is
+  // non-decreasing in the row index --, clamped at the start of the tensor: every valid (row, tap)
+  // of the tile then lies at a small non-negative 32-bit offset, whatever the size of the tensor.
+  int64_t tile_px;
+  {
+    const int n = m0 / HoWo;
+    const int r = m0 - n * HoWo;
+    const int ho = r / d.Wo;
+    const int wo = r - ho * d.Wo;
+    tile_px = ((int64_t)n * d.H + ho * d.stride - d.pad_t) * d.W + wo * d.stride - d.pad_l;
+    if (tile_px < 0) tile_px = 0;
+  }
   int r_hb, r_wb;
-  const char* r_px;
+  int r_off;                                      // byte offset of the row's (tap 0, 0) pixel (may be < 0)
   {
     const int mm = r_ok ? m0 + arow : 0;
     const int n = mm / HoWo;
@@ -97,12 +124,18 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
     const int wo = r - ho * d.Wo;
     r_hb = ho * d.stride - d.pad_t;
     r_wb = wo * d.stride - d.pad_l;
-    r_px = static_cast<const char*>(a.x_ps) + (((int64_t)n * d.H + r_hb) * d.W + r_wb) * pixb + koct * 16;
+    r_off = (int)(((((int64_t)n * d.H + r_hb) * d.W + r_wb) - tile_px) * pixb) + koct * 16;
   }
-  // ---- issue cursor (runs NST - 1 k-steps ahead of the multiply cursor) ---------------------
+  const int64_t a_left = ((int64_t)d.N * d.H * d.W - tile_px) * pixb;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(static_cast<const char*>(a.x_ps)) + tile_px * pixb, 0,
+      (int)(a_left < 0x7ff00000LL ? a_left : 0x7ff00000LL), 0x00020000);
+  constexpr int kOob = (int)0x80000000u;          // beyond any window this path accepts (< 2 GB)
+  // ---- issue cursor (runs NST - 1 stages ahead of the multiply cursor) ----------------------
   const int kt_begin = a.ksplit > 1 ? split * a.slabs_per_split : 0;
   const int kt_end = a.ksplit > 1 ? min(a.nk, kt_begin + a.slabs_per_split) : a.nk;
   const int nk_loc = kt_end - kt_begin;
+  const int nst_loc = (nk_loc + KS - 1) / KS;     // stages (the last one may be partly empty)
   int ct = 0, kh = 0, kw = 0;
   if (kt_begin > 0) {
     const int kpos = kt_begin / ctiles;
@@ -110,50 +143,74 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
     kh = kpos / d.KW;
     kw = kpos - kh * d.KW;
   }
-  const char* tap_px;
+  int tap_off;                                    // scalar: byte offset of tap (kh, kw)
   bool tap_ok;
   auto set_tap = [&]() {
     const int hi = r_hb + kh, wi = r_wb + kw;
     tap_ok = r_ok && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
-    tap_px = r_px + ((int64_t)kh * d.W + kw) * pixb;
+    tap_off = (kh * d.W + kw) * (int)pixb;
   };
   set_tap();
-  const char* const wt = static_cast<const char*>(a.w_bf16);
+  // B: piece p of this thread = slot tid + NT p of the stage's [k-step][part][column][octet]
+  // order; a wave's 64 slots are 32 whole columns of one (k-step, part) -- 1 KB contiguous in the
+  // weight image (column tile of 128 = (n0 + column) >> 7: wave-uniform) and in LDS.
   const int taps = d.KH * d.KW;
   const int64_t col_tile_bytes = (int64_t)taps * ctiles * (NS * 4096);
-  const char* bsrc[BPIECES];
+  __amdgpu_buffer_rsrc_t rs_b[BP];
+  int b_voff[BP], b_lds[BP], b_ks[BP];
 #pragma unroll
-  for (int p = 0; p < BPIECES; ++p) {
+  for (int p = 0; p < BP; ++p) {
     const int slot = tid + NT * p;
-    const int part = slot / (2 * BN);
-    const int rem = slot - part * (2 * BN);
+    const int ks = slot / BSLOTS1;
+    const int rem1 = slot - ks * BSLOTS1;
+    const int part = rem1 / (2 * BN);
+    const int rem = rem1 - part * (2 * BN);
     const int gcol = n0 + (rem >> 1);                          // (padded columns hold zeros)
-    bsrc[p] = wt + (gcol >> 7) * col_tile_bytes + (int64_t)kt_begin * (NS * 4096) + part * 4096 +
-              (gcol & 127) * 32 + (rem & 1) * 16;
+    b_voff[p] = ks * (NS * 4096) + part * 4096 + (gcol & 127) * 32 + (rem & 1) * 16;
+    b_ks[p] = __builtin_amdgcn_readfirstlane(ks);
+    const int slot0 = __builtin_amdgcn_readfirstlane(slot - lane);   // the wave's first slot
+    const int ks0 = slot0 / BSLOTS1;
+    b_lds[p] = ks0 * ST1 + A_ST + (slot0 - ks0 * BSLOTS1) * 16;
+    const int tile = __builtin_amdgcn_readfirstlane(gcol >> 7);
+    rs_b[p] = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.w_bf16)) + tile * col_tile_bytes, 0,
+        (int)col_tile_bytes, 0x00020000);
   }
-  const char* const zero = reinterpret_cast<const char*>(kZeroChunk);
+  int b_soff = kt_begin * (NS * 4096);            // scalar: the stage's first block of the weight image
+  int ikt = 0;                                    // k-steps issued so far
+  // LDS destination of a DMA piece = wave-uniform base (M0) + 16 x lane
+  const int wbase = __builtin_amdgcn_readfirstlane(wid) * 1024;
   auto issue = [&](int slot) {
     char* const base = ring + slot * ST;
-    const char* const s0 = tap_ok ? tap_px + ct * 64 : zero;
-    __builtin_amdgcn_global_load_lds((cglobal_void_t*)s0, (lds_void_t*)(base + tid * 16), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((cglobal_void_t*)(tap_ok ? s0 + 32 : zero),
-                                     (lds_void_t*)(base + A_PART + tid * 16), 16, 0, 0);
 #pragma unroll
-    for (int p = 0; p < BPIECES; ++p) {
-      __builtin_amdgcn_global_load_lds((cglobal_void_t*)bsrc[p],
-                                       (lds_void_t*)(base + A_ST + 16 * (tid + NT * p)), 16, 0, 0);
-      bsrc[p] += NS * 4096;
-    }
-    if (++ct == ctiles) {
-      ct = 0;
-      if (++kw == d.KW) { kw = 0; ++kh; }
+    for (int ks = 0; ks < KS; ++ks) {
+      const bool live = ikt + ks < nk_loc;        // (beyond the end: zeros into a slot nobody reads)
+      const int voff = (tap_ok && live) ? r_off + (tap_off + ct * 64) : kOob;
+      char* const dst = base + ks * ST1 + wbase;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_t*)dst, 16, voff, 0, 0, 0);
+      // (the lo half through the SCALAR offset: an immediate offset would move the LDS address too)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_t*)(dst + A_PART), 16, voff, 32, 0, 0);
+      // (branch-free: the loop body stays ONE basic block, so that the issues can be scheduled
+      //  between the MFMAs)
+      const bool cw = ct + 1 == ctiles;
+      const bool kww = cw && kw + 1 == d.KW;
+      ct = cw ? 0 : ct + 1;
+      kw = kww ? 0 : (cw ? kw + 1 : kw);
+      kh = kww ? kh + 1 : kh;
       set_tap();
     }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const bool live = ikt + b_ks[p] < nk_loc;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b[p], (lds_void_t*)(base + b_lds[p]), 16,
+                                               live ? b_voff[p] : kOob, b_soff, 0, 0);
+    }
+    b_soff += KS * (NS * 4096);
+    ikt += KS;
   };
 
 #pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (s < nk_loc) issue(s);
+  for (int s = 0; s < NST - 1; ++s) issue(s);
 
   f32x16 acc[TM][TN];
   if constexpr (RES_INIT) {
@@ -187,69 +244,104 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  int slot = 0;                 // ring slot of the k-step being multiplied
+  const int grp = (NT == 512 && SNAP_PS_STAGGER) ? __builtin_amdgcn_readfirstlane(wid >> 2) : 0;
+  int slot = 0;                 // ring slot of the stage being multiplied
   int islot = NST - 1;          // ring slot the next issue goes to
-  for (int kt = 0; kt < nk_loc; ++kt) {
-    // own pieces of k-step kt landed (the younger k-steps' may still travel) ...
-    const int ahead = nk_loc - 1 - kt;
-    if (ahead >= NST - 2) wait_vm<(NST - 2) * PIECES>();
-    else if (NST == 4 && ahead == 1) wait_vm<PIECES>();
-    else wait_vm<0>();
+  for (int st = 0; st < nst_loc; ++st) {
+    // own pieces of stage st landed (the NST - 2 younger stages' may still travel; every iteration
+    // issues a full set of pieces -- out-of-range ones past the end --, so the count is constant) ...
+    wait_vm<(NST - 2) * PIECES>();
     // ... and everybody's; all waves are also past their reads of the slot issued next.  (The
-    // fence-less barrier: __syncthreads() would drain the younger k-steps' DMAs as well.)
+    // fence-less barrier: __syncthreads() would drain the younger stages' DMAs as well.)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + NST - 1 < nk_loc) issue(islot);
-    islot = islot + 1 == NST ? 0 : islot + 1;
-    const char* as = ring + slot * ST;
-    const char* bs = as + A_ST;
+    // Waves w and w + 4 of a 512-thread workgroup share a SIMD.  A wave issuing its DMA pieces
+    // blocks while the vector-memory queue takes them, and right after the barrier every wave of
+    // the workgroup would do so at once with the matrix pipes idle: the upper four waves issue
+    // theirs after the first block of MFMAs instead, under which the lower four issue.
+    if (!(SNAP_PS_ABLATE & 1) && grp == 0) issue(islot);
+    const char* const stage = ring + slot * ST;
     slot = slot + 1 == NST ? 0 : slot + 1;
-    bf16x8 av[TM][NS], bv[TN][NS];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int R = wr * (BM / WR) + i * 32 + l31;
-      const char* p0 = as + R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks == KS / 2 && KS > 1) {
+        if (!(SNAP_PS_ABLATE & 1) && grp == 1) issue(islot);
+      }
+      const char* as = stage + ks * ST1;
+      const char* bs = as + A_ST;
+      bf16x8 av[TM][NS], bv[TN][NS];
+      if (SNAP_PS_ABLATE & 2) {
 #pragma unroll
-      for (int p = 0; p < NS; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(p0 + p * A_PART);
-    }
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int C = wc * (BN / 2) + j * 32 + l31;
-      const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+          for (int p = 0; p < NS; ++p) asm volatile("" : "=v"(av[i][p]));
 #pragma unroll
-      for (int p = 0; p < NS; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(p0 + p * B_PART);
-    }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int p = 0; p < NS; ++p) asm volatile("" : "=v"(bv[j][p]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int R = wr * (BM / WR) + i * 32 + l31;
+          const char* p0 = as + R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
+#pragma unroll
+          for (int p = 0; p < NS; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(p0 + p * A_PART);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int C = wc * (BN / 2) + j * 32 + l31;
+          const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+#pragma unroll
+          for (int p = 0; p < NS; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(p0 + p * B_PART);
+        }
+      }
 #define SNAP_PS_PRODUCT(PA, PB)                                                              \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA], bv[j][PB], acc[i][j], 0, 0, 0);
-    SNAP_PS_PRODUCT(1, 0)
-    SNAP_PS_PRODUCT(0, 1)
-    SNAP_PS_PRODUCT(0, 0)
+      if (!(SNAP_PS_ABLATE & 8)) {
+        SNAP_PS_PRODUCT(1, 0)
+        if (KS == 1) {
+          if (!(SNAP_PS_ABLATE & 1) && grp == 1) issue(islot);
+        }
+        SNAP_PS_PRODUCT(0, 1)
+        SNAP_PS_PRODUCT(0, 0)
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int p = 0; p < NS; ++p) asm volatile("" ::"v"(av[i][p]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int p = 0; p < NS; ++p) asm volatile("" ::"v"(bv[j][p]));
+      }
 #undef SNAP_PS_PRODUCT
+    }
+    islot = islot + 1 == NST ? 0 : islot + 1;
   }
   __syncthreads();              // the last stage is read: the ring becomes the epilogue's buffer
   conv_epilogue<BM, BN, DUAL, NT, RES_INIT>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
-// registers: 64 accumulators + 32 fragment registers + addressing; three 48 KB workgroups
-// (256 threads) or two 72 KB workgroups (512 threads) per CU
-template <int BM, int BN, int NT, int NST, bool RES_INIT, bool DUAL>
-__global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void conv_ps_kernel(const ConvArgs a) {
-  conv_ps_body<BM, BN, NT, NST, RES_INIT, DUAL>(a);
+// workgroups per CU: three of 256 threads (48 KB), two of 512 threads (72 KB), or ONE 256 x 192
+// tile (112 KB, 96 accumulator + 40 fragment registers per lane)
+template <int BM, int BN, int NT, int KS, int NST, bool RES_INIT, bool DUAL>
+__global__ __launch_bounds__(NT, NT == 512 ? (BN == 192 ? 2 : 4) : 3) void conv_ps_kernel(const ConvArgs a) {
+  conv_ps_body<BM, BN, NT, KS, NST, RES_INIT, DUAL>(a);
 }
 
-template <int BM, int BN, int NT, int NST>
+template <int BM, int BN, int NT, int KS, int NST>
 int launch_variant(const ConvArgs& a, bool res_init, bool dual, dim3 grid, hipStream_t s) {
   if constexpr (BN == 128) {
     if (res_init && dual)
-      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, NST, true, true>), grid, dim3(NT), 0, s, a);
+      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, KS, NST, true, true>), grid, dim3(NT), 0, s, a);
     else if (res_init)
-      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, NST, true, false>), grid, dim3(NT), 0, s, a);
+      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, KS, NST, true, false>), grid, dim3(NT), 0, s, a);
     else if (dual)
-      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, NST, false, true>), grid, dim3(NT), 0, s, a);
+      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, KS, NST, false, true>), grid, dim3(NT), 0, s, a);
     else
-      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, NST, false, false>), grid, dim3(NT), 0, s, a);
+      hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, KS, NST, false, false>), grid, dim3(NT), 0, s, a);
   } else {
-    hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, NST, false, false>), grid, dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((conv_ps_kernel<BM, BN, NT, KS, NST, false, false>), grid, dim3(NT), 0, s, a);
   }
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
@@ -259,8 +351,11 @@ int launch_variant(const ConvArgs& a, bool res_init, bool dual, dim3 grid, hipSt
 
 // Tile: 64-wide column tiles only for Cout <= 64 (the 3x3 convolutions of the first ResNet
 // stage); 256-row tiles (512 threads, two workgroups per CU) once they still give two full rounds
-// of the 512 slots; force: 1 = 128 rows, 2 = 256 rows (SnapConvExtras.ps_tile, tuning).
+// of the 512 slots; force: 1 = 128 rows, 2 = 256 rows, 3 = 256 x 192 (one workgroup per CU, two
+// k-steps per stage: the large-GEMM tile of the exhaustive voting; Cout % 192 == 0)
+// (SnapConvExtras.ps_tile).
 snapconv::PsTile snapconv::ps_choose_tile(int64_t M, int64_t N, int force) {
+  if (force == 3 && N % 192 == 0) return {256, 192, 512};
   if (N <= 64) return {128, 64, 256};
   const int64_t t256 = snap_cdiv(M, 256) * snap_cdiv(N, 128);
   if (force == 2 || (force == 0 && t256 >= 1024)) return {256, 128, 512};
@@ -271,7 +366,7 @@ snapconv::PsTile snapconv::ps_choose_tile(int64_t M, int64_t N, int force) {
 // workgroups, at least 8 k-steps per split, bounded by the workspace); 1 = none
 int snapconv::ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t kpartial_bytes) {
   const int64_t tiles = snap_cdiv(M, bm) * snap_cdiv((int64_t)Cout, bn);
-  const int64_t target = bm == 256 ? 1024 : 768;
+  const int64_t target = bn == 192 ? 768 : bm == 256 ? 1024 : 768;
   if (tiles > target / 2 || nk < 16) return 1;
   int64_t S = (target + tiles - 1) / tiles;
   S = S < nk / 8 ? S : nk / 8;
@@ -285,7 +380,21 @@ int snapconv::launch_ps(ConvArgs a, hipStream_t s) {
   if (!a.x_ps || !a.w_bf16) return SNAP_ERR_NULL;
   if (d.prologue != SNAP_PRO_NONE || d.Cin % 16 != 0 || a.rows_in || a.rows_out || a.row_count)
     return SNAP_ERR_UNSUPPORTED;
-  if ((int64_t)d.N * d.H * d.W * (d.Cin / 16) * 64 >= ((int64_t)1 << 40)) return SNAP_ERR_BAD_SHAPE;
+  // 32-bit buffer offsets with an out-of-range marker at 2^31: the input window of one row tile
+  // (256 output rows + the kernel's extent, two images) and one column tile of the weight image
+  // must stay below 2 GB
+  {
+    const int64_t Wo = d.Wo, Ho = d.Ho, st = d.stride;
+    int64_t dq = 255 / Wo + 1;                                   // output-row wraps inside a tile
+    if (dq > (int64_t)d.N * Ho - 1) dq = (int64_t)d.N * Ho - 1;
+    int64_t dn = dq / Ho + 1;                                    // image wraps
+    if (dn > d.N - 1) dn = d.N - 1;
+    const int64_t c = d.H - Ho * st > 0 ? d.H - Ho * st : 0;
+    const int64_t dwo = dq == 0 ? (Wo < 256 ? Wo : 256) : Wo;
+    const int64_t span = (dq * st + dn * c + d.KH - 1 + d.pad_t) * d.W + (dwo + 1) * st + d.KW + d.pad_l;
+    if (span * (d.Cin / 16) * 64 >= 0x7ff00000LL) return SNAP_ERR_UNSUPPORTED;
+  }
+  if ((int64_t)d.KH * d.KW * (d.Cin / 16) * 8192 >= 0x7ff00000LL) return SNAP_ERR_UNSUPPORTED;
   const PsTile t = ps_choose_tile(a.M, d.Cout, a.ps_tile);
   a.ctiles = d.Cin / 16;
   a.nk = d.KH * d.KW * a.ctiles;
@@ -314,12 +423,14 @@ int snapconv::launch_ps(ConvArgs a, hipStream_t s) {
   if (a.gn_partial2_done) *a.gn_partial2_done = dual ? 1 : 0;
   const dim3 grid((unsigned)nblocks);
   int st;
-  if (t.bm == 256)
-    st = launch_variant<256, 128, 512, 3>(a, res_init, dual, grid, s);
+  if (t.bn == 192)
+    st = launch_variant<256, 192, 512, 2, 2>(a, false, false, grid, s);
+  else if (t.bm == 256)
+    st = launch_variant<256, 128, 512, 1, 3>(a, res_init, dual, grid, s);
   else if (t.bn == 128)
-    st = launch_variant<128, 128, 256, 3>(a, res_init, dual, grid, s);
+    st = launch_variant<128, 128, 256, 1, 3>(a, res_init, dual, grid, s);
   else
-    st = launch_variant<128, 64, 256, 4>(a, false, false, grid, s);
+    st = launch_variant<128, 64, 256, 1, 4>(a, false, false, grid, s);
   if (st != SNAP_OK) return st;
   if (a.ksplit > 1) {
     const int64_t total4 = (int64_t)a.M * (d.Cout / 4);

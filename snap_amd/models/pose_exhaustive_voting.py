@@ -79,7 +79,15 @@ def _correlate(mp, tw, R, q_hw, templates=None):
   A4, B4 = -(-Ho // S), -(-Wo // S)
   pb = max(0, S * (A4 - 1) + (H + S - 1) - mp.shape[0])  # zero rows only cropped outputs can see
   pr = max(0, S * (B4 - 1) + (W + S - 1) - mp.shape[1])
-  raw4 = ops.conv2d(mp[None], tws, stride=S, padding=((0, pb), (0, pr)))[0]   # [A4, B4, R*S*S]
+  if (ops.MATMUL_PRECISION == 'bf16x3' and ops.USE_PRESPLIT_VOTING and mp.shape[-1] % 16 == 0
+      and (R * S * S) % 192 == 0):
+    # the correlation as ONE large GEMM on the pre-split engine: the map is split into its two
+    # bf16 parts once (instead of once per tap and column tile inside the K loop), both operands
+    # travel by LDS-DMA, 256 x 192 tiles (R S^2 = 576 = three column tiles); same products, same
+    # k order, same bits as the split engine's im2col body
+    raw4 = ops.conv2d(ops.presplit(mp[None]), tws, stride=S, padding=((0, pb), (0, pr)), ps_tile=3)[0]
+  else:
+    raw4 = ops.conv2d(mp[None], tws, stride=S, padding=((0, pb), (0, pr)))[0]   # [A4, B4, R*S*S]
   del tws
   raw = raw4.reshape(A4, B4, R, S, S).permute(0, 3, 1, 4, 2).reshape(A4 * S, B4 * S, R)
   return raw[:Ho, :Wo].contiguous()

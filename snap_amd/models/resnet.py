@@ -59,7 +59,7 @@ def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, emit=True, presplit=False, **k
   if base.needs_grad(x, w, gn_p['scale'], gn_p['bias']):
     return ag.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn_params=(gn_p['scale'], gn_p['bias']),
                      emit_gn_stats='raw' if emit else None, **kw)
-  if presplit and gn_stats is None and w.shape[2] % 16 == 0:
+  if presplit and ops.USE_PRESPLIT and gn_stats is None and w.shape[2] % 16 == 0:
     xs = ops.gn_norm_split(x, gn_p['scale'].reshape(-1), gn_p['bias'].reshape(-1))
     if xs is not None:
       return ops.conv2d(xs, w, emit_gn_stats=mode, **kw)

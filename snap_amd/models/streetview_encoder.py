@@ -155,7 +155,18 @@ class StreetViewEncoder(base.Module):
           cin=self.fusion_mlp.in_dim, Z=grid_shape[-1],
           relu_in=bool(cfg.fusion.apply_input_activation), x_split=split,
           zero_slabs=(nvar, nvar) if classed else None)
-      pred['feature_volume'] = types.FeatureVolume(features=None, valid=valid.reshape(grid_shape))
+      # the reference's pytree entry (streetview_encoder.py:282-286), produced on first access
+      # by the unfused chain on the same inputs: lift -> fusion MLP -> mask
+      kw_plain = {k: v for k, v in kw.items()
+                  if k not in ('valid_rows_only', 'out_split', 'class_rows')}
+      cam_p, rt_p = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
+
+      def volume(f_images=f_images, xyz_flat=xyz_flat, p=p):
+        pooled_d, valid_d = ops.lift_pool(f_images, cam_p, rt_p, xyz_flat, **kw_plain)[:2]
+        f = self.fusion_mlp(p, pooled_d, False, row_mask=valid_d)
+        return f.reshape(*grid_shape, f.shape[-1])
+
+      pred['feature_volume'] = types.LazyFeatureVolume(volume, valid=valid.reshape(grid_shape))
       pred['feature_plane'] = types.FeaturePlane(
           features=plane.reshape(*grid_shape[:-1], plane.shape[-1]),
           valid=pvalid.reshape(grid_shape[:-1]))

@@ -14,6 +14,39 @@ class FeatureVolume:
     return dataclasses.replace(self, **kw)
 
 
+class LazyFeatureVolume:
+  """A ``FeatureVolume`` whose ``features`` are produced on first access.
+
+  With ``bev_mapper.materialize_volume = False`` the StreetView encoder produces the BEV plane
+  straight from the pooled observations (fusion MLP + vertical max pooling in one kernel) and the
+  dense [..., X, Y, Z, D] volume of ``streetview_encoder.py:282-286`` is never written.  The
+  output pytree keeps the reference's entry: a consumer that does read ``features`` gets the
+  volume of the unfused chain (lift -> fusion MLP -> mask), computed then and remembered."""
+
+  def __init__(self, thunk, valid=None):
+    self._thunk = thunk
+    self._features = None
+    self.valid = valid
+
+  @property
+  def features(self):
+    if self._features is None and self._thunk is not None:
+      self._features = self._thunk()
+      self._thunk = None              # (drops the references to the encoder's inputs)
+    return self._features
+
+  @property
+  def materialized(self):
+    return self._features is not None
+
+  def replace(self, **kw):
+    if 'features' in kw:
+      return FeatureVolume(features=kw['features'], valid=kw.get('valid', self.valid))
+    out = LazyFeatureVolume(self._thunk, kw.get('valid', self.valid))
+    out._features = self._features
+    return out
+
+
 @dataclasses.dataclass
 class FeaturePlane:
   """2-D plane of features [..., X, Y, D] with validity mask [..., X, Y]."""

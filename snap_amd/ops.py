@@ -179,10 +179,13 @@ class PreSplit:
     return int(np.prod(self.shape))
 
 
-# The 3x3 and the closing 1x1 convolution of a bottleneck unit read their input through
-# ``gn_norm_split`` (one pass that also replaces the statistics finalize launch) when the engine
-# is 'bf16x3'.  Tools flip these for A/B runs.
-USE_PRESPLIT = True
+# USE_PRESPLIT: the 3x3 and the closing 1x1 convolution of a bottleneck unit read their input
+# through ``gn_norm_split`` (one pass that also replaces the statistics finalize launch) on the
+# 'bf16x3' engine.  Measured at C2 (tools/unit_bench.py, profiles/r03_unit_bench.json): the
+# pre-split convolutions are 10-25 % faster than the fused-prologue ones, the extra pass over the
+# activation costs what they gain -- off by default; the engine's own user is the exhaustive voting.
+USE_PRESPLIT = False
+USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
 PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
 PS_TILE = 0              # 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles
 
@@ -193,7 +196,7 @@ def gn_norm_split(y, gamma, beta, *, groups=32, eps=1e-5, want_stats=False):
   engine, no fused statistics, C % 16 != 0)."""
   fused = getattr(y, '_snap_gn_partial', None)
   N, H, W, C = y.shape
-  if (not USE_PRESPLIT or MATMUL_PRECISION != 'bf16x3' or fused is None or fused[2] or groups != 32
+  if (MATMUL_PRECISION != 'bf16x3' or fused is None or fused[2] or groups != 32
       or C % 16 or C > 2048 or not USE_FUSED_GN_STATS):
     return None
   lib = _lib.load()

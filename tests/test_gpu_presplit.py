@@ -97,7 +97,7 @@ PS_CASES = [
     (2, 40, 36, 64, 1, 64, 1, False),       # 64-wide column tile
     (1, 20, 96, 32, 3, 64, 1, False),       # 3x3 (W > 79: conv_split takes its im2col body too)
     (2, 20, 96, 32, 3, 128, 1, False),
-    (2, 41, 37, 48, 3, 128, 2, False),      # stride 2, ragged sizes
+    (2, 41, 37, 64, 3, 128, 2, False),      # stride 2, ragged sizes
     (3, 23, 19, 128, 1, 512, 1, True),      # ragged M tail
 ]
 
@@ -178,6 +178,31 @@ def test_conv_ps_split_k_and_plain_presplit():
   got = ops.conv2d(ops.presplit(x2), w2, bias=bias, relu=True, row_mask=mask)
   want = ops.conv2d(x2, w2, bias=bias, relu=True, row_mask=mask)
   assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('M,K,N', [(5000, 48, 192), (777, 80, 576), (4096, 256, 384)])
+def test_conv_ps_256x192_tile(M, K, N):
+  """The large-GEMM tile (256 x 192, two k-steps per ring stage, one workgroup per CU: the
+  exhaustive voting's): odd numbers of k-steps (a half-empty last stage), ragged M, column tiles
+  that straddle the 128-column blocks of the weight image, split-K."""
+  x = rnd((1, 1, M, K), 600 + K).to(DEV)
+  w = rnd((1, 1, K, N), 601, 1 / np.sqrt(K)).to(DEV)
+  ops.USE_SPLITK = False
+  try:
+    want = ops.conv2d(x, w)                                   # conv_split, im2col body
+    got = ops.conv2d(ops.presplit(x), w, ps_tile=3)
+  finally:
+    ops.USE_SPLITK = True
+  assert torch.equal(got, want)
+  got_k = ops.conv2d(ops.presplit(x), w, ps_tile=3)           # split-K where the shape asks for it
+  helpers.report('256x192 split-K', got_k, want, atol=2e-5, rtol=1e-5)
+  # a strided 5x5 correlation (the voting's shape class) against the oracle
+  xi = rnd((1, 37, 41, 32), 602).to(DEV)
+  wi = rnd((5, 5, 32, 192), 603, 1 / np.sqrt(800.0)).to(DEV)
+  kw = dict(stride=4, padding=((0, 3), (0, 2)))
+  got = ops.conv2d(ops.presplit(xi), wi, ps_tile=3, **kw)
+  want = oracle_ops.conv2d(xi.cpu(), wi.cpu(), **kw)
+  helpers.report('256x192 strided 5x5 vs oracle', got, want, atol=TOL, rtol=1e-5)
 
 
 def test_resnet_unit_takes_the_presplit_path_and_matches_the_fused_one():
