@@ -328,6 +328,8 @@ def main(argv=None):
   ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
   ap.add_argument('--device', default='cuda')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extra-legs', action='store_true',
+                  help='skip the two short reference-configuration legs (f32_exact, volume_materialized)')
   ap.add_argument('--dist-backend', default=None,
                   help='testing only: override the process-group backend (default nccl = RCCL)')
   ap.add_argument('--share-gpu', action='store_true',
@@ -406,6 +408,26 @@ def main(argv=None):
       dist.barrier()
     _sync(device)
 
+  # what a multi-GPU record must show: the process group really has N ranks on the collective
+  # library named, every rank sits on its own device and holds its own shard of scenes
+  dist_info = {
+      'world_size': world, 'rank_device': str(device),
+      'backend': dist.get_backend() if world > 1 else None,
+      'rccl_version': ('.'.join(str(v) for v in torch.cuda.nccl.version())
+                       if use_cuda and hasattr(torch.cuda, 'nccl') else None),
+  }
+  if world > 1:
+    digest = 0.0 if batch is None else float(
+        batch['map']['images'].double().sum() + batch['query']['images'].double().sum())
+    mine = torch.tensor([float(rank), float(device.index if use_cuda else -1), digest],
+                        dtype=torch.float64, device=device)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    allr = torch.stack(allr).cpu()
+    dist_info['ranks'] = [int(v) for v in allr[:, 0]]
+    dist_info['rank_devices'] = [int(v) for v in allr[:, 1]]
+    dist_info['shard_digests'] = [round(float(v), 3) for v in allr[:, 2]]
+
   # Warm-up and timed steps follow the SAME allocation pattern (result dropped before the next
   # step starts): the caching allocator then reaches its steady state in the first warm-up
   # step.  Holding the previous result across a step made the allocator fetch fresh 7.5 GiB
@@ -473,6 +495,7 @@ def main(argv=None):
                   else INFER_DTYPE[args.precision] + '; kernel gradients on the exact f32 engine' if args.precision in INFER_DTYPE
                   else 'bf16 GEMM operands, f32 accumulate / parameters / optimizer'),
         'data': 'synthetic',
+        'distributed': dist_info,
         'config': {
             'workload': WORKLOADS[args.workload]['desc'],
             'scenes_per_gpu': scenes_per_rank,
@@ -483,7 +506,8 @@ def main(argv=None):
                      'inference forward (BEVLocalizer.apply, train=False)' if args.mode == 'infer' else
                      f'train_step: forward + backward + gradient all-reduce + Adam ({args.precision})'),
             'feature_volume': ('n/a' if is_c4 else 'materialized' if (args.materialize_volume or args.mode != 'infer')
-                               else 'not materialized: fusion MLP + vertical max pooling fused, plane only'),
+                               else 'lazy: fusion MLP + vertical max pooling fused into the plane; '
+                                    'feature_volume.features is produced on first access (not in the timed step)'),
         },
     }
     if args.mode == 'infer' and not is_c4:
@@ -585,6 +609,39 @@ def main(argv=None):
       if dump:
         with open(dump, 'w') as f:
           json.dump({n: prof.launches(n) for n in summ}, f)
+    if (args.mode == 'infer' and not is_c4 and use_cuda and world == 1 and not args.no_extra_legs
+        and args.math == 'bf16x3' and not args.materialize_volume):
+      # The headline configuration is the split-bf16 engine without the dense feature volume.  The
+      # same workload in the two reference-shaped configurations, timed here (short legs, same
+      # bracketing) so that the driver's line carries them: exact f32 matrix-core arithmetic with
+      # every output written ('f32_exact'), and the headline engine with the dense feature volume
+      # written ('volume_materialized').
+      def leg(math, steps=5, warmup=2):
+        prev = (ops.MATMUL_PRECISION, cfg.bev_mapper.materialize_volume)
+        ops.MATMUL_PRECISION, cfg.bev_mapper.materialize_volume = math, True
+        try:
+          p = None
+          for i in range(warmup):
+            p = None
+            p = step(10_000 + i)
+          _sync(device)
+          t1 = time.perf_counter()
+          for i in range(steps):
+            p = None
+            p = step(20_000 + i)
+          _sync(device)
+          dt = time.perf_counter() - t1
+          vol = p['map']['streetview']['feature_volume']
+          assert getattr(vol, 'materialized', True) and vol.features is not None
+        finally:
+          ops.MATMUL_PRECISION, cfg.bev_mapper.materialize_volume = prev
+        return {'ms_per_step': round(1e3 * dt / steps, 3),
+                'scenes_per_sec': round(scenes_per_rank * steps / dt, 3),
+                'steps': steps, 'warmup': warmup, 'dtype': INFER_DTYPE[math],
+                'feature_volume': 'materialized'}
+      pred = None
+      out['f32_exact'] = leg('f32')
+      out['volume_materialized'] = leg('bf16x3')
     if args.mode == 'train':
       out['train_logs'] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in last_logs.items()}
     if (world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']

@@ -161,9 +161,15 @@ class StreetViewEncoder(base.Module):
                   if k not in ('valid_rows_only', 'out_split', 'class_rows')}
       cam_p, rt_p = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
 
+      engine = ops.MATMUL_PRECISION            # (the engine of THIS apply, whenever the access comes)
+
       def volume(f_images=f_images, xyz_flat=xyz_flat, p=p):
-        pooled_d, valid_d = ops.lift_pool(f_images, cam_p, rt_p, xyz_flat, **kw_plain)[:2]
-        f = self.fusion_mlp(p, pooled_d, False, row_mask=valid_d)
+        prev, ops.MATMUL_PRECISION = ops.MATMUL_PRECISION, engine
+        try:
+          pooled_d, valid_d = ops.lift_pool(f_images, cam_p, rt_p, xyz_flat, **kw_plain)[:2]
+          f = self.fusion_mlp(p, pooled_d, False, row_mask=valid_d)
+        finally:
+          ops.MATMUL_PRECISION = prev
         return f.reshape(*grid_shape, f.shape[-1])
 
       pred['feature_volume'] = types.LazyFeatureVolume(volume, valid=valid.reshape(grid_shape))

@@ -31,8 +31,9 @@ def main():
   metrics = {'err': torch.tensor([1.0, 3.0]) * (rank + 1), 'hit': torch.tensor([1.0, 0.0])}
   mask = torch.tensor([True, rank == 0])
   red = sdist.reduce_batch_metrics(metrics, mask)
-  # rank0: err 1,3 (both valid); rank1: err 2,(6 masked) -> (1+3+2)/3
-  assert abs(red['err'] - 2.0) < 1e-9 and abs(red['hit'] - 2.0 / 3.0) < 1e-9
+  # rank 0: err 1, 3 (both valid); rank r > 0: err r + 1 (its second entry masked); world 2 -> (1+3+2)/3
+  want_err = (4.0 + sum(r + 1 for r in range(1, world))) / (world + 1)
+  assert abs(red['err'] - want_err) < 1e-9 and abs(red['hit'] - world / (world + 1.0)) < 1e-9
   # overlapped reducer: hooks fire during backward(), buckets are reduced asynchronously
   leaves = [(b.clone() * 0 + 1.0).requires_grad_(True) for b in base[:4]]
   unused = torch.ones(3, requires_grad=True)                 # never reaches the loss
@@ -44,6 +45,15 @@ def main():
     assert torch.allclose(gavg, b * scale, atol=1e-6)
   assert float(avg[4].abs().max()) == 0.0 and all(l.grad is None for l in leaves)
   assert red.calls == len(red.buckets) >= 2, (red.calls, len(red.buckets))
+  # every rank derives the SAME bucket plan (a rank with a different plan would pair its buckets
+  # with other ranks' buckets of another size: a hang or silent corruption on RCCL)
+  import hashlib
+  h = int(hashlib.sha256(repr(red.buckets).encode()).hexdigest()[:12], 16)
+  plans = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+  dist.all_gather(plans, torch.tensor([h], dtype=torch.int64))
+  assert len({int(p) for p in plans}) == 1, plans
+  if rank == 0:
+    print('BUCKET_PLAN_EQUAL', world)
   if rank == 0:
     print('DIST_SYNC_OK', calls)
   dist.barrier()

@@ -43,6 +43,44 @@ def test_bench_two_ranks_gloo():
   assert 'cpu_baseline' not in rec    # rank 0 at N=1 only
 
 
+def test_bench_eight_ranks_gloo():
+  """The launch contract at the node's full width (8 ranks, as `bench.py --gpus 8` is launched):
+  rank -> shard mapping, distinct per-rank data, one JSON line, whole-job value, and the
+  process-group facts a multi-GPU record must carry (backend, world size, per-rank shards)."""
+  cmd = [
+      sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8',
+      '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+      os.path.join(ROOT, 'tests', 'dist_driver.py'),
+      '--gpus', '8', '--steps', '1', '--warmup', '1', '--workload', 'tiny', '--device', 'cpu',
+  ]
+  env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-3000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, f'expected exactly one JSON line, got {len(lines)}: {out.stdout[-2000:]}'
+  rec = json.loads(lines[0])
+  assert rec['n_gpus'] == 8 and rec['config']['global_batch'] == 16 and rec['config']['scenes_per_gpu'] == 2
+  d = rec['distributed']
+  assert d['world_size'] == 8 and d['backend'] == 'gloo' and d['ranks'] == list(range(8))
+  assert len(set(d['shard_digests'])) == 8, d           # every rank generated its OWN scenes
+  expect = rec['config']['global_batch'] * rec['steps'] / (rec['ms_per_step'] * rec['steps'] / 1e3)
+  assert abs(rec['value'] - expect) / expect < 1e-3
+
+
+def test_gradient_and_metric_sync_eight_ranks_gloo():
+  """The training exchange step (bucketed gradient mean, finite flag, metric psum, overlapped
+  reducer) at world size 8; every rank derives the same bucket plan."""
+  cmd = [
+      sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8',
+      '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+      os.path.join(ROOT, 'tests', 'dist_sync_driver.py'),
+  ]
+  env = dict(os.environ, OMP_NUM_THREADS='1')
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+  assert out.returncode == 0, out.stderr[-3000:]
+  assert 'DIST_SYNC_OK' in out.stdout and 'BUCKET_PLAN_EQUAL 8' in out.stdout
+
+
 def test_bench_rejects_world_size_mismatch():
   out = subprocess.run(
       [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'tiny',

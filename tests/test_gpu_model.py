@@ -94,7 +94,12 @@ def test_localizer_without_feature_volume():
   pred, _ = _run(cfg, 2, 3, (64, 64), seed=4, math='bf16x3')
   for side in ('map', 'query'):
     sv = pred[side]['streetview']
-    assert sv['feature_volume'].features is None
+    # the pytree keeps the reference's entry (streetview_encoder.py:282-286): not computed by the
+    # step, produced by the unfused chain on first access -- the volume of the materialising run
+    vol = sv['feature_volume']
+    assert not vol.materialized
+    assert torch.equal(vol.features, full[side]['streetview']['feature_volume'].features)
+    assert vol.materialized and torch.equal(vol.valid, full[side]['streetview']['feature_volume'].valid)
     _check_validity(f'{side} voxel validity', pred[side], ref[side], ob[side], cfg)
     fp, fp_full = sv['feature_plane'], full[side]['streetview']['feature_plane']
     assert torch.equal(fp.valid, fp_full.valid)
@@ -217,6 +222,13 @@ def test_output_pytree_keys():
       'feature_plane'}
   assert pred['scores_poses'].shape == (1, 17)
   assert pred['map_t_query_samples'].shape == (1, 17)
+  # the same pytree in the plane-only mode of the bench (bev_mapper.materialize_volume = False)
+  cfg.bev_mapper.materialize_volume = False
+  plane, _ = _run(cfg, 1, 3, (64, 64), seed=5, math='bf16x3')
+  assert set(plane) >= base and set(plane['map']['streetview']) == set(pred['map']['streetview'])
+  vol = plane['map']['streetview']['feature_volume']
+  assert vol.features.shape == pred['map']['streetview']['feature_volume'].features.shape
+  assert vol.valid.shape == vol.features.shape[:-1]
 
 
 def test_evaluator_contract_on_tiny_model(tmp_path):

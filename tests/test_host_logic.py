@@ -293,7 +293,9 @@ def test_fused_plane_path_host_plumbing(oracle_backend, monkeypatch):
   got = loc2.apply(variables, batch, train=False, rngs={'sampling': 3})
   assert all(k == {'valid_rows_only': True, 'out_split': True, 'class_rows': True} for k in seen['kw'])
   assert set(np.unique(seen['classes'].numpy())) <= {0, 1, 2} and int((seen['classes'] == 1).sum()) > 0
-  assert got['map']['streetview']['feature_volume'].features is None
+  vol = got['map']['streetview']['feature_volume']      # lazily produced: the reference's pytree entry
+  assert not vol.materialized
+  assert vol.features.shape == (2, 32, 32, 12, 32) and vol.materialized
   for side in ('map', 'query'):
     helpers.report(f'{side} bev_matching (fused, classed)', got[side]['bev_matching'].features,
                    ref[side]['bev_matching'].features, atol=2e-5)

@@ -51,7 +51,7 @@ def compare(pred, ref, args, t_hip, t_cpu):
                                     rsv['image_feature_pyramid']['features'][-1]),
       'voxel_validity_mismatch_fraction': float(mism.mean()),
       # (engine '<math>+plane': the volume is not materialised -- its vertical max is compared)
-      'feature_volume_rel_err': (None if sv['feature_volume'].features is None else
+      'feature_volume_rel_err': (None if not getattr(sv['feature_volume'], 'materialized', True) else
                                  rel(sv['feature_volume'].features.cpu().numpy()[~mism],
                                      rsv['feature_volume']['features'][~mism])),
       'streetview_plane_rel_err': rel(sv['feature_plane'].features, rsv['feature_plane']['features']),
