@@ -328,6 +328,7 @@ def main(argv=None):
   ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
   ap.add_argument('--device', default='cuda')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--dump', default=None, help='write the per-launch HIP-event timings of the profiled step (JSON)')
   ap.add_argument('--no-extra-legs', action='store_true',
                   help='skip the two short reference-configuration legs (f32_exact, volume_materialized)')
   ap.add_argument('--dist-backend', default=None,
@@ -605,7 +606,7 @@ def main(argv=None):
               'kernel': 'exhaustive_voting', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
               'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5), 'algorithmic_bytes': c4_algo['voting_bytes'],
               'note': 'algorithmic bytes of SURVEY 8(d); only a frequency-domain formulation is HBM-bound'}
-      dump = os.environ.get('SNAP_BENCH_DUMP')
+      dump = args.dump or os.environ.get('SNAP_BENCH_DUMP')
       if dump:
         with open(dump, 'w') as f:
           json.dump({n: prof.launches(n) for n in summ}, f)

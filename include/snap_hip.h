@@ -63,6 +63,11 @@ typedef struct SnapConvDesc {
                                          BEFORE zero padding                       */
   int32_t epilogue;                   /* OR of SNAP_EPI_*                          */
   float in_scale, in_shift;           /* SNAP_PRO_AFFINE: x*in_scale + in_shift    */
+  int32_t tile_hint;                  /* 0 = the engine picks the output tile; bm * 1000 + bn
+                                         (128128 | 128064 | 64128 | 64064) forces one -- part of
+                                         the descriptor because the size queries depend on it
+                                         (tests and tuning tools; the library reads no
+                                         environment variables)                    */
 } SnapConvDesc;
 
 /* y = epilogue( conv( prologue(x), w ) ).  w is HWIO flattened: [KH*KW*Cin, Cout].
@@ -126,7 +131,11 @@ typedef struct SnapConvExtras {
   int32_t ps_tile;            /* ... 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles (tuning) */
   int32_t ps_res_init;        /* ... 1 = a residual is loaded into the accumulators before the K loop
                                  (r + p1 + p2 + ... instead of (p1 + p2 + ...) + r) */
+  int32_t bk_hint;            /* f32 engine: K-slab depth 16 | 32 of the large tiles (0 = default 16) */
+  int32_t tune_flags;         /* SNAP_TUNE_*: A/B switches for tests and tuning tools (0 = defaults) */
 } SnapConvExtras;
+#define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
+#define SNAP_TUNE_ABLATE_SHIFT 8   /* bits 8..: timing-only ablations of the K loop (WRONG results) */
 /* Pre-split launches (extras->x_presplit): row tile, GroupNorm partial-sum bytes and split-K
  * workspace bytes of the launch `desc` + `ps_tile` describes (the counterparts of
  * snap_conv2d_tile_rows / _gn_partial_bytes / _workspace_bytes). */

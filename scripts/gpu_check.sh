@@ -33,9 +33,6 @@ for s in $STAGES; do
     bench)
       SNAP_BENCH_DUMP=gpurun_out/launches.json timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
       echo "== bench =="; tail -5 gpurun_out/bench.log ;;
-    bench32)
-      SNAP_CONV_BK=32 SNAP_BENCH_DUMP=gpurun_out/launches32.json timeout 1200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench32.log 2>&1
-      echo "== bench BK=32 =="; tail -5 gpurun_out/bench32.log | cut -c1-1500 ;;
     train)
       timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_backward.py -m gpu -q --timeout=600 2>&1 | tail -40 > gpurun_out/tests_train.log
       echo "== train tests =="; tail -5 gpurun_out/tests_train.log ;;

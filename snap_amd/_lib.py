@@ -27,7 +27,7 @@ class SnapConvDesc(ctypes.Structure):
       ('pad_l', c_int),
       ('Ho', c_int), ('Wo', c_int), ('Cout', c_int), ('Cout_stride', c_int),
       ('prologue', c_int), ('epilogue', c_int),
-      ('in_scale', c_float), ('in_shift', c_float),
+      ('in_scale', c_float), ('in_shift', c_float), ('tile_hint', c_int),
   ]
 
 
@@ -39,6 +39,7 @@ class SnapConvExtras(ctypes.Structure):
       ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
       ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
       ('x_presplit', c_int), ('ps_tile', c_int), ('ps_res_init', c_int),
+      ('bk_hint', c_int), ('tune_flags', c_int),
   ]
 
 

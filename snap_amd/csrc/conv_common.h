@@ -41,7 +41,9 @@ struct ConvArgs {
   int nk;      // number of K slabs
   int prio;    // experiment knob: s_setprio(1) around the MFMA block
   int ncol;    // number of column tiles (set in launch<>)
-  int ablate;  // tuning-only: bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
+  int ablate;  // tuning-only (SnapConvExtras.tune_flags >> 8): bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
+  int bk;      // f32 engine: K-slab depth of the large tiles (16 | 32)
+  int no_halo; // split engine: 1 = im2col body for every 3x3
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])
   int cin8;            // ... channel count rounded up to 8
   const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
@@ -304,46 +306,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
 // split-K heuristic: launches with at most splitk_max_tiles() output tiles (1.5 per CU)
 // are split into about splitk_target() workgroups.  Measured in one box (C2 inference /
 // C3 train step): off 59.75 / 162.5 ms; tiles<=128 59.96 / 159.9; tiles<=384, target 768
-// 59.34 / 157.8; tiles<=256, target 1024 59.55 / 158.4.
-// SNAP_CONV_SPLITK=<target> (0 disables), SNAP_CONV_SPLITK_TILES=<max tiles>.
-inline int64_t splitk_max_tiles() {
-  static const int t = []() {
-    const char* e = getenv("SNAP_CONV_SPLITK_TILES");
-    return e ? atoi(e) : 384;
-  }();
-  return t;
-}
-inline int splitk_target() {
-  static const int t = []() {
-    const char* e = getenv("SNAP_CONV_SPLITK");
-    return e ? atoi(e) : 768;
-  }();
-  return t;
-}
-
-// SNAP_CONV_TILE=128x128|128x64|64x128|64x64 forces a tile (tests / tuning).
-inline int conv_forced_tile() {
-  const char* e = getenv("SNAP_CONV_TILE");
-  if (!e) return 0;
-  int bm = 0, bn = 0;
-  if (sscanf(e, "%dx%d", &bm, &bn) != 2) return 0;
-  return bm * 1000 + bn;
-}
+// 59.34 / 157.8; tiles<=256, target 1024 59.55 / 158.4.  (A caller that wants no split-K
+// passes no workspace.)
+constexpr int64_t splitk_max_tiles() { return 384; }
+constexpr int splitk_target() { return 768; }
 
 // Tile choice: the largest tile that still yields >= 2 workgroups per CU; small-M
 // layers (deep stages, few images) fall back to 64x64 tiles to fill the 256 CUs.
 struct TileChoice { int bm, bn; };
-inline TileChoice choose_tile(int64_t M, int64_t N) {
+// forced = SnapConvDesc.tile_hint (bm * 1000 + bn; 0 = automatic)
+inline TileChoice choose_tile(int64_t M, int64_t N, int forced) {
   const int64_t kMin = 512;
   const bool n_wide_ok = N > 64 && !(N % 128 != 0 && N % 128 <= 64);
-  const int forced = conv_forced_tile();
+  if (forced != 128128 && forced != 128064 && forced != 64128 && forced != 64064) forced = 0;
   if (forced == 128128 || (!forced && n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin))
     return {128, 128};
   if (forced == 128064 || (!forced && snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)) return {128, 64};
   if (forced == 64128 ||
       (!forced && n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin))
     return {64, 128};
-  return {64, 64};
+  return {64, 64};   // (forced == 64064 included)
 }
 
 }  // namespace

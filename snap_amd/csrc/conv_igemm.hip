@@ -441,14 +441,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel_dma(const ConvArgs a) {
   conv_igemm_body<BM, BN, true, PRO, 16, true>(a);
 }
 
-// SNAP_CONV_DMA=0 keeps the register-staged loader for the NONE / RELU prologues too
-inline bool conv_dma_enabled() {
-  static const bool on = []() {
-    const char* e = getenv("SNAP_CONV_DMA");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+inline bool conv_dma_enabled() { return true; }   // (the LDS-DMA loader of the NONE / RELU prologues: settled)
 
 
 template <int BM, int BN, bool VEC, int PRO, int BK>
@@ -530,18 +523,14 @@ int launch_pro(const ConvArgs& a, hipStream_t s) {
   }
 }
 
-// K-slab depth of the big tiles (SNAP_CONV_BK=16|32, tuning knob; default set by
-// measurement on MI355X).
-inline int conv_bk() {
-  const char* e = getenv("SNAP_CONV_BK");
-  return (e && atoi(e) == 32) ? 32 : 16;
-}
+// K-slab depth of the big tiles (SnapConvExtras.bk_hint = 16 | 32; default 16, set by
+// measurement on MI355X)
 
 
 template <bool VEC>
 int launch_tile(const ConvArgs& a, hipStream_t s) {
-  const TileChoice t = choose_tile(a.M, a.d.Cout);
-  const bool deep = VEC && conv_bk() == 32 && a.d.Cin >= 32;
+  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint);
+  const bool deep = VEC && a.bk == 32 && a.d.Cin >= 32;
   if (t.bm == 128 && t.bn == 128) {
     if constexpr (VEC) {
       if (deep) return launch_pro<128, 128, VEC, 32>(a, s);
@@ -574,7 +563,7 @@ extern "C" size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc) {
   if (!desc) return 0;
   const SnapConvDesc& d = *desc;
   const int64_t HoWo = (int64_t)d.Ho * d.Wo;
-  const TileChoice t = choose_tile((int64_t)d.N * HoWo, d.Cout);
+  const TileChoice t = choose_tile((int64_t)d.N * HoWo, d.Cout, d.tile_hint);
   if (HoWo < t.bm) return 0;  // a tile would straddle more than two images: not produced
   return (size_t)d.N * (HoWo / t.bm + 2) * d.Cout * 2 * sizeof(float);
 }
@@ -583,7 +572,7 @@ extern "C" size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc) {
   if (!desc) return 0;
   const SnapConvDesc& d = *desc;
   const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
-  const TileChoice t = choose_tile(M, d.Cout);
+  const TileChoice t = choose_tile(M, d.Cout, d.tile_hint);
   const int64_t tiles = snap_cdiv(M, t.bm) * snap_cdiv((int64_t)d.Cout, t.bn);
   const int target = splitk_target();
   const int64_t nk = (int64_t)d.KH * d.KW * ((d.Cin + 15) / 16);
@@ -596,7 +585,7 @@ extern "C" size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc) {
 
 extern "C" int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc) {
   if (!desc) return 0;
-  return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout).bm;
+  return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint).bm;
 }
 
 // ---- pre-split launches (conv_ps.hip) ---------------------------------------------------------
@@ -699,12 +688,10 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
                    (!gn || (d.Cin % 4 == 0));
   a.ctiles = 0;
   a.nk = 0;  // set per K-slab depth in launch<>
-  {
-    const char* e = getenv("SNAP_CONV_PRIO");
-    a.prio = (e && e[0] == '1') ? 1 : 0;
-    const char* ab = getenv("SNAP_CONV_ABLATE");   // timing experiments only (wrong results)
-    a.ablate = ab ? atoi(ab) : 0;
-  }
+  a.prio = 0;
+  a.ablate = ex ? (ex->tune_flags >> SNAP_TUNE_ABLATE_SHIFT) : 0;   // timing experiments only (wrong results)
+  a.bk = (ex && ex->bk_hint == 32) ? 32 : 16;
+  a.no_halo = (ex && (ex->tune_flags & SNAP_TUNE_NO_HALO)) ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // bf16-operand engine (training precision): needs the packed bf16 weights and the float4
   // loader's alignment; anything else runs on the (more precise) f32 engine below.

@@ -672,10 +672,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 2) void conv3x3_halo_kernel(cons
 // the halo body takes: 3x3, stride 1, pad 1, whole 16-channel tiles, plain row order, no split-K,
 // images at least as large as the stage (BM + 2W + 2 pixels: the stage then touches <= 2 images)
 inline bool halo_ok(const ConvArgs& a) {
-  static const bool on = []() {
-    const char* e = getenv("SNAP_CONV_HALO");     // 0 = im2col body for every 3x3
-    return !(e && e[0] == '0');
-  }();
+  const bool on = !a.no_halo;                      // (SNAP_TUNE_NO_HALO: im2col body for every 3x3)
   const SnapConvDesc& d = a.d;
   const int hp = 128 + 2 * d.W + 2;
   return on && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 &&
@@ -789,7 +786,7 @@ int launch_pro(const ConvArgs& a, hipStream_t s) {
 
 template <int NS>
 int launch_tile(const ConvArgs& a, hipStream_t s) {
-  const TileChoice t = choose_tile(a.M, a.d.Cout);
+  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint);
   if (t.bm == 128 && t.bn == 128) return launch_pro<128, 128, NS>(a, s);
   if (t.bm == 128) return launch_pro<128, 64, NS>(a, s);
   if (t.bn == 128) return launch_pro<64, 128, NS>(a, s);

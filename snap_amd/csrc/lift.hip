@@ -842,10 +842,7 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   if ((reinterpret_cast<uintptr_t>(f_images) & 15) || (reinterpret_cast<uintptr_t>(pooled) & 15))
     return SNAP_ERR_BAD_SHAPE;
   const int nsel = d.K == 0 ? d.V : d.K;
-  static const int xcd_group = []() {
-    const char* e = getenv("SNAP_LIFT_XCD_GROUP");
-    return e ? atoi(e) : 64;
-  }();
+  constexpr int xcd_group = 64;     // workgroups per XCD-owned chunk (section 5h of DESIGN.md: settled)
   LiftArgs a{xcd_group, 0, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr};
   const int64_t total = (int64_t)d.B * d.N;
   if (total > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
@@ -853,26 +850,15 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   if (d.grid_y > 0 && d.N % (d.grid_y * d.grid_z) != 0) return SNAP_ERR_BAD_SHAPE;
   const dim3 grid((unsigned)snap_cdiv(total, 8));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  static const bool batched = []() {
-    const char* e = getenv("SNAP_LIFT_BATCHED");   // 0 = one voxel per half-wave (v1 kernel)
-    return !(e && e[0] == '0');
-  }();
+  constexpr bool batched = true;    // (the one-voxel-per-half-wave kernel remains for > 4 selected views)
   // 8 half-waves x 32 voxels per workgroup; with XCD groups the grid is padded to whole
   // (8 XCDs x G) rounds -- workgroups past the range exit at once
   const int64_t nb = snap_cdiv(total, 256);
   const int64_t round = xcd_group > 0 ? 8LL * xcd_group : 1;
   dim3 bgrid((unsigned)(snap_cdiv(nb, round) * round));
-  static const bool bev_tiles = []() {
-    const char* e = getenv("SNAP_LIFT_BEV_TILES");   // 0 = linear voxel order
-    return !(e && e[0] == '0');
-  }();
-  if (bev_tiles && d.grid_y > 0) {
+  if (d.grid_y > 0) {                // (no grid hint = linear voxel order)
     const int GX = d.N / (d.grid_y * d.grid_z);
-    static const int tile_log = []() {
-      const char* e = getenv("SNAP_LIFT_TILE_LOG");    // tile side = 2^n columns (default 8)
-      const int v = e ? atoi(e) : 3;
-      return v < 1 ? 1 : (v > 5 ? 5 : v);
-    }();
+    constexpr int tile_log = 3;      // 8 x 8-column tiles (4 x 4 / 16 x 16 measured slower)
     const int ts = 1 << tile_log;
     a.tile_log = tile_log;
     a.tile_cpt = (ts * ts * d.grid_z + 255) / 256;

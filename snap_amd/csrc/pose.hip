@@ -1453,8 +1453,9 @@ extern "C" int snap_sim_softmax_weighted_f32(const float* fq, const float* fm, i
   if (B <= 0 || Nq <= 0 || XY <= 0) return SNAP_ERR_BAD_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)snap_cdiv(XY, 256), (unsigned)snap_cdiv(Nq, SIM_TQ), (unsigned)B);
-  const char* env = getenv("SNAP_SIM_MFMA");    // 0 = the VALU kernel (tests compare the two)
-  const bool use_mfma = !(env && env[0] == '0');
+  // (the VALU kernel takes unaligned inputs and other Dm; tests reach it through a 4-byte
+  //  offset view and compare the two bit for bit)
+  const bool use_mfma = true;
   const bool aligned = ((reinterpret_cast<uintptr_t>(fq) | reinterpret_cast<uintptr_t>(fm)) & 15) == 0;
   int rc = SNAP_OK;
   if (use_mfma && aligned && (Dm == 8 || Dm == 16 || Dm == 32 || Dm == 64)) {
@@ -1592,8 +1593,8 @@ extern "C" int snap_ransac_sample_sim_f32(const float* fq, const float* fm,
   }
   {
     const int NC = (X * Y + SIM_CH - 1) / SIM_CH;
-    const char* e = getenv("SNAP_RANSAC_FAST");          // 0 = one correspondence per wave
-    if (lane_incl && sim && row_unscale && (NC + 63) / 64 <= 64 && !(e && e[0] == '0')) {
+    // (without a workspace: the table-free kernel, one correspondence per wave, same samples)
+    if (lane_incl && sim && row_unscale && (NC + 63) / 64 <= 64) {
       constexpr int NQ = 4;
       const dim3 fgrid((unsigned)snap_cdiv(S, 4 * NQ), (unsigned)B);
       hipLaunchKernelGGL(ransac_sample_fast_kernel<NQ>, fgrid, dim3(256), 0, s, chunk_stats, Nq, X, Y, S,
@@ -1677,10 +1678,7 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool bands = a.NB > 1;
   // double-buffered LDS-DMA variant: two whole planes must fit (2 * XY * 4 <= 128 KiB).
-  static const bool db_enabled = []() {
-    const char* e = getenv("SNAP_POSE_SCORE_DB");
-    return !(e && e[0] == '0');
-  }();
+  constexpr bool db_enabled = true;
   const bool use_db = db_enabled && !bands && (Y % 4 == 0) && X >= 2 && Y >= 2 &&
                       ((int64_t)X * (Y + 4) * 4 <= PS_DB_PLANE_BYTES);
   // banded double-buffered variant: a plane that does not fit streams through in row bands

@@ -26,13 +26,13 @@ def _stream():
 # A second HIP stream for work that does not depend on the main chain (the aerial encoder runs
 # next to the StreetView encoder: its deep stages are launches of 19-73 workgroups on a 256-CU
 # part).  SNAP_OVERLAP_AERIAL=0 keeps everything on one stream.
-OVERLAP_AERIAL = os.environ.get('SNAP_OVERLAP_AERIAL', '1') != '0'
+OVERLAP_AERIAL = True
 # the lift hands `pooled` to the fused MLP / pool kernel pre-split (LDS-DMA A operand); 0: as f32 rows
-POOLED_SPLIT = os.environ.get('SNAP_POOLED_SPLIT', '1') != '0'
+POOLED_SPLIT = True
 # ... and classed by their number of observations (single-observation rows carry no variance slabs); 0: off
-CLASS_ROWS = os.environ.get('SNAP_CLASS_ROWS', '1') != '0'
+CLASS_ROWS = True
 # image padding and the voxel-centre grid as one native pass each instead of torch fill + strided copies; 0: torch
-NATIVE_GLUE = os.environ.get('SNAP_NATIVE_GLUE', '1') != '0'
+NATIVE_GLUE = True
 _SIDE_STREAM = None
 
 
@@ -185,6 +185,13 @@ class PreSplit:
 # pre-split convolutions are 10-25 % faster than the fused-prologue ones, the extra pass over the
 # activation costs what they gain -- off by default; the engine's own user is the exhaustive voting.
 USE_PRESPLIT = False
+# Tests / tuning tools: force the conv engines' output tile ('128x128' | '128x64' | '64x128' |
+# '64x64'; travels as SnapConvDesc.tile_hint), the f32 engine's K-slab depth (16 | 32) and the
+# im2col body for every 3x3 convolution of the split engine.  None / False = the engines' choice.
+CONV_TILE = None
+CONV_BK = None
+CONV_NO_HALO = False
+CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
 USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
 PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
 PS_TILE = 0              # 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles
@@ -321,6 +328,9 @@ def conv2d(
       N, H, W, Cin, Cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout, prologue,
       epi, float(in_affine[0]), float(in_affine[1]),
   )
+  if CONV_TILE:
+    bm, bn = (int(v) for v in CONV_TILE.split('x'))
+    d.tile_hint = bm * 1000 + bn
   M = N * Ho * Wo
   ex = None
   partial = partial2 = None
@@ -385,6 +395,11 @@ def conv2d(
       ex.x_presplit = 1
       ex.ps_tile = pst
       ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
+  if CONV_BK or CONV_NO_HALO or CONV_ABLATE:
+    if ex is None:
+      ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
+    ex.bk_hint = int(CONV_BK or 0)
+    ex.tune_flags = int(bool(CONV_NO_HALO)) | (int(CONV_ABLATE) << 8)
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -787,7 +802,7 @@ def weight_standardize_bwd_multi(ws, dwss, eps=1e-10):
 
 USE_FUSED_GN_STATS = True
 # the last unit of a ResNet stage emits the statistics of relu(y) too (its FPN level reads them)
-GN_STATS_BOTH = os.environ.get('SNAP_GN_STATS_BOTH', '1') != '0'
+GN_STATS_BOTH = True
 # 'f32': every conv / dense runs on the exact f32 matrix-core path (inference, parity).
 # 'bf16': operands rounded to bf16, f32 accumulate -- the training-precision analogue of the
 # reference's float16 train config (train_localization.py:25); set by the trainer.

@@ -29,3 +29,16 @@ def oracle_backend(monkeypatch):
   for name in oracle_ops.ALL_OPS:
     monkeypatch.setattr(ops, name, getattr(oracle_ops, name))
   return oracle_ops
+
+
+def pytest_terminal_summary(terminalreporter):
+  """How often helpers.assert_same_argmax took its fp32 near-tie escape in this session."""
+  try:
+    import helpers
+  except ImportError:
+    return
+  n = helpers.NEAR_TIE
+  if n['rows']:
+    terminalreporter.write_line(
+        f"[argmax parity] {n['rows']} rows compared with the oracle's argmax, "
+        f"{n['escapes']} near-tie escape(s)")

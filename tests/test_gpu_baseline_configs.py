@@ -63,8 +63,8 @@ def test_c1_exact_shape_end_to_end_vs_oracle(math):
                    ref[side]['bev_matching']['features'], atol=1e-3)
     assert np.array_equal(pred[side]['bev_matching'].valid.cpu().numpy(), ref[side]['bev_matching']['valid'])
   helpers.report('C1 scores_poses', pred['scores_poses'], ref['scores_poses'], atol=1e-3, rtol=1e-3)
-  helpers.assert_same_argmax('C1 best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
-                             got_index=pred['best_index'])
+  assert helpers.assert_same_argmax('C1 best_index', pred['scores_poses'][:, 1:], ref['scores_poses'][:, 1:],
+                                    got_index=pred['best_index']) == 0   # no near-tie escape
 
 
 # ------------------------------------------------------------------------------------------
@@ -90,7 +90,7 @@ def test_c2_whole_scene_vs_oracle_every_engine():
     assert r['map_bev_matching_max_abs_err'] <= 1e-3, (m, r)
     assert r['query_bev_matching_max_abs_err'] <= 1e-3, (m, r)
     assert r['scores_poses_rel_err'] <= 1e-3, (m, r)
-    assert r['pose_argmax_equal'], (m, r)
+    assert r['pose_argmax_equal'], (m, r)          # exact: the near-tie escape is not available here
     pred = res['pred'][m]
     tgm._check_validity(f'C2 map voxel validity [{m}]', pred['map'], ref['map'], ob['map'], cfg)
     tgm._check_validity(f'C2 query voxel validity [{m}]', pred['query'], ref['query'], ob['query'], cfg)

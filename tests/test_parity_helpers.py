@@ -40,3 +40,25 @@ def test_validity_mismatch_helper_accepts_boundary_flips_and_rejects_real_ones()
   assert (far != want).sum() > 10
   with pytest.raises(AssertionError):
     helpers.assert_validity_mismatches_on_borders('shift 15cm', far, want, ob, xyz, stride, tol=5e-3)
+
+
+def test_template_validity_helper_accepts_boundary_flips_and_rejects_real_ones():
+  """helpers.assert_template_validity_mismatches_on_borders: a flip is accepted only where the
+  float64 rotated coordinate of the cell lies on a decision boundary."""
+  from oracle import voting as o_voting
+  H, R, cell = 16, 8, 0.25
+  rng = np.random.default_rng(0)
+  f = rng.standard_normal((H, H, 4)).astype(np.float32)
+  v = np.ones((H, H), bool)
+  _, tv = o_voting.sample_query_templates(f, v, R, o_grids.Grid2D((H, H), cell))
+  assert helpers.assert_template_validity_mismatches_on_borders('same', tv, tv, cell) == 0
+  # rotation 0 maps every cell centre onto itself: u - 0.5 is integral everywhere, i.e. every cell
+  # of template 0 sits on a tap-pair boundary -- a flip there is a boundary flip ...
+  flip = tv.copy()
+  flip[0, 3, 5] = ~flip[0, 3, 5]
+  assert helpers.assert_template_validity_mismatches_on_borders('boundary', flip, tv, cell) == 1
+  # ... template 1 (45 degrees): an interior cell is far from every boundary -- rejected
+  bad = tv.copy()
+  bad[1, 8, 7] = ~bad[1, 8, 7]
+  with pytest.raises(AssertionError):
+    helpers.assert_template_validity_mismatches_on_borders('interior', bad, tv, cell)
