@@ -451,18 +451,25 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   int cur = -1;
   float run = -INFINITY;
   const bool live = c < a.D && !(SNAP_MLP_POOL_ABLATE & 8);
+  // NaN is sticky, as in jnp.max / the unfused vertical_pool (fmaxf alone would drop it and the
+  // fused configuration would then hide exactly the non-finite forward passes): a column that saw
+  // one flushes the canonical positive NaN, which the integer atomic max ranks above +inf
+  bool seen_nan = false;
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
     const int cr = __builtin_amdgcn_readlane(cid, r);
     if (cr != cur) {
-      if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
+      if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, seen_nan ? __uint_as_float(0x7fc00000u) : run);
       cur = cr;
       run = -INFINITY;
+      seen_nan = false;
     }
     const int row = 64 * h + r;
-    run = fmaxf(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
+    const float val = smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))];
+    seen_nan |= val != val;
+    run = fmaxf(run, val);
   }
-  if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
+  if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, seen_nan ? __uint_as_float(0x7fc00000u) : run);
 }
 
 // plane prefilled with -inf -> where(any level valid, max, 0) + the validity byte

@@ -166,8 +166,13 @@ class BEVLocalizer(base.Module):
     # at bev_mapper.py:196 is likewise invisible to the caller).
     data_map, data_query = dict(data['map']), {**data['query'], 'xy_bev': q_xy_p}
     self.bev_mapper.start_aerial(params['bev_mapper'], data_map, train, ctx)   # (second stream)
-    self._encode_views_jointly(params, data_map, data_query, train, ctx)
-    pred['map'] = self.bev_mapper(params['bev_mapper'], data_map, train, debug, ctx=ctx, rng=rng)
+    try:
+      self._encode_views_jointly(params, data_map, data_query, train, ctx)
+      pred['map'] = self.bev_mapper(params['bev_mapper'], data_map, train, debug, ctx=ctx, rng=rng)
+    finally:
+      pending = data_map.pop('_aerial_async', None)
+      if pending is not None:      # an exception before the join: no side-stream work is left behind
+        torch.cuda.current_stream().wait_event(pending[1])
     mapper_q = self.bev_mapper_query or self.bev_mapper
     params_q = params['bev_mapper_query'] if self.bev_mapper_query is not None else params['bev_mapper']
     pred['query'] = mapper_q(

@@ -227,7 +227,11 @@ class BEVMapper(base.Module):
         yield t
     if base.needs_grad(rgb, *leaves(params['aerial_encoder'])):
       return
-    main, side = torch.cuda.current_stream(), ops.side_stream()
+    # the side stream of the input's OWN device; every tensor the encoder reads (image, parameters)
+    # was produced on the main stream before this point, so one wait orders them -- no tensor is
+    # freed while the side stream still reads it because the caller keeps `data` / `params` alive
+    # until the join
+    main, side = torch.cuda.current_stream(rgb.device), ops.side_stream(rgb.device)
     side.wait_stream(main)                      # the inputs were produced on the main stream
     with torch.cuda.stream(side):
       pred = self.encode_aerial(params, rgb, train=train, ctx=ctx)

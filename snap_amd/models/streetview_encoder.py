@@ -127,8 +127,10 @@ class StreetViewEncoder(base.Module):
       if xyz.dim() == 5:                     # [B, X, Y, Z, 3]: a voxel grid (traversal hint)
         kw.update(grid_yz=tuple(xyz.shape[2:4]))
       fused = pool_max and self.default_fusion and self._fused_pool_ok(params, f_images)
+      # (the pre-split rows exist in the batched kernel only, which addresses its taps by 32-bit
+      #  byte offsets: snap_lift_pool_f32 rejects out_split for f_images >= 4 GB)
       split = (fused and ops.POOLED_SPLIT and not cfg.fusion.apply_input_activation
-               and cfg.feature_dim % 8 == 0 and (K or V) <= 4)
+               and cfg.feature_dim % 8 == 0 and (K or V) <= 4 and f_images.numel() * 4 < 2 ** 32)
       if fused:                              # the fused kernel reads the rows of valid voxels only,
         kw.update(valid_rows_only=True, out_split=split)   # pre-split: its A operand goes by LDS-DMA
         # rows classed by their number of observations: one observation (most voxels of a map,

@@ -33,14 +33,18 @@ POOLED_SPLIT = True
 CLASS_ROWS = True
 # image padding and the voxel-centre grid as one native pass each instead of torch fill + strided copies; 0: torch
 NATIVE_GLUE = True
-_SIDE_STREAM = None
+_SIDE_STREAMS = {}
 
 
-def side_stream():
-  global _SIDE_STREAM
-  if _SIDE_STREAM is None:
-    _SIDE_STREAM = torch.cuda.Stream()
-  return _SIDE_STREAM
+def side_stream(device=None):
+  """The second stream of ``device`` (one per GPU of the process; default: the current device)."""
+  idx = torch.cuda.current_device() if device is None else torch.device(device).index
+  if idx is None:
+    idx = torch.cuda.current_device()
+  s = _SIDE_STREAMS.get(idx)
+  if s is None:
+    s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+  return s
 
 
 class KernelProfiler:
