@@ -725,10 +725,21 @@ int snap_colsum_rows_f32(const float* a, int64_t M, int32_t C, const int32_t* ro
                          const int32_t* row_count, float* out, int32_t accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* d f_images[B,V,h,w,C] = VJP of snap_lift_pool_f32 w.r.t. f_images (zeroed inside). */
+/* d f_images[B,V,h,w,C] = VJP of snap_lift_pool_f32 w.r.t. f_images (zeroed inside).  The
+ * bilinear taps are scatter-added with hardware float atomics: order-dependent sums. */
 int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_images, const float* cam,
                            const float* Rt, const float* points, const float* dpooled,
                            float* df_images, void* stream);
+/* The same VJP, DETERMINISTIC (bitwise reproducible) and atomic-free: every (voxel, selected
+ * view) observation becomes a record, the records are sorted by image pixel (stable radix sort)
+ * and one half-wave per pixel gathers the records that touch it in that order; every element of
+ * df_images is written exactly once.  workspace: snap_lift_pool_bwd_det_workspace_bytes(desc)
+ * bytes (0 = unsupported shape), 256-byte aligned; num_bins <= 32, <= 8 selected views. */
+size_t snap_lift_pool_bwd_det_workspace_bytes(const SnapLiftDesc* desc);
+int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float* f_images, const float* cam,
+                               const float* Rt, const float* points, const float* dpooled,
+                               float* df_images, void* workspace, size_t workspace_bytes,
+                               void* stream);
 int snap_vertical_pool_bwd_f32(const float* vol, const uint8_t* vvalid, const float* dplane,
                                float* dvol, int64_t M, int32_t Z, int32_t D, int32_t pooling,
                                void* stream);
@@ -748,6 +759,15 @@ int snap_pose_score_bwd_f32(const float* dscores, const float* poses, const floa
                             int32_t Nq, int32_t X, int32_t Y, int32_t P, float cell_size,
                             int32_t mask_oob, float* dsim, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* ... with flags: bit 0 = accumulate the score planes with float LDS atomics (order-dependent sums;
+ * A/B timing).  Default (0): where the 8-byte plane fits the LDS (X * Y <= 19 456 cells, no
+ * out-of-bounds mask, P <= 10 240) the plane is accumulated in 64-bit fixed point -- exactly
+ * associative, so d sim is bitwise reproducible. */
+int snap_pose_score_bwd_ex_f32(const float* dscores, const float* poses, const float* q_xy,
+                               const uint8_t* valid_q, const uint8_t* map_valid, int32_t B,
+                               int32_t Nq, int32_t X, int32_t Y, int32_t P, float cell_size,
+                               int32_t mask_oob, int32_t flags, float* dsim, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* In place: dsim <- dsim * [sim > 0 iff clip] * coef[b]; partial[B,num_partial] <- partial
  * sums of dsim*sim (temperature gradient). */
 int snap_sim_bwd_prepare_f32(float* dsim, const float* sim, int32_t B, int64_t per_scene,

@@ -243,6 +243,10 @@ SIGNATURES = {
     'snap_lift_pool_bwd_f32': (
         c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]
     ),
+    'snap_lift_pool_bwd_det_workspace_bytes': (c_size, [ctypes.POINTER(SnapLiftDesc)]),
+    'snap_lift_pool_bwd_det_f32': (
+        c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_size, ptr]
+    ),
     'snap_vertical_pool_bwd_f32': (
         c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, c_int, ptr]
     ),
@@ -255,6 +259,11 @@ SIGNATURES = {
     'snap_pose_score_bwd_f32': (
         c_int,
         [ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr,
+         c_size, ptr],
+    ),
+    'snap_pose_score_bwd_ex_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, ptr, ptr,
          c_size, ptr],
     ),
     'snap_sim_bwd_prepare_f32': (

@@ -1,12 +1,21 @@
 // Backward kernels of the lift and BEV stages (training path).
 //   * lift_pool backward: d pooled[B,N,257] -> d f_images[B,V,h,w,C]  (VJP of
-//     streetview_encoder.py:69-178; geometry carries no gradient).  Bilinear taps are
-//     scatter-added with hardware fp32 atomics (the only non-deterministic-order sums
-//     of the training path).
+//     streetview_encoder.py:69-178; geometry carries no gradient).  Two forms:
+//     - deterministic (default of the training step): every (voxel, selected view) observation
+//       becomes a RECORD (its gradient vector + the four bilinear taps); the records are sorted by
+//       the image pixel of their first tap (stable radix sort: ties stay in voxel order) and one
+//       half-wave per pixel GATHERS the records of the <= 4 lists that can touch it, in that
+//       order -- no atomics, bitwise reproducible, and the image gradient is written once;
+//     - scatter: the taps are scatter-added with hardware fp32 atomics (order-dependent sums).
 //   * vertical pooling backward (VJP of bev_mapper.py:56-88; max: equal split among ties,
 //     as jnp.max's VJP does)
 //   * modality fusion + matching head backward (VJP of bev_mapper.py:225-252,284-291,
 //     layers.py:45-52)
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
 #include "common.h"
 
 namespace {
@@ -20,6 +29,12 @@ struct LiftBwdArgs {
   const float* pts;
   const float* dpooled;
   float* df;
+  // deterministic form: record slot = voxel * nsel + selection rank
+  float* rec_vec;        // [slots][feature_dim]: d f of the observation (tap weights not applied)
+  float* rec_hdr;        // [slots][12]: w00 w01 w10 w11 | g(bin0) g(bin1) | bin0|bin1<<16 | i0|i1<<16 | j0|j1<<16
+  unsigned* keys;        // [slots]: pixel id of tap (i0, j0), or npix for an empty slot
+  unsigned* count;       // [npix + 1]: records per key
+  unsigned npix;
 };
 
 struct ProjB {
@@ -99,7 +114,7 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
-template <int KMAX>
+template <int KMAX, bool RECORDS>
 __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a) {
   const SnapLiftDesc& d = a.d;
   const int hl = threadIdx.x & 31;
@@ -110,6 +125,9 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
   const int fd = d.feature_dim;
   const bool all_views = d.K == 0;
   const int nsel = all_views ? d.V : d.K;
+  if constexpr (RECORDS) {       // every slot of this voxel starts empty (key = npix sorts last)
+    if (hl < nsel) a.keys[gv * nsel + hl] = a.npix;
+  }
   const float* p = a.pts + gv * 3;
   const float px = p[0], py = p[1], pz = p[2];
 
@@ -242,6 +260,27 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
     if (!ok[r]) continue;
     const float ds = wgt[r] * (dw[r] - dwbar) + ((score[r] == smax) ? dsmax / (float)nmax : 0.f);
     const TapsB& t = tp[r];
+    if constexpr (RECORDS) {
+      const int64_t rid = gv * nsel + r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = hl + 32 * e;
+        if (c < fd)
+          a.rec_vec[rid * fd + c] = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
+      }
+      if (hl == 0) {
+        float* h = a.rec_hdr + rid * 12;
+        reinterpret_cast<f32x4*>(h)[0] = f32x4{t.w00, t.w01, t.w10, t.w11};
+        reinterpret_cast<f32x4*>(h)[1] =
+            f32x4{(1.f - wb1[r]) * ds, wb1[r] * ds, __int_as_float(bin0[r] | (bin1[r] << 16)),
+                  __int_as_float(t.i0 | (t.i1 << 16))};
+        h[8] = __int_as_float(t.j0 | (t.j1 << 16));
+        const unsigned key = (unsigned)((((int64_t)b * d.V + view[r]) * d.h + t.i0) * d.w + t.j0);
+        a.keys[rid] = key;
+        atomicAdd(a.count + key, 1u);            // (integer: order-independent)
+      }
+      continue;
+    }
     float* img = a.df + ((int64_t)b * d.V + view[r]) * d.h * d.w * d.C;
     float* r00 = img + ((int64_t)t.i0 * d.w + t.j0) * d.C;
     float* r01 = img + ((int64_t)t.i0 * d.w + t.j1) * d.C;
@@ -266,6 +305,83 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
       unsafeAtomicAdd(rt + fd + (sb ? bin1[r] : bin0[r]), wt * wbin * ds);
     }
   }
+}
+
+// One half-wave per image pixel: the records whose first tap is one of the four pixels
+// (i - 1 .. i) x (j - 1 .. j) are the only ones that can touch (i, j) (the second tap index is the
+// first or the first + 1); their sorted lists are walked in a fixed order and every tap that
+// lands on the pixel adds weight x gradient.  Lane hl owns channels hl + 32 e and depth bin hl.
+struct LiftGatherArgs {
+  SnapLiftDesc d;
+  const unsigned* keys;      // sorted
+  const unsigned* vals;      // record slot of every sorted entry
+  const unsigned* start;     // [npix + 1] exclusive prefix of the per-key counts
+  const float* rec_vec;
+  const float* rec_hdr;
+  float* df;
+  unsigned npix;
+};
+
+__global__ __launch_bounds__(256) void lift_pool_bwd_gather_kernel(const LiftGatherArgs a) {
+  const SnapLiftDesc& d = a.d;
+  const int hl = threadIdx.x & 31;
+  const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (p >= (int64_t)a.npix) return;
+  const int fd = d.feature_dim;
+  const int hw = d.h * d.w;
+  const int64_t img = p / hw;
+  const int rem = (int)(p - img * hw);
+  const int i = rem / d.w, j = rem - i * d.w;
+  const bool lane_on = 4 * hl < fd;             // lane hl owns channels 4 hl .. 4 hl + 3 and bin hl
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float accb = 0.f;
+  // one record: its header (broadcast), the weight of its taps on (i, j), its vector
+  auto weight = [&](const f32x4& w, int ip, int jp) {
+    const int i0 = ip & 0xffff, i1 = ip >> 16, j0 = jp & 0xffff, j1 = jp >> 16;
+    float wt = 0.f;                              // taps 00, 01, 10, 11 that land on (i, j)
+    if (i0 == i && j0 == j) wt += w[0];
+    if (i0 == i && j1 == j) wt += w[1];
+    if (i1 == i && j0 == j) wt += w[2];
+    if (i1 == i && j1 == j) wt += w[3];
+    return wt;
+  };
+  constexpr int U = 4;                           // records in flight (their loads are independent)
+  for (int di = 1; di >= 0; --di)
+    for (int dj = 1; dj >= 0; --dj) {
+      const int bi = i - di, bj = j - dj;
+      if (bi < 0 || bj < 0) continue;
+      const unsigned key = (unsigned)(img * hw + (int64_t)bi * d.w + bj);
+      const unsigned k0 = a.start[key], k1 = a.start[key + 1];
+      for (unsigned k = k0; k < k1; k += U) {
+        unsigned rid[U];
+        f32x4 w[U], g[U], v[U];
+        float jp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rid[u] = a.vals[min(k + u, k1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float* h = a.rec_hdr + (int64_t)rid[u] * 12;
+          w[u] = reinterpret_cast<const f32x4*>(h)[0];
+          g[u] = reinterpret_cast<const f32x4*>(h)[1];
+          jp[u] = h[8];
+          v[u] = lane_on ? *reinterpret_cast<const f32x4*>(a.rec_vec + (int64_t)rid[u] * fd + 4 * hl)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {            // accumulated in list order: deterministic
+          if (k + u >= k1) break;
+          const float wt = weight(w[u], __float_as_int(g[u][3]), __float_as_int(jp[u]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += wt * v[u][e];
+          const int bins = __float_as_int(g[u][2]);
+          if (hl == (bins & 0xffff)) accb += wt * g[u][0];
+          if (hl == (bins >> 16)) accb += wt * g[u][1];
+        }
+      }
+    }
+  float* o = a.df + p * d.C;
+  if (lane_on) *reinterpret_cast<f32x4*>(o + 4 * hl) = acc;
+  if (hl < d.num_bins) o[fd + hl] = accb;
 }
 
 // ------------------------------- vertical pool --------------------------------
@@ -469,10 +585,109 @@ extern "C" int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_i
   if (hipMemsetAsync(df_images, 0, bytes, s) != hipSuccess) return SNAP_ERR_LAUNCH;
   LiftBwdArgs a{d, f_images, cam, Rt, points, dpooled, df_images};
   const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
-  if (nsel <= 1) hipLaunchKernelGGL(lift_pool_bwd_kernel<1>, grid, dim3(256), 0, s, a);
-  else if (nsel <= 4) hipLaunchKernelGGL(lift_pool_bwd_kernel<4>, grid, dim3(256), 0, s, a);
-  else if (nsel <= 8) hipLaunchKernelGGL(lift_pool_bwd_kernel<8>, grid, dim3(256), 0, s, a);
+  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, false>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, false>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 8) hipLaunchKernelGGL((lift_pool_bwd_kernel<8, false>), grid, dim3(256), 0, s, a);
   else return SNAP_ERR_UNSUPPORTED;
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+// ---- deterministic form ------------------------------------------------------------------
+namespace {
+struct LiftDetLayout {
+  size_t slots, npix;
+  size_t off_vec, off_hdr, off_keys, off_keys_out, off_vals_out, off_count, off_start, off_tmp;
+  size_t tmp_bytes, total;
+  int bits;
+};
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int lift_det_layout(const SnapLiftDesc& d, LiftDetLayout* L) {
+  const int nsel = d.K == 0 ? d.V : d.K;
+  L->slots = (size_t)d.B * d.N * nsel;
+  L->npix = (size_t)d.B * d.V * d.h * d.w;
+  if (L->slots >= 0x7fffffffULL || L->npix >= 0x7ffffffeULL || d.h > 0x7fff || d.w > 0x7fff) return SNAP_ERR_BAD_SHAPE;
+  L->bits = 1;
+  while (((size_t)1 << L->bits) <= L->npix) ++L->bits;          // keys 0 .. npix
+  size_t sort_tmp = 0, scan_tmp = 0;
+  unsigned* nul = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_tmp, nul, nul, rocprim::counting_iterator<unsigned>(0), nul,
+                                L->slots, 0, L->bits, (hipStream_t)0) != hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  if (rocprim::exclusive_scan(nullptr, scan_tmp, nul, nul, 0u, L->npix + 2, rocprim::plus<unsigned>(),
+                              (hipStream_t)0) != hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  L->tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+  size_t o = 0;
+  L->off_vec = o;       o += align256(L->slots * d.feature_dim * sizeof(float));
+  L->off_hdr = o;       o += align256(L->slots * 12 * sizeof(float));
+  L->off_keys = o;      o += align256(L->slots * sizeof(unsigned));
+  L->off_keys_out = o;  o += align256(L->slots * sizeof(unsigned));
+  L->off_vals_out = o;  o += align256(L->slots * sizeof(unsigned));
+  L->off_count = o;     o += align256((L->npix + 2) * sizeof(unsigned));
+  L->off_start = o;     o += align256((L->npix + 2) * sizeof(unsigned));
+  L->off_tmp = o;       o += align256(L->tmp_bytes);
+  L->total = o;
+  return SNAP_OK;
+}
+}  // namespace
+
+extern "C" size_t snap_lift_pool_bwd_det_workspace_bytes(const SnapLiftDesc* desc) {
+  if (!desc) return 0;
+  LiftDetLayout L;
+  if (lift_det_layout(*desc, &L) != SNAP_OK) return 0;
+  return L.total;
+}
+
+extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float* f_images,
+                                          const float* cam, const float* Rt, const float* points,
+                                          const float* dpooled, float* df_images, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  if (!desc || !f_images || !cam || !Rt || !points || !dpooled || !df_images || !workspace) return SNAP_ERR_NULL;
+  const SnapLiftDesc& d = *desc;
+  if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.V > 32 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0 || d.num_bins > 32)
+    return SNAP_ERR_UNSUPPORTED;
+  if (d.C != d.feature_dim + d.num_bins || d.C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.out_stride < 2 * d.feature_dim + 1 || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  const int nsel = d.K == 0 ? d.V : d.K;
+  if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
+  LiftDetLayout L;
+  const int rc = lift_det_layout(d, &L);
+  if (rc != SNAP_OK) return rc;
+  if (workspace_bytes < L.total || (reinterpret_cast<uintptr_t>(workspace) & 255)) return SNAP_ERR_WORKSPACE;
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  LiftBwdArgs a{d, f_images, cam, Rt, points, dpooled, df_images};
+  a.rec_vec = reinterpret_cast<float*>(ws + L.off_vec);
+  a.rec_hdr = reinterpret_cast<float*>(ws + L.off_hdr);
+  a.keys = reinterpret_cast<unsigned*>(ws + L.off_keys);
+  a.count = reinterpret_cast<unsigned*>(ws + L.off_count);
+  a.npix = (unsigned)L.npix;
+  unsigned* keys_out = reinterpret_cast<unsigned*>(ws + L.off_keys_out);
+  unsigned* vals_out = reinterpret_cast<unsigned*>(ws + L.off_vals_out);
+  unsigned* start = reinterpret_cast<unsigned*>(ws + L.off_start);
+  if (hipMemsetAsync(a.count, 0, (L.npix + 2) * sizeof(unsigned), s) != hipSuccess) return SNAP_ERR_LAUNCH;
+  // 1. records (+ their sort keys, + the per-pixel record counts)
+  const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
+  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, true>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lift_pool_bwd_kernel<8, true>), grid, dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  // 2. stable sort of the record slots by key (ties keep slot order = voxel order) and the list
+  //    starts (exclusive scan of the counts)
+  size_t tmp = L.tmp_bytes;
+  if (rocprim::radix_sort_pairs(ws + L.off_tmp, tmp, a.keys, keys_out, rocprim::counting_iterator<unsigned>(0),
+                                vals_out, L.slots, 0, L.bits, s) != hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  tmp = L.tmp_bytes;
+  if (rocprim::exclusive_scan(ws + L.off_tmp, tmp, a.count, start, 0u, L.npix + 2, rocprim::plus<unsigned>(), s) !=
+      hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  // 3. gather: every pixel of df_images written exactly once
+  LiftGatherArgs g{d, keys_out, vals_out, start, a.rec_vec, a.rec_hdr, df_images, (unsigned)L.npix};
+  hipLaunchKernelGGL(lift_pool_bwd_gather_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -451,25 +451,22 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   int cur = -1;
   float run = -INFINITY;
   const bool live = c < a.D && !(SNAP_MLP_POOL_ABLATE & 8);
-  // NaN is sticky, as in jnp.max / the unfused vertical_pool (fmaxf alone would drop it and the
-  // fused configuration would then hide exactly the non-finite forward passes): a column that saw
-  // one flushes the canonical positive NaN, which the integer atomic max ranks above +inf
-  bool seen_nan = false;
+  // (fmaxf = IEEE maxNum: a NaN operand is ignored -- exactly as in vertical_pool_kernel and in the
+  //  ReLU epilogues of the conv engines, so the fused and the unfused configuration treat a
+  //  non-finite forward pass alike (tested); the training step's finite check looks at the loss
+  //  and the gradients, trainer.py)
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
     const int cr = __builtin_amdgcn_readlane(cid, r);
     if (cr != cur) {
-      if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, seen_nan ? __uint_as_float(0x7fc00000u) : run);
+      if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
       cur = cr;
       run = -INFINITY;
-      seen_nan = false;
     }
     const int row = 64 * h + r;
-    const float val = smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))];
-    seen_nan |= val != val;
-    run = fmaxf(run, val);
+    run = fmaxf(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
   }
-  if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, seen_nan ? __uint_as_float(0x7fc00000u) : run);
+  if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
 }
 
 // plane prefilled with -inf -> where(any level valid, max, 0) + the validity byte
@@ -482,7 +479,9 @@ __global__ __launch_bounds__(256) void mlp2_pool_finalize_kernel(float* __restri
   const int64_t col = i / Q;
   f32x4* p = reinterpret_cast<f32x4*>(plane) + i;
   f32x4 v = *p;
-  const bool any = v[0] != -INFINITY;
+  // (a channel whose every value was NaN keeps its -inf, as in vertical_pool_kernel: the quad is
+  //  observed if ANY of its channels was written)
+  const bool any = v[0] != -INFINITY || v[1] != -INFINITY || v[2] != -INFINITY || v[3] != -INFINITY;
   if (!any) *p = f32x4{0.f, 0.f, 0.f, 0.f};
   if (i - col * Q == 0) pvalid[col] = any ? 1 : 0;
 }

@@ -170,6 +170,110 @@ __global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_fast_kernel(const S
   }
 }
 
+// Deterministic form of the fast path: the plane is accumulated in 64-bit FIXED POINT
+// (ds_add_u64: integer addition is associative, so the order in which the 16 waves' atomics reach
+// the LDS does not matter -- the float version's sums depend on it).  Scale: 2^(38 - e) with
+// 2^e >= the largest |cotangent| of the scene, found by an order-independent max over the
+// register-resident cotangents; every term |w g| <= 2^e then has 38 fractional bits (the f32
+// sums it replaces carry 24), ten thousand of them stay below 2^52, and a term is converted with
+// the 2^52 + 2^51 magic-number addition in f64 (exact below 2^51).  Planes up to 160 x 128 cells
+// (8 bytes per cell in the 160 KB LDS); the corner cells are summed per thread, per wave (DPP)
+// and then over the waves in a fixed order.
+__global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_det_kernel(const ScoreBwdArgs a) {
+  extern __shared__ long long iplane[];
+  __shared__ float corner[PB_THREADS / 64][4];
+  __shared__ float wmax[PB_THREADS / 64];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int Y = a.Y;
+  const int XY = a.X * Y;
+  const float Xf = (float)a.X, Yf = (float)Y;
+  const int n_begin = blockIdx.x * a.points_per_chunk;
+  const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
+  float pc[PB_PPT], ps[PB_PPT], ptx[PB_PPT], pty[PB_PPT], g[PB_PPT];
+  float gm = 0.f;
+#pragma unroll
+  for (int k = 0; k < PB_PPT; ++k) {
+    const int p = k * PB_THREADS + tid;
+    const bool live = p < a.P;
+    const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + (live ? p : 0)];
+    pc[k] = t[0]; ps[k] = t[1]; ptx[k] = t[2]; pty[k] = t[3];
+    g[k] = live ? a.dscores[(int64_t)b * a.P + p] : 0.f;
+    const float ag = fabsf(g[k]);
+    gm = (ag <= 3.0e38f) ? fmaxf(gm, ag) : gm;              // (non-finite cotangents do not set the scale)
+  }
+  gm = wave_max(gm);
+  if (lane == 0) wmax[wave] = gm;
+  __syncthreads();
+  gm = 0.f;
+#pragma unroll
+  for (int w = 0; w < PB_THREADS / 64; ++w) gm = fmaxf(gm, wmax[w]);
+  int e = 0;
+  frexpf(fmaxf(gm, 1e-37f), &e);                             // gm < 2^e
+  const double scale = ldexp(1.0, 38 - e), unscale = ldexp(1.0, e - 38);
+  const double magic = 6755399441055744.0;                   // 2^52 + 2^51
+  auto fixed = [&](float v) -> long long {
+    const double t = fma((double)v, scale, magic);
+    return __double_as_longlong(t) - __double_as_longlong(magic);
+  };
+  for (int n = n_begin; n < n_end; ++n) {
+    float* dst = a.dsim + ((int64_t)b * a.Nq + n) * XY;
+    if (!a.valid_q[(int64_t)b * a.Nq + n]) {   // block-uniform: zero gradient plane
+      for (int i = tid; i < XY; i += PB_THREADS) dst[i] = 0.f;
+      continue;
+    }
+    for (int i = tid; i < XY; i += PB_THREADS) iplane[i] = 0;
+    __syncthreads();
+    const float qx = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+    const float qy = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+    float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;   // corner cells (0,0) (0,Y-1) (X-1,0) (X-1,Y-1)
+#pragma unroll
+    for (int k = 0; k < PB_PPT; ++k) {
+      const float gk = g[k];
+      const float ru = fmaf(pc[k], qx, fmaf(-ps[k], qy, ptx[k]));
+      const float rv = fmaf(ps[k], qx, fmaf(pc[k], qy, pty[k]));
+      const bool ulo = ru <= 0.f, uhi = ru >= Xf - 1.f;
+      const bool vlo = rv <= 0.f, vhi = rv >= Yf - 1.f;
+      if ((ulo || uhi) && (vlo || vhi)) {       // clamped in both directions: one corner cell
+        if (ulo && vlo) c00 += gk;
+        else if (ulo) c01 += gk;
+        else if (vlo) c10 += gk;
+        else c11 += gk;
+        continue;
+      }
+      if (gk == 0.f) continue;
+      const float cu = fminf(fmaxf(ru, 0.f), Xf - 1.f), cv = fminf(fmaxf(rv, 0.f), Yf - 1.f);
+      const float fu = fminf(floorf(cu), Xf - 2.f), fv = fminf(floorf(cv), Yf - 2.f);
+      const float wu = cu - fu, wv = cv - fv;
+      unsigned long long* q = reinterpret_cast<unsigned long long*>(iplane) + (int)fmaf(fu, Yf, fv);
+      const float g0 = (1.f - wu) * gk, g1 = wu * gk;
+      const float w00 = g0 * (1.f - wv), w01 = g0 * wv, w10 = g1 * (1.f - wv), w11 = g1 * wv;
+      if (w00 != 0.f) atomicAdd(q, (unsigned long long)fixed(w00));
+      if (w01 != 0.f) atomicAdd(q + 1, (unsigned long long)fixed(w01));
+      if (w10 != 0.f) atomicAdd(q + Y, (unsigned long long)fixed(w10));
+      if (w11 != 0.f) atomicAdd(q + Y + 1, (unsigned long long)fixed(w11));
+    }
+    c00 = wave_sum(c00); c01 = wave_sum(c01); c10 = wave_sum(c10); c11 = wave_sum(c11);
+    if (lane == 0) { corner[wave][0] = c00; corner[wave][1] = c01; corner[wave][2] = c10; corner[wave][3] = c11; }
+    __syncthreads();
+    if (tid < 4) {                               // the waves' corner sums in a FIXED order
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < PB_THREADS / 64; ++w) t += corner[w][tid];
+      const int cell = tid == 0 ? 0 : tid == 1 ? Y - 1 : tid == 2 ? (a.X - 1) * Y : (a.X - 1) * Y + Y - 1;
+      corner[0][tid] = (float)((double)iplane[cell] * unscale) + t;
+    }
+    __syncthreads();
+    for (int i = tid; i < XY; i += PB_THREADS) {
+      const bool is_corner = i == 0 || i == Y - 1 || i == (a.X - 1) * Y || i == (a.X - 1) * Y + Y - 1;
+      const int ci = i == 0 ? 0 : i == Y - 1 ? 1 : i == (a.X - 1) * Y ? 2 : 3;
+      dst[i] = is_corner ? corner[0][ci] : (float)((double)iplane[i] * unscale);
+    }
+    __syncthreads();
+  }
+}
+
 // G = dsim * [sim > 0] * coef[b] in place; per-block partial of sum(dsim * sim).
 __global__ __launch_bounds__(256) void sim_bwd_prepare_kernel(float* __restrict__ dsim,
                                                               const float* __restrict__ sim,
@@ -219,6 +323,15 @@ extern "C" int snap_pose_score_bwd_f32(const float* dscores, const float* poses,
                                        int32_t Nq, int32_t X, int32_t Y, int32_t P,
                                        float cell_size, int32_t mask_oob, float* dsim,
                                        void* workspace, size_t workspace_bytes, void* stream) {
+  return snap_pose_score_bwd_ex_f32(dscores, poses, q_xy, valid_q, map_valid, B, Nq, X, Y, P, cell_size,
+                                    mask_oob, 0, dsim, workspace, workspace_bytes, stream);
+}
+
+extern "C" int snap_pose_score_bwd_ex_f32(const float* dscores, const float* poses, const float* q_xy,
+                                          const uint8_t* valid_q, const uint8_t* map_valid, int32_t B,
+                                          int32_t Nq, int32_t X, int32_t Y, int32_t P,
+                                          float cell_size, int32_t mask_oob, int32_t flags, float* dsim,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
   if (!dscores || !poses || !q_xy || !valid_q || !dsim || !workspace) return SNAP_ERR_NULL;
   if (mask_oob && !map_valid) return SNAP_ERR_NULL;
   if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || P <= 0) return SNAP_ERR_BAD_SHAPE;
@@ -237,14 +350,20 @@ extern "C" int snap_pose_score_bwd_f32(const float* dscores, const float* poses,
   if (nch > Nq) nch = Nq;
   a.points_per_chunk = (Nq + nch - 1) / nch;
   nch = (Nq + a.points_per_chunk - 1) / a.points_per_chunk;
-  const size_t lds = (size_t)X * Y * sizeof(float);
+  size_t lds = (size_t)X * Y * sizeof(float);
   const bool fast = !mask_oob && P <= PB_THREADS * PB_PPT && X >= 2 && Y >= 2;
-  const void* fn = fast ? (const void*)&pose_score_bwd_fast_kernel
-                        : (mask_oob ? (const void*)&pose_score_bwd_kernel<true>
-                                    : (const void*)&pose_score_bwd_kernel<false>);
+  // deterministic (fixed-point) form where the 8-byte plane fits: bit 1 of mask_oob's word is
+  // NOT used -- the choice is the shape's; SNAP_POSE_BWD_FLOAT_ATOMICS in `flags` asks for the
+  // float form (A/B timing)
+  const bool det = fast && (size_t)X * Y * 8 <= 152 * 1024 && !(flags & 1);
+  const void* fn = det ? (const void*)&pose_score_bwd_det_kernel
+                       : fast ? (const void*)&pose_score_bwd_fast_kernel
+                              : (mask_oob ? (const void*)&pose_score_bwd_kernel<true>
+                                          : (const void*)&pose_score_bwd_kernel<false>);
+  if (det) lds = (size_t)X * Y * 8;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(PB_LDS_FLOATS * sizeof(float))) != hipSuccess)
+                            det ? (int)lds : (int)(PB_LDS_FLOATS * sizeof(float))) != hipSuccess)
       return SNAP_ERR_LAUNCH;
   }
   void* kargs[] = {(void*)&a};

@@ -11,6 +11,13 @@ from snap_amd import _lib
 from snap_amd import ops
 from snap_amd.ops import _f32, _mask, _p, _region, _stream, POOLING
 
+# The lift's VJP: records -> stable sort by image pixel -> gather (bitwise reproducible, no
+# atomics); False = the scatter form with hardware float atomics (order-dependent sums).
+DETERMINISTIC_LIFT_BWD = True
+# The pose-scoring VJP accumulates its score planes in 64-bit fixed point (exactly associative);
+# False = float LDS atomics (order-dependent sums).
+DETERMINISTIC_POSE_BWD = True
+
 
 def _conv_desc(x_shape, w_shape, stride, padding, prologue, in_affine, cs=None):
   N, H, W, Cs = x_shape
@@ -153,6 +160,18 @@ def lift_pool_bwd(f_images, cam, Rt, points, dpooled, *, K, fisheye, feature_dim
       1, 1, 0,            # (the VJP exists for the default fusion options only)
   )
   df = torch.empty_like(f_images)
+  wsb = lib.snap_lift_pool_bwd_det_workspace_bytes(ctypes.byref(d)) if DETERMINISTIC_LIFT_BWD else 0
+  if wsb:
+    # records -> stable sort by image pixel -> gather: no atomics, bitwise reproducible
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=f_images.device)
+    off = (-ws.data_ptr()) % 256
+    with _region('lift_pool_bwd', 0.0, 4.0 * (f_images.numel() * 2 + dpooled.numel())):
+      st = lib.snap_lift_pool_bwd_det_f32(
+          ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(dpooled), _p(df),
+          ctypes.c_void_p(ws.data_ptr() + off), wsb, _stream()
+      )
+    _lib.check(st, 'snap_lift_pool_bwd_det_f32')
+    return df
   with _region('lift_pool_bwd', 0.0, 4.0 * (f_images.numel() * 2 + dpooled.numel())):
     st = lib.snap_lift_pool_bwd_f32(
         ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(dpooled), _p(df), _stream()
@@ -209,11 +228,12 @@ def pose_score_bwd(dscores, poses, q_xy, valid_q, map_valid, sim_shape, cell_siz
   ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=poses.device)
   dsim = torch.empty(sim_shape, dtype=torch.float32, device=poses.device)
   with _region('pose_score_bwd', 0.0, 4.0 * dsim.numel()):
-    st = lib.snap_pose_score_bwd_f32(
+    st = lib.snap_pose_score_bwd_ex_f32(
         _p(dscores), _p(poses), _p(q_xy), _p(valid_q), _p(map_valid), B, Nq, X, Y, P,
-        float(cell_size), int(mask_oob), _p(dsim), _p(ws), ws.numel() * 4, _stream(),
+        float(cell_size), int(mask_oob), 0 if DETERMINISTIC_POSE_BWD else 1, _p(dsim), _p(ws),
+        ws.numel() * 4, _stream(),
     )
-  _lib.check(st, 'snap_pose_score_bwd_f32')
+  _lib.check(st, 'snap_pose_score_bwd_ex_f32')
   return dsim
 
 

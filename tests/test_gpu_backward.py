@@ -308,9 +308,19 @@ def test_lift_pool_bwd(K, V):
   smax = torch.where(anyv, sm.max(-1).values, torch.zeros_like(anyv, dtype=torch.float64))
   pooled = torch.cat([mean, var, smax[:, None]], -1) * anyv[:, None]
   pooled.backward(dpooled[0, :, : 2 * fd + 1].double())
-  got = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
   ref = fdbl.grad.float()
-  helpers.report('lift bwd', got, ref, atol=2e-4 * float(ref.abs().max()) + 1e-6)
+  # both forms of the VJP: the deterministic one (records -> stable sort by pixel -> gather; the
+  # default) must also be BITWISE reproducible; the scatter form uses float atomics
+  got = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
+  helpers.report('lift bwd (deterministic)', got, ref, atol=2e-4 * float(ref.abs().max()) + 1e-6)
+  for _ in range(3):
+    assert torch.equal(ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw), got)
+  prev, ops_bwd.DETERMINISTIC_LIFT_BWD = ops_bwd.DETERMINISTIC_LIFT_BWD, False
+  try:
+    got_s = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
+  finally:
+    ops_bwd.DETERMINISTIC_LIFT_BWD = prev
+  helpers.report('lift bwd (scatter)', got_s, ref, atol=2e-4 * float(ref.abs().max()) + 1e-6)
 
 
 @pytest.mark.parametrize('pooling', ['max', 'sum', 'mean'])
@@ -402,6 +412,23 @@ def test_pose_score_bwd(mask_oob):
   got = ops_bwd.pose_score_bwd(G(dscores), G(poses), G(q_xy), G(valid_q), G(mv), tuple(sim.shape),
                                cell, mask_oob=mask_oob)
   helpers.report('pose_score bwd', got, sd.grad.float(), atol=2e-4, rtol=1e-4)
+  if not mask_oob:
+    # the default is the fixed-point (exactly associative) accumulation: bitwise reproducible, and
+    # at least as close to float64 as the float-atomics form; cotangents of any magnitude
+    for _ in range(3):
+      again = ops_bwd.pose_score_bwd(G(dscores), G(poses), G(q_xy), G(valid_q), G(mv), tuple(sim.shape),
+                                     cell, mask_oob=False)
+      assert torch.equal(again, got)
+    big = ops_bwd.pose_score_bwd(G(dscores * 2.0 ** 40), G(poses), G(q_xy), G(valid_q), G(mv),
+                                 tuple(sim.shape), cell, mask_oob=False)
+    assert torch.equal(big, got * 2.0 ** 40)            # (the scale is a power of two: exact)
+    prev, ops_bwd.DETERMINISTIC_POSE_BWD = ops_bwd.DETERMINISTIC_POSE_BWD, False
+    try:
+      flt = ops_bwd.pose_score_bwd(G(dscores), G(poses), G(q_xy), G(valid_q), G(mv), tuple(sim.shape),
+                                   cell, mask_oob=False)
+    finally:
+      ops_bwd.DETERMINISTIC_POSE_BWD = prev
+    helpers.report('pose_score bwd (float atomics)', flt, sd.grad.float(), atol=2e-4, rtol=1e-4)
 
 
 def test_similarity_bwd():
