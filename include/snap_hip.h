@@ -537,8 +537,24 @@ int snap_masked_softmax_rows_f32(const float* x, const uint8_t* mask, int32_t B,
                                  float* weights, float* cdf, void* stream);
 /* bev_confidence = where(valid, log_sigmoid(features . w + bias), 0)  (Dense(1) head of the BEV
  * plane, bev_mapper.py:154-157,292-295).  features [M, D], D % 4 == 0; valid may be NULL. */
-int snap_confidence_head_f32(const float* features, const uint8_t* valid, const float* w, float bias,
-                             int64_t M, int32_t D, float* out, void* stream);
+int snap_confidence_head_f32(const float* features, const uint8_t* valid, const float* w,
+                             const float* bias /* DEVICE scalar */, int64_t M, int32_t D, float* out,
+                             void* stream);
+/* Its VJP: d features [M, D] = ds w; prod [M, D] = ds f and dsv [M, 4] = (ds, 0, 0, 0) are the
+ * per-row terms whose fixed-order column sums (snap_colsum_f32) are d w and d bias;
+ * ds = dconf * sigmoid(-(f . w + bias)) * [valid]. */
+int snap_confidence_head_bwd_f32(const float* features, const uint8_t* valid, const float* w,
+                                 const float* bias, const float* dconf, int64_t M, int32_t D,
+                                 float* dfeatures, float* prod, float* dsv, void* stream);
+/* add_confidence_query (bev_localizer.py:165-168), training: rowdot[b, n] = sum_cells dsim * sim
+ * (the row's share of the temperature gradient; / weight = the gradient of the point weight), then
+ * dsim = dsim * [sim > 0] * row_coef[b, n] in place; and the VJP of layers.masked_softmax
+ * (layers.py:38-43): dx = w * (dw - sum_n w dw). */
+int snap_sim_bwd_prepare_rows_f32(float* dsim, const float* sim, int32_t B, int32_t Nq, int32_t XY,
+                                  int32_t clip_negative, const float* row_coef, float* rowdot,
+                                  void* stream);
+int snap_masked_softmax_rows_bwd_f32(const float* weights, const float* dweights, int32_t B,
+                                     int32_t N, float* dx, void* stream);
 
 /* Draw S correspondences per scene ~ prob_points (iid categorical; counter-based
  * Philox4x32-10 keyed by (seed, b, s)).  corr[B,S,3] = (n, i, j).
@@ -734,12 +750,27 @@ int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_images, cons
  * view) observation becomes a record, the records are sorted by image pixel (stable radix sort)
  * and one half-wave per pixel gathers the records that touch it in that order; every element of
  * df_images is written exactly once.  workspace: snap_lift_pool_bwd_det_workspace_bytes(desc)
- * bytes (0 = unsupported shape), 256-byte aligned; num_bins <= 32, <= 8 selected views. */
+ * bytes (0 = unsupported shape), 256-byte aligned; num_bins <= 32, <= 8 selected views.  Every
+ * fusion option of pool_multiview_features (desc->weighted / use_variance / add_minmax; the
+ * max / min cotangents are split equally among tied views, as jnp.max's VJP does). */
 size_t snap_lift_pool_bwd_det_workspace_bytes(const SnapLiftDesc* desc);
 int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float* f_images, const float* cam,
                                const float* Rt, const float* points, const float* dpooled,
                                float* df_images, void* workspace, size_t workspace_bytes,
                                void* stream);
+/* depth_mlp fusion (streetview_encoder.py:263-267), the VJPs of its two lift passes:
+ *   snap_lift_pool_observations_bwd_f32: d pooled -> d obs_feat' [B, N, S, fd] (zero for views that
+ *     do not see the point), the pooling VJP on the given (corrected) observations;
+ *   snap_lift_observations_bwd_f32: d obs [B, N, S, fd] (the caller's sum of the gradient of
+ *     obs[..., :fd] and of obs_feat; depth and ray carry none) -> d f_images, by the deterministic
+ *     records / sort / gather machinery with the rows of d obs as the record vectors. */
+int snap_lift_pool_observations_bwd_f32(const SnapLiftDesc* desc, const float* cam, const float* Rt,
+                                        const float* points, const float* obs_feat,
+                                        const float* dpooled, float* dobs, void* stream);
+size_t snap_lift_observations_bwd_workspace_bytes(const SnapLiftDesc* desc);
+int snap_lift_observations_bwd_f32(const SnapLiftDesc* desc, const float* cam, const float* Rt,
+                                   const float* points, const float* dobs, float* df_images,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 int snap_vertical_pool_bwd_f32(const float* vol, const uint8_t* vvalid, const float* dplane,
                                float* dvol, int64_t M, int32_t Z, int32_t D, int32_t pooling,
                                void* stream);

@@ -162,7 +162,10 @@ SIGNATURES = {
     'snap_sim_softmax_split_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr,
                                            c_int, ptr, ptr, ptr, c_size, ptr]),
     'snap_masked_softmax_rows_f32': (c_int, [ptr, ptr, c_int, c_int, ptr, ptr, ptr]),
-    'snap_confidence_head_f32': (c_int, [ptr, ptr, ptr, c_float, c_i64, c_int, ptr, ptr]),
+    'snap_confidence_head_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, ptr, ptr]),
+    'snap_confidence_head_bwd_f32': (c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_int, ptr, ptr, ptr, ptr]),
+    'snap_sim_bwd_prepare_rows_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, ptr, ptr, ptr]),
+    'snap_masked_softmax_rows_bwd_f32': (c_int, [ptr, ptr, c_int, c_int, ptr, ptr]),
     'snap_ransac_sample_sim_f32': (
         c_int,
         [ptr, ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
@@ -244,6 +247,11 @@ SIGNATURES = {
         c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]
     ),
     'snap_lift_pool_bwd_det_workspace_bytes': (c_size, [ctypes.POINTER(SnapLiftDesc)]),
+    'snap_lift_pool_observations_bwd_f32': (
+        c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
+    'snap_lift_observations_bwd_workspace_bytes': (c_size, [ctypes.POINTER(SnapLiftDesc)]),
+    'snap_lift_observations_bwd_f32': (
+        c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_size, ptr]),
     'snap_lift_pool_bwd_det_f32': (
         c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_size, ptr]
     ),

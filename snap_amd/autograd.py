@@ -47,16 +47,25 @@ def conv_dgrad(dy, w, x_shape, stride, padding):
   return ops.conv2d(dy.contiguous(), w_rot, padding=((pt2, pb2), (pl2, pr2)))
 
 
-def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid):
-  """VJP of sim = relu(fq . fm) * scale / num_valid.  `dsim` is overwritten.
+def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid, row_weight=None):
+  """VJP of sim = relu(fq . fm) * scale / num_valid -- or * scale * row_weight[b, n]
+  (add_confidence_query).  `dsim` is overwritten.
 
   Returns dfq [B,Nq,Dm], dfm [B,X,Y,Dm], dtemperature (scalar tensor, d/dT with
-  scale = exp(T))."""
+  scale = exp(T)), d row_weight [B,Nq] or None."""
   B, Nq, X, Y = sim.shape
   Dm = fq.shape[-1]
   XY = X * Y
-  coef = (scale / num_valid).to(torch.float32).contiguous()
-  dtemp = ops_bwd.sim_bwd_prepare_(dsim, sim, clip, coef).sum()
+  dweight = None
+  if row_weight is not None:
+    rowdot = ops_bwd.sim_bwd_prepare_rows_(dsim, sim, clip, (row_weight * scale).contiguous())
+    dtemp = rowdot.sum()
+    # d sim / d w = sim / w; a zero weight (a masked point) receives none: the masked softmax
+    # hands nothing back to it either
+    dweight = torch.where(row_weight > 0, rowdot / row_weight.clamp(min=1e-38), torch.zeros_like(rowdot))
+  else:
+    coef = (scale / num_valid).to(torch.float32).contiguous()
+    dtemp = ops_bwd.sim_bwd_prepare_(dsim, sim, clip, coef).sum()
   dfq = torch.empty_like(fq)
   dfm = torch.empty_like(fm)
   for b in range(B):
@@ -64,6 +73,8 @@ def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid):
     dfq[b] = ops.conv2d(g, fm[b].reshape(1, 1, XY, Dm)).reshape(Nq, Dm)
     dfm[b] = ops_bwd.conv2d_wgrad(g, fq[b].reshape(1, 1, Nq, Dm).contiguous(),
                                   (1, 1, XY, Dm)).reshape(X, Y, Dm)
+  if row_weight is not None:
+    return dfq, dfm, dtemp.to(torch.float32), dweight
   return dfq, dfm, dtemp.to(torch.float32)
 
 
@@ -400,9 +411,9 @@ class _LiftPool(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, f_images, cam, Rt, points, cfg):
-    K, fisheye, fd, nb, dmm, mvd = cfg
+    K, fisheye, fd, nb, dmm, mvd, opts = cfg
     pooled, valid = ops.lift_pool(f_images, cam, Rt, points, K=K, fisheye=fisheye, feature_dim=fd,
-                                  num_bins=nb, depth_min_max=dmm, max_view_distance=mvd)
+                                  num_bins=nb, depth_min_max=dmm, max_view_distance=mvd, **opts)
     ctx.cfg = cfg
     ctx.save_for_backward(f_images, cam, Rt, points)
     ctx.mark_non_differentiable(valid)
@@ -410,18 +421,79 @@ class _LiftPool(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, dpooled, _dvalid):
-    K, fisheye, fd, nb, dmm, mvd = ctx.cfg
+    K, fisheye, fd, nb, dmm, mvd, opts = ctx.cfg
     f_images, cam, Rt, points = ctx.saved_tensors
     df = ops_bwd.lift_pool_bwd(f_images, cam, Rt, points, dpooled.contiguous(), K=K,
                                fisheye=fisheye, feature_dim=fd, num_bins=nb, depth_min_max=dmm,
-                               max_view_distance=mvd)
+                               max_view_distance=mvd, **opts)
     return df, None, None, None, None
 
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins, depth_min_max,
-              max_view_distance=None):
-  cfg = (K, fisheye, feature_dim, num_bins, tuple(depth_min_max), max_view_distance)
+              max_view_distance=None, weighted=True, use_variance=True, add_minmax=False):
+  """Differentiable ``ops.lift_pool`` (every option of pool_multiview_features)."""
+  opts = dict(weighted=bool(weighted), use_variance=bool(use_variance), add_minmax=bool(add_minmax))
+  cfg = (K, fisheye, feature_dim, num_bins, tuple(depth_min_max), max_view_distance, opts)
   return _LiftPool.apply(f_images, cam, Rt, points, cfg)
+
+
+class _LiftObservations(torch.autograd.Function):
+  """First pass of the depth_mlp fusion (streetview_encoder.py:263-267): the un-pooled
+  observations.  Depth and viewing ray are geometry: only the feature channels carry gradient."""
+
+  @staticmethod
+  def forward(ctx, f_images, cam, Rt, points, cfg):
+    K, fisheye, fd, mvd = cfg
+    obs, feat, valid = ops.lift_observations(f_images, cam, Rt, points, K=K, fisheye=fisheye,
+                                             feature_dim=fd, max_view_distance=mvd)
+    ctx.cfg = cfg
+    ctx.f_shape = tuple(f_images.shape)
+    ctx.save_for_backward(cam, Rt, points)
+    ctx.mark_non_differentiable(valid)
+    return obs, feat, valid
+
+  @staticmethod
+  def backward(ctx, dobs, dfeat, _dvalid):
+    K, fisheye, fd, mvd = ctx.cfg
+    cam, Rt, points = ctx.saved_tensors
+    d = (dobs[..., :fd] + dfeat).contiguous()
+    df = ops_bwd.lift_observations_bwd(d, ctx.f_shape, cam, Rt, points, K=K, fisheye=fisheye,
+                                       feature_dim=fd, max_view_distance=mvd)
+    return df, None, None, None, None
+
+
+def lift_observations(f_images, cam, Rt, points, *, K, fisheye, feature_dim, max_view_distance=None):
+  return _LiftObservations.apply(f_images, cam, Rt, points, (K, fisheye, feature_dim, max_view_distance))
+
+
+class _LiftPoolObservations(torch.autograd.Function):
+  """Second pass: pool_multiview_features of the corrected observations."""
+
+  @staticmethod
+  def forward(ctx, obs_feat, cam, Rt, points, cfg):
+    f_shape, K, fisheye, fd, mvd, uv, mm = cfg
+    pooled, valid = ops.lift_pool_observations(obs_feat, f_shape, cam, Rt, points, K=K, fisheye=fisheye,
+                                               feature_dim=fd, max_view_distance=mvd, use_variance=uv,
+                                               add_minmax=mm)
+    ctx.cfg = cfg
+    ctx.save_for_backward(obs_feat, cam, Rt, points)
+    ctx.mark_non_differentiable(valid)
+    return pooled, valid
+
+  @staticmethod
+  def backward(ctx, dpooled, _dvalid):
+    f_shape, K, fisheye, fd, mvd, uv, mm = ctx.cfg
+    obs_feat, cam, Rt, points = ctx.saved_tensors
+    dobs = ops_bwd.lift_pool_observations_bwd(obs_feat, f_shape, cam, Rt, points, dpooled.contiguous(),
+                                              K=K, fisheye=fisheye, feature_dim=fd, max_view_distance=mvd,
+                                              use_variance=uv, add_minmax=mm)
+    return dobs, None, None, None, None
+
+
+def lift_pool_observations(obs_feat, f_shape, cam, Rt, points, *, K, fisheye, feature_dim,
+                           max_view_distance=None, use_variance=True, add_minmax=False):
+  cfg = (tuple(f_shape), K, fisheye, feature_dim, max_view_distance, bool(use_variance), bool(add_minmax))
+  return _LiftPoolObservations.apply(obs_feat.contiguous(), cam, Rt, points, cfg)
 
 
 class _VerticalPool(torch.autograd.Function):
@@ -518,6 +590,81 @@ def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None, normalize=
 # ----------------------------------------------------------------------------
 # pose head
 # ----------------------------------------------------------------------------
+class _ConfidenceHead(torch.autograd.Function):
+  """bev_confidence = where(valid, log_sigmoid(Dense(1)(features)), 0)  (bev_mapper.py:154-157,292-295)."""
+
+  @staticmethod
+  def forward(ctx, features, kernel, bias, valid):
+    w = kernel.reshape(-1).contiguous()
+    b = bias.reshape(-1)[:1].contiguous()
+    ctx.save_for_backward(features, w, b, valid)
+    ctx.kshape, ctx.bshape = tuple(kernel.shape), tuple(bias.shape)
+    return ops.confidence_head(features, valid, w, b)
+
+  @staticmethod
+  def backward(ctx, dconf):
+    features, w, b, valid = ctx.saved_tensors
+    df, dw, db = ops_bwd.confidence_head_bwd(features, valid, w, b, dconf.contiguous())
+    return df, dw.reshape(ctx.kshape), db.reshape(ctx.bshape), None
+
+
+def confidence_head(features, valid, kernel, bias):
+  return _ConfidenceHead.apply(features.contiguous(), kernel, bias, valid)
+
+
+class _MaskedSoftmaxRows(torch.autograd.Function):
+  """layers.masked_softmax over the last axis (layers.py:38-43) of x [B, N] (+ its CDF, no gradient)."""
+
+  @staticmethod
+  def forward(ctx, x, mask):
+    w, cdf = ops.masked_softmax_rows(x, mask)
+    ctx.save_for_backward(w)
+    ctx.mark_non_differentiable(cdf)
+    return w, cdf
+
+  @staticmethod
+  def backward(ctx, dw, _dcdf):
+    (w,) = ctx.saved_tensors
+    return ops_bwd.masked_softmax_rows_bwd(w, dw.contiguous()), None
+
+
+def masked_softmax_rows(x, mask):
+  return _MaskedSoftmaxRows.apply(x.contiguous(), mask.contiguous())
+
+
+class _SimSoftmaxWeighted(torch.autograd.Function):
+  """sim = relu(fq . fm) * exp(T) * weights[b, n]  (add_confidence_query, bev_localizer.py:165-168)."""
+
+  @staticmethod
+  def forward(ctx, fq, fm, temperature, weights, num_valid, clip, want_prob):
+    scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+    sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob,
+                                          row_weight=weights)
+    ctx.scale, ctx.clip = scale, clip
+    ctx.save_for_backward(fq, fm, sim, num_valid, weights)
+    ctx.has_t = temperature is not None
+    ctx.mark_non_differentiable(stats)
+    if prob is None:
+      prob = sim.new_zeros(())
+    ctx.mark_non_differentiable(prob)
+    return sim, stats, prob
+
+  @staticmethod
+  def backward(ctx, dsim, _ds, _dp):
+    fq, fm, sim, num_valid, weights = ctx.saved_tensors
+    dfq, dfm, dtemp, dw = similarity_bwd(dsim.contiguous().clone(), sim, fq, fm, ctx.scale, ctx.clip,
+                                         num_valid, row_weight=weights)
+    return dfq, dfm, (dtemp if ctx.has_t else None), dw, None, None, None
+
+
+def sim_softmax_weighted(fq, fm, temperature, weights, clip_negative, num_valid, want_prob=False):
+  """Returns (sim, chunk_stats, prob or None, scale) with per-point weights (differentiable)."""
+  sim, stats, prob = _SimSoftmaxWeighted.apply(fq, fm, temperature, weights.contiguous(), num_valid,
+                                               clip_negative, want_prob)
+  scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+  return sim, stats, (prob if want_prob else None), scale
+
+
 class _SimSoftmax(torch.autograd.Function):
 
   @staticmethod

@@ -35,6 +35,8 @@ struct LiftBwdArgs {
   unsigned* keys;        // [slots]: pixel id of tap (i0, j0), or npix for an empty slot
   unsigned* count;       // [npix + 1]: records per key
   unsigned npix;
+  const float* obs_in;   // MODE 2: the (corrected) observations [B, N, S, fd]
+  float* dobs;           // MODE 2: their gradient
 };
 
 struct ProjB {
@@ -114,7 +116,14 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
-template <int KMAX, bool RECORDS>
+// MODE 0: scatter with float atomics (default fusion options only)
+// MODE 1: records of the deterministic form, every fusion option (desc->weighted / use_variance /
+//         add_minmax: mean | var? | max, min? | score_max? -- pool_multiview_features :141-178)
+// MODE 2: VJP of the POOLING of given observations (depth_mlp fusion, second pass): a.obs_in
+//         [B, N, S, fd] -> a.dobs [B, N, S, fd]; no image taps
+// MODE 3: records of given observation gradients (depth_mlp fusion, first pass): only the taps,
+//         keys and counts are produced -- the record vectors ARE the caller's d obs [slots][fd]
+template <int KMAX, int MODE>
 __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a) {
   const SnapLiftDesc& d = a.d;
   const int hl = threadIdx.x & 31;
@@ -125,9 +134,13 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
   const int fd = d.feature_dim;
   const bool all_views = d.K == 0;
   const int nsel = all_views ? d.V : d.K;
+  constexpr bool RECORDS = MODE == 1 || MODE == 3;
   if constexpr (RECORDS) {       // every slot of this voxel starts empty (key = npix sorts last)
     if (hl < nsel) a.keys[gv * nsel + hl] = a.npix;
   }
+  const bool weighted = MODE == 0 || (MODE == 1 && d.weighted);
+  const bool use_var = MODE == 0 || d.use_variance;
+  const bool minmax = MODE != 0 && d.add_minmax;
   const float* p = a.pts + gv * 3;
   const float px = p[0], py = p[1], pz = p[2];
 
@@ -181,7 +194,16 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
     ok[r] = vis;
     if (!vis) continue;
     any = true;
+    if constexpr (MODE == 2) {                    // the observation is given
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = hl + 32 * e;
+        if (c < fd) feat[r][e] = a.obs_in[(gv * nsel + r) * (int64_t)fd + c];
+      }
+      continue;
+    }
     tp[r] = taps_b(pi, pj, d.h, d.w, all_views ? 0 : 1);
+    if constexpr (MODE == 3) continue;            // taps only
     const TapsB& t = tp[r];
     const float* img = a.f + ((int64_t)b * d.V + v) * d.h * d.w * d.C;
     const float* r00 = img + ((int64_t)t.i0 * d.w + t.j0) * d.C;
@@ -194,6 +216,7 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
       if (c < fd)                 // one contiguous 128-byte line per half-wave
         feat[r][e] = ((t.w00 * r00[c] + t.w01 * r01[c]) + t.w10 * r10[c]) + t.w11 * r11[c];
     }
+    if (!weighted) continue;      // (scores = None: no depth-score bins in f_images)
     const float dc = fminf(fmaxf(depth, d.depth_min), d.depth_max);
     const float tt = logf(dc / d.depth_min) / log_range;
     const float index = 0.5f + tt * (float)(d.num_bins - 1);
@@ -207,17 +230,57 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
     const float s1 = ((t.w00 * r00[c1] + t.w01 * r01[c1]) + t.w10 * r10[c1]) + t.w11 * r11[c1];
     score[r] = (1.f - wb1[r]) * s0 + wb1[r] * s1;
   }
-  if (!any) return;  // pooled == 0 (masked): no gradient
+  if constexpr (MODE == 2) {
+    if (!any) {                                   // pooled == 0 (masked): no gradient
+#pragma unroll
+      for (int r = 0; r < KMAX; ++r)
+        if (r < nsel)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = hl + 32 * e;
+            if (c < fd) a.dobs[(gv * nsel + r) * (int64_t)fd + c] = 0.f;
+          }
+      return;
+    }
+  } else {
+    if (!any) return;  // pooled == 0 (masked): no gradient
+  }
+  if constexpr (MODE == 3) {
+    // the record vector of slot (voxel, r) is the caller's d obs row: header, key and count only
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      if (!ok[r] || hl != 0) continue;
+      const TapsB& t = tp[r];
+      const int64_t rid = gv * nsel + r;
+      float* h = a.rec_hdr + rid * 12;
+      reinterpret_cast<f32x4*>(h)[0] = f32x4{t.w00, t.w01, t.w10, t.w11};
+      reinterpret_cast<f32x4*>(h)[1] = f32x4{0.f, 0.f, __int_as_float(0), __int_as_float(t.i0 | (t.i1 << 16))};
+      h[8] = __int_as_float(t.j0 | (t.j1 << 16));
+      const unsigned key = (unsigned)((((int64_t)b * d.V + view[r]) * d.h + t.i0) * d.w + t.j0);
+      a.keys[rid] = key;
+      atomicAdd(a.count + key, 1u);
+    }
+    return;
+  }
 
+  // ---- pooling weights: softmax(where = visible, initial = 0) of the depth scores, or 1 / count
   float m = 0.f, smax = -INFINITY;
-#pragma unroll
-  for (int r = 0; r < KMAX; ++r)
-    if (ok[r]) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
   float wgt[KMAX], den = 0.f;
+  if (weighted) {
 #pragma unroll
-  for (int r = 0; r < KMAX; ++r) {
-    wgt[r] = ok[r] ? expf(score[r] - m) : 0.f;
-    den += wgt[r];
+    for (int r = 0; r < KMAX; ++r)
+      if (ok[r]) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      wgt[r] = ok[r] ? expf(score[r] - m) : 0.f;
+      den += wgt[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      wgt[r] = ok[r] ? 1.f : 0.f;
+      den += wgt[r];
+    }
   }
   f32x4 mean = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -227,46 +290,98 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
     for (int e = 0; e < 4; ++e) mean[e] += wgt[r] * feat[r][e];
   }
 
-  // ---- upstream gradients ------------------------------------------------------
+  // ---- upstream gradients: mean | var? | max, min? | score_max? ------------------------------
   const float* g = a.dpooled + gv * d.out_stride;
+  const int o_var = fd, o_mm = fd * (1 + (use_var ? 1 : 0));
+  const int o_smax = fd * (1 + (use_var ? 1 : 0) + (minmax ? 2 : 0));
   f32x4 dmean = {0.f, 0.f, 0.f, 0.f}, dvar = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dmx = {0.f, 0.f, 0.f, 0.f}, dmn = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = hl + 32 * e;
-    if (c < fd) { dmean[e] = g[c]; dvar[e] = g[fd + c]; }
+    if (c < fd) {
+      dmean[e] = g[c];
+      if (use_var) dvar[e] = g[o_var + c];
+      if (minmax) { dmx[e] = g[o_mm + c]; dmn[e] = g[o_mm + fd + c]; }
+    }
   }
-  const float dsmax = g[2 * fd];
+  // max / min over the visible views: the cotangent is split equally among ties (jnp.max's VJP)
+  f32x4 vmx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, vmn = {INFINITY, INFINITY, INFINITY, INFINITY};
+  f32x4 nmx = {0.f, 0.f, 0.f, 0.f}, nmn = {0.f, 0.f, 0.f, 0.f};
+  if (minmax) {
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r)
+      if (ok[r])
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vmx[e] = fmaxf(vmx[e], feat[r][e]); vmn[e] = fminf(vmn[e], feat[r][e]); }
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r)
+      if (ok[r])
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          nmx[e] += feat[r][e] == vmx[e] ? 1.f : 0.f;
+          nmn[e] += feat[r][e] == vmn[e] ? 1.f : 0.f;
+        }
+  }
+  const float dsmax = weighted ? g[o_smax] : 0.f;
   int nmax = 0;
 #pragma unroll
   for (int r = 0; r < KMAX; ++r) nmax += (ok[r] && score[r] == smax) ? 1 : 0;
 
-  // d w_k = sum_c f_kc dmean_c + (f_kc - mean_c)^2 dvar_c   (half-wave reduction)
+  // d w_k = sum_c f_kc dmean_c + (f_kc - mean_c)^2 dvar_c   (half-wave reduction; weighted only)
   float dw[KMAX], dwbar = 0.f;
 #pragma unroll
   for (int r = 0; r < KMAX; ++r) {
     float t = 0.f;
-    if (ok[r]) {
+    if (ok[r] && weighted) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float dl = feat[r][e] - mean[e];
         t += feat[r][e] * dmean[e] + (dl * dl) * dvar[e];
       }
     }
-    dw[r] = half_sum(t);
+    dw[r] = weighted ? half_sum(t) : 0.f;
     dwbar += wgt[r] * dw[r];
   }
 #pragma unroll
   for (int r = 0; r < KMAX; ++r) {
-    if (!ok[r]) continue;
-    const float ds = wgt[r] * (dw[r] - dwbar) + ((score[r] == smax) ? dsmax / (float)nmax : 0.f);
+    if (!ok[r]) {
+      if constexpr (MODE == 2) {
+        if (r < nsel)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = hl + 32 * e;
+            if (c < fd) a.dobs[(gv * nsel + r) * (int64_t)fd + c] = 0.f;
+          }
+      }
+      continue;
+    }
+    const float ds = weighted ? wgt[r] * (dw[r] - dwbar) + ((score[r] == smax) ? dsmax / (float)nmax : 0.f) : 0.f;
+    float dfe[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
+      if (minmax) {
+        if (feat[r][e] == vmx[e]) t += dmx[e] / nmx[e];
+        if (feat[r][e] == vmn[e]) t += dmn[e] / nmn[e];
+      }
+      dfe[e] = t;
+    }
     const TapsB& t = tp[r];
-    if constexpr (RECORDS) {
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = hl + 32 * e;
+        if (c < fd) a.dobs[(gv * nsel + r) * (int64_t)fd + c] = dfe[e];
+      }
+      continue;
+    }
+    if constexpr (MODE == 1) {
       const int64_t rid = gv * nsel + r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = hl + 32 * e;
-        if (c < fd)
-          a.rec_vec[rid * fd + c] = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
+        if (c < fd) a.rec_vec[rid * fd + c] = dfe[e];
       }
       if (hl == 0) {
         float* h = a.rec_hdr + rid * 12;
@@ -290,7 +405,7 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
     for (int e = 0; e < 4; ++e) {
       const int c = hl + 32 * e;
       if (c >= fd) continue;
-      const float df = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
+      const float df = dfe[e];
       unsafeAtomicAdd(r00 + c, t.w00 * df);
       unsafeAtomicAdd(r01 + c, t.w01 * df);
       unsafeAtomicAdd(r10 + c, t.w10 * df);
@@ -579,15 +694,16 @@ extern "C" int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_i
   if (d.C != d.feature_dim + d.num_bins || d.C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
   if (d.out_stride < 2 * d.feature_dim + 1 || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
   if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  if (!d.weighted || !d.use_variance || d.add_minmax) return SNAP_ERR_UNSUPPORTED;   // (the det form has them)
   const int nsel = d.K == 0 ? d.V : d.K;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = (size_t)d.B * d.V * d.h * d.w * d.C * sizeof(float);
   if (hipMemsetAsync(df_images, 0, bytes, s) != hipSuccess) return SNAP_ERR_LAUNCH;
   LiftBwdArgs a{d, f_images, cam, Rt, points, dpooled, df_images};
   const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
-  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, false>), grid, dim3(256), 0, s, a);
-  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, false>), grid, dim3(256), 0, s, a);
-  else if (nsel <= 8) hipLaunchKernelGGL((lift_pool_bwd_kernel<8, false>), grid, dim3(256), 0, s, a);
+  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, 0>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, 0>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 8) hipLaunchKernelGGL((lift_pool_bwd_kernel<8, 0>), grid, dim3(256), 0, s, a);
   else return SNAP_ERR_UNSUPPORTED;
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
@@ -602,7 +718,7 @@ struct LiftDetLayout {
   int bits;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-inline int lift_det_layout(const SnapLiftDesc& d, LiftDetLayout* L) {
+inline int lift_det_layout(const SnapLiftDesc& d, LiftDetLayout* L, bool with_vec = true) {
   const int nsel = d.K == 0 ? d.V : d.K;
   L->slots = (size_t)d.B * d.N * nsel;
   L->npix = (size_t)d.B * d.V * d.h * d.w;
@@ -619,7 +735,7 @@ inline int lift_det_layout(const SnapLiftDesc& d, LiftDetLayout* L) {
     return SNAP_ERR_LAUNCH;
   L->tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
   size_t o = 0;
-  L->off_vec = o;       o += align256(L->slots * d.feature_dim * sizeof(float));
+  L->off_vec = o;       o += with_vec ? align256(L->slots * d.feature_dim * sizeof(float)) : 0;
   L->off_hdr = o;       o += align256(L->slots * 12 * sizeof(float));
   L->off_keys = o;      o += align256(L->slots * sizeof(unsigned));
   L->off_keys_out = o;  o += align256(L->slots * sizeof(unsigned));
@@ -648,8 +764,10 @@ extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float*
   if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
   if (d.V > 32 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0 || d.num_bins > 32)
     return SNAP_ERR_UNSUPPORTED;
-  if (d.C != d.feature_dim + d.num_bins || d.C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
-  if (d.out_stride < 2 * d.feature_dim + 1 || d.out_stride % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.C != d.feature_dim + (d.weighted ? d.num_bins : 0) || d.C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.out_stride < d.feature_dim * (1 + (d.use_variance ? 1 : 0) + (d.add_minmax ? 2 : 0)) + (d.weighted ? 1 : 0) ||
+      d.out_stride % 4 != 0)
+    return SNAP_ERR_BAD_SHAPE;
   if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
   const int nsel = d.K == 0 ? d.V : d.K;
   if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
@@ -671,9 +789,9 @@ extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float*
   if (hipMemsetAsync(a.count, 0, (L.npix + 2) * sizeof(unsigned), s) != hipSuccess) return SNAP_ERR_LAUNCH;
   // 1. records (+ their sort keys, + the per-pixel record counts)
   const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
-  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, true>), grid, dim3(256), 0, s, a);
-  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((lift_pool_bwd_kernel<8, true>), grid, dim3(256), 0, s, a);
+  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, 1>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, 1>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lift_pool_bwd_kernel<8, 1>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
   // 2. stable sort of the record slots by key (ties keep slot order = voxel order) and the list
   //    starts (exclusive scan of the counts)
@@ -687,6 +805,88 @@ extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float*
     return SNAP_ERR_LAUNCH;
   // 3. gather: every pixel of df_images written exactly once
   LiftGatherArgs g{d, keys_out, vals_out, start, a.rec_vec, a.rec_hdr, df_images, (unsigned)L.npix};
+  hipLaunchKernelGGL(lift_pool_bwd_gather_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+// ---- depth_mlp fusion (streetview_encoder.py:263-267): the VJPs of its two lift passes ------------
+extern "C" int snap_lift_pool_observations_bwd_f32(const SnapLiftDesc* desc, const float* cam,
+                                                   const float* Rt, const float* points,
+                                                   const float* obs_feat, const float* dpooled,
+                                                   float* dobs, void* stream) {
+  if (!desc || !cam || !Rt || !points || !obs_feat || !dpooled || !dobs) return SNAP_ERR_NULL;
+  const SnapLiftDesc& d = *desc;
+  if (d.B <= 0 || d.V <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.V > 32 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0 || d.weighted)
+    return SNAP_ERR_UNSUPPORTED;
+  if (d.out_stride < d.feature_dim * (1 + (d.use_variance ? 1 : 0) + (d.add_minmax ? 2 : 0)) || d.out_stride % 4 != 0)
+    return SNAP_ERR_BAD_SHAPE;
+  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  const int nsel = d.K == 0 ? d.V : d.K;
+  if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  LiftBwdArgs a{d, nullptr, cam, Rt, points, dpooled, nullptr};
+  a.obs_in = obs_feat;
+  a.dobs = dobs;
+  const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
+  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, 2>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, 2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lift_pool_bwd_kernel<8, 2>), grid, dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" size_t snap_lift_observations_bwd_workspace_bytes(const SnapLiftDesc* desc) {
+  if (!desc) return 0;
+  LiftDetLayout L;
+  if (lift_det_layout(*desc, &L, false) != SNAP_OK) return 0;
+  return L.total;
+}
+
+extern "C" int snap_lift_observations_bwd_f32(const SnapLiftDesc* desc, const float* cam,
+                                              const float* Rt, const float* points,
+                                              const float* dobs, float* df_images, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  if (!desc || !cam || !Rt || !points || !dobs || !df_images || !workspace) return SNAP_ERR_NULL;
+  const SnapLiftDesc& d = *desc;
+  if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.V > 32 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0 || d.C != d.feature_dim)
+    return SNAP_ERR_UNSUPPORTED;
+  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  const int nsel = d.K == 0 ? d.V : d.K;
+  if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
+  SnapLiftDesc dd = d;
+  dd.num_bins = 0;                                   // (the gather writes feature channels only)
+  LiftDetLayout L;
+  const int rc = lift_det_layout(dd, &L, false);
+  if (rc != SNAP_OK) return rc;
+  if (workspace_bytes < L.total || (reinterpret_cast<uintptr_t>(workspace) & 255)) return SNAP_ERR_WORKSPACE;
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  LiftBwdArgs a{dd, nullptr, cam, Rt, points, nullptr, df_images};
+  a.rec_hdr = reinterpret_cast<float*>(ws + L.off_hdr);
+  a.keys = reinterpret_cast<unsigned*>(ws + L.off_keys);
+  a.count = reinterpret_cast<unsigned*>(ws + L.off_count);
+  a.npix = (unsigned)L.npix;
+  unsigned* keys_out = reinterpret_cast<unsigned*>(ws + L.off_keys_out);
+  unsigned* vals_out = reinterpret_cast<unsigned*>(ws + L.off_vals_out);
+  unsigned* start = reinterpret_cast<unsigned*>(ws + L.off_start);
+  if (hipMemsetAsync(a.count, 0, (L.npix + 2) * sizeof(unsigned), s) != hipSuccess) return SNAP_ERR_LAUNCH;
+  const dim3 grid((unsigned)snap_cdiv((int64_t)dd.B * dd.N, 8));
+  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, 3>), grid, dim3(256), 0, s, a);
+  else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, 3>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lift_pool_bwd_kernel<8, 3>), grid, dim3(256), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  size_t tmp = L.tmp_bytes;
+  if (rocprim::radix_sort_pairs(ws + L.off_tmp, tmp, a.keys, keys_out, rocprim::counting_iterator<unsigned>(0),
+                                vals_out, L.slots, 0, L.bits, s) != hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  tmp = L.tmp_bytes;
+  if (rocprim::exclusive_scan(ws + L.off_tmp, tmp, a.count, start, 0u, L.npix + 2, rocprim::plus<unsigned>(), s) !=
+      hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  LiftGatherArgs g{dd, keys_out, vals_out, start, dobs, a.rec_hdr, df_images, (unsigned)L.npix};
   hipLaunchKernelGGL(lift_pool_bwd_gather_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
@@ -729,6 +929,52 @@ extern "C" int snap_plane_fuse_match_bwd_f32(const float* const* planes,
   a.dmatching = dmatching; a.dfused = dfused; a.dy = dy;
   hipLaunchKernelGGL(plane_fuse_match_bwd_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+// VJP of snap_confidence_head_f32 (bev_mapper.py:154-157,292-295): conf = where(valid,
+// log_sigmoid(f . w + bias), 0).  With s = f . w + bias and ds = g * sigmoid(-s) * [valid]:
+// d f = ds w (written here), d w = sum_m ds f_m, d bias = sum_m ds -- the two sums leave as
+// per-row products (prod [M, D] = ds f, dsv [M, 4] = (ds, 0, 0, 0)) for the fixed-order column
+// sums of snap_colsum_f32.  One half-wave per row.
+namespace {
+__global__ __launch_bounds__(256) void confidence_head_bwd_kernel(
+    const float* __restrict__ f, const uint8_t* __restrict__ valid, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ g, int64_t M, int D,
+    float* __restrict__ df, float* __restrict__ prod, float* __restrict__ dsv) {
+  const int hl = threadIdx.x & 31;
+  const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (m >= M) return;
+  float acc = 0.f;
+  for (int c = 4 * hl; c < D; c += 128) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(f + m * D + c);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+    acc += ((x[0] * ww[0] + x[1] * ww[1]) + x[2] * ww[2]) + x[3] * ww[3];
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 32);
+  const float s = acc + bias[0];
+  const bool ok = valid == nullptr || valid[m];
+  const float ds = ok ? g[m] / (1.f + expf(s)) : 0.f;             // sigmoid(-s)
+  for (int c = 4 * hl; c < D; c += 128) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(f + m * D + c);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+    *reinterpret_cast<f32x4*>(df + m * D + c) = f32x4{ds * ww[0], ds * ww[1], ds * ww[2], ds * ww[3]};
+    *reinterpret_cast<f32x4*>(prod + m * D + c) = f32x4{ds * x[0], ds * x[1], ds * x[2], ds * x[3]};
+  }
+  if (hl == 0) *reinterpret_cast<f32x4*>(dsv + m * 4) = f32x4{ds, 0.f, 0.f, 0.f};
+}
+}  // namespace
+
+extern "C" int snap_confidence_head_bwd_f32(const float* features, const uint8_t* valid, const float* w,
+                                            const float* bias, const float* dconf, int64_t M, int32_t D,
+                                            float* dfeatures, float* prod, float* dsv, void* stream) {
+  if (!features || !w || !bias || !dconf || !dfeatures || !prod || !dsv) return SNAP_ERR_NULL;
+  if (M <= 0 || D <= 0 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(confidence_head_bwd_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), features, valid, w, bias, dconf, M, D, dfeatures,
+                     prod, dsv);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

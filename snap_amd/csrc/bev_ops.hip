@@ -266,7 +266,7 @@ extern "C" int snap_plane_fuse_match_f32(const float* const* planes, const uint8
 namespace {
 __global__ __launch_bounds__(256) void confidence_head_kernel(
     const float* __restrict__ f, const uint8_t* __restrict__ valid, const float* __restrict__ w,
-    float bias, int64_t M, int D, float* __restrict__ out) {
+    const float* __restrict__ bias, int64_t M, int D, float* __restrict__ out) {
   const int hl = threadIdx.x & 31;
   const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (m >= M) return;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void confidence_head_kernel(
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 32);
   if (hl == 0) {
-    const float s = acc + bias;
+    const float s = acc + bias[0];
     const float ls = fminf(s, 0.f) - log1pf(expf(-fabsf(s)));
     out[m] = (valid == nullptr || valid[m]) ? ls : 0.f;
   }
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void confidence_head_kernel(
 }  // namespace
 
 extern "C" int snap_confidence_head_f32(const float* features, const uint8_t* valid, const float* w,
-                                        float bias, int64_t M, int32_t D, float* out, void* stream) {
-  if (!features || !w || !out) return SNAP_ERR_NULL;
+                                        const float* bias, int64_t M, int32_t D, float* out, void* stream) {
+  if (!features || !w || !bias || !out) return SNAP_ERR_NULL;
   if (M <= 0 || D <= 0 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
   if ((reinterpret_cast<uintptr_t>(features) | reinterpret_cast<uintptr_t>(w)) & 15) return SNAP_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(confidence_head_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,

@@ -301,6 +301,55 @@ __global__ __launch_bounds__(256) void sim_bwd_prepare_kernel(float* __restrict_
   if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = red[0];
 }
 
+// add_confidence_query (bev_localizer.py:165-168): sim = relu(fq . fm) * scale * w[b, n].  One wave per
+// (scene, point): rowdot[b, n] = sum_cells dsim * sim (fixed order: a lane's cells ascending, then
+// the DPP wave sum) -- it is both the row's share of the temperature gradient and, divided by
+// w[b, n], the gradient of the weight --, then G = dsim * [sim > 0] * coef[b, n] in place.
+__global__ __launch_bounds__(256) void sim_bwd_prepare_rows_kernel(float* __restrict__ dsim,
+                                                                   const float* __restrict__ sim,
+                                                                   int64_t rows, int XY, int clip,
+                                                                   const float* __restrict__ row_coef,
+                                                                   float* __restrict__ rowdot) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* g = dsim + r * XY;
+  const float* s = sim + r * XY;
+  const float cf = row_coef[r];
+  float acc = 0.f;
+  for (int i = lane; i < XY; i += 64) {
+    const float gv = g[i], sv = s[i];
+    acc += gv * sv;
+    g[i] = (!clip || sv > 0.f) ? gv * cf : 0.f;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) rowdot[r] = acc;
+}
+
+// VJP of layers.masked_softmax over the last axis (layers.py:38-43; an all-false mask acts as
+// all-true): dx = w * (dw - sum_n w dw) on the softmax's support, 0 elsewhere.  One workgroup
+// per row, fixed-order sums.
+__global__ __launch_bounds__(256) void masked_softmax_rows_bwd_kernel(const float* __restrict__ w,
+                                                                      const float* __restrict__ dw,
+                                                                      int N, float* __restrict__ dx) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* wr = w + (int64_t)b * N;
+  const float* dr = dw + (int64_t)b * N;
+  const int seg = (N + 255) / 256;
+  const int i0 = min(t * seg, N), i1 = min(i0 + seg, N);
+  float loc = 0.f;
+  for (int i = i0; i < i1; ++i) loc += wr[i] * dr[i];          // (w = 0 outside the support)
+  red[t] = loc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const float dot = red[0];
+  for (int i = i0; i < i1; ++i) dx[(int64_t)b * N + i] = wr[i] * (dr[i] - dot);
+}
+
 __global__ void pose_table_cells_bwd_kernel(const float* __restrict__ poses, int64_t total,
                                             float cell, float* __restrict__ table) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,6 +430,28 @@ extern "C" int snap_sim_bwd_prepare_f32(float* dsim, const float* sim, int32_t B
   hipLaunchKernelGGL(sim_bwd_prepare_kernel, dim3(num_partial, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), dsim, sim, per_scene, clip_negative, coef,
                      partial);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_sim_bwd_prepare_rows_f32(float* dsim, const float* sim, int32_t B, int32_t Nq,
+                                             int32_t XY, int32_t clip_negative, const float* row_coef,
+                                             float* rowdot, void* stream) {
+  if (!dsim || !sim || !row_coef || !rowdot) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || XY <= 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t rows = (int64_t)B * Nq;
+  hipLaunchKernelGGL(sim_bwd_prepare_rows_kernel, dim3((unsigned)snap_cdiv(rows, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dsim, sim, rows, XY, clip_negative, row_coef, rowdot);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_masked_softmax_rows_bwd_f32(const float* weights, const float* dweights, int32_t B,
+                                                int32_t N, float* dx, void* stream) {
+  if (!weights || !dweights || !dx) return SNAP_ERR_NULL;
+  if (B <= 0 || N <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(masked_softmax_rows_bwd_kernel, dim3((unsigned)B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), weights, dweights, N, dx);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -131,11 +131,17 @@ class BEVLocalizer(base.Module):
     fq, fm = f_p_q.contiguous(), plane_map.features.contiguous()
     clip = bool(cfg.clip_negative_scores)
     weights = row_cdf = None
+    train_w = conf_p is not None and base.needs_grad(fq, fm, temperature, conf_p)
     if conf_p is not None:
-      if base.needs_grad(fq, fm, temperature, conf_p):
-        raise NotImplementedError('add_confidence_query: no backward kernels yet (inference only)')
-      weights, row_cdf = ops.masked_softmax_rows(conf_p.contiguous(), valid_points.contiguous())
-    if base.needs_grad(fq, fm, temperature):
+      if train_w:      # the weights carry gradient back into the confidence head
+        weights, row_cdf = ag.masked_softmax_rows(conf_p, valid_points)
+      else:
+        weights, row_cdf = ops.masked_softmax_rows(conf_p.contiguous(), valid_points.contiguous())
+    if train_w:
+      sim, stats, prob, scale = ag.sim_softmax_weighted(fq, fm, temperature, weights, clip, num_valid,
+                                                        want_prob)
+      weights, row_cdf = weights.detach(), row_cdf.detach()
+    elif base.needs_grad(fq, fm, temperature):
       sim, stats, prob, scale = ag.sim_softmax(fq, fm, temperature, clip, num_valid, want_prob)
     else:
       # exp(temperature): a host scalar (one tiny D2H sync per apply).

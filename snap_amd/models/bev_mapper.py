@@ -328,10 +328,12 @@ class BEVMapper(base.Module):
       # bev_mapper.py:292-295: where(valid, log_sigmoid(Dense(1)(features)), 0)
       head = params['confidence_head']['layers_0']
       if base.needs_grad(plane.features, head['kernel'], head['bias']):
-        raise NotImplementedError('add_confidence: the confidence head has no backward kernel yet')
-      pred['bev_confidence'] = ops.confidence_head(
-          plane.features.contiguous(), plane.valid.contiguous(),
-          head['kernel'].reshape(-1).contiguous(), float(head['bias'].reshape(-1)[0]))
+        pred['bev_confidence'] = ag.confidence_head(plane.features, plane.valid.contiguous(),
+                                                    head['kernel'], head['bias'])
+      else:
+        pred['bev_confidence'] = ops.confidence_head(
+            plane.features.contiguous(), plane.valid.contiguous(),
+            head['kernel'].reshape(-1).contiguous(), head['bias'])       # (bias: a device scalar)
     return pred
 
   default_config = staticmethod(default_configs.bev_mapper)

@@ -119,9 +119,10 @@ class StreetViewEncoder(base.Module):
               max_view_distance=cfg.get('max_view_distance'))
     fused = split = classed = False
     if base.needs_grad(f_images):
-      if not self.default_fusion:
-        raise NotImplementedError('non-default fusion options have no backward kernel yet')
       lift = ag.lift_pool
+      if not self.default_fusion:
+        kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
+                  add_minmax=bool(cfg.fusion_add_minmax))
     else:
       lift = ops.lift_pool
       if xyz.dim() == 5:                     # [B, X, Y, Z, 3]: a voxel grid (traversal hint)
@@ -192,11 +193,23 @@ class StreetViewEncoder(base.Module):
     cfg = self.config
     p = params['depth_mlp']
     n = len(cfg.depth_mlp.layers)
-    if base.needs_grad(f_images, *(p[f'Dense_{i}'][k] for i in range(n) for k in ('kernel', 'bias'))):
-      raise NotImplementedError('depth_mlp fusion has no backward kernels yet')
     cam, Rt = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
     common = dict(K=K, fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
                   max_view_distance=cfg.get('max_view_distance'))
+    if base.needs_grad(f_images, *(p[f'Dense_{i}'][k] for i in range(n) for k in ('kernel', 'bias'))):
+      # training: the same three steps as autograd nodes (the lift passes' VJPs are the
+      # deterministic records / sort / gather kernels; the MLP is the conv engine's)
+      obs, feat, _ = ag.lift_observations(f_images, cam, Rt, xyz_flat, **common)
+      h = obs
+      for i in range(n):
+        d = p[f'Dense_{i}']
+        pro = ops.PRO_RELU if (i == 0 and cfg.depth_mlp.apply_input_activation) else ops.PRO_NONE
+        last = i + 1 == n
+        h = ag.dense(h, d['kernel'], d['bias'], cin=d['kernel'].shape[0], prologue=pro,
+                     relu=not last, residual=feat if last else None)
+      return ag.lift_pool_observations(
+          h, tuple(f_images.shape), cam, Rt, xyz_flat, use_variance=bool(cfg.fusion_use_variance),
+          add_minmax=bool(cfg.fusion_add_minmax), **common)
     obs, feat, _ = ops.lift_observations(f_images, cam, Rt, xyz_flat, **common)
     h = obs
     for i in range(n):

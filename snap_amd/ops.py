@@ -1180,12 +1180,15 @@ def confidence_head(features, valid, kernel, bias):
   [...] (bev_mapper.py:292-295)."""
   lib = _lib.load()
   _f32(features, 'features'); _f32(kernel, 'kernel')
+  if not torch.is_tensor(bias):
+    bias = torch.tensor([float(bias)], dtype=torch.float32, device=features.device)
+  bias = _f32(bias.reshape(-1)[:1].contiguous(), 'bias')      # a device scalar: no host sync
   if valid is not None:
     _mask(valid, 'valid')
   D = features.shape[-1]
   M = features.numel() // D
   out = torch.empty(features.shape[:-1], dtype=torch.float32, device=features.device)
-  st = lib.snap_confidence_head_f32(_p(features), _p(valid), _p(kernel), float(bias), M, D, _p(out),
+  st = lib.snap_confidence_head_f32(_p(features), _p(valid), _p(kernel), _p(bias), M, D, _p(out),
                                     _stream())
   _lib.check(st, 'snap_confidence_head_f32')
   return out

@@ -147,28 +147,40 @@ def colsum(a, rows=None, row_count=None):
   return out
 
 
+def _aligned_ws(nbytes, device):
+  ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+  return ws, ctypes.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
+
+
 def lift_pool_bwd(f_images, cam, Rt, points, dpooled, *, K, fisheye, feature_dim, num_bins,
-                  depth_min_max, max_view_distance=None):
+                  depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
+                  add_minmax=False):
+  """VJP of ``ops.lift_pool`` w.r.t. f_images, every fusion option (the non-default ones on the
+  deterministic form only)."""
   lib = _lib.load()
   _f32(f_images, 'f_images'); _f32(dpooled, 'dpooled')
   B, V, h, w, C = f_images.shape
   N = points.shape[1]
+  default = weighted and use_variance and not add_minmax
   d = _lib.SnapLiftDesc(
-      B, V, h, w, C, feature_dim, num_bins, N, K, int(fisheye), dpooled.shape[-1],
+      B, V, h, w, C, feature_dim, num_bins if weighted else 0, N, K, int(fisheye), dpooled.shape[-1],
       float(depth_min_max[0]), float(depth_min_max[1]),
       -1.0 if max_view_distance is None else float(max_view_distance),
-      1, 1, 0,            # (the VJP exists for the default fusion options only)
+      int(weighted), int(use_variance), int(add_minmax),
   )
   df = torch.empty_like(f_images)
-  wsb = lib.snap_lift_pool_bwd_det_workspace_bytes(ctypes.byref(d)) if DETERMINISTIC_LIFT_BWD else 0
+  wsb = (lib.snap_lift_pool_bwd_det_workspace_bytes(ctypes.byref(d))
+         if (DETERMINISTIC_LIFT_BWD or not default) else 0)
+  if not wsb and not default:
+    raise ValueError('lift_pool_bwd: the non-default fusion options need the deterministic form '
+                     '(<= 8 selected views, <= 32 depth bins)')
   if wsb:
     # records -> stable sort by image pixel -> gather: no atomics, bitwise reproducible
-    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=f_images.device)
-    off = (-ws.data_ptr()) % 256
+    ws, wsp = _aligned_ws(wsb, f_images.device)
     with _region('lift_pool_bwd', 0.0, 4.0 * (f_images.numel() * 2 + dpooled.numel())):
       st = lib.snap_lift_pool_bwd_det_f32(
-          ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(dpooled), _p(df),
-          ctypes.c_void_p(ws.data_ptr() + off), wsb, _stream()
+          ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(dpooled), _p(df), wsp, wsb,
+          _stream()
       )
     _lib.check(st, 'snap_lift_pool_bwd_det_f32')
     return df
@@ -177,6 +189,41 @@ def lift_pool_bwd(f_images, cam, Rt, points, dpooled, *, K, fisheye, feature_dim
         ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(dpooled), _p(df), _stream()
     )
   _lib.check(st, 'snap_lift_pool_bwd_f32')
+  return df
+
+
+def lift_pool_observations_bwd(obs_feat, f_shape, cam, Rt, points, dpooled, *, K, fisheye, feature_dim,
+                               max_view_distance=None, use_variance=True, add_minmax=False):
+  """VJP of ``ops.lift_pool_observations`` w.r.t. the observations [B, N, S, fd]."""
+  lib = _lib.load()
+  _f32(obs_feat, 'obs_feat'); _f32(dpooled, 'dpooled')
+  B, N = points.shape[:2]
+  d = ops._obs_desc(f_shape, N, K, fisheye, feature_dim, max_view_distance, use_variance, add_minmax,
+                    dpooled.shape[-1])
+  dobs = torch.empty_like(obs_feat)
+  with _region('lift_pool_bwd', 0.0, 4.0 * (obs_feat.numel() * 2 + dpooled.numel())):
+    st = lib.snap_lift_pool_observations_bwd_f32(ctypes.byref(d), _p(cam), _p(Rt), _p(points), _p(obs_feat),
+                                                 _p(dpooled), _p(dobs), _stream())
+  _lib.check(st, 'snap_lift_pool_observations_bwd_f32')
+  return dobs
+
+
+def lift_observations_bwd(dobs, f_shape, cam, Rt, points, *, K, fisheye, feature_dim, max_view_distance=None):
+  """VJP of ``ops.lift_observations`` w.r.t. f_images: dobs [B, N, S, fd] = the gradient of the
+  feature part of ``obs`` plus that of ``obs_feat`` (depth and ray carry none) -> [B, V, h, w, fd]."""
+  lib = _lib.load()
+  _f32(dobs, 'dobs')
+  B, N = points.shape[:2]
+  d = ops._obs_desc(f_shape, N, K, fisheye, feature_dim, max_view_distance, True, False, 0)
+  wsb = lib.snap_lift_observations_bwd_workspace_bytes(ctypes.byref(d))
+  if not wsb:
+    raise ValueError('lift_observations_bwd: unsupported shape (> 8 selected views)')
+  ws, wsp = _aligned_ws(wsb, dobs.device)
+  df = torch.empty(tuple(f_shape), dtype=torch.float32, device=dobs.device)
+  with _region('lift_pool_bwd', 0.0, 4.0 * (dobs.numel() + df.numel())):
+    st = lib.snap_lift_observations_bwd_f32(ctypes.byref(d), _p(cam), _p(Rt), _p(points), _p(dobs), _p(df),
+                                            wsp, wsb, _stream())
+  _lib.check(st, 'snap_lift_observations_bwd_f32')
   return df
 
 
@@ -311,3 +358,42 @@ def attention_bwd(qkv, out, dout, lse, scale=None):
                                          B, N, H, D, scale, _stream())
   _lib.check(st, 'snap_attention_bwd_bf16_f32')
   return dqkv
+
+
+def confidence_head_bwd(features, valid, kernel, bias, dconf):
+  """VJP of ``ops.confidence_head``: (d features, d kernel [D], d bias [1])."""
+  lib = _lib.load()
+  _f32(features, 'features'); _f32(kernel, 'kernel'); _f32(bias, 'bias'); _f32(dconf, 'dconf')
+  if valid is not None:
+    _mask(valid, 'valid')
+  D = features.shape[-1]
+  M = features.numel() // D
+  df = torch.empty_like(features)
+  prod = torch.empty((M, D), dtype=torch.float32, device=features.device)
+  dsv = torch.empty((M, 4), dtype=torch.float32, device=features.device)
+  st = lib.snap_confidence_head_bwd_f32(_p(features), _p(valid), _p(kernel), _p(bias), _p(dconf), M, D,
+                                        _p(df), _p(prod), _p(dsv), _stream())
+  _lib.check(st, 'snap_confidence_head_bwd_f32')
+  return df, colsum(prod), colsum(dsv)[:1]
+
+
+def sim_bwd_prepare_rows_(dsim, sim, clip_negative, row_coef):
+  """In place G = dsim * [sim > 0] * row_coef[b, n]; returns rowdot [B, Nq] = sum_cells dsim * sim."""
+  lib = _lib.load()
+  _f32(dsim, 'dsim'); _f32(sim, 'sim'); _f32(row_coef, 'row_coef')
+  B, Nq, X, Y = sim.shape
+  rowdot = torch.empty((B, Nq), dtype=torch.float32, device=sim.device)
+  st = lib.snap_sim_bwd_prepare_rows_f32(_p(dsim), _p(sim), B, Nq, X * Y, int(clip_negative), _p(row_coef),
+                                         _p(rowdot), _stream())
+  _lib.check(st, 'snap_sim_bwd_prepare_rows_f32')
+  return rowdot
+
+
+def masked_softmax_rows_bwd(weights, dweights):
+  lib = _lib.load()
+  _f32(weights, 'weights'); _f32(dweights, 'dweights')
+  B, N = weights.shape
+  dx = torch.empty_like(weights)
+  st = lib.snap_masked_softmax_rows_bwd_f32(_p(weights), _p(dweights), B, N, _p(dx), _stream())
+  _lib.check(st, 'snap_masked_softmax_rows_bwd_f32')
+  return dx

@@ -251,25 +251,19 @@ def test_small_backward_ops():
 
 
 # -- lift / BEV ------------------------------------------------------------------------------
-@pytest.mark.parametrize('K,V', [(0, 3), (2, 4)])
-def test_lift_pool_bwd(K, V):
-  """Reference: torch autograd through a differentiable restatement that takes the
-  projection geometry (taps, weights, visibility) from the numpy oracle."""
-  import test_gpu_kernels as tk
+def _lift_reference(f, cam, Rt, pts, K, fd, nb, opts, obs_override=None):
+  """float64 torch restatement of lift + pool_multiview_features (streetview_encoder.py:69-178) with
+  the projection geometry (taps, weights, visibility) taken from the numpy oracle.  Returns
+  (f as a float64 leaf, observations [N, Kv, C], pooled [N, channels], extras)."""
   from oracle import lift as o_lift
-  fd, nb = 16, 4
-  f, cam, Rt, pts = tk._lift_scene(1, V, 10, 12, fd, nb, 1500, seed=60 + V)
-  kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0))
-  stride = ops.pooled_stride(fd)
-  dpooled = rnd((1, 1500, stride), 61)
-  dpooled[..., 2 * fd + 1:] = 0
-  # torch restatement (float64)
+  weighted, use_var, minmax = opts
+  V = f.shape[1]
   cams = oracle_ops.unpack_cameras(cam, True)
   T = oracle_ops.unpack_transforms(Rt)
-  p2d, vis, depth, _ = o_lift.project_points_to_views(T, cams, pts.numpy())
+  p2d, vis, depth, rays = o_lift.project_points_to_views(T, cams, pts.numpy())
   if K > 0:
     idx, _ = o_lift.view_selection(pts.numpy(), T, vis, K)
-    p2d, vis, depth = (o_lift.gather_batched_observations(a, idx) for a in (p2d, vis, depth))
+    p2d, vis, depth, rays = (o_lift.gather_batched_observations(a, idx) for a in (p2d, vis, depth, rays))
   else:
     idx = np.broadcast_to(np.arange(V), vis.shape).copy()
   fdbl = f.double().requires_grad_(True)
@@ -289,38 +283,125 @@ def test_lift_pool_bwd(K, V):
          + (w0[..., 0] * w1[..., 1])[..., None] * img[vi, i0, j1]
          + (w1[..., 0] * w0[..., 1])[..., None] * img[vi, i1, j0]
          + (w1[..., 0] * w1[..., 1])[..., None] * img[vi, i1, j1])   # [N,Kv,C]
-  feats, scales = val[..., :fd], val[..., fd:]
-  dpt = torch.tensor(depth[0]).double().clamp(1.0, 16.0)
-  tt = torch.log(dpt / 1.0) / math.log(16.0)
-  c = (0.5 + tt * (nb - 1)) - 0.5
-  fl = torch.floor(c)
-  wb = c - fl
-  b0 = fl.long().clamp(0, nb - 1); b1 = (fl.long() + 1).clamp(0, nb - 1)
-  score = (1 - wb) * torch.gather(scales, -1, b0[..., None])[..., 0] + wb * torch.gather(
-      scales, -1, b1[..., None])[..., 0]
   visb = torch.tensor(vis[0])
   anyv = visb.any(-1)
-  sm = torch.where(visb, score, torch.full_like(score, -math.inf))
-  wgt = torch.softmax(torch.where(anyv[:, None], sm, torch.zeros_like(sm)), -1)
-  wgt = torch.where(visb, wgt, torch.zeros_like(wgt))
+  extras = dict(vis=visb, depth=torch.tensor(depth[0]).double(), rays=torch.tensor(rays[0]).double())
+  feats = val[..., :fd] if obs_override is None else obs_override
+  if weighted:
+    scales = val[..., fd:]
+    dpt = extras['depth'].clamp(1.0, 16.0)
+    tt = torch.log(dpt / 1.0) / math.log(16.0)
+    c = (0.5 + tt * (nb - 1)) - 0.5
+    fl = torch.floor(c)
+    wb = c - fl
+    b0 = fl.long().clamp(0, nb - 1); b1 = (fl.long() + 1).clamp(0, nb - 1)
+    score = (1 - wb) * torch.gather(scales, -1, b0[..., None])[..., 0] + wb * torch.gather(
+        scales, -1, b1[..., None])[..., 0]
+    sm = torch.where(visb, score, torch.full_like(score, -math.inf))
+    wgt = torch.softmax(torch.where(anyv[:, None], sm, torch.zeros_like(sm)), -1)
+    wgt = torch.where(visb, wgt, torch.zeros_like(wgt))
+  else:
+    cnt = visb.sum(-1, keepdim=True).clamp(min=1)
+    wgt = visb.double() / cnt
   mean = (wgt[..., None] * feats).sum(1)
-  var = (wgt[..., None] * (feats - mean[:, None]) ** 2).sum(1)
-  smax = torch.where(anyv, sm.max(-1).values, torch.zeros_like(anyv, dtype=torch.float64))
-  pooled = torch.cat([mean, var, smax[:, None]], -1) * anyv[:, None]
-  pooled.backward(dpooled[0, :, : 2 * fd + 1].double())
+  stats = [mean]
+  if use_var:
+    stats.append((wgt[..., None] * (feats - mean[:, None]) ** 2).sum(1))
+  if minmax:
+    big = torch.full_like(feats, math.inf)
+    stats.append(torch.where(visb[..., None], feats, -big).amax(1))
+    stats.append(torch.where(visb[..., None], feats, big).amin(1))
+  if weighted:
+    stats.append(torch.where(anyv, sm.max(-1).values, torch.zeros_like(anyv, dtype=torch.float64))[:, None])
+  pooled = torch.cat(stats, -1)
+  pooled = torch.where(anyv[:, None], pooled, torch.zeros_like(pooled))
+  return fdbl, val, pooled, extras
+
+
+LIFT_BWD_OPTS = [(True, True, False), (False, True, False), (True, False, False), (True, True, True),
+                 (False, False, True)]
+
+
+@pytest.mark.parametrize('opts', LIFT_BWD_OPTS, ids=['default', 'unweighted', 'novar', 'minmax', 'unweighted_novar_minmax'])
+@pytest.mark.parametrize('K,V', [(0, 3), (2, 4)])
+def test_lift_pool_bwd(K, V, opts):
+  """Reference: torch autograd through a differentiable restatement that takes the
+  projection geometry (taps, weights, visibility) from the numpy oracle.  Every option of
+  pool_multiview_features (weighted / use_variance / add_minmax)."""
+  import test_gpu_kernels as tk
+  weighted, use_var, minmax = opts
+  fd, nb = 16, 4
+  f, cam, Rt, pts = tk._lift_scene(1, V, 10, 12, fd, nb, 1500, seed=60 + V)
+  if not weighted:
+    f = f[..., :fd].contiguous()
+  if minmax:
+    f = torch.round(f * 4) / 4            # ties among the views' observations do occur
+  kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0),
+            weighted=weighted, use_variance=use_var, add_minmax=minmax)
+  nch = ops.pooled_channels(fd, weighted, use_var, minmax)
+  stride = ops.pooled_stride(fd, weighted, use_var, minmax)
+  dpooled = rnd((1, 1500, stride), 61)
+  dpooled[..., nch:] = 0
+  fdbl, _, pooled, _ = _lift_reference(f, cam, Rt, pts, K, fd, nb, opts)
+  pooled.backward(dpooled[0, :, :nch].double())
   ref = fdbl.grad.float()
+  tol = 2e-4 * float(ref.abs().max()) + 1e-6
   # both forms of the VJP: the deterministic one (records -> stable sort by pixel -> gather; the
   # default) must also be BITWISE reproducible; the scatter form uses float atomics
   got = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
-  helpers.report('lift bwd (deterministic)', got, ref, atol=2e-4 * float(ref.abs().max()) + 1e-6)
+  helpers.report('lift bwd (deterministic)', got, ref, atol=tol)
   for _ in range(3):
     assert torch.equal(ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw), got)
-  prev, ops_bwd.DETERMINISTIC_LIFT_BWD = ops_bwd.DETERMINISTIC_LIFT_BWD, False
-  try:
-    got_s = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
-  finally:
-    ops_bwd.DETERMINISTIC_LIFT_BWD = prev
-  helpers.report('lift bwd (scatter)', got_s, ref, atol=2e-4 * float(ref.abs().max()) + 1e-6)
+  if opts == (True, True, False):
+    prev, ops_bwd.DETERMINISTIC_LIFT_BWD = ops_bwd.DETERMINISTIC_LIFT_BWD, False
+    try:
+      got_s = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
+    finally:
+      ops_bwd.DETERMINISTIC_LIFT_BWD = prev
+    helpers.report('lift bwd (scatter)', got_s, ref, atol=tol)
+
+
+@pytest.mark.parametrize('use_var,minmax', [(True, False), (False, True)])
+@pytest.mark.parametrize('K,V', [(0, 3), (2, 4)])
+def test_depth_mlp_fusion_bwd(K, V, use_var, minmax):
+  """The depth_mlp fusion (streetview_encoder.py:263-267) as autograd nodes: observations ->
+  per-observation MLP (+ residual) -> pooling; gradients w.r.t. the image features and the MLP
+  parameters against a float64 torch restatement."""
+  import test_gpu_kernels as tk
+  from snap_amd import autograd as ag
+  fd = 16
+  f, cam, Rt, pts = tk._lift_scene(1, V, 10, 12, fd, 4, 1200, seed=80 + V)
+  f = f[..., :fd].contiguous()
+  w0 = rnd((fd + 4, 32), 81, 1 / math.sqrt(fd + 4)); b0 = rnd((32,), 82, 0.1)
+  w1 = rnd((32, fd), 83, 1 / math.sqrt(32.0)); b1 = rnd((fd,), 84, 0.1)
+  nch = ops.pooled_channels(fd, False, use_var, minmax)
+  stride = ops.pooled_stride(fd, False, use_var, minmax)
+  dpooled = rnd((1, 1200, stride), 85)
+  dpooled[..., nch:] = 0
+  # reference
+  fdbl, val, _, ex = _lift_reference(f, cam, Rt, pts, K, fd, 0, (False, use_var, minmax))
+  logd = torch.log10(ex['depth'].clamp(0.1, 100))
+  rays = torch.where(ex['vis'][..., None], ex['rays'], torch.zeros_like(ex['rays']))
+  x = torch.cat([val, logd[..., None], rays], -1)
+  W = [t.double().requires_grad_(True) for t in (w0, b0, w1, b1)]
+  corrected = val + torch.relu(x @ W[0] + W[1]) @ W[2] + W[3]
+  _, _, pooled, _ = _lift_reference(f, cam, Rt, pts, K, fd, 0, (False, use_var, minmax), obs_override=corrected)
+  pooled.backward(dpooled[0, :, :nch].double())
+  # the autograd nodes
+  fg = G(f).requires_grad_(True)
+  Wg = [G(t).requires_grad_(True) for t in (w0, b0, w1, b1)]
+  common = dict(K=K, fisheye=True, feature_dim=fd)
+  obs, feat, _ = ag.lift_observations(fg, G(cam), G(Rt), G(pts), **common)
+  hdn = ag.dense(obs, Wg[0], Wg[1], relu=True)
+  out = ag.dense(hdn, Wg[2], Wg[3], residual=feat)
+  pg, _ = ag.lift_pool_observations(out, tuple(f.shape), G(cam), G(Rt), G(pts), use_variance=use_var,
+                                    add_minmax=minmax, **common)
+  pg.backward(G(dpooled))
+  ref = fdbl.grad.float()
+  helpers.report('depth_mlp d f_images', fg.grad, ref, atol=3e-4 * float(ref.abs().max()) + 1e-6)
+  for name, got, want in zip(('w0', 'b0', 'w1', 'b1'), Wg, W):
+    helpers.report(f'depth_mlp d {name}', got.grad, want.grad.float(),
+                   atol=3e-4 * float(want.grad.abs().max()) + 1e-6)
 
 
 @pytest.mark.parametrize('pooling', ['max', 'sum', 'mean'])
@@ -429,6 +510,49 @@ def test_pose_score_bwd(mask_oob):
     finally:
       ops_bwd.DETERMINISTIC_POSE_BWD = prev
     helpers.report('pose_score bwd (float atomics)', flt, sd.grad.float(), atol=2e-4, rtol=1e-4)
+
+
+def test_confidence_head_bwd():
+  """VJP of where(valid, log_sigmoid(f . w + b), 0) (bev_mapper.py:154-157,292-295)."""
+  from snap_amd import autograd as ag
+  M, D = 700, 64
+  f = rnd((M, D), 300); w = rnd((D, 1), 301, 0.3); b = torch.tensor([0.2])
+  valid = torch.rand(M, generator=torch.Generator().manual_seed(302)) > 0.2
+  g = rnd((M,), 303)
+  fd, wd, bd = (t.double().requires_grad_(True) for t in (f, w, b))
+  out = torch.where(valid, torch.nn.functional.logsigmoid((fd @ wd)[:, 0] + bd[0]), torch.zeros(M, dtype=torch.float64))
+  out.backward(g.double())
+  fg, wg, bg = (G(t).requires_grad_(True) for t in (f, w, b))
+  ag.confidence_head(fg, G(valid), wg, bg).backward(G(g))
+  helpers.report('confidence d features', fg.grad, fd.grad.float(), atol=1e-5)
+  helpers.report('confidence d kernel', wg.grad, wd.grad.float(), atol=2e-4)
+  helpers.report('confidence d bias', bg.grad, bd.grad.float(), atol=2e-4)
+
+
+def test_similarity_with_confidence_weights_bwd():
+  """add_confidence_query (bev_localizer.py:165-168): sim = relu(fq . fm) exp(T) w[b, n] with
+  w = layers.masked_softmax(confidence, valid points): gradients of fq, fm, T and the confidence."""
+  from snap_amd import autograd as ag
+  B, Nq, X, Y, Dm = 2, 50, 12, 16, 32
+  fq = F.normalize(rnd((B, Nq, Dm), 310), dim=-1)
+  fm = F.normalize(rnd((B, X, Y, Dm), 311), dim=-1)
+  conf = rnd((B, Nq), 312)
+  valid = torch.rand((B, Nq), generator=torch.Generator().manual_seed(313)) > 0.2
+  nv = valid.sum(-1).float()
+  temp = torch.tensor(2.0)
+  dsim = rnd((B, Nq, X, Y), 314)
+  fqd, fmd, td, cd = (t.double().requires_grad_(True) for t in (fq, fm, temp, conf))
+  wref = torch.softmax(torch.where(valid, cd, torch.full_like(cd, -math.inf)), -1)
+  simr = torch.relu(torch.einsum('bnd,bxyd->bnxy', fqd, fmd)) * torch.exp(td) * wref[..., None, None]
+  simr.backward(dsim.double())
+  fqg, fmg, tg, cg = (G(t).requires_grad_(True) for t in (fq, fm, temp, conf))
+  wg, _ = ag.masked_softmax_rows(cg, G(valid))
+  sim, _, _, _ = ag.sim_softmax_weighted(fqg, fmg, tg, wg, True, G(nv))
+  helpers.report('weighted sim', sim, simr.detach().float(), atol=1e-6, rtol=1e-4)
+  sim.backward(G(dsim))
+  for name, got, want in (('fq', fqg, fqd), ('fm', fmg, fmd), ('temperature', tg, td), ('confidence', cg, cd)):
+    helpers.report(f'weighted sim d {name}', got.grad, want.grad.float(),
+                   atol=3e-4 * float(want.grad.abs().max()) + 1e-7)
 
 
 def test_similarity_bwd():

@@ -87,6 +87,51 @@ def test_end_to_end_gradients_match_finite_differences():
   assert not bad, bad
 
 
+@pytest.mark.parametrize('variant', ['confidence', 'unweighted_minmax', 'depth_mlp'])
+def test_train_through_the_optional_branches(variant):
+  """The reference differentiates through everything (trainer.py:223-234): the query-confidence
+  weighting with its Dense(1) head (bev_localizer.py:165-168, bev_mapper.py:154-157,292-295), the
+  non-default multi-view fusion options and the depth_mlp fusion (streetview_encoder.py:150-172,
+  263-267) train too -- every gradient finite, the optional branch's own parameters live, Adam
+  moves the loss."""
+  from snap_amd.configs import defaults
+  dev = torch.device('cuda')
+  cfg = helpers.tiny_localizer_config(num_pose_samples=48, retries=2)
+  sv = cfg.bev_mapper.streetview_encoder
+  live = []
+  if variant == 'confidence':
+    cfg.add_confidence_query = True
+    cfg.bev_mapper.add_confidence = True
+    live = ['bev_mapper/confidence_head/layers_0/kernel', 'bev_mapper/confidence_head/layers_0/bias']
+  elif variant == 'unweighted_minmax':
+    sv.do_weighted_fusion = False
+    sv.fusion_use_variance = False
+    sv.fusion_add_minmax = True
+  else:
+    sv.do_weighted_fusion = False
+    sv.depth_mlp = defaults.mlp()
+    sv.depth_mlp.layers = (32, sv.feature_dim)
+    live = ['bev_mapper/streetview_encoder/depth_mlp/Dense_0/kernel',
+            'bev_mapper/streetview_encoder/depth_mlp/Dense_1/bias']
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  model = models.get_model('bev_localizer')(cfg, meta)
+  params = helpers.params_to_device(model.flax_model.init(4, device='cpu')['params'], dev)
+  batch = helpers.batch_to_device(synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=9), dev)
+  state = trainer.TrainState.create(params, rng=0)
+  lr_fn = trainer.make_lr_fn(2e-3, 100)
+  names = [n for n, _ in trainer.flatten_params(params)]
+  losses = []
+  for i in range(5):
+    state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn, max_grad_norm=10.0)
+    assert logs['is_finite'] and np.isfinite(logs['loss']) and logs['l2_grads'] > 0
+    losses.append(logs['loss'])
+    if i == 0:
+      moments = dict(zip(names, state.m))
+      for n in live:
+        assert float(moments[n].abs().max()) > 0, f'no gradient reaches {n}'
+  assert losses[-1] < losses[0], losses
+
+
 def test_train_step_updates_and_decreases_loss():
   model, params, batch = _setup(seed=2)
   before = copy.deepcopy(params)
