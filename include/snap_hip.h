@@ -135,6 +135,9 @@ typedef struct SnapConvExtras {
   int32_t tune_flags;         /* SNAP_TUNE_*: A/B switches for tests and tuning tools (0 = defaults) */
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
+#define SNAP_TUNE_NO_RS 2     /* split engine: the tiled body also where the row-stationary 1x1 kernel applies */
+#define SNAP_TUNE_RS_FORCE 4   /* split engine: the row-stationary kernel also below its row-count threshold (tests) */
+#define SNAP_TUNE_RS_NSPLIT_SHIFT 4   /* bits 4..7: row-stationary kernel, forced column split (0 = automatic) */
 #define SNAP_TUNE_ABLATE_SHIFT 8   /* bits 8..: timing-only ablations of the K loop (WRONG results) */
 /* Pre-split launches (extras->x_presplit): row tile, GroupNorm partial-sum bytes and split-K
  * workspace bytes of the launch `desc` + `ps_tile` describes (the counterparts of
@@ -273,6 +276,12 @@ int snap_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, voi
 size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc);
 size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc);
 int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc);   /* row-tile height the launch uses */
+/* 1 when a split-bf16 launch (w_split_parts parts, no row lists) of this descriptor runs on the
+ * row-stationary 1x1 kernel (conv_rs.hip: the bottleneck units' closing / projection convolution,
+ * snap/models/resnet.py:112-132) instead of the tiled body; same output bits either way
+ * (tune_flags as in SnapConvExtras: SNAP_TUNE_NO_RS forces the tiled body, SNAP_TUNE_RS_FORCE the
+ * kernel below its row-count threshold).  For profiling labels and tests. */
+int32_t snap_conv2d_row_stationary(const SnapConvDesc* desc, int32_t parts, int32_t tune_flags);
 
 /* mu / sc (/ rstd) [N, C] from a conv launch's gn_partial.  tile_rows =
  * snap_conv2d_tile_rows(desc of that launch); HW = Ho*Wo of its output. */

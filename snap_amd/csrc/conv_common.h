@@ -44,6 +44,9 @@ struct ConvArgs {
   int ablate;  // tuning-only (SnapConvExtras.tune_flags >> 8): bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
   int bk;      // f32 engine: K-slab depth of the large tiles (16 | 32)
   int no_halo; // split engine: 1 = im2col body for every 3x3
+  int no_rs;   // split engine: 1 = tiled body also where conv_rs.hip applies
+  int rs_nsplit;  // ... forced column split of conv_rs.hip (0 = automatic)
+  int rs_force;   // ... conv_rs.hip also below its row-count threshold (tests)
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])
   int cin8;            // ... channel count rounded up to 8
   const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
@@ -61,6 +64,10 @@ int launch_split_root(ConvArgs a, int parts, hipStream_t s);
 // pre-split engine (conv_ps.hip): a.x_ps = the input already normalised and split in two bf16
 // parts (snap_gn_norm_split_f32 / snap_presplit_f32), a.w_bf16 = the split weight image (parts = 2)
 int launch_ps(ConvArgs a, hipStream_t s);
+// row-stationary 1 x 1 kernel (conv_rs.hip): Cin = 64 / 128 / 256 -> Cout >= 256, GroupNorm + ReLU
+// prologue, optional residual; bit-identical to launch_split(a, 2, s) where it applies
+bool rs_applicable(const ConvArgs& a, int parts);
+int launch_rs(ConvArgs a, hipStream_t s);
 struct PsTile { int bm, bn, nt; };
 PsTile ps_choose_tile(int64_t M, int64_t N, int force);
 int ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t kpartial_bytes);

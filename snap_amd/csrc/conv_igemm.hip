@@ -588,6 +588,16 @@ extern "C" int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc) {
   return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint).bm;
 }
 
+extern "C" int32_t snap_conv2d_row_stationary(const SnapConvDesc* desc, int32_t parts, int32_t tune_flags) {
+  if (!desc) return 0;
+  ConvArgs a{};
+  a.d = *desc;
+  a.M = (int)((int64_t)desc->N * desc->Ho * desc->Wo);
+  a.no_rs = (tune_flags & SNAP_TUNE_NO_RS) ? 1 : 0;
+  a.rs_force = (tune_flags & SNAP_TUNE_RS_FORCE) ? 1 : 0;
+  return snapconv::rs_applicable(a, parts) ? 1 : 0;
+}
+
 // ---- pre-split launches (conv_ps.hip) ---------------------------------------------------------
 extern "C" int32_t snap_conv2d_presplit_tile_rows(const SnapConvDesc* desc, int32_t ps_tile) {
   if (!desc) return 0;
@@ -692,6 +702,9 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.ablate = ex ? (ex->tune_flags >> SNAP_TUNE_ABLATE_SHIFT) : 0;   // timing experiments only (wrong results)
   a.bk = (ex && ex->bk_hint == 32) ? 32 : 16;
   a.no_halo = (ex && (ex->tune_flags & SNAP_TUNE_NO_HALO)) ? 1 : 0;
+  a.no_rs = (ex && (ex->tune_flags & SNAP_TUNE_NO_RS)) ? 1 : 0;
+  a.rs_nsplit = ex ? (ex->tune_flags >> SNAP_TUNE_RS_NSPLIT_SHIFT) & 15 : 0;
+  a.rs_force = (ex && (ex->tune_flags & SNAP_TUNE_RS_FORCE)) ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // bf16-operand engine (training precision): needs the packed bf16 weights and the float4
   // loader's alignment; anything else runs on the (more precise) f32 engine below.

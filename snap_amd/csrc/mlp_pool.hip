@@ -84,16 +84,33 @@ __device__ __forceinline__ void atomic_max_f32(float* p, float v) {
     atomicMax(reinterpret_cast<int*>(p), (int)u);
 }
 
-template <int N0, bool RELU_IN, bool XSPLIT>
-__global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
-  constexpr int BM = 128, N1 = 128;
+#ifndef SNAP_MLP_POOL_PAIRS
+#define SNAP_MLP_POOL_PAIRS 1      // 1: GEMM1 takes TWO k-steps per barrier (four 16 KB ring slots); 0: one (eight 8 KB slots)
+#endif
+// NT = 256: 128 rows per workgroup, two workgroups per CU.  NT = 512: 256 rows (eight waves), one
+// workgroup per CU -- the same 8 waves per CU, and W0 / W1 (426 KB per workgroup, 25 GB per C2 step
+// at 128 rows) stream from L2 once per 256 rows.  Measured at C2 (scripts/gpu_mlp_nt.sh, round 3):
+// 3.64 ms per step against 3.30 ms at NT = 256 -- halving the weight stream buys nothing, eight
+// waves behind ONE barrier chain lose more than two independent workgroups of four: the kernel is
+// bound by its phase structure, not by the L2 -> LDS stream.  NT = 256 stays.
+#ifndef SNAP_MLP_POOL_NT
+#define SNAP_MLP_POOL_NT 256
+#endif
+template <int N0, bool RELU_IN, bool XSPLIT, int NT>
+__global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
+  constexpr int BM = NT / 2, N1 = 128;
+  constexpr int RPP = NT / 4;                                 // rows staged per pass (4 threads per row)
   constexpr int T0 = N0 / 32, T1 = N1 / 32;
-  constexpr int A_PART = BM * 32, A_ST = 2 * A_PART;          // 8 KB per stage
+  constexpr int A_PART = BM * 32, A_ST = 2 * A_PART;          // 8 KB per stage at 128 rows
   constexpr int B0_ST = (N0 / 128) * 8192;                    // 16 KB per stage at N0 = 256
   constexpr int kB0 = 2 * A_ST;
-  constexpr int kBias = 65536;                                // b0 [N0] | b1 [N1] behind the 64 KB
-  static_assert(kB0 + 2 * B0_ST <= kBias, "GEMM0 stages overlap the bias table");
-  __shared__ __attribute__((aligned(16))) float smem[16384 + N0 + N1];   // 65.5 KB (two per CU)
+  // [GEMM0 stages | W1 ring] share the front of the buffer with the [BM][128] f32 tile of the max
+  // scan; 128 rows: the ring lies over the GEMM0 stages (64 KB in all), 256 rows: behind them
+  constexpr int kRing = NT == 256 ? 0 : 65536;
+  constexpr int kBias = NT == 256 ? 65536 : 131072;           // b0 [N0] | b1 [N1] behind
+  static_assert(kB0 + 2 * B0_ST <= 65536, "GEMM0 stages overlap the ring / the bias table");
+  static_assert(BM * N1 * 4 <= kBias, "scan tile overlaps the bias table");
+  __shared__ __attribute__((aligned(16))) float smem[kBias / 4 + N0 + N1];   // 65.5 KB (two per CU) / 129.5 KB
   char* const sm = reinterpret_cast<char*>(smem);
   float* const bias0 = reinterpret_cast<float*>(sm + kBias);
   float* const bias1 = bias0 + N0;
@@ -106,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   const int m0 = blockIdx.x * BM;
   if (m0 >= Meff) return;
 
-  for (int i = tid; i < N0 + N1; i += 256)
+  for (int i = tid; i < N0 + N1; i += NT)
     bias0[i] = i < N0 ? (i < a.H ? a.b0[i] : 0.f) : (i - N0 < a.D ? a.b1[i - N0] : 0.f);
 
   // ---- GEMM0: A staging as conv_split_body (4 threads per row, 2 rows per thread) --------------
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   bool r_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int m = m0 + (tid >> 2) + 64 * i;
+    const int m = m0 + (tid >> 2) + RPP * i;
     r_ok[i] = m < Meff;
     r_px[i] = a.x + (int64_t)a.rows[r_ok[i] ? m : m0] * a.x_stride;
   }
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
     if (SNAP_MLP_POOL_ABLATE & 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = (tid >> 2) + 64 * i;
+      const int row = (tid >> 2) + RPP * i;
       f32x4 v = xa[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -156,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
     }
   };
   // W0 slab s: per column tile of 128 one contiguous 8 KB block [part][column][32 B]
-  constexpr int B0_PIECES = B0_ST / 16 / 256;
+  constexpr int B0_PIECES = B0_ST / 16 / NT;
   auto issue_b0 = [&](int buf, int s) {
 #pragma unroll
     for (int p = 0; p < B0_PIECES; ++p) {
-      const int slot = tid + 256 * p;
+      const int slot = tid + NT * p;
       const int j = slot >> 9;
       const char* src = a.w0 + ((int64_t)j * a.ctiles0 + s) * 8192 + (slot & 511) * 16;
       __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
@@ -173,22 +190,21 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   // seven k-steps are kept in flight; slots 6, 7 lie behind the GEMM0 stages: k-steps 0 and 1
   // travel while GEMM0 runs.
   auto issue_b1 = [&](int ks) {
+    static_assert(SNAP_MLP_POOL_PAIRS || NT == 256, "the one-k-step ring is the 256-thread layout");
     const char* src = a.w1 + (int64_t)ks * 8192 + tid * 16;
     char* dst = sm + ((ks + 6) & 7) * 8192 + tid * 16;
     __builtin_amdgcn_global_load_lds((cglobal_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + 4096), (lds_void_t*)(dst + 4096), 16, 0, 0);
   };
-#ifndef SNAP_MLP_POOL_PAIRS
-#define SNAP_MLP_POOL_PAIRS 1      // 1: GEMM1 takes TWO k-steps per barrier (four 16 KB ring slots); 0: one (eight 8 KB slots)
-#endif
   // pair p = k-steps 2p, 2p + 1 (16 KB) -> slot (p + 3) & 3 of a four-slot ring over the same 64 KB:
   // pair 0 lands behind the GEMM0 stages (it travels while GEMM0 runs), as k-steps 0 and 1 did
+  constexpr int PP = 16384 / 16 / NT;                             // DMA instructions per thread and pair
   auto issue_b1_pair = [&](int p) {
     const char* src = a.w1 + (int64_t)p * 16384 + tid * 16;
-    char* dst = sm + ((p + 3) & 3) * 16384 + tid * 16;
+    char* dst = sm + kRing + ((p + 3) & 3) * 16384 + tid * 16;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + 4096 * q), (lds_void_t*)(dst + 4096 * q), 16, 0, 0);
+    for (int q = 0; q < PP; ++q)
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + NT * 16 * q), (lds_void_t*)(dst + NT * 16 * q), 16, 0, 0);
   };
   if (!(SNAP_MLP_POOL_ABLATE & 4)) {
     if (SNAP_MLP_POOL_PAIRS) {
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
   const char* xs_px[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int row = (tid >> 2) + 64 * i;
+    const int row = (tid >> 2) + RPP * i;
     const int c = (tid & 3) ^ ((row >> 1) & 3);
     xs_px[i] = r_ok[i] ? reinterpret_cast<const char*>(r_px[i]) + c * 16
                        : reinterpret_cast<const char*>(kZeroChunk);
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((cglobal_void_t*)(xs_px[i] + (r_ok[i] ? s_ * 64 : 0)),
-                                       (lds_void_t*)(sm + buf * A_ST + (tid + 256 * i) * 16), 16, 0, 0);
+                                       (lds_void_t*)(sm + buf * A_ST + (tid + NT * i) * 16), 16, 0, 0);
   };
   const int s_first = a.skip_lo > 0 ? 0 : a.skip_n;
   if constexpr (XSPLIT) {
@@ -346,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
       if (pr >= 1) {
         const int younger = min(pr + 2, npairs - 1) - pr;
         switch (younger) {
-          case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-          case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory"); break;
           default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
       }
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_pool_kernel(const MlpPoolArgs a) 
       if (pr >= 1 && pr + 3 < npairs) issue_b1_pair(pr + 3);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        const char* ws = sm + ((pr + 3) & 3) * 16384 + sub * 8192 + w_off;
+        const char* ws = sm + kRing + ((pr + 3) & 3) * 16384 + sub * 8192 + w_off;
         bf16x8 h_hi, h_lo;
         __builtin_memcpy(&h_hi, &f_hi[pr][sub], 16);
         __builtin_memcpy(&h_lo, &f_lo[pr][sub], 16);
@@ -512,15 +528,16 @@ static int mlp2_pool_check(const float* x, int64_t M, int32_t Cin, int32_t x_str
 }
 
 static void mlp2_pool_launch(const MlpPoolArgs& a, int relu_in, int x_split, hipStream_t s) {
-  const dim3 grid((unsigned)snap_cdiv(a.M, 128));
+  constexpr int NT = SNAP_MLP_POOL_NT;
+  const dim3 grid((unsigned)snap_cdiv(a.M, NT / 2));
   if (a.H <= 128) {
-    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true>), grid, dim3(256), 0, s, a);
-    else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<128, true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mlp2_pool_kernel<128, false, false>), grid, dim3(256), 0, s, a);
+    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true, NT>), grid, dim3(NT), 0, s, a);
+    else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<128, true, false, NT>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((mlp2_pool_kernel<128, false, false, NT>), grid, dim3(NT), 0, s, a);
   } else {
-    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<256, false, true>), grid, dim3(256), 0, s, a);
-    else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<256, true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mlp2_pool_kernel<256, false, false>), grid, dim3(256), 0, s, a);
+    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<256, false, true, NT>), grid, dim3(NT), 0, s, a);
+    else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<256, true, false, NT>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((mlp2_pool_kernel<256, false, false, NT>), grid, dim3(NT), 0, s, a);
   }
 }
 

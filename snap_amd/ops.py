@@ -195,6 +195,9 @@ USE_PRESPLIT = False
 CONV_TILE = None
 CONV_BK = None
 CONV_NO_HALO = False
+CONV_NO_RS = False      # tools / tests: the tiled body also where the row-stationary 1x1 kernel applies
+CONV_RS_NSPLIT = 0      # tools: forced column split of the row-stationary kernel (0 = automatic)
+CONV_RS_FORCE = False   # tests: the row-stationary kernel also below its row-count threshold
 CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
 USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
 PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
@@ -240,6 +243,10 @@ def presplit(x):
   _lib.check(st, 'snap_presplit_f32')
   shape = tuple(x.shape) if x.dim() == 4 else (1,) * (4 - x.dim()) + tuple(x.shape)
   return PreSplit(out, shape)
+
+
+def _rs_tune_flags():
+  return 2 * int(bool(CONV_NO_RS)) | 4 * int(bool(CONV_RS_FORCE))
 
 
 def conv2d(
@@ -399,11 +406,11 @@ def conv2d(
       ex.x_presplit = 1
       ex.ps_tile = pst
       ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
-  if CONV_BK or CONV_NO_HALO or CONV_ABLATE:
+  if CONV_BK or CONV_NO_HALO or CONV_NO_RS or CONV_RS_NSPLIT or CONV_RS_FORCE or CONV_ABLATE:
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.bk_hint = int(CONV_BK or 0)
-    ex.tune_flags = int(bool(CONV_NO_HALO)) | (int(CONV_ABLATE) << 8)
+    ex.tune_flags = int(bool(CONV_NO_HALO)) | _rs_tune_flags() | ((int(CONV_RS_NSPLIT) & 15) << 4) | (int(CONV_ABLATE) << 8)
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -412,9 +419,12 @@ def conv2d(
   else:  # resolved after the sync: only the listed rows are multiplied / moved
     flops = lambda: kflops * int(row_count.item())
     nbytes = lambda: 4.0 * (int(row_count.item()) * (Cin + Cout) + w.numel())
+  rs = (not ps and math == 'bf16x3' and KH == 1 and not CONV_NO_RS and rows_in is None
+        and rows_out is None and row_count is None
+        and bool(lib.snap_conv2d_row_stationary(ctypes.byref(d), 2, _rs_tune_flags())))
   with _region(
       family, flops, nbytes,
-      lambda: f'{"PS_" if ps else ""}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
+      lambda: f'{"PS_" if ps else "RS_" if rs else ""}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
               f'_s{stride}_p{prologue}_e{epi}',
   ):
     st = lib.snap_conv2d_nhwc_ex_f32(

@@ -1,0 +1,133 @@
+"""`-m gpu` tests of the row-stationary 1 x 1 kernel (conv_rs.hip).
+
+It multiplies exactly the operands the tiled split engine (conv_split.hip) builds -- same
+GroupNorm arithmetic, same split, same slab order, same product order per accumulator, residual
+added after the sum -- so against that engine (``ops.CONV_NO_RS = True``) the OUTPUT is compared
+bit for bit; the GroupNorm statistics it emits are summed in another order and are compared with
+the stand-alone statistics pass and the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import oracle_ops
+from snap_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+DEV = helpers.DEVICE
+TOL = 2.5e-4
+
+
+def rnd(shape, seed, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return torch.randn(shape, generator=g) * scale
+
+
+@pytest.fixture(autouse=True)
+def _engine():
+  prev = ops.MATMUL_PRECISION
+  ops.MATMUL_PRECISION = 'bf16x3'
+  prev_tile = ops.CONV_TILE
+  ops.CONV_TILE = '128x128'     # small test shapes: the 128-row tiles the big layers get by themselves
+  ops.CONV_RS_FORCE = True      # ... and the kernel below its row-count threshold
+  yield
+  ops.MATMUL_PRECISION = prev
+  ops.CONV_TILE = prev_tile
+  ops.CONV_RS_FORCE = False
+  ops.CONV_NO_RS = False
+
+
+def _layer(N, H, W, Cin, Cout, seed, residual):
+  x = rnd((N, H, W, Cin), seed)
+  w = rnd((1, 1, Cin, Cout), seed + 1, 1 / np.sqrt(Cin))
+  res = rnd((N, H, W, Cout), seed + 2) if residual else None
+  g_in = rnd((Cin,), seed + 3) * 0.3 + 1
+  b_in = rnd((Cin,), seed + 4) * 0.3
+  return x, w, res, g_in, b_in
+
+
+def _takes_rs(N, H, W, Cin, Cout, residual):
+  from snap_amd import _lib
+  import ctypes
+  d = _lib.SnapConvDesc(N=N, H=H, W=W, Cin=Cin, Cin_stride=Cin, KH=1, KW=1, stride=1, pad_t=0, pad_l=0,
+                        Ho=H, Wo=W, Cout=Cout, Cout_stride=Cout, prologue=ops.PRO_GN_RELU,
+                        epilogue=ops.EPI_RESIDUAL if residual else 0, in_scale=1.0, in_shift=0.0,
+                        tile_hint=128128)
+  return bool(_lib.load().snap_conv2d_row_stationary(ctypes.byref(d), 2, ops._rs_tune_flags()))
+
+
+def _run(x, w, res, g_in, b_in, emit, no_rs, relu=False):
+  xd = x.to(DEV)
+  mu, sc = ops.group_norm_stats(xd, g_in.to(DEV))
+  ops.CONV_NO_RS = no_rs
+  ops.USE_SPLITK = False      # (the tiled engine would split K = 256 on these small M: another sum order)
+  try:
+    y = ops.conv2d(xd, w.to(DEV), prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)),
+                   residual=None if res is None else res.to(DEV), relu=relu, emit_gn_stats=emit)
+  finally:
+    ops.CONV_NO_RS = False
+    ops.USE_SPLITK = True
+  return y
+
+
+# (N, H, W, Cin, Cout, residual): row tiles that straddle images, a ragged last tile, one / several
+# column tiles per workgroup, every Cin the kernel takes
+CASES = [
+    (3, 20, 23, 64, 256, True),
+    (2, 31, 29, 64, 512, False),
+    (5, 16, 17, 128, 512, True),
+    (2, 40, 37, 128, 256, False),
+    (3, 23, 17, 256, 1024, True),
+    (1, 70, 66, 256, 512, False),
+    (40, 34, 34, 256, 1024, True),       # the C2 stage-3 expansion, full size
+]
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,residual', CASES)
+@pytest.mark.parametrize('emit', [None, 'raw', 'both'])
+def test_row_stationary_equals_the_tiled_engine(N, H, W, Cin, Cout, residual, emit):
+  if emit is not None and N == 40:
+    pytest.skip('one statistics variant at full size is enough')
+  assert _takes_rs(N, H, W, Cin, Cout, residual)
+  layer = _layer(N, H, W, Cin, Cout, 1000 + Cin + Cout, residual)
+  y_rs = _run(*layer, emit, no_rs=False)
+  y_t = _run(*layer, emit, no_rs=True)
+  assert torch.equal(y_rs, y_t), float((y_rs - y_t).abs().max())
+  if emit is None:
+    return
+  assert hasattr(y_rs, '_snap_gn_partial')
+  if emit == 'both':                    # (every shape: the tiled engine only at 128 x 128 tiles)
+    assert hasattr(y_rs, '_snap_gn_partial_relu')
+  gamma = rnd((Cout,), 7) * 0.3 + 1
+  for relu_first in ((False, True) if emit == 'both' else (False,)):
+    mu_f, sc_f = ops.group_norm_stats(y_rs, gamma.to(DEV), relu_first=relu_first)
+    mu_w, sc_w = oracle_ops.group_norm_stats(y_rs.cpu(), gamma, relu_first=relu_first)
+    helpers.report(f'rs stats mu relu_first={relu_first}', mu_f, mu_w, atol=1e-5, rtol=1e-5)
+    helpers.report(f'rs stats sc relu_first={relu_first}', sc_f, sc_w, atol=1e-5, rtol=5e-5)
+
+
+def test_row_stationary_against_the_oracle_and_relu_epilogue():
+  x, w, res, g_in, b_in = _layer(2, 19, 21, 128, 512, 77, True)
+  y = _run(x, w, res, g_in, b_in, None, no_rs=False, relu=True)
+  mu, sc = oracle_ops.group_norm_stats(x, g_in)
+  want = oracle_ops.conv2d(x, w, prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in), residual=res, relu=True)
+  helpers.report('rs conv vs oracle', y, want, atol=TOL * float(want.abs().max()))
+  assert float(y.min()) >= 0
+
+
+def test_shapes_outside_the_kernel_take_the_tiled_engine():
+  """Cin = 512 / a bias / a stride: the dispatcher leaves them alone (same bits with the switch)."""
+  assert not _takes_rs(2, 17, 17, 512, 1024, True)
+  ops.CONV_RS_FORCE = False
+  assert not _takes_rs(8, 34, 34, 256, 1024, True)      # too few rows to pay (the aerial encoder)
+  assert _takes_rs(40, 34, 34, 256, 1024, True)
+  ops.CONV_RS_FORCE = True
+  assert not _takes_rs(3, 11, 11, 64, 256, True)        # fewer than 128 pixels per image (a row tile: two images at most)
+  assert not _takes_rs(3, 20, 20, 64, 128, True)        # a single column tile
+  assert not _takes_rs(3, 20, 20, 256, 256, True)       # Cin = 256 pays from Cout = 512
+  x, w, res, g_in, b_in = _layer(2, 17, 17, 512, 1024, 88, True)
+  y_a = _run(x, w, res, g_in, b_in, None, no_rs=False)
+  y_b = _run(x, w, res, g_in, b_in, None, no_rs=True)
+  assert torch.equal(y_a, y_b)
