@@ -153,14 +153,14 @@ def _to(tree, device):
 
 def _pmc_traffic(kernel, launches, workload, default_config=True):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-  (profiles/r01_c2_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate
+  (profiles/r0N_c2_hbm_traffic.json, newest round first: FETCH_SIZE / WRITE_SIZE collected in separate
   passes on this workload, gfx950 x2 read correction applied).  None if unavailable."""
   if workload != 'c2' or not default_config:     # (the counter passes ran the default configuration)
     return None
   fam = ('conv_split' if kernel.startswith('conv_split') else
          'mlp2_pool' if kernel.startswith('mlp2_pool') else kernel)
   rec = None
-  for name in ('r02_c2_hbm_traffic.json', 'r01_c2_hbm_traffic.json'):   # newest round first
+  for name in ('r03_c2_hbm_traffic.json', 'r02_c2_hbm_traffic.json', 'r01_c2_hbm_traffic.json'):   # newest round first
     try:
       with open(os.path.join(ROOT, 'profiles', name)) as f:
         rec = json.load(f)['per_step'].get(fam)
@@ -451,6 +451,10 @@ def main(argv=None):
     if use_cuda and rank == 0 and i == args.steps - 1:
       prof = ops.KernelProfiler()   # HIP events around every launch of the last step
       ops.set_profiler(prof)
+      # ... with the aerial encoder on the MAIN stream for this one step: next to the StreetView
+      # kernels on its side stream, two launches share the GPU and BOTH report inflated durations
+      # (their sum counts the shared wall time twice), which understates every family's rate
+      overlap_prev, ops.OVERLAP_AERIAL = ops.OVERLAP_AERIAL, False
     if use_cuda:
       ev = torch.cuda.Event(enable_timing=True)
       ev.record()
@@ -458,6 +462,8 @@ def main(argv=None):
     pred = None
     pred = step(args.warmup + i)
   ops.set_profiler(None)
+  if prof is not None:
+    ops.OVERLAP_AERIAL = overlap_prev
   if use_cuda:
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
@@ -583,6 +589,9 @@ def main(argv=None):
             'bytes_per_launch': s['bytes'] / s['launches'],
         }
       out['kernels'] = kern
+      out['kernels_note'] = ('HIP-event durations of the LAST timed step, which runs the aerial encoder on the main '
+                             'stream (no two launches share the GPU while they are timed); the other steps overlap it '
+                             'with the StreetView encoder on a second stream')
       if is_c4:
         # the direct-form correlation is MFMA-bound (AI ~ 1e5 flop/B); report BOTH the
         # matrix-core fraction on its direct-form flops and the HBM fraction its algorithmic bytes

@@ -163,3 +163,23 @@ class BaseModel:
 
   def default_flax_model_config(self):
     raise NotImplementedError('Subclasses must implement default_flax_model_config().')
+
+
+_DEVICE_CONSTS = {}
+
+
+def device_const(key, device, make, owner=None):
+  """A small constant tensor uploaded ONCE per (key, device): lattices, query grids and per-config
+  scales were re-uploaded on every apply (one pageable host-to-device blit kernel each, ~4 us of
+  stream time: the `__amd_rocclr_copyBuffer` rows of the round-2 profile).  ``make()`` builds the
+  host tensor; the cached device copy must be treated as read-only.  ``owner``: the object whose
+  state the constant derives from (the cache then lives and dies with it); without one the key
+  must identify the value globally."""
+  device = torch.device(device)
+  cache = _DEVICE_CONSTS if owner is None else owner.__dict__.setdefault('_device_consts', {})
+  k = (key, device.type, device.index)
+  t = cache.get(k)
+  if t is None:
+    t = make().to(device)
+    cache[k] = t
+  return t

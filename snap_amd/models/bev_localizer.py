@@ -85,8 +85,9 @@ class BEVLocalizer(base.Module):
     D = plane_sparse.features.shape[-1]
     feats = torch.zeros((*self.grid_query.extent, D), device=dev)
     valid = torch.zeros(self.grid_query.extent, dtype=torch.bool, device=dev)
-    q_xy_p = self.q_xy_p.squeeze(1).to(dev)
-    idx = self.grid_query.xyz_to_index(q_xy_p + self.qgrid_p_q[:2].to(dev))
+    q_xy_p = base.device_const('q_xy_p_flat', dev, lambda: self.q_xy_p.squeeze(1), owner=self)
+    idx = self.grid_query.xyz_to_index(
+        q_xy_p + base.device_const('qgrid_p_q', dev, lambda: self.qgrid_p_q[:2], owner=self))
     valid[idx[:, 0], idx[:, 1]] = plane_sparse.valid.reshape(len(idx))
     feats[idx[:, 0], idx[:, 1]] = plane_sparse.features.reshape(len(idx), -1)
     return types.FeaturePlane(features=feats, valid=valid)
@@ -164,7 +165,8 @@ class BEVLocalizer(base.Module):
     ctx = base.ForwardContext()
     dev = data['query']['images'].device
     batch_size = len(data['query']['images'])
-    q_xy_p = self.q_xy_p.to(dev)[None].expand(batch_size, -1, -1, -1)
+    q_xy_p = base.device_const('q_xy_p', dev, lambda: self.q_xy_p, owner=self)[None].expand(
+        batch_size, -1, -1, -1)
 
     pred = {}
     # shallow copies: the mappers add keys (xyz_query, image_feature_pyr) that must

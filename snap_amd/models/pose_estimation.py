@@ -70,9 +70,9 @@ def refinement_offsets(device):
   delta_p, delta_r, range_p, range_r = 0.2, 0.25, 4, 5
   offs_r = np.mgrid[slice(-range_r, range_r + delta_r, delta_r)]
   offs_p = np.mgrid[slice(-range_p, range_p + delta_p, delta_p)]
-  offs_r = torch.tensor(np.deg2rad(offs_r.astype(np.float32)), device=device)
-  offs_p = torch.tensor(offs_p.astype(np.float32), device=device)
-  return offs_r, offs_p
+  from snap_amd.models import base
+  return (base.device_const('refine_offs_r', device, lambda: torch.tensor(np.deg2rad(offs_r.astype(np.float32)))),
+          base.device_const('refine_offs_p', device, lambda: torch.tensor(offs_p.astype(np.float32))))
 
 
 def grid_refinement_batched(

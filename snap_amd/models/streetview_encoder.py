@@ -97,9 +97,9 @@ class StreetViewEncoder(base.Module):
     f_images = f_image_pyr.features[-1]
     B, V = f_images.shape[:2]
     feature_stride = f_image_pyr.strides[-1]
-    scale = torch.tensor(
-        (1.0 / feature_stride[::-1]).astype('float32'), device=f_images.device
-    )
+    inv_stride = tuple(float(v) for v in (1.0 / feature_stride[::-1]))
+    scale = base.device_const(('camera_scale', inv_stride), f_images.device,
+                              lambda: torch.tensor(inv_stride, dtype=torch.float32))
     cameras = data['camera'].scale(scale)
     scene_t_view = data['T_view2scene']
     pred = {'image_feature_pyramid': f_image_pyr}

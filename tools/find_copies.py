@@ -1,53 +1,68 @@
-"""Where do the torch-side copies / elementwise launches of one inference step come from?
-(torch.profiler with python stacks; prints the aten ops that launch device kernels or memcpys,
-grouped by the innermost snap_amd source line.)   python tools/find_copies.py"""
+"""Where do the small copies of one C2 inference step come from?  Wraps the torch entry points
+that end in a hipMemcpy / blit kernel (`copy_`, `clone`, `to`, `contiguous`, `cat`, `stack`,
+indexed assignment, `item`) for ONE step and groups the calls by the snap_amd source line."""
 import collections
-import os
 import sys
+import traceback
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402
-from snap_amd import ops  # noqa: E402
+import bench
+from snap_amd import ops
+
+COUNTS = collections.Counter()
+
+
+def _site():
+  for fr in reversed(traceback.extract_stack()[:-2]):
+    if 'snap_amd' in fr.filename or fr.filename.endswith('bench.py'):
+      return f'{fr.filename.split("repo/")[-1]}:{fr.lineno} {fr.line.strip()[:90]}'
+  return '?'
+
+
+def _wrap(owner, name):
+  orig = getattr(owner, name)
+
+  def f(*a, **k):
+    t = a[0] if a and isinstance(a[0], torch.Tensor) else None
+    note = ''
+    if t is not None and name in ('contiguous',) and t.is_contiguous():
+      return orig(*a, **k)
+    if t is not None and name == 'to':
+      r = orig(*a, **k)
+      if r is t:
+        return r
+      note = f' {t.device.type}->{r.device.type}'
+      COUNTS[(name + note, _site())] += 1
+      return r
+    COUNTS[(name + note, _site())] += 1
+    return orig(*a, **k)
+  setattr(owner, name, f)
+  return orig
 
 
 def main():
-  dev = torch.device('cuda', 0)
+  device = torch.device('cuda')
   ops.MATMUL_PRECISION = 'bf16x3'
-  loc, cfg, meta, variables, batch = bench.build('c2', dev, 0, materialize_volume=False)
-  for i in range(2):
-    loc.apply(variables, batch, train=False, rngs={'sampling': i})
+  loc, cfg, meta, variables, batch = bench.build('c2', device, 0, materialize_volume=False)
+  step = lambda i: loc.apply(variables, batch, train=False, rngs={'sampling': i})
+  for i in range(3):
+    step(i)
   torch.cuda.synchronize()
-  from torch.profiler import ProfilerActivity, profile
-  with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
-    loc.apply(variables, batch, train=False, rngs={'sampling': 7})
-    torch.cuda.synchronize()
-  agg = collections.defaultdict(lambda: [0, 0.0, set()])
-  for ev in prof.events():
-    if not ev.name.startswith('aten::'):
-      continue
-    dt = getattr(ev, 'device_time_total', 0) or getattr(ev, 'cuda_time_total', 0)
-    if ev.cpu_parent is not None and ev.cpu_parent.name.startswith('aten::'):
-      continue                     # top-level aten ops only
-    if dt <= 0:
-      continue
-    where = '?'
-    for fr in (ev.stack or []):
-      if 'snap_amd' in fr or 'bench.py' in fr:
-        where = fr.split('/root/repo/')[-1] if '/root/repo/' in fr else fr
-        break
-    a = agg[(where, ev.name)]
-    a[0] += 1
-    a[1] += dt
-    a[2].add(str(ev.input_shapes)[:80])
-  tot = 0.0
-  for (where, name), (n, t, shp) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    tot += t
-    print(f'{t:8.1f} us  x{n:<3d} {name:28s} {where[:90]}  {sorted(shp)[:2]}')
-  print('total', round(tot, 1), 'us of device time in top-level aten ops')
+  saved = [(torch.Tensor, n, _wrap(torch.Tensor, n)) for n in
+           ('copy_', 'clone', 'to', 'contiguous', '__setitem__', 'item', 'cpu', 'tolist', 'fill_', 'zero_')]
+  saved += [(torch, n, _wrap(torch, n)) for n in ('cat', 'stack', 'tensor', 'as_tensor', 'where', 'zeros', 'ones', 'full')]
+  step(3)
+  torch.cuda.synchronize()
+  for o, n, f in saved:
+    setattr(o, n, f)
+  tot = collections.Counter()
+  for (name, site), n in COUNTS.items():
+    tot[name] += n
+  print(dict(tot))
+  for (name, site), n in COUNTS.most_common(80):
+    print(f'{n:4d} {name:22s} {site}')
 
 
 if __name__ == '__main__':
-  main()
+  sys.exit(main())

@@ -18,7 +18,11 @@ import sys
 # kernel-name substring -> bench.py kernel family (the KernelProfiler region names)
 FAMILIES = [
     ('conv_igemm_kernel', 'conv_igemm'), ('conv_split_kernel', 'conv_split'), ('conv3x3_halo_kernel', 'conv_split'),
-    ('splitk_reduce_kernel', 'conv_split'),
+    ('splitk_reduce_kernel', 'conv_split'), ('conv_split_root_kernel', 'conv_split'),
+    ('conv1x1_rs_kernel', 'conv_split'), ('conv_ps_kernel', 'conv_split'),
+    ('gn_norm_split_kernel', 'gn_norm_split'), ('presplit_kernel', 'presplit'),
+    ('gn_finalize_tiled_kernel', 'group_norm_stats'), ('sim_split_kernel', 'sim_softmax'),
+    ('ransac_sample', 'ransac_sample'), ('template_', 'voting'), ('conv_bf16_kernel', 'conv_bf16'),
     ('mlp2_pool_kernel', 'mlp2_pool'), ('mlp2_pool_finalize_kernel', 'mlp2_pool'), ('fill_f32_kernel', 'mlp2_pool'),
     ('pack_weights_split', 'pack_weights'),
     ('pose_score_db_kernel', 'pose_score'), ('pose_score_kernel', 'pose_score'),
