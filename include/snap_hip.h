@@ -137,6 +137,7 @@ typedef struct SnapConvExtras {
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
 #define SNAP_TUNE_NO_RS 2     /* split engine: the tiled body also where the row-stationary 1x1 kernel applies */
 #define SNAP_TUNE_RS_FORCE 4   /* split engine: the row-stationary kernel also below its row-count threshold (tests) */
+#define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
 #define SNAP_TUNE_RS_NSPLIT_SHIFT 4   /* bits 4..7: row-stationary kernel, forced column split (0 = automatic) */
 #define SNAP_TUNE_ABLATE_SHIFT 8   /* bits 8..: timing-only ablations of the K loop (WRONG results) */
 /* Pre-split launches (extras->x_presplit): row tile, GroupNorm partial-sum bytes and split-K

@@ -45,6 +45,7 @@ struct ConvArgs {
   int bk;      // f32 engine: K-slab depth of the large tiles (16 | 32)
   int no_halo; // split engine: 1 = im2col body for every 3x3
   int no_rs;   // split engine: 1 = tiled body also where conv_rs.hip applies
+  int no_plain;  // split engine: 1 = the general loader also for 1 x 1 / stride 1 / unpadded layers
   int rs_nsplit;  // ... forced column split of conv_rs.hip (0 = automatic)
   int rs_force;   // ... conv_rs.hip also below its row-count threshold (tests)
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])

@@ -73,7 +73,13 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, u32x2 (&out)[NS]) {
 // channel 3 carry zero weights: snap_conv2d_pack_weights_split_root_bf16).  The launch sets KW = 2
 // "virtual taps" per kernel row; a thread's quad IS one pixel, so bounds are per thread.  K = 14 x
 // 16 = 224 for 147 real products -- against Cin = 3 padded to a 16-k slab PER TAP (49 slabs).
-template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool ROOT = false, bool DUAL = false>
+// PLAIN: a 1 x 1 / stride 1 / unpadded convolution over whole 16-channel slabs and consecutive rows
+// (most launches of a ResNet): no tap can fall outside the image and no channel outside Cin, so
+// the per-element selects, the bounds compares and the 64-bit address arithmetic of the general
+// loader drop out -- rows beyond M are CLAMPED to the last row (their accumulators are garbage the
+// epilogue never stores) and the A rows are fetched with buffer loads: a constant 32-bit byte
+// offset per thread plus the slab's offset in the scalar operand.  Same values, same bits.
+template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool ROOT = false, bool DUAL = false, bool PLAIN = false>
 __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   constexpr int BK = 16;
   constexpr int TM = BM / 64;
@@ -124,12 +130,13 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   const float* r_px[AROWS];
   int64_t r_gn[AROWS];
   int r_slot[AROWS];
+  int r_voff[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int row = (tid / QPR) + RPP * i;
     const int m = m0 + row;
     r_ok[i] = m < Meff;
-    int mm = r_ok[i] ? m : 0;
+    int mm = r_ok[i] ? m : (PLAIN ? Meff - 1 : 0);
     if (a.rows_in) mm = a.rows_in[mm];
     const int n = mm / HoWo;
     const int r = mm - n * HoWo;
@@ -139,9 +146,15 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     r_wb[i] = wo * d.stride - d.pad_l;
     r_px[i] = a.x + (((int64_t)n * d.H + r_hb[i]) * d.W + r_wb[i]) * d.Cin_stride;
     r_gn[i] = (int64_t)n * d.Cin;
-    r_slot[i] = m >= m_split ? 1 : 0;
+    r_slot[i] = (PLAIN ? mm : m) >= m_split ? 1 : 0;
+    if constexpr (PLAIN) r_voff[i] = (int)(((int64_t)(mm - m0) * d.Cin_stride + 4 * (tid % QPR)) * 4);
   }
   const int akq = tid % QPR;
+  // PLAIN: the tile's rows through one buffer resource (window from the tile's first row)
+  const int64_t x_left = ((int64_t)(Meff - m0) * d.Cin_stride) * 4;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (PLAIN ? (int64_t)m0 * d.Cin_stride : 0), 0,
+      (int)(x_left < 0x7ff00000LL ? x_left : 0x7ff00000LL), 0x00020000);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -187,6 +200,15 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   const int ablate = SNAP_CONV_SPLIT_ABLATE ? a.ablate : 0;
   auto load_a = [&]() {
     if (ablate & 1) return;
+    if constexpr (PLAIN) {
+      static_assert(!PLAIN || (GNT || !need_gn), "PLAIN takes the table variant of the GroupNorm prologue");
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs_x, r_voff[i], ct * (BK * 4), 0);
+        __builtin_memcpy(&xa[i], &r, 16);
+      }
+      return;
+    }
     const int c = ct * BK + 4 * akq;
     cur_c = c;
     const bool cvalid = ROOT || c < d.Cin;
@@ -289,7 +311,9 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
           pv = apply_pro<PRO>(v[e], xmu[i][e], xsc[i][e], xbeta[e], d.in_scale, d.in_shift);
         else
           pv = apply_pro<PRO>(v[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
-        if constexpr (TAIL)
+        if constexpr (PLAIN)
+          v[e] = pv;
+        else if constexpr (TAIL)
           v[e] = (xin[i] && (cur_c + e < d.Cin)) ? pv : 0.f;
         else
           v[e] = xin[i] ? pv : 0.f;
@@ -691,9 +715,9 @@ void launch_halo(const ConvArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((conv3x3_halo_kernel<BN, PRO, NS, 288>), grid, dim3(256), 0, s, a);
 }
 
-template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool DUAL = false>
+template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool DUAL = false, bool PLAIN = false>
 __global__ __launch_bounds__(256, NS == 2 ? 4 : 3) void conv_split_kernel(const ConvArgs a) {
-  conv_split_body<BM, BN, PRO, NS, GNT, TAIL, false, DUAL>(a);
+  conv_split_body<BM, BN, PRO, NS, GNT, TAIL, false, DUAL, PLAIN>(a);
 }
 
 template <int BN, int PRO, int NS>
@@ -752,6 +776,25 @@ int launch(ConvArgs a, hipStream_t s) {
     if (dual) {
       hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, true, false, true>), grid, dim3(256), 0, s, a);
       SNAP_CHECK_LAUNCH();
+      return SNAP_OK;
+    }
+  }
+  // the lean loader for 1 x 1 / stride 1 / unpadded layers over whole slabs (conv_split_body: PLAIN)
+  const bool plain = !a.no_plain && a.d.KH == 1 && a.d.KW == 1 && a.d.stride == 1 && a.d.pad_t == 0 &&
+                     a.d.pad_l == 0 && a.d.H == a.d.Ho && a.d.W == a.d.Wo && a.d.Cin % 16 == 0 &&
+                     (a.d.Cin_stride & 3) == 0 && !a.rows_in && !a.row_count && a.M > 0 &&
+                     (int64_t)BM * a.d.Cin_stride * 4 < 0x7ff00000LL;
+  if constexpr (NS == 2 && (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_NONE || PRO == SNAP_PRO_RELU_GN)) {
+    if (plain && (!need_gn || table_ok)) {
+      hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, need_gn, false, false, true>), grid, dim3(256), 0, s, a);
+      SNAP_CHECK_LAUNCH();
+      if (a.ksplit > 1) {
+        const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
+                           (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.Cout_stride,
+                           a.d.epilogue, a.bias, a.residual, a.row_mask, a.y);
+        SNAP_CHECK_LAUNCH();
+      }
       return SNAP_OK;
     }
   }

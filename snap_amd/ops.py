@@ -198,6 +198,7 @@ CONV_NO_HALO = False
 CONV_NO_RS = False      # tools / tests: the tiled body also where the row-stationary 1x1 kernel applies
 CONV_RS_NSPLIT = 0      # tools: forced column split of the row-stationary kernel (0 = automatic)
 CONV_RS_FORCE = False   # tests: the row-stationary kernel also below its row-count threshold
+CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
 CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
 USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
 PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
@@ -246,7 +247,7 @@ def presplit(x):
 
 
 def _rs_tune_flags():
-  return 2 * int(bool(CONV_NO_RS)) | 4 * int(bool(CONV_RS_FORCE))
+  return 2 * int(bool(CONV_NO_RS)) | 4 * int(bool(CONV_RS_FORCE)) | 8 * int(bool(CONV_NO_PLAIN))
 
 
 def conv2d(
@@ -406,7 +407,7 @@ def conv2d(
       ex.x_presplit = 1
       ex.ps_tile = pst
       ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
-  if CONV_BK or CONV_NO_HALO or CONV_NO_RS or CONV_RS_NSPLIT or CONV_RS_FORCE or CONV_ABLATE:
+  if CONV_BK or CONV_NO_HALO or CONV_NO_RS or CONV_RS_NSPLIT or CONV_RS_FORCE or CONV_NO_PLAIN or CONV_ABLATE:
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.bk_hint = int(CONV_BK or 0)
