@@ -67,7 +67,11 @@ typedef struct SnapConvDesc {
                                          (128128 | 128064 | 64128 | 64064) forces one -- part of
                                          the descriptor because the size queries depend on it
                                          (tests and tuning tools; the library reads no
-                                         environment variables)                    */
+                                         environment variables).  + 1 000 000 x mode selects
+                                         among the 1x1 bodies of the split engine (conv_rs.hip):
+                                         0 automatic, 1 tiled body only, 2 the stationary
+                                         kernels also below their row-count threshold, 3 no
+                                         weights-stationary kernel, 4 = 2 and 3              */
 } SnapConvDesc;
 
 /* y = epilogue( conv( prologue(x), w ) ).  w is HWIO flattened: [KH*KW*Cin, Cout].
@@ -135,8 +139,6 @@ typedef struct SnapConvExtras {
   int32_t tune_flags;         /* SNAP_TUNE_*: A/B switches for tests and tuning tools (0 = defaults) */
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
-#define SNAP_TUNE_NO_RS 2     /* split engine: the tiled body also where the row-stationary 1x1 kernel applies */
-#define SNAP_TUNE_RS_FORCE 4   /* split engine: the row-stationary kernel also below its row-count threshold (tests) */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
 #define SNAP_TUNE_RS_NSPLIT_SHIFT 4   /* bits 4..7: row-stationary kernel, forced column split (0 = automatic) */
 #define SNAP_TUNE_ABLATE_SHIFT 8   /* bits 8..: timing-only ablations of the K loop (WRONG results) */
@@ -277,12 +279,17 @@ int snap_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, voi
 size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc);
 size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc);
 int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc);   /* row-tile height the launch uses */
-/* 1 when a split-bf16 launch (w_split_parts parts, no row lists) of this descriptor runs on the
- * row-stationary 1x1 kernel (conv_rs.hip: the bottleneck units' closing / projection convolution,
- * snap/models/resnet.py:112-132) instead of the tiled body; same output bits either way
- * (tune_flags as in SnapConvExtras: SNAP_TUNE_NO_RS forces the tiled body, SNAP_TUNE_RS_FORCE the
- * kernel below its row-count threshold).  For profiling labels and tests. */
-int32_t snap_conv2d_row_stationary(const SnapConvDesc* desc, int32_t parts, int32_t tune_flags);
+/* ... of a launch on the split-operand engine with `split_parts` parts (SnapConvExtras.w_split_parts;
+ * 0 = any other engine): the weights-stationary 1x1 kernel of the two-part engine emits its
+ * GroupNorm partial sums per 32-row slab. */
+int32_t snap_conv2d_tile_rows_ex(const SnapConvDesc* desc, int32_t split_parts);
+size_t snap_conv2d_gn_partial_bytes_ex(const SnapConvDesc* desc, int32_t split_parts);
+/* Which body a split-bf16 launch (w_split_parts parts, no row lists) of this descriptor takes:
+ * 0 = the tiled body, 1 = the row-stationary 1x1 kernel (activation tile in registers), 2 = the
+ * weights-stationary 1x1 kernel (panel resident in LDS) -- conv_rs.hip: the bottleneck units' closing
+ * / projection convolution, snap/models/resnet.py:112-132.  Same output bits whichever it is; a pure
+ * function of the descriptor (desc->tile_hint carries the A/B mode).  For profiling labels and tests. */
+int32_t snap_conv2d_stationary_kind(const SnapConvDesc* desc, int32_t parts);
 
 /* mu / sc (/ rstd) [N, C] from a conv launch's gn_partial.  tile_rows =
  * snap_conv2d_tile_rows(desc of that launch); HW = Ho*Wo of its output. */

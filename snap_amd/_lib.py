@@ -74,7 +74,9 @@ SIGNATURES = {
     'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
-    'snap_conv2d_row_stationary': (c_int, [ctypes.POINTER(SnapConvDesc), c_int, c_int]),
+    'snap_conv2d_stationary_kind': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
+    'snap_conv2d_tile_rows_ex': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
+    'snap_conv2d_gn_partial_bytes_ex': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_presplit_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_presplit_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_presplit_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),

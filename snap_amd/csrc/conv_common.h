@@ -44,10 +44,8 @@ struct ConvArgs {
   int ablate;  // tuning-only (SnapConvExtras.tune_flags >> 8): bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
   int bk;      // f32 engine: K-slab depth of the large tiles (16 | 32)
   int no_halo; // split engine: 1 = im2col body for every 3x3
-  int no_rs;   // split engine: 1 = tiled body also where conv_rs.hip applies
   int no_plain;  // split engine: 1 = the general loader also for 1 x 1 / stride 1 / unpadded layers
-  int rs_nsplit;  // ... forced column split of conv_rs.hip (0 = automatic)
-  int rs_force;   // ... conv_rs.hip also below its row-count threshold (tests)
+  int rs_nsplit;  // split engine: forced column split of conv_rs.hip (0 = automatic)
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])
   int cin8;            // ... channel count rounded up to 8
   const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
@@ -65,10 +63,15 @@ int launch_split_root(ConvArgs a, int parts, hipStream_t s);
 // pre-split engine (conv_ps.hip): a.x_ps = the input already normalised and split in two bf16
 // parts (snap_gn_norm_split_f32 / snap_presplit_f32), a.w_bf16 = the split weight image (parts = 2)
 int launch_ps(ConvArgs a, hipStream_t s);
-// row-stationary 1 x 1 kernel (conv_rs.hip): Cin = 64 / 128 / 256 -> Cout >= 256, GroupNorm + ReLU
-// prologue, optional residual; bit-identical to launch_split(a, 2, s) where it applies
-bool rs_applicable(const ConvArgs& a, int parts);
+// stationary-operand 1 x 1 kernels (conv_rs.hip) for Cin = 64 / 128 / 256 -> Cout >= 256, GroupNorm
+// + ReLU prologue, optional residual; bit-identical to launch_split(a, 2, s) where they apply.
+// stationary_kind: 0 = tiled body, 1 = row-stationary (activation tile in registers, weights
+// streamed per 128 rows), 2 = weights-stationary (panel resident in LDS, Cin <= 128; GroupNorm
+// partials per 32-row slab).  A pure function of the descriptor (+ the launch's row lists): the
+// workspace / statistics queries must agree with the launch.
+int stationary_kind(const SnapConvDesc& d, int parts, bool row_lists);
 int launch_rs(ConvArgs a, hipStream_t s);
+int launch_bs(ConvArgs a, hipStream_t s);
 struct PsTile { int bm, bn, nt; };
 PsTile ps_choose_tile(int64_t M, int64_t N, int force);
 int ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t kpartial_bytes);
@@ -322,8 +325,14 @@ constexpr int splitk_target() { return 768; }
 // Tile choice: the largest tile that still yields >= 2 workgroups per CU; small-M
 // layers (deep stages, few images) fall back to 64x64 tiles to fill the 256 CUs.
 struct TileChoice { int bm, bn; };
-// forced = SnapConvDesc.tile_hint (bm * 1000 + bn; 0 = automatic)
+// SnapConvDesc.tile_hint = tile code (bm * 1000 + bn; 0 = automatic) + 1 000 000 x mode (tests and
+// tools; 0 = automatic): 1 = tiled body only, 2 = the stationary kernels also below their row-count
+// threshold, 3 = no weights-stationary kernel, 4 = 2 and 3
+inline int hint_tile(int h) { return h % 1000000; }
+inline int hint_mode(int h) { return h / 1000000; }
+// forced = SnapConvDesc.tile_hint
 inline TileChoice choose_tile(int64_t M, int64_t N, int forced) {
+  forced = hint_tile(forced);
   const int64_t kMin = 512;
   const bool n_wide_ok = N > 64 && !(N % 128 != 0 && N % 128 <= 64);
   if (forced != 128128 && forced != 128064 && forced != 64128 && forced != 64064) forced = 0;

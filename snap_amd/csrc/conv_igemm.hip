@@ -559,13 +559,25 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
                                  row_mask, nullptr, stream);
 }
 
-extern "C" size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc) {
+// (split_parts: SnapConvExtras.w_split_parts of the launch -- the weights-stationary kernel of the
+//  two-part split engine emits its statistics per 32-row slab; 0 = any other engine)
+extern "C" int32_t snap_conv2d_tile_rows_ex(const SnapConvDesc* desc, int32_t split_parts) {
+  if (!desc) return 0;
+  if (snapconv::stationary_kind(*desc, split_parts, false) == 2) return 32;
+  return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint).bm;
+}
+
+extern "C" size_t snap_conv2d_gn_partial_bytes_ex(const SnapConvDesc* desc, int32_t split_parts) {
   if (!desc) return 0;
   const SnapConvDesc& d = *desc;
   const int64_t HoWo = (int64_t)d.Ho * d.Wo;
-  const TileChoice t = choose_tile((int64_t)d.N * HoWo, d.Cout, d.tile_hint);
-  if (HoWo < t.bm) return 0;  // a tile would straddle more than two images: not produced
-  return (size_t)d.N * (HoWo / t.bm + 2) * d.Cout * 2 * sizeof(float);
+  const int bm = snap_conv2d_tile_rows_ex(desc, split_parts);
+  if (HoWo < bm) return 0;  // a tile would straddle more than two images: not produced
+  return (size_t)d.N * (HoWo / bm + 2) * d.Cout * 2 * sizeof(float);
+}
+
+extern "C" size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc) {
+  return snap_conv2d_gn_partial_bytes_ex(desc, 0);
 }
 
 extern "C" size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc) {
@@ -584,18 +596,12 @@ extern "C" size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc) {
 }
 
 extern "C" int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc) {
-  if (!desc) return 0;
-  return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint).bm;
+  return snap_conv2d_tile_rows_ex(desc, 0);
 }
 
-extern "C" int32_t snap_conv2d_row_stationary(const SnapConvDesc* desc, int32_t parts, int32_t tune_flags) {
+extern "C" int32_t snap_conv2d_stationary_kind(const SnapConvDesc* desc, int32_t parts) {
   if (!desc) return 0;
-  ConvArgs a{};
-  a.d = *desc;
-  a.M = (int)((int64_t)desc->N * desc->Ho * desc->Wo);
-  a.no_rs = (tune_flags & SNAP_TUNE_NO_RS) ? 1 : 0;
-  a.rs_force = (tune_flags & SNAP_TUNE_RS_FORCE) ? 1 : 0;
-  return snapconv::rs_applicable(a, parts) ? 1 : 0;
+  return snapconv::stationary_kind(*desc, parts, false);
 }
 
 // ---- pre-split launches (conv_ps.hip) ---------------------------------------------------------
@@ -639,9 +645,10 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
       (desc->epilogue & (SNAP_EPI_RESIDUAL | SNAP_EPI_UPSAMPLE2X_ADD | SNAP_EPI_ROWMASK)))
     return SNAP_ERR_UNSUPPORTED;  // row-indexed launches carry bias / ReLU only
   const bool presplit = ex && ex->x_presplit;
+  const bool split_vec = ex && ex->w_bf16 && !ex->w_split_root && !rows_in && !rows_out && !row_count;
   const size_t gn_need = !gn_partial ? 0
                          : presplit  ? snap_conv2d_presplit_gn_partial_bytes(desc, ex->ps_tile)
-                                     : snap_conv2d_gn_partial_bytes(desc);
+                                     : snap_conv2d_gn_partial_bytes_ex(desc, split_vec ? ex->w_split_parts : 0);
   if (gn_partial) {
     if (rows_in || rows_out || row_count) return SNAP_ERR_UNSUPPORTED;
     if (desc->Cout_stride != desc->Cout) return SNAP_ERR_UNSUPPORTED;
@@ -702,9 +709,7 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.ablate = ex ? (ex->tune_flags >> SNAP_TUNE_ABLATE_SHIFT) : 0;   // timing experiments only (wrong results)
   a.bk = (ex && ex->bk_hint == 32) ? 32 : 16;
   a.no_halo = (ex && (ex->tune_flags & SNAP_TUNE_NO_HALO)) ? 1 : 0;
-  a.no_rs = (ex && (ex->tune_flags & SNAP_TUNE_NO_RS)) ? 1 : 0;
   a.rs_nsplit = ex ? (ex->tune_flags >> SNAP_TUNE_RS_NSPLIT_SHIFT) & 15 : 0;
-  a.rs_force = (ex && (ex->tune_flags & SNAP_TUNE_RS_FORCE)) ? 1 : 0;
   a.no_plain = (ex && (ex->tune_flags & SNAP_TUNE_NO_PLAIN)) ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // bf16-operand engine (training precision): needs the packed bf16 weights and the float4

@@ -514,6 +514,265 @@ __global__ __launch_bounds__(SNAP_RS_NT, 2) void conv1x1_rs_kernel(const ConvArg
   reduce_stats(tiles_wg - 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// WEIGHTS STATIONARY (Cin = 64 / 128): the split weight panel of 256 output columns (Cin / 16 slabs x
+// 2 column tiles x 8 KB = 64 / 128 KB) is loaded into LDS ONCE per workgroup; the eight waves of the
+// (persistent, one per CU) workgroup then run INDEPENDENTLY of each other, each over its own
+// sequence of 32-row tiles: rows -> registers (normalised, split), 2 x (Cin / 16) x 12 MFMAs
+// against the resident panel, epilogue.  No DMA ring, no barrier and no wait count in the steady
+// state; the waves drift apart, so one wave's memory-bound epilogue runs under another's MFMAs.
+// What it buys (section 5j of DESIGN.md): the row-stationary kernel above re-streams the panel for
+// every 128 rows -- 18 % (Cin = 64) / 30 % (Cin = 128) of all bytes crossing the CU boundary, on
+// layers whose time IS those bytes over ~5.3 TB/s.
+// The GroupNorm statistics of the output leave per 32-ROW slab (conv_epilogue's layout with a
+// row tile of 32: snap_conv2d_tile_rows says so, the finalize pass takes any tile height): one wave
+// writes its own sums, nothing is reduced across waves.
+template <int KS, bool RES, int STATS /* 0 none, 1 one set, 2 also of relu(y) */>
+__global__ __launch_bounds__(512, 2) void conv1x1_bs_kernel(const ConvArgs a) {
+  constexpr int NT = 512, NW = NT / 64;
+  constexpr int TN = 4, BN = 128, NCT = 2;      // two column tiles of 128 per workgroup
+  constexpr int Cin = 16 * KS;
+  constexpr int kPanel = KS * NCT * 8192;       // [column tile][slab][part][128 columns][32 B]
+  constexpr int B_PART = 4096, B_SLAB = 8192;
+  constexpr int kStgRow = 32;
+  constexpr int kStg = 32 * kStgRow;            // floats per wave (also holds the wave's GroupNorm table)
+  static_assert(5 * Cin <= kStg, "GroupNorm table in the staging tile");
+  __shared__ __attribute__((aligned(16))) char panel[kPanel];
+  __shared__ __attribute__((aligned(16))) float staging[NW * kStg];
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Meff = a.M;
+  const int HoWo = d.Ho * d.Wo;
+  const int nbase = blockIdx.y * (NCT * BN);
+
+  // ---- the panel: both column tiles' contiguous Cin / 16 x 8 KB blocks of the weight image -------
+  {
+    const char* const wt = static_cast<const char*>(a.w_bf16);
+    const int64_t col_tile_bytes = (int64_t)KS * 8192;
+#pragma unroll
+    for (int p = 0; p < kPanel / 16 / NT; ++p) {
+      const int q = tid + NT * p;                                  // 16-byte piece
+      const int ct = q / (KS * 512);
+      const char* src = wt + (int64_t)((nbase >> 7) + ct) * col_tile_bytes + (q - ct * (KS * 512)) * 16;
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src, (lds_void_t*)(panel + 16 * q), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  float* const stg = staging + wid * kStg;
+  const int q8 = lane & 7, rg = lane >> 3;
+  const int relu_out = d.epilogue & SNAP_EPI_RELU;
+  const int ntile = (Meff + 31) >> 5;
+  const int nwaves = gridDim.x * NW;
+  for (int t = blockIdx.x * NW + wid; t < ntile; t += nwaves) {
+    const int mw0 = 32 * t;
+    const int n_first = mw0 / HoWo;
+    const int m_split = (n_first + 1) * HoWo;                      // first row of the next image
+    const bool straddle = mw0 + 32 > m_split && m_split < Meff;
+    // ---- output / residual windows of this tile --------------------------------------------
+    const int rows_here = min(32, Meff - mw0);
+    const int win = rows_here * d.Cout_stride * 4;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.y) + (int64_t)mw0 * d.Cout_stride * 4, 0, win, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(RES ? a.residual : a.y)) +
+            (int64_t)mw0 * d.Cout_stride * 4, 0, win, 0x00020000);
+    const int eo = (rg * d.Cout_stride + 4 * q8) * 4;
+    const int eo_it = 8 * d.Cout_stride * 4;
+    u32x4 res[RES ? 4 * TN : 1];
+    auto load_res = [&](int n0) {
+      if constexpr (RES) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            res[j * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(
+                rs_r, eo + it * eo_it + (n0 + 32 * j) * 4, 0, 0);
+      }
+    };
+
+    // ---- A: this wave's 32 rows, normalised and split once, in registers ------------------------
+    bf16x8 a_hi[KS], a_lo[KS];
+    {
+      const int m = mw0 + l31;
+      const bool ok = m < Meff;
+      const int mm = ok ? m : mw0;
+      const float* const px = a.x + (int64_t)mm * d.Cin_stride + 8 * lhi;
+      f32x4 xv[KS][2];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        xv[s][0] = *reinterpret_cast<const f32x4*>(px + 16 * s);
+        xv[s][1] = *reinterpret_cast<const f32x4*>(px + 16 * s + 4);
+      }
+      // GroupNorm operands of the tile's (at most two) images -> the wave's staging tile:
+      // [image][mu | sc][Cin], beta [Cin]  (wave-private: no barrier, LDS is in order per wave)
+      for (int i = lane; i < 5 * Cin / 4; i += 64) {
+        const int seg = i / (Cin / 4), c = 4 * (i - seg * (Cin / 4));
+        const int n = min(n_first + (seg >> 1), d.N - 1);
+        const float* src = seg == 4 ? a.gn_beta + c : ((seg & 1) ? a.gn_sc : a.gn_mu) + (int64_t)n * Cin + c;
+        *reinterpret_cast<f32x4*>(stg + seg * Cin + c) = *reinterpret_cast<const f32x4*>(src);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float* const tmu = stg + (mm >= m_split ? 2 * Cin : 0) + 8 * lhi;
+      const float* const tbe = stg + 4 * Cin + 8 * lhi;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        u32x2 h[2], l[2];
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const int c = 16 * s + 4 * hq;
+          f32x4 v = xv[s][hq];
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(tmu + c);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(tmu + Cin + c);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(tbe + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pv = apply_pro<SNAP_PRO_GN_RELU>(v[e], mu[e], sc[e], be[e], d.in_scale, d.in_shift);
+            v[e] = ok ? pv : 0.f;
+          }
+          split2(v, h[hq], l[hq]);
+        }
+        const u32x4 hh = {h[0][0], h[0][1], h[1][0], h[1][1]};
+        const u32x4 ll = {l[0][0], l[0][1], l[1][0], l[1][1]};
+        __builtin_memcpy(&a_hi[s], &hh, 16);
+        __builtin_memcpy(&a_lo[s], &ll, 16);
+        asm volatile("" : "+v"(a_hi[s]), "+v"(a_lo[s]) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    load_res(nbase);          // (consumed by the first epilogue, a column tile of MFMAs later)
+#pragma unroll 1
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int n0 = nbase + ct * BN;
+      f32x16 acc[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const char* bs = panel + (ct * KS + s) * B_SLAB;
+        bf16x8 bv[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int C = j * 32 + l31;
+          const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+          bv[j][0] = *reinterpret_cast<const bf16x8*>(p0);
+          bv[j][1] = *reinterpret_cast<const bf16x8*>(p0 + B_PART);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[s], bv[j][0], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bv[j][1], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[s], bv[j][0], acc[j], 0, 0, 0);
+      }
+      // ---- epilogue of (row tile, column tile) ---------------------------------------------------
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          stg[ri * kStgRow + l31] = acc[j][r];
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        float h1[4] = {0.f, 0.f, 0.f, 0.f}, h2[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool count = STATS > 0 && !straddle;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + (8 * it + rg) * kStgRow + 4 * q8);
+          if constexpr (RES) {
+            f32x4 rr;
+            __builtin_memcpy(&rr, &res[j * 4 + it], 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          }
+          if (relu_out) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          u32x4 vo;
+          __builtin_memcpy(&vo, &v, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(vo, rs_y, eo + it * eo_it + (n0 + 32 * j) * 4, 0, 0);
+          if constexpr (STATS > 0) {
+            if (count) {
+              const bool live = mw0 + 8 * it + rg < Meff;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float y = live ? v[e] : 0.f;
+                const float tt = a.gn_relu ? fmaxf(y, 0.f) : y;
+                s1[e] += tt;
+                s2[e] += tt * tt;
+                if constexpr (STATS == 2) {
+                  const float rl = fmaxf(y, 0.f);
+                  h1[e] += rl;
+                  h2[e] += rl * rl;
+                }
+              }
+            } else {
+              *reinterpret_cast<f32x4*>(stg + (8 * it + rg) * kStgRow + 4 * q8) = v;   // parked for the two masked passes
+            }
+          }
+        }
+        if constexpr (STATS > 0) {
+          // sums over the eight row groups (lane bits 3..5); lanes 0..7 write 4 columns x (sum, sum of squares)
+          auto publish = [&](int sl) {
+            const int n = n_first + sl;
+            const bool wr = rg == 0 && n < d.N;
+            const int slab = t - (int)(((int64_t)n * HoWo) >> 5);
+            const int64_t off = (((int64_t)n * a.gn_slabs + slab) * d.Cout + n0 + 32 * j + 4 * q8) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float r1 = xor_sum3(s1[e]), r2 = xor_sum3(s2[e]);
+              if (wr) *reinterpret_cast<float2*>(a.gn_partial + off + 2 * e) = float2{r1, r2};
+              if constexpr (STATS == 2) {
+                const float g1 = xor_sum3(h1[e]), g2 = xor_sum3(h2[e]);
+                if (wr) *reinterpret_cast<float2*>(a.gn_partial2 + off + 2 * e) = float2{g1, g2};
+              }
+            }
+          };
+          if (!straddle) {
+            publish(0);
+          } else {
+            for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; h1[e] = 0.f; h2[e] = 0.f; }
+              for (int it = 0; it < 4; ++it) {
+                const int m = mw0 + 8 * it + rg;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (8 * it + rg) * kStgRow + 4 * q8);
+                const bool live = m < Meff && (m >= m_split) == (sl == 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float y = live ? v[e] : 0.f;
+                  const float tt = a.gn_relu ? fmaxf(y, 0.f) : y;
+                  s1[e] += tt;
+                  s2[e] += tt * tt;
+                  if constexpr (STATS == 2) {
+                    const float rl = fmaxf(y, 0.f);
+                    h1[e] += rl;
+                    h2[e] += rl * rl;
+                  }
+                }
+              }
+              publish(sl);
+            }
+          }
+        }
+      }
+      if (ct + 1 < NCT) load_res(n0 + BN);
+    }
+  }
+}
+
 template <int KS, int TN, bool RES>
 int launch_rs_dual(const ConvArgs& a, dim3 grid, bool dual, hipStream_t s) {
   if (dual)
@@ -530,31 +789,61 @@ int launch_rs_res(const ConvArgs& a, dim3 grid, bool dual, hipStream_t s) {
                                             : launch_rs_dual<KS, TN, false>(a, grid, dual, s);
 }
 
+template <int KS, bool RES>
+int launch_bs_stats(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  const int stats = !a.gn_partial ? 0 : (a.gn_partial2 ? 2 : 1);
+  if (stats == 2)
+    hipLaunchKernelGGL((conv1x1_bs_kernel<KS, RES, 2>), grid, dim3(512), 0, s, a);
+  else if (stats == 1)
+    hipLaunchKernelGGL((conv1x1_bs_kernel<KS, RES, 1>), grid, dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv1x1_bs_kernel<KS, RES, 0>), grid, dim3(512), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
 }  // namespace
 
-// 1 when launch_rs takes the layer (the caller then sizes nothing differently: the row tile is
-// 128 as in the tiled engine, the statistics layout is conv_epilogue's)
-bool snapconv::rs_applicable(const ConvArgs& a, int parts) {
-  const SnapConvDesc& d = a.d;
-  if (parts != 2 || a.no_rs) return false;
+int snapconv::stationary_kind(const SnapConvDesc& d, int parts, bool row_lists) {
+  const int mode = hint_mode(d.tile_hint);
+  if (parts != 2 || mode == 1 || row_lists) return 0;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad_t || d.pad_l || d.H != d.Ho || d.W != d.Wo)
-    return false;
-  if (d.prologue != SNAP_PRO_GN_RELU) return false;
-  if (d.Cin != 64 && d.Cin != 128 && d.Cin != 256) return false;
-  if ((d.Cin_stride & 3) || (d.Cout_stride & 3)) return false;
+    return 0;
+  if (d.prologue != SNAP_PRO_GN_RELU) return 0;
+  if (d.Cin != 64 && d.Cin != 128 && d.Cin != 256) return 0;
+  if ((d.Cin_stride & 3) || (d.Cout_stride & 3)) return 0;
   const int bn = d.Cin == 256 ? 64 : 128;
-  if (d.Cout % bn != 0 || d.Cout < 256 || d.Cout < 2 * d.Cin) return false;   // (expansions: narrower outputs measured slower)
-  if (d.epilogue & ~(SNAP_EPI_RESIDUAL | SNAP_EPI_RELU)) return false;
-  if (a.rows_in || a.rows_out || a.row_count) return false;
-  if ((int64_t)d.Ho * d.Wo < SNAP_RS_NT / 2) return false;    // at most two images per row tile
-  if ((int64_t)256 * d.Cout_stride * 4 >= 0x7ff00000LL) return false;
-  if ((int64_t)d.N * (((int64_t)d.Ho * d.Wo) / 128 + 2) * d.Cout * 8 >= 0x7ff00000LL) return false;
-  // the row tile (and with it the statistics layout) must be the tiled engine's
-  if (choose_tile(a.M, d.Cout, d.tile_hint).bm != 128) return false;
+  if (d.Cout % bn != 0 || d.Cout < 256 || d.Cout < 2 * d.Cin) return 0;   // (expansions: narrower outputs measured slower)
+  if (d.epilogue & ~(SNAP_EPI_RESIDUAL | SNAP_EPI_RELU)) return 0;
+  const int64_t HoWo = (int64_t)d.Ho * d.Wo, M = (int64_t)d.N * HoWo;
+  if (M > 0x7fffffffLL) return 0;
+  if ((int64_t)256 * d.Cout_stride * 4 >= 0x7ff00000LL) return 0;
   // measured (tools/rs_bench.py): 12-15 % faster than the tiled body at M = 46240 ... 739840, level
   // at M = 147968 (K = 64), 15-25 % slower on the aerial encoder's M <= 36992 layers
-  if (a.M < 40000 && !a.rs_force) return false;
-  return true;
+  if (M < 40000 && mode != 2 && mode != 4) return 0;
+  // weights-stationary: the panel of 256 columns must fit LDS next to the staging tiles
+  if (mode != 3 && mode != 4 && d.Cin <= 128 && d.Cout % 256 == 0 && HoWo >= 32 &&
+      d.N * (HoWo / 32 + 2) * (int64_t)d.Cout * 8 < 0x7ff00000LL)
+    return 2;
+  if (HoWo < SNAP_RS_NT / 2) return 0;                           // at most two images per row tile
+  if (d.N * (HoWo / 128 + 2) * (int64_t)d.Cout * 8 >= 0x7ff00000LL) return 0;
+  // the row tile (and with it the statistics layout) must be the tiled engine's
+  if (choose_tile(M, d.Cout, d.tile_hint).bm != 128) return 0;
+  return 1;
+}
+
+int snapconv::launch_bs(ConvArgs a, hipStream_t s) {
+  const SnapConvDesc& d = a.d;
+  a.gn_slabs = (d.Ho * d.Wo) / 32 + 2;
+  a.ksplit = 1;
+  if (a.gn_partial2_done) *a.gn_partial2_done = (a.gn_partial2 && a.gn_partial) ? 1 : 0;
+  const int64_t ntile = snap_cdiv(a.M, 32);
+  // one persistent workgroup per CU (the panel takes most of its LDS); fewer where the rows run out
+  const int wgs = (int)(ntile / 8 < 256 ? (ntile + 7) / 8 : 256);
+  const dim3 grid((unsigned)wgs, (unsigned)(d.Cout / 256));
+  const bool res = (d.epilogue & SNAP_EPI_RESIDUAL) != 0;
+  if (d.Cin == 64) return res ? launch_bs_stats<4, true>(a, grid, s) : launch_bs_stats<4, false>(a, grid, s);
+  return res ? launch_bs_stats<8, true>(a, grid, s) : launch_bs_stats<8, false>(a, grid, s);
 }
 
 int snapconv::launch_rs(ConvArgs a, hipStream_t s) {

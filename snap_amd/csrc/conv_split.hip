@@ -960,7 +960,11 @@ int snapconv::launch_split_root(ConvArgs a, int parts, hipStream_t s) {
 }
 
 int snapconv::launch_split(ConvArgs a, int parts, hipStream_t s) {
-  if (rs_applicable(a, parts)) return launch_rs(a, s);
+  switch (stationary_kind(a.d, parts, a.rows_in || a.rows_out || a.row_count)) {
+    case 1: return launch_rs(a, s);
+    case 2: return launch_bs(a, s);
+    default: break;
+  }
   if (parts == 2) return launch_tile<2>(a, s);
   if (parts == 3) return launch_tile<3>(a, s);
   return SNAP_ERR_UNSUPPORTED;

@@ -195,9 +195,10 @@ USE_PRESPLIT = False
 CONV_TILE = None
 CONV_BK = None
 CONV_NO_HALO = False
-CONV_NO_RS = False      # tools / tests: the tiled body also where the row-stationary 1x1 kernel applies
+CONV_NO_RS = False      # tools / tests: the tiled body also where a stationary 1x1 kernel applies
 CONV_RS_NSPLIT = 0      # tools: forced column split of the row-stationary kernel (0 = automatic)
-CONV_RS_FORCE = False   # tests: the row-stationary kernel also below its row-count threshold
+CONV_RS_FORCE = False   # tests: the stationary kernels also below their row-count threshold
+CONV_NO_WS = False      # tools / tests: no weights-stationary kernel (the row-stationary one where it applies)
 CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
 CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
 USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
@@ -246,8 +247,13 @@ def presplit(x):
   return PreSplit(out, shape)
 
 
-def _rs_tune_flags():
-  return 2 * int(bool(CONV_NO_RS)) | 4 * int(bool(CONV_RS_FORCE)) | 8 * int(bool(CONV_NO_PLAIN))
+def _stationary_mode():
+  """SnapConvDesc.tile_hint // 1 000 000: which 1x1 bodies of the split engine may run."""
+  if CONV_NO_RS:
+    return 1
+  if CONV_RS_FORCE:
+    return 4 if CONV_NO_WS else 2
+  return 3 if CONV_NO_WS else 0
 
 
 def conv2d(
@@ -343,7 +349,16 @@ def conv2d(
   if CONV_TILE:
     bm, bn = (int(v) for v in CONV_TILE.split('x'))
     d.tile_hint = bm * 1000 + bn
+  d.tile_hint += 1000000 * _stationary_mode()
   M = N * Ho * Wo
+  # the engine the launch will take (the statistics layout depends on it)
+  math = MATMUL_PRECISION if math is None else math
+  if math not in ('f32', 'bf16', 'bf16x3', 'bf16x6'):
+    raise ValueError(f'conv2d: math={math!r}')
+  parts = SPLIT_PARTS.get(math, 0)
+  if parts and lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts) == 0:
+    math, parts = 'f32', 0     # weight image beyond the split engine's 32-bit offsets (template banks)
+  qparts = parts if (Cs % 4 == 0 and Cin >= 4 and not ps) else 0   # (what SnapConvExtras.w_split_parts will say)
   ex = None
   partial = partial2 = None
   kws = None
@@ -361,24 +376,18 @@ def conv2d(
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes, None, 0)
     elif emit_gn_stats is not None:
       pbytes = (lib.snap_conv2d_presplit_gn_partial_bytes(ctypes.byref(d), pst) if ps
-                else lib.snap_conv2d_gn_partial_bytes(ctypes.byref(d)))
+                else lib.snap_conv2d_gn_partial_bytes_ex(ctypes.byref(d), qparts))
       if pbytes:
         partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
         ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes,
                                  int(emit_gn_stats == 'relu'), None, 0, None, 0)
-        if emit_gn_stats == 'both' and (MATMUL_PRECISION if math is None else math) in SPLIT_PARTS:
+        if emit_gn_stats == 'both' and math in SPLIT_PARTS:
           # the statistics of y AND of relu(y): a request (SnapConvExtras.gn_partial2_done)
           partial2 = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
           ex.gn_partial2 = partial2.data_ptr()
           ex.gn_partial2_bytes = pbytes
-  math = MATMUL_PRECISION if math is None else math
-  if math not in ('f32', 'bf16', 'bf16x3', 'bf16x6'):
-    raise ValueError(f'conv2d: math={math!r}')
   family = 'conv_igemm'
   wpk = None
-  parts = SPLIT_PARTS.get(math, 0)
-  if parts and lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts) == 0:
-    math = 'f32'     # weight image beyond the split engine's 32-bit offsets (template banks)
   # the RGB root convolution (7 x 7 / stride 2 / pad 3) of an image stored with 4 floats per pixel
   # runs on the split engine with its own weight image (a K slab = 4 pixels of a kernel row)
   if ps and (parts != 2 or Cin % 16):
@@ -407,11 +416,12 @@ def conv2d(
       ex.x_presplit = 1
       ex.ps_tile = pst
       ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
-  if CONV_BK or CONV_NO_HALO or CONV_NO_RS or CONV_RS_NSPLIT or CONV_RS_FORCE or CONV_NO_PLAIN or CONV_ABLATE:
+  if CONV_BK or CONV_NO_HALO or CONV_RS_NSPLIT or CONV_NO_PLAIN or CONV_ABLATE:
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.bk_hint = int(CONV_BK or 0)
-    ex.tune_flags = int(bool(CONV_NO_HALO)) | _rs_tune_flags() | ((int(CONV_RS_NSPLIT) & 15) << 4) | (int(CONV_ABLATE) << 8)
+    ex.tune_flags = (int(bool(CONV_NO_HALO)) | 8 * int(bool(CONV_NO_PLAIN)) | ((int(CONV_RS_NSPLIT) & 15) << 4)
+                     | (int(CONV_ABLATE) << 8))
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -420,12 +430,11 @@ def conv2d(
   else:  # resolved after the sync: only the listed rows are multiplied / moved
     flops = lambda: kflops * int(row_count.item())
     nbytes = lambda: 4.0 * (int(row_count.item()) * (Cin + Cout) + w.numel())
-  rs = (not ps and math == 'bf16x3' and KH == 1 and not CONV_NO_RS and rows_in is None
-        and rows_out is None and row_count is None
-        and bool(lib.snap_conv2d_row_stationary(ctypes.byref(d), 2, _rs_tune_flags())))
+  kind = (lib.snap_conv2d_stationary_kind(ctypes.byref(d), qparts)
+          if (qparts == 2 and KH == 1 and rows_in is None and rows_out is None and row_count is None) else 0)
   with _region(
       family, flops, nbytes,
-      lambda: f'{"PS_" if ps else "RS_" if rs else ""}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
+      lambda: f'{"PS_" if ps else ("", "RS_", "WS_")[kind]}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
               f'_s{stride}_p{prologue}_e{epi}',
   ):
     st = lib.snap_conv2d_nhwc_ex_f32(
@@ -436,7 +445,7 @@ def conv2d(
   _lib.check(st, 'snap_conv2d_nhwc_ex_f32')
   if partial is not None:
     tile_rows = (lib.snap_conv2d_presplit_tile_rows(ctypes.byref(d), pst) if ps
-                 else lib.snap_conv2d_tile_rows(ctypes.byref(d)))
+                 else lib.snap_conv2d_tile_rows_ex(ctypes.byref(d), qparts))
     y._snap_gn_partial = (partial, tile_rows, emit_gn_stats == 'relu')
     if partial2 is not None and ex.gn_partial2_done:
       y._snap_gn_partial_relu = (partial2, y._snap_gn_partial[1], True)

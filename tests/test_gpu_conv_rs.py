@@ -1,10 +1,11 @@
-"""`-m gpu` tests of the row-stationary 1 x 1 kernel (conv_rs.hip).
+"""`-m gpu` tests of the stationary-operand 1 x 1 kernels (conv_rs.hip): row-stationary
+(activation tile in registers) and weights-stationary (weight panel resident in LDS).
 
-It multiplies exactly the operands the tiled split engine (conv_split.hip) builds -- same
+Both multiply exactly the operands the tiled split engine (conv_split.hip) builds -- same
 GroupNorm arithmetic, same split, same slab order, same product order per accumulator, residual
 added after the sum -- so against that engine (``ops.CONV_NO_RS = True``) the OUTPUT is compared
-bit for bit; the GroupNorm statistics it emits are summed in another order and are compared with
-the stand-alone statistics pass and the oracle.
+bit for bit; the GroupNorm statistics they emit are summed in another order (the
+weights-stationary kernel: per 32-row slab) and are compared with the oracle.
 """
 import numpy as np
 import pytest
@@ -37,6 +38,7 @@ def _engine():
   ops.CONV_TILE = prev_tile
   ops.CONV_RS_FORCE = False
   ops.CONV_NO_RS = False
+  ops.CONV_NO_WS = False
 
 
 def _layer(N, H, W, Cin, Cout, seed, residual):
@@ -48,14 +50,19 @@ def _layer(N, H, W, Cin, Cout, seed, residual):
   return x, w, res, g_in, b_in
 
 
-def _takes_rs(N, H, W, Cin, Cout, residual):
+def _kind(N, H, W, Cin, Cout, residual):
+  """0 = tiled body, 1 = row-stationary, 2 = weights-stationary (under the current ops.CONV_* switches)."""
   from snap_amd import _lib
   import ctypes
   d = _lib.SnapConvDesc(N=N, H=H, W=W, Cin=Cin, Cin_stride=Cin, KH=1, KW=1, stride=1, pad_t=0, pad_l=0,
                         Ho=H, Wo=W, Cout=Cout, Cout_stride=Cout, prologue=ops.PRO_GN_RELU,
                         epilogue=ops.EPI_RESIDUAL if residual else 0, in_scale=1.0, in_shift=0.0,
-                        tile_hint=128128)
-  return bool(_lib.load().snap_conv2d_row_stationary(ctypes.byref(d), 2, ops._rs_tune_flags()))
+                        tile_hint=128128 + 1000000 * ops._stationary_mode())
+  return int(_lib.load().snap_conv2d_stationary_kind(ctypes.byref(d), 2))
+
+
+def _takes_rs(*a):
+  return _kind(*a) != 0
 
 
 def _run(x, w, res, g_in, b_in, emit, no_rs, relu=False):
@@ -77,6 +84,7 @@ def _run(x, w, res, g_in, b_in, emit, no_rs, relu=False):
 CASES = [
     (3, 20, 23, 64, 256, True),
     (2, 31, 29, 64, 512, False),
+    (7, 9, 11, 64, 256, True),           # 99 pixels per image: 32-row tiles straddle images all the time (ws only)
     (5, 16, 17, 128, 512, True),
     (2, 40, 37, 128, 256, False),
     (3, 23, 17, 256, 1024, True),
@@ -87,10 +95,17 @@ CASES = [
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,residual', CASES)
 @pytest.mark.parametrize('emit', [None, 'raw', 'both'])
-def test_row_stationary_equals_the_tiled_engine(N, H, W, Cin, Cout, residual, emit):
+@pytest.mark.parametrize('kernel', ['ws', 'rs'])
+def test_stationary_kernels_equal_the_tiled_engine(N, H, W, Cin, Cout, residual, emit, kernel):
   if emit is not None and N == 40:
     pytest.skip('one statistics variant at full size is enough')
-  assert _takes_rs(N, H, W, Cin, Cout, residual)
+  ops.CONV_NO_WS = kernel == 'rs'
+  want = 1 if (kernel == 'rs' or Cin == 256 or Cout % 256) else 2
+  if kernel == 'ws' and want == 1:
+    pytest.skip('the weights-stationary kernel does not take this shape (covered by the rs case)')
+  if kernel == 'rs' and H * W < 128:
+    pytest.skip('a 128-row tile would touch more than two images')
+  assert _kind(N, H, W, Cin, Cout, residual) == want
   layer = _layer(N, H, W, Cin, Cout, 1000 + Cin + Cout, residual)
   y_rs = _run(*layer, emit, no_rs=False)
   y_t = _run(*layer, emit, no_rs=True)
@@ -108,7 +123,9 @@ def test_row_stationary_equals_the_tiled_engine(N, H, W, Cin, Cout, residual, em
     helpers.report(f'rs stats sc relu_first={relu_first}', sc_f, sc_w, atol=1e-5, rtol=5e-5)
 
 
-def test_row_stationary_against_the_oracle_and_relu_epilogue():
+@pytest.mark.parametrize('kernel', ['ws', 'rs'])
+def test_stationary_kernels_against_the_oracle_and_relu_epilogue(kernel):
+  ops.CONV_NO_WS = kernel == 'rs'
   x, w, res, g_in, b_in = _layer(2, 19, 21, 128, 512, 77, True)
   y = _run(x, w, res, g_in, b_in, None, no_rs=False, relu=True)
   mu, sc = oracle_ops.group_norm_stats(x, g_in)
@@ -122,9 +139,13 @@ def test_shapes_outside_the_kernel_take_the_tiled_engine():
   assert not _takes_rs(2, 17, 17, 512, 1024, True)
   ops.CONV_RS_FORCE = False
   assert not _takes_rs(8, 34, 34, 256, 1024, True)      # too few rows to pay (the aerial encoder)
-  assert _takes_rs(40, 34, 34, 256, 1024, True)
+  assert _kind(40, 34, 34, 256, 1024, True) == 1        # Cin = 256: the panel does not fit LDS
+  assert _kind(40, 68, 68, 128, 512, True) == 2
   ops.CONV_RS_FORCE = True
+  ops.CONV_NO_WS = True
   assert not _takes_rs(3, 11, 11, 64, 256, True)        # fewer than 128 pixels per image (a row tile: two images at most)
+  ops.CONV_NO_WS = False
+  assert not _takes_rs(3, 5, 5, 64, 256, True)          # ... fewer than 32 for the weights-stationary kernel
   assert not _takes_rs(3, 20, 20, 64, 128, True)        # a single column tile
   assert not _takes_rs(3, 20, 20, 256, 256, True)       # Cin = 256 pays from Cout = 512
   x, w, res, g_in, b_in = _layer(2, 17, 17, 512, 1024, 88, True)

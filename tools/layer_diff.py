@@ -11,8 +11,8 @@ def agg(path):
     if not fam.startswith('conv'):
       continue
     for tag, ms, fl, by in rows:
-      t = tag.replace('RS_', '').replace('PS_', '')
-      x = a.setdefault(t, [0, 0.0, 0.0, 0.0, tag[:3] if tag[:3] in ('RS_', 'PS_') else ''])
+      t = tag.replace('RS_', '').replace('PS_', '').replace('WS_', '')
+      x = a.setdefault(t, [0, 0.0, 0.0, 0.0, tag[:3] if tag[:3] in ('RS_', 'PS_', 'WS_') else ''])
       x[0] += 1; x[1] += ms; x[2] += fl; x[3] += by
   return a, {k: sum(x[1] for x in v) for k, v in d.items()}
 

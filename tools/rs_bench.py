@@ -39,8 +39,9 @@ def main():
     beta = torch.zeros(Cin, device=dev)
     mu, sc = ops.group_norm_stats(x, gamma)
     row = {'shape': [N, H, W, Cin, Cout]}
-    for name, no_rs in (('tiled', True), ('rs', False)):
+    for name, no_rs, no_ws in (('tiled', True, False), ('rs', False, True), ('ws', False, False)):
       ops.CONV_NO_RS = no_rs
+      ops.CONV_NO_WS = no_ws
       kw = dict(prologue=ops.PRO_GN_RELU, gn=(mu, sc, beta), residual=res,
                 emit_gn_stats=None if args.stats == 'none' else args.stats)
       for _ in range(3):
@@ -58,6 +59,7 @@ def main():
       row[name] = {'ms': round(ms, 4), 'TF': round(2.0 * M * Cin * Cout / ms / 1e9, 1),
                    'TBs': round(byt / ms / 1e9, 2)}
     ops.CONV_NO_RS = False
+    ops.CONV_NO_WS = False
     print(json.dumps(row), flush=True)
     out.append(row)
 
