@@ -221,7 +221,24 @@ __global__ __launch_bounds__(256) void gn_finalize_tiled_kernel(
   const int live = (int)((((int64_t)(n + 1) * HW - 1) / tile_rows) - (((int64_t)n * HW) / tile_rows)) + 1;
   const int count = live * cpg;
   double t1 = 0.0, t2 = 0.0;
-  for (int e = threadIdx.x; e < count; e += 256) {
+  // four entries in flight per thread (the weights-stationary conv kernel emits 32-row slabs: up to
+  // ~4600 entries per (image, group)); the order of the sum per thread is unchanged
+  int e = threadIdx.x;
+  for (; e + 768 < count; e += 1024) {
+    float2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ee = e + 256 * u;
+      const int s = ee / cpg, cc = ee - s * cpg;
+      v[u] = *reinterpret_cast<const float2*>(partial + (((int64_t)n * S + s) * C + c_lo + cc) * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      t1 += (double)v[u].x;
+      t2 += (double)v[u].y;
+    }
+  }
+  for (; e < count; e += 256) {
     const int s = e / cpg, cc = e - s * cpg;
     const float* pp = partial + (((int64_t)n * S + s) * C + c_lo + cc) * 2;
     t1 += (double)pp[0];
