@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(
 }  // namespace
 
 int snapconv::launch_bf16(ConvArgs a, hipStream_t s) {
-  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint);
+  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint, desc_k(a.d));
   if (t.bm == 128 && t.bn == 128) return launch_pro<128, 128>(a, s);
   if (t.bm == 128) return launch_pro<128, 64>(a, s);
   if (t.bn == 128) return launch_pro<64, 128>(a, s);

@@ -330,14 +330,22 @@ struct TileChoice { int bm, bn; };
 // threshold, 3 = no weights-stationary kernel, 4 = 2 and 3
 inline int hint_tile(int h) { return h % 1000000; }
 inline int hint_mode(int h) { return h / 1000000; }
-// forced = SnapConvDesc.tile_hint
-inline TileChoice choose_tile(int64_t M, int64_t N, int forced) {
+// forced = SnapConvDesc.tile_hint; K = KH * KW * Cin.  Deep reductions over few rows (the 3 x 3
+// layers of the aerial encoder and of the last StreetView stage: K >= 2304) keep the 128 x 128 tile
+// and fill the machine by split-K instead of shrinking the tile: measured 0.098 -> 0.068 ms
+// (8 x 34 x 34, 3x3 256 -> 256), 0.087 -> 0.076 (8 x 17 x 17, 3x3 512 -> 512), 0.234 -> 0.208
+// (40 x 17 x 17), tools/conv3x3_small_bench.py; in the C2 step these layers 1.65 -> 1.24 ms.  (From
+// K = 1024 the 1 x 1 layers would switch too: level in time, and a split-K launch cannot emit the
+// GroupNorm partial sums -- the stand-alone statistics pass then costs what the 3 x 3 layers gain.)
+inline int64_t desc_k(const SnapConvDesc& d) { return (int64_t)d.KH * d.KW * d.Cin; }
+inline TileChoice choose_tile(int64_t M, int64_t N, int forced, int64_t K) {
   forced = hint_tile(forced);
   const int64_t kMin = 512;
   const bool n_wide_ok = N > 64 && !(N % 128 != 0 && N % 128 <= 64);
   if (forced != 128128 && forced != 128064 && forced != 64128 && forced != 64064) forced = 0;
   if (forced == 128128 || (!forced && n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin))
     return {128, 128};
+  if (!forced && n_wide_ok && K >= 2304 && M >= 128) return {128, 128};
   if (forced == 128064 || (!forced && snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)) return {128, 64};
   if (forced == 64128 ||
       (!forced && n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin))

@@ -529,7 +529,7 @@ int launch_pro(const ConvArgs& a, hipStream_t s) {
 
 template <bool VEC>
 int launch_tile(const ConvArgs& a, hipStream_t s) {
-  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint);
+  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint, desc_k(a.d));
   const bool deep = VEC && a.bk == 32 && a.d.Cin >= 32;
   if (t.bm == 128 && t.bn == 128) {
     if constexpr (VEC) {
@@ -564,7 +564,7 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
 extern "C" int32_t snap_conv2d_tile_rows_ex(const SnapConvDesc* desc, int32_t split_parts) {
   if (!desc) return 0;
   if (snapconv::stationary_kind(*desc, split_parts, false) == 2) return 32;
-  return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint).bm;
+  return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint, desc_k(*desc)).bm;
 }
 
 extern "C" size_t snap_conv2d_gn_partial_bytes_ex(const SnapConvDesc* desc, int32_t split_parts) {
@@ -584,7 +584,7 @@ extern "C" size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc) {
   if (!desc) return 0;
   const SnapConvDesc& d = *desc;
   const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
-  const TileChoice t = choose_tile(M, d.Cout, d.tile_hint);
+  const TileChoice t = choose_tile(M, d.Cout, d.tile_hint, desc_k(d));
   const int64_t tiles = snap_cdiv(M, t.bm) * snap_cdiv((int64_t)d.Cout, t.bn);
   const int target = splitk_target();
   const int64_t nk = (int64_t)d.KH * d.KW * ((d.Cin + 15) / 16);

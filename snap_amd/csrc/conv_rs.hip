@@ -828,7 +828,7 @@ int snapconv::stationary_kind(const SnapConvDesc& d, int parts, bool row_lists) 
   if (HoWo < SNAP_RS_NT / 2) return 0;                           // at most two images per row tile
   if (d.N * (HoWo / 128 + 2) * (int64_t)d.Cout * 8 >= 0x7ff00000LL) return 0;
   // the row tile (and with it the statistics layout) must be the tiled engine's
-  if (choose_tile(M, d.Cout, d.tile_hint).bm != 128) return 0;
+  if (choose_tile(M, d.Cout, d.tile_hint, desc_k(d)).bm != 128) return 0;
   return 1;
 }
 

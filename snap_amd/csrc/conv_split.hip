@@ -476,7 +476,9 @@ __device__ __forceinline__ void conv3x3_halo_body(const ConvArgs& a) {
   const int wr = wid >> 1, wc = wid & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int ncol = a.ncol;
-  const int bid = blockIdx.x;
+  // split-K (small-M layers): split `split` takes the channel tiles [ct_begin, ct_end), all nine taps
+  const int split = a.ksplit > 1 ? blockIdx.x / a.tiles_per_split : 0;
+  const int bid = a.ksplit > 1 ? blockIdx.x - split * a.tiles_per_split : blockIdx.x;
   const int xcd = bid & 7;
   const int seq = bid >> 3;
   const int col_t = seq % ncol;
@@ -605,10 +607,12 @@ __device__ __forceinline__ void conv3x3_halo_body(const ConvArgs& a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // prologue: table + halo of channel tile 0, weights of slab (0, tap 0)
-  issue_gn(0, 0);
-  load_halo(0);
-  issue_b(0, 0, 0);
+  // prologue: table + halo of the first channel tile, weights of its slab (tap 0)
+  const int ct_begin = a.ksplit > 1 ? split * a.slabs_per_split : 0;          // (here: channel tiles per split)
+  const int ct_end = a.ksplit > 1 ? min(ctiles, ct_begin + a.slabs_per_split) : ctiles;
+  issue_gn(0, ct_begin);
+  load_halo(ct_begin);
+  issue_b(0, ct_begin, 0);
   if constexpr (need_gn) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -618,9 +622,9 @@ __device__ __forceinline__ void conv3x3_halo_body(const ConvArgs& a) {
   __syncthreads();
 
   int bcur = 0;
-  for (int ct = 0; ct < ctiles; ++ct) {
-    const int hb = ct & 1;
-    const bool more_ct = ct + 1 < ctiles;
+  for (int ct = ct_begin; ct < ct_end; ++ct) {
+    const int hb = (ct - ct_begin) & 1;
+    const bool more_ct = ct + 1 < ct_end;
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
       const bool last = !more_ct && t == 8;
@@ -685,7 +689,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const ConvArgs& a) {
       bcur ^= 1;
     }
   }
-  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, 0);
+  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
 template <int BN, int PRO, int NS, int HPMAX>
@@ -693,7 +697,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 2) void conv3x3_halo_kernel(cons
   conv3x3_halo_body<BN, PRO, NS, HPMAX>(a);
 }
 
-// the halo body takes: 3x3, stride 1, pad 1, whole 16-channel tiles, plain row order, no split-K,
+// the halo body takes: 3x3, stride 1, pad 1, whole 16-channel tiles, plain row order (split-K by
+// channel tiles),
 // images at least as large as the stage (BM + 2W + 2 pixels: the stage then touches <= 2 images)
 inline bool halo_ok(const ConvArgs& a) {
   const bool on = !a.no_halo;                      // (SNAP_TUNE_NO_HALO: im2col body for every 3x3)
@@ -701,7 +706,7 @@ inline bool halo_ok(const ConvArgs& a) {
   const int hp = 128 + 2 * d.W + 2;
   return on && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 &&
          d.Ho == d.H && d.Wo == d.W && d.Cin % 16 == 0 && !a.rows_in && !a.rows_out &&
-         !a.row_count && a.ksplit == 1 && hp <= 288 && d.H * d.W >= hp &&
+         !a.row_count && hp <= 288 && d.H * d.W >= hp &&
          (int64_t)d.N * d.H * d.W * d.Cin_stride < 0x7fffffffLL &&
          (d.prologue == SNAP_PRO_GN_RELU || d.prologue == SNAP_PRO_NONE);
 }
@@ -760,6 +765,29 @@ int launch(ConvArgs a, hipStream_t s) {
   const dim3 grid((unsigned)nblocks);
   if constexpr (BM == 128 && (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_NONE)) {
     if (halo_ok(a)) {
+      if (a.ksplit > 1) {
+        // split by whole channel tiles (the halo body stages a channel tile once for its nine taps)
+        const int per = (a.ctiles + a.ksplit - 1) / a.ksplit;
+        ConvArgs h = a;
+        h.slabs_per_split = per;
+        h.ksplit = (a.ctiles + per - 1) / per;
+        if (h.ksplit > 1) {
+          const dim3 hgrid((unsigned)(h.tiles_per_split * h.ksplit));
+          launch_halo<BN, PRO, NS>(h, hgrid, s);
+          SNAP_CHECK_LAUNCH();
+          const int64_t total4 = (int64_t)h.M * (h.d.Cout / 4);
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
+                             (const float*)h.kpartial, h.ksplit, (int64_t)h.M, h.d.Cout, h.d.Cout_stride,
+                             h.d.epilogue, h.bias, h.residual, h.row_mask, h.y);
+          SNAP_CHECK_LAUNCH();
+          return SNAP_OK;
+        }
+        h.ksplit = 1;
+        h.slabs_per_split = h.nk;
+        launch_halo<BN, PRO, NS>(h, dim3((unsigned)h.tiles_per_split), s);
+        SNAP_CHECK_LAUNCH();
+        return SNAP_OK;
+      }
       launch_halo<BN, PRO, NS>(a, grid, s);
       SNAP_CHECK_LAUNCH();
       return SNAP_OK;
@@ -829,7 +857,7 @@ int launch_pro(const ConvArgs& a, hipStream_t s) {
 
 template <int NS>
 int launch_tile(const ConvArgs& a, hipStream_t s) {
-  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint);
+  const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint, desc_k(a.d));
   if (t.bm == 128 && t.bn == 128) return launch_pro<128, 128, NS>(a, s);
   if (t.bm == 128) return launch_pro<128, 64, NS>(a, s);
   if (t.bn == 128) return launch_pro<64, 128, NS>(a, s);
