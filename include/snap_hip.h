@@ -137,6 +137,12 @@ typedef struct SnapConvExtras {
                                  (r + p1 + p2 + ... instead of (p1 + p2 + ...) + r) */
   int32_t bk_hint;            /* f32 engine: K-slab depth 16 | 32 of the large tiles (0 = default 16) */
   int32_t tune_flags;         /* SNAP_TUNE_*: A/B switches for tests and tuning tools (0 = defaults) */
+  int32_t gn_partial_rows;    /* 0: gn_partial is laid out per row tile of the launch
+                                 (snap_conv2d_tile_rows_ex); 32: per 32-row slab, sized by
+                                 snap_conv2d_splitk_gn_partial_bytes -- a split-K launch of the
+                                 split-operand engine (workspace given), whose reduce pass then emits
+                                 the partial sums (a split-K launch has no epilogue that sees
+                                 finished outputs) */
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
@@ -284,6 +290,7 @@ int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc);   /* row-tile height th
  * GroupNorm partial sums per 32-row slab. */
 int32_t snap_conv2d_tile_rows_ex(const SnapConvDesc* desc, int32_t split_parts);
 size_t snap_conv2d_gn_partial_bytes_ex(const SnapConvDesc* desc, int32_t split_parts);
+size_t snap_conv2d_splitk_gn_partial_bytes(const SnapConvDesc* desc);   /* see SnapConvExtras.gn_partial_rows */
 /* Which body a split-bf16 launch (w_split_parts parts, no row lists) of this descriptor takes:
  * 0 = the tiled body, 1 = the row-stationary 1x1 kernel (activation tile in registers), 2 = the
  * weights-stationary 1x1 kernel (panel resident in LDS) -- conv_rs.hip: the bottleneck units' closing

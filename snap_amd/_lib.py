@@ -39,7 +39,7 @@ class SnapConvExtras(ctypes.Structure):
       ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
       ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
       ('x_presplit', c_int), ('ps_tile', c_int), ('ps_res_init', c_int),
-      ('bk_hint', c_int), ('tune_flags', c_int),
+      ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int),
   ]
 
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     'snap_conv2d_stationary_kind': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_tile_rows_ex': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_gn_partial_bytes_ex': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
+    'snap_conv2d_splitk_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_presplit_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_presplit_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_presplit_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),

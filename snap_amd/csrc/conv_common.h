@@ -34,6 +34,7 @@ struct ConvArgs {
   float* gn_partial2;        // optional, with gn_partial (gn_relu = 0): the same sums of relu(y)
   int32_t* gn_partial2_done; // HOST pointer (launcher only): 1 when the launch emits gn_partial2
   int gn_relu;               // ... of relu(y) (FPN order)
+  int gn_rows32;             // gn_partial is laid out per 32-row slab (split-K launches: the reduce pass emits it)
   int gn_slabs;              // row tiles per image in gn_partial (= HoWo / BM + 2)
   int M;       // N*Ho*Wo  (upper bound of the row count when row_count is set)
   int K;       // KH*KW*Cin
@@ -137,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
   // GroupNorm statistics of the OUTPUT (consumed by the next layer's fused GN prologue):
   // every thread owns 4 fixed columns (NT % Q == 0), accumulates sum / sum of squares of
   // what it stores, split by image (a tile of BM <= HoWo rows touches at most two).
-  const bool want_stats = a.gn_partial != nullptr;
+  const bool want_stats = a.gn_partial != nullptr && a.ksplit == 1;   // (split-K: the reduce pass emits them)
   const int n_first = m0 / HoWo;
   const int m_split = (n_first + 1) * HoWo;   // first row of the second image
   float gs1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -312,6 +313,120 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   }
   if ((epi & SNAP_EPI_ROWMASK) && row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
   *reinterpret_cast<f32x4*>(y + o) = v;
+}
+
+// The same reduce for a launch that also owes GroupNorm partial sums (a split-K launch has no
+// epilogue that sees finished outputs): one workgroup = 32 consecutive rows x all columns, a thread =
+// a column quad and every PW-th row; the sums of what is stored leave per (image, 32-ROW slab,
+// channel) in conv_epilogue's layout (tile_rows = 32), reduced over the row lanes in a fixed order.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(
+    const float* __restrict__ partial, int S, int64_t M, int Cout, int epi,
+    const float* __restrict__ bias, const float* __restrict__ residual,
+    const uint8_t* __restrict__ row_mask, float* __restrict__ y, int HoWo, int N, int gn_slabs,
+    int gn_relu, float* __restrict__ gn_partial) {
+  __shared__ float red[256 * 16];
+  const int Q = Cout >> 2;
+  const int QW = Q < 256 ? Q : 256;                   // column quads in flight (Cout % 4 == 0; Q | 256 or Q >= 256)
+  const int PW = 256 / QW;                            // row lanes
+  const int tq = threadIdx.x % QW, tp = threadIdx.x / QW;
+  const int64_t m0 = (int64_t)blockIdx.x * 32;
+  const int n_first = (int)(m0 / HoWo);
+  const int64_t m_split = (int64_t)(n_first + 1) * HoWo;
+  for (int q0 = 0; q0 < Q; q0 += QW) {
+    const int q = q0 + tq;
+    const int col = 4 * q;
+    float s1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (q < Q && tp < PW) {
+      for (int r = tp; r < 32; r += PW) {
+        const int64_t m = m0 + r;
+        if (m >= M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(partial + m * Cout + col);
+        for (int sp = 1; sp < S; ++sp) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(partial + ((int64_t)sp * M + m) * Cout + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += t[e];
+        }
+        const int64_t o = m * Cout + col;
+        if (epi & SNAP_EPI_BIAS) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bb[e];
+        }
+        if (epi & SNAP_EPI_RESIDUAL) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(residual + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+        }
+        if (epi & SNAP_EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (epi & SNAP_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = snap_gelu_tanh(v[e]);
+        }
+        if ((epi & SNAP_EPI_ROWMASK) && row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(y + o) = v;
+        const int sl = m >= m_split ? 1 : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = gn_relu ? fmaxf(v[e], 0.f) : v[e];
+          s1[sl][e] += t;
+          s2[sl][e] += t * t;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[threadIdx.x * 16 + sl * 8 + e] = s1[sl][e];
+        red[threadIdx.x * 16 + sl * 8 + 4 + e] = s2[sl][e];
+      }
+    __syncthreads();
+    // one writer per (slot, column quad): fixed order over the row lanes
+    if (tp == 0 && q < Q) {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int n = n_first + sl;
+        const bool live = n < N && (sl == 0 || (m0 + 32 > m_split && m_split < M));
+        if (!live) continue;
+        const int slab = (int)(blockIdx.x - (((int64_t)n * HoWo) >> 5));
+        float* o = gn_partial + (((int64_t)n * gn_slabs + slab) * Cout + col) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int pp = 0; pp < PW; ++pp) {
+            t1 += red[(pp * QW + tq) * 16 + sl * 8 + e];
+            t2 += red[(pp * QW + tq) * 16 + sl * 8 + 4 + e];
+          }
+          o[2 * e] = t1;
+          o[2 * e + 1] = t2;
+        }
+      }
+    }
+  }
+}
+
+// the closing pass of a split-K launch (with the GroupNorm partial sums where the launch owes them)
+inline int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
+  if (a.gn_partial) {
+    if (!a.gn_rows32 || (a.d.Cout & 3) || (256 % ((a.d.Cout >> 2) < 256 ? (a.d.Cout >> 2) : 256)) != 0)
+      return SNAP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)snap_cdiv((int64_t)a.M, 32)), dim3(256), 0, s,
+                       (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.epilogue, a.bias,
+                       a.residual, a.row_mask, a.y, a.d.Ho * a.d.Wo, a.d.N, (a.d.Ho * a.d.Wo) / 32 + 2,
+                       a.gn_relu, a.gn_partial);
+  } else {
+    const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
+                       (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.Cout_stride,
+                       a.d.epilogue, a.bias, a.residual, a.row_mask, a.y);
+  }
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
 }
 
 // split-K heuristic: launches with at most splitk_max_tiles() output tiles (1.5 per CU)

@@ -580,6 +580,18 @@ extern "C" size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc) {
   return snap_conv2d_gn_partial_bytes_ex(desc, 0);
 }
 
+// ... of a SPLIT-K launch of the split-operand engine (snap_conv2d_workspace_bytes(desc) > 0 and the
+// workspace passed): partial sums per 32-row slab out of the reduce pass (SnapConvExtras.gn_partial_rows
+// = 32; snap_group_norm_stats_from_partial_f32 with tile_rows = 32).  0 = not available for this shape.
+extern "C" size_t snap_conv2d_splitk_gn_partial_bytes(const SnapConvDesc* desc) {
+  if (!desc || snap_conv2d_workspace_bytes(desc) == 0) return 0;
+  const SnapConvDesc& d = *desc;
+  const int64_t HoWo = (int64_t)d.Ho * d.Wo;
+  const int q = d.Cout >> 2;
+  if (HoWo < 32 || (d.Cout & 3) || d.Cout_stride != d.Cout || 256 % (q < 256 ? q : 256) != 0) return 0;
+  return (size_t)d.N * (HoWo / 32 + 2) * d.Cout * 2 * sizeof(float);
+}
+
 extern "C" size_t snap_conv2d_workspace_bytes(const SnapConvDesc* desc) {
   if (!desc) return 0;
   const SnapConvDesc& d = *desc;
@@ -646,7 +658,14 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
     return SNAP_ERR_UNSUPPORTED;  // row-indexed launches carry bias / ReLU only
   const bool presplit = ex && ex->x_presplit;
   const bool split_vec = ex && ex->w_bf16 && !ex->w_split_root && !rows_in && !rows_out && !row_count;
+  // gn_partial_rows = 32: a split-K launch of the split engine (workspace given), whose reduce pass
+  // emits the sums per 32-row slab
+  const bool rows32 = gn_partial && ex->gn_partial_rows == 32;
+  if (gn_partial && ex->gn_partial_rows != 0 && ex->gn_partial_rows != 32) return SNAP_ERR_BAD_SHAPE;
+  if (rows32 && (presplit || !split_vec || ex->w_split_parts < 2 || !ex->workspace || ex->gn_partial2))
+    return SNAP_ERR_UNSUPPORTED;
   const size_t gn_need = !gn_partial ? 0
+                         : rows32    ? snap_conv2d_splitk_gn_partial_bytes(desc)
                          : presplit  ? snap_conv2d_presplit_gn_partial_bytes(desc, ex->ps_tile)
                                      : snap_conv2d_gn_partial_bytes_ex(desc, split_vec ? ex->w_split_parts : 0);
   if (gn_partial) {
@@ -683,6 +702,7 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.rows_in = rows_in; a.rows_out = rows_out; a.row_count = row_count;
   a.gn_partial = gn_partial;
   a.gn_relu = ex ? ex->gn_partial_relu : 0;
+  a.gn_rows32 = rows32 ? 1 : 0;
   a.gn_partial2 = nullptr;
   a.gn_partial2_done = nullptr;
   if (gn_partial && ex->gn_partial2) {

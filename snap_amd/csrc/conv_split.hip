@@ -746,7 +746,7 @@ int launch(ConvArgs a, hipStream_t s) {
   const int64_t tiles = nrow * a.ncol;
   const int target = splitk_target();
   if (a.kpartial && target > 0 && tiles <= splitk_max_tiles() && a.nk >= 16 && !a.rows_in &&
-      !a.rows_out && !a.row_count && !a.gn_partial &&
+      !a.rows_out && !a.row_count && (!a.gn_partial || (a.gn_rows32 && a.d.Cout_stride == a.d.Cout)) &&
       !(a.d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) {
     int64_t S = (target + tiles - 1) / tiles;
     S = S < a.nk / 8 ? S : a.nk / 8;                        // >= 8 slabs (128 k) per split
@@ -758,6 +758,7 @@ int launch(ConvArgs a, hipStream_t s) {
       nblocks *= a.ksplit;
     }
   }
+  if (a.gn_partial && a.gn_rows32 && a.ksplit == 1) return SNAP_ERR_WORKSPACE;   // (the caller sized for a split-K launch)
   constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
   // the LDS statistics table needs "a row tile touches at most two images"
   const bool table_ok = !need_gn || (a.d.Ho * a.d.Wo >= BM && !a.rows_in);
@@ -775,13 +776,9 @@ int launch(ConvArgs a, hipStream_t s) {
           const dim3 hgrid((unsigned)(h.tiles_per_split * h.ksplit));
           launch_halo<BN, PRO, NS>(h, hgrid, s);
           SNAP_CHECK_LAUNCH();
-          const int64_t total4 = (int64_t)h.M * (h.d.Cout / 4);
-          hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
-                             (const float*)h.kpartial, h.ksplit, (int64_t)h.M, h.d.Cout, h.d.Cout_stride,
-                             h.d.epilogue, h.bias, h.residual, h.row_mask, h.y);
-          SNAP_CHECK_LAUNCH();
-          return SNAP_OK;
+          return launch_splitk_reduce(h, s);
         }
+        if (h.gn_partial) return SNAP_ERR_UNSUPPORTED;     // (cannot happen: nk >= 16 gives >= 2 channel tiles)
         h.ksplit = 1;
         h.slabs_per_split = h.nk;
         launch_halo<BN, PRO, NS>(h, dim3((unsigned)h.tiles_per_split), s);
@@ -816,14 +813,7 @@ int launch(ConvArgs a, hipStream_t s) {
     if (plain && (!need_gn || table_ok)) {
       hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, need_gn, false, false, true>), grid, dim3(256), 0, s, a);
       SNAP_CHECK_LAUNCH();
-      if (a.ksplit > 1) {
-        const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
-                           (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.Cout_stride,
-                           a.d.epilogue, a.bias, a.residual, a.row_mask, a.y);
-        SNAP_CHECK_LAUNCH();
-      }
-      return SNAP_OK;
+      return a.ksplit > 1 ? launch_splitk_reduce(a, s) : SNAP_OK;
     }
   }
   if (need_gn && table_ok)           // (GroupNorm operands are per channel QUAD: Cin % 4 == 0)
@@ -833,14 +823,7 @@ int launch(ConvArgs a, hipStream_t s) {
   else
     hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, false, false>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
-  if (a.ksplit > 1) {
-    const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
-                       (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.Cout_stride,
-                       a.d.epilogue, a.bias, a.residual, a.row_mask, a.y);
-    SNAP_CHECK_LAUNCH();
-  }
-  return SNAP_OK;
+  return a.ksplit > 1 ? launch_splitk_reduce(a, s) : SNAP_OK;
 }
 
 template <int BM, int BN, int NS>

@@ -199,6 +199,7 @@ CONV_NO_RS = False      # tools / tests: the tiled body also where a stationary 
 CONV_RS_NSPLIT = 0      # tools: forced column split of the row-stationary kernel (0 = automatic)
 CONV_RS_FORCE = False   # tests: the stationary kernels also below their row-count threshold
 CONV_NO_WS = False      # tools / tests: no weights-stationary kernel (the row-stationary one where it applies)
+SPLITK_STATS = True     # split-K launches of the split engine emit GroupNorm partial sums from their reduce pass
 CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
 CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
 USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
@@ -362,6 +363,7 @@ def conv2d(
   ex = None
   partial = partial2 = None
   kws = None
+  rows32 = False
   if rows_in is not None or rows_out is not None or row_count is not None:
     ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0,
                              None, 0)
@@ -371,9 +373,19 @@ def conv2d(
       wbytes = lib.snap_conv2d_presplit_workspace_bytes(ctypes.byref(d), pst) if USE_SPLITK else 0
     else:
       wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if USE_SPLITK else 0
-    if wbytes:   # small-M / deep-K layer: split K (its statistics are cheap to take after)
+    if wbytes:   # small-M / deep-K layer: split K
       kws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes, None, 0)
+      if emit_gn_stats is not None and qparts >= 2 and SPLITK_STATS:
+        # the split engine's reduce pass emits the partial sums (per 32-row slab)
+        pbytes = lib.snap_conv2d_splitk_gn_partial_bytes(ctypes.byref(d))
+        if pbytes:
+          partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
+          ex.gn_partial = partial.data_ptr()
+          ex.gn_partial_bytes = pbytes
+          ex.gn_partial_relu = int(emit_gn_stats == 'relu')
+          ex.gn_partial_rows = 32
+          rows32 = True
     elif emit_gn_stats is not None:
       pbytes = (lib.snap_conv2d_presplit_gn_partial_bytes(ctypes.byref(d), pst) if ps
                 else lib.snap_conv2d_gn_partial_bytes_ex(ctypes.byref(d), qparts))
@@ -444,7 +456,7 @@ def conv2d(
     )
   _lib.check(st, 'snap_conv2d_nhwc_ex_f32')
   if partial is not None:
-    tile_rows = (lib.snap_conv2d_presplit_tile_rows(ctypes.byref(d), pst) if ps
+    tile_rows = (32 if rows32 else lib.snap_conv2d_presplit_tile_rows(ctypes.byref(d), pst) if ps
                  else lib.snap_conv2d_tile_rows_ex(ctypes.byref(d), qparts))
     y._snap_gn_partial = (partial, tile_rows, emit_gn_stats == 'relu')
     if partial2 is not None and ex.gn_partial2_done:

@@ -351,6 +351,39 @@ def test_conv_emits_both_groupnorm_statistics(math):
     helpers.report(f'both stats sc relu_first={relu_first}', sc_f, sc_w, atol=1e-5, rtol=5e-5)
 
 
+@pytest.mark.parametrize('shape', [(8, 34, 34, 256, 256, 3), (3, 17, 19, 512, 512, 3), (5, 9, 7, 1024, 256, 1),
+                                   (2, 12, 12, 1024, 512, 1)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_split_k_launches_emit_groupnorm_statistics(shape, relu):
+  """Deep reductions over few rows run split-K; their reduce pass emits the GroupNorm partial sums
+  (per 32-row slab: tiles straddling images, ragged last tile, residual) -- the output is bitwise
+  what the launch without statistics writes, the statistics agree with the stand-alone pass."""
+  N, H, W, Cin, Cout, k = shape
+  x = rnd((N, H, W, Cin), 1200 + Cin)
+  w = rnd((k, k, Cin, Cout), 1201 + Cout, 1 / np.sqrt(k * k * Cin))
+  res = rnd((N, H, W, Cout), 1202)
+  g_in = rnd((Cin,), 1203) * 0.3 + 1
+  b_in = rnd((Cin,), 1204) * 0.3
+  xd = x.to(DEV)
+  mu, sc = ops.group_norm_stats(xd, g_in.to(DEV))
+  pad = ((k // 2, k // 2), (k // 2, k // 2))
+  kw = dict(padding=pad, prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)), residual=res.to(DEV), math='bf16x3')
+  y = ops.conv2d(xd, w.to(DEV), emit_gn_stats='relu' if relu else 'raw', **kw)
+  assert getattr(y, '_snap_gn_partial', (None, 0, None))[1] == 32, 'not a split-K launch with fused statistics'
+  ops.SPLITK_STATS = False
+  try:
+    y0 = ops.conv2d(xd, w.to(DEV), emit_gn_stats='raw', **kw)
+  finally:
+    ops.SPLITK_STATS = True
+  assert not hasattr(y0, '_snap_gn_partial')
+  assert torch.equal(y, y0)
+  gamma = rnd((Cout,), 1205) * 0.3 + 1
+  mu_f, sc_f = ops.group_norm_stats(y, gamma.to(DEV), relu_first=relu)
+  mu_w, sc_w = oracle_ops.group_norm_stats(y.cpu(), gamma, relu_first=relu)
+  helpers.report('split-K stats mu', mu_f, mu_w, atol=1e-5, rtol=1e-5)
+  helpers.report('split-K stats sc', sc_f, sc_w, atol=1e-5, rtol=5e-5)
+
+
 def test_conv_split_accuracy_class():
   """The split engines against float64 on a deep reduction (K = 4608), next to the exact f32
   engine: 'bf16x6' must sit in the f32 engine's error class (<= 2x its rms error), 'bf16x3'
