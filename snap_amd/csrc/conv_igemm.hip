@@ -563,7 +563,7 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
 //  two-part split engine emits its statistics per 32-row slab; 0 = any other engine)
 extern "C" int32_t snap_conv2d_tile_rows_ex(const SnapConvDesc* desc, int32_t split_parts) {
   if (!desc) return 0;
-  if (snapconv::stationary_kind(*desc, split_parts, false) == 2) return 32;
+  if (snapconv::stationary_kind(*desc, split_parts, false) >= 2) return 32;
   return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint, desc_k(*desc)).bm;
 }
 

@@ -773,6 +773,202 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bs_kernel(const ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same for the 3 x 3 / stride 1 / pad 1 convolution of the first ResNet stage (64 -> 64 channels,
+// 136 pixels wide: too wide for the halo body of conv_split.hip, so the tiled engine runs it as
+// im2col -- 9 x 4 slabs of weights re-streamed per 128 rows, 850 MB of L2 -> LDS traffic per launch
+// for 378 MB of input + output).  The split weight panel of all nine taps (36 slabs x 4 KB = 144 KB)
+// is resident in LDS; eight independent waves per CU; per tap a wave fetches its 32 pixels' rows of
+// that tap straight into the A-fragment layout (the taps of neighbouring pixels overlap: L1 / L2
+// serve them), normalises, zeroes the lanes whose tap falls outside the image (the reference pads
+// the NORMALISED tensor) and splits; the next tap's rows are in flight meanwhile.  Slab order = tap
+// major, channel tile minor, products lo-hi / hi-lo / hi-hi: the im2col body's, bit for bit.  No
+// staging tile (LDS is full): the epilogue stores straight from the MFMA layout (128-byte runs) and
+// takes the GroupNorm sums of a column from one lane's 16 rows + its partner half-wave.
+template <int STATS /* 0 none, 1 one set */>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) {
+  constexpr int NT = 512, NW = NT / 64;
+  constexpr int KS = 4, TAPS = 9, TN = 2, Cin = 64;
+  constexpr int B_PART = 2048, B_SLAB = 4096;
+  constexpr int kPanel = TAPS * KS * B_SLAB;      // 147456
+  constexpr int kTab = 5 * Cin;                   // floats per wave: [image][mu | sc][64], beta [64]
+  __shared__ __attribute__((aligned(16))) char panel[kPanel];
+  __shared__ __attribute__((aligned(16))) float tables[NW * kTab];
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Meff = a.M;
+  const int W = d.W, HW = d.H * d.W;
+
+  {
+    const char* const wt = static_cast<const char*>(a.w_bf16);
+#pragma unroll
+    for (int p = 0; p < kPanel / 16 / NT; ++p) {
+      const int q = tid + NT * p;                 // 16-byte piece: [slab][part][64 columns][2 octets]
+      const int sl = q >> 8, within = q & 255;
+      const int part = within >> 7, rem = within & 127;
+      const char* src = wt + (int64_t)sl * 8192 + part * 4096 + (rem >> 1) * 32 + (rem & 1) * 16;
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src, (lds_void_t*)(panel + 16 * q), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  float* const tab = tables + wid * kTab;
+  const int relu_out = d.epilogue & SNAP_EPI_RELU;
+  const int ntile = (Meff + 31) >> 5;
+  const int nwaves = gridDim.x * NW;
+  for (int t = blockIdx.x * NW + wid; t < ntile; t += nwaves) {
+    const int mw0 = 32 * t;
+    const int n_first = mw0 / HW;
+    const int m_split = (n_first + 1) * HW;
+    const bool straddle = mw0 + 32 > m_split && m_split < Meff;
+    // this lane's output pixel and the taps that stay inside its image
+    const int m = mw0 + l31;
+    const bool ok = m < Meff;
+    const int mm = ok ? m : mw0;
+    int tapmask = 0;
+    {
+      const int r = mm % HW;
+      const int y = r / W, x = r - y * W;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+        if (ok && yy >= 0 && yy < d.H && xx >= 0 && xx < W) tapmask |= 1 << tp;
+      }
+    }
+    // GroupNorm operands of the tile's (at most two) images -> the wave's table (wave-private)
+    for (int i = lane; i < kTab / 4; i += 64) {
+      const int seg = i / (Cin / 4), c = 4 * (i - seg * (Cin / 4));
+      const int n = min(n_first + (seg >> 1), d.N - 1);
+      const float* src = seg == 4 ? a.gn_beta + c : ((seg & 1) ? a.gn_sc : a.gn_mu) + (int64_t)n * Cin + c;
+      *reinterpret_cast<f32x4*>(tab + seg * Cin + c) = *reinterpret_cast<const f32x4*>(src);
+    }
+    const float* const px = a.x + (int64_t)mm * d.Cin_stride + 8 * lhi;
+    auto load_tap = [&](int tp, f32x4 (&xs)[KS][2]) {
+      // (a tap outside the image: the centre pixel's address -- loaded, never used)
+      const bool in = (tapmask >> tp) & 1;
+      const float* p = px + (in ? ((tp / 3 - 1) * W + (tp % 3 - 1)) * d.Cin_stride : 0);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        xs[s][0] = *reinterpret_cast<const f32x4*>(p + 16 * s);
+        xs[s][1] = *reinterpret_cast<const f32x4*>(p + 16 * s + 4);
+      }
+    };
+    f32x4 xa[KS][2], xb[KS][2];
+    load_tap(0, xa);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float* const tmu = tab + (mm >= m_split ? 2 * Cin : 0) + 8 * lhi;
+    const float* const tbe = tab + 4 * Cin + 8 * lhi;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    auto do_tap = [&](int tp, const f32x4 (&xs)[KS][2]) {
+      const bool in = (tapmask >> tp) & 1;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        u32x2 h[2], l[2];
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const int c = 16 * s + 4 * hq;
+          f32x4 v = xs[s][hq];
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(tmu + c);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(tmu + Cin + c);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(tbe + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pv = apply_pro<SNAP_PRO_GN_RELU>(v[e], mu[e], sc[e], be[e], d.in_scale, d.in_shift);
+            v[e] = in ? pv : 0.f;
+          }
+          split2(v, h[hq], l[hq]);
+        }
+        const u32x4 hh = {h[0][0], h[0][1], h[1][0], h[1][1]};
+        const u32x4 ll = {l[0][0], l[0][1], l[1][0], l[1][1]};
+        bf16x8 a_hi, a_lo;
+        __builtin_memcpy(&a_hi, &hh, 16);
+        __builtin_memcpy(&a_lo, &ll, 16);
+        const char* bs = panel + (tp * KS + s) * B_SLAB;
+        bf16x8 bv[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int C = j * 32 + l31;
+          const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+          bv[j][0] = *reinterpret_cast<const bf16x8*>(p0);
+          bv[j][1] = *reinterpret_cast<const bf16x8*>(p0 + B_PART);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bv[j][0], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][1], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][0], acc[j], 0, 0, 0);
+      }
+    };
+    // taps two at a time: the rows of the next tap travel while this one is converted / multiplied
+#pragma unroll 1
+    for (int tp = 0; tp < 8; tp += 2) {
+      load_tap(tp + 1, xb);
+      do_tap(tp, xa);
+      load_tap(tp + 2, xa);
+      do_tap(tp + 1, xb);
+    }
+    do_tap(8, xa);
+
+    // ---- epilogue straight from the MFMA layout: lane = column 32 j + l31, rows 8 (r >> 2) + 4 lhi + (r & 3)
+    float* const yb = a.y + (int64_t)mw0 * d.Cout_stride + l31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float v = acc[j][r];
+        if (relu_out) v = fmaxf(v, 0.f);
+        const bool live = mw0 + ri < Meff;
+        if (live) yb[(int64_t)ri * d.Cout_stride + 32 * j] = v;
+        if constexpr (STATS > 0) {
+          const float y0 = live ? v : 0.f;
+          const float tt = a.gn_relu ? fmaxf(y0, 0.f) : y0;
+          const bool second = straddle && mw0 + ri >= m_split;
+          s1a += second ? 0.f : tt;
+          s2a += second ? 0.f : tt * tt;
+          s1b += second ? tt : 0.f;
+          s2b += second ? tt * tt : 0.f;
+        }
+      }
+      if constexpr (STATS > 0) {
+        s1a += __shfl_xor(s1a, 32);
+        s2a += __shfl_xor(s2a, 32);
+        s1b += __shfl_xor(s1b, 32);
+        s2b += __shfl_xor(s2b, 32);
+        if (lhi == 0) {
+          const int col = 32 * j + l31;
+          {
+            const int slab = t - (int)(((int64_t)n_first * HW) >> 5);
+            *reinterpret_cast<float2*>(a.gn_partial + (((int64_t)n_first * a.gn_slabs + slab) * d.Cout + col) * 2) =
+                float2{s1a, s2a};
+          }
+          if (straddle && n_first + 1 < d.N) {
+            const int slab = t - (int)(((int64_t)(n_first + 1) * HW) >> 5);
+            *reinterpret_cast<float2*>(a.gn_partial + (((int64_t)(n_first + 1) * a.gn_slabs + slab) * d.Cout + col) * 2) =
+                float2{s1b, s2b};
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int KS, int TN, bool RES>
 int launch_rs_dual(const ConvArgs& a, dim3 grid, bool dual, hipStream_t s) {
   if (dual)
@@ -807,6 +1003,19 @@ int launch_bs_stats(const ConvArgs& a, dim3 grid, hipStream_t s) {
 int snapconv::stationary_kind(const SnapConvDesc& d, int parts, bool row_lists) {
   const int mode = hint_mode(d.tile_hint);
   if (parts != 2 || mode == 1 || row_lists) return 0;
+  // 3: the 3 x 3 of the first ResNet stage (64 -> 64 channels, images too wide for the halo body)
+  if (d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && d.H == d.Ho && d.W == d.Wo &&
+      d.Cin == 64 && d.Cout == 64 && d.Cout_stride == 64 && (d.Cin_stride & 3) == 0 &&
+      d.prologue == SNAP_PRO_GN_RELU && !(d.epilogue & ~SNAP_EPI_RELU) && mode != 3 && mode != 4) {
+    const int64_t HW3 = (int64_t)d.H * d.W, M3 = (int64_t)d.N * HW3;
+    // measured in the C2 step: 0.848 -> 0.807 ms over three launches at M = 739 840, 0.212 -> 0.223 at
+    // M = 147 968 (the kernel converts every pixel once per tap, as the im2col body does, and is bound
+    // by that VALU work: removing the weight stream alone buys 5 %)
+    if (128 + 2 * d.W + 2 > 288 && HW3 >= 32 && M3 <= 0x7fffffffLL && (M3 >= 400000 || mode == 2) &&
+        d.N * (HW3 / 32 + 2) * (int64_t)d.Cout * 8 < 0x7ff00000LL)
+      return 3;
+    return 0;
+  }
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad_t || d.pad_l || d.H != d.Ho || d.W != d.Wo)
     return 0;
   if (d.prologue != SNAP_PRO_GN_RELU) return 0;
@@ -836,6 +1045,17 @@ int snapconv::launch_bs(ConvArgs a, hipStream_t s) {
   const SnapConvDesc& d = a.d;
   a.gn_slabs = (d.Ho * d.Wo) / 32 + 2;
   a.ksplit = 1;
+  if (d.KH == 3) {                               // the first stage's 3 x 3 (stationary_kind == 3)
+    if (a.gn_partial2_done) *a.gn_partial2_done = 0;
+    const int64_t nt = snap_cdiv(a.M, 32);
+    const dim3 g3((unsigned)(nt / 8 < 256 ? (nt + 7) / 8 : 256));
+    if (a.gn_partial)
+      hipLaunchKernelGGL((conv3x3_ws64_kernel<1>), g3, dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((conv3x3_ws64_kernel<0>), g3, dim3(512), 0, s, a);
+    SNAP_CHECK_LAUNCH();
+    return SNAP_OK;
+  }
   if (a.gn_partial2_done) *a.gn_partial2_done = (a.gn_partial2 && a.gn_partial) ? 1 : 0;
   const int64_t ntile = snap_cdiv(a.M, 32);
   // one persistent workgroup per CU (the panel takes most of its LDS); fewer where the rows run out

@@ -973,7 +973,7 @@ int snapconv::launch_split_root(ConvArgs a, int parts, hipStream_t s) {
 int snapconv::launch_split(ConvArgs a, int parts, hipStream_t s) {
   switch (stationary_kind(a.d, parts, a.rows_in || a.rows_out || a.row_count)) {
     case 1: return launch_rs(a, s);
-    case 2: return launch_bs(a, s);
+    case 2: case 3: return launch_bs(a, s);
     default: break;
   }
   if (parts == 2) return launch_tile<2>(a, s);

@@ -443,10 +443,10 @@ def conv2d(
     flops = lambda: kflops * int(row_count.item())
     nbytes = lambda: 4.0 * (int(row_count.item()) * (Cin + Cout) + w.numel())
   kind = (lib.snap_conv2d_stationary_kind(ctypes.byref(d), qparts)
-          if (qparts == 2 and KH == 1 and rows_in is None and rows_out is None and row_count is None) else 0)
+          if (qparts == 2 and rows_in is None and rows_out is None and row_count is None) else 0)
   with _region(
       family, flops, nbytes,
-      lambda: f'{"PS_" if ps else ("", "RS_", "WS_")[kind]}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
+      lambda: f'{"PS_" if ps else ("", "RS_", "WS_", "WS_")[kind]}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
               f'_s{stride}_p{prologue}_e{epi}',
   ):
     st = lib.snap_conv2d_nhwc_ex_f32(

@@ -152,3 +152,59 @@ def test_shapes_outside_the_kernel_take_the_tiled_engine():
   y_a = _run(x, w, res, g_in, b_in, None, no_rs=False)
   y_b = _run(x, w, res, g_in, b_in, None, no_rs=True)
   assert torch.equal(y_a, y_b)
+
+
+# ---- the weights-stationary 3 x 3 of the first stage (64 -> 64 channels, images wider than the halo body takes)
+CASES_3X3 = [
+    (2, 20, 90),          # ragged last tile
+    (3, 11, 85),          # 935 pixels per image: tiles straddle images
+    (1, 47, 136),
+    (40, 136, 136),       # the C2 StreetView layer, full size
+]
+
+
+def _kind3(N, H, W):
+  from snap_amd import _lib
+  import ctypes
+  d = _lib.SnapConvDesc(N=N, H=H, W=W, Cin=64, Cin_stride=64, KH=3, KW=3, stride=1, pad_t=1, pad_l=1,
+                        Ho=H, Wo=W, Cout=64, Cout_stride=64, prologue=ops.PRO_GN_RELU, epilogue=0,
+                        in_scale=1.0, in_shift=0.0, tile_hint=1000000 * ops._stationary_mode())
+  return int(_lib.load().snap_conv2d_stationary_kind(ctypes.byref(d), 2))
+
+
+@pytest.mark.parametrize('N,H,W', CASES_3X3)
+@pytest.mark.parametrize('emit', [None, 'raw', 'relu'])
+def test_weights_stationary_3x3_equals_the_im2col_body(N, H, W, emit):
+  if emit is not None and N == 40:
+    pytest.skip('one statistics variant at full size is enough')
+  ops.CONV_TILE = None
+  assert _kind3(N, H, W) == 3
+  x = rnd((N, H, W, 64), 3000 + W)
+  w = rnd((3, 3, 64, 64), 3001, 1 / 24.0)
+  g_in = rnd((64,), 3002) * 0.3 + 1
+  b_in = rnd((64,), 3003) * 0.3
+  xd = x.to(DEV)
+  mu, sc = ops.group_norm_stats(xd, g_in.to(DEV))
+  kw = dict(padding=((1, 1), (1, 1)), prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)), emit_gn_stats=emit)
+  y_ws = ops.conv2d(xd, w.to(DEV), **kw)
+  ops.CONV_NO_RS = True
+  ops.USE_SPLITK = False
+  try:
+    assert _kind3(N, H, W) == 0
+    y_t = ops.conv2d(xd, w.to(DEV), **kw)
+  finally:
+    ops.CONV_NO_RS = False
+    ops.USE_SPLITK = True
+  assert torch.equal(y_ws, y_t), float((y_ws - y_t).abs().max())
+  if N <= 3:
+    want = oracle_ops.conv2d(x, w, padding=((1, 1), (1, 1)), prologue=ops.PRO_GN_RELU,
+                             gn=(*oracle_ops.group_norm_stats(x, g_in), b_in))
+    helpers.report('ws 3x3 vs oracle', y_ws, want, atol=TOL * float(want.abs().max()))
+  if emit is None:
+    return
+  assert y_ws._snap_gn_partial[1] == 32
+  gamma = rnd((64,), 3004) * 0.3 + 1
+  mu_f, sc_f = ops.group_norm_stats(y_ws, gamma.to(DEV), relu_first=emit == 'relu')
+  mu_w, sc_w = oracle_ops.group_norm_stats(y_ws.cpu(), gamma, relu_first=emit == 'relu')
+  helpers.report('ws 3x3 stats mu', mu_f, mu_w, atol=1e-5, rtol=1e-5)
+  helpers.report('ws 3x3 stats sc', sc_f, sc_w, atol=1e-5, rtol=5e-5)
