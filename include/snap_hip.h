@@ -758,6 +758,12 @@ int snap_epilogue_bwd_f32(const float* dy, const float* y, const uint8_t* row_ma
                           int64_t M, int32_t C, int32_t relu, void* stream);
 /* out[C] (+)= column sums of a[M,C]  (bias gradients). */
 size_t snap_colsum_workspace_bytes(int64_t M, int32_t C);
+/* snap_epilogue_bwd_f32 and the column sums of ITS OUTPUT over the first *row_count rows (all M if
+ * NULL) in one pass: the gradient of a bias that sits in front of a ReLU / row mask (layers.py:55-78
+ * under jax.grad).  workspace: snap_colsum_workspace_bytes(M, C). */
+int snap_epilogue_bwd_colsum_f32(const float* dy, const float* y, const uint8_t* row_mask, float* out,
+                                 int64_t M, int32_t C, int32_t relu, const int32_t* row_count,
+                                 float* colsum, void* workspace, size_t workspace_bytes, void* stream);
 int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* ... over the listed rows only: sum_{m < *row_count} a[rows[m], :]  (rows / row_count may be NULL). */

@@ -245,6 +245,7 @@ SIGNATURES = {
     'snap_max_pool_3x3s2_bwd_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr]),
     'snap_upsample2x_bwd_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, ptr]),
     'snap_epilogue_bwd_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, ptr]),
+    'snap_epilogue_bwd_colsum_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, ptr]),
     'snap_colsum_workspace_bytes': (c_size, [c_i64, c_int]),
     'snap_colsum_f32': (c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_size, ptr]),
     'snap_lift_pool_bwd_f32': (

@@ -109,15 +109,20 @@ class _FusedConv(torch.autograd.Function):
     x, w, gamma, beta, mu, sc, rstd, y, row_mask = ctx.saved_tensors
     has_bias, has_res, has_up = ctx.has
     dy = dy.contiguous()
-    if relu or row_mask is not None:
-      dy = ops_bwd.epilogue_bwd(dy, y, row_mask, relu=relu)
     need = ctx.needs_input_grad
+    dbias = None
+    if relu or row_mask is not None:
+      if has_bias and need[4]:      # the gate and the bias gradient (column sums of the gated dy) in one pass
+        dy, dbias = ops_bwd.epilogue_bwd_colsum(dy, y, row_mask, relu=relu)
+      else:
+        dy = ops_bwd.epilogue_bwd(dy, y, row_mask, relu=relu)
     gn = (mu, sc, beta.reshape(-1)) if prologue in _GN_MODES else None
     dw = None
     if need[1]:
       dw = ops_bwd.conv2d_wgrad(x, dy, tuple(w.shape), stride=stride, padding=padding,
                                 prologue=prologue, gn=gn, in_affine=in_affine)
-    dbias = ops_bwd.colsum(dy) if (has_bias and need[4]) else None
+    if dbias is None and has_bias and need[4]:
+      dbias = ops_bwd.colsum(dy)
     dres = dy if (has_res and need[5]) else None
     dup = ops_bwd.upsample2x_bwd(dy) if (has_up and need[6]) else None
     dx = dgamma = dbeta = None
@@ -312,8 +317,12 @@ class _MaskedRowsMLP(torch.autograd.Function):
       last = i + 1 == n
       W = Ws[i]
       cin, cout = W.shape
+      db_fused = None
       if not last:                      # ReLU gate of this layer's output (compact rows)
-        g = ops_bwd.epilogue_bwd(g, acts[i], None, relu=True)
+        if ctx.needs_input_grad[4 + 2 * i]:
+          g, db_fused = ops_bwd.epilogue_bwd_colsum(g, acts[i], None, relu=True, row_count=count)
+        else:
+          g = ops_bwd.epilogue_bwd(g, acts[i], None, relu=True)
       rows_dy = index if last else None
       inp = x2 if i == 0 else acts[i - 1]
       pro = ops.PRO_RELU if (i == 0 and ctx.relu_input) else ops.PRO_NONE
@@ -323,7 +332,8 @@ class _MaskedRowsMLP(torch.autograd.Function):
             prologue=pro, rows_z=index if i == 0 else None, rows_dy=rows_dy, row_count=count,
         ).reshape(cin, cout)
       if ctx.needs_input_grad[4 + 2 * i]:
-        grads[2 * i + 1] = ops_bwd.colsum(g, rows=rows_dy, row_count=count)
+        grads[2 * i + 1] = (db_fused if db_fused is not None
+                            else ops_bwd.colsum(g, rows=rows_dy, row_count=count))
       if i > 0 or ctx.needs_input_grad[0]:
         width = Cs if i == 0 else cin               # d input row width (x keeps its padded stride)
         Wt = W.t()

@@ -360,6 +360,55 @@ __global__ void epilogue_bwd_kernel(const float* __restrict__ dy, const float* _
   reinterpret_cast<f32x4*>(out)[i] = g;
 }
 
+// The gate and the column sums of its OUTPUT in one pass (a Dense / conv layer with a bias behind a
+// ReLU: the bias gradient is the column sum of the gated gradient -- a second full read of it
+// otherwise).  One workgroup = a slab of rows x a chunk of <= 1024 columns; a thread = a column quad
+// and every PW-th row of the slab; partial[s][c] as colsum_partial_kernel writes it (rows beyond
+// *row_count are gated and stored like the others but not summed).
+__global__ __launch_bounds__(256) void epilogue_bwd_colsum_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const uint8_t* __restrict__ row_mask,
+    float* __restrict__ out, int64_t M, int C, int relu, int64_t rows_per_block,
+    const int32_t* __restrict__ row_count, float* __restrict__ partial) {
+  __shared__ float red[256 * 4];
+  const int cbase = blockIdx.y * 1024;
+  const int cchunk = min(C - cbase, 1024);
+  const int QW = cchunk >> 2;                         // (C % 4 == 0; QW divides 256 or equals it)
+  const int PW = 256 / QW;
+  const int tq = threadIdx.x % QW, tp = threadIdx.x / QW;
+  const int c0 = cbase + 4 * tq;
+  const int64_t Msum = row_count ? min((int64_t)*row_count, M) : M;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tp < PW) {
+    for (int64_t r = r0 + tp; r < r1; r += PW) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + c0);
+      if (row_mask && !row_mask[r]) g = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (relu) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * C + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(out + r * C + c0) = g;
+      if (r < Msum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += g[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = t[e];
+  __syncthreads();
+  if (tp == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = 0.f;
+      for (int pp = 0; pp < PW; ++pp) a += red[(pp * QW + tq) * 4 + e];
+      partial[(int64_t)blockIdx.x * C + c0 + e] = a;
+    }
+  }
+}
+
 // column sums: partial[s][c] over row slabs, then fixed-order reduce.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int64_t M,
                                                              int C, int64_t rows_per_block,
@@ -537,6 +586,28 @@ extern "C" int snap_epilogue_bwd_f32(const float* dy, const float* y, const uint
   const int64_t total4 = M * (C / 4);
   hipLaunchKernelGGL(epilogue_bwd_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), dy, y, row_mask, out, total4, C / 4, relu);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_epilogue_bwd_colsum_f32(const float* dy, const float* y, const uint8_t* row_mask,
+                                           float* out, int64_t M, int32_t C, int32_t relu,
+                                           const int32_t* row_count, float* colsum, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (!dy || !out || !colsum || !workspace) return SNAP_ERR_NULL;
+  if (relu && !y) return SNAP_ERR_NULL;
+  if (M <= 0 || C <= 0 || C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int q = C < 1024 ? C / 4 : 256;
+  if (256 % q != 0 || (C > 1024 && C % 1024 != 0)) return SNAP_ERR_UNSUPPORTED;
+  if (workspace_bytes < snap_colsum_workspace_bytes(M, C)) return SNAP_ERR_WORKSPACE;
+  const int S = colsum_slabs(M);
+  const int64_t rpb = (M + S - 1) / S;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(epilogue_bwd_colsum_kernel, dim3(S, (unsigned)snap_cdiv(C, 1024)), dim3(256), 0, s, dy, y,
+                     row_mask, out, M, C, relu, rpb, row_count, static_cast<float*>(workspace));
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 32)), dim3(256), 0, s,
+                     (const float*)workspace, S, C, colsum, 0);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -132,6 +132,27 @@ def epilogue_bwd(dy, y=None, row_mask=None, relu=False):
   return out
 
 
+def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None):
+  """``epilogue_bwd`` and the column sums of its output (over the first *row_count rows) in one
+  pass -> (gated dy, [C] sums); falls back to the two passes for widths the kernel does not take."""
+  lib = _lib.load()
+  _f32(dy, 'dy')
+  C = dy.shape[-1]
+  M = dy.numel() // C
+  q = C // 4 if C < 1024 else 256
+  if C % 4 or 256 % q or (C > 1024 and C % 1024):
+    out = epilogue_bwd(dy, y, row_mask, relu=relu)
+    return out, colsum(out, row_count=row_count)
+  out = torch.empty_like(dy)
+  wsb = lib.snap_colsum_workspace_bytes(M, C)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=dy.device)
+  sums = torch.empty(C, dtype=torch.float32, device=dy.device)
+  st = lib.snap_epilogue_bwd_colsum_f32(_p(dy), _p(y), _p(row_mask), _p(out), M, C, int(relu),
+                                        _p(row_count), _p(sums), _p(ws), ws.numel() * 4, _stream())
+  _lib.check(st, 'snap_epilogue_bwd_colsum_f32')
+  return out, sums
+
+
 def colsum(a, rows=None, row_count=None):
   """Column sums of a [..., C] -> [C]  (bias gradients); optionally over a row list."""
   lib = _lib.load()
