@@ -215,6 +215,15 @@ typedef struct SnapPackItem {
   int32_t taps, Cin, Cout, block_begin;
 } SnapPackItem;
 int32_t snap_conv2d_pack_weights_split_blocks(int32_t taps, int32_t Cin, int32_t Cout);
+/* The same for the bf16-operand engine's images (training precision): one launch for every kernel
+ * of a step.  An item with taps < 0 asks for the ROTATED image of |taps| taps that the
+ * data-gradient convolution reads -- the image of w.flip(0, 1).permute(0, 1, 3, 2) with the output
+ * channels padded to a multiple of four: out = snap_conv2d_packed_weights_bytes(|taps|, Cout,
+ * roundup(Cin, 4)) bytes.  Items sorted by block_begin; item i owns
+ * snap_conv2d_pack_weights_blocks(taps, Cin, Cout) workgroups. */
+int32_t snap_conv2d_pack_weights_blocks(int32_t taps, int32_t Cin, int32_t Cout);
+int snap_conv2d_pack_weights_multi_bf16(const SnapPackItem* items, int32_t n_items,
+                                        int32_t total_blocks, void* stream);
 int snap_conv2d_pack_weights_split_multi_bf16(const SnapPackItem* items, int32_t n_items,
                                               int32_t total_blocks, int32_t parts, void* stream);
 

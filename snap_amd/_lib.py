@@ -74,6 +74,8 @@ SIGNATURES = {
     'snap_conv2d_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
+    'snap_conv2d_pack_weights_blocks': (c_int, [c_int, c_int, c_int]),
+    'snap_conv2d_pack_weights_multi_bf16': (c_int, [ptr, c_int, c_int, ptr]),
     'snap_conv2d_stationary_kind': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_tile_rows_ex': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_gn_partial_bytes_ex': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),

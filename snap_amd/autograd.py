@@ -37,10 +37,18 @@ def conv_dgrad(dy, w, x_shape, stride, padding):
     dyd[:, ::stride, ::stride] = dy
     dy = dyd
   Ho, Wo = dy.shape[1:3]
-  w_rot = w.flip(0, 1).permute(0, 1, 3, 2)                    # [KH,KW,Cout,Cin]
-  if Cin % 4:                                                  # engine writes 4-channel groups:
-    w_rot = F.pad(w_rot, (0, 4 - Cin % 4))                     # extra channels come out as exact zeros
-  w_rot = w_rot.contiguous()
+  rot_img = ops.packed_rot_image(w) if ops.MATMUL_PRECISION == 'bf16' else None
+  if rot_img is not None:
+    # training precision: the rotated kernel's bf16 image was prepared with every other image of the
+    # step (ops.pack_weights_bf16_multi); the engine reads only the image, so the f32 tensor is a
+    # shape carrier (no flip / permute / pad / pack launches here)
+    w_rot = torch.empty((KH, KW, Cout, (Cin + 3) // 4 * 4), dtype=torch.float32, device=dy.device)
+    w_rot._snap_packed = {'bf16': (ops.PACK_EPOCH, w_rot._version, rot_img)}
+  else:
+    w_rot = w.flip(0, 1).permute(0, 1, 3, 2)                    # [KH,KW,Cout,Cin]
+    if Cin % 4:                                                  # engine writes 4-channel groups:
+      w_rot = F.pad(w_rot, (0, 4 - Cin % 4))                     # extra channels come out as exact zeros
+    w_rot = w_rot.contiguous()
   pt2, pl2 = KH - 1 - pt, KW - 1 - pl
   pb2 = H - Ho - pt2 + KH - 1
   pr2 = W - Wo - pl2 + KW - 1

@@ -303,7 +303,76 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(
   }
 }
 
+// every weight image of a training step in ONE launch (the forward images and, items with taps < 0,
+// the ROTATED images the data-gradient convolutions read: out [Cin4][taps][cout8] = w[T-1-t][ci][co],
+// i.e. the image of w.flip(0, 1).permute(0, 1, 3, 2) padded to four output channels -- both sides
+// contiguous along co, no transposition through LDS).  Items sorted by block_begin.
+__global__ __launch_bounds__(256) void pack_weights_bf16_multi_kernel(const SnapPackItem* __restrict__ items,
+                                                                      int n_items) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SnapPackItem it = items[lo];
+  const bool rot = it.taps < 0;
+  const int taps = rot ? -it.taps : it.taps;
+  const int Cin = it.Cin, Cout = it.Cout;
+  const int local = blockIdx.x - it.block_begin;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  __bf16* const out = static_cast<__bf16*>(it.out);
+  if (!rot) {
+    const int cin8 = (Cin + 7) / 8 * 8;
+    const int gx = (cin8 + 31) / 32, gy = (Cout + 31) / 32;
+    const int t = local / (gx * gy), rem = local - t * (gx * gy);
+    const int c0 = (rem % gx) * 32, n0 = (rem / gx) * 32;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+      const int c = c0 + j, n = n0 + tx;
+      tile[j][tx] = (c < Cin && n < Cout) ? it.w[((int64_t)t * Cin + c) * Cout + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+      const int n = n0 + j, c = c0 + tx;
+      if (n < Cout && c < cin8) out[((int64_t)n * taps + t) * cin8 + c] = (__bf16)tile[tx][j];
+    }
+  } else {
+    const int cin4 = (Cin + 3) / 4 * 4, cout8 = (Cout + 7) / 8 * 8;
+    const int gx = (cout8 + 31) / 32, gy = (cin4 + 31) / 32;
+    const int t = local / (gx * gy), rem = local - t * (gx * gy);
+    const int co0 = (rem % gx) * 32, ci0 = (rem / gx) * 32;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+      const int ci = ci0 + j, co = co0 + tx;
+      if (ci < cin4 && co < cout8) {
+        const float v = (ci < Cin && co < Cout) ? it.w[((int64_t)(taps - 1 - t) * Cin + ci) * Cout + co] : 0.f;
+        out[((int64_t)ci * taps + t) * cout8 + co] = (__bf16)v;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int32_t snap_conv2d_pack_weights_blocks(int32_t taps, int32_t Cin, int32_t Cout) {
+  if (taps == 0 || Cin <= 0 || Cout <= 0) return 0;
+  const bool rot = taps < 0;
+  const int T = rot ? -taps : taps;
+  if (rot) return ((((Cin + 3) / 4 * 4) + 31) / 32) * ((((Cout + 7) / 8 * 8) + 31) / 32) * T;
+  return ((((Cin + 7) / 8 * 8) + 31) / 32) * ((Cout + 31) / 32) * T;
+}
+
+extern "C" int snap_conv2d_pack_weights_multi_bf16(const SnapPackItem* items, int32_t n_items,
+                                                   int32_t total_blocks, void* stream) {
+  if (!items) return SNAP_ERR_NULL;
+  if (n_items <= 0 || total_blocks <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, n_items);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
 
 int snapconv::launch_bf16(ConvArgs a, hipStream_t s) {
   const TileChoice t = choose_tile(a.M, a.d.Cout, a.d.tile_hint, desc_k(a.d));

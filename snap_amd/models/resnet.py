@@ -151,8 +151,12 @@ class ResNetV2(base.Module):
       # training: every StdConv kernel of the encoder standardised by one launch (and one
       # backward launch) instead of ~53 latency-bound ones.
       pre = dict(getattr(ctx, 'pre_std', None) or {})
-      pre.update({id(k): s for k, s in zip(kernels, ag.weight_standardize_multi(kernels))})
+      std = ag.weight_standardize_multi(kernels)
+      pre.update({id(k): s for k, s in zip(kernels, std)})
       ctx.pre_std = pre
+      if ops.MATMUL_PRECISION == 'bf16':
+        # ... and their bf16 images, forward and rotated (data gradient), by one launch
+        ops.pack_weights_bf16_multi(list(std))
     else:   # inference: one launch for all StdConv kernels of this encoder
       ctx.standardize_all(kernels, ops.weight_standardize_multi)
       if ops.MATMUL_PRECISION in ops.SPLIT_PARTS:

@@ -581,6 +581,62 @@ def pack_weights_split_multi(ws, math):
     slot[math] = (PACK_EPOCH, w._version, out)
 
 
+def pack_weights_bf16_multi(ws, with_rotated=True):
+  """Training precision: the bf16 engine's image of every kernel in ``ws`` (HWIO tensors) -- and, for
+  the data-gradient convolutions, of its rotated transpose -- with ONE launch; remembered on the
+  tensors for the current apply (``_packed_weights`` / ``packed_rot_image``)."""
+  lib = _lib.load()
+  todo = []
+  for w in ws:
+    slot = getattr(w, '_snap_packed', None)
+    hit = None if slot is None else slot.get('bf16')
+    if isinstance(hit, tuple) and hit[0] == PACK_EPOCH and hit[1] == w._version:
+      continue
+    if w.shape[2] < 4:
+      continue                       # (runs on the f32 engine)
+    todo.append(w)
+  if not todo:
+    return
+  n = len(todo) * (2 if with_rotated else 1)
+  items = np.zeros(n, dtype=_PACK_ITEM)
+  outs = []
+  blk = 0
+  i = 0
+  for w in todo:
+    _f32(w, 'w')
+    KH, KW, Cin, Cout = w.shape
+    taps = KH * KW
+    for rot in ((False, True) if with_rotated else (False,)):
+      nbytes = (lib.snap_conv2d_packed_weights_bytes(taps, Cout, (Cin + 3) // 4 * 4) if rot
+                else lib.snap_conv2d_packed_weights_bytes(taps, Cin, Cout))
+      out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+      outs.append(out)
+      items[i] = (w.data_ptr(), out.data_ptr(), -taps if rot else taps, Cin, Cout, blk)
+      blk += lib.snap_conv2d_pack_weights_blocks(-taps if rot else taps, Cin, Cout)
+      i += 1
+  table = torch.from_numpy(items.view(np.uint8).copy()).to(todo[0].device, non_blocking=True)
+  st = lib.snap_conv2d_pack_weights_multi_bf16(_p(table), n, blk, _stream())
+  _lib.check(st, 'snap_conv2d_pack_weights_multi_bf16')
+  k = 0
+  for w in todo:
+    slot = getattr(w, '_snap_packed', None)
+    if slot is None:
+      slot = {}
+      w._snap_packed = slot
+    slot['bf16'] = (PACK_EPOCH, w._version, outs[k]); k += 1
+    if with_rotated:
+      slot['bf16/rot'] = (PACK_EPOCH, w._version, outs[k]); k += 1
+
+
+def packed_rot_image(w):
+  """The rotated bf16 image ``pack_weights_bf16_multi`` prepared for ``w`` in this apply, or None."""
+  slot = getattr(w, '_snap_packed', None)
+  hit = None if slot is None else slot.get('bf16/rot')
+  if isinstance(hit, tuple) and hit[0] == PACK_EPOCH and hit[1] == w._version:
+    return hit[2]
+  return None
+
+
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
           row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None,
           gelu=False, residual=None):
