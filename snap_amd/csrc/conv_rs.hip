@@ -28,7 +28,7 @@
 // Measured (round 3, tools/rs_bench.py, C2 StreetView shapes with residual + statistics; isolated
 // launches): 0.435 -> 0.377 ms (M = 739840, 64 -> 256), 0.268 -> 0.229 (M = 184960, 128 -> 512),
 // 0.183 -> 0.161 (M = 46240, 256 -> 1024), i.e. 12-15 % over the tiled body; level at M = 147968,
-// 15-25 % SLOWER on the aerial encoder's M <= 36992 layers (too few row tiles: rs_applicable
+// 15-25 % SLOWER on the aerial encoder's M <= 36992 layers (too few row tiles: stationary_kind
 // leaves those to the tiled body).  Inside the C2 step the same layers gain 2-8 %.
 // What the ablations (SNAP_RS_ABLATE alt builds, scripts/gpu_rs_ablate.sh) say about these layers:
 // the time of all three shapes is (bytes through the CU boundary) / 5.0-5.5 TB/s, L2-resident
