@@ -141,6 +141,31 @@ def test_conv_wgrad_bf16_rows():
   helpers.report('wgrad bf16 rows', got, ref, atol=2e-5 * float(ref.abs().max()) + 1e-5)
 
 
+@pytest.mark.parametrize('Cin,Cs,Cout,relu', [(257, 260, 256, False), (256, 256, 128, True), (64, 64, 256, False)])
+def test_conv_wgrad_bf16_tall_products(Cin, Cs, Cout, relu):
+  """The fusion MLP's weight gradients at their real height (M > 2^19 rows, flat), with row lists and
+  a device-side row count; vs the rounded-operand restatement in float64.  (256-wide output tiles on
+  512 threads were tried for these launches in round 3: the byte counts halve, the time does not
+  move -- 4.03 -> 4.33 ms on the largest --, so the 128 x 128 tiles stay.)"""
+  from oracle import encoder as o_enc
+  M = (1 << 19) + 1234
+  x = rnd((M, Cs), 171)
+  x[:, Cin:] = 0
+  dy = rnd((M, Cout), 172)
+  mask = torch.rand(M, generator=torch.Generator().manual_seed(173)) > 0.3
+  index, count = ops.compact_rows(G(mask))
+  got = ops_bwd.conv2d_wgrad(G(x).reshape(1, 1, M, Cs), G(dy).reshape(1, 1, M, Cout),
+                             (1, 1, Cin, Cout), rows_z=index, rows_dy=index, row_count=count,
+                             prologue=ops.PRO_RELU if relu else ops.PRO_NONE, math='bf16')
+  z = x.numpy()[mask.numpy()][:, :Cin]
+  if relu:
+    z = np.maximum(z, 0)
+  zr = o_enc.bf16_round(z.astype(np.float32)).astype(np.float64)
+  dr = o_enc.bf16_round(dy.numpy()[mask.numpy()]).astype(np.float64)
+  ref = torch.from_numpy(zr.T @ dr).float().reshape(1, 1, Cin, Cout)
+  helpers.report('wgrad bf16 tall', got, ref, atol=2e-5 * float(ref.abs().max()) + 1e-4)
+
+
 @pytest.mark.parametrize('math_', ['f32', 'bf16'])
 def test_conv_wgrad_and_dgrad_random_shapes_fuzz(math_):
   """16 seeded random (shape, stride, padding, prologue) combinations per engine: kernel and data
