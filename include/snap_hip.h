@@ -296,7 +296,9 @@ size_t snap_conv2d_gn_partial_bytes(const SnapConvDesc* desc);
 int32_t snap_conv2d_tile_rows(const SnapConvDesc* desc);   /* row-tile height the launch uses */
 /* ... of a launch on the split-operand engine with `split_parts` parts (SnapConvExtras.w_split_parts;
  * 0 = any other engine): the weights-stationary 1x1 kernel of the two-part engine emits its
- * GroupNorm partial sums per 32-row slab. */
+ * GroupNorm partial sums per 32-row slab; a NEGATIVE value -S: S slabs per image, all of them live
+ * (the weights-stationary 3x3 kernel: one slab per row-aligned tile) -- pass it on to
+ * snap_group_norm_stats_from_partial_f32 as it is. */
 int32_t snap_conv2d_tile_rows_ex(const SnapConvDesc* desc, int32_t split_parts);
 size_t snap_conv2d_gn_partial_bytes_ex(const SnapConvDesc* desc, int32_t split_parts);
 size_t snap_conv2d_splitk_gn_partial_bytes(const SnapConvDesc* desc);   /* see SnapConvExtras.gn_partial_rows */

@@ -563,7 +563,9 @@ extern "C" int snap_conv2d_nhwc_f32(const SnapConvDesc* desc, const float* x,
 //  two-part split engine emits its statistics per 32-row slab; 0 = any other engine)
 extern "C" int32_t snap_conv2d_tile_rows_ex(const SnapConvDesc* desc, int32_t split_parts) {
   if (!desc) return 0;
-  if (snapconv::stationary_kind(*desc, split_parts, false) >= 2) return 32;
+  const int kind = snapconv::stationary_kind(*desc, split_parts, false);
+  if (kind == 3) return -(desc->H * ((desc->W + 29) / 30));   // (< 0: that many slabs per image, all live)
+  if (kind == 2) return 32;
   return choose_tile((int64_t)desc->N * desc->Ho * desc->Wo, desc->Cout, desc->tile_hint, desc_k(*desc)).bm;
 }
 
@@ -572,6 +574,7 @@ extern "C" size_t snap_conv2d_gn_partial_bytes_ex(const SnapConvDesc* desc, int3
   const SnapConvDesc& d = *desc;
   const int64_t HoWo = (int64_t)d.Ho * d.Wo;
   const int bm = snap_conv2d_tile_rows_ex(desc, split_parts);
+  if (bm < 0) return (size_t)d.N * (size_t)(-bm) * d.Cout * 2 * sizeof(float);
   if (HoWo < bm) return 0;  // a tile would straddle more than two images: not produced
   return (size_t)d.N * (HoWo / bm + 2) * d.Cout * 2 * sizeof(float);
 }

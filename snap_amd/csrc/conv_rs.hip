@@ -777,21 +777,37 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bs_kernel(const ConvArgs a) {
 // The same for the 3 x 3 / stride 1 / pad 1 convolution of the first ResNet stage (64 -> 64 channels,
 // 136 pixels wide: too wide for the halo body of conv_split.hip, so the tiled engine runs it as
 // im2col -- 9 x 4 slabs of weights re-streamed per 128 rows, 850 MB of L2 -> LDS traffic per launch
-// for 378 MB of input + output).  The split weight panel of all nine taps (36 slabs x 4 KB = 144 KB)
-// is resident in LDS; eight independent waves per CU; per tap a wave fetches its 32 pixels' rows of
-// that tap straight into the A-fragment layout (the taps of neighbouring pixels overlap: L1 / L2
-// serve them), normalises, zeroes the lanes whose tap falls outside the image (the reference pads
-// the NORMALISED tensor) and splits; the next tap's rows are in flight meanwhile.  Slab order = tap
-// major, channel tile minor, products lo-hi / hi-lo / hi-hi: the im2col body's, bit for bit.  No
-// staging tile (LDS is full): the epilogue stores straight from the MFMA layout (128-byte runs) and
-// takes the GroupNorm sums of a column from one lane's 16 rows + its partner half-wave.
+// for 378 MB of input + output, and every pixel normalised and split once per TAP).  Here the split
+// weight panel of all nine taps (36 slabs x 4 KB = 144 KB) is resident in LDS and eight independent
+// waves per CU each take row-aligned tiles of 30 output pixels: lane l31 holds pixel x0 - 1 + l31 of
+// the row (lanes 0 and 31 are the halo columns, their outputs are dropped), so for a kernel row kh
+// the wave fetches, normalises and splits ONE image row segment -- the fragments of tap kw = 1 --
+// and the fragments of kw = 0 / kw = 2 are the same registers shifted by one lane (v_mov_b32 with
+// the wave_shr:1 / wave_shl:1 DPP controls: one VALU instruction per register instead of ~30 for
+// a conversion).  Three conversions per pixel instead of nine.  Slab order = tap major, channel
+// tile minor, products lo-hi / hi-lo / hi-hi: the im2col body's, bit for bit.  No staging tile (LDS
+// is full): the epilogue stores straight from the MFMA layout and takes the GroupNorm sums of a
+// column from one lane's 16 rows + its partner half-wave; a tile never straddles images, its sums
+// go to slab (y, tile of the row) of the image (the finalize pass is told to sum all slabs).
+__device__ __forceinline__ bf16x8 lane_shift(const bf16x8& v, bool left) {
+  u32x4 r;
+  __builtin_memcpy(&r, &v, 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = left ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)r[i], 0x130, 0xf, 0xf, false)    // lane l <- lane l + 1
+                : (unsigned)__builtin_amdgcn_update_dpp(0, (int)r[i], 0x138, 0xf, 0xf, false);   // lane l <- lane l - 1
+  bf16x8 o;
+  __builtin_memcpy(&o, &r, 16);
+  return o;
+}
+
 template <int STATS /* 0 none, 1 one set */>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) {
   constexpr int NT = 512, NW = NT / 64;
-  constexpr int KS = 4, TAPS = 9, TN = 2, Cin = 64;
+  constexpr int KS = 4, TAPS = 9, TN = 2, Cin = 64, TP = 30;
   constexpr int B_PART = 2048, B_SLAB = 4096;
   constexpr int kPanel = TAPS * KS * B_SLAB;      // 147456
-  constexpr int kTab = 5 * Cin;                   // floats per wave: [image][mu | sc][64], beta [64]
+  constexpr int kTab = 3 * Cin;                   // floats per wave: mu | sc | beta of the tile's image
   __shared__ __attribute__((aligned(16))) char panel[kPanel];
   __shared__ __attribute__((aligned(16))) float tables[NW * kTab];
 
@@ -800,8 +816,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) 
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int Meff = a.M;
-  const int W = d.W, HW = d.H * d.W;
+  const int W = d.W, H = d.H;
+  const int TX = (W + TP - 1) / TP;               // tiles per image row
 
   {
     const char* const wt = static_cast<const char*>(a.w_bf16);
@@ -819,59 +835,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) 
 
   float* const tab = tables + wid * kTab;
   const int relu_out = d.epilogue & SNAP_EPI_RELU;
-  const int ntile = (Meff + 31) >> 5;
+  const int ntile = d.N * H * TX;
   const int nwaves = gridDim.x * NW;
+  int n_tab = -1;
   for (int t = blockIdx.x * NW + wid; t < ntile; t += nwaves) {
-    const int mw0 = 32 * t;
-    const int n_first = mw0 / HW;
-    const int m_split = (n_first + 1) * HW;
-    const bool straddle = mw0 + 32 > m_split && m_split < Meff;
-    // this lane's output pixel and the taps that stay inside its image
-    const int m = mw0 + l31;
-    const bool ok = m < Meff;
-    const int mm = ok ? m : mw0;
-    int tapmask = 0;
-    {
-      const int r = mm % HW;
-      const int y = r / W, x = r - y * W;
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-        if (ok && yy >= 0 && yy < d.H && xx >= 0 && xx < W) tapmask |= 1 << tp;
+    const int n = t / (H * TX);
+    const int ry = t - n * (H * TX);
+    const int y = ry / TX, tx = ry - y * TX;
+    const int x0 = tx * TP;
+    const int xl = x0 - 1 + l31;                  // this lane's pixel column
+    const bool px_ok = xl >= 0 && xl < W;
+    const int xc = min(max(xl, 0), W - 1);
+    if (n != n_tab) {                             // GroupNorm operands of image n -> the wave's table
+      for (int i = lane; i < kTab / 4; i += 64) {
+        const int seg = i / (Cin / 4), c = 4 * (i - seg * (Cin / 4));
+        const float* src = seg == 2 ? a.gn_beta + c : (seg ? a.gn_sc : a.gn_mu) + (int64_t)n * Cin + c;
+        *reinterpret_cast<f32x4*>(tab + seg * Cin + c) = *reinterpret_cast<const f32x4*>(src);
       }
+      n_tab = n;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // GroupNorm operands of the tile's (at most two) images -> the wave's table (wave-private)
-    for (int i = lane; i < kTab / 4; i += 64) {
-      const int seg = i / (Cin / 4), c = 4 * (i - seg * (Cin / 4));
-      const int n = min(n_first + (seg >> 1), d.N - 1);
-      const float* src = seg == 4 ? a.gn_beta + c : ((seg & 1) ? a.gn_sc : a.gn_mu) + (int64_t)n * Cin + c;
-      *reinterpret_cast<f32x4*>(tab + seg * Cin + c) = *reinterpret_cast<const f32x4*>(src);
-    }
-    const float* const px = a.x + (int64_t)mm * d.Cin_stride + 8 * lhi;
-    auto load_tap = [&](int tp, f32x4 (&xs)[KS][2]) {
-      // (a tap outside the image: the centre pixel's address -- loaded, never used)
-      const bool in = (tapmask >> tp) & 1;
-      const float* p = px + (in ? ((tp / 3 - 1) * W + (tp % 3 - 1)) * d.Cin_stride : 0);
+    const float* const tmu = tab + 8 * lhi;
+    auto load_row = [&](int kh, f32x4 (&xs)[KS][2]) {
+      const int yy = min(max(y + kh - 1, 0), H - 1);          // (a row outside the image: loaded, never used)
+      const float* p = a.x + (((int64_t)n * H + yy) * W + xc) * d.Cin_stride + 8 * lhi;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         xs[s][0] = *reinterpret_cast<const f32x4*>(p + 16 * s);
         xs[s][1] = *reinterpret_cast<const f32x4*>(p + 16 * s + 4);
       }
     };
-    f32x4 xa[KS][2], xb[KS][2];
-    load_tap(0, xa);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const float* const tmu = tab + (mm >= m_split ? 2 * Cin : 0) + 8 * lhi;
-    const float* const tbe = tab + 4 * Cin + 8 * lhi;
-
     f32x16 acc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    auto do_tap = [&](int tp, const f32x4 (&xs)[KS][2]) {
-      const bool in = (tapmask >> tp) & 1;
+    auto do_row = [&](int kh, const f32x4 (&xs)[KS][2]) {
+      const int yy = y + kh - 1;
+      if (yy < 0 || yy >= H) return;                          // wave-uniform: the row is zero padding
+      bf16x8 f_hi[KS], f_lo[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         u32x2 h[2], l[2];
@@ -881,89 +884,81 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) 
           f32x4 v = xs[s][hq];
           const f32x4 mu = *reinterpret_cast<const f32x4*>(tmu + c);
           const f32x4 sc = *reinterpret_cast<const f32x4*>(tmu + Cin + c);
-          const f32x4 be = *reinterpret_cast<const f32x4*>(tbe + c);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(tmu + 2 * Cin + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float pv = apply_pro<SNAP_PRO_GN_RELU>(v[e], mu[e], sc[e], be[e], d.in_scale, d.in_shift);
-            v[e] = in ? pv : 0.f;
+            v[e] = px_ok ? pv : 0.f;
           }
           split2(v, h[hq], l[hq]);
         }
         const u32x4 hh = {h[0][0], h[0][1], h[1][0], h[1][1]};
         const u32x4 ll = {l[0][0], l[0][1], l[1][0], l[1][1]};
-        bf16x8 a_hi, a_lo;
-        __builtin_memcpy(&a_hi, &hh, 16);
-        __builtin_memcpy(&a_lo, &ll, 16);
-        const char* bs = panel + (tp * KS + s) * B_SLAB;
-        bf16x8 bv[TN][2];
+        __builtin_memcpy(&f_hi[s], &hh, 16);
+        __builtin_memcpy(&f_lo[s], &ll, 16);
+      }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int C = j * 32 + l31;
-          const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
-          bv[j][0] = *reinterpret_cast<const bf16x8*>(p0);
-          bv[j][1] = *reinterpret_cast<const bf16x8*>(p0 + B_PART);
+      for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          // tap kw of output lane l = the pixel of lane l + kw - 1
+          const bf16x8 a_hi = kw == 1 ? f_hi[s] : lane_shift(f_hi[s], kw == 2);
+          const bf16x8 a_lo = kw == 1 ? f_lo[s] : lane_shift(f_lo[s], kw == 2);
+          const char* bs = panel + ((kh * 3 + kw) * KS + s) * B_SLAB;
+          bf16x8 bv[TN][2];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int C = j * 32 + l31;
+            const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+            bv[j][0] = *reinterpret_cast<const bf16x8*>(p0);
+            bv[j][1] = *reinterpret_cast<const bf16x8*>(p0 + B_PART);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bv[j][0], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][1], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][0], acc[j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bv[j][0], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][1], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][0], acc[j], 0, 0, 0);
       }
     };
-    // taps two at a time: the rows of the next tap travel while this one is converted / multiplied
-#pragma unroll 1
-    for (int tp = 0; tp < 8; tp += 2) {
-      load_tap(tp + 1, xb);
-      do_tap(tp, xa);
-      load_tap(tp + 2, xa);
-      do_tap(tp + 1, xb);
-    }
-    do_tap(8, xa);
+    // the rows of the next kernel row travel while this one is converted / multiplied
+    f32x4 xa[KS][2], xb[KS][2];
+    load_row(0, xa);
+    load_row(1, xb);
+    do_row(0, xa);
+    load_row(2, xa);
+    do_row(1, xb);
+    do_row(2, xa);
 
-    // ---- epilogue straight from the MFMA layout: lane = column 32 j + l31, rows 8 (r >> 2) + 4 lhi + (r & 3)
-    float* const yb = a.y + (int64_t)mw0 * d.Cout_stride + l31;
+    // ---- epilogue straight from the MFMA layout: lane = column 32 j + l31, tile rows 8 (r >> 2) + 4 lhi + (r & 3)
+    float* const yb = a.y + (((int64_t)n * H + y) * W + x0 - 1) * d.Cout_stride + l31;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;      // tile row = pixel x0 - 1 + ri
         float v = acc[j][r];
         if (relu_out) v = fmaxf(v, 0.f);
-        const bool live = mw0 + ri < Meff;
+        const bool live = ri >= 1 && ri <= TP && x0 - 1 + ri < W;
         if (live) yb[(int64_t)ri * d.Cout_stride + 32 * j] = v;
         if constexpr (STATS > 0) {
           const float y0 = live ? v : 0.f;
           const float tt = a.gn_relu ? fmaxf(y0, 0.f) : y0;
-          const bool second = straddle && mw0 + ri >= m_split;
-          s1a += second ? 0.f : tt;
-          s2a += second ? 0.f : tt * tt;
-          s1b += second ? tt : 0.f;
-          s2b += second ? tt * tt : 0.f;
+          s1 += tt;
+          s2 += tt * tt;
         }
       }
       if constexpr (STATS > 0) {
-        s1a += __shfl_xor(s1a, 32);
-        s2a += __shfl_xor(s2a, 32);
-        s1b += __shfl_xor(s1b, 32);
-        s2b += __shfl_xor(s2b, 32);
-        if (lhi == 0) {
-          const int col = 32 * j + l31;
-          {
-            const int slab = t - (int)(((int64_t)n_first * HW) >> 5);
-            *reinterpret_cast<float2*>(a.gn_partial + (((int64_t)n_first * a.gn_slabs + slab) * d.Cout + col) * 2) =
-                float2{s1a, s2a};
-          }
-          if (straddle && n_first + 1 < d.N) {
-            const int slab = t - (int)(((int64_t)(n_first + 1) * HW) >> 5);
-            *reinterpret_cast<float2*>(a.gn_partial + (((int64_t)(n_first + 1) * a.gn_slabs + slab) * d.Cout + col) * 2) =
-                float2{s1b, s2b};
-          }
-        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lhi == 0)
+          *reinterpret_cast<float2*>(a.gn_partial + (((int64_t)n * a.gn_slabs + ry) * d.Cout + 32 * j + l31) * 2) =
+              float2{s1, s2};
       }
     }
   }
@@ -1008,11 +1003,11 @@ int snapconv::stationary_kind(const SnapConvDesc& d, int parts, bool row_lists) 
       d.Cin == 64 && d.Cout == 64 && d.Cout_stride == 64 && (d.Cin_stride & 3) == 0 &&
       d.prologue == SNAP_PRO_GN_RELU && !(d.epilogue & ~SNAP_EPI_RELU) && mode != 3 && mode != 4) {
     const int64_t HW3 = (int64_t)d.H * d.W, M3 = (int64_t)d.N * HW3;
-    // measured in the C2 step: 0.848 -> 0.807 ms over three launches at M = 739 840, 0.212 -> 0.223 at
-    // M = 147 968 (the kernel converts every pixel once per tap, as the im2col body does, and is bound
-    // by that VALU work: removing the weight stream alone buys 5 %)
-    if (128 + 2 * d.W + 2 > 288 && HW3 >= 32 && M3 <= 0x7fffffffLL && (M3 >= 400000 || mode == 2) &&
-        d.N * (HW3 / 32 + 2) * (int64_t)d.Cout * 8 < 0x7ff00000LL)
+    // measured in the C2 step: 0.848 -> 0.623 ms over three launches at M = 739 840, 0.212 -> 0.159 at
+    // M = 147 968 (a first version that converted every pixel once per TAP, as the im2col body does,
+    // gained 5 %: the conversion, not the weight stream, bounds this layer)
+    if (128 + 2 * d.W + 2 > 288 && HW3 >= 32 && M3 <= 0x7fffffffLL && (M3 >= 40000 || mode == 2) &&
+        (int64_t)d.N * d.H * ((d.W + 29) / 30) * d.Cout * 8 < 0x7ff00000LL)
       return 3;
     return 0;
   }
@@ -1047,7 +1042,8 @@ int snapconv::launch_bs(ConvArgs a, hipStream_t s) {
   a.ksplit = 1;
   if (d.KH == 3) {                               // the first stage's 3 x 3 (stationary_kind == 3)
     if (a.gn_partial2_done) *a.gn_partial2_done = 0;
-    const int64_t nt = snap_cdiv(a.M, 32);
+    a.gn_slabs = d.H * ((d.W + 29) / 30);         // one slab per tile of an image (snap_conv2d_tile_rows_ex < 0)
+    const int64_t nt = (int64_t)d.N * a.gn_slabs;
     const dim3 g3((unsigned)(nt / 8 < 256 ? (nt + 7) / 8 : 256));
     if (a.gn_partial)
       hipLaunchKernelGGL((conv3x3_ws64_kernel<1>), g3, dim3(512), 0, s, a);

@@ -971,7 +971,11 @@ int snapconv::launch_split_root(ConvArgs a, int parts, hipStream_t s) {
 }
 
 int snapconv::launch_split(ConvArgs a, int parts, hipStream_t s) {
-  switch (stationary_kind(a.d, parts, a.rows_in || a.rows_out || a.row_count)) {
+  const int kind = stationary_kind(a.d, parts, a.rows_in || a.rows_out || a.row_count);
+  // (a caller that sized its statistics buffer for a split-K launch asked the wrong query:
+  //  the stationary kernels never split K and lay their partial sums out their own way)
+  if (kind && a.gn_partial && a.gn_rows32) return SNAP_ERR_WORKSPACE;
+  switch (kind) {
     case 1: return launch_rs(a, s);
     case 2: case 3: return launch_bs(a, s);
     default: break;

@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void gn_finalize_tiled_kernel(
   const int n = i / groups, g = i - n * groups;
   const int cpg = C / groups;
   const int c_lo = g * cpg;
-  const int live = (int)((((int64_t)(n + 1) * HW - 1) / tile_rows) - (((int64_t)n * HW) / tile_rows)) + 1;
+  // (tile_rows < 0: S = -tile_rows slabs per image, all of them live)
+  const int live = tile_rows < 0 ? S
+                   : (int)((((int64_t)(n + 1) * HW - 1) / tile_rows) - (((int64_t)n * HW) / tile_rows)) + 1;
   const int count = live * cpg;
   double t1 = 0.0, t2 = 0.0;
   // four entries in flight per thread (the weights-stationary conv kernel emits 32-row slabs: up to
@@ -397,10 +399,10 @@ extern "C" int snap_group_norm_stats_from_partial_f32(const float* partial, int3
                                                       void* stream) {
   if (!partial || !gamma || !mu || !sc) return SNAP_ERR_NULL;
   if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0) return SNAP_ERR_BAD_SHAPE;
-  if (tile_rows <= 0 || HW < tile_rows) return SNAP_ERR_BAD_SHAPE;
+  if (tile_rows == 0 || HW < tile_rows) return SNAP_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(gn_finalize_tiled_kernel, dim3((unsigned)(N * groups)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), partial, HW / tile_rows + 2, HW, C, groups, eps,
-                     gamma, mu, sc, rstd, tile_rows);
+                     static_cast<hipStream_t>(stream), partial, tile_rows < 0 ? -tile_rows : HW / tile_rows + 2,
+                     HW, C, groups, eps, gamma, mu, sc, rstd, tile_rows);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -371,6 +371,8 @@ def conv2d(
     pst = (PS_TILE if ps_tile is None else int(ps_tile)) if ps else 0
     if ps:
       wbytes = lib.snap_conv2d_presplit_workspace_bytes(ctypes.byref(d), pst) if USE_SPLITK else 0
+    elif qparts == 2 and lib.snap_conv2d_stationary_kind(ctypes.byref(d), qparts):
+      wbytes = 0        # a stationary-operand kernel takes the launch: it never splits K
     else:
       wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if USE_SPLITK else 0
     if wbytes:   # small-M / deep-K layer: split K
