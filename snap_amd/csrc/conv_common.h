@@ -73,6 +73,7 @@ int launch_ps(ConvArgs a, hipStream_t s);
 int stationary_kind(const SnapConvDesc& d, int parts, bool row_lists);
 int launch_rs(ConvArgs a, hipStream_t s);
 int launch_bs(ConvArgs a, hipStream_t s);
+int launch_root_ws(const ConvArgs& a, hipStream_t s);   // the RGB root convolution, 64 output channels
 struct PsTile { int bm, bn, nt; };
 PsTile ps_choose_tile(int64_t M, int64_t N, int force);
 int ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t kpartial_bytes);

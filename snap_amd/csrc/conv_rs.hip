@@ -964,6 +964,136 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ... and for the 7 x 7 / stride 2 / pad 3 root convolution of an RGB image stored with four floats
+// per pixel (conv_split_root_kernel: K slab = 4 consecutive pixels x 4 floats of one kernel row, 14
+// slabs): the 56 KB panel resident in LDS, eight independent waves, a wave = a row-aligned tile of
+// 32 output pixels; per kernel row a lane fetches the 2 x 32 bytes its two k-octets cover (pixels
+// 2 xo - 3 + 4 g + 2 lhi + {0, 1}), applies the affine prologue, zeroes what lies outside the
+// image, splits, and multiplies against the resident slab.  Same slab and product order as the
+// tiled root kernel: bit-identical.  Output straight from the MFMA layout.
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void conv_root_ws64_kernel(const ConvArgs a) {
+  constexpr int NT = 512, NW = NT / 64;
+  constexpr int NSLAB = 14, TN = 2;
+  constexpr int B_PART = 2048, B_SLAB = 4096;
+  constexpr int kPanel = NSLAB * B_SLAB;          // 57344
+  __shared__ __attribute__((aligned(16))) char panel[kPanel];
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int W = d.W, H = d.H, Wo = d.Wo, Ho = d.Ho;
+  const int TX = (Wo + 31) / 32;
+  {
+    const char* const wt = static_cast<const char*>(a.w_bf16);
+#pragma unroll
+    for (int p = 0; p < kPanel / 16 / NT; ++p) {
+      const int q = tid + NT * p;                 // 16-byte piece: [slab][part][64 columns][2 octets]
+      const int sl = q >> 8, within = q & 255;
+      const int part = within >> 7, rem = within & 127;
+      const char* src = wt + (int64_t)sl * 8192 + part * 4096 + (rem >> 1) * 32 + (rem & 1) * 16;
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src, (lds_void_t*)(panel + 16 * q), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const int relu_out = d.epilogue & SNAP_EPI_RELU;
+  const int ntile = d.N * Ho * TX;
+  const int nwaves = gridDim.x * NW;
+  for (int t = blockIdx.x * NW + wid; t < ntile; t += nwaves) {
+    const int n = t / (Ho * TX);
+    const int ry = t - n * (Ho * TX);
+    const int yo = ry / TX, x0 = (ry - yo * TX) * 32;
+    const int xo = x0 + l31;                      // this lane's output pixel (may lie beyond the row: dropped)
+    const int xi0 = 2 * xo - 3 + 2 * lhi;         // first input pixel of the lane's octet at g = 0
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float* const img = a.x + (int64_t)n * H * W * 4;
+    auto load_row = [&](int kh, f32x4 (&xs)[2][2]) {
+      const int yy = min(max(2 * yo - 3 + kh, 0), H - 1);     // (a row outside the image: loaded, never used)
+      const float* p = img + (int64_t)yy * W * 4;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int xi = min(max(xi0 + 4 * g + q, 0), W - 1);
+          xs[g][q] = *reinterpret_cast<const f32x4*>(p + 4 * xi);
+        }
+    };
+    auto do_row = [&](int kh, const f32x4 (&xs)[2][2]) {
+      const int yy = 2 * yo - 3 + kh;
+      if (yy < 0 || yy >= H) return;                          // wave-uniform: zero padding
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        u32x2 h[2], l[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int xi = xi0 + 4 * g + q;
+          const bool in = xi >= 0 && xi < W;
+          f32x4 v = xs[g][q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pv = apply_pro<PRO>(v[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+            v[e] = in ? pv : 0.f;
+          }
+          split2(v, h[q], l[q]);
+        }
+        const u32x4 hh = {h[0][0], h[0][1], h[1][0], h[1][1]};
+        const u32x4 ll = {l[0][0], l[0][1], l[1][0], l[1][1]};
+        bf16x8 a_hi, a_lo;
+        __builtin_memcpy(&a_hi, &hh, 16);
+        __builtin_memcpy(&a_lo, &ll, 16);
+        const char* bs = panel + (kh * 2 + g) * B_SLAB;
+        bf16x8 bv[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int C = j * 32 + l31;
+          const char* p0 = bs + C * 32 + ((lhi ^ ((C >> 3) & 1)) * 16);
+          bv[j][0] = *reinterpret_cast<const bf16x8*>(p0);
+          bv[j][1] = *reinterpret_cast<const bf16x8*>(p0 + B_PART);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bv[j][0], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][1], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bv[j][0], acc[j], 0, 0, 0);
+      }
+    };
+    // the next kernel row's pixels travel while this one is converted / multiplied
+    f32x4 xa[2][2], xb[2][2];
+    load_row(0, xa);
+#pragma unroll 1
+    for (int kh = 0; kh < 6; kh += 2) {
+      load_row(kh + 1, xb);
+      do_row(kh, xa);
+      load_row(kh + 2, xa);
+      do_row(kh + 1, xb);
+    }
+    do_row(6, xa);
+
+    float* const yb = a.y + (((int64_t)n * Ho + yo) * Wo + x0) * d.Cout_stride + l31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float v = acc[j][r];
+        if (relu_out) v = fmaxf(v, 0.f);
+        if (x0 + ri < Wo) yb[(int64_t)ri * d.Cout_stride + 32 * j] = v;
+      }
+  }
+}
+
 template <int KS, int TN, bool RES>
 int launch_rs_dual(const ConvArgs& a, dim3 grid, bool dual, hipStream_t s) {
   if (dual)
@@ -1034,6 +1164,19 @@ int snapconv::stationary_kind(const SnapConvDesc& d, int parts, bool row_lists) 
   // the row tile (and with it the statistics layout) must be the tiled engine's
   if (choose_tile(M, d.Cout, d.tile_hint, desc_k(d)).bm != 128) return 0;
   return 1;
+}
+
+// the RGB root convolution on the weights-stationary kernel (called by launch_split_root where it applies)
+int snapconv::launch_root_ws(const ConvArgs& a, hipStream_t s) {
+  const SnapConvDesc& d = a.d;
+  const int64_t nt = (int64_t)d.N * d.Ho * ((d.Wo + 31) / 32);
+  const dim3 grid((unsigned)(nt / 8 < 256 ? (nt + 7) / 8 : 256));
+  if (d.prologue == SNAP_PRO_AFFINE)
+    hipLaunchKernelGGL((conv_root_ws64_kernel<SNAP_PRO_AFFINE>), grid, dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_root_ws64_kernel<SNAP_PRO_NONE>), grid, dim3(512), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
 }
 
 int snapconv::launch_bs(ConvArgs a, hipStream_t s) {

@@ -952,6 +952,11 @@ int snapconv::launch_split_root(ConvArgs a, int parts, hipStream_t s) {
   if (d.KH != 7 || d.KW != 7 || d.stride != 2 || d.pad_t != 3 || d.pad_l != 3 || d.Cin != 3 ||
       d.Cin_stride != 4 || a.rows_in || a.rows_out || a.row_count || a.gn_partial)
     return SNAP_ERR_UNSUPPORTED;
+  // 64 output channels, two-part split: the weights-stationary kernel (conv_rs.hip), same bits
+  if (parts == 2 && d.Cout == 64 && d.Cout_stride == 64 && hint_mode(d.tile_hint) != 1 &&
+      (d.prologue == SNAP_PRO_AFFINE || d.prologue == SNAP_PRO_NONE) && !(d.epilogue & ~SNAP_EPI_RELU) &&
+      (a.M >= 40000 || hint_mode(d.tile_hint) == 2 || hint_mode(d.tile_hint) == 4) && d.W >= 8)
+    return launch_root_ws(a, s);
   a.d.KW = 2;                      // two 4-pixel slabs per kernel row
   a.ctiles = 1;
   a.nk = 14;

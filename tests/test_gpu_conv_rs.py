@@ -209,3 +209,30 @@ def test_weights_stationary_3x3_equals_the_im2col_body(N, H, W, emit):
   mu_w, sc_w = oracle_ops.group_norm_stats(y_ws.cpu(), gamma, relu_first=emit == 'relu')
   helpers.report('ws 3x3 stats mu', mu_f, mu_w, atol=1e-5, rtol=1e-5)
   helpers.report('ws 3x3 stats sc', sc_f, sc_w, atol=1e-5, rtol=5e-5)
+
+
+# ---- the weights-stationary RGB root convolution (7 x 7 / stride 2 / pad 3, 64 output channels)
+@pytest.mark.parametrize('N,H,W', [(2, 64, 96), (1, 50, 70), (3, 33, 130), (40, 544, 680)])
+@pytest.mark.parametrize('affine', [True, False])
+def test_weights_stationary_root_conv_equals_the_tiled_root_kernel(N, H, W, affine):
+  if N == 40 and not affine:
+    pytest.skip('one variant at full size is enough')
+  ops.CONV_TILE = None
+  x = torch.rand((N, H, W, 4), generator=torch.Generator().manual_seed(4000 + W))
+  x[..., 3] = 0.37                                  # (must not matter: zero weights)
+  w = rnd((7, 7, 3, 64), 4001, 1 / np.sqrt(147))
+  kw = dict(stride=2, padding=((3, 3), (3, 3)), cin=3)
+  if affine:
+    kw.update(prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0))
+  xd, wd = x.to(DEV), w.to(DEV)
+  y_ws = ops.conv2d(xd, wd, **kw)
+  ops.CONV_NO_RS = True
+  try:
+    y_t = ops.conv2d(xd, wd, **kw)
+  finally:
+    ops.CONV_NO_RS = False
+  assert y_ws.shape == (N, (H + 1) // 2, (W + 1) // 2, 64)
+  assert torch.equal(y_ws, y_t), float((y_ws - y_t).abs().max())
+  if N <= 3:
+    want = oracle_ops.conv2d(x, w, **kw)
+    helpers.report('ws root vs oracle', y_ws, want, atol=TOL * float(want.abs().max()))
