@@ -13,6 +13,9 @@ SHAPES = [  # N, H, W, Cin, Cout
     (40, 136, 136, 64, 256), (40, 68, 68, 128, 512), (40, 34, 34, 256, 1024),
     (8, 136, 136, 64, 256), (8, 68, 68, 128, 512), (8, 34, 34, 256, 1024),
 ]
+REDUCTIONS = [  # the first stage's 256 -> 64 / 128 (run with --reductions --no-res)
+    (40, 136, 136, 256, 64), (40, 136, 136, 256, 128), (8, 136, 136, 256, 64), (8, 136, 136, 256, 128),
+]
 
 
 def main():
@@ -22,19 +25,20 @@ def main():
   ap.add_argument('--stats', default='raw')
   ap.add_argument('--no-res', action='store_true')
   ap.add_argument('--nsplit', type=int, default=0)
+  ap.add_argument('--reductions', action='store_true')
   args = ap.parse_args()
   ops.MATMUL_PRECISION = 'bf16x3'
   ops.CONV_RS_NSPLIT = args.nsplit
   ops.CONV_RS_FORCE = True
   dev = torch.device('cuda')
   out = []
-  for i, (N, H, W, Cin, Cout) in enumerate(SHAPES):
+  for i, (N, H, W, Cin, Cout) in enumerate(REDUCTIONS if args.reductions else SHAPES):
     if args.only is not None and i != args.only:
       continue
     g = torch.Generator().manual_seed(i)
     x = torch.randn((N, H, W, Cin), generator=g).to(dev)
     w = (torch.randn((1, 1, Cin, Cout), generator=g) / np.sqrt(Cin)).to(dev)
-    res = None if args.no_res else torch.randn((N, H, W, Cout), generator=g).to(dev)
+    res = None if (args.no_res or args.reductions) else torch.randn((N, H, W, Cout), generator=g).to(dev)
     gamma = torch.ones(Cin, device=dev)
     beta = torch.zeros(Cin, device=dev)
     mu, sc = ops.group_norm_stats(x, gamma)
