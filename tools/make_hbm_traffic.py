@@ -19,7 +19,7 @@ import sys
 FAMILIES = [
     ('conv_igemm_kernel', 'conv_igemm'), ('conv_split_kernel', 'conv_split'), ('conv3x3_halo_kernel', 'conv_split'),
     ('splitk_reduce_kernel', 'conv_split'), ('conv_split_root_kernel', 'conv_split'),
-    ('conv1x1_rs_kernel', 'conv_split'), ('conv1x1_bs_kernel', 'conv_split'), ('conv3x3_ws64_kernel', 'conv_split'),
+    ('conv1x1_rs_kernel', 'conv_split'), ('conv1x1_bs_kernel', 'conv_split'), ('conv3x3_ws64_kernel', 'conv_split'), ('conv_root_ws64_kernel', 'conv_split'),
     ('splitk_reduce_stats_kernel', 'conv_split'), ('conv_ps_kernel', 'conv_split'),
     ('gn_norm_split_kernel', 'gn_norm_split'), ('presplit_kernel', 'presplit'),
     ('gn_finalize_tiled_kernel', 'group_norm_stats'), ('sim_split_kernel', 'sim_softmax'),
