@@ -485,6 +485,293 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same computation on 256-ROW tiles, for pre-split rows and H = 256: one workgroup of four waves
+// per CU (launch bound: one wave per SIMD, so a wave may hold 512 registers -- the accumulators live
+// in the AccVGPR half), each wave owns 64 rows = TWO 32-row blocks.  Why: the 128-row kernel moves
+// W0 + W1 (up to 400 KB) from L2 into LDS once per 128 rows -- 18 GB of its 24 GB per C2 step, at
+// the ~7 TB/s the CUs take from L2 that IS its run time -- and every weight fragment a wave reads
+// from LDS feeds one MFMA.  Here the weight stream is paid once per 256 rows and a fragment feeds
+// two MFMAs; the eight-wave variant of the old kernel (SNAP_MLP_POOL_NT = 512) had the same stream
+// but twice the waves behind every barrier and measured slower.  With one workgroup per CU nothing
+// else hides a memory round trip, so the GEMM0 slabs travel THREE ahead through a four-stage ring
+// (4 x 32 KB), all of W1 (128 KB) is resident before GEMM1 needs it (pair 0 arrives while GEMM0
+// runs, pairs 1-7 while the hidden activations are converted), and the scan tile ([256][128] f32)
+// takes the ring's place at the end.  Slab order and product order per accumulator are the
+// 128-row kernel's: the plane is bit-identical (tests/test_gpu_kernels.py).
+// MEASURED (tools/mlp_pool_bench.py, the C2 map: 6.8 M rows in two classes): 4.11-4.18 ms against
+// 3.30-3.43 ms for the 128-row kernel.  One wave per SIMD cannot hide its own non-matrix phases --
+// row-list fetch and first slab (~4 us), the ReLU / split conversion of 256 accumulator registers
+// (~3 us), the scan (~4 us), the LDS latency after every barrier -- which two co-resident 128-row
+// workgroups hide for each other: 39 us per 256-row tile for 11-16 us of MFMA time.  Halving the
+// weight stream is worth less than that overlap.  Kept as an opt-in (x_split = 3) with its test.
+template <int N0>
+__global__ __launch_bounds__(256, 1) void mlp2_pool_wide_kernel(const MlpPoolArgs a) {
+  constexpr int NT = 256, BM = 256, N1 = 128, RB = 2;
+  constexpr int T0 = N0 / 32, T1 = N1 / 32;
+  constexpr int A_ST = BM * 64;                               // 16 KB: [row][4 x 16 B] (hi k0-7 | hi k8-15 | lo | lo)
+  constexpr int B0_ST = (N0 / 128) * 8192;                    // 16 KB
+  constexpr int kStage = A_ST + B0_ST;
+  constexpr int NSTG = 4;
+  constexpr int kPair0 = NSTG * kStage;                       // W1 pair 0 behind the ring
+  constexpr int kBias = kPair0 + 16384;
+  static_assert(BM * N1 * 4 <= kPair0, "scan tile overlaps pair 0 / the bias table");
+  static_assert(7 * 16384 <= kPair0, "W1 pairs 1..7 take the ring's place");
+  __shared__ __attribute__((aligned(16))) float smem[kBias / 4 + N0 + N1];   // 145.5 KB
+  char* const sm = reinterpret_cast<char*>(smem);
+  float* const bias0 = reinterpret_cast<float*>(sm + kBias);
+  float* const bias1 = bias0 + N0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Meff = min(*a.row_count, a.M);
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= Meff) return;
+
+  for (int i = tid; i < N0 + N1; i += NT)
+    bias0[i] = i < N0 ? (i < a.H ? a.b0[i] : 0.f) : (i - N0 < a.D ? a.b1[i - N0] : 0.f);
+
+  // W1 pair p = k-steps 2p, 2p + 1 (16 KB)
+  auto issue_b1_pair = [&](int p, int dst_off) {
+    const char* src = a.w1 + (int64_t)p * 16384 + tid * 16;
+    char* dst = sm + dst_off + tid * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + NT * 16 * q), (lds_void_t*)(dst + NT * 16 * q), 16, 0, 0);
+  };
+  issue_b1_pair(0, kPair0);
+
+  // rows: thread = (row tid >> 2 (+ 64 i), 16-byte chunk tid & 3); the DMA writes LDS lane-contiguously,
+  // so each lane FETCHES the global chunk its (XOR-swizzled) slot holds
+  const char* xs_px[4];
+  bool r_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 2) + 64 * i;
+    const int m = m0 + row;
+    r_ok[i] = m < Meff;
+    const int c = (tid & 3) ^ ((row >> 1) & 3);
+    xs_px[i] = r_ok[i] ? reinterpret_cast<const char*>(a.x + (int64_t)a.rows[m] * a.x_stride) + c * 16
+                       : reinterpret_cast<const char*>(kZeroChunk);
+  }
+  auto issue_slab = [&](int stg, int s_) {
+    char* const base = sm + stg * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)(xs_px[i] + (r_ok[i] ? s_ * 64 : 0)),
+                                       (lds_void_t*)(base + (tid + NT * i) * 16), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < B0_ST / 16 / NT; ++p) {
+      const int slot = tid + NT * p;
+      const int j = slot >> 9;
+      const char* src = a.w0 + ((int64_t)j * a.ctiles0 + s_) * 8192 + (slot & 511) * 16;
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src, (lds_void_t*)(base + A_ST + 16 * slot), 16, 0, 0);
+    }
+  };
+  constexpr int kSlabOps = 4 + B0_ST / 16 / NT;                 // DMA instructions per thread and slab
+  const int nk0 = a.ctiles0 - a.skip_n;
+  auto slab_of = [&](int kt) { return kt < a.skip_lo ? kt : kt + a.skip_n; };   // the kt-th visited slab
+#pragma unroll
+  for (int kt = 0; kt < NSTG - 1; ++kt)
+    if (kt < nk0) issue_slab(kt, slab_of(kt));
+
+  f32x16 acc0[RB][T0];
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int t = 0; t < T0; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[b][t][r] = 0.f;
+
+  int a_off[RB], a_lo_off[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    const int R = 64 * wid + 32 * b + l31;                      // this lane's row of the tile
+    a_off[b] = R * 64 + ((lhi ^ ((R >> 1) & 3)) * 16);
+    a_lo_off[b] = R * 64 + (((2 + lhi) ^ ((R >> 1) & 3)) * 16);
+  }
+  const int w_off = l31 * 32 + ((lhi ^ ((l31 >> 3) & 1)) * 16);   // column 32 t' + l31 of a 128-tile
+
+  for (int kt = 0; kt < nk0; ++kt) {
+    // slabs <= kt + 2 are issued; slab kt must have landed, the younger ones may travel on
+    const int younger = min(kt + 2, nk0 - 1) - kt;
+    if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kSlabOps) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kSlabOps) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // every wave is past slab kt - 1: its stage takes slab kt + 3
+    if (kt + NSTG - 1 < nk0) issue_slab((kt + NSTG - 1) & (NSTG - 1), slab_of(kt + NSTG - 1));
+    const char* const st = sm + (kt & (NSTG - 1)) * kStage;
+    bf16x8 x_hi[RB], x_lo[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      x_hi[b] = *reinterpret_cast<const bf16x8*>(st + a_off[b]);
+      x_lo[b] = *reinterpret_cast<const bf16x8*>(st + a_lo_off[b]);
+    }
+    const char* const bs = st + A_ST + w_off;
+#pragma unroll
+    for (int g = 0; g < T0 / 4; ++g) {
+      bf16x8 w_hi[4], w_lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * g + j;
+        const char* p0 = bs + (t >> 2) * 8192 + (t & 3) * 1024;
+        w_hi[j] = *reinterpret_cast<const bf16x8*>(p0);
+        w_lo[j] = *reinterpret_cast<const bf16x8*>(p0 + 4096);
+      }
+      // per accumulator: x_lo w_hi, x_hi w_lo, x_hi w_hi (conv_split's order at NS = 2)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc0[b][4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], x_lo[b], acc0[b][4 * g + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc0[b][4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[j], x_hi[b], acc0[b][4 * g + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc0[b][4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], x_hi[b], acc0[b][4 * g + j], 0, 0, 0);
+      }
+    }
+  }
+  // every wave is done with the ring: W1 pairs 1..7 take its place while the hidden activations
+  // are converted (pair 0 has landed: the last slab's wait drained the queue)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int p = 1; p < 8; ++p) issue_b1_pair(p, (p - 1) * 16384);
+
+  // ---- hidden = relu(acc0 + b0) -> the GEMM1 operand fragments, in place of the accumulators ----
+  u32x4 f_hi[RB][T0][2], f_lo[RB][T0][2];
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int t = 0; t < T0; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias0 + 32 * t + 16 * s + 8 * q + 4 * lhi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(acc0[b][t][8 * s + 4 * q + e] + bb[e], 0.f);
+        }
+        // half 0: columns 0-3 | 8-11, half 1: 4-7 | 12-15  ->  half 0: 0-7, half 1: 8-15
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0][e]),
+                                                           __float_as_uint(v[1][e]), false, false);
+          v[0][e] = __uint_as_float(sw[0]);
+          v[1][e] = __uint_as_float(sw[1]);
+        }
+        u32x2 h0, l0, h1, l1;
+        split2(v[0], h0, l0);
+        split2(v[1], h1, l1);
+        f_hi[b][t][s] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        f_lo[b][t][s] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+
+  // ---- GEMM1: W1 resident, one barrier per pair of k-steps (the pair's arrival) ------------------
+  f32x16 acc1[RB][T1];
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[b][t][r] = 0.f;
+#pragma unroll
+  for (int pr = 0; pr < 8; ++pr) {
+    if (pr >= 1) {                                              // pairs pr + 1 .. 7 may travel on (4 DMAs each)
+      switch (7 - pr) {
+        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const char* ws = sm + (pr == 0 ? kPair0 : (pr - 1) * 16384) + sub * 8192 + w_off;
+      bf16x8 w_hi[T1], w_lo[T1];
+#pragma unroll
+      for (int j = 0; j < T1; ++j) {
+        const char* p0 = ws + j * 1024;
+        w_hi[j] = *reinterpret_cast<const bf16x8*>(p0);
+        w_lo[j] = *reinterpret_cast<const bf16x8*>(p0 + 4096);
+      }
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        bf16x8 h_hi, h_lo;
+        __builtin_memcpy(&h_hi, &f_hi[b][pr][sub], 16);
+        __builtin_memcpy(&h_lo, &f_lo[b][pr][sub], 16);
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_lo, acc1[b][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo[j], h_hi, acc1[b][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T1; ++j)
+          acc1[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], h_hi, acc1[b][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- + b1, stage [256 rows][128 channels] (float4 quads XOR-swizzled by the row) -------------
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int j = 0; j < T1; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias1 + 32 * j + 8 * q + 4 * lhi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc1[b][j][4 * q + e] += bb[e];
+      }
+  __syncthreads();                                                // W1 drained
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    const int R = 64 * wid + 32 * b + l31;
+#pragma unroll
+    for (int j = 0; j < T1; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int quad = (8 * j + 2 * q + lhi) ^ (R & 31);
+        *reinterpret_cast<f32x4*>(smem + R * N1 + 4 * quad) =
+            f32x4{acc1[b][j][4 * q], acc1[b][j][4 * q + 1], acc1[b][j][4 * q + 2], acc1[b][j][4 * q + 3]};
+      }
+  }
+  __syncthreads();
+
+  // ---- segmented max down the rows: thread = (channel, half of the tile), 2 x 64 rows ------------
+  const int c = tid & 127;
+  const int h = tid >> 7;                                         // wave-uniform (two waves per half)
+  int cur = -1;
+  float run = -INFINITY;
+  const bool live = c < a.D;
+  for (int q = 0; q < 2; ++q) {
+    const int my = m0 + 128 * h + 64 * q + lane;
+    const int cid = my < Meff ? a.rows[my] / a.Z : -1;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const int cr = __builtin_amdgcn_readlane(cid, r);
+      if (cr != cur) {
+        if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
+        cur = cr;
+        run = -INFINITY;
+      }
+      const int row = 128 * h + 64 * q + r;
+      run = fmaxf(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
+    }
+  }
+  if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
+}
+
 // plane prefilled with -inf -> where(any level valid, max, 0) + the validity byte
 __global__ __launch_bounds__(256) void mlp2_pool_finalize_kernel(float* __restrict__ plane,
                                                                  uint8_t* __restrict__ pvalid,
@@ -529,6 +816,10 @@ static int mlp2_pool_check(const float* x, int64_t M, int32_t Cin, int32_t x_str
 
 static void mlp2_pool_launch(const MlpPoolArgs& a, int relu_in, int x_split, hipStream_t s) {
   constexpr int NT = SNAP_MLP_POOL_NT;
+  if (x_split == 3 && !relu_in && a.H == 256) {      // 256-row tiles: measured slower (see the kernel), opt-in
+    hipLaunchKernelGGL((mlp2_pool_wide_kernel<256>), dim3((unsigned)snap_cdiv(a.M, 256)), dim3(256), 0, s, a);
+    return;
+  }
   const dim3 grid((unsigned)snap_cdiv(a.M, NT / 2));
   if (a.H <= 128) {
     if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true, NT>), grid, dim3(NT), 0, s, a);

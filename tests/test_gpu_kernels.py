@@ -803,6 +803,7 @@ MLP_POOL_CASES = [
     # cin, stride, H, D, Z, columns, relu_in
     (257, 260, 256, 128, 60, 37, False),     # the reference's fusion MLP / 12 m column at 0.2 m
     (257, 260, 256, 128, 60, 300, True),     # several row tiles, columns straddling them
+    (257, 260, 256, 128, 60, 301, False),    # ... and the opt-in 256-row kernel of the pre-split rows over 70 tiles
     (65, 68, 64, 32, 12, 50, False),         # the tiny test models (feature_dim 32)
     (129, 132, 128, 64, 7, 91, False),
     (33, 36, 96, 20, 64, 9, True),           # H not a multiple of 64, D < 32
@@ -867,6 +868,13 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
     assert xs.shape == (M, ks * 16)
     ps, vs = ops.mlp2_pool_max(xs.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
                                cin=cin, Z=Z, x_split=True)
+    assert torch.equal(vs, vg) and torch.equal(ps, pg), float((ps - pg).abs().max())
+    ops.MLP_POOL_WIDE = True                   # (H = 256: 256-row tiles, 64 rows per wave; elsewhere the same kernel again)
+    try:
+      ps, vs = ops.mlp2_pool_max(xs.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
+                                 cin=cin, Z=Z, x_split=True)
+    finally:
+      ops.MLP_POOL_WIDE = False
     assert torch.equal(vs, vg) and torch.equal(ps, pg), float((ps - pg).abs().max())
     # two row classes into one plane: class-1 rows are zero over a slab range and hold GARBAGE
     # there (never read, never multiplied); the plane is the one-list plane of the zeroed rows
