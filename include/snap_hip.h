@@ -343,7 +343,8 @@ int snap_compact_rows_range_u8(const uint8_t* mask, int64_t M, int32_t lo, int32
  *   relu_in: MLP.apply_input_activation;  plane [ncols, D], pvalid [ncols].
  *   x_split = 1: x holds the rows pre-split (SnapLiftDesc.out_split: [slab][hi | lo][16] bf16,
  *   x_stride still in floats); the A operand then travels global -> LDS by LDS-DMA.  Same
- *   results bit for bit; relu_in must be 0.  x_split = 3 (tuning / tests; H = 256 only, else as 1):
+ *   results bit for bit; relu_in must be 0.  x_split = 5 (tuning / tests): the same with the GEMM0
+ *   slabs one ahead (two LDS stages) instead of two ahead (three).  x_split = 3 (tuning / tests; H = 256 only, else as 1):
  *   the rows are taken 256 per workgroup (64 per wave, accumulators in AccVGPRs; the weights cross
  *   L2 -> LDS once per 256 rows) -- same bits, measured slower than the 128-row kernel. */
 int snap_mlp2_pool_max_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,

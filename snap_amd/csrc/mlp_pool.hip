@@ -96,19 +96,26 @@ __device__ __forceinline__ void atomic_max_f32(float* p, float v) {
 #ifndef SNAP_MLP_POOL_NT
 #define SNAP_MLP_POOL_NT 256
 #endif
-template <int N0, bool RELU_IN, bool XSPLIT, int NT>
+template <int N0, bool RELU_IN, bool XSPLIT, int NT, int NST = 2>
 __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
+  // NST = 3 (pre-split rows only, the default for them): the GEMM0 slabs (rows + W0, 24 KB) travel TWO
+  // ahead through a three-stage ring -- one barrier per slab as before, but a slab's 24 MFMAs per wave
+  // (0.3 us) no longer wait for a memory round trip (~1 us) that started one slab earlier.  The ring
+  // takes 72 KB, so W1's first pair cannot travel during GEMM0 any more; all four ring slots are
+  // issued after GEMM0 and arrive under the ReLU / split conversion.  C2 map, 6.8 M rows:
+  // 3.09-3.10 ms against 3.21-3.39 ms (tools/mlp_pool_bench.py), same bits.
+  static_assert(NST == 2 || (NST == 3 && XSPLIT && NT == 256), "the ring is the LDS-DMA path's");
   constexpr int BM = NT / 2, N1 = 128;
   constexpr int RPP = NT / 4;                                 // rows staged per pass (4 threads per row)
   constexpr int T0 = N0 / 32, T1 = N1 / 32;
   constexpr int A_PART = BM * 32, A_ST = 2 * A_PART;          // 8 KB per stage at 128 rows
   constexpr int B0_ST = (N0 / 128) * 8192;                    // 16 KB per stage at N0 = 256
-  constexpr int kB0 = 2 * A_ST;
+  constexpr int kB0 = NST * A_ST;
   // [GEMM0 stages | W1 ring] share the front of the buffer with the [BM][128] f32 tile of the max
   // scan; 128 rows: the ring lies over the GEMM0 stages (64 KB in all), 256 rows: behind them
   constexpr int kRing = NT == 256 ? 0 : 65536;
-  constexpr int kBias = NT == 256 ? 65536 : 131072;           // b0 [N0] | b1 [N1] behind
-  static_assert(kB0 + 2 * B0_ST <= 65536, "GEMM0 stages overlap the ring / the bias table");
+  constexpr int kBias = NT == 256 ? (NST == 3 ? 73728 : 65536) : 131072;   // b0 [N0] | b1 [N1] behind
+  static_assert(kB0 + NST * B0_ST <= (NST == 3 ? 73728 : 65536), "GEMM0 stages overlap the ring / the bias table");
   static_assert(BM * N1 * 4 <= kBias, "scan tile overlaps the bias table");
   __shared__ __attribute__((aligned(16))) float smem[kBias / 4 + N0 + N1];   // 65.5 KB (two per CU) / 129.5 KB
   char* const sm = reinterpret_cast<char*>(smem);
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
     for (int q = 0; q < PP; ++q)
       __builtin_amdgcn_global_load_lds((cglobal_void_t*)(src + NT * 16 * q), (lds_void_t*)(dst + NT * 16 * q), 16, 0, 0);
   };
-  if (!(SNAP_MLP_POOL_ABLATE & 4)) {
+  if (!(SNAP_MLP_POOL_ABLATE & 4) && NST == 2) {
     if (SNAP_MLP_POOL_PAIRS) {
       issue_b1_pair(0);
     } else {
@@ -241,27 +248,48 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
                                        (lds_void_t*)(sm + buf * A_ST + (tid + NT * i) * 16), 16, 0, 0);
   };
   const int s_first = a.skip_lo > 0 ? 0 : a.skip_n;
-  if constexpr (XSPLIT) {
+  const int nk0 = a.ctiles0 - a.skip_n;
+  auto slab_of = [&](int kt) { return kt < a.skip_lo ? kt : kt + a.skip_n; };   // the kt-th visited slab
+  if constexpr (NST == 3) {
     issue_a(0, s_first);
     issue_b0(0, s_first);
+    if (nk0 > 1) {
+      issue_a(1, slab_of(1));
+      issue_b0(1, slab_of(1));
+    }
   } else {
-    load_a(s_first);
-    issue_b0(0, s_first);
-    store_a(0);
+    if constexpr (XSPLIT) {
+      issue_a(0, s_first);
+      issue_b0(0, s_first);
+    } else {
+      load_a(s_first);
+      issue_b0(0, s_first);
+      store_a(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   const int R = 32 * wid + l31;                                   // this lane's row of the tile
   const int a_off = XSPLIT ? R * 64 + ((lhi ^ ((R >> 1) & 3)) * 16)
                            : R * 32 + ((lhi ^ ((R >> 3) & 1)) * 16);
   const int a_lo_off = XSPLIT ? R * 64 + (((2 + lhi) ^ ((R >> 1) & 3)) * 16) : a_off + A_PART;
   const int w_off = l31 * 32 + ((lhi ^ ((l31 >> 3) & 1)) * 16);   // column 32 t' + l31 of a 128-tile
-  const int nk0 = a.ctiles0 - a.skip_n;
+  constexpr int kSlabOps = 2 + B0_PIECES;                         // DMA instructions per thread and slab (pre-split rows)
   for (int kt = 0; kt < nk0; ++kt) {
-    const int cur = kt & 1;
+    const int cur = NST == 3 ? kt % 3 : (kt & 1);
     const bool more = kt + 1 < nk0;
-    if (more) {
+    if constexpr (NST == 3) {
+      // slabs <= kt + 1 are issued: slab kt must have landed, the next one may travel on
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kSlabOps) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // every wave is past slab kt - 1: its stage takes slab kt + 2
+      if (kt + 2 < nk0) {
+        issue_a((kt + 2) % 3, slab_of(kt + 2));
+        issue_b0((kt + 2) % 3, slab_of(kt + 2));
+      }
+    } else if (more) {
       const int sn = kt + 1 < a.skip_lo ? kt + 1 : kt + 1 + a.skip_n;    // the next visited slab
       if constexpr (XSPLIT) issue_a(cur ^ 1, sn); else load_a(sn);
       issue_b0(cur ^ 1, sn);
@@ -293,9 +321,12 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
     if constexpr (!XSPLIT) {
       if (more) store_a(cur ^ 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (NST == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
+  if constexpr (NST == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is free: W1 takes its place
 
   // ---- hidden = relu(acc0 + b0) -> the GEMM1 operand fragments, IN PLACE (16 accumulator
   // registers of a tile become 2 k-steps x (hi, lo) x 4 registers), while the first W1 stages
@@ -306,8 +337,8 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   if (run1) {
     if (SNAP_MLP_POOL_PAIRS) {
 #pragma unroll
-      for (int p = 1; p < 4; ++p)
-        if (p < npairs) issue_b1_pair(p);                         // (pair 0: issued at the start)
+      for (int p = NST == 3 ? 0 : 1; p < 4; ++p)
+        if (p < npairs) issue_b1_pair(p);                         // (NST = 2: pair 0 was issued at the start)
     } else {
 #pragma unroll
       for (int k = 2; k < 8; ++k)
@@ -359,9 +390,10 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
     if (pr < npairs && run1) {
       // wait for pair pr; issued so far: 1 .. pr + 2, so pr + 1 .. min(pr + 2, npairs - 1) may stay
       // in flight, four DMA instructions each (pair 0 was drained by GEMM0's waits)
-      if (pr >= 1) {
-        const int younger = min(pr + 2, npairs - 1) - pr;
+      if (pr >= 1 || NST == 3) {
+        const int younger = min(pr == 0 ? 3 : pr + 2, npairs - 1) - pr;
         switch (younger) {
+          case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PP) : "memory"); break;
           case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory"); break;
           case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory"); break;
           default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -821,12 +853,16 @@ static void mlp2_pool_launch(const MlpPoolArgs& a, int relu_in, int x_split, hip
     return;
   }
   const dim3 grid((unsigned)snap_cdiv(a.M, NT / 2));
+  // pre-split rows: the three-stage ring (x_split = 5: the two-stage loop, tuning / tests)
+  constexpr bool kRingOk = NT == 256;
   if (a.H <= 128) {
-    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true, NT>), grid, dim3(NT), 0, s, a);
+    if (x_split && x_split != 5 && kRingOk) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true, 256, 3>), grid, dim3(NT), 0, s, a);
+    else if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, true, NT>), grid, dim3(NT), 0, s, a);
     else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<128, true, false, NT>), grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((mlp2_pool_kernel<128, false, false, NT>), grid, dim3(NT), 0, s, a);
   } else {
-    if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<256, false, true, NT>), grid, dim3(NT), 0, s, a);
+    if (x_split && x_split != 5 && kRingOk) hipLaunchKernelGGL((mlp2_pool_kernel<256, false, true, 256, 3>), grid, dim3(NT), 0, s, a);
+    else if (x_split) hipLaunchKernelGGL((mlp2_pool_kernel<256, false, true, NT>), grid, dim3(NT), 0, s, a);
     else if (relu_in) hipLaunchKernelGGL((mlp2_pool_kernel<256, true, false, NT>), grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((mlp2_pool_kernel<256, false, false, NT>), grid, dim3(NT), 0, s, a);
   }

@@ -200,6 +200,7 @@ CONV_RS_NSPLIT = 0      # tools: forced column split of the row-stationary kerne
 CONV_RS_FORCE = False   # tests: the stationary kernels also below their row-count threshold
 CONV_NO_WS = False      # tools / tests: no weights-stationary kernel (the row-stationary one where it applies)
 SPLITK_STATS = True     # split-K launches of the split engine emit GroupNorm partial sums from their reduce pass
+MLP_POOL_NO_RING = False  # tuning / tests: pre-split rows on the two-stage GEMM0 loop instead of the three-stage ring (x_split = 5)
 MLP_POOL_WIDE = False     # tuning / tests: pre-split rows on the 256-row mlp2_pool kernel (x_split = 3; measured slower, mlp_pool.hip)
 CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
 CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
@@ -825,7 +826,7 @@ def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split
     st = lib.snap_mlp2_pool_max_classes_f32(
         _p(x), M, cin, Cs, _p(index), _p(count), _p(index_z) if index_z is not None else None,
         _p(count_z) if count_z is not None else None, zlo, zn, _p(w0p), w0p.numel() * 2, _p(b0), H,
-        _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), (3 if MLP_POOL_WIDE else 1) if x_split else 0, Z, ncols, _p(plane),
+        _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), (3 if MLP_POOL_WIDE else 5 if MLP_POOL_NO_RING else 1) if x_split else 0, Z, ncols, _p(plane),
         _p(pvalid), _stream())
   _lib.check(st, 'snap_mlp2_pool_max_classes_f32')
   return plane, pvalid

@@ -869,13 +869,16 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
     ps, vs = ops.mlp2_pool_max(xs.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
                                cin=cin, Z=Z, x_split=True)
     assert torch.equal(vs, vg) and torch.equal(ps, pg), float((ps - pg).abs().max())
-    ops.MLP_POOL_WIDE = True                   # (H = 256: 256-row tiles, 64 rows per wave; elsewhere the same kernel again)
-    try:
-      ps, vs = ops.mlp2_pool_max(xs.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
-                                 cin=cin, Z=Z, x_split=True)
-    finally:
-      ops.MLP_POOL_WIDE = False
-    assert torch.equal(vs, vg) and torch.equal(ps, pg), float((ps - pg).abs().max())
+    # (the line above ran the three-stage ring) the two-stage loop, and 256-row tiles with 64 rows per wave
+    # (H = 256; elsewhere the default kernel again)
+    for switch in ('MLP_POOL_NO_RING', 'MLP_POOL_WIDE'):
+      setattr(ops, switch, True)
+      try:
+        ps, vs = ops.mlp2_pool_max(xs.to(DEV), md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV),
+                                   cin=cin, Z=Z, x_split=True)
+      finally:
+        setattr(ops, switch, False)
+      assert torch.equal(vs, vg) and torch.equal(ps, pg), (switch, float((ps - pg).abs().max()))
     # two row classes into one plane: class-1 rows are zero over a slab range and hold GARBAGE
     # there (never read, never multiplied); the plane is the one-list plane of the zeroed rows
     zlo, zn = (ks - 1) // 2, (ks - 1) // 2

@@ -1,6 +1,7 @@
 """Isolated timing of the fused fusion-MLP / vertical max-pool kernel at the C2 map size (8 scenes x
-128 x 128 columns x 60 levels, 87 % of the voxels observed, 72 % of those by one view): the opt-in
-256-row kernel (ops.MLP_POOL_WIDE) against the 128-row kernel on the same pre-split rows."""
+128 x 128 columns x 60 levels, 87 % of the voxels observed, 72 % of those by one view): the 128-row
+kernel with the two-stage GEMM0 loop (ops.MLP_POOL_NO_RING), with the three-stage ring (the default) and the opt-in
+256-row kernel (ops.MLP_POOL_WIDE), on the same pre-split rows."""
 import argparse
 import json
 
@@ -29,8 +30,10 @@ def main():
   b1 = torch.zeros(D, device=dev)
   out = {}
   planes = {}
-  for name, narrow in (('rows128', True), ('rows256', False), ('rows128_b', True), ('rows256_b', False)):
+  for name, narrow, ring3 in (('rows128', True, False), ('rows128_ring3', True, True), ('rows256', False, False),
+                              ('rows128_b', True, False), ('rows128_ring3_b', True, True)):
     ops.MLP_POOL_WIDE = not narrow
+    ops.MLP_POOL_NO_RING = not ring3
     kw = dict(cin=cin, Z=Z, x_split=True, zero_slabs=(8, 8))
     for _ in range(2):
       p, v = ops.mlp2_pool_max(xs, cls, w0, b0, w1, b1, **kw)
@@ -44,6 +47,8 @@ def main():
     out[name] = round(e0.elapsed_time(e1) / args.reps, 4)
     planes[name] = p
   ops.MLP_POOL_WIDE = False
+  ops.MLP_POOL_NO_RING = False
+  out['equal_ring3'] = bool(torch.equal(planes['rows128'], planes['rows128_ring3']))
   out['equal'] = bool(torch.equal(planes['rows128'], planes['rows256']))
   print(json.dumps(out))
 
