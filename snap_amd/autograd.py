@@ -93,7 +93,7 @@ class _FusedConv(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, gamma, beta, bias, residual, up_prev, cfg):
-    stride, padding, prologue, in_affine, relu, row_mask, cin, emit = cfg
+    stride, padding, prologue, in_affine, relu, row_mask, cin, emit, fork = cfg
     gn = None
     mu = sc = rstd = None
     if prologue in _GN_MODES:
@@ -109,11 +109,16 @@ class _FusedConv(torch.autograd.Function):
     ctx.cfg = cfg
     ctx.has = (bias is not None, residual is not None, up_prev is not None)
     ctx.save_for_backward(x, w, gamma, beta, mu, sc, rstd, y if relu else None, row_mask)
+    if fork:
+      # a second output that IS the input: the caller routes the other consumer of x (a residual
+      # unit's shortcut) through it, so that both gradients of x arrive in this node's backward
+      # and the sum is formed by the kernel that writes dx instead of by a separate add pass
+      return y, x.view_as(x)
     return y
 
   @staticmethod
-  def backward(ctx, dy):
-    stride, padding, prologue, in_affine, relu, _, cin, _ = ctx.cfg
+  def backward(ctx, dy, dalias=None):
+    stride, padding, prologue, in_affine, relu, _, cin, _, fork = ctx.cfg
     x, w, gamma, beta, mu, sc, rstd, y, row_mask = ctx.saved_tensors
     has_bias, has_res, has_up = ctx.has
     dy = dy.contiguous()
@@ -142,9 +147,13 @@ class _FusedConv(torch.autograd.Function):
         dz = dz[..., :Cs].contiguous()
       Cin = dz.shape[-1]                                       # zero-padded channel count
       if prologue in _GN_MODES:
+        fused_add = dalias is not None and Cs == Cin
         dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
-            x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), prologue
+            x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), prologue,
+            add=dalias.contiguous() if fused_add else None,
         )
+        if fused_add:
+          dalias = None
         dgamma = dgamma.reshape(gamma.shape)
         dbeta = dbeta.reshape(beta.shape)
       elif prologue == ops.PRO_RELU:
@@ -156,16 +165,20 @@ class _FusedConv(torch.autograd.Function):
         dx = dz
       if Cs != Cin:
         dx = F.pad(dx, (0, Cs - Cin))
+    if dalias is not None:            # (no GroupNorm prologue to fold it into, or nothing else to add it to)
+      dx = dalias if dx is None else dx + dalias
     return dx, dw, dgamma, dbeta, dbias, dres, dup, None
 
 
 def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=ops.PRO_NONE,
            gn_params=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
-           up_prev=None, row_mask=None, emit_gn_stats=None):
+           up_prev=None, row_mask=None, emit_gn_stats=None, fork_input=False):
   """Differentiable ``ops.conv2d``.  ``gn_params = (gamma, beta)`` for GN prologues
-  (statistics are computed inside, so the VJP covers them)."""
+  (statistics are computed inside, so the VJP covers them).  ``fork_input``: returns ``(y, x')`` with
+  ``x'`` an alias of ``x`` for its other consumer -- the gradient that comes back through ``x'`` is
+  added by the kernel that writes this node's ``dx`` (one pass less over the tensor)."""
   gamma, beta = gn_params if gn_params is not None else (None, None)
-  cfg = (stride, padding, prologue, tuple(in_affine), relu, row_mask, cin, emit_gn_stats)
+  cfg = (stride, padding, prologue, tuple(in_affine), relu, row_mask, cin, emit_gn_stats, bool(fork_input))
   return _FusedConv.apply(x, w, gamma, beta, bias, residual, up_prev, cfg)
 
 

@@ -68,6 +68,9 @@ def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, emit=True, presplit=False, **k
                     emit_gn_stats=mode, **kw)
 
 
+FORK_SHORTCUT = True     # training: see residual_unit (False = autograd adds the two gradients of a unit's input)
+
+
 def _gn(x, p, relu_first=False):
   mu, sc = ops.group_norm_stats(x, p['scale'].reshape(-1), relu_first=relu_first)
   return mu, sc, p['bias'].reshape(-1)
@@ -80,11 +83,18 @@ def residual_unit(ctx, p, x, stride, nmid, last_of_stage=False):
   nout = nmid * 4
   train = base.needs_grad(x, p['conv1']['kernel'])
   gn1 = None if train else _gn(x, p['gn1'])     # shared by conv_proj and conv1
-  if x.shape[-1] != nout or stride != 1:
-    residual = _conv_gn(ctx, x, p['conv_proj']['kernel'], p['gn1'], gn1, emit=False, stride=stride)
+  if train and FORK_SHORTCUT:
+    # conv1's node also hands out the alias of x the shortcut reads: the shortcut's gradient then
+    # arrives in conv1's backward and is added where dx is written (no separate add pass)
+    y, xs = _conv_gn(ctx, x, p['conv1']['kernel'], p['gn1'], gn1, fork_input=True)
   else:
-    residual = x
-  y = _conv_gn(ctx, x, p['conv1']['kernel'], p['gn1'], gn1)
+    y, xs = None, x
+  if x.shape[-1] != nout or stride != 1:
+    residual = _conv_gn(ctx, xs, p['conv_proj']['kernel'], p['gn1'], gn1, emit=False, stride=stride)
+  else:
+    residual = xs
+  if y is None:
+    y = _conv_gn(ctx, x, p['conv1']['kernel'], p['gn1'], gn1)
   y = _conv_gn(ctx, y, p['conv2']['kernel'], p['gn2'], stride=stride, padding=((1, 1), (1, 1)),
                presplit=True)
   y = _conv_gn(ctx, y, p['conv3']['kernel'], p['gn3'], residual=residual, presplit=True,
