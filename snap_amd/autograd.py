@@ -20,8 +20,10 @@ _GN_MODES = (ops.PRO_GN_RELU, ops.PRO_RELU_GN)
 # ----------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------
-def conv_dgrad(dy, w, x_shape, stride, padding):
+def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None):
   """d(prologue output) of a conv: transposed convolution through the forward engine.
+  accumulate [N,H,W,roundup(Cin,4)]: added in the engine's epilogue (the data gradient of another
+  conv reading the same activation).
 
   dy [N,Ho,Wo,Cout]; w [KH,KW,Cin,Cout]; returns dz [N,H,W,roundup(Cin,4)] (channels
   past Cin are zero).
@@ -52,7 +54,7 @@ def conv_dgrad(dy, w, x_shape, stride, padding):
   pt2, pl2 = KH - 1 - pt, KW - 1 - pl
   pb2 = H - Ho - pt2 + KH - 1
   pr2 = W - Wo - pl2 + KW - 1
-  return ops.conv2d(dy.contiguous(), w_rot, padding=((pt2, pb2), (pl2, pr2)))
+  return ops.conv2d(dy.contiguous(), w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
 
 
 def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid, row_weight=None):
@@ -168,6 +170,54 @@ class _FusedConv(torch.autograd.Function):
     if dalias is not None:            # (no GroupNorm prologue to fold it into, or nothing else to add it to)
       dx = dalias if dx is None else dx + dalias
     return dx, dw, dgamma, dbeta, dbias, dres, dup, None
+
+
+class _SharedPrologueConvPair(torch.autograd.Function):
+  """Two convolutions behind ONE GroupNorm -> ReLU of the same tensor (a projection unit's conv1 and
+  conv_proj, resnet.py:117-124 of the reference): the statistics are taken once, and in the backward
+  the second data gradient is accumulated onto the first in the conv engine's epilogue, so that the
+  GroupNorm VJP (linear in its incoming gradient) runs once over x instead of twice plus an add."""
+
+  @staticmethod
+  def forward(ctx, x, w1, w2, gamma, beta, cfg):
+    stride2, emit1 = cfg
+    mu, sc, rstd = ops.group_norm_stats(x, gamma.reshape(-1), want_rstd=True)
+    gn = (mu, sc, beta.reshape(-1))
+    y1 = ops.conv2d(x, w1, prologue=ops.PRO_GN_RELU, gn=gn, emit_gn_stats=emit1)
+    y2 = ops.conv2d(x, w2, stride=stride2, prologue=ops.PRO_GN_RELU, gn=gn)
+    ctx.stride2 = stride2
+    ctx.save_for_backward(x, w1, w2, gamma, beta, mu, sc, rstd)
+    return y1, y2
+
+  @staticmethod
+  def backward(ctx, dy1, dy2):
+    x, w1, w2, gamma, beta, mu, sc, rstd = ctx.saved_tensors
+    need = ctx.needs_input_grad
+    pad0 = ((0, 0), (0, 0))
+    gn = (mu, sc, beta.reshape(-1))
+    dy1, dy2 = dy1.contiguous(), dy2.contiguous()
+    dw1 = dw2 = None
+    if need[1]:
+      dw1 = ops_bwd.conv2d_wgrad(x, dy1, tuple(w1.shape), prologue=ops.PRO_GN_RELU, gn=gn)
+    if need[2]:
+      dw2 = ops_bwd.conv2d_wgrad(x, dy2, tuple(w2.shape), stride=ctx.stride2, prologue=ops.PRO_GN_RELU, gn=gn)
+    dx = dgamma = dbeta = None
+    if need[0] or need[3] or need[4]:
+      N, H, W, C = x.shape
+      dz = conv_dgrad(dy1, w1, (N, H, W, C), 1, pad0)
+      dz = conv_dgrad(dy2, w2, (N, H, W, C), ctx.stride2, pad0, accumulate=dz)
+      dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
+          x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), ops.PRO_GN_RELU)
+      dgamma = dgamma.reshape(gamma.shape)
+      dbeta = dbeta.reshape(beta.shape)
+    return dx, dw1, dw2, dgamma, dbeta, None
+
+
+def conv2d_shared_gn(x, w1, w2, gn_params, *, stride2=1, emit_gn_stats=None):
+  """``(conv(gn_relu(x), w1), conv(gn_relu(x), w2, stride2))`` for two 1 x 1 kernels behind one
+  GroupNorm -> ReLU (whole 4-channel groups), differentiable as one node."""
+  gamma, beta = gn_params
+  return _SharedPrologueConvPair.apply(x, w1, w2, gamma, beta, (int(stride2), emit_gn_stats))
 
 
 def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=ops.PRO_NONE,

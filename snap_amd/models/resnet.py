@@ -68,6 +68,7 @@ def _conv_gn(ctx, x, kernel, gn_p, gn_stats=None, emit=True, presplit=False, **k
                     emit_gn_stats=mode, **kw)
 
 
+SHARE_PROJ_GN = True     # training: a projection unit's conv1 + conv_proj as one autograd node (see residual_unit)
 FORK_SHORTCUT = True     # training: see residual_unit (False = autograd adds the two gradients of a unit's input)
 
 
@@ -83,6 +84,15 @@ def residual_unit(ctx, p, x, stride, nmid, last_of_stage=False):
   nout = nmid * 4
   train = base.needs_grad(x, p['conv1']['kernel'])
   gn1 = None if train else _gn(x, p['gn1'])     # shared by conv_proj and conv1
+  proj = x.shape[-1] != nout or stride != 1
+  if train and proj and SHARE_PROJ_GN and x.shape[-1] % 4 == 0 and x.shape[-1] == p['conv1']['kernel'].shape[2]:
+    # conv1 and conv_proj read the same GroupNorm -> ReLU of x: one autograd node (one statistics pass,
+    # one GroupNorm VJP over x; the second data gradient accumulates onto the first inside the conv engine)
+    y, residual = ag.conv2d_shared_gn(x, _std(ctx, p['conv1']['kernel']), _std(ctx, p['conv_proj']['kernel']),
+                                      (p['gn1']['scale'], p['gn1']['bias']), stride2=stride, emit_gn_stats='raw')
+    y = _conv_gn(ctx, y, p['conv2']['kernel'], p['gn2'], stride=stride, padding=((1, 1), (1, 1)), presplit=True)
+    return _conv_gn(ctx, y, p['conv3']['kernel'], p['gn3'], residual=residual, presplit=True,
+                    emit='both' if (last_of_stage and ops.GN_STATS_BOTH) else True)
   if train and FORK_SHORTCUT:
     # conv1's node also hands out the alias of x the shortcut reads: the shortcut's gradient then
     # arrives in conv1's backward and is added where dx is written (no separate add pass)
