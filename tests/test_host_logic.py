@@ -86,6 +86,39 @@ def test_entry_point_argument_validation_codes():
 
 
 # -- configs ----------------------------------------------------------------------------
+def test_conv_dispatch_queries_follow_the_documented_rules():
+  """`snap_conv2d_stationary_kind` / `snap_conv2d_tile_rows_ex` / `snap_conv2d_gn_partial_bytes_ex` are pure
+  host functions of the descriptor (no launch, no device): the kernel a layer gets and the layout of
+  the GroupNorm partial sums it emits, on the C2 layer shapes."""
+  lib = _lib.load()
+
+  def query(N, H, W, Cin, Cout, K=1, res=False, mode=0):
+    pad = 1 if K == 3 else 0
+    d = _lib.SnapConvDesc(N=N, H=H, W=W, Cin=Cin, Cin_stride=Cin, KH=K, KW=K, stride=1, pad_t=pad, pad_l=pad,
+                          Ho=H, Wo=W, Cout=Cout, Cout_stride=Cout, prologue=ops.PRO_GN_RELU,
+                          epilogue=ops.EPI_RESIDUAL if res else 0, in_scale=1.0, in_shift=0.0,
+                          tile_hint=1000000 * mode)
+    return (int(lib.snap_conv2d_stationary_kind(ctypes.byref(d), 2)),
+            int(lib.snap_conv2d_tile_rows_ex(ctypes.byref(d), 2)),
+            int(lib.snap_conv2d_gn_partial_bytes_ex(ctypes.byref(d), 2)))
+
+  # StreetView stage-1 expansion: weight panel resident in LDS, statistics per 32-row slab
+  assert query(40, 136, 136, 64, 256, res=True) == (2, 32, 40 * (136 * 136 // 32 + 2) * 256 * 8)
+  # stage-3 expansion (Cin = 256: no panel fits): activation tile in registers, the tiled engine's 128-row slabs
+  assert query(40, 34, 34, 256, 1024, res=True) == (1, 128, 40 * (34 * 34 // 128 + 2) * 1024 * 8)
+  # stage-1 3 x 3: one slab per 30-pixel tile of an image row, all of them live (negative = slabs per image)
+  assert query(40, 136, 136, 64, 64, K=3) == (3, -(136 * 5), 40 * 136 * 5 * 64 * 8)
+  # below 40 000 rows (aerial encoder), K >= 512, the reductions, narrower 3 x 3 layers: the tiled bodies
+  for shape in ((8, 68, 68, 128, 512, 1, True), (40, 17, 17, 512, 2048, 1, True), (40, 136, 136, 256, 64),
+                (40, 68, 68, 128, 128, 3)):
+    assert query(*shape)[:2] == (0, 128), shape
+  # tile_hint modes: 1 = tiled bodies only, 2 = stationary kernels below the row threshold too, 3 = no panel kernels
+  assert query(40, 136, 136, 64, 256, res=True, mode=1)[:2] == (0, 128)
+  assert query(8, 68, 68, 128, 512, res=True, mode=2)[:2] == (2, 32)
+  assert query(40, 136, 136, 64, 256, res=True, mode=3)[0] == 1
+  assert query(40, 136, 136, 64, 64, K=3, mode=3)[0] == 0
+
+
 def test_default_config_values_match_reference_defaults():
   c = defaults.bev_localizer()
   assert (c.mask_score_out_of_bounds, c.clip_negative_scores, c.add_temperature) == (False, True, True)
