@@ -151,26 +151,63 @@ def _to(tree, device):
   return tree.to(device)
 
 
-def _pmc_traffic(kernel, launches, workload, default_config=True):
+def source_digest():
+  """sha256 (16 hex) over the kernel sources + the op dispatch: ties a committed counter file to the
+  build it was collected on (.git does not travel to the GPU box, the sources do)."""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  files = sorted(glob.glob(os.path.join(ROOT, 'snap_amd', 'csrc', '*.h*')))
+  files += [os.path.join(ROOT, 'include', 'snap_hip.h'), os.path.join(ROOT, 'snap_amd', 'ops.py')]
+  for f in files:
+    with open(f, 'rb') as fh:
+      h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+  return h.hexdigest()[:16]
+
+
+TRAFFIC_FILES = ('r04_c2_hbm_traffic.json', 'r03_c2_hbm_traffic.json', 'r02_c2_hbm_traffic.json',
+                 'r01_c2_hbm_traffic.json')   # newest round first
+
+
+def _pmc_traffic_record(kernel, launches, workload, default_config=True):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
   (profiles/r0N_c2_hbm_traffic.json, newest round first: FETCH_SIZE / WRITE_SIZE collected in separate
-  passes on this workload, gfx950 x2 read correction applied).  None if unavailable."""
+  passes on this workload, gfx950 x2 read correction applied) + where the figure comes from: the file,
+  the git head / source digest / launch count recorded in it, and `traffic_stale` = the file was
+  collected on other sources or on a step with another launch count of this family than the step
+  timed now (the counters are a separate run by construction; this says when they have aged)."""
   if workload != 'c2' or not default_config:     # (the counter passes ran the default configuration)
     return None
   fam = ('conv_split' if kernel.startswith('conv_split') else
          'mlp2_pool' if kernel.startswith('mlp2_pool') else kernel)
-  rec = None
-  for name in ('r03_c2_hbm_traffic.json', 'r02_c2_hbm_traffic.json', 'r01_c2_hbm_traffic.json'):   # newest round first
+  rec, doc, used = None, None, None
+  for name in TRAFFIC_FILES:
     try:
       with open(os.path.join(ROOT, 'profiles', name)) as f:
-        rec = json.load(f)['per_step'].get(fam)
+        doc = json.load(f)
+      rec = doc['per_step'].get(fam)
     except (OSError, ValueError, KeyError):
       rec = None
     if rec:
+      used = name
       break
   if not rec or not launches:
     return None
-  return round((rec['hbm_read_bytes'] + rec['hbm_write_bytes']) / launches, 1)
+  rec_launches = rec.get('launches')
+  digest_now = source_digest()
+  stale = (doc.get('source_digest') != digest_now) or (rec_launches is not None and rec_launches != launches)
+  return {
+      'traffic': round((rec['hbm_read_bytes'] + rec['hbm_write_bytes']) / launches, 1),
+      'traffic_source': {'file': 'profiles/' + used, 'git_head': doc.get('git_head'),
+                         'source_digest': doc.get('source_digest'), 'source_digest_now': digest_now,
+                         'family_launches_per_step': rec_launches, 'launches_timed': launches},
+      'traffic_stale': bool(stale),
+  }
+
+
+def _pmc_traffic(kernel, launches, workload, default_config=True):
+  rec = _pmc_traffic_record(kernel, launches, workload, default_config)
+  return None if rec is None else rec['traffic']
 
 
 def _sync(device):
@@ -320,7 +357,7 @@ def cpu_baseline(cfg, meta, workload, budget_s=40.0):
   }
 
 
-def main(argv=None):
+def main(argv=None, emit=True):
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=50)
@@ -330,7 +367,7 @@ def main(argv=None):
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--dump', default=None, help='write the per-launch HIP-event timings of the profiled step (JSON)')
   ap.add_argument('--no-extra-legs', action='store_true',
-                  help='skip the two short reference-configuration legs (f32_exact, volume_materialized)')
+                  help='skip the short extra legs (f32_exact, volume_materialized, train_c3, c4, c5)')
   ap.add_argument('--dist-backend', default=None,
                   help='testing only: override the process-group backend (default nccl = RCCL)')
   ap.add_argument('--share-gpu', action='store_true',
@@ -569,6 +606,10 @@ def main(argv=None):
             'traffic': _pmc_traffic(dom, s['launches'], args.workload, default_cfg),
             'launches': s['launches'], 'avg_launch_ms': round(s['ms'] / s['launches'], 4),
         }
+      stamp = _pmc_traffic_record(dom, s['launches'], args.workload, default_cfg)
+      if stamp is not None:
+        out['roofline']['traffic_source'] = stamp['traffic_source']
+        out['roofline']['traffic_stale'] = stamp['traffic_stale']
       if dom.startswith('conv_split') and out['roofline'].get('traffic'):
         # the same family against the HBM roofline: most of its launches are 1x1 convolutions with
         # short reductions, which run at the memory system's pace, not the matrix pipe's
@@ -652,6 +693,37 @@ def main(argv=None):
       pred = None
       out['f32_exact'] = leg('f32')
       out['volume_materialized'] = leg('bf16x3')
+      # The other BASELINE configurations as short driver-timed legs of the same command (same
+      # bracketing: warm-up, sync, K steps, sync; each leg builds its own workload and reports its
+      # dominant kernel against that kernel's roofline): C3 = one train_step (forward + backward +
+      # exchange + Adam) on 4 scenes at the training precision, C4 = the eval pose-estimation path
+      # at 256^2 / 36 yaw hypotheses, C5 = the ViT-B/16 encoder build.
+      loc = variables = batch = None
+      dump_env = os.environ.pop('SNAP_BENCH_DUMP', None)     # (the legs must not overwrite the C2 dump)
+      for key, leg_args in (
+          ('train_c3', ['--mode', 'train', '--workload', 'c3', '--precision', 'bf16', '--steps', '5', '--warmup', '2']),
+          ('c4', ['--workload', 'c4', '--steps', '3', '--warmup', '1']),
+          ('c5', ['--workload', 'c5', '--steps', '5', '--warmup', '2'])):
+        torch.cuda.empty_cache()
+        t1 = time.perf_counter()
+        try:
+          r = main(leg_args + ['--no-cpu-baseline', '--no-extra-legs'], emit=False)
+          out[key] = {
+              'ms_per_step': r['ms_per_step'], 'scenes_per_sec': r['value'], 'metric': r['metric'],
+              'steps': r['steps'], 'warmup': r['warmup'], 'dtype': r['dtype'],
+              'workload': r['config']['workload'], 'mode': r['config']['mode'],
+              'roofline': {k: r['roofline'].get(k) for k in
+                           ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_ms', 'ms')
+                           if k in r.get('roofline', {})},
+              'leg_wall_s': round(time.perf_counter() - t1, 2),
+          }
+          if 'train_logs' in r:
+            out[key]['is_finite'] = r['train_logs'].get('is_finite')
+        except Exception as e:   # a leg must never take the headline down
+          out[key] = {'error': repr(e)}
+      ops.MATMUL_PRECISION = args.math
+      if dump_env is not None:
+        os.environ['SNAP_BENCH_DUMP'] = dump_env
     if args.mode == 'train':
       out['train_logs'] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in last_logs.items()}
     if (world == 1 and not args.no_cpu_baseline and not WORKLOADS[args.workload]['tiny']
@@ -663,7 +735,8 @@ def main(argv=None):
         out['cpu_baseline'] = fn(cfg, meta, args.workload)
       except Exception as e:  # the baseline must never take the bench line down
         out['cpu_baseline'] = {'error': repr(e)}
-    print(json.dumps(out), flush=True)
+    if emit:
+      print(json.dumps(out), flush=True)
   if world > 1:
     dist.barrier()
     dist.destroy_process_group()

@@ -154,6 +154,11 @@ typedef struct SnapConvExtras {
 int32_t snap_conv2d_presplit_tile_rows(const SnapConvDesc* desc, int32_t ps_tile);
 size_t snap_conv2d_presplit_gn_partial_bytes(const SnapConvDesc* desc, int32_t ps_tile);
 size_t snap_conv2d_presplit_workspace_bytes(const SnapConvDesc* desc, int32_t ps_tile);
+/* 1 when the pre-split engine takes the shape `desc` describes (prologue NONE, Cin % 16 == 0, the
+ * input window of a row tile and one column tile of the weight image below its 32-bit offset
+ * limits), else 0: callers that have another engine for the shape (the exhaustive voting of
+ * pose_exhaustive_voting.py:72-104 on very large templates) ask before they pre-split. */
+int32_t snap_conv2d_presplit_supported(const SnapConvDesc* desc);
 /* GroupNorm -> ReLU (resnet.py:34-60,117-130) of a conv output y [N, HW, C] whose partial sums
  * came out of the producing conv's epilogue (extras->gn_partial, row tile `tile_rows`), written
  * ONCE in the pre-split format: out [N*HW][C/16][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] bf16

@@ -83,6 +83,7 @@ SIGNATURES = {
     'snap_conv2d_presplit_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_presplit_gn_partial_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_presplit_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
+    'snap_conv2d_presplit_supported': (c_int, [ctypes.POINTER(SnapConvDesc)]),
     'snap_gn_norm_split_f32': (
         c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr, ptr, ptr, ptr]),
     'snap_presplit_f32': (c_int, [ptr, c_i64, c_int, ptr, ptr]),

@@ -375,26 +375,35 @@ int snapconv::ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t 
   return S >= 2 ? (int)S : 1;
 }
 
+// Shapes the pre-split engine takes (shared by the launch and by snap_conv2d_presplit_supported).
+// 32-bit buffer offsets with an out-of-range marker at 2^31: the input window of one row tile
+// (256 output rows + the kernel's extent, two images) and one column tile of the weight image
+// must stay below 2 GB.
+static bool ps_shape_supported(const SnapConvDesc& d) {
+  if (d.prologue != SNAP_PRO_NONE || d.Cin % 16 != 0 || d.Cin <= 0) return false;
+  const int64_t Wo = d.Wo, Ho = d.Ho, st = d.stride;
+  if (Wo <= 0 || Ho <= 0 || d.N <= 0) return false;
+  int64_t dq = 255 / Wo + 1;                                   // output-row wraps inside a tile
+  if (dq > (int64_t)d.N * Ho - 1) dq = (int64_t)d.N * Ho - 1;
+  int64_t dn = dq / Ho + 1;                                    // image wraps
+  if (dn > d.N - 1) dn = d.N - 1;
+  const int64_t c = d.H - Ho * st > 0 ? d.H - Ho * st : 0;
+  const int64_t dwo = dq == 0 ? (Wo < 256 ? Wo : 256) : Wo;
+  const int64_t span = (dq * st + dn * c + d.KH - 1 + d.pad_t) * d.W + (dwo + 1) * st + d.KW + d.pad_l;
+  if (span * (d.Cin / 16) * 64 >= 0x7ff00000LL) return false;
+  if ((int64_t)d.KH * d.KW * (d.Cin / 16) * 8192 >= 0x7ff00000LL) return false;
+  return true;
+}
+
+extern "C" int32_t snap_conv2d_presplit_supported(const SnapConvDesc* desc) {
+  return (desc && ps_shape_supported(*desc)) ? 1 : 0;
+}
+
 int snapconv::launch_ps(ConvArgs a, hipStream_t s) {
   const SnapConvDesc& d = a.d;
   if (!a.x_ps || !a.w_bf16) return SNAP_ERR_NULL;
-  if (d.prologue != SNAP_PRO_NONE || d.Cin % 16 != 0 || a.rows_in || a.rows_out || a.row_count)
-    return SNAP_ERR_UNSUPPORTED;
-  // 32-bit buffer offsets with an out-of-range marker at 2^31: the input window of one row tile
-  // (256 output rows + the kernel's extent, two images) and one column tile of the weight image
-  // must stay below 2 GB
-  {
-    const int64_t Wo = d.Wo, Ho = d.Ho, st = d.stride;
-    int64_t dq = 255 / Wo + 1;                                   // output-row wraps inside a tile
-    if (dq > (int64_t)d.N * Ho - 1) dq = (int64_t)d.N * Ho - 1;
-    int64_t dn = dq / Ho + 1;                                    // image wraps
-    if (dn > d.N - 1) dn = d.N - 1;
-    const int64_t c = d.H - Ho * st > 0 ? d.H - Ho * st : 0;
-    const int64_t dwo = dq == 0 ? (Wo < 256 ? Wo : 256) : Wo;
-    const int64_t span = (dq * st + dn * c + d.KH - 1 + d.pad_t) * d.W + (dwo + 1) * st + d.KW + d.pad_l;
-    if (span * (d.Cin / 16) * 64 >= 0x7ff00000LL) return SNAP_ERR_UNSUPPORTED;
-  }
-  if ((int64_t)d.KH * d.KW * (d.Cin / 16) * 8192 >= 0x7ff00000LL) return SNAP_ERR_UNSUPPORTED;
+  if (a.rows_in || a.rows_out || a.row_count) return SNAP_ERR_UNSUPPORTED;
+  if (!ps_shape_supported(d)) return SNAP_ERR_UNSUPPORTED;
   const PsTile t = ps_choose_tile(a.M, d.Cout, a.ps_tile);
   a.ctiles = d.Cin / 16;
   a.nk = d.KH * d.KW * a.ctiles;

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_det_kernel(const Sc
   extern __shared__ long long iplane[];
   __shared__ float corner[PB_THREADS / 64][4];
   __shared__ float wmax[PB_THREADS / 64];
+  __shared__ float wbad[PB_THREADS / 64];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_det_kernel(const Sc
   const int n_begin = blockIdx.x * a.points_per_chunk;
   const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
   float pc[PB_PPT], ps[PB_PPT], ptx[PB_PPT], pty[PB_PPT], g[PB_PPT];
-  float gm = 0.f;
+  float gm = 0.f, bad = 0.f;
 #pragma unroll
   for (int k = 0; k < PB_PPT; ++k) {
     const int p = k * PB_THREADS + tid;
@@ -202,13 +203,29 @@ __global__ __launch_bounds__(PB_THREADS) void pose_score_bwd_det_kernel(const Sc
     g[k] = live ? a.dscores[(int64_t)b * a.P + p] : 0.f;
     const float ag = fabsf(g[k]);
     gm = (ag <= 3.0e38f) ? fmaxf(gm, ag) : gm;              // (non-finite cotangents do not set the scale)
+    bad = (ag <= 3.0e38f) ? bad : 1.f;                      // NaN / Inf cotangent (NaN fails the compare)
   }
   gm = wave_max(gm);
-  if (lane == 0) wmax[wave] = gm;
+  bad = wave_max(bad);
+  if (lane == 0) { wmax[wave] = gm; wbad[wave] = bad; }
   __syncthreads();
-  gm = 0.f;
+  gm = 0.f; bad = 0.f;
 #pragma unroll
-  for (int w = 0; w < PB_THREADS / 64; ++w) gm = fmaxf(gm, wmax[w]);
+  for (int w = 0; w < PB_THREADS / 64; ++w) { gm = fmaxf(gm, wmax[w]); bad = fmaxf(bad, wbad[w]); }
+  if (bad != 0.f) {
+    // A non-finite cotangent of this scene cannot go through the fixed-point sums (the conversion
+    // would turn it into a large FINITE number and the trainer's non-finite step skip /
+    // DynamicScale back-off, trainer.py:260-277, would never see the overflow).  The float path
+    // spreads NaN / Inf over the taps of that pose and from there into every parameter gradient;
+    // here the scene's gradient planes are NaN outright: the step is skipped either way.
+    const float nan = __int_as_float(0x7fc00000);
+    for (int n = n_begin; n < n_end; ++n) {
+      float* dst = a.dsim + ((int64_t)b * a.Nq + n) * XY;
+      const float v = a.valid_q[(int64_t)b * a.Nq + n] ? nan : 0.f;
+      for (int i = tid; i < XY; i += PB_THREADS) dst[i] = v;
+    }
+    return;
+  }
   int e = 0;
   frexpf(fmaxf(gm, 1e-37f), &e);                             // gm < 2^e
   const double scale = ldexp(1.0, 38 - e), unscale = ldexp(1.0, e - 38);

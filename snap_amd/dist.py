@@ -17,10 +17,25 @@ import torch
 import torch.distributed as dist
 
 
+# Testing aid: with a process group of ONE rank every path below would
+# short-circuit and never touch the collective library.  ``FORCE_COLLECTIVES = True`` makes an
+# initialised group of any size issue its all-reduces, so that a single-GPU box can prove that
+# RCCL loads next to libsnap_hip.so, that the bucket buffers are device tensors RCCL accepts and
+# that hooks issued from autograd threads order correctly with RCCL's stream.
+FORCE_COLLECTIVES = False
+
+
 def _world(group=None):
   if not (dist.is_available() and dist.is_initialized()):
     return 1
   return dist.get_world_size(group)
+
+
+def _exchanges(group=None) -> bool:
+  """True when the exchange step must really run its collectives."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
 def flatten_tree(tree, prefix=''):
@@ -43,7 +58,7 @@ def allreduce_mean_(tensors: Iterable[torch.Tensor], group=None,
   """
   tensors = [t for t in tensors if t is not None]
   world = _world(group)
-  if world == 1 or not tensors:
+  if not _exchanges(group) or not tensors:
     return 0
   calls = 0
   bucket: List[torch.Tensor] = []
@@ -90,6 +105,7 @@ class OverlappedGradReducer:
     self.leaves = list(leaves)
     self.group = group
     self.world = _world(group)
+    self.exchanges = _exchanges(group)
     self.buckets: List[List[int]] = []
     cur: List[int] = []
     size = 0
@@ -133,7 +149,7 @@ class OverlappedGradReducer:
       self.calls_in_backward += self.calls - before
 
   def _launch(self, bi):
-    if self.handles[bi] is None and self.world > 1:
+    if self.handles[bi] is None and self.exchanges:
       self.handles[bi] = dist.all_reduce(self._buffer(bi), op=dist.ReduceOp.SUM, group=self.group,
                                          async_op=True)
       self.calls += 1
@@ -178,7 +194,9 @@ def all_finite(tensors: Iterable[torch.Tensor], group=None) -> bool:
     ok = torch.isfinite(peak).all().to(torch.float32)
   else:
     ok = torch.ones((), dtype=torch.float32)
-  if _world(group) > 1:
+  if _exchanges(group):
+    if dist.get_backend(group) == 'nccl' and not ok.is_cuda:     # (no tensors: RCCL needs a device buffer)
+      ok = ok.to(torch.device('cuda', torch.cuda.current_device()))
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
   return bool(ok.item() > 0)
 
@@ -192,7 +210,7 @@ def psum_metric_normalizer(metrics: Dict[str, Tuple[torch.Tensor, torch.Tensor]]
       torch.stack([metrics[k][0].to(torch.float64).sum(), metrics[k][1].to(torch.float64).sum()])
       for k in keys
   ])
-  if _world(group) > 1:
+  if _exchanges(group):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
   return {k: (flat[i, 0], flat[i, 1]) for i, k in enumerate(keys)}
 

@@ -122,6 +122,26 @@ class BEVLocalizer(base.Module):
         strides=pyr.strides,
     )
 
+  def _prefetch_scale(self, params):
+    """Queue the D2H read of exp(temperature) at the START of an apply (same value, same bits as a
+    blocking ``float(torch.exp(t))``: the exponential is computed by the same torch kernel)."""
+    self._scale_pending = None
+    t = params.get('temperature') if self.config.add_temperature else None
+    if t is None or not t.is_cuda or base.needs_grad(t):
+      return
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+    host.copy_(torch.exp(t.detach().to(torch.float32)).reshape(1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    self._scale_pending = (t, host, ev)
+
+  def _host_scale(self, temperature):
+    pend, self._scale_pending = getattr(self, '_scale_pending', None), None
+    if pend is not None and pend[0] is temperature:
+      pend[2].synchronize()
+      return float(pend[1][0])
+    return float(torch.exp(temperature.to(torch.float32)))
+
   def similarity(self, params, f_p_q, plane_map, valid_points, want_prob=False, conf_p=None):
     """bev_localizer.py:157-173: sim_points (+ softmax statistics) on the GPU.  ``conf_p`` [B,Nq]:
     query-point confidences (add_confidence_query, :165-168): their masked softmax weights
@@ -145,8 +165,10 @@ class BEVLocalizer(base.Module):
     elif base.needs_grad(fq, fm, temperature):
       sim, stats, prob, scale = ag.sim_softmax(fq, fm, temperature, clip, num_valid, want_prob)
     else:
-      # exp(temperature): a host scalar (one tiny D2H sync per apply).
-      scale = 1.0 if temperature is None else float(torch.exp(temperature.to(torch.float32)))
+      # exp(temperature) is a kernel ARGUMENT (host scalar).  It was read back at the start of this
+      # apply (``_prefetch_scale``: 4 bytes into pinned memory, queued in front of the encoders), so
+      # waiting for its event does not drain the stream: the apply has no blocking host sync.
+      scale = 1.0 if temperature is None else self._host_scale(temperature)
       sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob,
                                             row_weight=weights)
     # the sampler sees stop_gradient(prob_points) (bev_localizer.py:178): detached inputs.
@@ -173,6 +195,7 @@ class BEVLocalizer(base.Module):
     # not leak into the caller's batch (under jax.jit the reference's dict mutation
     # at bev_mapper.py:196 is likewise invisible to the caller).
     data_map, data_query = dict(data['map']), {**data['query'], 'xy_bev': q_xy_p}
+    self._prefetch_scale(params)
     self.bev_mapper.start_aerial(params['bev_mapper'], data_map, train, ctx)   # (second stream)
     try:
       self._encode_views_jointly(params, data_map, data_query, train, ctx)

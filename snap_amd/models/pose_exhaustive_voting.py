@@ -80,11 +80,14 @@ def _correlate(mp, tw, R, q_hw, templates=None):
   pb = max(0, S * (A4 - 1) + (H + S - 1) - mp.shape[0])  # zero rows only cropped outputs can see
   pr = max(0, S * (B4 - 1) + (W + S - 1) - mp.shape[1])
   if (ops.MATMUL_PRECISION == 'bf16x3' and ops.USE_PRESPLIT_VOTING and mp.shape[-1] % 16 == 0
-      and (R * S * S) % 192 == 0):
+      and (R * S * S) % 192 == 0
+      and ops.conv2d_presplit_supported((1,) + tuple(mp.shape), tuple(tws.shape), S, ((0, pb), (0, pr)))):
     # the correlation as ONE large GEMM on the pre-split engine: the map is split into its two
     # bf16 parts once (instead of once per tap and column tile inside the K loop), both operands
     # travel by LDS-DMA, 256 x 192 tiles (R S^2 = 576 = three column tiles); same products, same
-    # k order, same bits as the split engine's im2col body
+    # k order, same bits as the split engine's im2col body.  Template banks beyond the engine's
+    # 32-bit offsets (matching_dim 64 at 256^2, queries of ~360^2 cells) keep the plain-input
+    # launch below, which drops to the f32 engine where the split weight image does not fit
     raw4 = ops.conv2d(ops.presplit(mp[None]), tws, stride=S, padding=((0, pb), (0, pr)), ps_tile=3)[0]
   else:
     raw4 = ops.conv2d(mp[None], tws, stride=S, padding=((0, pb), (0, pr)))[0]   # [A4, B4, R*S*S]

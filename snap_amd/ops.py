@@ -259,6 +259,26 @@ def _stationary_mode():
   return 3 if CONV_NO_WS else 0
 
 
+def conv2d_presplit_supported(x_shape, w_shape, stride=1, padding=((0, 0), (0, 0))):
+  """True when ``conv2d(presplit(x), w, ...)`` has an engine for the shape: the pre-split engine's
+  own limits (``snap_conv2d_presplit_supported``) and a two-part weight image within the split
+  engine's 32-bit offsets.  Callers with a plain-input alternative ask before they pre-split."""
+  lib = _lib.load()
+  N, H, W, Cs = x_shape
+  KH, KW, Cin, Cout = w_shape
+  (pt, pb), (pl, pr) = padding
+  if Cs != Cin or Cin % 16:
+    return False
+  Ho = (H + pt + pb - KH) // stride + 1
+  Wo = (W + pl + pr - KW) // stride + 1
+  if Ho <= 0 or Wo <= 0:
+    return False
+  if lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, 2) == 0:
+    return False
+  d = _lib.SnapConvDesc(N, H, W, Cin, Cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout, PRO_NONE, 0, 1.0, 0.0)
+  return bool(lib.snap_conv2d_presplit_supported(ctypes.byref(d)))
+
+
 def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,

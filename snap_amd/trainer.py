@@ -226,7 +226,7 @@ def _forward_backward(state, batch, model, leaves, sampling_rng, group, debug, o
     total = losses['total']
     loss = torch.where(mask, total, torch.zeros_like(total)).sum() / mask.sum().clamp(min=1)
     objective = loss if loss_scale is None else loss * loss_scale
-    if sdist._world(group) > 1 and overlap_allreduce:
+    if sdist._exchanges(group) and overlap_allreduce:
       reducer = sdist.OverlappedGradReducer(leaves, group).attach()
       objective.backward()                             # buckets go out as their grads land
       grads = reducer.finish()                         # jax.lax.pmean(grad, 'batch')

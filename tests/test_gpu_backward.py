@@ -535,6 +535,17 @@ def test_pose_score_bwd(mask_oob):
     finally:
       ops_bwd.DETERMINISTIC_POSE_BWD = prev
     helpers.report('pose_score bwd (float atomics)', flt, sd.grad.float(), atol=2e-4, rtol=1e-4)
+    # a NaN / Inf cotangent must REACH dsim (trainer.py:260-277: the non-finite step skip and the
+    # DynamicScale back-off look at the gradients): the fixed-point conversion must not turn it into
+    # a finite number.  Scene 0 poisoned, scene 1 clean: scene 1's planes stay bit-identical.
+    for poison in (float('nan'), float('inf'), -float('inf')):
+      ds = dscores.clone()
+      ds[0, 17] = poison
+      bad = ops_bwd.pose_score_bwd(G(ds), G(poses), G(q_xy), G(valid_q), G(mv), tuple(sim.shape),
+                                   cell, mask_oob=False)
+      assert not bool(torch.isfinite(bad[0][G(valid_q)[0]]).all()), poison
+      assert bool((bad[0][~G(valid_q)[0]] == 0).all())
+      assert torch.equal(bad[1], got[1])
 
 
 def test_confidence_head_bwd():

@@ -167,7 +167,17 @@ def test_c4_exhaustive_voting_256_identity_and_planted_pose():
   _voting_known_answers(256)
 
 
-def _voting_known_answers(H, D=32, R=36, dev=None):
+def test_c4_voting_matching_dim_64_beyond_the_presplit_engine():
+  """matching_dim 64 at 256^2: the shift-stacked template bank (259 x 259 x 64 per filter) is beyond
+  the pre-split engine's 32-bit offsets (``snap_conv2d_presplit_supported`` = 0), so the voting must
+  take the plain-input launch instead of raising -- and still find the identity peak."""
+  from snap_amd import ops
+  assert ops.conv2d_presplit_supported((1, 770, 770, 32), (259, 259, 32, 576), 4)
+  assert not ops.conv2d_presplit_supported((1, 770, 770, 64), (259, 259, 64, 576), 4)
+  _voting_known_answers(256, D=64, planted=False)
+
+
+def _voting_known_answers(H, D=32, R=36, dev=None, planted=True):
   """H = W = 256, R = 36, D = 32 (3.94e13 direct-form flops per call).  Identity: the map
   against itself peaks at (0, H-1, W-1).  Planted pose: the query is the map rotated by
   rotation index k = 9 (a quarter turn, exact on the grid) and shifted by s = (3, -4) cells
@@ -189,6 +199,8 @@ def _voting_known_answers(H, D=32, R=36, dev=None):
   centre = c.inv @ tf @ c
   assert abs(float(centre.angle)) < 1e-6 and float(centre.t.abs().max()) <= 0.5 * 0.2 + 1e-6
   del s
+  if not planted:
+    return
   # planted pose: q(u) = m(T u), T = centre-frame rotation by -2 pi k / R and a shift of s cells;
   # k = 9 is a quarter turn, so the resampling is an exact index permutation: q = rot90 + roll
   k, sx, sy = 9, 3, -4

@@ -53,3 +53,17 @@ def test_two_rank_train_step_gradients_on_one_gpu():
   line = [l for l in out.stdout.splitlines() if 'DIST_GPU_OK' in l]
   assert line, out.stdout[-2000:]
   print(f'[dist] {line[0]} (ran on {ran})')
+
+
+def test_rccl_single_rank_forced_collectives():
+  """Backend 'nccl' (RCCL) at world size 1 with ``dist.FORCE_COLLECTIVES``: the exchange step of a
+  real tiny train_step goes through librccl on the GPU (no fallback: RCCL must run here)."""
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4',
+             MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1',
+             LOCAL_RANK='0')
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dist_rccl1_driver.py')],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  line = [l for l in out.stdout.splitlines() if 'RCCL1_OK' in l]
+  assert line and 'backend=nccl' in line[0], out.stdout[-2000:]
+  print(f'[dist] {line[0]}')

@@ -119,6 +119,18 @@ def test_conv_dispatch_queries_follow_the_documented_rules():
   assert query(40, 136, 136, 64, 64, K=3, mode=3)[0] == 0
 
 
+def test_presplit_engine_support_query():
+  """`snap_conv2d_presplit_supported` (host-only): the exhaustive voting asks it before it pre-splits
+  the map.  C4 (256^2, matching_dim 32, shift-stacked by 4) fits; matching_dim 64 at 256^2 and a
+  ~360^2 query do not (32-bit offsets of the weight column tile / the input window): those keep the
+  plain-input launch (pose_exhaustive_voting._correlate)."""
+  assert ops.conv2d_presplit_supported((1, 770, 770, 32), (259, 259, 32, 576), 4)
+  assert not ops.conv2d_presplit_supported((1, 770, 770, 64), (259, 259, 64, 576), 4)
+  assert not ops.conv2d_presplit_supported((1, 1082, 1082, 32), (367, 367, 32, 576), 4)
+  assert not ops.conv2d_presplit_supported((1, 64, 64, 24), (3, 3, 24, 64))       # Cin % 16
+  assert ops.conv2d_presplit_supported((8, 34, 34, 256), (3, 3, 256, 256), 1, ((1, 1), (1, 1)))
+
+
 def test_default_config_values_match_reference_defaults():
   c = defaults.bev_localizer()
   assert (c.mask_score_out_of_bounds, c.clip_negative_scores, c.add_temperature) == (False, True, True)

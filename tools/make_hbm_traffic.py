@@ -62,7 +62,7 @@ def main():
   f, fc = read(fetch_csv, 'FETCH_SIZE')
   w, _ = read(write_csv, 'WRITE_SIZE')
   kernels = {}
-  per_step = collections.defaultdict(lambda: {'hbm_read_bytes': 0.0, 'hbm_write_bytes': 0.0})
+  per_step = collections.defaultdict(lambda: {'hbm_read_bytes': 0.0, 'hbm_write_bytes': 0.0, 'launches': 0})
   for k in sorted(set(f) | set(w)):
     kernels[k] = {f'launches_{steps}steps': fc.get(k, 0), 'FETCH_SIZE_KiB': f.get(k, 0.0),
                   'WRITE_SIZE_KiB': w.get(k, 0.0)}
@@ -71,13 +71,21 @@ def main():
       fam = 'other'
     per_step[fam]['hbm_read_bytes'] += 2.0 * f.get(k, 0.0) * 1024 / steps
     per_step[fam]['hbm_write_bytes'] += w.get(k, 0.0) * 1024 / steps
+    per_step[fam]['launches'] += fc.get(k, 0) // steps
   note = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in SEPARATE passes over `bench.py --steps 1 '
           f'--warmup 1` ({steps} steps per pass), C2 workload. Units KiB. read bytes = 2 x FETCH_SIZE '
           'x 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM '
           'section; exact for 16-B/lane streaming kernels, an upper bound for strided access); write '
           'bytes = WRITE_SIZE x 1024. per_step = bytes of ONE bench step per kernel family '
           '(tools/make_hbm_traffic.py).')
-  json.dump({'_note': note, 'kernels': kernels, 'per_step': per_step}, open(out, 'w'), indent=1)
+  # what bench.py's `roofline.traffic_stale` compares against: the sources the passes ran on (the
+  # digest is computed on the box; the git head is handed in through SNAP_GIT_HEAD -- .git does not
+  # travel) and the launches of a family in one step
+  import os
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import bench
+  json.dump({'_note': note, 'git_head': os.environ.get('SNAP_GIT_HEAD'), 'source_digest': bench.source_digest(),
+             'kernels': kernels, 'per_step': per_step}, open(out, 'w'), indent=1)
   for fam in ('conv_igemm', 'conv_split', 'pose_score', 'lift_pool', 'sim_softmax'):
     if fam in per_step:
       print(fam, {k: f'{v / 1e9:.3f} GB' for k, v in per_step[fam].items()})
