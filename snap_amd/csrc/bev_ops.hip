@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void vertical_pool_kernel(
         const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)z * D + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          acc[i][e] = pooling == SNAP_POOL_MAX ? fmaxf(acc[i][e], v[e]) : acc[i][e] + v[e];
+          acc[i][e] = pooling == SNAP_POOL_MAX ? snap_max_nan(acc[i][e], v[e]) : acc[i][e] + v[e];
       }
     }
   }
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256) void vertical_pool_wave_kernel(
         if (zb >= 0) vb = *reinterpret_cast<const f32x4*>(base + (int64_t)zb * D + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[i][e] = is_max ? fmaxf(acc[i][e], va[e]) : acc[i][e] + va[e];
-          acc[i][e] = is_max ? fmaxf(acc[i][e], vb[e]) : acc[i][e] + vb[e];
+          acc[i][e] = is_max ? snap_max_nan(acc[i][e], va[e]) : acc[i][e] + va[e];
+          acc[i][e] = is_max ? snap_max_nan(acc[i][e], vb[e]) : acc[i][e] + vb[e];
         }
       }
     }
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void vertical_pool_wave_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float other = __shfl_xor(o[e], 32);
-      o[e] = is_max ? fmaxf(o[e], other) : o[e] + other;
+      o[e] = is_max ? snap_max_nan(o[e], other) : o[e] + other;
     }
     if (q < nq && half == 0) {
       if (!any) o = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void plane_fuse_match_kernel(const FuseArgs a)
         const f32x4 x = *reinterpret_cast<const f32x4*>(a.planes[p] + m * a.D + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          acc[i][e] = a.pooling == SNAP_POOL_MAX ? fmaxf(acc[i][e], x[e]) : acc[i][e] + x[e];
+          acc[i][e] = a.pooling == SNAP_POOL_MAX ? snap_max_nan(acc[i][e], x[e]) : acc[i][e] + x[e];
       }
     }
   }

@@ -48,4 +48,16 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(snap_lane(v, 0), snap_lane(v, 16)), fmaxf(snap_lane(v, 32), snap_lane(v, 48)));
 }
 
+// jnp.max / jnp.maximum semantics: a NaN operand makes the result NaN (fmaxf alone is IEEE maxNum
+// and DROPS it).  The pooling kernels (bev_mapper.py:63-78: jnp.max(where=...)) and the ReLUs of
+// the MLP / epilogue paths use these, so that a non-finite forward pass reaches the plane -- and
+// from there the loss and the trainer's non-finite step skip (trainer.py:260-277) -- as it does
+// in the reference.  snap_max_nan returns the canonical POSITIVE quiet NaN: through the
+// sign-split integer atomic max of mlp_pool.hip its bit pattern beats every finite value.
+__device__ __forceinline__ float snap_max_nan(float a, float b) {
+  const float m = fmaxf(a, b);
+  return (a != a || b != b) ? __int_as_float(0x7fc00000) : m;
+}
+__device__ __forceinline__ float snap_relu(float v) { return v < 0.f ? 0.f : v; }   // relu(NaN) = NaN
+
 #endif  // SNAP_CSRC_COMMON_H_

@@ -92,7 +92,7 @@ __device__ __forceinline__ float apply_pro(float v, float mu, float sc, float be
   if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
   if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
   if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
-  if constexpr (PRO == SNAP_PRO_RELU) return fmaxf(v, 0.f);
+  if constexpr (PRO == SNAP_PRO_RELU) return snap_relu(v);
   return v;
 }
 
@@ -216,7 +216,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
       }
       if (epi & SNAP_EPI_RELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = snap_relu(v[e]);
       }
       if (epi & SNAP_EPI_GELU) {
 #pragma unroll
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   }
   if (epi & SNAP_EPI_RELU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    for (int e = 0; e < 4; ++e) v[e] = snap_relu(v[e]);
   }
   if (epi & SNAP_EPI_GELU) {
 #pragma unroll
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(
         }
         if (epi & SNAP_EPI_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = snap_relu(v[e]);
         }
         if (epi & SNAP_EPI_GELU) {
 #pragma unroll

@@ -333,7 +333,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
           av[i][h] = *reinterpret_cast<const f32x4*>(as + 4 * (R * 4 + pq));
           if constexpr (PRO == SNAP_PRO_RELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[i][h][e] = fmaxf(av[i][h][e], 0.f);
+            for (int e = 0; e < 4; ++e) av[i][h][e] = snap_relu(av[i][h][e]);
           }
         }
       // B operand fetch runs one k-pair ahead of the MFMAs (pinned below)

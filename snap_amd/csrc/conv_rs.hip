@@ -429,7 +429,7 @@ __global__ __launch_bounds__(SNAP_RS_NT, 2) void conv1x1_rs_kernel(const ConvArg
         }
         if (relu_out) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = snap_relu(v[e]);
         }
         u32x4 vo;
         __builtin_memcpy(&vo, &v, 16);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bs_kernel(const ConvArgs a) {
           }
           if (relu_out) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = snap_relu(v[e]);
           }
           u32x4 vo;
           __builtin_memcpy(&vo, &v, 16);
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) 
       for (int r = 0; r < 16; ++r) {
         const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;      // tile row = pixel x0 - 1 + ri
         float v = acc[j][r];
-        if (relu_out) v = fmaxf(v, 0.f);
+        if (relu_out) v = snap_relu(v);
         const bool live = ri >= 1 && ri <= TP && x0 - 1 + ri < W;
         if (live) yb[(int64_t)ri * d.Cout_stride + 32 * j] = v;
         if constexpr (STATS > 0) {
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void conv_root_ws64_kernel(const ConvArgs a
       for (int r = 0; r < 16; ++r) {
         const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
         float v = acc[j][r];
-        if (relu_out) v = fmaxf(v, 0.f);
+        if (relu_out) v = snap_relu(v);
         if (x0 + ri < Wo) yb[(int64_t)ri * d.Cout_stride + 32 * j] = v;
       }
   }

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
       f32x4 v = xa[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float pv = RELU_IN ? fmaxf(v[e], 0.f) : v[e];
+        const float pv = RELU_IN ? snap_relu(v[e]) : v[e];
         v[e] = (xin[i] && cur_c + e < a.Cin) ? pv : 0.f;
       }
       u32x2 hi, lo;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
       for (int q = 0; q < 2; ++q) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bias0 + 32 * t + 16 * s + 8 * q + 4 * lhi);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(acc0[t][8 * s + 4 * q + e] + bb[e], 0.f);
+        for (int e = 0; e < 4; ++e) v[q][e] = snap_relu(acc0[t][8 * s + 4 * q + e] + bb[e]);
       }
       // half 0: columns 0-3 | 8-11, half 1: 4-7 | 12-15  ->  half 0: 0-7, half 1: 8-15
 #pragma unroll
@@ -499,10 +499,9 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   int cur = -1;
   float run = -INFINITY;
   const bool live = c < a.D && !(SNAP_MLP_POOL_ABLATE & 8);
-  // (fmaxf = IEEE maxNum: a NaN operand is ignored -- exactly as in vertical_pool_kernel and in the
-  //  ReLU epilogues of the conv engines, so the fused and the unfused configuration treat a
-  //  non-finite forward pass alike (tested); the training step's finite check looks at the loss
-  //  and the gradients, trainer.py)
+  // (snap_max_nan: a NaN of an observed voxel makes the column's maximum NaN, as jnp.max does
+  //  (bev_mapper.py:63-78) -- the same in vertical_pool_kernel; the canonical positive NaN wins the
+  //  integer atomic max below.  The MLP's ReLUs propagate it too (snap_relu).)
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
     const int cr = __builtin_amdgcn_readlane(cid, r);
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
       run = -INFINITY;
     }
     const int row = 64 * h + r;
-    run = fmaxf(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
+    run = snap_max_nan(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
   }
   if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
 }
@@ -687,7 +686,7 @@ __global__ __launch_bounds__(256, 1) void mlp2_pool_wide_kernel(const MlpPoolArg
         for (int q = 0; q < 2; ++q) {
           const f32x4 bb = *reinterpret_cast<const f32x4*>(bias0 + 32 * t + 16 * s + 8 * q + 4 * lhi);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(acc0[b][t][8 * s + 4 * q + e] + bb[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[q][e] = snap_relu(acc0[b][t][8 * s + 4 * q + e] + bb[e]);
         }
         // half 0: columns 0-3 | 8-11, half 1: 4-7 | 12-15  ->  half 0: 0-7, half 1: 8-15
 #pragma unroll
@@ -798,7 +797,7 @@ __global__ __launch_bounds__(256, 1) void mlp2_pool_wide_kernel(const MlpPoolArg
         run = -INFINITY;
       }
       const int row = 128 * h + 64 * q + r;
-      run = fmaxf(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
+      run = snap_max_nan(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
     }
   }
   if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
@@ -814,8 +813,7 @@ __global__ __launch_bounds__(256) void mlp2_pool_finalize_kernel(float* __restri
   const int64_t col = i / Q;
   f32x4* p = reinterpret_cast<f32x4*>(plane) + i;
   f32x4 v = *p;
-  // (a channel whose every value was NaN keeps its -inf, as in vertical_pool_kernel: the quad is
-  //  observed if ANY of its channels was written)
+  // (the quad is observed if ANY of its channels was written; a NaN maximum counts as written)
   const bool any = v[0] != -INFINITY || v[1] != -INFINITY || v[2] != -INFINITY || v[3] != -INFINITY;
   if (!any) *p = f32x4{0.f, 0.f, 0.f, 0.f};
   if (i - col * Q == 0) pvalid[col] = any ? 1 : 0;

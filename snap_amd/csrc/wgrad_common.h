@@ -67,7 +67,7 @@ __device__ __forceinline__ float wg_pro(float v, float mu, float sc, float beta,
   if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
   if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
   if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
-  if constexpr (PRO == SNAP_PRO_RELU) return fmaxf(v, 0.f);
+  if constexpr (PRO == SNAP_PRO_RELU) return snap_relu(v);
   return v;
 }
 

@@ -799,6 +799,69 @@ def test_vertical_pool(pooling, Z, D):
   helpers.report('vpool plane', pg, pw, atol=1e-5, rtol=1e-6)
 
 
+@pytest.mark.parametrize('Z', [60, 70])
+def test_pooling_propagates_nan_of_observed_voxels(Z):
+  """bev_mapper.py:63-78: ``jnp.max(features, where=valid_any_or_all, initial=-inf)`` -- a NaN of an
+  OBSERVED voxel makes that channel of the column NaN; a NaN of a masked voxel (or anywhere in a
+  column without observations) never reaches the plane.  Both pooling paths against oracle/bev.py:
+  the stand-alone kernels (wave-per-column Z <= 64, half-wave Z = 70) and the fused MLP + max kernel
+  (NaN planted in the MLP's INPUT rows: it has to survive both layers, the hidden ReLU included,
+  and the integer atomic max)."""
+  D, ncols = 128, 41
+  g = torch.Generator().manual_seed(71 + Z)
+  vol = torch.randn(ncols, Z, D, generator=g)
+  valid = torch.rand(ncols, Z, generator=g) > 0.5
+  valid[0] = False
+  valid[1] = True
+  valid[2] = False; valid[2, 3] = True
+  vol[1, 5, 7] = float('nan')                      # observed voxel, one channel
+  vol[2, 3, :] = float('nan')                      # the single observed level of its column
+  vol[0, 4, 9] = float('nan')                      # column without observations
+  zi = int((~valid[5]).nonzero()[0]); vol[5, zi, 11] = float('nan')      # masked voxel of an observed column
+  zv = int(valid[6].nonzero()[0]); vol[6, zv, 0] = -float('nan')          # negative-signed NaN, observed
+  vol[7, int(valid[7].nonzero()[-1]), 1] = float('inf')
+  (pg, vg), (pw, vw) = both('vertical_pool', (vol, valid, 'max'))
+  helpers.report('vpool valid', vg, vw, 0)
+  helpers.report('vpool plane (NaN-aware)', pg, pw, atol=0)
+  pg = pg.cpu()
+  assert bool(torch.isnan(pg[1, 7])) and int(torch.isnan(pg[1]).sum()) == 1
+  assert bool(torch.isnan(pg[2]).all()) and not bool(torch.isnan(pg[0]).any())
+  assert not bool(torch.isnan(pg[5]).any()) and bool(torch.isnan(pg[6, 0])) and float(pg[7, 1]) == float('inf')
+  # sum / mean propagate by arithmetic; checked against the oracle too
+  for pooling in ('sum', 'mean'):
+    (pg2, _), (pw2, _) = both('vertical_pool', (vol, valid, pooling))
+    helpers.report(f'vpool {pooling} (NaN-aware)', pg2, pw2, atol=1e-4, rtol=1e-5)
+  # modality fusion: the same masked max over stacked planes (bev_mapper.py:225-252)
+  pa, pb = torch.randn(50, D, generator=g), torch.randn(50, D, generator=g)
+  va, vb = torch.rand(50, generator=g) > 0.3, torch.rand(50, generator=g) > 0.3
+  va[0], vb[0] = True, True; pa[0, 3] = float('nan')          # valid modality: propagates
+  va[1], vb[1] = False, True; pa[1, 4] = float('nan')         # masked modality: ignored
+  got, want = both('plane_fuse_match', ([pa, pb], [va, vb]), dict(pooling='max'))
+  helpers.report('fused plane (NaN-aware)', got[0], want[0], atol=0)
+  assert bool(torch.isnan(got[0][0, 3])) and not bool(torch.isnan(got[0][1]).any())
+  # the fused MLP + max kernel, NaN planted in the input rows
+  cin, stride, H = 257, 260, 256
+  M = ncols * Z
+  x = torch.randn(M, stride, generator=g)
+  x[:, cin:] = 0
+  mask = valid.reshape(-1).clone()
+  w0 = torch.randn(cin, H, generator=g) / cin ** 0.5
+  b0 = torch.randn(H, generator=g) * 0.1
+  w1 = torch.randn(H, D, generator=g) / H ** 0.5
+  b1 = torch.randn(D, generator=g) * 0.1
+  r_obs = 1 * Z + 5                                 # observed row (column 1 is fully observed)
+  r_msk = 5 * Z + zi                                # masked row of an observed column
+  x[r_obs, 100] = float('nan')
+  x[r_msk, 3] = float('nan')
+  x[0 * Z + 2, 8] = float('nan')                    # column without observations
+  (pg, vg), (pw, vw) = both('mlp2_pool_max', (x, mask, w0, b0, w1, b1), dict(cin=cin, Z=Z))
+  helpers.report('mlp2_pool valid', vg, vw, 0)
+  helpers.report('mlp2_pool plane (NaN-aware)', pg, pw, atol=1e-4, rtol=1e-4)
+  pg = pg.cpu()
+  assert bool(torch.isnan(pg[1]).all())             # NaN input -> every hidden unit -> every channel
+  assert int(torch.isnan(pg).any(-1).sum()) == 1    # ... and no other column
+
+
 MLP_POOL_CASES = [
     # cin, stride, H, D, Z, columns, relu_in
     (257, 260, 256, 128, 60, 37, False),     # the reference's fusion MLP / 12 m column at 0.2 m
@@ -843,9 +906,9 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
   plane, pvalid = ops.vertical_pool(vol.reshape(ncols, Z, D), md.reshape(ncols, Z), 'max')
   assert torch.equal(pvalid, vg)
   assert torch.equal(plane, pg), float((plane - pg).abs().max())
-  # a non-finite value that reaches the pooling must look the same in both configurations (both
-  # take IEEE maxNum, which ignores a NaN operand: the channel's maximum stays -inf).  A NaN bias
-  # of the last layer: the fmaxf-based ReLUs in front of it would swallow an earlier one.
+  # a non-finite value that reaches the pooling must look the same in both configurations: the
+  # maximum over a column with a NaN voxel is NaN (jnp.max semantics, bev_mapper.py:63-78).  A NaN
+  # bias of the last layer makes that channel NaN in every observed column, on both paths.
   b1n = b1.clone()
   b1n[D // 2] = float('nan')
   pn, vn = ops.mlp2_pool_max(xd, md, w0.to(DEV), b0.to(DEV), w1.to(DEV), b1n.to(DEV), **kw)
@@ -853,6 +916,7 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
   ops.fill_masked_rows_(voln, md)
   plane_n, _ = ops.vertical_pool(voln.reshape(ncols, Z, D), md.reshape(ncols, Z), 'max')
   assert torch.equal(torch.isnan(pn), torch.isnan(plane_n))
+  assert bool(torch.isnan(pn[vg][:, D // 2]).all()) and not bool(torch.isnan(pn[~vg]).any())
   bad = torch.nan_to_num(pn) != torch.nan_to_num(plane_n)
   assert not bool(bad.any()), (int(bad.sum()), bad.nonzero()[:4].tolist(), pn[bad][:4].tolist(), plane_n[bad][:4].tolist())
   assert torch.equal(vn, vg)
