@@ -567,7 +567,9 @@ int snap_sim_softmax_weighted_f32(const float* fq, const float* fm, int32_t B, i
 /* The same sim / chunk_stats with the Nq x XY x Dm contraction on the bf16 matrix cores at f32
  * grade: fq / fm are split into `parts` bf16 parts per element (3: six products per MAC, ~2^-24
  * per product -- the arithmetic of the conv engine's 'bf16x6'; 2: three products, ~2^-17) into
- * `workspace` first.  Dm in {16, 32, 64}.  (prob / rowstats: use snap_sim_softmax_weighted_f32.) */
+ * `workspace` first.  Dm in {16, 32, 64}.  (prob / rowstats: use snap_sim_softmax_weighted_f32.)
+ * XY % 256 == 0 takes a leaner kernel with the same bits; clip_negative bit 1 (value 2) pins the
+ * general kernel (tests compare the two). */
 size_t snap_sim_split_workspace_bytes(int32_t B, int32_t Nq, int32_t XY, int32_t Dm, int32_t parts);
 int snap_sim_softmax_split_f32(const float* fq, const float* fm, int32_t B, int32_t Nq, int32_t XY,
                                int32_t Dm, float scale, int32_t clip_negative,

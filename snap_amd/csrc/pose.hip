@@ -402,6 +402,142 @@ __global__ __launch_bounds__(256, 3) void sim_split_kernel(
   }
 }
 
+// The same kernel for XY % 256 == 0 (every chunk of every workgroup full: C2 128 x 128, C4 256 x 256,
+// the reference's 120 x 160 map), leaner around the same arithmetic -- identical bits in sim and in
+// the chunk statistics (tests/test_gpu_kernels.py compares the two kernels bit for bit):
+//   * operand roles swapped in the MFMA (A = map cells, B = query rows: the same products in the same
+//     k positions, the transposed accumulator tile): a lane then holds FOUR CONSECUTIVE cells of one
+//     row per accumulator quad, so the tile goes to the staging buffer in 8 ds_write_b128 instead of
+//     32 ds_write_b32 (stride 68 floats: the 16 rows of a lane group land on distinct banks; the old
+//     b32 pattern had a 25 % conflict rate);
+//   * no tail masks (4 compare / select per element) and the clip flag at compile time;
+//   * the (max, sum) pairs of the workgroup's four chunks leave as ONE 32-byte store per row (they
+//     are adjacent in [row][chunk][2]) instead of four 8-byte partial-line writes: the statistics
+//     were a third of the kernel's write requests;
+//   * sim is written with non-temporal stores (2.5 GB streamed once, read back later by the scoring
+//     kernel: nothing of it is worth an L2 line now).
+template <int DM, int NS, bool CLIP>
+__global__ __launch_bounds__(256, 3) void sim_split_fast_kernel(
+    const __bf16* __restrict__ fqs, const __bf16* __restrict__ fms, int Nq, int XY, float scale,
+    const float* __restrict__ num_valid, float* __restrict__ sim, float* __restrict__ stats,
+    const float* __restrict__ row_weight) {
+  constexpr int KS = DM / 16;
+  constexpr int LD = 64 + 4;
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * SIM_TQ;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int chunk = blockIdx.x * 4 + wave;
+  const int cell0 = chunk * SIM_CH;
+  const int NC = XY / SIM_CH;
+  sim_bf16x8 bq[2][KS][NS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const __bf16* src = fms + ((int64_t)b * XY + cell0 + 32 * t + l31) * (NS * DM) + 8 * lhi;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) bq[t][s][p] = *reinterpret_cast<const sim_bf16x8*>(src + p * DM + 16 * s);
+  }
+  __shared__ __attribute__((aligned(16))) float stage[4][32][LD];
+  __shared__ __attribute__((aligned(16))) float sstat[SIM_TQ][8];
+  float (*st)[LD] = stage[wave];
+  const float rnv = 1.0f / num_valid[b];
+  const int sub = lane >> 4;
+  const int c4 = (lane & 15) * 4;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    sim_bf16x8 aq[KS][NS];
+    {
+      const int row = n0 + 32 * ti + l31;
+      const bool rv = row < Nq;
+      const __bf16* src = fqs + ((int64_t)b * Nq + (rv ? row : 0)) * (NS * DM) + 8 * lhi;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          aq[s][p] = *reinterpret_cast<const sim_bf16x8*>(src + p * DM + 16 * s);
+          if (!rv) aq[s][p] = sim_bf16x8{};
+        }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // (cells as the A operand, rows as B: acc[tj][r] = sim[row l31][cell 32 tj + (r & 3) + 8 (r >> 2) + 4 lhi])
+#define SNAP_SIM_PRODUCT(PA, PB)                                                               \
+  _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)                                               \
+      acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[tj][s][PB], aq[s][PA], acc[tj], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if constexpr (NS == 3) {
+        SNAP_SIM_PRODUCT(2, 0)
+        SNAP_SIM_PRODUCT(0, 2)
+        SNAP_SIM_PRODUCT(1, 1)
+        SNAP_SIM_PRODUCT(1, 0)
+        SNAP_SIM_PRODUCT(0, 1)
+        SNAP_SIM_PRODUCT(0, 0)
+      } else {
+        SNAP_SIM_PRODUCT(1, 0)
+        SNAP_SIM_PRODUCT(0, 1)
+        SNAP_SIM_PRODUCT(0, 0)
+      }
+    }
+#undef SNAP_SIM_PRODUCT
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(&st[l31][32 * tj + 8 * g + 4 * lhi]) =
+            f32x4{acc[tj][4 * g], acc[tj][4 * g + 1], acc[tj][4 * g + 2], acc[tj][4 * g + 3]};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int rr = 4 * p + sub;
+      const int n = n0 + 32 * ti + rr;
+      const bool live = n < Nq;
+      const int64_t row = (int64_t)b * Nq + (live ? n : 0);
+      const float wrow = row_weight ? row_weight[row] : rnv;
+      f32x4 x = *reinterpret_cast<const f32x4*>(&st[rr][c4]);
+      float m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (CLIP) x[e] = fmaxf(x[e], 0.f);
+        x[e] *= scale;
+        m = fmaxf(m, x[e]);
+      }
+      m = fmaxf(m, snap_dpp<0x128>(m));
+      m = fmaxf(m, snap_dpp<0x124>(m));
+      m = fmaxf(m, snap_dpp<0x122>(m));
+      m = fmaxf(m, snap_dpp<0x121>(m));
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += __expf(x[e] - m);
+      sum += snap_dpp<0x128>(sum);
+      sum += snap_dpp<0x124>(sum);
+      sum += snap_dpp<0x122>(sum);
+      sum += snap_dpp<0x121>(sum);
+      if (live) {
+        const f32x4 o = f32x4{x[0] * wrow, x[1] * wrow, x[2] * wrow, x[3] * wrow};
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(sim + row * XY + cell0 + c4));
+      }
+      if ((lane & 15) == 0) {
+        sstat[32 * ti + rr][2 * wave] = m;
+        sstat[32 * ti + rr][2 * wave + 1] = sum;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * SIM_TQ) {
+    const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+    const int n = n0 + r;
+    if (n < Nq)
+      *reinterpret_cast<f32x4*>(stats + (((int64_t)b * Nq + n) * NC + blockIdx.x * 4) * 2 + 4 * h) =
+          *reinterpret_cast<const f32x4*>(&sstat[r][4 * h]);
+  }
+}
+
 // layers.masked_softmax over the query points (snap/models/layers.py:38-43) + its inclusive CDF
 // (the sampler's row distribution).  One workgroup per scene; fixed-order sums.
 __global__ __launch_bounds__(256) void masked_softmax_rows_kernel(
@@ -1507,6 +1643,8 @@ extern "C" int snap_sim_softmax_split_f32(const float* fq, const float* fm, int3
   if ((Dm != 16 && Dm != 32 && Dm != 64) || (parts != 2 && parts != 3)) return SNAP_ERR_UNSUPPORTED;
   if (workspace_bytes < snap_sim_split_workspace_bytes(B, Nq, XY, Dm, parts)) return SNAP_ERR_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(workspace) & 15) return SNAP_ERR_BAD_SHAPE;
+  const bool force_general = (clip_negative & 2) != 0;   // bit 1: tests / tools pin the general kernel
+  clip_negative &= 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   __bf16* fqs = static_cast<__bf16*>(workspace);
   __bf16* fms = fqs + (size_t)B * Nq * parts * Dm;
@@ -1520,10 +1658,22 @@ extern "C" int snap_sim_softmax_split_f32(const float* fq, const float* fm, int3
   }
   SNAP_CHECK_LAUNCH();
   const dim3 grid((unsigned)snap_cdiv(XY, 256), (unsigned)snap_cdiv(Nq, SIM_TQ), (unsigned)B);
+  // full-chunk shapes (XY % 256 == 0, 16-byte aligned rows) take the lean kernel: same bits
+  const bool fast = (XY % 256 == 0) && !(reinterpret_cast<uintptr_t>(sim) & 15) &&
+                    !(reinterpret_cast<uintptr_t>(chunk_stats) & 15) && !force_general;
 #define SNAP_SIM_SPLIT_CASE(D, P)                                                                  \
-  hipLaunchKernelGGL((sim_split_kernel<D, P>), grid, dim3(256), 0, s, (const __bf16*)fqs,          \
-                     (const __bf16*)fms, Nq, XY, scale, clip_negative, num_valid, sim, chunk_stats, \
-                     row_weight)
+  do {                                                                                             \
+    if (fast && clip_negative)                                                                     \
+      hipLaunchKernelGGL((sim_split_fast_kernel<D, P, true>), grid, dim3(256), 0, s, (const __bf16*)fqs, \
+                         (const __bf16*)fms, Nq, XY, scale, num_valid, sim, chunk_stats, row_weight); \
+    else if (fast)                                                                                 \
+      hipLaunchKernelGGL((sim_split_fast_kernel<D, P, false>), grid, dim3(256), 0, s, (const __bf16*)fqs, \
+                         (const __bf16*)fms, Nq, XY, scale, num_valid, sim, chunk_stats, row_weight); \
+    else                                                                                           \
+      hipLaunchKernelGGL((sim_split_kernel<D, P>), grid, dim3(256), 0, s, (const __bf16*)fqs,      \
+                         (const __bf16*)fms, Nq, XY, scale, clip_negative, num_valid, sim, chunk_stats, \
+                         row_weight);                                                              \
+  } while (0)
   if (parts == 3) {
     if (Dm == 16) SNAP_SIM_SPLIT_CASE(16, 3); else if (Dm == 32) SNAP_SIM_SPLIT_CASE(32, 3); else SNAP_SIM_SPLIT_CASE(64, 3);
   } else {

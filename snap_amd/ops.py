@@ -1223,6 +1223,9 @@ def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None,
 # ----------------------------------------------------------------------------
 # pose
 # ----------------------------------------------------------------------------
+SIM_GENERAL_KERNEL = False   # tests: pin the general split kernel (the full-chunk kernel is bit-identical)
+
+
 def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
                 want_rowstats=False, row_weight=None, math=None):
   """fq [B,Nq,Dm], fm [B,X,Y,Dm], num_valid [B] float ->
@@ -1258,8 +1261,8 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
     with _region('sim_softmax', 2.0 * B * Nq * XY * Dm,
                  4.0 * (fq.numel() + fm.numel() + sim.numel() + stats.numel())):
       st = lib.snap_sim_softmax_split_f32(
-          _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(clip_negative), _p(num_valid),
-          _p(row_weight), parts, _p(sim), _p(stats), _p(ws), wsb, _stream())
+          _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(bool(clip_negative)) | (2 if SIM_GENERAL_KERNEL else 0),
+          _p(num_valid), _p(row_weight), parts, _p(sim), _p(stats), _p(ws), wsb, _stream())
     _lib.check(st, 'snap_sim_softmax_split_f32')
     return sim, stats, None, None
   with _region(

@@ -1059,6 +1059,33 @@ def test_sim_softmax_split_bf16(X, Y, Dm, Nq, math, tol):
   helpers.report(f'weighted sim {math}', gw[0], ww[0], atol=tol / 10, rtol=tol)
 
 
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('X,Y,Dm,Nq,clip', [(16, 16, 32, 70, True), (32, 24, 16, 150, False), (128, 128, 32, 131, True),
+                                            (16, 48, 64, 64, True)])
+def test_sim_softmax_full_chunk_kernel_keeps_the_general_kernels_bits(X, Y, Dm, Nq, clip, math):
+  """X Y % 256 == 0 takes ``sim_split_fast_kernel`` (operand roles swapped in the MFMA, no tail
+  masks, statistics combined per workgroup, non-temporal stores): sim and the chunk statistics are
+  BIT-IDENTICAL to the general kernel's, with and without confidence weights, ragged row tiles."""
+  B = 2
+  fq = _unit(rnd((B, Nq, Dm), 390)).to(DEV)
+  fm = _unit(rnd((B, X, Y, Dm), 391)).to(DEV)
+  fq[0, 3] = 0
+  nv = torch.tensor([float(Nq - 1), float(Nq)], device=DEV)
+  scale = float(np.exp(2.0))
+  w = torch.rand(B, Nq, generator=torch.Generator().manual_seed(6)) + 0.1
+  w = (w / w.sum(-1, keepdim=True)).contiguous().to(DEV)
+  for rw in (None, w):
+    fast = ops.sim_softmax(fq, fm, scale, clip, nv, math=math, row_weight=rw)
+    try:
+      ops.SIM_GENERAL_KERNEL = True
+      gen = ops.sim_softmax(fq, fm, scale, clip, nv, math=math, row_weight=rw)
+    finally:
+      ops.SIM_GENERAL_KERNEL = False
+    assert torch.equal(fast[0], gen[0]), float((fast[0] - gen[0]).abs().max())
+    assert torch.equal(fast[1], gen[1]), float((fast[1] - gen[1]).abs().max())
+  assert float(fast[0].abs().max()) > 0
+
+
 def test_ransac_sample_given_uniforms():
   B, Nq, X, Y, Dm, S = 2, 40, 24, 20, 16, 600
   fq = _unit(rnd((B, Nq, Dm), 95))
