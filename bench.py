@@ -372,9 +372,10 @@ def main(argv=None, emit=True):
                   help='testing only: override the process-group backend (default nccl = RCCL)')
   ap.add_argument('--share-gpu', action='store_true',
                   help='testing only: every rank uses GPU 0 (multi-process plumbing check on a 1-GPU box)')
-  ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16x3', 'bf16x6'],
+  ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'fp16', 'bf16x3', 'bf16x6'],
                   help="train mode only: 'bf16' rounds the conv / dense operands to bf16 (f32 "
-                       "accumulate) -- the analogue of the reference's float16 train config; the "
+                       "accumulate) -- the analogue of the reference's float16 train config; 'fp16' is "
+                       "that config itself (IEEE-half operands + DynamicScale(minimum_scale=256)); the "
                        "inference headline always runs the exact f32 path")
   ap.add_argument('--math', default='bf16x3', choices=['f32', 'bf16x6', 'bf16x3'],
                   help="infer mode: conv / dense engine.  'f32' = exact f32 MFMA (v_mfma_f32_32x32x2_f32); "
@@ -423,7 +424,10 @@ def main(argv=None, emit=True):
     model = models.get_model('bev_localizer')(cfg, meta)
     tcfg = train_localization.get_config()
     lr_fn = trainer.make_lr_fn(tcfg.lr_configs['base_learning_rate'], tcfg.num_training_steps)
-    state = trainer.TrainState.create(variables['params'], rng=1000 * rank)
+    state = trainer.TrainState.create(
+        variables['params'], rng=1000 * rank,
+        # (trainer.py:391-392: float16 runs carry DynamicScale(minimum_scale=256))
+        dynamic_scale=trainer.DynamicScale(minimum_scale=256.0) if args.precision == 'fp16' else None)
     last_logs = {}
 
     def step(i):
@@ -537,6 +541,8 @@ def main(argv=None, emit=True):
                   else INFER_DTYPE[args.math] if args.mode == 'infer'
                   else 'f32' if args.precision == 'f32'
                   else INFER_DTYPE[args.precision] + '; kernel gradients on the exact f32 engine' if args.precision in INFER_DTYPE
+                  else 'fp16 (IEEE half) GEMM operands and kernel images, f32 accumulate / master parameters / '
+                       'optimizer, DynamicScale loss scaling' if args.precision == 'fp16'
                   else 'bf16 GEMM operands, f32 accumulate / parameters / optimizer'),
         'data': 'synthetic',
         'distributed': dist_info,
@@ -580,7 +586,7 @@ def main(argv=None, emit=True):
       s = summ[dom]
       if s['flops'] > 0:
         ach = s['flops'] / s['ms'] / 1e9
-        peak = PEAK_MFMA_BF16_TFLOPS if dom.endswith('bf16') else PEAK_MFMA_F32_TFLOPS
+        peak = PEAK_MFMA_BF16_TFLOPS if dom.endswith(('bf16', 'fp16')) else PEAK_MFMA_F32_TFLOPS   # (f16 MFMA: same rate)
         nprod = SPLIT_PRODUCTS.get(dom)
         if nprod:   # algorithmic (f32-equivalent) flops against the bf16 peak / products per MAC
           peak = round(PEAK_MFMA_BF16_TFLOPS / nprod, 1)

@@ -143,6 +143,12 @@ typedef struct SnapConvExtras {
                                  split-operand engine (workspace given), whose reduce pass then emits
                                  the partial sums (a split-K launch has no epilogue that sees
                                  finished outputs) */
+  int32_t w_half;             /* with w_split_parts = 0: 1 = the training-precision engine in IEEE
+                                 half -- w_bf16 holds snap_conv2d_pack_weights[_multi]_f16 images,
+                                 the A operand is rounded to f16 (RNE; beyond 65504 -> inf) and the
+                                 products run on v_mfma_f32_32x32x16_f16 (f32 accumulate): the
+                                 reference's dtype=float16 train config (train_localization.py:93,
+                                 resnet.py:97), driven by DynamicScale (trainer.py:391-392) */
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
@@ -194,6 +200,10 @@ int snap_conv2d_pack_weights_split_root_bf16(const float* w /* [7,7,3,Cout] */, 
 size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, int32_t Cout);
 int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
                                   void* out, size_t out_bytes, void* stream);
+/* ... the same image in IEEE half for extras->w_half = 1 (the reference's float16 compute /
+ * parameter dtype, train_localization.py:93, resnet.py:97): same size, same layout */
+int snap_conv2d_pack_weights_f16(const float* w, int32_t taps, int32_t Cin, int32_t Cout,
+                                 void* out, size_t out_bytes, void* stream);
 /* f32-grade engine on the bf16 matrix cores (inference / parity path; replaces the same
  * flax.linen.Conv / Dense calls: resnet.py:73-132, image_encoder.py:67-94, layers.py:55-78).
  * Each f32 operand is split into `parts` bf16 values (hi = bf16(v), then bf16 of the exact f32
@@ -229,6 +239,9 @@ int32_t snap_conv2d_pack_weights_split_blocks(int32_t taps, int32_t Cin, int32_t
 int32_t snap_conv2d_pack_weights_blocks(int32_t taps, int32_t Cin, int32_t Cout);
 int snap_conv2d_pack_weights_multi_bf16(const SnapPackItem* items, int32_t n_items,
                                         int32_t total_blocks, void* stream);
+/* ... the same images in IEEE half (SnapConvExtras.w_half; same sizes and layout) */
+int snap_conv2d_pack_weights_multi_f16(const SnapPackItem* items, int32_t n_items,
+                                       int32_t total_blocks, void* stream);
 int snap_conv2d_pack_weights_split_multi_bf16(const SnapPackItem* items, int32_t n_items,
                                               int32_t total_blocks, int32_t parts, void* stream);
 
@@ -749,6 +762,7 @@ int snap_conv2d_wgrad_rows_f32(const SnapConvDesc* desc, const float* x, const f
  * not carry (Cin < 4, unaligned channel rows) run in f32. */
 #define SNAP_MATH_F32 0
 #define SNAP_MATH_BF16 1
+#define SNAP_MATH_F16 2   /* operands rounded to IEEE half (the reference's float16 train config) */
 int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x, const float* dy,
                              float* dw, const float* gn_mu, const float* gn_sc,
                              const float* gn_beta, int32_t accumulate, void* workspace,

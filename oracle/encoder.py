@@ -36,6 +36,15 @@ def conv2d(x, kernel, strides=(1, 1), padding=((0, 0), (0, 0)), bias=None):
   return out.astype(x.dtype)
 
 
+def fp16_round(x):
+  """float32 -> nearest IEEE binary16 (ties to even; beyond 65504 -> inf, tiny values flush through
+  the subnormals), returned as float32: the rounding step of the 'fp16' training engine -- the
+  reference's ``dtype='float16'`` train config itself (``snap/configs/train_localization.py:93``,
+  ``snap/models/resnet.py:97``)."""
+  with np.errstate(over='ignore'):
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
 def bf16_round(x):
   """float32 -> nearest bfloat16 (ties to even), returned as float32.
 

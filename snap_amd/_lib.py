@@ -39,7 +39,7 @@ class SnapConvExtras(ctypes.Structure):
       ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
       ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
       ('x_presplit', c_int), ('ps_tile', c_int), ('ps_res_init', c_int),
-      ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int),
+      ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int), ('w_half', c_int),
   ]
 
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     'snap_conv2d_tile_rows': (c_int, [ctypes.POINTER(SnapConvDesc)]),
     'snap_conv2d_pack_weights_blocks': (c_int, [c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_multi_bf16': (c_int, [ptr, c_int, c_int, ptr]),
+    'snap_conv2d_pack_weights_multi_f16': (c_int, [ptr, c_int, c_int, ptr]),
     'snap_conv2d_stationary_kind': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_tile_rows_ex': (c_int, [ctypes.POINTER(SnapConvDesc), c_int]),
     'snap_conv2d_gn_partial_bytes_ex': (c_size, [ctypes.POINTER(SnapConvDesc), c_int]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     'snap_gelu_bwd_f32': (c_int, [ptr, ptr, ptr, c_i64, ptr]),
     'snap_conv2d_packed_weights_bytes': (c_size, [c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
+    'snap_conv2d_pack_weights_f16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_conv2d_packed_weights_split_bytes': (c_size, [c_int, c_int, c_int, c_int]),
     'snap_conv2d_packed_weights_split_root_bytes': (c_size, [c_int, c_int]),
     'snap_conv2d_pack_weights_split_root_bf16': (c_int, [ptr, c_int, c_int, ptr, c_size, ptr]),

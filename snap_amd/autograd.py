@@ -39,13 +39,19 @@ def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None):
     dyd[:, ::stride, ::stride] = dy
     dy = dyd
   Ho, Wo = dy.shape[1:3]
-  rot_img = ops.packed_rot_image(w) if ops.MATMUL_PRECISION == 'bf16' else None
+  half_math = ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None
+  rot_img = ops.packed_rot_image(w, half_math) if half_math else None
+  # (the image-only weight below is read only by the bf16 / fp16 engine, which takes the
+  #  launch when the rotated kernel's input channels -- the original Cout -- form aligned quads;
+  #  anything else must rebuild the f32 rotated kernel, or the f32 engine would read garbage)
+  if rot_img is not None and not (Cout >= 4 and Cout % 4 == 0 and dy.data_ptr() % 16 == 0):
+    rot_img = None
   if rot_img is not None:
     # training precision: the rotated kernel's bf16 image was prepared with every other image of the
     # step (ops.pack_weights_bf16_multi); the engine reads only the image, so the f32 tensor is a
     # shape carrier (no flip / permute / pad / pack launches here)
     w_rot = torch.empty((KH, KW, Cout, (Cin + 3) // 4 * 4), dtype=torch.float32, device=dy.device)
-    w_rot._snap_packed = {'bf16': (ops.PACK_EPOCH, w_rot._version, rot_img)}
+    w_rot._snap_packed = {half_math: (ops.PACK_EPOCH, w_rot._version, rot_img)}
   else:
     w_rot = w.flip(0, 1).permute(0, 1, 3, 2)                    # [KH,KW,Cout,Cin]
     if Cin % 4:                                                  # engine writes 4-channel groups:

@@ -22,9 +22,33 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int PRO>
+// Element type of the rounded operands: bf16 (default) or IEEE half (F16: the reference's
+// dtype=float16 train config, train_localization.py:93 -- 11 significand bits instead of 8, the
+// exponent range of half: values beyond 65504 round to inf and reach the trainer's non-finite
+// check, gradients below 6e-8 flush -- which is what DynamicScale is for, trainer.py:391-392).
+template <bool F16> struct Elem;
+template <> struct Elem<false> {
+  typedef __bf16 T; typedef bf16x8 x8; typedef bf16x4 x4;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<true> {
+  typedef _Float16 T; typedef f16x8 x8; typedef f16x4 x4;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int BM, int BN, int PRO, bool F16>
 __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
+  typedef Elem<F16> E;
+  typedef typename E::T ET;
+  typedef typename E::x8 etx8;
+  typedef typename E::x4 etx4;
   constexpr int BK = 32;
   constexpr int TM = BM / 64;
   constexpr int TN = BN / 64;
@@ -136,7 +160,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
       }
     }
   };
-  const __bf16* const wt = static_cast<const __bf16*>(a.w_bf16);
+  const ET* const wt = static_cast<const ET*>(a.w_bf16);
   auto issue_b = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < BPIECES; ++p) {
@@ -173,9 +197,9 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
           pv = apply_pro<PRO>(v[e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
         v[e] = (xin[i] && (cur_c + e < d.Cin)) ? pv : 0.f;
       }
-      const bf16x4 b = __builtin_convertvector(v, bf16x4);
+      const etx4 b = __builtin_convertvector(v, etx4);
       const int oct = (akq >> 1) ^ ((row >> 2) & 3);
-      *reinterpret_cast<bf16x4*>(Ab + buf * (A_ST * 4) + row * 64 + oct * 16 + (akq & 1) * 8) = b;
+      *reinterpret_cast<etx4*>(Ab + buf * (A_ST * 4) + row * 64 + oct * 16 + (akq & 1) * 8) = b;
     }
   };
 
@@ -200,22 +224,22 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
     const char* bs = Bb + cur * (B_ST * 4);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 av[TM], bv[TN];
+      etx8 av[TM], bv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int R = wr * (BM / 2) + i * 32 + l31;
-        av[i] = *reinterpret_cast<const bf16x8*>(as + R * 64 + (((2 * s + lhi) ^ ((R >> 2) & 3)) * 16));
+        av[i] = *reinterpret_cast<const etx8*>(as + R * 64 + (((2 * s + lhi) ^ ((R >> 2) & 3)) * 16));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int C = wc * (BN / 2) + j * 32 + l31;
-        bv[j] = *reinterpret_cast<const bf16x8*>(bs + C * 64 + (((2 * s + lhi) ^ ((C >> 2) & 3)) * 16));
+        bv[j] = *reinterpret_cast<const etx8*>(bs + C * 64 + (((2 * s + lhi) ^ ((C >> 2) & 3)) * 16));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = E::mfma(av[i], bv[j], acc[i][j]);
     }
     if (more) store_a(cur ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the B octets of slab kt+1 landed
@@ -225,9 +249,9 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
   conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
-template <int BM, int BN, int PRO>
+template <int BM, int BN, int PRO, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs a) {
-  conv_bf16_body<BM, BN, PRO>(a);
+  conv_bf16_body<BM, BN, PRO, F16>(a);
 }
 
 template <int BM, int BN, int PRO>
@@ -258,7 +282,10 @@ int launch(ConvArgs a, hipStream_t s) {
       nblocks *= a.ksplit;
     }
   }
-  hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  if (a.half)
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
   if (a.ksplit > 1) {
     const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
@@ -285,8 +312,9 @@ int launch_pro(const ConvArgs& a, hipStream_t s) {
 // w [taps*Cin, Cout] f32 -> out [Cout][taps][cin8] bf16 (RNE), channels Cin..cin8 zero.
 // One 32 x 32 (k x n) tile per workgroup through LDS: coalesced along n on the way in,
 // along k on the way out.
+template <typename ET>
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(
-    const float* __restrict__ w, __bf16* __restrict__ out, int taps, int Cin, int cin8, int Cout) {
+    const float* __restrict__ w, ET* __restrict__ out, int taps, int Cin, int cin8, int Cout) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32, t = blockIdx.z;
@@ -299,7 +327,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(
 #pragma unroll
   for (int j = ty; j < 32; j += 8) {
     const int n = n0 + j, c = c0 + tx;
-    if (n < Cout && c < cin8) out[((int64_t)n * taps + t) * cin8 + c] = (__bf16)tile[tx][j];
+    if (n < Cout && c < cin8) out[((int64_t)n * taps + t) * cin8 + c] = (ET)tile[tx][j];
   }
 }
 
@@ -307,6 +335,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(
 // the ROTATED images the data-gradient convolutions read: out [Cin4][taps][cout8] = w[T-1-t][ci][co],
 // i.e. the image of w.flip(0, 1).permute(0, 1, 3, 2) padded to four output channels -- both sides
 // contiguous along co, no transposition through LDS).  Items sorted by block_begin.
+template <typename ET>
 __global__ __launch_bounds__(256) void pack_weights_bf16_multi_kernel(const SnapPackItem* __restrict__ items,
                                                                       int n_items) {
   __shared__ float tile[32][33];
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_multi_kernel(const Snap
   const int Cin = it.Cin, Cout = it.Cout;
   const int local = blockIdx.x - it.block_begin;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  __bf16* const out = static_cast<__bf16*>(it.out);
+  ET* const out = static_cast<ET*>(it.out);
   if (!rot) {
     const int cin8 = (Cin + 7) / 8 * 8;
     const int gx = (cin8 + 31) / 32, gy = (Cout + 31) / 32;
@@ -336,7 +365,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_multi_kernel(const Snap
 #pragma unroll
     for (int j = ty; j < 32; j += 8) {
       const int n = n0 + j, c = c0 + tx;
-      if (n < Cout && c < cin8) out[((int64_t)n * taps + t) * cin8 + c] = (__bf16)tile[tx][j];
+      if (n < Cout && c < cin8) out[((int64_t)n * taps + t) * cin8 + c] = (ET)tile[tx][j];
     }
   } else {
     const int cin4 = (Cin + 3) / 4 * 4, cout8 = (Cout + 7) / 8 * 8;
@@ -348,7 +377,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_multi_kernel(const Snap
       const int ci = ci0 + j, co = co0 + tx;
       if (ci < cin4 && co < cout8) {
         const float v = (ci < Cin && co < Cout) ? it.w[((int64_t)(taps - 1 - t) * Cin + ci) * Cout + co] : 0.f;
-        out[((int64_t)ci * taps + t) * cout8 + co] = (__bf16)v;
+        out[((int64_t)ci * taps + t) * cout8 + co] = (ET)v;
       }
     }
   }
@@ -368,7 +397,17 @@ extern "C" int snap_conv2d_pack_weights_multi_bf16(const SnapPackItem* items, in
                                                    int32_t total_blocks, void* stream) {
   if (!items) return SNAP_ERR_NULL;
   if (n_items <= 0 || total_blocks <= 0) return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+  hipLaunchKernelGGL(pack_weights_bf16_multi_kernel<__bf16>, dim3((unsigned)total_blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, n_items);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_conv2d_pack_weights_multi_f16(const SnapPackItem* items, int32_t n_items,
+                                                  int32_t total_blocks, void* stream) {
+  if (!items) return SNAP_ERR_NULL;
+  if (n_items <= 0 || total_blocks <= 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(pack_weights_bf16_multi_kernel<_Float16>, dim3((unsigned)total_blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), items, n_items);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
@@ -388,17 +427,32 @@ extern "C" size_t snap_conv2d_packed_weights_bytes(int32_t taps, int32_t Cin, in
   return (size_t)Cout * taps * cin8 * 2;
 }
 
-extern "C" int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin,
-                                             int32_t Cout, void* out, size_t out_bytes,
-                                             void* stream) {
+static int pack_weights_one(const float* w, int32_t taps, int32_t Cin, int32_t Cout, void* out,
+                            size_t out_bytes, bool half, void* stream) {
   if (!w || !out) return SNAP_ERR_NULL;
   if (taps <= 0 || Cin <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
   if (out_bytes < snap_conv2d_packed_weights_bytes(taps, Cin, Cout)) return SNAP_ERR_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(out) & 15) return SNAP_ERR_BAD_SHAPE;
   const int cin8 = (Cin + 7) / 8 * 8;
   const dim3 grid((unsigned)snap_cdiv(cin8, 32), (unsigned)snap_cdiv(Cout, 32), (unsigned)taps);
-  hipLaunchKernelGGL(pack_weights_bf16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
-                     w, static_cast<__bf16*>(out), taps, Cin, cin8, Cout);
+  if (half)
+    hipLaunchKernelGGL(pack_weights_bf16_kernel<_Float16>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w, static_cast<_Float16*>(out), taps, Cin, cin8, Cout);
+  else
+    hipLaunchKernelGGL(pack_weights_bf16_kernel<__bf16>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w, static_cast<__bf16*>(out), taps, Cin, cin8, Cout);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
+}
+
+extern "C" int snap_conv2d_pack_weights_bf16(const float* w, int32_t taps, int32_t Cin,
+                                             int32_t Cout, void* out, size_t out_bytes,
+                                             void* stream) {
+  return pack_weights_one(w, taps, Cin, Cout, out, out_bytes, false, stream);
+}
+
+extern "C" int snap_conv2d_pack_weights_f16(const float* w, int32_t taps, int32_t Cin,
+                                            int32_t Cout, void* out, size_t out_bytes,
+                                            void* stream) {
+  return pack_weights_one(w, taps, Cin, Cout, out, out_bytes, true, stream);
 }

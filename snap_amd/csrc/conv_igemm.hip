@@ -738,6 +738,8 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   // bf16-operand engine (training precision): needs the packed bf16 weights and the float4
   // loader's alignment; anything else runs on the (more precise) f32 engine below.
   a.w_bf16 = ex ? ex->w_bf16 : nullptr;
+  a.half = (ex && ex->w_half) ? 1 : 0;
+  if (a.half && (ex->w_split_parts != 0 || presplit || ex->w_split_root)) return SNAP_ERR_UNSUPPORTED;
   a.cin8 = (d.Cin + 7) / 8 * 8;
   a.x_ps = nullptr;
   a.ps_tile = 0;

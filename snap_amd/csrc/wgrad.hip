@@ -348,7 +348,7 @@ extern "C" int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x
                                         size_t workspace_bytes, const int32_t* rows_z,
                                         const int32_t* rows_dy, const int32_t* row_count,
                                         int32_t math, void* stream) {
-  if (math != SNAP_MATH_F32 && math != SNAP_MATH_BF16) return SNAP_ERR_UNSUPPORTED;
+  if (math != SNAP_MATH_F32 && math != SNAP_MATH_BF16 && math != SNAP_MATH_F16) return SNAP_ERR_UNSUPPORTED;
   if (!desc || !x || !dy || !dw || !workspace) return SNAP_ERR_NULL;
   if ((rows_z || rows_dy) && !(desc->KH == 1 && desc->KW == 1 && desc->stride == 1 &&
                                desc->N == 1 && desc->H == 1 && desc->pad_t == 0 &&
@@ -379,8 +379,8 @@ extern "C" int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x
   a.rows_z = rows_z; a.rows_dy = rows_dy; a.row_count = row_count;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
-  if (vec && math == SNAP_MATH_BF16) {
-    rc = snapwg::launch_bf16(a, p, s);
+  if (vec && math != SNAP_MATH_F32) {
+    rc = snapwg::launch_bf16(a, p, math == SNAP_MATH_F16, s);
   } else if (vec) {
     if (p.bkt == 128) rc = p.bn == 128 ? wg_launch_pro<128, 128, true>(a, p, s) : wg_launch_pro<128, 64, true>(a, p, s);
     else rc = p.bn == 128 ? wg_launch_pro<64, 128, true>(a, p, s) : wg_launch_pro<64, 64, true>(a, p, s);

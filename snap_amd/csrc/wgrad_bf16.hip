@@ -17,9 +17,29 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int BKT, int BN, int PRO>
+// element type of the rounded operands (as conv_bf16.hip): bf16, or IEEE half for SNAP_MATH_F16
+template <bool F16> struct Elem;
+template <> struct Elem<false> {
+  typedef bf16x8 x8; typedef bf16x4 x4;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<true> {
+  typedef f16x8 x8; typedef f16x4 x4;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int BKT, int BN, int PRO, bool F16 = false>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
+  typedef Elem<F16> E;
+  typedef typename E::x8 etx8;
+  typedef typename E::x4 etx4;
   constexpr int RS = 32;                   // reduction slab (output pixels) = two MFMA k-steps
   constexpr int RSB = 80;                  // LDS row stride in bytes (32 bf16 + 16 B pad)
   constexpr int TM = BKT / 64, TN = BN / 64;
@@ -135,14 +155,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x4 t = {zv[0][e], zv[1][e], zv[2][e], zv[3][e]};   // 4 consecutive m of channel e
-        *reinterpret_cast<bf16x4*>(zs + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, bf16x4);
+        *reinterpret_cast<etx4*>(zs + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, etx4);
       }
     }
     if (d_on) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x4 t = {dv[0][e], dv[1][e], dv[2][e], dv[3][e]};
-        *reinterpret_cast<bf16x4*>(ds + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, bf16x4);
+        *reinterpret_cast<etx4*>(ds + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, etx4);
       }
     }
   };
@@ -164,18 +184,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
     const char* ds = Ds0 + cur * D_ST;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 av[TM], bv[TN];
+      etx8 av[TM], bv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        av[i] = *reinterpret_cast<const bf16x8*>(zs + (wr * (BKT / 2) + i * 32 + l31) * RSB + (2 * s + lhi) * 16);
+        av[i] = *reinterpret_cast<const etx8*>(zs + (wr * (BKT / 2) + i * 32 + l31) * RSB + (2 * s + lhi) * 16);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bv[j] = *reinterpret_cast<const bf16x8*>(ds + (wc * (BN / 2) + j * 32 + l31) * RSB + (2 * s + lhi) * 16);
+        bv[j] = *reinterpret_cast<const etx8*>(ds + (wc * (BN / 2) + j * 32 + l31) * RSB + (2 * s + lhi) * 16);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = E::mfma(av[i], bv[j], acc[i][j]);
     }
     if (more) store_slab(cur ^ 1);
     __syncthreads();
@@ -200,28 +220,32 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
 }
 
 template <int BKT, int BN, int PRO>
-int wg_launch(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
+int wg_launch(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
   const dim3 grid((unsigned)(p.ktiles * p.ncol), (unsigned)p.S);
-  hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO>), grid, dim3(256), 0, s, a);
+  if (half)
+    hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, false>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
 
 template <int BKT, int BN>
-int wg_launch_pro(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
+int wg_launch_pro(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
   switch (a.d.prologue) {
-    case SNAP_PRO_NONE: return wg_launch<BKT, BN, SNAP_PRO_NONE>(a, p, s);
-    case SNAP_PRO_AFFINE: return wg_launch<BKT, BN, SNAP_PRO_AFFINE>(a, p, s);
-    case SNAP_PRO_GN_RELU: return wg_launch<BKT, BN, SNAP_PRO_GN_RELU>(a, p, s);
-    case SNAP_PRO_RELU_GN: return wg_launch<BKT, BN, SNAP_PRO_RELU_GN>(a, p, s);
-    case SNAP_PRO_RELU: return wg_launch<BKT, BN, SNAP_PRO_RELU>(a, p, s);
+    case SNAP_PRO_NONE: return wg_launch<BKT, BN, SNAP_PRO_NONE>(a, p, half, s);
+    case SNAP_PRO_AFFINE: return wg_launch<BKT, BN, SNAP_PRO_AFFINE>(a, p, half, s);
+    case SNAP_PRO_GN_RELU: return wg_launch<BKT, BN, SNAP_PRO_GN_RELU>(a, p, half, s);
+    case SNAP_PRO_RELU_GN: return wg_launch<BKT, BN, SNAP_PRO_RELU_GN>(a, p, half, s);
+    case SNAP_PRO_RELU: return wg_launch<BKT, BN, SNAP_PRO_RELU>(a, p, half, s);
     default: return SNAP_ERR_UNSUPPORTED;
   }
 }
 
 }  // namespace
 
-int snapwg::launch_bf16(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
-  if (p.bkt == 128) return p.bn == 128 ? wg_launch_pro<128, 128>(a, p, s) : wg_launch_pro<128, 64>(a, p, s);
-  return p.bn == 128 ? wg_launch_pro<64, 128>(a, p, s) : wg_launch_pro<64, 64>(a, p, s);
+int snapwg::launch_bf16(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
+  if (p.bkt == 128)
+    return p.bn == 128 ? wg_launch_pro<128, 128>(a, p, half, s) : wg_launch_pro<128, 64>(a, p, half, s);
+  return p.bn == 128 ? wg_launch_pro<64, 128>(a, p, half, s) : wg_launch_pro<64, 64>(a, p, half, s);
 }

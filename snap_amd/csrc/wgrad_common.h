@@ -53,7 +53,7 @@ inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
 
 
 // bf16-operand engine (wgrad_bf16.hip); `a` / `p` prepared by snap_conv2d_wgrad_ex_f32
-int launch_bf16(const WgradArgs& a, const WgPlan& p, hipStream_t s);
+int launch_bf16(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s);   // half: IEEE f16 operands
 
 }  // namespace snapwg
 

@@ -174,9 +174,9 @@ class ResNetV2(base.Module):
       std = ag.weight_standardize_multi(kernels)
       pre.update({id(k): s for k, s in zip(kernels, std)})
       ctx.pre_std = pre
-      if ops.MATMUL_PRECISION == 'bf16':
-        # ... and their bf16 images, forward and rotated (data gradient), by one launch
-        ops.pack_weights_bf16_multi(list(std))
+      if ops.MATMUL_PRECISION in ops.HALF_MATH:
+        # ... and their bf16 / fp16 images, forward and rotated (data gradient), by one launch
+        ops.pack_weights_bf16_multi(list(std), math=ops.MATMUL_PRECISION)
     else:   # inference: one launch for all StdConv kernels of this encoder
       ctx.standardize_all(kernels, ops.weight_standardize_multi)
       if ops.MATMUL_PRECISION in ops.SPLIT_PARTS:

@@ -376,7 +376,7 @@ def conv2d(
   M = N * Ho * Wo
   # the engine the launch will take (the statistics layout depends on it)
   math = MATMUL_PRECISION if math is None else math
-  if math not in ('f32', 'bf16', 'bf16x3', 'bf16x6'):
+  if math not in ('f32', 'bf16', 'fp16', 'bf16x3', 'bf16x6'):
     raise ValueError(f'conv2d: math={math!r}')
   parts = SPLIT_PARTS.get(math, 0)
   if parts and lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts) == 0:
@@ -447,7 +447,8 @@ def conv2d(
     ex.w_bf16 = wpk.data_ptr()
     ex.w_bf16_bytes = wpk.numel() * 2
     ex.w_split_parts = parts
-    family = f'conv_split_{math}' if parts else 'conv_bf16'
+    ex.w_half = int(math == 'fp16')
+    family = f'conv_split_{math}' if parts else ('conv_fp16' if math == 'fp16' else 'conv_bf16')
     if ps:
       ex.x_presplit = 1
       ex.ps_tile = pst
@@ -488,16 +489,22 @@ def conv2d(
   return y
 
 
-def pack_weights_bf16(w):
-  """w [KH,KW,Cin,Cout] f32 -> the bf16 engine's weight image [Cout][KH*KW][roundup(Cin,8)]."""
+def pack_weights_bf16(w, half=False):
+  """w [KH,KW,Cin,Cout] f32 -> the training-precision engine's weight image
+  [Cout][KH*KW][roundup(Cin,8)] in bf16, or (half) IEEE float16 -- math 'fp16'."""
   lib = _lib.load()
   _f32(w, 'w')
   KH, KW, Cin, Cout = w.shape
   nbytes = lib.snap_conv2d_packed_weights_bytes(KH * KW, Cin, Cout)
-  out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
-  st = lib.snap_conv2d_pack_weights_bf16(_p(w), KH * KW, Cin, Cout, _p(out), nbytes, _stream())
-  _lib.check(st, 'snap_conv2d_pack_weights_bf16')
+  out = torch.empty(nbytes // 2, dtype=torch.float16 if half else torch.bfloat16, device=w.device)
+  fn = lib.snap_conv2d_pack_weights_f16 if half else lib.snap_conv2d_pack_weights_bf16
+  st = fn(_p(w), KH * KW, Cin, Cout, _p(out), nbytes, _stream())
+  _lib.check(st, 'snap_conv2d_pack_weights_f16' if half else 'snap_conv2d_pack_weights_bf16')
   return out
+
+
+# the training-precision engines: operands rounded to bf16 / IEEE half, f32 accumulate
+HALF_MATH = ('bf16', 'fp16')
 
 
 SPLIT_PARTS = {'bf16x3': 2, 'bf16x6': 3}
@@ -522,7 +529,7 @@ def _packed_weights(w, math, parts):
   if math.endswith('/root'):
     wpk = pack_weights_split_root_bf16(w, parts)
   else:
-    wpk = pack_weights_split_bf16(w, parts) if parts else pack_weights_bf16(w)
+    wpk = pack_weights_split_bf16(w, parts) if parts else pack_weights_bf16(w, half=(math == 'fp16'))
   if slot is None:
     slot = {}
     try:
@@ -605,15 +612,18 @@ def pack_weights_split_multi(ws, math):
     slot[math] = (PACK_EPOCH, w._version, out)
 
 
-def pack_weights_bf16_multi(ws, with_rotated=True):
-  """Training precision: the bf16 engine's image of every kernel in ``ws`` (HWIO tensors) -- and, for
-  the data-gradient convolutions, of its rotated transpose -- with ONE launch; remembered on the
-  tensors for the current apply (``_packed_weights`` / ``packed_rot_image``)."""
+def pack_weights_bf16_multi(ws, with_rotated=True, math='bf16'):
+  """Training precision (math 'bf16' | 'fp16'): the engine's image of every kernel in ``ws`` (HWIO
+  tensors) -- and, for the data-gradient convolutions, of its rotated transpose -- with ONE launch;
+  remembered on the tensors for the current apply (``_packed_weights`` / ``packed_rot_image``)."""
   lib = _lib.load()
+  if math not in HALF_MATH:
+    raise ValueError(f'pack_weights_bf16_multi: math={math!r}')
+  half = math == 'fp16'
   todo = []
   for w in ws:
     slot = getattr(w, '_snap_packed', None)
-    hit = None if slot is None else slot.get('bf16')
+    hit = None if slot is None else slot.get(math)
     if isinstance(hit, tuple) and hit[0] == PACK_EPOCH and hit[1] == w._version:
       continue
     if w.shape[2] < 4:
@@ -633,29 +643,30 @@ def pack_weights_bf16_multi(ws, with_rotated=True):
     for rot in ((False, True) if with_rotated else (False,)):
       nbytes = (lib.snap_conv2d_packed_weights_bytes(taps, Cout, (Cin + 3) // 4 * 4) if rot
                 else lib.snap_conv2d_packed_weights_bytes(taps, Cin, Cout))
-      out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+      out = torch.empty(nbytes // 2, dtype=torch.float16 if half else torch.bfloat16, device=w.device)
       outs.append(out)
       items[i] = (w.data_ptr(), out.data_ptr(), -taps if rot else taps, Cin, Cout, blk)
       blk += lib.snap_conv2d_pack_weights_blocks(-taps if rot else taps, Cin, Cout)
       i += 1
   table = torch.from_numpy(items.view(np.uint8).copy()).to(todo[0].device, non_blocking=True)
-  st = lib.snap_conv2d_pack_weights_multi_bf16(_p(table), n, blk, _stream())
-  _lib.check(st, 'snap_conv2d_pack_weights_multi_bf16')
+  fn = lib.snap_conv2d_pack_weights_multi_f16 if half else lib.snap_conv2d_pack_weights_multi_bf16
+  st = fn(_p(table), n, blk, _stream())
+  _lib.check(st, 'snap_conv2d_pack_weights_multi_f16' if half else 'snap_conv2d_pack_weights_multi_bf16')
   k = 0
   for w in todo:
     slot = getattr(w, '_snap_packed', None)
     if slot is None:
       slot = {}
       w._snap_packed = slot
-    slot['bf16'] = (PACK_EPOCH, w._version, outs[k]); k += 1
+    slot[math] = (PACK_EPOCH, w._version, outs[k]); k += 1
     if with_rotated:
-      slot['bf16/rot'] = (PACK_EPOCH, w._version, outs[k]); k += 1
+      slot[math + '/rot'] = (PACK_EPOCH, w._version, outs[k]); k += 1
 
 
-def packed_rot_image(w):
-  """The rotated bf16 image ``pack_weights_bf16_multi`` prepared for ``w`` in this apply, or None."""
+def packed_rot_image(w, math='bf16'):
+  """The rotated image ``pack_weights_bf16_multi`` prepared for ``w`` in this apply, or None."""
   slot = getattr(w, '_snap_packed', None)
-  hit = None if slot is None else slot.get('bf16/rot')
+  hit = None if slot is None else slot.get(math + '/rot')
   if isinstance(hit, tuple) and hit[0] == PACK_EPOCH and hit[1] == w._version:
     return hit[2]
   return None

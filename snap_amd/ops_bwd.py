@@ -37,11 +37,11 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   """dw [KH,KW,Cin,Cout] = im2col(prologue(x))^T dy  (MFMA; deterministic split-M).
 
   rows_z / rows_dy / row_count: row lists over flat [1,1,M,C] operands (masked MLP).
-  math: 'f32' | 'bf16' (None = ``ops.MATMUL_PRECISION``), as ``ops.conv2d``."""
+  math: 'f32' | 'bf16' | 'fp16' (None = ``ops.MATMUL_PRECISION``), as ``ops.conv2d``."""
   math = ops.MATMUL_PRECISION if math is None else math
   if math in ops.SPLIT_PARTS:
     math = 'f32'         # the split engine has no weight-gradient kernel: exact f32 (trainer 'bf16x3')
-  if math not in ('f32', 'bf16'):
+  if math not in ('f32', 'bf16', 'fp16'):
     raise ValueError(f'conv2d_wgrad: math={math!r}')
   lib = _lib.load()
   _f32(x, 'x'); _f32(dy, 'dy')
@@ -61,11 +61,13 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   M = yshape[0] * yshape[1] * yshape[2]
   kfl = 2.0 * KH * KW * Cin * Cout
   flops = kfl * M if row_count is None else (lambda: kfl * int(row_count.item()))
-  bf16 = math == 'bf16' and x.shape[-1] % 4 == 0 and Cin >= 4
-  with _region('conv_wgrad_bf16' if bf16 else 'conv_wgrad', flops, 4.0 * (x.numel() + dy.numel())):
+  bf16 = math in ops.HALF_MATH and x.shape[-1] % 4 == 0 and Cin >= 4
+  code = (2 if math == 'fp16' else 1) if bf16 else 0          # SNAP_MATH_F16 / _BF16 / _F32
+  with _region(('conv_wgrad_fp16' if code == 2 else 'conv_wgrad_bf16') if bf16 else 'conv_wgrad', flops,
+               4.0 * (x.numel() + dy.numel())):
     st = lib.snap_conv2d_wgrad_ex_f32(
         ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(mu), _p(sc), _p(beta), 0, _p(ws),
-        ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), int(bf16), _stream(),
+        ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), code, _stream(),
     )
   _lib.check(st, 'snap_conv2d_wgrad_ex_f32')
   return dw

@@ -150,7 +150,12 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   precision: 'f32' -- every conv / dense (forward, dgrad, wgrad) on the exact f32 matrix
   cores; 'bf16' -- their operands are rounded to bf16 with f32 accumulation (the analogue of
   the reference's ``dtype='float16'`` train config, train_localization.py:25, trainer.py:391;
-  bf16 keeps the f32 exponent range, so no DynamicScale loss scaling is needed); 'bf16x3' /
+  bf16 keeps the f32 exponent range, so no DynamicScale loss scaling is needed); 'fp16' -- the
+  reference's configuration itself: operands (activations, gradients AND the kernel images the
+  engine multiplies: resnet.py:97 param_dtype) rounded to IEEE half, f32 accumulate, to be run with
+  ``TrainState.dynamic_scale = DynamicScale(minimum_scale=256)`` (trainer.py:391-392): an overflow
+  to inf in the half-precision operands reaches the gradients, the step is skipped and the scale
+  halves; 'bf16x3' /
   'bf16x6' -- forward and data-gradient convs / denses on the f32-grade split-bf16 engine
   (``conv_split.hip``: 2 / 3 bf16 parts per operand, f32 accumulate), kernel gradients on the
   exact f32 engine: an f32-class step at well under the f32 engine's cost.  Parameters,
@@ -167,7 +172,7 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   state.rng += 1
   rank = torch.distributed.get_rank(group) if sdist._world(group) > 1 else 0
   sampling_rng = state.rng * 7919 + rank            # bind the stream to the device
-  if precision not in ('f32', 'bf16', 'bf16x3', 'bf16x6'):
+  if precision not in ('f32', 'bf16', 'fp16', 'bf16x3', 'bf16x6'):
     raise ValueError(f'train_step: precision={precision!r}')
   prev_precision = ops.MATMUL_PRECISION
   ops.MATMUL_PRECISION = precision      # read by the backward thread too (module global)

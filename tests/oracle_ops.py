@@ -73,9 +73,10 @@ def conv2d(x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_N
   cin = wn.shape[2] if cin is None else cin
   cs = xn.shape[-1]
   xn = _prologue(xn, prologue, gn, in_affine, cin)
-  if math == 'bf16' and cs % 4 == 0 and cin >= 4:   # (other shapes run on the f32 engine)
-    xn = o_enc.bf16_round(xn.astype(np.float32)).astype(np.float64)
-    wn = o_enc.bf16_round(wn.astype(np.float32)).astype(np.float64)
+  if math in ('bf16', 'fp16') and cs % 4 == 0 and cin >= 4:   # (other shapes run on the f32 engine)
+    rnd_ = o_enc.fp16_round if math == 'fp16' else o_enc.bf16_round
+    xn = rnd_(xn.astype(np.float32)).astype(np.float64)
+    wn = rnd_(wn.astype(np.float32)).astype(np.float64)
     y = o_enc.conv2d(xn, wn, (stride, stride), padding).astype(DTYPE)
     xn = None
   if xn is not None:

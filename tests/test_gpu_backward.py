@@ -166,14 +166,14 @@ def test_conv_wgrad_bf16_tall_products(Cin, Cs, Cout, relu):
   helpers.report('wgrad bf16 tall', got, ref, atol=2e-5 * float(ref.abs().max()) + 1e-4)
 
 
-@pytest.mark.parametrize('math_', ['f32', 'bf16'])
+@pytest.mark.parametrize('math_', ['f32', 'bf16', 'fp16'])
 def test_conv_wgrad_and_dgrad_random_shapes_fuzz(math_):
   """16 seeded random (shape, stride, padding, prologue) combinations per engine: kernel and data
   gradients vs torch fp64 autograd of the plain restatement (operands rounded to bf16 first for
   the bf16 engine, so the tolerance stays in the f32 round-off class)."""
   from oracle import encoder as o_enc
   from snap_amd import autograd as ag
-  rng = np.random.default_rng(3030 if math_ == 'f32' else 3031)
+  rng = np.random.default_rng({'f32': 3030, 'bf16': 3031, 'fp16': 3032}[math_])
   for it in range(16):
     N = int(rng.integers(1, 3))
     k = int(rng.choice([1, 3]))
@@ -190,7 +190,7 @@ def test_conv_wgrad_and_dgrad_random_shapes_fuzz(math_):
     dy = rnd((N, Ho, Wo, Cout), 300 + it)
     aff = (1.5, -0.25) if pro == ops.PRO_AFFINE else (1.0, 0.0)
     z32 = oracle_ops._prologue(x.numpy(), pro, None, aff, Cin)
-    rnd_ = o_enc.bf16_round if math_ == 'bf16' else (lambda a: a)
+    rnd_ = {'bf16': o_enc.bf16_round, 'fp16': o_enc.fp16_round}.get(math_, lambda a: a)
     zd = torch.from_numpy(rnd_(z32)).double()
     wd = torch.from_numpy(rnd_(w.numpy())).double().requires_grad_(True)
     zd.requires_grad_(True)

@@ -124,6 +124,54 @@ def test_conv_bf16_plain(case):
     assert (got.cpu() - exact).abs().max() > 1e-4
 
 
+# IEEE-half operand engine (math='fp16': the reference's dtype=float16 train config,
+# train_localization.py:93): the same kernels on v_mfma_f32_32x32x16_f16, compared with the
+# restatement that rounds both operands to binary16 (oracle/encoder.py:fp16_round).
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fp16_plain(case):
+  _, N, H, W, Cin, KH, KW, Cout, stride, pad = case
+  x = rnd((N, H, W, Cin), 1)
+  w = rnd((KH, KW, Cin, Cout), 2, 1.0 / np.sqrt(KH * KW * Cin))
+  kw = dict(stride=stride, padding=((pad, pad), (pad, pad)), math='fp16')
+  got, want = both('conv2d', (x, w), kw)
+  helpers.report('conv fp16 ' + case[0], got, want, atol=3e-5, rtol=1e-5)
+  if Cin >= 4 and Cin % 4 == 0 and DEV == 'cuda':
+    exact = oracle_ops.conv2d(x, w, stride=stride, padding=((pad, pad), (pad, pad)))
+    bf = ops.conv2d(x.to(DEV), w.to(DEV), math='bf16', **{k: v for k, v in kw.items() if k != 'math'})
+    e16 = float((got.cpu() - exact).abs().max())
+    assert 1e-6 < e16 < float((bf.cpu() - exact).abs().max())       # half really ran: 11 bits beat 8
+
+
+def test_conv_fp16_prologues_overflow_and_underflow():
+  """GroupNorm prologues / residual / bias / ReLU on the half engine; an operand beyond 65504 becomes
+  inf (and reaches the output: what DynamicScale watches for), one below 2^-25 flushes to zero."""
+  N, H, W, Cin, Cout = 2, 15, 13, 96, 200
+  x = rnd((N, H, W, Cin), 31) + 0.2
+  w = rnd((3, 3, Cin, Cout), 32, 1 / np.sqrt(9 * Cin))
+  gamma, beta = rnd((Cin,), 33) + 1, rnd((Cin,), 34) * 0.1
+  res = rnd((N, H, W, Cout), 35)
+  bias = rnd((Cout,), 36)
+  for pro, relu_first in ((ops.PRO_GN_RELU, False), (ops.PRO_RELU_GN, True)):
+    mu, sc = oracle_ops.group_norm_stats(x, gamma, relu_first=relu_first)
+    kw = dict(padding=((1, 1), (1, 1)), prologue=pro, gn=(mu, sc, beta), residual=res,
+              bias=bias, relu=True, math='fp16')
+    got, want = both('conv2d', (x, w), kw)
+    helpers.report(f'conv fp16 pro {pro}', got, want, atol=5e-5, rtol=1e-5)
+  xs = rnd((1, 1, 700, 260), 37)
+  ws = rnd((1, 1, 257, 256), 38, 1 / 16.0)
+  got, want = both('conv2d', (xs, ws), dict(cin=257, prologue=ops.PRO_RELU, math='fp16'))
+  helpers.report('dense fp16 k257', got, want, atol=5e-5, rtol=1e-5)
+  xo = rnd((1, 4, 4, 64), 39)
+  wo = rnd((1, 1, 64, 64), 40, 0.1)
+  xo[0, 1, 2, 5] = 7.0e4                         # > 65504: inf in half
+  xo[0, 2, 2, 7] = 1.0e-9                        # < 2^-25: zero in half
+  y = ops.conv2d(xo.to(DEV), wo.to(DEV), math='fp16').cpu()
+  assert bool(torch.isinf(y[0, 1, 2]).all()) and bool(torch.isfinite(y[0, 2, 2]).all())
+  got, want = both('conv2d', (xo, wo), dict(math='fp16'))
+  helpers.report('conv fp16 overflow', got, want, atol=3e-5, rtol=1e-5)
+  assert bool(torch.isfinite(ops.conv2d(xo.to(DEV), wo.to(DEV), math='bf16')).all())
+
+
 @pytest.mark.parametrize('tile', ['128x128', '128x64', '64x128', '64x64'])
 def test_conv_bf16_every_tile_variant(tile, monkeypatch):
   monkeypatch.setattr(ops, 'CONV_TILE', tile)

@@ -247,6 +247,63 @@ def test_bf16_training_precision_tracks_f32():
   assert min(losses[3:]) < losses[0], losses
 
 
+def test_fp16_training_precision_with_dynamic_scale():
+  """precision='fp16' is the reference's own train configuration (train_localization.py:93
+  dtype=float16, resnet.py:97 param_dtype, trainer.py:391-392 DynamicScale(minimum_scale=256)):
+  GEMM operands and kernel images in IEEE half, f32 accumulate, loss scaling.  (1) loss and
+  gradients track the exact f32 step, closer than the bf16 engine's (11 vs 8 significand bits);
+  (2) scaled steps are finite and the loss goes down; (3) a scale that overflows the half operands
+  of the backward GEMMs produces non-finite gradients: the update is skipped, the scale backs off."""
+  from snap_amd import ops
+  from snap_amd.utils import geometry
+  model, params, batch = _setup(seed=4)
+  with torch.no_grad():
+    pred = model.flax_model.apply({'params': params}, batch, train=False, rngs={'sampling': 5})
+  s = pred['map_t_query_samples']
+  pose_samples = geometry.Transform2D(s.angle[:, 1:].contiguous(), s.t[:, 1:].contiguous())
+  leaves = dict(trainer.flatten_params(params))
+  out = {}
+  for precision in ('f32', 'bf16', 'fp16'):
+    for t in leaves.values():
+      t.requires_grad_(True)
+    ops.MATMUL_PRECISION = precision
+    try:
+      loss = _loss(model, params, batch, pose_samples)
+      # (loss scaling as trainer._forward_backward does it: a power of two, exact)
+      grads = torch.autograd.grad(loss * 1024.0, list(leaves.values()), allow_unused=True)
+    finally:
+      ops.MATMUL_PRECISION = 'f32'
+    for t in leaves.values():
+      t.requires_grad_(False)
+    out[precision] = (float(loss), torch.cat([g.reshape(-1) for g in grads]) / 1024.0)
+  (l32, g32), (lb, gb), (lh, gh) = out['f32'], out['bf16'], out['fp16']
+  assert lh != l32 and lh != lb                                      # the half engine really ran
+  assert abs(lh - l32) <= 5e-3 * abs(l32) + 1e-3, (l32, lh)
+  assert abs(lh - l32) <= abs(lb - l32) + 1e-6, (l32, lb, lh)
+  cos_h = float(torch.dot(g32, gh) / (g32.norm() * gh.norm()))
+  cos_b = float(torch.dot(g32, gb) / (g32.norm() * gb.norm()))
+  assert cos_h > 0.995 and cos_h >= cos_b - 1e-4 and 0.95 < float(gh.norm() / g32.norm()) < 1.05, (cos_h, cos_b)
+  state = trainer.TrainState.create(copy.deepcopy(params), rng=0,
+                                    dynamic_scale=trainer.DynamicScale(minimum_scale=256.0))
+  lr_fn = trainer.make_lr_fn(2e-3, 100)
+  losses = []
+  for _ in range(6):
+    state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn, max_grad_norm=10.0,
+                                        precision='fp16')
+    assert logs['is_finite'] and np.isfinite(logs['loss']) and logs['loss_scale'] == 65536.0
+    losses.append(logs['loss'])
+  assert ops.MATMUL_PRECISION == 'f32'
+  assert min(losses[3:]) < losses[0], losses
+  # overflow: 2^100 x gradient does not fit binary16 (nor the f32 accumulators) anywhere in the backward GEMMs
+  state.dynamic_scale = trainer.DynamicScale(scale=2.0 ** 100, minimum_scale=256.0)
+  before = copy.deepcopy(state.params)
+  count = state.opt_count
+  state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn, precision='fp16')
+  assert not logs['is_finite'] and logs['loss_scale'] == 2.0 ** 99 and state.opt_count == count
+  assert all(torch.equal(a, b) for (_, a), (_, b) in
+             zip(trainer.flatten_params(before), trainer.flatten_params(state.params)))
+
+
 def test_vit_encoder_gradients_match_torch_autograd():
   """encoder_name='vit' training path: d loss / d theta of the hand-written VJP chain (f32 GEMMs,
   bf16 attention) vs torch fp64 autograd of a plain torch restatement of the same tiny ViT."""
