@@ -770,6 +770,23 @@ int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x, const flo
                              const int32_t* rows_dy, const int32_t* row_count, int32_t math,
                              void* stream);
 
+/* Adam over every parameter tensor in ONE launch (optax.adam as train_step applies it,
+ * snap/trainer.py:236-243: m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2,
+ * p -= lr / (1 - b1^step) * m / (sqrt(v / (1 - b2^step)) + eps); `step` counts from 1).
+ * `items`: DEVICE table sorted by block_begin; item i owns snap_adam_multi_blocks(n) workgroups
+ * of 1024 elements.  p, m, v are updated in place; g is read. */
+typedef struct SnapAdamItem {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  int64_t block_begin;
+} SnapAdamItem;
+int64_t snap_adam_multi_blocks(int64_t n);
+int snap_adam_multi_f32(const SnapAdamItem* items, int32_t n_items, int64_t total_blocks, float lr,
+                        float b1, float b2, float eps, int32_t step, void* stream);
+
 /* GroupNorm(+ReLU) backward.  dz: grad w.r.t. the prologue output; add: optional extra
  * gradient summed into dx (identity-residual branch).  mode: SNAP_PRO_GN_RELU /
  * SNAP_PRO_RELU_GN.  dgamma/dbeta [C] (+)=. */

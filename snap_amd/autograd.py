@@ -63,6 +63,14 @@ def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None):
   return ops.conv2d(dy.contiguous(), w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
 
 
+def _own(grad):
+  """A contiguous gradient buffer this node may overwrite: the incoming one itself when the op that
+  produced it handed it over (ops_bwd.mark_scratch: the pose-score VJP's 1.2 GB plane stack at C3 --
+  the clone was 0.5 ms per step), else a copy."""
+  g = grad.contiguous()
+  return g if ops_bwd.take_scratch(g) else g.clone()
+
+
 def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid, row_weight=None):
   """VJP of sim = relu(fq . fm) * scale / num_valid -- or * scale * row_weight[b, n]
   (add_confidence_query).  `dsim` is overwritten.
@@ -739,7 +747,7 @@ class _SimSoftmaxWeighted(torch.autograd.Function):
   @staticmethod
   def backward(ctx, dsim, _ds, _dp):
     fq, fm, sim, num_valid, weights = ctx.saved_tensors
-    dfq, dfm, dtemp, dw = similarity_bwd(dsim.contiguous().clone(), sim, fq, fm, ctx.scale, ctx.clip,
+    dfq, dfm, dtemp, dw = similarity_bwd(_own(dsim), sim, fq, fm, ctx.scale, ctx.clip,
                                          num_valid, row_weight=weights)
     return dfq, dfm, (dtemp if ctx.has_t else None), dw, None, None, None
 
@@ -770,7 +778,7 @@ class _SimSoftmax(torch.autograd.Function):
   @staticmethod
   def backward(ctx, dsim, _ds, _dp):
     fq, fm, sim, num_valid = ctx.saved_tensors
-    dfq, dfm, dtemp = similarity_bwd(dsim.contiguous().clone(), sim, fq, fm, ctx.scale, ctx.clip,
+    dfq, dfm, dtemp = similarity_bwd(_own(dsim), sim, fq, fm, ctx.scale, ctx.clip,
                                      num_valid)
     return dfq, dfm, (dtemp if ctx.has_t else None), None, None, None
 

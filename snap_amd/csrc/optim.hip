@@ -1,0 +1,58 @@
+// Optimizer step of the training loop as ONE launch over every parameter tensor (the reference:
+// optax.adam inside train_step, snap/trainer.py:236-243; bias-corrected, eps outside the sqrt):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// HBM-bound elementwise work: 4 tensors read, 3 written (28 B per parameter; ~48 M parameters =
+// 1.3 GB per step).  The torch._foreach_* formulation it replaces ran 9 multi-tensor passes
+// (1.55 ms per C3 step); here every element is touched once.  `items` is a DEVICE table sorted
+// by block_begin; a workgroup owns 1024 consecutive elements of one tensor.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const SnapAdamItem* __restrict__ items,
+                                                         int n_items, float b1, float b2,
+                                                         float step_size, float inv_sqrt_c2, float eps) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SnapAdamItem it = items[lo];
+  const int64_t base = ((int64_t)blockIdx.x - it.block_begin) * 1024;
+  float* __restrict__ p = it.p;
+  const float* __restrict__ g = it.g;
+  float* __restrict__ m = it.m;
+  float* __restrict__ v = it.v;
+  const float one_b1 = 1.f - b1, one_b2 = 1.f - b2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = base + threadIdx.x + 256 * k;
+    if (i >= it.n) break;
+    const float gi = g[i];
+    const float mi = m[i] * b1 + gi * one_b1;
+    const float vi = v[i] * b2 + (gi * gi) * one_b2;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_c2 + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t snap_adam_multi_blocks(int64_t n) { return n > 0 ? (n + 1023) / 1024 : 0; }
+
+extern "C" int snap_adam_multi_f32(const SnapAdamItem* items, int32_t n_items, int64_t total_blocks,
+                                   float lr, float b1, float b2, float eps, int32_t step,
+                                   void* stream) {
+  if (!items) return SNAP_ERR_NULL;
+  if (n_items <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL || step <= 0) return SNAP_ERR_BAD_SHAPE;
+  const double c1 = 1.0 - pow((double)b1, (double)step);
+  const double c2 = 1.0 - pow((double)b2, (double)step);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), items, n_items, b1, b2, (float)((double)lr / c1),
+                     (float)(1.0 / sqrt(c2)), eps);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}

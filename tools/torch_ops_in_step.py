@@ -20,26 +20,43 @@ from snap_amd import ops  # noqa: E402
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--workload', default='c2')
+  ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
+  ap.add_argument('--precision', default='bf16')
   args = ap.parse_args()
   dev = torch.device('cuda', 0)
-  loc, cfg, meta, variables, batch = bench.build(args.workload, dev, 0, materialize_volume=False)
-  ops.MATMUL_PRECISION = 'bf16x3'
+  train = args.mode == 'train'
+  loc, cfg, meta, variables, batch = bench.build(args.workload, dev, 0, materialize_volume=train)
+  if train:
+    from snap_amd import models, trainer
+    from snap_amd.configs import train_localization
+    model = models.get_model('bev_localizer')(cfg, meta)
+    state = trainer.TrainState.create(variables['params'], rng=0)
+
+    def step(i):
+      trainer.train_step(state, batch, model=model, lr_fn=lambda s: 1e-4, precision=args.precision)
+  else:
+    ops.MATMUL_PRECISION = 'bf16x3'
+
+    def step(i):
+      loc.apply(variables, batch, train=False, rngs={'sampling': i})
   for i in range(3):
-    loc.apply(variables, batch, train=False, rngs={'sampling': i})
+    step(i)
   torch.cuda.synchronize()
   from torch.profiler import ProfilerActivity, profile
-  with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    loc.apply(variables, batch, train=False, rngs={'sampling': 7})
+  with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    step(7)
     torch.cuda.synchronize()
   agg = collections.defaultdict(lambda: [0, 0.0])
   for ev in prof.events():
     if not ev.name.startswith('aten::') or ev.device_time_total <= 0 or not ev.kernels:
       continue
     where = '?'
-    for fr in ev.stack:
+    for fr in (ev.stack or []):
       if 'snap_amd' in fr and 'site-packages' not in fr:
         where = fr.split('snap_amd/')[-1]
         break
+    if where == '?':           # no Python stack on this build: the input shapes identify the call site
+      where = str([tuple(sh) for sh in (ev.input_shapes or []) if sh])[:90]
     k = (where, ev.name)
     agg[k][0] += 1
     agg[k][1] += sum(kk.duration for kk in ev.kernels)
