@@ -149,6 +149,13 @@ typedef struct SnapConvExtras {
                                  products run on v_mfma_f32_32x32x16_f16 (f32 accumulate): the
                                  reference's dtype=float16 train config (train_localization.py:93,
                                  resnet.py:97), driven by DynamicScale (trainer.py:391-392) */
+  int32_t x_half;             /* with w_split_parts = 0 (training-precision engine), prologue NONE, no row
+                                 lists, Cin_stride % 8 == 0: 1 = `x` is NOT f32 but the tensor already
+                                 rounded to the engine's element type (bf16, or IEEE half with w_half),
+                                 [N, H, W, Cin_stride] -- the half-precision twin a GroupNorm VJP wrote
+                                 next to its f32 gradient (snap_group_norm_bwd_ex_f32).  The
+                                 data-gradient convolution then moves both operands by LDS-DMA: half the
+                                 input bytes, no conversion in the loop; same bits as the f32 input */
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
@@ -707,6 +714,13 @@ int snap_stack_templates_f32(const float* tw, float* tws, int32_t H, int32_t W, 
  * output may then be NULL: the r-fastest HWIO copy is only needed by the unstacked path). */
 int snap_stack_templates_rhwd_f32(const float* templates, float* tws, int32_t H, int32_t W,
                                   int32_t D, int32_t R, int32_t S, void* stream);
+/* ... and written DIRECTLY as the split engine's two-part weight image of that bank (what
+ * snap_conv2d_pack_weights_split_bf16(tws, taps = (H+S-1)(W+S-1), Cin = D, Cout = R S^2, parts = 2)
+ * would produce, bit for bit): the f32 bank is never materialised.  out:
+ * snap_conv2d_packed_weights_split_bytes(taps, D, R S^2, 2) bytes, 16-byte aligned; D % 4 == 0. */
+int snap_pack_stacked_templates_split_bf16(const float* templates, int32_t H, int32_t W, int32_t D,
+                                           int32_t R, int32_t S, void* out, size_t out_bytes,
+                                           void* stream);
 int snap_pad_map_f32(const float* map, const uint8_t* mvalid, int32_t H, int32_t W,
                      int32_t D, float* map_pad, float* mvalid_pad, void* stream);
 
@@ -791,6 +805,16 @@ int snap_adam_multi_f32(const SnapAdamItem* items, int32_t n_items, int64_t tota
  * gradient summed into dx (identity-residual branch).  mode: SNAP_PRO_GN_RELU /
  * SNAP_PRO_RELU_GN.  dgamma/dbeta [C] (+)=. */
 size_t snap_group_norm_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C, int32_t groups);
+/* ... _ex: dx_half (optional, [N, HW, C] 2-byte elements) also receives dx rounded to bf16
+ * (half_kind = 1) or IEEE half (half_kind = 2), RNE -- the operand image the producing layer's
+ * data-gradient convolution (SnapConvExtras.x_half) and kernel-gradient GEMM read instead of the
+ * f32 tensor. */
+int snap_group_norm_bwd_ex_f32(const float* x, const float* dz, const float* add, float* dx,
+                               int32_t N, int32_t HW, int32_t C, int32_t groups,
+                               const float* mu, const float* rstd, const float* gamma,
+                               const float* beta, int32_t mode, float* dgamma, float* dbeta,
+                               int32_t accumulate, void* workspace, size_t workspace_bytes,
+                               void* dx_half, int32_t half_kind, void* stream);
 int snap_group_norm_bwd_f32(const float* x, const float* dz, const float* add, float* dx,
                             int32_t N, int32_t HW, int32_t C, int32_t groups,
                             const float* mu, const float* rstd, const float* gamma,

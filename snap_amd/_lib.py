@@ -39,7 +39,7 @@ class SnapConvExtras(ctypes.Structure):
       ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
       ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
       ('x_presplit', c_int), ('ps_tile', c_int), ('ps_res_init', c_int),
-      ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int), ('w_half', c_int),
+      ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int), ('w_half', c_int), ('x_half', c_int),
   ]
 
 
@@ -95,6 +95,7 @@ SIGNATURES = {
     'snap_semantic_onehot_f32': (c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, c_int, ptr]),
     'snap_stack_templates_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
     'snap_stack_templates_rhwd_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
+    'snap_pack_stacked_templates_split_bf16': (c_int, [ptr, c_int, c_int, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_layer_norm_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_attention_bf16_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_attention_lse_bf16_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
@@ -247,6 +248,11 @@ SIGNATURES = {
         c_int,
         [ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr, ptr, ptr, ptr, c_int, ptr, ptr,
          c_int, ptr, c_size, ptr],
+    ),
+    'snap_group_norm_bwd_ex_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr, ptr, ptr, ptr, c_int, ptr, ptr,
+         c_int, ptr, c_size, ptr, c_int, ptr],
     ),
     'snap_weight_standardize_bwd_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_float, ptr]),
     'snap_max_pool_3x3s2_bwd_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr]),

@@ -60,7 +60,14 @@ def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None):
   pt2, pl2 = KH - 1 - pt, KW - 1 - pl
   pb2 = H - Ho - pt2 + KH - 1
   pr2 = W - Wo - pl2 + KW - 1
-  return ops.conv2d(dy.contiguous(), w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
+  dy = dy.contiguous()
+  if half_math and stride == 1 and Cout % 8 == 0:
+    # the GroupNorm VJP that wrote dy also wrote it in the engine's element type: read that twin
+    # (both operands by LDS-DMA, half the bytes; same bits as rounding the f32 tensor in the loop)
+    twin = ops_bwd.half_twin(dy, half_math)
+    if twin is not None:
+      return ops.conv2d(twin, w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
+  return ops.conv2d(dy, w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
 
 
 def _own(grad):
@@ -167,6 +174,7 @@ class _FusedConv(torch.autograd.Function):
         dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
             x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), prologue,
             add=dalias.contiguous() if fused_add else None,
+            half=ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None,
         )
         if fused_add:
           dalias = None
@@ -221,7 +229,8 @@ class _SharedPrologueConvPair(torch.autograd.Function):
       dz = conv_dgrad(dy1, w1, (N, H, W, C), 1, pad0)
       dz = conv_dgrad(dy2, w2, (N, H, W, C), ctx.stride2, pad0, accumulate=dz)
       dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
-          x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), ops.PRO_GN_RELU)
+          x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), ops.PRO_GN_RELU,
+          half=ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None)
       dgamma = dgamma.reshape(gamma.shape)
       dbeta = dbeta.reshape(beta.shape)
     return dx, dw1, dw2, dgamma, dbeta, None

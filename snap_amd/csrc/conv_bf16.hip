@@ -249,6 +249,168 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
   conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
+// The same GEMM with the A operand ALREADY in the engine's element type in HBM (ConvArgs.x_half:
+// [N, H, W, Cin_stride] bf16 / f16, Cin_stride % 8 == 0, prologue NONE): the data-gradient
+// convolutions of the training step, whose input -- the gradient a GroupNorm VJP just wrote -- has
+// a half-precision twin (snap_group_norm_bwd_ex_f32).  Both operands then travel global -> LDS by
+// LDS-DMA in 16-byte pieces (A: one piece = 8 channels of one tap of one output row, the k-octet
+// swizzle applied on the source side exactly as for B; a tap outside the image or a row beyond M
+// fetches the zero chunk): no staging registers, no conversion, no store phase, half the bytes.
+// Same products, same k order and accumulation as conv_bf16_body on the rounded operand: the
+// results are bit-identical to the f32-input launch of the same tensor (tested).
+template <int BM, int BN, bool F16>
+__device__ __forceinline__ void conv_bf16_xh_body(const ConvArgs& a) {
+  typedef Elem<F16> E;
+  typedef typename E::T ET;
+  typedef typename E::x8 etx8;
+  constexpr int BK = 32;
+  constexpr int TM = BM / 64;
+  constexpr int TN = BN / 64;
+  constexpr int APIECES = (BM * 4) / 256;
+  constexpr int BPIECES = (BN * 4) / 256;
+  constexpr int A_ST = BM * 16;           // floats per A stage (64 B per row)
+  constexpr int B_ST = BN * 16;
+  constexpr int NST = 3;                  // ring depth
+  constexpr int kSlabFloats = NST * (A_ST + B_ST);
+  constexpr int kStageFloats = 64 * BN;
+  constexpr int kSmemFloats = kSlabFloats > kStageFloats ? kSlabFloats : kStageFloats;
+  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
+  char* const Ab = reinterpret_cast<char*>(smem);
+  char* const Bb = reinterpret_cast<char*>(smem + NST * A_ST);
+
+  const SnapConvDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int ncol = a.ncol;
+  const int split = a.ksplit > 1 ? blockIdx.x / a.tiles_per_split : 0;
+  const int bid = a.ksplit > 1 ? blockIdx.x - split * a.tiles_per_split : blockIdx.x;
+  const int xcd = bid & 7;
+  const int seq = bid >> 3;
+  const int col_t = seq % ncol;
+  const int row_t = (seq / ncol) * 8 + xcd;
+  const int Meff = a.M;
+  if (row_t * BM >= Meff) return;
+  const int m0 = row_t * BM;
+  const int n0 = col_t * BN;
+  const int HoWo = d.Ho * d.Wo;
+  const ET* const xh = static_cast<const ET*>(a.x_half);
+
+  // A pieces of this thread: slot = tid + 256 p -> row slot >> 2, physical octet slot & 3
+  int r_hb[APIECES], r_wb[APIECES], r_oct[APIECES];
+  bool r_ok[APIECES];
+  const ET* r_px[APIECES];
+#pragma unroll
+  for (int p = 0; p < APIECES; ++p) {
+    const int slot = tid + 256 * p;
+    const int row = slot >> 2;
+    const int m = m0 + row;
+    r_ok[p] = m < Meff;
+    const int mm = r_ok[p] ? m : 0;
+    const int n = mm / HoWo;
+    const int r = mm - n * HoWo;
+    const int ho = r / d.Wo;
+    const int wo = r - ho * d.Wo;
+    r_hb[p] = ho * d.stride - d.pad_t;
+    r_wb[p] = wo * d.stride - d.pad_l;
+    r_oct[p] = (slot & 3) ^ ((row >> 2) & 3);     // logical k-octet this LDS slot holds
+    r_px[p] = xh + (((int64_t)n * d.H + r_hb[p]) * d.W + r_wb[p]) * d.Cin_stride + 8 * r_oct[p];
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int taps = d.KH * d.KW;
+  const int kt_begin = a.ksplit > 1 ? split * a.slabs_per_split : 0;
+  const int kt_end = a.ksplit > 1 ? min(a.nk, kt_begin + a.slabs_per_split) : a.nk;
+  int kpos = 0, ct = 0, kh = 0, kw = 0;
+  if (kt_begin > 0) {
+    kpos = kt_begin / a.ctiles;
+    ct = kt_begin - kpos * a.ctiles;
+    kh = kpos / d.KW;
+    kw = kpos - kh * d.KW;
+  }
+  const ET* const wt = static_cast<const ET*>(a.w_bf16);
+  auto issue = [&](int buf) {
+    const int64_t delta = ((int64_t)kh * d.W + kw) * d.Cin_stride + ct * BK;
+#pragma unroll
+    for (int p = 0; p < APIECES; ++p) {
+      const int slot = tid + 256 * p;
+      const int hi = r_hb[p] + kh, wi = r_wb[p] + kw;
+      const bool ok = r_ok[p] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W &&
+                      (ct * BK + 8 * r_oct[p]) < d.Cin;          // (Cin % 8 == 0: whole octets)
+      const void* src = ok ? static_cast<const void*>(r_px[p] + delta) : static_cast<const void*>(kZeroChunk);
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                       (lds_void_t*)(Ab + buf * (A_ST * 4) + 16 * slot), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BPIECES; ++p) {
+      const int slot = tid + 256 * p;
+      const int col = slot >> 2;
+      const int oct = (slot & 3) ^ ((col >> 2) & 3);
+      const int kc = ct * BK + 8 * oct;
+      const bool ok = kc < a.cin8 && (n0 + col) < d.Cout;
+      const void* src = ok ? static_cast<const void*>(wt + ((int64_t)(n0 + col) * taps + kpos) * a.cin8 + kc)
+                           : static_cast<const void*>(kZeroChunk);
+      __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                       (lds_void_t*)(Bb + buf * (B_ST * 4) + 16 * slot), 16, 0, 0);
+    }
+    if (++ct == a.ctiles) {
+      ct = 0;
+      ++kpos;
+      if (++kw == d.KW) { kw = 0; ++kh; }
+    }
+  };
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int nslab = kt_end - kt_begin;
+  // three-stage ring: slabs i + 1 and i + 2 are in flight while slab i is multiplied; every thread
+  // issues the same APIECES + BPIECES loads per slab, so the waits are compile-time counts
+  if (nslab > 0) issue(0);
+  if (nslab > 1) issue(1);
+  for (int i = 0; i < nslab; ++i) {
+    const int cur = i % NST;
+    if (i + 1 < nslab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APIECES + BPIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // slab i landed everywhere; stage (i + 2) % 3 was consumed in iteration i - 1
+    if (i + 2 < nslab) issue((i + 2) % NST);
+    const char* as = Ab + cur * (A_ST * 4);
+    const char* bs = Bb + cur * (B_ST * 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      etx8 av[TM], bv[TN];
+#pragma unroll
+      for (int ii = 0; ii < TM; ++ii) {
+        const int R = wr * (BM / 2) + ii * 32 + l31;
+        av[ii] = *reinterpret_cast<const etx8*>(as + R * 64 + (((2 * s + lhi) ^ ((R >> 2) & 3)) * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int C = wc * (BN / 2) + j * 32 + l31;
+        bv[j] = *reinterpret_cast<const etx8*>(bs + C * 64 + (((2 * s + lhi) ^ ((C >> 2) & 3)) * 16));
+      }
+#pragma unroll
+      for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[ii][j] = E::mfma(av[ii], bv[j], acc[ii][j]);
+    }
+  }
+  __syncthreads();                        // the ring is drained: the epilogue reuses it as its staging tile
+  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
+}
+
+template <int BM, int BN, bool F16>
+__global__ __launch_bounds__(256) void conv_bf16_xh_kernel(const ConvArgs a) {
+  conv_bf16_xh_body<BM, BN, F16>(a);
+}
+
 template <int BM, int BN, int PRO, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs a) {
   conv_bf16_body<BM, BN, PRO, F16>(a);
@@ -282,7 +444,16 @@ int launch(ConvArgs a, hipStream_t s) {
       nblocks *= a.ksplit;
     }
   }
-  if (a.half)
+  if (a.x_half) {
+    if constexpr (PRO == SNAP_PRO_NONE) {
+      if (a.half)
+        hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+    } else {
+      return SNAP_ERR_UNSUPPORTED;
+    }
+  } else if (a.half)
     hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);

@@ -50,6 +50,8 @@ struct ConvArgs {
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])
   int cin8;            // ... channel count rounded up to 8
   int half;            // ... 1: the image and the A operand are IEEE half (SnapConvExtras.w_half)
+  const void* x_half;  // ... non-NULL: the input ALREADY in the engine's element type, [N,H,W,Cin_stride]
+                       //     (SnapConvExtras.x_half; prologue NONE): both operands by LDS-DMA
   const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
   int ps_tile;         // ... 0 = automatic tile, 1 = 128 rows, 2 = 256 rows
   int ps_res_init;     // ... 1 = the residual is loaded into the accumulators before the K loop

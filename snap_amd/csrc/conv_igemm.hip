@@ -740,10 +740,21 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.w_bf16 = ex ? ex->w_bf16 : nullptr;
   a.half = (ex && ex->w_half) ? 1 : 0;
   if (a.half && (ex->w_split_parts != 0 || presplit || ex->w_split_root)) return SNAP_ERR_UNSUPPORTED;
+  a.x_half = nullptr;
   a.cin8 = (d.Cin + 7) / 8 * 8;
   a.x_ps = nullptr;
   a.ps_tile = 0;
   a.ps_res_init = 0;
+  if (ex && ex->x_half) {     // the input is already bf16 / f16: training-precision engine, both operands by DMA
+    if (!a.w_bf16 || ex->w_split_parts != 0 || presplit || ex->w_split_root || d.prologue != SNAP_PRO_NONE ||
+        rows_in || rows_out || row_count || d.Cin_stride % 8 != 0 || d.Cin % 8 != 0)
+      return SNAP_ERR_UNSUPPORTED;
+    if (ex->w_bf16_bytes < snap_conv2d_packed_weights_bytes(d.KH * d.KW, d.Cin, d.Cout)) return SNAP_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(a.w_bf16) | reinterpret_cast<uintptr_t>(x)) & 15) return SNAP_ERR_BAD_SHAPE;
+    a.x_half = x;
+    a.x = nullptr;
+    return snapconv::launch_bf16(a, s);
+  }
   if (presplit) {                            // both operands pre-split: conv_ps.hip
     if (!a.w_bf16 || ex->w_split_parts != 2 || ex->w_split_root) return SNAP_ERR_UNSUPPORTED;
     const size_t need = snap_conv2d_packed_weights_split_bytes(d.KH * d.KW, d.Cin, d.Cout, 2);

@@ -121,13 +121,15 @@ __global__ void gn_bwd_group_kernel(const float* __restrict__ ab, const float* _
   }
 }
 
-template <int MODE>
+// HALF: 0 = f32 output only; 1 / 2 = also the same values rounded (RNE) to bf16 / IEEE half into
+// dx_half -- the operand image of the producing layer's backward GEMMs
+template <int MODE, int HALF = 0>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                     const float* __restrict__ add, float* __restrict__ dx,
                                     int64_t total4, int HW, int C, int groups,
                                     const float* __restrict__ mu, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ s12) {
+                                    const float* __restrict__ s12, void* __restrict__ dx_half = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int C4 = C >> 2;
@@ -165,6 +167,13 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     for (int e = 0; e < 4; ++e) o[e] += av[e];
   }
   reinterpret_cast<f32x4*>(dx)[i] = o;
+  if constexpr (HALF == 1) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<bf16x4*>(dx_half)[i] = __builtin_convertvector(o, bf16x4);
+  } else if constexpr (HALF == 2) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<f16x4*>(dx_half)[i] = __builtin_convertvector(o, f16x4);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -484,6 +493,19 @@ extern "C" int snap_group_norm_bwd_f32(const float* x, const float* dz, const fl
                                        const float* beta, int32_t mode, float* dgamma,
                                        float* dbeta, int32_t accumulate, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+  return snap_group_norm_bwd_ex_f32(x, dz, add, dx, N, HW, C, groups, mu, rstd, gamma, beta, mode, dgamma,
+                                    dbeta, accumulate, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int snap_group_norm_bwd_ex_f32(const float* x, const float* dz, const float* add,
+                                          float* dx, int32_t N, int32_t HW, int32_t C, int32_t groups,
+                                          const float* mu, const float* rstd, const float* gamma,
+                                          const float* beta, int32_t mode, float* dgamma,
+                                          float* dbeta, int32_t accumulate, void* workspace,
+                                          size_t workspace_bytes, void* dx_half, int32_t half_kind,
+                                          void* stream) {
+  if (half_kind < 0 || half_kind > 2 || (half_kind != 0) != (dx_half != nullptr)) return SNAP_ERR_BAD_SHAPE;
+  if (dx_half && (reinterpret_cast<uintptr_t>(dx_half) & 7)) return SNAP_ERR_BAD_SHAPE;
   if (!x || !dz || !dx || !mu || !rstd || !gamma || !beta || !dgamma || !dbeta || !workspace)
     return SNAP_ERR_NULL;
   if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || C % 4 != 0)
@@ -516,14 +538,20 @@ extern "C" int snap_group_norm_bwd_f32(const float* x, const float* dz, const fl
                      (const float*)ab, gamma, N, C, groups, s12, dgamma, dbeta, accumulate);
   SNAP_CHECK_LAUNCH();
   const int64_t total4 = (int64_t)N * HW * (C / 4);
-  if (mode == SNAP_PRO_GN_RELU)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<SNAP_PRO_GN_RELU>, dim3((unsigned)snap_cdiv(total4, 256)),
-                       dim3(256), 0, s, x, dz, add, dx, total4, HW, C, groups, mu, rstd, gamma, beta,
-                       (const float*)s12);
-  else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<SNAP_PRO_RELU_GN>, dim3((unsigned)snap_cdiv(total4, 256)),
-                       dim3(256), 0, s, x, dz, add, dx, total4, HW, C, groups, mu, rstd, gamma, beta,
-                       (const float*)s12);
+#define SNAP_GN_APPLY(MODE_, HALF_)                                                                   \
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<MODE_, HALF_>), dim3((unsigned)snap_cdiv(total4, 256)),       \
+                     dim3(256), 0, s, x, dz, add, dx, total4, HW, C, groups, mu, rstd, gamma, beta,     \
+                     (const float*)s12, dx_half)
+  if (mode == SNAP_PRO_GN_RELU) {
+    if (half_kind == 1) SNAP_GN_APPLY(SNAP_PRO_GN_RELU, 1);
+    else if (half_kind == 2) SNAP_GN_APPLY(SNAP_PRO_GN_RELU, 2);
+    else SNAP_GN_APPLY(SNAP_PRO_GN_RELU, 0);
+  } else {
+    if (half_kind == 1) SNAP_GN_APPLY(SNAP_PRO_RELU_GN, 1);
+    else if (half_kind == 2) SNAP_GN_APPLY(SNAP_PRO_RELU_GN, 2);
+    else SNAP_GN_APPLY(SNAP_PRO_RELU_GN, 0);
+  }
+#undef SNAP_GN_APPLY
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

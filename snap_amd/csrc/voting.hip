@@ -205,6 +205,82 @@ extern "C" int snap_stack_templates_rhwd_f32(const float* templates, float* tws,
   return SNAP_OK;
 }
 
+// The shift-stacked bank written DIRECTLY as the split engine's two-part weight image
+//   out[column tile of 128][tap (i', j')][channel tile of 16][part][column 0..127][16 k] bf16
+// (conv_split.hip's layout, octet swizzle applied at rest, columns >= R S^2 zero): the f32 bank
+// [H+S-1, W+S-1, D, R S^2] (4.9 GB at C4) is never materialised and the separate pack pass (read
+// 4.9 GB, write 4.9 GB) disappears -- one pass that reads the 0.3 GB of templates and writes the
+// image.  A thread = one 8-channel octet of one (tap, column): 32 B in, 2 x 16 B out.
+__global__ __launch_bounds__(256) void pack_stacked_templates_split_kernel(
+    const float* __restrict__ templates, __bf16* __restrict__ out, int H, int W, int D, int R, int S,
+    int ctiles, int ncolpad, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int op = (int)(i & 1);                       // physical octet within the column's 16 k
+  int64_t t = i >> 1;
+  const int n = (int)(t % ncolpad); t /= ncolpad;    // output column (filter) incl. padding
+  const int ct = (int)(t % ctiles);
+  const int64_t tap = t / ctiles;                    // i' * (W + S - 1) + j'
+  const int KW = W + S - 1;
+  const int ip = (int)(tap / KW), jp = (int)(tap - (int64_t)ip * KW);
+  const int col = n & 127;
+  const int oct = op ^ ((col >> 3) & 1);             // logical octet stored in this slot
+  const int d0 = 16 * ct + 8 * oct;
+  const int RS = R * S * S;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (n < RS) {
+    const int sb = n % S, sa = (n / S) % S, r = n / (S * S);
+    const int ii = ip - sa, jj = jp - sb;
+    if (ii >= 0 && ii < H && jj >= 0 && jj < W) {
+      const float* src = templates + (((int64_t)r * H + ii) * W + jj) * D + d0;
+      if (d0 + 8 <= D) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = d0 + e < D ? src[e] : 0.f;
+      }
+    }
+  }
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+  const int64_t blk = (((int64_t)(n >> 7) * ((int64_t)(H + S - 1) * KW) + tap) * ctiles + ct);
+  __bf16* o = out + blk * (2 * 2048) + col * 16 + op * 8;
+  *reinterpret_cast<bf16x8*>(o) = hi;
+  *reinterpret_cast<bf16x8*>(o + 2048) = lo;
+}
+
+extern "C" int snap_pack_stacked_templates_split_bf16(const float* templates, int32_t H, int32_t W,
+                                                      int32_t D, int32_t R, int32_t S, void* out,
+                                                      size_t out_bytes, void* stream) {
+  if (!templates || !out) return SNAP_ERR_NULL;
+  if (H <= 0 || W <= 0 || D <= 0 || R <= 0 || S < 1 || S > 8 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int64_t taps = (int64_t)(H + S - 1) * (W + S - 1);
+  const int RS = R * S * S;
+  if (taps > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  const size_t need = snap_conv2d_packed_weights_split_bytes((int32_t)taps, D, RS, 2);
+  if (need == 0) return SNAP_ERR_UNSUPPORTED;
+  if (out_bytes < need) return SNAP_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(templates)) & 15) return SNAP_ERR_BAD_SHAPE;
+  const int ctiles = (D + 15) / 16;
+  const int ncolpad = (RS + 127) / 128 * 128;
+  const int64_t total = taps * ctiles * ncolpad * 2;
+  if (snap_cdiv(total, 256) > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(pack_stacked_templates_split_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), templates, static_cast<__bf16*>(out), H, W, D, R, S,
+                     ctiles, ncolpad, total);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
 extern "C" int snap_stack_templates_f32(const float* tw, float* tws, int32_t H, int32_t W,
                                         int32_t D, int32_t R, int32_t S, void* stream) {
   if (!tw || !tws) return SNAP_ERR_NULL;

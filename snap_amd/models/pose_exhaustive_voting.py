@@ -75,13 +75,20 @@ def _correlate(mp, tw, R, q_hw, templates=None):
     if tw is None:
       tw = templates.permute(1, 2, 3, 0).contiguous()
     return ops.conv2d(mp[None], tw)[0]                  # [Ho, Wo, R]
-  tws = ops.stack_templates(templates, S, 'rhwd') if templates is not None else ops.stack_templates(tw, S)
   A4, B4 = -(-Ho // S), -(-Wo // S)
   pb = max(0, S * (A4 - 1) + (H + S - 1) - mp.shape[0])  # zero rows only cropped outputs can see
   pr = max(0, S * (B4 - 1) + (W + S - 1) - mp.shape[1])
-  if (ops.MATMUL_PRECISION == 'bf16x3' and ops.USE_PRESPLIT_VOTING and mp.shape[-1] % 16 == 0
-      and (R * S * S) % 192 == 0
-      and ops.conv2d_presplit_supported((1,) + tuple(mp.shape), tuple(tws.shape), S, ((0, pb), (0, pr)))):
+  tws_shape = (H + S - 1, W + S - 1, mp.shape[-1], R * S * S)
+  presplit = (ops.MATMUL_PRECISION == 'bf16x3' and ops.USE_PRESPLIT_VOTING and mp.shape[-1] % 16 == 0
+              and (R * S * S) % 192 == 0
+              and ops.conv2d_presplit_supported((1,) + tuple(mp.shape), tws_shape, S, ((0, pb), (0, pr))))
+  tws = None
+  if presplit and templates is not None and ops.FUSED_TEMPLATE_PACK:
+    # the bank goes straight into the engine's weight image (no f32 bank, no pack pass)
+    tws = ops.pack_stacked_templates_split(templates, S)
+  if tws is None:
+    tws = ops.stack_templates(templates, S, 'rhwd') if templates is not None else ops.stack_templates(tw, S)
+  if presplit:
     # the correlation as ONE large GEMM on the pre-split engine: the map is split into its two
     # bf16 parts once (instead of once per tap and column tile inside the K loop), both operands
     # travel by LDS-DMA, 256 x 192 tiles (R S^2 = 576 = three column tiles); same products, same

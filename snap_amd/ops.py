@@ -259,6 +259,37 @@ def _stationary_mode():
   return 3 if CONV_NO_WS else 0
 
 
+class PackedWeights:
+  """A conv kernel that exists ONLY as the split engine's two-part weight image (``data``: bf16,
+  the layout of snap_conv2d_pack_weights_split_bf16 for ``shape`` = (KH, KW, Cin, Cout)) -- e.g. the
+  shift-stacked template bank of the exhaustive voting, written directly in that form by
+  ``pack_stacked_templates_split``.  ``conv2d`` takes it with a ``PreSplit`` input."""
+
+  def __init__(self, data, shape):
+    self.data = data
+    self.shape = tuple(int(v) for v in shape)
+
+  def numel(self):
+    return int(np.prod(self.shape))
+
+
+def pack_stacked_templates_split(templates, S):
+  """templates [R, H, W, D] -> ``PackedWeights`` of the shift-stacked bank [H+S-1, W+S-1, D, R S^2]
+  (``stack_templates`` + ``pack_weights_split_bf16(., 2)`` in one pass; the f32 bank is never built)."""
+  lib = _lib.load()
+  _f32(templates, 'templates')
+  R, H, W, D = templates.shape
+  KH, KW, RS = H + S - 1, W + S - 1, R * S * S
+  nbytes = lib.snap_conv2d_packed_weights_split_bytes(KH * KW, D, RS, 2)
+  if nbytes == 0:
+    return None
+  out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=templates.device)
+  with _region('pack_stacked_templates', 0.0, 4.0 * templates.numel() + float(nbytes)):
+    st = lib.snap_pack_stacked_templates_split_bf16(_p(templates), H, W, D, R, S, _p(out), nbytes, _stream())
+  _lib.check(st, 'snap_pack_stacked_templates_split_bf16')
+  return PackedWeights(out, (KH, KW, D, RS))
+
+
 def conv2d_presplit_supported(x_shape, w_shape, stride=1, padding=((0, 0), (0, 0))):
   """True when ``conv2d(presplit(x), w, ...)`` has an engine for the shape: the pre-split engine's
   own limits (``snap_conv2d_presplit_supported``) and a two-part weight image within the split
@@ -309,6 +340,18 @@ def conv2d(
   """
   lib = _lib.load()
   ps = isinstance(x, PreSplit)
+  xh = (not ps) and x.dtype in (torch.bfloat16, torch.float16)
+  if xh:
+    # the input already in the training-precision engine's element type (the half twin a GroupNorm
+    # VJP wrote next to its f32 gradient): both operands by LDS-DMA (conv_bf16.hip)
+    want = 'fp16' if x.dtype == torch.float16 else 'bf16'
+    math = want if math is None else math
+    if (math != want or prologue != PRO_NONE or rows_in is not None or rows_out is not None
+        or row_count is not None or x.shape[-1] % 8 or w.shape[2] % 8 or emit_gn_stats is not None):
+      raise ValueError('conv2d: a half-precision input takes the matching engine, prologue NONE, whole '
+                       'channel octets, no row lists / statistics')
+    _chk(x, x.dtype, 'x')
+    N, H, W, Cs = x.shape
   if ps:
     if (prologue != PRO_NONE or rows_in is not None or rows_out is not None or row_count is not None
         or math not in (None, 'bf16x3')):
@@ -317,11 +360,18 @@ def conv2d(
     xs, x = x, x.data
     _chk(x, torch.bfloat16, 'x')
     N, H, W, Cs = xs.shape
-  else:
+  elif not xh:
     _f32(x, 'x')
     N, H, W, Cs = x.shape
-  _f32(w, 'w')
-  KH, KW, Cin, Cout = w.shape
+  pw = isinstance(w, PackedWeights)
+  if pw:
+    if not ps:
+      raise ValueError('conv2d: PackedWeights (a two-part split image) go with a PreSplit input')
+    w_img, w = w, w.data          # (the engine reads only the image; `w` passes a non-NULL pointer)
+    KH, KW, Cin, Cout = w_img.shape
+  else:
+    _f32(w, 'w')
+    KH, KW, Cin, Cout = w.shape
   if cin is None:
     cin = Cs
   if cin != Cin:
@@ -441,13 +491,14 @@ def conv2d(
     ex.w_split_root = 1
     family = f'conv_split_{math}'
   elif math != 'f32' and Cs % 4 == 0 and Cin >= 4:
-    wpk = _packed_weights(w, math, parts)
+    wpk = w_img.data if pw else _packed_weights(w, math, parts)
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.w_bf16 = wpk.data_ptr()
     ex.w_bf16_bytes = wpk.numel() * 2
     ex.w_split_parts = parts
     ex.w_half = int(math == 'fp16')
+    ex.x_half = int(xh)
     family = f'conv_split_{math}' if parts else ('conv_fp16' if math == 'fp16' else 'conv_bf16')
     if ps:
       ex.x_presplit = 1
@@ -462,7 +513,7 @@ def conv2d(
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
-    nbytes = 4.0 * ((xs.numel() if ps else x.numel()) + w.numel() + y.numel()
+    nbytes = 4.0 * ((xs.numel() if ps else x.numel() * (0.5 if xh else 1.0)) + (w_img.numel() if pw else w.numel()) + y.numel()
                     + (residual.numel() if residual is not None else 0))
   else:  # resolved after the sync: only the listed rows are multiplied / moved
     flops = lambda: kflops * int(row_count.item())
@@ -1234,6 +1285,7 @@ def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None,
 # ----------------------------------------------------------------------------
 # pose
 # ----------------------------------------------------------------------------
+FUSED_TEMPLATE_PACK = True    # exhaustive voting: templates -> split weight image in one pass
 SIM_GENERAL_KERNEL = False   # tests: pin the general split kernel (the full-chunk kernel is bit-identical)
 
 

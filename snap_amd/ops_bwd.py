@@ -3,6 +3,7 @@
 Same conventions as :mod:`snap_amd.ops`: GPU tensors only, no fallback.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -73,8 +74,31 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   return dw
 
 
-def group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, *, groups=32, add=None):
-  """VJP of the fused GroupNorm(+ReLU) prologue.  Returns dx, dgamma, dbeta."""
+# f32 gradient tensor -> its half-precision twin (bf16 / f16, same shape), written by the kernel
+# that produced the gradient (``group_norm_bwd(half=...)``): the producing layer's data-gradient
+# convolution reads the twin instead (both operands by LDS-DMA, half the bytes).  Keyed by data_ptr,
+# checked against a weak reference, one entry per live gradient.
+_HALF_TWINS = {}
+HALF_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+USE_HALF_TWINS = True
+
+
+def half_twin(t, math):
+  """The twin of gradient tensor ``t`` in the element type of ``math`` ('bf16' | 'fp16'), or None."""
+  hit = _HALF_TWINS.get(t.data_ptr())
+  if hit is None:
+    return None
+  ref, twin, ver = hit
+  owner = ref()
+  if (owner is None or owner.data_ptr() != t.data_ptr() or owner.shape != t.shape or owner._version != ver
+      or twin.dtype != HALF_DTYPE.get(math) or not t.is_contiguous()):
+    return None
+  return twin
+
+
+def group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, *, groups=32, add=None, half=None):
+  """VJP of the fused GroupNorm(+ReLU) prologue.  Returns dx, dgamma, dbeta.  half ('bf16' | 'fp16'):
+  dx is also written rounded to that type (``half_twin(dx, half)`` finds it)."""
   lib = _lib.load()
   _f32(x, 'x'); _f32(dz, 'dz'); _f32(mu, 'mu'); _f32(rstd, 'rstd')
   N, H, W, C = x.shape
@@ -83,12 +107,21 @@ def group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, *, groups=32, add=None):
   dx = torch.empty_like(x)
   dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
   dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-  with _region('group_norm_bwd', 0.0, 16.0 * x.numel()):
-    st = lib.snap_group_norm_bwd_f32(
+  twin = None
+  if half in HALF_DTYPE and USE_HALF_TWINS and C % 8 == 0:
+    twin = torch.empty(x.shape, dtype=HALF_DTYPE[half], device=x.device)
+  with _region('group_norm_bwd', 0.0, 16.0 * x.numel() + (2.0 * x.numel() if twin is not None else 0.0)):
+    st = lib.snap_group_norm_bwd_ex_f32(
         _p(x), _p(dz), _p(add), _p(dx), N, H * W, C, groups, _p(mu), _p(rstd), _p(gamma),
-        _p(beta), mode, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel() * 4, _stream(),
+        _p(beta), mode, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel() * 4,
+        _p(twin), 0 if twin is None else (2 if half == 'fp16' else 1), _stream(),
     )
-  _lib.check(st, 'snap_group_norm_bwd_f32')
+  _lib.check(st, 'snap_group_norm_bwd_ex_f32')
+  if twin is not None:
+    if len(_HALF_TWINS) > 256:
+      for k in [k for k, v in _HALF_TWINS.items() if v[0]() is None]:
+        del _HALF_TWINS[k]
+    _HALF_TWINS[dx.data_ptr()] = (weakref.ref(dx), twin, dx._version)
   return dx, dgamma, dbeta
 
 

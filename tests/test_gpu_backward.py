@@ -209,6 +209,42 @@ def test_conv_wgrad_and_dgrad_random_shapes_fuzz(math_):
     helpers.report('dgrad ' + tag, dz[..., :Cin], wantz, atol=3e-5 * float(wantz.abs().max()) + 1e-6)
 
 
+@pytest.mark.parametrize('math_', ['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,C,Cout_prev,k', [(3, 9, 7, 64, 256, 1), (2, 13, 11, 128, 128, 3), (2, 5, 6, 256, 1024, 1),
+                                                (1, 34, 34, 64, 64, 3), (2, 4, 3, 512, 2048, 1)])
+def test_dgrad_reads_the_half_twin_of_the_groupnorm_vjp(N, H, W, C, Cout_prev, k, math_):
+  """``group_norm_bwd(half=...)`` writes its f32 gradient AND the same values rounded to the training
+  engine's element type; the producing layer's data-gradient convolution reads that twin with both
+  operands by LDS-DMA (``conv_bf16_xh_kernel``).  The twin equals the rounded f32 tensor, and the
+  convolution's result is BIT-IDENTICAL to the launch that rounds the f32 tensor in its loop --
+  1 x 1 and 3 x 3, split-K shapes (deep K, few rows), channel counts up to 2048."""
+  from snap_amd import autograd as ag
+  x = rnd((N, H, W, C), 410) * 1.5 + 0.4
+  gamma, beta = rnd((C,), 411) * 0.3 + 1, rnd((C,), 412) * 0.2
+  dz = rnd((N, H, W, C), 413)
+  add = rnd((N, H, W, C), 414)
+  mu, sc, rstd = ops.group_norm_stats(G(x), G(gamma), want_rstd=True)
+  plain = ops_bwd.group_norm_bwd(G(x), G(dz), mu, rstd, G(gamma), G(beta), ops.PRO_GN_RELU, add=G(add))
+  dx, dgamma, dbeta = ops_bwd.group_norm_bwd(G(x), G(dz), mu, rstd, G(gamma), G(beta), ops.PRO_GN_RELU,
+                                             add=G(add), half=math_)
+  assert torch.equal(dx, plain[0]) and torch.equal(dgamma, plain[1]) and torch.equal(dbeta, plain[2])
+  twin = ops_bwd.half_twin(dx, math_)
+  assert twin is not None and ops_bwd.half_twin(dx, 'fp16' if math_ == 'bf16' else 'bf16') is None
+  assert torch.equal(twin, dx.to(twin.dtype))                     # RNE, as the engine's in-loop rounding
+  # dx is the gradient w.r.t. the output of the PREVIOUS conv (Cprev -> C channels, k x k)
+  w = G(rnd((k, k, Cout_prev, C), 415, 1 / math.sqrt(k * k * Cout_prev)))
+  pad = (k - 1) // 2
+  ops.MATMUL_PRECISION = math_
+  try:
+    via_twin = ag.conv_dgrad(dx, w, (N, H, W, Cout_prev), 1, ((pad, pad), (pad, pad)))
+    ops_bwd._HALF_TWINS.clear()
+    via_f32 = ag.conv_dgrad(dx, w, (N, H, W, Cout_prev), 1, ((pad, pad), (pad, pad)))
+  finally:
+    ops.MATMUL_PRECISION = 'f32'
+  assert torch.equal(via_twin, via_f32), float((via_twin - via_f32).abs().max())
+  assert float(via_twin.abs().max()) > 0
+
+
 @pytest.mark.parametrize('k,stride,pad', [(1, 1, 0), (3, 1, 1), (3, 2, 1), (1, 2, 0)])
 def test_conv_dgrad_via_engine(k, stride, pad):
   from snap_amd import autograd as ag

@@ -1302,6 +1302,40 @@ def test_template_matching_shift_stacked(H, R, D, S, monkeypatch):
   helpers.report(f'stacked S={S} vs plain', stacked, plain, atol=2e-5, rtol=1e-6)
 
 
+@pytest.mark.parametrize('H,W,R,D,S', [(24, 24, 36, 32, 4), (10, 13, 12, 16, 3), (9, 9, 8, 20, 2), (17, 16, 36, 64, 4)])
+def test_fused_template_pack_equals_stack_then_pack(H, W, R, D, S):
+  """``snap_pack_stacked_templates_split_bf16``: templates [R, H, W, D] -> the split engine's two-part
+  weight image of the shift-stacked bank, BIT FOR BIT what ``stack_templates`` followed by
+  ``pack_weights_split_bf16(., 2)`` writes (D not a multiple of 16, column padding, every shift)."""
+  t = rnd((R, H, W, D), 160 + S).to(DEV)
+  bank = ops.stack_templates(t, S, 'rhwd')
+  want = ops.pack_weights_split_bf16(bank, 2)
+  got = ops.pack_stacked_templates_split(t, S)
+  assert got.shape == tuple(bank.shape)
+  assert got.data.numel() == want.numel()
+  assert torch.equal(got.data.view(torch.int16), want.view(torch.int16))
+
+
+def test_voting_with_the_fused_template_pack_keeps_its_bits(monkeypatch):
+  from snap_amd.models import pose_exhaustive_voting as pev
+  H, R, D = 24, 36, 32
+  rng = np.random.default_rng(171)
+  t = rng.standard_normal((R, H, H, D)).astype(np.float32)
+  tv = rng.random((R, H, H)) > 0.2
+  t = t * tv[..., None]
+  fm = rng.standard_normal((H, H, D)).astype(np.float32)
+  vm = rng.random((H, H)) > 0.1
+  args = [torch.tensor(a).to(DEV) for a in (t, tv, fm, vm)]
+  monkeypatch.setattr(pev, 'STACK_MIN_CELLS', 0)
+  monkeypatch.setattr(ops, 'MATMUL_PRECISION', 'bf16x3')
+  monkeypatch.setattr(ops, 'FUSED_TEMPLATE_PACK', True)
+  fused = pev.template_matching(*args)
+  monkeypatch.setattr(ops, 'FUSED_TEMPLATE_PACK', False)
+  plain = pev.template_matching(*args)
+  assert torch.equal(fused, plain)
+  assert bool(torch.isfinite(fused).any())
+
+
 def test_overlap_count_on_the_bf16_engine_is_exact(monkeypatch):
   """The 0/1 overlap-count correlation folded onto the bf16 engine (W % 32 == 0 maps) returns the
   same integers as the f32 scalar path -- bit for bit."""

@@ -276,7 +276,7 @@ def test_fused_adam_matches_optax_formula_and_the_foreach_path():
   for p, pf, p64, m, m64, v, v64 in zip(P, Pf, P64, M, M64, V, V64):
     assert float((p.double() - p64).abs().max()) <= 2e-6 * (1 + float(p64.abs().max()))
     assert float((p - pf).abs().max()) <= 2e-6 * (1 + float(pf.abs().max()))
-    assert torch.allclose(m.double(), m64, rtol=1e-5, atol=1e-12) and torch.allclose(v.double(), v64, rtol=1e-5, atol=1e-20)
+    assert torch.allclose(m.double(), m64, rtol=1e-4, atol=1e-12) and torch.allclose(v.double(), v64, rtol=1e-4, atol=1e-20)
 
 
 def test_fp16_training_precision_with_dynamic_scale():
