@@ -123,6 +123,61 @@ __global__ void gn_bwd_group_kernel(const float* __restrict__ ab, const float* _
 
 // HALF: 0 = f32 output only; 1 / 2 = also the same values rounded (RNE) to bf16 / IEEE half into
 // dx_half -- the operand image of the producing layer's backward GEMMs
+// gn_bwd_reduce_kernel + gn_bwd_group_kernel in ONE launch (two dependent ~8 us launches per
+// GroupNorm layer, ~100 layers per training step): a workgroup owns CB channels (whole groups) of
+// every image -- slab totals of (n, c) into LDS in the reduce kernel's order (slabs ascending), then
+// the group sums (channels ascending) and the parameter gradients (images ascending) from LDS.
+// Same sums, same orders, same bits as the two kernels.
+template <int CB>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_group_kernel(
+    const float* __restrict__ partial, int S, int N, int C, int groups, const float* __restrict__ gamma,
+    float* __restrict__ s12, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  extern __shared__ float ab[];                       // [N][CB][2]
+  const int c0 = blockIdx.x * CB;
+  const int cpg = C / groups;
+  for (int i = threadIdx.x; i < N * CB; i += 256) {
+    const int n = i / CB, cl = i - n * CB;
+    const int c = c0 + cl;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+#pragma unroll 8
+      for (int sl = 0; sl < S; ++sl) {
+        const float2 p = *reinterpret_cast<const float2*>(partial + (((int64_t)n * S + sl) * C + c) * 2);
+        a1 += p.x;
+        a2 += p.y;
+      }
+    }
+    ab[i * 2 + 0] = a1;
+    ab[i * 2 + 1] = a2;
+  }
+  __syncthreads();
+  const int gpb = CB / cpg;                           // groups per block (CB % cpg == 0)
+  for (int i = threadIdx.x; i < N * gpb; i += 256) {
+    const int n = i / gpb, gl = i - n * gpb;
+    const int g = c0 / cpg + gl;
+    if (g >= groups) continue;
+    float t1 = 0.f, t2 = 0.f;
+    for (int cl = gl * cpg; cl < (gl + 1) * cpg; ++cl) {
+      const float gm = gamma[c0 + cl];
+      t1 += gm * ab[(n * CB + cl) * 2 + 0];
+      t2 += gm * ab[(n * CB + cl) * 2 + 1];
+    }
+    s12[((int64_t)n * groups + g) * 2 + 0] = t1;
+    s12[((int64_t)n * groups + g) * 2 + 1] = t2;
+  }
+  for (int cl = threadIdx.x; cl < CB; cl += 256) {
+    const int c = c0 + cl;
+    if (c >= C) continue;
+    float da = 0.f, db = 0.f;
+    for (int n = 0; n < N; ++n) {
+      da += ab[(n * CB + cl) * 2 + 1];
+      db += ab[(n * CB + cl) * 2 + 0];
+    }
+    dgamma[c] = accumulate ? dgamma[c] + da : da;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+  }
+}
+
 template <int MODE, int HALF = 0>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                     const float* __restrict__ add, float* __restrict__ dx,
@@ -530,12 +585,23 @@ extern "C" int snap_group_norm_bwd_ex_f32(const float* x, const float* dz, const
     hipLaunchKernelGGL(gn_bwd_partial_kernel<SNAP_PRO_RELU_GN>, grid, dim3(256), 0, s, x, dz, HW, C,
                        mu, rstd, gamma, beta, pl.ppb, partial);
   SNAP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)snap_cdiv((int64_t)N * C, 256)),
-                     dim3(256), 0, s, (const float*)partial, pl.S, C, N * C, ab);
-  SNAP_CHECK_LAUNCH();
-  const int work = N * groups > C ? N * groups : C;
-  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)snap_cdiv(work, 256)), dim3(256), 0, s,
-                     (const float*)ab, gamma, N, C, groups, s12, dgamma, dbeta, accumulate);
+  const int cpg = C / groups;
+  const size_t lds16 = (size_t)N * 16 * 2 * sizeof(float), lds64 = (size_t)N * 64 * 2 * sizeof(float);
+  if (cpg <= 16 && 16 % cpg == 0 && C % 16 == 0 && lds16 <= 64 * 1024) {
+    // slab totals, group sums and parameter gradients in one launch (16 channels per workgroup)
+    hipLaunchKernelGGL(gn_bwd_reduce_group_kernel<16>, dim3((unsigned)(C / 16)), dim3(256), lds16, s,
+                       (const float*)partial, pl.S, N, C, groups, gamma, s12, dgamma, dbeta, accumulate);
+  } else if (cpg <= 64 && 64 % cpg == 0 && C % 64 == 0 && lds64 <= 64 * 1024) {
+    hipLaunchKernelGGL(gn_bwd_reduce_group_kernel<64>, dim3((unsigned)(C / 64)), dim3(256), lds64, s,
+                       (const float*)partial, pl.S, N, C, groups, gamma, s12, dgamma, dbeta, accumulate);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)snap_cdiv((int64_t)N * C, 256)),
+                       dim3(256), 0, s, (const float*)partial, pl.S, C, N * C, ab);
+    SNAP_CHECK_LAUNCH();
+    const int work = N * groups > C ? N * groups : C;
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)snap_cdiv(work, 256)), dim3(256), 0, s,
+                       (const float*)ab, gamma, N, C, groups, s12, dgamma, dbeta, accumulate);
+  }
   SNAP_CHECK_LAUNCH();
   const int64_t total4 = (int64_t)N * HW * (C / 4);
 #define SNAP_GN_APPLY(MODE_, HALF_)                                                                   \

@@ -187,6 +187,12 @@ def allreduce_mean_tree_(grads: Dict, group=None, bucket_bytes: int = 64 << 20) 
 
 def all_finite(tensors: Iterable[torch.Tensor], group=None) -> bool:
   """True iff every element on every rank is finite (trainer.py:260-266)."""
+  return bool(all_finite_tensor(tensors, group).item() > 0)
+
+
+def all_finite_tensor(tensors: Iterable[torch.Tensor], group=None) -> torch.Tensor:
+  """``all_finite`` as a 0-d f32 tensor (1 = finite) left on the device: the caller reads it back
+  together with its other step scalars in ONE transfer instead of one host sync per scalar."""
   tensors = [t for t in tensors if t is not None]
   if tensors:
     # max|.| per tensor in one multi-tensor launch; inf / nan propagate into the max.
@@ -198,7 +204,7 @@ def all_finite(tensors: Iterable[torch.Tensor], group=None) -> bool:
     if dist.get_backend(group) == 'nccl' and not ok.is_cuda:     # (no tensors: RCCL needs a device buffer)
       ok = ok.to(torch.device('cuda', torch.cuda.current_device()))
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-  return bool(ok.item() > 0)
+  return ok
 
 
 def psum_metric_normalizer(metrics: Dict[str, Tuple[torch.Tensor, torch.Tensor]], group=None):
@@ -219,10 +225,23 @@ def reduce_batch_metrics(metrics: Dict[str, torch.Tensor], batch_mask: torch.Ten
   """Per-example metric vectors [B] -> global masked means (trainer.py:57-67,258)."""
   # metric_mask = batch_mask * isfinite(v): a non-finite value (e.g. on a padding example)
   # leaves both the sum and the count (trainer.py:57-67), instead of NaN * 0 = NaN.
-  pairs = {}
-  for k, v in metrics.items():
-    v = v.to(torch.float64)
-    keep = batch_mask.to(torch.bool) & torch.isfinite(v)
-    pairs[k] = (torch.where(keep, v, torch.zeros_like(v)).sum(), keep.to(torch.float64).sum())
-  summed = psum_metric_normalizer(pairs, group)
-  return {k: float(s / torch.clamp(c, min=1.0)) for k, (s, c) in summed.items()}
+  keys, vals = reduce_batch_metrics_tensor(metrics, batch_mask, group)
+  return dict(zip(keys, vals.cpu().tolist()))
+
+
+def reduce_batch_metrics_tensor(metrics: Dict[str, torch.Tensor], batch_mask: torch.Tensor, group=None):
+  """``reduce_batch_metrics`` without the host round trips: (sorted keys, f64 tensor of the global
+  masked means on the device) -- ONE stacked collective, no per-metric ``float()``."""
+  if not metrics:
+    return [], torch.zeros(0, dtype=torch.float64, device=batch_mask.device)
+  keys = sorted(metrics)
+  keep_b = batch_mask.to(torch.bool)
+  rows = []
+  for k in keys:
+    v = metrics[k].to(torch.float64)
+    keep = keep_b & torch.isfinite(v)
+    rows.append(torch.stack([torch.where(keep, v, torch.zeros_like(v)).sum(), keep.to(torch.float64).sum()]))
+  flat = torch.stack(rows)
+  if _exchanges(group):
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+  return keys, flat[:, 0] / torch.clamp(flat[:, 1], min=1.0)

@@ -498,7 +498,7 @@ def adam_update_(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
       raise ValueError('adam_update_: tensor sizes differ')
     items[i] = (p.data_ptr(), g.data_ptr(), mi.data_ptr(), vi.data_ptr(), p.numel(), blk)
     blk += lib.snap_adam_multi_blocks(p.numel())
-  table = torch.from_numpy(items.view(np.uint8).copy()).to(params[0].device, non_blocking=True)
+  table = ops.upload_table(items, params[0].device)
   st = lib.snap_adam_multi_f32(_p(table), len(params), blk, float(lr), float(b1), float(b2), float(eps),
                                int(step), _stream())
   _lib.check(st, 'snap_adam_multi_f32')

@@ -197,11 +197,15 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
     gn = _global_norm(grads)
     factor = torch.clamp(max_grad_norm / (gn + 1e-6), max=1.0)
     torch._foreach_mul_(grads, factor)
-  is_fin = sdist.all_finite(grads, group)
+  # the step's host-visible scalars travel in TWO transfers (one here: the update below depends on
+  # the finite flag; one at the end), not one blocking read per scalar (~20 per step before)
+  head = torch.stack([sdist.all_finite_tensor(grads, group).to(torch.float64).reshape(()),
+                      _global_norm(grads).reshape(())]).cpu()
+  is_fin = bool(head[0] > 0)
   if state.dynamic_scale is not None:
     state.dynamic_scale = state.dynamic_scale.update(is_fin)
     logs['loss_scale'] = state.dynamic_scale.scale
-  logs['l2_grads'] = float(_global_norm(grads))
+  logs['l2_grads'] = float(head[1])
   # The reference restores the whole opt_state on a skipped step, optax's step and schedule
   # counts included (trainer.py:269-276): bias correction and schedule follow opt_count.
   lr = lr_fn(state.opt_count)
@@ -212,13 +216,16 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
       _adam_update_(leaves, grads, state.m, state.v, state.opt_count + 1, lr)
     state.opt_count += 1
   with torch.no_grad():
-    logs['l2_params'] = float(_global_norm(leaves))
     per_example = {k: v.detach().to(torch.float32) for k, v in metrics.items()}
     for k, v in losses.items():
       per_example[f'loss/{k}'] = v.detach()
-    reduced = sdist.reduce_batch_metrics(per_example, batch['batch_mask'], group)
+    keys, means = sdist.reduce_batch_metrics_tensor(per_example, batch['batch_mask'], group)
+    tail = torch.cat([torch.stack([_global_norm(leaves).reshape(()), loss.detach().to(torch.float64).reshape(())]),
+                      means.to(torch.float64)]).cpu().tolist()
+  logs['l2_params'] = tail[0]
+  logs['loss'] = tail[1]
+  reduced = dict(zip(keys, tail[2:]))
   state.global_step += 1
-  logs['loss'] = float(loss.detach())
   return state, reduced, logs
 
 
