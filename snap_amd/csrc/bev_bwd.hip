@@ -748,8 +748,26 @@ inline int lift_det_layout(const SnapLiftDesc& d, LiftDetLayout* L, bool with_ve
 }
 }  // namespace
 
+// the shapes the deterministic form takes: ONE validator for the workspace query and the launch, so
+// that "workspace_bytes != 0" means "the launch will not refuse the shape" (callers fall back to the
+// scatter kernel on 0)
+static int lift_det_validate(const SnapLiftDesc& d) {
+  if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.V > 32 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0 || d.num_bins > 32)
+    return SNAP_ERR_UNSUPPORTED;
+  if (d.C != d.feature_dim + (d.weighted ? d.num_bins : 0) || d.C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (d.out_stride < d.feature_dim * (1 + (d.use_variance ? 1 : 0) + (d.add_minmax ? 2 : 0)) + (d.weighted ? 1 : 0) ||
+      d.out_stride % 4 != 0)
+    return SNAP_ERR_BAD_SHAPE;
+  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  const int nsel = d.K == 0 ? d.V : d.K;
+  if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
+  return SNAP_OK;
+}
+
 extern "C" size_t snap_lift_pool_bwd_det_workspace_bytes(const SnapLiftDesc* desc) {
   if (!desc) return 0;
+  if (lift_det_validate(*desc) != SNAP_OK) return 0;
   LiftDetLayout L;
   if (lift_det_layout(*desc, &L) != SNAP_OK) return 0;
   return L.total;
@@ -761,16 +779,9 @@ extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float*
                                           size_t workspace_bytes, void* stream) {
   if (!desc || !f_images || !cam || !Rt || !points || !dpooled || !df_images || !workspace) return SNAP_ERR_NULL;
   const SnapLiftDesc& d = *desc;
-  if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
-  if (d.V > 32 || d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0 || d.num_bins > 32)
-    return SNAP_ERR_UNSUPPORTED;
-  if (d.C != d.feature_dim + (d.weighted ? d.num_bins : 0) || d.C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
-  if (d.out_stride < d.feature_dim * (1 + (d.use_variance ? 1 : 0) + (d.add_minmax ? 2 : 0)) + (d.weighted ? 1 : 0) ||
-      d.out_stride % 4 != 0)
-    return SNAP_ERR_BAD_SHAPE;
-  if (d.K < 0 || (d.K > 0 && d.K >= d.V)) return SNAP_ERR_BAD_SHAPE;
+  const int vrc = lift_det_validate(d);
+  if (vrc != SNAP_OK) return vrc;
   const int nsel = d.K == 0 ? d.V : d.K;
-  if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
   LiftDetLayout L;
   const int rc = lift_det_layout(d, &L);
   if (rc != SNAP_OK) return rc;

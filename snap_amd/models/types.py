@@ -14,18 +14,24 @@ class FeatureVolume:
     return dataclasses.replace(self, **kw)
 
 
-class LazyFeatureVolume:
+class LazyFeatureVolume(FeatureVolume):
   """A ``FeatureVolume`` whose ``features`` are produced on first access.
 
   With ``bev_mapper.materialize_volume = False`` the StreetView encoder produces the BEV plane
   straight from the pooled observations (fusion MLP + vertical max pooling in one kernel) and the
   dense [..., X, Y, Z, D] volume of ``streetview_encoder.py:282-286`` is never written.  The
   output pytree keeps the reference's entry: a consumer that does read ``features`` gets the
-  volume of the unfused chain (lift -> fusion MLP -> mask), computed then and remembered."""
+  volume of the unfused chain (lift -> fusion MLP -> mask), computed then and remembered.
 
-  def __init__(self, thunk, valid=None):
-    self._thunk = thunk
-    self._features = None
+  It IS a ``FeatureVolume`` (``isinstance`` checks and ``dataclasses.replace`` work; the latter
+  reads ``features`` and therefore materialises).  Until ``features`` is read -- or ``discard()``
+  is called -- the object keeps the encoder inputs its thunk needs alive (the image features and
+  the voxel coordinates: ~0.5 GB at C2); ``discard()`` drops them for consumers that will never
+  read the volume."""
+
+  def __init__(self, thunk=None, valid=None, features=None):
+    self._thunk = None if features is not None else thunk
+    self._features = features
     self.valid = valid
 
   @property
@@ -35,9 +41,19 @@ class LazyFeatureVolume:
       self._thunk = None              # (drops the references to the encoder's inputs)
     return self._features
 
+  @features.setter
+  def features(self, value):
+    self._features = value
+    self._thunk = None
+
   @property
   def materialized(self):
     return self._features is not None
+
+  def discard(self):
+    """Release the inputs held for a volume nobody will read (``features`` is then None)."""
+    self._thunk = None
+    return self
 
   def replace(self, **kw):
     if 'features' in kw:

@@ -119,6 +119,25 @@ def test_conv_dispatch_queries_follow_the_documented_rules():
   assert query(40, 136, 136, 64, 64, K=3, mode=3)[0] == 0
 
 
+def test_lazy_feature_volume_is_a_feature_volume():
+  """types.LazyFeatureVolume (plane-only mode of the StreetView encoder): a FeatureVolume by
+  ``isinstance``, lazy until ``features`` is read, ``dataclasses.replace`` works (and materialises),
+  ``discard()`` releases the captured encoder inputs."""
+  import dataclasses
+  from snap_amd.models import types
+  calls = []
+  v = types.LazyFeatureVolume(lambda: calls.append(1) or 'F', valid='V')
+  assert isinstance(v, types.FeatureVolume) and not v.materialized
+  w = v.replace(valid='W')
+  assert not w.materialized and w.valid == 'W' and calls == []
+  r = dataclasses.replace(v, valid='X')
+  assert r.features == 'F' and r.valid == 'X' and isinstance(r, types.FeatureVolume)
+  assert v.materialized and calls == [1]
+  assert v.replace(features='G').features == 'G'
+  d = types.LazyFeatureVolume(lambda: 1 / 0, valid=1).discard()
+  assert d.features is None and d.valid == 1
+
+
 def test_presplit_engine_support_query():
   """`snap_conv2d_presplit_supported` (host-only): the exhaustive voting asks it before it pre-splits
   the map.  C4 (256^2, matching_dim 32, shift-stacked by 4) fits; matching_dim 64 at 256^2 and a
