@@ -155,7 +155,13 @@ typedef struct SnapConvExtras {
                                  [N, H, W, Cin_stride] -- the half-precision twin a GroupNorm VJP wrote
                                  next to its f32 gradient (snap_group_norm_bwd_ex_f32).  The
                                  data-gradient convolution then moves both operands by LDS-DMA: half the
-                                 input bytes, no conversion in the loop; same bits as the f32 input */
+                                 input bytes, no conversion in the loop; same bits as the f32 input.
+                                 rows_out / row_count are honoured (compact row buffers), rows_in is not */
+  void* y_half;               /* with w_split_parts = 0, prologue NONE / RELU, no statistics: the stored
+                                 values ALSO go, rounded (RNE) to the engine's element type, to y_half
+                                 (same indexing as y, 2-byte elements) -- and ONLY there when y is NULL:
+                                 the hidden activations / inter-layer gradients of the masked MLP
+                                 (layers.py:55-78), which every consumer rounds to that type anyway */
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
@@ -784,6 +790,18 @@ int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x, const flo
                              const int32_t* rows_dy, const int32_t* row_count, int32_t math,
                              void* stream);
 
+/* ... with ONE of the operands already in the engine's 2-byte element type (math BF16 / F16):
+ * x_is_half -- x [rows, Cin_stride] (prologue NONE), dy_is_half -- dy [rows, Cout_stride]; the other
+ * operand stays f32.  The hidden activations and inter-layer gradients of the masked MLP, written in
+ * that type by SnapConvExtras.y_half / snap_epilogue_bwd_colsum_half: half the bytes, no rounding
+ * work, same bits as rounding an f32 copy in the loop. */
+int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* x, const void* dy, float* dw,
+                               const float* gn_mu, const float* gn_sc, const float* gn_beta,
+                               int32_t accumulate, void* workspace, size_t workspace_bytes,
+                               const int32_t* rows_z, const int32_t* rows_dy,
+                               const int32_t* row_count, int32_t math, int32_t x_is_half,
+                               int32_t dy_is_half, void* stream);
+
 /* Adam over every parameter tensor in ONE launch (optax.adam as train_step applies it,
  * snap/trainer.py:236-243: m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2,
  * p -= lr / (1 - b1^step) * m / (sqrt(v / (1 - b2^step)) + eps); `step` counts from 1).
@@ -840,6 +858,13 @@ size_t snap_colsum_workspace_bytes(int64_t M, int32_t C);
 int snap_epilogue_bwd_colsum_f32(const float* dy, const float* y, const uint8_t* row_mask, float* out,
                                  int64_t M, int32_t C, int32_t relu, const int32_t* row_count,
                                  float* colsum, void* workspace, size_t workspace_bytes, void* stream);
+/* ... on 2-byte tensors of the training engine's element type (half_kind 1 = bf16, 2 = IEEE half):
+ * dy, y, out [rows, C]; the column sums stay f32.  Rows beyond *row_count are neither read nor
+ * written (compact row buffers of the masked MLP). */
+int snap_epilogue_bwd_colsum_half(const void* dy, const void* y, void* out, int64_t M, int32_t C,
+                                  int32_t relu, const int32_t* row_count, float* colsum,
+                                  void* workspace, size_t workspace_bytes, int32_t half_kind,
+                                  void* stream);
 int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* ... over the listed rows only: sum_{m < *row_count} a[rows[m], :]  (rows / row_count may be NULL). */

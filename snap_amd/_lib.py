@@ -39,7 +39,7 @@ class SnapConvExtras(ctypes.Structure):
       ('w_bf16', ptr), ('w_bf16_bytes', c_size), ('w_split_parts', c_int), ('w_split_root', c_int),
       ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
       ('x_presplit', c_int), ('ps_tile', c_int), ('ps_res_init', c_int),
-      ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int), ('w_half', c_int), ('x_half', c_int),
+      ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int), ('w_half', c_int), ('x_half', c_int), ('y_half', ptr),
   ]
 
 
@@ -106,6 +106,12 @@ SIGNATURES = {
         c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr, c_size, ptr]),
     'snap_gelu_f32': (c_int, [ptr, ptr, c_i64, ptr]),
     'snap_gelu_bwd_f32': (c_int, [ptr, ptr, ptr, c_i64, ptr]),
+    'snap_epilogue_bwd_colsum_half': (c_int, [ptr, ptr, ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, c_int, ptr]),
+    'snap_conv2d_wgrad_half_f32': (
+        c_int,
+        [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr, ptr, ptr, c_int,
+         c_int, c_int, ptr],
+    ),
     'snap_adam_multi_blocks': (c_i64, [c_i64]),
     'snap_adam_multi_f32': (c_int, [ptr, c_int, c_i64, c_float, c_float, c_float, c_float, c_int, ptr]),
     'snap_conv2d_packed_weights_bytes': (c_size, [c_int, c_int, c_int]),

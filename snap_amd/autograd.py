@@ -379,16 +379,24 @@ class _MaskedRowsMLP(torch.autograd.Function):
     pro0 = ops.PRO_RELU if relu_input else ops.PRO_NONE
     acts = []
     h = x.reshape(M, x.shape[-1])
+    # training-precision engines, two layers (the fusion / projection MLPs): the hidden activation --
+    # and, in the backward pass, the gradient w.r.t. it -- exist ONLY in the engine's element type
+    # (compact rows).  Every consumer rounds them to that type anyway, so nothing changes in the
+    # arithmetic; they move at half the bytes and their GEMMs read them by LDS-DMA.
+    half = (MASKED_MLP_HALF and ops.MATMUL_PRECISION in ops.HALF_MATH and n == 2 and x.shape[-1] % 4 == 0
+            and wb[0].shape[0] >= 4 and wb[0].shape[1] % 8 == 0 and wb[2].shape[1] % 4 == 0)
     for i in range(n):
       W, b = wb[2 * i], wb[2 * i + 1]
       last = i + 1 == n
       h = ops.dense(h, W, b, cin=W.shape[0], prologue=pro0 if i == 0 else ops.PRO_NONE,
                     relu=not last, rows_in=index if i == 0 else None,
-                    rows_out=index if last else None, row_count=count)
+                    rows_out=index if last else None, row_count=count,
+                    out_half=half and not last)
       if not last:
         acts.append(h)
     ops.fill_masked_rows_(h, mask)
     ctx.relu_input = relu_input
+    ctx.half = half
     ctx.n = n
     ctx.xshape = x.shape
     ctx.save_for_backward(x, mask, index, count, *acts, *[wb[2 * i] for i in range(n)])
@@ -407,6 +415,8 @@ class _MaskedRowsMLP(torch.autograd.Function):
     g = dy.contiguous().reshape(M, dy.shape[-1])
     grads = [None] * (2 * n)
     dx = None
+    if ctx.half:
+      return _MaskedRowsMLP._backward_half(ctx, x2, g, mask, index, count, acts[0], Ws)
     for i in reversed(range(n)):
       last = i + 1 == n
       W = Ws[i]
@@ -443,6 +453,47 @@ class _MaskedRowsMLP(torch.autograd.Function):
           dx = gi.reshape(ctx.xshape)
         g = gi
     return (dx, None, None, *grads)
+
+
+def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
+  """The two-layer backward with the hidden activation h0 and the gradient w.r.t. it in the engine's
+  element type (see ``_MaskedRowsMLP.forward``): same GEMMs, same rounded operands."""
+  M = mask.numel()
+  Cs = x2.shape[-1]
+  W0, W1 = Ws
+  cin0, H = W0.shape
+  D1 = W1.shape[1]
+  need = ctx.needs_input_grad
+  grads = [None] * 4
+  if need[5]:      # dW1 = h0^T g  (Z: half, compact; dY: f32 through the row list)
+    grads[2] = ops_bwd.conv2d_wgrad(h0.reshape(1, 1, M, H), g.reshape(1, 1, M, D1), (1, 1, H, D1),
+                                    rows_dy=index, row_count=count).reshape(H, D1)
+  if need[6]:
+    grads[3] = ops_bwd.colsum(g, rows=index, row_count=count)
+  # d h0 (compact, half only), then the ReLU gate + the bias gradient of layer 0 in one pass
+  g1 = ops.dense(g, W1.t().contiguous(), None, cin=D1, rows_in=index, row_count=count, out_half=True)
+  g1, db0 = ops_bwd.epilogue_bwd_colsum(g1, h0, None, relu=True, row_count=count)
+  if need[4]:
+    grads[1] = db0
+  pro = ops.PRO_RELU if ctx.relu_input else ops.PRO_NONE
+  if need[3]:      # dW0 = x^T g1  (Z: f32 through the row list; dY: half, compact)
+    grads[0] = ops_bwd.conv2d_wgrad(x2.reshape(1, 1, M, Cs), g1.reshape(1, 1, M, H), (1, 1, cin0, H),
+                                    prologue=pro, rows_z=index, row_count=count).reshape(cin0, H)
+  dx = None
+  if need[0]:
+    Wt = W0.t()
+    if Cs != cin0:
+      Wt = F.pad(Wt, (0, Cs - cin0))
+    gi = ops.dense(g1, Wt.contiguous(), None, cin=H, rows_out=index, row_count=count)   # half in, f32 rows out
+    ops.fill_masked_rows_(gi, mask)
+    if ctx.relu_input:
+      gi = ops_bwd.epilogue_bwd(gi, x2, None, relu=True)
+    dx = gi.reshape(ctx.xshape)
+  return (dx, None, None, *grads)
+
+
+_MaskedRowsMLP._backward_half = staticmethod(_masked_rows_mlp_backward_half)
+MASKED_MLP_HALF = True      # (tests: False pins the f32-tensor formulation; same arithmetic)
 
 
 def masked_rows_mlp(x, mask, relu_input, weights_and_biases):

@@ -43,7 +43,7 @@ template <> struct Elem<true> {
   }
 };
 
-template <int BM, int BN, int PRO, bool F16>
+template <int BM, int BN, int PRO, bool F16, bool YH = false>
 __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
   typedef Elem<F16> E;
   typedef typename E::T ET;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
     __syncthreads();
   }
 
-  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
+  conv_epilogue<BM, BN, false, 256, false, YH ? (F16 ? 2 : 1) : 0>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
 // The same GEMM with the A operand ALREADY in the engine's element type in HBM (ConvArgs.x_half:
@@ -290,7 +290,7 @@ __device__ __forceinline__ void conv_bf16_xh_body(const ConvArgs& a) {
   const int seq = bid >> 3;
   const int col_t = seq % ncol;
   const int row_t = (seq / ncol) * 8 + xcd;
-  const int Meff = a.M;
+  const int Meff = a.row_count ? min(*a.row_count, a.M) : a.M;     // (compact row buffers: the first *row_count rows)
   if (row_t * BM >= Meff) return;
   const int m0 = row_t * BM;
   const int n0 = col_t * BN;
@@ -411,9 +411,9 @@ __global__ __launch_bounds__(256) void conv_bf16_xh_kernel(const ConvArgs a) {
   conv_bf16_xh_body<BM, BN, F16>(a);
 }
 
-template <int BM, int BN, int PRO, bool F16 = false>
+template <int BM, int BN, int PRO, bool F16 = false, bool YH = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs a) {
-  conv_bf16_body<BM, BN, PRO, F16>(a);
+  conv_bf16_body<BM, BN, PRO, F16, YH>(a);
 }
 
 template <int BM, int BN, int PRO>
@@ -432,7 +432,7 @@ int launch(ConvArgs a, hipStream_t s) {
   const int64_t tiles = nrow * a.ncol;
   const int target = splitk_target();
   if (a.kpartial && target > 0 && tiles <= splitk_max_tiles() && a.nk >= 8 && !a.rows_in &&
-      !a.rows_out && !a.row_count && !a.gn_partial &&
+      !a.rows_out && !a.row_count && !a.gn_partial && !a.y_half &&
       !(a.d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) {
     int64_t S = (target + tiles - 1) / tiles;
     S = S < a.nk / 4 ? S : a.nk / 4;                        // >= 4 slabs (128 k) per split
@@ -450,6 +450,17 @@ int launch(ConvArgs a, hipStream_t s) {
         hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
       else
         hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+    } else {
+      return SNAP_ERR_UNSUPPORTED;
+    }
+  } else if (a.y_half) {
+    // half (also / only) output: the dense layers of the masked MLP (prologue NONE / RELU)
+    if constexpr (PRO == SNAP_PRO_NONE || PRO == SNAP_PRO_RELU) {
+      if (a.ksplit > 1) return SNAP_ERR_UNSUPPORTED;
+      if (a.half)
+        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, true, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
     } else {
       return SNAP_ERR_UNSUPPORTED;
     }

@@ -52,6 +52,8 @@ struct ConvArgs {
   int half;            // ... 1: the image and the A operand are IEEE half (SnapConvExtras.w_half)
   const void* x_half;  // ... non-NULL: the input ALREADY in the engine's element type, [N,H,W,Cin_stride]
                        //     (SnapConvExtras.x_half; prologue NONE): both operands by LDS-DMA
+  void* y_half;        // ... non-NULL: the output (also / only, when y is NULL) rounded to the engine's
+                       //     element type, same row / column indexing as y (SnapConvExtras.y_half)
   const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
   int ps_tile;         // ... 0 = automatic tile, 1 = 128 rows, 2 = 256 rows
   int ps_res_init;     // ... 1 = the residual is loaded into the accumulators before the K loop
@@ -115,7 +117,10 @@ __device__ __forceinline__ float snap_gelu_tanh(float x) {
 // ---- epilogue ------------------------------------------------------------
 // NT threads = NT / 64 waves laid out (NT / 128) x 2; SKIP_RES: the residual already sits in the
 // accumulators (conv_ps.hip loads it there before the K loop)
-template <int BM, int BN, bool DUAL = false, int NT = 256, bool SKIP_RES = false>
+// OUTH (training-precision engine only): 1 / 2 = the stored values also go, rounded (RNE) to bf16 /
+// IEEE half, to a.y_half; a.y may then be NULL (half-only output: the hidden activations and
+// inter-layer gradients of the masked MLP, which every consumer rounds to that type anyway)
+template <int BM, int BN, bool DUAL = false, int NT = 256, bool SKIP_RES = false, int OUTH = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
                                               f32x16 (&acc)[BM / (NT / 4)][BN / 64],
                                               float* smem, int m0, int n0, int Meff, int row_t,
@@ -226,7 +231,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
         for (int e = 0; e < 4; ++e) v[e] = snap_gelu_tanh(v[e]);
       }
       if ((epi & SNAP_EPI_ROWMASK) && a.row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(a.y + o) = v;
+      if constexpr (OUTH == 0) {
+        *reinterpret_cast<f32x4*>(a.y + o) = v;
+      } else {
+        if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
+        if constexpr (OUTH == 1) {
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<bf16x4_t*>(static_cast<__bf16*>(a.y_half) + o) = __builtin_convertvector(v, bf16x4_t);
+        } else {
+          typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<f16x4_t*>(static_cast<_Float16*>(a.y_half) + o) = __builtin_convertvector(v, f16x4_t);
+        }
+      }
       if (want_stats) {
         const int sl = m >= m_split ? 1 : 0;
 #pragma unroll

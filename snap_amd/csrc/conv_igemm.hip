@@ -651,7 +651,7 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
                                        const float* bias, const float* residual,
                                        const float* up_prev, const uint8_t* row_mask,
                                        const SnapConvExtras* ex, void* stream) {
-  if (!desc || !x || !w || !y) return SNAP_ERR_NULL;
+  if (!desc || !x || !w || (!y && !(ex && ex->y_half))) return SNAP_ERR_NULL;
   const int32_t* rows_in = ex ? ex->rows_in : nullptr;
   const int32_t* rows_out = ex ? ex->rows_out : nullptr;
   const int32_t* row_count = ex ? ex->row_count : nullptr;
@@ -741,14 +741,23 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.half = (ex && ex->w_half) ? 1 : 0;
   if (a.half && (ex->w_split_parts != 0 || presplit || ex->w_split_root)) return SNAP_ERR_UNSUPPORTED;
   a.x_half = nullptr;
+  a.y_half = nullptr;
+  if (ex && ex->y_half) {       // half (also / only) output: training-precision engine, no split-K, no statistics
+    if (!a.w_bf16 || ex->w_split_parts != 0 || presplit || ex->w_split_root || gn_partial ||
+        (d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD) || d.Cout_stride % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(ex->y_half) & 7))
+      return SNAP_ERR_UNSUPPORTED;
+    a.y_half = ex->y_half;
+    a.kpartial = nullptr;
+  }
   a.cin8 = (d.Cin + 7) / 8 * 8;
   a.x_ps = nullptr;
   a.ps_tile = 0;
   a.ps_res_init = 0;
   if (ex && ex->x_half) {     // the input is already bf16 / f16: training-precision engine, both operands by DMA
     if (!a.w_bf16 || ex->w_split_parts != 0 || presplit || ex->w_split_root || d.prologue != SNAP_PRO_NONE ||
-        rows_in || rows_out || row_count || d.Cin_stride % 8 != 0 || d.Cin % 8 != 0)
-      return SNAP_ERR_UNSUPPORTED;
+        rows_in || d.Cin_stride % 8 != 0 || d.Cin % 8 != 0 || ex->y_half)
+      return SNAP_ERR_UNSUPPORTED;       // (rows_out / row_count: the compact buffers of the masked MLP)
     if (ex->w_bf16_bytes < snap_conv2d_packed_weights_bytes(d.KH * d.KW, d.Cin, d.Cout)) return SNAP_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(a.w_bf16) | reinterpret_cast<uintptr_t>(x)) & 15) return SNAP_ERR_BAD_SHAPE;
     a.x_half = x;

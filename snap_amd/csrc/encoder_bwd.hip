@@ -428,7 +428,7 @@ __global__ void epilogue_bwd_kernel(const float* __restrict__ dy, const float* _
 // ReLU: the bias gradient is the column sum of the gated gradient -- a second full read of it
 // otherwise).  One workgroup = a slab of rows x a chunk of <= 1024 columns; a thread = a column quad
 // and every PW-th row of the slab; partial[s][c] as colsum_partial_kernel writes it (rows beyond
-// *row_count are gated and stored like the others but not summed).
+// *row_count are neither read nor written).
 __global__ __launch_bounds__(256) void epilogue_bwd_colsum_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const uint8_t* __restrict__ row_mask,
     float* __restrict__ out, int64_t M, int C, int relu, int64_t rows_per_block,
@@ -442,7 +442,9 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_kernel(
   const int c0 = cbase + 4 * tq;
   const int64_t Msum = row_count ? min((int64_t)*row_count, M) : M;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = min(M, r0 + rows_per_block);
+  // (with a row count only the listed rows exist: the compact buffers of the masked MLP hold
+  //  nothing beyond them that anybody reads -- 40 % of the rows at C3)
+  const int64_t r1 = min(Msum, r0 + rows_per_block);
   float t[4] = {0.f, 0.f, 0.f, 0.f};
   if (tp < PW) {
     for (int64_t r = r0 + tp; r < r1; r += PW) {
@@ -458,6 +460,52 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] += g[e];
       }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = t[e];
+  __syncthreads();
+  if (tp == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = 0.f;
+      for (int pp = 0; pp < PW; ++pp) a += red[(pp * QW + tq) * 4 + e];
+      partial[(int64_t)blockIdx.x * C + c0 + e] = a;
+    }
+  }
+}
+
+// The same gate + column sums on 2-byte tensors of the training engine's element type (ET = __bf16 /
+// _Float16): dy, y and out are [rows, C] of ET -- the inter-layer gradient and hidden activation of
+// the masked MLP.  The gate is exact on the rounded values (an element is kept or zeroed); the bias
+// gradient sums the kept elements in f32, in the f32 kernel's order.
+template <typename ET>
+__global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
+    const ET* __restrict__ dy, const ET* __restrict__ y, ET* __restrict__ out, int64_t M, int C, int relu,
+    int64_t rows_per_block, const int32_t* __restrict__ row_count, float* __restrict__ partial) {
+  typedef ET etx4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[256 * 4];
+  const int cbase = blockIdx.y * 1024;
+  const int cchunk = min(C - cbase, 1024);
+  const int QW = cchunk >> 2;
+  const int PW = 256 / QW;
+  const int tq = threadIdx.x % QW, tp = threadIdx.x / QW;
+  const int c0 = cbase + 4 * tq;
+  const int64_t Msum = row_count ? min((int64_t)*row_count, M) : M;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(Msum, r0 + rows_per_block);
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tp < PW) {
+    for (int64_t r = r0 + tp; r < r1; r += PW) {
+      etx4 g = *reinterpret_cast<const etx4*>(dy + r * C + c0);
+      if (relu) {
+        const etx4 yv = *reinterpret_cast<const etx4*>(y + r * C + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = (float)yv[e] > 0.f ? g[e] : (ET)0.f;
+      }
+      *reinterpret_cast<etx4*>(out + r * C + c0) = g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += (float)g[e];
     }
   }
 #pragma unroll
@@ -699,6 +747,38 @@ extern "C" int snap_epilogue_bwd_colsum_f32(const float* dy, const float* y, con
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(epilogue_bwd_colsum_kernel, dim3(S, (unsigned)snap_cdiv(C, 1024)), dim3(256), 0, s, dy, y,
                      row_mask, out, M, C, relu, rpb, row_count, static_cast<float*>(workspace));
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 32)), dim3(256), 0, s,
+                     (const float*)workspace, S, C, colsum, 0);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_epilogue_bwd_colsum_half(const void* dy, const void* y, void* out, int64_t M,
+                                             int32_t C, int32_t relu, const int32_t* row_count,
+                                             float* colsum, void* workspace, size_t workspace_bytes,
+                                             int32_t half_kind, void* stream) {
+  if (!dy || !out || !colsum || !workspace) return SNAP_ERR_NULL;
+  if (relu && !y) return SNAP_ERR_NULL;
+  if (half_kind != 1 && half_kind != 2) return SNAP_ERR_UNSUPPORTED;
+  if (M <= 0 || C <= 0 || C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  const int q = C < 1024 ? C / 4 : 256;
+  if (256 % q != 0 || (C > 1024 && C % 1024 != 0)) return SNAP_ERR_UNSUPPORTED;
+  if (workspace_bytes < snap_colsum_workspace_bytes(M, C)) return SNAP_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(y)) & 7)
+    return SNAP_ERR_BAD_SHAPE;
+  const int S = colsum_slabs(M);
+  const int64_t rpb = (M + S - 1) / S;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(S, (unsigned)snap_cdiv(C, 1024));
+  if (half_kind == 2)
+    hipLaunchKernelGGL(epilogue_bwd_colsum_half_kernel<_Float16>, grid, dim3(256), 0, s,
+                       static_cast<const _Float16*>(dy), static_cast<const _Float16*>(y),
+                       static_cast<_Float16*>(out), M, C, relu, rpb, row_count, static_cast<float*>(workspace));
+  else
+    hipLaunchKernelGGL(epilogue_bwd_colsum_half_kernel<__bf16>, grid, dim3(256), 0, s,
+                       static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y),
+                       static_cast<__bf16*>(out), M, C, relu, rpb, row_count, static_cast<float*>(workspace));
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 32)), dim3(256), 0, s,
                      (const float*)workspace, S, C, colsum, 0);

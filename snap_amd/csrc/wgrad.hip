@@ -348,7 +348,25 @@ extern "C" int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x
                                         size_t workspace_bytes, const int32_t* rows_z,
                                         const int32_t* rows_dy, const int32_t* row_count,
                                         int32_t math, void* stream) {
+  return snap_conv2d_wgrad_half_f32(desc, x, dy, dw, gn_mu, gn_sc, gn_beta, accumulate, workspace,
+                                    workspace_bytes, rows_z, rows_dy, row_count, math, 0, 0, stream);
+}
+
+extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* x_,
+                                          const void* dy_, float* dw, const float* gn_mu,
+                                          const float* gn_sc, const float* gn_beta,
+                                          int32_t accumulate, void* workspace,
+                                          size_t workspace_bytes, const int32_t* rows_z,
+                                          const int32_t* rows_dy, const int32_t* row_count,
+                                          int32_t math, int32_t x_is_half, int32_t dy_is_half,
+                                          void* stream) {
+  const float* x = static_cast<const float*>(x_);
+  const float* dy = static_cast<const float*>(dy_);
   if (math != SNAP_MATH_F32 && math != SNAP_MATH_BF16 && math != SNAP_MATH_F16) return SNAP_ERR_UNSUPPORTED;
+  if ((x_is_half || dy_is_half) &&
+      (math == SNAP_MATH_F32 || (x_is_half && dy_is_half) || (x_is_half && desc && desc->prologue != SNAP_PRO_NONE) ||
+       (desc && (desc->Cin % 4 != 0 || desc->Cin_stride % 4 != 0))))
+    return SNAP_ERR_UNSUPPORTED;
   if (!desc || !x || !dy || !dw || !workspace) return SNAP_ERR_NULL;
   if ((rows_z || rows_dy) && !(desc->KH == 1 && desc->KW == 1 && desc->stride == 1 &&
                                desc->N == 1 && desc->H == 1 && desc->pad_t == 0 &&
@@ -361,13 +379,14 @@ extern "C" int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x
   if (d.Cin_stride < d.Cin || d.Cout_stride < d.Cout || d.Cout % 4 != 0 || d.Cout_stride % 4 != 0)
     return SNAP_ERR_BAD_SHAPE;
   if ((int64_t)d.N * d.Ho * d.Wo > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
-  if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+  if ((reinterpret_cast<uintptr_t>(dy) & (dy_is_half ? 7 : 15)) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return SNAP_ERR_BAD_SHAPE;
   const bool gn = d.prologue == SNAP_PRO_GN_RELU || d.prologue == SNAP_PRO_RELU_GN;
   if (gn && (!gn_mu || !gn_sc || !gn_beta)) return SNAP_ERR_NULL;
   if (workspace_bytes < snap_conv2d_wgrad_workspace_bytes(desc)) return SNAP_ERR_WORKSPACE;
   const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
-                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (!gn || (d.Cin % 4 == 0));
+                   ((reinterpret_cast<uintptr_t>(x) & (x_is_half ? 7 : 15)) == 0) && (!gn || (d.Cin % 4 == 0));
+  if ((x_is_half || dy_is_half) && !vec) return SNAP_ERR_UNSUPPORTED;
   const WgPlan p = wg_plan(d, vec);
   WgradArgs a;
   a.d = d;
@@ -377,6 +396,8 @@ extern "C" int snap_conv2d_wgrad_ex_f32(const SnapConvDesc* desc, const float* x
   a.K = d.KH * d.KW * d.Cin;
   a.ctiles = p.ctiles; a.ncol = p.ncol; a.slabs_per_chunk = p.slabs_per_chunk;
   a.rows_z = rows_z; a.rows_dy = rows_dy; a.row_count = row_count;
+  a.x_is_half = x_is_half ? 1 : 0;
+  a.dy_is_half = dy_is_half ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (vec && math != SNAP_MATH_F32) {

@@ -35,8 +35,14 @@ template <> struct Elem<true> {
   }
 };
 
-template <int BKT, int BN, int PRO, bool F16 = false>
+// ZH / DH: the Z / dY operand is read in the engine's element type (2 bytes) instead of f32: 8-byte
+// row quads, transposed with byte permutes (two v_perm_b32 per output dword) instead of converted --
+// half the bytes of that operand, no rounding work (the values ARE the rounded ones)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int BKT, int BN, int PRO, bool F16 = false, bool ZH = false, bool DH = false>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
+  static_assert(!ZH || PRO == SNAP_PRO_NONE, "a half Z operand has no prologue");
   typedef Elem<F16> E;
   typedef typename E::x8 etx8;
   typedef typename E::x4 etx4;
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
   bool zin[4];
   f32x4 dr[4];
   bool din[4];
+  u32x2 zrh[4], drh[4];          // ZH / DH: the row quads as two dwords of packed 2-byte elements
   if constexpr (need_gn) {
     zbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + ((z_on && zc < d.Cin) ? zc : 0));
   }
@@ -121,7 +128,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
       zin[p] = inb;
       int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + zc : (int64_t)0;
       if (a.rows_z) off = inb ? (int64_t)a.rows_z[m] * d.Cin_stride + zc : (int64_t)0;
-      zr[p] = *reinterpret_cast<const f32x4*>(a.x + off);
+      if constexpr (ZH)
+        zrh[p] = inb ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.x) + off) : u32x2{0u, 0u};
+      else
+        zr[p] = *reinterpret_cast<const f32x4*>(a.x + off);
       if constexpr (need_gn) {
         const int64_t so = inb ? (int64_t)n * d.Cin + zc : (int64_t)0;
         zmu[p] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
@@ -130,39 +140,65 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
       const bool ok = mok && d_on && dcol < d.Cout;
       din[p] = ok;
       const int64_t drow = (ok && a.rows_dy) ? (int64_t)a.rows_dy[m] : m;
-      dr[p] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? drow * d.Cout_stride + dcol : (int64_t)0));
+      if constexpr (DH)
+        drh[p] = ok ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.dy) + drow * d.Cout_stride + dcol)
+                    : u32x2{0u, 0u};
+      else
+        dr[p] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? drow * d.Cout_stride + dcol : (int64_t)0));
     }
   };
 
   auto store_slab = [&](int buf) {
     char* zs = Zs0 + buf * Z_ST;
     char* ds = Ds0 + buf * D_ST;
+    // element e of the four rows' packed quads -> one 8-byte (4 consecutive m) store per channel
+    auto transpose_store = [&](const u32x2 (&r)[4], char* base) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;   // high / low halves of (src0, src1)
+        const int w = e >> 1;
+        u32x2 o;
+        o[0] = __builtin_amdgcn_perm(r[1][w], r[0][w], sel);        // rows 0, 1
+        o[1] = __builtin_amdgcn_perm(r[3][w], r[2][w], sel);        // rows 2, 3
+        *reinterpret_cast<u32x2*>(base + (4 * quad + e) * RSB + mg * 8) = o;
+      }
+    };
     f32x4 zv[4], dv[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
+      if constexpr (!ZH) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float pv;
-        if constexpr (need_gn)
-          pv = wg_pro<PRO>(zr[p][e], zmu[p][e], zsc[p][e], zbeta[e], d.in_scale, d.in_shift);
-        else
-          pv = wg_pro<PRO>(zr[p][e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
-        zv[p][e] = (zin[p] && (zc + e < d.Cin)) ? pv : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          float pv;
+          if constexpr (need_gn)
+            pv = wg_pro<PRO>(zr[p][e], zmu[p][e], zsc[p][e], zbeta[e], d.in_scale, d.in_shift);
+          else
+            pv = wg_pro<PRO>(zr[p][e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
+          zv[p][e] = (zin[p] && (zc + e < d.Cin)) ? pv : 0.f;
+        }
       }
-      dv[p] = din[p] ? dr[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!DH) dv[p] = din[p] ? dr[p] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (z_on) {
+      if constexpr (ZH) {
+        transpose_store(zrh, zs);        // (Cin % 4 == 0 for a half operand: whole quads or nothing)
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 t = {zv[0][e], zv[1][e], zv[2][e], zv[3][e]};   // 4 consecutive m of channel e
-        *reinterpret_cast<etx4*>(zs + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, etx4);
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 t = {zv[0][e], zv[1][e], zv[2][e], zv[3][e]};   // 4 consecutive m of channel e
+          *reinterpret_cast<etx4*>(zs + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, etx4);
+        }
       }
     }
     if (d_on) {
+      if constexpr (DH) {
+        transpose_store(drh, ds);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 t = {dv[0][e], dv[1][e], dv[2][e], dv[3][e]};
-        *reinterpret_cast<etx4*>(ds + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, etx4);
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 t = {dv[0][e], dv[1][e], dv[2][e], dv[3][e]};
+          *reinterpret_cast<etx4*>(ds + (4 * quad + e) * RSB + mg * 8) = __builtin_convertvector(t, etx4);
+        }
       }
     }
   };
@@ -222,7 +258,25 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
 template <int BKT, int BN, int PRO>
 int wg_launch(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
   const dim3 grid((unsigned)(p.ktiles * p.ncol), (unsigned)p.S);
-  if (half)
+  if (a.x_is_half || a.dy_is_half) {
+    // half operands (the masked MLP's hidden activations / inter-layer gradients): one of the two
+    if (a.x_is_half && a.dy_is_half) return SNAP_ERR_UNSUPPORTED;
+    if (a.x_is_half) {
+      if constexpr (PRO == SNAP_PRO_NONE) {
+        if (half) hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, true, true, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, false, true, false>), grid, dim3(256), 0, s, a);
+      } else {
+        return SNAP_ERR_UNSUPPORTED;
+      }
+    } else {
+      if constexpr (PRO == SNAP_PRO_NONE || PRO == SNAP_PRO_RELU) {
+        if (half) hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, true, false, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, false, false, true>), grid, dim3(256), 0, s, a);
+      } else {
+        return SNAP_ERR_UNSUPPORTED;
+      }
+    }
+  } else if (half)
     hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, true>), grid, dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, false>), grid, dim3(256), 0, s, a);

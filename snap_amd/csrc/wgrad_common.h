@@ -24,6 +24,9 @@ struct WgradArgs {
   const int32_t* rows_z;     // optional: reduction row m reads x row rows_z[m] (flat 1x1 only)
   const int32_t* rows_dy;    // optional: ... and dy row rows_dy[m]
   const int32_t* row_count;  // optional device scalar: only the first *row_count rows exist
+  int x_is_half;             // wgrad_bf16.hip: `x` holds 2-byte elements of the engine's type (prologue NONE,
+                             //   Cin_stride % 4 == 0): the hidden activations of the masked MLP
+  int dy_is_half;            // ... and / or `dy` does (the inter-layer gradients of the masked MLP)
 };
 
 struct WgPlan { int bkt, bn, ctiles, ncol, ktiles, S, slabs_per_chunk; };

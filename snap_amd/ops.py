@@ -347,7 +347,7 @@ def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
-    emit_gn_stats=None, math=None, gelu=False, res_init=None, ps_tile=None,
+    emit_gn_stats=None, math=None, gelu=False, res_init=None, ps_tile=None, out_half=False,
 ):
   """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
@@ -369,6 +369,9 @@ def conv2d(
   y; they travel as ``y._snap_gn_partial`` ('both' = 'raw' plus, where the engine has the kernel
   variant -- split-bf16, GroupNorm -> ReLU prologue, 128 x 128 tiles --, those of relu(y) as
   ``y._snap_gn_partial_relu``).  Ignored where the shape does not allow it.
+  out_half (training-precision engines 'bf16' / 'fp16' only): the result is written ONLY rounded to the
+  engine's element type and returned as a bf16 / f16 tensor (the hidden activations and inter-layer
+  gradients of the masked MLP: every consumer rounds them to that type anyway).
   Returns y [N,Ho,Wo,Cout].
   """
   lib = _lib.load()
@@ -379,10 +382,10 @@ def conv2d(
     # VJP wrote next to its f32 gradient): both operands by LDS-DMA (conv_bf16.hip)
     want = 'fp16' if x.dtype == torch.float16 else 'bf16'
     math = want if math is None else math
-    if (math != want or prologue != PRO_NONE or rows_in is not None or rows_out is not None
-        or row_count is not None or x.shape[-1] % 8 or w.shape[2] % 8 or emit_gn_stats is not None):
+    if (math != want or prologue != PRO_NONE or rows_in is not None or x.shape[-1] % 8 or w.shape[2] % 8
+        or emit_gn_stats is not None or out_half):
       raise ValueError('conv2d: a half-precision input takes the matching engine, prologue NONE, whole '
-                       'channel octets, no row lists / statistics')
+                       'channel octets, no input row list / statistics')
     _chk(x, x.dtype, 'x')
     N, H, W, Cs = x.shape
   if ps:
@@ -412,7 +415,16 @@ def conv2d(
   (pt, pb), (pl, pr) = padding
   Ho = (H + pt + pb - KH) // stride + 1
   Wo = (W + pl + pr - KW) // stride + 1
-  if out is None:
+  yh = None
+  if out_half:
+    hm = MATMUL_PRECISION if math is None else math
+    if (hm not in HALF_MATH or out is not None or emit_gn_stats is not None or up_prev is not None
+        or prologue not in (PRO_NONE, PRO_RELU) or Cs % 4 or Cin < 4 or Cout % 4):
+      raise ValueError('conv2d: out_half needs a training-precision engine launch (prologue NONE / RELU, '
+                       'no statistics / up-sampling epilogue, channel quads)')
+    yh = torch.empty((N, Ho, Wo, Cout), dtype=torch.float16 if hm == 'fp16' else torch.bfloat16, device=x.device)
+    y = yh                      # (shape carrier for the checks below; the f32 pointer passed is NULL)
+  elif out is None:
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
   else:
     y = _f32(out, 'out')
@@ -479,7 +491,7 @@ def conv2d(
     elif qparts == 2 and lib.snap_conv2d_stationary_kind(ctypes.byref(d), qparts):
       wbytes = 0        # a stationary-operand kernel takes the launch: it never splits K
     else:
-      wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if USE_SPLITK else 0
+      wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if (USE_SPLITK and yh is None) else 0
     if wbytes:   # small-M / deep-K layer: split K
       kws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes, None, 0)
@@ -532,6 +544,8 @@ def conv2d(
     ex.w_split_parts = parts
     ex.w_half = int(math == 'fp16')
     ex.x_half = int(xh)
+    if yh is not None:
+      ex.y_half = yh.data_ptr()
     family = f'conv_split_{math}' if parts else ('conv_fp16' if math == 'fp16' else 'conv_bf16')
     if ps:
       ex.x_presplit = 1
@@ -559,7 +573,7 @@ def conv2d(
               f'_s{stride}_p{prologue}_e{epi}',
   ):
     st = lib.snap_conv2d_nhwc_ex_f32(
-        ctypes.byref(d), _p(x), _p(w), _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
+        ctypes.byref(d), _p(x), _p(w), None if yh is not None else _p(y), _p(mu), _p(sc), _p(beta), _p(bias),
         _p(residual), _p(up_prev), _p(row_mask), None if ex is None else ctypes.byref(ex),
         _stream(),
     )
@@ -758,7 +772,7 @@ def packed_rot_image(w, math='bf16'):
 
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
           row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None,
-          gelu=False, residual=None):
+          gelu=False, residual=None, out_half=False):
   """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1)."""
   lead = x.shape[:-1]
   M = int(np.prod(lead)) if len(lead) else 1
@@ -768,7 +782,7 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
       bias=bias, relu=relu, row_mask=row_mask, rows_in=rows_in, rows_out=rows_out,
       row_count=row_count, out=None if out is None else out.reshape(1, 1, M, kernel.shape[1]),
       math=math, gelu=gelu,
-      residual=None if residual is None else residual.reshape(1, 1, M, kernel.shape[1]),
+      residual=None if residual is None else residual.reshape(1, 1, M, kernel.shape[1]), out_half=out_half,
   )
   return y.reshape(*lead, kernel.shape[1])
 

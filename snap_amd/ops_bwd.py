@@ -45,7 +45,18 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   if math not in ('f32', 'bf16', 'fp16'):
     raise ValueError(f'conv2d_wgrad: math={math!r}')
   lib = _lib.load()
-  _f32(x, 'x'); _f32(dy, 'dy')
+  x_half = x.dtype in (torch.bfloat16, torch.float16)
+  dy_half = dy.dtype in (torch.bfloat16, torch.float16)
+  if x_half or dy_half:
+    # one operand already in the engine's element type (masked MLP: hidden activations / inter-layer
+    # gradients): 2-byte loads and byte permutes instead of f32 loads and conversions
+    want = HALF_DTYPE.get(math)
+    if want is None or (x_half and dy_half) or (x_half and (x.dtype != want or prologue != ops.PRO_NONE)) or \
+       (dy_half and dy.dtype != want):
+      raise ValueError('conv2d_wgrad: a half-precision operand needs the matching engine (one operand, prologue NONE for x)')
+    ops._chk(x, x.dtype, 'x'); ops._chk(dy, dy.dtype, 'dy')
+  else:
+    _f32(x, 'x'); _f32(dy, 'dy')
   d, yshape = _conv_desc(x.shape, w_shape, stride, padding, prologue, in_affine)
   if tuple(dy.shape) != yshape:
     raise ValueError(f'conv2d_wgrad: dy {tuple(dy.shape)} vs {yshape}')
@@ -66,11 +77,11 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   code = (2 if math == 'fp16' else 1) if bf16 else 0          # SNAP_MATH_F16 / _BF16 / _F32
   with _region(('conv_wgrad_fp16' if code == 2 else 'conv_wgrad_bf16') if bf16 else 'conv_wgrad', flops,
                4.0 * (x.numel() + dy.numel())):
-    st = lib.snap_conv2d_wgrad_ex_f32(
+    st = lib.snap_conv2d_wgrad_half_f32(
         ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(mu), _p(sc), _p(beta), 0, _p(ws),
-        ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), code, _stream(),
+        ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), code, int(x_half), int(dy_half), _stream(),
     )
-  _lib.check(st, 'snap_conv2d_wgrad_ex_f32')
+  _lib.check(st, 'snap_conv2d_wgrad_half_f32')
   return dw
 
 
@@ -169,8 +180,26 @@ def epilogue_bwd(dy, y=None, row_mask=None, relu=False):
 
 def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None):
   """``epilogue_bwd`` and the column sums of its output (over the first *row_count rows) in one
-  pass -> (gated dy, [C] sums); falls back to the two passes for widths the kernel does not take."""
+  pass -> (gated dy, [C] sums); falls back to the two passes for widths the kernel does not take.
+  dy / y in bf16 / f16 (both): the half kernel, gated dy in the same type."""
   lib = _lib.load()
+  if dy.dtype in (torch.bfloat16, torch.float16):
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    q = C // 4 if C < 1024 else 256
+    if row_mask is not None or C % 4 or 256 % q or (C > 1024 and C % 1024) or (y is not None and y.dtype != dy.dtype):
+      raise ValueError('epilogue_bwd_colsum: half tensors take no row mask, matching types, C % 4 == 0')
+    ops._chk(dy, dy.dtype, 'dy')
+    if y is not None:
+      ops._chk(y, y.dtype, 'y')
+    out = torch.empty_like(dy)
+    wsb = lib.snap_colsum_workspace_bytes(M, C)
+    ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=dy.device)
+    sums = torch.empty(C, dtype=torch.float32, device=dy.device)
+    st = lib.snap_epilogue_bwd_colsum_half(_p(dy), _p(y), _p(out), M, C, int(relu), _p(row_count), _p(sums),
+                                           _p(ws), ws.numel() * 4, 2 if dy.dtype == torch.float16 else 1, _stream())
+    _lib.check(st, 'snap_epilogue_bwd_colsum_half')
+    return out, sums
   _f32(dy, 'dy')
   C = dy.shape[-1]
   M = dy.numel() // C

@@ -710,6 +710,56 @@ def test_masked_rows_mlp_gradients_match_dense_path(layers_, in_dim, stride, rel
   assert bool((g_c[0][~mask] == 0).all())
 
 
+@pytest.mark.parametrize('math_', ['bf16', 'fp16'])
+@pytest.mark.parametrize('layers_,in_dim,stride,relu_in', [((256, 128), 257, 260, False), ((64, 32), 65, 68, True)])
+def test_masked_rows_mlp_half_hidden_tensors_keep_the_bits(layers_, in_dim, stride, relu_in, math_, monkeypatch):
+  """Training-precision engines: the hidden activation and the gradient w.r.t. it live ONLY in the
+  engine's element type (``autograd.MASKED_MLP_HALF``: epilogue half output, half-input GEMMs by
+  LDS-DMA, half-operand kernel-gradient loaders, half ReLU gate).  Every consumer of those tensors
+  rounds them to that type anyway: outputs, input gradient, both kernel gradients and the last bias
+  gradient are BIT-IDENTICAL to the f32-tensor formulation; the first layer's bias gradient sums the
+  rounded instead of the unrounded gated gradient (checked to 1e-2 of its scale)."""
+  from snap_amd import autograd as ag
+  from snap_amd.models import layers
+  from snap_amd.utils import config_dict
+  cfg = config_dict.ConfigDict(dict(layers=layers_, activation='relu', apply_input_activation=relu_in))
+  mlp = layers.MLP(cfg, in_dim=in_dim)
+  gen = torch.Generator().manual_seed(12)
+  params = helpers.params_to_device(mlp.init_params(gen, 'cpu'), 'cuda')
+  for i in range(len(layers_)):
+    params[f'Dense_{i}']['bias'] = torch.randn(layers_[i], generator=gen).cuda()
+  M = 50001
+  x = torch.randn(M, stride, generator=gen).cuda()
+  x[:, in_dim:] = 0
+  mask = (torch.rand(M, generator=gen) < 0.6).cuda()
+  dy = torch.randn(M, layers_[-1], generator=gen).cuda()
+  monkeypatch.setattr(layers.MLP, 'COMPACT_MIN_ROWS', 0)
+  monkeypatch.setattr(ops, 'MATMUL_PRECISION', math_)
+
+  def run(half):
+    monkeypatch.setattr(ag, 'MASKED_MLP_HALF', half)
+    leaves = [x.clone().requires_grad_(True)]
+    p = {}
+    for i in range(len(layers_)):
+      k = params[f'Dense_{i}']['kernel'].clone().requires_grad_(True)
+      b = params[f'Dense_{i}']['bias'].clone().requires_grad_(True)
+      p[f'Dense_{i}'] = {'kernel': k, 'bias': b}
+      leaves += [k, b]
+    y = mlp(p, leaves[0], train=True, row_mask=mask)
+    y.backward(dy)
+    return y.detach(), [t.grad for t in leaves]
+
+  y_f, g_f = run(False)
+  y_h, g_h = run(True)
+  assert torch.equal(y_f, y_h)
+  for nm, a, b in zip(('dx', 'dW0', 'db0', 'dW1', 'db1'), g_h, g_f):
+    if nm == 'db0':
+      assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()), nm
+    else:
+      assert torch.equal(a, b), (nm, float((a - b).abs().max()))
+  assert float(g_h[0].abs().max()) > 0 and bool((g_h[0][~mask] == 0).all())
+
+
 @pytest.mark.parametrize('mode', ['softmax', 'weighted'])
 def test_vertical_pool_conf_bwd(mode):
   from snap_amd import autograd as ag
