@@ -365,7 +365,7 @@ extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* 
   if (math != SNAP_MATH_F32 && math != SNAP_MATH_BF16 && math != SNAP_MATH_F16) return SNAP_ERR_UNSUPPORTED;
   if ((x_is_half || dy_is_half) &&
       (math == SNAP_MATH_F32 || (x_is_half && dy_is_half) || (x_is_half && desc && desc->prologue != SNAP_PRO_NONE) ||
-       (desc && (desc->Cin % 4 != 0 || desc->Cin_stride % 4 != 0))))
+       (x_is_half && desc && (desc->Cin % 4 != 0 || desc->Cin_stride % 4 != 0))))
     return SNAP_ERR_UNSUPPORTED;
   if (!desc || !x || !dy || !dw || !workspace) return SNAP_ERR_NULL;
   if ((rows_z || rows_dy) && !(desc->KH == 1 && desc->KW == 1 && desc->stride == 1 &&

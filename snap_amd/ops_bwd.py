@@ -96,12 +96,13 @@ USE_HALF_TWINS = True
 
 def half_twin(t, math):
   """The twin of gradient tensor ``t`` in the element type of ``math`` ('bf16' | 'fp16'), or None."""
-  hit = _HALF_TWINS.get(t.data_ptr())
-  if hit is None:
+  ref = _HALF_TWINS.get(t.data_ptr())
+  owner = None if ref is None else ref()
+  held = None if owner is None else getattr(owner, '_snap_half_twin', None)
+  if held is None:
     return None
-  ref, twin, ver = hit
-  owner = ref()
-  if (owner is None or owner.data_ptr() != t.data_ptr() or owner.shape != t.shape or owner._version != ver
+  twin, ver = held
+  if (owner.data_ptr() != t.data_ptr() or owner.shape != t.shape or owner._version != ver
       or twin.dtype != HALF_DTYPE.get(math) or not t.is_contiguous()):
     return None
   return twin
@@ -129,10 +130,14 @@ def group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, *, groups=32, add=None, h
     )
   _lib.check(st, 'snap_group_norm_bwd_ex_f32')
   if twin is not None:
+    # the twin lives exactly as long as its f32 tensor (an attribute of it; the table only holds weak
+    # references): keeping it in the table would hold a whole step's twins -- gigabytes -- alive into
+    # the next step and push the caching allocator into fresh hipMallocs in the middle of a run
     if len(_HALF_TWINS) > 256:
-      for k in [k for k, v in _HALF_TWINS.items() if v[0]() is None]:
+      for k in [k for k, v in _HALF_TWINS.items() if v() is None]:
         del _HALF_TWINS[k]
-    _HALF_TWINS[dx.data_ptr()] = (weakref.ref(dx), twin, dx._version)
+    dx._snap_half_twin = (twin, dx._version)
+    _HALF_TWINS[dx.data_ptr()] = weakref.ref(dx)
   return dx, dgamma, dbeta
 
 
