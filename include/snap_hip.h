@@ -865,6 +865,15 @@ int snap_epilogue_bwd_colsum_half(const void* dy, const void* y, void* out, int6
                                   int32_t relu, const int32_t* row_count, float* colsum,
                                   void* workspace, size_t workspace_bytes, int32_t half_kind,
                                   void* stream);
+/* ... plus wsum[C] = sum_r w(r) * out[r, :], w(r) = round_to_element_type(relu?(wsrc[wrows[r] * wstride]))
+ * (wrows may be NULL: r itself): the kernel-gradient row of ONE extra input channel of the layer in
+ * front -- the 257th channel of the fusion MLP (streetview_encoder.py:277-283) -- taken in the gate
+ * pass.  workspace: 2 x snap_colsum_workspace_bytes(M, C). */
+int snap_epilogue_bwd_colsum_wsum_half(const void* dy, const void* y, void* out, int64_t M, int32_t C,
+                                       int32_t relu, const int32_t* row_count, float* colsum,
+                                       void* workspace, size_t workspace_bytes, int32_t half_kind,
+                                       const float* wsrc, const int32_t* wrows, int64_t wstride,
+                                       int32_t wrelu, float* wsum, void* stream);
 int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* ... over the listed rows only: sum_{m < *row_count} a[rows[m], :]  (rows / row_count may be NULL). */

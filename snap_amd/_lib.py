@@ -107,6 +107,8 @@ SIGNATURES = {
     'snap_gelu_f32': (c_int, [ptr, ptr, c_i64, ptr]),
     'snap_gelu_bwd_f32': (c_int, [ptr, ptr, ptr, c_i64, ptr]),
     'snap_epilogue_bwd_colsum_half': (c_int, [ptr, ptr, ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, c_int, ptr]),
+    'snap_epilogue_bwd_colsum_wsum_half': (
+        c_int, [ptr, ptr, ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, c_int, ptr, ptr, c_i64, c_int, ptr, ptr]),
     'snap_conv2d_wgrad_half_f32': (
         c_int,
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr, ptr, ptr, c_int,

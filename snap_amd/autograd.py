@@ -431,10 +431,9 @@ class _MaskedRowsMLP(torch.autograd.Function):
       inp = x2 if i == 0 else acts[i - 1]
       pro = ops.PRO_RELU if (i == 0 and ctx.relu_input) else ops.PRO_NONE
       if ctx.needs_input_grad[3 + 2 * i]:
-        grads[2 * i] = ops_bwd.conv2d_wgrad(
-            inp.reshape(1, 1, M, inp.shape[-1]), g.reshape(1, 1, M, cout), (1, 1, cin, cout),
-            prologue=pro, rows_z=index if i == 0 else None, rows_dy=rows_dy, row_count=count,
-        ).reshape(cin, cout)
+        grads[2 * i] = ops_bwd.dense_wgrad_rows(inp, g.reshape(M, cout), cin, cout, prologue=pro,
+                                                rows_z=index if i == 0 else None, rows_dy=rows_dy,
+                                                row_count=count)
       if ctx.needs_input_grad[4 + 2 * i]:
         grads[2 * i + 1] = (db_fused if db_fused is not None
                             else ops_bwd.colsum(g, rows=rows_dy, row_count=count))
@@ -472,13 +471,21 @@ def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
     grads[3] = ops_bwd.colsum(g, rows=index, row_count=count)
   # d h0 (compact, half only), then the ReLU gate + the bias gradient of layer 0 in one pass
   g1 = ops.dense(g, W1.t().contiguous(), None, cin=D1, rows_in=index, row_count=count, out_half=True)
-  g1, db0 = ops_bwd.epilogue_bwd_colsum(g1, h0, None, relu=True, row_count=count)
+  split = ops_bwd.dense_wgrad_tail(cin0, Cs) if need[3] else None
+  tail_row = None
+  if split is not None and split[1] == 1:
+    # a single channel above the 128-channel tiles (the fusion MLP's 257th input: the view score):
+    # its kernel-gradient row leaves the gate pass as a weighted column sum
+    g1, db0, tail_row = ops_bwd.epilogue_bwd_colsum(g1, h0, None, relu=True, row_count=count,
+                                                    wsum=(x2, split[0], index, ctx.relu_input))
+  else:
+    g1, db0 = ops_bwd.epilogue_bwd_colsum(g1, h0, None, relu=True, row_count=count)
   if need[4]:
     grads[1] = db0
   pro = ops.PRO_RELU if ctx.relu_input else ops.PRO_NONE
   if need[3]:      # dW0 = x^T g1  (Z: f32 through the row list; dY: half, compact)
-    grads[0] = ops_bwd.conv2d_wgrad(x2.reshape(1, 1, M, Cs), g1.reshape(1, 1, M, H), (1, 1, cin0, H),
-                                    prologue=pro, rows_z=index, row_count=count).reshape(cin0, H)
+    grads[0] = ops_bwd.dense_wgrad_rows(x2, g1, cin0, H, prologue=pro, rows_z=index, rows_dy=None,
+                                        row_count=count, tail_row=tail_row)
   dx = None
   if need[0]:
     Wt = W0.t()

@@ -479,10 +479,16 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_kernel(
 // _Float16): dy, y and out are [rows, C] of ET -- the inter-layer gradient and hidden activation of
 // the masked MLP.  The gate is exact on the rounded values (an element is kept or zeroed); the bias
 // gradient sums the kept elements in f32, in the f32 kernel's order.
-template <typename ET>
+// WSUM: also partial2[s][c] = sum_r w(r) * out[r][c] with w(r) = wsrc[wrows[r] * wstride] (ReLU'd if
+// wrelu): the kernel-gradient row of ONE extra input channel of the layer in front (the 257th channel
+// of the fusion MLP: dW0[256, :] = x[:, 256]^T g) taken in this pass instead of a third 128-channel
+// tile in the GEMM.
+template <typename ET, bool WSUM = false>
 __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
     const ET* __restrict__ dy, const ET* __restrict__ y, ET* __restrict__ out, int64_t M, int C, int relu,
-    int64_t rows_per_block, const int32_t* __restrict__ row_count, float* __restrict__ partial) {
+    int64_t rows_per_block, const int32_t* __restrict__ row_count, float* __restrict__ partial,
+    const float* __restrict__ wsrc = nullptr, const int32_t* __restrict__ wrows = nullptr, int64_t wstride = 0,
+    int wrelu = 0, float* __restrict__ partial2 = nullptr) {
   typedef ET etx4 __attribute__((ext_vector_type(4)));
   __shared__ float red[256 * 4];
   const int cbase = blockIdx.y * 1024;
@@ -495,6 +501,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(Msum, r0 + rows_per_block);
   float t[4] = {0.f, 0.f, 0.f, 0.f};
+  float u[4] = {0.f, 0.f, 0.f, 0.f};
   if (tp < PW) {
     for (int64_t r = r0 + tp; r < r1; r += PW) {
       etx4 g = *reinterpret_cast<const etx4*>(dy + r * C + c0);
@@ -506,6 +513,14 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
       *reinterpret_cast<etx4*>(out + r * C + c0) = g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] += (float)g[e];
+      if constexpr (WSUM) {
+        float w = wsrc[(int64_t)(wrows ? wrows[r] : (int32_t)r) * wstride];
+        if (wrelu) w = snap_relu(w);
+        // (the engine would multiply the ROUNDED operands: round w to ET like the GEMM's loader does)
+        w = (float)(ET)w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] += w * (float)g[e];
+      }
     }
   }
 #pragma unroll
@@ -517,6 +532,20 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
       float a = 0.f;
       for (int pp = 0; pp < PW; ++pp) a += red[(pp * QW + tq) * 4 + e];
       partial[(int64_t)blockIdx.x * C + c0 + e] = a;
+    }
+  }
+  if constexpr (WSUM) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = u[e];
+    __syncthreads();
+    if (tp == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = 0.f;
+        for (int pp = 0; pp < PW; ++pp) a += red[(pp * QW + tq) * 4 + e];
+        partial2[(int64_t)blockIdx.x * C + c0 + e] = a;
+      }
     }
   }
 }
@@ -758,31 +787,52 @@ extern "C" int snap_epilogue_bwd_colsum_half(const void* dy, const void* y, void
                                              int32_t C, int32_t relu, const int32_t* row_count,
                                              float* colsum, void* workspace, size_t workspace_bytes,
                                              int32_t half_kind, void* stream) {
+  return snap_epilogue_bwd_colsum_wsum_half(dy, y, out, M, C, relu, row_count, colsum, workspace,
+                                            workspace_bytes, half_kind, nullptr, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int snap_epilogue_bwd_colsum_wsum_half(const void* dy, const void* y, void* out, int64_t M,
+                                                  int32_t C, int32_t relu, const int32_t* row_count,
+                                                  float* colsum, void* workspace, size_t workspace_bytes,
+                                                  int32_t half_kind, const float* wsrc,
+                                                  const int32_t* wrows, int64_t wstride, int32_t wrelu,
+                                                  float* wsum, void* stream) {
+  if ((wsrc != nullptr) != (wsum != nullptr)) return SNAP_ERR_NULL;
   if (!dy || !out || !colsum || !workspace) return SNAP_ERR_NULL;
   if (relu && !y) return SNAP_ERR_NULL;
   if (half_kind != 1 && half_kind != 2) return SNAP_ERR_UNSUPPORTED;
   if (M <= 0 || C <= 0 || C % 4 != 0) return SNAP_ERR_BAD_SHAPE;
   const int q = C < 1024 ? C / 4 : 256;
   if (256 % q != 0 || (C > 1024 && C % 1024 != 0)) return SNAP_ERR_UNSUPPORTED;
-  if (workspace_bytes < snap_colsum_workspace_bytes(M, C)) return SNAP_ERR_WORKSPACE;
+  // (with the weighted sums the workspace holds two partial arrays)
+  if (workspace_bytes < snap_colsum_workspace_bytes(M, C) * (wsrc ? 2 : 1)) return SNAP_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(y)) & 7)
     return SNAP_ERR_BAD_SHAPE;
   const int S = colsum_slabs(M);
   const int64_t rpb = (M + S - 1) / S;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(S, (unsigned)snap_cdiv(C, 1024));
-  if (half_kind == 2)
-    hipLaunchKernelGGL(epilogue_bwd_colsum_half_kernel<_Float16>, grid, dim3(256), 0, s,
-                       static_cast<const _Float16*>(dy), static_cast<const _Float16*>(y),
-                       static_cast<_Float16*>(out), M, C, relu, rpb, row_count, static_cast<float*>(workspace));
-  else
-    hipLaunchKernelGGL(epilogue_bwd_colsum_half_kernel<__bf16>, grid, dim3(256), 0, s,
-                       static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y),
-                       static_cast<__bf16*>(out), M, C, relu, rpb, row_count, static_cast<float*>(workspace));
+  float* p1 = static_cast<float*>(workspace);
+  float* p2 = p1 + (size_t)S * C;
+#define SNAP_GATE_LAUNCH(ET_, W_)                                                                       \
+  hipLaunchKernelGGL((epilogue_bwd_colsum_half_kernel<ET_, W_>), grid, dim3(256), 0, s,                  \
+                     static_cast<const ET_*>(dy), static_cast<const ET_*>(y), static_cast<ET_*>(out), M, C, \
+                     relu, rpb, row_count, p1, wsrc, wrows, wstride, wrelu, p2)
+  if (half_kind == 2) {
+    if (wsrc) SNAP_GATE_LAUNCH(_Float16, true); else SNAP_GATE_LAUNCH(_Float16, false);
+  } else {
+    if (wsrc) SNAP_GATE_LAUNCH(__bf16, true); else SNAP_GATE_LAUNCH(__bf16, false);
+  }
+#undef SNAP_GATE_LAUNCH
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 32)), dim3(256), 0, s,
-                     (const float*)workspace, S, C, colsum, 0);
+                     (const float*)p1, S, C, colsum, 0);
   SNAP_CHECK_LAUNCH();
+  if (wsrc) {
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 32)), dim3(256), 0, s,
+                       (const float*)p2, S, C, wsum, 0);
+    SNAP_CHECK_LAUNCH();
+  }
   return SNAP_OK;
 }
 

@@ -34,11 +34,13 @@ def _conv_desc(x_shape, w_shape, stride, padding, prologue, in_affine, cs=None):
 
 def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue=ops.PRO_NONE,
                  gn=None, in_affine=(1.0, 0.0), rows_z=None, rows_dy=None, row_count=None,
-                 math=None):
+                 math=None, x_channel_offset=0):
   """dw [KH,KW,Cin,Cout] = im2col(prologue(x))^T dy  (MFMA; deterministic split-M).
 
   rows_z / rows_dy / row_count: row lists over flat [1,1,M,C] operands (masked MLP).
-  math: 'f32' | 'bf16' | 'fp16' (None = ``ops.MATMUL_PRECISION``), as ``ops.conv2d``."""
+  math: 'f32' | 'bf16' | 'fp16' (None = ``ops.MATMUL_PRECISION``), as ``ops.conv2d``.
+  x_channel_offset (multiple of 4, f32 x): the kernel's Cin input channels start at that channel of
+  x's rows (x keeps its row stride): the gradient of a channel slice without copying it."""
   math = ops.MATMUL_PRECISION if math is None else math
   if math in ops.SPLIT_PARTS:
     math = 'f32'         # the split engine has no weight-gradient kernel: exact f32 (trainer 'bf16x3')
@@ -60,6 +62,9 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   d, yshape = _conv_desc(x.shape, w_shape, stride, padding, prologue, in_affine)
   if tuple(dy.shape) != yshape:
     raise ValueError(f'conv2d_wgrad: dy {tuple(dy.shape)} vs {yshape}')
+  if x_channel_offset:
+    if x_half or x_channel_offset % 4 or x_channel_offset + min(w_shape[2], 4) > x.shape[-1] or gn is not None:
+      raise ValueError('conv2d_wgrad: x_channel_offset needs an f32 x, a multiple of 4 inside the row, no GroupNorm')
   for t, nm in ((rows_z, 'rows_z'), (rows_dy, 'rows_dy'), (row_count, 'row_count')):
     if t is not None:
       ops._chk(t, torch.int32, nm)
@@ -78,7 +83,8 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   with _region(('conv_wgrad_fp16' if code == 2 else 'conv_wgrad_bf16') if bf16 else 'conv_wgrad', flops,
                4.0 * (x.numel() + dy.numel())):
     st = lib.snap_conv2d_wgrad_half_f32(
-        ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(mu), _p(sc), _p(beta), 0, _p(ws),
+        ctypes.byref(d), ctypes.c_void_p(x.data_ptr() + 4 * int(x_channel_offset)), _p(dy), _p(dw), _p(mu), _p(sc),
+        _p(beta), 0, _p(ws),
         ws.numel() * 4, _p(rows_z), _p(rows_dy), _p(row_count), code, int(x_half), int(dy_half), _stream(),
     )
   _lib.check(st, 'snap_conv2d_wgrad_half_f32')
@@ -106,6 +112,37 @@ def half_twin(t, math):
       or twin.dtype != HALF_DTYPE.get(math) or not t.is_contiguous()):
     return None
   return twin
+
+
+def dense_wgrad_tail(cin, Cs):
+  """(main, tail) channel split of ``dense_wgrad_rows`` for a [*, Cs] input with cin live channels,
+  or None where the single launch stays."""
+  tail = cin % 128
+  if cin > 128 and 0 < tail <= 4 and Cs % 4 == 0 and Cs >= cin - tail + 4:
+    return cin - tail, tail
+  return None
+
+
+def dense_wgrad_rows(x2, g, cin, H, *, prologue, rows_z, rows_dy, row_count, tail_row=None):
+  """dW [cin, H] = prologue(x2[rows, :cin])^T g over a row list (the masked MLP's first layer).  A
+  channel count just above a multiple of the engine's 128-channel tile (the fusion MLP: 257 = mean +
+  variance + the view score) would spend a whole extra tile on its last 1-4 channels -- a third of the
+  launch at 257; the tail quad goes through a narrow launch of its own instead (same sums per
+  element, the row stride of x2 carries the zero padding of the quad)."""
+  M, Cs = x2.shape
+  split = dense_wgrad_tail(cin, Cs)
+  if split is not None:
+    main, tail = split
+    dw_main = conv2d_wgrad(x2.reshape(1, 1, M, Cs), g.reshape(1, 1, M, H), (1, 1, main, H), prologue=prologue,
+                           rows_z=rows_z, rows_dy=rows_dy, row_count=row_count).reshape(main, H)
+    if tail_row is not None and tail == 1:      # (the caller took the one tail channel in its gate pass)
+      return torch.cat([dw_main, tail_row.reshape(1, H)], 0)
+    dw_tail = conv2d_wgrad(x2.reshape(1, 1, M, Cs), g.reshape(1, 1, M, H), (1, 1, 4, H), prologue=prologue,
+                           rows_z=rows_z, rows_dy=rows_dy, row_count=row_count,
+                           x_channel_offset=main).reshape(4, H)
+    return torch.cat([dw_main, dw_tail[:tail]], 0)
+  return conv2d_wgrad(x2.reshape(1, 1, M, Cs), g.reshape(1, 1, M, H), (1, 1, cin, H), prologue=prologue,
+                      rows_z=rows_z, rows_dy=rows_dy, row_count=row_count).reshape(cin, H)
 
 
 def group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, *, groups=32, add=None, half=None):
@@ -183,11 +220,16 @@ def epilogue_bwd(dy, y=None, row_mask=None, relu=False):
   return out
 
 
-def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None):
+def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None, wsum=None):
   """``epilogue_bwd`` and the column sums of its output (over the first *row_count rows) in one
   pass -> (gated dy, [C] sums); falls back to the two passes for widths the kernel does not take.
-  dy / y in bf16 / f16 (both): the half kernel, gated dy in the same type."""
+  dy / y in bf16 / f16 (both): the half kernel, gated dy in the same type.  wsum (half kernel only) =
+  (x2 [rows, Cs] f32, channel, row list or None, relu): a third result, sum_r x2[rows[r], channel] *
+  out[r, :] with the weight rounded to the element type -- one extra input channel's kernel-gradient
+  row of the layer in front, in the same pass."""
   lib = _lib.load()
+  if wsum is not None and dy.dtype not in (torch.bfloat16, torch.float16):
+    raise ValueError('epilogue_bwd_colsum: wsum goes with half tensors')
   if dy.dtype in (torch.bfloat16, torch.float16):
     C = dy.shape[-1]
     M = dy.numel() // C
@@ -198,13 +240,26 @@ def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None):
     if y is not None:
       ops._chk(y, y.dtype, 'y')
     out = torch.empty_like(dy)
-    wsb = lib.snap_colsum_workspace_bytes(M, C)
+    wsb = lib.snap_colsum_workspace_bytes(M, C) * (2 if wsum is not None else 1)
     ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=dy.device)
     sums = torch.empty(C, dtype=torch.float32, device=dy.device)
-    st = lib.snap_epilogue_bwd_colsum_half(_p(dy), _p(y), _p(out), M, C, int(relu), _p(row_count), _p(sums),
-                                           _p(ws), ws.numel() * 4, 2 if dy.dtype == torch.float16 else 1, _stream())
-    _lib.check(st, 'snap_epilogue_bwd_colsum_half')
-    return out, sums
+    kind = 2 if dy.dtype == torch.float16 else 1
+    if wsum is None:
+      st = lib.snap_epilogue_bwd_colsum_half(_p(dy), _p(y), _p(out), M, C, int(relu), _p(row_count), _p(sums),
+                                             _p(ws), ws.numel() * 4, kind, _stream())
+      _lib.check(st, 'snap_epilogue_bwd_colsum_half')
+      return out, sums
+    x2, channel, wrows, wrelu = wsum
+    _f32(x2, 'wsum source')
+    if wrows is not None:
+      ops._chk(wrows, torch.int32, 'wsum rows')
+    wout = torch.empty(C, dtype=torch.float32, device=dy.device)
+    st = lib.snap_epilogue_bwd_colsum_wsum_half(
+        _p(dy), _p(y), _p(out), M, C, int(relu), _p(row_count), _p(sums), _p(ws), ws.numel() * 4, kind,
+        ctypes.c_void_p(x2.data_ptr() + 4 * int(channel)), _p(wrows), int(x2.shape[-1]), int(bool(wrelu)),
+        _p(wout), _stream())
+    _lib.check(st, 'snap_epilogue_bwd_colsum_wsum_half')
+    return out, sums, wout
   _f32(dy, 'dy')
   C = dy.shape[-1]
   M = dy.numel() // C
