@@ -507,6 +507,9 @@ typedef struct SnapLiftDesc {
    * (snap_mlp2_pool_max_classes_f32): 47 % fewer bytes written and re-read for such a row, same
    * plane bits (products with +0 leave an accumulator unchanged). */
   int32_t class_rows;
+  /* A/B switches for tests and tools (0 = defaults).  Bit 0: snap_lift_pool_bwd_det_f32 takes the
+   * half-wave-per-voxel record producer also where the batched one applies. */
+  int32_t tune_flags;
 } SnapLiftDesc;
 
 /* cam: [B,V,11] = wh(2) f(2) c(2) k_radial(3) max_fov(1) tan(max_fov/2)(1) ALREADY scaled to

@@ -52,7 +52,7 @@ class SnapLiftDesc(ctypes.Structure):
       ('max_view_distance', c_float),
       ('weighted', c_int), ('use_variance', c_int), ('add_minmax', c_int),
       ('grid_y', c_int), ('grid_z', c_int), ('valid_rows_only', c_int), ('out_split', c_int),
-      ('class_rows', c_int),
+      ('class_rows', c_int), ('tune_flags', c_int),
   ]
 
 

@@ -422,6 +422,256 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_kernel(const LiftBwdArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------
+// Batched record producer for the default fusion options (weighted, variance, no min / max; <= 4
+// selected views): the structure of the forward's lift_pool_batched_kernel (lift.hip).
+//   phase A  lane = voxel: projection into the views, selection, tap geometry and depth bins run
+//            once per voxel on a full lane set (in the half-wave-per-voxel kernel above 4 of 32
+//            lanes do that work while 28 wait); records go to LDS.
+//   phase B  lane = channel quad: the workgroup's 256 voxels, ordered by their number of
+//            observations so that the two half-waves of a wave walk voxels of one class, are taken
+//            one per half-wave: float4 taps (one 512-byte row per tap), pooling weights, the VJP of
+//            mean / variance / score_max, one float4 of the record vector per lane.
+// Same record format, same keys and counts as lift_pool_bwd_kernel<KMAX, 1>: the sort and the
+// gather pass do not change.  Deterministic like it (integer counts, fixed-order sums); the
+// half-wave reduction of d w_k sums the channels in another order than the strided kernel, so
+// the two producers agree to rounding, not bit for bit.
+template <int KMAX>
+__global__ __launch_bounds__(256) void lift_pool_bwd_batched_kernel(const LiftBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) int recs[256][KMAX][4];   // pixel key | packed | wi1 | wj1
+  __shared__ float wbs[256][KMAX];
+  __shared__ int ijs[256][KMAX];                                    // i0 | j0 << 16
+  __shared__ __attribute__((aligned(16))) float vhdr[256][4];       // (-, -, voxel or -1, observations)
+  __shared__ int cls_cnt[4][KMAX + 2];
+  __shared__ uint8_t order[256];
+  const SnapLiftDesc& d = a.d;
+  const int hl = threadIdx.x & 31;
+  const int hw = threadIdx.x >> 5;
+  const int fd = d.feature_dim;
+  const int nq = fd >> 2;
+  const bool all_views = d.K == 0;
+  const int nsel = all_views ? d.V : d.K;
+  const int64_t total = (int64_t)d.B * d.N;
+  const float log_range = logf(d.depth_max / d.depth_min);
+
+  // ---------------- phase A: lane = voxel ----------------
+  {
+    const int64_t gv = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = gv < total;
+    const int b = live ? (int)(gv / d.N) : 0;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (live) {
+      const float* p = a.pts + gv * 3;
+      px = p[0]; py = p[1]; pz = p[2];
+    }
+    float kd[KMAX], kpi[KMAX], kpj[KMAX], kdep[KMAX];
+    int kv[KMAX];
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) { kd[r] = INFINITY; kpi[r] = kpj[r] = kdep[r] = 0.f; kv[r] = -1; }
+    for (int v = 0; v < d.V; ++v) {
+      const ProjB pr = project_b(a.cam + ((int64_t)b * d.V + v) * 11, a.Rt + ((int64_t)b * d.V + v) * 12, px, py,
+                                 pz, d.fisheye);
+      const bool vis = live && pr.vis;
+      if (all_views) {
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r)
+          if (r == v) { kv[r] = vis ? v : -1; kpi[r] = pr.pi; kpj[r] = pr.pj; kdep[r] = pr.depth; }
+      } else if (vis) {
+        // stable insertion (strict <): equal distances keep the lower view index first
+        float cd = pr.dist, cpi = pr.pi, cpj = pr.pj, cdep = pr.depth;
+        int cv = v;
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) {
+          if (r < nsel && cd < kd[r]) {
+            const float td = kd[r], tpi = kpi[r], tpj = kpj[r], tdep = kdep[r];
+            const int tv = kv[r];
+            kd[r] = cd; kpi[r] = cpi; kpj[r] = cpj; kdep[r] = cdep; kv[r] = cv;
+            cd = td; cpi = tpi; cpj = tpj; cdep = tdep; cv = tv;
+          }
+        }
+      }
+    }
+    int nvis = 0;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      if (r >= nsel || kv[r] < 0) continue;
+      const TapsB t = taps_b(kpi[r], kpj[r], d.h, d.w, all_views ? 0 : 1);
+      // the 1-D weights the products of taps_b are built from (phase B rebuilds the same products)
+      float ci = kpi[r] - 0.5f, cj = kpj[r] - 0.5f;
+      if (!all_views) {
+        ci = fmaxf(fminf(ci, (float)(d.h - 1)), 0.f);
+        cj = fmaxf(fminf(cj, (float)(d.w - 1)), 0.f);
+      }
+      const float wi1 = ci - floorf(ci), wj1 = cj - floorf(cj);
+      const float dc = fminf(fmaxf(kdep[r], d.depth_min), d.depth_max);
+      const float tt = logf(dc / d.depth_min) / log_range;
+      const float index = 0.5f + tt * (float)(d.num_bins - 1);
+      const float c = index - 0.5f;
+      const float fl = floorf(c);
+      const int b0 = (int)fminf(fmaxf(fl, 0.f), (float)(d.num_bins - 1));
+      const int b1 = (int)fminf(fmaxf(fl + 1.f, 0.f), (float)(d.num_bins - 1));
+      int* rec = recs[threadIdx.x][nvis];
+      rec[0] = (int)(unsigned)((((int64_t)b * d.V + kv[r]) * d.h + t.i0) * d.w + t.j0);
+      rec[1] = kv[r] | ((t.i1 != t.i0) << 8) | ((t.j1 != t.j0) << 9) | (b0 << 10) | (b1 << 18);
+      rec[2] = __float_as_int(wi1);
+      rec[3] = __float_as_int(wj1);
+      wbs[threadIdx.x][nvis] = c - fl;
+      ijs[threadIdx.x][nvis] = t.i0 | (t.j0 << 16);
+      ++nvis;
+    }
+    if (live) {                    // slots without an observation: key = npix sorts last
+      for (int r = nvis; r < nsel; ++r) a.keys[gv * nsel + r] = a.npix;
+    }
+    vhdr[threadIdx.x][2] = __int_as_float(live ? (int)gv : -1);      // (B * N < 2^31: checked by the launcher)
+    vhdr[threadIdx.x][3] = __int_as_float(nvis);
+    const int key = live ? nvis : KMAX + 1;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < KMAX + 2; ++c) {
+      const unsigned long long m = __ballot(key == c);
+      if (key == c) rank = __popcll(m & ((1ull << ln) - 1ull));
+      if (ln == 0) cls_cnt[wv][c] = __popcll(m);
+    }
+    __syncthreads();
+    int pos = rank;
+#pragma unroll
+    for (int c = 0; c < KMAX + 2; ++c)
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (c < key || (c == key && w < wv)) pos += cls_cnt[w][c];
+    order[pos] = (uint8_t)threadIdx.x;
+  }
+  __syncthreads();
+
+  // ---------------- phase B: lane = channel quad ----------------
+  const char* fb = reinterpret_cast<const char*>(a.f);
+  const uint32_t Cb = (uint32_t)d.C * 4u, Wb = (uint32_t)d.w * Cb, fdb = (uint32_t)fd * 4u;
+  const uint32_t lane_off = 16u * hl;
+  const bool lane_on = hl < nq;
+  for (int j = 0; j < 32; ++j) {
+    const int v = order[8 * j + hw];                    // (half-wave uniform)
+    const int gvi = __float_as_int(vhdr[v][2]);
+    const int nvis = __float_as_int(vhdr[v][3]);
+    if (gvi < 0 || nvis == 0) continue;                 // pooled == 0 (masked): no gradient, no record
+    const int64_t gv = gvi;
+    f32x4 feat[KMAX];
+    float score[KMAX], w4[KMAX][4];
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      if (r >= nvis) continue;
+      const i32x4 q4 = *reinterpret_cast<const i32x4*>(recs[v][r]);
+      const int pk = q4[1];
+      const float wi1 = __int_as_float(q4[2]), wj1 = __int_as_float(q4[3]);
+      const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
+      const float w00 = wi0 * wj0, w01 = wi0 * wj1, w10 = wi1 * wj0, w11 = wi1 * wj1;
+      w4[r][0] = w00; w4[r][1] = w01; w4[r][2] = w10; w4[r][3] = w11;
+      const uint32_t o00 = (uint32_t)q4[0] * Cb;
+      const uint32_t o01 = o00 + ((pk >> 9) & 1 ? Cb : 0u);
+      const uint32_t o10 = o00 + ((pk >> 8) & 1 ? Wb : 0u);
+      const uint32_t o11 = o10 + (o01 - o00);
+      const uint32_t c0 = fdb + ((pk >> 10) & 0xff) * 4u, c1 = fdb + ((pk >> 18) & 0xff) * 4u;
+      const float t00 = *reinterpret_cast<const float*>(fb + (o00 + c0));
+      const float t01 = *reinterpret_cast<const float*>(fb + (o01 + c0));
+      const float t10 = *reinterpret_cast<const float*>(fb + (o10 + c0));
+      const float t11 = *reinterpret_cast<const float*>(fb + (o11 + c0));
+      const float u00 = *reinterpret_cast<const float*>(fb + (o00 + c1));
+      const float u01 = *reinterpret_cast<const float*>(fb + (o01 + c1));
+      const float u10 = *reinterpret_cast<const float*>(fb + (o10 + c1));
+      const float u11 = *reinterpret_cast<const float*>(fb + (o11 + c1));
+      feat[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (lane_on) {
+        const f32x4 a00 = *reinterpret_cast<const f32x4*>(fb + (o00 + lane_off));
+        const f32x4 a01 = *reinterpret_cast<const f32x4*>(fb + (o01 + lane_off));
+        const f32x4 a10 = *reinterpret_cast<const f32x4*>(fb + (o10 + lane_off));
+        const f32x4 a11 = *reinterpret_cast<const f32x4*>(fb + (o11 + lane_off));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) feat[r][e] = ((w00 * a00[e] + w01 * a01[e]) + w10 * a10[e]) + w11 * a11[e];
+      }
+      const float wb1 = wbs[v][r];
+      const float s0 = ((w00 * t00 + w01 * t01) + w10 * t10) + w11 * t11;
+      const float s1 = ((w00 * u00 + w01 * u01) + w10 * u10) + w11 * u11;
+      score[r] = (1.f - wb1) * s0 + wb1 * s1;
+    }
+    // pooling weights: softmax(where = visible, initial = 0) of the depth scores
+    float m = 0.f, smax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r)
+      if (r < nvis) { m = fmaxf(m, score[r]); smax = fmaxf(smax, score[r]); }
+    float wgt[KMAX], den = 0.f;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      wgt[r] = r < nvis ? expf(score[r] - m) : 0.f;
+      den += wgt[r];
+    }
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      wgt[r] = wgt[r] / den;
+      if (r < nvis) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mean[e] += wgt[r] * feat[r][e];
+      }
+    }
+    // upstream gradients: mean | var | score_max
+    const float* g = a.dpooled + gv * d.out_stride;
+    f32x4 dmean = {0.f, 0.f, 0.f, 0.f}, dvar = {0.f, 0.f, 0.f, 0.f};
+    if (lane_on) {
+      dmean = *reinterpret_cast<const f32x4*>(g + 4 * hl);
+      dvar = *reinterpret_cast<const f32x4*>(g + fd + 4 * hl);
+    }
+    const float dsmax = g[2 * fd];
+    int nmax = 0;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) nmax += (r < nvis && score[r] == smax) ? 1 : 0;
+    // d w_k = sum_c f_kc dmean_c + (f_kc - mean_c)^2 dvar_c   (half-wave reduction)
+    float dw[KMAX], dwbar = 0.f;
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      float t = 0.f;
+      if (r < nvis) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dl = feat[r][e] - mean[e];
+          t += feat[r][e] * dmean[e] + (dl * dl) * dvar[e];
+        }
+      }
+      dw[r] = r < nvis ? half_sum(t) : 0.f;            // (half-wave uniform condition)
+      dwbar += wgt[r] * dw[r];
+    }
+    const int b = (int)(gv / d.N);
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+      if (r >= nvis) continue;
+      const float ds = wgt[r] * (dw[r] - dwbar) + ((score[r] == smax) ? dsmax / (float)nmax : 0.f);
+      const int64_t rid = gv * nsel + r;
+      if (lane_on) {
+        f32x4 dfe;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dfe[e] = wgt[r] * dmean[e] + 2.f * wgt[r] * (feat[r][e] - mean[e]) * dvar[e];
+        *reinterpret_cast<f32x4*>(a.rec_vec + rid * fd + 4 * hl) = dfe;
+      }
+      if (hl == 0) {
+        const int pk = recs[v][r][1];
+        const int ij = ijs[v][r];
+        const int i0 = ij & 0xffff, j0 = ij >> 16;
+        const int i1 = i0 + ((pk >> 8) & 1), j1 = j0 + ((pk >> 9) & 1);
+        const float wb1 = wbs[v][r];
+        float* h = a.rec_hdr + rid * 12;
+        reinterpret_cast<f32x4*>(h)[0] = f32x4{w4[r][0], w4[r][1], w4[r][2], w4[r][3]};
+        reinterpret_cast<f32x4*>(h)[1] =
+            f32x4{(1.f - wb1) * ds, wb1 * ds, __int_as_float(((pk >> 10) & 0xff) | (((pk >> 18) & 0xff) << 16)),
+                  __int_as_float(i0 | (i1 << 16))};
+        h[8] = __int_as_float(j0 | (j1 << 16));
+        const unsigned key = (unsigned)recs[v][r][0];
+        a.keys[rid] = key;
+        atomicAdd(a.count + key, 1u);            // (integer: order-independent)
+      }
+    }
+    (void)b;
+  }
+}
+
 // One half-wave per image pixel: the records whose first tap is one of the four pixels
 // (i - 1 .. i) x (j - 1 .. j) are the only ones that can touch (i, j) (the second tap index is the
 // first or the first + 1); their sorted lists are walked in a fixed order and every tap that
@@ -800,7 +1050,14 @@ extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float*
   if (hipMemsetAsync(a.count, 0, (L.npix + 2) * sizeof(unsigned), s) != hipSuccess) return SNAP_ERR_LAUNCH;
   // 1. records (+ their sort keys, + the per-pixel record counts)
   const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
-  if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, 1>), grid, dim3(256), 0, s, a);
+  // default fusion options, <= 4 views, f_images addressable with 32-bit byte offsets: the batched
+  // producer (lane = voxel for the geometry, lane = channel quad for the gradients)
+  const bool batched = d.weighted && d.use_variance && !d.add_minmax && nsel <= 4 && d.h < 65536 && d.w < 65536 &&
+                       (int64_t)d.B * d.V * d.h * d.w * d.C * 4 < 0xfff00000LL && !(d.tune_flags & 1);
+  const dim3 gridb((unsigned)snap_cdiv((int64_t)d.B * d.N, 256));
+  if (batched && nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_batched_kernel<1>), gridb, dim3(256), 0, s, a);
+  else if (batched) hipLaunchKernelGGL((lift_pool_bwd_batched_kernel<4>), gridb, dim3(256), 0, s, a);
+  else if (nsel <= 1) hipLaunchKernelGGL((lift_pool_bwd_kernel<1, 1>), grid, dim3(256), 0, s, a);
   else if (nsel <= 4) hipLaunchKernelGGL((lift_pool_bwd_kernel<4, 1>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((lift_pool_bwd_kernel<8, 1>), grid, dim3(256), 0, s, a);
   SNAP_CHECK_LAUNCH();

@@ -18,6 +18,8 @@ DETERMINISTIC_LIFT_BWD = True
 # The pose-scoring VJP accumulates its score planes in 64-bit fixed point (exactly associative);
 # False = float LDS atomics (order-dependent sums).
 DETERMINISTIC_POSE_BWD = True
+# tests / tools: the half-wave-per-voxel record producer of the deterministic lift VJP (A/B)
+LIFT_BWD_UNBATCHED = False
 
 
 def _conv_desc(x_shape, w_shape, stride, padding, prologue, in_affine, cs=None):
@@ -313,6 +315,7 @@ def lift_pool_bwd(f_images, cam, Rt, points, dpooled, *, K, fisheye, feature_dim
       -1.0 if max_view_distance is None else float(max_view_distance),
       int(weighted), int(use_variance), int(add_minmax),
   )
+  d.tune_flags = int(bool(LIFT_BWD_UNBATCHED))
   df = torch.empty_like(f_images)
   wsb = (lib.snap_lift_pool_bwd_det_workspace_bytes(ctypes.byref(d))
          if (DETERMINISTIC_LIFT_BWD or not default) else 0)

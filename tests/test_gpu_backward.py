@@ -420,6 +420,42 @@ def test_lift_pool_bwd(K, V, opts):
     finally:
       ops_bwd.DETERMINISTIC_LIFT_BWD = prev
     helpers.report('lift bwd (scatter)', got_s, ref, atol=tol)
+    # the default options take the BATCHED record producer (lane = voxel for the geometry, lane =
+    # channel quad for the gradients); the half-wave-per-voxel producer it replaces must agree with
+    # it to rounding (same records, another summation order inside d w_k)
+    prev, ops_bwd.LIFT_BWD_UNBATCHED = ops_bwd.LIFT_BWD_UNBATCHED, True
+    try:
+      got_u = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
+    finally:
+      ops_bwd.LIFT_BWD_UNBATCHED = prev
+    helpers.report('lift bwd (half-wave-per-voxel producer)', got_u, ref, atol=tol)
+    assert float((got_u - got).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize('K,V,fd,nb', [(0, 4, 128, 32), (1, 3, 128, 32), (3, 5, 32, 8)])
+def test_lift_pool_bwd_batched_producer_real_widths(K, V, fd, nb):
+  """The batched record producer at the model's widths (feature_dim 128 + 32 depth bins: every lane
+  owns a channel quad; feature_dim 32: lanes 8.. idle), all views / one / three of five selected,
+  25 000 voxels (ragged last workgroup): vs the half-wave-per-voxel producer and bitwise
+  repeatable."""
+  import test_gpu_kernels as tk
+  N = 25000 + 37
+  f, cam, Rt, pts = tk._lift_scene(2, V, 16, 20, fd, nb, N, seed=70 + V)
+  kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0))
+  stride = ops.pooled_stride(fd, True, True, False)
+  nch = ops.pooled_channels(fd, True, True, False)
+  dpooled = rnd((2, N, stride), 71)
+  dpooled[..., nch:] = 0
+  got = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
+  assert torch.equal(ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw), got)
+  prev, ops_bwd.LIFT_BWD_UNBATCHED = ops_bwd.LIFT_BWD_UNBATCHED, True
+  try:
+    ref = ops_bwd.lift_pool_bwd(G(f), G(cam), G(Rt), G(pts), G(dpooled), **kw)
+  finally:
+    ops_bwd.LIFT_BWD_UNBATCHED = prev
+  scale = float(ref.abs().max())
+  assert scale > 0
+  assert float((got - ref).abs().max()) <= 2e-5 * scale, float((got - ref).abs().max()) / scale
 
 
 @pytest.mark.parametrize('use_var,minmax', [(True, False), (False, True)])
