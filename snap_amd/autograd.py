@@ -799,7 +799,7 @@ class _SimSoftmaxWeighted(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, fq, fm, temperature, weights, num_valid, clip, want_prob):
-    scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+    scale = 1.0 if temperature is None else ops.host_exp(temperature)
     sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob,
                                           row_weight=weights)
     ctx.scale, ctx.clip = scale, clip
@@ -823,7 +823,7 @@ def sim_softmax_weighted(fq, fm, temperature, weights, clip_negative, num_valid,
   """Returns (sim, chunk_stats, prob or None, scale) with per-point weights (differentiable)."""
   sim, stats, prob = _SimSoftmaxWeighted.apply(fq, fm, temperature, weights.contiguous(), num_valid,
                                                clip_negative, want_prob)
-  scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+  scale = 1.0 if temperature is None else ops.host_exp(temperature)
   return sim, stats, (prob if want_prob else None), scale
 
 
@@ -831,7 +831,7 @@ class _SimSoftmax(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, fq, fm, temperature, num_valid, clip, want_prob):
-    scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+    scale = 1.0 if temperature is None else ops.host_exp(temperature)
     sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob)
     ctx.scale, ctx.clip = scale, clip
     ctx.save_for_backward(fq, fm, sim, num_valid)
@@ -853,7 +853,7 @@ class _SimSoftmax(torch.autograd.Function):
 def sim_softmax(fq, fm, temperature, clip_negative, num_valid, want_prob=False):
   """Returns (sim, chunk_stats, prob or None, scale)."""
   sim, stats, prob = _SimSoftmax.apply(fq, fm, temperature, num_valid, clip_negative, want_prob)
-  scale = 1.0 if temperature is None else float(torch.exp(temperature.detach().to(torch.float32)))
+  scale = 1.0 if temperature is None else ops.host_exp(temperature)
   return sim, stats, (prob if want_prob else None), scale
 
 

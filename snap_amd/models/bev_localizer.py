@@ -123,24 +123,10 @@ class BEVLocalizer(base.Module):
     )
 
   def _prefetch_scale(self, params):
-    """Queue the D2H read of exp(temperature) at the START of an apply (same value, same bits as a
-    blocking ``float(torch.exp(t))``: the exponential is computed by the same torch kernel)."""
-    self._scale_pending = None
-    t = params.get('temperature') if self.config.add_temperature else None
-    if t is None or not t.is_cuda or base.needs_grad(t):
-      return
-    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-    host.copy_(torch.exp(t.detach().to(torch.float32)).reshape(1), non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    self._scale_pending = (t, host, ev)
-
-  def _host_scale(self, temperature):
-    pend, self._scale_pending = getattr(self, '_scale_pending', None), None
-    if pend is not None and pend[0] is temperature:
-      pend[2].synchronize()
-      return float(pend[1][0])
-    return float(torch.exp(temperature.to(torch.float32)))
+    """Queue the D2H read of exp(temperature) at the START of an apply, inference and training alike
+    (``ops.prefetch_exp``: same value, same bits as a blocking ``float(torch.exp(t))``)."""
+    if self.config.add_temperature:
+      ops.prefetch_exp(params.get('temperature'))
 
   def similarity(self, params, f_p_q, plane_map, valid_points, want_prob=False, conf_p=None):
     """bev_localizer.py:157-173: sim_points (+ softmax statistics) on the GPU.  ``conf_p`` [B,Nq]:
@@ -168,7 +154,7 @@ class BEVLocalizer(base.Module):
       # exp(temperature) is a kernel ARGUMENT (host scalar).  It was read back at the start of this
       # apply (``_prefetch_scale``: 4 bytes into pinned memory, queued in front of the encoders), so
       # waiting for its event does not drain the stream: the apply has no blocking host sync.
-      scale = 1.0 if temperature is None else self._host_scale(temperature)
+      scale = 1.0 if temperature is None else ops.host_exp(temperature)
       sim, stats, prob, _ = ops.sim_softmax(fq, fm, scale, clip, num_valid, want_prob=want_prob,
                                             row_weight=weights)
     # the sampler sees stop_gradient(prob_points) (bev_localizer.py:178): detached inputs.

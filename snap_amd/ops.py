@@ -6,6 +6,7 @@ current stream.  There is no CPU or PyTorch fallback: tensors must live on a
 ROCm device and the shared library must be built, otherwise these raise.
 """
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -171,6 +172,35 @@ def upload_table(items, device):
   ev.record()
   slot[1] = ev
   return out
+
+
+# exp(temperature) is a KERNEL ARGUMENT of the similarity / sampling kernels (a host scalar).  Reading
+# it back where it is needed drains the stream in the middle of a step (everything after it is then
+# dispatched into an empty queue: ~3 ms of launch-bound gaps per training step).  ``prefetch_exp``
+# queues the 4-byte read at the START of the apply; ``host_exp`` then only waits for that copy.
+_HOST_SCALARS = {}
+
+
+def prefetch_exp(t):
+  if t is None or not t.is_cuda:
+    return
+  host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+  host.copy_(torch.exp(t.detach().to(torch.float32)).reshape(1), non_blocking=True)
+  ev = torch.cuda.Event()
+  ev.record()
+  if len(_HOST_SCALARS) > 64:
+    _HOST_SCALARS.clear()
+  _HOST_SCALARS[id(t)] = (weakref.ref(t), t._version, host, ev)
+
+
+def host_exp(t):
+  """float(exp(t)) -- the prefetched value when ``prefetch_exp(t)`` ran for this version of ``t``
+  (same torch kernel, same bits), else a blocking read."""
+  hit = _HOST_SCALARS.get(id(t))
+  if hit is not None and hit[0]() is t and hit[1] == t._version:
+    hit[3].synchronize()
+    return float(hit[2][0])
+  return float(torch.exp(t.detach().to(torch.float32)))
 
 
 def _chk(t, dtype, name):
