@@ -809,7 +809,9 @@ int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* x, const vo
  * snap/trainer.py:236-243: m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2,
  * p -= lr / (1 - b1^step) * m / (sqrt(v / (1 - b2^step)) + eps); `step` counts from 1).
  * `items`: DEVICE table sorted by block_begin; item i owns snap_adam_multi_blocks(n) workgroups
- * of 1024 elements.  p, m, v are updated in place; g is read. */
+ * of 1024 elements.  p, m, v are updated in place; g is read.  apply_flag (optional DEVICE scalar):
+ * the whole update is skipped unless *apply_flag > 0 -- the non-finite step skip of
+ * trainer.py:269-276 without a host round trip between the finite check and the update. */
 typedef struct SnapAdamItem {
   float* p;
   const float* g;
@@ -820,7 +822,8 @@ typedef struct SnapAdamItem {
 } SnapAdamItem;
 int64_t snap_adam_multi_blocks(int64_t n);
 int snap_adam_multi_f32(const SnapAdamItem* items, int32_t n_items, int64_t total_blocks, float lr,
-                        float b1, float b2, float eps, int32_t step, void* stream);
+                        float b1, float b2, float eps, int32_t step, const float* apply_flag,
+                        void* stream);
 
 /* GroupNorm(+ReLU) backward.  dz: grad w.r.t. the prologue output; add: optional extra
  * gradient summed into dx (identity-residual branch).  mode: SNAP_PRO_GN_RELU /

@@ -115,7 +115,7 @@ SIGNATURES = {
          c_int, c_int, ptr],
     ),
     'snap_adam_multi_blocks': (c_i64, [c_i64]),
-    'snap_adam_multi_f32': (c_int, [ptr, c_int, c_i64, c_float, c_float, c_float, c_float, c_int, ptr]),
+    'snap_adam_multi_f32': (c_int, [ptr, c_int, c_i64, c_float, c_float, c_float, c_float, c_int, ptr, ptr]),
     'snap_conv2d_packed_weights_bytes': (c_size, [c_int, c_int, c_int]),
     'snap_conv2d_pack_weights_bf16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_conv2d_pack_weights_f16': (c_int, [ptr, c_int, c_int, c_int, ptr, c_size, ptr]),

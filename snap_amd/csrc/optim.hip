@@ -12,7 +12,12 @@ namespace {
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(const SnapAdamItem* __restrict__ items,
                                                          int n_items, float b1, float b2,
-                                                         float step_size, float inv_sqrt_c2, float eps) {
+                                                         float step_size, float inv_sqrt_c2, float eps,
+                                                         const float* __restrict__ apply_flag) {
+  // (trainer.py:269-276: a non-finite step restores parameters and optimizer state -- here the update
+  //  is not applied in the first place; the flag is a DEVICE scalar so that the host need not read
+  //  the finite check back before it may launch the update)
+  if (apply_flag && !(*apply_flag > 0.f)) return;
   int lo = 0, hi = n_items - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -45,14 +50,14 @@ extern "C" int64_t snap_adam_multi_blocks(int64_t n) { return n > 0 ? (n + 1023)
 
 extern "C" int snap_adam_multi_f32(const SnapAdamItem* items, int32_t n_items, int64_t total_blocks,
                                    float lr, float b1, float b2, float eps, int32_t step,
-                                   void* stream) {
+                                   const float* apply_flag, void* stream) {
   if (!items) return SNAP_ERR_NULL;
   if (n_items <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL || step <= 0) return SNAP_ERR_BAD_SHAPE;
   const double c1 = 1.0 - pow((double)b1, (double)step);
   const double c2 = 1.0 - pow((double)b2, (double)step);
   hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), items, n_items, b1, b2, (float)((double)lr / c1),
-                     (float)(1.0 / sqrt(c2)), eps);
+                     (float)(1.0 / sqrt(c2)), eps, apply_flag);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -575,9 +575,10 @@ _ADAM_ITEM = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v
                        ('n', np.int64), ('block_begin', np.int64)])
 
 
-def adam_update_(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+def adam_update_(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, apply_flag=None):
   """optax.adam (bias-corrected, eps outside the sqrt) over every tensor of the lists in ONE launch;
-  in place on params / m / v (trainer.py:236-243).  ``step`` counts from 1."""
+  in place on params / m / v (trainer.py:236-243).  ``step`` counts from 1.  apply_flag: optional
+  0-d f32 DEVICE tensor -- the update is skipped unless it is > 0 (the non-finite step skip)."""
   lib = _lib.load()
   items = np.zeros(len(params), dtype=_ADAM_ITEM)
   blk = 0
@@ -591,6 +592,8 @@ def adam_update_(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     items[i] = (p.data_ptr(), g.data_ptr(), mi.data_ptr(), vi.data_ptr(), p.numel(), blk)
     blk += lib.snap_adam_multi_blocks(p.numel())
   table = ops.upload_table(items, params[0].device)
+  if apply_flag is not None:
+    _f32(apply_flag, 'apply_flag')
   st = lib.snap_adam_multi_f32(_p(table), len(params), blk, float(lr), float(b1), float(b2), float(eps),
-                               int(step), _stream())
+                               int(step), _p(apply_flag), _stream())
   _lib.check(st, 'snap_adam_multi_f32')

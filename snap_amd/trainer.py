@@ -145,6 +145,11 @@ def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
   torch._foreach_addcdiv_(leaves, m, denom, value=-lr / c1)
 
 
+def ops_bwd_adam(leaves, grads, m, v, step, lr, apply_flag):
+  from snap_amd import ops_bwd
+  ops_bwd.adam_update_(leaves, grads, m, v, step, lr, 0.9, 0.999, 1e-8, apply_flag=apply_flag)
+
+
 def _global_norm(tensors):
   """sqrt(sum ||t||^2): one multi-tensor launch + a tiny fp64 reduction."""
   return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)).double())
@@ -197,34 +202,46 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
     gn = _global_norm(grads)
     factor = torch.clamp(max_grad_norm / (gn + 1e-6), max=1.0)
     torch._foreach_mul_(grads, factor)
-  # the step's host-visible scalars travel in TWO transfers (one here: the update below depends on
-  # the finite flag; one at the end), not one blocking read per scalar (~20 per step before)
-  head = torch.stack([sdist.all_finite_tensor(grads, group).to(torch.float64).reshape(()),
-                      _global_norm(grads).reshape(())]).cpu()
-  is_fin = bool(head[0] > 0)
-  if state.dynamic_scale is not None:
-    state.dynamic_scale = state.dynamic_scale.update(is_fin)
-    logs['loss_scale'] = state.dynamic_scale.scale
-  logs['l2_grads'] = float(head[1])
   # The reference restores the whole opt_state on a skipped step, optax's step and schedule
   # counts included (trainer.py:269-276): bias correction and schedule follow opt_count.
   lr = lr_fn(state.opt_count)
   logs['learning_rate'] = lr
-  logs['is_finite'] = is_fin
-  if is_fin:                                           # otherwise: skip the update
+  fin_t = sdist.all_finite_tensor(grads, group).to(torch.float32).reshape(())
+  gnorm_t = _global_norm(grads).reshape(())
+  device_skip = FUSED_ADAM and bool(leaves) and leaves[0].is_cuda
+  if device_skip:
+    # ONE host transfer per step, at its end: the update kernel itself reads the finite flag on the
+    # device and applies nothing when a gradient is non-finite (the reference does the same inside
+    # the traced step, trainer.py:269-276) -- the host need not know before it launches it
     with torch.no_grad():
-      _adam_update_(leaves, grads, state.m, state.v, state.opt_count + 1, lr)
-    state.opt_count += 1
+      ops_bwd_adam(leaves, grads, state.m, state.v, state.opt_count + 1, lr, fin_t)
+    is_fin = None
+  else:
+    head = torch.stack([fin_t.to(torch.float64), gnorm_t]).cpu()
+    is_fin = bool(head[0] > 0)
+    if is_fin:                                           # otherwise: skip the update
+      with torch.no_grad():
+        _adam_update_(leaves, grads, state.m, state.v, state.opt_count + 1, lr)
   with torch.no_grad():
     per_example = {k: v.detach().to(torch.float32) for k, v in metrics.items()}
     for k, v in losses.items():
       per_example[f'loss/{k}'] = v.detach()
     keys, means = sdist.reduce_batch_metrics_tensor(per_example, batch['batch_mask'], group)
-    tail = torch.cat([torch.stack([_global_norm(leaves).reshape(()), loss.detach().to(torch.float64).reshape(())]),
+    tail = torch.cat([torch.stack([_global_norm(leaves).reshape(()), loss.detach().to(torch.float64).reshape(()),
+                                   fin_t.to(torch.float64), gnorm_t.to(torch.float64)]),
                       means.to(torch.float64)]).cpu().tolist()
+  if is_fin is None:
+    is_fin = tail[2] > 0
+  if is_fin:
+    state.opt_count += 1
+  if state.dynamic_scale is not None:
+    state.dynamic_scale = state.dynamic_scale.update(is_fin)
+    logs['loss_scale'] = state.dynamic_scale.scale
+  logs['l2_grads'] = tail[3]
+  logs['is_finite'] = is_fin
   logs['l2_params'] = tail[0]
   logs['loss'] = tail[1]
-  reduced = dict(zip(keys, tail[2:]))
+  reduced = dict(zip(keys, tail[4:]))
   state.global_step += 1
   return state, reduced, logs
 
