@@ -193,7 +193,7 @@ def _pmc_traffic_record(kernel, launches, workload, default_config=True):
       break
   if not rec or not launches:
     return None
-  rec_launches = rec.get('launches')
+  rec_launches = rec.get('body_launches', rec.get('launches'))   # (kernels the event regions count)
   digest_now = source_digest()
   stale = (doc.get('source_digest') != digest_now) or (rec_launches is not None and rec_launches != launches)
   return {

@@ -23,6 +23,7 @@ FAMILIES = [
     ('splitk_reduce_stats_kernel', 'conv_split'), ('conv_ps_kernel', 'conv_split'),
     ('gn_norm_split_kernel', 'gn_norm_split'), ('presplit_kernel', 'presplit'),
     ('gn_finalize_tiled_kernel', 'group_norm_stats'), ('sim_split_kernel', 'sim_softmax'),
+    ('sim_split_fast_kernel', 'sim_softmax'), ('sim_presplit_kernel', 'sim_softmax'),
     ('ransac_sample', 'ransac_sample'), ('template_', 'voting'), ('conv_bf16_kernel', 'conv_bf16'),
     ('mlp2_pool_kernel', 'mlp2_pool'), ('mlp2_pool_finalize_kernel', 'mlp2_pool'), ('fill_f32_kernel', 'mlp2_pool'),
     ('pack_weights_split', 'pack_weights'),
@@ -62,7 +63,7 @@ def main():
   f, fc = read(fetch_csv, 'FETCH_SIZE')
   w, _ = read(write_csv, 'WRITE_SIZE')
   kernels = {}
-  per_step = collections.defaultdict(lambda: {'hbm_read_bytes': 0.0, 'hbm_write_bytes': 0.0, 'launches': 0})
+  per_step = collections.defaultdict(lambda: {'hbm_read_bytes': 0.0, 'hbm_write_bytes': 0.0, 'launches': 0, 'body_launches': 0})
   for k in sorted(set(f) | set(w)):
     kernels[k] = {f'launches_{steps}steps': fc.get(k, 0), 'FETCH_SIZE_KiB': f.get(k, 0.0),
                   'WRITE_SIZE_KiB': w.get(k, 0.0)}
@@ -72,6 +73,9 @@ def main():
     per_step[fam]['hbm_read_bytes'] += 2.0 * f.get(k, 0.0) * 1024 / steps
     per_step[fam]['hbm_write_bytes'] += w.get(k, 0.0) * 1024 / steps
     per_step[fam]['launches'] += fc.get(k, 0) // steps
+    # (the launches bench.py's event regions count: not the reduce / finalize / fill passes behind them)
+    if not any(t in k for t in ('reduce', 'finalize', 'fill_', 'presplit')):
+      per_step[fam]['body_launches'] += fc.get(k, 0) // steps
   note = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in SEPARATE passes over `bench.py --steps 1 '
           f'--warmup 1` ({steps} steps per pass), C2 workload. Units KiB. read bytes = 2 x FETCH_SIZE '
           'x 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM '
