@@ -95,8 +95,8 @@ template <int PRO>
 __device__ __forceinline__ float apply_pro(float v, float mu, float sc, float beta, float s,
                                            float t) {
   if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
-  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
-  if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
+  if constexpr (PRO == SNAP_PRO_GN_RELU) return snap_relu((v - mu) * sc + beta);
+  if constexpr (PRO == SNAP_PRO_RELU_GN) return (snap_relu(v) - mu) * sc + beta;
   if constexpr (PRO == SNAP_PRO_RELU) return snap_relu(v);
   return v;
 }
@@ -247,11 +247,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
         const int sl = m >= m_split ? 1 : 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float t = a.gn_relu ? fmaxf(v[e], 0.f) : v[e];
+          const float t = a.gn_relu ? snap_relu(v[e]) : v[e];
           gs1[sl][e] += t;
           gs2[sl][e] += t * t;
           if constexpr (DUAL) {
-            const float r = fmaxf(v[e], 0.f);
+            const float r = snap_relu(v[e]);
             hs1[sl][e] += r;
             hs2[sl][e] += r * r;
           }
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(
         const int sl = m >= m_split ? 1 : 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float t = gn_relu ? fmaxf(v[e], 0.f) : v[e];
+          const float t = gn_relu ? snap_relu(v[e]) : v[e];
           s1[sl][e] += t;
           s2[sl][e] += t * t;
         }

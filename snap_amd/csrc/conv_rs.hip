@@ -439,11 +439,11 @@ __global__ __launch_bounds__(SNAP_RS_NT, 2) void conv1x1_rs_kernel(const ConvArg
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float y = live ? v[e] : 0.f;
-            const float tt = a.gn_relu ? fmaxf(y, 0.f) : y;
+            const float tt = a.gn_relu ? snap_relu(y) : y;
             s1[e] += tt;
             s2[e] += tt * tt;
             if constexpr (DUAL) {
-              const float rl = fmaxf(y, 0.f);
+              const float rl = snap_relu(y);
               h1[e] += rl;
               h2[e] += rl * rl;
             }
@@ -491,11 +491,11 @@ __global__ __launch_bounds__(SNAP_RS_NT, 2) void conv1x1_rs_kernel(const ConvArg
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float y = live ? v[e] : 0.f;
-                const float tt = a.gn_relu ? fmaxf(y, 0.f) : y;
+                const float tt = a.gn_relu ? snap_relu(y) : y;
                 s1[e] += tt;
                 s2[e] += tt * tt;
                 if constexpr (DUAL) {
-                  const float rl = fmaxf(y, 0.f);
+                  const float rl = snap_relu(y);
                   h1[e] += rl;
                   h2[e] += rl * rl;
                 }
@@ -709,11 +709,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bs_kernel(const ConvArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float y = live ? v[e] : 0.f;
-                const float tt = a.gn_relu ? fmaxf(y, 0.f) : y;
+                const float tt = a.gn_relu ? snap_relu(y) : y;
                 s1[e] += tt;
                 s2[e] += tt * tt;
                 if constexpr (STATS == 2) {
-                  const float rl = fmaxf(y, 0.f);
+                  const float rl = snap_relu(y);
                   h1[e] += rl;
                   h2[e] += rl * rl;
                 }
@@ -753,11 +753,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bs_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const float y = live ? v[e] : 0.f;
-                  const float tt = a.gn_relu ? fmaxf(y, 0.f) : y;
+                  const float tt = a.gn_relu ? snap_relu(y) : y;
                   s1[e] += tt;
                   s2[e] += tt * tt;
                   if constexpr (STATS == 2) {
-                    const float rl = fmaxf(y, 0.f);
+                    const float rl = snap_relu(y);
                     h1[e] += rl;
                     h2[e] += rl * rl;
                   }
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvArgs a) 
         if (live) yb[(int64_t)ri * d.Cout_stride + 32 * j] = v;
         if constexpr (STATS > 0) {
           const float y0 = live ? v : 0.f;
-          const float tt = a.gn_relu ? fmaxf(y0, 0.f) : y0;
+          const float tt = a.gn_relu ? snap_relu(y0) : y0;
           s1 += tt;
           s2 += tt * tt;
         }

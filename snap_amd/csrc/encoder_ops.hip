@@ -109,14 +109,14 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(
   f32x4 piv = *reinterpret_cast<const f32x4*>(xb);
   if (relu_first) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) piv[e] = fmaxf(piv[e], 0.f);
+    for (int e = 0; e < 4; ++e) piv[e] = snap_relu(piv[e]);
   }
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   for (int p = p_begin + tp; p < p_end; p += PW) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)p * Cs);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float t = (relu_first ? fmaxf(v[e], 0.f) : v[e]) - piv[e];
+      const float t = (relu_first ? snap_relu(v[e]) : v[e]) - piv[e];
       s1[e] += t;
       s2[e] += t * t;
     }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   for (int e = lane; e < count; e += 64) {
     const int s = e / cpg, cc = e - s * cpg;
     float pv = tiled ? 0.f : xp[cc];
-    if (relu_first && !tiled) pv = fmaxf(pv, 0.f);
+    if (relu_first && !tiled) pv = snap_relu(pv);
     const float* pp = partial + (((int64_t)n * S + s) * C + c_lo + cc) * 2;
     const double a1 = (double)pp[0];
     t1 += a1;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   }
   for (int cc = lane; cc < cpg && !tiled; cc += 64) {
     float pv = xp[cc];
-    if (relu_first) pv = fmaxf(pv, 0.f);
+    if (relu_first) pv = snap_relu(pv);
     p1 += (double)pv;
     p2 += (double)pv * (double)pv;
   }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   const float meanf = (float)mean;
   const float var = (float)(m2 / (cnt * cpg));
   // x / sqrt(mean(x^2) + eps): division by the sqrt, as in resnet.py:40.
-  const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
+  const float rstd = 1.0f / sqrtf(snap_relu(var) + eps);
   for (int cc = lane; cc < cpg; cc += 64) {
     mu[(int64_t)n * C + c_lo + cc] = meanf;
     sc[(int64_t)n * C + c_lo + cc] = rstd * gamma[c_lo + cc];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void gn_finalize_tiled_kernel(
   const double m2 = t2 - 2.0 * mean * t1 + cnt * (cpg * mean * mean);
   const float meanf = (float)mean;
   const float var = (float)(m2 / (cnt * cpg));
-  const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
+  const float rstd = 1.0f / sqrtf(snap_relu(var) + eps);
   for (int cc = threadIdx.x; cc < cpg; cc += 256) {
     mu[(int64_t)n * C + c_lo + cc] = meanf;
     sc[(int64_t)n * C + c_lo + cc] = rstd * gamma[c_lo + cc];
@@ -283,9 +283,9 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (mode == SNAP_PRO_GN_RELU)
-      o[e] = fmaxf((v[e] - m[e]) * s[e] + b[e], 0.f);
+      o[e] = snap_relu((v[e] - m[e]) * s[e] + b[e]);
     else
-      o[e] = (fmaxf(v[e], 0.f) - m[e]) * s[e] + b[e];
+      o[e] = (snap_relu(v[e]) - m[e]) * s[e] + b[e];
   }
   reinterpret_cast<f32x4*>(y)[i] = o;
 }
@@ -313,7 +313,7 @@ __global__ void max_pool_kernel(const float* __restrict__ x, float* __restrict__
       const f32x4 v =
           *reinterpret_cast<const f32x4*>(x + (((int64_t)n * H + hi) * W + wi) * C + 4 * q);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v[e]);
+      for (int e = 0; e < 4; ++e) best[e] = snap_max_nan(best[e], v[e]);
     }
   }
   reinterpret_cast<f32x4*>(y)[i] = best;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gn_norm_split_kernel(const NormSplitArgs 
     const double m2 = t2 - 2.0 * mean * t1 + cnt * (cpg * mean * mean);
     const float var = (float)(m2 / (cnt * cpg));
     g_mean[g] = (float)mean;
-    g_rstd[g] = 1.0f / sqrtf(fmaxf(var, 0.f) + a.eps);   // x / sqrt(var + eps): resnet.py:40
+    g_rstd[g] = 1.0f / sqrtf(snap_relu(var) + a.eps);   // x / sqrt(var + eps): resnet.py:40
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {

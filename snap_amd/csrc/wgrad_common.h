@@ -68,8 +68,8 @@ using snapwg::wg_plan;
 template <int PRO>
 __device__ __forceinline__ float wg_pro(float v, float mu, float sc, float beta, float s, float t) {
   if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
-  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf((v - mu) * sc + beta, 0.f);
-  if constexpr (PRO == SNAP_PRO_RELU_GN) return (fmaxf(v, 0.f) - mu) * sc + beta;
+  if constexpr (PRO == SNAP_PRO_GN_RELU) return snap_relu((v - mu) * sc + beta);
+  if constexpr (PRO == SNAP_PRO_RELU_GN) return (snap_relu(v) - mu) * sc + beta;
   if constexpr (PRO == SNAP_PRO_RELU) return snap_relu(v);
   return v;
 }

@@ -847,6 +847,35 @@ def test_vertical_pool(pooling, Z, D):
   helpers.report('vpool plane', pg, pw, atol=1e-5, rtol=1e-6)
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x3', 'bf16'])
+def test_encoder_ops_propagate_nan_like_jnp(math):
+  """jnp.maximum / nn.relu / nn.max_pool / the GroupNorm statistics propagate a NaN; so do the fused
+  prologues (GroupNorm -> ReLU, ReLU -> GroupNorm, ReLU) and epilogues of every conv engine, the
+  statistics kernels and the max-pool: a NaN pixel poisons its image's normalised activations (and
+  nothing of the other image), as in the reference -- where it ends in the trainer's non-finite step
+  skip (trainer.py:260-277).  Against the numpy oracle, NaN positions included."""
+  N, H, W, Cin, Cout = 2, 9, 11, 64, 128
+  x = rnd((N, H, W, Cin), 501) + 0.2
+  x[1, 4, 5, 7] = float('nan')
+  w = rnd((3, 3, Cin, Cout), 502, 1 / np.sqrt(9 * Cin))
+  gamma, beta = rnd((Cin,), 503) + 1, rnd((Cin,), 504) * 0.1
+  for pro, relu_first in ((ops.PRO_GN_RELU, False), (ops.PRO_RELU_GN, True)):
+    (mg, sg), (mw, sw) = both('group_norm_stats', (x, gamma), dict(relu_first=relu_first))
+    helpers.report('gn mean (NaN-aware)', mg, mw, atol=1e-5, rtol=1e-5)
+    helpers.report('gn scale (NaN-aware)', sg, sw, atol=1e-4, rtol=1e-4)
+    assert bool(torch.isnan(mg[1]).any()) and not bool(torch.isnan(mg[0]).any())
+    kw = dict(padding=((1, 1), (1, 1)), prologue=pro, gn=(mw, sw, beta), relu=True, math=math)
+    got, want = both('conv2d', (x, w), kw)
+    helpers.report(f'conv {math} pro {pro} (NaN-aware)', got, want, atol=2e-4 if math == 'bf16' else 5e-5, rtol=1e-4)
+    assert bool(torch.isnan(got[1]).all()) and not bool(torch.isnan(got[0]).any())
+  got, want = both('conv2d', (x, w), dict(padding=((1, 1), (1, 1)), prologue=ops.PRO_RELU, relu=True, math=math))
+  helpers.report(f'conv {math} relu prologue (NaN-aware)', got, want, atol=2e-4 if math == 'bf16' else 5e-5, rtol=1e-4)
+  assert int(torch.isnan(got).any(-1).sum()) == 9               # the 3 x 3 footprint of the one NaN pixel
+  got, want = both('max_pool_3x3s2', (x,))
+  helpers.report('max pool (NaN-aware)', got, want, atol=0)
+  assert bool(torch.isnan(got).any())
+
+
 @pytest.mark.parametrize('Z', [60, 70])
 def test_pooling_propagates_nan_of_observed_voxels(Z):
   """bev_mapper.py:63-78: ``jnp.max(features, where=valid_any_or_all, initial=-inf)`` -- a NaN of an
