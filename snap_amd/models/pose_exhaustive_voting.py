@@ -122,7 +122,9 @@ def _overlap_count(mvp, cw, R, q_hw):
   need = 32 * (ncol - 1) + 31 + 31 + 1     # widest index + 1
   mv = torch.nn.functional.pad(mvp, (0, max(0, need - Wp)))
   win = mv.unfold(1, 32, 1)[:, :32 * ncol]                       # win[row, s, c] = mv[row, s + c]
-  X = win.reshape(Hp, ncol, 32, 32).permute(2, 0, 1, 3).contiguous()   # [br, row, col, c]
+  # (0 / 1 are exact in bf16: the folded image is written in the engine's element type, and the launch
+  #  moves both operands by LDS-DMA -- conv_bf16_xh_kernel -- instead of converting f32 in its loop)
+  X = win.reshape(Hp, ncol, 32, 32).permute(2, 0, 1, 3).to(torch.bfloat16).contiguous()   # [br, row, col, c]
   wq = cw.reshape(H, W // 32, 32, R)                               # [i, t, c, r], j = 32 t + c
   out = ops.conv2d(X, wq, math='bf16')                             # [32, Ho, nbq, R]
   return out.permute(1, 2, 0, 3).reshape(Ho, nbq * 32, R)[:, :Wo].contiguous()
