@@ -766,6 +766,10 @@ int snap_vertical_pool_conf_bwd_f32(const float* vol, const uint8_t* vvalid, con
  * ------------------------------------------------------------------------- */
 /* dw[KH*KW*Cin, Cout] (+)= im2col(prologue(x))^T dy   on f32 MFMA; dy [N,Ho,Wo,Cout]. */
 size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc);
+/* A/B switch (tools, tests): 0 keeps the half-precision engines' flat kernel gradients (1 x 1, Cin >= 192,
+ * >= 65 536 rows) on the 128 x 128 tiles instead of the 512-thread 256-wide plan; returns the previous
+ * setting.  Same rounded operands, another summation order.  Default 1. */
+int32_t snap_conv2d_wgrad_set_wide(int32_t on);
 int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, const float* dy,
                           float* dw, const float* gn_mu, const float* gn_sc,
                           const float* gn_beta, int32_t accumulate, void* workspace,

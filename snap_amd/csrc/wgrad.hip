@@ -315,10 +315,19 @@ int wg_launch_pro(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
 
 }  // namespace
 
+// A/B switch of the wide plan (tools / tests; the workspace is always sized for it)
+static int g_wgrad_wide = 1;
+extern "C" int32_t snap_conv2d_wgrad_set_wide(int32_t on) {
+  const int prev = g_wgrad_wide;
+  g_wgrad_wide = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc) {
   if (!desc) return 0;
   // the loader variant depends on the pointer alignment seen at launch: size for both.
-  const int S = max(wg_plan(*desc, true).S, wg_plan(*desc, false).S);
+  int S = max(wg_plan(*desc, true).S, wg_plan(*desc, false).S);
+  if (snapwg::wg_wide_ok(*desc, true, SNAP_MATH_BF16)) S = max(S, snapwg::wg_plan_wide(*desc).S);
   return (size_t)S * desc->KH * desc->KW * desc->Cin * desc->Cout * sizeof(float);
 }
 
@@ -387,7 +396,7 @@ extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* 
   const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
                    ((reinterpret_cast<uintptr_t>(x) & (x_is_half ? 7 : 15)) == 0) && (!gn || (d.Cin % 4 == 0));
   if ((x_is_half || dy_is_half) && !vec) return SNAP_ERR_UNSUPPORTED;
-  const WgPlan p = wg_plan(d, vec);
+  const WgPlan p = (g_wgrad_wide && snapwg::wg_wide_ok(d, vec, math)) ? snapwg::wg_plan_wide(d) : wg_plan(d, vec);
   WgradArgs a;
   a.d = d;
   a.x = x; a.dy = dy; a.partial = static_cast<float*>(workspace);

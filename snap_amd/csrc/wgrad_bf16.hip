@@ -40,15 +40,23 @@ template <> struct Elem<true> {
 // half the bytes of that operand, no rounding work (the values ARE the rounded ones)
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int BKT, int BN, int PRO, bool F16 = false, bool ZH = false, bool DH = false>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
+//
+// NT = 512 (eight waves, 4 x 2): the WIDE tile of the flat (Dense) kernel gradients -- a whole 256 x 256 (or
+// 256 x 128) dW per workgroup, so a chunk of rows is read ONCE (the 128 x 128 tiling reads Z per column tile
+// and dY per channel tile: 2.3 x the bytes at 256 x 256), and the row-list entries travel one slab ahead of
+// the rows they address (one memory round trip per slab instead of two).
+template <int BKT, int BN, int PRO, bool F16 = false, bool ZH = false, bool DH = false, int NT = 256>
+__global__ __launch_bounds__(NT) void wgrad_bf16_kernel(const WgradArgs a) {
   static_assert(!ZH || PRO == SNAP_PRO_NONE, "a half Z operand has no prologue");
+  static_assert(BKT / 4 <= NT / 8 && BN / 4 <= NT / 8, "one channel quad per loader thread");
   typedef Elem<F16> E;
   typedef typename E::x8 etx8;
   typedef typename E::x4 etx4;
   constexpr int RS = 32;                   // reduction slab (output pixels) = two MFMA k-steps
   constexpr int RSB = 80;                  // LDS row stride in bytes (32 bf16 + 16 B pad)
-  constexpr int TM = BKT / 64, TN = BN / 64;
+  constexpr int WR = NT / 128;             // wave rows (x 2 wave columns)
+  constexpr int ZROWS = BKT / WR;          // channels per wave row
+  constexpr int TM = ZROWS / 32, TN = BN / 64;
   constexpr int ZQ = BKT / 4, DQ = BN / 4; // float4 quads per row
   constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
   constexpr int Z_ST = BKT * RSB, D_ST = BN * RSB;   // bytes per stage
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
 
   // loader coordinates: row group (4 consecutive m) and quad
   const int mg = tid & 7;
-  const int quad = tid >> 3;                  // 0..31
+  const int quad = tid >> 3;                  // 0..NT/8-1
   const bool z_on = quad < ZQ, d_on = quad < DQ;
   const int zc = c0 + 4 * quad;
   const int dcol = n0 + 4 * quad;
@@ -116,6 +124,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
     }
   };
 
+  // row-list entries of a slab, fetched one slab ahead of the rows they address
+  int zidx[4] = {0, 0, 0, 0}, didx[4] = {0, 0, 0, 0};
+  auto load_idx = [&](int sl) {
+    const int64_t ms = m_begin + (int64_t)sl * RS + 4 * mg;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t m = ms + p;
+      if (a.rows_z) zidx[p] = (m < m_end && z_on) ? a.rows_z[m] : 0;
+      if (a.rows_dy) didx[p] = (m < m_end && d_on) ? a.rows_dy[m] : 0;
+    }
+  };
+
   auto load_slab = [&](int sl) {
     const int64_t ms = m_begin + (int64_t)sl * RS + 4 * mg;
 #pragma unroll
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
       const bool inb = mok && z_on && zc < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
       zin[p] = inb;
       int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + zc : (int64_t)0;
-      if (a.rows_z) off = inb ? (int64_t)a.rows_z[m] * d.Cin_stride + zc : (int64_t)0;
+      if (a.rows_z) off = inb ? (int64_t)zidx[p] * d.Cin_stride + zc : (int64_t)0;
       if constexpr (ZH)
         zrh[p] = inb ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.x) + off) : u32x2{0u, 0u};
       else
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
       }
       const bool ok = mok && d_on && dcol < d.Cout;
       din[p] = ok;
-      const int64_t drow = (ok && a.rows_dy) ? (int64_t)a.rows_dy[m] : m;
+      const int64_t drow = (ok && a.rows_dy) ? (int64_t)didx[p] : m;
       if constexpr (DH)
         drh[p] = ok ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.dy) + drow * d.Cout_stride + dcol)
                     : u32x2{0u, 0u};
@@ -204,8 +224,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
   };
 
   if (nslab > 0) {
+    load_idx(0);
     load_slab(0);
     advance_rows();
+    if (nslab > 1) load_idx(1);
     store_slab(0);
   }
   __syncthreads();
@@ -215,6 +237,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
     if (more) {
       load_slab(sl + 1);
       advance_rows();
+      if (sl + 2 < nslab) load_idx(sl + 2);
     }
     const char* zs = Zs0 + cur * Z_ST;
     const char* ds = Ds0 + cur * D_ST;
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
       etx8 av[TM], bv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        av[i] = *reinterpret_cast<const etx8*>(zs + (wr * (BKT / 2) + i * 32 + l31) * RSB + (2 * s + lhi) * 16);
+        av[i] = *reinterpret_cast<const etx8*>(zs + (wr * ZROWS + i * 32 + l31) * RSB + (2 * s + lhi) * 16);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         bv[j] = *reinterpret_cast<const etx8*>(ds + (wc * (BN / 2) + j * 32 + l31) * RSB + (2 * s + lhi) * 16);
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ri = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const int c = c0 + wr * (BKT / 2) + i * 32 + ri;
+      const int c = c0 + wr * ZROWS + i * 32 + ri;
       if (c >= d.Cin) continue;
       const int64_t krow = (int64_t)kpos * d.Cin + c;
 #pragma unroll
@@ -296,9 +319,39 @@ int wg_launch_pro(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s)
   }
 }
 
+
+
+// the wide tiles (wg_plan_wide): prologues NONE / RELU / AFFINE
+template <int BN, int PRO, bool ZH, bool DH>
+int wg_launch_wide(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
+  const dim3 grid((unsigned)(p.ktiles * p.ncol), (unsigned)p.S);
+  if (half) hipLaunchKernelGGL((wgrad_bf16_kernel<256, BN, PRO, true, ZH, DH, 512>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((wgrad_bf16_kernel<256, BN, PRO, false, ZH, DH, 512>), grid, dim3(512), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+template <int BN>
+int wg_launch_wide_pro(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
+  if (a.x_is_half && a.dy_is_half) return SNAP_ERR_UNSUPPORTED;
+  const int pro = a.d.prologue;
+  if (a.x_is_half) return pro == SNAP_PRO_NONE ? wg_launch_wide<BN, SNAP_PRO_NONE, true, false>(a, p, half, s)
+                                                : SNAP_ERR_UNSUPPORTED;
+  if (a.dy_is_half) {
+    if (pro == SNAP_PRO_NONE) return wg_launch_wide<BN, SNAP_PRO_NONE, false, true>(a, p, half, s);
+    if (pro == SNAP_PRO_RELU) return wg_launch_wide<BN, SNAP_PRO_RELU, false, true>(a, p, half, s);
+    return SNAP_ERR_UNSUPPORTED;
+  }
+  if (pro == SNAP_PRO_NONE) return wg_launch_wide<BN, SNAP_PRO_NONE, false, false>(a, p, half, s);
+  if (pro == SNAP_PRO_RELU) return wg_launch_wide<BN, SNAP_PRO_RELU, false, false>(a, p, half, s);
+  if (pro == SNAP_PRO_AFFINE) return wg_launch_wide<BN, SNAP_PRO_AFFINE, false, false>(a, p, half, s);
+  return SNAP_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 int snapwg::launch_bf16(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
+  if (p.bkt == 256) return p.bn == 256 ? wg_launch_wide_pro<256>(a, p, half, s) : wg_launch_wide_pro<128>(a, p, half, s);
   if (p.bkt == 128)
     return p.bn == 128 ? wg_launch_pro<128, 128>(a, p, half, s) : wg_launch_pro<128, 64>(a, p, half, s);
   return p.bn == 128 ? wg_launch_pro<64, 128>(a, p, half, s) : wg_launch_pro<64, 64>(a, p, half, s);

@@ -54,6 +54,32 @@ inline WgPlan wg_plan(const SnapConvDesc& d, bool vec) {
   return p;
 }
 
+// WIDE plan of the half-precision engine (wgrad_bf16.hip, 512 threads): flat / 1 x 1 kernel gradients with
+// many rows and >= 192 input channels -- one workgroup owns a 256 x 256 (256 x 128) tile of dW, i.e. for the
+// fusion / projection MLPs ALL of it, and reads its chunk of rows once.
+inline bool wg_wide_ok(const SnapConvDesc& d, bool vec, int math) {
+  const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+  return vec && math != SNAP_MATH_F32 && d.KH == 1 && d.KW == 1 && d.Cin >= 192 && d.Cout > 64 && M >= 65536 &&
+         (d.prologue == SNAP_PRO_NONE || d.prologue == SNAP_PRO_RELU || d.prologue == SNAP_PRO_AFFINE);
+}
+
+inline WgPlan wg_plan_wide(const SnapConvDesc& d) {
+  WgPlan p;
+  p.bkt = 256;
+  p.bn = d.Cout > 128 ? 256 : 128;
+  p.ctiles = (d.Cin + 255) / 256;
+  p.ncol = (d.Cout + p.bn - 1) / p.bn;
+  p.ktiles = p.ctiles;
+  const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+  const int tiles = p.ktiles * p.ncol;
+  int64_t S = ((p.bn == 256 ? 256 : 512) + tiles - 1) / tiles;     // one (two) workgroup(s) per CU
+  const int64_t slabs = (M + 15) / 16;
+  int64_t spc = (slabs + S - 1) / S;
+  spc += spc & 1;                                                  // whole 32-row slabs per chunk
+  p.slabs_per_chunk = (int)spc;
+  p.S = (int)((slabs + spc - 1) / spc);
+  return p;
+}
 
 // bf16-operand engine (wgrad_bf16.hip); `a` / `p` prepared by snap_conv2d_wgrad_ex_f32
 int launch_bf16(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s);   // half: IEEE f16 operands
