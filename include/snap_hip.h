@@ -422,8 +422,7 @@ int snap_weight_standardize_f32(const float* w, float* out, int32_t K,
 /* All StdConv kernels of an encoder in one launch (training standardises ~53 kernels per
  * encoder every step; one launch per kernel is pure launch latency).  `items` is a DEVICE
  * array; item i owns workgroups [block_begin, block_begin + ceil(Cout / 32)) of the forward
- * launch, ceil(Cout / 8) of the backward launch; items sorted by block_begin; total_blocks =
- * sum.  Forward: out = standardise(w) (dws unused).
+ * and of the backward launch; items sorted by block_begin; total_blocks = sum.  Forward: out = standardise(w) (dws unused).
  * Backward (snap_weight_standardize_bwd_multi_f32): out = d w given dws = d standardise(w). */
 typedef struct SnapWstdItem {
   const float* w;

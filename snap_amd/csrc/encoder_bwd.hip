@@ -234,70 +234,86 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 // ---------------------------------------------------------------------------
 // StdConv backward: ws = (w - mean)/sigma per column;  dw = (dws - mean(dws) - ws*mean(dws*ws))/sigma
 // ---------------------------------------------------------------------------
+// Geometry of the forward kernel (encoder_ops.hip): 32 columns x 32 k-slices on 1024 threads -- a wave reads two
+// 128-byte row runs per load -- and the forward's statistics (pivoted sums, combined in double: the same mean and
+// sigma bits).  Three passes over the column block: statistics, the two gradient means, the output.
+constexpr int WSB_COLS = 32, WSB_SLICES = 32;
 __device__ __forceinline__ void weight_std_bwd_body(const float* __restrict__ w,
                                                     const float* __restrict__ dws,
                                                     float* __restrict__ dw, int K, int Cout,
                                                     float eps, int blk) {
-  // same geometry as the forward kernel (encoder_ops.hip): 8 columns x 32 k-slices.
-  constexpr int COLS = 8, SLICES = 256 / COLS;
-  __shared__ float red[SLICES][COLS + 1];
-  __shared__ float stat[4][COLS];
-  const int tc = threadIdx.x % COLS, tk = threadIdx.x / COLS;
-  const int col = blk * COLS + tc;
+  __shared__ float red[2][WSB_SLICES][WSB_COLS + 1];
+  __shared__ float stat[4][WSB_COLS];
+  const int tc = threadIdx.x % WSB_COLS, tk = threadIdx.x / WSB_COLS;
+  const int col = blk * WSB_COLS + tc;
   const bool ok = col < Cout;
-  auto reduce = [&](float v, int slot, float scale) {
-    red[tk][tc] = v;
-    __syncthreads();
-    if (tk == 0) {
-      float t = 0.f;
+  const float piv = ok ? w[col] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int k = tk; k < K; k += WSB_SLICES) {
+      const float t = w[(int64_t)k * Cout + col] - piv;
+      s1 += t;
+      s2 += t * t;
+    }
+  red[0][tk][tc] = s1;
+  red[1][tk][tc] = s2;
+  __syncthreads();
+  if (tk == 0) {
+    double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-      for (int i = 0; i < SLICES; ++i) t += red[i][tc];
-      stat[slot][tc] = t * scale;
+    for (int i = 0; i < WSB_SLICES; ++i) {
+      t1 += (double)red[0][i][tc];
+      t2 += (double)red[1][i][tc];
     }
-    __syncthreads();
-  };
-  float s = 0.f;
-  if (ok)
-    for (int k = tk; k < K; k += SLICES) s += w[(int64_t)k * Cout + col];
-  reduce(s, 0, 1.0f / (float)K);
+    const double m = t1 / (double)K;
+    const double var = t2 / (double)K - m * m;
+    stat[0][tc] = (float)((double)piv + m);
+    stat[1][tc] = sqrtf((float)fmax(var, 0.0) + eps);
+  }
+  __syncthreads();
   const float mean = stat[0][tc];
-  float q = 0.f;
-  if (ok)
-    for (int k = tk; k < K; k += SLICES) {
-      const float dl = w[(int64_t)k * Cout + col] - mean;
-      q += dl * dl;
-    }
-  reduce(q, 1, 1.0f / (float)K);
-  const float sigma = sqrtf(stat[1][tc] + eps);
+  const float sigma = stat[1][tc];
   float g1 = 0.f, g2 = 0.f;
   if (ok)
-    for (int k = tk; k < K; k += SLICES) {
+    for (int k = tk; k < K; k += WSB_SLICES) {
       const int64_t o = (int64_t)k * Cout + col;
       const float ws = (w[o] - mean) / sigma;
-      g1 += dws[o];
-      g2 += dws[o] * ws;
+      const float g = dws[o];
+      g1 += g;
+      g2 += g * ws;
     }
-  reduce(g1, 2, 1.0f / (float)K);
-  reduce(g2, 3, 1.0f / (float)K);
+  red[0][tk][tc] = g1;
+  red[1][tk][tc] = g2;
+  __syncthreads();
+  if (tk == 0) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < WSB_SLICES; ++i) {
+      t1 += red[0][i][tc];
+      t2 += red[1][i][tc];
+    }
+    stat[2][tc] = t1 * (1.0f / (float)K);
+    stat[3][tc] = t2 * (1.0f / (float)K);
+  }
+  __syncthreads();
   const float mg = stat[2][tc], mgw = stat[3][tc];
-  // d sigma carries the eps: sigma^2 = var + eps, so d/dw (1/sigma) uses var/sigma... exact form:
-  // ws = (w-mean)/sigma; dw = (dws - mean(dws) - ws * mean(dws*ws)) / sigma.
+  // ws = (w - mean) / sigma;  dw = (dws - mean(dws) - ws * mean(dws * ws)) / sigma   (sigma^2 = var + eps)
   if (ok)
-    for (int k = tk; k < K; k += SLICES) {
+    for (int k = tk; k < K; k += WSB_SLICES) {
       const int64_t o = (int64_t)k * Cout + col;
       const float ws = (w[o] - mean) / sigma;
       dw[o] = (dws[o] - mg - ws * mgw) / sigma;
     }
 }
 
-__global__ __launch_bounds__(256) void weight_std_bwd_kernel(const float* __restrict__ w,
+__global__ __launch_bounds__(1024) void weight_std_bwd_kernel(const float* __restrict__ w,
                                                              const float* __restrict__ dws,
                                                              float* __restrict__ dw, int K,
                                                              int Cout, float eps) {
   weight_std_bwd_body(w, dws, dw, K, Cout, eps, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void weight_std_bwd_multi_kernel(
+__global__ __launch_bounds__(1024) void weight_std_bwd_multi_kernel(
     const SnapWstdItem* __restrict__ items, int n_items, float eps) {
   int lo = 0, hi = n_items - 1;
   while (lo < hi) {
@@ -703,7 +719,7 @@ extern "C" int snap_weight_standardize_bwd_f32(const float* w, const float* dws,
                                                int32_t K, int32_t Cout, float eps, void* stream) {
   if (!w || !dws || !dw) return SNAP_ERR_NULL;
   if (K <= 0 || Cout <= 0) return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((unsigned)snap_cdiv(Cout, 8)), dim3(256), 0,
+  hipLaunchKernelGGL(weight_std_bwd_kernel, dim3((unsigned)snap_cdiv(Cout, WSB_COLS)), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), w, dws, dw, K, Cout, eps);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
@@ -714,7 +730,7 @@ extern "C" int snap_weight_standardize_bwd_multi_f32(const SnapWstdItem* items, 
                                                      void* stream) {
   if (!items) return SNAP_ERR_NULL;
   if (n_items <= 0 || total_blocks <= 0) return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(weight_std_bwd_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+  hipLaunchKernelGGL(weight_std_bwd_multi_kernel, dim3((unsigned)total_blocks), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), items, n_items, eps);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;

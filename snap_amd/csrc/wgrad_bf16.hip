@@ -124,15 +124,19 @@ __global__ __launch_bounds__(NT) void wgrad_bf16_kernel(const WgradArgs a) {
     }
   };
 
-  // row-list entries of a slab, fetched one slab ahead of the rows they address
-  int zidx[4] = {0, 0, 0, 0}, didx[4] = {0, 0, 0, 0};
+  // wide plan: row-list entries of a slab, fetched one slab ahead of the rows they address (the 128 x 128
+  // tiles sit right at 128 registers = four workgroups per CU and read the entries in place)
+  constexpr bool IDX = NT == 512;
+  int zidx[IDX ? 4 : 1] = {0}, didx[IDX ? 4 : 1] = {0};
   auto load_idx = [&](int sl) {
-    const int64_t ms = m_begin + (int64_t)sl * RS + 4 * mg;
+    if constexpr (IDX) {
+      const int64_t ms = m_begin + (int64_t)sl * RS + 4 * mg;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t m = ms + p;
-      if (a.rows_z) zidx[p] = (m < m_end && z_on) ? a.rows_z[m] : 0;
-      if (a.rows_dy) didx[p] = (m < m_end && d_on) ? a.rows_dy[m] : 0;
+      for (int p = 0; p < 4; ++p) {
+        const int64_t m = ms + p;
+        if (a.rows_z) zidx[p] = (m < m_end && z_on) ? a.rows_z[m] : 0;
+        if (a.rows_dy) didx[p] = (m < m_end && d_on) ? a.rows_dy[m] : 0;
+      }
     }
   };
 
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(NT) void wgrad_bf16_kernel(const WgradArgs a) {
       const bool inb = mok && z_on && zc < d.Cin && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
       zin[p] = inb;
       int64_t off = inb ? (((int64_t)n * d.H + hi) * d.W + wi) * d.Cin_stride + zc : (int64_t)0;
-      if (a.rows_z) off = inb ? (int64_t)zidx[p] * d.Cin_stride + zc : (int64_t)0;
+      if (a.rows_z) off = inb ? (int64_t)(IDX ? zidx[IDX ? p : 0] : a.rows_z[m]) * d.Cin_stride + zc : (int64_t)0;
       if constexpr (ZH)
         zrh[p] = inb ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.x) + off) : u32x2{0u, 0u};
       else
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(NT) void wgrad_bf16_kernel(const WgradArgs a) {
       }
       const bool ok = mok && d_on && dcol < d.Cout;
       din[p] = ok;
-      const int64_t drow = (ok && a.rows_dy) ? (int64_t)didx[p] : m;
+      const int64_t drow = (ok && a.rows_dy) ? (int64_t)(IDX ? didx[IDX ? p : 0] : a.rows_dy[m]) : m;
       if constexpr (DH)
         drh[p] = ok ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.dy) + drow * d.Cout_stride + dcol)
                     : u32x2{0u, 0u};

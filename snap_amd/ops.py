@@ -1020,8 +1020,8 @@ _WSTD_ITEM = np.dtype([('w', '<u8'), ('dws', '<u8'), ('out', '<u8'), ('K', '<i4'
                        ('block_begin', '<i4'), ('reserved', '<i4')])   # == SnapWstdItem
 
 
-def _wstd_table(ws, dwss, outs, cols=8):
-  """cols: output columns per workgroup of the kernel the table is for (forward 32, backward 8)."""
+def _wstd_table(ws, dwss, outs, cols=32):
+  """cols: output columns per workgroup of the kernel the table is for."""
   items = np.zeros(len(ws), dtype=_WSTD_ITEM)
   blk = 0
   for i, w in enumerate(ws):
