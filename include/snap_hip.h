@@ -765,9 +765,11 @@ int snap_vertical_pool_conf_bwd_f32(const float* vol, const uint8_t* vvalid, con
  * ------------------------------------------------------------------------- */
 /* dw[KH*KW*Cin, Cout] (+)= im2col(prologue(x))^T dy   on f32 MFMA; dy [N,Ho,Wo,Cout]. */
 size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc);
-/* A/B switch (tools, tests): 0 keeps the half-precision engines' flat kernel gradients (1 x 1, Cin >= 192,
- * >= 65 536 rows) on the 128 x 128 tiles instead of the 512-thread 256-wide plan; returns the previous
- * setting.  Same rounded operands, another summation order.  Default 1. */
+/* A/B switch (tools, tests) of the half-precision engines' plans, a bit mask; returns the previous one.
+ * Bit 0: flat kernel gradients (1 x 1, Cin >= 192, >= 65 536 rows) on the 512-thread 256-wide tiles; bit 1:
+ * 3 x 3 / stride 1 / pad 1 kernel gradients with a half-precision dy on the fused-tap kernel (all nine taps
+ * per workgroup, patch-ordered reduction).  A cleared bit keeps the per-tap 128 x 128 tiles.  Same rounded
+ * operands, another summation order.  Default 3. */
 int32_t snap_conv2d_wgrad_set_wide(int32_t on);
 int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, const float* dy,
                           float* dw, const float* gn_mu, const float* gn_sc,

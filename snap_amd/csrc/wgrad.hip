@@ -316,10 +316,10 @@ int wg_launch_pro(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
 }  // namespace
 
 // A/B switch of the wide plan (tools / tests; the workspace is always sized for it)
-static int g_wgrad_wide = 1;
+static int g_wgrad_wide = 3;      // bit 0: the wide flat plan; bit 1: the fused-tap 3 x 3 plan
 extern "C" int32_t snap_conv2d_wgrad_set_wide(int32_t on) {
   const int prev = g_wgrad_wide;
-  g_wgrad_wide = on ? 1 : 0;
+  g_wgrad_wide = on & 3;
   return prev;
 }
 
@@ -328,6 +328,7 @@ extern "C" size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc) {
   // the loader variant depends on the pointer alignment seen at launch: size for both.
   int S = max(wg_plan(*desc, true).S, wg_plan(*desc, false).S);
   if (snapwg::wg_wide_ok(*desc, true, SNAP_MATH_BF16)) S = max(S, snapwg::wg_plan_wide(*desc).S);
+  if (snapwg::wg_3x3_ok(*desc, true, SNAP_MATH_BF16, false, true, false)) S = max(S, snapwg::wg_plan_3x3(*desc).S);
   return (size_t)S * desc->KH * desc->KW * desc->Cin * desc->Cout * sizeof(float);
 }
 
@@ -396,7 +397,10 @@ extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* 
   const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
                    ((reinterpret_cast<uintptr_t>(x) & (x_is_half ? 7 : 15)) == 0) && (!gn || (d.Cin % 4 == 0));
   if ((x_is_half || dy_is_half) && !vec) return SNAP_ERR_UNSUPPORTED;
-  const WgPlan p = (g_wgrad_wide && snapwg::wg_wide_ok(d, vec, math)) ? snapwg::wg_plan_wide(d) : wg_plan(d, vec);
+  const bool fused3 = (g_wgrad_wide & 2) &&
+                      snapwg::wg_3x3_ok(d, vec, math, x_is_half != 0, dy_is_half != 0, rows_z || rows_dy || row_count);
+  const WgPlan p = fused3 ? snapwg::wg_plan_3x3(d)
+                   : ((g_wgrad_wide & 1) && snapwg::wg_wide_ok(d, vec, math)) ? snapwg::wg_plan_wide(d) : wg_plan(d, vec);
   WgradArgs a;
   a.d = d;
   a.x = x; a.dy = dy; a.partial = static_cast<float*>(workspace);
@@ -409,7 +413,9 @@ extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* 
   a.dy_is_half = dy_is_half ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
-  if (vec && math != SNAP_MATH_F32) {
+  if (fused3) {
+    rc = snapwg::launch_3x3(a, p, math == SNAP_MATH_F16, s);
+  } else if (vec && math != SNAP_MATH_F32) {
     rc = snapwg::launch_bf16(a, p, math == SNAP_MATH_F16, s);
   } else if (vec) {
     if (p.bkt == 128) rc = p.bn == 128 ? wg_launch_pro<128, 128, true>(a, p, s) : wg_launch_pro<128, 64, true>(a, p, s);

@@ -296,12 +296,9 @@ int wg_launch(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s) {
         return SNAP_ERR_UNSUPPORTED;
       }
     } else {
-      if constexpr (PRO == SNAP_PRO_NONE || PRO == SNAP_PRO_RELU) {
-        if (half) hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, true, false, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, false, false, true>), grid, dim3(256), 0, s, a);
-      } else {
-        return SNAP_ERR_UNSUPPORTED;
-      }
+      // (every prologue: the ResNet's kernel gradients read the half twin of the GroupNorm VJP's output)
+      if (half) hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, true, false, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, false, false, true>), grid, dim3(256), 0, s, a);
     }
   } else if (half)
     hipLaunchKernelGGL((wgrad_bf16_kernel<BKT, BN, PRO, true>), grid, dim3(256), 0, s, a);

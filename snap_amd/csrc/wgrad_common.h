@@ -81,8 +81,37 @@ inline WgPlan wg_plan_wide(const SnapConvDesc& d) {
   return p;
 }
 
+// Fused-tap plan of the 3 x 3 / stride 1 / pad 1 kernel gradients (wgrad3x3.hip): 64 input channels x 128 (64)
+// output channels x 9 taps per workgroup, the reduction in patches of 4 x 8 output pixels; slabs_per_chunk
+// counts PATCHES, S counts partial slots (two per chunk for the 64-column tile).
+inline bool wg_3x3_ok(const SnapConvDesc& d, bool vec, int math, bool x_half, bool dy_half, bool lists) {
+  return vec && math != SNAP_MATH_F32 && dy_half && !x_half && !lists && d.KH == 3 && d.KW == 3 && d.stride == 1 &&
+         d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W && d.Cin % 4 == 0 && d.Cin >= 32 && d.Cout >= 32 &&
+         (d.prologue == SNAP_PRO_NONE || d.prologue == SNAP_PRO_GN_RELU);
+}
+
+inline WgPlan wg_plan_3x3(const SnapConvDesc& d) {
+  WgPlan p;
+  p.bkt = 64;
+  p.bn = d.Cout > 64 ? 128 : 64;
+  p.ctiles = (d.Cin + 63) / 64;
+  p.ncol = (d.Cout + p.bn - 1) / p.bn;
+  p.ktiles = p.ctiles;
+  const int64_t NP = (int64_t)d.N * ((d.Ho + 3) / 4) * ((d.Wo + 7) / 8);
+  const int tiles = p.ktiles * p.ncol;
+  int64_t S = (256 + tiles - 1) / tiles;          // eight-wave workgroups: one per CU
+  const int64_t smax = (NP + 7) / 8;              // >= 8 patches per chunk
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  const int64_t ppc = (NP + S - 1) / S;
+  p.slabs_per_chunk = (int)ppc;
+  p.S = (int)((NP + ppc - 1) / ppc) * (p.bn == 64 ? 2 : 1);
+  return p;
+}
+
 // bf16-operand engine (wgrad_bf16.hip); `a` / `p` prepared by snap_conv2d_wgrad_ex_f32
 int launch_bf16(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s);   // half: IEEE f16 operands
+int launch_3x3(const WgradArgs& a, const WgPlan& p, bool half, hipStream_t s);    // wgrad3x3.hip (wg_plan_3x3)
 
 }  // namespace snapwg
 

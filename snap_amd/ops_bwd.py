@@ -50,6 +50,13 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
     raise ValueError(f'conv2d_wgrad: math={math!r}')
   lib = _lib.load()
   x_half = x.dtype in (torch.bfloat16, torch.float16)
+  if (WGRAD_DY_TWIN and math in HALF_DTYPE and not x_half and dy.dtype == torch.float32 and x.shape[-1] % 4 == 0
+      and w_shape[2] >= 4 and w_shape[3] % 4 == 0 and (gn is None or w_shape[2] % 4 == 0)):
+    # the gradient came out of the GroupNorm VJP with its rounded twin (``half_twin``): the engine rounds dy to
+    # that type anyway -- read the twin (half the bytes, byte permutes instead of conversions)
+    twin = half_twin(dy, math)
+    if twin is not None:
+      dy = twin
   dy_half = dy.dtype in (torch.bfloat16, torch.float16)
   if x_half or dy_half:
     # one operand already in the engine's element type (masked MLP: hidden activations / inter-layer
@@ -83,7 +90,8 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   bf16 = math in ops.HALF_MATH and x.shape[-1] % 4 == 0 and Cin >= 4
   code = (2 if math == 'fp16' else 1) if bf16 else 0          # SNAP_MATH_F16 / _BF16 / _F32
   with _region(('conv_wgrad_fp16' if code == 2 else 'conv_wgrad_bf16') if bf16 else 'conv_wgrad', flops,
-               4.0 * (x.numel() + dy.numel())):
+               4.0 * (x.numel() + dy.numel()),
+               tag=f'M{M}_K{KH}x{KW}x{Cin}_N{Cout}_s{stride}_p{prologue}' + ('_dyh' if dy_half else '') + ('_xh' if x_half else '')):
     st = lib.snap_conv2d_wgrad_half_f32(
         ctypes.byref(d), ctypes.c_void_p(x.data_ptr() + 4 * int(x_channel_offset)), _p(dy), _p(dw), _p(mu), _p(sc),
         _p(beta), 0, _p(ws),
@@ -100,6 +108,7 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
 _HALF_TWINS = {}
 HALF_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16}
 USE_HALF_TWINS = True
+WGRAD_DY_TWIN = True        # (tests / tools: False keeps the kernel gradients on the f32 dy)
 
 
 def half_twin(t, math):

@@ -245,6 +245,87 @@ def test_dgrad_reads_the_half_twin_of_the_groupnorm_vjp(N, H, W, C, Cout_prev, k
   assert float(via_twin.abs().max()) > 0
 
 
+@pytest.mark.parametrize('math_', ['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,C,Cprev,k,pro', [(3, 9, 7, 64, 256, 1, ops.PRO_GN_RELU), (2, 13, 11, 128, 128, 3, ops.PRO_GN_RELU),
+                                                 (2, 20, 18, 64, 64, 3, ops.PRO_RELU_GN), (2, 5, 6, 256, 1024, 1, ops.PRO_NONE),
+                                                 (1, 7, 9, 128, 512, 1, ops.PRO_GN_RELU)])
+def test_wgrad_reads_the_half_twin_of_the_groupnorm_vjp(N, H, W, C, Cprev, k, pro, math_):
+  """The same twin is the dY operand of the producing layer's KERNEL gradient (2-byte loads, byte
+  permutes instead of conversions, every prologue on the Z side): same rounded operands, same plan,
+  same summation order -- bit-identical to the launch that rounds the f32 gradient in its loader."""
+  x = rnd((N, H, W, C), 420) * 1.5 + 0.4
+  gamma, beta = rnd((C,), 421) * 0.3 + 1, rnd((C,), 422) * 0.2
+  dz = rnd((N, H, W, C), 423)
+  mu, sc, rstd = ops.group_norm_stats(G(x), G(gamma), want_rstd=True)
+  dx, _, _ = ops_bwd.group_norm_bwd(G(x), G(dz), mu, rstd, G(gamma), G(beta), ops.PRO_GN_RELU, half=math_)
+  assert ops_bwd.half_twin(dx, math_) is not None
+  # dx = d(output of the previous conv): xp [N,H,W,Cprev] -> (k x k) -> C channels, GroupNorm prologue on xp
+  xp = G(rnd((N, H, W, Cprev), 424) + 0.2)
+  gn = None
+  if pro in (ops.PRO_GN_RELU, ops.PRO_RELU_GN):
+    gp, bp = G(rnd((Cprev,), 425) * 0.3 + 1), G(rnd((Cprev,), 426) * 0.2)
+    mup, scp, _ = ops.group_norm_stats(xp, gp, relu_first=pro == ops.PRO_RELU_GN, want_rstd=True)
+    gn = (mup, scp, bp)
+  pad = (k - 1) // 2
+  kw = dict(padding=((pad, pad), (pad, pad)), prologue=pro, gn=gn, math=math_)
+  # (3 x 3: the twin also unlocks the fused-tap kernel -- another summation order, tested on its own;
+  #  the per-tap plan is pinned here so that both launches are the same kernel)
+  lib = ops_bwd._lib.load()
+  prev = lib.snap_conv2d_wgrad_set_wide(1)
+  try:
+    via_twin = ops_bwd.conv2d_wgrad(xp, dx, (k, k, Cprev, C), **kw)
+    ops_bwd.WGRAD_DY_TWIN = False
+    via_f32 = ops_bwd.conv2d_wgrad(xp, dx, (k, k, Cprev, C), **kw)
+  finally:
+    ops_bwd.WGRAD_DY_TWIN = True
+    lib.snap_conv2d_wgrad_set_wide(prev)
+  assert torch.equal(via_twin, via_f32), float((via_twin - via_f32).abs().max())
+  assert float(via_twin.abs().max()) > 0
+
+
+@pytest.mark.parametrize('math_', ['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,Cin,Cout,pro', [
+    (2, 12, 16, 64, 64, ops.PRO_GN_RELU),       # whole patches, the 64-column tile (k-steps split between wave sets)
+    (3, 17, 17, 128, 128, ops.PRO_GN_RELU),     # ragged patches in both directions
+    (1, 34, 34, 256, 256, ops.PRO_GN_RELU),
+    (2, 9, 7, 96, 160, ops.PRO_NONE),           # partial channel / column tiles, one patch column
+    (5, 4, 8, 64, 32, ops.PRO_GN_RELU),         # one patch per image
+    (20, 17, 17, 512, 512, ops.PRO_GN_RELU),    # the C3 stage-4 layer (32 tiles, few patches per chunk)
+])
+def test_conv_wgrad_3x3_fused_taps(N, H, W, Cin, Cout, pro, math_):
+  """``wgrad3x3.hip``: all nine taps of a 3 x 3 / stride 1 / pad 1 kernel gradient in one workgroup, the
+  reduction in 4 x 8-pixel patches, dy in the engine's element type.  Versus the rounded-operand
+  restatement in float64 (the tolerance of ``test_conv_wgrad_bf16``) and versus the per-tap kernel
+  (same rounded operands, another summation order)."""
+  from oracle import encoder as o_enc
+  rnd_ = o_enc.bf16_round if math_ == 'bf16' else o_enc.fp16_round
+  hd = ops_bwd.HALF_DTYPE[math_]
+  x = rnd((N, H, W, Cin), 431) + 0.1
+  gamma, beta = rnd((Cin,), 432) * 0.3 + 1, rnd((Cin,), 433) * 0.2
+  dyh = G(rnd((N, H, W, Cout), 434)).to(hd)
+  gn = gn_cpu = None
+  if pro == ops.PRO_GN_RELU:
+    mu, sc = oracle_ops.group_norm_stats(x, gamma, relu_first=False)
+    gn, gn_cpu = (G(mu), G(sc), G(beta)), (mu, sc, beta)
+  z32 = oracle_ops._prologue(x.numpy().astype(np.float32), pro, gn_cpu, (1.0, 0.0), Cin)
+  wd = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+  ref_conv(torch.from_numpy(rnd_(z32)).double(), wd, 1, 1).backward(dyh.cpu().double())
+  ref = wd.grad.float()
+  lib = ops_bwd._lib.load()
+  kw = dict(padding=((1, 1), (1, 1)), prologue=pro, gn=gn, math=math_)
+  got = ops_bwd.conv2d_wgrad(G(x), dyh, (3, 3, Cin, Cout), **kw)
+  prev = lib.snap_conv2d_wgrad_set_wide(1)
+  try:
+    per_tap = ops_bwd.conv2d_wgrad(G(x), dyh, (3, 3, Cin, Cout), **kw)
+  finally:
+    lib.snap_conv2d_wgrad_set_wide(prev)
+  assert prev == 3
+  tol = 2e-5 * float(ref.abs().max()) + 1e-5
+  helpers.report(f'wgrad 3x3 fused {math_} {N}x{H}x{W} {Cin}->{Cout}', got, ref, atol=tol)
+  helpers.report(f'wgrad 3x3 per-tap {math_}', per_tap, ref, atol=tol)
+  assert not torch.equal(got, per_tap) or N * H * W <= 32     # (two kernels: the A/B switch switches)
+
+
 @pytest.mark.parametrize('k,stride,pad', [(1, 1, 0), (3, 1, 1), (3, 2, 1), (1, 2, 0)])
 def test_conv_dgrad_via_engine(k, stride, pad):
   from snap_amd import autograd as ag
