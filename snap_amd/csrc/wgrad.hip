@@ -393,6 +393,8 @@ extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* 
     return SNAP_ERR_BAD_SHAPE;
   const bool gn = d.prologue == SNAP_PRO_GN_RELU || d.prologue == SNAP_PRO_RELU_GN;
   if (gn && (!gn_mu || !gn_sc || !gn_beta)) return SNAP_ERR_NULL;
+  if (gn && math != SNAP_MATH_F32 && d.Ho * d.Wo < 4) math = SNAP_MATH_F32;   // (the half engines' loaders assume four
+                                                                              //  consecutive rows span <= two images)
   if (workspace_bytes < snap_conv2d_wgrad_workspace_bytes(desc)) return SNAP_ERR_WORKSPACE;
   const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
                    ((reinterpret_cast<uintptr_t>(x) & (x_is_half ? 7 : 15)) == 0) && (!gn || (d.Cin % 4 == 0));

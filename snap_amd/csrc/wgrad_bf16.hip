@@ -96,7 +96,8 @@ __global__ __launch_bounds__(NT) void wgrad_bf16_kernel(const WgradArgs a) {
   const bool z_on = quad < ZQ, d_on = quad < DQ;
   const int zc = c0 + 4 * quad;
   const int dcol = n0 + 4 * quad;
-  f32x4 zr[4], zmu[4], zsc[4], zbeta = {0.f, 0.f, 0.f, 0.f};
+  f32x4 zr[4], zmu[2], zsc[2], zbeta = {0.f, 0.f, 0.f, 0.f};
+  bool zfirst[4] = {true, true, true, true};
   bool zin[4];
   f32x4 dr[4];
   bool din[4];
@@ -157,9 +158,16 @@ __global__ __launch_bounds__(NT) void wgrad_bf16_kernel(const WgradArgs a) {
       else
         zr[p] = *reinterpret_cast<const f32x4*>(a.x + off);
       if constexpr (need_gn) {
-        const int64_t so = inb ? (int64_t)n * d.Cin + zc : (int64_t)0;
-        zmu[p] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
-        zsc[p] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
+        // the thread's four rows are consecutive output pixels: they lie in at most two images (Ho Wo >= 4,
+        // checked by the entry point) -- the table rows of the first and the last row's image, a select per row
+        // (half the table loads; they were half of the loop's vector-memory instructions)
+        if (p == 0 || p == 3) {
+          const bool zok = z_on && zc < d.Cin;
+          const int64_t so = zok ? (int64_t)min(n, d.N - 1) * d.Cin + zc : (int64_t)0;   // (rows past the end: masked)
+          zmu[p ? 1 : 0] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
+          zsc[p ? 1 : 0] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
+        }
+        zfirst[p] = n == rn[0];
       }
       const bool ok = mok && d_on && dcol < d.Cout;
       din[p] = ok;
@@ -195,7 +203,8 @@ __global__ __launch_bounds__(NT) void wgrad_bf16_kernel(const WgradArgs a) {
         for (int e = 0; e < 4; ++e) {
           float pv;
           if constexpr (need_gn)
-            pv = wg_pro<PRO>(zr[p][e], zmu[p][e], zsc[p][e], zbeta[e], d.in_scale, d.in_shift);
+            pv = wg_pro<PRO>(zr[p][e], zfirst[p] ? zmu[0][e] : zmu[1][e], zfirst[p] ? zsc[0][e] : zsc[1][e], zbeta[e],
+                             d.in_scale, d.in_shift);
           else
             pv = wg_pro<PRO>(zr[p][e], 0.f, 0.f, 0.f, d.in_scale, d.in_shift);
           zv[p][e] = (zin[p] && (zc + e < d.Cin)) ? pv : 0.f;
