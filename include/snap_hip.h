@@ -885,6 +885,16 @@ int snap_epilogue_bwd_colsum_wsum_half(const void* dy, const void* y, void* out,
                                        void* workspace, size_t workspace_bytes, int32_t half_kind,
                                        const float* wsrc, const int32_t* wrows, int64_t wstride,
                                        int32_t wrelu, float* wsum, void* stream);
+/* ... plus (C == 256) the DATA gradient of that channel: dtail[wrows[r] * dstride .. + 3] =
+ * (sum_c out[r, c] * round_to_element_type(wtail[c]), 0, 0, 0) -- dtail points at the channel's column of
+ * the layer-0 input gradient (f32 rows of dstride floats, 16-byte aligned): with it the data-gradient GEMM
+ * in front writes only the whole 128-column tiles (snap_conv2d with Cout_stride > Cout). */
+int snap_epilogue_bwd_colsum_wsum_tail_half(const void* dy, const void* y, void* out, int64_t M, int32_t C,
+                                            int32_t relu, const int32_t* row_count, float* colsum,
+                                            void* workspace, size_t workspace_bytes, int32_t half_kind,
+                                            const float* wsrc, const int32_t* wrows, int64_t wstride,
+                                            int32_t wrelu, float* wsum, const float* wtail, float* dtail,
+                                            int64_t dstride, void* stream);
 int snap_colsum_f32(const float* a, int64_t M, int32_t C, float* out, int32_t accumulate,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* ... over the listed rows only: sum_{m < *row_count} a[rows[m], :]  (rows / row_count may be NULL). */

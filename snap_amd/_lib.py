@@ -109,6 +109,9 @@ SIGNATURES = {
     'snap_epilogue_bwd_colsum_half': (c_int, [ptr, ptr, ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, c_int, ptr]),
     'snap_epilogue_bwd_colsum_wsum_half': (
         c_int, [ptr, ptr, ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, c_int, ptr, ptr, c_i64, c_int, ptr, ptr]),
+    'snap_epilogue_bwd_colsum_wsum_tail_half': (
+        c_int, [ptr, ptr, ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, c_int, ptr, ptr, c_i64, c_int, ptr,
+                ptr, ptr, c_i64, ptr]),
     'snap_conv2d_wgrad_half_f32': (
         c_int,
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr, ptr, ptr, c_int,

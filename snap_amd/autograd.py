@@ -473,11 +473,18 @@ def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
   g1 = ops.dense(g, W1.t().contiguous(), None, cin=D1, rows_in=index, row_count=count, out_half=True)
   split = ops_bwd.dense_wgrad_tail(cin0, Cs) if need[3] else None
   tail_row = None
+  gi = None
   if split is not None and split[1] == 1:
     # a single channel above the 128-channel tiles (the fusion MLP's 257th input: the view score):
-    # its kernel-gradient row leaves the gate pass as a weighted column sum
+    # its kernel-gradient row leaves the gate pass as a weighted column sum -- and, where the input
+    # gradient is wanted and the channel sits in the last (zero-padded) quad of the rows, so does its
+    # data gradient: the GEMM below then writes 256 columns (two 128-column tiles) instead of 260 (three)
+    dtail = None
+    if need[0] and MASKED_MLP_DX_TAIL and H == 256 and split[0] + 4 == Cs:
+      gi = torch.empty((M, Cs), dtype=torch.float32, device=x2.device)
+      dtail = (W0[split[0]].contiguous(), gi)
     g1, db0, tail_row = ops_bwd.epilogue_bwd_colsum(g1, h0, None, relu=True, row_count=count,
-                                                    wsum=(x2, split[0], index, ctx.relu_input))
+                                                    wsum=(x2, split[0], index, ctx.relu_input), dtail=dtail)
   else:
     g1, db0 = ops_bwd.epilogue_bwd_colsum(g1, h0, None, relu=True, row_count=count)
   if need[4]:
@@ -488,10 +495,14 @@ def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
                                         row_count=count, tail_row=tail_row)
   dx = None
   if need[0]:
-    Wt = W0.t()
-    if Cs != cin0:
-      Wt = F.pad(Wt, (0, Cs - cin0))
-    gi = ops.dense(g1, Wt.contiguous(), None, cin=H, rows_out=index, row_count=count)   # half in, f32 rows out
+    if gi is not None:     # (columns split[0] .. Cs of the listed rows: written by the gate pass above)
+      ops.dense(g1, W0[:split[0]].t().contiguous(), None, cin=H, rows_out=index, row_count=count, out=gi,
+                out_stride=Cs)
+    else:
+      Wt = W0.t()
+      if Cs != cin0:
+        Wt = F.pad(Wt, (0, Cs - cin0))
+      gi = ops.dense(g1, Wt.contiguous(), None, cin=H, rows_out=index, row_count=count)   # half in, f32 rows out
     ops.fill_masked_rows_(gi, mask)
     if ctx.relu_input:
       gi = ops_bwd.epilogue_bwd(gi, x2, None, relu=True)
@@ -501,6 +512,7 @@ def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
 
 _MaskedRowsMLP._backward_half = staticmethod(_masked_rows_mlp_backward_half)
 MASKED_MLP_HALF = True      # (tests: False pins the f32-tensor formulation; same arithmetic)
+MASKED_MLP_DX_TAIL = True   # (tests: False keeps the 257th channel's data gradient inside the GEMM)
 
 
 def masked_rows_mlp(x, mask, relu_input, weights_and_biases):

@@ -499,12 +499,17 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_kernel(
 // wrelu): the kernel-gradient row of ONE extra input channel of the layer in front (the 257th channel
 // of the fusion MLP: dW0[256, :] = x[:, 256]^T g) taken in this pass instead of a third 128-channel
 // tile in the GEMM.
-template <typename ET, bool WSUM = false>
+// TAIL (with WSUM, C == 256: a row is one wave): also the DATA gradient of that extra channel,
+// dtail[wrows[r] * dstride .. +3] = (sum_c out[r, c] * round(wtail[c]), 0, 0, 0) -- the four columns of the
+// layer-0 input gradient (row stride 260 = 257 padded to quads) that would otherwise cost the GEMM in front a
+// third, almost empty, 128-column tile.
+template <typename ET, bool WSUM = false, bool TAIL = false>
 __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
     const ET* __restrict__ dy, const ET* __restrict__ y, ET* __restrict__ out, int64_t M, int C, int relu,
     int64_t rows_per_block, const int32_t* __restrict__ row_count, float* __restrict__ partial,
     const float* __restrict__ wsrc = nullptr, const int32_t* __restrict__ wrows = nullptr, int64_t wstride = 0,
-    int wrelu = 0, float* __restrict__ partial2 = nullptr) {
+    int wrelu = 0, float* __restrict__ partial2 = nullptr, const float* __restrict__ wtail = nullptr,
+    float* __restrict__ dtail = nullptr, int64_t dstride = 0) {
   typedef ET etx4 __attribute__((ext_vector_type(4)));
   __shared__ float red[256 * 4];
   const int cbase = blockIdx.y * 1024;
@@ -518,6 +523,11 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
   const int64_t r1 = min(Msum, r0 + rows_per_block);
   float t[4] = {0.f, 0.f, 0.f, 0.f};
   float u[4] = {0.f, 0.f, 0.f, 0.f};
+  float wt[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wt[e] = (float)(ET)wtail[c0 + e];      // (rounded like the GEMM's weight image)
+  }
   if (tp < PW) {
     for (int64_t r = r0 + tp; r < r1; r += PW) {
       etx4 g = *reinterpret_cast<const etx4*>(dy + r * C + c0);
@@ -536,6 +546,12 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
         w = (float)(ET)w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] += w * (float)g[e];
+      }
+      if constexpr (TAIL) {
+        float dp = ((float)g[0] * wt[0] + (float)g[1] * wt[1]) + ((float)g[2] * wt[2] + (float)g[3] * wt[3]);
+        dp = wave_sum(dp);                                              // QW == 64: the row is this wave
+        if (tq == 0)
+          *reinterpret_cast<f32x4*>(dtail + (int64_t)(wrows ? wrows[r] : (int32_t)r) * dstride) = f32x4{dp, 0.f, 0.f, 0.f};
       }
     }
   }
@@ -813,7 +829,22 @@ extern "C" int snap_epilogue_bwd_colsum_wsum_half(const void* dy, const void* y,
                                                   int32_t half_kind, const float* wsrc,
                                                   const int32_t* wrows, int64_t wstride, int32_t wrelu,
                                                   float* wsum, void* stream) {
+  return snap_epilogue_bwd_colsum_wsum_tail_half(dy, y, out, M, C, relu, row_count, colsum, workspace, workspace_bytes,
+                                                 half_kind, wsrc, wrows, wstride, wrelu, wsum, nullptr, nullptr, 0,
+                                                 stream);
+}
+
+extern "C" int snap_epilogue_bwd_colsum_wsum_tail_half(const void* dy, const void* y, void* out, int64_t M,
+                                                       int32_t C, int32_t relu, const int32_t* row_count,
+                                                       float* colsum, void* workspace, size_t workspace_bytes,
+                                                       int32_t half_kind, const float* wsrc,
+                                                       const int32_t* wrows, int64_t wstride, int32_t wrelu,
+                                                       float* wsum, const float* wtail, float* dtail,
+                                                       int64_t dstride, void* stream) {
   if ((wsrc != nullptr) != (wsum != nullptr)) return SNAP_ERR_NULL;
+  if ((wtail != nullptr) != (dtail != nullptr)) return SNAP_ERR_NULL;
+  if (wtail && (!wsrc || C != 256 || dstride < 4 || dstride % 4 != 0 || (reinterpret_cast<uintptr_t>(dtail) & 15)))
+    return SNAP_ERR_UNSUPPORTED;
   if (!dy || !out || !colsum || !workspace) return SNAP_ERR_NULL;
   if (relu && !y) return SNAP_ERR_NULL;
   if (half_kind != 1 && half_kind != 2) return SNAP_ERR_UNSUPPORTED;
@@ -830,14 +861,18 @@ extern "C" int snap_epilogue_bwd_colsum_wsum_half(const void* dy, const void* y,
   const dim3 grid(S, (unsigned)snap_cdiv(C, 1024));
   float* p1 = static_cast<float*>(workspace);
   float* p2 = p1 + (size_t)S * C;
-#define SNAP_GATE_LAUNCH(ET_, W_)                                                                       \
-  hipLaunchKernelGGL((epilogue_bwd_colsum_half_kernel<ET_, W_>), grid, dim3(256), 0, s,                  \
+#define SNAP_GATE_LAUNCH(ET_, W_, T_)                                                                   \
+  hipLaunchKernelGGL((epilogue_bwd_colsum_half_kernel<ET_, W_, T_>), grid, dim3(256), 0, s,              \
                      static_cast<const ET_*>(dy), static_cast<const ET_*>(y), static_cast<ET_*>(out), M, C, \
-                     relu, rpb, row_count, p1, wsrc, wrows, wstride, wrelu, p2)
+                     relu, rpb, row_count, p1, wsrc, wrows, wstride, wrelu, p2, wtail, dtail, dstride)
   if (half_kind == 2) {
-    if (wsrc) SNAP_GATE_LAUNCH(_Float16, true); else SNAP_GATE_LAUNCH(_Float16, false);
+    if (wtail) SNAP_GATE_LAUNCH(_Float16, true, true);
+    else if (wsrc) SNAP_GATE_LAUNCH(_Float16, true, false);
+    else SNAP_GATE_LAUNCH(_Float16, false, false);
   } else {
-    if (wsrc) SNAP_GATE_LAUNCH(__bf16, true); else SNAP_GATE_LAUNCH(__bf16, false);
+    if (wtail) SNAP_GATE_LAUNCH(__bf16, true, true);
+    else if (wsrc) SNAP_GATE_LAUNCH(__bf16, true, false);
+    else SNAP_GATE_LAUNCH(__bf16, false, false);
   }
 #undef SNAP_GATE_LAUNCH
   SNAP_CHECK_LAUNCH();

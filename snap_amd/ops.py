@@ -377,7 +377,7 @@ def conv2d(
     x, w, *, stride=1, padding=((0, 0), (0, 0)), cin=None, prologue=PRO_NONE,
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
-    emit_gn_stats=None, math=None, gelu=False, res_init=None, ps_tile=None, out_half=False,
+    emit_gn_stats=None, math=None, gelu=False, res_init=None, ps_tile=None, out_half=False, out_stride=None,
 ):
   """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
@@ -402,7 +402,9 @@ def conv2d(
   out_half (training-precision engines 'bf16' / 'fp16' only): the result is written ONLY rounded to the
   engine's element type and returned as a bf16 / f16 tensor (the hidden activations and inter-layer
   gradients of the masked MLP: every consumer rounds them to that type anyway).
-  Returns y [N,Ho,Wo,Cout].
+  out_stride (with ``out``, a multiple of 4 >= Cout): out's rows hold out_stride floats and the result goes
+  to their first Cout (the other columns are not touched); no statistics, residual or up-sampling epilogue.
+  Returns y [N,Ho,Wo,Cout] (``out`` itself, [.., out_stride], with out_stride).
   """
   lib = _lib.load()
   ps = isinstance(x, PreSplit)
@@ -458,8 +460,14 @@ def conv2d(
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
   else:
     y = _f32(out, 'out')
-    if y.numel() != N * Ho * Wo * Cout:
+    if out_stride is not None:
+      if (out_stride % 4 or out_stride < Cout or y.numel() != N * Ho * Wo * out_stride or emit_gn_stats is not None
+          or residual is not None or up_prev is not None or isinstance(x, PreSplit)):
+        raise ValueError('conv2d: out_stride needs out [rows, out_stride], out_stride % 4 == 0, a plain epilogue')
+    elif y.numel() != N * Ho * Wo * Cout:
       raise ValueError('conv2d: out has the wrong size')
+  if out_stride is not None and out is None:
+    raise ValueError('conv2d: out_stride goes with out')
   for t, nm in ((rows_in, 'rows_in'), (rows_out, 'rows_out'), (row_count, 'row_count')):
     if t is not None:
       _chk(t, torch.int32, nm)
@@ -491,7 +499,7 @@ def conv2d(
     if row_mask.numel() != N * Ho * Wo:
       raise ValueError('conv2d: row_mask size')
   d = _lib.SnapConvDesc(
-      N, H, W, Cin, Cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout, prologue,
+      N, H, W, Cin, Cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout if out_stride is None else int(out_stride), prologue,
       epi, float(in_affine[0]), float(in_affine[1]),
   )
   if CONV_TILE:
@@ -802,10 +810,16 @@ def packed_rot_image(w, math='bf16'):
 
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
           row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None,
-          gelu=False, residual=None, out_half=False):
-  """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1)."""
+          gelu=False, residual=None, out_half=False, out_stride=None):
+  """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1).  out_stride: ``conv2d``."""
   lead = x.shape[:-1]
   M = int(np.prod(lead)) if len(lead) else 1
+  if out_stride is not None:
+    conv2d(x.reshape(1, 1, M, x.shape[-1]), kernel.reshape(1, 1, *kernel.shape),
+           cin=cin if cin is not None else kernel.shape[0], prologue=prologue, bias=bias, relu=relu, row_mask=row_mask,
+           rows_in=rows_in, rows_out=rows_out, row_count=row_count, out=out, math=math, gelu=gelu,
+           out_stride=out_stride)
+    return out
   y = conv2d(
       x.reshape(1, 1, M, x.shape[-1]), kernel.reshape(1, 1, *kernel.shape),
       cin=cin if cin is not None else kernel.shape[0], prologue=prologue,

@@ -231,14 +231,18 @@ def epilogue_bwd(dy, y=None, row_mask=None, relu=False):
   return out
 
 
-def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None, wsum=None):
+def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None, wsum=None, dtail=None):
   """``epilogue_bwd`` and the column sums of its output (over the first *row_count rows) in one
   pass -> (gated dy, [C] sums); falls back to the two passes for widths the kernel does not take.
   dy / y in bf16 / f16 (both): the half kernel, gated dy in the same type.  wsum (half kernel only) =
   (x2 [rows, Cs] f32, channel, row list or None, relu): a third result, sum_r x2[rows[r], channel] *
   out[r, :] with the weight rounded to the element type -- one extra input channel's kernel-gradient
-  row of the layer in front, in the same pass."""
+  row of the layer in front, in the same pass.  dtail (with wsum, C == 256) = (w_row [C] f32, dx [rows, Cs]
+  f32): also that channel's DATA gradient, dx[rows[r], channel : channel + 4] = (out[r, :] . round(w_row),
+  0, 0, 0) (``channel + 4 == Cs``: the zero padding of the row)."""
   lib = _lib.load()
+  if dtail is not None and wsum is None:
+    raise ValueError('epilogue_bwd_colsum: dtail goes with wsum')
   if wsum is not None and dy.dtype not in (torch.bfloat16, torch.float16):
     raise ValueError('epilogue_bwd_colsum: wsum goes with half tensors')
   if dy.dtype in (torch.bfloat16, torch.float16):
@@ -265,11 +269,20 @@ def epilogue_bwd_colsum(dy, y=None, row_mask=None, relu=False, row_count=None, w
     if wrows is not None:
       ops._chk(wrows, torch.int32, 'wsum rows')
     wout = torch.empty(C, dtype=torch.float32, device=dy.device)
-    st = lib.snap_epilogue_bwd_colsum_wsum_half(
+    wt = dt = None
+    dstride = 0
+    if dtail is not None:
+      w_row, dx = dtail
+      _f32(w_row, 'dtail weights'); _f32(dx, 'dtail dx')
+      dstride = int(dx.shape[-1])
+      if w_row.numel() != C or C != 256 or int(channel) + 4 != dstride or dstride % 4:
+        raise ValueError('epilogue_bwd_colsum: dtail needs C == 256 and the channel in the last quad of dx rows')
+      wt, dt = ctypes.c_void_p(w_row.data_ptr()), ctypes.c_void_p(dx.data_ptr() + 4 * int(channel))
+    st = lib.snap_epilogue_bwd_colsum_wsum_tail_half(
         _p(dy), _p(y), _p(out), M, C, int(relu), _p(row_count), _p(sums), _p(ws), ws.numel() * 4, kind,
         ctypes.c_void_p(x2.data_ptr() + 4 * int(channel)), _p(wrows), int(x2.shape[-1]), int(bool(wrelu)),
-        _p(wout), _stream())
-    _lib.check(st, 'snap_epilogue_bwd_colsum_wsum_half')
+        _p(wout), wt, dt, dstride, _stream())
+    _lib.check(st, 'snap_epilogue_bwd_colsum_wsum_tail_half')
     return out, sums, wout
   _f32(dy, 'dy')
   C = dy.shape[-1]

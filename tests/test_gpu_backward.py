@@ -872,6 +872,17 @@ def test_masked_rows_mlp_half_hidden_tensors_keep_the_bits(layers_, in_dim, stri
   for nm, a, b in zip(('dx', 'dW0', 'db0', 'dW1', 'db1'), g_h, g_f):
     if nm == 'db0':
       assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()), nm
+    elif nm == 'dx' and in_dim % 128 == 1:
+      # (that channel's data gradient is a row-wise dot product of the gate pass on the half path --
+      #  ``MASKED_MLP_DX_TAIL`` --, a column of the GEMM on the other; the padding columns stay zero)
+      c = in_dim - 1
+      assert torch.equal(a[:, :c], b[:, :c]), (nm, float((a[:, :c] - b[:, :c]).abs().max()))
+      assert float((a[:, c] - b[:, c]).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, nm
+      assert bool((a[:, in_dim:] == 0).all()) and bool((b[:, in_dim:] == 0).all())
+      monkeypatch.setattr(ag, 'MASKED_MLP_DX_TAIL', False)
+      _, g_t = run(True)
+      monkeypatch.setattr(ag, 'MASKED_MLP_DX_TAIL', True)
+      assert torch.equal(g_t[0], b), 'dx without the tail pass'
     elif nm == 'dW0' and in_dim % 128 == 1:
       # (the one channel above the 128-channel tiles is a weighted column sum of the gate pass on the
       #  half path, a narrow GEMM launch on the other: same rounded operands, another summation order)
