@@ -43,7 +43,11 @@ template <> struct Elem<true> {
   }
 };
 
-template <int BM, int BN, int PRO, bool F16, bool YH = false>
+// GNT (as conv_split.hip): the GroupNorm operands of the slab's 32 channels -- mean and rstd * gamma of the (at
+// most two) images a row tile of BM <= Ho Wo pixels touches, and beta -- come from a 640-byte LDS table that 40
+// lanes fetch by LDS-DMA two slabs ahead (three-slot ring; the slab's closing barrier publishes it), instead of
+// two float4 global loads per staged ROW: those were two thirds of the loop's vector-memory instructions.
+template <int BM, int BN, int PRO, bool F16, bool YH = false, bool GNT = false>
 __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
   typedef Elem<F16> E;
   typedef typename E::T ET;
@@ -61,9 +65,13 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
   constexpr int kSlabFloats = 2 * (A_ST + B_ST);
   constexpr int kStageFloats = 64 * BN;
   constexpr int kSmemFloats = kSlabFloats > kStageFloats ? kSlabFloats : kStageFloats;
-  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
+  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  constexpr bool gn_tab = need_gn && GNT;
+  constexpr int kGnRing = 640;            // bytes per table: [mu n0 | sc n0 | mu n1 | sc n1 | beta] x 32 channels
+  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats + (gn_tab ? 3 * kGnRing / 4 : 0)];
   char* const Ab = reinterpret_cast<char*>(smem);
   char* const Bb = reinterpret_cast<char*>(smem + 2 * A_ST);
+  char* const Gt = reinterpret_cast<char*>(smem + kSmemFloats);
 
   const SnapConvDesc& d = a.d;
   const int tid = threadIdx.x;
@@ -83,16 +91,20 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
   const int m0 = row_t * BM;
   const int n0 = col_t * BN;
   const int HoWo = d.Ho * d.Wo;
-  constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+  const int n_first = m0 / HoWo;
+  const int m_split = (n_first + 1) * HoWo;   // first row of the tile's second image
+  const int n_second = min(n_first + 1, d.N - 1);
 
   int r_hb[AROWS], r_wb[AROWS];
   bool r_ok[AROWS];
   const float* r_px[AROWS];
   int64_t r_gn[AROWS];
+  int r_slot[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int row = (tid / QPR) + RPP * i;
     const int m = m0 + row;
+    r_slot[i] = m >= m_split ? 1 : 0;
     r_ok[i] = m < Meff;
     int mm = r_ok[i] ? m : 0;
     if (a.rows_in) mm = a.rows_in[mm];
@@ -146,14 +158,14 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
     const int c = ct * BK + 4 * akq;
     cur_c = c;
     const bool cvalid = c < d.Cin;
-    if constexpr (need_gn) xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
+    if constexpr (need_gn && !gn_tab) xbeta = *reinterpret_cast<const f32x4*>(a.gn_beta + (cvalid ? c : 0));
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const bool inb = tap_in[i] && cvalid;
       xin[i] = inb;
       const float* px = inb ? tap_px[i] + c : a.x;
       xa[i] = *reinterpret_cast<const f32x4*>(px);
-      if constexpr (need_gn) {
+      if constexpr (need_gn && !gn_tab) {
         const int64_t so = inb ? r_gn[i] + c : (int64_t)0;
         xmu[i] = *reinterpret_cast<const f32x4*>(a.gn_mu + so);
         xsc[i] = *reinterpret_cast<const f32x4*>(a.gn_sc + so);
@@ -175,6 +187,22 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
                                        (lds_void_t*)(Bb + buf * (B_ST * 4) + 16 * slot), 16, 0, 0);
     }
   };
+  // GroupNorm table of channel tile `ctile` -> ring slot `ring` (lanes 0..39 of wave 0)
+  auto issue_gn = [&](int ring, int ctile) {
+    if constexpr (gn_tab) {
+      if (tid < 40) {
+        const int seg = tid >> 3;
+        const int c = ctile * BK + 4 * (tid & 7);
+        const float* base = seg == 4 ? a.gn_beta
+                                     : ((seg & 1) ? a.gn_sc : a.gn_mu) +
+                                           (int64_t)(seg >= 2 ? n_second : n_first) * d.Cin;
+        const void* src = c < d.Cin ? static_cast<const void*>(base + c)
+                                    : static_cast<const void*>(kZeroChunk);
+        __builtin_amdgcn_global_load_lds((cglobal_void_t*)src,
+                                         (lds_void_t*)(Gt + ring * kGnRing + 16 * tid), 16, 0, 0);
+      }
+    }
+  };
   auto advance = [&]() {
     if (++ct == a.ctiles) {
       ct = 0;
@@ -183,11 +211,17 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
       set_tap();
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int buf, int ring) {
+    const float* const tb = reinterpret_cast<const float*>(Gt + ring * kGnRing);
+    if constexpr (gn_tab) xbeta = *reinterpret_cast<const f32x4*>(tb + 128 + 4 * akq);
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int row = (tid / QPR) + RPP * i;
       f32x4 v = xa[i];
+      if constexpr (gn_tab) {
+        xmu[i] = *reinterpret_cast<const f32x4*>(tb + r_slot[i] * 64 + 4 * akq);
+        xsc[i] = *reinterpret_cast<const f32x4*>(tb + r_slot[i] * 64 + 32 + 4 * akq);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float pv;
@@ -204,21 +238,36 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
   };
 
   const int l31 = lane & 31, lhi = lane >> 5;
+  int g_ct = ct;                 // channel tile of the next table to fetch
+  auto next_gct = [&]() { if (++g_ct == a.ctiles) g_ct = 0; };
+  int ring_cur = 0;              // ring slot of the slab being multiplied
   if (kt_begin < kt_end) {
+    if constexpr (gn_tab) {
+      issue_gn(0, g_ct); next_gct();
+      issue_gn(1, g_ct); next_gct();
+    }
     load_a();
     issue_b(0);
     advance();
-    store_a(0);
+    if constexpr (gn_tab) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();           // tables of slabs 0 and 1 visible to every wave
+    }
+    store_a(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
+    const int ring_next = ring_cur == 2 ? 0 : ring_cur + 1;
     if (more) {
       load_a();
       issue_b(cur ^ 1);
       advance();
+      if constexpr (gn_tab) {
+        if (kt + 2 < kt_end) { issue_gn(ring_next == 2 ? 0 : ring_next + 1, g_ct); next_gct(); }
+      }
     }
     const char* as = Ab + cur * (A_ST * 4);
     const char* bs = Bb + cur * (B_ST * 4);
@@ -241,7 +290,8 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = E::mfma(av[i], bv[j], acc[i][j]);
     }
-    if (more) store_a(cur ^ 1);
+    if (more) store_a(cur ^ 1, ring_next);
+    ring_cur = ring_next;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the B octets of slab kt+1 landed
     __syncthreads();
   }
@@ -411,9 +461,9 @@ __global__ __launch_bounds__(256) void conv_bf16_xh_kernel(const ConvArgs a) {
   conv_bf16_xh_body<BM, BN, F16>(a);
 }
 
-template <int BM, int BN, int PRO, bool F16 = false, bool YH = false>
+template <int BM, int BN, int PRO, bool F16 = false, bool YH = false, bool GNT = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs a) {
-  conv_bf16_body<BM, BN, PRO, F16, YH>(a);
+  conv_bf16_body<BM, BN, PRO, F16, YH, GNT>(a);
 }
 
 template <int BM, int BN, int PRO>
@@ -464,10 +514,25 @@ int launch(ConvArgs a, hipStream_t s) {
     } else {
       return SNAP_ERR_UNSUPPORTED;
     }
-  } else if (a.half)
-    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  } else {
+    constexpr bool need_gn = (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN);
+    // the LDS statistics table needs "a row tile touches at most two images"
+    const bool table = need_gn && a.d.Ho * a.d.Wo >= BM && !a.rows_in && !a.no_plain;   // (SNAP_TUNE_NO_PLAIN: A/B)
+    if constexpr (need_gn) {
+      if (table) {
+        if (a.half)
+          hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+        else
+          hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, false, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+      }
+    }
+    if (!table) {
+      if (a.half)
+        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, PRO, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+    }
+  }
   SNAP_CHECK_LAUNCH();
   if (a.ksplit > 1) {
     const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);

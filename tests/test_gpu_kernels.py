@@ -204,6 +204,27 @@ def test_conv_bf16_every_tile_variant(tile, monkeypatch):
   helpers.report(f'conv bf16 upsample-add tile {tile}', got, want, atol=5e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('math_', ['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,Cin,Cout,k,pro', [(3, 17, 17, 64, 256, 1, ops.PRO_GN_RELU), (2, 15, 13, 128, 200, 3, ops.PRO_RELU_GN),
+                                                  (5, 12, 11, 512, 128, 1, ops.PRO_GN_RELU), (2, 34, 34, 256, 64, 3, ops.PRO_GN_RELU)])
+def test_conv_bf16_groupnorm_table_keeps_the_bits(N, H, W, Cin, Cout, k, pro, math_, monkeypatch):
+  """Training-precision engines, GroupNorm prologue: the statistics of a slab's 32 channels come from an LDS table
+  fetched two slabs ahead (row tiles of <= Ho Wo pixels: at most two images) instead of two loads per staged row.
+  Same operands, same arithmetic: bit-identical to the per-row loader (``CONV_NO_PLAIN`` pins it), tiles that
+  straddle images and split-K shapes included."""
+  x = (rnd((N, H, W, Cin), 61) + 0.2).to(DEV)
+  w = rnd((k, k, Cin, Cout), 62, 1 / np.sqrt(k * k * Cin)).to(DEV)
+  gamma, beta = (rnd((Cin,), 63) + 1).to(DEV), (rnd((Cin,), 64) * 0.1).to(DEV)
+  mu, sc = ops.group_norm_stats(x, gamma, relu_first=pro == ops.PRO_RELU_GN)
+  pad = (k - 1) // 2
+  kw = dict(padding=((pad, pad), (pad, pad)), prologue=pro, gn=(mu, sc, beta), math=math_)
+  table = ops.conv2d(x, w, **kw)
+  monkeypatch.setattr(ops, 'CONV_NO_PLAIN', True)
+  rows = ops.conv2d(x, w, **kw)
+  assert torch.equal(table, rows), float((table - rows).abs().max())
+  assert float(table.abs().max()) > 0
+
+
 # split-bf16 engine (f32-grade accuracy on the bf16 matrix cores): compared with the EXACT conv of
 # the f32 operands, like the f32 engine.  'bf16x6' (3 parts, 6 products) is held to the f32
 # engine's own tolerance; 'bf16x3' (2 parts, 3 products, ~2^-17 per product) to 1e-4.
