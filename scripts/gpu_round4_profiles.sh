@@ -6,9 +6,6 @@ O=gpurun_out/r04p
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp PYTHONPATH=.
 R=$PWD
-# 1. the headline line exactly as the driver runs it (default flags: CPU baseline + the two extra legs)
-SNAP_BENCH_DUMP=$O/r04_c2_launches.json timeout 900 python bench.py > $O/bench_c2.log 2>&1
-tail -1 $O/bench_c2.log > $O/r04_c2_bench.json
 # 2. rocprofv3 kernel stats of the same workload (1 warm-up + 3 timed steps, no extra legs)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o snap -- \
   python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs) > $O/prof.log 2>&1
@@ -19,6 +16,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
     python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs) > $O/pmc_$C.log 2>&1
 done
 SNAP_GIT_HEAD=${SNAP_GIT_HEAD:-unknown} python tools/make_hbm_traffic.py $O/pmc_FETCH_SIZE/pmc_counter_collection.csv $O/pmc_WRITE_SIZE/pmc_counter_collection.csv $O/r04_c2_hbm_traffic.json 2 > $O/traffic.log 2>&1
+# 1. the headline line exactly as the driver runs it (default flags: CPU baseline + the extra legs), AFTER the
+#    traffic record of these sources exists (bench.py reads profiles/r04_c2_hbm_traffic.json: traffic_stale false)
+cp $O/r04_c2_hbm_traffic.json profiles/r04_c2_hbm_traffic.json 2>/dev/null
+SNAP_BENCH_DUMP=$O/r04_c2_launches.json timeout 900 python bench.py > $O/bench_c2.log 2>&1
+tail -1 $O/bench_c2.log > $O/r04_c2_bench.json
 # 4. utilisation counters
 i=0
 for C in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY" "SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do
@@ -52,6 +54,8 @@ SNAP_BENCH_DUMP=$O/r04_c3_train_bf16_launches.json timeout 300 python bench.py -
 cp $O/prof_c3/snap_kernel_stats.csv $O/r04_c3_train_bf16_kernel_stats.csv 2>/dev/null
 timeout 300 python bench.py --workload c5 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/r04_c5_vit_bench.json
 timeout 300 python bench.py --mode train --workload c3 --precision fp16 --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/r04_c3_train_fp16_bench.json
+python tools/family_table.py $O/r04_c3_train_bf16_launches.json > $O/r04_c3_train_bf16_layers.txt 2>&1
+timeout 200 python tools/wgrad_bench.py 2>/dev/null | tail -1 > $O/r04_wgrad_bench.json
 # 7. the operand path's own ceiling (global -> LDS by LDS-DMA, no compute): tools/lds_dma_probe.hip
 [ -x tools/lds_dma_probe ] && timeout 120 ./tools/lds_dma_probe > $O/r04_lds_dma_probe.log 2>&1
 # 8. whole-scene parity on the bench's configuration (one oracle run) + the eval variant
