@@ -234,14 +234,18 @@ def reduce_batch_metrics_tensor(metrics: Dict[str, torch.Tensor], batch_mask: to
   masked means on the device) -- ONE stacked collective, no per-metric ``float()``."""
   if not metrics:
     return [], torch.zeros(0, dtype=torch.float64, device=batch_mask.device)
-  keys = sorted(metrics)
-  keep_b = batch_mask.to(torch.bool)
-  rows = []
-  for k in keys:
-    v = metrics[k].to(torch.float64)
-    keep = keep_b & torch.isfinite(v)
-    rows.append(torch.stack([torch.where(keep, v, torch.zeros_like(v)).sum(), keep.to(torch.float64).sum()]))
-  flat = torch.stack(rows)
+  # one [K, B] tensor instead of ~8 launches per metric (17 metrics at C3: ~150 of the step's ~520 torch
+  # launches): the metrics are stacked per dtype (the key order that comes back says which row is which; it is
+  # the same on every rank -- sorted keys, grouped by dtype in order of first appearance)
+  groups = {}
+  for k in sorted(metrics):
+    groups.setdefault(metrics[k].dtype, []).append(k)
+  keys = [k for ks in groups.values() for k in ks]
+  B = batch_mask.numel()
+  V = torch.cat([torch.stack([metrics[k].reshape(-1).expand(B) for k in ks]).to(torch.float64)
+                 for ks in groups.values()])
+  keep = batch_mask.to(torch.bool).reshape(1, -1) & torch.isfinite(V)
+  flat = torch.stack([torch.where(keep, V, 0.0).sum(1), keep.to(torch.float64).sum(1)], 1)
   if _exchanges(group):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
   return keys, flat[:, 0] / torch.clamp(flat[:, 1], min=1.0)

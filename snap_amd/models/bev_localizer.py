@@ -36,6 +36,19 @@ def build_query_frustum_grid(cell_size, depth, filter_points_in_fov=False, hfov_
   return grid, grid_p_view, q_xy_p
 
 
+_CONSTS = {}
+
+
+def _const(values, like):
+  """Small constant vector on ``like``'s device, uploaded once (a host -> device copy inside a step stalls the
+  launch queue)."""
+  key = (tuple(values), like.dtype, like.device)
+  t = _CONSTS.get(key)
+  if t is None:
+    t = _CONSTS[key] = torch.tensor(values, dtype=like.dtype, device=like.device)
+  return t
+
+
 class BEVLocalizer(base.Module):
   """Estimate the relative pose between a pair of overlapping scenes."""
 
@@ -287,14 +300,20 @@ class BEVLocalizerModel(base.BaseModel):
         'loc/err_max_rotation': dr,
         'loc/recall_top1': torch.argmax(pred['scores_poses'], dim=-1) == 0,
     }
-    for t in [0.5, 1, 2, 5]:
-      metrics[f'loc/recall_max_{t}m'] = dt < t
-      metrics[f'loc/recall_max_{t}°'] = dr < t
+    # (the threshold families as one comparison each: the dict entries are rows of the stacked results)
+    ts = [0.5, 1, 2, 5]
+    tt = _const(ts, dt).reshape(-1, *([1] * dt.dim()))
+    rec_t, rec_r = dt[None] < tt, dr[None] < tt
+    for i, t in enumerate(ts):
+      metrics[f'loc/recall_max_{t}m'] = rec_t[i]
+      metrics[f'loc/recall_max_{t}°'] = rec_r[i]
     if self.config.add_temperature and model_params is not None:
       metrics['loc/temperature'] = model_params['temperature'].repeat(len(nll))
-    for dt_thresh, dr_thresh in [(0.5, 1), (1, 2), (2, 4)]:
-      recall = (dr_samples < dr_thresh) & (dt_samples < dt_thresh)
-      metrics[f'loc/recall_samples_{dt_thresh}m_{dr_thresh}°'] = (
-          recall[..., 1:].to(torch.float32).mean(-1)
-      )
+    pairs = [(0.5, 1), (1, 2), (2, 4)]
+    shape = (-1, *([1] * dt_samples.dim()))
+    td = _const([p[0] for p in pairs], dt_samples).reshape(shape)
+    tr = _const([p[1] for p in pairs], dr_samples).reshape(shape)
+    recall = ((dr_samples[None] < tr) & (dt_samples[None] < td))[..., 1:].to(torch.float32).mean(-1)
+    for i, (dt_thresh, dr_thresh) in enumerate(pairs):
+      metrics[f'loc/recall_samples_{dt_thresh}m_{dr_thresh}°'] = recall[i]
     return losses, metrics

@@ -223,7 +223,7 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
       with torch.no_grad():
         _adam_update_(leaves, grads, state.m, state.v, state.opt_count + 1, lr)
   with torch.no_grad():
-    per_example = {k: v.detach().to(torch.float32) for k, v in metrics.items()}
+    per_example = {k: v.detach() for k, v in metrics.items()}      # (stacked per dtype and widened once by the reduce)
     for k, v in losses.items():
       per_example[f'loss/{k}'] = v.detach()
     keys, means = sdist.reduce_batch_metrics_tensor(per_example, batch['batch_mask'], group)
