@@ -383,6 +383,79 @@ __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float* __restri
   *reinterpret_cast<vec_t*>(dx + ((int64_t)n * H * W + (int64_t)hi * W + wi) * C + VEC * cq) = g;
 }
 
+// The same VJP, tiled (C % 4 == 0): a workgroup owns 16 x 16 input pixels x 16 channel quads.  Phase 1 reads every
+// window that touches them ONCE (9 x 9 windows: nine float4 per window and quad instead of 36 per input pixel) and
+// keeps, per (window, channel), the 9-bit set of positions that receive the window's gradient -- the first maximum
+// in scan order, plus every NaN position (exactly the set the per-pixel test above selects: a NaN compares neither
+// greater nor equal).  Phase 2: an input pixel adds dy of its (at most four) windows, in the same order as above:
+// bit-identical.  0.89 -> ~0.3 ms on the C3 root output (20 x 272 x 272 x 64).
+__global__ __launch_bounds__(256) void max_pool_bwd_tiled_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, int N, int H, int W,
+                                                                 int C, int Ho, int Wo, int tiles_x) {
+  __shared__ uint16_t sel[81 * 16 * 4];          // [window 9 x 9][quad][channel]: position set
+  const int n = blockIdx.z;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int q0 = blockIdx.y * 16;                // first channel quad of this workgroup
+  const int CQ = C >> 2;
+  const int ho0 = ty * 8, wo0 = tx * 8;          // first window; owned input pixels: rows 2 ho0 .., cols 2 wo0 ..
+  const float* const xn = x + (int64_t)n * H * W * C;
+  const float* const dyn = dy + (int64_t)n * Ho * Wo * C;
+  for (int it = threadIdx.x; it < 81 * 16; it += 256) {
+    const int q = it & 15, w = it >> 4;
+    const int wy = w / 9, wx = w - wy * 9;
+    const int ho = ho0 + wy, wo = wo0 + wx;
+    uint16_t m[4] = {0, 0, 0, 0};
+    if (ho < Ho && wo < Wo && q0 + q < CQ) {
+      float best[4] = {0.f, 0.f, 0.f, 0.f};
+      int bi[4] = {-1, -1, -1, -1};
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) {
+        const int h2 = ho * 2 - 1 + dh;
+        if (h2 < 0 || h2 >= H) continue;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+          const int w2 = wo * 2 - 1 + dw;
+          if (w2 < 0 || w2 >= W) continue;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xn + ((int64_t)h2 * W + w2) * C + 4 * (q0 + q));
+          const int p = dh * 3 + dw;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (v[e] != v[e]) m[e] |= (uint16_t)(1u << p);
+            else if (bi[e] < 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = p; }
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (bi[e] >= 0) m[e] |= (uint16_t)(1u << bi[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sel[it * 4 + e] = m[e];
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < 256 * 16; it += 256) {
+    const int q = it & 15, px = it >> 4;
+    const int py = px >> 4, pxx = px & 15;
+    const int hi = 2 * ho0 + py, wi = 2 * wo0 + pxx;
+    if (hi >= H || wi >= W || q0 + q >= CQ) continue;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {
+      if (ho >= Ho) continue;
+      for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
+        if (wo >= Wo) continue;
+        const int p = (hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1));
+        const uint16_t* const mm = sel + (((ho - ho0) * 9 + (wo - wo0)) * 16 + q) * 4;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dyn + ((int64_t)ho * Wo + wo) * C + 4 * (q0 + q));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((mm[e] >> p) & 1) g[e] += d[e];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + ((int64_t)n * H * W + (int64_t)hi * W + wi) * C + 4 * (q0 + q)) = g;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // bilinear x2 up-sample backward: dprev[n,hp,wp,:] = sum over fine pixels whose taps hit it.
 // ---------------------------------------------------------------------------
@@ -760,7 +833,11 @@ extern "C" int snap_max_pool_3x3s2_bwd_f32(const float* x, const float* dy, floa
   const bool v4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
                                    reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
   const int64_t total = (int64_t)N * H * W * (v4 ? C / 4 : C);
-  if (v4)
+  if (v4 && N <= 65535 && snap_cdiv(C, 64) <= 65535) {
+    const int tiles_y = (int)snap_cdiv(H, 16), tiles_x = (int)snap_cdiv(W, 16);
+    hipLaunchKernelGGL(max_pool_bwd_tiled_kernel, dim3((unsigned)(tiles_y * tiles_x), (unsigned)snap_cdiv(C, 64), (unsigned)N),
+                       dim3(256), 0, static_cast<hipStream_t>(stream), x, dy, dx, N, H, W, C, Ho, Wo, tiles_x);
+  } else if (v4)
     hipLaunchKernelGGL(max_pool_bwd_kernel<4>, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, dy, dx, N, H, W, C, Ho, Wo);
   else

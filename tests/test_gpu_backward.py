@@ -326,6 +326,29 @@ def test_conv_wgrad_3x3_fused_taps(N, H, W, Cin, Cout, pro, math_):
   assert not torch.equal(got, per_tap) or N * H * W <= 32     # (two kernels: the A/B switch switches)
 
 
+@pytest.mark.parametrize('N,H,W,C', [(2, 37, 41, 64), (1, 16, 16, 8), (3, 33, 17, 72), (1, 5, 3, 4)])
+def test_max_pool_bwd_tiled_kernel(N, H, W, C):
+  """The tiled 3 x 3 / 2 max-pool VJP (a workgroup reads each window once and keeps the 9-bit set of positions
+  that receive its gradient): ties go to the first maximum in scan order (vs torch autograd in float64), and
+  with NaNs planted the result is bit-identical to the per-pixel kernel (reached through a channel count that
+  is not a multiple of four: the op is channel-wise)."""
+  g = torch.Generator().manual_seed(440)
+  x = torch.randint(-3, 4, (N, H, W, C), generator=g).float()            # many ties
+  Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+  dy = torch.randn(N, Ho, Wo, C, generator=g)
+  xd = x.double().requires_grad_(True)
+  F.max_pool2d(xd.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).backward(dy.double())
+  got = ops_bwd.max_pool_3x3s2_bwd(G(x), G(dy))
+  helpers.report(f'maxpool bwd tiled {N}x{H}x{W}x{C}', got, xd.grad.float(), atol=1e-6)
+  xn = x + torch.randn(N, H, W, C, generator=g) * 0.1
+  xn[torch.rand(N, H, W, C, generator=g) < 0.05] = float('nan')
+  xn[0, :3, :3] = float('nan')                                            # a whole window of NaNs
+  tiled = ops_bwd.max_pool_3x3s2_bwd(G(xn), G(dy))
+  c1 = C - 1                                                              # -> the scalar per-pixel kernel
+  plain = ops_bwd.max_pool_3x3s2_bwd(G(xn[..., :c1].contiguous()), G(dy[..., :c1].contiguous()))
+  assert torch.equal(tiled[..., :c1], plain)
+
+
 @pytest.mark.parametrize('k,stride,pad', [(1, 1, 0), (3, 1, 1), (3, 2, 1), (1, 2, 0)])
 def test_conv_dgrad_via_engine(k, stride, pad):
   from snap_amd import autograd as ag
