@@ -20,18 +20,31 @@ _GN_MODES = (ops.PRO_GN_RELU, ops.PRO_RELU_GN)
 # ----------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------
-def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None):
+def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None, accumulate_inplace=False):
   """d(prologue output) of a conv: transposed convolution through the forward engine.
   accumulate [N,H,W,roundup(Cin,4)]: added in the engine's epilogue (the data gradient of another
-  conv reading the same activation).
+  conv reading the same activation); accumulate_inplace: the caller owns that tensor and it may be
+  overwritten with the sum.
 
   dy [N,Ho,Wo,Cout]; w [KH,KW,Cin,Cout]; returns dz [N,H,W,roundup(Cin,4)] (channels
   past Cin are zero).
-  Stride > 1: dy is zero-dilated first (the few strided layers of the ResNet).
+  Stride > 1, 1 x 1 unpadded (the projection shortcuts): the GEMM runs over the Ho x Wo pixels that
+  have a gradient at all and is added into every stride-th pixel of the result.  Other strided
+  kernels: dy is zero-dilated first (the three strided 3 x 3 layers of a ResNet).
   """
   N, H, W, Cin = x_shape
   KH, KW, _, Cout = w.shape
   (pt, pb), (pl, pr) = padding
+  if stride > 1 and STRIDED_1X1_DGRAD and KH == 1 and KW == 1 and pt == pb == pl == pr == 0:
+    Ho, Wo = dy.shape[1:3]
+    t = conv_dgrad(dy, w, (N, Ho, Wo, Cin), 1, padding)             # [N, Ho, Wo, C4]: 1 / stride^2 of the rows
+    if accumulate is None:
+      out = torch.zeros((N, H, W, t.shape[-1]), dtype=torch.float32, device=dy.device)
+      out[:, :(Ho - 1) * stride + 1:stride, :(Wo - 1) * stride + 1:stride] = t
+    else:
+      out = accumulate if accumulate_inplace else accumulate.clone()
+      out[:, :(Ho - 1) * stride + 1:stride, :(Wo - 1) * stride + 1:stride] += t
+    return out
   if stride > 1:
     Ho, Wo = dy.shape[1:3]
     Hd, Wd = (Ho - 1) * stride + 1, (Wo - 1) * stride + 1
@@ -68,6 +81,9 @@ def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None):
     if twin is not None:
       return ops.conv2d(twin, w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
   return ops.conv2d(dy, w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
+
+
+STRIDED_1X1_DGRAD = True     # (tests: False keeps the zero-dilated formulation)
 
 
 def _own(grad):
@@ -227,7 +243,7 @@ class _SharedPrologueConvPair(torch.autograd.Function):
     if need[0] or need[3] or need[4]:
       N, H, W, C = x.shape
       dz = conv_dgrad(dy1, w1, (N, H, W, C), 1, pad0)
-      dz = conv_dgrad(dy2, w2, (N, H, W, C), ctx.stride2, pad0, accumulate=dz)
+      dz = conv_dgrad(dy2, w2, (N, H, W, C), ctx.stride2, pad0, accumulate=dz, accumulate_inplace=True)
       dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
           x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), ops.PRO_GN_RELU,
           half=ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None)

@@ -362,6 +362,31 @@ def test_conv_dgrad_via_engine(k, stride, pad):
   helpers.report(f'dgrad k{k} s{stride}', got, x.grad.float(), atol=3e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('math_', ['f32', 'bf16'])
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 11, 10, 64, 128), (3, 8, 8, 256, 512), (1, 17, 17, 100, 64)])
+def test_strided_1x1_dgrad_on_the_coarse_grid(N, H, W, Cin, Cout, math_, monkeypatch):
+  """The data gradient of a 1 x 1 / stride 2 projection: a GEMM over the Ho x Wo pixels that carry a gradient,
+  added into every second pixel of the accumulated tensor -- the same products in the same order as the
+  zero-dilated launch over all H x W pixels (bit-identical), with and without an accumulated gradient."""
+  from snap_amd import autograd as ag
+  monkeypatch.setattr(ops, 'MATMUL_PRECISION', math_)
+  Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+  dy, w = G(rnd((N, Ho, Wo, Cout), 450)), G(rnd((1, 1, Cin, Cout), 451, 1 / math.sqrt(Cin)))
+  C4 = (Cin + 3) // 4 * 4
+  acc = G(rnd((N, H, W, C4), 452))
+  pad0 = ((0, 0), (0, 0))
+  for accumulate in (None, acc):
+    new = ag.conv_dgrad(dy, w, (N, H, W, Cin), 2, pad0, accumulate=accumulate)
+    monkeypatch.setattr(ag, 'STRIDED_1X1_DGRAD', False)
+    old = ag.conv_dgrad(dy, w, (N, H, W, Cin), 2, pad0, accumulate=accumulate)
+    monkeypatch.setattr(ag, 'STRIDED_1X1_DGRAD', True)
+    assert new.shape == old.shape and torch.equal(new, old), float((new - old).abs().max())
+  assert torch.equal(acc, G(rnd((N, H, W, C4), 452)))                      # (not overwritten without the flag)
+  own = acc.clone()
+  out = ag.conv_dgrad(dy, w, (N, H, W, Cin), 2, pad0, accumulate=own, accumulate_inplace=True)
+  assert out.data_ptr() == own.data_ptr() and torch.equal(out, new)
+
+
 # -- GroupNorm backward -------------------------------------------------------------------
 @pytest.mark.parametrize('mode', [ops.PRO_GN_RELU, ops.PRO_RELU_GN])
 @pytest.mark.parametrize('C,HW', [(64, (9, 7)), (256, (5, 6)), (2048, (3, 2))])
