@@ -674,6 +674,47 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
   partial[(int64_t)blockIdx.x * C + c] = t;
 }
+// The same partial sums with every lane busy and several rows in flight (C % 4 == 0, C / 4 divides 256): a thread
+// owns one column quad and every PW-th row of the slab, four rows per iteration (independent float4 loads; the
+// per-column loop above has ONE 4-byte load in flight per thread and half the workgroup idle at C = 128: it ran at
+// the latency of 1920 dependent iterations, 294 us per GB).  The PW row phases are combined in a fixed order.
+__global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __restrict__ a, int64_t M, int C,
+                                                                int64_t rows_per_block, float* __restrict__ partial,
+                                                                const int32_t* __restrict__ rows,
+                                                                const int32_t* __restrict__ row_count) {
+  __shared__ float red[256 * 4];
+  const int QW = C >> 2, PW = 256 / QW;
+  const int tq = threadIdx.x % QW, tp = threadIdx.x / QW;
+  const int64_t Meff = row_count ? min((int64_t)*row_count, M) : M;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(Meff, r0 + rows_per_block);
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  int64_t r = r0 + tp;
+  for (; r + 3 * PW < r1; r += 4 * PW) {
+    int64_t i0 = r, i1 = r + PW, i2 = r + 2 * PW, i3 = r + 3 * PW;
+    if (rows) { i0 = rows[i0]; i1 = rows[i1]; i2 = rows[i2]; i3 = rows[i3]; }
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(a + i0 * C + 4 * tq);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(a + i1 * C + 4 * tq);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(a + i2 * C + 4 * tq);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(a + i3 * C + 4 * tq);
+    t += (v0 + v1) + (v2 + v3);
+  }
+  for (; r < r1; r += PW) {
+    const int64_t i = rows ? (int64_t)rows[r] : r;
+    t += *reinterpret_cast<const f32x4*>(a + i * C + 4 * tq);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = t[e];
+  __syncthreads();
+  if (tp == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+      for (int pp = 0; pp < PW; ++pp) s += red[(pp * QW + tq) * 4 + e];
+      partial[(int64_t)blockIdx.x * C + 4 * tq + e] = s;
+    }
+  }
+}
 // 32 columns x 8 slab groups per workgroup; fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial,
                                                             int S, int C, float* __restrict__ out,
@@ -983,8 +1024,12 @@ extern "C" int snap_colsum_rows_f32(const float* a, int64_t M, int32_t C, const 
   const int S = colsum_slabs(M);
   const int64_t rpb = (M + S - 1) / S;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(S, (unsigned)snap_cdiv(C, 256)), dim3(256), 0, s, a,
-                     M, C, rpb, static_cast<float*>(workspace), rows, row_count);
+  if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(S), dim3(256), 0, s, a, M, C, rpb,
+                       static_cast<float*>(workspace), rows, row_count);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(S, (unsigned)snap_cdiv(C, 256)), dim3(256), 0, s, a,
+                       M, C, rpb, static_cast<float*>(workspace), rows, row_count);
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)snap_cdiv(C, 32)), dim3(256), 0, s,
                      (const float*)workspace, S, C, out, accumulate);

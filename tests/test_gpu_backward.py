@@ -326,6 +326,27 @@ def test_conv_wgrad_3x3_fused_taps(N, H, W, Cin, Cout, pro, math_):
   assert not torch.equal(got, per_tap) or N * H * W <= 32     # (two kernels: the A/B switch switches)
 
 
+@pytest.mark.parametrize('M,C,listed', [(70001, 128, True), (5000, 96, False), (300007, 256, True), (1234, 160, True),
+                                        (4099, 1024, False), (9, 4, True)])
+def test_colsum_kernels(M, C, listed):
+  """Column sums (bias gradients) dense and over a row list with a device-side count: the vector kernel (column
+  quads x row phases, four rows in flight) where C / 4 divides 256, the per-column kernel elsewhere; fixed order
+  (two runs agree bit for bit)."""
+  g = torch.Generator().manual_seed(460)
+  a = torch.randn(M, C, generator=g)
+  if listed:
+    mask = torch.rand(M, generator=g) < 0.45
+    index, count = ops.compact_rows(G(mask))
+    got = ops_bwd.colsum(G(a), rows=index, row_count=count)
+    again = ops_bwd.colsum(G(a), rows=index, row_count=count)
+    ref = a[mask].double().sum(0).float()
+  else:
+    got, again = ops_bwd.colsum(G(a)), ops_bwd.colsum(G(a))
+    ref = a.double().sum(0).float()
+  assert torch.equal(got, again)
+  helpers.report(f'colsum {M}x{C}', got, ref, atol=3e-6 * math.sqrt(M) + 1e-5)
+
+
 @pytest.mark.parametrize('N,H,W,C', [(2, 37, 41, 64), (1, 16, 16, 8), (3, 33, 17, 72), (1, 5, 3, 4)])
 def test_max_pool_bwd_tiled_kernel(N, H, W, C):
   """The tiled 3 x 3 / 2 max-pool VJP (a workgroup reads each window once and keeps the 9-bit set of positions
