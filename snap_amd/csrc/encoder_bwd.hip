@@ -601,32 +601,57 @@ __global__ __launch_bounds__(256) void epilogue_bwd_colsum_half_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) wt[e] = (float)(ET)wtail[c0 + e];      // (rounded like the GEMM's weight image)
   }
-  if (tp < PW) {
-    for (int64_t r = r0 + tp; r < r1; r += PW) {
-      etx4 g = *reinterpret_cast<const etx4*>(dy + r * C + c0);
-      if (relu) {
-        const etx4 yv = *reinterpret_cast<const etx4*>(y + r * C + c0);
+  // four rows per iteration, every load of the four issued before the first use (one row per iteration ran at the
+  // latency of its two dependent loads: 1.65 TB/s); the sums are taken in row order as before: same bits
+  auto rows4 = [&](int64_t r, int nr) {
+    etx4 g[4], yv[4];
+    int64_t wi[4] = {0, 0, 0, 0};
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = (float)yv[e] > 0.f ? g[e] : (ET)0.f;
-      }
-      *reinterpret_cast<etx4*>(out + r * C + c0) = g;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] += (float)g[e];
-      if constexpr (WSUM) {
-        float w = wsrc[(int64_t)(wrows ? wrows[r] : (int32_t)r) * wstride];
-        if (wrelu) w = snap_relu(w);
-        // (the engine would multiply the ROUNDED operands: round w to ET like the GEMM's loader does)
-        w = (float)(ET)w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] += w * (float)g[e];
-      }
-      if constexpr (TAIL) {
-        float dp = ((float)g[0] * wt[0] + (float)g[1] * wt[1]) + ((float)g[2] * wt[2] + (float)g[3] * wt[3]);
-        dp = wave_sum(dp);                                              // QW == 64: the row is this wave
-        if (tq == 0)
-          *reinterpret_cast<f32x4*>(dtail + (int64_t)(wrows ? wrows[r] : (int32_t)r) * dstride) = f32x4{dp, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k) {
+      const int64_t rr = r + (int64_t)k * PW;
+      if (k < nr) {
+        g[k] = *reinterpret_cast<const etx4*>(dy + rr * C + c0);
+        if (relu) yv[k] = *reinterpret_cast<const etx4*>(y + rr * C + c0);
+        if constexpr (WSUM) wi[k] = wrows ? (int64_t)wrows[rr] : rr;
       }
     }
+    if constexpr (WSUM) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nr) w[k] = wsrc[wi[k] * wstride];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < nr) {
+        const int64_t rr = r + (int64_t)k * PW;
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[k][e] = (float)yv[k][e] > 0.f ? g[k][e] : (ET)0.f;
+        }
+        *reinterpret_cast<etx4*>(out + rr * C + c0) = g[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += (float)g[k][e];
+        if constexpr (WSUM) {
+          float wv = w[k];
+          if (wrelu) wv = snap_relu(wv);
+          // (the engine would multiply the ROUNDED operands: round w to ET like the GEMM's loader does)
+          wv = (float)(ET)wv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] += wv * (float)g[k][e];
+        }
+        if constexpr (TAIL) {
+          float dp = ((float)g[k][0] * wt[0] + (float)g[k][1] * wt[1]) + ((float)g[k][2] * wt[2] + (float)g[k][3] * wt[3]);
+          dp = wave_sum(dp);                                              // QW == 64: the row is this wave
+          if (tq == 0) *reinterpret_cast<f32x4*>(dtail + wi[k] * dstride) = f32x4{dp, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  };
+  if (tp < PW) {
+    int64_t r = r0 + tp;
+    for (; r + 3 * PW < r1; r += 4 * PW) rows4(r, 4);
+    if (r < r1) rows4(r, (int)((r1 - r + PW - 1) / PW));
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = t[e];
@@ -674,7 +699,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
   partial[(int64_t)blockIdx.x * C + c] = t;
 }
-// The same partial sums with every lane busy and several rows in flight (C % 4 == 0, C / 4 divides 256): a thread
+// The same partial sums with (nearly) every lane busy and several rows in flight (C % 4 == 0, C <= 1024): a thread
 // owns one column quad and every PW-th row of the slab, four rows per iteration (independent float4 loads; the
 // per-column loop above has ONE 4-byte load in flight per thread and half the workgroup idle at C = 128: it ran at
 // the latency of 1920 dependent iterations, 294 us per GB).  The PW row phases are combined in a fixed order.
@@ -683,11 +708,11 @@ __global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __r
                                                                 const int32_t* __restrict__ rows,
                                                                 const int32_t* __restrict__ row_count) {
   __shared__ float red[256 * 4];
-  const int QW = C >> 2, PW = 256 / QW;
+  const int QW = C >> 2, PW = 256 / QW;            // (threads beyond QW * PW idle: C / 4 need not divide 256)
   const int tq = threadIdx.x % QW, tp = threadIdx.x / QW;
   const int64_t Meff = row_count ? min((int64_t)*row_count, M) : M;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = min(Meff, r0 + rows_per_block);
+  const int64_t r1 = tp < PW ? min(Meff, r0 + rows_per_block) : r0;
   f32x4 t = {0.f, 0.f, 0.f, 0.f};
   int64_t r = r0 + tp;
   for (; r + 3 * PW < r1; r += 4 * PW) {
@@ -1024,7 +1049,7 @@ extern "C" int snap_colsum_rows_f32(const float* a, int64_t M, int32_t C, const 
   const int S = colsum_slabs(M);
   const int64_t rpb = (M + S - 1) / S;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0)
+  if (C % 4 == 0 && C <= 1024 && (reinterpret_cast<uintptr_t>(a) & 15) == 0)
     hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(S), dim3(256), 0, s, a, M, C, rpb,
                        static_cast<float*>(workspace), rows, row_count);
   else
