@@ -176,6 +176,34 @@ def test_masked_metric_reduction_drops_non_finite_examples():
   assert out['b'] == pytest.approx(8.0 / 3.0)
 
 
+def test_stacked_metric_reduction_equals_the_per_metric_one():
+  """The train step reduces all per-example metrics as ONE [K, B] tensor stacked per dtype (bool recalls, float
+  errors, a broadcast scalar): same masked means as metric-by-metric (trainer.py:57-67), keys returned in the
+  order of the rows."""
+  from snap_amd import dist as sdist
+  g = torch.Generator().manual_seed(5)
+  B = 6
+  mask = torch.tensor([True, True, False, True, True, False])
+  metrics = {
+      'z/err': torch.randn(B, generator=g).abs(),
+      'a/recall': torch.rand(B, generator=g) < 0.5,
+      'm/err64': torch.randn(B, generator=g).double(),
+      'b/recall': torch.rand(B, generator=g) < 0.5,
+      'k/temperature': torch.tensor(2.5),
+      'n/nan': torch.tensor([1.0, float('nan'), float('nan'), 4.0, float('inf'), 2.0]),
+  }
+  keys, vals = sdist.reduce_batch_metrics_tensor(metrics, mask)
+  assert sorted(keys) == sorted(metrics) and vals.dtype == torch.float64 and vals.shape == (len(metrics),)
+  got = dict(zip(keys, vals.tolist()))
+  for k, v in metrics.items():
+    v = v.double().expand(B)
+    keep = mask & torch.isfinite(v)
+    want = float(v[keep].sum() / max(int(keep.sum()), 1))
+    assert got[k] == pytest.approx(want, rel=1e-12, abs=1e-12), k
+  assert sdist.reduce_batch_metrics(metrics, mask)['n/nan'] == pytest.approx(2.5)
+  assert sdist.reduce_batch_metrics_tensor({}, mask)[0] == []
+
+
 def test_eval_step_dispatches_on_the_model(monkeypatch):
   """evaluator.py:100-108: the localizer is packed by the evaluator, any other model by its own
   pack_evaluation_metrics; a model with neither raises."""
