@@ -33,7 +33,17 @@ def main():
   b0 = torch.randn(256, device=dev, generator=g)
   g1 = torch.randn(M, 256, device=dev, generator=g).to(torch.bfloat16)
   out = {'rows': M, 'observed': int(count.item())}
-  for cs in (260, 272, 288, 320):
+  x = torch.randn(M, 260, device=dev, generator=g)
+  gfull = torch.randn(M, 128, device=dev, generator=g)
+  W1t = torch.randn(128, 256, device=dev, generator=g) / 11
+  for tile in (None, '128x128', '128x64', '64x128', '64x64'):
+    ops.CONV_TILE = tile
+    fwd = lambda: ops.dense(x, W0, b0, cin=257, relu=True, rows_in=index, row_count=count, out_half=True, math='bf16')
+    dg1 = lambda: ops.dense(gfull, W1t, None, cin=128, rows_in=index, row_count=count, out_half=True, math='bf16')
+    out[f'tile_{tile}'] = {'fwd_L0': timeit(fwd), 'dgrad_L1': timeit(dg1)}
+  ops.CONV_TILE = None
+  del x, gfull
+  for cs in (260, 288):
     x = torch.randn(M, cs, device=dev, generator=g)
     x[:, 257:] = 0
     fwd = lambda: ops.dense(x, W0, b0, cin=257, relu=True, rows_in=index, row_count=count, out_half=True, math='bf16')
