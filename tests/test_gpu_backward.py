@@ -962,6 +962,39 @@ def test_masked_rows_mlp_half_hidden_tensors_keep_the_bits(layers_, in_dim, stri
   assert float(g_h[0].abs().max()) > 0 and bool((g_h[0][~mask] == 0).all())
 
 
+@pytest.mark.parametrize('math_', ['f32', 'bf16'])
+def test_masked_rows_mlp_with_an_empty_row_list(math_, monkeypatch):
+  """No observed voxel at all (a query that sees nothing): the row-list GEMMs, the wide kernel-gradient plan, the
+  gate pass with its weighted sums / tail column and the vector column sums all run over ZERO rows -- outputs and
+  every gradient are exact zeros, nothing is read out of bounds (M large enough for the wide plan)."""
+  from snap_amd.models import layers
+  from snap_amd.utils import config_dict
+  cfg = config_dict.ConfigDict(dict(layers=(256, 128), activation='relu', apply_input_activation=False))
+  mlp = layers.MLP(cfg, in_dim=257)
+  gen = torch.Generator().manual_seed(13)
+  params = helpers.params_to_device(mlp.init_params(gen, 'cpu'), 'cuda')
+  M = 70000
+  x = torch.randn(M, 260, generator=gen).cuda().requires_grad_(True)
+  mask = torch.zeros(M, dtype=torch.bool, device='cuda')
+  monkeypatch.setattr(layers.MLP, 'COMPACT_MIN_ROWS', 0)
+  monkeypatch.setattr(ops, 'MATMUL_PRECISION', math_)
+  p = {k: {n: t.clone().requires_grad_(True) for n, t in v.items()} for k, v in params.items()}
+  y = mlp(p, x, train=True, row_mask=mask)
+  assert bool((y == 0).all())
+  y.backward(torch.randn(M, 128, generator=gen).cuda())
+  assert bool((x.grad == 0).all())
+  for v in p.values():
+    for n, t in v.items():
+      assert t.grad is not None and bool((t.grad == 0).all()), n
+  # one observed row: the same kernels over a single row
+  mask[12345] = True
+  x.grad = None
+  y = mlp(p, x, train=True, row_mask=mask)
+  y.backward(torch.ones(M, 128, device='cuda'))
+  assert bool((x.grad[~mask] == 0).all()) and float(x.grad[12345].abs().max()) > 0
+  assert bool((x.grad[12345, 257:] == 0).all())
+
+
 @pytest.mark.parametrize('mode', ['softmax', 'weighted'])
 def test_vertical_pool_conf_bwd(mode):
   from snap_amd import autograd as ag
