@@ -162,6 +162,20 @@ typedef struct SnapConvExtras {
                                  (same indexing as y, 2-byte elements) -- and ONLY there when y is NULL:
                                  the hidden activations / inter-layer gradients of the masked MLP
                                  (layers.py:55-78), which every consumer rounds to that type anyway */
+  /* The statistics pass of a GroupNorm VJP inside the data-gradient convolution that produces its incoming
+   * gradient (x_half launches without split-K, Cout_stride == Cout, no row lists; gn_partial / gn_partial_bytes
+   * as for the forward statistics: snap_conv2d_gn_partial_bytes_ex(desc, 0)).  gnb_mode = SNAP_PRO_GN_RELU /
+   * SNAP_PRO_RELU_GN (0 = off): with dz = the stored output, xh = (x - mu) * rstd (relu(x) for RELU_GN) and
+   * dyp = dz gated by (xh * gamma + beta > 0) (GN_RELU) the epilogue emits, per (image, row tile, channel), the
+   * sums of dyp and dyp * xh -- what snap_group_norm_bwd_ex_f32's first pass computes by re-reading x and dz;
+   * snap_group_norm_bwd_stats_f32 consumes them.  gnb_x [N, Ho, Wo, Cout] f32 (the layer input the GroupNorm
+   * normalises), gnb_mu / gnb_rstd [N, Cout], gnb_gamma / gnb_beta [Cout]. */
+  const float* gnb_x;
+  const float* gnb_mu;
+  const float* gnb_rstd;
+  const float* gnb_gamma;
+  const float* gnb_beta;
+  int32_t gnb_mode;
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
@@ -844,6 +858,16 @@ int snap_group_norm_bwd_ex_f32(const float* x, const float* dz, const float* add
                                const float* beta, int32_t mode, float* dgamma, float* dbeta,
                                int32_t accumulate, void* workspace, size_t workspace_bytes,
                                void* dx_half, int32_t half_kind, void* stream);
+/* ... with the statistics pass already done by the convolution that wrote dz (SnapConvExtras.gnb_*):
+ * stats = that launch's gn_partial ([N][HW / tile_rows + 2][C][2]), tile_rows = snap_conv2d_tile_rows_ex of
+ * its descriptor.  stats == NULL: exactly snap_group_norm_bwd_ex_f32. */
+int snap_group_norm_bwd_stats_f32(const float* x, const float* dz, const float* add, float* dx,
+                                  int32_t N, int32_t HW, int32_t C, int32_t groups,
+                                  const float* mu, const float* rstd, const float* gamma,
+                                  const float* beta, int32_t mode, float* dgamma, float* dbeta,
+                                  int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                  void* dx_half, int32_t half_kind, const float* stats, int32_t tile_rows,
+                                  void* stream);
 int snap_group_norm_bwd_f32(const float* x, const float* dz, const float* add, float* dx,
                             int32_t N, int32_t HW, int32_t C, int32_t groups,
                             const float* mu, const float* rstd, const float* gamma,

@@ -40,6 +40,7 @@ class SnapConvExtras(ctypes.Structure):
       ('gn_partial2', ptr), ('gn_partial2_bytes', c_size), ('gn_partial2_done', c_int),
       ('x_presplit', c_int), ('ps_tile', c_int), ('ps_res_init', c_int),
       ('bk_hint', c_int), ('tune_flags', c_int), ('gn_partial_rows', c_int), ('w_half', c_int), ('x_half', c_int), ('y_half', ptr),
+      ('gnb_x', ptr), ('gnb_mu', ptr), ('gnb_rstd', ptr), ('gnb_gamma', ptr), ('gnb_beta', ptr), ('gnb_mode', c_int),
   ]
 
 
@@ -265,6 +266,11 @@ SIGNATURES = {
         c_int,
         [ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr, ptr, ptr, ptr, c_int, ptr, ptr,
          c_int, ptr, c_size, ptr, c_int, ptr],
+    ),
+    'snap_group_norm_bwd_stats_f32': (
+        c_int,
+        [ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr, ptr, ptr, ptr, c_int, ptr, ptr,
+         c_int, ptr, c_size, ptr, c_int, ptr, c_int, ptr],
     ),
     'snap_weight_standardize_bwd_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_float, ptr]),
     'snap_max_pool_3x3s2_bwd_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, ptr]),

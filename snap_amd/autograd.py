@@ -20,11 +20,13 @@ _GN_MODES = (ops.PRO_GN_RELU, ops.PRO_RELU_GN)
 # ----------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------
-def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None, accumulate_inplace=False):
+def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None, accumulate_inplace=False, gn_bwd_stats=None):
   """d(prologue output) of a conv: transposed convolution through the forward engine.
   accumulate [N,H,W,roundup(Cin,4)]: added in the engine's epilogue (the data gradient of another
   conv reading the same activation); accumulate_inplace: the caller owns that tensor and it may be
-  overwritten with the sum.
+  overwritten with the sum.  gn_bwd_stats = (x, mu, rstd, gamma, beta, mode) of the GroupNorm prologue whose
+  VJP consumes the result: its statistics pass rides in the epilogue of the (half-input, unsplit) launch
+  (``ops.conv2d(gn_bwd_stats=)``); ignored where the launch cannot carry it.
 
   dy [N,Ho,Wo,Cout]; w [KH,KW,Cin,Cout]; returns dz [N,H,W,roundup(Cin,4)] (channels
   past Cin are zero).
@@ -79,11 +81,13 @@ def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None, accumulate_inpl
     # (both operands by LDS-DMA, half the bytes; same bits as rounding the f32 tensor in the loop)
     twin = ops_bwd.half_twin(dy, half_math)
     if twin is not None:
-      return ops.conv2d(twin, w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
+      return ops.conv2d(twin, w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate,
+                        gn_bwd_stats=gn_bwd_stats if GN_BWD_STATS_IN_DGRAD else None)
   return ops.conv2d(dy, w_rot, padding=((pt2, pb2), (pl2, pr2)), residual=accumulate)
 
 
 STRIDED_1X1_DGRAD = True     # (tests: False keeps the zero-dilated formulation)
+GN_BWD_STATS_IN_DGRAD = True  # (tests: False = the GroupNorm VJP always takes its own statistics pass)
 
 
 def _own(grad):
@@ -181,7 +185,10 @@ class _FusedConv(torch.autograd.Function):
     if need[0] or (prologue in _GN_MODES and (need[2] or need[3])):
       N, H, W, Cs = x.shape
       Cin = w.shape[2]
-      dz = conv_dgrad(dy, w, (N, H, W, Cin), stride, padding)
+      gnb = None
+      if prologue in _GN_MODES and stride == 1 and Cs == Cin and Cin % 4 == 0:
+        gnb = (x, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), prologue)
+      dz = conv_dgrad(dy, w, (N, H, W, Cin), stride, padding, gn_bwd_stats=gnb)
       if dz.shape[-1] > Cs:
         dz = dz[..., :Cs].contiguous()
       Cin = dz.shape[-1]                                       # zero-padded channel count
@@ -243,7 +250,11 @@ class _SharedPrologueConvPair(torch.autograd.Function):
     if need[0] or need[3] or need[4]:
       N, H, W, C = x.shape
       dz = conv_dgrad(dy1, w1, (N, H, W, C), 1, pad0)
-      dz = conv_dgrad(dy2, w2, (N, H, W, C), ctx.stride2, pad0, accumulate=dz, accumulate_inplace=True)
+      gnb = None
+      if ctx.stride2 == 1 and C % 4 == 0:      # (the sum of both data gradients leaves the second launch's epilogue)
+        gnb = (x, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), ops.PRO_GN_RELU)
+      dz = conv_dgrad(dy2, w2, (N, H, W, C), ctx.stride2, pad0, accumulate=dz, accumulate_inplace=True,
+                      gn_bwd_stats=gnb)
       dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
           x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), ops.PRO_GN_RELU,
           half=ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None)

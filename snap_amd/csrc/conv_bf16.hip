@@ -308,7 +308,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvArgs& a) {
 // fetches the zero chunk): no staging registers, no conversion, no store phase, half the bytes.
 // Same products, same k order and accumulation as conv_bf16_body on the rounded operand: the
 // results are bit-identical to the f32-input launch of the same tensor (tested).
-template <int BM, int BN, bool F16>
+template <int BM, int BN, bool F16, bool GNB = false>
 __device__ __forceinline__ void conv_bf16_xh_body(const ConvArgs& a) {
   typedef Elem<F16> E;
   typedef typename E::T ET;
@@ -453,12 +453,13 @@ __device__ __forceinline__ void conv_bf16_xh_body(const ConvArgs& a) {
     }
   }
   __syncthreads();                        // the ring is drained: the epilogue reuses it as its staging tile
-  conv_epilogue<BM, BN>(a, acc, smem, m0, n0, Meff, row_t, split);
+  conv_epilogue<BM, BN, false, 256, false, 0, GNB>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
-template <int BM, int BN, bool F16>
+// GNB: the epilogue also emits the statistics of the GroupNorm VJP this gradient feeds (ConvArgs.gnb_*)
+template <int BM, int BN, bool F16, bool GNB = false>
 __global__ __launch_bounds__(256) void conv_bf16_xh_kernel(const ConvArgs a) {
-  conv_bf16_xh_body<BM, BN, F16>(a);
+  conv_bf16_xh_body<BM, BN, F16, GNB>(a);
 }
 
 template <int BM, int BN, int PRO, bool F16 = false, bool YH = false, bool GNT = false>
@@ -496,7 +497,13 @@ int launch(ConvArgs a, hipStream_t s) {
   }
   if (a.x_half) {
     if constexpr (PRO == SNAP_PRO_NONE) {
-      if (a.half)
+      if (a.gnb_mode) {
+        if (a.ksplit > 1 || !a.gn_partial) return SNAP_ERR_UNSUPPORTED;
+        if (a.half)
+          hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, true, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+        else
+          hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+      } else if (a.half)
         hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
       else
         hipLaunchKernelGGL((conv_bf16_xh_kernel<BM, BN, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);

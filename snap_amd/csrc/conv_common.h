@@ -57,6 +57,13 @@ struct ConvArgs {
   const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
   int ps_tile;         // ... 0 = automatic tile, 1 = 128 rows, 2 = 256 rows
   int ps_res_init;     // ... 1 = the residual is loaded into the accumulators before the K loop
+  // GroupNorm-VJP statistics in the epilogue (SnapConvExtras.gnb_*; conv_epilogue<..., GNB = true> only)
+  const float* gnb_x;
+  const float* gnb_mu;
+  const float* gnb_rstd;
+  const float* gnb_gamma;
+  const float* gnb_beta;
+  int gnb_mode;
 };
 
 // bf16-operand engine (conv_bf16.hip); `a` validated by snap_conv2d_nhwc_ex_f32
@@ -120,7 +127,9 @@ __device__ __forceinline__ float snap_gelu_tanh(float x) {
 // OUTH (training-precision engine only): 1 / 2 = the stored values also go, rounded (RNE) to bf16 /
 // IEEE half, to a.y_half; a.y may then be NULL (half-only output: the hidden activations and
 // inter-layer gradients of the masked MLP, which every consumer rounds to that type anyway)
-template <int BM, int BN, bool DUAL = false, int NT = 256, bool SKIP_RES = false, int OUTH = 0>
+// GNB (the half-input data-gradient kernels only): with a.gnb_mode the statistics are those of the GroupNorm VJP
+// this gradient feeds (sums of dyp and dyp * xh, see SnapConvExtras.gnb_*) instead of y / y^2.
+template <int BM, int BN, bool DUAL = false, int NT = 256, bool SKIP_RES = false, int OUTH = 0, bool GNB = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
                                               f32x16 (&acc)[BM / (NT / 4)][BN / 64],
                                               float* smem, int m0, int n0, int Meff, int row_t,
@@ -159,6 +168,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
   const bool want_relu_too = DUAL && want_stats;
   float hs1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float hs2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // GNB: the thread's four columns are fixed (NT % Q == 0): gamma / beta once, mean / rstd of the two images
+  f32x4 vb_mu[2], vb_rs[2], vb_g = {0.f, 0.f, 0.f, 0.f}, vb_b = {0.f, 0.f, 0.f, 0.f};
+  const bool gnb = GNB && want_stats && a.gnb_mode != 0;
+  if constexpr (GNB) {
+    vb_mu[0] = vb_mu[1] = vb_rs[0] = vb_rs[1] = vb_g;
+    const int colq = n0 + 4 * (tid % Q);
+    if (gnb && colq < d.Cout) {
+      vb_g = *reinterpret_cast<const f32x4*>(a.gnb_gamma + colq);
+      vb_b = *reinterpret_cast<const f32x4*>(a.gnb_beta + colq);
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int64_t so = (int64_t)min(n_first + sl, d.N - 1) * d.Cout + colq;
+        vb_mu[sl] = *reinterpret_cast<const f32x4*>(a.gnb_mu + so);
+        vb_rs[sl] = *reinterpret_cast<const f32x4*>(a.gnb_rstd + so);
+      }
+    }
+  }
 #pragma unroll
   for (int h = 0; h < TM; ++h) {
     if (h > 0) __syncthreads();
@@ -243,7 +269,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
           *reinterpret_cast<f16x4_t*>(static_cast<_Float16*>(a.y_half) + o) = __builtin_convertvector(v, f16x4_t);
         }
       }
-      if (want_stats) {
+      if (GNB && gnb) {
+        const int sl = m >= m_split ? 1 : 0;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.gnb_x + (int64_t)m * d.Cout + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // (the arithmetic of gn_bwd_partial_kernel / gn_bwd_apply_kernel: the same gate, bit for bit)
+          float xh, dyp;
+          if (a.gnb_mode == SNAP_PRO_GN_RELU) {
+            xh = (xv[e] - vb_mu[sl][e]) * vb_rs[sl][e];
+            dyp = (xh * vb_g[e] + vb_b[e] > 0.f) ? v[e] : 0.f;
+          } else {
+            xh = (fmaxf(xv[e], 0.f) - vb_mu[sl][e]) * vb_rs[sl][e];
+            dyp = v[e];
+          }
+          gs1[sl][e] += dyp;
+          gs2[sl][e] += dyp * xh;
+        }
+      } else if (want_stats) {
         const int sl = m >= m_split ? 1 : 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

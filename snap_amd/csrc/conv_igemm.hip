@@ -750,6 +750,22 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
     a.y_half = ex->y_half;
     a.kpartial = nullptr;
   }
+  a.gnb_x = a.gnb_mu = a.gnb_rstd = a.gnb_gamma = a.gnb_beta = nullptr;
+  a.gnb_mode = 0;
+  if (ex && ex->gnb_mode) {   // GroupNorm-VJP statistics in the epilogue: half-input data-gradient launches only
+    if ((ex->gnb_mode != SNAP_PRO_GN_RELU && ex->gnb_mode != SNAP_PRO_RELU_GN) || !ex->x_half || !gn_partial ||
+        ex->gn_partial_rows != 0 || ex->gn_partial2 || ex->gn_partial_relu || ex->workspace ||
+        (d.epilogue & ~(SNAP_EPI_RESIDUAL | SNAP_EPI_BIAS)))
+      return SNAP_ERR_UNSUPPORTED;
+    if (!ex->gnb_x || !ex->gnb_mu || !ex->gnb_rstd || !ex->gnb_gamma || !ex->gnb_beta) return SNAP_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(ex->gnb_x) | reinterpret_cast<uintptr_t>(ex->gnb_mu) |
+         reinterpret_cast<uintptr_t>(ex->gnb_rstd) | reinterpret_cast<uintptr_t>(ex->gnb_gamma) |
+         reinterpret_cast<uintptr_t>(ex->gnb_beta)) & 15)
+      return SNAP_ERR_BAD_SHAPE;
+    a.gnb_x = ex->gnb_x; a.gnb_mu = ex->gnb_mu; a.gnb_rstd = ex->gnb_rstd;
+    a.gnb_gamma = ex->gnb_gamma; a.gnb_beta = ex->gnb_beta;
+    a.gnb_mode = ex->gnb_mode;
+  }
   a.cin8 = (d.Cin + 7) / 8 * 8;
   a.x_ps = nullptr;
   a.ps_tile = 0;

@@ -76,15 +76,23 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(
   }
 }
 
+// tile_rows > 0: `partial` comes from a convolution's epilogue ([N][HW / tile_rows + 2][C][2], slot = row tile
+// within the image): only the slots of the row tiles that touch image n are written (as gn_finalize_tiled_kernel).
+__device__ __forceinline__ int gn_live_slots(int n, int S, int HW, int tile_rows) {
+  return tile_rows <= 0 ? S
+                        : (int)((((int64_t)(n + 1) * HW - 1) / tile_rows) - (((int64_t)n * HW) / tile_rows)) + 1;
+}
+
 // thread per (n, c): slab totals -> AB[n,c,2]
 __global__ void gn_bwd_reduce_kernel(const float* __restrict__ partial, int S, int C, int total,
-                                     float* __restrict__ ab) {
+                                     float* __restrict__ ab, int HW = 0, int tile_rows = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*C
   if (i >= total) return;
   const int n = i / C, c = i - n * C;
   float a1 = 0.f, a2 = 0.f;
+  const int live = gn_live_slots(n, S, HW, tile_rows);
 #pragma unroll 8
-  for (int s = 0; s < S; ++s) {   // unrolled: 8 independent loads in flight (pure latency)
+  for (int s = 0; s < live; ++s) {   // unrolled: 8 independent loads in flight (pure latency)
     const float2 p = *reinterpret_cast<const float2*>(partial + (((int64_t)n * S + s) * C + c) * 2);
     a1 += p.x;
     a2 += p.y;
@@ -131,7 +139,8 @@ __global__ void gn_bwd_group_kernel(const float* __restrict__ ab, const float* _
 template <int CB>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_group_kernel(
     const float* __restrict__ partial, int S, int N, int C, int groups, const float* __restrict__ gamma,
-    float* __restrict__ s12, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    float* __restrict__ s12, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+    int HW = 0, int tile_rows = 0) {
   extern __shared__ float ab[];                       // [N][CB][2]
   const int c0 = blockIdx.x * CB;
   const int cpg = C / groups;
@@ -140,8 +149,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_group_kernel(
     const int c = c0 + cl;
     float a1 = 0.f, a2 = 0.f;
     if (c < C) {
+      const int live = gn_live_slots(n, S, HW, tile_rows);
 #pragma unroll 8
-      for (int sl = 0; sl < S; ++sl) {
+      for (int sl = 0; sl < live; ++sl) {
         const float2 p = *reinterpret_cast<const float2*>(partial + (((int64_t)n * S + sl) * C + c) * 2);
         a1 += p.x;
         a2 += p.y;
@@ -807,6 +817,18 @@ extern "C" int snap_group_norm_bwd_ex_f32(const float* x, const float* dz, const
                                           float* dbeta, int32_t accumulate, void* workspace,
                                           size_t workspace_bytes, void* dx_half, int32_t half_kind,
                                           void* stream) {
+  return snap_group_norm_bwd_stats_f32(x, dz, add, dx, N, HW, C, groups, mu, rstd, gamma, beta, mode, dgamma, dbeta,
+                                       accumulate, workspace, workspace_bytes, dx_half, half_kind, nullptr, 0, stream);
+}
+
+extern "C" int snap_group_norm_bwd_stats_f32(const float* x, const float* dz, const float* add,
+                                             float* dx, int32_t N, int32_t HW, int32_t C, int32_t groups,
+                                             const float* mu, const float* rstd, const float* gamma,
+                                             const float* beta, int32_t mode, float* dgamma,
+                                             float* dbeta, int32_t accumulate, void* workspace,
+                                             size_t workspace_bytes, void* dx_half, int32_t half_kind,
+                                             const float* stats, int32_t tile_rows, void* stream) {
+  if (stats && (tile_rows <= 0 || HW < tile_rows || (reinterpret_cast<uintptr_t>(stats) & 7))) return SNAP_ERR_BAD_SHAPE;
   if (half_kind < 0 || half_kind > 2 || (half_kind != 0) != (dx_half != nullptr)) return SNAP_ERR_BAD_SHAPE;
   if (dx_half && (reinterpret_cast<uintptr_t>(dx_half) & 7)) return SNAP_ERR_BAD_SHAPE;
   if (!x || !dz || !dx || !mu || !rstd || !gamma || !beta || !dgamma || !dbeta || !workspace)
@@ -826,25 +848,35 @@ extern "C" int snap_group_norm_bwd_ex_f32(const float* x, const float* dz, const
   float* s12 = ab + (size_t)N * C * 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(pl.S, N, nchunks);
-  if (mode == SNAP_PRO_GN_RELU)
-    hipLaunchKernelGGL(gn_bwd_partial_kernel<SNAP_PRO_GN_RELU>, grid, dim3(256), 0, s, x, dz, HW, C,
-                       mu, rstd, gamma, beta, pl.ppb, partial);
-  else
-    hipLaunchKernelGGL(gn_bwd_partial_kernel<SNAP_PRO_RELU_GN>, grid, dim3(256), 0, s, x, dz, HW, C,
-                       mu, rstd, gamma, beta, pl.ppb, partial);
-  SNAP_CHECK_LAUNCH();
+  // the sums the reduce pass reads: this launch's own first pass, or the epilogue statistics of the convolution
+  // that wrote dz (one slot per row tile of tile_rows pixels)
+  const float* sums = partial;
+  int S = pl.S, tr = 0;
+  if (stats) {
+    sums = stats;
+    S = HW / tile_rows + 2;
+    tr = tile_rows;
+  } else {
+    if (mode == SNAP_PRO_GN_RELU)
+      hipLaunchKernelGGL(gn_bwd_partial_kernel<SNAP_PRO_GN_RELU>, grid, dim3(256), 0, s, x, dz, HW, C,
+                         mu, rstd, gamma, beta, pl.ppb, partial);
+    else
+      hipLaunchKernelGGL(gn_bwd_partial_kernel<SNAP_PRO_RELU_GN>, grid, dim3(256), 0, s, x, dz, HW, C,
+                         mu, rstd, gamma, beta, pl.ppb, partial);
+    SNAP_CHECK_LAUNCH();
+  }
   const int cpg = C / groups;
   const size_t lds16 = (size_t)N * 16 * 2 * sizeof(float), lds64 = (size_t)N * 64 * 2 * sizeof(float);
   if (cpg <= 16 && 16 % cpg == 0 && C % 16 == 0 && lds16 <= 64 * 1024) {
     // slab totals, group sums and parameter gradients in one launch (16 channels per workgroup)
     hipLaunchKernelGGL(gn_bwd_reduce_group_kernel<16>, dim3((unsigned)(C / 16)), dim3(256), lds16, s,
-                       (const float*)partial, pl.S, N, C, groups, gamma, s12, dgamma, dbeta, accumulate);
+                       sums, S, N, C, groups, gamma, s12, dgamma, dbeta, accumulate, HW, tr);
   } else if (cpg <= 64 && 64 % cpg == 0 && C % 64 == 0 && lds64 <= 64 * 1024) {
     hipLaunchKernelGGL(gn_bwd_reduce_group_kernel<64>, dim3((unsigned)(C / 64)), dim3(256), lds64, s,
-                       (const float*)partial, pl.S, N, C, groups, gamma, s12, dgamma, dbeta, accumulate);
+                       sums, S, N, C, groups, gamma, s12, dgamma, dbeta, accumulate, HW, tr);
   } else {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)snap_cdiv((int64_t)N * C, 256)),
-                       dim3(256), 0, s, (const float*)partial, pl.S, C, N * C, ab);
+                       dim3(256), 0, s, sums, S, C, N * C, ab, HW, tr);
     SNAP_CHECK_LAUNCH();
     const int work = N * groups > C ? N * groups : C;
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)snap_cdiv(work, 256)), dim3(256), 0, s,

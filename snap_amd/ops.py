@@ -378,6 +378,7 @@ def conv2d(
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
     emit_gn_stats=None, math=None, gelu=False, res_init=None, ps_tile=None, out_half=False, out_stride=None,
+    gn_bwd_stats=None,
 ):
   """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
@@ -402,6 +403,11 @@ def conv2d(
   out_half (training-precision engines 'bf16' / 'fp16' only): the result is written ONLY rounded to the
   engine's element type and returned as a bf16 / f16 tensor (the hidden activations and inter-layer
   gradients of the masked MLP: every consumer rounds them to that type anyway).
+  gn_bwd_stats = (x_gn, mu, rstd, gamma, beta, mode) (a half-precision input -- the data-gradient launch that
+  reads a GroupNorm VJP's twin): the epilogue also emits the statistics of the GroupNorm VJP that consumes THIS
+  result as its incoming gradient (x_gn [N,Ho,Wo,Cout] is that GroupNorm's input, mode its prologue);
+  ``ops_bwd.group_norm_bwd`` finds them on the result (``y._snap_gnb_partial``) and skips its first pass.
+  Silently not done where the launch splits K or the shape has no statistics layout.
   out_stride (with ``out``, a multiple of 4 >= Cout): out's rows hold out_stride floats and the result goes
   to their first Cout (the other columns are not touched); no statistics, residual or up-sampling epilogue.
   Returns y [N,Ho,Wo,Cout] (``out`` itself, [.., out_stride], with out_stride).
@@ -519,6 +525,7 @@ def conv2d(
   partial = partial2 = None
   kws = None
   rows32 = False
+  gnb_done = False
   if rows_in is not None or rows_out is not None or row_count is not None:
     ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0,
                              None, 0)
@@ -543,6 +550,19 @@ def conv2d(
           ex.gn_partial_relu = int(emit_gn_stats == 'relu')
           ex.gn_partial_rows = 32
           rows32 = True
+    elif (gn_bwd_stats is not None and xh and emit_gn_stats is None and out is None and up_prev is None
+          and not relu and not gelu and row_mask is None):
+      pbytes = lib.snap_conv2d_gn_partial_bytes_ex(ctypes.byref(d), 0)
+      gx, gmu, grs, gga, gbe, gmode = gn_bwd_stats
+      if (pbytes and tuple(gx.shape) == (N, Ho, Wo, Cout) and gmu.numel() == N * Cout and grs.numel() == N * Cout
+          and gga.numel() == Cout and gbe.numel() == Cout and gmode in (PRO_GN_RELU, PRO_RELU_GN)):
+        for t, nm in ((gx, 'gn_bwd x'), (gmu, 'gn_bwd mu'), (grs, 'gn_bwd rstd'), (gga, 'gn_bwd gamma'), (gbe, 'gn_bwd beta')):
+          _f32(t, nm)
+        partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)
+        ex = _lib.SnapConvExtras(None, None, None, partial.data_ptr(), pbytes, 0, None, 0, None, 0)
+        ex.gnb_x, ex.gnb_mu, ex.gnb_rstd = gx.data_ptr(), gmu.data_ptr(), grs.data_ptr()
+        ex.gnb_gamma, ex.gnb_beta, ex.gnb_mode = gga.data_ptr(), gbe.data_ptr(), int(gmode)
+        gnb_done = True
     elif emit_gn_stats is not None:
       pbytes = (lib.snap_conv2d_presplit_gn_partial_bytes(ctypes.byref(d), pst) if ps
                 else lib.snap_conv2d_gn_partial_bytes_ex(ctypes.byref(d), qparts))
@@ -616,7 +636,11 @@ def conv2d(
         _stream(),
     )
   _lib.check(st, 'snap_conv2d_nhwc_ex_f32')
-  if partial is not None:
+  if gnb_done:
+    # (the GroupNorm VJP checks that it is handed the same x before it trusts these sums)
+    y._snap_gnb_partial = (partial, lib.snap_conv2d_tile_rows_ex(ctypes.byref(d), 0), gn_bwd_stats[0].data_ptr(),
+                           gn_bwd_stats[0]._version, int(gn_bwd_stats[5]))
+  elif partial is not None:
     tile_rows = (32 if rows32 else lib.snap_conv2d_presplit_tile_rows(ctypes.byref(d), pst) if ps
                  else lib.snap_conv2d_tile_rows_ex(ctypes.byref(d), qparts))
     y._snap_gn_partial = (partial, tile_rows, emit_gn_stats == 'relu')

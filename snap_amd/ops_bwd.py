@@ -109,6 +109,7 @@ _HALF_TWINS = {}
 HALF_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16}
 USE_HALF_TWINS = True
 WGRAD_DY_TWIN = True        # (tests / tools: False keeps the kernel gradients on the f32 dy)
+USE_GNB_STATS = True        # (tests / tools: False = the GroupNorm VJP always takes its own statistics pass)
 
 
 def half_twin(t, math):
@@ -170,13 +171,20 @@ def group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, *, groups=32, add=None, h
   twin = None
   if half in HALF_DTYPE and USE_HALF_TWINS and C % 8 == 0:
     twin = torch.empty(x.shape, dtype=HALF_DTYPE[half], device=x.device)
-  with _region('group_norm_bwd', 0.0, 16.0 * x.numel() + (2.0 * x.numel() if twin is not None else 0.0)):
-    st = lib.snap_group_norm_bwd_ex_f32(
+  # the statistics pass may already have been taken by the convolution that wrote dz (ops.conv2d(gn_bwd_stats=))
+  stats, tile_rows = None, 0
+  held = getattr(dz, '_snap_gnb_partial', None) if USE_GNB_STATS else None
+  if (held is not None and held[2] == x.data_ptr() and held[3] == x._version and held[4] == int(mode)
+      and dz.shape == x.shape and H * W >= held[1] > 0):
+    stats, tile_rows = held[0], held[1]
+  with _region('group_norm_bwd', 0.0, (16.0 if stats is None else 8.0) * x.numel()
+               + (2.0 * x.numel() if twin is not None else 0.0)):
+    st = lib.snap_group_norm_bwd_stats_f32(
         _p(x), _p(dz), _p(add), _p(dx), N, H * W, C, groups, _p(mu), _p(rstd), _p(gamma),
         _p(beta), mode, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel() * 4,
-        _p(twin), 0 if twin is None else (2 if half == 'fp16' else 1), _stream(),
+        _p(twin), 0 if twin is None else (2 if half == 'fp16' else 1), _p(stats), int(tile_rows), _stream(),
     )
-  _lib.check(st, 'snap_group_norm_bwd_ex_f32')
+  _lib.check(st, 'snap_group_norm_bwd_stats_f32')
   if twin is not None:
     # the twin lives exactly as long as its f32 tensor (an attribute of it; the table only holds weak
     # references): keeping it in the table would hold a whole step's twins -- gigabytes -- alive into

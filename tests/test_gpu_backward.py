@@ -383,6 +383,45 @@ def test_conv_dgrad_via_engine(k, stride, pad):
   helpers.report(f'dgrad k{k} s{stride}', got, x.grad.float(), atol=3e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('math_', ['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,C,Cnext,k,mode,acc', [
+    (3, 17, 17, 64, 256, 1, ops.PRO_GN_RELU, False),     # tiles straddle images
+    (2, 13, 11, 128, 128, 3, ops.PRO_GN_RELU, True),     # 3 x 3, accumulated second gradient
+    (5, 12, 12, 256, 64, 1, ops.PRO_RELU_GN, False),
+    (2, 34, 34, 512, 128, 1, ops.PRO_GN_RELU, True),
+])
+def test_groupnorm_vjp_statistics_from_the_dgrad_epilogue(N, H, W, C, Cnext, k, mode, acc, math_, monkeypatch):
+  """The first pass of the GroupNorm VJP (sums of the gated gradient and of gradient x normalised input per
+  (image, channel)) taken in the epilogue of the half-input data-gradient launch that writes that gradient
+  (``ops.conv2d(gn_bwd_stats=)``): dx / dgamma / dbeta agree with the stand-alone pass to summation order, the
+  gradient tensor itself is bit-identical, and a different x (or mode) makes the VJP ignore the sums."""
+  hd = ops_bwd.HALF_DTYPE[math_]
+  monkeypatch.setattr(ops, 'USE_SPLITK', False)          # (a split-K launch leaves the statistics to the stand-alone pass)
+  x = G(rnd((N, H, W, C), 470) * 1.5 + 0.4)
+  gamma, beta = G(rnd((C,), 471) * 0.3 + 1), G(rnd((C,), 472) * 0.2)
+  mu, sc, rstd = ops.group_norm_stats(x, gamma, relu_first=mode == ops.PRO_RELU_GN, want_rstd=True)
+  dyh = G(rnd((N, H, W, Cnext), 473)).to(hd)                     # gradient w.r.t. the NEXT conv's output (a half twin)
+  w_rot = G(rnd((k, k, Cnext, C), 474, 1 / math.sqrt(k * k * Cnext)))
+  res = G(rnd((N, H, W, C), 475)) if acc else None
+  pad = (k - 1) // 2
+  kw = dict(padding=((pad, pad), (pad, pad)), residual=res, math=math_)
+  dz_plain = ops.conv2d(dyh, w_rot, **kw)
+  dz = ops.conv2d(dyh, w_rot, gn_bwd_stats=(x, mu, rstd, gamma, beta, mode), **kw)
+  assert torch.equal(dz, dz_plain) and getattr(dz, '_snap_gnb_partial', None) is not None
+  add = G(rnd((N, H, W, C), 476))
+  fused = ops_bwd.group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, add=add, half=math_)
+  monkeypatch.setattr(ops_bwd, 'USE_GNB_STATS', False)
+  plain = ops_bwd.group_norm_bwd(x, dz, mu, rstd, gamma, beta, mode, add=add, half=math_)
+  monkeypatch.setattr(ops_bwd, 'USE_GNB_STATS', True)
+  for nm, a, b in zip(('dx', 'dgamma', 'dbeta'), fused, plain):
+    helpers.report(f'gn vjp fused stats {nm}', a, b, atol=2e-5 * float(b.abs().max()) + 1e-6)
+  assert not torch.equal(fused[1], plain[1]) or C * H * W < 4096          # (another summation order: really fused)
+  # stale sums are not trusted: another x tensor / another mode -> the stand-alone pass (bit-identical to `plain`)
+  x2 = x.clone()
+  again = ops_bwd.group_norm_bwd(x2, dz, mu, rstd, gamma, beta, mode, add=add, half=math_)
+  assert all(torch.equal(a, b) for a, b in zip(again, plain))
+
+
 @pytest.mark.parametrize('math_', ['f32', 'bf16'])
 @pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 11, 10, 64, 128), (3, 8, 8, 256, 512), (1, 17, 17, 100, 64)])
 def test_strided_1x1_dgrad_on_the_coarse_grid(N, H, W, Cin, Cout, math_, monkeypatch):
