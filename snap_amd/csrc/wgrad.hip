@@ -279,14 +279,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t total,
-                                    float* __restrict__ dw, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  float t = accumulate ? dw[i] : 0.f;
+// Fixed-order reduction of the partial tiles over the chunks.  A workgroup owns 64 consecutive elements; its four
+// waves take the slots s = p, p + 4, ... (eight loads in flight each) and are combined in the order p = 0..3: four
+// times the loads in flight of the one-thread-per-element loop, which ran at the latency of S / 8 dependent rounds
+// on a handful of workgroups (126 launches, 1.3 ms per C3 step).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t total,
+                                                           float* __restrict__ dw, int accumulate) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + l;
+  float t = 0.f;
+  if (i < total) {
 #pragma unroll 8
-  for (int s = 0; s < S; ++s) t += partial[(int64_t)s * total + i];
-  dw[i] = t;
+    for (int s = p; s < S; s += 4) t += partial[(int64_t)s * total + i];
+  }
+  red[p][l] = t;
+  __syncthreads();
+  if (p == 0 && i < total) {
+    float r = accumulate ? dw[i] : 0.f;
+    r += ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+    dw[i] = r;
+  }
 }
 
 template <int BKT, int BN, bool VEC, int PRO>
@@ -427,7 +440,7 @@ extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* 
   }
   if (rc != SNAP_OK) return rc;
   const int64_t total = (int64_t)a.K * d.Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)snap_cdiv(total, 64)), dim3(256), 0, s,
                      (const float*)a.partial, p.S, total, dw, accumulate);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
