@@ -746,6 +746,29 @@ int snap_pack_stacked_templates_split_bf16(const float* templates, int32_t H, in
 int snap_pad_map_f32(const float* map, const uint8_t* mvalid, int32_t H, int32_t W,
                      int32_t D, float* map_pad, float* mvalid_pad, void* stream);
 
+/* Frequency-domain template matching (snap/models/pose_exhaustive_voting.py:72-104, padded mode) in
+ * ONE call: templates[R,H,W,D] (zero where tvalid is 0), tvalid[R,H,W], map[Hm,Wm,D], mvalid[Hm,Wm],
+ * tcount[R] = q_valid.sum((-1,-2)) -> scores[R, 3Hm-1-H, 3Wm-1-W]:
+ *   scores[r,a,b] = sum_ijd templates[r,i,j,d] * edge_pad(map)[a+i, b+j, d]            (:82-91)
+ *   -inf where the overlap count (the 180-degree rotated template mask correlated with the
+ *   zero-padded map mask, :93-101) is <= overlap_threshold (= min_overlap * H * W) if use_overlap,
+ *   then / tcount[r]                                                                    (:103).
+ * The correlation is evaluated as FFT products (channel pairs packed as complex numbers, mixed-radix
+ * 2/3/4 transforms of 2^a or 3*2^a points per axis in LDS, f32): ~1e-6 relative to the largest
+ * score instead of the direct form's summation order -- snap_conv2d_* on the stacked template bank
+ * remains the direct form (and the checker).  The overlap count is rounded to the nearest integer
+ * (operands are 0/1): the -inf mask is the direct form's.
+ * workspace: snap_voting_fft_workspace_bytes() bytes, 256-byte aligned; 0 = unsupported geometry
+ * (3*max(Hm,Wm)-2 > 1024 points per axis), for which snap_voting_fft_f32 returns
+ * SNAP_ERR_UNSUPPORTED.  templates / map 8-byte aligned. */
+size_t snap_voting_fft_workspace_bytes(int32_t R, int32_t H, int32_t W, int32_t D, int32_t Hm,
+                                       int32_t Wm);
+int snap_voting_fft_f32(const float* templates, const uint8_t* tvalid, const float* map,
+                        const uint8_t* mvalid, const float* tcount, int32_t R, int32_t H, int32_t W,
+                        int32_t D, int32_t Hm, int32_t Wm, float overlap_threshold,
+                        int32_t use_overlap, void* workspace, size_t workspace_bytes, float* scores,
+                        void* stream);
+
 /* raw[Ho,Wo,Rp], cnt[Ho,Wo,Rp] (engine outputs) -> scores[R,Ho,Wo]:
  * -inf where cnt <= min_overlap*H*W (if min_overlap >= 0), then / tcount[r]. */
 int snap_template_finalize_f32(const float* raw, const float* cnt,

@@ -94,6 +94,10 @@ SIGNATURES = {
     'snap_semantic_embed_f32': (
         c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, ptr, c_int, ptr, ptr]),
     'snap_semantic_onehot_f32': (c_int, [ptr, c_i64, c_int, ptr, c_int, ptr, c_int, ptr, c_int, ptr]),
+    'snap_voting_fft_workspace_bytes': (c_size, [c_int] * 6),
+    'snap_voting_fft_f32': (
+        c_int, [ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, ptr, c_size,
+                ptr, ptr]),
     'snap_stack_templates_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
     'snap_stack_templates_rhwd_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
     'snap_pack_stacked_templates_split_bf16': (c_int, [ptr, c_int, c_int, c_int, c_int, c_int, ptr, c_size, ptr]),

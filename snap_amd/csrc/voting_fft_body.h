@@ -1,0 +1,491 @@
+// Frequency-domain exhaustive (x, y, theta) voting: kernel bodies and launch sequence.
+//
+// Replaces the direct-form correlation of snap/models/pose_exhaustive_voting.py:72-104
+// (jax.scipy.signal.convolve over every template, summed over channels, the overlap count and the
+// -inf / normalisation pass) by its frequency-domain equivalent, which needs ~1e-3 of the direct
+// form's multiply-adds:
+//
+//   scores[r,a,b] = sum_{i,j,d} q[r,i,j,d] m_pad[a+i, b+j, d]
+//                 = Re IFFT2( sum_p conj(FFT2(z_q[r,p])) * FFT2(z_m[p]) )[a, b]
+//
+// with the channel PAIRS (2p, 2p+1) packed as the real / imaginary part of one complex signal
+// (z = c_2p + i c_2p+1: the channels-last f32 tensors ARE complex arrays [.., D/2] in memory; the
+// cross terms of a pair land in the imaginary part of the result, which is dropped).  The overlap
+// count packs the ROTATIONS r and r + R/2 the same way: Re -> count of r, -Im -> count of r + R/2,
+// rounded to the nearest integer (operands are 0/1: the count is exact).
+//
+// Transforms: in-place mixed-radix (3, 2, 4...) FFTs of SIXTEEN columns at a time in LDS, layout
+// [n][16] complex64 -- the 16 columns are the 16 channel pairs of one 32-channel group (128 B of a
+// channels-last row: every global access is a whole 128-byte run).  Forward = decimation in
+// frequency (natural order in, digit-reversed out); the spectra stay in digit-reversed order (the
+// map's, produced by the same routine, are permuted identically); inverse = decimation in time, the
+// exact conjugate transpose of the forward stages in reverse order (digit-reversed in, natural
+// out).  No reordering pass exists.  tools/fft_voting_model.py is the index-exact numpy model.
+//
+// This header is compiled twice: by hipcc into libsnap_hip.so (voting_fft.hip), and by g++ with
+// VF_EMU into the CPU emulation harness of the tests (tests/emu/voting_fft_emu.cpp: one pthread per
+// GPU thread, a pthread barrier per __syncthreads) -- test infrastructure that lets the index
+// arithmetic be checked against oracle/voting.py without a GPU.  The product never loads the
+// emulation.
+#ifndef SNAP_CSRC_VOTING_FFT_BODY_H_
+#define SNAP_CSRC_VOTING_FFT_BODY_H_
+
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+
+#ifdef VF_EMU
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+#define VF_DEV static inline
+void vf_emu_barrier();
+float vf_emu_shfl_xor(float v, int mask, int tid);
+#define VF_SYNC() vf_emu_barrier()
+#define VF_SHFL_XOR(v, m, tid) vf_emu_shfl_xor(v, m, tid)
+#else
+#define VF_DEV __device__ __forceinline__
+#define VF_SYNC() __syncthreads()
+#define VF_SHFL_XOR(v, m, tid) __shfl_xor(v, m, 16)
+#endif
+
+namespace vfft {
+
+constexpr int kMaxStages = 8;
+constexpr int kCols = 16;          // columns transformed together (= channel pairs of a group)
+constexpr int kMaxN = 1024;        // (16 + 2) * N * 8 B of LDS: 147 KB at N = 1024
+
+struct Plan {                      // one axis: N = prod radix[s]; stage s works on spans of L[s]
+  int N, nst;
+  int radix[kMaxStages];
+  int L[kMaxStages];               // span entering stage s (forward order): L[0] = N
+  int logM[kMaxStages];            // M = L / radix is a power of two (the 3, if any, goes first)
+  int tstep[kMaxStages];           // N / L: twiddle-table step of the stage
+};
+
+// smallest N >= n of the form 2^a or 3 * 2^a (a >= 2)
+static inline int fft_size(int n) {
+  int best = 0;
+  for (int base = 1; base <= 3; base += 2) {
+    int N = base * 4;
+    while (N < n) N *= 2;
+    if (!best || N < best) best = N;
+  }
+  return best;
+}
+
+static inline bool make_plan(int N, Plan* pl) {
+  pl->N = N; pl->nst = 0;
+  int n = N, rad[kMaxStages + 8], ns = 0;
+  if (n % 3 == 0) { rad[ns++] = 3; n /= 3; }
+  int k = 0;
+  while (n > 1) { if (n & 1) return false; n >>= 1; ++k; }
+  if (k & 1) rad[ns++] = 2;
+  for (int i = 0; i < k / 2; ++i) rad[ns++] = 4;
+  if (ns > kMaxStages || ns == 0) return false;
+  int L = N;
+  for (int s = 0; s < ns; ++s) {
+    const int M = L / rad[s];
+    int lg = 0;
+    while ((1 << lg) < M) ++lg;
+    if ((1 << lg) != M) return false;
+    pl->radix[s] = rad[s]; pl->L[s] = L; pl->logM[s] = lg; pl->tstep[s] = N / L;
+    L = M;
+  }
+  pl->nst = ns;
+  return true;
+}
+
+VF_DEV float2 cadd(float2 a, float2 b) { float2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+VF_DEV float2 csub(float2 a, float2 b) { float2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+VF_DEV float2 cmul(float2 a, float2 b) {            // a * b
+  float2 r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r;
+}
+VF_DEV float2 cmulc(float2 a, float2 b) {           // a * conj(b)
+  float2 r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r;
+}
+// multiply by -i (forward) or +i (inverse)
+template <bool INV> VF_DEV float2 rot90c(float2 a) {
+  float2 r;
+  if (INV) { r.x = -a.y; r.y = a.x; } else { r.x = a.y; r.y = -a.x; }
+  return r;
+}
+
+// In-place transform of C interleaved columns, buf[n * C + p].  tw[t] = exp(-2 pi i t / N).
+// Forward: DIF, stages 0..nst-1; inverse: DIT, stages nst-1..0, each the conjugate transpose of the
+// forward stage (conjugate twiddles BEFORE the conjugate butterfly) => N * ifft, natural order out.
+// The data must be visible (barrier) on entry; it is on exit.
+template <int C, bool INV>
+VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int nt) {
+  for (int ss = 0; ss < pl.nst; ++ss) {
+    const int s = INV ? pl.nst - 1 - ss : ss;
+    const int R = pl.radix[s], logM = pl.logM[s], M = 1 << logM, L = pl.L[s], ts = pl.tstep[s];
+    const int total = (pl.N / R) * C;
+    const int st = M * C;
+    for (int item = tid; item < total; item += nt) {
+      const int p = item % C, bi = item / C;
+      const int k = bi & (M - 1), blk = bi >> logM;
+      float2* b = buf + ((blk * L + k) * C + p);
+      const int t1 = k * ts;
+      if (R == 4) {
+        float2 x0 = b[0], x1 = b[st], x2 = b[2 * st], x3 = b[3 * st];
+        float2 w1, w2, w3;
+        if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; w3 = tw[3 * t1]; }
+        if (INV && k) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); x3 = cmulc(x3, w3); }
+        const float2 t0 = cadd(x0, x2), u1 = csub(x0, x2), u2 = cadd(x1, x3);
+        const float2 u3 = rot90c<INV>(csub(x1, x3));
+        float2 y0 = cadd(t0, u2), y1 = cadd(u1, u3), y2 = csub(t0, u2), y3 = csub(u1, u3);
+        if (!INV && k) { y1 = cmul(y1, w1); y2 = cmul(y2, w2); y3 = cmul(y3, w3); }
+        b[0] = y0; b[st] = y1; b[2 * st] = y2; b[3 * st] = y3;
+      } else if (R == 3) {
+        float2 x0 = b[0], x1 = b[st], x2 = b[2 * st];
+        float2 w1, w2;
+        if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; }
+        if (INV && k) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); }
+        const float2 sm = cadd(x1, x2), df = csub(x1, x2);
+        float2 h; h.x = x0.x - 0.5f * sm.x; h.y = x0.y - 0.5f * sm.y;
+        const float c3 = 0.86602540378443864676f;
+        float2 e; e.x = c3 * df.x; e.y = c3 * df.y;
+        const float2 g = rot90c<INV>(e);               // -+ i (sqrt 3 / 2) (x1 - x2)
+        float2 y0 = cadd(x0, sm), y1 = cadd(h, g), y2 = csub(h, g);
+        if (!INV && k) { y1 = cmul(y1, w1); y2 = cmul(y2, w2); }
+        b[0] = y0; b[st] = y1; b[2 * st] = y2;
+      } else {
+        float2 x0 = b[0], x1 = b[st];
+        float2 w1;
+        if (k) w1 = tw[t1];
+        if (INV && k) x1 = cmulc(x1, w1);
+        float2 y0 = cadd(x0, x1), y1 = csub(x0, x1);
+        if (!INV && k) y1 = cmul(y1, w1);
+        b[0] = y0; b[st] = y1;
+      }
+    }
+    VF_SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A: forward transform along the SLOW spatial axis (rows) of one column of 16-pair vectors.
+//   grid (ncols, nbatch); dst[batch][k1'][col][16]
+// ------------------------------------------------------------------------------------------------
+enum { kSlowTemplate = 0, kSlowMap = 1, kSlowCount = 2, kSlowMvalid = 3 };
+
+struct SlowArgs {
+  Plan pl;
+  const float2* tw;
+  int mode;
+  const float* srcf;        // TEMPLATE: q [R, sH, sW, D]; MAP: m [sH, sW, D]
+  const uint8_t* srcb;      // COUNT: tvalid [R, sH, sW]; MVALID: mvalid [sH, sW]
+  int n_in;                 // logical input rows (H, or 3 sH - 2 for the padded map)
+  int ncols;                // logical columns = gridDim.x
+  int sH, sW, D, G;         // source dims; G = 32-channel groups (batch = r * G + g / g)
+  int R, R2;                // COUNT: rotations, ceil(R / 2)
+  float2* dst;
+};
+
+VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2* buf, float2* twl) {
+  const int N = a.pl.N;
+  for (int t = tid; t < N; t += nt) twl[t] = a.tw[t];
+  const int p = tid & (kCols - 1), slot = tid >> 4, nslot = nt >> 4;
+  const int col = bx, batch = by;
+  for (int row = slot; row < N; row += nslot) {
+    float2 v; v.x = 0.f; v.y = 0.f;
+    if (row < a.n_in) {
+      if (a.mode == kSlowTemplate || a.mode == kSlowMap) {
+        int g, si, sj; int64_t img = 0;
+        if (a.mode == kSlowTemplate) {
+          const int r = batch / a.G; g = batch - r * a.G; si = row; sj = col;
+          img = (int64_t)r * a.sH * a.sW;
+        } else {                                          // edge padding folded into the load
+          g = batch;
+          si = row - (a.sH - 1); si = si < 0 ? 0 : (si > a.sH - 1 ? a.sH - 1 : si);
+          sj = col - (a.sW - 1); sj = sj < 0 ? 0 : (sj > a.sW - 1 ? a.sW - 1 : sj);
+        }
+        const int c = 32 * g + 2 * p;
+        if (c < a.D) {
+          const float* s = a.srcf + (img + (int64_t)si * a.sW + sj) * a.D + c;
+          if (c + 1 < a.D && !(a.D & 1)) v = *reinterpret_cast<const float2*>(s);
+          else { v.x = s[0]; if (c + 1 < a.D) v.y = s[1]; }
+        }
+      } else if (a.mode == kSlowCount) {
+        // count filter = 180-degree rotated template mask (pose_exhaustive_voting.py:97-99 passes
+        // q_valid UN-flipped to a true convolution); rotations rp and rp + R2 as re / im
+        const int rp = kCols * batch + p;
+        if (rp < a.R2) {
+          const int64_t idx = (int64_t)(a.sH - 1 - row) * a.sW + (a.sW - 1 - col);
+          const int64_t hw = (int64_t)a.sH * a.sW;
+          v.x = a.srcb[rp * hw + idx] ? 1.f : 0.f;
+          if (rp + a.R2 < a.R) v.y = a.srcb[(rp + a.R2) * hw + idx] ? 1.f : 0.f;
+        }
+      } else {                                            // map validity, ZERO outside the map
+        if (p == 0) {
+          const int si = row - (a.sH - 1), sj = col - (a.sW - 1);
+          if (si >= 0 && si < a.sH && sj >= 0 && sj < a.sW)
+            v.x = a.srcb[(int64_t)si * a.sW + sj] ? 1.f : 0.f;
+        }
+      }
+    }
+    buf[row * kCols + p] = v;
+  }
+  VF_SYNC();
+  fft_lds<kCols, false>(buf, twl, a.pl, tid, nt);
+  float2* d = a.dst + ((int64_t)batch * N * a.ncols + col) * kCols + p;
+  for (int row = slot; row < N; row += nslot) d[(int64_t)row * a.ncols * kCols] = buf[row * kCols + p];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel B: forward transform along the FAST spatial axis of one k1 row, then by mode
+//   STORE16 -> Z[batch][k1][k2'][16]        (map spectrum)
+//   STORE1  -> Z[k1][k2']  (column 0 only)  (map-validity spectrum)
+//   DOT     -> S[k2'] = sum_g sum_p conj(X[k2'][p]) Zm[g][k1][k2'][p]; inverse along k2 -> Y[outer][k1][b]
+//   MUL     -> X[k2'][p] = conj(X) Zv[k1][k2']; inverse along k2 (16 columns) -> Yc[batch][k1][b][16]
+//   grid (N1, nouter); x1[outer * gloop + g][k1][n_in][16]
+// ------------------------------------------------------------------------------------------------
+enum { kFastStore16 = 0, kFastStore1 = 1, kFastDot = 2, kFastMul = 3 };
+
+struct FastArgs {
+  Plan pl;
+  const float2* tw;
+  int mode;
+  const float2* x1;
+  int n_in, N1, gloop;
+  const float2* z;
+  float2* out;
+  int ld_out;               // DOT / MUL: row stride of the output in b (multiple of 16)
+  int nb_out;               // DOT / MUL: columns b written (<= min(ld_out, N))
+};
+
+VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2* buf, float2* twl,
+                      float2* sbuf) {
+  const int N = a.pl.N;
+  for (int t = tid; t < N; t += nt) twl[t] = a.tw[t];
+  if (a.mode == kFastDot)
+    for (int t = tid; t < N; t += nt) { sbuf[t].x = 0.f; sbuf[t].y = 0.f; }
+  const int p = tid & (kCols - 1), slot = tid >> 4, nslot = nt >> 4;
+  const int k1 = bx, outer = by;
+  for (int g = 0; g < a.gloop; ++g) {
+    const int64_t batch = (int64_t)outer * a.gloop + g;
+    const float4* src = reinterpret_cast<const float4*>(a.x1 + (batch * a.N1 + k1) * a.n_in * kCols);
+    float4* b4 = reinterpret_cast<float4*>(buf);
+    const int n4_in = a.n_in * (kCols / 2), n4 = N * (kCols / 2);
+    for (int i = tid; i < n4; i += nt) {
+      float4 v; v.x = v.y = v.z = v.w = 0.f;
+      if (i < n4_in) v = src[i];
+      b4[i] = v;
+    }
+    VF_SYNC();
+    fft_lds<kCols, false>(buf, twl, a.pl, tid, nt);
+    if (a.mode == kFastStore16) {
+      float4* d = reinterpret_cast<float4*>(a.out + (batch * a.N1 + k1) * N * kCols);
+      for (int i = tid; i < n4; i += nt) d[i] = b4[i];
+    } else if (a.mode == kFastStore1) {
+      for (int t = tid; t < N; t += nt) a.out[(int64_t)k1 * N + t] = buf[t * kCols];
+    } else if (a.mode == kFastDot) {
+      const float2* z = a.z + ((int64_t)g * a.N1 + k1) * N * kCols;
+      const int iters = (N + nslot - 1) / nslot;
+      for (int it = 0; it < iters; ++it) {            // uniform trip count: the shuffles below
+        const int k2 = it * nslot + slot;             // run in every lane
+        float2 pr; pr.x = 0.f; pr.y = 0.f;
+        if (k2 < N) pr = cmulc(z[k2 * kCols + p], buf[k2 * kCols + p]);   // Zm * conj(X)
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+          pr.x += VF_SHFL_XOR(pr.x, m, tid);
+          pr.y += VF_SHFL_XOR(pr.y, m, tid);
+        }
+        if (p == 0 && k2 < N) { sbuf[k2].x += pr.x; sbuf[k2].y += pr.y; }
+      }
+    } else {
+      for (int i = tid; i < N * kCols; i += nt) buf[i] = cmulc(a.z[(int64_t)k1 * N + (i >> 4)], buf[i]);
+    }
+    VF_SYNC();
+  }
+  if (a.mode == kFastDot) {
+    fft_lds<1, true>(sbuf, twl, a.pl, tid, nt);
+    float2* d = a.out + ((int64_t)outer * a.N1 + k1) * a.ld_out;
+    for (int t = tid; t < a.nb_out; t += nt) d[t] = sbuf[t];
+  } else if (a.mode == kFastMul) {
+    fft_lds<kCols, true>(buf, twl, a.pl, tid, nt);
+    float2* d = a.out + ((int64_t)outer * a.N1 + k1) * a.ld_out * kCols;
+    for (int i = tid; i < a.nb_out * kCols; i += nt) d[i] = buf[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel C: inverse transform along k1 of 16 columns, then
+//   SCORE: columns = 16 adjacent b of Y[r][k1][b]; scores[r][a][b] = Re / (N1 N2), -inf where the
+//          overlap flag is 0, / tcount[r]   (pose_exhaustive_voting.py:101-104)      grid (ld / 16, R)
+//   COUNT: columns = 16 rotation pairs of Yc[gc][k1][b][16]; flag[r][a][b] = rint(count) > thr
+//                                                                                    grid (Wo, GC)
+// ------------------------------------------------------------------------------------------------
+enum { kInvScore = 0, kInvCount = 1 };
+
+struct InvArgs {
+  Plan pl;
+  const float2* tw;
+  int mode;
+  const float2* y;
+  int ld, nb_valid;         // row stride of y in b; columns b that were written
+  int Ho, Wo, R, R2;
+  float scale, thr;
+  int use_overlap;
+  const uint8_t* flags_in;
+  uint8_t* flags_out;
+  const float* tcount;
+  float* scores;
+};
+
+VF_DEV void inv_body(const InvArgs& a, int bx, int by, int tid, int nt, float2* buf, float2* twl) {
+  const int N = a.pl.N;
+  for (int t = tid; t < N; t += nt) twl[t] = a.tw[t];
+  const int p = tid & (kCols - 1), slot = tid >> 4, nslot = nt >> 4;
+  if (a.mode == kInvScore) {
+    const int r = by, b = bx * kCols + p;
+    const float2* y = a.y + (int64_t)r * N * a.ld + b;
+    for (int row = slot; row < N; row += nslot) {
+      float2 v; v.x = 0.f; v.y = 0.f;
+      if (b < a.nb_valid) v = y[(int64_t)row * a.ld];
+      buf[row * kCols + p] = v;
+    }
+  } else {
+    const float2* y = a.y + ((int64_t)by * N * a.ld + bx) * kCols + p;
+    for (int row = slot; row < N; row += nslot) buf[row * kCols + p] = y[(int64_t)row * a.ld * kCols];
+  }
+  VF_SYNC();
+  fft_lds<kCols, true>(buf, twl, a.pl, tid, nt);
+  if (a.mode == kInvScore) {
+    const int r = by, b = bx * kCols + p;
+    if (b < a.Wo) {
+      const float tc = a.tcount[r];
+      for (int row = slot; row < a.Ho; row += nslot) {
+        const int64_t o = ((int64_t)r * a.Ho + row) * a.Wo + b;
+        float v = buf[row * kCols + p].x * a.scale;
+        if (a.use_overlap && !a.flags_in[o]) v = -INFINITY;
+        a.scores[o] = v / tc;
+      }
+    }
+  } else {
+    const int rp = kCols * by + p, b = bx;
+    if (rp < a.R2) {
+      for (int row = slot; row < a.Ho; row += nslot) {
+        const float2 c = buf[row * kCols + p];
+        a.flags_out[((int64_t)rp * a.Ho + row) * a.Wo + b] = rintf(c.x * a.scale) > a.thr ? 1 : 0;
+        if (rp + a.R2 < a.R)
+          a.flags_out[((int64_t)(rp + a.R2) * a.Ho + row) * a.Wo + b] = rintf(-c.y * a.scale) > a.thr ? 1 : 0;
+      }
+    }
+  }
+}
+
+// tw[t] = exp(-2 pi i t / N), evaluated in double precision
+VF_DEV void twiddle_body(float2* tw, int N, int t) {
+  if (t < N) {
+    const double ang = -2.0 * 3.14159265358979323846 * (double)t / (double)N;
+    float2 w; w.x = (float)cos(ang); w.y = (float)sin(ang);
+    tw[t] = w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Problem geometry, workspace carving and the launch sequence (shared with the emulation).
+// ------------------------------------------------------------------------------------------------
+struct Geometry {
+  int R, H, W, D, Hm, Wm;
+  int Hp, Wp, Ho, Wo, N1, N2, G, R2, GC, ld, nb;
+  Plan p1, p2;
+  // workspace offsets in bytes
+  size_t o_tw1, o_tw2, o_xm1, o_zm, o_x1, o_y, o_zv, o_xc1, o_yc, o_flags, total;
+};
+
+static inline size_t vf_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static inline bool make_geometry(int R, int H, int W, int D, int Hm, int Wm, Geometry* g) {
+  if (R <= 0 || H <= 0 || W <= 0 || D <= 0 || Hm <= 0 || Wm <= 0) return false;
+  g->R = R; g->H = H; g->W = W; g->D = D; g->Hm = Hm; g->Wm = Wm;
+  g->Hp = 3 * Hm - 2; g->Wp = 3 * Wm - 2;
+  g->Ho = g->Hp - H + 1; g->Wo = g->Wp - W + 1;
+  if (g->Ho <= 0 || g->Wo <= 0) return false;
+  g->N1 = fft_size(g->Hp); g->N2 = fft_size(g->Wp);
+  if (g->N1 > kMaxN || g->N2 > kMaxN) return false;
+  if (!make_plan(g->N1, &g->p1) || !make_plan(g->N2, &g->p2)) return false;
+  g->G = (D + 31) / 32;
+  g->R2 = (R + 1) / 2; g->GC = (g->R2 + kCols - 1) / kCols;
+  g->ld = (g->Wo + kCols - 1) / kCols * kCols;
+  g->nb = g->ld < g->N2 ? g->ld : g->N2;
+  const size_t c = sizeof(float2);
+  size_t o = 0;
+  g->o_tw1 = o; o += vf_align(c * g->N1);
+  g->o_tw2 = o; o += vf_align(c * g->N2);
+  g->o_xm1 = o; o += vf_align(c * kCols * (size_t)g->G * g->N1 * g->Wp);     // also the validity pass
+  g->o_zm = o;  o += vf_align(c * kCols * (size_t)g->G * g->N1 * g->N2);
+  g->o_x1 = o;  o += vf_align(c * kCols * (size_t)R * g->G * g->N1 * W);
+  g->o_y = o;   o += vf_align(c * (size_t)R * g->N1 * g->ld);
+  g->o_zv = o;  o += vf_align(c * (size_t)g->N1 * g->N2);
+  g->o_xc1 = o; o += vf_align(c * kCols * (size_t)g->GC * g->N1 * W);
+  g->o_yc = o;  o += vf_align(c * kCols * (size_t)g->GC * g->N1 * g->ld);
+  g->o_flags = o; o += vf_align((size_t)R * g->Ho * g->Wo);
+  g->total = o;
+  return true;
+}
+
+// LAUNCH: a functor with  twiddle(float2*, N), slow(SlowArgs, gx, gy), fast(FastArgs, gx, gy),
+// inv(InvArgs, gx, gy), each returning false on a launch failure.
+template <class LAUNCH>
+static inline bool run_voting(const Geometry& g, const float* q, const uint8_t* q_valid, const float* m,
+                              const uint8_t* m_valid, const float* tcount, float thr, int use_overlap,
+                              char* ws, float* scores, LAUNCH& L) {
+  float2* tw1 = reinterpret_cast<float2*>(ws + g.o_tw1);
+  float2* tw2 = reinterpret_cast<float2*>(ws + g.o_tw2);
+  float2* xm1 = reinterpret_cast<float2*>(ws + g.o_xm1);
+  float2* zm = reinterpret_cast<float2*>(ws + g.o_zm);
+  float2* x1 = reinterpret_cast<float2*>(ws + g.o_x1);
+  float2* y = reinterpret_cast<float2*>(ws + g.o_y);
+  float2* zv = reinterpret_cast<float2*>(ws + g.o_zv);
+  float2* xc1 = reinterpret_cast<float2*>(ws + g.o_xc1);
+  float2* yc = reinterpret_cast<float2*>(ws + g.o_yc);
+  uint8_t* flags = reinterpret_cast<uint8_t*>(ws + g.o_flags);
+  if (!L.twiddle(tw1, g.N1) || !L.twiddle(tw2, g.N2)) return false;
+  const float scale = (float)(1.0 / ((double)g.N1 * (double)g.N2));
+
+  SlowArgs sa; FastArgs fa; InvArgs ia;
+  if (use_overlap) {
+    // map validity -> Zv[k1'][k2']
+    sa = SlowArgs(); sa.pl = g.p1; sa.tw = tw1; sa.mode = kSlowMvalid; sa.srcf = nullptr; sa.srcb = m_valid;
+    sa.n_in = g.Hp; sa.ncols = g.Wp; sa.sH = g.Hm; sa.sW = g.Wm; sa.D = g.D; sa.G = 1; sa.R = g.R; sa.R2 = g.R2;
+    sa.dst = xm1;
+    if (!L.slow(sa, g.Wp, 1)) return false;
+    fa = FastArgs(); fa.pl = g.p2; fa.tw = tw2; fa.mode = kFastStore1; fa.x1 = xm1; fa.n_in = g.Wp; fa.N1 = g.N1;
+    fa.gloop = 1; fa.z = nullptr; fa.out = zv; fa.ld_out = 0; fa.nb_out = 0;
+    if (!L.fast(fa, g.N1, 1)) return false;
+    // template masks (rotation pairs) -> counts -> flags
+    sa.mode = kSlowCount; sa.srcb = q_valid; sa.n_in = g.H; sa.ncols = g.W; sa.sH = g.H; sa.sW = g.W; sa.dst = xc1;
+    if (!L.slow(sa, g.W, g.GC)) return false;
+    fa.mode = kFastMul; fa.x1 = xc1; fa.n_in = g.W; fa.z = zv; fa.out = yc; fa.ld_out = g.ld; fa.nb_out = g.nb;
+    if (!L.fast(fa, g.N1, g.GC)) return false;
+    ia = InvArgs(); ia.pl = g.p1; ia.tw = tw1; ia.mode = kInvCount; ia.y = yc; ia.ld = g.ld; ia.nb_valid = g.nb;
+    ia.Ho = g.Ho; ia.Wo = g.Wo; ia.R = g.R; ia.R2 = g.R2; ia.scale = scale; ia.thr = thr; ia.use_overlap = 1;
+    ia.flags_in = nullptr; ia.flags_out = flags; ia.tcount = tcount; ia.scores = nullptr;
+    if (!L.inv(ia, g.Wo, g.GC)) return false;
+  }
+  // map features -> Zm[g][k1'][k2'][16]
+  sa = SlowArgs(); sa.pl = g.p1; sa.tw = tw1; sa.mode = kSlowMap; sa.srcf = m; sa.srcb = nullptr;
+  sa.n_in = g.Hp; sa.ncols = g.Wp; sa.sH = g.Hm; sa.sW = g.Wm; sa.D = g.D; sa.G = g.G; sa.R = g.R; sa.R2 = g.R2;
+  sa.dst = xm1;
+  if (!L.slow(sa, g.Wp, g.G)) return false;
+  fa = FastArgs(); fa.pl = g.p2; fa.tw = tw2; fa.mode = kFastStore16; fa.x1 = xm1; fa.n_in = g.Wp; fa.N1 = g.N1;
+  fa.gloop = 1; fa.z = nullptr; fa.out = zm; fa.ld_out = 0; fa.nb_out = 0;
+  if (!L.fast(fa, g.N1, g.G)) return false;
+  // templates -> X1[r * G + g][k1'][j][16] -> Y[r][k1'][b] -> scores
+  sa.mode = kSlowTemplate; sa.srcf = q; sa.n_in = g.H; sa.ncols = g.W; sa.sH = g.H; sa.sW = g.W; sa.dst = x1;
+  if (!L.slow(sa, g.W, g.R * g.G)) return false;
+  fa.mode = kFastDot; fa.x1 = x1; fa.n_in = g.W; fa.gloop = g.G; fa.z = zm; fa.out = y; fa.ld_out = g.ld;
+  fa.nb_out = g.nb;
+  if (!L.fast(fa, g.N1, g.R)) return false;
+  ia = InvArgs(); ia.pl = g.p1; ia.tw = tw1; ia.mode = kInvScore; ia.y = y; ia.ld = g.ld; ia.nb_valid = g.nb;
+  ia.Ho = g.Ho; ia.Wo = g.Wo; ia.R = g.R; ia.R2 = g.R2; ia.scale = scale; ia.thr = thr; ia.use_overlap = use_overlap;
+  ia.flags_in = flags; ia.flags_out = nullptr; ia.tcount = tcount; ia.scores = scores;
+  if (!L.inv(ia, g.ld / kCols, g.R)) return false;
+  return true;
+}
+
+}  // namespace vfft
+
+#endif  // SNAP_CSRC_VOTING_FFT_BODY_H_

@@ -1,9 +1,16 @@
 """Exhaustive (x, y, theta) pose voting (``snap/models/pose_exhaustive_voting.py``).
 
-``template_matching`` is a dense contraction (2*R*(2H-1)(2W-1)*H*W*D flop): it runs
-on the f32-MFMA conv engine with the R rotated templates as an (H x W x D) -> R
-filter bank over the edge-padded map; rotation, padding and the -inf/normalise
-pass are small HIP kernels (voting.hip).
+``template_matching`` has two formulations of the same correlation:
+
+* ``method='fft'`` (voting_fft.hip; the default where the geometry fits): FFT products of the
+  templates and the edge-padded map, channel pairs packed as complex numbers, the overlap count the
+  same way and rounded to the nearest integer -- ~1e-3 of the direct form's multiply-adds, scores
+  within ~1e-6 (relative to the largest score) of the direct sum, the -inf mask identical;
+* ``method='direct'``: the dense contraction (2*R*(2H-1)(2W-1)*H*W*D flop) on the MFMA conv engine
+  with the R rotated templates as an (H x W x D) -> R filter bank over the edge-padded map -- the
+  reference's own formulation (``jax.scipy.signal.convolve``, :86-91) and the checker of the other.
+
+Rotation, padding and the -inf / normalise pass are small HIP kernels (voting.hip).
 """
 import math
 
@@ -46,7 +53,8 @@ def sample_query_templates(features, valid, num_rotations, grid, _engine=False):
   out = ops.rotate_templates(
       features.contiguous(), valid.contiguous(), tfm[: num_rotations // 4].contiguous(),
       num_rotations, grid.cell_size,
-      want_tw=_engine and not _stacked(num_rotations, (H, W)),   # (the stacked path reads `templates`)
+      # (the stacked and the frequency-domain paths read `templates`)
+      want_tw=bool(_engine) and _engine != 'fft' and not _stacked(num_rotations, (H, W)),
   )
   if _engine:
     return out
@@ -59,6 +67,24 @@ def sample_query_templates(features, valid, num_rotations, grid, _engine=False):
 # = 9 full tiles for 2.4 % more multiply-adds: the same products, summed in the same k order.
 STACK_SHIFT = 4
 STACK_MIN_CELLS = 64 * 64      # below this the plain form is already launch-bound
+# 'auto': the frequency-domain form from FFT_MIN_CELLS map cells on (below, the direct form is a
+# handful of launch-bound kernels), 'fft' / 'direct': forced.  Per call: the ``method`` argument.
+VOTING_METHOD = 'auto'
+FFT_MIN_CELLS = 64 * 64
+
+
+def _use_fft(method, R, q_hw, D, m_hw):
+  method = method or VOTING_METHOD
+  if method not in ('auto', 'fft', 'direct'):
+    raise ValueError(f'voting method {method!r}: expected auto | fft | direct')
+  if method == 'direct':
+    return False
+  ok = ops.voting_fft_supported(R, q_hw[0], q_hw[1], D, m_hw[0], m_hw[1])
+  if method == 'fft':
+    if not ok:
+      raise ValueError(f'voting method fft: map {m_hw} is beyond the transform sizes of voting_fft.hip')
+    return True
+  return ok and m_hw[0] * m_hw[1] >= FFT_MIN_CELLS
 
 
 def _stacked(R, q_hw):
@@ -141,9 +167,14 @@ def _match(tw, cw, tcount, R, q_hw, m, m_valid, min_overlap, templates=None):
   return ops.template_finalize(raw, cnt, tcount, R, thr, use_overlap=min_overlap is not None)
 
 
-def template_matching(q, q_valid, m, m_valid, do_padding=True, min_overlap=0.05):
+def template_matching(q, q_valid, m, m_valid, do_padding=True, min_overlap=0.05, method=None):
   """pose_exhaustive_voting.py:72-104 with explicit templates q [R,H,W,D]."""
   R, H, W, D = q.shape
+  if do_padding and _use_fft(method, R, (H, W), D, tuple(m.shape[:2])):
+    tcount = q_valid.sum((-1, -2)).to(torch.float32)
+    thr = 0.0 if min_overlap is None else min_overlap * H * W
+    return ops.voting_fft(q.contiguous(), q_valid.contiguous(), m.contiguous(), m_valid.contiguous(), tcount,
+                          thr, use_overlap=min_overlap is not None)
   cw = q_valid.flip(1, 2).permute(1, 2, 0).to(torch.float32)[:, :, None, :].contiguous()
   tcount = q_valid.sum((-1, -2)).to(torch.float32)
   if not do_padding:
@@ -160,15 +191,19 @@ def template_matching(q, q_valid, m, m_valid, do_padding=True, min_overlap=0.05)
   return _match(None, cw, tcount, R, (H, W), m, m_valid, min_overlap, templates=q.contiguous())
 
 
-def exhaustive_pose_voting(plane_q, plane_map, num_rotations, grid, conf_q=None):
+def exhaustive_pose_voting(plane_q, plane_map, num_rotations, grid, conf_q=None, method=None):
   """pose_exhaustive_voting.py:107-124 -> scores [R, 2H-1, 2W-1]."""
   feats_q = plane_q.features
   if conf_q is not None:
     feats_q = feats_q * conf_q[..., None]
-  templates, _, tw, cw, tcount = sample_query_templates(
-      feats_q, plane_q.valid, num_rotations, grid, _engine=True
-  )
   H, W = feats_q.shape[:2]
+  fft = _use_fft(method, num_rotations, (H, W), feats_q.shape[-1], tuple(plane_map.features.shape[:2]))
+  templates, tvalid, tw, cw, tcount = sample_query_templates(
+      feats_q, plane_q.valid, num_rotations, grid, _engine='fft' if fft else True
+  )
+  if fft:
+    return ops.voting_fft(templates, tvalid, plane_map.features.contiguous(), plane_map.valid.contiguous(),
+                          tcount, 0.05 * H * W, use_overlap=True)
   return _match(tw, cw, tcount, num_rotations, (H, W), plane_map.features, plane_map.valid, 0.05,
                 templates=templates)
 

@@ -1659,6 +1659,37 @@ def pad_map(m, mvalid):
   return mp, mvp
 
 
+def voting_fft_supported(R, H, W, D, Hm, Wm):
+  """True where ``voting_fft`` takes the geometry (<= 1024 transform points per axis)."""
+  return _lib.load().snap_voting_fft_workspace_bytes(R, H, W, D, Hm, Wm) > 0
+
+
+def voting_fft(templates, tvalid, m, mvalid, tcount, threshold, use_overlap=True):
+  """Frequency-domain template matching: templates [R,H,W,D], tvalid [R,H,W], m [Hm,Wm,D],
+  mvalid [Hm,Wm], tcount [R] -> finalised scores [R, 3Hm-1-H, 3Wm-1-W]."""
+  lib = _lib.load()
+  _f32(templates, 'templates'); _f32(m, 'map'); _f32(tcount, 'tcount')
+  if use_overlap:
+    _mask(tvalid, 'tvalid'); _mask(mvalid, 'mvalid')
+  R, H, W, D = templates.shape
+  Hm, Wm = m.shape[:2]
+  if m.shape[2] != D:
+    raise ValueError(f'voting_fft: map has {m.shape[2]} channels, templates {D}')
+  nbytes = lib.snap_voting_fft_workspace_bytes(R, H, W, D, Hm, Wm)
+  if nbytes == 0:
+    raise ValueError(f'voting_fft: unsupported geometry R={R} H={H} W={W} D={D} map {Hm}x{Wm}')
+  ws = torch.empty((nbytes,), dtype=torch.uint8, device=templates.device)
+  scores = torch.empty((R, 3 * Hm - 1 - H, 3 * Wm - 1 - W), dtype=torch.float32, device=templates.device)
+  with _region('voting_fft', flops=0.0, nbytes=4.0 * (templates.numel() + m.numel() + scores.numel())):
+    st = lib.snap_voting_fft_f32(
+        _p(templates), _p(tvalid) if use_overlap else None, _p(m), _p(mvalid) if use_overlap else None,
+        _p(tcount), R, H, W, D, Hm, Wm, float(threshold), int(bool(use_overlap)), _p(ws), nbytes, _p(scores),
+        _stream(),
+    )
+  _lib.check(st, 'snap_voting_fft_f32')
+  return scores
+
+
 def template_finalize(raw, cnt, tcount, R, threshold, use_overlap=True):
   """raw, cnt [Ho,Wo,Rp] -> scores [R,Ho,Wo]."""
   lib = _lib.load()

@@ -163,8 +163,34 @@ def _smooth_plane(H, D, seed):
   return f[0].permute(1, 2, 0).contiguous()
 
 
-def test_c4_exhaustive_voting_256_identity_and_planted_pose():
-  _voting_known_answers(256)
+@pytest.mark.parametrize('method', ['fft', 'direct'])
+def test_c4_exhaustive_voting_256_identity_and_planted_pose(method):
+  _voting_known_answers(256, method=method)
+
+
+def test_c4_voting_fft_equals_the_direct_form_at_256():
+  """C4 size (256^2 map, R = 36, D = 32): the frequency-domain voting against the direct-form GEMM on
+  the same planes -- the -inf mask IDENTICAL (the FFT overlap count is rounded to the integer the
+  direct form counts), every finite score within 1e-3 (absolute; scores are O(1) means of unit
+  features: the direct form's own split-operand rounding is the larger term), argmax equal."""
+  H, D, R = 256, 32, 36
+  DEV = helpers.DEVICE
+  f = _smooth_plane(H, D, seed=47).to(DEV)
+  q = _smooth_plane(H, D, seed=48).to(DEV)
+  g = torch.Generator().manual_seed(49)
+  vm = (torch.rand(H, H, generator=g) > 0.1).to(DEV)
+  vq = (torch.rand(H, H, generator=g) > 0.15).to(DEV)
+  q = (q * vq[..., None]).contiguous()
+  grid = grids.Grid2D((H, H), 0.2)
+  a = pev.exhaustive_pose_voting(types.FeaturePlane(q, vq), types.FeaturePlane(f, vm), R, grid, method='fft')
+  b = pev.exhaustive_pose_voting(types.FeaturePlane(q, vq), types.FeaturePlane(f, vm), R, grid, method='direct')
+  fa, fb = torch.isfinite(a), torch.isfinite(b)
+  assert torch.equal(fa, fb), int((fa != fb).sum())
+  assert 0 < int(fa.sum()) < fa.numel()
+  err = float((a[fa] - b[fb]).abs().max())
+  print(f'[voting fft vs direct @256] max |d| {err:.3e}  max |score| {float(b[fb].abs().max()):.3e}')
+  assert err < 1e-3
+  assert int(torch.argmax(a)) == int(torch.argmax(b))
 
 
 def test_c4_voting_matching_dim_64_beyond_the_presplit_engine():
@@ -174,10 +200,15 @@ def test_c4_voting_matching_dim_64_beyond_the_presplit_engine():
   from snap_amd import ops
   assert ops.conv2d_presplit_supported((1, 770, 770, 32), (259, 259, 32, 576), 4)
   assert not ops.conv2d_presplit_supported((1, 770, 770, 64), (259, 259, 64, 576), 4)
-  _voting_known_answers(256, D=64, planted=False)
+  _voting_known_answers(256, D=64, planted=False, method='direct')
 
 
-def _voting_known_answers(H, D=32, R=36, dev=None, planted=True):
+def test_c4_voting_fft_matching_dim_64():
+  """matching_dim 64 = two 32-channel groups accumulated in the frequency domain."""
+  _voting_known_answers(256, D=64, planted=False, method='fft')
+
+
+def _voting_known_answers(H, D=32, R=36, dev=None, planted=True, method=None):
   """H = W = 256, R = 36, D = 32 (3.94e13 direct-form flops per call).  Identity: the map
   against itself peaks at (0, H-1, W-1).  Planted pose: the query is the map rotated by
   rotation index k = 9 (a quarter turn, exact on the grid) and shifted by s = (3, -4) cells
@@ -188,7 +219,7 @@ def _voting_known_answers(H, D=32, R=36, dev=None, planted=True):
   ones = torch.ones(H, H, dtype=torch.bool, device=DEV)
   grid = grids.Grid2D((H, H), 0.2)
   plane = types.FeaturePlane(f, ones)
-  s = pev.exhaustive_pose_voting(plane, plane, R, grid)
+  s = pev.exhaustive_pose_voting(plane, plane, R, grid, method=method)
   assert s.shape == (R, 2 * H - 1, 2 * H - 1)
   idx = tuple(int(i) for i in np.unravel_index(int(torch.argmax(s)), s.shape))
   assert idx == (0, H - 1, H - 1)
@@ -214,7 +245,7 @@ def _voting_known_answers(H, D=32, R=36, dev=None, planted=True):
   q = torch.zeros(H * H, D, device=DEV)
   q[inside] = f[ij[inside, 0], ij[inside, 1]]
   qplane = types.FeaturePlane(q.reshape(H, H, D).contiguous(), inside.reshape(H, H).contiguous())
-  s2 = pev.exhaustive_pose_voting(qplane, plane, R, grid)
+  s2 = pev.exhaustive_pose_voting(qplane, plane, R, grid, method=method)
   idx2 = tuple(int(i) for i in np.unravel_index(int(torch.argmax(s2)), s2.shape))
   assert idx2 == (k, H - 1 + sx, H - 1 + sy), idx2
   back = pev.exhaustive_tfm_to_index(pev.exhaustive_index_to_tfm(torch.tensor(idx2, device=DEV), grid, R),

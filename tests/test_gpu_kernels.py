@@ -1293,8 +1293,9 @@ def test_refine_lattice_and_argmax_ties():
 # ----------------------------------------------------------------------------
 # exhaustive voting
 # ----------------------------------------------------------------------------
+@pytest.mark.parametrize('method', ['direct', 'fft'])
 @pytest.mark.parametrize('H,R,D', [(16, 8, 8), (24, 36, 32)])
-def test_rotate_templates_and_matching(H, R, D):
+def test_rotate_templates_and_matching(H, R, D, method):
   from oracle import grids as o_grids
   from oracle import voting as o_voting
   from snap_amd.models import pose_exhaustive_voting as pev
@@ -1318,11 +1319,11 @@ def test_rotate_templates_and_matching(H, R, D):
   helpers.report('templates', t_g.cpu().numpy()[~mism], t_w[~mism], atol=2e-5)
   s_w = o_voting.template_matching(t_w, tv_w, fm, vm)
   s_g = pev.template_matching(torch.tensor(t_w).to(DEV), torch.tensor(tv_w).to(DEV),
-                              torch.tensor(fm).to(DEV), torch.tensor(vm).to(DEV))
+                              torch.tensor(fm).to(DEV), torch.tensor(vm).to(DEV), method=method)
   helpers.report('template scores', s_g, s_w, atol=1e-4, rtol=1e-5)
   full = pev.exhaustive_pose_voting(
       types.FeaturePlane(torch.tensor(fq).to(DEV), torch.tensor(vq).to(DEV)),
-      types.FeaturePlane(torch.tensor(fm).to(DEV), torch.tensor(vm).to(DEV)), R, g)
+      types.FeaturePlane(torch.tensor(fm).to(DEV), torch.tensor(vm).to(DEV)), R, g, method=method)
   if mism.sum() == 0:
     helpers.report('exhaustive voting', full, s_w, atol=1e-4, rtol=1e-5)
   assert full.shape == (R, 2 * H - 1, 2 * H - 1)
@@ -1343,13 +1344,59 @@ def test_template_matching_shift_stacked(H, R, D, S, monkeypatch):
   vm = rng.random((H, H)) > 0.1
   args = [torch.tensor(a).to(DEV) for a in (t, tv, fm, vm)]
   monkeypatch.setattr(pev, 'STACK_SHIFT', 1)
-  plain = pev.template_matching(*args)
+  plain = pev.template_matching(*args, method='direct')
   monkeypatch.setattr(pev, 'STACK_SHIFT', S)
   monkeypatch.setattr(pev, 'STACK_MIN_CELLS', 0)
-  stacked = pev.template_matching(*args)
+  stacked = pev.template_matching(*args, method='direct')
   want = o_voting.template_matching(t, tv, fm, vm)
   helpers.report(f'stacked S={S} vs oracle', stacked, want, atol=1e-4, rtol=1e-5)
   helpers.report(f'stacked S={S} vs plain', stacked, plain, atol=2e-5, rtol=1e-6)
+
+
+@pytest.mark.parametrize('H,W,Hm,Wm,R,D', [
+    (16, 16, 16, 16, 8, 8),      # N = 48 = 3 * 4 * 4
+    (24, 24, 24, 24, 36, 32),    # N = 96 = 3 * 2 * 4 * 4: the radix-2 stage
+    (22, 22, 22, 22, 7, 34),     # N = 64 = 4^3; odd R (an unpaired rotation), two channel groups, D % 4 != 0
+    (10, 13, 12, 9, 12, 16),     # rectangular template AND a map of another size
+    (43, 43, 43, 43, 36, 64),    # N = 128 = 2 * 4^3; two full channel groups
+    (86, 86, 86, 86, 4, 8),      # N = 256
+])
+@pytest.mark.parametrize('overlap', [0.05, None])
+def test_voting_fft_vs_oracle(H, W, Hm, Wm, R, D, overlap):
+  """``snap_voting_fft_f32`` against oracle/voting.py's direct sliding-window sum: the -inf mask
+  EXACT, finite scores to 2e-5 (f32 transforms; the oracle sums in f32 too)."""
+  from oracle import voting as o_voting
+  from snap_amd.models import pose_exhaustive_voting as pev
+  rng = np.random.default_rng(500 + H + R + D)
+  t = rng.standard_normal((R, H, W, D)).astype(np.float32)
+  tv = rng.random((R, H, W)) > 0.2
+  t = t * tv[..., None]
+  fm = rng.standard_normal((Hm, Wm, D)).astype(np.float32)
+  vm = rng.random((Hm, Wm)) > 0.1
+  want = o_voting.template_matching(t, tv, fm, vm, min_overlap=overlap)
+  got = pev.template_matching(*[torch.tensor(a).to(DEV) for a in (t, tv, fm, vm)], min_overlap=overlap,
+                              method='fft').cpu().numpy()
+  assert got.shape == want.shape
+  fw, fg = np.isfinite(want), np.isfinite(got)
+  assert (fw == fg).all(), int((fw != fg).sum())
+  if overlap is not None:
+    assert (want[~fw] == got[~fg]).all()      # -inf, not +inf / NaN
+  scale = float(np.abs(want[fw]).max())
+  helpers.report(f'fft voting H={H} R={R} D={D}', got[fg], want[fw], atol=2e-5 * max(1.0, scale))
+
+
+def test_voting_fft_rejects_maps_beyond_its_transform_sizes():
+  from snap_amd.models import pose_exhaustive_voting as pev
+  assert ops.voting_fft_supported(36, 256, 256, 32, 256, 256)
+  assert ops.voting_fft_supported(36, 342, 342, 32, 342, 342)       # 3 * 342 - 2 = 1024
+  assert not ops.voting_fft_supported(36, 343, 343, 32, 343, 343)
+  q = torch.zeros(4, 8, 8, 4, device=DEV)
+  with pytest.raises(ValueError):
+    pev._use_fft('fft', 4, (343, 343), 32, (343, 343))
+  assert pev._use_fft('auto', 4, (343, 343), 32, (343, 343)) is False     # falls back to the direct form
+  assert pev._use_fft('auto', 4, (8, 8), 4, (8, 8)) is False              # small maps stay direct
+  assert pev._use_fft('auto', 36, (256, 256), 32, (256, 256)) is True
+  del q
 
 
 @pytest.mark.parametrize('H,W,R,D,S', [(24, 24, 36, 32, 4), (10, 13, 12, 16, 3), (9, 9, 8, 20, 2), (17, 16, 36, 64, 4)])
@@ -1379,9 +1426,9 @@ def test_voting_with_the_fused_template_pack_keeps_its_bits(monkeypatch):
   monkeypatch.setattr(pev, 'STACK_MIN_CELLS', 0)
   monkeypatch.setattr(ops, 'MATMUL_PRECISION', 'bf16x3')
   monkeypatch.setattr(ops, 'FUSED_TEMPLATE_PACK', True)
-  fused = pev.template_matching(*args)
+  fused = pev.template_matching(*args, method='direct')
   monkeypatch.setattr(ops, 'FUSED_TEMPLATE_PACK', False)
-  plain = pev.template_matching(*args)
+  plain = pev.template_matching(*args, method='direct')
   assert torch.equal(fused, plain)
   assert bool(torch.isfinite(fused).any())
 

@@ -3,6 +3,7 @@ API (driven through the test-only oracle backend) and failure behaviour."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -510,3 +511,82 @@ def test_sample_transforms_random_is_uniform_in_the_corner_frame():
   assert bool((centre.t.abs() <= lim + 1e-3).all()) and float(centre.t.abs().max()) > 0.9 * float(lim.min())
   again = pose_estimation.sample_transforms_random(7, 5000, grid, device='cpu')
   assert torch.equal(again.t, tf.t) and torch.equal(again.angle, tf.angle)
+
+
+# ----------------------------------------------------------------------------
+# frequency-domain voting: the numpy model and the CPU emulation of the HIP kernel bodies
+# ----------------------------------------------------------------------------
+def _voting_case(R, H, W, D, seed):
+  rng = np.random.default_rng(seed)
+  t = rng.standard_normal((R, H, W, D)).astype(np.float32)
+  tv = rng.random((R, H, W)) > 0.2
+  t = t * tv[..., None]
+  m = rng.standard_normal((H, W, D)).astype(np.float32)
+  mv = rng.random((H, W)) > 0.1
+  return t, tv, m, mv
+
+
+def test_fft_voting_model_equals_the_direct_form():
+  """tools/fft_voting_model.py (the index-exact model of voting_fft.hip: DIF forward / DIT inverse
+  mixed-radix stages, digit-reversed spectra, channel pairs and rotation pairs packed as complex
+  numbers) against oracle/voting.py's sliding-window sum."""
+  sys.path.insert(0, os.path.join(ROOT, 'tools'))
+  import fft_voting_model as fm
+  from oracle import voting as o_voting
+  for N in (12, 16, 24, 32, 48, 96, 768):
+    x = np.random.default_rng(N).standard_normal((N, 2)) + 1j * np.random.default_rng(N + 1).standard_normal((N, 2))
+    X = fm.dif_forward(x, 0)
+    ref = np.fft.fft(x, axis=0)
+    perm = [int(np.argmin(np.abs(ref[:, 0] - X[k, 0]))) for k in range(N)]
+    assert sorted(perm) == list(range(N))                      # a permutation of the spectrum ...
+    np.testing.assert_allclose(X, ref[perm], atol=1e-9)
+    np.testing.assert_allclose(fm.dit_inverse(X, 0) / N, x, atol=1e-9)   # ... that the inverse undoes
+  for (R, H, W, D) in [(4, 8, 8, 6), (9, 5, 7, 4)]:
+    t, tv, m, mv = _voting_case(R, H, W, D, 7)
+    want = o_voting.template_matching(t, tv, m, mv)
+    got = fm.template_matching_fft(t, tv, m, mv)
+    fin = np.isfinite(want)
+    assert (fin == np.isfinite(got)).all()
+    np.testing.assert_allclose(got[fin], want[fin], atol=2e-6)
+
+
+def test_voting_fft_kernel_bodies_on_the_cpu_emulation():
+  """The kernel bodies of snap_amd/csrc/voting_fft_body.h -- the same header hipcc compiles into
+  libsnap_hip.so -- built with g++ (tests/emu/voting_fft_emu.cpp: a pthread per GPU thread, a barrier
+  per __syncthreads) and run against oracle/voting.py: plan, index arithmetic, workspace carving and
+  launch sequence checked without a GPU (odd R, two channel groups with a partial one, a rectangular
+  map; with and without the overlap mask)."""
+  import ctypes
+  import subprocess
+  from oracle import voting as o_voting
+  build = os.path.join(ROOT, 'tests', '_build')
+  os.makedirs(build, exist_ok=True)
+  so = os.path.join(build, 'libvoting_fft_emu.so')
+  src = os.path.join(ROOT, 'tests', 'emu', 'voting_fft_emu.cpp')
+  hdr = os.path.join(ROOT, 'snap_amd', 'csrc', 'voting_fft_body.h')
+  if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread',
+                    '-I' + os.path.join(ROOT, 'snap_amd', 'csrc'), src, '-o', so], check=True)
+  lib = ctypes.CDLL(so)
+  lib.emu_voting_fft_workspace_bytes.restype = ctypes.c_size_t
+  lib.emu_voting_fft_workspace_bytes.argtypes = [ctypes.c_int] * 6
+  lib.emu_voting_fft_f32.restype = ctypes.c_int
+  lib.emu_voting_fft_f32.argtypes = ([ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 +
+                                     [ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int])
+  for (R, H, W, D, nt, overlap) in [(4, 8, 8, 6, 32, 0.05), (3, 6, 6, 34, 16, 0.05), (5, 5, 7, 4, 32, None)]:
+    t, tv, m, mv = _voting_case(R, H, W, D, 11 + R)
+    nb = lib.emu_voting_fft_workspace_bytes(R, H, W, D, H, W)
+    assert nb > 0
+    ws = np.zeros(nb + 256, np.uint8)
+    off = (-ws.ctypes.data) % 256
+    out = np.full((R, 2 * H - 1, 2 * W - 1), np.nan, np.float32)
+    tvb, mvb = tv.astype(np.uint8), mv.astype(np.uint8)
+    tc = tv.sum((-1, -2)).astype(np.float32)
+    rc = lib.emu_voting_fft_f32(t.ctypes.data, tvb.ctypes.data, m.ctypes.data, mvb.ctypes.data, tc.ctypes.data,
+                                R, H, W, D, H, W, float(0.0 if overlap is None else overlap * H * W),
+                                int(overlap is not None), ws.ctypes.data + off, out.ctypes.data, nt)
+    assert rc == 0
+    want = o_voting.template_matching(t, tv, m, mv, min_overlap=overlap)
+    fin = np.isfinite(want)
+    assert (fin == np.isfinite(out)).all()
+    np.testing.assert_allclose(out[fin], want[fin], atol=5e-6)
