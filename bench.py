@@ -59,7 +59,7 @@ WORKLOADS = {
                     'batch 32 over 8 GPUs = 4 scenes/GPU, forward'),
     'c4': dict(batch=1, c4=True, tiny=False,
                desc='C4: eval_localization pose-estimation path on a 256x256 BEV map (D = 32): exhaustive '
-                    '(x, y, theta) voting with 36 yaw hypotheses (rotated templates + direct correlation, '
+                    '(x, y, theta) voting with 36 yaw hypotheses (rotated templates correlated with the edge-padded map, '
                     '[36, 511, 511] scores) + point-vs-map similarity for the 4652 frustum points + scoring '
                     'of 20 001 pose hypotheses + the 41^3 refinement lattice; one scene per step'),
     'tiny': dict(batch=2, views=3, image=64, grid=(6.4, 6.4, 12), tiny=True,
@@ -92,7 +92,7 @@ def build(workload, device, rank, materialize_volume=True):
   return loc, cfg, meta, variables, batch
 
 
-def build_c4(device, rank):
+def build_c4(device, rank, method='auto'):
   """Synthetic 256^2 planes for the eval pose-estimation path (unit-norm random
   features smoothed with a 2-cell Gaussian so that the correlation peak is unique)."""
   import math
@@ -134,7 +134,8 @@ def build_c4(device, rank):
   def step(i):
     # (the outer region times the WHOLE voting call: rotate, pad, stack, correlate, count, finalize)
     with ops._region('exhaustive_voting_total', algo['voting_flops'], algo['voting_bytes']):
-      votes = pev.exhaustive_pose_voting(types.FeaturePlane(fqp, ones), types.FeaturePlane(fm, ones), R, grid)
+      votes = pev.exhaustive_pose_voting(types.FeaturePlane(fqp, ones), types.FeaturePlane(fm, ones), R, grid,
+                                         method=method)
     sim, _, _, _ = ops.sim_softmax(fq, fm[None], scale, True, nv)
     scores = ops.pose_score(sim, poses, q_xy, vq, ones[None], cell)
     best = ops.argmax_rows(scores).to(torch.int64)
@@ -381,6 +382,9 @@ def main(argv=None, emit=True):
                   help="infer mode: conv / dense engine.  'f32' = exact f32 MFMA (v_mfma_f32_32x32x2_f32); "
                        "'bf16x6' / 'bf16x3' = f32-grade split-bf16 engine (each f32 operand split into 3 / 2 "
                        "bf16 parts, 6 / 3 part products on v_mfma_f32_32x32x16_bf16, f32 accumulate)")
+  ap.add_argument('--voting', default='auto', choices=['auto', 'fft', 'direct'],
+                  help="c4: exhaustive-voting formulation ('auto' = frequency domain where the map fits its transform "
+                       "sizes; 'direct' = the reference's direct-form correlation on the MFMA conv engine)")
   ap.add_argument('--materialize-volume', action='store_true',
                   help='infer mode: also write the dense [B, X, Y, Z, D] StreetView feature volume (an '
                        'intermediate the localisation outputs do not need; under jit the reference drops it '
@@ -411,7 +415,7 @@ def main(argv=None, emit=True):
   if is_c4:
     if args.mode != 'infer':
       raise SystemExit('--workload c4 is an inference (eval) path')
-    c4_step, c4_algo = build_c4(device, rank)
+    c4_step, c4_algo = build_c4(device, rank, args.voting)
     loc = cfg = meta = variables = batch = None
   else:
     loc, cfg, meta, variables, batch = build(
@@ -421,26 +425,28 @@ def main(argv=None, emit=True):
 
   if args.mode == 'train':
     from snap_amd import models, trainer
-    model = models.get_model('bev_localizer')(cfg, meta)
+    # the reference's selection (trainer.py:387-397): config.dtype_str -> dtype -> model + DynamicScale;
+    # the f32-grade split engines are float32 models with an explicit engine
+    dtype_str = {'fp16': 'float16', 'bf16': 'bfloat16'}.get(args.precision, 'float32')
+    dtype, dyn_scale = trainer.dtype_and_dynamic_scale(dtype_str)
+    model = models.get_model('bev_localizer')(
+        cfg, meta, dtype, engine=args.precision if dtype == torch.float32 else None)
     tcfg = train_localization.get_config()
     lr_fn = trainer.make_lr_fn(tcfg.lr_configs['base_learning_rate'], tcfg.num_training_steps)
-    state = trainer.TrainState.create(
-        variables['params'], rng=1000 * rank,
-        # (trainer.py:391-392: float16 runs carry DynamicScale(minimum_scale=256))
-        dynamic_scale=trainer.DynamicScale(minimum_scale=256.0) if args.precision == 'fp16' else None)
+    state = trainer.TrainState.create(variables['params'], rng=1000 * rank, dynamic_scale=dyn_scale)
     last_logs = {}
 
     def step(i):
       nonlocal state
-      state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn,
-                                          precision=args.precision)
+      state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn)   # (the model's engine)
       last_logs.update(logs)
       return logs
   elif is_c4:
-    ops.MATMUL_PRECISION = args.math     # the correlation runs on the selected conv engine
-    step = c4_step
+    def step(i):
+      with ops.engine_scope(args.math):  # the direct-form correlation (if selected) runs on this engine
+        return c4_step(i)
   else:
-    ops.MATMUL_PRECISION = args.math
+    loc.engine = args.math               # the arithmetic is a property of the model (models/base.py)
 
     def step(i):
       return loc.apply(variables, batch, train=False, rngs={'sampling': 1000 * rank + i})
@@ -646,7 +652,35 @@ def main(argv=None, emit=True):
         conv = [n for n in summ if n.startswith('conv_')]
         vms = summ.get('exhaustive_voting_total', {}).get('ms', 0.0)
         kern.pop('exhaustive_voting_total', None)
-        if vms > 0:
+        gbs = c4_algo['voting_bytes'] / vms / 1e6 if vms > 0 else 0.0
+        if vms > 0 and 'voting_fft' in summ:
+          # frequency-domain formulation: ~1e-3 of the direct form's multiply-adds -- the call is held to the
+          # HBM roofline on SURVEY 8(d)'s algorithmic bytes (templates + map + scores = what any formulation
+          # must move); `pipeline_hbm_bytes` is what THIS pipeline moves on top (its intermediate spectra)
+          H_, D_, R_, N_, ld_ = 256, 32, 36, 768, 512
+          pipe = (4.0 * R_ * H_ * H_ * D_                      # rotated templates written ...
+                  + 4.0 * R_ * H_ * H_ * D_                    # ... and read by the first transform
+                  + 2 * 128.0 * R_ * N_ * H_                   # X1[r][k1][j][16]: written, read
+                  + 2 * 128.0 * N_ * (3 * H_ - 2) + 128.0 * N_ * N_   # map: Xm1 written / read, Zm written
+                  + 2 * 8.0 * R_ * N_ * ld_                    # Y[r][k1][b]: written, read
+                  + 4.0 * R_ * (2 * H_ - 1) ** 2)              # scores
+          out['roofline'] = {
+              'kernel': 'exhaustive_voting (rotate + voting_fft: vf_slow / vf_fast / vf_inv kernels)',
+              'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+              'frac': round(gbs / PEAK_HBM_GBS, 5), 'traffic': None, 'ms': round(vms, 3),
+              'formulation': 'frequency domain (voting_fft.hip): 768-point mixed-radix LDS FFTs of 16 channel-pair '
+                             'columns, spectra multiplied in digit-reversed order, overlap count by rotation pairs',
+              'algorithmic_bytes': c4_algo['voting_bytes'],
+              'pipeline_hbm_bytes': pipe, 'pipeline_gbs': round(pipe / vms / 1e6, 1),
+              'pipeline_frac': round(pipe / vms / 1e6 / PEAK_HBM_GBS, 4),
+              'fft_ms': round(summ['voting_fft']['ms'], 3),
+              'flops_direct_form': c4_algo['voting_flops'],
+              'direct_form_equivalent_tflops': round(c4_algo['voting_flops'] / vms / 1e9, 1),
+          }
+          out['roofline_voting_hbm'] = {k: out['roofline'][k] for k in
+                                        ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_bytes',
+                                         'formulation')}
+        elif vms > 0:
           nprod = max([SPLIT_PRODUCTS.get(n, 0) for n in conv] + [0])
           peak = PEAK_MFMA_BF16_TFLOPS / nprod if nprod else PEAK_MFMA_F32_TFLOPS
           ach = c4_algo['voting_flops'] / vms / 1e9
@@ -657,7 +691,6 @@ def main(argv=None, emit=True):
               'formulation': 'direct form (as the reference: jax.scipy.signal.convolve), shift-stacked',
               'flops_direct_form': c4_algo['voting_flops'],
           }
-          gbs = c4_algo['voting_bytes'] / vms / 1e6
           out['roofline_voting_hbm'] = {
               'kernel': 'exhaustive_voting', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
               'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5), 'algorithmic_bytes': c4_algo['voting_bytes'],
@@ -674,8 +707,8 @@ def main(argv=None, emit=True):
       # every output written ('f32_exact'), and the headline engine with the dense feature volume
       # written ('volume_materialized').
       def leg(math, steps=5, warmup=2):
-        prev = (ops.MATMUL_PRECISION, cfg.bev_mapper.materialize_volume)
-        ops.MATMUL_PRECISION, cfg.bev_mapper.materialize_volume = math, True
+        prev = (loc.engine, cfg.bev_mapper.materialize_volume)
+        loc.engine, cfg.bev_mapper.materialize_volume = math, True
         try:
           p = None
           for i in range(warmup):
@@ -691,7 +724,7 @@ def main(argv=None, emit=True):
           vol = p['map']['streetview']['feature_volume']
           assert getattr(vol, 'materialized', True) and vol.features is not None
         finally:
-          ops.MATMUL_PRECISION, cfg.bev_mapper.materialize_volume = prev
+          loc.engine, cfg.bev_mapper.materialize_volume = prev
         return {'ms_per_step': round(1e3 * dt / steps, 3),
                 'scenes_per_sec': round(scenes_per_rank * steps / dt, 3),
                 'steps': steps, 'warmup': warmup, 'dtype': INFER_DTYPE[math],
@@ -708,6 +741,8 @@ def main(argv=None, emit=True):
       dump_env = os.environ.pop('SNAP_BENCH_DUMP', None)     # (the legs must not overwrite the C2 dump)
       for key, leg_args in (
           ('train_c3', ['--mode', 'train', '--workload', 'c3', '--precision', 'bf16', '--steps', '5', '--warmup', '2']),
+          # the reference's literal train config: dtype_str = 'float16' + DynamicScale(minimum_scale=256)
+          ('train_c3_fp16', ['--mode', 'train', '--workload', 'c3', '--precision', 'fp16', '--steps', '5', '--warmup', '2']),
           ('c4', ['--workload', 'c4', '--steps', '3', '--warmup', '1']),
           ('c5', ['--workload', 'c5', '--steps', '5', '--warmup', '2'])):
         torch.cuda.empty_cache()
@@ -725,9 +760,10 @@ def main(argv=None, emit=True):
           }
           if 'train_logs' in r:
             out[key]['is_finite'] = r['train_logs'].get('is_finite')
+            if 'loss_scale' in r['train_logs']:
+              out[key]['loss_scale'] = r['train_logs']['loss_scale']
         except Exception as e:   # a leg must never take the headline down
           out[key] = {'error': repr(e)}
-      ops.MATMUL_PRECISION = args.math
       if dump_env is not None:
         os.environ['SNAP_BENCH_DUMP'] = dump_env
     if args.mode == 'train':

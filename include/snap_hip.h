@@ -802,12 +802,15 @@ int snap_vertical_pool_conf_bwd_f32(const float* vol, const uint8_t* vvalid, con
  * ------------------------------------------------------------------------- */
 /* dw[KH*KW*Cin, Cout] (+)= im2col(prologue(x))^T dy   on f32 MFMA; dy [N,Ho,Wo,Cout]. */
 size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc);
-/* A/B switch (tools, tests) of the half-precision engines' plans, a bit mask; returns the previous one.
- * Bit 0: flat kernel gradients (1 x 1, Cin >= 192, >= 65 536 rows) on the 512-thread 256-wide tiles; bit 1:
- * 3 x 3 / stride 1 / pad 1 kernel gradients with a half-precision dy on the fused-tap kernel (all nine taps
- * per workgroup, patch-ordered reduction).  A cleared bit keeps the per-tap 128 x 128 tiles.  Same rounded
- * operands, another summation order.  Default 3. */
-int32_t snap_conv2d_wgrad_set_wide(int32_t on);
+/* Per-call A/B switches (tools, tests) of the half-precision engines' plans, OR-ed into
+ * desc->tile_hint of a snap_conv2d_wgrad_* call (no process-wide state):
+ *   SNAP_WGRAD_NO_WIDE   flat kernel gradients (1 x 1, Cin >= 192, >= 65 536 rows) stay on the per-tap
+ *                        128 x 128 tiles instead of the 512-thread 256-wide tiles;
+ *   SNAP_WGRAD_NO_FUSED3 3 x 3 / stride 1 / pad 1 kernel gradients with a half-precision dy stay on the
+ *                        per-tap kernel instead of the fused-tap kernel (all nine taps per workgroup,
+ *                        patch-ordered reduction).
+ * Same rounded operands, another summation order.  Default (0): both plans where they apply. */
+enum { SNAP_WGRAD_NO_WIDE = 1 << 8, SNAP_WGRAD_NO_FUSED3 = 1 << 9 };
 int snap_conv2d_wgrad_f32(const SnapConvDesc* desc, const float* x, const float* dy,
                           float* dw, const float* gn_mu, const float* gn_sc,
                           const float* gn_beta, int32_t accumulate, void* workspace,

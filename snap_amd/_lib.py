@@ -244,7 +244,6 @@ SIGNATURES = {
     ),
     # ---- training path ----
     'snap_conv2d_wgrad_workspace_bytes': (c_size, [ctypes.POINTER(SnapConvDesc)]),
-    'snap_conv2d_wgrad_set_wide': (c_int, [c_int]),
     'snap_conv2d_wgrad_f32': (
         c_int,
         [ctypes.POINTER(SnapConvDesc), ptr, ptr, ptr, ptr, ptr, ptr, c_int, ptr, c_size, ptr],
@@ -319,7 +318,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 

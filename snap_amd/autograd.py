@@ -17,6 +17,27 @@ from snap_amd import ops_bwd
 _GN_MODES = (ops.PRO_GN_RELU, ops.PRO_RELU_GN)
 
 
+def _engine_scoped(cls):
+  """Class decorator of every Function below: the node records the engine in force at its forward
+  (``ops.precision()``: the applying model's, see ops.engine_scope) and re-enters it in its backward
+  -- autograd runs backward passes on its own threads, where the forward thread's scope is not
+  visible.  A model's backward therefore runs on the model's engine whatever else the process is
+  doing, and two models of different precision can be trained / evaluated side by side."""
+  fwd, bwd = cls.forward, cls.backward
+
+  def forward(ctx, *args):
+    ctx._snap_engine = ops.precision()
+    return fwd(ctx, *args)
+
+  def backward(ctx, *grads):
+    with ops.engine_scope(ctx._snap_engine):
+      return bwd(ctx, *grads)
+
+  cls.forward = staticmethod(forward)
+  cls.backward = staticmethod(backward)
+  return cls
+
+
 # ----------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------
@@ -54,7 +75,7 @@ def conv_dgrad(dy, w, x_shape, stride, padding, accumulate=None, accumulate_inpl
     dyd[:, ::stride, ::stride] = dy
     dy = dyd
   Ho, Wo = dy.shape[1:3]
-  half_math = ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None
+  half_math = ops.precision() if ops.precision() in ops.HALF_MATH else None
   rot_img = ops.packed_rot_image(w, half_math) if half_math else None
   # (the image-only weight below is read only by the bf16 / fp16 engine, which takes the
   #  launch when the rotated kernel's input channels -- the original Cout -- form aligned quads;
@@ -132,6 +153,7 @@ def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid, row_weight=None):
 # ----------------------------------------------------------------------------
 # conv / dense
 # ----------------------------------------------------------------------------
+@_engine_scoped
 class _FusedConv(torch.autograd.Function):
 
   @staticmethod
@@ -197,7 +219,7 @@ class _FusedConv(torch.autograd.Function):
         dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
             x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), prologue,
             add=dalias.contiguous() if fused_add else None,
-            half=ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None,
+            half=ops.precision() if ops.precision() in ops.HALF_MATH else None,
         )
         if fused_add:
           dalias = None
@@ -217,6 +239,7 @@ class _FusedConv(torch.autograd.Function):
     return dx, dw, dgamma, dbeta, dbias, dres, dup, None
 
 
+@_engine_scoped
 class _SharedPrologueConvPair(torch.autograd.Function):
   """Two convolutions behind ONE GroupNorm -> ReLU of the same tensor (a projection unit's conv1 and
   conv_proj, resnet.py:117-124 of the reference): the statistics are taken once, and in the backward
@@ -257,7 +280,7 @@ class _SharedPrologueConvPair(torch.autograd.Function):
                       gn_bwd_stats=gnb)
       dx, dgamma, dbeta = ops_bwd.group_norm_bwd(
           x, dz, mu, rstd, gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous(), ops.PRO_GN_RELU,
-          half=ops.MATMUL_PRECISION if ops.MATMUL_PRECISION in ops.HALF_MATH else None)
+          half=ops.precision() if ops.precision() in ops.HALF_MATH else None)
       dgamma = dgamma.reshape(gamma.shape)
       dbeta = dbeta.reshape(beta.shape)
     return dx, dw1, dw2, dgamma, dbeta, None
@@ -297,6 +320,7 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=ops.PRO_NONE, relu=False, 
   return y.reshape(*lead, kernel.shape[1])
 
 
+@_engine_scoped
 class _SemanticEmbed(torch.autograd.Function):
   """Embedding lookups of the semantic rasters; table gradients = one-hot^T @ dy on the
   deterministic wgrad engine (exact f32), then the few rows are regrouped on the host."""
@@ -334,6 +358,7 @@ def semantic_embed(rasters, idx_road, idx_other, table_road, table_other):
 # ----------------------------------------------------------------------------
 # ViT pieces (vit_ops.hip / vit_bwd.hip)
 # ----------------------------------------------------------------------------
+@_engine_scoped
 class _LayerNorm(torch.autograd.Function):
 
   @staticmethod
@@ -353,6 +378,7 @@ def layer_norm(x, gamma, beta, eps=1e-6):
   return _LayerNorm.apply(x.contiguous(), gamma, beta, eps)
 
 
+@_engine_scoped
 class _Gelu(torch.autograd.Function):
 
   @staticmethod
@@ -370,6 +396,7 @@ def gelu(x):
   return _Gelu.apply(x.contiguous())
 
 
+@_engine_scoped
 class _Attention(torch.autograd.Function):
 
   @staticmethod
@@ -389,6 +416,7 @@ def attention(qkv, scale=None):
   return _Attention.apply(qkv.contiguous(), scale)
 
 
+@_engine_scoped
 class _MaskedRowsMLP(torch.autograd.Function):
   """ReLU MLP over the rows with mask != 0 only; masked rows of the output are zero.
 
@@ -410,7 +438,7 @@ class _MaskedRowsMLP(torch.autograd.Function):
     # and, in the backward pass, the gradient w.r.t. it -- exist ONLY in the engine's element type
     # (compact rows).  Every consumer rounds them to that type anyway, so nothing changes in the
     # arithmetic; they move at half the bytes and their GEMMs read them by LDS-DMA.
-    half = (MASKED_MLP_HALF and ops.MATMUL_PRECISION in ops.HALF_MATH and n == 2 and x.shape[-1] % 4 == 0
+    half = (MASKED_MLP_HALF and ops.precision() in ops.HALF_MATH and n == 2 and x.shape[-1] % 4 == 0
             and wb[0].shape[0] >= 4 and wb[0].shape[1] % 8 == 0 and wb[2].shape[1] % 4 == 0)
     for i in range(n):
       W, b = wb[2 * i], wb[2 * i + 1]
@@ -546,6 +574,7 @@ def masked_rows_mlp(x, mask, relu_input, weights_and_biases):
   return _MaskedRowsMLP.apply(x, mask, relu_input, *weights_and_biases)
 
 
+@_engine_scoped
 class _WeightStd(torch.autograd.Function):
 
   @staticmethod
@@ -563,6 +592,7 @@ def weight_standardize(w):
   return _WeightStd.apply(w)
 
 
+@_engine_scoped
 class _WeightStdMulti(torch.autograd.Function):
   """All StdConv kernels of an encoder: one launch forward, one backward."""
 
@@ -588,6 +618,7 @@ def weight_standardize_multi(ws):
   return _WeightStdMulti.apply(*ws)
 
 
+@_engine_scoped
 class _MaxPool(torch.autograd.Function):
 
   @staticmethod
@@ -608,6 +639,7 @@ def max_pool_3x3s2(x):
 # ----------------------------------------------------------------------------
 # lift / BEV
 # ----------------------------------------------------------------------------
+@_engine_scoped
 class _LiftPool(torch.autograd.Function):
 
   @staticmethod
@@ -638,6 +670,7 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins, d
   return _LiftPool.apply(f_images, cam, Rt, points, cfg)
 
 
+@_engine_scoped
 class _LiftObservations(torch.autograd.Function):
   """First pass of the depth_mlp fusion (streetview_encoder.py:263-267): the un-pooled
   observations.  Depth and viewing ray are geometry: only the feature channels carry gradient."""
@@ -667,6 +700,7 @@ def lift_observations(f_images, cam, Rt, points, *, K, fisheye, feature_dim, max
   return _LiftObservations.apply(f_images, cam, Rt, points, (K, fisheye, feature_dim, max_view_distance))
 
 
+@_engine_scoped
 class _LiftPoolObservations(torch.autograd.Function):
   """Second pass: pool_multiview_features of the corrected observations."""
 
@@ -697,6 +731,7 @@ def lift_pool_observations(obs_feat, f_shape, cam, Rt, points, *, K, fisheye, fe
   return _LiftPoolObservations.apply(obs_feat.contiguous(), cam, Rt, points, cfg)
 
 
+@_engine_scoped
 class _VerticalPool(torch.autograd.Function):
 
   @staticmethod
@@ -717,6 +752,7 @@ def vertical_pool(vol, valid, pooling='max'):
   return _VerticalPool.apply(vol, valid, pooling)
 
 
+@_engine_scoped
 class _VerticalPoolConf(torch.autograd.Function):
   """'softmax' / 'weighted' VerticalPooling.  The scores / weights outputs are diagnostic
   (pred['scores'], pred['weights']; nothing in the localisation loss reads them) and are
@@ -744,6 +780,7 @@ def vertical_pool_conf(vol, valid, w, bias, log_sigmoid_scores):
   return _VerticalPoolConf.apply(vol, valid, w, bias, log_sigmoid_scores)
 
 
+@_engine_scoped
 class _PlaneFuseMatch(torch.autograd.Function):
 
   @staticmethod
@@ -791,6 +828,7 @@ def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None, normalize=
 # ----------------------------------------------------------------------------
 # pose head
 # ----------------------------------------------------------------------------
+@_engine_scoped
 class _ConfidenceHead(torch.autograd.Function):
   """bev_confidence = where(valid, log_sigmoid(Dense(1)(features)), 0)  (bev_mapper.py:154-157,292-295)."""
 
@@ -813,6 +851,7 @@ def confidence_head(features, valid, kernel, bias):
   return _ConfidenceHead.apply(features.contiguous(), kernel, bias, valid)
 
 
+@_engine_scoped
 class _MaskedSoftmaxRows(torch.autograd.Function):
   """layers.masked_softmax over the last axis (layers.py:38-43) of x [B, N] (+ its CDF, no gradient)."""
 
@@ -833,6 +872,7 @@ def masked_softmax_rows(x, mask):
   return _MaskedSoftmaxRows.apply(x.contiguous(), mask.contiguous())
 
 
+@_engine_scoped
 class _SimSoftmaxWeighted(torch.autograd.Function):
   """sim = relu(fq . fm) * exp(T) * weights[b, n]  (add_confidence_query, bev_localizer.py:165-168)."""
 
@@ -866,6 +906,7 @@ def sim_softmax_weighted(fq, fm, temperature, weights, clip_negative, num_valid,
   return sim, stats, (prob if want_prob else None), scale
 
 
+@_engine_scoped
 class _SimSoftmax(torch.autograd.Function):
 
   @staticmethod
@@ -896,6 +937,7 @@ def sim_softmax(fq, fm, temperature, clip_negative, num_valid, want_prob=False):
   return sim, stats, (prob if want_prob else None), scale
 
 
+@_engine_scoped
 class _PoseScore(torch.autograd.Function):
 
   @staticmethod

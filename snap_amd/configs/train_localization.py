@@ -27,8 +27,9 @@ def get_config(args_str: None | str = None) -> ConfigDict:
     model.bev_mapper_query = query
   return ConfigDict(
       model_name='bev_localizer', model=model, batch_size=1, rng_seed=0,
-      # the reference trains in float16 with dynamic loss scaling (train_localization.py:93);
-      # this build computes the training step in float32 (>= that precision, no scaling needed)
-      dtype_str='float32', voxel_size=0.2,
+      # the reference trains in float16 with dynamic loss scaling (train_localization.py:93):
+      # ``trainer.dtype_and_dynamic_scale(config.dtype_str)`` -> (torch.float16, DynamicScale(256)),
+      # and ``model_cls(config.model, meta, dtype)`` then runs the IEEE-half engine ('fp16')
+      dtype_str='float16', voxel_size=0.2,
       lr_configs=dict(base_learning_rate=5e-5), num_training_steps=400_000,
   )

@@ -328,13 +328,9 @@ int wg_launch_pro(const WgradArgs& a, const WgPlan& p, hipStream_t s) {
 
 }  // namespace
 
-// A/B switch of the wide plan (tools / tests; the workspace is always sized for it)
-static int g_wgrad_wide = 3;      // bit 0: the wide flat plan; bit 1: the fused-tap 3 x 3 plan
-extern "C" int32_t snap_conv2d_wgrad_set_wide(int32_t on) {
-  const int prev = g_wgrad_wide;
-  g_wgrad_wide = on & 3;
-  return prev;
-}
+// (the A/B switches of the wide / fused-tap plans travel PER CALL in desc->tile_hint:
+//  SNAP_WGRAD_NO_WIDE / SNAP_WGRAD_NO_FUSED3 -- no process-wide state; the workspace is always sized
+//  for every plan)
 
 extern "C" size_t snap_conv2d_wgrad_workspace_bytes(const SnapConvDesc* desc) {
   if (!desc) return 0;
@@ -412,10 +408,11 @@ extern "C" int snap_conv2d_wgrad_half_f32(const SnapConvDesc* desc, const void* 
   const bool vec = (d.Cin_stride % 4 == 0) && (d.Cin >= 4) &&
                    ((reinterpret_cast<uintptr_t>(x) & (x_is_half ? 7 : 15)) == 0) && (!gn || (d.Cin % 4 == 0));
   if ((x_is_half || dy_is_half) && !vec) return SNAP_ERR_UNSUPPORTED;
-  const bool fused3 = (g_wgrad_wide & 2) &&
+  const bool allow_wide = !(d.tile_hint & SNAP_WGRAD_NO_WIDE), allow_fused3 = !(d.tile_hint & SNAP_WGRAD_NO_FUSED3);
+  const bool fused3 = allow_fused3 &&
                       snapwg::wg_3x3_ok(d, vec, math, x_is_half != 0, dy_is_half != 0, rows_z || rows_dy || row_count);
   const WgPlan p = fused3 ? snapwg::wg_plan_3x3(d)
-                   : ((g_wgrad_wide & 1) && snapwg::wg_wide_ok(d, vec, math)) ? snapwg::wg_plan_wide(d) : wg_plan(d, vec);
+                   : (allow_wide && snapwg::wg_wide_ok(d, vec, math)) ? snapwg::wg_plan_wide(d) : wg_plan(d, vec);
   WgradArgs a;
   a.d = d;
   a.x = x; a.dy = dy; a.partial = static_cast<float*>(workspace);

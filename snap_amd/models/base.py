@@ -17,6 +17,8 @@ from typing import Any, Callable, Dict, Optional, Tuple
 
 import torch
 
+from snap_amd import ops
+
 Batch = Dict[str, Any]
 Predictions = Dict[str, Any]
 LossMetricsTuple = Tuple[Dict[str, Any], Dict[str, Any]]
@@ -122,7 +124,10 @@ class Module:
       seed = rngs.get('sampling')
     elif rngs is not None:
       seed = rngs
-    out = self(variables['params'], *args, rng=seed, **kwargs)
+    # the arithmetic of this apply is the MODEL's (BaseModel(dtype=, engine=) sets ``engine`` on its
+    # flax_model); a bare Module without one runs on whatever scope / process default is in force
+    with ops.engine_scope(getattr(self, 'engine', None)):
+      out = self(variables['params'], *args, rng=seed, **kwargs)
     if mutable:
       return out, {}
     return out
@@ -149,11 +154,28 @@ def truncated_normal(gen, shape, std, device):
 class BaseModel:
   """Trainer-facing wrapper (snap/models/base.py:32-67)."""
 
-  def __init__(self, config, dataset_meta_data: Dict[str, Any], dtype=torch.float32):
+  def __init__(self, config, dataset_meta_data: Dict[str, Any], dtype=torch.float32, engine=None):
+    """``dtype`` selects the arithmetic as in the reference (``model_cls(config.model, meta, dtype)``,
+    trainer.py:387-397, evaluator.py:179-184): float16 -> IEEE-half operands with f32 accumulation
+    (to be trained under ``DynamicScale``: ``trainer.make_dynamic_scale(model)``), bfloat16 -> bf16
+    operands, float32 -> an f32-class engine.  ``engine`` names the engine explicitly where the dtype
+    leaves a choice: 'f32' (exact f32 matrix instructions) | 'bf16x3' | 'bf16x6' (split-bf16, f32
+    grade; what bench.py measures) for float32.  None with float32: the process default
+    (``ops.MATMUL_PRECISION``, 'f32' unless a tool changed it)."""
     self.config = config
     self.dataset_meta_data = dataset_meta_data
     self.dtype = dtype
+    by_dtype = ops.engine_of_dtype(dtype)
+    if engine is not None:
+      if engine not in ops.ENGINES:
+        raise ValueError(f'engine {engine!r}: expected one of {ops.ENGINES}')
+      if by_dtype is not None and engine != by_dtype:
+        raise ValueError(f'engine {engine!r} contradicts dtype {dtype} (-> {by_dtype!r})')
+      if by_dtype is None and engine in ops.HALF_MATH:
+        raise ValueError(f'engine {engine!r} needs dtype float16 / bfloat16, got {dtype}')
+    self.engine = engine if engine is not None else by_dtype
     self.flax_model = self.build_flax_model()
+    self.flax_model.engine = self.engine
 
   def loss_metrics_function(self, pred, batch, model_params=None) -> LossMetricsTuple:
     raise NotImplementedError('Subclasses must implement metrics.')

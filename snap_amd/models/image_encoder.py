@@ -114,7 +114,7 @@ class ImageEncoder(base.Module):
       return types.FeatureImagePyramid(
           features=[f[..., :h, :w, :]], strides=[np.array([patch, patch], dtype=np.float64)])
     # (inference on a split-bf16 engine: RGB + one zero float per pixel -- see pad_to_multiple)
-    rgb4 = (image.shape[-1] == 3 and ops.MATMUL_PRECISION in ops.SPLIT_PARTS
+    rgb4 = (image.shape[-1] == 3 and ops.precision() in ops.SPLIT_PARTS
             and not base.needs_grad(image) and not train)
     image_padded = pad_to_multiple(image, 2**self.max_stride, channel_pad=1 if rgb4 else 0).contiguous()
     padded_shape = np.array(image_padded.shape[-3:-1])

@@ -105,7 +105,7 @@ def _correlate(mp, tw, R, q_hw, templates=None):
   pb = max(0, S * (A4 - 1) + (H + S - 1) - mp.shape[0])  # zero rows only cropped outputs can see
   pr = max(0, S * (B4 - 1) + (W + S - 1) - mp.shape[1])
   tws_shape = (H + S - 1, W + S - 1, mp.shape[-1], R * S * S)
-  presplit = (ops.MATMUL_PRECISION == 'bf16x3' and ops.USE_PRESPLIT_VOTING and mp.shape[-1] % 16 == 0
+  presplit = (ops.precision() == 'bf16x3' and ops.USE_PRESPLIT_VOTING and mp.shape[-1] % 16 == 0
               and (R * S * S) % 192 == 0
               and ops.conv2d_presplit_supported((1,) + tuple(mp.shape), tws_shape, S, ((0, pb), (0, pr))))
   tws = None

@@ -174,14 +174,14 @@ class ResNetV2(base.Module):
       std = ag.weight_standardize_multi(kernels)
       pre.update({id(k): s for k, s in zip(kernels, std)})
       ctx.pre_std = pre
-      if ops.MATMUL_PRECISION in ops.HALF_MATH:
+      if ops.precision() in ops.HALF_MATH:
         # ... and their bf16 / fp16 images, forward and rotated (data gradient), by one launch
-        ops.pack_weights_bf16_multi(list(std), math=ops.MATMUL_PRECISION)
+        ops.pack_weights_bf16_multi(list(std), math=ops.precision())
     else:   # inference: one launch for all StdConv kernels of this encoder
       ctx.standardize_all(kernels, ops.weight_standardize_multi)
-      if ops.MATMUL_PRECISION in ops.SPLIT_PARTS:
+      if ops.precision() in ops.SPLIT_PARTS:
         # split-bf16 engine: the weight images of all standardised kernels, one launch
-        ops.pack_weights_split_multi([ctx._lookup(k) for k in kernels], ops.MATMUL_PRECISION)
+        ops.pack_weights_split_multi([ctx._lookup(k) for k in kernels], ops.precision())
     # `image * 2 - 1` (resnet.py:199) is fused into the root conv's operand staging.
     # (the image may carry padding channels: image_encoder.pad_to_multiple(channel_pad=...))
     w_root = params['conv_root' if self.config.skip_root_block else 'root_block']

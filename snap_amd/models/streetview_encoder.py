@@ -67,7 +67,7 @@ class StreetViewEncoder(base.Module):
     needs gradients, the conv engine in use is the one the kernel is written for and the MLP
     has the two-layer shape of the reference's configs."""
     layers_ = tuple(self.config.fusion.layers)
-    if len(layers_) != 2 or ops.MATMUL_PRECISION != 'bf16x3':
+    if len(layers_) != 2 or ops.precision() != 'bf16x3':
       return False
     p = params['fusion_mlp']
     if base.needs_grad(f_images, *(p[f'Dense_{i}'][k] for i in range(2) for k in ('kernel', 'bias'))):
@@ -164,15 +164,12 @@ class StreetViewEncoder(base.Module):
                   if k not in ('valid_rows_only', 'out_split', 'class_rows')}
       cam_p, rt_p = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
 
-      engine = ops.MATMUL_PRECISION            # (the engine of THIS apply, whenever the access comes)
+      engine = ops.precision()                 # (the engine of THIS apply, whenever the access comes)
 
       def volume(f_images=f_images, xyz_flat=xyz_flat, p=p):
-        prev, ops.MATMUL_PRECISION = ops.MATMUL_PRECISION, engine
-        try:
+        with ops.engine_scope(engine):
           pooled_d, valid_d = ops.lift_pool(f_images, cam_p, rt_p, xyz_flat, **kw_plain)[:2]
           f = self.fusion_mlp(p, pooled_d, False, row_mask=valid_d)
-        finally:
-          ops.MATMUL_PRECISION = prev
         return f.reshape(*grid_shape, f.shape[-1])
 
       pred['feature_volume'] = types.LazyFeatureVolume(volume, valid=valid.reshape(grid_shape))

@@ -5,7 +5,9 @@ torch (device memory plumbing only) and launches the HIP kernel on torch's
 current stream.  There is no CPU or PyTorch fallback: tensors must live on a
 ROCm device and the shared library must be built, otherwise these raise.
 """
+import contextlib
 import ctypes
+import threading
 import weakref
 import os
 
@@ -278,7 +280,7 @@ def gn_norm_split(y, gamma, beta, *, groups=32, eps=1e-5, want_stats=False):
   engine, no fused statistics, C % 16 != 0)."""
   fused = getattr(y, '_snap_gn_partial', None)
   N, H, W, C = y.shape
-  if (MATMUL_PRECISION != 'bf16x3' or fused is None or fused[2] or groups != 32
+  if (precision() != 'bf16x3' or fused is None or fused[2] or groups != 32
       or C % 16 or C > 2048 or not USE_FUSED_GN_STATS):
     return None
   lib = _lib.load()
@@ -455,7 +457,7 @@ def conv2d(
   Wo = (W + pl + pr - KW) // stride + 1
   yh = None
   if out_half:
-    hm = MATMUL_PRECISION if math is None else math
+    hm = precision() if math is None else math
     if (hm not in HALF_MATH or out is not None or emit_gn_stats is not None or up_prev is not None
         or prologue not in (PRO_NONE, PRO_RELU) or Cs % 4 or Cin < 4 or Cout % 4):
       raise ValueError('conv2d: out_half needs a training-precision engine launch (prologue NONE / RELU, '
@@ -514,7 +516,7 @@ def conv2d(
   d.tile_hint += 1000000 * _stationary_mode()
   M = N * Ho * Wo
   # the engine the launch will take (the statistics layout depends on it)
-  math = MATMUL_PRECISION if math is None else math
+  math = precision() if math is None else math
   if math not in ('f32', 'bf16', 'fp16', 'bf16x3', 'bf16x6'):
     raise ValueError(f'conv2d: math={math!r}')
   parts = SPLIT_PARTS.get(math, 0)
@@ -1096,10 +1098,54 @@ def weight_standardize_bwd_multi(ws, dwss, eps=1e-10):
 USE_FUSED_GN_STATS = True
 # the last unit of a ResNet stage emits the statistics of relu(y) too (its FPN level reads them)
 GN_STATS_BOTH = True
-# 'f32': every conv / dense runs on the exact f32 matrix-core path (inference, parity).
-# 'bf16': operands rounded to bf16, f32 accumulate -- the training-precision analogue of the
-# reference's float16 train config (train_localization.py:25); set by the trainer.
+# The arithmetic of every conv / dense ("engine"):
+#   'f32'    the exact f32 matrix-core path (inference, parity);
+#   'bf16x3' / 'bf16x6'  f32-grade: 2 / 3 bf16 parts per operand, f32 accumulate (conv_split.hip);
+#   'bf16' / 'fp16'      operands rounded to the half type, f32 accumulate -- the reference's
+#                        dtype='float16' train config (train_localization.py:93, trainer.py:387-397).
+# The engine is a property of the MODEL (``BaseModel(config, meta, dtype, engine=...)``: dtype selects
+# it exactly as the reference's ``model_cls(config.model, meta, dtype)`` does): every apply and the
+# train step enter ``engine_scope(model.engine)``, a per-thread scope that the autograd nodes carry
+# into the backward thread (autograd._engine_scoped).  MATMUL_PRECISION is only the PROCESS DEFAULT
+# for calls outside any scope (direct ``ops.conv2d`` calls of tools and kernel tests).
 MATMUL_PRECISION = 'f32'
+ENGINES = ('f32', 'bf16', 'fp16', 'bf16x3', 'bf16x6')
+_ENGINE_TLS = threading.local()
+
+
+def precision():
+  """The engine in force: the innermost ``engine_scope`` of this thread, else the process default."""
+  e = getattr(_ENGINE_TLS, 'engine', None)
+  return MATMUL_PRECISION if e is None else e
+
+
+@contextlib.contextmanager
+def engine_scope(engine):
+  """Run the enclosed ops on ``engine`` (None: no change).  Per thread, re-entrant; two models of
+  different precision interleave freely in one process."""
+  if engine is None:
+    yield
+    return
+  if engine not in ENGINES:
+    raise ValueError(f'engine {engine!r}: expected one of {ENGINES}')
+  prev = getattr(_ENGINE_TLS, 'engine', None)
+  _ENGINE_TLS.engine = engine
+  try:
+    yield
+  finally:
+    _ENGINE_TLS.engine = prev
+
+
+def engine_of_dtype(dtype):
+  """reference ``dtype`` -> engine: float32 -> the process default's f32-class engine ('f32' unless
+  the default is itself 'bf16x3' / 'bf16x6'), float16 -> 'fp16', bfloat16 -> 'bf16'."""
+  if dtype in (torch.float16, 'float16', 'fp16'):
+    return 'fp16'
+  if dtype in (torch.bfloat16, 'bfloat16', 'bf16'):
+    return 'bf16'
+  if dtype in (torch.float32, 'float32', 'f32', None):
+    return None                      # f32 class: the process default (exact f32 unless configured)
+  raise ValueError(f'dtype {dtype!r}: expected float32 | float16 | bfloat16')
 USE_SPLITK = True           # tests flip it: split-K vs single-pass launches   # tests flip it to compare against the stand-alone kernel
 
 
@@ -1431,7 +1477,7 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
       if (want_prob or want_rowstats) else None
   )
   if math is None:
-    math = 'f32' if MATMUL_PRECISION == 'f32' else 'bf16x6'
+    math = 'f32' if precision() == 'f32' else 'bf16x6'
   parts = SPLIT_PARTS.get(math, 0)
   if parts and not (want_prob or want_rowstats) and Dm in (16, 32, 64):
     wsb = lib.snap_sim_split_workspace_bytes(B, Nq, XY, Dm, parts)

@@ -34,16 +34,21 @@ def _conv_desc(x_shape, w_shape, stride, padding, prologue, in_affine, cs=None):
   ), (N, Ho, Wo, Cout)
 
 
+WGRAD_NO_WIDE, WGRAD_NO_FUSED3 = 1 << 8, 1 << 9      # SnapConvDesc.tile_hint bits (snap_hip.h)
+
+
 def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue=ops.PRO_NONE,
                  gn=None, in_affine=(1.0, 0.0), rows_z=None, rows_dy=None, row_count=None,
-                 math=None, x_channel_offset=0):
+                 math=None, x_channel_offset=0, plans=3):
   """dw [KH,KW,Cin,Cout] = im2col(prologue(x))^T dy  (MFMA; deterministic split-M).
 
+  plans (tools / tests, per call): bit 0 = the wide flat plan, bit 1 = the fused-tap 3 x 3 plan may be
+  chosen where they apply (default both); a cleared bit pins the per-tap 128 x 128 tiles.
   rows_z / rows_dy / row_count: row lists over flat [1,1,M,C] operands (masked MLP).
   math: 'f32' | 'bf16' | 'fp16' (None = ``ops.MATMUL_PRECISION``), as ``ops.conv2d``.
   x_channel_offset (multiple of 4, f32 x): the kernel's Cin input channels start at that channel of
   x's rows (x keeps its row stride): the gradient of a channel slice without copying it."""
-  math = ops.MATMUL_PRECISION if math is None else math
+  math = ops.precision() if math is None else math
   if math in ops.SPLIT_PARTS:
     math = 'f32'         # the split engine has no weight-gradient kernel: exact f32 (trainer 'bf16x3')
   if math not in ('f32', 'bf16', 'fp16'):
@@ -69,6 +74,7 @@ def conv2d_wgrad(x, dy, w_shape, *, stride=1, padding=((0, 0), (0, 0)), prologue
   else:
     _f32(x, 'x'); _f32(dy, 'dy')
   d, yshape = _conv_desc(x.shape, w_shape, stride, padding, prologue, in_affine)
+  d.tile_hint = (0 if plans & 1 else WGRAD_NO_WIDE) | (0 if plans & 2 else WGRAD_NO_FUSED3)
   if tuple(dy.shape) != yshape:
     raise ValueError(f'conv2d_wgrad: dy {tuple(dy.shape)} vs {yshape}')
   if x_channel_offset:
@@ -610,20 +616,34 @@ def adam_update_(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, appl
   in place on params / m / v (trainer.py:236-243).  ``step`` counts from 1.  apply_flag: optional
   0-d f32 DEVICE tensor -- the update is skipped unless it is > 0 (the non-finite step skip)."""
   lib = _lib.load()
-  items = np.zeros(len(params), dtype=_ADAM_ITEM)
+  quads = [q for q in zip(params, grads, m, v) if q[0].numel()]       # (empty tensors: nothing to do)
+  if not quads:
+    return
+  items = np.zeros(len(quads), dtype=_ADAM_ITEM)
   blk = 0
   keep = []
-  for i, (p, g, mi, vi) in enumerate(zip(params, grads, m, v)):
+  seen = set()
+  for i, (p, g, mi, vi) in enumerate(quads):
     _f32(p, 'param'); _f32(mi, 'm'); _f32(vi, 'v')
     g = _f32(g if g.is_contiguous() else g.contiguous(), 'grad')
     keep.append(g)
     if not (p.numel() == g.numel() == mi.numel() == vi.numel()):
       raise ValueError('adam_update_: tensor sizes differ')
+    if p.data_ptr() in seen:
+      raise ValueError('adam_update_: a parameter is listed twice (it would be updated twice)')
+    seen.add(p.data_ptr())
     items[i] = (p.data_ptr(), g.data_ptr(), mi.data_ptr(), vi.data_ptr(), p.numel(), blk)
     blk += lib.snap_adam_multi_blocks(p.numel())
-  table = ops.upload_table(items, params[0].device)
+  table = ops.upload_table(items, quads[0][0].device)
   if apply_flag is not None:
     _f32(apply_flag, 'apply_flag')
-  st = lib.snap_adam_multi_f32(_p(table), len(params), blk, float(lr), float(b1), float(b2), float(eps),
+  st = lib.snap_adam_multi_f32(_p(table), len(quads), blk, float(lr), float(b1), float(b2), float(eps),
                                int(step), _p(apply_flag), _stream())
   _lib.check(st, 'snap_adam_multi_f32')
+  # the kernel writes through raw pointers: tell torch (and every cache keyed on ``_version``:
+  # ops.host_exp's prefetched exp(temperature), base._WSTD_CACHE, the packed-weight images) that
+  # params / m / v changed in place, as the torch._foreach_* path does
+  for p, _, mi, vi in quads:
+    torch.autograd.graph.increment_version(p)
+    torch.autograd.graph.increment_version(mi)
+    torch.autograd.graph.increment_version(vi)

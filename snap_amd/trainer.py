@@ -84,6 +84,23 @@ class TrainState:
                dynamic_scale=dynamic_scale)
 
 
+DTYPES = {'float32': torch.float32, 'float16': torch.float16, 'bfloat16': torch.bfloat16}
+
+
+def dtype_and_dynamic_scale(dtype_str: str):
+  """``config.dtype_str`` -> (dtype, DynamicScale | None), the reference's selection
+  (``trainer.py:387-394``): float32 / bfloat16 train unscaled, float16 under
+  ``DynamicScale(minimum_scale=256)``; anything else is an error.  Use as
+
+      dtype, ds = trainer.dtype_and_dynamic_scale(config.dtype_str)
+      model = model_cls(config.model, meta, dtype)          # dtype selects the engine (models/base.py)
+      state = TrainState.create(params, dynamic_scale=ds)"""
+  if dtype_str not in DTYPES:
+    raise ValueError(f'Unsupported dtype: {dtype_str}')
+  dtype = DTYPES[dtype_str]
+  return dtype, (DynamicScale(minimum_scale=256) if dtype == torch.float16 else None)
+
+
 def save_train_state(path, state: TrainState) -> None:
   """Checkpoint for resume (the reference: ``train_utils.save_checkpoint`` of the Flax TrainState,
   ``trainer.py:594-602``): parameters under ``params/...`` (Flax names, so the file doubles as a
@@ -127,12 +144,18 @@ def load_train_state(path, template: TrainState) -> TrainState:
 FUSED_ADAM = True     # device tensors: one HIP launch over every parameter (optim.hip)
 
 
-def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
-  """optax.adam (bias-corrected, eps outside the sqrt); in place on `leaves`."""
-  if FUSED_ADAM and leaves and leaves[0].is_cuda:
+def _adam_update_(leaves, grads, m, v, step, lr, b1=None, b2=None, eps=None, apply_flag=None):
+  """optax.adam (bias-corrected, eps outside the sqrt); in place on `leaves`.  apply_flag (0-d f32
+  device tensor, fused path only): the update applies only where it is > 0."""
+  b1 = ADAM_B1 if b1 is None else b1
+  b2 = ADAM_B2 if b2 is None else b2
+  eps = ADAM_EPS if eps is None else eps
+  if _fusable(leaves, grads, m, v):
     from snap_amd import ops_bwd
-    ops_bwd.adam_update_(leaves, grads, m, v, step, lr, b1, b2, eps)
+    ops_bwd.adam_update_(leaves, grads, m, v, step, lr, b1, b2, eps, apply_flag=apply_flag)
     return
+  if apply_flag is not None:
+    raise ValueError('_adam_update_: apply_flag needs the fused device path')
   torch._foreach_mul_(m, b1)
   torch._foreach_add_(m, grads, alpha=1 - b1)
   torch._foreach_mul_(v, b2)
@@ -145,9 +168,24 @@ def _adam_update_(leaves, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
   torch._foreach_addcdiv_(leaves, m, denom, value=-lr / c1)
 
 
-def ops_bwd_adam(leaves, grads, m, v, step, lr, apply_flag):
-  from snap_amd import ops_bwd
-  ops_bwd.adam_update_(leaves, grads, m, v, step, lr, 0.9, 0.999, 1e-8, apply_flag=apply_flag)
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # optax.adam defaults (trainer.py:236-243): ONE set for every path
+
+
+def _fusable(leaves, grads, m, v):
+  """The fused launch takes contiguous f32 device tensors, each listed once."""
+  if not (FUSED_ADAM and leaves and leaves[0].is_cuda):
+    return False
+  seen = set()
+  for t4 in zip(leaves, grads, m, v):
+    for t in t4:
+      if t.dtype != torch.float32 or not t.is_cuda:
+        return False
+    if not (t4[0].is_contiguous() and t4[2].is_contiguous() and t4[3].is_contiguous()):
+      return False
+    if t4[0].numel() and t4[0].data_ptr() in seen:
+      return False
+    seen.add(t4[0].data_ptr())
+  return True
 
 
 def _global_norm(tensors):
@@ -156,10 +194,12 @@ def _global_norm(tensors):
 
 
 def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_norm=None,
-               group=None, debug=False, overlap_allreduce=True, precision='f32'):
+               group=None, debug=False, overlap_allreduce=True, precision=None):
   """One optimisation step.  Returns (state, metrics, training_logs).
 
-  precision: 'f32' -- every conv / dense (forward, dgrad, wgrad) on the exact f32 matrix
+  precision: None (the reference's behaviour: the arithmetic is the MODEL's -- ``model.engine``, chosen
+  by the ``dtype`` it was built with, models/base.py; the process default where the model names none)
+  or an explicit engine for this step: 'f32' -- every conv / dense (forward, dgrad, wgrad) on the exact f32 matrix
   cores; 'bf16' -- their operands are rounded to bf16 with f32 accumulation (the analogue of
   the reference's ``dtype='float16'`` train config, train_localization.py:25, trainer.py:391;
   bf16 keeps the f32 exponent range, so no DynamicScale loss scaling is needed); 'fp16' -- the
@@ -184,16 +224,15 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   state.rng += 1
   rank = torch.distributed.get_rank(group) if sdist._world(group) > 1 else 0
   sampling_rng = state.rng * 7919 + rank            # bind the stream to the device
-  if precision not in ('f32', 'bf16', 'fp16', 'bf16x3', 'bf16x6'):
+  if precision is None:
+    precision = getattr(model, 'engine', None)
+  if precision is not None and precision not in ops.ENGINES:
     raise ValueError(f'train_step: precision={precision!r}')
-  prev_precision = ops.MATMUL_PRECISION
-  ops.MATMUL_PRECISION = precision      # read by the backward thread too (module global)
   loss_scale = state.dynamic_scale.scale if state.dynamic_scale is not None else None
-  try:
+  # a per-thread scope; the autograd nodes carry it into the backward thread (autograd._engine_scoped)
+  with ops.engine_scope(precision):
     grads, loss, losses, metrics = _forward_backward(state, batch, model, leaves, sampling_rng,
                                                      group, debug, overlap_allreduce, loss_scale)
-  finally:
-    ops.MATMUL_PRECISION = prev_precision
   for t in leaves:
     t.requires_grad_(False)
     t.grad = None
@@ -208,13 +247,13 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   logs['learning_rate'] = lr
   fin_t = sdist.all_finite_tensor(grads, group).to(torch.float32).reshape(())
   gnorm_t = _global_norm(grads).reshape(())
-  device_skip = FUSED_ADAM and bool(leaves) and leaves[0].is_cuda
+  device_skip = _fusable(leaves, grads, state.m, state.v)
   if device_skip:
     # ONE host transfer per step, at its end: the update kernel itself reads the finite flag on the
     # device and applies nothing when a gradient is non-finite (the reference does the same inside
     # the traced step, trainer.py:269-276) -- the host need not know before it launches it
     with torch.no_grad():
-      ops_bwd_adam(leaves, grads, state.m, state.v, state.opt_count + 1, lr, fin_t)
+      _adam_update_(leaves, grads, state.m, state.v, state.opt_count + 1, lr, apply_flag=fin_t)
     is_fin = None
   else:
     head = torch.stack([fin_t.to(torch.float64), gnorm_t]).cpu()

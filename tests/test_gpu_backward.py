@@ -270,15 +270,12 @@ def test_wgrad_reads_the_half_twin_of_the_groupnorm_vjp(N, H, W, C, Cprev, k, pr
   kw = dict(padding=((pad, pad), (pad, pad)), prologue=pro, gn=gn, math=math_)
   # (3 x 3: the twin also unlocks the fused-tap kernel -- another summation order, tested on its own;
   #  the per-tap plan is pinned here so that both launches are the same kernel)
-  lib = ops_bwd._lib.load()
-  prev = lib.snap_conv2d_wgrad_set_wide(1)
   try:
-    via_twin = ops_bwd.conv2d_wgrad(xp, dx, (k, k, Cprev, C), **kw)
+    via_twin = ops_bwd.conv2d_wgrad(xp, dx, (k, k, Cprev, C), plans=1, **kw)
     ops_bwd.WGRAD_DY_TWIN = False
-    via_f32 = ops_bwd.conv2d_wgrad(xp, dx, (k, k, Cprev, C), **kw)
+    via_f32 = ops_bwd.conv2d_wgrad(xp, dx, (k, k, Cprev, C), plans=1, **kw)
   finally:
     ops_bwd.WGRAD_DY_TWIN = True
-    lib.snap_conv2d_wgrad_set_wide(prev)
   assert torch.equal(via_twin, via_f32), float((via_twin - via_f32).abs().max())
   assert float(via_twin.abs().max()) > 0
 
@@ -311,15 +308,9 @@ def test_conv_wgrad_3x3_fused_taps(N, H, W, Cin, Cout, pro, math_):
   wd = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
   ref_conv(torch.from_numpy(rnd_(z32)).double(), wd, 1, 1).backward(dyh.cpu().double())
   ref = wd.grad.float()
-  lib = ops_bwd._lib.load()
   kw = dict(padding=((1, 1), (1, 1)), prologue=pro, gn=gn, math=math_)
   got = ops_bwd.conv2d_wgrad(G(x), dyh, (3, 3, Cin, Cout), **kw)
-  prev = lib.snap_conv2d_wgrad_set_wide(1)
-  try:
-    per_tap = ops_bwd.conv2d_wgrad(G(x), dyh, (3, 3, Cin, Cout), **kw)
-  finally:
-    lib.snap_conv2d_wgrad_set_wide(prev)
-  assert prev == 3
+  per_tap = ops_bwd.conv2d_wgrad(G(x), dyh, (3, 3, Cin, Cout), plans=1, **kw)     # (a per-call switch)
   tol = 2e-5 * float(ref.abs().max()) + 1e-5
   helpers.report(f'wgrad 3x3 fused {math_} {N}x{H}x{W} {Cin}->{Cout}', got, ref, atol=tol)
   helpers.report(f'wgrad 3x3 per-tap {math_}', per_tap, ref, atol=tol)

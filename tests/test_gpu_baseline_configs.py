@@ -108,11 +108,19 @@ def test_c3_full_size_train_step():
   finite loss and gradients, the update moves every parameter group, a repeated step from the
   same state is BITWISE the same step -- loss, gradient norm, every first Adam moment (= 0.1 x the
   gradient, so every gradient) and every updated parameter: no sum of the training path depends
-  on execution order --, and the bf16-operand precision tracks the f32 step."""
+  on execution order --, and the bf16-operand precision tracks the f32 step.  Then the reference's
+  LITERAL train configuration (``config.dtype_str = 'float16'``, train_localization.py:93): a model
+  built with ``dtype=torch.float16`` (the dtype selects the IEEE-half engine) stepped under
+  ``DynamicScale(minimum_scale=256)`` exactly as ``trainer.py:387-397`` pairs them -- finite, within
+  the bf16 bounds of the f32 step, the scale unchanged after a finite step, bitwise repeatable."""
   from snap_amd import models, trainer
   cfg = train_localization.get_config().model
   meta = synthetic.meta_data(0.2, (25.6, 25.6, 12))
   model = models.get_model('bev_localizer')(cfg, meta)
+  dtype16, ds16 = trainer.dtype_and_dynamic_scale(train_localization.get_config().dtype_str)
+  assert dtype16 == torch.float16 and ds16 is not None and ds16.minimum_scale == 256
+  model16 = models.get_model('bev_localizer')(cfg, meta, dtype16)
+  assert model16.engine == 'fp16' and model.engine is None
   params0 = model.flax_model.init(0, device=DEV)['params']
   batch = synthetic.make_batch(4, meta['grid'], 4, (512, 512), seed=31, device=DEV)
   tcfg = train_localization.get_config()
@@ -145,6 +153,23 @@ def test_c3_full_size_train_step():
               'bev_mapper/matching_proj/kernel', 'temperature'):
     assert moved[key], key
   assert 'loss/total' in out['a'][1] and math.isfinite(out['a'][1]['loss/total'])
+  # float16 + DynamicScale, twice from the same state (no precision= keyword: the model's dtype decides)
+  h = {}
+  for tag in ('h1', 'h2'):
+    state = trainer.TrainState.create(_clone_tree(params0), rng=5, dynamic_scale=ds16)
+    state, reduced, logs = trainer.train_step(state, batch, model=model16, lr_fn=lr_fn)
+    torch.cuda.synchronize()
+    h[tag] = (logs, state)
+    assert logs['is_finite'] and math.isfinite(logs['loss']) and logs['l2_grads'] > 0
+    assert logs['loss_scale'] == ds16.scale and state.dynamic_scale.fin_steps == 1   # a finite step keeps the scale
+    assert state.opt_count == 1
+  l16 = h['h1'][0]
+  print(f"[C3 fp16] loss {l16['loss']:.6f} (f32 {la['loss']:.6f})  |g| {l16['l2_grads']:.5f} (f32 {la['l2_grads']:.5f})"
+        f"  scale {l16['loss_scale']}")
+  assert abs(l16['loss'] - la['loss']) <= 2e-2 * abs(la['loss'])
+  assert abs(l16['l2_grads'] - la['l2_grads']) <= 0.15 * la['l2_grads']
+  assert h['h1'][0]['loss'] == h['h2'][0]['loss'] and h['h1'][0]['l2_grads'] == h['h2'][0]['l2_grads']
+  assert all(torch.equal(a, b) for a, b in zip(h['h1'][1].m, h['h2'][1].m))
 
 
 # ------------------------------------------------------------------------------------------

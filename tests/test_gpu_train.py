@@ -1,5 +1,6 @@
 """`-m gpu` end-to-end checks of the training path (tiny model)."""
 import copy
+import math
 
 import numpy as np
 import pytest
@@ -406,3 +407,91 @@ def test_vit_encoder_gradients_match_torch_autograd():
     if err > 3e-2:
       bad.append((name, err))
   assert not bad, bad
+
+
+def test_models_of_different_dtype_interleave_in_one_process():
+  """``model_cls(config, meta, dtype)`` selects the arithmetic (trainer.py:387-397): an f32 model, a
+  float16 model and a float32 model on the split engine, applied and differentiated INTERLEAVED in one
+  process -- no module global touched -- produce bit for bit what each produces alone (the engine is
+  a per-thread scope that the autograd nodes carry into the backward thread)."""
+  from snap_amd import ops
+  from snap_amd.utils import geometry
+  dev = torch.device('cuda')
+  cfg = helpers.tiny_localizer_config(num_pose_samples=48, retries=2)
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  mk = models.get_model('bev_localizer')
+  m32 = mk(cfg, meta, torch.float32)
+  m16 = mk(cfg, meta, torch.float16)
+  mx3 = mk(cfg, meta, torch.float32, engine='bf16x3')
+  assert (m32.engine, m16.engine, mx3.engine) == (None, 'fp16', 'bf16x3')
+  with pytest.raises(ValueError):
+    mk(cfg, meta, torch.float16, engine='f32')
+  with pytest.raises(ValueError):
+    mk(cfg, meta, torch.float32, engine='bf16')
+  params = helpers.params_to_device(m32.flax_model.init(4, device='cpu')['params'], dev)
+  batch = helpers.batch_to_device(synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=5), dev)
+  with torch.no_grad():
+    pred = m32.flax_model.apply({'params': params}, batch, train=False, rngs={'sampling': 5})
+  s = pred['map_t_query_samples']
+  pose_samples = geometry.Transform2D(s.angle[:, 1:].contiguous(), s.t[:, 1:].contiguous())
+  leaves = [t for _, t in trainer.flatten_params(params)]
+
+  def fwd_bwd(model):
+    for t in leaves:
+      t.requires_grad_(True)
+    loss = _loss(model, params, batch, pose_samples)
+    return loss, leaves
+
+  def finish(loss):
+    g = torch.autograd.grad(loss, leaves, allow_unused=True)
+    for t in leaves:
+      t.requires_grad_(False)
+    return float(loss), torch.cat([x.reshape(-1) for x in g if x is not None])
+
+  alone = {k: finish(fwd_bwd(m)[0]) for k, m in (('f32', m32), ('fp16', m16), ('bf16x3', mx3))}
+  assert alone['f32'][0] != alone['fp16'][0] and alone['f32'][0] != alone['bf16x3'][0]   # three engines really ran
+  # interleaved: all three forwards first (graphs alive together), then the backwards in another order
+  for t in leaves:
+    t.requires_grad_(True)
+  l16 = _loss(m16, params, batch, pose_samples)
+  l32 = _loss(m32, params, batch, pose_samples)
+  lx3 = _loss(mx3, params, batch, pose_samples)
+  gx3 = torch.autograd.grad(lx3, leaves, allow_unused=True)
+  g16 = torch.autograd.grad(l16, leaves, allow_unused=True)
+  g32 = torch.autograd.grad(l32, leaves, allow_unused=True)
+  for t in leaves:
+    t.requires_grad_(False)
+  cat = lambda g: torch.cat([x.reshape(-1) for x in g if x is not None])
+  for k, l, g in (('f32', l32, g32), ('fp16', l16, g16), ('bf16x3', lx3, gx3)):
+    assert float(l) == alone[k][0], k
+    assert torch.equal(cat(g), alone[k][1]), k
+  assert ops.precision() == ops.MATMUL_PRECISION == 'f32'      # nothing leaked out of the scopes
+
+
+def test_fused_adam_bumps_tensor_versions():
+  """the fused Adam launch writes params / m / v through raw pointers; the caches keyed on
+  ``tensor._version`` (``ops.host_exp``'s prefetched exp(temperature), the standardised-kernel cache)
+  must see the change."""
+  from snap_amd import ops, ops_bwd
+  dev = torch.device('cuda')
+  t = torch.full((), 2.0, device=dev)
+  ops.prefetch_exp(t)
+  assert abs(ops.host_exp(t) - math.exp(2.0)) < 1e-5
+  p = [t, torch.ones(7, device=dev), torch.zeros(0, device=dev)]
+  g = [torch.full((), 1.0, device=dev), torch.ones(7, device=dev), torch.zeros(0, device=dev)]
+  m = [torch.zeros_like(x) for x in p]
+  v = [torch.zeros_like(x) for x in p]
+  vers = [x._version for x in p[:2]]
+  ops_bwd.adam_update_(p, g, m, v, 1, 0.5)                       # (the empty tensor is skipped)
+  torch.cuda.synchronize()
+  assert all(x._version > v0 for x, v0 in zip(p[:2], vers))
+  assert abs(float(t) - 1.5) < 1e-5                              # first Adam step: -lr * sign(g)
+  assert abs(ops.host_exp(t) - math.exp(float(t))) < 1e-5        # not the prefetched exp(2)
+  with pytest.raises(ValueError):
+    ops_bwd.adam_update_([p[1], p[1]], [g[1], g[1]], [m[1], m[1]], [v[1], v[1]], 2, 0.1)
+  # non-contiguous leaves take the foreach path of the trainer instead of raising
+  q = torch.ones(4, 6, device=dev).t()
+  assert not q.is_contiguous()
+  mq, vq = torch.zeros_like(q), torch.zeros_like(q)
+  trainer._adam_update_([q], [torch.ones_like(q)], [mq], [vq], 1, 0.5)
+  assert torch.allclose(q, torch.full_like(q, 0.5), atol=1e-5)

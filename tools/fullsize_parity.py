@@ -104,10 +104,9 @@ def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
   batch_dev = helpers.batch_to_device(batch, dev)
   preds, t_hip = {}, {}
   inject = None
-  prev = ops.MATMUL_PRECISION
   try:
     for math in maths:
-      ops.MATMUL_PRECISION = math.split('+')[0]
+      loc.engine = math.split('+')[0]
       cfg.bev_mapper.materialize_volume = not math.endswith('+plane')
       t0 = time.perf_counter()
       # every engine scores the SAME hypotheses (those the first engine's sampler drew), so that
@@ -120,7 +119,6 @@ def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
         smp = preds[math]['map_t_query_samples']
         inject = _geo.Transform2D(smp.angle[:, 1:].contiguous(), smp.t[:, 1:].contiguous())
   finally:
-    ops.MATMUL_PRECISION = prev
     cfg.bev_mapper.materialize_volume = True
   ps = o_geo.Transform2D(inject.angle.cpu().numpy(), inject.t.cpu().numpy())
   t0 = time.perf_counter()

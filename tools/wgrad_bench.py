@@ -41,19 +41,17 @@ def main():
   gbig = torch.randn(M, 256, device=dev, generator=g)
   out = {'rows': M, 'observed': n, 'math': a.math}
   cases = {
-      'dW0 x(f32,list)[256] x g1(half)[256]': lambda: ops_bwd.conv2d_wgrad(
-          x.reshape(1, 1, M, 260), g1.reshape(1, 1, M, 256), (1, 1, 256, 256), rows_z=index, row_count=count, math=a.math),
-      'dW1 h0(half)[256] x g(f32,list)[128]': lambda: ops_bwd.conv2d_wgrad(
-          h0.reshape(1, 1, M, 256), gout.reshape(1, 1, M, 128), (1, 1, 256, 128), rows_dy=index, row_count=count, math=a.math),
-      'dW f32 x f32 lists [256]x[256]': lambda: ops_bwd.conv2d_wgrad(
-          x.reshape(1, 1, M, 260), gbig.reshape(1, 1, M, 256), (1, 1, 256, 256), rows_z=index, rows_dy=index, row_count=count, math=a.math),
+      'dW0 x(f32,list)[256] x g1(half)[256]': lambda plans=3: ops_bwd.conv2d_wgrad(
+          x.reshape(1, 1, M, 260), g1.reshape(1, 1, M, 256), (1, 1, 256, 256), rows_z=index, row_count=count, math=a.math, plans=plans),
+      'dW1 h0(half)[256] x g(f32,list)[128]': lambda plans=3: ops_bwd.conv2d_wgrad(
+          h0.reshape(1, 1, M, 256), gout.reshape(1, 1, M, 128), (1, 1, 256, 128), rows_dy=index, row_count=count, math=a.math, plans=plans),
+      'dW f32 x f32 lists [256]x[256]': lambda plans=3: ops_bwd.conv2d_wgrad(
+          x.reshape(1, 1, M, 260), gbig.reshape(1, 1, M, 256), (1, 1, 256, 256), rows_z=index, rows_dy=index, row_count=count, math=a.math, plans=plans),
   }
   for name, fn in cases.items():
     r = {}
     for wide in (0, 1):
-      lib.snap_conv2d_wgrad_set_wide(wide)
-      r['wide' if wide else 'tiles128'] = round(timeit(fn), 4)
-    lib.snap_conv2d_wgrad_set_wide(1)
+      r['wide' if wide else 'tiles128'] = round(timeit(lambda: fn(2 | wide)), 4)
     out[name] = r
   print(json.dumps(out))
 
