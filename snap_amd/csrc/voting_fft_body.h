@@ -53,6 +53,7 @@ namespace vfft {
 constexpr int kMaxStages = 8;
 constexpr int kCols = 16;          // columns transformed together (= channel pairs of a group)
 constexpr int kMaxN = 1024;        // (16 + 2) * N * 8 B of LDS: 147 KB at N = 1024
+constexpr int kZPre = 8;           // 16-byte map-spectrum loads a thread keeps in flight across the transform
 
 struct Plan {                      // one axis: N = prod radix[s]; stage s works on spans of L[s]
   int N, nst;
@@ -102,6 +103,13 @@ VF_DEV float2 cmul(float2 a, float2 b) {            // a * b
 }
 VF_DEV float2 cmulc(float2 a, float2 b) {           // a * conj(b)
   float2 r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r;
+}
+// two complex products a * conj(b) packed in 16 bytes
+VF_DEV float4 cmulc2(float4 a, float4 b) {
+  float4 r;
+  r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y;
+  r.z = a.z * b.z + a.w * b.w; r.w = a.w * b.z - a.z * b.w;
+  return r;
 }
 // multiply by -i (forward) or +i (inverse)
 template <bool INV> VF_DEV float2 rot90c(float2 a) {
@@ -260,7 +268,6 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
   for (int t = tid; t < N; t += nt) twl[t] = a.tw[t];
   if (a.mode == kFastDot)
     for (int t = tid; t < N; t += nt) { sbuf[t].x = 0.f; sbuf[t].y = 0.f; }
-  const int p = tid & (kCols - 1), slot = tid >> 4, nslot = nt >> 4;
   const int k1 = bx, outer = by;
   for (int g = 0; g < a.gloop; ++g) {
     const int64_t batch = (int64_t)outer * a.gloop + g;
@@ -272,6 +279,19 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
       if (i < n4_in) v = src[i];
       b4[i] = v;
     }
+    // DOT: this row of the map spectrum is requested BEFORE the transform (its L2 / HBM round trip runs
+    // under the five LDS passes), two complex values per 16-byte load, fully coalesced
+    float4 zreg[kZPre];
+    const float4* z4 = nullptr;
+    if (a.mode == kFastDot) {
+      z4 = reinterpret_cast<const float4*>(a.z + ((int64_t)g * a.N1 + k1) * N * kCols);
+#pragma unroll
+      for (int u = 0; u < kZPre; ++u) {
+        const int i = tid + u * nt;
+        zreg[u].x = zreg[u].y = zreg[u].z = zreg[u].w = 0.f;
+        if (i < n4) zreg[u] = z4[i];
+      }
+    }
     VF_SYNC();
     fft_lds<kCols, false>(buf, twl, a.pl, tid, nt);
     if (a.mode == kFastStore16) {
@@ -280,18 +300,20 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
     } else if (a.mode == kFastStore1) {
       for (int t = tid; t < N; t += nt) a.out[(int64_t)k1 * N + t] = buf[t * kCols];
     } else if (a.mode == kFastDot) {
-      const float2* z = a.z + ((int64_t)g * a.N1 + k1) * N * kCols;
-      const int iters = (N + nslot - 1) / nslot;
-      for (int it = 0; it < iters; ++it) {            // uniform trip count: the shuffles below
-        const int k2 = it * nslot + slot;             // run in every lane
-        float2 pr; pr.x = 0.f; pr.y = 0.f;
-        if (k2 < N) pr = cmulc(z[k2 * kCols + p], buf[k2 * kCols + p]);   // Zm * conj(X)
+      // products Zm * conj(X) in place, then one thread per k2' sums its 16 pairs (rotated start: the
+      // 128-byte row stride would put every lane on the same banks)
 #pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) {
-          pr.x += VF_SHFL_XOR(pr.x, m, tid);
-          pr.y += VF_SHFL_XOR(pr.y, m, tid);
-        }
-        if (p == 0 && k2 < N) { sbuf[k2].x += pr.x; sbuf[k2].y += pr.y; }
+      for (int u = 0; u < kZPre; ++u) {
+        const int i = tid + u * nt;
+        if (i < n4) b4[i] = cmulc2(zreg[u], b4[i]);
+      }
+      for (int i = tid + kZPre * nt; i < n4; i += nt) b4[i] = cmulc2(z4[i], b4[i]);
+      VF_SYNC();
+      for (int k2 = tid; k2 < N; k2 += nt) {
+        float2 acc = sbuf[k2];
+#pragma unroll
+        for (int j = 0; j < kCols; ++j) acc = cadd(acc, buf[k2 * kCols + ((j + tid) & (kCols - 1))]);
+        sbuf[k2] = acc;
       }
     } else {
       for (int i = tid; i < N * kCols; i += nt) buf[i] = cmulc(a.z[(int64_t)k1 * N + (i >> 4)], buf[i]);
