@@ -769,6 +769,19 @@ int snap_voting_fft_f32(const float* templates, const uint8_t* tvalid, const flo
                         int32_t use_overlap, void* workspace, size_t workspace_bytes, float* scores,
                         void* stream);
 
+/* exhaustive_pose_voting (snap/models/pose_exhaustive_voting.py:107-124) in one call: the query plane
+ * feat[H,H,D] (already multiplied by its confidence), valid[H,H], tfm[R/4,4] = (cos, sin, tx, ty) of
+ * templates_t_grid for the first quadrant of rotations (:44-50), cell_size; map[Hm,Wm,D],
+ * mvalid[Hm,Wm] -> scores[R, 3Hm-1-H, 3Wm-1-H] with min_overlap (0.05 in the reference).
+ * sample_query_templates (:37-69) runs inside the first transform: template rows are interpolated on
+ * the fly with the arithmetic of snap_rotate_templates_f32 (bit for bit), rotations R/4..R-1 are rot90
+ * index maps; the [R,H,H,D] template tensor is never written.  R % 4 == 0, square query plane.
+ * workspace: snap_voting_fft_workspace_bytes(R, H, H, D, Hm, Wm). */
+int snap_voting_fft_rotated_f32(const float* feat, const uint8_t* valid, const float* tfm,
+                                float cell_size, const float* map, const uint8_t* mvalid, int32_t R,
+                                int32_t H, int32_t D, int32_t Hm, int32_t Wm, float min_overlap,
+                                void* workspace, size_t workspace_bytes, float* scores, void* stream);
+
 /* raw[Ho,Wo,Rp], cnt[Ho,Wo,Rp] (engine outputs) -> scores[R,Ho,Wo]:
  * -inf where cnt <= min_overlap*H*W (if min_overlap >= 0), then / tcount[r]. */
 int snap_template_finalize_f32(const float* raw, const float* cnt,

@@ -98,6 +98,8 @@ SIGNATURES = {
     'snap_voting_fft_f32': (
         c_int, [ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, ptr, c_size,
                 ptr, ptr]),
+    'snap_voting_fft_rotated_f32': (
+        c_int, [ptr, ptr, ptr, c_float, ptr, ptr, c_int, c_int, c_int, c_int, c_int, c_float, ptr, c_size, ptr, ptr]),
     'snap_stack_templates_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
     'snap_stack_templates_rhwd_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_int, ptr]),
     'snap_pack_stacked_templates_split_bf16': (c_int, [ptr, c_int, c_int, c_int, c_int, c_int, ptr, c_size, ptr]),
@@ -318,7 +320,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 

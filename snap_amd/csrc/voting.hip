@@ -6,6 +6,7 @@
 // Replaces snap/models/pose_exhaustive_voting.py:37-69 (sample_query_templates)
 // and the non-GEMM parts of :72-104 (template_matching).
 #include "common.h"
+#include "rotate_sample.h"
 
 namespace {
 
@@ -28,22 +29,9 @@ __global__ void rotate_templates_kernel(const float* __restrict__ feat,
   const int sj = (int)(r % W); r /= W;
   const int si = (int)(r % H);
   const int r0 = (int)(r / H);
-  const float c = tfm[r0 * 4 + 0], s = tfm[r0 * 4 + 1], tx = tfm[r0 * 4 + 2], ty = tfm[r0 * 4 + 3];
-  // cell centre in metres, transformed, back to cell units.
-  const float gx = ((float)si + 0.5f) * cell, gy = ((float)sj + 0.5f) * cell;
-  const float xm = (c * gx - s * gy) + tx;
-  const float ym = (s * gx + c * gy) + ty;
-  const float u = xm / cell, v = ym / cell;
-  bool ok = (u >= 0.f) && (u < (float)H) && (v >= 0.f) && (v < (float)W);
-  const float cu = u - 0.5f, cv = v - 0.5f;
-  const float fu = floorf(cu), fv = floorf(cv);
-  const float wu1 = cu - fu, wu0 = 1.f - wu1, wv1 = cv - fv, wv0 = 1.f - wv1;
-  const int i0 = (int)fminf(fmaxf(fu, 0.f), (float)(H - 1));
-  const int i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), (float)(H - 1));
-  const int j0 = (int)fminf(fmaxf(fv, 0.f), (float)(W - 1));
-  const int j1 = (int)fminf(fmaxf(fv + 1.f, 0.f), (float)(W - 1));
-  // NaN-mask validity: every tap must be valid, even with zero weight.
-  ok = ok && valid[i0 * W + j0] && valid[i0 * W + j1] && valid[i1 * W + j0] && valid[i1 * W + j1];
+  const SnapRotSample rs = snap_rot_sample(tfm + r0 * 4, si, sj, H, W, cell, valid);
+  const bool ok = rs.ok;
+  const int i0 = rs.i0, i1 = rs.i1, j0 = rs.j0, j1 = rs.j1;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
     const f32x4 a00 = *reinterpret_cast<const f32x4*>(feat + ((int64_t)i0 * W + j0) * D + 4 * q);
@@ -51,9 +39,7 @@ __global__ void rotate_templates_kernel(const float* __restrict__ feat,
     const f32x4 a10 = *reinterpret_cast<const f32x4*>(feat + ((int64_t)i1 * W + j0) * D + 4 * q);
     const f32x4 a11 = *reinterpret_cast<const f32x4*>(feat + ((int64_t)i1 * W + j1) * D + 4 * q);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      o[e] = (((wu0 * wv0) * a00[e] + (wu0 * wv1) * a01[e]) + (wu1 * wv0) * a10[e]) +
-             (wu1 * wv1) * a11[e];
+    for (int e = 0; e < 4; ++e) o[e] = snap_rot_mix(rs, a00[e], a01[e], a10[e], a11[e]);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

@@ -34,6 +34,8 @@
 #include <stddef.h>
 #include <math.h>
 
+#include "rotate_sample.h"
+
 #ifdef VF_EMU
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
@@ -49,6 +51,9 @@ float vf_emu_shfl_xor(float v, int mask, int tid);
 #endif
 
 namespace vfft {
+
+// The query plane a rotated call samples its templates from (null feat: explicit templates in `q`).
+struct RotSource { const float* feat; const uint8_t* valid; const float* tfm; float cell; };
 
 constexpr int kMaxStages = 8;
 constexpr int kCols = 16;          // columns transformed together (= channel pairs of a group)
@@ -175,7 +180,7 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
 // Kernel A: forward transform along the SLOW spatial axis (rows) of one column of 16-pair vectors.
 //   grid (ncols, nbatch); dst[batch][k1'][col][16]
 // ------------------------------------------------------------------------------------------------
-enum { kSlowTemplate = 0, kSlowMap = 1, kSlowCount = 2, kSlowMvalid = 3 };
+enum { kSlowTemplate = 0, kSlowMap = 1, kSlowCount = 2, kSlowMvalid = 3, kSlowRotate = 4 };
 
 struct SlowArgs {
   Plan pl;
@@ -187,6 +192,11 @@ struct SlowArgs {
   int ncols;                // logical columns = gridDim.x
   int sH, sW, D, G;         // source dims; G = 32-channel groups (batch = r * G + g / g)
   int R, R2;                // COUNT: rotations, ceil(R / 2)
+  // ROTATE: the templates are sampled on the fly from the query plane (srcf = feat [sH, sW, D], srcb =
+  // its validity): rotation r = k * R/4 + r0 is rot90^k of the bilinear sample under tfm[r0]
+  // (pose_exhaustive_voting.py:37-69) -- the [R, H, W, D] template tensor is never materialised
+  const float* tfm;         // [R / 4, 4] (cos, sin, tx, ty)
+  float cell;
   float2* dst;
 };
 
@@ -213,6 +223,28 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
           const float* s = a.srcf + (img + (int64_t)si * a.sW + sj) * a.D + c;
           if (c + 1 < a.D && !(a.D & 1)) v = *reinterpret_cast<const float2*>(s);
           else { v.x = s[0]; if (c + 1 < a.D) v.y = s[1]; }
+        }
+      } else if (a.mode == kSlowRotate) {
+        const int r = batch / a.G, g = batch - r * a.G, RQ = a.R >> 2;
+        const int k = r / RQ, r0 = r - k * RQ;
+        int si, sj;
+        snap_rot90_source(k, row, col, a.sH, a.sW, &si, &sj);
+        const SnapRotSample rs = snap_rot_sample(a.tfm + r0 * 4, si, sj, a.sH, a.sW, a.cell, a.srcb);
+        const int c = 32 * g + 2 * p;
+        if (rs.ok && c < a.D) {
+          const float* f00 = a.srcf + ((int64_t)rs.i0 * a.sW + rs.j0) * a.D + c;
+          const float* f01 = a.srcf + ((int64_t)rs.i0 * a.sW + rs.j1) * a.D + c;
+          const float* f10 = a.srcf + ((int64_t)rs.i1 * a.sW + rs.j0) * a.D + c;
+          const float* f11 = a.srcf + ((int64_t)rs.i1 * a.sW + rs.j1) * a.D + c;
+          if (c + 1 < a.D && !(a.D & 1)) {
+            const float2 a00 = *reinterpret_cast<const float2*>(f00), a01 = *reinterpret_cast<const float2*>(f01);
+            const float2 a10 = *reinterpret_cast<const float2*>(f10), a11 = *reinterpret_cast<const float2*>(f11);
+            v.x = snap_rot_mix(rs, a00.x, a01.x, a10.x, a11.x);
+            v.y = snap_rot_mix(rs, a00.y, a01.y, a10.y, a11.y);
+          } else {
+            v.x = snap_rot_mix(rs, f00[0], f01[0], f10[0], f11[0]);
+            if (c + 1 < a.D) v.y = snap_rot_mix(rs, f00[1], f01[1], f10[1], f11[1]);
+          }
         }
       } else if (a.mode == kSlowCount) {
         // count filter = 180-degree rotated template mask (pose_exhaustive_voting.py:97-99 passes
@@ -397,6 +429,27 @@ VF_DEV void inv_body(const InvArgs& a, int bx, int by, int tid, int nt, float2* 
   }
 }
 
+// Template masks of a rotated call: cell idx of the first quadrant (r0, si, sj) -> tvalid of its four
+// rot90 copies; returns the validity (the caller counts: tcount[k * RQ + r0] += ok).
+VF_DEV bool rot_mask_body(const RotSource& rs, int H, int W, int R, int64_t idx, uint8_t* tvalid, int* r0_out) {
+  const int RQ = R >> 2;
+  const int sj = (int)(idx % W);
+  const int64_t t = idx / W;
+  const int si = (int)(t % H);
+  const int r0 = (int)(t / H);
+  *r0_out = r0;
+  const bool ok = snap_rot_sample(rs.tfm + r0 * 4, si, sj, H, W, rs.cell, rs.valid).ok;
+  for (int k = 0; k < 4; ++k) {
+    int di, dj;                           // destination of (si, sj) under rot90(., k, axes=(2,1))
+    if (k == 0) { di = si; dj = sj; }
+    else if (k == 1) { di = sj; dj = H - 1 - si; }
+    else if (k == 2) { di = H - 1 - si; dj = W - 1 - sj; }
+    else { di = H - 1 - sj; dj = si; }
+    tvalid[((int64_t)(k * RQ + r0) * H + di) * W + dj] = ok ? 1 : 0;
+  }
+  return ok;
+}
+
 // tw[t] = exp(-2 pi i t / N), evaluated in double precision
 VF_DEV void twiddle_body(float2* tw, int N, int t) {
   if (t < N) {
@@ -414,7 +467,7 @@ struct Geometry {
   int Hp, Wp, Ho, Wo, N1, N2, G, R2, GC, ld, nb;
   Plan p1, p2;
   // workspace offsets in bytes
-  size_t o_tw1, o_tw2, o_xm1, o_zm, o_x1, o_y, o_zv, o_xc1, o_yc, o_flags, total;
+  size_t o_tw1, o_tw2, o_xm1, o_zm, o_x1, o_y, o_zv, o_xc1, o_yc, o_flags, o_tvalid, o_tcount, total;
 };
 
 static inline size_t vf_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -444,6 +497,8 @@ static inline bool make_geometry(int R, int H, int W, int D, int Hm, int Wm, Geo
   g->o_xc1 = o; o += vf_align(c * kCols * (size_t)g->GC * g->N1 * W);
   g->o_yc = o;  o += vf_align(c * kCols * (size_t)g->GC * g->N1 * g->ld);
   g->o_flags = o; o += vf_align((size_t)R * g->Ho * g->Wo);
+  g->o_tvalid = o; o += vf_align((size_t)R * H * W);      // (rotated entry point: the template masks)
+  g->o_tcount = o; o += vf_align(sizeof(float) * (size_t)R);
   g->total = o;
   return true;
 }
@@ -453,7 +508,7 @@ static inline bool make_geometry(int R, int H, int W, int D, int Hm, int Wm, Geo
 template <class LAUNCH>
 static inline bool run_voting(const Geometry& g, const float* q, const uint8_t* q_valid, const float* m,
                               const uint8_t* m_valid, const float* tcount, float thr, int use_overlap,
-                              char* ws, float* scores, LAUNCH& L) {
+                              char* ws, float* scores, LAUNCH& L, const RotSource* rot = nullptr) {
   float2* tw1 = reinterpret_cast<float2*>(ws + g.o_tw1);
   float2* tw2 = reinterpret_cast<float2*>(ws + g.o_tw2);
   float2* xm1 = reinterpret_cast<float2*>(ws + g.o_xm1);
@@ -497,6 +552,9 @@ static inline bool run_voting(const Geometry& g, const float* q, const uint8_t* 
   if (!L.fast(fa, g.N1, g.G)) return false;
   // templates -> X1[r * G + g][k1'][j][16] -> Y[r][k1'][b] -> scores
   sa.mode = kSlowTemplate; sa.srcf = q; sa.n_in = g.H; sa.ncols = g.W; sa.sH = g.H; sa.sW = g.W; sa.dst = x1;
+  if (rot && rot->feat) {
+    sa.mode = kSlowRotate; sa.srcf = rot->feat; sa.srcb = rot->valid; sa.tfm = rot->tfm; sa.cell = rot->cell;
+  }
   if (!L.slow(sa, g.W, g.R * g.G)) return false;
   fa.mode = kFastDot; fa.x1 = x1; fa.n_in = g.W; fa.gloop = g.G; fa.z = zm; fa.out = y; fa.ld_out = g.ld;
   fa.nb_out = g.nb;

@@ -53,8 +53,7 @@ def sample_query_templates(features, valid, num_rotations, grid, _engine=False):
   out = ops.rotate_templates(
       features.contiguous(), valid.contiguous(), tfm[: num_rotations // 4].contiguous(),
       num_rotations, grid.cell_size,
-      # (the stacked and the frequency-domain paths read `templates`)
-      want_tw=bool(_engine) and _engine != 'fft' and not _stacked(num_rotations, (H, W)),
+      want_tw=_engine and not _stacked(num_rotations, (H, W)),   # (the stacked path reads `templates`)
   )
   if _engine:
     return out
@@ -198,12 +197,20 @@ def exhaustive_pose_voting(plane_q, plane_map, num_rotations, grid, conf_q=None,
     feats_q = feats_q * conf_q[..., None]
   H, W = feats_q.shape[:2]
   fft = _use_fft(method, num_rotations, (H, W), feats_q.shape[-1], tuple(plane_map.features.shape[:2]))
-  templates, tvalid, tw, cw, tcount = sample_query_templates(
-      feats_q, plane_q.valid, num_rotations, grid, _engine='fft' if fft else True
-  )
   if fft:
-    return ops.voting_fft(templates, tvalid, plane_map.features.contiguous(), plane_map.valid.contiguous(),
-                          tcount, 0.05 * H * W, use_overlap=True)
+    # sample_query_templates runs INSIDE the first transform (rows interpolated on the fly, rot90
+    # quadrants as index maps): the [R, H, W, D] template tensor is never written
+    if num_rotations % 4 != 0:
+      raise ValueError('num_rotations must be divisible by 4')
+    if H != W:
+      raise ValueError('the rot90 completion requires a square BEV')
+    tfm = _template_transforms(num_rotations, grid, feats_q.device)[: num_rotations // 4].contiguous()
+    return ops.voting_fft_rotated(feats_q.contiguous(), plane_q.valid.contiguous(), tfm, grid.cell_size,
+                                  plane_map.features.contiguous(), plane_map.valid.contiguous(),
+                                  num_rotations, 0.05)
+  templates, tvalid, tw, cw, tcount = sample_query_templates(
+      feats_q, plane_q.valid, num_rotations, grid, _engine=True
+  )
   return _match(tw, cw, tcount, num_rotations, (H, W), plane_map.features, plane_map.valid, 0.05,
                 templates=templates)
 

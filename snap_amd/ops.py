@@ -1736,6 +1736,30 @@ def voting_fft(templates, tvalid, m, mvalid, tcount, threshold, use_overlap=True
   return scores
 
 
+def voting_fft_rotated(feat, valid, tfm, cell_size, m, mvalid, num_rotations, min_overlap=0.05):
+  """exhaustive_pose_voting in the frequency domain with the templates sampled on the fly: feat [H,H,D],
+  valid [H,H], tfm [R/4,4] (first-quadrant template transforms), m [Hm,Wm,D], mvalid [Hm,Wm] ->
+  scores [R, 3Hm-1-H, 3Wm-1-H]."""
+  lib = _lib.load()
+  _f32(feat, 'feat'); _mask(valid, 'valid'); _f32(tfm, 'tfm'); _f32(m, 'map'); _mask(mvalid, 'mvalid')
+  H, W, D = feat.shape
+  R = int(num_rotations)
+  Hm, Wm = m.shape[:2]
+  if H != W or R % 4 or tuple(tfm.shape) != (R // 4, 4) or m.shape[2] != D:
+    raise ValueError('voting_fft_rotated: square query plane, R % 4 == 0, tfm [R/4, 4], equal channel counts')
+  nbytes = lib.snap_voting_fft_workspace_bytes(R, H, H, D, Hm, Wm)
+  if nbytes == 0:
+    raise ValueError(f'voting_fft_rotated: unsupported geometry R={R} H={H} D={D} map {Hm}x{Wm}')
+  ws = torch.empty((nbytes,), dtype=torch.uint8, device=feat.device)
+  scores = torch.empty((R, 3 * Hm - 1 - H, 3 * Wm - 1 - H), dtype=torch.float32, device=feat.device)
+  with _region('voting_fft', flops=0.0, nbytes=4.0 * (R * feat.numel() + m.numel() + scores.numel())):
+    st = lib.snap_voting_fft_rotated_f32(
+        _p(feat), _p(valid), _p(tfm), float(cell_size), _p(m), _p(mvalid), R, H, D, Hm, Wm, float(min_overlap),
+        _p(ws), nbytes, _p(scores), _stream())
+  _lib.check(st, 'snap_voting_fft_rotated_f32')
+  return scores
+
+
 def template_finalize(raw, cnt, tcount, R, threshold, use_overlap=True):
   """raw, cnt [Ho,Wo,Rp] -> scores [R,Ho,Wo]."""
   lib = _lib.load()

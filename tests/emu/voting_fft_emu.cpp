@@ -97,3 +97,24 @@ extern "C" int emu_voting_fft_f32(const float* templates, const uint8_t* tvalid,
   return vfft::run_voting(g, templates, tvalid, map, mvalid, tcount, thr, use_overlap, static_cast<char*>(ws),
                           scores, L) ? 0 : -4;
 }
+
+extern "C" int emu_voting_fft_rotated_f32(const float* feat, const uint8_t* valid, const float* tfm, float cell,
+                                          const float* map, const uint8_t* mvalid, int R, int H, int D, int Hm,
+                                          int Wm, float min_overlap, void* ws_, float* scores, int nt) {
+  vfft::Geometry g;
+  if (!vfft::make_geometry(R, H, H, D, Hm, Wm, &g)) return -2;
+  char* ws = static_cast<char*>(ws_);
+  uint8_t* tvalid = reinterpret_cast<uint8_t*>(ws + g.o_tvalid);
+  float* tcount = reinterpret_cast<float*>(ws + g.o_tcount);
+  for (int r = 0; r < R; ++r) tcount[r] = 0.f;
+  vfft::RotSource rs{feat, valid, tfm, cell};
+  const int RQ = R / 4;
+  for (int64_t idx = 0; idx < (int64_t)RQ * H * H; ++idx) {
+    int r0;
+    if (vfft::rot_mask_body(rs, H, H, R, idx, tvalid, &r0))
+      for (int k = 0; k < 4; ++k) tcount[k * RQ + r0] += 1.f;
+  }
+  EmuLaunch L{nt};
+  return vfft::run_voting(g, nullptr, tvalid, map, mvalid, tcount, min_overlap * (float)H * (float)H, 1, ws, scores,
+                          L, &rs) ? 0 : -4;
+}

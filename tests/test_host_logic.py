@@ -564,7 +564,8 @@ def test_voting_fft_kernel_bodies_on_the_cpu_emulation():
   so = os.path.join(build, 'libvoting_fft_emu.so')
   src = os.path.join(ROOT, 'tests', 'emu', 'voting_fft_emu.cpp')
   hdr = os.path.join(ROOT, 'snap_amd', 'csrc', 'voting_fft_body.h')
-  if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+  hdr2 = os.path.join(ROOT, 'snap_amd', 'csrc', 'rotate_sample.h')
+  if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
     subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread',
                     '-I' + os.path.join(ROOT, 'snap_amd', 'csrc'), src, '-o', so], check=True)
   lib = ctypes.CDLL(so)
@@ -587,6 +588,46 @@ def test_voting_fft_kernel_bodies_on_the_cpu_emulation():
                                 int(overlap is not None), ws.ctypes.data + off, out.ctypes.data, nt)
     assert rc == 0
     want = o_voting.template_matching(t, tv, m, mv, min_overlap=overlap)
+    fin = np.isfinite(want)
+    assert (fin == np.isfinite(out)).all()
+    np.testing.assert_allclose(out[fin], want[fin], atol=5e-6)
+
+
+def test_voting_fft_rotated_entry_on_the_cpu_emulation():
+  """exhaustive_pose_voting's frequency-domain entry (templates sampled inside the first transform,
+  rot90 quadrants as index maps, masks + counts from the validity-only pass) on the CPU emulation vs
+  oracle/voting.py: sample_query_templates + template_matching."""
+  import ctypes
+  build = os.path.join(ROOT, 'tests', '_build')
+  so = os.path.join(build, 'libvoting_fft_emu.so')
+  if not os.path.exists(so):
+    test_voting_fft_kernel_bodies_on_the_cpu_emulation()
+  lib = ctypes.CDLL(so)
+  lib.emu_voting_fft_workspace_bytes.restype = ctypes.c_size_t
+  lib.emu_voting_fft_workspace_bytes.argtypes = [ctypes.c_int] * 6
+  lib.emu_voting_fft_rotated_f32.restype = ctypes.c_int
+  lib.emu_voting_fft_rotated_f32.argtypes = ([ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
+                                             [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                                                   ctypes.c_int])
+  rng = np.random.default_rng(5)
+  for (H, R, D) in [(8, 8, 6), (10, 12, 4)]:
+    cell = 0.25
+    vq = rng.random((H, H)) > 0.15
+    fq = rng.standard_normal((H, H, D)).astype(np.float32) * vq[..., None]
+    fm = rng.standard_normal((H, H, D)).astype(np.float32)
+    vm = rng.random((H, H)) > 0.1
+    t_w, tv_w = o_voting.sample_query_templates(fq, vq, R, o_grids.Grid2D((H, H), cell))
+    want = o_voting.template_matching(t_w, tv_w, fm, vm)
+    tfm = pev._template_transforms(R, grids.Grid2D((H, H), cell), 'cpu')[: R // 4].contiguous().numpy()
+    nb = lib.emu_voting_fft_workspace_bytes(R, H, H, D, H, H)
+    ws = np.zeros(nb + 256, np.uint8)
+    off = (-ws.ctypes.data) % 256
+    out = np.full((R, 2 * H - 1, 2 * H - 1), np.nan, np.float32)
+    vqb, vmb = vq.astype(np.uint8), vm.astype(np.uint8)
+    rc = lib.emu_voting_fft_rotated_f32(fq.ctypes.data, vqb.ctypes.data, tfm.ctypes.data, cell, fm.ctypes.data,
+                                        vmb.ctypes.data, R, H, D, H, H, 0.05, ws.ctypes.data + off,
+                                        out.ctypes.data, 32)
+    assert rc == 0
     fin = np.isfinite(want)
     assert (fin == np.isfinite(out)).all()
     np.testing.assert_allclose(out[fin], want[fin], atol=5e-6)
