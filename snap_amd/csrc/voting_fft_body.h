@@ -44,10 +44,16 @@ void vf_emu_barrier();
 float vf_emu_shfl_xor(float v, int mask, int tid);
 #define VF_SYNC() vf_emu_barrier()
 #define VF_SHFL_XOR(v, m, tid) vf_emu_shfl_xor(v, m, tid)
+#define VF_KEEP(v) ((void)(v))
 #else
 #define VF_DEV __device__ __forceinline__
-#define VF_SYNC() __syncthreads()
+// LDS-only workgroup barrier: every hand-off between threads of these kernels goes through LDS, so the
+// barrier waits for this wave's LDS traffic (lgkmcnt) and NOT for its outstanding global loads / stores
+// (__syncthreads() drains vmcnt too: a load issued before a transform to be consumed after it would be
+// waited for at the transform's first barrier)
+#define VF_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define VF_SHFL_XOR(v, m, tid) __shfl_xor(v, m, 16)
+#define VF_KEEP(v) asm volatile("" ::"v"(v))      // a use the optimiser cannot drop or move
 #endif
 
 namespace vfft {
@@ -58,7 +64,7 @@ struct RotSource { const float* feat; const uint8_t* valid; const float* tfm; fl
 constexpr int kMaxStages = 8;
 constexpr int kCols = 16;          // columns transformed together (= channel pairs of a group)
 constexpr int kMaxN = 1024;        // (16 + 2) * N * 8 B of LDS: 147 KB at N = 1024
-constexpr int kZPre = 8;           // 16-byte map-spectrum loads a thread keeps in flight across the transform
+constexpr int kZPre = 6;           // 16-byte map-spectrum loads a thread keeps in flight across the transform
 
 struct Plan {                      // one axis: N = prod radix[s]; stage s works on spans of L[s]
   int N, nst;
@@ -123,14 +129,85 @@ template <bool INV> VF_DEV float2 rot90c(float2 a) {
   return r;
 }
 
+// One radix-4 stage butterfly on four registers.  Forward (DIF): butterfly, then the stage twiddles
+// w_m = exp(-2 pi i k m / L) on outputs 1..3; inverse (DIT, the conjugate transpose): conjugate
+// twiddles on inputs 1..3, then the conjugate butterfly.  tw = false (k == 0): the twiddles are 1.
+template <bool INV>
+VF_DEV void bfly4(float2& x0, float2& x1, float2& x2, float2& x3, bool tw, float2 w1, float2 w2, float2 w3) {
+  if (INV && tw) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); x3 = cmulc(x3, w3); }
+  const float2 t0 = cadd(x0, x2), u1 = csub(x0, x2), u2 = cadd(x1, x3);
+  const float2 u3 = rot90c<INV>(csub(x1, x3));
+  x0 = cadd(t0, u2); x1 = cadd(u1, u3); x2 = csub(t0, u2); x3 = csub(u1, u3);
+  if (!INV && tw) { x1 = cmul(x1, w1); x2 = cmul(x2, w2); x3 = cmul(x3, w3); }
+}
+
 // In-place transform of C interleaved columns, buf[n * C + p].  tw[t] = exp(-2 pi i t / N).
 // Forward: DIF, stages 0..nst-1; inverse: DIT, stages nst-1..0, each the conjugate transpose of the
 // forward stage (conjugate twiddles BEFORE the conjugate butterfly) => N * ifft, natural order out.
+// Two consecutive radix-4 stages run as ONE pass over LDS: the 16 elements {b0 + k + q' M/4 + m M}
+// that the four butterflies of the outer stage and the four of the inner stage share stay in a
+// thread's registers (the same butterflies with the same operands: bit-identical to two passes, with
+// one barrier, one round of index arithmetic and 15 instead of 24 twiddle loads per 16 elements).
+// N = 768: three passes (3 | 4,4 | 4,4) instead of five.
 // The data must be visible (barrier) on entry; it is on exit.
 template <int C, bool INV>
 VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int nt) {
-  for (int ss = 0; ss < pl.nst; ++ss) {
-    const int s = INV ? pl.nst - 1 - ss : ss;
+  int ss = 0;
+  while (ss < pl.nst) {
+    const int s = INV ? pl.nst - 1 - ss : ss;                 // the stage this pass starts with
+    const int s2 = INV ? s - 1 : s + 1;                       // ... and its partner, if both are radix 4
+    const bool pair = pl.radix[s] == 4 && s2 >= 0 && s2 < pl.nst && pl.radix[s2] == 4;
+    if (pair) {
+      const int so = INV ? s2 : s, si = INV ? s : s2;         // outer (larger span) / inner stage
+      const int logM = pl.logM[so], logMi = pl.logM[si];      // M = L / 4, M' = M / 4
+      const int M = 1 << logM, Mi = 1 << logMi;
+      const int tso = pl.tstep[so], tsi = pl.tstep[si];
+      const int total = (pl.N >> 4) * C;
+      for (int item = tid; item < total; item += nt) {
+        const int p = item % C, ti = item / C;
+        const int kk = ti & (Mi - 1), blk = ti >> logMi;
+        float2* b = buf + (((blk << (logM + 2)) + kk) * C + p);
+        float2 v[4][4];                                        // [q' : inner position][m : outer position]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) v[q][m] = b[(q * Mi + m * M) * C];
+        float2 w1, w2, w3;
+        w1.x = w2.x = w3.x = 1.f; w1.y = w2.y = w3.y = 0.f;
+        if (!INV) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                        // outer stage: k = kk + q M'
+            const int t1 = (kk + q * Mi) * tso;
+            const bool has = (kk + q * Mi) != 0;
+            if (has) { w1 = tw[t1]; w2 = tw[2 * t1]; w3 = tw[3 * t1]; }
+            bfly4<false>(v[q][0], v[q][1], v[q][2], v[q][3], has, w1, w2, w3);
+          }
+          const int t1 = kk * tsi;
+          if (kk) { w1 = tw[t1]; w2 = tw[2 * t1]; w3 = tw[3 * t1]; }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) bfly4<false>(v[0][m], v[1][m], v[2][m], v[3][m], kk != 0, w1, w2, w3);
+        } else {
+          const int t1 = kk * tsi;
+          if (kk) { w1 = tw[t1]; w2 = tw[2 * t1]; w3 = tw[3 * t1]; }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) bfly4<true>(v[0][m], v[1][m], v[2][m], v[3][m], kk != 0, w1, w2, w3);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t1o = (kk + q * Mi) * tso;
+            const bool has = (kk + q * Mi) != 0;
+            if (has) { w1 = tw[t1o]; w2 = tw[2 * t1o]; w3 = tw[3 * t1o]; }
+            bfly4<true>(v[q][0], v[q][1], v[q][2], v[q][3], has, w1, w2, w3);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) b[(q * Mi + m * M) * C] = v[q][m];
+      }
+      VF_SYNC();
+      ss += 2;
+      continue;
+    }
     const int R = pl.radix[s], logM = pl.logM[s], M = 1 << logM, L = pl.L[s], ts = pl.tstep[s];
     const int total = (pl.N / R) * C;
     const int st = M * C;
@@ -142,16 +219,14 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
       if (R == 4) {
         float2 x0 = b[0], x1 = b[st], x2 = b[2 * st], x3 = b[3 * st];
         float2 w1, w2, w3;
+        w1.x = w2.x = w3.x = 1.f; w1.y = w2.y = w3.y = 0.f;
         if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; w3 = tw[3 * t1]; }
-        if (INV && k) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); x3 = cmulc(x3, w3); }
-        const float2 t0 = cadd(x0, x2), u1 = csub(x0, x2), u2 = cadd(x1, x3);
-        const float2 u3 = rot90c<INV>(csub(x1, x3));
-        float2 y0 = cadd(t0, u2), y1 = cadd(u1, u3), y2 = csub(t0, u2), y3 = csub(u1, u3);
-        if (!INV && k) { y1 = cmul(y1, w1); y2 = cmul(y2, w2); y3 = cmul(y3, w3); }
-        b[0] = y0; b[st] = y1; b[2 * st] = y2; b[3 * st] = y3;
+        bfly4<INV>(x0, x1, x2, x3, k != 0, w1, w2, w3);
+        b[0] = x0; b[st] = x1; b[2 * st] = x2; b[3 * st] = x3;
       } else if (R == 3) {
         float2 x0 = b[0], x1 = b[st], x2 = b[2 * st];
         float2 w1, w2;
+        w1.x = w2.x = 1.f; w1.y = w2.y = 0.f;
         if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; }
         if (INV && k) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); }
         const float2 sm = cadd(x1, x2), df = csub(x1, x2);
@@ -164,7 +239,7 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
         b[0] = y0; b[st] = y1; b[2 * st] = y2;
       } else {
         float2 x0 = b[0], x1 = b[st];
-        float2 w1;
+        float2 w1; w1.x = 1.f; w1.y = 0.f;
         if (k) w1 = tw[t1];
         if (INV && k) x1 = cmulc(x1, w1);
         float2 y0 = cadd(x0, x1), y1 = csub(x0, x1);
@@ -173,6 +248,7 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
       }
     }
     VF_SYNC();
+    ss += 1;
   }
 }
 
@@ -311,18 +387,18 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
       if (i < n4_in) v = src[i];
       b4[i] = v;
     }
-    // DOT: this row of the map spectrum is requested BEFORE the transform (its L2 / HBM round trip runs
-    // under the five LDS passes), two complex values per 16-byte load, fully coalesced
-    float4 zreg[kZPre];
+    // DOT: this row of the map spectrum (98 KB, shared by every rotation: L2 / Infinity-Cache resident
+    // after the first) is TOUCHED before the transform -- one dword per 128-byte line, a register each
+    // -- so that its trip from the Infinity Cache / HBM into this XCD's L2 runs under the LDS passes;
+    // the 16-byte loads that follow the transform then hit L2.  (Holding the row itself in registers
+    // across the transform spilled: the fused radix-16 passes need the registers.)
     const float4* z4 = nullptr;
+    float touch = 0.f;
     if (a.mode == kFastDot) {
       z4 = reinterpret_cast<const float4*>(a.z + ((int64_t)g * a.N1 + k1) * N * kCols);
-#pragma unroll
-      for (int u = 0; u < kZPre; ++u) {
-        const int i = tid + u * nt;
-        zreg[u].x = zreg[u].y = zreg[u].z = zreg[u].w = 0.f;
-        if (i < n4) zreg[u] = z4[i];
-      }
+      const float* zt = reinterpret_cast<const float*>(z4);
+      if (tid < N) touch = zt[tid * 32];               // ONE un-waited load per thread (nt >= N on the GPU) ...
+      for (int line = tid + nt; line < N; line += nt) touch += zt[line * 32];   // ... (smaller workgroups: the rest)
     }
     VF_SYNC();
     fft_lds<kCols, false>(buf, twl, a.pl, tid, nt);
@@ -332,14 +408,24 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
     } else if (a.mode == kFastStore1) {
       for (int t = tid; t < N; t += nt) a.out[(int64_t)k1 * N + t] = buf[t * kCols];
     } else if (a.mode == kFastDot) {
-      // products Zm * conj(X) in place, then one thread per k2' sums its 16 pairs (rotated start: the
-      // 128-byte row stride would put every lane on the same banks)
+      // products Zm * conj(X) in place (kZPre coalesced 16-byte loads in flight per thread), then one
+      // thread per k2' sums its 16 pairs (rotated start: the 128-byte row stride would put every lane
+      // on the same banks)
+      for (int i0 = tid; i0 < n4; i0 += kZPre * nt) {
+        float4 zreg[kZPre];
 #pragma unroll
-      for (int u = 0; u < kZPre; ++u) {
-        const int i = tid + u * nt;
-        if (i < n4) b4[i] = cmulc2(zreg[u], b4[i]);
+        for (int u = 0; u < kZPre; ++u) {
+          const int i = i0 + u * nt;
+          zreg[u].x = zreg[u].y = zreg[u].z = zreg[u].w = 0.f;
+          if (i < n4) zreg[u] = z4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kZPre; ++u) {
+          const int i = i0 + u * nt;
+          if (i < n4) b4[i] = cmulc2(zreg[u], b4[i]);
+        }
       }
-      for (int i = tid + kZPre * nt; i < n4; i += nt) b4[i] = cmulc2(z4[i], b4[i]);
+      VF_KEEP(touch);                                  // the touch loads' only use: after the transform
       VF_SYNC();
       for (int k2 = tid; k2 < N; k2 += nt) {
         float2 acc = sbuf[k2];
