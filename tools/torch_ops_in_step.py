@@ -35,7 +35,7 @@ def main():
     def step(i):
       trainer.train_step(state, batch, model=model, lr_fn=lambda s: 1e-4, precision=args.precision)
   else:
-    ops.MATMUL_PRECISION = 'bf16x3'
+    loc.engine = 'bf16x3'
 
     def step(i):
       loc.apply(variables, batch, train=False, rngs={'sampling': i})
