@@ -497,8 +497,14 @@ inline int launch_splitk_reduce(const ConvArgs& a, hipStream_t s) {
 // C3 train step): off 59.75 / 162.5 ms; tiles<=128 59.96 / 159.9; tiles<=384, target 768
 // 59.34 / 157.8; tiles<=256, target 1024 59.55 / 158.4.  (A caller that wants no split-K
 // passes no workspace.)
-constexpr int64_t splitk_max_tiles() { return 384; }
-constexpr int splitk_target() { return 768; }
+#ifndef SNAP_SPLITK_MAX_TILES
+#define SNAP_SPLITK_MAX_TILES 384
+#endif
+#ifndef SNAP_SPLITK_TARGET
+#define SNAP_SPLITK_TARGET 768
+#endif
+constexpr int64_t splitk_max_tiles() { return SNAP_SPLITK_MAX_TILES; }
+constexpr int splitk_target() { return SNAP_SPLITK_TARGET; }
 
 // Tile choice: the largest tile that still yields >= 2 workgroups per CU; small-M
 // layers (deep stages, few images) fall back to 64x64 tiles to fill the 256 CUs.
