@@ -135,106 +135,6 @@ class BEVLocalizer(base.Module):
         strides=pyr.strides,
     )
 
-  # -- inference: the mapper software-pipelined over chunks of scenes ------------------------------------
-  def _pipeline_chunks(self, data, train, debug):
-    """Scene ranges of the pipelined mapper, or None (one batch).  Inference on a GPU with the shared
-    StreetView encoder only: nothing of a scene's mapper output depends on another scene (GroupNorm
-    statistics are per image), so the chunks compute what the batch computes."""
-    n = ops.SCENE_PIPELINE_CHUNK
-    im = data['map'].get('images')
-    if (not n or train or debug or self.bev_mapper_query is not None or im is None or not im.is_cuda
-        or self.bev_mapper.streetview_encoder is None
-        or 'image_feature_pyr' in data['map'] or 'image_feature_pyr' in data['query']
-        or data['map']['images'].shape[2:] != data['query']['images'].shape[2:]):
-      return None
-    B = len(im)
-    if B < 2 * n:
-      return None
-
-    def leaves(t):
-      if isinstance(t, dict):
-        for v in t.values():
-          yield from leaves(v)
-      elif isinstance(t, torch.Tensor):
-        yield t
-    if base.needs_grad(im, data['query']['images'], *leaves(data['_params'])):
-      return None
-    return [(b, min(B, b + n)) for b in range(0, B, n)]
-
-  @staticmethod
-  def _slice_tree(t, b0, b1):
-    if isinstance(t, dict):
-      return {k: BEVLocalizer._slice_tree(v, b0, b1) for k, v in t.items()}
-    if isinstance(t, (torch.Tensor, geometry._Struct)):
-      return t[b0:b1]
-    return t
-
-  def _map_pipelined(self, params, data_map, data_query, chunks, ctx, rng):
-    """pred['map'], pred['query'] over scene chunks on two worker streams.  Chunk c's image encoder
-    starts when chunk c - 1's has finished (the encoders run back to back, as in one batch); everything
-    behind it -- lift, fusion MLP + vertical pooling, modality fusion, matching head: kernels bound by
-    gathers, VALU work and LDS traffic -- runs NEXT TO the encoder of chunk c + 1, whose convolutions
-    leave most of the vector pipe and the L2 -> LDS path idle.  The aerial encoder (whole batch) stays
-    on its own stream.  Same kernels on the same per-scene operands as the batched call."""
-    dev = data_map['images'].device
-    main = torch.cuda.current_stream(dev)
-    workers = [ops.side_stream(dev, 1), ops.side_stream(dev, 2)]
-    aerial = data_map.pop('_aerial_async', None)
-    mapper_q = self.bev_mapper
-    preds_m, preds_q = [], []
-    enc_done = tail_done = None
-    for c, (b0, b1) in enumerate(chunks):
-      w = workers[c % 2]
-      if c < 2:
-        w.wait_stream(main)                       # the batch was produced on the main stream
-      if enc_done is not None:
-        w.wait_event(enc_done)
-      with torch.cuda.stream(w):
-        dm = self._slice_tree(data_map, b0, b1)
-        dq = self._slice_tree(data_query, b0, b1)
-        self._encode_views_jointly(params, dm, dq, False, ctx)
-        enc_done = w.record_event()
-        # the tails run in chunk order too: what a tail prepares once per apply (packed weight images,
-        # device constants) is complete before the next chunk's tail reads it from the other stream
-        if tail_done is not None:
-          w.wait_event(tail_done)
-        if aerial is not None:                    # this chunk's planes of the whole-batch aerial pass
-          ap, adone = aerial
-          plane = ap['feature_plane']
-          dm['_aerial_async'] = ({'feature_plane': types.FeaturePlane(plane.features[b0:b1],
-                                                                      plane.valid[b0:b1])}, adone)
-        preds_m.append(self.bev_mapper(params['bev_mapper'], dm, False, False, ctx=ctx, rng=rng))
-        preds_q.append(mapper_q(params['bev_mapper'], dq, False, False, is_query=True, ctx=ctx, rng=rng))
-        tail_done = w.record_event()
-    for w in workers:
-      main.wait_stream(w)
-    pm, pq = types.cat_trees(preds_m), types.cat_trees(preds_q)
-    if aerial is not None:                        # the aerial entry: the whole-batch tensors themselves
-      pm['aerial'] = aerial[0]
-
-    def record(t):                                # worker-stream allocations now live on the main stream
-      if isinstance(t, torch.Tensor):
-        t.record_stream(main)
-      elif isinstance(t, dict):
-        for v in t.values():
-          record(v)
-      elif isinstance(t, (list, tuple)):
-        for v in t:
-          record(v)
-      elif isinstance(t, types.LazyFeatureVolume):
-        record(t.valid)
-        record(t._features)
-        fn = t._thunk                            # (what a later materialisation on this stream will read)
-        if fn is not None:
-          record(list(fn.__defaults__ or ()))
-          record([c.cell_contents for c in (fn.__closure__ or ()) if isinstance(c.cell_contents,
-                                                                                (torch.Tensor, dict, list, tuple))])
-      elif hasattr(t, '__dict__'):
-        for v in vars(t).values():
-          record(v)
-    record(pm); record(pq)
-    return pm, pq
-
   def _prefetch_scale(self, params):
     """Queue the D2H read of exp(temperature) at the START of an apply, inference and training alike
     (``ops.prefetch_exp``: same value, same bits as a blocking ``float(torch.exp(t))``)."""
@@ -296,26 +196,18 @@ class BEVLocalizer(base.Module):
     data_map, data_query = dict(data['map']), {**data['query'], 'xy_bev': q_xy_p}
     self._prefetch_scale(params)
     self.bev_mapper.start_aerial(params['bev_mapper'], data_map, train, ctx)   # (second stream)
-    chunks = self._pipeline_chunks({**data, '_params': params}, train, debug)
-    if chunks is not None and ('rasters' not in data_map or '_aerial_async' in data_map):
-      try:
-        pred['map'], pred['query'] = self._map_pipelined(params, data_map, data_query, chunks, ctx, rng)
-      finally:                     # an exception mid-pipeline: no worker-stream work is left behind
-        for wi in (0, 1, 2):
-          torch.cuda.current_stream().wait_stream(ops.side_stream(dev, wi))
-    else:
-      try:
-        self._encode_views_jointly(params, data_map, data_query, train, ctx)
-        pred['map'] = self.bev_mapper(params['bev_mapper'], data_map, train, debug, ctx=ctx, rng=rng)
-      finally:
-        pending = data_map.pop('_aerial_async', None)
-        if pending is not None:      # an exception before the join: no side-stream work is left behind
-          torch.cuda.current_stream().wait_event(pending[1])
-      mapper_q = self.bev_mapper_query or self.bev_mapper
-      params_q = params['bev_mapper_query'] if self.bev_mapper_query is not None else params['bev_mapper']
-      pred['query'] = mapper_q(
-          params_q, data_query, train, debug, is_query=True, ctx=ctx, rng=rng,
-      )
+    try:
+      self._encode_views_jointly(params, data_map, data_query, train, ctx)
+      pred['map'] = self.bev_mapper(params['bev_mapper'], data_map, train, debug, ctx=ctx, rng=rng)
+    finally:
+      pending = data_map.pop('_aerial_async', None)
+      if pending is not None:      # an exception before the join: no side-stream work is left behind
+        torch.cuda.current_stream().wait_event(pending[1])
+    mapper_q = self.bev_mapper_query or self.bev_mapper
+    params_q = params['bev_mapper_query'] if self.bev_mapper_query is not None else params['bev_mapper']
+    pred['query'] = mapper_q(
+        params_q, data_query, train, debug, is_query=True, ctx=ctx, rng=rng,
+    )
 
     plane_map = pred['map']['bev_matching']
     plane_q = pred['query']['bev_matching']

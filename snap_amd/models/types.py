@@ -83,37 +83,3 @@ class FeatureImagePyramid:
 
   def replace(self, **kw):
     return dataclasses.replace(self, **kw)
-
-
-def cat_trees(trees, dim=0):
-  """Concatenate output pytrees of scene CHUNKS along the batch axis: tensors, the containers above,
-  ``_Struct`` geometry objects, lists / tuples (element-wise), dicts (key-wise); ``None`` and other
-  leaves must agree and are taken from the first tree.  A ``LazyFeatureVolume`` stays lazy: the
-  merged volume is produced (chunk by chunk) on first access."""
-  import torch
-  first = trees[0]
-  if isinstance(first, torch.Tensor):
-    return torch.cat(list(trees), dim)
-  if isinstance(first, LazyFeatureVolume):
-    parts = list(trees)
-    valid = None if first.valid is None else torch.cat([p.valid for p in parts], dim)
-    if all(p.materialized for p in parts):
-      return LazyFeatureVolume(None, valid, features=torch.cat([p.features for p in parts], dim))
-
-    def thunk():
-      feats = [p.features for p in parts]
-      return None if any(f is None for f in feats) else torch.cat(feats, dim)
-    return LazyFeatureVolume(thunk, valid)
-  if isinstance(first, (FeatureVolume, FeaturePlane)):
-    return type(first)(features=cat_trees([t.features for t in trees], dim),
-                       valid=cat_trees([t.valid for t in trees], dim))
-  if isinstance(first, FeatureImagePyramid):
-    return FeatureImagePyramid(features=[cat_trees([t.features[i] for t in trees], dim)
-                                         for i in range(len(first.features))], strides=first.strides)
-  if isinstance(first, dict):
-    return {k: cat_trees([t[k] for t in trees], dim) for k in first}
-  if isinstance(first, (list, tuple)):
-    return type(first)(cat_trees([t[i] for t in trees], dim) for i in range(len(first)))
-  if hasattr(type(first), 'cat') and hasattr(first, '_fields'):        # geometry._Struct
-    return type(first).cat(list(trees), dim)
-  return first

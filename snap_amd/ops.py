@@ -36,22 +36,17 @@ POOLED_SPLIT = True
 CLASS_ROWS = True
 # image padding and the voxel-centre grid as one native pass each instead of torch fill + strided copies; 0: torch
 NATIVE_GLUE = True
-# Inference: the mapper runs over chunks of SCENE_PIPELINE_CHUNK scenes, software-pipelined on two worker
-# streams -- the lift / fusion-MLP / pooling of chunk c next to the image encoder of chunk c + 1
-# (bev_localizer._map_pipelined).  0: one batch, one stream.
-SCENE_PIPELINE_CHUNK = int(os.environ.get('SNAP_SCENE_PIPELINE_CHUNK', '2'))
 _SIDE_STREAMS = {}
 
 
-def side_stream(device=None, which=0):
-  """Side stream ``which`` of ``device`` (created once per GPU of the process; default: the current
-  device).  0: the aerial encoder's; 1, 2: the scene pipeline's workers (bev_localizer)."""
+def side_stream(device=None):
+  """The second stream of ``device`` (one per GPU of the process; default: the current device)."""
   idx = torch.cuda.current_device() if device is None else torch.device(device).index
   if idx is None:
     idx = torch.cuda.current_device()
-  s = _SIDE_STREAMS.get((idx, which))
+  s = _SIDE_STREAMS.get(idx)
   if s is None:
-    s = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(device=idx)
+    s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
   return s
 
 
