@@ -166,7 +166,7 @@ def source_digest():
   return h.hexdigest()[:16]
 
 
-TRAFFIC_FILES = ('r04_c2_hbm_traffic.json', 'r03_c2_hbm_traffic.json', 'r02_c2_hbm_traffic.json',
+TRAFFIC_FILES = ('r05_c2_hbm_traffic.json', 'r04_c2_hbm_traffic.json', 'r03_c2_hbm_traffic.json', 'r02_c2_hbm_traffic.json',
                  'r01_c2_hbm_traffic.json')   # newest round first
 
 
