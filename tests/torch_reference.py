@@ -20,6 +20,10 @@ F64 = torch.float64
 
 
 def t64(a):
+  """float64 tensor; a torch tensor passes through ``.to`` (differentiable: the whole-model gradient
+  test hands in float64 leaves that require grad)."""
+  if isinstance(a, torch.Tensor):
+    return a.to(F64)
   return torch.as_tensor(np.asarray(a), dtype=F64)
 
 
@@ -290,7 +294,7 @@ def bev_localizer(params, cfg, hfov_deg, grid_extent, cell, batch, pose_angles, 
     if cfg['clip_negative_scores']:
       sim = torch.clamp(sim, min=0)
     if cfg['add_temperature']:
-      sim = sim * math.exp(float(params['temperature']))
+      sim = sim * torch.exp(t64(params['temperature']))
     sim = sim / max(int(vq.sum()), 1)
     out['sim'].append(sim)
     # poses: ground truth first (Transform2D.from_Transform3D: angle = atan2(R10, R00), t = t[:2])
