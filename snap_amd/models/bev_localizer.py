@@ -49,29 +49,6 @@ def _const(values, like):
   return t
 
 
-def _record_stream_tree(t, stream):
-  """Outputs allocated on a side stream are used (and eventually freed) on ``stream`` from here on."""
-  if isinstance(t, torch.Tensor):
-    t.record_stream(stream)
-  elif isinstance(t, dict):
-    for v in t.values():
-      _record_stream_tree(v, stream)
-  elif isinstance(t, (list, tuple)):
-    for v in t:
-      _record_stream_tree(v, stream)
-  elif isinstance(t, types.LazyFeatureVolume):
-    _record_stream_tree(t.valid, stream)
-    _record_stream_tree(t._features, stream)
-    fn = t._thunk                  # (what a later materialisation on ``stream`` will read)
-    if fn is not None:
-      _record_stream_tree(list(fn.__defaults__ or ()), stream)
-      _record_stream_tree([c.cell_contents for c in (fn.__closure__ or ())
-                           if isinstance(c.cell_contents, (torch.Tensor, dict, list, tuple))], stream)
-  elif hasattr(t, '__dict__'):
-    for v in vars(t).values():
-      _record_stream_tree(v, stream)
-
-
 class BEVLocalizer(base.Module):
   """Estimate the relative pose between a pair of overlapping scenes."""
 
@@ -219,36 +196,18 @@ class BEVLocalizer(base.Module):
     data_map, data_query = dict(data['map']), {**data['query'], 'xy_bev': q_xy_p}
     self._prefetch_scale(params)
     self.bev_mapper.start_aerial(params['bev_mapper'], data_map, train, ctx)   # (second stream)
-    mapper_q = self.bev_mapper_query or self.bev_mapper
-    params_q = params['bev_mapper_query'] if self.bev_mapper_query is not None else params['bev_mapper']
-    qside = None
     try:
       self._encode_views_jointly(params, data_map, data_query, train, ctx)
-      if (ops.OVERLAP_QUERY and not train and not debug and dev.type == 'cuda'
-          and 'image_feature_pyr' in data_query and not torch.is_grad_enabled()):
-        # Inference: the query scene's tail (lift of one view, fusion MLP + pooling, matching head:
-        # ~1.3 ms at C2) runs on its own stream NEXT TO the map scene's (4 views, ~5 ms): the two share
-        # only the image features encoded above.  Every tensor the side stream reads was produced on the
-        # main stream before this point; its outputs are joined (event + record_stream) below.
-        main, qside = torch.cuda.current_stream(dev), ops.side_stream(dev, 1)
-        qside.wait_stream(main)
-        with torch.cuda.stream(qside):
-          pred['query'] = mapper_q(params_q, data_query, train, debug, is_query=True, ctx=ctx, rng=rng)
-          qdone = qside.record_event()
       pred['map'] = self.bev_mapper(params['bev_mapper'], data_map, train, debug, ctx=ctx, rng=rng)
     finally:
       pending = data_map.pop('_aerial_async', None)
       if pending is not None:      # an exception before the join: no side-stream work is left behind
         torch.cuda.current_stream().wait_event(pending[1])
-      if qside is not None:
-        torch.cuda.current_stream(dev).wait_stream(qside)
-    if qside is not None:
-      main.wait_event(qdone)
-      _record_stream_tree(pred['query'], main)
-    else:
-      pred['query'] = mapper_q(
-          params_q, data_query, train, debug, is_query=True, ctx=ctx, rng=rng,
-      )
+    mapper_q = self.bev_mapper_query or self.bev_mapper
+    params_q = params['bev_mapper_query'] if self.bev_mapper_query is not None else params['bev_mapper']
+    pred['query'] = mapper_q(
+        params_q, data_query, train, debug, is_query=True, ctx=ctx, rng=rng,
+    )
 
     plane_map = pred['map']['bev_matching']
     plane_q = pred['query']['bev_matching']

@@ -36,21 +36,17 @@ POOLED_SPLIT = True
 CLASS_ROWS = True
 # image padding and the voxel-centre grid as one native pass each instead of torch fill + strided copies; 0: torch
 NATIVE_GLUE = True
-# inference: the query scene's mapper tail (lift, fusion MLP + pooling, matching head) on its own stream next
-# to the map scene's (they share only the jointly encoded image features); SNAP_OVERLAP_QUERY=0: one stream
-OVERLAP_QUERY = os.environ.get('SNAP_OVERLAP_QUERY', '1') != '0'
 _SIDE_STREAMS = {}
 
 
-def side_stream(device=None, which=0):
-  """Side stream ``which`` of ``device`` (created once per GPU of the process; default: the current
-  device).  0: the aerial encoder's; 1: the query branch of the mapper (bev_localizer)."""
+def side_stream(device=None):
+  """The second stream of ``device`` (one per GPU of the process; default: the current device)."""
   idx = torch.cuda.current_device() if device is None else torch.device(device).index
   if idx is None:
     idx = torch.cuda.current_device()
-  s = _SIDE_STREAMS.get((idx, which))
+  s = _SIDE_STREAMS.get(idx)
   if s is None:
-    s = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(device=idx)
+    s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
   return s
 
 
