@@ -8,6 +8,7 @@ engine with the validity mask fused into its last epilogue.
 """
 import copy
 
+import numpy as np
 import torch
 
 from snap_amd import autograd as ag
@@ -62,6 +63,42 @@ class StreetViewEncoder(base.Module):
     params['fusion_mlp'] = self.fusion_mlp.init_params(gen, device)
     return params
 
+  def _project(self, p, f, train):
+    """``proj_mlp`` over the image features [B, V, h, w, C].  The encoder hands them over as a CROP of its
+    padded output (``pad_to_multiple`` pads 512 -> 544, image_encoder.py:32-39,139-143): instead of
+    copying the crop (268 MB at C2) the single Dense of the projection gathers its rows from the padded
+    tensor through the engine's row list (``rows_in``: a constant index table, uploaded once)."""
+    cfgp = self.proj_mlp.config
+    if (train or f.is_contiguous() or not f.is_cuda or len(cfgp.layers) != 1 or not ops.NATIVE_GLUE
+        or base.needs_grad(f, p['Dense_0']['kernel'], p['Dense_0']['bias'])):
+      return self.proj_mlp(p, f.contiguous(), train)
+    src = f._base
+    B, V, h, w, C = f.shape
+    st = f.stride()
+    ok = (src is not None and src.is_contiguous() and src.dtype == torch.float32 and st[4] == 1 and st[3] == C
+          and st[2] % C == 0 and st[1] % st[2] == 0 and st[0] == V * st[1]
+          and (f.storage_offset() - src.storage_offset()) % C == 0)
+    if not ok:
+      return self.proj_mlp(p, f.contiguous(), train)
+    Wp, HpWp = st[2] // C, st[1] // C
+    off = (f.storage_offset() - src.storage_offset()) // C
+    M = B * V * h * w
+    total = src.numel() // C
+    if off + (B * V - 1) * HpWp + (h - 1) * Wp + w > total or total >= 2 ** 31:
+      return self.proj_mlp(p, f.contiguous(), train)
+
+    def make():
+      n = np.arange(B * V, dtype=np.int64)[:, None, None] * HpWp
+      rows = off + n + np.arange(h, dtype=np.int64)[None, :, None] * Wp + np.arange(w, dtype=np.int64)[None, None, :]
+      return torch.from_numpy(rows.reshape(-1).astype(np.int32))
+    rows = base.device_const(('proj_crop_rows', B * V, h, w, Wp, HpWp, off), f.device, make)
+    count = base.device_const(('proj_crop_count', M), f.device, lambda: torch.tensor([M], dtype=torch.int32))
+    pro = ops.PRO_RELU if cfgp.apply_input_activation else ops.PRO_NONE
+    d = p['Dense_0']
+    y = ops.dense(src.reshape(total, C), d['kernel'], d['bias'], cin=d['kernel'].shape[0], prologue=pro,
+                  rows_in=rows, row_count=count)
+    return y[:M].reshape(B, V, h, w, y.shape[-1])     # (rows past M are never written nor read)
+
   def _fused_pool_ok(self, params, f_images):
     """The fusion MLP + vertical max pooling run as ONE kernel (ops.mlp2_pool_max) when nothing
     needs gradients, the conv engine in use is the one the kernel is written for and the MLP
@@ -105,7 +142,7 @@ class StreetViewEncoder(base.Module):
     pred = {'image_feature_pyramid': f_image_pyr}
 
     if self.weighted:
-      f_images = self.proj_mlp(params['proj_mlp'], f_images.contiguous(), train)
+      f_images = self._project(params['proj_mlp'], f_images, train)
       pred['scores_images'] = f_images[..., -cfg.num_scale_bins:]
     else:
       f_images = f_images.contiguous()

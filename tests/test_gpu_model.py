@@ -432,3 +432,31 @@ def test_semantic_net_forward_parity(decoder):
     grads = torch.autograd.grad(losses['total'].mean(), leaves, allow_unused=True)
   assert all(g_ is not None and bool(torch.isfinite(g_).all()) for g_ in grads)
   assert 'semantics/accuracy' in metrics and float(losses['total'].mean()) > 0
+
+
+@pytest.mark.parametrize('engine', ['f32', 'bf16x3'])
+def test_projection_gathers_the_cropped_image_features(engine):
+  """``StreetViewEncoder._project``: the projection Dense reads the encoder's CROPPED features through
+  the conv engine's row list instead of a copied crop -- bit for bit what the copy gives, for the map
+  slice (offset 0) and the query slice (an offset into the joint batch) of one padded tensor."""
+  from snap_amd import ops
+  dev = torch.device('cuda')
+  cfg = helpers.tiny_localizer_config()
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  loc = bev_localizer.BEVLocalizer(cfg, meta['build_config'].scene_config, meta['grid'].bev())
+  sv = loc.bev_mapper.streetview_encoder
+  p = helpers.params_to_device(loc.init(0, device='cpu')['params'], dev)['bev_mapper']['streetview_encoder']['proj_mlp']
+  C = sv.proj_mlp.in_dim
+  g = torch.Generator(device='cpu').manual_seed(9)
+  padded = torch.randn(5 * 3 + 5, 24, 20, C, generator=g).to(dev)          # B V + B images of 24 x 20 (padded)
+  crop = padded[:, :16, :13]                                                # (the encoder's crop: a view)
+  fm = crop[:15].reshape(5, 3, 16, 13, C)
+  fq = crop[15:].reshape(5, 1, 16, 13, C)
+  with ops.engine_scope(engine):
+    for f in (fm, fq):
+      assert not f.is_contiguous() and f._base is not None
+      got = sv._project(p, f, False)
+      want = sv.proj_mlp(p, f.contiguous(), False)
+      assert got.shape == want.shape
+      assert torch.equal(got, want), float((got - want).abs().max())
+      assert float(got.abs().max()) > 0
