@@ -574,5 +574,6 @@ def test_whole_model_gradient_vs_torch_fp64_autograd():
   print(f'[whole-model gradient] {len(named)} parameters ({live} with a live gradient), loss {float(loss):.6f} '
         f'(f64 {loss_ref:.6f}), global rel L2 {rel:.2e}, cosine {cos:.8f}, worst parameter {worst[0]} {worst[1]:.2e}')
   assert live >= 0.8 * len(named)
-  assert rel <= 5e-3 and cos >= 0.99998, (rel, cos)
-  assert worst[1] <= 3e-2, worst
+  # (measured on MI355X: global 9.1e-6, worst parameter 1.9e-5, cosine 1 - 4e-11)
+  assert rel <= 2e-4 and cos >= 0.9999999, (rel, cos)
+  assert worst[1] <= 2e-3, worst
