@@ -191,15 +191,17 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   };
   set_tap();
 
-  // a.ablate (SNAP_CONV_ABLATE, timing experiments only -- wrong results): bit0 no A loads,
-  // bit1 no B DMA, bit2 no MFMAs, bit3 no prologue / split math, bit4 no A LDS stores, bit5 no
-  // fragment fetches
-#ifndef SNAP_CONV_SPLIT_ABLATE
-#define SNAP_CONV_SPLIT_ABLATE 0     // build with EXTRA=-DSNAP_CONV_SPLIT_ABLATE=1 (an alt library:
-#endif                               // the hooks cost registers, 11 spilled VGPRs at 4 waves / SIMD)
-  const int ablate = SNAP_CONV_SPLIT_ABLATE ? a.ablate : 0;
+  // Timing ablations of this loop (WRONG results; tools/conv_ablate_split.py) exist ONLY in an alt
+  // build (scripts/build_alt.sh ... -DSNAP_CONV_SPLIT_ABLATE=1 pulls conv_split_ablate.inc in): the
+  // product source carries no hook.  SNAP_ABL(bit) is a compile-time false here.
+#if defined(SNAP_CONV_SPLIT_ABLATE) && SNAP_CONV_SPLIT_ABLATE
+  const int ablate = a.ablate;       // bit0 no A loads, bit1 no B DMA, bit2 no MFMAs, bit3 no prologue /
+#define SNAP_ABL(bit) (ablate & (bit))   // split math, bit4 no A LDS stores, bit5 no fragment fetches
+#else
+#define SNAP_ABL(bit) false
+#endif
   auto load_a = [&]() {
-    if (ablate & 1) return;
+    if (SNAP_ABL(1)) return;
     if constexpr (PLAIN) {
       static_assert(!PLAIN || (GNT || !need_gn), "PLAIN takes the table variant of the GroupNorm prologue");
 #pragma unroll
@@ -246,7 +248,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
               (part < NS ? part : 0) * 4096 + (gcol & 127) * 32 + (rem & 1) * 16;
   }
   auto issue_b = [&](int buf) {
-    if (ablate & 2) return;
+    if (SNAP_ABL(2)) return;
 #pragma unroll
     for (int p = 0; p < BPIECES; ++p) {
       const int slot = tid + 256 * p;
@@ -282,18 +284,10 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     }
   };
   auto store_a = [&](int buf, int ring) {
-    if (ablate & 16) return;
-    if (ablate & 8) {
-#pragma unroll
-      for (int i = 0; i < AROWS; ++i) {
-        const int row = (tid / QPR) + RPP * i;
-        char* dst = Ab + buf * A_ST + row * 32 + (akq >> 1) * 16 + (akq & 1) * 8;
-#pragma unroll
-        for (int p = 0; p < NS; ++p)
-          *reinterpret_cast<u32x2*>(dst + p * A_PART) = u32x2{__float_as_uint(xa[i][0]), __float_as_uint(xa[i][1])};
-      }
-      return;
-    }
+    if (SNAP_ABL(16)) return;
+#if defined(SNAP_CONV_SPLIT_ABLATE) && SNAP_CONV_SPLIT_ABLATE
+#include "conv_split_ablate.inc"       // (bit 3: raw stores instead of prologue + split)
+#endif
     const float* const tb = reinterpret_cast<const float*>(Gt + ring * kGnRing);
     if constexpr (gn_tab) xbeta = *reinterpret_cast<const f32x4*>(tb + 64 + 4 * akq);
 #pragma unroll
@@ -362,7 +356,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     const char* as = Ab + cur * A_ST;
     const char* bs = Bb + cur * B_ST;
     bf16x8 av[TM][NS], bv[TN][NS];
-    if (!(ablate & 32)) {
+    if (!SNAP_ABL(32)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int R = wr * (BM / 2) + i * 32 + l31;
@@ -392,7 +386,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
 #define SNAP_SPLIT_PRODUCT(PA, PB)                                                          \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA], bv[j][PB], acc[i][j], 0, 0, 0);
-    if (!(ablate & 4)) {
+    if (!SNAP_ABL(4)) {
     if constexpr (NS == 3) {
       SNAP_SPLIT_PRODUCT(2, 0)
       SNAP_SPLIT_PRODUCT(0, 2)
