@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int kNT = 1024;
+constexpr int kNT = 64 * vfft::kCols;     // 512 threads at 8 columns: two workgroups per CU
 
 __global__ __launch_bounds__(256) void vf_twiddle_kernel(float2* tw, int N) {
   vfft::twiddle_body(tw, N, (int)(blockIdx.x * 256 + threadIdx.x));
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256) void vf_rot_mask_kernel(vfft::RotSource rs, in
   }
 }
 
-// threads per workgroup: every thread should own at least one radix-4 butterfly of the 16 columns
+// threads per workgroup: one fused radix-16 item (16 elements of one column) per thread
 inline int threads_for(int N) {
-  const int want = N * vfft::kCols / 4;
+  const int want = N * vfft::kCols / 16;
   int nt = 64;
   while (nt < want && nt < kNT) nt *= 2;
   return nt;

@@ -62,8 +62,18 @@ namespace vfft {
 struct RotSource { const float* feat; const uint8_t* valid; const float* tfm; float cell; };
 
 constexpr int kMaxStages = 8;
-constexpr int kCols = 16;          // columns transformed together (= channel pairs of a group)
-constexpr int kMaxN = 1024;        // (16 + 2) * N * 8 B of LDS: 147 KB at N = 1024
+#ifndef VF_COLS
+#define VF_COLS 8
+#endif
+// Columns transformed together = channel pairs of a group (a group = 2 kCols channels: one 64-byte run
+// of a channels-last pixel at kCols = 8).  8 columns: 49 KB of LDS per transform at N = 768, so TWO
+// workgroups share a CU and the staging / transform / product phases of one run under the other's
+// (16 columns = whole 128-byte lines but one workgroup per CU: measured slower).
+constexpr int kCols = VF_COLS;
+constexpr int kColShift = kCols == 16 ? 4 : (kCols == 8 ? 3 : 2);
+static_assert((1 << kColShift) == kCols, "kCols: 4, 8 or 16");
+constexpr int kGroupCh = 2 * kCols;     // channels per group
+constexpr int kMaxN = 1024;        // (kCols + 2) * N * 8 B of LDS
 constexpr int kZPre = 6;           // 16-byte map-spectrum loads a thread keeps in flight across the transform
 
 struct Plan {                      // one axis: N = prod radix[s]; stage s works on spans of L[s]
@@ -279,7 +289,7 @@ struct SlowArgs {
 VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2* buf, float2* twl) {
   const int N = a.pl.N;
   for (int t = tid; t < N; t += nt) twl[t] = a.tw[t];
-  const int p = tid & (kCols - 1), slot = tid >> 4, nslot = nt >> 4;
+  const int p = tid & (kCols - 1), slot = tid >> kColShift, nslot = nt >> kColShift;
   const int col = bx, batch = by;
   for (int row = slot; row < N; row += nslot) {
     float2 v; v.x = 0.f; v.y = 0.f;
@@ -294,7 +304,7 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
           si = row - (a.sH - 1); si = si < 0 ? 0 : (si > a.sH - 1 ? a.sH - 1 : si);
           sj = col - (a.sW - 1); sj = sj < 0 ? 0 : (sj > a.sW - 1 ? a.sW - 1 : sj);
         }
-        const int c = 32 * g + 2 * p;
+        const int c = kGroupCh * g + 2 * p;
         if (c < a.D) {
           const float* s = a.srcf + (img + (int64_t)si * a.sW + sj) * a.D + c;
           if (c + 1 < a.D && !(a.D & 1)) v = *reinterpret_cast<const float2*>(s);
@@ -306,7 +316,7 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
         int si, sj;
         snap_rot90_source(k, row, col, a.sH, a.sW, &si, &sj);
         const SnapRotSample rs = snap_rot_sample(a.tfm + r0 * 4, si, sj, a.sH, a.sW, a.cell, a.srcb);
-        const int c = 32 * g + 2 * p;
+        const int c = kGroupCh * g + 2 * p;
         if (rs.ok && c < a.D) {
           const float* f00 = a.srcf + ((int64_t)rs.i0 * a.sW + rs.j0) * a.D + c;
           const float* f01 = a.srcf + ((int64_t)rs.i0 * a.sW + rs.j1) * a.D + c;
@@ -397,8 +407,9 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
     if (a.mode == kFastDot) {
       z4 = reinterpret_cast<const float4*>(a.z + ((int64_t)g * a.N1 + k1) * N * kCols);
       const float* zt = reinterpret_cast<const float*>(z4);
-      if (tid < N) touch = zt[tid * 32];               // ONE un-waited load per thread (nt >= N on the GPU) ...
-      for (int line = tid + nt; line < N; line += nt) touch += zt[line * 32];   // ... (smaller workgroups: the rest)
+      const int nlines = N * kCols / 16;                // 128-byte lines of the row
+      if (tid < nlines) touch = zt[tid * 32];          // ONE un-waited load per thread (nt >= nlines on the GPU) ...
+      for (int line = tid + nt; line < nlines; line += nt) touch += zt[line * 32];   // ... (smaller workgroups: the rest)
     }
     VF_SYNC();
     fft_lds<kCols, false>(buf, twl, a.pl, tid, nt);
@@ -434,7 +445,7 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
         sbuf[k2] = acc;
       }
     } else {
-      for (int i = tid; i < N * kCols; i += nt) buf[i] = cmulc(a.z[(int64_t)k1 * N + (i >> 4)], buf[i]);
+      for (int i = tid; i < N * kCols; i += nt) buf[i] = cmulc(a.z[(int64_t)k1 * N + (i >> kColShift)], buf[i]);
     }
     VF_SYNC();
   }
@@ -476,7 +487,7 @@ struct InvArgs {
 VF_DEV void inv_body(const InvArgs& a, int bx, int by, int tid, int nt, float2* buf, float2* twl) {
   const int N = a.pl.N;
   for (int t = tid; t < N; t += nt) twl[t] = a.tw[t];
-  const int p = tid & (kCols - 1), slot = tid >> 4, nslot = nt >> 4;
+  const int p = tid & (kCols - 1), slot = tid >> kColShift, nslot = nt >> kColShift;
   if (a.mode == kInvScore) {
     const int r = by, b = bx * kCols + p;
     const float2* y = a.y + (int64_t)r * N * a.ld + b;
@@ -567,7 +578,7 @@ static inline bool make_geometry(int R, int H, int W, int D, int Hm, int Wm, Geo
   g->N1 = fft_size(g->Hp); g->N2 = fft_size(g->Wp);
   if (g->N1 > kMaxN || g->N2 > kMaxN) return false;
   if (!make_plan(g->N1, &g->p1) || !make_plan(g->N2, &g->p2)) return false;
-  g->G = (D + 31) / 32;
+  g->G = (D + kGroupCh - 1) / kGroupCh;
   g->R2 = (R + 1) / 2; g->GC = (g->R2 + kCols - 1) / kCols;
   g->ld = (g->Wo + kCols - 1) / kCols * kCols;
   g->nb = g->ld < g->N2 ? g->ld : g->N2;
