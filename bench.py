@@ -658,9 +658,8 @@ def main(argv=None, emit=True):
           # HBM roofline on SURVEY 8(d)'s algorithmic bytes (templates + map + scores = what any formulation
           # must move); `pipeline_hbm_bytes` is what THIS pipeline moves on top (its intermediate spectra)
           H_, D_, R_, N_, ld_ = 256, 32, 36, 768, 512
-          pipe = (4.0 * R_ * H_ * H_ * D_                      # rotated templates written ...
-                  + 4.0 * R_ * H_ * H_ * D_                    # ... and read by the first transform
-                  + 2 * 128.0 * R_ * N_ * H_                   # X1[r][k1][j][16]: written, read
+          pipe = (2 * 128.0 * R_ * N_ * H_                     # X1[r][g][k1][j][8]: written, read (templates are sampled
+                                                               #  inside the first transform: no template tensor)
                   + 2 * 128.0 * N_ * (3 * H_ - 2) + 128.0 * N_ * N_   # map: Xm1 written / read, Zm written
                   + 2 * 8.0 * R_ * N_ * ld_                    # Y[r][k1][b]: written, read
                   + 4.0 * R_ * (2 * H_ - 1) ** 2)              # scores
@@ -668,7 +667,7 @@ def main(argv=None, emit=True):
               'kernel': 'exhaustive_voting (rotate + voting_fft: vf_slow / vf_fast / vf_inv kernels)',
               'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
               'frac': round(gbs / PEAK_HBM_GBS, 5), 'traffic': None, 'ms': round(vms, 3),
-              'formulation': 'frequency domain (voting_fft.hip): 768-point mixed-radix LDS FFTs of 16 channel-pair '
+              'formulation': 'frequency domain (voting_fft.hip): 768-point mixed-radix LDS FFTs of 8 channel-pair '
                              'columns, spectra multiplied in digit-reversed order, overlap count by rotation pairs',
               'algorithmic_bytes': c4_algo['voting_bytes'],
               'pipeline_hbm_bytes': pipe, 'pipeline_gbs': round(pipe / vms / 1e6, 1),

@@ -14,9 +14,9 @@
 // count packs the ROTATIONS r and r + R/2 the same way: Re -> count of r, -Im -> count of r + R/2,
 // rounded to the nearest integer (operands are 0/1: the count is exact).
 //
-// Transforms: in-place mixed-radix (3, 2, 4...) FFTs of SIXTEEN columns at a time in LDS, layout
-// [n][16] complex64 -- the 16 columns are the 16 channel pairs of one 32-channel group (128 B of a
-// channels-last row: every global access is a whole 128-byte run).  Forward = decimation in
+// Transforms: in-place mixed-radix (3, 2, 4...) FFTs of kCols (= 8) columns at a time in LDS, layout
+// [n][kCols] complex64 -- the columns are the channel pairs of one 2 kCols-channel group (one 64-byte
+// run of a channels-last pixel: every global access is a whole run).  Forward = decimation in
 // frequency (natural order in, digit-reversed out); the spectra stay in digit-reversed order (the
 // map's, produced by the same routine, are permuted identically); inverse = decimation in time, the
 // exact conjugate transpose of the forward stages in reverse order (digit-reversed in, natural
