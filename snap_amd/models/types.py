@@ -50,6 +50,18 @@ class LazyFeatureVolume(FeatureVolume):
   def materialized(self):
     return self._features is not None
 
+  # (the dataclass-generated __repr__ / __eq__ of FeatureVolume read ``features``: printing or
+  #  comparing a prediction dict would silently run the unfused lift + MLP chain)
+  def __repr__(self):
+    state = 'materialized' if self._features is not None else ('lazy' if self._thunk is not None else 'discarded')
+    shape = None if self.valid is None else tuple(self.valid.shape)
+    return f'LazyFeatureVolume({state}, valid shape={shape})'
+
+  def __eq__(self, other):
+    return self is other
+
+  __hash__ = object.__hash__
+
   def discard(self):
     """Release the inputs held for a volume nobody will read (``features`` is then None)."""
     self._thunk = None

@@ -152,6 +152,9 @@ _PIN_RING = []
 _PIN_NEXT = 0
 
 
+_PIN_LOCK = threading.Lock()
+
+
 def upload_table(items, device):
   """numpy structured / plain array -> uint8 device tensor holding its bytes."""
   raw = np.ascontiguousarray(items).view(np.uint8).reshape(-1)
@@ -160,19 +163,22 @@ def upload_table(items, device):
     return torch.from_numpy(raw.copy()).to(device)
   global _PIN_NEXT
   n = raw.size
-  if not _PIN_RING:          # the whole ring at once (a pinned allocation takes ~0.2 s: never inside a step)
-    _PIN_RING.extend([torch.empty(1 << 17, dtype=torch.uint8, pin_memory=True), None] for _ in range(16))
-  slot = _PIN_RING[_PIN_NEXT % 16]
-  _PIN_NEXT += 1
-  if slot[1] is not None:
-    slot[1].synchronize()
-  if slot[0].numel() < n:
-    slot[0] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-  slot[0][:n].numpy()[:] = raw
-  out = slot[0][:n].to(device, non_blocking=True)
-  ev = torch.cuda.Event()
-  ev.record()
-  slot[1] = ev
+  # one lock around slot selection, fill and the copy's issue: autograd hook / backward threads
+  # (the overlapped gradient reducer) call this next to the main thread
+  with _PIN_LOCK:
+    if not _PIN_RING:          # the whole ring at once (a pinned allocation takes ~0.2 s: never inside a step)
+      _PIN_RING.extend([torch.empty(1 << 17, dtype=torch.uint8, pin_memory=True), None] for _ in range(16))
+    slot = _PIN_RING[_PIN_NEXT % 16]
+    _PIN_NEXT += 1
+    if slot[1] is not None:
+      slot[1].synchronize()
+    if slot[0].numel() < n:
+      slot[0] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    slot[0][:n].numpy()[:] = raw
+    out = slot[0][:n].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    slot[1] = ev
   return out
 
 

@@ -454,11 +454,32 @@ def plane_fuse_match_bwd(planes, valids, pooling, Wm, bm, normalize, eps, dmatch
 # may overwrite in place instead of cloning first (data_ptr -> weak reference).  Autograd passes a
 # single incoming gradient through unchanged (same storage); a sum of several gradients is a new
 # tensor and never matches.  One-time: ``take_scratch`` removes the entry.
+# ONLY inside ``owning_scratch_grads()``: the hand-over is safe when nobody else can see the
+# gradient tensor -- the trainer's own backward pass (no retain_grad, no tensor hooks on intermediate
+# gradients, no retain_graph).  A caller who differentiates the model himself (torch.autograd.grad with
+# an intermediate as input, hooks, a second backward over a retained graph) gets the clone.
+import contextlib
 import weakref
 _SCRATCH_GRADS = {}
+_SCRATCH_OWNERS = 0
+
+
+@contextlib.contextmanager
+def owning_scratch_grads():
+  """The enclosed backward pass owns every gradient tensor it produces (``trainer._forward_backward``)."""
+  global _SCRATCH_OWNERS
+  _SCRATCH_OWNERS += 1
+  try:
+    yield
+  finally:
+    _SCRATCH_OWNERS -= 1
+    if _SCRATCH_OWNERS == 0:
+      _SCRATCH_GRADS.clear()          # marks nobody consumed do not outlive the pass
 
 
 def mark_scratch(t):
+  if _SCRATCH_OWNERS <= 0:
+    return t
   if len(_SCRATCH_GRADS) > 64:
     _SCRATCH_GRADS.clear()
   _SCRATCH_GRADS[t.data_ptr()] = (weakref.ref(t), t.numel())

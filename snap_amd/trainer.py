@@ -301,14 +301,18 @@ def _forward_backward(state, batch, model, leaves, sampling_rng, group, debug, o
     total = losses['total']
     loss = torch.where(mask, total, torch.zeros_like(total)).sum() / mask.sum().clamp(min=1)
     objective = loss if loss_scale is None else loss * loss_scale
-    if sdist._exchanges(group) and overlap_allreduce:
-      reducer = sdist.OverlappedGradReducer(leaves, group).attach()
-      objective.backward()                             # buckets go out as their grads land
-      grads = reducer.finish()                         # jax.lax.pmean(grad, 'batch')
-    else:
-      grads = torch.autograd.grad(objective, leaves, allow_unused=True)
-      grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
-      sdist.allreduce_mean_(grads, group)              # jax.lax.pmean(grad, 'batch')
+    from snap_amd import ops_bwd
+    # (this backward pass owns its intermediate gradients: VJP nodes may overwrite the buffer they are
+    #  handed instead of cloning it -- ops_bwd.owning_scratch_grads)
+    with ops_bwd.owning_scratch_grads():
+      if sdist._exchanges(group) and overlap_allreduce:
+        reducer = sdist.OverlappedGradReducer(leaves, group).attach()
+        objective.backward()                             # buckets go out as their grads land
+        grads = reducer.finish()                         # jax.lax.pmean(grad, 'batch')
+      else:
+        grads = torch.autograd.grad(objective, leaves, allow_unused=True)
+        grads = [torch.zeros_like(t) if g is None else g.contiguous() for g, t in zip(grads, leaves)]
+        sdist.allreduce_mean_(grads, group)              # jax.lax.pmean(grad, 'batch')
     if loss_scale is not None:
       torch._foreach_mul_(grads, 1.0 / loss_scale)
   return grads, loss, losses, metrics
