@@ -46,6 +46,7 @@ struct ConvArgs {
   int bk;      // f32 engine: K-slab depth of the large tiles (16 | 32)
   int no_halo; // split engine: 1 = im2col body for every 3x3
   int no_plain;  // split engine: 1 = the general loader also for 1 x 1 / stride 1 / unpadded layers
+  int no_raw;    // split engine: 1 = no raw-row LDS-DMA body (conv_raw.hip) for the K >= 256 1 x 1 layers
   int rs_nsplit;  // split engine: forced column split of conv_rs.hip (0 = automatic)
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])
   int cin8;            // ... channel count rounded up to 8
@@ -86,6 +87,10 @@ int stationary_kind(const SnapConvDesc& d, int parts, bool row_lists);
 int launch_rs(ConvArgs a, hipStream_t s);
 int launch_bs(ConvArgs a, hipStream_t s);
 int launch_root_ws(const ConvArgs& a, hipStream_t s);   // the RGB root convolution, 64 output channels
+// raw-row LDS-DMA body for 1 x 1 / stride 1 layers with a GroupNorm prologue and K >= 256 (conv_raw.hip):
+// bit-identical to the tiled body; `a` as launch<128, bn, pro, 2> of conv_split.hip has set it up
+bool raw_ok(const ConvArgs& a, int bm, int bn, int pro);
+int launch_raw(const ConvArgs& a, int bn, int pro, dim3 grid, hipStream_t s);
 struct PsTile { int bm, bn, nt; };
 PsTile ps_choose_tile(int64_t M, int64_t N, int force);
 int ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t kpartial_bytes);

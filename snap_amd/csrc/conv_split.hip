@@ -803,6 +803,15 @@ int launch(ConvArgs a, hipStream_t s) {
                      a.d.pad_l == 0 && a.d.H == a.d.Ho && a.d.W == a.d.Wo && a.d.Cin % 16 == 0 &&
                      (a.d.Cin_stride & 3) == 0 && !a.rows_in && !a.row_count && a.M > 0 &&
                      (int64_t)BM * a.d.Cin_stride * 4 < 0x7ff00000LL;
+  // K >= 256 with a GroupNorm prologue: the raw rows through an LDS ring, converted at fragment fetch
+  // (conv_raw.hip: two k-steps in flight instead of one memory round trip per k-step; same bits)
+  if constexpr (BM == 128 && NS == 2 && (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_RELU_GN)) {
+    if (plain && table_ok && snapconv::raw_ok(a, BM, BN, PRO)) {
+      const int rc = snapconv::launch_raw(a, BN, PRO, grid, s);
+      if (rc != SNAP_OK) return rc;
+      return a.ksplit > 1 ? launch_splitk_reduce(a, s) : SNAP_OK;
+    }
+  }
   if constexpr (NS == 2 && (PRO == SNAP_PRO_GN_RELU || PRO == SNAP_PRO_NONE || PRO == SNAP_PRO_RELU_GN)) {
     if (plain && (!need_gn || table_ok)) {
       hipLaunchKernelGGL((conv_split_kernel<BM, BN, PRO, NS, need_gn, false, false, true>), grid, dim3(256), 0, s, a);

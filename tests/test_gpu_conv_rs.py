@@ -39,6 +39,7 @@ def _engine():
   ops.CONV_RS_FORCE = False
   ops.CONV_NO_RS = False
   ops.CONV_NO_WS = False
+  ops.CONV_NO_RAW = False
 
 
 def _layer(N, H, W, Cin, Cout, seed, residual):
@@ -145,6 +146,7 @@ def test_shapes_outside_the_kernel_take_the_tiled_engine():
   ops.CONV_NO_WS = True
   assert not _takes_rs(3, 11, 11, 64, 256, True)        # fewer than 128 pixels per image (a row tile: two images at most)
   ops.CONV_NO_WS = False
+  ops.CONV_NO_RAW = False
   assert not _takes_rs(3, 5, 5, 64, 256, True)          # ... fewer than 32 for the weights-stationary kernel
   assert not _takes_rs(3, 20, 20, 64, 128, True)        # a single column tile
   assert not _takes_rs(3, 20, 20, 256, 256, True)       # Cin = 256 pays from Cout = 512
@@ -236,3 +238,77 @@ def test_weights_stationary_root_conv_equals_the_tiled_root_kernel(N, H, W, affi
   if N <= 3:
     want = oracle_ops.conv2d(x, w, **kw)
     helpers.report('ws root vs oracle', y_ws, want, atol=TOL * float(want.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------
+# conv_raw.hip: 1 x 1 layers with K >= 256 -- raw rows through an LDS ring, GroupNorm + split at
+# fragment fetch.  Same arithmetic as the tiled (plain) body: bit for bit.
+# ------------------------------------------------------------------------------------------
+RAW_CASES = [
+    # N, H, W, Cin, Cout, prologue, residual, relu, up_prev, tile
+    (3, 34, 34, 1024, 256, 'gn_relu', False, False, False, '128x128'),    # stage-3 reduction (two column tiles)
+    (2, 17, 17, 2048, 512, 'gn_relu', False, False, False, '128x128'),    # 289 pixels per image: tiles straddle two images
+    (2, 17, 17, 512, 2048, 'gn_relu', True, False, False, '128x128'),     # expansion with a residual, K = 512
+    (1, 23, 19, 256, 128, 'gn_relu', False, True, False, '128x64'),       # ragged last tile, 64-column tiles, ReLU epilogue
+    (2, 16, 24, 256, 128, 'relu_gn', False, False, True, '128x128'),      # FPN skip conv: ReLU -> GroupNorm, upsample-add epilogue
+    (40, 34, 34, 1024, 256, 'gn_relu', False, False, False, None),        # the C2 layer at full size, automatic tile
+]
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,pro,residual,relu,up,tile', RAW_CASES)
+@pytest.mark.parametrize('emit', [None, 'raw'])
+def test_raw_row_ring_body_equals_the_tiled_body(N, H, W, Cin, Cout, pro, residual, relu, up, tile, emit):
+  if emit is not None and (N == 40 or up):
+    pytest.skip('one statistics variant per epilogue kind is enough')
+  ops.CONV_TILE = tile
+  ops.CONV_NO_RS = True                 # (the stationary kernels have their own tests above)
+  relu_first = pro == 'relu_gn'
+  prologue = ops.PRO_RELU_GN if relu_first else ops.PRO_GN_RELU
+  x, w, res, g_in, b_in = _layer(N, H, W, Cin, Cout, 3000 + Cin + Cout, residual)
+  xd = x.to(DEV)
+  mu, sc = ops.group_norm_stats(xd, g_in.to(DEV), relu_first=relu_first)
+  upp = rnd((N, H // 2, W // 2, Cout), 3100).to(DEV) if up else None
+  out = {}
+  for no_raw in (False, True):
+    ops.CONV_NO_RAW = no_raw
+    ops.USE_SPLITK = False
+    try:
+      out[no_raw] = ops.conv2d(xd, w.to(DEV), prologue=prologue, gn=(mu, sc, b_in.to(DEV)),
+                               residual=None if res is None else res.to(DEV), relu=relu, up_prev=upp,
+                               emit_gn_stats=emit)
+    finally:
+      ops.CONV_NO_RAW = False
+      ops.USE_SPLITK = True
+  y_raw, y_t = out[False], out[True]
+  assert torch.equal(y_raw, y_t), float((y_raw - y_t).abs().max())
+  assert float(y_raw.abs().max()) > 0
+  mu_w, sc_w = oracle_ops.group_norm_stats(x, g_in, relu_first=relu_first)
+  want = oracle_ops.conv2d(x, w, prologue=prologue, gn=(mu_w, sc_w, b_in), residual=res, relu=relu,
+                           up_prev=None if upp is None else upp.cpu())
+  helpers.report('raw-ring conv vs oracle', y_raw, want, atol=TOL * float(want.abs().max()))
+  if emit is not None:
+    assert hasattr(y_raw, '_snap_gn_partial')
+    gamma = rnd((Cout,), 7) * 0.3 + 1
+    mu_f, sc_f = ops.group_norm_stats(y_raw, gamma.to(DEV))
+    mu_o, sc_o = oracle_ops.group_norm_stats(y_raw.cpu(), gamma)
+    helpers.report('raw-ring stats mu', mu_f, mu_o, atol=1e-5, rtol=1e-5)
+    helpers.report('raw-ring stats sc', sc_f, sc_o, atol=1e-5, rtol=5e-5)
+
+
+def test_raw_row_ring_body_with_split_k_keeps_the_bits():
+  """A small-M / deep-K launch that the engine splits along K (each split >= 16 k-steps): the ring body inside
+  every split + the shared reduce pass = the tiled body's bits."""
+  ops.CONV_TILE = '128x128'
+  ops.CONV_NO_RS = True
+  # 100 output tiles -> 8 splits of 16 k-steps each (conv_common.h: target 768 workgroups, >= 8 slabs per split)
+  x, w, res, g_in, b_in = _layer(4, 40, 40, 2048, 256, 3333, False)
+  xd = x.to(DEV)
+  mu, sc = ops.group_norm_stats(xd, g_in.to(DEV))
+  out = {}
+  for no_raw in (False, True):
+    ops.CONV_NO_RAW = no_raw
+    try:
+      out[no_raw] = ops.conv2d(xd, w.to(DEV), prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)))
+    finally:
+      ops.CONV_NO_RAW = False
+  assert torch.equal(out[False], out[True]), float((out[False] - out[True]).abs().max())
