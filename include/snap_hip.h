@@ -178,7 +178,7 @@ typedef struct SnapConvExtras {
   int32_t gnb_mode;
 } SnapConvExtras;
 #define SNAP_TUNE_NO_HALO 1   /* split engine: the im2col body for every 3x3 convolution */
-#define SNAP_TUNE_NO_RAW 2   /* split engine: no raw-row LDS-DMA body for the K >= 256 1x1 layers (the tiled body instead; same bits) */
+#define SNAP_TUNE_RAW_RING 2   /* split engine: the raw-row LDS-DMA ring body (conv_raw.hip) for the K >= 256 1x1 layers with a GroupNorm prologue -- same bits as the tiled body; opt-in (measured level to 20 % slower: DESIGN.md 5a) */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
 #define SNAP_TUNE_RS_NSPLIT_SHIFT 4   /* bits 4..7: row-stationary kernel, forced column split (0 = automatic) */
 #define SNAP_TUNE_ABLATE_SHIFT 8   /* bits 8..: timing-only ablations of the K loop (WRONG results) */

@@ -46,7 +46,7 @@ struct ConvArgs {
   int bk;      // f32 engine: K-slab depth of the large tiles (16 | 32)
   int no_halo; // split engine: 1 = im2col body for every 3x3
   int no_plain;  // split engine: 1 = the general loader also for 1 x 1 / stride 1 / unpadded layers
-  int no_raw;    // split engine: 1 = no raw-row LDS-DMA body (conv_raw.hip) for the K >= 256 1 x 1 layers
+  int use_raw;   // split engine: 1 = the raw-row LDS-DMA ring body (conv_raw.hip) for the K >= 256 1 x 1 layers (opt-in: measured level / slower)
   int rs_nsplit;  // split engine: forced column split of conv_rs.hip (0 = automatic)
   const void* w_bf16;  // bf16 engine: weights packed by snap_conv2d_pack_weights_bf16 ([Cout][taps][cin8])
   int cin8;            // ... channel count rounded up to 8

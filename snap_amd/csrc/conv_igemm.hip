@@ -734,7 +734,7 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.no_halo = (ex && (ex->tune_flags & SNAP_TUNE_NO_HALO)) ? 1 : 0;
   a.rs_nsplit = ex ? (ex->tune_flags >> SNAP_TUNE_RS_NSPLIT_SHIFT) & 15 : 0;
   a.no_plain = (ex && (ex->tune_flags & SNAP_TUNE_NO_PLAIN)) ? 1 : 0;
-  a.no_raw = (ex && (ex->tune_flags & SNAP_TUNE_NO_RAW)) ? 1 : 0;
+  a.use_raw = (ex && (ex->tune_flags & SNAP_TUNE_RAW_RING)) ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // bf16-operand engine (training precision): needs the packed bf16 weights and the float4
   // loader's alignment; anything else runs on the (more precise) f32 engine below.

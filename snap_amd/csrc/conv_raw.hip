@@ -3,15 +3,19 @@
 // registers), and the GroupNorm + ReLU prologue and the two-part bf16 split run AT FRAGMENT FETCH, in
 // the wave that multiplies the fragment.
 //
-// Why: the tiled body of conv_split.hip fetches a k-step's A rows through registers ONE
-// step ahead, so every 16-k step exposes a memory round trip (1.0-1.4 us against 0.17 us of MFMAs on
-// the K >= 256 layers of ResNet stages 2-4); a load that should stay in flight across two iterations
-// must be younger than everything the next iteration waits for (vmcnt is an in-order queue), i.e. it
-// needs its own registers -- which the 128 x 128 tile does not have at four workgroups per CU.  Here
-// the ring slots ARE the extra storage: three 16 KB stages (A raw 8 KB + split weights 8 KB), two of
-// them in flight while the third is multiplied, 48 KB per workgroup = three workgroups per CU.  The
-// price is the conversion done twice (the two waves that share a row block each convert it): ~140
-// instead of ~80 VALU instructions per wave and k-step, under the other waves' MFMAs.
+// AN EXPERIMENT THAT ANSWERED A QUESTION (round 5; opt-in: SNAP_TUNE_RAW_RING / ops.CONV_RAW_RING, off by
+// default).  Hypothesis: the tiled body of conv_split.hip fetches a k-step's A rows through registers
+// ONE step ahead, so every 16-k step exposes a memory round trip; with the ring slots as the extra
+// storage -- three 16 KB stages (A raw 8 KB + split weights 8 KB), TWO in flight while the third is
+// multiplied, 48 KB per workgroup = three workgroups per CU -- the loop should run at the pace of its
+// instructions.  Result (tools/conv_raw_bench.py, profiles/r05_conv_raw_bench.log): bit-identical, and
+// LEVEL TO 20 % SLOWER on every K >= 256 layer of the C2 encoders (1024 -> 256 @ 34^2: 121 vs 119 us;
+// 2048 -> 512 @ 17^2: 154 vs 124).  With two k-steps in flight the loop still takes ~4100 cycles per
+// k-step and SIMD: three waves x (12 MFMAs = 384 cycles + ~250 VALU instructions of conversion at ~4
+// cycles + 18 LDS fetches) -- the waves of a SIMD do NOT hide each other's VALU under their MFMAs
+// here, the phases add up (what round 2's ablation build had already shown from the other side).  The
+// conv family is bound by SIMD ISSUE (prologue / split VALU + MFMA + LDS), not by memory latency:
+// what moves it is fewer VALU cycles per element, not more loads in flight.
 //
 // Same arithmetic as conv_split_body<..., PLAIN>: apply_pro on the same f32 value, the same RNE
 // split (hi = bf16(v), lo = bf16(v - hi)), the same products in the same order per accumulator (lo x
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256, 3) void conv_raw_kernel(const ConvArgs a) {
 bool snapconv::raw_ok(const ConvArgs& a, int bm, int bn, int pro) {
   const SnapConvDesc& d = a.d;
   const bool gn = pro == SNAP_PRO_GN_RELU || pro == SNAP_PRO_RELU_GN;
-  return !a.no_raw && bm == 128 && (bn == 128 || bn == 64) && gn && d.KH == 1 && d.KW == 1 && d.stride == 1 &&
+  return a.use_raw && bm == 128 && (bn == 128 || bn == 64) && gn && d.KH == 1 && d.KW == 1 && d.stride == 1 &&
          d.pad_t == 0 && d.pad_l == 0 && d.H == d.Ho && d.W == d.Wo && d.Cin % 16 == 0 && (d.Cin_stride & 3) == 0 &&
          !a.rows_in && !a.rows_out && !a.row_count && a.M > 0 && d.Ho * d.Wo >= bm &&
          (a.ksplit > 1 ? a.slabs_per_split : a.nk) >= 16 &&          // K >= 256 per workgroup: the ring pays from there

@@ -274,7 +274,7 @@ SPLITK_STATS = True     # split-K launches of the split engine emit GroupNorm pa
 MLP_POOL_NO_RING = False  # tuning / tests: pre-split rows on the two-stage GEMM0 loop instead of the three-stage ring (x_split = 5)
 MLP_POOL_WIDE = False     # tuning / tests: pre-split rows on the 256-row mlp2_pool kernel (x_split = 3; measured slower, mlp_pool.hip)
 CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
-CONV_NO_RAW = False     # tests / tools: no raw-row LDS-DMA body (conv_raw.hip) for the K >= 256 1x1 layers
+CONV_RAW_RING = False   # tests / tools: the raw-row LDS-DMA ring body (conv_raw.hip) for the K >= 256 1x1 layers (same bits; not faster)
 CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
 USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
 PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
@@ -618,11 +618,11 @@ def conv2d(
       ex.x_presplit = 1
       ex.ps_tile = pst
       ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
-  if CONV_BK or CONV_NO_HALO or CONV_RS_NSPLIT or CONV_NO_PLAIN or CONV_ABLATE or CONV_NO_RAW:
+  if CONV_BK or CONV_NO_HALO or CONV_RS_NSPLIT or CONV_NO_PLAIN or CONV_ABLATE or CONV_RAW_RING:
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.bk_hint = int(CONV_BK or 0)
-    ex.tune_flags = (int(bool(CONV_NO_HALO)) | 2 * int(bool(CONV_NO_RAW)) | 8 * int(bool(CONV_NO_PLAIN))
+    ex.tune_flags = (int(bool(CONV_NO_HALO)) | 2 * int(bool(CONV_RAW_RING)) | 8 * int(bool(CONV_NO_PLAIN))
                      | ((int(CONV_RS_NSPLIT) & 15) << 4)
                      | (int(CONV_ABLATE) << 8))
   kflops = 2.0 * KH * KW * Cin * Cout

@@ -39,7 +39,7 @@ def _engine():
   ops.CONV_RS_FORCE = False
   ops.CONV_NO_RS = False
   ops.CONV_NO_WS = False
-  ops.CONV_NO_RAW = False
+  ops.CONV_RAW_RING = False
 
 
 def _layer(N, H, W, Cin, Cout, seed, residual):
@@ -146,7 +146,7 @@ def test_shapes_outside_the_kernel_take_the_tiled_engine():
   ops.CONV_NO_WS = True
   assert not _takes_rs(3, 11, 11, 64, 256, True)        # fewer than 128 pixels per image (a row tile: two images at most)
   ops.CONV_NO_WS = False
-  ops.CONV_NO_RAW = False
+  ops.CONV_RAW_RING = False
   assert not _takes_rs(3, 5, 5, 64, 256, True)          # ... fewer than 32 for the weights-stationary kernel
   assert not _takes_rs(3, 20, 20, 64, 128, True)        # a single column tile
   assert not _takes_rs(3, 20, 20, 256, 256, True)       # Cin = 256 pays from Cout = 512
@@ -270,14 +270,14 @@ def test_raw_row_ring_body_equals_the_tiled_body(N, H, W, Cin, Cout, pro, residu
   upp = rnd((N, H // 2, W // 2, Cout), 3100).to(DEV) if up else None
   out = {}
   for no_raw in (False, True):
-    ops.CONV_NO_RAW = no_raw
+    ops.CONV_RAW_RING = not no_raw
     ops.USE_SPLITK = False
     try:
       out[no_raw] = ops.conv2d(xd, w.to(DEV), prologue=prologue, gn=(mu, sc, b_in.to(DEV)),
                                residual=None if res is None else res.to(DEV), relu=relu, up_prev=upp,
                                emit_gn_stats=emit)
     finally:
-      ops.CONV_NO_RAW = False
+      ops.CONV_RAW_RING = False
       ops.USE_SPLITK = True
   y_raw, y_t = out[False], out[True]
   assert torch.equal(y_raw, y_t), float((y_raw - y_t).abs().max())
@@ -306,9 +306,9 @@ def test_raw_row_ring_body_with_split_k_keeps_the_bits():
   mu, sc = ops.group_norm_stats(xd, g_in.to(DEV))
   out = {}
   for no_raw in (False, True):
-    ops.CONV_NO_RAW = no_raw
+    ops.CONV_RAW_RING = not no_raw
     try:
       out[no_raw] = ops.conv2d(xd, w.to(DEV), prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)))
     finally:
-      ops.CONV_NO_RAW = False
+      ops.CONV_RAW_RING = False
   assert torch.equal(out[False], out[True]), float((out[False] - out[True]).abs().max())

@@ -1,5 +1,5 @@
 """The K >= 256 1 x 1 layers of the C2 encoders on the split engine: raw-row LDS-ring body (conv_raw.hip)
-vs the tiled plain body (ops.CONV_NO_RAW), isolated launches with a GroupNorm prologue.
+vs the tiled plain body (ops.CONV_RAW_RING off), isolated launches with a GroupNorm prologue.
 
   python tools/conv_raw_bench.py
 """
@@ -35,7 +35,7 @@ def main():
     w._snap_packed = {'bf16x3': ops.pack_weights_split_bf16(w, 2)}
     line = f'{name:34s}'
     for label, no_raw, no_rs in (('raw', False, True), ('tiled', True, True), ('auto', False, False)):
-      ops.CONV_NO_RAW, ops.CONV_NO_RS = no_raw, no_rs
+      ops.CONV_RAW_RING, ops.CONV_NO_RS = not no_raw, no_rs
       try:
         for _ in range(3):
           ops.conv2d(x, w, math='bf16x3', prologue=ops.PRO_GN_RELU, gn=gn)
@@ -47,7 +47,7 @@ def main():
         torch.cuda.synchronize()
         line += f'  {label}: {e0.elapsed_time(e1) / 20 * 1e3:6.1f} us'
       finally:
-        ops.CONV_NO_RAW, ops.CONV_NO_RS = False, False
+        ops.CONV_RAW_RING, ops.CONV_NO_RS = False, False
     print(line, flush=True)
 
 
