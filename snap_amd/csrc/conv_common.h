@@ -107,9 +107,6 @@ template <int PRO>
 __device__ __forceinline__ float apply_pro(float v, float mu, float sc, float beta, float s,
                                            float t) {
   if constexpr (PRO == SNAP_PRO_AFFINE) return v * s + t;
-#if defined(SNAP_FAST_PRO) && SNAP_FAST_PRO     // TIMING EXPERIMENT (alt build): 3 instead of 5 VALU per element
-  if constexpr (PRO == SNAP_PRO_GN_RELU) return fmaxf(fmaf(v - mu, sc, beta), 0.f);
-#endif
   if constexpr (PRO == SNAP_PRO_GN_RELU) return snap_relu((v - mu) * sc + beta);
   if constexpr (PRO == SNAP_PRO_RELU_GN) return (snap_relu(v) - mu) * sc + beta;
   if constexpr (PRO == SNAP_PRO_RELU) return snap_relu(v);
