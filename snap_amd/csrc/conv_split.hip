@@ -79,6 +79,10 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, u32x2 (&out)[NS]) {
 // loader drop out -- rows beyond M are CLAMPED to the last row (their accumulators are garbage the
 // epilogue never stores) and the A rows are fetched with buffer loads: a constant 32-bit byte
 // offset per thread plus the slab's offset in the scalar operand.  Same values, same bits.
+#if defined(SNAP_CONV_TIMELINE) && SNAP_CONV_TIMELINE
+__device__ unsigned long long g_conv_timeline[1024 * 4 * 8];
+#endif
+
 template <int BM, int BN, int PRO, int NS, bool GNT, bool TAIL, bool ROOT = false, bool DUAL = false, bool PLAIN = false>
 __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
   constexpr int BK = 16;
@@ -341,10 +345,22 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+#if defined(SNAP_CONV_TIMELINE) && SNAP_CONV_TIMELINE
+  // ALT BUILD ONLY (tools/conv_timeline.py): where a wave's cycles go, phase by phase (s_memtime around
+  // fenced phases: the fences themselves cost overlap, so read the SHARES, not the total)
+  unsigned long long tl_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define TL_MARK(i) do { asm volatile("" ::: "memory"); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl_acc[i] += tn_ - tl_t; tl_t = tn_; } while (0)
+  unsigned long long tl_t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define TL_MARK(i) do {} while (0)
+#endif
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
     const int ring_next = ring_cur == 2 ? 0 : ring_cur + 1;
+    TL_MARK(6);                       // loop control / back edge
     if (more) {
       load_a();
       issue_b(cur ^ 1);
@@ -353,6 +369,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
         if (kt + 2 < kt_end) { issue_gn(ring_next == 2 ? 0 : ring_next + 1, g_ct); next_gct(); }
       }
     }
+    TL_MARK(0);                       // issue of the loads / DMA of the next k-step
     const char* as = Ab + cur * A_ST;
     const char* bs = Bb + cur * B_ST;
     bf16x8 av[TM][NS], bv[TN][NS];
@@ -381,6 +398,10 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
 #pragma unroll
         for (int p = 0; p < NS; ++p) asm volatile("" : "=v"(bv[j][p]));
     }
+#if defined(SNAP_CONV_TIMELINE) && SNAP_CONV_TIMELINE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    TL_MARK(1);                       // fragment fetches landed
     // smallest terms first; the four (i, j) accumulators interleave so that two MFMAs on the
     // same accumulator are TM*TN issues apart
 #define SNAP_SPLIT_PRODUCT(PA, PB)                                                          \
@@ -410,11 +431,29 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& a) {
         for (int p = 0; p < NS; ++p) asm volatile("" ::"v"(bv[j][p]));
     }
 #undef SNAP_SPLIT_PRODUCT
+    TL_MARK(2);                       // MFMA issue (12 x 32 cycles if the pipe is free)
+#if defined(SNAP_CONV_TIMELINE) && SNAP_CONV_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TL_MARK(3);                       // wait for the next k-step's A rows (+ B, table)
     if (more) store_a(cur ^ 1, ring_next);
     ring_cur = ring_next;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B octets of slab kt+1 (+ table kt+2) landed
+#if defined(SNAP_CONV_TIMELINE) && SNAP_CONV_TIMELINE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    TL_MARK(4);                       // prologue + split + LDS stores
     __syncthreads();
+    TL_MARK(5);                       // barrier
   }
+#if defined(SNAP_CONV_TIMELINE) && SNAP_CONV_TIMELINE
+  if (PLAIN && lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) g_conv_timeline[(blockIdx.x * 4 + wid) * 8 + i] = tl_acc[i];
+    g_conv_timeline[(blockIdx.x * 4 + wid) * 8 + 7] = (unsigned long long)(kt_end - kt_begin);
+  }
+#endif
+#undef TL_MARK
 
   conv_epilogue<BM, BN, DUAL>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
@@ -1059,3 +1098,10 @@ extern "C" int snap_conv2d_pack_weights_split_root_bf16(const float* w, int32_t 
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
+
+#if defined(SNAP_CONV_TIMELINE) && SNAP_CONV_TIMELINE
+// alt build only: copy the phase counters of the last plain-body launch to the host (tools/conv_timeline.py)
+extern "C" int snap_debug_conv_timeline(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_timeline), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
