@@ -672,81 +672,105 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_batched_kernel(const LiftBw
   }
 }
 
-// One half-wave per image pixel: the records whose first tap is one of the four pixels
-// (i - 1 .. i) x (j - 1 .. j) are the only ones that can touch (i, j) (the second tap index is the
-// first or the first + 1); their sorted lists are walked in a fixed order and every tap that
-// lands on the pixel adds weight x gradient.  Lane hl owns channels hl + 32 e and depth bin hl.
+// The image gradient from the sorted records, every record read ONCE.  A record whose first tap is pixel
+// (i0, j0) touches (i0 + di, j0 + dj), di, dj in {0, 1} (a tap clamped at the border falls back on the first
+// row / column).  Pass 1 (one half-wave per KEY pixel) walks that pixel's list in sorted order and keeps four
+// sums, one per offset (di, dj); pass 2 adds, for every pixel, the four sums that land on it -- in the fixed
+// order (i-1, j-1), (i-1, j), (i, j-1), (i, j): deterministic.  (The earlier one-pass gather walked the lists
+// of the four neighbours from every pixel: each 560-byte record read four times, 7 GB per C3 step.)
+// Lane hl owns channels 4 hl .. 4 hl + 3 and depth bin hl.
 struct LiftGatherArgs {
   SnapLiftDesc d;
-  const unsigned* keys;      // sorted
   const unsigned* vals;      // record slot of every sorted entry
   const unsigned* start;     // [npix + 1] exclusive prefix of the per-key counts
   const float* rec_vec;
   const float* rec_hdr;
+  float* taps;               // [npix][4 offsets][C]
   float* df;
   unsigned npix;
 };
 
-__global__ __launch_bounds__(256) void lift_pool_bwd_gather_kernel(const LiftGatherArgs a) {
+__global__ __launch_bounds__(256) void lift_pool_bwd_taps_kernel(const LiftGatherArgs a) {
   const SnapLiftDesc& d = a.d;
   const int hl = threadIdx.x & 31;
   const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (p >= (int64_t)a.npix) return;
   const int fd = d.feature_dim;
-  const int hw = d.h * d.w;
-  const int64_t img = p / hw;
-  const int rem = (int)(p - img * hw);
-  const int i = rem / d.w, j = rem - i * d.w;
-  const bool lane_on = 4 * hl < fd;             // lane hl owns channels 4 hl .. 4 hl + 3 and bin hl
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  float accb = 0.f;
-  // one record: its header (broadcast), the weight of its taps on (i, j), its vector
-  auto weight = [&](const f32x4& w, int ip, int jp) {
-    const int i0 = ip & 0xffff, i1 = ip >> 16, j0 = jp & 0xffff, j1 = jp >> 16;
-    float wt = 0.f;                              // taps 00, 01, 10, 11 that land on (i, j)
-    if (i0 == i && j0 == j) wt += w[0];
-    if (i0 == i && j1 == j) wt += w[1];
-    if (i1 == i && j0 == j) wt += w[2];
-    if (i1 == i && j1 == j) wt += w[3];
-    return wt;
-  };
-  constexpr int U = 4;                           // records in flight (their loads are independent)
-  for (int di = 1; di >= 0; --di)
-    for (int dj = 1; dj >= 0; --dj) {
-      const int bi = i - di, bj = j - dj;
-      if (bi < 0 || bj < 0) continue;
-      const unsigned key = (unsigned)(img * hw + (int64_t)bi * d.w + bj);
-      const unsigned k0 = a.start[key], k1 = a.start[key + 1];
-      for (unsigned k = k0; k < k1; k += U) {
-        unsigned rid[U];
-        f32x4 w[U], g[U], v[U];
-        float jp[U];
+  const bool lane_on = 4 * hl < fd;
+  f32x4 acc[4];
+  float accb[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rid[u] = a.vals[min(k + u, k1 - 1)];
+  for (int s = 0; s < 4; ++s) { acc[s] = f32x4{0.f, 0.f, 0.f, 0.f}; accb[s] = 0.f; }
+  // the record slots of up to 32 entries by one coalesced load (lane = entry, handed round by shuffles),
+  // U records in flight
+  constexpr int U = 8;
+  const unsigned k0 = a.start[p], k1 = a.start[p + 1];
+  for (unsigned base = k0; base < k1; base += 32) {
+    const unsigned slot = a.vals[min(base + (unsigned)hl, k1 - 1u)];
+    const unsigned nb = min(32u, k1 - base);
+    for (unsigned b0 = 0; b0 < nb; b0 += U) {
+      f32x4 w[U], g[U], v[U];
+      float jp[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float* h = a.rec_hdr + (int64_t)rid[u] * 12;
-          w[u] = reinterpret_cast<const f32x4*>(h)[0];
-          g[u] = reinterpret_cast<const f32x4*>(h)[1];
-          jp[u] = h[8];
-          v[u] = lane_on ? *reinterpret_cast<const f32x4*>(a.rec_vec + (int64_t)rid[u] * fd + 4 * hl)
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+      for (int u = 0; u < U; ++u) {
+        const unsigned rid = (unsigned)__shfl((int)slot, (int)min(b0 + u, nb - 1u), 32);
+        const float* h = a.rec_hdr + (int64_t)rid * 12;
+        w[u] = reinterpret_cast<const f32x4*>(h)[0];
+        g[u] = reinterpret_cast<const f32x4*>(h)[1];
+        jp[u] = h[8];
+        v[u] = lane_on ? *reinterpret_cast<const f32x4*>(a.rec_vec + (int64_t)rid * fd + 4 * hl)
+                       : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {            // accumulated in list order: deterministic
-          if (k + u >= k1) break;
-          const float wt = weight(w[u], __float_as_int(g[u][3]), __float_as_int(jp[u]));
+      for (int u = 0; u < U; ++u) {              // accumulated in list order: deterministic
+        if (b0 + u >= nb) break;
+        const int ip = __float_as_int(g[u][3]), jq = __float_as_int(jp[u]);
+        const bool ei = (ip >> 16) != (ip & 0xffff), ej = (jq >> 16) != (jq & 0xffff);
+        // taps 00, 01, 10, 11 -> offset (di & ei, dj & ej); weights of taps that share an offset add up
+        float ws[4];
+        ws[0] = ((w[u][0] + (ej ? 0.f : w[u][1])) + (ei ? 0.f : w[u][2])) + ((ei || ej) ? 0.f : w[u][3]);
+        ws[1] = (ej ? w[u][1] : 0.f) + ((ej && !ei) ? w[u][3] : 0.f);
+        ws[2] = (ei ? w[u][2] : 0.f) + ((ei && !ej) ? w[u][3] : 0.f);
+        ws[3] = (ei && ej) ? w[u][3] : 0.f;
+        const int bins = __float_as_int(g[u][2]);
+        const float gb = (hl == (bins & 0xffff) ? g[u][0] : 0.f) + (hl == (bins >> 16) ? g[u][1] : 0.f);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += wt * v[u][e];
-          const int bins = __float_as_int(g[u][2]);
-          if (hl == (bins & 0xffff)) accb += wt * g[u][0];
-          if (hl == (bins >> 16)) accb += wt * g[u][1];
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[s][e] += ws[s] * v[u][e];
+          accb[s] += ws[s] * gb;
         }
       }
     }
-  float* o = a.df + p * d.C;
-  if (lane_on) *reinterpret_cast<f32x4*>(o + 4 * hl) = acc;
-  if (hl < d.num_bins) o[fd + hl] = accb;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float* o = a.taps + (p * 4 + s) * d.C;
+    if (lane_on) *reinterpret_cast<f32x4*>(o + 4 * hl) = acc[s];
+    if (hl < d.num_bins) o[fd + hl] = accb[s];
+  }
+}
+
+__global__ __launch_bounds__(256) void lift_pool_bwd_combine_kernel(const LiftGatherArgs a) {
+  const SnapLiftDesc& d = a.d;
+  const int C4 = d.C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)a.npix * C4) return;
+  const int64_t p = t / C4;
+  const int q = (int)(t - p * C4);
+  const int hw = d.h * d.w;
+  const int rem = (int)(p % hw);
+  const int i = rem / d.w, j = rem - i * d.w;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 3; s >= 0; --s) {
+    const int di = s >> 1, dj = s & 1;
+    if (i - di < 0 || j - dj < 0) continue;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.taps + ((p - (int64_t)di * d.w - dj) * 4 + s) * d.C + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+  }
+  *reinterpret_cast<f32x4*>(a.df + p * d.C + 4 * q) = acc;
 }
 
 // ------------------------------- vertical pool --------------------------------
@@ -963,7 +987,7 @@ extern "C" int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_i
 namespace {
 struct LiftDetLayout {
   size_t slots, npix;
-  size_t off_vec, off_hdr, off_keys, off_keys_out, off_vals_out, off_count, off_start, off_tmp;
+  size_t off_vec, off_hdr, off_keys, off_keys_out, off_vals_out, off_count, off_start, off_taps, off_tmp;
   size_t tmp_bytes, total;
   int bits;
 };
@@ -992,6 +1016,7 @@ inline int lift_det_layout(const SnapLiftDesc& d, LiftDetLayout* L, bool with_ve
   L->off_vals_out = o;  o += align256(L->slots * sizeof(unsigned));
   L->off_count = o;     o += align256((L->npix + 2) * sizeof(unsigned));
   L->off_start = o;     o += align256((L->npix + 2) * sizeof(unsigned));
+  L->off_taps = o;      o += align256(L->npix * 4 * d.C * sizeof(float));
   L->off_tmp = o;       o += align256(L->tmp_bytes);
   L->total = o;
   return SNAP_OK;
@@ -1071,9 +1096,13 @@ extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float*
   if (rocprim::exclusive_scan(ws + L.off_tmp, tmp, a.count, start, 0u, L.npix + 2, rocprim::plus<unsigned>(), s) !=
       hipSuccess)
     return SNAP_ERR_LAUNCH;
-  // 3. gather: every pixel of df_images written exactly once
-  LiftGatherArgs g{d, keys_out, vals_out, start, a.rec_vec, a.rec_hdr, df_images, (unsigned)L.npix};
-  hipLaunchKernelGGL(lift_pool_bwd_gather_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
+  // 3. per-key sums by tap offset, then the four that land on every pixel: df_images written exactly once
+  LiftGatherArgs g{d, vals_out, start, a.rec_vec, a.rec_hdr, reinterpret_cast<float*>(ws + L.off_taps), df_images,
+                   (unsigned)L.npix};
+  hipLaunchKernelGGL(lift_pool_bwd_taps_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lift_pool_bwd_combine_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix * (d.C / 4), 256)),
+                     dim3(256), 0, s, g);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
@@ -1154,8 +1183,13 @@ extern "C" int snap_lift_observations_bwd_f32(const SnapLiftDesc* desc, const fl
   if (rocprim::exclusive_scan(ws + L.off_tmp, tmp, a.count, start, 0u, L.npix + 2, rocprim::plus<unsigned>(), s) !=
       hipSuccess)
     return SNAP_ERR_LAUNCH;
-  LiftGatherArgs g{dd, keys_out, vals_out, start, dobs, a.rec_hdr, df_images, (unsigned)L.npix};
-  hipLaunchKernelGGL(lift_pool_bwd_gather_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
+  (void)keys_out;
+  LiftGatherArgs g{dd, vals_out, start, dobs, a.rec_hdr, reinterpret_cast<float*>(ws + L.off_taps), df_images,
+                   (unsigned)L.npix};
+  hipLaunchKernelGGL(lift_pool_bwd_taps_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lift_pool_bwd_combine_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix * (dd.C / 4), 256)),
+                     dim3(256), 0, s, g);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -535,10 +535,14 @@ inline TileChoice choose_tile(int64_t M, int64_t N, int forced, int64_t K) {
   if (forced == 128128 || (!forced && n_wide_ok && snap_cdiv(M, 128) * snap_cdiv(N, 128) >= kMin))
     return {128, 128};
   if (!forced && n_wide_ok && K >= 2304 && M >= 128) return {128, 128};
+  // deep 1 x 1 reductions: a row's K operands are fetched / normalised / split once per COLUMN tile, so the
+  // 128-wide tile halves that work per MFMA (tools/conv_tile_sweep.py: 2048 -> 512 @ 40 x 17 x 17 119 -> 100 us,
+  // 1024 -> 256 @ 8 x 34 x 34 42.7 -> 33.3 us on one workgroup per CU)
+  const int64_t t64128 = snap_cdiv(M, 64) * snap_cdiv(N, 128);
+  if (!forced && n_wide_ok && N >= 512 && K >= 1024 && t64128 >= kMin) return {64, 128};
   if (forced == 128064 || (!forced && snap_cdiv(M, 128) * snap_cdiv(N, 64) >= kMin)) return {128, 64};
-  if (forced == 64128 ||
-      (!forced && n_wide_ok && N >= 512 && snap_cdiv(M, 64) * snap_cdiv(N, 128) >= kMin))
-    return {64, 128};
+  if (forced == 64128 || (!forced && n_wide_ok && N >= 512 && t64128 >= kMin)) return {64, 128};
+  if (!forced && n_wide_ok && K >= 1024 && t64128 >= 256) return {64, 128};
   return {64, 64};   // (forced == 64064 included)
 }
 

@@ -222,6 +222,8 @@ __global__ __launch_bounds__(256) void gn_finalize_tiled_kernel(
   const int live = tile_rows < 0 ? S
                    : (int)((((int64_t)(n + 1) * HW - 1) / tile_rows) - (((int64_t)n * HW) / tile_rows)) + 1;
   const int count = live * cpg;
+  // (gamma travels with the partial sums instead of after the barrier: one round trip less per launch)
+  const float gam = (int)threadIdx.x < cpg ? gamma[c_lo + threadIdx.x] : 0.f;
   double t1 = 0.0, t2 = 0.0;
   // four entries in flight per thread (the weights-stationary conv kernel emits 32-row slabs: up to
   // ~4600 entries per (image, group)); the order of the sum per thread is unchanged
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256) void gn_finalize_tiled_kernel(
   const float rstd = 1.0f / sqrtf(snap_relu(var) + eps);
   for (int cc = threadIdx.x; cc < cpg; cc += 256) {
     mu[(int64_t)n * C + c_lo + cc] = meanf;
-    sc[(int64_t)n * C + c_lo + cc] = rstd * gamma[c_lo + cc];
+    sc[(int64_t)n * C + c_lo + cc] = rstd * (cc < 256 ? gam : gamma[c_lo + cc]);
     if (rstd_out) rstd_out[(int64_t)n * C + c_lo + cc] = rstd;
   }
 }

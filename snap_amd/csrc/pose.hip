@@ -1745,7 +1745,10 @@ extern "C" int snap_ransac_sample_sim_f32(const float* fq, const float* fm,
     const int NC = (X * Y + SIM_CH - 1) / SIM_CH;
     // (without a workspace: the table-free kernel, one correspondence per wave, same samples)
     if (lane_incl && sim && row_unscale && (NC + 63) / 64 <= 64) {
-      constexpr int NQ = 4;
+#ifndef SNAP_RANSAC_NQ
+#define SNAP_RANSAC_NQ 4
+#endif
+      constexpr int NQ = SNAP_RANSAC_NQ;
       const dim3 fgrid((unsigned)snap_cdiv(S, 4 * NQ), (unsigned)B);
       hipLaunchKernelGGL(ransac_sample_fast_kernel<NQ>, fgrid, dim3(256), 0, s, chunk_stats, Nq, X, Y, S,
                          seed, uniforms, corr, (const float*)lane_incl, (const float*)rowmax, row_cdf,
