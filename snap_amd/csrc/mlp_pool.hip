@@ -502,6 +502,15 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   // (snap_max_nan: a NaN of an observed voxel makes the column's maximum NaN, as jnp.max does
   //  (bev_mapper.py:63-78) -- the same in vertical_pool_kernel; the canonical positive NaN wins the
   //  integer atomic max below.  The MLP's ReLUs propagate it too (snap_relu).)
+  // the thread's 64 values first (the accumulators are dead: 64 free registers): read inside the
+  // loop, every ds_read sat behind the row's scalar branch and was waited for at once -- 64 dependent
+  // LDS round trips (~3.4 us of a tile's ~18)
+  float vals[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int row = 64 * h + r;
+    vals[r] = smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))];
+  }
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
     const int cr = __builtin_amdgcn_readlane(cid, r);
@@ -510,8 +519,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
       cur = cr;
       run = -INFINITY;
     }
-    const int row = 64 * h + r;
-    run = snap_max_nan(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
+    run = snap_max_nan(run, vals[r]);
   }
   if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
 }
@@ -788,6 +796,12 @@ __global__ __launch_bounds__(256, 1) void mlp2_pool_wide_kernel(const MlpPoolArg
   for (int q = 0; q < 2; ++q) {
     const int my = m0 + 128 * h + 64 * q + lane;
     const int cid = my < Meff ? a.rows[my] / a.Z : -1;
+    float vals[64];                          // (read ahead of the branches, as in the 128-row kernel)
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const int row = 128 * h + 64 * q + r;
+      vals[r] = smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))];
+    }
 #pragma unroll
     for (int r = 0; r < 64; ++r) {
       const int cr = __builtin_amdgcn_readlane(cid, r);
@@ -796,8 +810,7 @@ __global__ __launch_bounds__(256, 1) void mlp2_pool_wide_kernel(const MlpPoolArg
         cur = cr;
         run = -INFINITY;
       }
-      const int row = 128 * h + 64 * q + r;
-      run = snap_max_nan(run, smem[row * N1 + ((((c >> 2) ^ (row & 31)) << 2) | (c & 3))]);
+      run = snap_max_nan(run, vals[r]);
     }
   }
   if (cur >= 0 && live) atomic_max_f32(a.plane + (int64_t)cur * a.D + c, run);
