@@ -568,6 +568,15 @@ enum { SNAP_POOL_MAX = 0, SNAP_POOL_SUM = 1, SNAP_POOL_MEAN = 2 };
 int snap_vertical_pool_f32(const float* vol, const uint8_t* vvalid, float* plane,
                            uint8_t* pvalid, int64_t M, int32_t Z, int32_t D,
                            int32_t pooling, void* stream);
+/* The max pooling above (Z <= 64, D <= 128) that also records, per (column, channel), the level of the
+ * maximum -- the first of equal ones, found with the comparisons of the VJP (`>` then `==` over the
+ * valid levels in ascending order, a NaN never wins) -- and how many levels hold it (saturating at
+ * 255): argz [M, D], ties [M, D] bytes (255 / 0 for a column without a valid level).  What
+ * snap_vertical_pool_max_bwd_arg_f32 reads instead of the volume (VerticalPooling('max') in a
+ * training step: snap/models/bev_mapper.py:56-88). */
+int snap_vertical_pool_max_arg_f32(const float* vol, const uint8_t* vvalid, float* plane,
+                                   uint8_t* pvalid, uint8_t* argz, uint8_t* ties, int64_t M,
+                                   int32_t Z, int32_t D, void* stream);
 
 /* Fuse `num_planes` modality planes (planes[i] [M,D], valids[i] [M] or NULL=all
  * valid) with masked max/sum/mean, then matching head: Dense(D->Dm)+bias, L2
@@ -999,6 +1008,13 @@ int snap_lift_observations_bwd_f32(const SnapLiftDesc* desc, const float* cam, c
 int snap_vertical_pool_bwd_f32(const float* vol, const uint8_t* vvalid, const float* dplane,
                                float* dvol, int64_t M, int32_t Z, int32_t D, int32_t pooling,
                                void* stream);
+/* The same VJP for pooling = max from the forward's record (snap_vertical_pool_max_arg_f32): dvol
+ * [M, Z, D] is written once and the volume is read only for channels whose maximum is shared by
+ * several levels (ties > 1: the gradient is divided between them, as jnp.max's VJP does).  Same
+ * values as snap_vertical_pool_bwd_f32, bit for bit. */
+int snap_vertical_pool_max_bwd_arg_f32(const float* vol, const uint8_t* vvalid, const uint8_t* argz,
+                                       const uint8_t* ties, const float* dplane, float* dvol,
+                                       int64_t M, int32_t Z, int32_t D, void* stream);
 /* VJP of snap_plane_fuse_match_f32: dplanes[i][M,D] and dy[M,Dm] (gradient w.r.t. the
  * Dense output, for the kernel / bias gradients via wgrad / colsum). */
 int snap_plane_fuse_match_bwd_f32(const float* const* planes, const uint8_t* const* valids,

@@ -173,6 +173,9 @@ SIGNATURES = {
     'snap_vertical_pool_f32': (
         c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, c_int, ptr]
     ),
+    'snap_vertical_pool_max_arg_f32': (
+        c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_int, c_int, ptr]
+    ),
     'snap_plane_fuse_match_f32': (
         c_int,
         [ptr, ptr, c_int, c_i64, c_int, c_int, ptr, ptr, ptr, ptr, c_int, c_int,
@@ -299,6 +302,9 @@ SIGNATURES = {
     'snap_vertical_pool_bwd_f32': (
         c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_int, c_int, ptr]
     ),
+    'snap_vertical_pool_max_bwd_arg_f32': (
+        c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, c_int, c_int, ptr]
+    ),
     'snap_plane_fuse_match_bwd_f32': (
         c_int,
         [ptr, ptr, ptr, c_int, c_i64, c_int, c_int, ptr, ptr, c_int, c_int, c_float, ptr, ptr,
@@ -320,7 +326,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 

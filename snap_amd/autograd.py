@@ -736,16 +736,19 @@ class _VerticalPool(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, vol, valid, pooling):
-    plane, pvalid = ops.vertical_pool(vol, valid, pooling)
+    # (max: the kernel also records where every maximum sits; the VJP then writes dvol without reading vol)
+    plane, pvalid, arg = ops.vertical_pool(vol, valid, pooling, want_arg=True)
     ctx.pooling = pooling
-    ctx.save_for_backward(vol, valid)
+    ctx.has_arg = arg is not None
+    ctx.save_for_backward(vol, valid, *(arg or ()))
     ctx.mark_non_differentiable(pvalid)
     return plane, pvalid
 
   @staticmethod
   def backward(ctx, dplane, _dv):
-    vol, valid = ctx.saved_tensors
-    return ops_bwd.vertical_pool_bwd(vol, valid, dplane.contiguous(), ctx.pooling), None, None
+    vol, valid, *arg = ctx.saved_tensors
+    return ops_bwd.vertical_pool_bwd(vol, valid, dplane.contiguous(), ctx.pooling,
+                                     arg=tuple(arg) if ctx.has_arg else None), None, None
 
 
 def vertical_pool(vol, valid, pooling='max'):

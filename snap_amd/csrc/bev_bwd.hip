@@ -819,6 +819,61 @@ __global__ __launch_bounds__(256) void vertical_pool_bwd_kernel(
   }
 }
 
+// Max pooling with the forward's record of where the maximum sits (snap_vertical_pool_max_arg_f32): a level
+// receives the gradient iff it is the recorded one -- the volume is not read at all (2 x 2 GB per C3 step in
+// the kernel above).  Channels whose maximum is held by several levels (ties > 1: the gradient is shared, as
+// jnp.max's VJP does) take the two passes of the kernel above for their quad: the same values, bit for bit.
+__global__ __launch_bounds__(256) void vertical_pool_max_bwd_arg_kernel(
+    const float* __restrict__ vol, const uint8_t* __restrict__ vvalid, const uint8_t* __restrict__ argz,
+    const uint8_t* __restrict__ ties, const float* __restrict__ dplane, float* __restrict__ dvol, int64_t M,
+    int Z, int D) {
+  const int hl = threadIdx.x & 31;
+  const int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (m >= M) return;
+  const int nq = D >> 2;
+  const uint8_t* vv = vvalid + m * Z;
+  const float* base = vol + m * Z * D;
+  float* dbase = dvol + m * Z * D;
+  for (int q = hl; q < nq; q += 32) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dplane + m * D + 4 * q);
+    const unsigned pa = *reinterpret_cast<const unsigned*>(argz + m * D + 4 * q);
+    const unsigned pc = *reinterpret_cast<const unsigned*>(ties + m * D + 4 * q);
+    const bool shared = ((pc >> 0) & 255) > 1 || ((pc >> 8) & 255) > 1 || ((pc >> 16) & 255) > 1 || (pc >> 24) > 1;
+    if (!shared) {
+      for (int z = 0; z < Z; ++z) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (vv[z]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = (((pc >> (8 * e)) & 255) == 1 && (int)((pa >> (8 * e)) & 255) == z) ? g[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dbase + (int64_t)z * D + 4 * q) = o;
+      }
+      continue;
+    }
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 cnt = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < Z; ++z) {
+      if (!vv[z]) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)z * D + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (v[e] > best[e]) { best[e] = v[e]; cnt[e] = 1.f; }
+        else if (v[e] == best[e]) cnt[e] += 1.f;
+      }
+    }
+    for (int z = 0; z < Z; ++z) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (vv[z]) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)z * D + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[e] == best[e]) ? g[e] / cnt[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dbase + (int64_t)z * D + 4 * q) = o;
+    }
+  }
+}
+
 // ------------------------------- fuse + matching --------------------------------
 struct FuseBwdArgs {
   const float* planes[4];
@@ -1190,6 +1245,17 @@ extern "C" int snap_lift_observations_bwd_f32(const SnapLiftDesc* desc, const fl
   SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(lift_pool_bwd_combine_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix * (dd.C / 4), 256)),
                      dim3(256), 0, s, g);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_vertical_pool_max_bwd_arg_f32(const float* vol, const uint8_t* vvalid, const uint8_t* argz,
+                                                  const uint8_t* ties, const float* dplane, float* dvol,
+                                                  int64_t M, int32_t Z, int32_t D, void* stream) {
+  if (!vol || !vvalid || !argz || !ties || !dplane || !dvol) return SNAP_ERR_NULL;
+  if (M <= 0 || Z <= 0 || Z > 255 || D <= 0 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(vertical_pool_max_bwd_arg_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), vol, vvalid, argz, ties, dplane, dvol, M, Z, D);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

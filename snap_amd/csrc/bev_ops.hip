@@ -125,6 +125,72 @@ __global__ __launch_bounds__(256) void vertical_pool_wave_kernel(
   if (lane == 0) pvalid[m] = any ? 1 : 0;
 }
 
+// Max pooling of a training step (Z <= 64, D <= 128: one channel quad per lane): the plane of the kernel
+// above, bit for bit, plus the level of every maximum (first of equals) and the number of levels that
+// hold it -- what the VJP needs instead of a pass over the volume (vertical_pool_max_bwd_arg_kernel).
+// The tracked maximum follows that VJP's comparisons (`>` then `==` over the valid levels in ascending
+// order: a NaN never wins), not snap_max_nan; count << 8 | level travel in one register.
+__global__ __launch_bounds__(256) void vertical_pool_max_arg_kernel(
+    const float* __restrict__ vol, const uint8_t* __restrict__ vvalid, float* __restrict__ plane,
+    uint8_t* __restrict__ pvalid, uint8_t* __restrict__ argz, uint8_t* __restrict__ ties, int64_t M, int Z,
+    int D) {
+  const int lane = threadIdx.x & 63;
+  const int hl = lane & 31, half = lane >> 5;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const bool on = 4 * hl < D;
+  unsigned long long mask = __ballot(lane < Z && vvalid[m * Z + lane] != 0);
+  const bool any = mask != 0;
+  const float* base = vol + m * Z * D + 4 * (on ? hl : 0);
+  f32x4 acc = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, tb = acc;
+  int tk[4] = {255, 255, 255, 255};
+#pragma unroll 1
+  while (mask) {
+    int z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      z[k] = mask ? (int)__builtin_ctzll(mask) : -1;
+      mask &= mask - 1;
+    }
+    const int za = half ? z[1] : z[0], zb = half ? z[3] : z[2];
+    f32x4 va = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, vb = va;
+    if (za >= 0) va = *reinterpret_cast<const f32x4*>(base + (int64_t)za * D);
+    if (zb >= 0) vb = *reinterpret_cast<const f32x4*>(base + (int64_t)zb * D);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] = snap_max_nan(snap_max_nan(acc[e], va[e]), vb[e]);
+      if (za >= 0) {
+        tk[e] = va[e] > tb[e] ? (256 | za) : (va[e] == tb[e] ? tk[e] + 256 : tk[e]);
+        tb[e] = va[e] > tb[e] ? va[e] : tb[e];
+      }
+      if (zb >= 0) {
+        tk[e] = vb[e] > tb[e] ? (256 | zb) : (vb[e] == tb[e] ? tk[e] + 256 : tk[e]);
+        tb[e] = vb[e] > tb[e] ? vb[e] : tb[e];
+      }
+    }
+  }
+  unsigned pa = 0, pc = 0;
+  f32x4 o = acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = snap_max_nan(o[e], __shfl_xor(o[e], 32));
+    const float ob = __shfl_xor(tb[e], 32);
+    const int ok = __shfl_xor(tk[e], 32);
+    int a_ = tk[e] & 255, c_ = tk[e] >> 8;
+    if (ob > tb[e]) { a_ = ok & 255; c_ = ok >> 8; }
+    else if (ob == tb[e]) { a_ = min(a_, ok & 255); c_ += ok >> 8; }
+    pa |= (unsigned)(a_ & 255) << (8 * e);
+    pc |= (unsigned)min(c_, 255) << (8 * e);
+  }
+  if (on && half == 0) {
+    if (!any) o = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(plane + m * D + 4 * hl) = o;
+    *reinterpret_cast<unsigned*>(argz + m * D + 4 * hl) = pa;
+    *reinterpret_cast<unsigned*>(ties + m * D + 4 * hl) = pc;
+  }
+  if (lane == 0) pvalid[m] = any ? 1 : 0;
+}
+
 struct FuseArgs {
   const float* planes[4];
   const uint8_t* valids[4];
@@ -224,6 +290,18 @@ extern "C" int snap_vertical_pool_f32(const float* vol, const uint8_t* vvalid, f
                        static_cast<hipStream_t>(stream), vol, vvalid, plane, pvalid, M, Z, D,
                        pooling);
   }
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_vertical_pool_max_arg_f32(const float* vol, const uint8_t* vvalid, float* plane,
+                                              uint8_t* pvalid, uint8_t* argz, uint8_t* ties, int64_t M,
+                                              int32_t Z, int32_t D, void* stream) {
+  if (!vol || !vvalid || !plane || !pvalid || !argz || !ties) return SNAP_ERR_NULL;
+  if (M <= 0 || Z <= 0 || D <= 0 || D % 4 != 0) return SNAP_ERR_BAD_SHAPE;
+  if (Z > 64 || D > 128) return SNAP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(vertical_pool_max_arg_kernel, dim3((unsigned)snap_cdiv(M, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), vol, vvalid, plane, pvalid, argz, ties, M, Z, D);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

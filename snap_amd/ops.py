@@ -1375,8 +1375,10 @@ def project_points(cam, Rt, points, fisheye):
 # ----------------------------------------------------------------------------
 # BEV
 # ----------------------------------------------------------------------------
-def vertical_pool(vol, valid, pooling='max'):
-  """vol [..., Z, D], valid [..., Z] -> plane [..., D], pvalid [...]."""
+def vertical_pool(vol, valid, pooling='max', want_arg=False):
+  """vol [..., Z, D], valid [..., Z] -> plane [..., D], pvalid [...].  want_arg (max pooling, Z <= 64, D <= 128):
+  also (argz, ties) [..., D] uint8 -- the level of every maximum and how many levels hold it, which
+  ``ops_bwd.vertical_pool_bwd(arg=...)`` reads instead of the volume; None where not available."""
   lib = _lib.load()
   _f32(vol, 'vol'); _mask(valid, 'valid')
   lead = vol.shape[:-2]
@@ -1384,6 +1386,16 @@ def vertical_pool(vol, valid, pooling='max'):
   M = int(np.prod(lead))
   plane = torch.empty((*lead, D), dtype=torch.float32, device=vol.device)
   pvalid = torch.empty(lead, dtype=torch.bool, device=vol.device)
+  if want_arg:
+    if pooling != 'max' or Z > 64 or D > 128:
+      return (*vertical_pool(vol, valid, pooling), None)
+    argz = torch.empty((*lead, D), dtype=torch.uint8, device=vol.device)
+    ties = torch.empty((*lead, D), dtype=torch.uint8, device=vol.device)
+    with _region('vertical_pool', 0.0, 4.0 * (vol.numel() + plane.numel()) + valid.numel()):
+      st = lib.snap_vertical_pool_max_arg_f32(_p(vol), _p(valid), _p(plane), _p(pvalid), _p(argz), _p(ties),
+                                              M, Z, D, _stream())
+    _lib.check(st, 'snap_vertical_pool_max_arg_f32')
+    return plane, pvalid, (argz, ties)
   with _region('vertical_pool', 0.0, 4.0 * (vol.numel() + plane.numel()) + valid.numel()):
     st = lib.snap_vertical_pool_f32(
         _p(vol), _p(valid), _p(plane), _p(pvalid), M, Z, D, POOLING[pooling], _stream()

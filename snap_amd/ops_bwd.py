@@ -411,15 +411,29 @@ def lift_observations_bwd(dobs, f_shape, cam, Rt, points, *, K, fisheye, feature
   return df
 
 
-def vertical_pool_bwd(vol, valid, dplane, pooling='max'):
+def vertical_pool_bwd(vol, valid, dplane, pooling='max', arg=None):
+  """arg = (argz, ties) of ``ops.vertical_pool(want_arg=True)``: max pooling without a pass over vol."""
   lib = _lib.load()
   _f32(vol, 'vol'); _mask(valid, 'valid'); _f32(dplane, 'dplane')
   Z, D = vol.shape[-2:]
   M = vol.numel() // (Z * D)
   dvol = torch.empty_like(vol)
-  st = lib.snap_vertical_pool_bwd_f32(
-      _p(vol), _p(valid), _p(dplane), _p(dvol), M, Z, D, POOLING[pooling], _stream()
-  )
+  if arg is not None:
+    if pooling != 'max':
+      raise ValueError('vertical_pool_bwd: arg goes with max pooling')
+    argz, ties = arg
+    ops._chk(argz, torch.uint8, 'argz'); ops._chk(ties, torch.uint8, 'ties')
+    if argz.numel() != M * D or ties.numel() != M * D:
+      raise ValueError('vertical_pool_bwd: argz / ties must be [..., D]')
+    with _region('vertical_pool_bwd', 0.0, 4.0 * dvol.numel()):
+      st = lib.snap_vertical_pool_max_bwd_arg_f32(_p(vol), _p(valid), _p(argz), _p(ties), _p(dplane), _p(dvol),
+                                                  M, Z, D, _stream())
+    _lib.check(st, 'snap_vertical_pool_max_bwd_arg_f32')
+    return dvol
+  with _region('vertical_pool_bwd', 0.0, 12.0 * dvol.numel()):
+    st = lib.snap_vertical_pool_bwd_f32(
+        _p(vol), _p(valid), _p(dplane), _p(dvol), M, Z, D, POOLING[pooling], _stream()
+    )
   _lib.check(st, 'snap_vertical_pool_bwd_f32')
   return dvol
 

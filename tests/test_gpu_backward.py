@@ -701,6 +701,40 @@ def test_vertical_pool_bwd(pooling):
   helpers.report('vpool bwd ' + pooling, got, vd.grad.float(), atol=1e-6)
 
 
+@pytest.mark.parametrize('Z,D,ties', [(7, 32, False), (60, 128, False), (64, 64, True), (12, 128, True)])
+def test_vertical_pool_max_bwd_from_the_forward_record(Z, D, ties):
+  """Max pooling in a training step: the forward also records where every maximum sits
+  (snap_vertical_pool_max_arg_f32) and the VJP writes dvol from that record without reading the volume --
+  bit for bit the two-pass kernel, including shared maxima (the gradient is divided), columns without
+  a valid level, -inf and NaN entries."""
+  from snap_amd import autograd as ag
+  g = torch.Generator().manual_seed(700 + Z)
+  vol = torch.randn((3, 5, 4, Z, D), generator=g)
+  if ties:
+    vol = (vol * 2).round() / 2               # many equal maxima
+  vol[0, 1, 2, Z // 2, :8] = float('nan')
+  vol[1, 0, 0, :, 3] = -math.inf
+  valid = torch.rand((3, 5, 4, Z), generator=g) > 0.4
+  valid[0, 0] = False
+  dplane = torch.randn((3, 5, 4, D), generator=g)
+  plane0, pv0 = ops.vertical_pool(G(vol), G(valid), 'max')
+  plane1, pv1, arg = ops.vertical_pool(G(vol), G(valid), 'max', want_arg=True)
+  assert arg is not None
+  assert torch.equal(plane0.view(torch.int32), plane1.view(torch.int32)) and torch.equal(pv0, pv1)
+  want = ops_bwd.vertical_pool_bwd(G(vol), G(valid), G(dplane), 'max')
+  got = ops_bwd.vertical_pool_bwd(G(vol), G(valid), G(dplane), 'max', arg=arg)
+  assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+  if ties:
+    assert int((arg[1] > 1).sum()) > 0          # (the shared-maximum path ran)
+  # and through autograd
+  vg = G(vol).requires_grad_(True)
+  out, _ = ag.vertical_pool(vg, G(valid), 'max')
+  out.backward(G(dplane))
+  assert torch.equal(vg.grad.view(torch.int32), want.view(torch.int32))
+  # other poolings have no record
+  assert ops.vertical_pool(G(vol), G(valid), 'sum', want_arg=True)[2] is None
+
+
 @pytest.mark.parametrize('nplanes', [1, 2])
 def test_plane_fuse_match_bwd(nplanes):
   D, Dm, M = 64, 16, 140
