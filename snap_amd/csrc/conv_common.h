@@ -406,42 +406,67 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(
     float s1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (q < Q && tp < PW) {
-      for (int r = tp; r < 32; r += PW) {
-        const int64_t m = m0 + r;
-        if (m >= M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(partial + m * Cout + col);
+      // RB rows at a time: the loads of a split are issued for all of them before the first is added (a row
+      // at a time, the S partial tiles of its quad were S dependent round trips, times 8-32 rows per thread);
+      // every element still adds its splits in ascending order: the bits of splitk_reduce_kernel
+      constexpr int RB = 8;
+      for (int r0 = tp; r0 < 32; r0 += RB * PW) {
+        f32x4 v[RB];
+        bool ok[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+          const int64_t m = m0 + r0 + k * PW;
+          ok[k] = r0 + k * PW < 32 && m < M;
+          v[k] = *reinterpret_cast<const f32x4*>(partial + (ok[k] ? m : m0) * Cout + col);
+        }
         for (int sp = 1; sp < S; ++sp) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(partial + ((int64_t)sp * M + m) * Cout + col);
+          f32x4 t[RB];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += t[e];
-        }
-        const int64_t o = m * Cout + col;
-        if (epi & SNAP_EPI_BIAS) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col);
+          for (int k = 0; k < RB; ++k)
+            t[k] = *reinterpret_cast<const f32x4*>(partial + ((int64_t)sp * M + (ok[k] ? m0 + r0 + k * PW : m0)) * Cout + col);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bb[e];
+          for (int k = 0; k < RB; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] += t[k][e];
         }
+        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+        if (epi & SNAP_EPI_BIAS) bb = *reinterpret_cast<const f32x4*>(bias + col);
+        f32x4 rr[RB];
         if (epi & SNAP_EPI_RESIDUAL) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(residual + o);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          for (int k = 0; k < RB; ++k)
+            rr[k] = *reinterpret_cast<const f32x4*>(residual + (ok[k] ? m0 + r0 + k * PW : m0) * Cout + col);
         }
-        if (epi & SNAP_EPI_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = snap_relu(v[e]);
-        }
-        if (epi & SNAP_EPI_GELU) {
+        for (int k = 0; k < RB; ++k) {
+          if (!ok[k]) continue;
+          const int64_t m = m0 + r0 + k * PW;
+          const int64_t o = m * Cout + col;
+          if (epi & SNAP_EPI_BIAS) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = snap_gelu_tanh(v[e]);
-        }
-        if ((epi & SNAP_EPI_ROWMASK) && row_mask[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(y + o) = v;
-        const int sl = m >= m_split ? 1 : 0;
+            for (int e = 0; e < 4; ++e) v[k][e] += bb[e];
+          }
+          if (epi & SNAP_EPI_RESIDUAL) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = gn_relu ? snap_relu(v[e]) : v[e];
-          s1[sl][e] += t;
-          s2[sl][e] += t * t;
+            for (int e = 0; e < 4; ++e) v[k][e] += rr[k][e];
+          }
+          if (epi & SNAP_EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] = snap_relu(v[k][e]);
+          }
+          if (epi & SNAP_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] = snap_gelu_tanh(v[k][e]);
+          }
+          if ((epi & SNAP_EPI_ROWMASK) && row_mask[m] == 0) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(y + o) = v[k];
+          const int sl = m >= m_split ? 1 : 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = gn_relu ? snap_relu(v[k][e]) : v[k][e];
+            s1[sl][e] += t;
+            s2[sl][e] += t * t;
+          }
         }
       }
     }
