@@ -483,8 +483,8 @@ int launch(ConvArgs a, hipStream_t s) {
   const int64_t tiles = nrow * a.ncol;
   const int target = splitk_target();
   if (a.kpartial && target > 0 && tiles <= splitk_max_tiles() && a.nk >= 8 && !a.rows_in &&
-      !a.rows_out && !a.row_count && !a.gn_partial && !a.y_half &&
-      !(a.d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) {
+      !a.rows_out && !a.row_count && (!a.gn_partial || (a.gn_rows32 && a.d.Cout_stride == a.d.Cout)) && !a.y_half &&
+      !a.gnb_mode && !(a.d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) {
     int64_t S = (target + tiles - 1) / tiles;
     S = S < a.nk / 4 ? S : a.nk / 4;                        // >= 4 slabs (128 k) per split
     const int64_t fit = (int64_t)(a.kpartial_bytes / ((size_t)a.M * a.d.Cout * sizeof(float)));
@@ -495,6 +495,7 @@ int launch(ConvArgs a, hipStream_t s) {
       nblocks *= a.ksplit;
     }
   }
+  if (a.gn_partial && a.gn_rows32 && a.ksplit == 1) return SNAP_ERR_WORKSPACE;   // (the caller sized for a split-K launch)
   if (a.x_half) {
     if constexpr (PRO == SNAP_PRO_NONE) {
       if (a.gnb_mode) {
@@ -541,13 +542,8 @@ int launch(ConvArgs a, hipStream_t s) {
     }
   }
   SNAP_CHECK_LAUNCH();
-  if (a.ksplit > 1) {
-    const int64_t total4 = (int64_t)a.M * (a.d.Cout / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)snap_cdiv(total4, 256)), dim3(256), 0, s,
-                       (const float*)a.kpartial, a.ksplit, (int64_t)a.M, a.d.Cout, a.d.Cout_stride,
-                       a.d.epilogue, a.bias, a.residual, a.row_mask, a.y);
-    SNAP_CHECK_LAUNCH();
-  }
+  // (the reduce pass also emits the GroupNorm partial sums of a launch that owes them: per 32-row slab)
+  if (a.ksplit > 1) return launch_splitk_reduce(a, s);
   return SNAP_OK;
 }
 

@@ -661,11 +661,12 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
     return SNAP_ERR_UNSUPPORTED;  // row-indexed launches carry bias / ReLU only
   const bool presplit = ex && ex->x_presplit;
   const bool split_vec = ex && ex->w_bf16 && !ex->w_split_root && !rows_in && !rows_out && !row_count;
-  // gn_partial_rows = 32: a split-K launch of the split engine (workspace given), whose reduce pass
-  // emits the sums per 32-row slab
+  // gn_partial_rows = 32: a split-K launch of the split engine or of the bf16 / fp16 engine (workspace
+  // given), whose reduce pass emits the sums per 32-row slab
   const bool rows32 = gn_partial && ex->gn_partial_rows == 32;
   if (gn_partial && ex->gn_partial_rows != 0 && ex->gn_partial_rows != 32) return SNAP_ERR_BAD_SHAPE;
-  if (rows32 && (presplit || !split_vec || ex->w_split_parts < 2 || !ex->workspace || ex->gn_partial2))
+  if (rows32 && (presplit || !split_vec || ex->w_split_parts == 1 || !ex->workspace || ex->gn_partial2 ||
+                 ex->y_half || ex->gnb_mode))
     return SNAP_ERR_UNSUPPORTED;
   const size_t gn_need = !gn_partial ? 0
                          : rows32    ? snap_conv2d_splitk_gn_partial_bytes(desc)

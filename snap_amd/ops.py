@@ -270,7 +270,7 @@ CONV_NO_RS = False      # tools / tests: the tiled body also where a stationary 
 CONV_RS_NSPLIT = 0      # tools: forced column split of the row-stationary kernel (0 = automatic)
 CONV_RS_FORCE = False   # tests: the stationary kernels also below their row-count threshold
 CONV_NO_WS = False      # tools / tests: no weights-stationary kernel (the row-stationary one where it applies)
-SPLITK_STATS = True     # split-K launches of the split engine emit GroupNorm partial sums from their reduce pass
+SPLITK_STATS = True     # split-K launches of the split / bf16 / fp16 engines emit GroupNorm partial sums from their reduce pass
 MLP_POOL_NO_RING = False  # tuning / tests: pre-split rows on the two-stage GEMM0 loop instead of the three-stage ring (x_split = 5)
 MLP_POOL_WIDE = False     # tuning / tests: pre-split rows on the 256-row mlp2_pool kernel (x_split = 3; measured slower, mlp_pool.hip)
 CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
@@ -549,8 +549,9 @@ def conv2d(
     if wbytes:   # small-M / deep-K layer: split K
       kws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes, None, 0)
-      if emit_gn_stats is not None and qparts >= 2 and SPLITK_STATS:
-        # the split engine's reduce pass emits the partial sums (per 32-row slab)
+      half_engine = math in ('bf16', 'fp16') and Cs % 4 == 0 and Cin % 4 == 0 and Cin >= 4 and not ps
+      if emit_gn_stats is not None and (qparts >= 2 or half_engine) and SPLITK_STATS:
+        # the reduce pass of the split / bf16 / fp16 engine emits the partial sums (per 32-row slab)
         pbytes = lib.snap_conv2d_splitk_gn_partial_bytes(ctypes.byref(d))
         if pbytes:
           partial = torch.empty(pbytes // 4, dtype=torch.float32, device=x.device)

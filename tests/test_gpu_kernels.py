@@ -423,10 +423,13 @@ def test_conv_emits_both_groupnorm_statistics(math):
 @pytest.mark.parametrize('shape', [(8, 34, 34, 256, 256, 3), (3, 17, 19, 512, 512, 3), (5, 9, 7, 1024, 256, 1),
                                    (2, 12, 12, 1024, 512, 1)])
 @pytest.mark.parametrize('relu', [False, True])
-def test_split_k_launches_emit_groupnorm_statistics(shape, relu):
+@pytest.mark.parametrize('math', ['bf16x3', 'bf16', 'fp16'])
+def test_split_k_launches_emit_groupnorm_statistics(shape, relu, math):
   """Deep reductions over few rows run split-K; their reduce pass emits the GroupNorm partial sums
   (per 32-row slab: tiles straddling images, ragged last tile, residual) -- the output is bitwise
-  what the launch without statistics writes, the statistics agree with the stand-alone pass."""
+  what the launch without statistics writes, the statistics agree with the stand-alone pass.  The
+  split engine and the training-precision engines (whose forward convolutions in a C3 step took a
+  stand-alone statistics pass after every split-K launch before round 5)."""
   N, H, W, Cin, Cout, k = shape
   x = rnd((N, H, W, Cin), 1200 + Cin)
   w = rnd((k, k, Cin, Cout), 1201 + Cout, 1 / np.sqrt(k * k * Cin))
@@ -436,7 +439,7 @@ def test_split_k_launches_emit_groupnorm_statistics(shape, relu):
   xd = x.to(DEV)
   mu, sc = ops.group_norm_stats(xd, g_in.to(DEV))
   pad = ((k // 2, k // 2), (k // 2, k // 2))
-  kw = dict(padding=pad, prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)), residual=res.to(DEV), math='bf16x3')
+  kw = dict(padding=pad, prologue=ops.PRO_GN_RELU, gn=(mu, sc, b_in.to(DEV)), residual=res.to(DEV), math=math)
   y = ops.conv2d(xd, w.to(DEV), emit_gn_stats='relu' if relu else 'raw', **kw)
   assert getattr(y, '_snap_gn_partial', (None, 0, None))[1] == 32, 'not a split-K launch with fused statistics'
   ops.SPLITK_STATS = False
