@@ -355,7 +355,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   const int64_t m = i / Q;
   const int col = 4 * (int)(i - m * Q);
   f32x4 v = *reinterpret_cast<const f32x4*>(partial + m * Cout + col);
-  for (int s = 1; s < S; ++s) {
+  int s = 1;
+  for (; s + 3 < S; s += 4) {        // four splits in flight (added in ascending order: the same sum)
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      t[u] = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(s + u) * M + m) * Cout + col);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += t[u][e];
+  }
+  for (; s < S; ++s) {
     const f32x4 t = *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * M + m) * Cout + col);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += t[e];
