@@ -273,6 +273,77 @@ __global__ __launch_bounds__(256) void plane_fuse_match_kernel(const FuseArgs a)
   if (j < a.Dm) a.matching[m * a.Dm + j] = any ? y : 0.f;
 }
 
+// The same kernel for D = 128 with a matching head (the bench's planes): the head is a [128] x [128, Dm]
+// product per cell, and in the kernel above every one of its 128 terms costs a lane exchange and an L1
+// load of the kernel entry.  Here a lane keeps ITS column of Wm in registers for all the cells its
+// half-wave visits (a persistent grid), and the cell's fused vector comes back from LDS as 32 broadcast
+// 16-byte reads.  Terms added in the same (ascending channel) order: the same bits.
+__global__ __launch_bounds__(256) void plane_fuse_match_d128_kernel(const FuseArgs a) {
+  __shared__ __attribute__((aligned(16))) float sv[8][128];
+  const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  const int j = hl;
+  float wreg[128];
+#pragma unroll
+  for (int k = 0; k < 128; ++k) wreg[k] = j < a.Dm ? a.Wm[(int64_t)k * a.Dm + j] : 0.f;
+  const float bj = j < a.Dm ? a.bm[j] : 0.f;
+  const float init = a.pooling == SNAP_POOL_MAX ? -INFINITY : 0.f;
+  for (int64_t m = (int64_t)blockIdx.x * 8 + hw; m < a.M; m += (int64_t)gridDim.x * 8) {
+    // every plane's validity byte and row are requested before the first is looked at (one memory round
+    // trip per cell instead of two per plane); a row of an invalid plane is fetched and dropped
+    f32x4 acc = {init, init, init, init};
+    int count = 0;
+    bool pv[4];
+    f32x4 px[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      pv[p] = false;
+      px[p] = acc;
+      if (p < a.num_planes) {
+        pv[p] = a.valids[p] ? (a.valids[p][m] != 0) : true;
+        px[p] = *reinterpret_cast<const f32x4*>(a.planes[p] + m * 128 + 4 * hl);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (!pv[p]) continue;
+      ++count;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc[e] = a.pooling == SNAP_POOL_MAX ? snap_max_nan(acc[e], px[p][e]) : acc[e] + px[p][e];
+    }
+    const bool any = count > 0;
+    if (!any) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (any && a.pooling == SNAP_POOL_MEAN) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] / (float)count;
+    }
+    if (a.fused) *reinterpret_cast<f32x4*>(a.fused + m * 128 + 4 * hl) = acc;
+    if (hl == 0 && a.fvalid) a.fvalid[m] = any ? 1 : 0;
+    *reinterpret_cast<f32x4*>(&sv[hw][4 * hl]) = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float y = bj;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(&sv[hw][4 * q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y += xv[e] * wreg[4 * q + e];
+    }
+    __builtin_amdgcn_wave_barrier();       // (the row is rewritten by the next cell)
+    if (a.normalize) {
+      float ss = (j < a.Dm) ? y * y : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 32);
+      const float nrm = sqrtf(ss);
+      const bool invalid = nrm < a.eps;
+      const float denom = invalid ? sqrtf((float)a.Dm) * a.eps : nrm;
+      y = invalid ? 0.f : y / denom;
+    }
+    if (j < a.Dm) a.matching[m * a.Dm + j] = any ? y : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" int snap_vertical_pool_f32(const float* vol, const uint8_t* vvalid, float* plane,
@@ -328,8 +399,11 @@ extern "C" int snap_plane_fuse_match_f32(const float* const* planes, const uint8
   a.fused = fused; a.fvalid = fvalid;
   a.Wm = Wm; a.bm = bm; a.Dm = Dm; a.normalize = normalize; a.eps = eps;
   a.matching = matching;
-  hipLaunchKernelGGL(plane_fuse_match_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (matching && D == 128 && M >= 8192)
+    hipLaunchKernelGGL(plane_fuse_match_d128_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(plane_fuse_match_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -1083,6 +1083,38 @@ def test_plane_fuse_match(nplanes):
   helpers.report('matching', mg, mw, atol=2e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize('pooling,Dm,normalize', [('max', 32, True), ('mean', 16, True), ('sum', 32, False)])
+def test_plane_fuse_match_persistent_kernel_for_128_channels(pooling, Dm, normalize):
+  """From 8192 cells of 128 channels the fuse + matching-head launch takes the kernel that keeps the head's
+  columns in registers (plane_fuse_match_d128_kernel): against the oracle, and bit for bit what the
+  per-cell kernel gives on the same cells in launches below the threshold (every pooling mode, a
+  plane without validity, cells no plane covers, NaN, a ragged cell count)."""
+  G = lambda t: t.to(DEV).contiguous()
+  D, M = 128, 8192 + 1037
+  planes = [rnd((M, D), 170 + i) for i in range(3)]
+  valids = [torch.rand((M,), generator=torch.Generator().manual_seed(180 + i)) > 0.4 for i in range(3)]
+  planes[1][5, 7] = float('nan')
+  Wm, bm = rnd((D, Dm), 175, 0.1), rnd((Dm,), 176, 0.01)
+  args = ([G(p) for p in planes], [G(v) for v in valids], pooling, G(Wm), G(bm))
+  fg, vg, mg = ops.plane_fuse_match(*args, normalize=normalize)
+  fw, vw, mw = oracle_ops.plane_fuse_match(planes, valids, pooling, Wm, bm) if normalize else (None, None, None)
+  if normalize:
+    ok = ~torch.isnan(fw).any(-1)
+    helpers.report('fuse valid', vg.cpu(), vw, 0)
+    helpers.report('fused', fg.cpu()[ok], fw[ok], atol=1e-6)
+    helpers.report('matching', mg.cpu()[ok], mw[ok], atol=2e-6, rtol=1e-5)
+  for lo in range(0, M, 4096):        # (4096 cells per launch: the per-cell kernel)
+    hi = min(lo + 4096, M)
+    f0, v0, m0 = ops.plane_fuse_match([G(p[lo:hi]) for p in planes], [G(v[lo:hi]) for v in valids], pooling,
+                                      G(Wm), G(bm), normalize=normalize)
+    assert torch.equal(f0.view(torch.int32), fg[lo:hi].view(torch.int32)) and torch.equal(v0, vg[lo:hi])
+    assert torch.equal(m0.view(torch.int32), mg[lo:hi].view(torch.int32))
+  # one plane, no validity
+  f1, v1, m1 = ops.plane_fuse_match([G(planes[0])], [None], pooling, G(Wm), G(bm), normalize=normalize)
+  f2, v2, m2 = ops.plane_fuse_match([G(planes[0][:4096])], [None], pooling, G(Wm), G(bm), normalize=normalize)
+  assert torch.equal(m1[:4096].view(torch.int32), m2.view(torch.int32)) and bool(v1.all())
+
+
 def test_matching_zero_norm():
   D, Dm = 32, 8
   plane = torch.zeros(1, 4, 4, D)
