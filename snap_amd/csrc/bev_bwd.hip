@@ -1010,6 +1010,129 @@ __global__ __launch_bounds__(256) void plane_fuse_match_bwd_kernel(const FuseBwd
   }
 }
 
+// The same VJP for 128-channel planes with a matching head (the training step's planes), as a persistent
+// kernel: in the kernel above each of the 2 x 128 x Dm products of a cell costs a lane exchange and an L1 load
+// of the kernel entry.  Here a lane keeps ITS column of Wm in registers for the forward product, the
+// transposed kernel sits in LDS for d fused = Wm dy (a conflict-free 16-byte read per output channel of dy),
+// and the cell's fused vector / dy come back from LDS as broadcast reads.  Same terms in the same order:
+// the same bits.
+__global__ __launch_bounds__(256) void plane_fuse_match_bwd_d128_kernel(const FuseBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float wt[32][128];      // Wm^T, rows beyond Dm zero
+  __shared__ __attribute__((aligned(16))) float sv[8][128];
+  __shared__ __attribute__((aligned(16))) float sd[8][32];
+  const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  const int j = hl;
+  for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+    const int jj = i >> 7, k = i & 127;
+    wt[jj][k] = jj < a.Dm ? a.Wm[(int64_t)k * a.Dm + jj] : 0.f;
+  }
+  float wreg[128];
+#pragma unroll
+  for (int k = 0; k < 128; ++k) wreg[k] = j < a.Dm ? a.Wm[(int64_t)k * a.Dm + j] : 0.f;
+  const float bj = j < a.Dm ? a.bm[j] : 0.f;
+  __syncthreads();
+  const float init = a.pooling == SNAP_POOL_MAX ? -INFINITY : 0.f;
+  for (int64_t m = (int64_t)blockIdx.x * 8 + hw; m < a.M; m += (int64_t)gridDim.x * 8) {
+    f32x4 fused = {init, init, init, init};
+    f32x4 x[4];
+    bool pv[4];
+    int count = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      pv[p] = false;
+      x[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p < a.num_planes) {
+        pv[p] = a.valids[p] ? (a.valids[p][m] != 0) : true;
+        if (pv[p]) x[p] = *reinterpret_cast<const f32x4*>(a.planes[p] + m * 128 + 4 * hl);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (!pv[p]) continue;
+      ++count;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        fused[e] = a.pooling == SNAP_POOL_MAX ? fmaxf(fused[e], x[p][e]) : fused[e] + x[p][e];
+    }
+    const bool any = count > 0;
+    if (!any) fused = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (any && a.pooling == SNAP_POOL_MEAN) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fused[e] = fused[e] / (float)count;
+    }
+    // ---- matching head backward: dy (lane j) ----------------------------------
+    *reinterpret_cast<f32x4*>(&sv[hw][4 * hl]) = fused;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float y = bj;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(&sv[hw][4 * q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y += xv[e] * wreg[4 * q + e];
+    }
+    float dyj = 0.f;
+    const float dz = (j < a.Dm && any) ? a.dmatching[m * a.Dm + j] : 0.f;
+    if (a.normalize) {
+      const float nrm = sqrtf(half_sum((j < a.Dm) ? y * y : 0.f));
+      if (nrm >= a.eps) {
+        const float z = y / nrm;
+        const float zdz = half_sum((j < a.Dm) ? z * dz : 0.f);
+        dyj = (dz - z * zdz) / nrm;
+      }
+    } else {
+      dyj = dz;
+    }
+    if (j < a.Dm) a.dy[m * a.Dm + j] = dyj;
+    // ---- d fused = Wm dy (+ dfused) and routing to the planes -------------------
+    sd[hw][hl] = dyj;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 df = {0.f, 0.f, 0.f, 0.f};
+    for (int j4 = 0; j4 < a.Dm; j4 += 4) {
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(&sd[hw][j4]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j4 + u >= a.Dm) break;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&wt[j4 + u][4 * hl]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) df[e] += w[e] * dv[u];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();       // (sv / sd are rewritten by the next cell)
+    if (a.dfused && any) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.dfused + m * 128 + 4 * hl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) df[e] += g[e];
+    }
+    f32x4 ties = {0.f, 0.f, 0.f, 0.f};
+    if (a.pooling == SNAP_POOL_MAX) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (pv[p]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ties[e] += (x[p][e] == fused[e]) ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p >= a.num_planes || !a.dplanes[p]) continue;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (pv[p]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (a.pooling == SNAP_POOL_MAX) o[e] = (x[p][e] == fused[e]) ? df[e] / ties[e] : 0.f;
+          else if (a.pooling == SNAP_POOL_SUM) o[e] = df[e];
+          else o[e] = df[e] / (float)count;
+        }
+      }
+      *reinterpret_cast<f32x4*>(a.dplanes[p] + m * 128 + 4 * hl) = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int snap_lift_pool_bwd_f32(const SnapLiftDesc* desc, const float* f_images,
@@ -1295,8 +1418,11 @@ extern "C" int snap_plane_fuse_match_bwd_f32(const float* const* planes,
   a.num_planes = num_planes; a.M = M; a.D = D; a.pooling = pooling;
   a.Wm = Wm; a.bm = bm; a.Dm = Dm; a.normalize = normalize; a.eps = eps;
   a.dmatching = dmatching; a.dfused = dfused; a.dy = dy;
-  hipLaunchKernelGGL(plane_fuse_match_bwd_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (dmatching && D == 128 && M >= 8192)
+    hipLaunchKernelGGL(plane_fuse_match_bwd_d128_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(plane_fuse_match_bwd_kernel, dim3((unsigned)snap_cdiv(M, 8)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -768,6 +768,46 @@ def test_plane_fuse_match_bwd(nplanes):
   helpers.report('dbm', ops_bwd.colsum(dy), bd.grad.float(), atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('pooling,Dm,normalize,with_dfused', [('max', 32, True, False), ('mean', 16, True, True),
+                                                              ('sum', 32, False, True)])
+def test_plane_fuse_match_bwd_persistent_kernel_for_128_channels(pooling, Dm, normalize, with_dfused):
+  """From 8192 cells of 128 channels the VJP takes the persistent kernel (head columns in registers, the
+  transposed head in LDS): bit for bit what the per-cell kernel gives on the same cells in launches below
+  the threshold, and against torch autograd for max pooling."""
+  D, M = 128, 8192 + 517
+  planes = [rnd((M, D), 280 + i) for i in range(3)]
+  valids = [torch.rand(M, generator=torch.Generator().manual_seed(290 + i)) > 0.4 for i in range(3)]
+  valids[2] = None if pooling == 'sum' else valids[2]
+  planes[0][17] = planes[1][17]                 # (a cell whose maximum is shared)
+  Wm, bm = rnd((D, Dm), 285, 0.2), rnd((Dm,), 286, 0.05)
+  dmat = rnd((M, Dm), 287)
+  dfu = rnd((M, D), 288) if with_dfused else None
+  gv = [None if v is None else G(v) for v in valids]
+  dplanes, dy = ops_bwd.plane_fuse_match_bwd([G(p) for p in planes], gv, pooling, G(Wm), G(bm), normalize, 1e-5,
+                                             G(dmat), None if dfu is None else G(dfu))
+  for lo in range(0, M, 4096):
+    hi = min(lo + 4096, M)
+    dp0, dy0 = ops_bwd.plane_fuse_match_bwd([G(p[lo:hi]) for p in planes],
+                                            [None if v is None else G(v[lo:hi]) for v in valids], pooling,
+                                            G(Wm), G(bm), normalize, 1e-5, G(dmat[lo:hi]),
+                                            None if dfu is None else G(dfu[lo:hi]))
+    assert torch.equal(dy0.view(torch.int32), dy[lo:hi].view(torch.int32))
+    for a, b in zip(dp0, dplanes):
+      assert torch.equal(a.view(torch.int32), b[lo:hi].view(torch.int32))
+  if pooling == 'max' and not with_dfused:
+    pd = [p.double().requires_grad_(True) for p in planes]
+    vs = torch.stack([torch.ones(M, dtype=torch.bool) if v is None else v for v in valids], -1)
+    st = torch.stack(pd, -2)
+    anyv = vs.any(-1)
+    fused = torch.where(vs[..., None], st, torch.full_like(st, -math.inf)).amax(-2)
+    fused = torch.where(anyv[:, None], fused, torch.zeros_like(fused))
+    y = fused @ Wm.double() + bm.double()
+    z = y / y.norm(dim=-1, keepdim=True)
+    (z * anyv[:, None]).backward(dmat.double())
+    for i in range(3):
+      helpers.report(f'dplane{i}', dplanes[i], pd[i].grad.float(), atol=3e-5, rtol=1e-4)
+
+
 # -- pose head --------------------------------------------------------------------------------
 @pytest.mark.parametrize('mask_oob', [False, True])
 def test_pose_score_bwd(mask_oob):
