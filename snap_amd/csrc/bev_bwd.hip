@@ -555,6 +555,36 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_batched_kernel(const LiftBw
     const int nvis = __float_as_int(vhdr[v][3]);
     if (gvi < 0 || nvis == 0) continue;                 // pooled == 0 (masked): no gradient, no record
     const int64_t gv = gvi;
+    if (nvis == 1) {
+      // ONE observation (72 % of the observed voxels of a four-view map, every voxel of a query): its pooling
+      // weight is e / e = 1 exactly (the forward takes the same shortcut), so mean = f, the variance term
+      // 2 w (f - mean) dvar vanishes and d f = d mean -- the record's vector IS the row of dpooled: nothing is
+      // gathered from the image and nothing written but the header; bit 31 of the sort key (above the bits the
+      // sort looks at) tells the sum pass to read the vector there -- and d score = w (dw - w dw) + d score_max
+      // = d score_max.
+      if (hl == 0) {
+        const float ds = (a.dpooled + gv * d.out_stride)[2 * fd];
+        const int64_t rid = gv * nsel;
+        const i32x4 q4 = *reinterpret_cast<const i32x4*>(recs[v][0]);
+        const int pk = q4[1];
+        const float wi1 = __int_as_float(q4[2]), wj1 = __int_as_float(q4[3]);
+        const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
+        const int ij = ijs[v][0];
+        const int i0 = ij & 0xffff, j0 = ij >> 16;
+        const int i1 = i0 + ((pk >> 8) & 1), j1 = j0 + ((pk >> 9) & 1);
+        const float wb1 = wbs[v][0];
+        float* h = a.rec_hdr + rid * 12;
+        reinterpret_cast<f32x4*>(h)[0] = f32x4{wi0 * wj0, wi0 * wj1, wi1 * wj0, wi1 * wj1};
+        reinterpret_cast<f32x4*>(h)[1] =
+            f32x4{(1.f - wb1) * ds, wb1 * ds, __int_as_float(((pk >> 10) & 0xff) | (((pk >> 18) & 0xff) << 16)),
+                  __int_as_float(i0 | (i1 << 16))};
+        h[8] = __int_as_float(j0 | (j1 << 16));
+        const unsigned key = (unsigned)q4[0];
+        a.keys[rid] = key | 0x80000000u;
+        atomicAdd(a.count + key, 1u);            // (integer: order-independent)
+      }
+      continue;
+    }
     f32x4 feat[KMAX];
     float score[KMAX], w4[KMAX][4];
 #pragma unroll
@@ -683,8 +713,11 @@ struct LiftGatherArgs {
   SnapLiftDesc d;
   const unsigned* vals;      // record slot of every sorted entry
   const unsigned* start;     // [npix + 1] exclusive prefix of the per-key counts
+  const unsigned* keys;      // sorted keys (bit 31: the record's vector is the row of dpooled)
   const float* rec_vec;
   const float* rec_hdr;
+  const float* dpooled;
+  int nsel;
   float* taps;               // [npix][4 offsets][C]
   float* df;
   unsigned npix;
@@ -707,6 +740,7 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_taps_kernel(const LiftGathe
   const unsigned k0 = a.start[p], k1 = a.start[p + 1];
   for (unsigned base = k0; base < k1; base += 32) {
     const unsigned slot = a.vals[min(base + (unsigned)hl, k1 - 1u)];
+    const unsigned kflag = a.keys[min(base + (unsigned)hl, k1 - 1u)];
     const unsigned nb = min(32u, k1 - base);
     for (unsigned b0 = 0; b0 < nb; b0 += U) {
       f32x4 w[U], g[U], v[U];
@@ -714,12 +748,14 @@ __global__ __launch_bounds__(256) void lift_pool_bwd_taps_kernel(const LiftGathe
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const unsigned rid = (unsigned)__shfl((int)slot, (int)min(b0 + u, nb - 1u), 32);
+        const bool pooled_row = __shfl((int)kflag, (int)min(b0 + u, nb - 1u), 32) < 0;
         const float* h = a.rec_hdr + (int64_t)rid * 12;
         w[u] = reinterpret_cast<const f32x4*>(h)[0];
         g[u] = reinterpret_cast<const f32x4*>(h)[1];
         jp[u] = h[8];
-        v[u] = lane_on ? *reinterpret_cast<const f32x4*>(a.rec_vec + (int64_t)rid * fd + 4 * hl)
-                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* vp = pooled_row ? a.dpooled + (int64_t)(rid / (unsigned)a.nsel) * d.out_stride
+                                     : a.rec_vec + (int64_t)rid * fd;
+        v[u] = lane_on ? *reinterpret_cast<const f32x4*>(vp + 4 * hl) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {              // accumulated in list order: deterministic
@@ -1275,7 +1311,7 @@ extern "C" int snap_lift_pool_bwd_det_f32(const SnapLiftDesc* desc, const float*
       hipSuccess)
     return SNAP_ERR_LAUNCH;
   // 3. per-key sums by tap offset, then the four that land on every pixel: df_images written exactly once
-  LiftGatherArgs g{d, vals_out, start, a.rec_vec, a.rec_hdr, reinterpret_cast<float*>(ws + L.off_taps), df_images,
+  LiftGatherArgs g{d, vals_out, start, keys_out, a.rec_vec, a.rec_hdr, dpooled, nsel, reinterpret_cast<float*>(ws + L.off_taps), df_images,
                    (unsigned)L.npix};
   hipLaunchKernelGGL(lift_pool_bwd_taps_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
   SNAP_CHECK_LAUNCH();
@@ -1361,8 +1397,7 @@ extern "C" int snap_lift_observations_bwd_f32(const SnapLiftDesc* desc, const fl
   if (rocprim::exclusive_scan(ws + L.off_tmp, tmp, a.count, start, 0u, L.npix + 2, rocprim::plus<unsigned>(), s) !=
       hipSuccess)
     return SNAP_ERR_LAUNCH;
-  (void)keys_out;
-  LiftGatherArgs g{dd, vals_out, start, dobs, a.rec_hdr, reinterpret_cast<float*>(ws + L.off_taps), df_images,
+  LiftGatherArgs g{dd, vals_out, start, keys_out, dobs, a.rec_hdr, nullptr, nsel, reinterpret_cast<float*>(ws + L.off_taps), df_images,
                    (unsigned)L.npix};
   hipLaunchKernelGGL(lift_pool_bwd_taps_kernel, dim3((unsigned)snap_cdiv((int64_t)L.npix, 8)), dim3(256), 0, s, g);
   SNAP_CHECK_LAUNCH();
