@@ -2,10 +2,18 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp PYTHONPATH=.
-R=$PWD
-timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_train.py -m gpu -q -x -k "lift or observ or train_step or gradient" 2>&1 | tail -2
-rm -rf gpurun_out/c3prof; mkdir -p gpurun_out/c3prof
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/c3prof" -o c3 -- python "$R/bench.py" --mode train --workload c3 --precision bf16 --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs) > gpurun_out/c3prof.log 2>&1
-cp gpurun_out/c3prof/c3_kernel_stats.csv gpurun_out/c3_kernel_stats.csv
-rm -rf gpurun_out/c3prof
-grep -i "lift_pool_bwd" gpurun_out/c3_kernel_stats.csv | awk -F, '{print substr($1,1,70), $(NF-6), $(NF-5), $(NF-4), "min", $(NF-2), "max", $(NF-1)}'
+run() { timeout 300 python - "$@" <<'PY'
+import sys, json, io, contextlib
+from snap_amd import ops
+mode = sys.argv[1]
+if mode == 'overlap': ops.OVERLAP_AERIAL_TRAIN = True
+import bench
+sys.argv = ['bench.py', '--mode', 'train', '--workload', 'c3', '--precision', 'bf16', '--steps', '8', '--warmup', '3', '--no-cpu-baseline', '--no-extra-legs']
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+  bench.main()
+d = json.loads(buf.getvalue().strip().splitlines()[-1])
+print(mode, d['ms_per_step'], d['step_ms'], 'loss', d.get('loss'), d.get('grad_norm'))
+PY
+}
+run default; run overlap; run default; run overlap
