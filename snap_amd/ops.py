@@ -192,7 +192,14 @@ _HOST_SCALARS = {}
 def prefetch_exp(t):
   if t is None or not t.is_cuda:
     return
-  host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+  # one pinned scalar per temperature tensor, reused apply after apply: a read-back still in
+  # flight into it was consumed by ``host_exp`` -- or is superseded by this one -- once its event has passed
+  prev = _HOST_SCALARS.get(id(t))
+  if prev is not None and prev[0]() is t:
+    host = prev[2]
+    prev[3].synchronize()
+  else:
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
   host.copy_(torch.exp(t.detach().to(torch.float32)).reshape(1), non_blocking=True)
   ev = torch.cuda.Event()
   ev.record()
