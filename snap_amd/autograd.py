@@ -644,9 +644,9 @@ class _LiftPool(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, f_images, cam, Rt, points, cfg):
-    K, fisheye, fd, nb, dmm, mvd, opts = cfg
+    K, fisheye, fd, nb, dmm, mvd, opts, fwd_only = cfg
     pooled, valid = ops.lift_pool(f_images, cam, Rt, points, K=K, fisheye=fisheye, feature_dim=fd,
-                                  num_bins=nb, depth_min_max=dmm, max_view_distance=mvd, **opts)
+                                  num_bins=nb, depth_min_max=dmm, max_view_distance=mvd, **opts, **fwd_only)
     ctx.cfg = cfg
     ctx.save_for_backward(f_images, cam, Rt, points)
     ctx.mark_non_differentiable(valid)
@@ -654,7 +654,7 @@ class _LiftPool(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, dpooled, _dvalid):
-    K, fisheye, fd, nb, dmm, mvd, opts = ctx.cfg
+    K, fisheye, fd, nb, dmm, mvd, opts, _ = ctx.cfg
     f_images, cam, Rt, points = ctx.saved_tensors
     df = ops_bwd.lift_pool_bwd(f_images, cam, Rt, points, dpooled.contiguous(), K=K,
                                fisheye=fisheye, feature_dim=fd, num_bins=nb, depth_min_max=dmm,
@@ -663,10 +663,15 @@ class _LiftPool(torch.autograd.Function):
 
 
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins, depth_min_max,
-              max_view_distance=None, weighted=True, use_variance=True, add_minmax=False):
-  """Differentiable ``ops.lift_pool`` (every option of pool_multiview_features)."""
+              max_view_distance=None, weighted=True, use_variance=True, add_minmax=False,
+              grid_yz=None, valid_rows_only=False):
+  """Differentiable ``ops.lift_pool`` (every option of pool_multiview_features).  ``grid_yz`` (the forward's
+  traversal hint) and ``valid_rows_only`` (rows of voxels no view sees stay unwritten: for a consumer that
+  reads the rows of valid voxels only, such as the masked fusion MLP) as in ``ops.lift_pool``; the VJP treats
+  the gradient rows of unobserved voxels as zero either way."""
   opts = dict(weighted=bool(weighted), use_variance=bool(use_variance), add_minmax=bool(add_minmax))
-  cfg = (K, fisheye, feature_dim, num_bins, tuple(depth_min_max), max_view_distance, opts)
+  fwd_only = dict(grid_yz=None if grid_yz is None else tuple(grid_yz), valid_rows_only=bool(valid_rows_only))
+  cfg = (K, fisheye, feature_dim, num_bins, tuple(depth_min_max), max_view_distance, opts, fwd_only)
   return _LiftPool.apply(f_images, cam, Rt, points, cfg)
 
 

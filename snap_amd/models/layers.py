@@ -62,6 +62,14 @@ class MLP(base.Module):
   # Below this many rows the three tiny compaction launches cost more than they save.
   COMPACT_MIN_ROWS = 1 << 16
 
+  def reads_listed_rows_only(self, params, n_rows):
+    """True when ``__call__(params, x, row_mask=mask)`` with ``n_rows`` rows never touches a row of ``x`` whose mask
+    is False -- forward or backward (the compacted-row paths above; the dense fallback multiplies every row, and
+    its kernel gradient would pick up whatever sits in the masked ones)."""
+    n = len(self.config.layers)
+    return (n_rows >= self.COMPACT_MIN_ROWS and not self.config.apply_input_activation
+            and all(params[f'Dense_{i}']['kernel'].shape[1] % 4 == 0 for i in range(n)))
+
   def _masked_rows(self, params, x, row_mask):
     """Inference path for a row-masked MLP: rows with mask == 0 come out as zeros whatever
     the MLP computes (streetview_encoder.py:281-283), so only the listed rows are

@@ -157,6 +157,12 @@ class StreetViewEncoder(base.Module):
     fused = split = classed = False
     if base.needs_grad(f_images):
       lift = ag.lift_pool
+      if xyz.dim() == 5:                     # (the traversal hint of the inference branch below)
+        kw.update(grid_yz=tuple(xyz.shape[2:4]))
+      # the masked fusion MLP reads the rows of valid voxels only (row list): the ~40 % of a map's voxels that
+      # no view sees need no 1 KB row of zeros (with an input activation its VJP gates on every row: then kept)
+      if self.depth_mlp is None and self.fusion_mlp.reads_listed_rows_only(params['fusion_mlp'], xyz_flat.shape[0] * xyz_flat.shape[1]):
+        kw.update(valid_rows_only=True)
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))
