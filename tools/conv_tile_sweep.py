@@ -19,6 +19,16 @@ EXTRA = [
     ('stage2 1x1 512->128 40x68x68', (40, 68, 68, 512), (1, 1, 512, 128), 1, 0, ops.PRO_GN_RELU),
     ('aerial s3 3x3 256 8x34x34', (8, 34, 34, 256), (3, 3, 256, 256), 1, 1, ops.PRO_GN_RELU),
     ('aerial s3 1x1 1024->256 8x34x34', (8, 34, 34, 1024), (1, 1, 1024, 256), 1, 0, ops.PRO_GN_RELU),
+    # the aerial encoder's other small-M layers
+    ('aerial s3 1x1 256->1024 8x34x34', (8, 34, 34, 256), (1, 1, 256, 1024), 1, 0, ops.PRO_GN_RELU),
+    ('aerial s3 1x1 1024->512 8x34x34', (8, 34, 34, 1024), (1, 1, 1024, 512), 1, 0, ops.PRO_GN_RELU),
+    ('aerial s2 1x1 128->512 8x68x68', (8, 68, 68, 128), (1, 1, 128, 512), 1, 0, ops.PRO_GN_RELU),
+    ('aerial s2 3x3 128 8x68x68', (8, 68, 68, 128), (3, 3, 128, 128), 1, 1, ops.PRO_GN_RELU),
+    ('aerial s2 1x1 512->128 8x68x68', (8, 68, 68, 512), (1, 1, 512, 128), 1, 0, ops.PRO_GN_RELU),
+    ('aerial s4 3x3 512 8x17x17', (8, 17, 17, 512), (3, 3, 512, 512), 1, 1, ops.PRO_GN_RELU),
+    ('aerial s4 1x1 512->2048 8x17x17', (8, 17, 17, 512), (1, 1, 512, 2048), 1, 0, ops.PRO_GN_RELU),
+    ('aerial s4 1x1 2048->512 8x17x17', (8, 17, 17, 2048), (1, 1, 2048, 512), 1, 0, ops.PRO_GN_RELU),
+    ('aerial s1 1x1 256->64 8x136x136', (8, 136, 136, 256), (1, 1, 256, 64), 1, 0, ops.PRO_GN_RELU),
 ]
 
 
