@@ -392,7 +392,16 @@ def main(argv=None, emit=True):
   ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                   help='infer: BEVLocalizer forward (the headline metric); train: one '
                        'snap_amd.trainer.train_step (fwd + bwd + grad all-reduce + Adam)')
+  ap.add_argument('--tune', action='append', default=[], metavar='KNOB=VALUE',
+                  help='A/B runs: set a tuning switch of snap_amd.ops (e.g. LIFT_IN_CONSUMER=0); results do not '
+                       'depend on any of them beyond summation order')
   args = ap.parse_args(argv)
+  for kv in args.tune:
+    from snap_amd import ops as _ops
+    k, v = kv.split('=', 1)
+    if not hasattr(_ops, k):
+      raise SystemExit(f'--tune: snap_amd.ops has no switch {k}')
+    setattr(_ops, k, type(getattr(_ops, k))(int(v)))
 
   rank = int(os.environ.get('RANK', 0))
   world = int(os.environ.get('WORLD_SIZE', 1))

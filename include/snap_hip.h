@@ -181,7 +181,6 @@ typedef struct SnapConvExtras {
 #define SNAP_TUNE_RAW_RING 2   /* split engine: the raw-row LDS-DMA ring body (conv_raw.hip) for the K >= 256 1x1 layers with a GroupNorm prologue -- same bits as the tiled body; opt-in (measured level to 20 % slower: DESIGN.md 5a) */
 #define SNAP_TUNE_NO_PLAIN 8   /* split engine: the general A loader also for 1x1 / stride-1 / unpadded layers */
 #define SNAP_TUNE_RS_NSPLIT_SHIFT 4   /* bits 4..7: row-stationary kernel, forced column split (0 = automatic) */
-#define SNAP_TUNE_ABLATE_SHIFT 8   /* bits 8..: timing-only ablations of the K loop (WRONG results) */
 /* Pre-split launches (extras->x_presplit): row tile, GroupNorm partial-sum bytes and split-K
  * workspace bytes of the launch `desc` + `ps_tile` describes (the counterparts of
  * snap_conv2d_tile_rows / _gn_partial_bytes / _workspace_bytes). */
@@ -414,6 +413,26 @@ int snap_mlp2_pool_max_classes_f32(const float* x, int64_t M, int32_t Cin, int32
                                    int32_t relu_in, int32_t x_split, int32_t Z, int64_t ncols,
                                    float* plane, uint8_t* pvalid, void* stream);
 
+/* The lift INSIDE the consumer (replaces k3-k6 for voxels with one visible observation:
+ * streetview_encoder.py:69-105 gather, :141-178 pooling, :279-286 fusion MLP; bev_mapper.py:78-88 max):
+ * `rows_g` lists voxels whose `pooled` row does not exist; tap_records [*, 8] u32
+ * (snap_lift_pool_records_f32) hold their four-tap bilinear record, and the kernel gathers and blends
+ * 16 channels of the four taps per GEMM0 slab while it stages the operand (mean = the observation,
+ * variance slabs = 0: skipped, score slab from the record).  `rows` (several observations) are read
+ * pre-split from x (SnapLiftDesc.out_split) as snap_mlp2_pool_max_classes_f32 does.  The plane equals
+ * that entry point's bit for bit.  f_images [.., img_w, img_C] f32, f_bytes < 4 GB; Cin = 2 fd + 1,
+ * feature_dim % 16 == 0; xcd_group: runs of that many 128-row tiles of rows_g per XCD (0: dispatch
+ * order; results do not depend on it). */
+int snap_mlp2_pool_max_gather_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                                  const int32_t* rows, const int32_t* row_count,
+                                  const int32_t* rows_g, const int32_t* row_count_g,
+                                  const float* f_images, int64_t f_bytes, int32_t img_w,
+                                  int32_t img_C, int32_t feature_dim, const uint32_t* tap_records,
+                                  int32_t xcd_group, const void* w0_split, size_t w0_bytes,
+                                  const float* b0, int32_t H, const void* w1_split, size_t w1_bytes,
+                                  const float* b1, int32_t D, int32_t Z, int64_t ncols, float* plane,
+                                  uint8_t* pvalid, void* stream);
+
 /* y[m, 0..C) = value for every row with mask[m] == 0 (the masked voxels of a volume
  * whose observed rows were written through rows_out).  C % 4 == 0. */
 int snap_fill_masked_rows_f32(float* y, const uint8_t* mask, int64_t M, int32_t C,
@@ -535,6 +554,17 @@ typedef struct SnapLiftDesc {
 int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_images,
                        const float* cam, const float* Rt, const float* points,
                        float* pooled, uint8_t* valid, void* stream);
+
+/* The same with TAP RECORDS (class_rows, out_split and valid_rows_only set): a voxel with ONE visible
+ * observation writes no row into `pooled` but tap_records[voxel][8] (u32) = byte offset of tap
+ * (i0, j0) channel 0 in f_images | bit 8: i1 != i0, bit 9: j1 != j0 (the clamped upper taps), depth
+ * bins | wi1 | wj1 (f32 bits) | depth score (f32 bits) | 0 0 0 -- streetview_encoder.py:93-124 for
+ * that observation; its mean is the bilinear blend (softmax weight exactly 1), its variance 0.
+ * snap_mlp2_pool_max_gather_f32 consumes the records.  Voxels with several observations write
+ * their rows as above; valid[] carries the classes 0 / 1 / 2. */
+int snap_lift_pool_records_f32(const SnapLiftDesc* desc, const float* f_images,
+                               const float* cam, const float* Rt, const float* points,
+                               float* pooled, uint8_t* valid, uint32_t* tap_records, void* stream);
 
 /* depth_mlp fusion (streetview_encoder.py:263-267; do_weighted_fusion = False, so desc->weighted
  * = 0 and C = feature_dim): the lift in two passes around a per-observation MLP.

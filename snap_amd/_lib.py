@@ -144,6 +144,9 @@ SIGNATURES = {
     'snap_mlp2_pool_max_classes_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, ptr, c_int, c_int,
                                                ptr, c_size, ptr, c_int, ptr, c_size, ptr, c_int, c_int,
                                                c_int, c_int, c_i64, ptr, ptr, ptr]),
+    'snap_mlp2_pool_max_gather_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, ptr, ptr, c_i64, c_int,
+                                              c_int, c_int, ptr, c_int, ptr, c_size, ptr, c_int, ptr, c_size,
+                                              ptr, c_int, c_int, c_i64, ptr, ptr, ptr]),
     'snap_mlp2_pool_max_f32': (c_int, [ptr, c_i64, c_int, c_int, ptr, ptr, ptr, c_size, ptr, c_int,
                                        ptr, c_size, ptr, c_int, c_int, c_int, c_int, c_i64, ptr, ptr, ptr]),
     'snap_pad_image_f32': (c_int, [ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ptr, ptr]),
@@ -164,6 +167,9 @@ SIGNATURES = {
     'snap_max_pool_3x3s2_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, ptr]),
     'snap_lift_pool_f32': (
         c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]
+    ),
+    'snap_lift_pool_records_f32': (
+        c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr]
     ),
     'snap_lift_observations_f32': (c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
     'snap_lift_pool_observations_f32': (c_int, [ctypes.POINTER(SnapLiftDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
@@ -326,7 +332,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 

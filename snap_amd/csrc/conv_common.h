@@ -42,7 +42,7 @@ struct ConvArgs {
   int nk;      // number of K slabs
   int prio;    // experiment knob: s_setprio(1) around the MFMA block
   int ncol;    // number of column tiles (set in launch<>)
-  int ablate;  // tuning-only (SnapConvExtras.tune_flags >> 8): bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier
+  int ablate;  // alt builds only (-DSNAP_CONV_SPLIT_ABLATE=1, env SNAP_ALT_ABLATE): bit0 skip global loads, bit1 skip LDS stores+barrier, bit2 skip LDS reads, bit3 skip the barrier; 0 in the product build
   int bk;      // f32 engine: K-slab depth of the large tiles (16 | 32)
   int no_halo; // split engine: 1 = im2col body for every 3x3
   int no_plain;  // split engine: 1 = the general loader also for 1 x 1 / stride 1 / unpadded layers
@@ -99,6 +99,20 @@ int ps_ksplit(int64_t M, int Cout, int64_t nk, int bm, int bn, size_t kpartial_b
 
 namespace {
 using snapconv::ConvArgs;
+
+// Timing ablations of the K loops (WRONG results; tools/conv_ablate*.py) exist only in an alt build
+// (-DSNAP_CONV_SPLIT_ABLATE=1; the bits come from the environment variable SNAP_ALT_ABLATE): the
+// product build has neither a switch in the ABI nor a run-time branch.
+#if defined(SNAP_CONV_SPLIT_ABLATE) && SNAP_CONV_SPLIT_ABLATE
+inline int snap_alt_ablate_bits() {
+  const char* e = getenv("SNAP_ALT_ABLATE");
+  return e ? atoi(e) : 0;
+}
+#define SNAP_IGEMM_ABL(bit) (a.ablate & (bit))
+#else
+inline int snap_alt_ablate_bits() { return 0; }
+#define SNAP_IGEMM_ABL(bit) false
+#endif
 
 
 // The prologue is a COMPILE-TIME parameter: a run-time switch here is lowered to a

@@ -371,7 +371,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
-    if (more && !(a.ablate & 1)) {
+    if (more && !SNAP_IGEMM_ABL(1)) {
       load_slab(kt + 1);
       advance();
     }
@@ -411,9 +411,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     if (a.prio) __builtin_amdgcn_s_setprio(0);
-    if (!(a.ablate & 2)) {
+    if (!SNAP_IGEMM_ABL(2)) {
       if (more) store_slab(cur ^ 1);
-      if (!(a.ablate & 8)) __syncthreads();   // bit3: keep the stores, drop only the barrier
+      if (!SNAP_IGEMM_ABL(8)) __syncthreads();   // bit3: keep the stores, drop only the barrier
     }
   }
 
@@ -730,7 +730,7 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.ctiles = 0;
   a.nk = 0;  // set per K-slab depth in launch<>
   a.prio = 0;
-  a.ablate = ex ? (ex->tune_flags >> SNAP_TUNE_ABLATE_SHIFT) : 0;   // timing experiments only (wrong results)
+  a.ablate = snap_alt_ablate_bits();   // alt builds only (timing experiments, wrong results); 0 in the product build
   a.bk = (ex && ex->bk_hint == 32) ? 32 : 16;
   a.no_halo = (ex && (ex->tune_flags & SNAP_TUNE_NO_HALO)) ? 1 : 0;
   a.rs_nsplit = ex ? (ex->tune_flags >> SNAP_TUNE_RS_NSPLIT_SHIFT) & 15 : 0;

@@ -41,6 +41,10 @@ struct LiftArgs {
   float* obs_out;        // [B*N, nsel, fd + 4]: per-observation features | log10 depth | ray(3)
   float* obs_feat;       // [B*N, nsel, fd]: the features alone (the MLP's residual operand)
   const float* obs_in;   // [B*N, nsel, fd]: observations to pool instead of gathering them
+  // tap records (batched kernel, class_rows): a voxel with ONE visible observation leaves no row in
+  // `pooled` but a 32-byte record [B*N][8] = tap byte offset | clamp flags | wi1 | wj1 | score | 0 0 0;
+  // the consumer (mlp2_pool_kernel<.., GATHER>) gathers and blends the four taps itself
+  uint32_t* tap_recs;
 };
 
 struct Proj {
@@ -597,6 +601,43 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
       *wbp = c - fl;
     }
     hdr[hw][hl][3] = __int_as_float(nvis);
+    if (a.tap_recs && live && nvis <= 1) {
+      // record mode: this voxel is finished here.  Its score is the one phase B would compute (the
+      // same taps, weights and expression order, lane = voxel instead of a broadcast per half-wave);
+      // mean = the blended features (softmax weight e / e == 1), variance = 0: left to the consumer.
+      bool vld = nvis > 0;
+      if (d.max_view_distance >= 0.f && !all_views) vld = vld && (min_dist <= d.max_view_distance);
+      if (nvis == 1) {
+        const int* rec = recs[hw][hl][0];
+        const int pk = rec[1];
+        const float wi1 = __int_as_float(rec[2]), wj1 = __int_as_float(rec[3]);
+        const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;
+        const float w00 = wi0 * wj0, w01 = wi0 * wj1, w10 = wi1 * wj0, w11 = wi1 * wj1;
+        const uint32_t Cb_ = (uint32_t)d.C * 4u, Wb_ = (uint32_t)d.w * Cb_, fdb_ = (uint32_t)d.feature_dim * 4u;
+        const uint32_t o00 = (uint32_t)rec[0];
+        const uint32_t o01 = o00 + ((pk >> 9) & 1 ? Cb_ : 0u);
+        const uint32_t o10 = o00 + ((pk >> 8) & 1 ? Wb_ : 0u);
+        const uint32_t o11 = o10 + (o01 - o00);
+        const uint32_t c0 = fdb_ + ((pk >> 10) & 0xff) * 4u, c1 = fdb_ + ((pk >> 18) & 0xff) * 4u;
+        const char* fb_ = reinterpret_cast<const char*>(a.f);
+        const float t00 = *reinterpret_cast<const float*>(fb_ + (o00 + c0));
+        const float t01 = *reinterpret_cast<const float*>(fb_ + (o01 + c0));
+        const float t10 = *reinterpret_cast<const float*>(fb_ + (o10 + c0));
+        const float t11 = *reinterpret_cast<const float*>(fb_ + (o11 + c0));
+        const float u00 = *reinterpret_cast<const float*>(fb_ + (o00 + c1));
+        const float u01 = *reinterpret_cast<const float*>(fb_ + (o01 + c1));
+        const float u10 = *reinterpret_cast<const float*>(fb_ + (o10 + c1));
+        const float u11 = *reinterpret_cast<const float*>(fb_ + (o11 + c1));
+        const float wb1 = wbs[hw][hl][0], wb0 = 1.f - wb1;
+        const float s0 = ((w00 * t00 + w01 * t01) + w10 * t10) + w11 * t11;
+        const float s1 = ((w00 * u00 + w01 * u01) + w10 * u10) + w11 * u11;
+        const float score = wb0 * s0 + wb1 * s1;
+        uint4* ro = reinterpret_cast<uint4*>(a.tap_recs + gv * 8);
+        ro[0] = uint4{o00, (uint32_t)pk, (uint32_t)rec[2], (uint32_t)rec[3]};
+        ro[1] = uint4{__float_as_uint(score), 0u, 0u, 0u};
+      }
+      a.valid[gv] = vld ? 1 : 0;
+    }
     // The two half-waves of a wave walk their voxels in lock step, so a wave pays for the longer
     // of the two paths (no observation / one / several + softmax: ~30 / ~160 / ~400 instructions);
     // in voxel order 36 % of the pairs of a four-view map contain a several-observation voxel.
@@ -642,6 +683,7 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
     if (gv < 0) continue;
     const float min_dist = vh[1];
     const int nvis = __float_as_int(vh[3]);
+    if (a.tap_recs && nvis <= 1) continue;      // record mode: finished in phase A
     // Per visible slot: gather + blend right away (16 live tap registers, not 64: occupancy
     // matters more here than loads in flight per wave).  Nothing is zero-initialised and every
     // use is guarded by r < nvis; voxels seen by ONE view skip the softmax (weight e/e == 1
@@ -817,11 +859,15 @@ __global__ void project_points_kernel(int B, int V, int N, int fisheye,
 
 }  // namespace
 
-extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_images,
-                                  const float* cam, const float* Rt, const float* points,
-                                  float* pooled, uint8_t* valid, void* stream) {
+static int lift_pool_launch(const SnapLiftDesc* desc, const float* f_images,
+                            const float* cam, const float* Rt, const float* points,
+                            float* pooled, uint8_t* valid, uint32_t* tap_recs, void* stream) {
   if (!desc || !f_images || !cam || !Rt || !points || !pooled || !valid) return SNAP_ERR_NULL;
   const SnapLiftDesc& d = *desc;
+  // tap records exist in the batched kernel with classed, pre-split, valid-only rows
+  if (tap_recs && (!d.class_rows || !d.out_split || !d.valid_rows_only ||
+                   (reinterpret_cast<uintptr_t>(tap_recs) & 15)))
+    return SNAP_ERR_UNSUPPORTED;
   if (d.B <= 0 || d.V <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0) return SNAP_ERR_BAD_SHAPE;
   if (d.V > 32) return SNAP_ERR_UNSUPPORTED;
   if (d.feature_dim % 4 != 0 || d.feature_dim > 128 || d.feature_dim <= 0) return SNAP_ERR_UNSUPPORTED;
@@ -843,7 +889,7 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
     return SNAP_ERR_BAD_SHAPE;
   const int nsel = d.K == 0 ? d.V : d.K;
   constexpr int xcd_group = 64;     // workgroups per XCD-owned chunk (section 5h of DESIGN.md: settled)
-  LiftArgs a{xcd_group, 0, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr};
+  LiftArgs a{xcd_group, 0, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr, tap_recs};
   const int64_t total = (int64_t)d.B * d.N;
   if (total > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   if (d.grid_y < 0 || d.grid_z < 0 || (d.grid_y > 0) != (d.grid_z > 0)) return SNAP_ERR_BAD_SHAPE;
@@ -888,6 +934,20 @@ extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_image
   }
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
+}
+
+extern "C" int snap_lift_pool_f32(const SnapLiftDesc* desc, const float* f_images,
+                                  const float* cam, const float* Rt, const float* points,
+                                  float* pooled, uint8_t* valid, void* stream) {
+  return lift_pool_launch(desc, f_images, cam, Rt, points, pooled, valid, nullptr, stream);
+}
+
+extern "C" int snap_lift_pool_records_f32(const SnapLiftDesc* desc, const float* f_images,
+                                          const float* cam, const float* Rt, const float* points,
+                                          float* pooled, uint8_t* valid, uint32_t* tap_records,
+                                          void* stream) {
+  if (!tap_records) return SNAP_ERR_NULL;
+  return lift_pool_launch(desc, f_images, cam, Rt, points, pooled, valid, tap_records, stream);
 }
 
 // depth_mlp fusion (streetview_encoder.py:263-267, do_weighted_fusion = False): the observations

@@ -56,6 +56,16 @@ struct MlpPoolArgs {
   // GEMM0 slabs [skip_lo, skip_lo + skip_n) are not visited: the listed rows hold exact zeros
   // there (and may not have written them): single-observation rows, SnapLiftDesc.class_rows
   int skip_lo, skip_n;
+  // GATHER (the lift inside the consumer): the listed rows are voxels with ONE visible observation
+  // and `recs` holds their tap records (lift.hip: tap byte offset | clamp flags | wi1 | wj1 | score);
+  // slab s < nmean of such a row = the bilinear blend of 16 channels of four image taps (mean = the
+  // observation, weight e / e == 1), slab 2 nmean = (score, 0, ...), the variance slabs are zero
+  const char* fimg;        // f_images [B, V, h, w, C] f32 (< 4 GB: 32-bit byte offsets)
+  const uint32_t* recs;    // [*, 8]
+  uint32_t Cb, Wb;         // bytes per pixel / per image row
+  int nmean;               // feature_dim / 16
+  // consecutive tiles owned by one XCD (0: dispatch order): a tile's taps then stay in ITS L2
+  int xcd_group;
 };
 
 // hi / lo bf16 parts of four f32 (as conv_split.hip: one v_cvt_pk per pair, exact residual)
@@ -96,7 +106,7 @@ __device__ __forceinline__ void atomic_max_f32(float* p, float v) {
 #ifndef SNAP_MLP_POOL_NT
 #define SNAP_MLP_POOL_NT 256
 #endif
-template <int N0, bool RELU_IN, bool XSPLIT, int NT, int NST = 2>
+template <int N0, bool RELU_IN, bool XSPLIT, int NT, int NST = 2, bool GATHER = false>
 __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   // NST = 3 (pre-split rows only, the default for them): the GEMM0 slabs (rows + W0, 24 KB) travel TWO
   // ahead through a three-stage ring -- one barrier per slab as before, but a slab's 24 MFMAs per wave
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   // issued after GEMM0 and arrive under the ReLU / split conversion.  C2 map, 6.8 M rows:
   // 3.09-3.10 ms against 3.21-3.39 ms (tools/mlp_pool_bench.py), same bits.
   static_assert(NST == 2 || (NST == 3 && XSPLIT && NT == 256), "the ring is the LDS-DMA path's");
+  static_assert(!GATHER || (!XSPLIT && !RELU_IN && NST == 2), "the gather stages through registers");
   constexpr int BM = NT / 2, N1 = 128;
   constexpr int RPP = NT / 4;                                 // rows staged per pass (4 threads per row)
   constexpr int T0 = N0 / 32, T1 = N1 / 32;
@@ -127,7 +138,12 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   const int wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int Meff = min(*a.row_count, a.M);
-  const int m0 = blockIdx.x * BM;
+  int bid = blockIdx.x;
+  if (a.xcd_group > 0) {               // runs of G tiles per XCD (workgroups go round-robin over the XCDs)
+    const int G = a.xcd_group, xc = bid & 7, sq = bid >> 3;
+    bid = ((sq / G) * 8 + xc) * G + (sq % G);
+  }
+  const int m0 = bid * BM;
   if (m0 >= Meff) return;
 
   for (int i = tid; i < N0 + N1; i += NT)
@@ -146,10 +162,42 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
   f32x4 xa[2];
   bool xin[2];
   int cur_c = 0;
+  // GATHER: per row the four tap offsets (this thread's 16-byte quad folded in), the four bilinear
+  // weights and the score; ta = the taps of the slab in flight
+  uint32_t g_o[2][4];
+  float g_w[2][4], g_s[2];
+  f32x4 ta[2][4];
+  if constexpr (GATHER) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (tid >> 2) + RPP * i;
+      const uint4* rp = reinterpret_cast<const uint4*>(a.recs + (int64_t)a.rows[r_ok[i] ? m : m0] * 8);
+      const uint4 r0 = rp[0];
+      g_s[i] = __uint_as_float(rp[1].x);
+      const float wi1 = __uint_as_float(r0.z), wj1 = __uint_as_float(r0.w);
+      const float wi0 = 1.f - wi1, wj0 = 1.f - wj1;                 // (lift.hip phase B, the same products)
+      g_w[i][0] = wi0 * wj0; g_w[i][1] = wi0 * wj1; g_w[i][2] = wi1 * wj0; g_w[i][3] = wi1 * wj1;
+      const uint32_t o00 = r0.x + 16u * (tid & 3);
+      const uint32_t o01 = o00 + ((r0.y >> 9) & 1u ? a.Cb : 0u);
+      const uint32_t o10 = o00 + ((r0.y >> 8) & 1u ? a.Wb : 0u);
+      g_o[i][0] = o00; g_o[i][1] = o01; g_o[i][2] = o10; g_o[i][3] = o10 + (o01 - o00);
+    }
+  }
 #ifndef SNAP_MLP_POOL_ABLATE
 #define SNAP_MLP_POOL_ABLATE 0     // timing experiments only (wrong results): 1 = no A loads,
 #endif                             // 2 = no A loads / split / LDS stores, 4 = no GEMM1, 8 = no max scan
   auto load_a = [&](int ct) {
+    if constexpr (GATHER) {
+      cur_c = ct;
+      if (ct < a.nmean) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            ta[i][t] = *reinterpret_cast<const f32x4*>(a.fimg + (g_o[i][t] + 64u * (uint32_t)ct));
+      }
+      return;
+    }
     if (SNAP_MLP_POOL_ABLATE & 3) { cur_c = 0; xa[0] = xa[1] = f32x4{1.f, 1.f, 1.f, 1.f}; xin[0] = xin[1] = true; return; }
     const int c = ct * 16 + 4 * akq;
     cur_c = c;
@@ -166,10 +214,21 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int row = (tid >> 2) + RPP * i;
       f32x4 v = xa[i];
+      if constexpr (GATHER) {
+        if (cur_c < a.nmean) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pv = RELU_IN ? snap_relu(v[e]) : v[e];
-        v[e] = (xin[i] && cur_c + e < a.Cin) ? pv : 0.f;
+          for (int e = 0; e < 4; ++e)
+            v[e] = ((g_w[i][0] * ta[i][0][e] + g_w[i][1] * ta[i][1][e]) + g_w[i][2] * ta[i][2][e]) + g_w[i][3] * ta[i][3][e];
+        } else {
+          v = f32x4{akq == 0 ? g_s[i] : 0.f, 0.f, 0.f, 0.f};
+        }
+        if (!r_ok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = RELU_IN ? snap_relu(v[e]) : v[e];
+          v[e] = (xin[i] && cur_c + e < a.Cin) ? pv : 0.f;
+        }
       }
       u32x2 hi, lo;
       split2(v, hi, lo);
@@ -859,6 +918,13 @@ static int mlp2_pool_check(const float* x, int64_t M, int32_t Cin, int32_t x_str
 
 static void mlp2_pool_launch(const MlpPoolArgs& a, int relu_in, int x_split, hipStream_t s) {
   constexpr int NT = SNAP_MLP_POOL_NT;
+  if (x_split == 7) {                                // tap records: the gather inside the kernel
+    int64_t nb = snap_cdiv(a.M, 128);
+    if (a.xcd_group > 0) nb = snap_cdiv(nb, 8LL * a.xcd_group) * 8LL * a.xcd_group;
+    if (a.H <= 128) hipLaunchKernelGGL((mlp2_pool_kernel<128, false, false, 256, 2, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp2_pool_kernel<256, false, false, 256, 2, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    return;
+  }
   if (x_split == 3 && !relu_in && a.H == 256) {      // 256-row tiles: measured slower (see the kernel), opt-in
     hipLaunchKernelGGL((mlp2_pool_wide_kernel<256>), dim3((unsigned)snap_cdiv(a.M, 256)), dim3(256), 0, s, a);
     return;
@@ -910,6 +976,7 @@ extern "C" int snap_mlp2_pool_max_classes_f32(const float* x, int64_t M, int32_t
   a.w1 = static_cast<const char*>(w1_split); a.b1 = b1; a.D = D;
   a.Z = Z; a.plane = plane;
   a.skip_lo = ctiles0; a.skip_n = 0;
+  a.fimg = nullptr; a.recs = nullptr; a.Cb = a.Wb = 0; a.nmean = 0; a.xcd_group = 0;
   mlp2_pool_launch(a, relu_in, x_split, s);
   SNAP_CHECK_LAUNCH();
   if (rows_z) {           // the rows that are zero over [zero_slab_lo, +zero_slabs): same plane (max)
@@ -918,6 +985,62 @@ extern "C" int snap_mlp2_pool_max_classes_f32(const float* x, int64_t M, int32_t
     mlp2_pool_launch(a, relu_in, x_split, s);
     SNAP_CHECK_LAUNCH();
   }
+  hipLaunchKernelGGL(mlp2_pool_finalize_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s,
+                     plane, pvalid, ncols, D);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+// The lift inside the consumer: rows_g lists voxels with ONE visible observation whose `pooled` row
+// does not exist -- the kernel blends their four image taps from the tap records
+// (snap_lift_pool_records_f32) while it stages GEMM0's operand; `rows` (several observations) are
+// read pre-split from x as snap_mlp2_pool_max_classes_f32 does.  One plane, the same bits.
+extern "C" int snap_mlp2_pool_max_gather_f32(const float* x, int64_t M, int32_t Cin, int32_t x_stride,
+                                             const int32_t* rows, const int32_t* row_count,
+                                             const int32_t* rows_g, const int32_t* row_count_g,
+                                             const float* f_images, int64_t f_bytes, int32_t img_w,
+                                             int32_t img_C, int32_t feature_dim,
+                                             const uint32_t* tap_records, int32_t xcd_group,
+                                             const void* w0_split, size_t w0_bytes, const float* b0,
+                                             int32_t H, const void* w1_split, size_t w1_bytes,
+                                             const float* b1, int32_t D, int32_t Z, int64_t ncols,
+                                             float* plane, uint8_t* pvalid, void* stream) {
+  if (!x || !rows || !row_count || !rows_g || !row_count_g || !f_images || !tap_records || !w0_split ||
+      !b0 || !w1_split || !b1 || !plane || !pvalid)
+    return SNAP_ERR_NULL;
+  const int st = mlp2_pool_check(x, M, Cin, x_stride, w0_split, w0_bytes, H, w1_split, w1_bytes, D,
+                                 0, 1, Z, ncols, plane);
+  if (st != SNAP_OK) return st;
+  // rows = mean(fd) | var(fd) | score: whole 16-channel slabs, the score opens a slab of its own
+  if (feature_dim <= 0 || feature_dim % 16 != 0 || Cin != 2 * feature_dim + 1 || img_C < feature_dim ||
+      img_C % 4 != 0 || img_w <= 0 || xcd_group < 0)
+    return SNAP_ERR_BAD_SHAPE;
+  if (f_bytes <= 0 || f_bytes >= (1LL << 32)) return SNAP_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(f_images) | reinterpret_cast<uintptr_t>(tap_records)) & 15)
+    return SNAP_ERR_BAD_SHAPE;
+  const int ctiles0 = (Cin + 15) / 16;
+  const int nmean = feature_dim / 16;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n4 = ncols * (D / 4);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s, plane, n4,
+                     -INFINITY);
+  SNAP_CHECK_LAUNCH();
+  MlpPoolArgs a;
+  a.x = x; a.x_stride = x_stride; a.Cin = Cin;
+  a.rows = rows; a.row_count = row_count; a.M = (int)M;
+  a.w0 = static_cast<const char*>(w0_split); a.ctiles0 = ctiles0; a.b0 = b0; a.H = H;
+  a.w1 = static_cast<const char*>(w1_split); a.b1 = b1; a.D = D;
+  a.Z = Z; a.plane = plane;
+  a.skip_lo = ctiles0; a.skip_n = 0;
+  a.fimg = reinterpret_cast<const char*>(f_images); a.recs = tap_records;
+  a.Cb = (uint32_t)img_C * 4u; a.Wb = (uint32_t)img_w * a.Cb; a.nmean = nmean; a.xcd_group = 0;
+  mlp2_pool_launch(a, 0, 1, s);
+  SNAP_CHECK_LAUNCH();
+  a.rows = rows_g; a.row_count = row_count_g;
+  a.skip_lo = nmean; a.skip_n = nmean;
+  a.xcd_group = xcd_group;
+  mlp2_pool_launch(a, 0, 7, s);
+  SNAP_CHECK_LAUNCH();
   hipLaunchKernelGGL(mlp2_pool_finalize_kernel, dim3((unsigned)snap_cdiv(n4, 256)), dim3(256), 0, s,
                      plane, pvalid, ncols, D);
   SNAP_CHECK_LAUNCH();

@@ -154,7 +154,7 @@ class StreetViewEncoder(base.Module):
     kw = dict(K=K, fisheye=cameras.is_fisheye, feature_dim=cfg.feature_dim,
               num_bins=cfg.num_scale_bins, depth_min_max=cfg.depth_min_max,
               max_view_distance=cfg.get('max_view_distance'))
-    fused = split = classed = False
+    fused = split = classed = records = False
     if base.needs_grad(f_images):
       lift = ag.lift_pool
       if xyz.dim() == 5:                     # (the traversal hint of the inference branch below)
@@ -181,6 +181,9 @@ class StreetViewEncoder(base.Module):
         # every voxel of the query) = zero variance, neither written nor read nor multiplied
         classed = split and ops.CLASS_ROWS and cfg.feature_dim % 16 == 0
         kw.update(class_rows=classed)
+        # ... and those rows are never written: a tap record instead, blended inside the MLP kernel
+        records = classed and ops.LIFT_IN_CONSUMER
+        kw.update(tap_records=records)
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))
@@ -200,11 +203,12 @@ class StreetViewEncoder(base.Module):
           p['Dense_0']['kernel'], p['Dense_0']['bias'], p['Dense_1']['kernel'], p['Dense_1']['bias'],
           cin=self.fusion_mlp.in_dim, Z=grid_shape[-1],
           relu_in=bool(cfg.fusion.apply_input_activation), x_split=split,
-          zero_slabs=(nvar, nvar) if classed else None)
+          zero_slabs=(nvar, nvar) if classed else None,
+          gather=(f_images, classes[1]) if records else None)
       # the reference's pytree entry (streetview_encoder.py:282-286), produced on first access
       # by the unfused chain on the same inputs: lift -> fusion MLP -> mask
       kw_plain = {k: v for k, v in kw.items()
-                  if k not in ('valid_rows_only', 'out_split', 'class_rows')}
+                  if k not in ('valid_rows_only', 'out_split', 'class_rows', 'tap_records')}
       cam_p, rt_p = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
 
       engine = ops.precision()                 # (the engine of THIS apply, whenever the access comes)

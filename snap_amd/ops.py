@@ -34,6 +34,10 @@ OVERLAP_AERIAL = True
 POOLED_SPLIT = True
 # ... and classed by their number of observations (single-observation rows carry no variance slabs); 0: off
 CLASS_ROWS = True
+# ... and the class-1 rows (one observation) are never written: the lift leaves a 32-byte tap record and the
+# fused MLP / pool kernel blends the four image taps itself (the lift inside the consumer); 0: rows through HBM
+LIFT_IN_CONSUMER = True
+MLP_GATHER_XCD_GROUP = 8      # runs of 128-row tiles of the gathered class per XCD (its L2 keeps their taps)
 # image padding and the voxel-centre grid as one native pass each instead of torch fill + strided copies; 0: torch
 NATIVE_GLUE = True
 _SIDE_STREAMS = {}
@@ -282,7 +286,6 @@ MLP_POOL_NO_RING = False  # tuning / tests: pre-split rows on the two-stage GEMM
 MLP_POOL_WIDE = False     # tuning / tests: pre-split rows on the 256-row mlp2_pool kernel (x_split = 3; measured slower, mlp_pool.hip)
 CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
 CONV_RAW_RING = False   # tests / tools: the raw-row LDS-DMA ring body (conv_raw.hip) for the K >= 256 1x1 layers (same bits; not faster)
-CONV_ABLATE = 0              # timing-only ablations of the K loops (WRONG results): tools/conv_ablate*.py
 USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
 PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
 PS_TILE = 0              # 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles
@@ -626,13 +629,12 @@ def conv2d(
       ex.x_presplit = 1
       ex.ps_tile = pst
       ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
-  if CONV_BK or CONV_NO_HALO or CONV_RS_NSPLIT or CONV_NO_PLAIN or CONV_ABLATE or CONV_RAW_RING:
+  if CONV_BK or CONV_NO_HALO or CONV_RS_NSPLIT or CONV_NO_PLAIN or CONV_RAW_RING:
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
     ex.bk_hint = int(CONV_BK or 0)
     ex.tune_flags = (int(bool(CONV_NO_HALO)) | 2 * int(bool(CONV_RAW_RING)) | 8 * int(bool(CONV_NO_PLAIN))
-                     | ((int(CONV_RS_NSPLIT) & 15) << 4)
-                     | (int(CONV_ABLATE) << 8))
+                     | ((int(CONV_RS_NSPLIT) & 15) << 4))
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -992,7 +994,7 @@ def mlp2_pool_supported(cin, hidden, out_dim):
 
 
 def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False,
-                  zero_slabs=None):
+                  zero_slabs=None, gather=None):
   """Fusion MLP (Dense -> relu -> Dense) over the rows with row_mask != 0 + max over the Z
   levels of every column, in one kernel on the bf16x3 engine (streetview_encoder.py:279-286 +
   bev_mapper.py:78-88).  x [M, Cs] (M = columns * Z, level fastest), row_mask [M];
@@ -1003,7 +1005,9 @@ def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split
   row_mask is a CLASS per row (uint8, ``lift_pool(class_rows=True)``): rows of class 1 are exactly
   zero over those 16-channel slabs (and did not write them), rows of class >= 2 are complete --
   two row lists into one plane, the zero slabs of the first neither read nor multiplied; the same
-  plane bit for bit."""
+  plane bit for bit.  ``gather`` = (f_images [B,V,h,w,C], records [B,N,8]) from
+  ``lift_pool(tap_records=True)``: the class-1 rows do not exist in x -- the kernel blends their four
+  image taps per GEMM0 slab from the records (the lift inside the consumer); the same plane bit for bit."""
   lib = _lib.load()
   _f32(x, 'x'); _mask(row_mask, 'row_mask')
   for t, n in ((w0, 'w0'), (b0, 'b0'), (w1, 'w1'), (b1, 'b1')):
@@ -1035,6 +1039,22 @@ def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split
   def rows_():
     return int(count.item()), (int(count_z.item()) if count_z is not None else 0)
 
+  if gather is not None:
+    f_img, recs = gather
+    _f32(f_img, 'f_images')
+    fd = (cin - 1) // 2
+    if (zero_slabs is None or not x_split or relu_in or recs.dtype != torch.int32 or recs.numel() != M * 8
+        or (zlo, zn) != (fd // 16, fd // 16) or fd % 16 or cin != 2 * fd + 1):
+      raise ValueError('mlp2_pool_max: gather needs classed pre-split rows of mean | var | score and [M, 8] records')
+    with _region('mlp2_pool_bf16x3', lambda: kflops * rows_()[0] + kflops_z * rows_()[1],
+                 lambda: 4.0 * (rows_()[0] * cin + rows_()[1] * 8 + plane.numel()),
+                 lambda: f'M{M}r_K{cin}_H{H}_N{D}_Z{Z}_gather'):
+      st = lib.snap_mlp2_pool_max_gather_f32(
+          _p(x), M, cin, Cs, _p(index), _p(count), _p(index_z), _p(count_z), _p(f_img), f_img.numel() * 4,
+          f_img.shape[-2], f_img.shape[-1], fd, _p(recs), int(MLP_GATHER_XCD_GROUP), _p(w0p), w0p.numel() * 2,
+          _p(b0), H, _p(w1p), w1p.numel() * 2, _p(b1), D, Z, ncols, _p(plane), _p(pvalid), _stream())
+    _lib.check(st, 'snap_mlp2_pool_max_gather_f32')
+    return plane, pvalid
   with _region('mlp2_pool_bf16x3', lambda: kflops * rows_()[0] + kflops_z * rows_()[1],
                lambda: 4.0 * (rows_()[0] * cin + rows_()[1] * (cin - 16 * zn) + plane.numel()),
                lambda: f'M{M}r_K{cin}_H{H}_N{D}_Z{Z}'):
@@ -1267,7 +1287,7 @@ def pooled_stride(feature_dim, weighted=True, use_variance=True, add_minmax=Fals
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
               add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False,
-              class_rows=False):
+              class_rows=False, tap_records=False):
   """Fused k1-k5.  f_images [B,V,h,w,C]; cam [B,V,11]; Rt [B,V,12]; points [B,N,3].
 
   K = 0 selects all views.  Returns pooled [B,N,stride] (mean|var|score_max|pad by default;
@@ -1281,6 +1301,10 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   ``class_rows`` (with out_split): a third result, classes [B,N] uint8 = 0 invalid / 1 one visible
   observation / 2 several, and rows of class 1 do not write their (all-zero) variance slabs --
   ``mlp2_pool_max(zero_slabs=(fd / 16, fd / 16))`` takes the classes as its row mask.
+  ``tap_records`` (with class_rows, out_split, valid_rows_only): a fourth result, records [B,N,8] int32;
+  a class-1 voxel writes NO row but its four-tap record (byte offset | flags | wi1 | wj1 | depth score) --
+  ``mlp2_pool_max(gather=(f_images, records))`` blends the taps inside the MLP kernel (the lift inside
+  the consumer): those rows never exist in memory.
   """
   lib = _lib.load()
   _f32(f_images, 'f_images'); _f32(cam, 'cam'); _f32(Rt, 'Rt'); _f32(points, 'points')
@@ -1302,14 +1326,27 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
   d.valid_rows_only = int(bool(valid_rows_only))
   d.out_split = int(bool(out_split))
   d.class_rows = int(bool(class_rows))
+  recs = None
+  if tap_records:
+    if not (class_rows and out_split and valid_rows_only):
+      raise ValueError('lift_pool: tap_records needs class_rows, out_split and valid_rows_only')
+    recs = torch.empty((B, N, 8), dtype=torch.int32, device=f_images.device)
   with _region(
       'lift_pool', 0.0, 4.0 * (f_images.numel() + points.numel() + pooled.numel())
   ):
-    st = lib.snap_lift_pool_f32(
-        ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(pooled),
-        _p(valid), _stream(),
-    )
-  _lib.check(st, 'snap_lift_pool_f32')
+    if recs is not None:
+      st = lib.snap_lift_pool_records_f32(
+          ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(pooled),
+          _p(valid), _p(recs), _stream(),
+      )
+    else:
+      st = lib.snap_lift_pool_f32(
+          ctypes.byref(d), _p(f_images), _p(cam), _p(Rt), _p(points), _p(pooled),
+          _p(valid), _stream(),
+      )
+  _lib.check(st, 'snap_lift_pool_records_f32' if recs is not None else 'snap_lift_pool_f32')
+  if recs is not None:
+    return pooled, valid != 0, valid, recs
   if class_rows:
     return pooled, valid != 0, valid
   return pooled, valid

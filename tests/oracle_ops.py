@@ -201,16 +201,65 @@ def _unsplit_rows(x):
   return (parts[..., 0, :] + parts[..., 1, :]).reshape(*t.shape[:-1], ks * 16).numpy()
 
 
+def _tap_records(f, p2d, vis, idx, scores, selective):
+  """The tap records of lift.hip (SnapLiftDesc tap records) for the voxels with ONE visible
+  observation: byte offset of tap (i0, j0) | bit 8: i1 != i0, bit 9: j1 != j0 | wi1 | wj1 | score.
+  Taps as streetview_encoder.py:93-105 (selective: the point clipped) / grids.interpolate_nd (all
+  views: every tap index clipped); the weights come from the unclipped-index coordinate."""
+  B, V, h, w, C = f.shape
+  recs = np.zeros(vis.shape[:2] + (8,), np.int32)
+  bi, ni = np.nonzero(vis.sum(-1) == 1)
+  ss = vis[bi, ni].argmax(-1)
+  view = idx[bi, ni, ss] if idx is not None else ss
+  c = p2d[bi, ni, ss].astype(np.float32) - np.float32(0.5)            # [n, 2] (i, j)
+  size = np.array([h, w], np.float32)
+  if selective:
+    c = np.maximum(np.minimum(c, size - 1), 0)
+  fl = np.floor(c)
+  w1 = (c - fl).astype(np.float32)
+  lo = np.clip(fl, 0, size - 1).astype(np.int64)
+  hi = np.clip(fl + 1, 0, size - 1).astype(np.int64)
+  off = ((((bi * V + view) * h + lo[:, 0]) * w + lo[:, 1]) * (C * 4)).astype(np.uint32)
+  flags = ((hi[:, 0] != lo[:, 0]).astype(np.uint32) << 8) | ((hi[:, 1] != lo[:, 1]).astype(np.uint32) << 9)
+  recs[bi, ni, 0] = off.view(np.int32)
+  recs[bi, ni, 1] = flags.view(np.int32)
+  recs[bi, ni, 2] = w1[:, 0].view(np.int32)
+  recs[bi, ni, 3] = w1[:, 1].view(np.int32)
+  recs[bi, ni, 4] = scores[bi, ni, ss].astype(np.float32).view(np.int32)
+  return recs
+
+
+def _rows_from_tap_records(f_images, recs, fd, sel):
+  """What mlp2_pool_kernel<.., GATHER> stages for a record: mean = the four-tap blend (weight order
+  of lift.hip phase B), variance = 0, score from the record.  [M, 2 fd + 1]; rows outside ``sel``
+  (no / several observations: their records are uninitialised) are zero."""
+  f = _np(f_images, np.float32)
+  B, V, h, w, C = f.shape
+  sel = np.asarray(sel).reshape(-1)
+  r = np.ascontiguousarray(_np(recs)).reshape(-1, 8)[sel]
+  px = np.ascontiguousarray(r[:, 0]).view(np.uint32).astype(np.int64) // (C * 4)
+  di = (r[:, 1] >> 8) & 1
+  dj = (r[:, 1] >> 9) & 1
+  wi1, wj1, sc = (np.ascontiguousarray(r[:, k]).view(np.float32) for k in (2, 3, 4))
+  wi0, wj0 = 1 - wi1, 1 - wj1
+  ff = f.reshape(-1, C)[:, :fd]
+  a00, a01, a10, a11 = ff[px], ff[px + dj], ff[px + di * w], ff[px + di * w + dj]
+  mean = (((wi0 * wj0)[:, None] * a00 + (wi0 * wj1)[:, None] * a01) + (wi1 * wj0)[:, None] * a10) + (wi1 * wj1)[:, None] * a11
+  out = np.zeros((sel.size, 2 * fd + 1), np.float32)
+  out[sel] = np.concatenate([mean, np.zeros_like(mean), sc[:, None]], -1)
+  return out
+
+
 def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
               depth_min_max, max_view_distance=None, weighted=True, use_variance=True,
               add_minmax=False, grid_yz=None, valid_rows_only=False, out_split=False,
-              class_rows=False):
+              class_rows=False, tap_records=False):
   f = _np(f_images, DTYPE)
   cams = unpack_cameras(cam, fisheye)
   T = unpack_transforms(Rt)
   pts = _np(points, DTYPE)
   p2d, vis, depth, _ = o_lift.project_points_to_views(T, cams, pts)
-  min_distance = None
+  min_distance = idx = None
   if K > 0:
     idx, min_distance = o_lift.view_selection(pts, T, vis, K)
     p2d, vis, depth = (
@@ -239,6 +288,12 @@ def lift_pool(f_images, cam, Rt, points, *, K, fisheye, feature_dim, num_bins,
     out[nvis == 0] = np.nan
   if class_rows:
     classes = np.where(valid, np.where(nvis > 1, 2, 1), 0).astype(np.uint8)
+    if tap_records:                # one observation: no row at all, a tap record instead
+      assert out_split and valid_rows_only and weighted
+      out[nvis == 1] = np.nan
+      recs = _tap_records(f, p2d, vis, idx, scores, K > 0)
+      return (_t(out, f_images), _t(valid, f_images), _t(classes, f_images, dtype=torch.uint8),
+              _t(recs, f_images, dtype=torch.int32))
     return _t(out, f_images), _t(valid, f_images), _t(classes, f_images, dtype=torch.uint8)
   return _t(out, f_images), _t(valid, f_images)
 
@@ -261,12 +316,15 @@ def mlp2_pool_supported(cin, hidden, out_dim):
 
 
 def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split=False,
-                  zero_slabs=None):
+                  zero_slabs=None, gather=None):
   xx = _np(x, DTYPE)
   if x_split:
     xx = _unsplit_rows(xx)
   xx = xx[:, :cin].copy()
   m = _np(row_mask)
+  if gather is not None:          # class-1 rows do not exist: blended from their tap records
+    one = m.reshape(-1) == 1
+    xx[one] = _rows_from_tap_records(gather[0], gather[1], (cin - 1) // 2, one)[one].astype(xx.dtype)
   if zero_slabs is not None:      # row classes: class 1 is exactly zero over the slab range
     lo, n = zero_slabs
     xx[m == 1, 16 * lo:16 * (lo + n)] = 0

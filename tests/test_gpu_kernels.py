@@ -1066,6 +1066,53 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
     assert torch.equal(vgot, vwant) and torch.equal(got, want), float((got - want).abs().max())
 
 
+@pytest.mark.parametrize('X,Y,Z,K,V,fd,nb,H', [(16, 8, 60, 0, 4, 128, 32, 256), (9, 24, 60, 2, 5, 128, 32, 256),
+                                               (8, 8, 3, 0, 1, 128, 32, 256), (11, 13, 7, 0, 3, 32, 8, 64),
+                                               (40, 24, 60, 0, 4, 128, 32, 256)])
+def test_lift_inside_the_consumer(X, Y, Z, K, V, fd, nb, H):
+  """Tap records (snap_lift_pool_records_f32) + the gather inside the fused MLP / pool kernel
+  (snap_mlp2_pool_max_gather_f32): voxels with ONE visible observation never get a `pooled` row, and the
+  plane is, bit for bit, the plane of the rows-through-memory path; the records themselves are checked
+  against the numpy restatement of the format (tests/oracle_ops.py)."""
+  import oracle_ops
+  f, cam, Rt, pts = _lift_scene(2, V, 12, 16, fd, nb, X * Y * Z, seed=500 + X)
+  kw = dict(K=K, fisheye=True, feature_dim=fd, num_bins=nb, depth_min_max=(1.0, 16.0), grid_yz=(Y, Z),
+            valid_rows_only=True, out_split=True, class_rows=True)
+  args = [t.to(DEV) for t in (f, cam, Rt, pts)]
+  p4, v4, c4 = ops.lift_pool(*args, **kw)
+  p5, v5, c5, r5 = ops.lift_pool(*args, tap_records=True, **kw)
+  one, many = c4 == 1, c4 == 2
+  assert torch.equal(c5, c4) and torch.equal(v5, v4) and int(one.sum()) > 0 and (V == 1 or int(many.sum()) > 0)
+  assert torch.equal(p5[many], p4[many])
+  # the records reproduce the rows the other path wrote (mean | 0 | score), up to the hi + lo split
+  ks = (2 * fd + 1 + 15) // 16
+  rows = torch.from_numpy(oracle_ops._rows_from_tap_records(f, r5.cpu(), fd, one.cpu().numpy())).reshape(*c4.shape, -1)
+  parts = p4.cpu().view(torch.int32).view(torch.int16).view(torch.bfloat16).reshape(*p4.shape[:2], ks, 2, 16).float()
+  stored = (parts[..., 0, :] + parts[..., 1, :]).reshape(*p4.shape[:2], ks * 16)
+  oc = one.cpu()
+  assert float((rows[oc][:, :fd] - stored[oc][:, :fd]).abs().max()) <= 2e-5 * float(stored[oc][:, :fd].abs().max())
+  assert float((rows[oc][:, 2 * fd] - stored[oc][:, 2 * fd]).abs().max()) <= 2e-5
+  # the plane: records + in-kernel gather == classed rows through memory
+  g = torch.Generator().manual_seed(X)
+  cin, D = 2 * fd + 1, fd
+  w0 = (torch.randn((cin, H), generator=g) / cin ** 0.5).to(DEV)
+  b0 = (torch.randn(H, generator=g) * 0.1).to(DEV)
+  w1 = (torch.randn((H, D), generator=g) / H ** 0.5).to(DEV)
+  b1 = (torch.randn(D, generator=g) * 0.1).to(DEV)
+  nv = fd // 16
+  flat = lambda t: t.reshape(-1, t.shape[-1])
+  want, vwant = ops.mlp2_pool_max(flat(p4), c4.reshape(-1), w0, b0, w1, b1, cin=cin, Z=Z, x_split=True,
+                                  zero_slabs=(nv, nv))
+  for group in (0, 1, 8):
+    ops.MLP_GATHER_XCD_GROUP, keep = group, ops.MLP_GATHER_XCD_GROUP
+    try:
+      got, vgot = ops.mlp2_pool_max(flat(p5), c5.reshape(-1), w0, b0, w1, b1, cin=cin, Z=Z, x_split=True,
+                                    zero_slabs=(nv, nv), gather=(args[0], r5))
+    finally:
+      ops.MLP_GATHER_XCD_GROUP = keep
+    assert torch.equal(vgot, vwant) and torch.equal(got, want), (group, float((got - want).abs().max()))
+
+
 @pytest.mark.parametrize('nplanes', [1, 2])
 def test_plane_fuse_match(nplanes):
   D, Dm = 128, 32

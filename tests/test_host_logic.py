@@ -342,7 +342,7 @@ def test_fused_plane_path_host_plumbing(oracle_backend, monkeypatch):
 
   def spy(*a, **kw):
     out = lift(*a, **kw)
-    seen.setdefault('kw', []).append({k: kw.get(k) for k in ('valid_rows_only', 'out_split', 'class_rows')})
+    seen.setdefault('kw', []).append({k: kw.get(k) for k in ('valid_rows_only', 'out_split', 'class_rows', 'tap_records')})
     if kw.get('class_rows'):
       seen['classes'] = out[2]
     return out
@@ -356,7 +356,7 @@ def test_fused_plane_path_host_plumbing(oracle_backend, monkeypatch):
   loc2 = bev_localizer.BEVLocalizer(cfg2, meta['build_config'].scene_config, meta['grid'].bev())
   batch = synthetic.make_batch(2, meta['grid'], 3, (64, 64), seed=1)
   got = loc2.apply(variables, batch, train=False, rngs={'sampling': 3})
-  assert all(k == {'valid_rows_only': True, 'out_split': True, 'class_rows': True} for k in seen['kw'])
+  assert all(k == {'valid_rows_only': True, 'out_split': True, 'class_rows': True, 'tap_records': True} for k in seen['kw'])
   assert set(np.unique(seen['classes'].numpy())) <= {0, 1, 2} and int((seen['classes'] == 1).sum()) > 0
   vol = got['map']['streetview']['feature_volume']      # lazily produced: the reference's pytree entry
   assert not vol.materialized

@@ -1,5 +1,5 @@
-"""Tuning aid: times the conv engine on a few shapes under ops.CONV_ABLATE variants
-(SnapConvExtras.tune_flags >> 8; timing only, wrong results)."""
+"""Tuning aid: times the conv engine on a few shapes under the ablation bits of an ALT build
+(-DSNAP_CONV_SPLIT_ABLATE=1 reads the environment variable SNAP_ALT_ABLATE; timing only, wrong results)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,10 +20,10 @@ for name, N, H, W, Cin, k, Cout in shapes:
   mu = torch.zeros(N, Cin, device='cuda'); sc = torch.ones(N, Cin, device='cuda'); beta = torch.zeros(Cin, device='cuda')
   for pro in (0, 2):
     for ab in (0, 1, 2, 8, 9, 3):
-      ops.CONV_ABLATE = ab
+      os.environ['SNAP_ALT_ABLATE'] = str(ab)     # read by the ALT build only (-DSNAP_CONV_SPLIT_ABLATE=1)
       pad = ((k // 2, k // 2), (k // 2, k // 2))
       kw = dict(padding=pad, prologue=pro, gn=(mu, sc, beta) if pro else None)
       ms = bench(lambda: ops.conv2d(x, w, **kw))
       fl = 2.0 * N * H * W * k * k * Cin * Cout
       print(f'{name} pro={pro} ablate={ab}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF', flush=True)
-ops.CONV_ABLATE = 0
+os.environ['SNAP_ALT_ABLATE'] = '0'

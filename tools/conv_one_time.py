@@ -11,7 +11,7 @@ import conv_bench  # noqa: E402
 
 name, xs, ws, stride, pad, pro = conv_bench.LAYERS[int(sys.argv[1])]
 math = sys.argv[2]
-ops.CONV_ABLATE = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # timing-only ablation bits
+os.environ['SNAP_ALT_ABLATE'] = sys.argv[3] if len(sys.argv) > 3 else '0'   # timing-only ablation bits (alt build only)
 dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(xs, device=dev, generator=g)
