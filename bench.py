@@ -118,6 +118,7 @@ def build_c4(device, rank, method='auto'):
   _, _, q_xy_p = bev_localizer.build_query_frustum_grid(cell, 16.0, True, 72.0)
   q_xy = q_xy_p[:, 0].to(device)[None].contiguous()                    # [1, 4652, 2]
   Nq = q_xy.shape[1]
+  q_norm_max = float(q_xy_p.norm(dim=-1).max())
   fq = torch.nn.functional.normalize(torch.randn(1, Nq, D, generator=g), dim=-1).to(device)
   poses = torch.stack([torch.rand(1, P, generator=g) * 2 * math.pi,
                        torch.rand(1, P, generator=g) * H * cell,
@@ -140,7 +141,9 @@ def build_c4(device, rank, method='auto'):
     scores = ops.pose_score(sim, poses, q_xy, vq, ones[None], cell)
     best = ops.argmax_rows(scores).to(torch.int64)
     init = geometry.Transform2D.from_packed(poses[torch.arange(1, device=device), best])
-    refined, lattice = pose_estimation.grid_refinement_batched(init, sim, q_xy, vq, ones[None], grid, False)
+    # (max_point_norm: the frustum's farthest point, a host constant -- as BEVLocalizer passes it)
+    refined, lattice = pose_estimation.grid_refinement_batched(init, sim, q_xy, vq, ones[None], grid, False,
+                                                               max_point_norm=q_norm_max)
     return dict(votes=votes, scores_poses=scores, map_t_query=refined, scores_grid_refine=lattice)
 
   return step, algo

@@ -639,6 +639,9 @@ int snap_sim_softmax_f32(const float* fq, const float* fm, int32_t B, int32_t Nq
                          float* sim, float* chunk_stats, float* prob,
                          float* rowstats, void* stream);
 
+/* Bytes of the optional rowstats [B, Nq, 2] buffer of the similarity entry points (caller-owned). */
+size_t snap_sim_rowstats_bytes(int32_t B, int32_t Nq);
+
 /* add_confidence_query (bev_localizer.py:165-168): the 1 / num_valid normalisation of sim (and
  * prob) is replaced by per-point weights row_weight[B, Nq] = layers.masked_softmax(bev_confidence
  * of the query points, valid points).  row_weight == NULL is snap_sim_softmax_f32. */
@@ -718,6 +721,23 @@ int snap_ransac_sample_ws_f32(const float* fq, const float* fm, const float* chu
                               float scale, int32_t clip_negative, int32_t S, uint64_t seed,
                               const float* uniforms, int32_t* corr, void* workspace,
                               size_t workspace_bytes, void* stream);
+
+/* snap_pose_score_f32 for pose sets CLUSTERED around one centre pose per scene -- the 41^3
+ * refinement lattice of grid_refinement (pose_estimation.py:168-205): every pose of scene b maps every
+ * query point to within `radius_cells` cells of where centers[b] (angle, tx, ty) maps it (the caller
+ * guarantees it: |t - t_c| / cell + max |q| * |angle - angle_c| / cell, rounded up, + 1).  A point's
+ * score plane is then read as ONE window of <= (2 r + 3) x (2 r + 6) cells instead of whole, once per
+ * pose chunk (256 x 256 maps: 27 KB instead of 262 KB per point).  Same arithmetic per sample and the
+ * same order of every sum as snap_pose_score_f32 (mask_oob = 0): the scores are the same bits.
+ * snap_pose_score_window_supported: 1 when the window of that radius fits the kernel's LDS buffers
+ * (else call snap_pose_score_f32).  A pose outside the promised radius reads a clamped cell of the
+ * window (a wrong score, never out of bounds). */
+size_t snap_pose_score_window_workspace_bytes(int32_t B, int32_t Nq, int32_t P, int32_t X, int32_t Y);
+int32_t snap_pose_score_window_supported(int32_t X, int32_t Y, int32_t radius_cells);
+int snap_pose_score_window_f32(const float* sim, const float* poses, const float* centers,
+                               int32_t radius_cells, const float* q_xy, const uint8_t* valid_q,
+                               int32_t B, int32_t Nq, int32_t X, int32_t Y, int32_t P, float cell_size,
+                               float* scores, void* workspace, size_t workspace_bytes, void* stream);
 
 /* corr[B,P*retries*2,3] -> poses[B,P,3] = (angle, tx, ty) of map_t_query:
  * most distance-consistent retry, 2-point Kabsch (pose_estimation.py:146-165). */

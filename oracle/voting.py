@@ -61,11 +61,20 @@ def template_matching(q, q_valid, m, m_valid, do_padding=True, min_overlap=0.05)
       out[r,a,b] = sum_{i,j,d} q[r,i,j,d] * m_pad[a+i, b+j, d].
   Computed here with an explicit sliding-window view (direct form).
   """
-  assert do_padding, 'only the padded (default) mode is restated'
   dtype = q.dtype
   R, H, W, D = q.shape
   Hm, Wm = m.shape[:2]
-  m_pad = np.pad(m, ((Hm - 1,) * 2, (Wm - 1,) * 2, (0, 0)), mode='edge')
+  if do_padding:
+    m_pad = np.pad(m, ((Hm - 1,) * 2, (Wm - 1,) * 2, (0, 0)), mode='edge')
+  else:
+    # :86 mode='full': the true convolution of the flipped template with the UNPADDED map at every
+    # overlap = the same correlation over the map zero-extended by (H - 1, W - 1): [Hm+H-1, Wm+W-1].
+    # The reference pads the validity mask by (Hm - 1, Wm - 1) whatever the mode (:93-96), so its
+    # count has another shape and `jnp.where` fails to broadcast: only min_overlap=None runs there.
+    if min_overlap is not None:
+      raise ValueError('template_matching(do_padding=False): the overlap count of the reference has '
+                       'the padded shape (pose_exhaustive_voting.py:93-101); pass min_overlap=None')
+    m_pad = np.pad(m, ((H - 1,) * 2, (W - 1,) * 2, (0, 0)), mode='constant')
   Ho, Wo = m_pad.shape[0] - H + 1, m_pad.shape[1] - W + 1
   scores = np.empty((R, Ho, Wo), dtype)
   win = np.lib.stride_tricks.sliding_window_view(m_pad, (H, W), axis=(0, 1))

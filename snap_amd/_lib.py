@@ -187,6 +187,7 @@ SIGNATURES = {
         [ptr, ptr, c_int, c_i64, c_int, c_int, ptr, ptr, ptr, ptr, c_int, c_int,
          c_float, ptr, ptr],
     ),
+    'snap_sim_rowstats_bytes': (c_size, [c_int, c_int]),
     'snap_sim_softmax_f32': (
         c_int,
         [ptr, ptr, c_int, c_int, c_int, c_int, c_float, c_int, ptr, ptr, ptr,
@@ -229,6 +230,10 @@ SIGNATURES = {
     'snap_poses_from_corr_f32': (
         c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr, ptr]
     ),
+    'snap_pose_score_window_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    'snap_pose_score_window_supported': (c_int, [c_int, c_int, c_int]),
+    'snap_pose_score_window_f32': (c_int, [ptr, ptr, ptr, c_int, ptr, ptr, c_int, c_int, c_int, c_int, c_int,
+                                           c_float, ptr, ptr, c_size, ptr]),
     'snap_pose_score_workspace_bytes': (c_size, [c_int, c_int, c_int, c_int, c_int]),
     'snap_pose_score_f32': (
         c_int,
@@ -332,7 +337,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 

@@ -160,11 +160,13 @@ __global__ __launch_bounds__(256) void vertical_pool_max_arg_kernel(
     for (int e = 0; e < 4; ++e) {
       acc[e] = snap_max_nan(snap_max_nan(acc[e], va[e]), vb[e]);
       if (za >= 0) {
-        tk[e] = va[e] > tb[e] ? (256 | za) : (va[e] == tb[e] ? tk[e] + 256 : tk[e]);
+        // (a first -inf EQUALS the initial bound: it becomes the recorded level, as the recompute path of the
+        //  VJP shares the gradient among the -inf holders)
+        tk[e] = va[e] > tb[e] ? (256 | za) : (va[e] == tb[e] ? ((tk[e] & 255) == 255 ? (256 | za) : tk[e] + 256) : tk[e]);
         tb[e] = va[e] > tb[e] ? va[e] : tb[e];
       }
       if (zb >= 0) {
-        tk[e] = vb[e] > tb[e] ? (256 | zb) : (vb[e] == tb[e] ? tk[e] + 256 : tk[e]);
+        tk[e] = vb[e] > tb[e] ? (256 | zb) : (vb[e] == tb[e] ? ((tk[e] & 255) == 255 ? (256 | zb) : tk[e] + 256) : tk[e]);
         tb[e] = vb[e] > tb[e] ? vb[e] : tb[e];
       }
     }

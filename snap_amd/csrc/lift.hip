@@ -27,7 +27,8 @@ struct LiftArgs {
   // BEV-tiled traversal (d.grid_y > 0): the voxels of an 8 x 8 block of columns (all levels) are
   // the unit an XCD works on
   int tile_cpt;      // 256-voxel chunks per tile (0 = linear order)
-  int tile_log;      // log2 of the tile's side in columns
+  int tile_log;      // log2 of the tile's extent along y, in columns (8 x 8; narrower grids: 64 / ty x ty)
+  int tile_log_x;    // ... along x
   int tiles_x, tiles_y;
   int64_t tiles_total;
   SnapLiftDesc d;
@@ -460,7 +461,8 @@ __device__ __forceinline__ void split_row_quad(const f32x4& v, unsigned (&hi)[2]
 #ifndef SNAP_LIFT_ABLATE
 #define SNAP_LIFT_ABLATE 0     // timing experiments only (wrong results): 1 = no row stores (and what
 #endif                         // feeds them: dead code), 2 = no feature loads, 4 = rows stored into a 4 MB
-                               // window (every instruction stays, no HBM write traffic)
+                               // window (every instruction stays, no HBM write traffic), 8 = phase A alone,
+                               // 16 = no depth-score loads in phase A (tap records)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pair_lo(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f32x2 pair_hi(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
@@ -511,9 +513,9 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
     const int Z = d.grid_z, GY = d.grid_y, GX = d.N / (GY * Z);
     const int l = chunk * 256 + hw * 32 + hl;
     const int col = l / Z, z = l - col * Z;
-    const int tl = a.tile_log, ts = 1 << tl;
-    const int X = tx * ts + (col >> tl), Y = ty * ts + (col & (ts - 1));
-    const bool in = col < ts * ts && X < GX && Y < GY;
+    const int tl = a.tile_log, ts = 1 << tl, tsx = 1 << a.tile_log_x;
+    const int X = tx * tsx + (col >> tl), Y = ty * ts + (col & (ts - 1));
+    const bool in = col < tsx * ts && X < GX && Y < GY;
     my_gv = in ? (((int64_t)b * GX + X) * GY + Y) * Z + z : -1;
   } else {
     if (a.xcd_group > 0) {
@@ -620,6 +622,10 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
         const uint32_t o11 = o10 + (o01 - o00);
         const uint32_t c0 = fdb_ + ((pk >> 10) & 0xff) * 4u, c1 = fdb_ + ((pk >> 18) & 0xff) * 4u;
         const char* fb_ = reinterpret_cast<const char*>(a.f);
+#if SNAP_LIFT_ABLATE & 16
+        const float t00 = w00, t01 = w01, t10 = w10, t11 = w11, u00 = w00, u01 = w01, u10 = w10, u11 = w11;
+        (void)fb_; (void)o11; (void)c0; (void)c1;
+#else
         const float t00 = *reinterpret_cast<const float*>(fb_ + (o00 + c0));
         const float t01 = *reinterpret_cast<const float*>(fb_ + (o01 + c0));
         const float t10 = *reinterpret_cast<const float*>(fb_ + (o10 + c0));
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
         const float u01 = *reinterpret_cast<const float*>(fb_ + (o01 + c1));
         const float u10 = *reinterpret_cast<const float*>(fb_ + (o10 + c1));
         const float u11 = *reinterpret_cast<const float*>(fb_ + (o11 + c1));
+#endif
         const float wb1 = wbs[hw][hl][0], wb0 = 1.f - wb1;
         const float s0 = ((w00 * t00 + w01 * t01) + w10 * t10) + w11 * t11;
         const float s1 = ((w00 * u00 + w01 * u01) + w10 * u10) + w11 * u11;
@@ -665,6 +672,9 @@ __global__ __launch_bounds__(256, KMAX > 1 ? 6 : 8) void lift_pool_batched_kerne
     order[pos] = (uint8_t)threadIdx.x;
   }
   __syncthreads();
+#if SNAP_LIFT_ABLATE & 8
+  return;                      // (timing: phase A alone)
+#endif
 
   // ---------------- phase B: lane = channel quad ----------------
   // The kernel is VALU-bound (PMC r02: VALU 72 % busy), so phase B spends as few instructions
@@ -889,7 +899,7 @@ static int lift_pool_launch(const SnapLiftDesc* desc, const float* f_images,
     return SNAP_ERR_BAD_SHAPE;
   const int nsel = d.K == 0 ? d.V : d.K;
   constexpr int xcd_group = 64;     // workgroups per XCD-owned chunk (section 5h of DESIGN.md: settled)
-  LiftArgs a{xcd_group, 0, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr, tap_recs};
+  LiftArgs a{xcd_group, 0, 3, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, nullptr, nullptr, nullptr, tap_recs};
   const int64_t total = (int64_t)d.B * d.N;
   if (total > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   if (d.grid_y < 0 || d.grid_z < 0 || (d.grid_y > 0) != (d.grid_z > 0)) return SNAP_ERR_BAD_SHAPE;
@@ -904,11 +914,15 @@ static int lift_pool_launch(const SnapLiftDesc* desc, const float* f_images,
   dim3 bgrid((unsigned)(snap_cdiv(nb, round) * round));
   if (d.grid_y > 0) {                // (no grid hint = linear voxel order)
     const int GX = d.N / (d.grid_y * d.grid_z);
-    constexpr int tile_log = 3;      // 8 x 8-column tiles (4 x 4 / 16 x 16 measured slower)
-    const int ts = 1 << tile_log;
+    // 8 x 8-column tiles (4 x 4 / 16 x 16 measured slower); a grid narrower than 8 columns (the query
+    // frustum is [Nq, 1, Z]) takes 64 columns as (64 / ty) x ty -- square tiles left 7 of 8 lanes dead there
+    int tile_log = 3;
+    while (tile_log > 0 && (1 << (tile_log - 1)) >= d.grid_y) --tile_log;
+    const int ts = 1 << tile_log, tsx = 64 / ts;
     a.tile_log = tile_log;
-    a.tile_cpt = (ts * ts * d.grid_z + 255) / 256;
-    a.tiles_x = (GX + ts - 1) / ts;
+    a.tile_log_x = 6 - tile_log;
+    a.tile_cpt = (tsx * ts * d.grid_z + 255) / 256;
+    a.tiles_x = (GX + tsx - 1) / tsx;
     a.tiles_y = (d.grid_y + ts - 1) / ts;
     a.tiles_total = (int64_t)d.B * a.tiles_x * a.tiles_y;
     bgrid = dim3((unsigned)(snap_cdiv(a.tiles_total, 8) * 8 * a.tile_cpt));
@@ -963,7 +977,7 @@ static int launch_obs(const SnapLiftDesc& d, const float* f_images, const float*
   if ((int64_t)d.B * d.N > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
   const int nsel = d.K == 0 ? d.V : d.K;
   if (nsel > 8) return SNAP_ERR_UNSUPPORTED;
-  LiftArgs a{0, 0, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, obs_out, obs_feat, obs_in};
+  LiftArgs a{0, 0, 3, 3, 0, 0, 0, d, f_images, cam, Rt, points, pooled, valid, obs_out, obs_feat, obs_in, nullptr};
   const dim3 grid((unsigned)snap_cdiv((int64_t)d.B * d.N, 8));
   if (nsel <= 1) hipLaunchKernelGGL(lift_pool_kernel<1>, grid, dim3(256), 0, s, a);
   else if (nsel <= 4) hipLaunchKernelGGL(lift_pool_kernel<4>, grid, dim3(256), 0, s, a);

@@ -1471,6 +1471,158 @@ __global__ __launch_bounds__(PS_THREADS) void pose_score_band_db_kernel(const Sc
   }
 }
 
+// Windowed variant for pose sets whose samples of a point all fall within `rad` cells of ONE centre
+// pose per scene -- the 41 x 41 x 41 refinement lattice of grid_refinement (pose_estimation.py:168-205:
+// +-4 m, +-5 degrees around the RANSAC pose).  The general kernels above stream the WHOLE score plane of
+// every point through LDS once per pose chunk (256 x 256 maps: 262 KB per point and chunk, nine chunks
+// for 68 921 poses = 11 GB per scene); here a point's plane is read as ONE window of <= (2 rad + 3) rows x
+// (2 rad + 6) columns around the centre pose's image of the point (~80 x 84 cells = 27 KB): 0.14 GB per
+// pose chunk.  Arithmetic per sample (coordinates from the same cell-unit pose table, clamp, floor, the
+// two lerps) and the order of the sums (points ascending inside the same point chunks, chunks ascending in
+// the reduce pass) are those of pose_score_band_db_kernel: the scores are the same bits.  No validity
+// mask (MASK launches take the general kernels).
+struct ScoreWinArgs {
+  ScoreArgs s;
+  const float* ctable;   // [B, 4] the centre poses as cell-unit affine maps (pose_table_cells_kernel)
+  int rad;               // every sample of a point lies within `rad` cells of the centre's
+  int WR, WC;            // window rows / columns (WC % 4 == 0)
+};
+constexpr int PS_WIN_ROUNDS = 3;          // 16-byte DMA chunks per thread and window (max): 48 KB per buffer
+constexpr int PS_WIN_PPT = 12;
+
+template <int PPT>
+__global__ __launch_bounds__(PS_THREADS) void pose_score_window_kernel(const ScoreWinArgs w) {
+  extern __shared__ float plane[];
+  const ScoreArgs& a = w.s;
+  const int b = blockIdx.z;
+  const int chunk = blockIdx.y;
+  const int NCH = gridDim.y;
+  const int p_base = blockIdx.x * (PS_THREADS * PPT);
+  const int tid = threadIdx.x;
+  const int X = a.X, Y = a.Y;
+  const int XY = X * Y;
+  const int WR = w.WR, WC = w.WC, rad = w.rad;
+  const int S = WC + 4;                    // LDS row pitch (floats): the window row + one pad chunk
+  const int CRP = (WC >> 2) + 1;           // 16-byte chunks per LDS row
+  const int PLANE = WR * S;
+  f32x2 pcs[PPT], pt[PPT];
+  float acc[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    acc[k] = 0.f;
+    const f32x4 t = reinterpret_cast<const f32x4*>(a.table)[(int64_t)b * a.P + min(p, a.P - 1)];
+    pcs[k] = f32x2{t[0], t[1]};
+    pt[k] = f32x2{t[2], t[3]};
+  }
+  const f32x4 ct = reinterpret_cast<const f32x4*>(w.ctable)[b];
+  const int n_begin = chunk * a.points_per_chunk;
+  const int n_end = min(n_begin + a.points_per_chunk, a.Nq);
+  const float Xf = (float)X, Yf = (float)Y, Sf = (float)S;
+  const f32x2 lim1 = {Xf - 1.f, Yf - 1.f}, lim2 = {Xf - 2.f, Yf - 2.f}, zero2 = {0.f, 0.f};
+  const uint8_t* vq = a.valid_q + (int64_t)b * a.Nq;
+
+  // chunk -> float offset relative to the window's first cell (window-invariant)
+  int goff[PS_WIN_ROUNDS];
+#pragma unroll
+  for (int k = 0; k < PS_WIN_ROUNDS; ++k) {
+    const int c = k * PS_THREADS + tid;
+    const int row = c / CRP;
+    goff[k] = row * Y + 4 * min(c - row * CRP, CRP - 2);
+  }
+  const int nchunks = WR * CRP;
+  // first cell (row0, col0) of the window of point (qx, qy): the centre pose's cell minus the radius,
+  // one more for the floor, kept inside the plane; col0 % 4 == 0 (16-byte DMA chunks)
+  auto origin = [&](float qx, float qy) {
+    const float cu = fmaf(ct[0], qx, fmaf(ct[1], -qy, ct[2]));
+    const float cv = fmaf(ct[1], qx, fmaf(ct[0], qy, ct[3]));
+    const float ru = fminf(fmaxf(floorf(cu) - (float)(rad + 1), 0.f), (float)(X - WR));
+    const float rv = fminf(fmaxf(floorf(cv) - (float)(rad + 1), 0.f), (float)(Y - WC));
+    return make_int2((int)ru, ((int)rv) & ~3);
+  };
+  auto issue = [&](int n, int2 o, int buf) {
+    const float* src = a.sim + ((int64_t)b * a.Nq + n) * XY + (int64_t)o.x * Y + o.y;
+    float* dst = plane + buf * PLANE;
+#pragma unroll
+    for (int k = 0; k < PS_WIN_ROUNDS; ++k) {
+      const int c = k * PS_THREADS + tid;
+      if (c < nchunks)
+        __builtin_amdgcn_global_load_lds((global_void_t*)(src + goff[k]),
+                                         (lds_void_t*)(dst + 4 * c), 16, 0, 0);
+    }
+  };
+  __shared__ int pt_n[PS_DB_MAX_POINTS];
+  __shared__ float pt_x[PS_DB_MAX_POINTS], pt_y[PS_DB_MAX_POINTS];
+  __shared__ int pt_count;
+  if (tid < 64) {
+    int count = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+      const int n = n0 + tid;
+      const bool v = n < n_end && vq[n] != 0;
+      const unsigned long long m = __ballot(v);
+      if (v) {
+        const int slot = count + __popcll(m & ((1ull << tid) - 1ull));
+        pt_n[slot] = n;
+        pt_x[slot] = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 0];
+        pt_y[slot] = a.q_xy[((int64_t)b * a.Nq + n) * 2 + 1];
+      }
+      count += __popcll(m);
+    }
+    if (tid == 0) pt_count = count;
+  }
+  __syncthreads();
+  const int count = pt_count;
+  int buf = 0;
+  int2 o_cur = make_int2(0, 0);
+  if (count > 0) {
+    o_cur = origin(uniform_f(pt_x[0]), uniform_f(pt_y[0]));
+    issue(pt_n[0], o_cur, 0);
+  }
+  const int off_max = PLANE - S - 2;
+  for (int i = 0; i < count; ++i) {
+    const float qx = uniform_f(pt_x[i]), qy = uniform_f(pt_y[i]);
+    const f32x2 qx2 = {qx, qx}, qyn = {-qy, qy};
+    const int obase = o_cur.x * S + o_cur.y;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // window i landed for every wave; the other buffer is free
+    if (i + 1 < count) {
+      o_cur = origin(uniform_f(pt_x[i + 1]), uniform_f(pt_y[i + 1]));
+      issue(pt_n[i + 1], o_cur, buf ^ 1);
+    }
+    const float* pl = plane + buf * PLANE;
+    // four poses at a time: coordinates, the eight LDS reads, the lerps (per-pose state stays in 5 registers)
+#pragma unroll
+    for (int g = 0; g < PPT; g += 4) {
+      float wu[4], wv[4];
+      const float* q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = g + j;
+        const f32x2 r = __builtin_elementwise_fma(pcs[k], qx2, __builtin_elementwise_fma(pcs[k].yx, qyn, pt[k]));
+        const f32x2 c = __builtin_elementwise_min(__builtin_elementwise_max(r, zero2), lim1);
+        const f32x2 f = __builtin_elementwise_min(f32x2{floorf(c.x), floorf(c.y)}, lim2);
+        wu[j] = c.x - f.x;
+        wv[j] = c.y - f.y;
+        // (a pose outside the promised radius reads a clamped cell of the window: wrong, never out of bounds)
+        q[j] = pl + min(max((int)fmaf(f.x, Sf, f.y) - obase, 0), off_max);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 s0 = {q[j][0], q[j][1]};
+        const f32x2 s1 = {q[j][S], q[j][S + 1]};
+        const f32x2 tt = __builtin_elementwise_fma(f32x2{wu[j], wu[j]}, s1 - s0, s0);
+        acc[g + j] += fmaf(wv[j], tt.y - tt.x, tt.x);
+      }
+    }
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = p_base + k * PS_THREADS + tid;
+    if (p < a.P) a.partial[((int64_t)b * NCH + chunk) * a.P + p] = acc[k];
+  }
+}
+
 __global__ void pose_score_reduce_kernel(const float* __restrict__ partial, int NCH, int P,
                                          int64_t total, float* __restrict__ scores) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*P
@@ -1877,6 +2029,73 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
     // (the banded kernel carries 8 poses per thread; the point chunking and the partial buffer
     // layout [B, nch, P] are the same)
     const int gx = use_band_db ? (P + PS_THREADS * PS_BAND_PPT - 1) / (PS_THREADS * PS_BAND_PPT) : pch;
+    if (hipLaunchKernel(fn, dim3(gx, nch, B), dim3(PS_THREADS), kargs, lds_bytes, s) != hipSuccess)
+      return SNAP_ERR_LAUNCH;
+  }
+  SNAP_CHECK_LAUNCH();
+  const int64_t total = (int64_t)B * P;
+  hipLaunchKernelGGL(pose_score_reduce_kernel, dim3((unsigned)snap_cdiv(total, 256)), dim3(256), 0,
+                     s, (const float*)a.partial, nch, P, total, scores);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" size_t snap_pose_score_window_workspace_bytes(int32_t B, int32_t Nq, int32_t P, int32_t X,
+                                                         int32_t Y) {
+  return snap_pose_score_workspace_bytes(B, Nq, P, X, Y) + (size_t)B * 4 * sizeof(float) + 16;
+}
+
+extern "C" int32_t snap_pose_score_window_supported(int32_t X, int32_t Y, int32_t radius_cells) {
+  if (X < 2 || Y < 4 || Y % 4 != 0 || radius_cells < 0) return 0;
+  const int WR = min(2 * radius_cells + 3, X);
+  const int WC = min((2 * radius_cells + 6 + 3) & ~3, Y);
+  return (int64_t)WR * ((WC >> 2) + 1) <= (int64_t)PS_WIN_ROUNDS * PS_THREADS ? 1 : 0;
+}
+
+extern "C" int snap_pose_score_window_f32(const float* sim, const float* poses, const float* centers,
+                                          int32_t radius_cells, const float* q_xy,
+                                          const uint8_t* valid_q, int32_t B, int32_t Nq, int32_t X,
+                                          int32_t Y, int32_t P, float cell_size, float* scores,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!sim || !poses || !centers || !q_xy || !valid_q || !scores || !workspace) return SNAP_ERR_NULL;
+  if (B <= 0 || Nq <= 0 || X <= 0 || Y <= 0 || P <= 0) return SNAP_ERR_BAD_SHAPE;
+  if (!snap_pose_score_window_supported(X, Y, radius_cells)) return SNAP_ERR_UNSUPPORTED;
+  if (workspace_bytes < snap_pose_score_window_workspace_bytes(B, Nq, P, X, Y)) return SNAP_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return SNAP_ERR_BAD_SHAPE;
+  ScoreWinArgs w;
+  ScoreArgs& a = w.s;
+  a.sim = sim; a.poses = poses; a.q_xy = q_xy; a.valid_q = valid_q; a.map_valid = nullptr;
+  a.B = B; a.Nq = Nq; a.X = X; a.Y = Y; a.P = P;
+  a.cell = cell_size; a.mask_oob = 0;
+  // the point chunking (and so the order of every sum) of snap_pose_score_f32
+  const int pch = score_pose_chunks(P);
+  const int nch = score_chunks(B, Nq, pch);
+  a.points_per_chunk = (Nq + nch - 1) / nch;
+  a.RB = X; a.NB = 1;
+  float* table = static_cast<float*>(workspace);
+  a.table = table;
+  a.partial = table + (size_t)B * P * 4;
+  float* ctable = a.partial + (size_t)B * nch * P;
+  ctable = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ctable) + 15) & ~(uintptr_t)15);
+  w.ctable = ctable;
+  w.rad = radius_cells;
+  w.WR = min(2 * radius_cells + 3, X);
+  w.WC = min((2 * radius_cells + 6 + 3) & ~3, Y);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(pose_table_cells_kernel, dim3((unsigned)snap_cdiv((int64_t)B * P, 256)), dim3(256), 0,
+                     s, poses, (int64_t)B * P, cell_size, table);
+  SNAP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pose_table_cells_kernel, dim3((unsigned)snap_cdiv((int64_t)B, 256)), dim3(256), 0, s,
+                     centers, (int64_t)B, cell_size, ctable);
+  SNAP_CHECK_LAUNCH();
+  const size_t lds_bytes = (size_t)2 * w.WR * (w.WC + 4) * sizeof(float);
+  const void* fn = (const void*)&pose_score_window_kernel<PS_WIN_PPT>;
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+    return SNAP_ERR_LAUNCH;
+  {
+    void* kargs[] = {(void*)&w};
+    const int gx = (P + PS_THREADS * PS_WIN_PPT - 1) / (PS_THREADS * PS_WIN_PPT);
     if (hipLaunchKernel(fn, dim3(gx, nch, B), dim3(PS_THREADS), kargs, lds_bytes, s) != hipSuccess)
       return SNAP_ERR_LAUNCH;
   }

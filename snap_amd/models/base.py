@@ -157,7 +157,8 @@ class BaseModel:
   def __init__(self, config, dataset_meta_data: Dict[str, Any], dtype=torch.float32, engine=None):
     """``dtype`` selects the arithmetic as in the reference (``model_cls(config.model, meta, dtype)``,
     trainer.py:387-397, evaluator.py:179-184): float16 -> IEEE-half operands with f32 accumulation
-    (to be trained under ``DynamicScale``: ``trainer.make_dynamic_scale(model)``), bfloat16 -> bf16
+    (to be trained under ``DynamicScale``: ``trainer.dtype_and_dynamic_scale(config.dtype_str)`` returns the
+    pair; ``train_step`` warns when an fp16 model steps without one), bfloat16 -> bf16
     operands, float32 -> an f32-class engine.  ``engine`` names the engine explicitly where the dtype
     leaves a choice: 'f32' (exact f32 matrix instructions) | 'bf16x3' | 'bf16x6' (split-bf16, f32
     grade; what bench.py measures) for float32.  None with float32: the process default

@@ -257,6 +257,7 @@ class BEVLocalizer(base.Module):
           pose_estimation.grid_refinement_batched(
               pred['map_t_query'], sim_points, q_xy_p, valid_points,
               plane_map.valid, self.grid_map, cfg.mask_score_out_of_bounds,
+              max_point_norm=float(self.q_xy_p.norm(dim=-1).max()),      # (a host constant: the query frustum)
           )
       )
     return pred

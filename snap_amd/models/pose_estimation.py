@@ -75,22 +75,44 @@ def refinement_offsets(device):
           base.device_const('refine_offs_p', device, lambda: torch.tensor(offs_p.astype(np.float32))))
 
 
+LATTICE_WINDOW = True     # tools / tests: False = the lattice through the general scoring kernels (same bits)
+
+
 def grid_refinement_batched(
     j_t_i_init, scores_points_all, i_xy_points, valid_points, valid_j, grid,
-    mask_out_of_bounds,
+    mask_out_of_bounds, max_point_norm=None,
 ):
   """pose_estimation.py:168-205 (vmapped :212-214).
 
-  Returns (Transform2D [B], scores [B, 41, 41, 41]).
+  Returns (Transform2D [B], scores [B, 41, 41, 41]).  ``max_point_norm``: an upper bound of |i_xy_points|
+  in metres (a host constant of the query frustum); with it the lattice is scored from one small window of
+  every point's score plane (``ops.pose_score_window``: the lattice poses move a point by at most
+  range_p * sqrt(2) + |point| * range_r around the initial pose's image of it) -- same bits as the general
+  kernels, a tenth of the plane traffic.
   """
   dev = scores_points_all.device
   offs_r, offs_p = refinement_offsets(dev)
-  samples = ops.refine_lattice(j_t_i_init.packed(), offs_r, offs_p)
-  scores = ops.pose_score(
-      scores_points_all, samples, i_xy_points.contiguous(),
-      valid_points.contiguous(), valid_j.contiguous(), grid.cell_size,
-      mask_oob=mask_out_of_bounds,
-  )
+  init = j_t_i_init.packed()
+  samples = ops.refine_lattice(init, offs_r, offs_p)
+  X, Y = scores_points_all.shape[-2:]
+  radius = None
+  if LATTICE_WINDOW and max_point_norm is not None and not mask_out_of_bounds:
+    # |R(a0 + da) q + t0 + R(a0) d - (R(a0) q + t0)| <= |d| + |q| * 2 sin(|da| / 2) <= |d| + |q| |da|
+    range_p = float(np.abs(np.mgrid[slice(-4, 4 + 0.2, 0.2)]).max())
+    range_r = float(np.deg2rad(np.abs(np.mgrid[slice(-5, 5 + 0.25, 0.25)]).max()))
+    radius = int(np.ceil((range_p * np.sqrt(2.0) + float(max_point_norm) * range_r) / grid.cell_size * 1.0001)) + 1
+    if not ops.pose_score_window_supported(X, Y, radius):
+      radius = None
+  if radius is not None:
+    scores = ops.pose_score_window(
+        scores_points_all, samples, init.contiguous(), radius, i_xy_points.contiguous(),
+        valid_points.contiguous(), grid.cell_size)
+  else:
+    scores = ops.pose_score(
+        scores_points_all, samples, i_xy_points.contiguous(),
+        valid_points.contiguous(), valid_j.contiguous(), grid.cell_size,
+        mask_oob=mask_out_of_bounds,
+    )
   best = ops.argmax_rows(scores).to(torch.int64)
   B = samples.shape[0]
   refined = samples[torch.arange(B, device=dev), best]

@@ -68,8 +68,15 @@ STACK_SHIFT = 4
 STACK_MIN_CELLS = 64 * 64      # below this the plain form is already launch-bound
 # 'auto': the frequency-domain form from FFT_MIN_CELLS map cells on (below, the direct form is a
 # handful of launch-bound kernels), 'fft' / 'direct': forced.  Per call: the ``method`` argument.
+# Two behaviours of the frequency-domain form differ from the direct form and are why 'direct' stays
+# selectable: (1) the transforms are GLOBAL -- one NaN / Inf anywhere in the map features (valid cell or
+# not: the reference does not mask them out of the scores either) or in the query plane makes every
+# score of every rotation NaN, where the direct form poisons only the placements that overlap the bad
+# cell; (2) its workspace grows with R * D * N^2 (0.9 GB of first-axis spectra at R = 36, 256^2, D = 32):
+# 'auto' falls back to the direct form beyond FFT_WORKSPACE_BUDGET bytes.
 VOTING_METHOD = 'auto'
 FFT_MIN_CELLS = 64 * 64
+FFT_WORKSPACE_BUDGET = 16 << 30
 
 
 def _use_fft(method, R, q_hw, D, m_hw):
@@ -83,7 +90,8 @@ def _use_fft(method, R, q_hw, D, m_hw):
     if not ok:
       raise ValueError(f'voting method fft: map {m_hw} is beyond the transform sizes of voting_fft.hip')
     return True
-  return ok and m_hw[0] * m_hw[1] >= FFT_MIN_CELLS
+  return (ok and m_hw[0] * m_hw[1] >= FFT_MIN_CELLS
+          and ops.voting_fft_workspace_bytes(R, q_hw[0], q_hw[1], D, m_hw[0], m_hw[1]) <= FFT_WORKSPACE_BUDGET)
 
 
 def _stacked(R, q_hw):

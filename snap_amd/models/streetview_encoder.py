@@ -69,18 +69,22 @@ class StreetViewEncoder(base.Module):
     copying the crop (268 MB at C2) the single Dense of the projection gathers its rows from the padded
     tensor through the engine's row list (``rows_in``: a constant index table, uploaded once)."""
     cfgp = self.proj_mlp.config
+    self.last_projection_path = 'copy'         # (tests assert 'rows' at the bench geometry: no silent 268 MB copy)
     if (train or f.is_contiguous() or not f.is_cuda or len(cfgp.layers) != 1 or not ops.NATIVE_GLUE
         or base.needs_grad(f, p['Dense_0']['kernel'], p['Dense_0']['bias'])):
       return self.proj_mlp(p, f.contiguous(), train)
     src = f._base
     B, V, h, w, C = f.shape
     st = f.stride()
+    # image pitch of the flattened (scene, view) index; the stride of a size-1 axis carries no information
+    # (the query slice has V = 1: its st[1] is arbitrary)
+    pitch = st[1] if V > 1 else (st[0] if B > 1 else h * st[2])
     ok = (src is not None and src.is_contiguous() and src.dtype == torch.float32 and st[4] == 1 and st[3] == C
-          and st[2] % C == 0 and st[1] % st[2] == 0 and st[0] == V * st[1]
+          and st[2] % C == 0 and pitch % st[2] == 0 and (B == 1 or V == 1 or st[0] == V * pitch)
           and (f.storage_offset() - src.storage_offset()) % C == 0)
     if not ok:
       return self.proj_mlp(p, f.contiguous(), train)
-    Wp, HpWp = st[2] // C, st[1] // C
+    Wp, HpWp = st[2] // C, pitch // C
     off = (f.storage_offset() - src.storage_offset()) // C
     M = B * V * h * w
     total = src.numel() // C
@@ -97,6 +101,7 @@ class StreetViewEncoder(base.Module):
     d = p['Dense_0']
     y = ops.dense(src.reshape(total, C), d['kernel'], d['bias'], cin=d['kernel'].shape[0], prologue=pro,
                   rows_in=rows, row_count=count)
+    self.last_projection_path = 'rows'
     return y[:M].reshape(B, V, h, w, y.shape[-1])     # (rows past M are never written nor read)
 
   def _fused_pool_ok(self, params, f_images):

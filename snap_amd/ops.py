@@ -1538,7 +1538,7 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
   stats = torch.empty((B, Nq, NC, 2), dtype=torch.float32, device=dev)
   prob = torch.empty_like(sim) if want_prob else None
   rowstats = (
-      torch.empty((B, Nq, 2), dtype=torch.float32, device=dev)
+      torch.empty(lib.snap_sim_rowstats_bytes(B, Nq) // 4, dtype=torch.float32, device=dev).view(B, Nq, 2)
       if (want_prob or want_rowstats) else None
   )
   if math is None:
@@ -1668,6 +1668,33 @@ def pose_score(sim, poses, q_xy, valid_q, map_valid, cell_size, mask_oob=False):
   return scores
 
 
+def pose_score_window_supported(X, Y, radius_cells):
+  """True where ``pose_score_window`` takes a window of that radius on an [X, Y] score plane."""
+  return bool(_lib.load().snap_pose_score_window_supported(int(X), int(Y), int(radius_cells)))
+
+
+def pose_score_window(sim, poses, centers, radius_cells, q_xy, valid_q, cell_size):
+  """``pose_score`` (mask_oob=False) for poses clustered around ``centers`` [B,3]: every pose of scene b maps
+  every query point to within ``radius_cells`` cells of where centers[b] maps it (the refinement lattice of
+  grid_refinement).  Same bits as ``pose_score``; a point's score plane is read as one small window."""
+  lib = _lib.load()
+  _f32(sim, 'sim'); _f32(poses, 'poses'); _f32(centers, 'centers'); _f32(q_xy, 'q_xy'); _mask(valid_q, 'valid_q')
+  B, Nq, X, Y = sim.shape
+  P = poses.shape[1]
+  if tuple(centers.shape) != (B, 3):
+    raise ValueError('pose_score_window: centers [B, 3]')
+  wsb = lib.snap_pose_score_window_workspace_bytes(B, Nq, P, X, Y)
+  ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device=sim.device)
+  scores = torch.empty((B, P), dtype=torch.float32, device=sim.device)
+  WR, WC = min(2 * radius_cells + 3, X), min((2 * radius_cells + 9) & ~3, Y)
+  with _region('pose_score', 0.0, 4.0 * (B * Nq * WR * WC + poses.numel() + scores.numel())):
+    st = lib.snap_pose_score_window_f32(
+        _p(sim), _p(poses), _p(centers), int(radius_cells), _p(q_xy), _p(valid_q), B, Nq, X, Y, P,
+        float(cell_size), _p(scores), _p(ws), ws.numel() * 4, _stream())
+  _lib.check(st, 'snap_pose_score_window_f32')
+  return scores
+
+
 def refine_lattice(init, offs_r, offs_p):
   """init [B,3]; offs_r [nr] (rad); offs_p [np] (m) -> [B, nr*np*np, 3]."""
   lib = _lib.load()
@@ -1773,6 +1800,11 @@ def pad_map(m, mvalid):
 def voting_fft_supported(R, H, W, D, Hm, Wm):
   """True where ``voting_fft`` takes the geometry (<= 1024 transform points per axis)."""
   return _lib.load().snap_voting_fft_workspace_bytes(R, H, W, D, Hm, Wm) > 0
+
+
+def voting_fft_workspace_bytes(R, H, W, D, Hm, Wm):
+  """Bytes of device workspace one ``voting_fft`` call allocates (0: unsupported geometry)."""
+  return int(_lib.load().snap_voting_fft_workspace_bytes(R, H, W, D, Hm, Wm))
 
 
 def voting_fft(templates, tvalid, m, mvalid, tcount, threshold, use_overlap=True):

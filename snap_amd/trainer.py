@@ -224,10 +224,21 @@ def train_step(state: TrainState, batch, *, model, lr_fn: Callable, max_grad_nor
   state.rng += 1
   rank = torch.distributed.get_rank(group) if sdist._world(group) > 1 else 0
   sampling_rng = state.rng * 7919 + rank            # bind the stream to the device
+  model_engine = getattr(model, 'engine', None)
   if precision is None:
-    precision = getattr(model, 'engine', None)
+    precision = model_engine
   if precision is not None and precision not in ops.ENGINES:
     raise ValueError(f'train_step: precision={precision!r}')
+  if model_engine is not None and precision != model_engine:
+    # Module.apply enters the model's own engine scope, which would silently win over this argument
+    raise ValueError(f'train_step: precision={precision!r} contradicts the engine the model was built with '
+                     f'({model_engine!r}: BaseModel(dtype=..., engine=...)); build the model for the engine '
+                     'or pass precision=None')
+  if precision == 'fp16' and state.dynamic_scale is None:
+    import warnings
+    warnings.warn("train_step: IEEE-half engine ('fp16') without TrainState.dynamic_scale -- the reference trains "
+                  'float16 under DynamicScale(minimum_scale=256) (trainer.py:391-392); see '
+                  'trainer.dtype_and_dynamic_scale', RuntimeWarning, stacklevel=2)
   loss_scale = state.dynamic_scale.scale if state.dynamic_scale is not None else None
   # a per-thread scope; the autograd nodes carry it into the backward thread (autograd._engine_scoped)
   with ops.engine_scope(precision):

@@ -716,6 +716,10 @@ def test_vertical_pool_max_bwd_from_the_forward_record(Z, D, ties):
   vol[1, 0, 0, :, 3] = -math.inf
   valid = torch.rand((3, 5, 4, Z), generator=g) > 0.4
   valid[0, 0] = False
+  # a column whose ONLY valid level holds -inf in a channel: that level is the recorded maximum (count 1)
+  valid[2, 1, 1] = False
+  valid[2, 1, 1, Z // 3] = True
+  vol[2, 1, 1, Z // 3, 5] = -math.inf
   dplane = torch.randn((3, 5, 4, D), generator=g)
   plane0, pv0 = ops.vertical_pool(G(vol), G(valid), 'max')
   plane1, pv1, arg = ops.vertical_pool(G(vol), G(valid), 'max', want_arg=True)

@@ -78,6 +78,8 @@ def test_c2_whole_scene_vs_oracle_every_engine():
   engines = ENGINES + ['bf16x3+plane']      # + the fused fusion-MLP / max-pool kernel (bench default)
   res = fullsize_parity.run(engines, views=4, image=512)
   ref, ob, cfg = res['ref'], res['oracle_batch'], res['cfg']
+  # the projection Dense read the 544 -> 512 crop through the row list at this geometry (no 268 MB copy)
+  assert all(v == 'rows' for v in res['projection_path'].values()), res['projection_path']
   for m in engines:
     r = res['per_math'][m]
     print(f'[parity] C2 scene, engine {m}: ' + ', '.join(
@@ -218,6 +220,37 @@ def test_c4_voting_fft_equals_the_direct_form_at_256():
   assert int(torch.argmax(a)) == int(torch.argmax(b))
 
 
+def test_c4_voting_fft_against_the_float64_numpy_fft_checker():
+  """C4 size (256^2 map, R = 36, D = 32, N = 768 = 3 * 4^4 transform points per axis, partial validity
+  on both planes): ``method='fft'`` against tests/fft_reference.py -- a float64 numpy / scipy FFT
+  correlation that shares nothing with the HIP formulations and is itself pinned to oracle/voting.py
+  at the small geometries (tests/test_oracle_pins.py).  -inf mask EXACT, every finite score within
+  2e-5 x max |score|, argmax equal."""
+  import fft_reference
+  H, D, R = 256, 32, 36
+  DEV = helpers.DEVICE
+  rng = np.random.default_rng(256)
+  t = rng.standard_normal((R, H, H, D)).astype(np.float32)
+  tv = rng.random((R, H, H)) > 0.2
+  t = t * tv[..., None]
+  fm = rng.standard_normal((H, H, D)).astype(np.float32)
+  vm = rng.random((H, H)) > 0.1
+  vm[:90, :70] = False            # (an unobserved corner: placements with too little overlap exist)
+  tv[:, 200:, :] = False
+  t = t * tv[..., None]
+  got = pev.template_matching(*[torch.tensor(a).to(DEV) for a in (t, tv, fm, vm)], method='fft').cpu().numpy()
+  want = fft_reference.template_matching_fft64(t, tv, fm, vm)
+  assert got.shape == want.shape == (R, 2 * H - 1, 2 * H - 1)
+  fw, fg = np.isfinite(want), np.isfinite(got)
+  assert (fw == fg).all(), int((fw != fg).sum())
+  assert 0 < int((~fw).sum()) < fw.size and (got[~fg] == -np.inf).all()
+  scale = float(np.abs(want[fw]).max())
+  err = float(np.abs(got[fg] - want[fw]).max())
+  print(f'[voting fft vs float64 numpy.fft @256] max |d| {err:.3e}  max |score| {scale:.3e}  masked {int((~fw).sum())}')
+  assert err <= 2e-5 * scale
+  assert int(np.argmax(np.where(fg, got, -np.inf))) == int(np.argmax(np.where(fw, want, -np.inf)))
+
+
 def test_c4_voting_matching_dim_64_beyond_the_presplit_engine():
   """matching_dim 64 at 256^2: the shift-stacked template bank (259 x 259 x 64 per filter) is beyond
   the pre-split engine's 32-bit offsets (``snap_conv2d_presplit_supported`` = 0), so the voting must
@@ -312,6 +345,17 @@ def test_c4_pose_scoring_256_full_point_set_and_lattice():
   init = geometry.Transform2D(gt[:, 0].contiguous(), gt[:, 1:].contiguous())
   ref_t, lat = pose_estimation.grid_refinement_batched(init, sim, q_xy, vq, mv, grid, False)
   assert lat.shape == (B, 41, 41, 41)
+  # the lattice through ONE WINDOW per point (ops.pose_score_window: what BEVLocalizer runs, given the
+  # frustum's largest point norm) -- the same bits as the general kernels, also for an initial pose near
+  # the map's corner (windows clipped at two borders) and with a third of the points invalid
+  qn = float(q_xy_p.norm(dim=-1).max())
+  vq3 = vq.clone(); vq3[:, ::3] = False
+  corner = geometry.Transform2D(torch.tensor([2.5], device=DEV), torch.tensor([[1.0, 50.5]], device=DEV))
+  for ini, vv in ((init, vq), (corner, vq), (init, vq3)):
+    rw, lw = pose_estimation.grid_refinement_batched(ini, sim, q_xy, vv, mv, grid, False, max_point_norm=qn)
+    rg, lg = pose_estimation.grid_refinement_batched(ini, sim, q_xy, vv, mv, grid, False)
+    assert torch.equal(lw, lg), float((lw - lg).abs().max())
+    assert torch.equal(rw.packed(), rg.packed())
   best = tuple(int(i) for i in np.unravel_index(int(torch.argmax(lat[0])), (41, 41, 41)))
   assert best == (20, 20, 20)
   assert abs(float(lat[0, 20, 20, 20]) - float(s[0, 777])) <= 1e-5 * abs(float(s[0, 777]))

@@ -783,7 +783,8 @@ def test_lift_pool_full_width_and_maxdist():
   helpers.report('lift pooled fd128', pg.cpu()[~mism], pw[~mism], atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize('X,Y,Z,K,V', [(11, 13, 7, 0, 3), (16, 8, 60, 0, 4), (9, 24, 60, 2, 5), (8, 8, 3, 0, 1)])
+@pytest.mark.parametrize('X,Y,Z,K,V', [(11, 13, 7, 0, 3), (16, 8, 60, 0, 4), (9, 24, 60, 2, 5), (8, 8, 3, 0, 1),
+                                       (301, 1, 60, 0, 1), (70, 3, 7, 0, 3), (33, 2, 9, 2, 4)])
 def test_lift_bev_tiled_traversal_is_a_pure_reordering(X, Y, Z, K, V):
   """grid_yz: the 8 x 8-column-block traversal (one block per XCD at a time) writes the same
   rows, bit for bit, as the linear voxel order -- grids that are not multiples of the block,
@@ -1068,7 +1069,7 @@ def test_mlp2_pool_max(cin, stride, H, D, Z, ncols, relu_in):
 
 @pytest.mark.parametrize('X,Y,Z,K,V,fd,nb,H', [(16, 8, 60, 0, 4, 128, 32, 256), (9, 24, 60, 2, 5, 128, 32, 256),
                                                (8, 8, 3, 0, 1, 128, 32, 256), (11, 13, 7, 0, 3, 32, 8, 64),
-                                               (40, 24, 60, 0, 4, 128, 32, 256)])
+                                               (40, 24, 60, 0, 4, 128, 32, 256), (301, 1, 60, 0, 1, 128, 32, 256)])
 def test_lift_inside_the_consumer(X, Y, Z, K, V, fd, nb, H):
   """Tap records (snap_lift_pool_records_f32) + the gather inside the fused MLP / pool kernel
   (snap_mlp2_pool_max_gather_f32): voxels with ONE visible observation never get a `pooled` row, and the
@@ -1478,6 +1479,14 @@ def test_voting_fft_rejects_maps_beyond_its_transform_sizes():
   assert pev._use_fft('auto', 4, (343, 343), 32, (343, 343)) is False     # falls back to the direct form
   assert pev._use_fft('auto', 4, (8, 8), 4, (8, 8)) is False              # small maps stay direct
   assert pev._use_fft('auto', 36, (256, 256), 32, (256, 256)) is True
+  # a workspace beyond the budget sends 'auto' back to the direct form ('fft' stays forced)
+  keep, pev.FFT_WORKSPACE_BUDGET = pev.FFT_WORKSPACE_BUDGET, 1 << 20
+  try:
+    assert ops.voting_fft_workspace_bytes(36, 256, 256, 32, 256, 256) > 1 << 20
+    assert pev._use_fft('auto', 36, (256, 256), 32, (256, 256)) is False
+    assert pev._use_fft('fft', 36, (256, 256), 32, (256, 256)) is True
+  finally:
+    pev.FFT_WORKSPACE_BUDGET = keep
   del q
 
 
@@ -1975,6 +1984,37 @@ def test_template_matching_without_padding_is_the_zero_extended_correlation():
   with pytest.raises(ValueError):
     pev.template_matching(torch.from_numpy(q).to(DEV), torch.from_numpy(qv).to(DEV),
                           torch.from_numpy(m).to(DEV), torch.from_numpy(mv).to(DEV), do_padding=False)
+
+
+@pytest.mark.parametrize('X,Y,Nq,B,rad', [(64, 64, 300, 2, 9), (40, 72, 77, 3, 30), (256, 256, 500, 1, 39), (33, 36, 50, 1, 4)])
+def test_pose_score_window_is_pose_score_bit_for_bit(X, Y, Nq, B, rad):
+  """snap_pose_score_window_f32: poses clustered around one centre pose per scene, scored from one window
+  of every point's plane -- the bits of snap_pose_score_f32 (same sample arithmetic, same order of sums):
+  windows clipped by the plane's borders, windows as large as the plane, invalid points, a scene whose centre
+  lies outside the map."""
+  cell = 0.2
+  g = torch.Generator().manual_seed(X + Nq)
+  sim = torch.randn((B, Nq, X, Y), generator=g).to(DEV)
+  q_xy = ((torch.rand((B, Nq, 2), generator=g) - 0.5) * 6.0).to(DEV)
+  qn = float(q_xy.norm(dim=-1).max())
+  centers = torch.stack([torch.rand(B, generator=g) * 6.28, torch.rand(B, generator=g) * X * cell,
+                         torch.rand(B, generator=g) * Y * cell], -1)
+  centers[0, 1:] = torch.tensor([-1.0, Y * cell + 0.7])          # (a centre outside the map)
+  # poses within the promised radius: |dt| + |q| |da| <= (rad - 1) cells
+  P = 3000
+  budget = (rad - 1) * cell
+  da = (torch.rand(B, P, generator=g) - 0.5) * 2 * min(0.3 * budget / max(qn, 1e-3), 0.5)
+  room = budget - qn * da.abs().max()
+  ang = torch.rand(B, P, generator=g) * 6.28
+  rr = torch.rand(B, P, generator=g) * float(room)
+  poses = torch.stack([centers[:, None, 0] + da, centers[:, None, 1] + rr * torch.cos(ang),
+                       centers[:, None, 2] + rr * torch.sin(ang)], -1).contiguous().to(DEV)
+  vq = (torch.rand(B, Nq, generator=g) > 0.2).to(DEV)
+  assert ops.pose_score_window_supported(X, Y, rad)
+  want = ops.pose_score(sim, poses, q_xy, vq, None, cell)
+  got = ops.pose_score_window(sim, poses, centers.to(DEV), rad, q_xy, vq, cell)
+  assert torch.equal(got, want), float((got - want).abs().max())
+  assert not ops.pose_score_window_supported(2048, 2048, 400)     # (a window beyond the LDS buffers)
 
 
 def test_ransac_sample_reading_the_chunk_scores_from_sim():

@@ -456,6 +456,7 @@ def test_projection_gathers_the_cropped_image_features(engine):
     for f in (fm, fq):
       assert not f.is_contiguous() and f._base is not None
       got = sv._project(p, f, False)
+      assert sv.last_projection_path == 'rows'          # (the row-list path ran, not the copying fallback)
       want = sv.proj_mlp(p, f.contiguous(), False)
       assert got.shape == want.shape
       assert torch.equal(got, want), float((got - want).abs().max())

@@ -47,6 +47,11 @@ def test_abi_library_loads_and_exports_every_symbol():
   raw = ctypes.CDLL(_lib.LIB_PATH)
   for name in _header_symbols():
     assert hasattr(raw, name), f'{name} declared in snap_hip.h but not exported'
+  # ... and the reverse inclusion: nothing named snap_* leaves the library undeclared
+  import subprocess
+  nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+  exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith('snap_')}
+  assert exported == _header_symbols(), sorted(exported ^ _header_symbols())
   assert lib.snap_abi_version() == _lib.ABI_VERSION
   assert lib.snap_build_arch() == b'gfx950'
   assert lib.snap_status_string(0) == b'ok'
@@ -631,3 +636,24 @@ def test_voting_fft_rotated_entry_on_the_cpu_emulation():
     fin = np.isfinite(want)
     assert (fin == np.isfinite(out)).all()
     np.testing.assert_allclose(out[fin], want[fin], atol=5e-6)
+
+
+def test_train_step_rejects_a_precision_that_contradicts_the_models_engine():
+  """``Module.apply`` enters the model's own engine scope, so an explicit ``precision=`` that
+  differs from ``model.engine`` would be silently ignored -- it raises instead (before any compute); an
+  fp16 model stepping without a DynamicScale warns."""
+  import types as pytypes
+  import warnings
+  from snap_amd import trainer
+  state = trainer.TrainState.create({'w': torch.zeros(3)})
+  model = pytypes.SimpleNamespace(engine='bf16x3')
+  with pytest.raises(ValueError, match='contradicts the engine'):
+    trainer.train_step(state, {}, model=model, lr_fn=lambda s: 1e-3, precision='f32')
+  with pytest.raises(ValueError, match='precision='):
+    trainer.train_step(state, {}, model=model, lr_fn=lambda s: 1e-3, precision='no-such-engine')
+  half = pytypes.SimpleNamespace(engine='fp16')
+  with warnings.catch_warnings(record=True) as rec:
+    warnings.simplefilter('always')
+    with pytest.raises(Exception):                      # (no GPU / no flax_model: the step itself cannot run here)
+      trainer.train_step(state, {}, model=half, lr_fn=lambda s: 1e-3)
+  assert any('dynamic_scale' in str(w.message) for w in rec)

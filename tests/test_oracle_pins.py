@@ -88,6 +88,51 @@ def test_template_matching_matches_scipy_convolve():
   np.testing.assert_allclose(s[fin], ref[fin], atol=1e-12)
 
 
+def test_template_matching_without_padding_matches_scipy_full_convolve():
+  """pose_exhaustive_voting.py:86 mode='full' (do_padding=False): the oracle's zero-extended correlation
+  against the literal scipy.signal.convolve(mode='full'); with an overlap threshold the reference's
+  count has the padded shape and cannot broadcast (:93-101): the oracle raises."""
+  rng = np.random.default_rng(12)
+  R, H, W, Hm, Wm, D = 3, 6, 7, 9, 5, 2
+  q = rng.standard_normal((R, H, W, D))
+  qv = rng.random((R, H, W)) > 0.2
+  m = rng.standard_normal((Hm, Wm, D))
+  mv = rng.random((Hm, Wm)) > 0.1
+  s = o_voting.template_matching(q, qv, m, mv, do_padding=False, min_overlap=None)
+  ref = np.stack([
+      sum(sig.convolve(q[r, ::-1, ::-1, d], m[..., d], mode='full', method='direct') for d in range(D))
+      for r in range(R)
+  ]) / qv.sum((-1, -2), keepdims=True)
+  assert s.shape == ref.shape == (R, Hm + H - 1, Wm + W - 1)
+  np.testing.assert_allclose(s, ref, atol=1e-12)
+  with pytest.raises(ValueError):
+    o_voting.template_matching(q, qv, m, mv, do_padding=False)
+
+
+@pytest.mark.parametrize('H,W,Hm,Wm,R,D', [(16, 16, 16, 16, 8, 8), (24, 24, 24, 24, 12, 32), (22, 22, 22, 22, 7, 34),
+                                           (10, 13, 12, 9, 12, 16), (43, 43, 43, 43, 4, 8), (30, 30, 30, 30, 4, 4)])
+@pytest.mark.parametrize('overlap', [0.05, None])
+def test_fft64_template_matching_equals_the_oracle(H, W, Hm, Wm, R, D, overlap):
+  """tests/fft_reference.py (float64 numpy / scipy FFT correlation, the checker of the frequency-domain
+  voting at 256 x 256 cells) == oracle/voting.template_matching (direct sliding-window sum) at the small
+  geometries the GPU test runs: -inf mask exact, finite scores to 1e-10 (both float64 here)."""
+  import fft_reference
+  rng = np.random.default_rng(500 + H + R + D)
+  t = rng.standard_normal((R, H, W, D))
+  tv = rng.random((R, H, W)) > 0.2
+  t = t * tv[..., None]
+  fm = rng.standard_normal((Hm, Wm, D))
+  vm = rng.random((Hm, Wm)) > 0.1
+  want = o_voting.template_matching(t, tv, fm, vm, min_overlap=overlap)
+  got = fft_reference.template_matching_fft64(t, tv, fm, vm, min_overlap=overlap)
+  assert got.shape == want.shape
+  fw, fg = np.isfinite(want), np.isfinite(got)
+  assert (fw == fg).all()
+  if overlap is not None:
+    assert 0 < int((~fw).sum()) and (want[~fw] == got[~fg]).all()
+  np.testing.assert_allclose(got[fg], want[fw], atol=1e-10)
+
+
 def test_exhaustive_identity_known_answer():
   """identity pose => argmax at (0, H-1, W-1)."""
   rng = np.random.default_rng(3)

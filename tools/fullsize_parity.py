@@ -102,7 +102,7 @@ def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
   batch = synthetic.make_batch(1, meta['grid'], views, (image, image), seed=seed)
   params_dev = helpers.params_to_device(variables['params'], dev)
   batch_dev = helpers.batch_to_device(batch, dev)
-  preds, t_hip = {}, {}
+  preds, t_hip, paths = {}, {}, {}
   inject = None
   try:
     for math in maths:
@@ -115,6 +115,7 @@ def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
                               debug=True, pose_samples=inject)
       torch.cuda.synchronize()
       t_hip[math] = time.perf_counter() - t0
+      paths[math] = getattr(loc.bev_mapper.streetview_encoder, 'last_projection_path', None)
       if inject is None:
         smp = preds[math]['map_t_query_samples']
         inject = _geo.Transform2D(smp.angle[:, 1:].contiguous(), smp.t[:, 1:].contiguous())
@@ -133,7 +134,7 @@ def run(maths=('f32',), views=4, image=512, eval_mode=False, seed=21):
   args = _A()
   args.views, args.image, args.eval = views, image, eval_mode
   results = {m: compare(preds[m], ref, args, t_hip[m], t_cpu) for m in maths}
-  return {'per_math': results, 'pred': preds, 'ref': ref, 'oracle_batch': ob, 'cfg': cfg}
+  return {'per_math': results, 'pred': preds, 'ref': ref, 'oracle_batch': ob, 'cfg': cfg, 'projection_path': paths}
 
 
 def main():
