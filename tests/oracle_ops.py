@@ -453,6 +453,26 @@ def pose_score(sim, poses, q_xy, valid_q, map_valid, cell_size, mask_oob=False):
   return _t(out, sim)
 
 
+def pose_score_window_supported(X, Y, radius_cells):
+  return True
+
+
+def pose_score_window(sim, poses, centers, radius_cells, q_xy, valid_q, cell_size):
+  """The windowed scoring is ``pose_score`` on a promise: every pose of a scene maps every query point to
+  within ``radius_cells`` cells of where the scene's centre pose maps it.  The twin CHECKS the promise
+  (the host's radius bound, pose_estimation.grid_refinement_batched) before it scores."""
+  p, c, xy = _np(poses, np.float64), _np(centers, np.float64), _np(q_xy, np.float64)
+
+  def image(th, t):          # [B, P] angles, [B, P, 2] translations -> [B, P, Nq, 2] in cells
+    co, si = np.cos(th)[..., None], np.sin(th)[..., None]
+    x = co * xy[:, None, :, 0] - si * xy[:, None, :, 1] + t[..., 0:1]
+    y = si * xy[:, None, :, 0] + co * xy[:, None, :, 1] + t[..., 1:2]
+    return np.stack([x, y], -1) / cell_size
+  far = np.abs(image(p[..., 0], p[..., 1:]) - image(c[:, None, 0], c[:, None, 1:])).max()
+  assert far <= radius_cells, (far, radius_cells)
+  return pose_score(sim, poses, q_xy, valid_q, None, cell_size)
+
+
 def refine_lattice(init, offs_r, offs_p):
   i, r, p = _np(init, DTYPE), _np(offs_r, DTYPE), _np(offs_p, DTYPE)
   rr, xx, yy = np.meshgrid(r, p, p, indexing='ij')
@@ -518,6 +538,7 @@ def template_finalize(raw, cnt, tcount, R, threshold, use_overlap=True):
 ALL_OPS = [
     'conv2d', 'dense', 'weight_standardize', 'weight_standardize_multi', 'group_norm_stats', 'group_norm_apply',
     'max_pool_3x3s2', 'pooled_stride', 'lift_pool', 'project_points', 'vertical_pool', 'mlp2_pool_max',
-    'plane_fuse_match', 'sim_softmax', 'ransac_sample', 'poses_from_corr', 'pose_score',
+    'plane_fuse_match', 'sim_softmax', 'ransac_sample', 'poses_from_corr', 'pose_score', 'pose_score_window',
+    'pose_score_window_supported',
     'refine_lattice', 'argmax_rows', 'rotate_templates', 'pad_map', 'template_finalize',
 ]
