@@ -169,7 +169,7 @@ def source_digest():
   return h.hexdigest()[:16]
 
 
-TRAFFIC_FILES = ('r05_c2_hbm_traffic.json', 'r04_c2_hbm_traffic.json', 'r03_c2_hbm_traffic.json', 'r02_c2_hbm_traffic.json',
+TRAFFIC_FILES = ('r06_c2_hbm_traffic.json', 'r05_c2_hbm_traffic.json', 'r04_c2_hbm_traffic.json', 'r03_c2_hbm_traffic.json', 'r02_c2_hbm_traffic.json',
                  'r01_c2_hbm_traffic.json')   # newest round first
 
 
@@ -402,9 +402,10 @@ def main(argv=None, emit=True):
   for kv in args.tune:
     from snap_amd import ops as _ops
     k, v = kv.split('=', 1)
-    if not hasattr(_ops, k):
-      raise SystemExit(f'--tune: snap_amd.ops has no switch {k}')
-    setattr(_ops, k, type(getattr(_ops, k))(int(v)))
+    if k not in _ops._TUNING_DEFAULTS:
+      raise SystemExit(f'--tune: snap_amd.ops.Tuning has no switch {k}')
+    cur = getattr(_ops, k)
+    setattr(_ops, k, v if (cur is None or isinstance(cur, str)) else type(cur)(int(v)))     # (the process default)
 
   rank = int(os.environ.get('RANK', 0))
   world = int(os.environ.get('WORLD_SIZE', 1))

@@ -27,10 +27,11 @@ def _engine_scoped(cls):
 
   def forward(ctx, *args):
     ctx._snap_engine = ops.precision()
+    ctx._snap_tuning = ops.tuning()          # (the Tuning object travels with the engine)
     return fwd(ctx, *args)
 
   def backward(ctx, *grads):
-    with ops.engine_scope(ctx._snap_engine):
+    with ops.engine_scope(ctx._snap_engine, tuning=ctx._snap_tuning):
       return bwd(ctx, *grads)
 
   cls.forward = staticmethod(forward)

@@ -75,9 +75,6 @@ def refinement_offsets(device):
           base.device_const('refine_offs_p', device, lambda: torch.tensor(offs_p.astype(np.float32))))
 
 
-LATTICE_WINDOW = True     # tools / tests: False = the lattice through the general scoring kernels (same bits)
-
-
 def grid_refinement_batched(
     j_t_i_init, scores_points_all, i_xy_points, valid_points, valid_j, grid,
     mask_out_of_bounds, max_point_norm=None,
@@ -96,7 +93,7 @@ def grid_refinement_batched(
   samples = ops.refine_lattice(init, offs_r, offs_p)
   X, Y = scores_points_all.shape[-2:]
   radius = None
-  if LATTICE_WINDOW and max_point_norm is not None and not mask_out_of_bounds:
+  if ops.LATTICE_WINDOW and max_point_norm is not None and not mask_out_of_bounds:
     # |R(a0 + da) q + t0 + R(a0) d - (R(a0) q + t0)| <= |d| + |q| * 2 sin(|da| / 2) <= |d| + |q| |da|
     range_p = float(np.abs(np.mgrid[slice(-4, 4 + 0.2, 0.2)]).max())
     range_r = float(np.deg2rad(np.abs(np.mgrid[slice(-5, 5 + 0.25, 0.25)]).max()))

@@ -6,6 +6,7 @@ current stream.  There is no CPU or PyTorch fallback: tensors must live on a
 ROCm device and the shared library must be built, otherwise these raise.
 """
 import contextlib
+import sys
 import ctypes
 import threading
 import weakref
@@ -22,6 +23,110 @@ POOLING = {'max': 0, 'sum': 1, 'mean': 2}
 SIM_CHUNK = 64
 
 
+
+# ----------------------------------------------------------------------------------------------------
+# Tuning: every tuning / test switch of the kernel wrappers in ONE object.  None of them is needed to
+# run the models and none changes a result beyond summation order; tools and tests flip them to A/B
+# kernels.  The object in force is per thread and scoped (``tuning_scope(...)`` /
+# ``engine_scope(engine, tuning=...)``); outside any scope it is the process default, of which the
+# module attributes of the same names (``ops.CONV_TILE = '64x64'``) are thin aliases -- reading
+# ``ops.CONV_TILE`` anywhere gives the value in force in the calling thread.
+#   OVERLAP_AERIAL     the aerial encoder on a second HIP stream next to the StreetView encoder
+#   POOLED_SPLIT       the lift hands `pooled` to the fused MLP / pool kernel pre-split (LDS-DMA A operand)
+#   CLASS_ROWS         ... classed by observation count (single-observation rows carry no variance slabs)
+#   LIFT_IN_CONSUMER   ... and class-1 rows are never written: a 32-byte tap record, the four image taps
+#                      blended inside the fused MLP / pool kernel (the lift inside the consumer)
+#   MLP_GATHER_XCD_GROUP  runs of 128-row tiles of the gathered class per XCD (its L2 keeps their taps)
+#   NATIVE_GLUE        image padding / voxel-centre grid as native passes instead of torch fill + copies
+#   USE_PRESPLIT       bottleneck 3x3 / closing 1x1 convs read their input through gn_norm_split (off:
+#                      the pre-split convs are 10-25 percent faster, the extra pass costs what they gain)
+#   CONV_TILE / CONV_BK / CONV_NO_HALO / CONV_NO_RS / CONV_RS_NSPLIT / CONV_RS_FORCE / CONV_NO_WS /
+#   CONV_NO_PLAIN / CONV_RAW_RING   forced tile ('128x128' | '128x64' | '64x128' | '64x64'), f32 K-slab
+#                      depth, and which body a conv launch takes (tests pin every body against the others)
+#   SPLITK_STATS / USE_SPLITK / USE_FUSED_GN_STATS / GN_STATS_BOTH   GroupNorm statistics from the conv
+#                      epilogues / split-K reduce passes vs the stand-alone kernels
+#   MLP_POOL_NO_RING / MLP_POOL_WIDE   fused MLP / pool kernel variants (x_split = 5 / 3)
+#   USE_PRESPLIT_VOTING / FUSED_TEMPLATE_PACK / PS_RES_INIT / PS_TILE   pre-split GEMM engine (direct-form voting)
+#   SIM_GENERAL_KERNEL  tests: pin the general similarity kernel (the full-chunk kernel is bit-identical)
+#   LATTICE_WINDOW     the refinement lattice scored from one window per point (pose_score_window; same bits)
+# ----------------------------------------------------------------------------------------------------
+_TUNING_DEFAULTS = {
+    'OVERLAP_AERIAL': True,
+    'POOLED_SPLIT': True,
+    'CLASS_ROWS': True,
+    'LIFT_IN_CONSUMER': True,
+    'MLP_GATHER_XCD_GROUP': 8,
+    'NATIVE_GLUE': True,
+    'USE_PRESPLIT': False,
+    'CONV_TILE': None,
+    'CONV_BK': None,
+    'CONV_NO_HALO': False,
+    'CONV_NO_RS': False,
+    'CONV_RS_NSPLIT': 0,
+    'CONV_RS_FORCE': False,
+    'CONV_NO_WS': False,
+    'SPLITK_STATS': True,
+    'MLP_POOL_NO_RING': False,
+    'MLP_POOL_WIDE': False,
+    'CONV_NO_PLAIN': False,
+    'CONV_RAW_RING': False,
+    'USE_PRESPLIT_VOTING': True,
+    'PS_RES_INIT': True,
+    'PS_TILE': 0,
+    'USE_FUSED_GN_STATS': True,
+    'GN_STATS_BOTH': True,
+    'USE_SPLITK': True,
+    'FUSED_TEMPLATE_PACK': True,
+    'SIM_GENERAL_KERNEL': False,
+    'LATTICE_WINDOW': True,
+}
+
+
+class Tuning:
+  """The switches listed above as one value object (``Tuning(CONV_TILE='64x64')``; unknown names raise)."""
+  __slots__ = tuple(_TUNING_DEFAULTS)
+
+  def __init__(self, **kw):
+    for k, v in _TUNING_DEFAULTS.items():
+      object.__setattr__(self, k, kw.pop(k, v))
+    if kw:
+      raise TypeError(f'Tuning: unknown switch(es) {sorted(kw)}')
+
+  def replace(self, **kw):
+    vals = {k: getattr(self, k) for k in _TUNING_DEFAULTS}
+    for k in kw:
+      if k not in vals:
+        raise TypeError(f'Tuning: unknown switch {k!r}')
+    vals.update(kw)
+    return Tuning(**vals)
+
+  def __repr__(self):
+    diff = {k: getattr(self, k) for k, v in _TUNING_DEFAULTS.items() if getattr(self, k) != v}
+    return 'Tuning(' + ', '.join(f'{k}={v!r}' for k, v in diff.items()) + ')'
+
+
+_DEFAULT_TUNING = Tuning()
+_TUNING_TLS = threading.local()
+
+
+def tuning():
+  """The ``Tuning`` in force in this thread: the innermost scope's, else the process default."""
+  t = getattr(_TUNING_TLS, 'tuning', None)
+  return _DEFAULT_TUNING if t is None else t
+
+
+@contextlib.contextmanager
+def tuning_scope(base=None, **overrides):
+  """Run the enclosed ops under ``base`` (default: the tuning in force) with ``overrides`` applied.
+  Per thread, re-entrant; autograd nodes carry it into the backward thread with the engine."""
+  prev = getattr(_TUNING_TLS, 'tuning', None)
+  _TUNING_TLS.tuning = (base if base is not None else tuning()).replace(**overrides)
+  try:
+    yield _TUNING_TLS.tuning
+  finally:
+    _TUNING_TLS.tuning = prev
+
+
 def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -29,17 +134,11 @@ def _stream():
 # A second HIP stream for work that does not depend on the main chain (the aerial encoder runs
 # next to the StreetView encoder: its deep stages are launches of 19-73 workgroups on a 256-CU
 # part).  SNAP_OVERLAP_AERIAL=0 keeps everything on one stream.
-OVERLAP_AERIAL = True
 # the lift hands `pooled` to the fused MLP / pool kernel pre-split (LDS-DMA A operand); 0: as f32 rows
-POOLED_SPLIT = True
 # ... and classed by their number of observations (single-observation rows carry no variance slabs); 0: off
-CLASS_ROWS = True
 # ... and the class-1 rows (one observation) are never written: the lift leaves a 32-byte tap record and the
 # fused MLP / pool kernel blends the four image taps itself (the lift inside the consumer); 0: rows through HBM
-LIFT_IN_CONSUMER = True
-MLP_GATHER_XCD_GROUP = 8      # runs of 128-row tiles of the gathered class per XCD (its L2 keeps their taps)
 # image padding and the voxel-centre grid as one native pass each instead of torch fill + strided copies; 0: torch
-NATIVE_GLUE = True
 _SIDE_STREAMS = {}
 
 
@@ -270,25 +369,9 @@ class PreSplit:
 # 'bf16x3' engine.  Measured at C2 (tools/unit_bench.py, profiles/r03_unit_bench.json): the
 # pre-split convolutions are 10-25 % faster than the fused-prologue ones, the extra pass over the
 # activation costs what they gain -- off by default; the engine's own user is the exhaustive voting.
-USE_PRESPLIT = False
 # Tests / tuning tools: force the conv engines' output tile ('128x128' | '128x64' | '64x128' |
 # '64x64'; travels as SnapConvDesc.tile_hint), the f32 engine's K-slab depth (16 | 32) and the
 # im2col body for every 3x3 convolution of the split engine.  None / False = the engines' choice.
-CONV_TILE = None
-CONV_BK = None
-CONV_NO_HALO = False
-CONV_NO_RS = False      # tools / tests: the tiled body also where a stationary 1x1 kernel applies
-CONV_RS_NSPLIT = 0      # tools: forced column split of the row-stationary kernel (0 = automatic)
-CONV_RS_FORCE = False   # tests: the stationary kernels also below their row-count threshold
-CONV_NO_WS = False      # tools / tests: no weights-stationary kernel (the row-stationary one where it applies)
-SPLITK_STATS = True     # split-K launches of the split / bf16 / fp16 engines emit GroupNorm partial sums from their reduce pass
-MLP_POOL_NO_RING = False  # tuning / tests: pre-split rows on the two-stage GEMM0 loop instead of the three-stage ring (x_split = 5)
-MLP_POOL_WIDE = False     # tuning / tests: pre-split rows on the 256-row mlp2_pool kernel (x_split = 3; measured slower, mlp_pool.hip)
-CONV_NO_PLAIN = False   # tests / tools: the general A loader also for 1x1 / stride-1 / unpadded layers
-CONV_RAW_RING = False   # tests / tools: the raw-row LDS-DMA ring body (conv_raw.hip) for the K >= 256 1x1 layers (same bits; not faster)
-USE_PRESPLIT_VOTING = True   # exhaustive voting: the correlation GEMM on the pre-split engine
-PS_RES_INIT = True       # the residual of the closing 1x1 conv is loaded into the accumulators
-PS_TILE = 0              # 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles
 
 
 def gn_norm_split(y, gamma, beta, *, groups=32, eps=1e-5, want_stats=False):
@@ -298,7 +381,7 @@ def gn_norm_split(y, gamma, beta, *, groups=32, eps=1e-5, want_stats=False):
   fused = getattr(y, '_snap_gn_partial', None)
   N, H, W, C = y.shape
   if (precision() != 'bf16x3' or fused is None or fused[2] or groups != 32
-      or C % 16 or C > 2048 or not USE_FUSED_GN_STATS):
+      or C % 16 or C > 2048 or not tuning().USE_FUSED_GN_STATS):
     return None
   lib = _lib.load()
   _f32(y, 'y'); _f32(gamma, 'gamma'); _f32(beta, 'beta')
@@ -334,11 +417,11 @@ def presplit(x):
 
 def _stationary_mode():
   """SnapConvDesc.tile_hint // 1 000 000: which 1x1 bodies of the split engine may run."""
-  if CONV_NO_RS:
+  if tuning().CONV_NO_RS:
     return 1
-  if CONV_RS_FORCE:
-    return 4 if CONV_NO_WS else 2
-  return 3 if CONV_NO_WS else 0
+  if tuning().CONV_RS_FORCE:
+    return 4 if tuning().CONV_NO_WS else 2
+  return 3 if tuning().CONV_NO_WS else 0
 
 
 class PackedWeights:
@@ -527,8 +610,8 @@ def conv2d(
       N, H, W, Cin, Cs, KH, KW, stride, pt, pl, Ho, Wo, Cout, Cout if out_stride is None else int(out_stride), prologue,
       epi, float(in_affine[0]), float(in_affine[1]),
   )
-  if CONV_TILE:
-    bm, bn = (int(v) for v in CONV_TILE.split('x'))
+  if tuning().CONV_TILE:
+    bm, bn = (int(v) for v in tuning().CONV_TILE.split('x'))
     d.tile_hint = bm * 1000 + bn
   d.tile_hint += 1000000 * _stationary_mode()
   M = N * Ho * Wo
@@ -549,18 +632,18 @@ def conv2d(
     ex = _lib.SnapConvExtras(_pv(rows_in), _pv(rows_out), _pv(row_count), None, 0, 0, None, 0,
                              None, 0)
   else:
-    pst = (PS_TILE if ps_tile is None else int(ps_tile)) if ps else 0
+    pst = (tuning().PS_TILE if ps_tile is None else int(ps_tile)) if ps else 0
     if ps:
-      wbytes = lib.snap_conv2d_presplit_workspace_bytes(ctypes.byref(d), pst) if USE_SPLITK else 0
+      wbytes = lib.snap_conv2d_presplit_workspace_bytes(ctypes.byref(d), pst) if tuning().USE_SPLITK else 0
     elif qparts == 2 and lib.snap_conv2d_stationary_kind(ctypes.byref(d), qparts):
       wbytes = 0        # a stationary-operand kernel takes the launch: it never splits K
     else:
-      wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if (USE_SPLITK and yh is None) else 0
+      wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if (tuning().USE_SPLITK and yh is None) else 0
     if wbytes:   # small-M / deep-K layer: split K
       kws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, kws.data_ptr(), wbytes, None, 0)
       half_engine = math in ('bf16', 'fp16') and Cs % 4 == 0 and Cin % 4 == 0 and Cin >= 4 and not ps
-      if emit_gn_stats is not None and (qparts >= 2 or half_engine) and SPLITK_STATS:
+      if emit_gn_stats is not None and (qparts >= 2 or half_engine) and tuning().SPLITK_STATS:
         # the reduce pass of the split / bf16 / fp16 engine emits the partial sums (per 32-row slab)
         pbytes = lib.snap_conv2d_splitk_gn_partial_bytes(ctypes.byref(d))
         if pbytes:
@@ -628,13 +711,13 @@ def conv2d(
     if ps:
       ex.x_presplit = 1
       ex.ps_tile = pst
-      ex.ps_res_init = int(PS_RES_INIT if res_init is None else bool(res_init))
-  if CONV_BK or CONV_NO_HALO or CONV_RS_NSPLIT or CONV_NO_PLAIN or CONV_RAW_RING:
+      ex.ps_res_init = int(tuning().PS_RES_INIT if res_init is None else bool(res_init))
+  if tuning().CONV_BK or tuning().CONV_NO_HALO or tuning().CONV_RS_NSPLIT or tuning().CONV_NO_PLAIN or tuning().CONV_RAW_RING:
     if ex is None:
       ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
-    ex.bk_hint = int(CONV_BK or 0)
-    ex.tune_flags = (int(bool(CONV_NO_HALO)) | 2 * int(bool(CONV_RAW_RING)) | 8 * int(bool(CONV_NO_PLAIN))
-                     | ((int(CONV_RS_NSPLIT) & 15) << 4))
+    ex.bk_hint = int(tuning().CONV_BK or 0)
+    ex.tune_flags = (int(bool(tuning().CONV_NO_HALO)) | 2 * int(bool(tuning().CONV_RAW_RING)) | 8 * int(bool(tuning().CONV_NO_PLAIN))
+                     | ((int(tuning().CONV_RS_NSPLIT) & 15) << 4))
   kflops = 2.0 * KH * KW * Cin * Cout
   if row_count is None:
     flops = kflops * M
@@ -1051,7 +1134,7 @@ def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split
                  lambda: f'M{M}r_K{cin}_H{H}_N{D}_Z{Z}_gather'):
       st = lib.snap_mlp2_pool_max_gather_f32(
           _p(x), M, cin, Cs, _p(index), _p(count), _p(index_z), _p(count_z), _p(f_img), f_img.numel() * 4,
-          f_img.shape[-2], f_img.shape[-1], fd, _p(recs), int(MLP_GATHER_XCD_GROUP), _p(w0p), w0p.numel() * 2,
+          f_img.shape[-2], f_img.shape[-1], fd, _p(recs), int(tuning().MLP_GATHER_XCD_GROUP), _p(w0p), w0p.numel() * 2,
           _p(b0), H, _p(w1p), w1p.numel() * 2, _p(b1), D, Z, ncols, _p(plane), _p(pvalid), _stream())
     _lib.check(st, 'snap_mlp2_pool_max_gather_f32')
     return plane, pvalid
@@ -1061,7 +1144,7 @@ def mlp2_pool_max(x, row_mask, w0, b0, w1, b1, *, cin, Z, relu_in=False, x_split
     st = lib.snap_mlp2_pool_max_classes_f32(
         _p(x), M, cin, Cs, _p(index), _p(count), _p(index_z) if index_z is not None else None,
         _p(count_z) if count_z is not None else None, zlo, zn, _p(w0p), w0p.numel() * 2, _p(b0), H,
-        _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), (3 if MLP_POOL_WIDE else 5 if MLP_POOL_NO_RING else 1) if x_split else 0, Z, ncols, _p(plane),
+        _p(w1p), w1p.numel() * 2, _p(b1), D, int(relu_in), (3 if tuning().MLP_POOL_WIDE else 5 if tuning().MLP_POOL_NO_RING else 1) if x_split else 0, Z, ncols, _p(plane),
         _p(pvalid), _stream())
   _lib.check(st, 'snap_mlp2_pool_max_classes_f32')
   return plane, pvalid
@@ -1131,9 +1214,7 @@ def weight_standardize_bwd_multi(ws, dwss, eps=1e-10):
   return outs
 
 
-USE_FUSED_GN_STATS = True
 # the last unit of a ResNet stage emits the statistics of relu(y) too (its FPN level reads them)
-GN_STATS_BOTH = True
 # The arithmetic of every conv / dense ("engine"):
 #   'f32'    the exact f32 matrix-core path (inference, parity);
 #   'bf16x3' / 'bf16x6'  f32-grade: 2 / 3 bf16 parts per operand, f32 accumulate (conv_split.hip);
@@ -1156,9 +1237,14 @@ def precision():
 
 
 @contextlib.contextmanager
-def engine_scope(engine):
-  """Run the enclosed ops on ``engine`` (None: no change).  Per thread, re-entrant; two models of
-  different precision interleave freely in one process."""
+def engine_scope(engine, tuning=None):
+  """Run the enclosed ops on ``engine`` (None: no change) and, if given, under the ``Tuning`` object
+  ``tuning``.  Per thread, re-entrant; two models of different precision interleave freely in one process."""
+  if tuning is not None:
+    with tuning_scope(tuning):
+      with engine_scope(engine):
+        yield
+    return
   if engine is None:
     yield
     return
@@ -1182,7 +1268,6 @@ def engine_of_dtype(dtype):
   if dtype in (torch.float32, 'float32', 'f32', None):
     return None                      # f32 class: the process default (exact f32 unless configured)
   raise ValueError(f'dtype {dtype!r}: expected float32 | float16 | bfloat16')
-USE_SPLITK = True           # tests flip it: split-K vs single-pass launches   # tests flip it to compare against the stand-alone kernel
 
 
 def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False, want_rstd=False):
@@ -1199,7 +1284,7 @@ def group_norm_stats(x, gamma, *, groups=32, eps=1e-5, relu_first=False, want_rs
   fused = getattr(x, '_snap_gn_partial', None)
   if fused is not None and fused[2] != bool(relu_first):
     fused = getattr(x, '_snap_gn_partial_relu', None) if relu_first else None
-  if fused is not None and fused[2] == bool(relu_first) and groups == 32 and USE_FUSED_GN_STATS:
+  if fused is not None and fused[2] == bool(relu_first) and groups == 32 and tuning().USE_FUSED_GN_STATS:
     partial, tile_rows, _ = fused        # emitted by the conv that produced x
     with _region('group_norm_stats', 0.0, 4.0 * partial.numel()):
       st = lib.snap_group_norm_stats_from_partial_f32(
@@ -1511,8 +1596,6 @@ def plane_fuse_match(planes, valids, pooling='max', Wm=None, bm=None,
 # ----------------------------------------------------------------------------
 # pose
 # ----------------------------------------------------------------------------
-FUSED_TEMPLATE_PACK = True    # exhaustive voting: templates -> split weight image in one pass
-SIM_GENERAL_KERNEL = False   # tests: pin the general split kernel (the full-chunk kernel is bit-identical)
 
 
 def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
@@ -1550,7 +1633,7 @@ def sim_softmax(fq, fm, scale, clip_negative, num_valid, want_prob=False,
     with _region('sim_softmax', 2.0 * B * Nq * XY * Dm,
                  4.0 * (fq.numel() + fm.numel() + sim.numel() + stats.numel())):
       st = lib.snap_sim_softmax_split_f32(
-          _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(bool(clip_negative)) | (2 if SIM_GENERAL_KERNEL else 0),
+          _p(fq), _p(fm), B, Nq, XY, Dm, float(scale), int(bool(clip_negative)) | (2 if tuning().SIM_GENERAL_KERNEL else 0),
           _p(num_valid), _p(row_weight), parts, _p(sim), _p(stats), _p(ws), wsb, _stream())
     _lib.check(st, 'snap_sim_softmax_split_f32')
     return sim, stats, None, None
@@ -1871,3 +1954,15 @@ def template_finalize(raw, cnt, tcount, R, threshold, use_overlap=True):
   )
   _lib.check(st, 'snap_template_finalize_f32')
   return scores
+
+
+# Module attributes of the switches: aliases of the tuning in force (read) / the process default (write).
+class _OpsModule(type(sys)):
+  pass
+
+
+for _name in _TUNING_DEFAULTS:
+  setattr(_OpsModule, _name, property(
+      lambda self, _n=_name: getattr(tuning(), _n),
+      lambda self, v, _n=_name: object.__setattr__(_DEFAULT_TUNING, _n, v)))
+sys.modules[__name__].__class__ = _OpsModule

@@ -657,3 +657,33 @@ def test_train_step_rejects_a_precision_that_contradicts_the_models_engine():
     with pytest.raises(Exception):                      # (no GPU / no flax_model: the step itself cannot run here)
       trainer.train_step(state, {}, model=half, lr_fn=lambda s: 1e-3)
   assert any('dynamic_scale' in str(w.message) for w in rec)
+
+
+def test_tuning_object_scopes_and_module_aliases():
+  """Every tuning / test switch of the kernel wrappers lives in ONE ``ops.Tuning`` object: per-thread scopes
+  (``ops.tuning_scope`` / ``ops.engine_scope(engine, tuning=...)``), the module attributes are aliases (read:
+  the tuning in force; write: the process default), unknown switches raise."""
+  import threading
+  assert ops.tuning() is ops._DEFAULT_TUNING and ops.CONV_TILE is None and ops.LIFT_IN_CONSUMER is True
+  with ops.tuning_scope(CONV_TILE='64x64', MLP_POOL_WIDE=True) as t:
+    assert ops.CONV_TILE == '64x64' and ops.MLP_POOL_WIDE is True and ops.tuning() is t
+    seen = {}
+    th = threading.Thread(target=lambda: seen.update(tile=ops.CONV_TILE))     # another thread: the default
+    th.start(); th.join()
+    assert seen['tile'] is None
+    with ops.engine_scope('bf16x3', tuning=ops.Tuning(CONV_NO_HALO=True)):
+      assert ops.precision() == 'bf16x3' and ops.CONV_NO_HALO is True and ops.CONV_TILE is None
+    assert ops.CONV_TILE == '64x64' and ops.CONV_NO_HALO is False
+  assert ops.CONV_TILE is None and ops.MLP_POOL_WIDE is False
+  ops.CONV_RS_FORCE = True                       # (module attribute = the process default)
+  try:
+    assert ops.tuning().CONV_RS_FORCE is True and repr(ops.tuning()) == 'Tuning(CONV_RS_FORCE=True)'
+  finally:
+    ops.CONV_RS_FORCE = False
+  with pytest.raises(TypeError):
+    ops.Tuning(NO_SUCH_SWITCH=1)
+  with pytest.raises(TypeError):
+    with ops.tuning_scope(NO_SUCH_SWITCH=1):
+      pass
+  # no switch is left as a plain module global (they would shadow nothing, and nothing would read them)
+  assert not [k for k in ops._TUNING_DEFAULTS if k in vars(ops)]
