@@ -1670,22 +1670,25 @@ __global__ void refine_lattice_kernel(const float* __restrict__ init,
   out[i * 3 + 2] = ty0 + (s * ox + c * oy);
 }
 
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ scores, int P,
-                                                          int start, int32_t* __restrict__ idx) {
-  __shared__ float bv[256];
-  __shared__ int bi[256];
+// NT threads per row: long rows (the 68 921-pose refinement lattice with one scene per GPU) take 1024 -- one
+// workgroup is all the parallelism a row has here, and the scan is bound by its loads in flight
+template <int NT>
+__global__ __launch_bounds__(NT) void argmax_rows_kernel(const float* __restrict__ scores, int P,
+                                                         int start, int32_t* __restrict__ idx) {
+  __shared__ float bv[NT];
+  __shared__ int bi[NT];
   const int b = blockIdx.x;
   const float* row = scores + (int64_t)b * P;
   float best = -INFINITY;
   int besti = 0x7fffffff;
-  for (int p = start + threadIdx.x; p < P; p += 256) {
+  for (int p = start + threadIdx.x; p < P; p += NT) {
     const float v = row[p];
     if (v > best || besti == 0x7fffffff) { best = v; besti = p; }
   }
   bv[threadIdx.x] = best;
   bi[threadIdx.x] = besti;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = NT / 2; o > 0; o >>= 1) {
     if (threadIdx.x < o) {
       const float ov = bv[threadIdx.x + o];
       const int oi = bi[threadIdx.x + o];
@@ -2123,8 +2126,12 @@ extern "C" int snap_argmax_rows_f32(const float* scores, int32_t B, int32_t P, i
                                     int32_t* idx, void* stream) {
   if (!scores || !idx) return SNAP_ERR_NULL;
   if (B <= 0 || P <= 0 || start < 0 || start >= P) return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     scores, P, start, idx);
+  if (P - start > 4096)
+    hipLaunchKernelGGL(argmax_rows_kernel<1024>, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       scores, P, start, idx);
+  else
+    hipLaunchKernelGGL(argmax_rows_kernel<256>, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       scores, P, start, idx);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

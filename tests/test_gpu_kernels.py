@@ -1371,6 +1371,14 @@ def test_refine_lattice_and_argmax_ties():
   helpers.report('argmax ties', ig, iw, 0)
   ig, iw = both('argmax_rows', (s, 600))
   helpers.report('argmax start', ig, iw, 0)
+  # long rows (the 68 921-pose lattice) take the 1024-thread kernel: ties -> first index, start offsets
+  g = torch.Generator().manual_seed(5)
+  s = torch.randn(2, 68921, generator=g)
+  s[0, 40000] = 9.0; s[0, 66000] = 9.0
+  s[1, 68920] = 9.0
+  for start in (0, 1, 50000):
+    ig, iw = both('argmax_rows', (s, start))
+    helpers.report(f'argmax long rows start {start}', ig, iw, 0)
 
 
 # ----------------------------------------------------------------------------
