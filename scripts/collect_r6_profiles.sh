@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies what scripts/gpu_r6_final.sh left under gpurun_out/r06p and gpurun_out/r06f into profiles/ (the
-# files profiles/README.md lists for round 5).
+# files profiles/README.md lists for round 6).
 set -eu
 cd "$(dirname "$0")/.."
 cp gpurun_out/r06p/r06_*.json gpurun_out/r06p/r06_*.csv gpurun_out/r06p/r06_*.txt gpurun_out/r06p/r06_*.log profiles/

@@ -7,8 +7,6 @@ mkdir -p gpurun_out/r06f
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/r06f/r06_gpu_suite.log
 tail -4 gpurun_out/r06f/r06_gpu_suite.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/r06f/smoke.log
-timeout 300 python tools/conv_tile_sweep.py > gpurun_out/r06f/r06_conv_tile_sweep.log 2>&1
-timeout 300 python tools/conv_raw_bench.py > gpurun_out/r06f/r06_conv_raw_bench.log 2>&1
 timeout 300 python tools/torch_ops_in_step.py > gpurun_out/r06f/r06_torch_ops_c2.log 2>&1
 timeout 300 python tools/torch_ops_in_step.py --mode train --workload c3 --precision bf16 > gpurun_out/r06f/r06_torch_ops_c3.log 2>&1
 tail -1 gpurun_out/r06f/r06_torch_ops_c2.log
