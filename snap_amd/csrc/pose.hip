@@ -1646,7 +1646,7 @@ inline int score_chunks(int B, int Nq, int pose_chunks) {
   return nch;
 }
 constexpr int PS_PPT = 10;
-constexpr int PS_BAND_PPT = 8;   // the banded kernel keeps per-pose sampling state in registers
+constexpr int PS_BAND_PPT = 10;  // the banded kernel keeps per-pose sampling state in registers (128 VGPRs at 10: 20 001 hypotheses = two pose chunks, not three)
 inline int score_pose_chunks(int P) { return (P + PS_THREADS * PS_PPT - 1) / (PS_THREADS * PS_PPT); }
 
 __global__ void refine_lattice_kernel(const float* __restrict__ init,
@@ -2029,7 +2029,7 @@ extern "C" int snap_pose_score_f32(const float* sim, const float* poses, const f
   SNAP_CHECK_LAUNCH();
   {
     void* kargs[] = {(void*)&a};
-    // (the banded kernel carries 8 poses per thread; the point chunking and the partial buffer
+    // (the banded kernel carries PS_BAND_PPT poses per thread; the point chunking and the partial buffer
     // layout [B, nch, P] are the same)
     const int gx = use_band_db ? (P + PS_THREADS * PS_BAND_PPT - 1) / (PS_THREADS * PS_BAND_PPT) : pch;
     if (hipLaunchKernel(fn, dim3(gx, nch, B), dim3(PS_THREADS), kargs, lds_bytes, s) != hipSuccess)
