@@ -89,6 +89,22 @@ def test_entry_point_argument_validation_codes():
   assert lib.snap_vertical_pool_f32(one, one, one, one, 4, 3, 8, 7, None) == -2   # pooling
   assert lib.snap_pose_score_f32(one, one, one, one, None, 1, 4, 8, 8, 10, 0.2, 0, one, one, 0,
                                  None) == -5                                      # workspace
+  # round-6 entry points: tap records need classed, pre-split, valid-only rows; the gather needs whole
+  # 16-channel slabs of mean | var | score; the scoring window must fit its LDS stage
+  dl = _lib.SnapLiftDesc(1, 1, 8, 8, 160, 128, 32, 64, 0, 0, 272, 1.0, 32.0, -1.0, 1, 1, 0)
+  dl.out_split, dl.valid_rows_only, dl.class_rows = 1, 1, 0
+  assert lib.snap_lift_pool_records_f32(ctypes.byref(dl), one, one, one, one, one, one, one, None) == -2
+  assert lib.snap_lift_pool_records_f32(ctypes.byref(dl), one, one, one, one, one, one, None, None) == -3
+  wb = lib.snap_conv2d_packed_weights_split_bytes(1, 257, 256, 2), lib.snap_conv2d_packed_weights_split_bytes(1, 256, 128, 2)
+  args = lambda fd, cin: (one, 1024, cin, 272, one, one, one, one, one, 4096, 8, 160, fd, one, 0, one, wb[0], one, 256,
+                          one, wb[1], one, 128, 4, 256, one, one, None)
+  assert lib.snap_mlp2_pool_max_gather_f32(*args(120, 257)) == -1                    # feature_dim % 16
+  assert lib.snap_mlp2_pool_max_gather_f32(*args(128, 260)) == -1                    # Cin != 2 fd + 1
+  assert lib.snap_pose_score_window_supported(256, 256, 39) == 1
+  assert lib.snap_pose_score_window_supported(256, 254, 39) == 0                     # Y % 4
+  assert lib.snap_pose_score_window_supported(2048, 2048, 400) == 0                  # beyond the LDS stage
+  assert lib.snap_pose_score_window_f32(one, one, one, 400, one, one, 1, 4, 2048, 2048, 10, 0.2, one, one, 1 << 30,
+                                        None) == -2
 
 
 # -- configs ----------------------------------------------------------------------------
