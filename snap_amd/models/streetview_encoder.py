@@ -192,13 +192,13 @@ class StreetViewEncoder(base.Module):
       if not self.default_fusion:
         kw.update(weighted=self.weighted, use_variance=bool(cfg.fusion_use_variance),
                   add_minmax=bool(cfg.fusion_add_minmax))
+    cam_p = rt_p = None
     if self.depth_mlp is not None:
       pooled, valid = self._lift_with_depth_mlp(params, f_images, cameras, scene_t_view, xyz_flat, K, train)
     else:
-      pooled, valid, *classes = lift(
-          f_images, cameras.packed().to(torch.float32),
-          scene_t_view.packed().to(torch.float32), xyz_flat, **kw,
-      )
+      # (packed once: the lazy volume closure below reuses them)
+      cam_p, rt_p = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
+      pooled, valid, *classes = lift(f_images, cam_p, rt_p, xyz_flat, **kw)
     grid_shape = (-1, *xyz.shape[-4:-1])
     if fused:
       p = params['fusion_mlp']
@@ -214,8 +214,6 @@ class StreetViewEncoder(base.Module):
       # by the unfused chain on the same inputs: lift -> fusion MLP -> mask
       kw_plain = {k: v for k, v in kw.items()
                   if k not in ('valid_rows_only', 'out_split', 'class_rows', 'tap_records')}
-      cam_p, rt_p = cameras.packed().to(torch.float32), scene_t_view.packed().to(torch.float32)
-
       engine = ops.precision()                 # (the engine of THIS apply, whenever the access comes)
 
       def volume(f_images=f_images, xyz_flat=xyz_flat, p=p):
