@@ -63,10 +63,92 @@ __device__ __forceinline__ void weight_std_body(const float* __restrict__ w,
     }
 }
 
+// The same for Cout % 4 == 0 (every StdConv of the encoders): a thread owns a QUAD of columns and 16-byte
+// loads, four of them in flight, 128 k-slices per workgroup -- the scalar body above keeps one 4-byte load in
+// flight per thread and ran at 1.4 TB/s (131 us per encoder and step; this one: see DESIGN.md 5).  Same
+// per-element arithmetic around the same pivots; the k-slices partition the sums differently (fixed order:
+// deterministic; the statistics agree to f64 rounding of other partial sums).
+constexpr int WS4_SLICES = 128;
+
+__device__ __forceinline__ void weight_std_body_v4(const float* __restrict__ w, float* __restrict__ out,
+                                                   int K, int Cout, float eps, int blk) {
+  __shared__ float red4[2][WS4_SLICES][WS_COLS + 1];
+  __shared__ float stat4[2][WS_COLS];
+  const int tq = threadIdx.x & 7, tk = threadIdx.x >> 3;       // 8 column quads x 128 k-slices
+  const int col0 = blk * WS_COLS + 4 * tq;
+  const bool ok = col0 < Cout;                                  // (Cout % 4 == 0: whole quads)
+  const f32x4 piv = ok ? *reinterpret_cast<const f32x4*>(w + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    int k = tk;
+    for (; k + 3 * WS4_SLICES < K; k += 4 * WS4_SLICES) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = *reinterpret_cast<const f32x4*>(w + (int64_t)(k + u * WS4_SLICES) * Cout + col0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = v[u][e] - piv[e];
+          s1[e] += t;
+          s2[e] += t * t;
+        }
+    }
+    for (; k < K; k += WS4_SLICES) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w + (int64_t)k * Cout + col0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = v[e] - piv[e];
+        s1[e] += t;
+        s2[e] += t * t;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red4[0][tk][4 * tq + e] = s1[e];
+    red4[1][tk][4 * tq + e] = s2[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < WS_COLS) {
+    const int tc = threadIdx.x;
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < WS4_SLICES; ++i) {
+      t1 += (double)red4[0][i][tc];
+      t2 += (double)red4[1][i][tc];
+    }
+    const float pv = (blk * WS_COLS + tc) < Cout ? w[blk * WS_COLS + tc] : 0.f;
+    const double m = t1 / (double)K;                 // mean - pivot
+    const double var = t2 / (double)K - m * m;       // mean((v - mean)^2)
+    stat4[0][tc] = (float)((double)pv + m);
+    stat4[1][tc] = sqrtf((float)fmax(var, 0.0) + eps);
+  }
+  __syncthreads();
+  if (ok) {
+    f32x4 mean, denom;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mean[e] = stat4[0][4 * tq + e]; denom[e] = stat4[1][4 * tq + e]; }
+    for (int k = tk; k < K; k += WS4_SLICES) {
+      const int64_t o = (int64_t)k * Cout + col0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w + o);
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = (v[e] - mean[e]) / denom[e];
+      *reinterpret_cast<f32x4*>(out + o) = r;
+    }
+  }
+}
+
+__device__ __forceinline__ bool weight_std_quads_ok(const float* w, const float* out, int Cout) {
+  return (Cout & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+}
+
 __global__ __launch_bounds__(1024) void weight_std_kernel(const float* __restrict__ w,
                                                           float* __restrict__ out, int K,
                                                           int Cout, float eps) {
-  weight_std_body(w, out, K, Cout, eps, blockIdx.x);
+  if (weight_std_quads_ok(w, out, Cout)) weight_std_body_v4(w, out, K, Cout, eps, blockIdx.x);
+  else weight_std_body(w, out, K, Cout, eps, blockIdx.x);
 }
 
 // every StdConv kernel of an encoder in ONE launch: workgroup -> (item, column group of 32) by
@@ -79,7 +161,8 @@ __global__ __launch_bounds__(1024) void weight_std_multi_kernel(const SnapWstdIt
     if (items[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const SnapWstdItem it = items[lo];
-  weight_std_body(it.w, it.out, it.K, it.Cout, eps, blockIdx.x - it.block_begin);
+  if (weight_std_quads_ok(it.w, it.out, it.Cout)) weight_std_body_v4(it.w, it.out, it.K, it.Cout, eps, blockIdx.x - it.block_begin);
+  else weight_std_body(it.w, it.out, it.K, it.Cout, eps, blockIdx.x - it.block_begin);
 }
 
 // ---------------------------------------------------------------------------
