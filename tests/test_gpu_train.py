@@ -449,7 +449,10 @@ def test_models_of_different_dtype_interleave_in_one_process():
     return float(loss), torch.cat([x.reshape(-1) for x in g if x is not None])
 
   alone = {k: finish(fwd_bwd(m)[0]) for k, m in (('f32', m32), ('fp16', m16), ('bf16x3', mx3))}
-  assert alone['f32'][0] != alone['fp16'][0] and alone['f32'][0] != alone['bf16x3'][0]   # three engines really ran
+  # three engines really ran: the gradient vectors differ (the scalar losses of the f32 and the split engine
+  # are ~1e-6 apart and can round to the same float)
+  assert not torch.equal(alone['f32'][1], alone['fp16'][1]) and not torch.equal(alone['f32'][1], alone['bf16x3'][1])
+  assert alone['f32'][0] != alone['fp16'][0]
   # interleaved: all three forwards first (graphs alive together), then the backwards in another order
   for t in leaves:
     t.requires_grad_(True)
