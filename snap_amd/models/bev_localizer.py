@@ -120,9 +120,8 @@ class BEVLocalizer(base.Module):
       return
     B, V = im.shape[:2]
     Vq = iq.shape[1]
-    both = torch.cat(
-        [im.reshape(B * V, *im.shape[2:]), iq.reshape(B * Vq, *iq.shape[2:])], 0
-    ).to(torch.float32)
+    # (a LIST: the encoder pads each set straight into its slice of the joint batch -- no concatenation pass)
+    both = [im.reshape(B * V, *im.shape[2:]), iq.reshape(B * Vq, *iq.shape[2:])]
     pyr = sv.image_encoder(
         params['bev_mapper']['streetview_encoder']['image_encoder'], both, train, ctx=ctx
     )

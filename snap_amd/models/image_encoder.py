@@ -16,6 +16,23 @@ def pad_to_multiple(images, stride, channel_pad=0):
   full stride (``pad = stride - size % stride``).  ``channel_pad``: extra zero channels appended
   in the same copy (an RGB image stored with 4 floats per pixel lets the split-bf16 engine take
   the root convolution: ops.conv2d, ``cin=3``)."""
+  if isinstance(images, (list, tuple)):
+    # several image sets [Ni, H, W, C] of one size -> ONE padded batch [sum Ni, ...]: each set is padded
+    # straight into its slice (no concatenation pass over the raw images first)
+    parts = list(images)
+    shape = np.array(parts[0].shape[-3:-1])
+    pad = stride - shape % stride
+    native = all(p.is_cuda and p.is_contiguous() and p.dim() == 4 and not base.needs_grad(p) for p in parts)
+    if native and ops.NATIVE_GLUE and all(p.shape[1:] == parts[0].shape[1:] for p in parts):
+      H, W, C = parts[0].shape[1:]
+      out = torch.empty((sum(p.shape[0] for p in parts), H + int(pad[0]), W + int(pad[1]), C + int(channel_pad)),
+                        dtype=torch.float32, device=parts[0].device)
+      n0 = 0
+      for p in parts:
+        ops.pad_image(p, int(pad[0]), int(pad[1]), int(channel_pad), out=out[n0:n0 + p.shape[0]])
+        n0 += p.shape[0]
+      return out
+    images = torch.cat(parts, 0)
   shape = np.array(images.shape[-3:-1])
   pad = stride - shape % stride
   if (images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
@@ -104,8 +121,14 @@ class ImageEncoder(base.Module):
     }
 
   def __call__(self, params, image, train=False, ctx=None, rng=None):
-    image = image.to(torch.float32)
-    input_shape = np.array(image.shape[-3:-1])
+    """``image`` [N, H, W, C], or a list of such batches of one image size (encoded as ONE batch in list
+    order: the localizer's map and query views)."""
+    parts = [im.to(torch.float32) for im in image] if isinstance(image, (list, tuple)) else [image.to(torch.float32)]
+    input_shape = np.array(parts[0].shape[-3:-1])
+    if self.is_vit or len(parts) == 1:
+      image = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+    else:
+      image = parts                      # (pad_to_multiple pads every set into its slice of the joint batch)
     if self.is_vit:   # one level at the patch stride
       patch = self.config.encoder.patch_size
       padded = vit.pad_to_patch(image, patch)
@@ -114,8 +137,8 @@ class ImageEncoder(base.Module):
       return types.FeatureImagePyramid(
           features=[f[..., :h, :w, :]], strides=[np.array([patch, patch], dtype=np.float64)])
     # (inference on a split-bf16 engine: RGB + one zero float per pixel -- see pad_to_multiple)
-    rgb4 = (image.shape[-1] == 3 and ops.precision() in ops.SPLIT_PARTS
-            and not base.needs_grad(image) and not train)
+    rgb4 = (parts[0].shape[-1] == 3 and ops.precision() in ops.SPLIT_PARTS
+            and not any(base.needs_grad(p) for p in parts) and not train)
     image_padded = pad_to_multiple(image, 2**self.max_stride, channel_pad=1 if rgb4 else 0).contiguous()
     padded_shape = np.array(image_padded.shape[-3:-1])
     encoder_features = self.encoder(params['encoder'], image_padded, train=train, ctx=ctx)

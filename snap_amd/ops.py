@@ -1316,14 +1316,22 @@ def group_norm_apply(x, mu, sc, beta, mode):
   return y
 
 
-def pad_image(x, pad_h, pad_w, pad_c=0):
+def pad_image(x, pad_h, pad_w, pad_c=0, out=None):
   """x [..., H, W, C] -> [..., H + pad_h, W + pad_w, C + pad_c], zeros at the bottom / right / in
-  the extra channels, one pass (pad_to_multiple, image_encoder.py:32-39)."""
+  the extra channels, one pass (pad_to_multiple, image_encoder.py:32-39).  ``out``: a contiguous tensor
+  of that shape to write into (a slice of a joint batch: several image sets padded side by side without
+  concatenating them first)."""
   lib = _lib.load()
   _f32(x, 'x')
   *lead, H, W, C = x.shape
   N = int(np.prod(lead)) if lead else 1
-  y = torch.empty((*lead, H + pad_h, W + pad_w, C + pad_c), dtype=torch.float32, device=x.device)
+  shape = (*lead, H + pad_h, W + pad_w, C + pad_c)
+  if out is None:
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+  else:
+    y = _f32(out, 'out')
+    if tuple(y.shape) != tuple(shape):
+      raise ValueError(f'pad_image: out {tuple(y.shape)} != {tuple(shape)}')
   st = lib.snap_pad_image_f32(_p(x), N, H, W, C, int(pad_h), int(pad_w), int(pad_c), _p(y), _stream())
   _lib.check(st, 'snap_pad_image_f32')
   return y
