@@ -908,20 +908,25 @@ __device__ __forceinline__ void pack_weights_split_body(const float* __restrict_
     tile[j][tx] = (c < Cin && n < Cout) ? w[((int64_t)t * Cin + c) * Cout + n] : 0.f;
   }
   __syncthreads();
+  // one 16-byte chunk (8 consecutive k of one column and part) per thread and round: the image's own
+  // granule -- 2-byte scattered stores ran this kernel at 1.8 TB/s.  Same conversions, same bits.
+  for (int i = threadIdx.x; i < 128 * parts; i += 256) {
+    const int p = i >> 7, q = i & 127;
+    const int j = q >> 2, slab = (q >> 1) & 1, ko = q & 1;      // column of the tile, channel tile, k-octet
+    const int n = n0 + j, cb = c0 + 16 * slab;
+    if (cb >= 16 * ctiles) continue;
+    const int col = n & 127;
+    const int oct = ko ^ ((col >> 3) & 1);
+    const int64_t blk = ((int64_t)(n >> 7) * taps + t) * ctiles + (cb >> 4);
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    bf16x8v v;
 #pragma unroll
-  for (int j = ty; j < 32; j += 8) {
-    const int n = n0 + j, c = c0 + tx;          // n < padded Cout, c < 16 * ctiles by the grid
-    if (c >= 16 * ctiles) continue;
-    const int col = n & 127, k = c & 15;
-    const int oct = (k >> 3) ^ ((col >> 3) & 1);
-    const int64_t blk = ((int64_t)(n >> 7) * taps + t) * ctiles + (c >> 4);
-    __bf16* o = out + blk * ((int64_t)parts * 2048) + col * 16 + oct * 8 + (k & 7);
-    float r = tile[tx][j];
-    for (int p = 0; p < parts; ++p) {
-      const __bf16 b = (__bf16)r;
-      o[p * 2048] = b;
-      r -= (float)b;
+    for (int e = 0; e < 8; ++e) {
+      float r = tile[16 * slab + 8 * ko + e][j];
+      for (int pp = 0; pp < p; ++pp) r -= (float)(__bf16)r;
+      v[e] = (__bf16)r;
     }
+    *reinterpret_cast<bf16x8v*>(out + blk * ((int64_t)parts * 2048) + p * 2048 + col * 16 + oct * 8) = v;
   }
 }
 
