@@ -906,6 +906,9 @@ static int mlp2_pool_check(const float* x, int64_t M, int32_t Cin, int32_t x_str
       ncols <= 0 || ncols * Z > 0x7fffffffLL)
     return SNAP_ERR_BAD_SHAPE;
   if (H <= 0 || H % 32 != 0 || H > 256 || D <= 0 || D % 4 != 0 || D > 128) return SNAP_ERR_UNSUPPORTED;
+  // x_split: 0 f32 rows | 1 pre-split rows (three-stage ring) | 3 / 5 its measured alternatives; 7 (tap records) is
+  // internal to snap_mlp2_pool_max_gather_f32, which brings the records and the image with it
+  if (x_split != 0 && x_split != 1 && x_split != 3 && x_split != 5) return SNAP_ERR_UNSUPPORTED;
   if (x_split && (relu_in || x_stride < ((Cin + 15) / 16) * 16)) return SNAP_ERR_UNSUPPORTED;
   if (w0_bytes < snap_conv2d_packed_weights_split_bytes(1, Cin, H, 2) ||
       w1_bytes < snap_conv2d_packed_weights_split_bytes(1, H, D, 2))

@@ -98,6 +98,8 @@ def test_entry_point_argument_validation_codes():
   wb = lib.snap_conv2d_packed_weights_split_bytes(1, 257, 256, 2), lib.snap_conv2d_packed_weights_split_bytes(1, 256, 128, 2)
   args = lambda fd, cin: (one, 1024, cin, 272, one, one, one, one, one, 4096, 8, 160, fd, one, 0, one, wb[0], one, 256,
                           one, wb[1], one, 128, 4, 256, one, one, None)
+  assert lib.snap_mlp2_pool_max_f32(one, 1024, 257, 272, one, one, one, wb[0], one, 256, one, wb[1], one, 128, 0, 7, 4,
+                                    256, one, one, None) == -2                       # x_split 7 is not a public mode
   assert lib.snap_mlp2_pool_max_gather_f32(*args(120, 257)) == -1                    # feature_dim % 16
   assert lib.snap_mlp2_pool_max_gather_f32(*args(128, 260)) == -1                    # Cin != 2 fd + 1
   assert lib.snap_pose_score_window_supported(256, 256, 39) == 1
