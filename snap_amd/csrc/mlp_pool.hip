@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (tid >> 2) + RPP * i;
-      f32x4 v = xa[i];
+      f32x4 v;
       if constexpr (GATHER) {
         if (cur_c < a.nmean) {
 #pragma unroll
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(NT, 2) void mlp2_pool_kernel(const MlpPoolArgs a) {
         }
         if (!r_ok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
+        v = xa[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float pv = RELU_IN ? snap_relu(v[e]) : v[e];
