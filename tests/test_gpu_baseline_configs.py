@@ -98,6 +98,29 @@ def test_c2_whole_scene_vs_oracle_every_engine():
     tgm._check_validity(f'C2 query voxel validity [{m}]', pred['query'], ref['query'], ob['query'], cfg)
 
 
+def test_c2_full_batch_lift_inside_the_consumer_is_bitwise_the_rows_through_memory_path():
+  """The bench's own workload (8 scenes, 4 views @512 px + aerial, 128 x 128 x 60 voxels, R50, plane-only
+  mode): tap records + the in-kernel gather (the default) against pooled rows through memory
+  (``Tuning(LIFT_IN_CONSUMER=False)``) -- StreetView planes, matching features, similarity-derived scores and
+  the pose argmax are the SAME BITS for the map and the query branch (6.8 M + 2.2 M voxel rows)."""
+  import bench
+  from snap_amd import ops
+  loc, cfg, meta, variables, batch = bench.build('c2', torch.device(DEV), 0, materialize_volume=False)
+  loc.engine = 'bf16x3'
+  preds = {}
+  for consumer in (True, False):
+    with ops.tuning_scope(LIFT_IN_CONSUMER=consumer):
+      preds[consumer] = loc.apply(variables, batch, train=False, rngs={'sampling': 3})
+    torch.cuda.synchronize()
+  a, b = preds[True], preds[False]
+  for side in ('map', 'query'):
+    pa, pb = a[side]['streetview']['feature_plane'], b[side]['streetview']['feature_plane']
+    assert torch.equal(pa.valid, pb.valid) and 0 < int(pa.valid.sum())
+    assert torch.equal(pa.features, pb.features), (side, float((pa.features - pb.features).abs().max()))
+    assert torch.equal(a[side]['bev_matching'].features, b[side]['bev_matching'].features)
+  assert torch.equal(a['scores_poses'], b['scores_poses']) and torch.equal(a['best_index'], b['best_index'])
+
+
 # ------------------------------------------------------------------------------------------
 # C3: the train_localization default model at its full size, 4 scenes per GPU
 # ------------------------------------------------------------------------------------------
