@@ -15,6 +15,7 @@ including ``roofline`` (dominant kernel, HIP-event timed inside the timed region
 and ``cpu_baseline`` (the numpy oracle timed on the host cores on a bounded sample).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -395,6 +396,14 @@ def main(argv=None, emit=True):
   ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                   help='infer: BEVLocalizer forward (the headline metric); train: one '
                        'snap_amd.trainer.train_step (fwd + bwd + grad all-reduce + Adam)')
+  ap.add_argument('--in-flight', type=int, default=None,
+                  help='infer mode: batches in flight (snap_amd.pipeline; default 2) -- step i runs on HIP stream '
+                       'i %% N, so the dispatch gaps and tail waves of one batch are filled by the kernels of the '
+                       'next.  Every step does all of its work and gives the same bits; ms_per_step = elapsed / '
+                       'steps.  1 = one batch at a time (also reported as the leg `one_batch_at_a_time`)')
+  ap.add_argument('--digest', action='store_true',
+                  help='testing: add a float64 digest of every timed step\'s pose scores / best index to the line '
+                       '(the same whatever --in-flight is)')
   ap.add_argument('--tune', action='append', default=[], metavar='KNOB=VALUE',
                   help='A/B runs: set a tuning switch of snap_amd.ops (e.g. LIFT_IN_CONSUMER=0); results do not '
                        'depend on any of them beyond summation order')
@@ -494,10 +503,31 @@ def main(argv=None, emit=True):
   # step.  Holding the previous result across a step made the allocator fetch fresh 7.5 GiB
   # segments in the middle of the timed loop (hipMalloc of that size: ~200 ms, seen as one
   # 280 ms step in an otherwise 56 ms run).
-  pred = None
-  for i in range(args.warmup):
-    pred = None
-    pred = step(i)
+  # Batches in flight: step i is enqueued on stream i % N (N = 1: torch's current stream).  Every stream
+  # keeps the allocation pattern described above for itself (its previous result dropped before its
+  # next step starts); the caching allocator pools blocks per stream.
+  from snap_amd import pipeline
+  nfl = args.in_flight if args.in_flight is not None else (2 if args.mode == 'infer' else 1)
+  nfl = max(1, nfl) if (use_cuda and args.mode == 'infer') else 1
+  ring = pipeline.BatchesInFlight(nfl, device)
+  preds = [None] * nfl
+  digests = []
+
+  def run_step(slot, i, mark=None):
+    with ring.slot(slot):
+      if mark is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        mark.append(ev)
+      preds[slot] = None
+      preds[slot] = step(i)
+      if mark is not None and args.digest and isinstance(preds[slot], dict) and 'scores_poses' in preds[slot]:
+        bi = preds[slot].get('best_index')
+        digests.append(torch.stack([preds[slot]['scores_poses'].double().sum(),
+                                    (bi if bi is not None else preds[slot]['scores_poses'].argmax(-1)).double().sum()]))
+
+  for i in range(args.warmup * nfl):
+    run_step(i % nfl, i)
   # a generational GC pass over the Python heap in the middle of the loop costs 100+ ms
   # (seen as one 280 ms step in an otherwise 56 ms run): collect now, pause it while timing
   import gc
@@ -509,29 +539,33 @@ def main(argv=None, emit=True):
   t0 = time.perf_counter()
   for i in range(args.steps):
     if use_cuda and rank == 0 and i == args.steps - 1:
+      if nfl > 1:
+        torch.cuda.synchronize(device)  # the profiled step runs ALONE (its events time single launches)
       prof = ops.KernelProfiler()   # HIP events around every launch of the last step
       ops.set_profiler(prof)
       # ... with the aerial encoder on the MAIN stream for this one step: next to the StreetView
       # kernels on its side stream, two launches share the GPU and BOTH report inflated durations
       # (their sum counts the shared wall time twice), which understates every family's rate
       overlap_prev, ops.OVERLAP_AERIAL = ops.OVERLAP_AERIAL, False
-    if use_cuda:
-      ev = torch.cuda.Event(enable_timing=True)
-      ev.record()
-      marks.append(ev)
-    pred = None
-    pred = step(args.warmup + i)
+    run_step(i % nfl, 100_000 + i, marks if use_cuda else None)
   ops.set_profiler(None)
   if prof is not None:
     ops.OVERLAP_AERIAL = overlap_prev
   if use_cuda:
+    ring.join()
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
     marks.append(ev)
   barrier()
   elapsed = time.perf_counter() - t0
   gc.enable()
-  step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+  pred = preds[(args.steps - 1) % nfl]
+  # (N batches in flight: a mark is a step's START on its own stream; the period of a stream / N is
+  #  the per-step time while N batches share the GPU -- the drained last step is left out)
+  if nfl == 1:
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+  else:
+    step_ms = [marks[i].elapsed_time(marks[i + nfl]) / nfl for i in range(max(0, len(marks) - 2 - nfl))]
   t = torch.tensor([elapsed], dtype=torch.float64, device=device)
   if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -568,6 +602,7 @@ def main(argv=None, emit=True):
         'config': {
             'workload': WORKLOADS[args.workload]['desc'],
             'scenes_per_gpu': scenes_per_rank,
+            'batches_in_flight': nfl,
             'global_batch': scenes_per_rank * world,
             'parallelism': (f'scene-sharded x{world}, no data-path collective' if args.mode == 'infer'
                             else f'dp{world}: scene-sharded, RCCL gradient all-reduce'),
@@ -579,6 +614,8 @@ def main(argv=None, emit=True):
                                     'feature_volume.features is produced on first access (not in the timed step)'),
         },
     }
+    if digests:
+      out['step_digests'] = [[float(v) for v in d.cpu()] for d in digests]
     if args.mode == 'infer' and not is_c4:
       # share of voxels seen by at least one camera: the fusion MLP multiplies only those
       # rows (the others are masked to zero by the reference too), so the step time
@@ -655,9 +692,10 @@ def main(argv=None, emit=True):
             'bytes_per_launch': s['bytes'] / s['launches'],
         }
       out['kernels'] = kern
-      out['kernels_note'] = ('HIP-event durations of the LAST timed step, which runs the aerial encoder on the main '
-                             'stream (no two launches share the GPU while they are timed); the other steps overlap it '
-                             'with the StreetView encoder on a second stream')
+      out['kernels_note'] = ('HIP-event durations of the LAST timed step, which runs ALONE (the other batch in flight '
+                             'is drained first) and with the aerial encoder on its main stream: no two launches share '
+                             'the GPU while they are timed; the other steps run ' + str(nfl) + ' batches in flight and overlap '
+                             'the aerial encoder with the StreetView encoder on a side stream')
       if is_c4:
         # the direct-form correlation is MFMA-bound (AI ~ 1e5 flop/B); report BOTH the
         # matrix-core fraction on its direct-form flops and the HBM fraction its algorithmic bytes
@@ -742,6 +780,23 @@ def main(argv=None, emit=True):
                 'steps': steps, 'warmup': warmup, 'dtype': INFER_DTYPE[math],
                 'feature_volume': 'materialized'}
       pred = None
+      preds[:] = [None] * nfl
+      if nfl > 1:
+        # the same workload, same engine, ONE batch at a time on one stream (what `--in-flight 1` measures)
+        p = None
+        for i in range(3):
+          p = None
+          p = step(30_000 + i)
+        _sync(device)
+        t1 = time.perf_counter()
+        for i in range(10):
+          p = None
+          p = step(40_000 + i)
+        _sync(device)
+        dt = time.perf_counter() - t1
+        p = None
+        out['one_batch_at_a_time'] = {'ms_per_step': round(1e2 * dt, 3), 'scenes_per_sec': round(scenes_per_rank * 10 / dt, 3),
+                                      'steps': 10, 'warmup': 3, 'batches_in_flight': 1}
       out['f32_exact'] = leg('f32')
       out['volume_materialized'] = leg('bf16x3')
       # The other BASELINE configurations as short driver-timed legs of the same command (same
@@ -755,8 +810,8 @@ def main(argv=None, emit=True):
           ('train_c3', ['--mode', 'train', '--workload', 'c3', '--precision', 'bf16', '--steps', '5', '--warmup', '2']),
           # the reference's literal train config: dtype_str = 'float16' + DynamicScale(minimum_scale=256)
           ('train_c3_fp16', ['--mode', 'train', '--workload', 'c3', '--precision', 'fp16', '--steps', '5', '--warmup', '2']),
-          ('c4', ['--workload', 'c4', '--steps', '3', '--warmup', '1']),
-          ('c5', ['--workload', 'c5', '--steps', '5', '--warmup', '2'])):
+          ('c4', ['--workload', 'c4', '--steps', '12', '--warmup', '2']),
+          ('c5', ['--workload', 'c5', '--steps', '8', '--warmup', '2'])):
         torch.cuda.empty_cache()
         t1 = time.perf_counter()
         try:

@@ -70,14 +70,38 @@ def eval_step(params, batch, *, rng, model) -> Dict[str, torch.Tensor]:
   raise ValueError(f'No packing function for model {type(model).__name__}.')
 
 
-def eval_on_batches(model, params, batches: Iterable[Dict[str, Any]], rng: int = 0) -> Dict[str, np.ndarray]:
-  """Rows of every example with batch_mask set, stacked per metric."""
+def eval_on_batches(model, params, batches: Iterable[Dict[str, Any]], rng: int = 0,
+                    in_flight: int = 2) -> Dict[str, np.ndarray]:
+  """Rows of every example with batch_mask set, stacked per metric.
+
+  ``in_flight`` batches are enqueued on alternating HIP streams before the oldest one's metrics are
+  fetched (``snap_amd.pipeline``): the batches are independent, the rows are the same bits in the
+  same order whatever the value; 1 = one batch at a time."""
+  import collections
+  from snap_amd import pipeline
   rows: Dict[str, list] = {}
-  for batch in batches:
-    metrics = eval_step(params, batch, rng=rng, model=model)
-    keep = batch['batch_mask'].to(torch.bool).cpu().numpy()
-    for k, v in metrics.items():
-      rows.setdefault(k, []).append(v.detach().to(torch.float64).cpu().numpy()[keep])
+  ring = None
+  pending = collections.deque()
+
+  def fetch(entry):
+    i, batch, metrics = entry
+    with ring.slot(i):                   # (the copies queue on the batch's own stream and wait for it only)
+      keep = batch['batch_mask'].to(torch.bool).cpu().numpy()
+      for k, v in metrics.items():
+        rows.setdefault(k, []).append(v.detach().to(torch.float64).cpu().numpy()[keep])
+
+  for i, batch in enumerate(batches):
+    if ring is None:
+      ring = pipeline.BatchesInFlight(in_flight, batch['batch_mask'].device)
+    with ring.slot(i):
+      metrics = eval_step(params, batch, rng=rng, model=model)
+    pending.append((i, batch, metrics))  # (the batch stays alive until its stream has consumed it)
+    if len(pending) >= ring.n:
+      fetch(pending.popleft())
+  while pending:
+    fetch(pending.popleft())
+  if ring is not None:
+    ring.join()
   return {k: np.concatenate(v) for k, v in rows.items()}
 
 

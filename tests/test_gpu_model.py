@@ -261,6 +261,45 @@ def test_evaluator_contract_on_tiny_model(tmp_path):
   assert rec[-1] == 100.0 * np.mean(res['error_max_meter'] < 5.0)
 
 
+def test_batches_in_flight_same_bits():
+  """snap_amd.pipeline: batches on alternating HIP streams give the bits of one batch at a time --
+  predictions of the localiser AND the evaluator's rows (order included)."""
+  from snap_amd import evaluator, models, pipeline
+  dev = torch.device('cuda')
+  cfg = helpers.tiny_localizer_config(num_pose_samples=64, retries=2)
+  meta = synthetic.meta_data(0.2, (6.4, 6.4, 12))
+  model = models.get_model('bev_localizer')(cfg, meta)
+  params = helpers.params_to_device(model.flax_model.init(0, device='cpu')['params'], dev)
+  batches = []
+  for s in range(5):
+    b = helpers.batch_to_device(synthetic.make_batch(3, meta['grid'], 2, (64, 64), seed=10 + s), dev)
+    b['batch_mask'] = torch.tensor([True, s % 2 == 0, True], device=dev)
+    batches.append(b)
+  ref = evaluator.eval_on_batches(model, params, batches, rng=3, in_flight=1)
+  for n in (2, 3):
+    got = evaluator.eval_on_batches(model, params, batches, rng=3, in_flight=n)
+    assert set(got) == set(ref)
+    for k in ref:
+      np.testing.assert_array_equal(got[k], ref[k], err_msg=f'{k} with {n} batches in flight')
+  # the raw predictions, twice through a ring of two
+  def run(n):
+    ring = pipeline.BatchesInFlight(n, dev)
+    outs = []
+    for rep in range(2):
+      for i, b in enumerate(batches):
+        with ring.slot(len(outs)):
+          p = model.flax_model.apply({'params': params}, b, train=False, rngs={'sampling': 100 + i})
+          outs.append((p['scores_poses'], p['best_index'], p['map_t_query'].packed()))
+    ring.join()
+    torch.cuda.synchronize()
+    return outs
+  a, c = run(1), run(2)
+  for (s0, b0, t0), (s1, b1, t1) in zip(a, c):
+    assert torch.equal(s0, s1) and torch.equal(b0, b1) and torch.equal(t0, t1)
+  with pytest.raises(ValueError):
+    pipeline.BatchesInFlight(0, dev)
+
+
 def _tiny_vit_config():
   from snap_amd.configs import defaults
   cfg = defaults.image_encoder('vit')
