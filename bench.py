@@ -547,10 +547,12 @@ def main(argv=None, emit=True):
       # kernels on its side stream, two launches share the GPU and BOTH report inflated durations
       # (their sum counts the shared wall time twice), which understates every family's rate
       overlap_prev, ops.OVERLAP_AERIAL = ops.OVERLAP_AERIAL, False
+      wgside_prev, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False     # (train: kernel gradients too)
     run_step(i % nfl, 100_000 + i, marks if use_cuda else None)
   ops.set_profiler(None)
   if prof is not None:
     ops.OVERLAP_AERIAL = overlap_prev
+    ops.WGRAD_SIDE_STREAM = wgside_prev
   if use_cuda:
     ring.join()
     ev = torch.cuda.Event(enable_timing=True)

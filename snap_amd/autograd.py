@@ -8,6 +8,8 @@ transposed kernel; kernel gradients use the transpose-A engine (wgrad.hip).
 
 With ``torch.no_grad()`` (inference) the wrappers reduce to the plain ``ops`` calls.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -154,6 +156,35 @@ def similarity_bwd(dsim, sim, fq, fm, scale, clip, num_valid, row_weight=None):
 # ----------------------------------------------------------------------------
 # conv / dense
 # ----------------------------------------------------------------------------
+# A node's KERNEL gradient (dw = im2col(x)^T dy) has no consumer inside the backward chain: it leaves
+# on the device's second HIP stream, next to the node's data gradient + GroupNorm VJP on the main
+# stream, and the node joins it before it returns (so every later reader -- the gradient accumulation,
+# the bucketed reducer's hooks, an in-place reuse of dy by the next node -- sees it complete, and
+# nothing it reads is freed or overwritten while it runs).  The backward pass is a chain of 60-200 us
+# launches; the second queue fills their dispatch gaps and tail waves as a second batch does in
+# inference (snap_amd/pipeline.py).  Same kernels, same bits (ops.Tuning.WGRAD_SIDE_STREAM).
+@contextlib.contextmanager
+def _kernel_grad_stream(ref, forks):
+  if not (ops.tuning().WGRAD_SIDE_STREAM and ref.is_cuda):
+    yield
+    return
+  main = torch.cuda.current_stream(ref.device)
+  side = ops.side_stream(ref.device)
+  if side.cuda_stream == main.cuda_stream:
+    yield
+    return
+  side.wait_stream(main)            # x, dy and the statistics were produced on the main stream before here
+  with torch.cuda.stream(side):
+    yield
+  forks.append((main, side))
+
+
+def _join_kernel_grads(forks):
+  for main, side in forks:
+    main.wait_stream(side)
+  forks.clear()
+
+
 @_engine_scoped
 class _FusedConv(torch.autograd.Function):
 
@@ -197,9 +228,11 @@ class _FusedConv(torch.autograd.Function):
         dy = ops_bwd.epilogue_bwd(dy, y, row_mask, relu=relu)
     gn = (mu, sc, beta.reshape(-1)) if prologue in _GN_MODES else None
     dw = None
+    forks = []
     if need[1]:
-      dw = ops_bwd.conv2d_wgrad(x, dy, tuple(w.shape), stride=stride, padding=padding,
-                                prologue=prologue, gn=gn, in_affine=in_affine)
+      with _kernel_grad_stream(dy, forks):
+        dw = ops_bwd.conv2d_wgrad(x, dy, tuple(w.shape), stride=stride, padding=padding,
+                                  prologue=prologue, gn=gn, in_affine=in_affine)
     if dbias is None and has_bias and need[4]:
       dbias = ops_bwd.colsum(dy)
     dres = dy if (has_res and need[5]) else None
@@ -237,6 +270,7 @@ class _FusedConv(torch.autograd.Function):
         dx = F.pad(dx, (0, Cs - Cin))
     if dalias is not None:            # (no GroupNorm prologue to fold it into, or nothing else to add it to)
       dx = dalias if dx is None else dx + dalias
+    _join_kernel_grads(forks)
     return dx, dw, dgamma, dbeta, dbias, dres, dup, None
 
 
@@ -266,10 +300,12 @@ class _SharedPrologueConvPair(torch.autograd.Function):
     gn = (mu, sc, beta.reshape(-1))
     dy1, dy2 = dy1.contiguous(), dy2.contiguous()
     dw1 = dw2 = None
-    if need[1]:
-      dw1 = ops_bwd.conv2d_wgrad(x, dy1, tuple(w1.shape), prologue=ops.PRO_GN_RELU, gn=gn)
-    if need[2]:
-      dw2 = ops_bwd.conv2d_wgrad(x, dy2, tuple(w2.shape), stride=ctx.stride2, prologue=ops.PRO_GN_RELU, gn=gn)
+    forks = []
+    with _kernel_grad_stream(dy1, forks):
+      if need[1]:
+        dw1 = ops_bwd.conv2d_wgrad(x, dy1, tuple(w1.shape), prologue=ops.PRO_GN_RELU, gn=gn)
+      if need[2]:
+        dw2 = ops_bwd.conv2d_wgrad(x, dy2, tuple(w2.shape), stride=ctx.stride2, prologue=ops.PRO_GN_RELU, gn=gn)
     dx = dgamma = dbeta = None
     if need[0] or need[3] or need[4]:
       N, H, W, C = x.shape
@@ -284,6 +320,7 @@ class _SharedPrologueConvPair(torch.autograd.Function):
           half=ops.precision() if ops.precision() in ops.HALF_MATH else None)
       dgamma = dgamma.reshape(gamma.shape)
       dbeta = dbeta.reshape(beta.shape)
+    _join_kernel_grads(forks)
     return dx, dw1, dw2, dgamma, dbeta, None
 
 
@@ -520,9 +557,11 @@ def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
   D1 = W1.shape[1]
   need = ctx.needs_input_grad
   grads = [None] * 4
+  forks = []
   if need[5]:      # dW1 = h0^T g  (Z: half, compact; dY: f32 through the row list)
-    grads[2] = ops_bwd.conv2d_wgrad(h0.reshape(1, 1, M, H), g.reshape(1, 1, M, D1), (1, 1, H, D1),
-                                    rows_dy=index, row_count=count).reshape(H, D1)
+    with _kernel_grad_stream(g, forks):
+      grads[2] = ops_bwd.conv2d_wgrad(h0.reshape(1, 1, M, H), g.reshape(1, 1, M, D1), (1, 1, H, D1),
+                                      rows_dy=index, row_count=count).reshape(H, D1)
   if need[6]:
     grads[3] = ops_bwd.colsum(g, rows=index, row_count=count)
   # d h0 (compact, half only), then the ReLU gate + the bias gradient of layer 0 in one pass
@@ -547,8 +586,9 @@ def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
     grads[1] = db0
   pro = ops.PRO_RELU if ctx.relu_input else ops.PRO_NONE
   if need[3]:      # dW0 = x^T g1  (Z: f32 through the row list; dY: half, compact)
-    grads[0] = ops_bwd.dense_wgrad_rows(x2, g1, cin0, H, prologue=pro, rows_z=index, rows_dy=None,
-                                        row_count=count, tail_row=tail_row)
+    with _kernel_grad_stream(g, forks):
+      grads[0] = ops_bwd.dense_wgrad_rows(x2, g1, cin0, H, prologue=pro, rows_z=index, rows_dy=None,
+                                          row_count=count, tail_row=tail_row)
   dx = None
   if need[0]:
     if gi is not None:     # (columns split[0] .. Cs of the listed rows: written by the gate pass above)
@@ -563,6 +603,7 @@ def _masked_rows_mlp_backward_half(ctx, x2, g, mask, index, count, h0, Ws):
     if ctx.relu_input:
       gi = ops_bwd.epilogue_bwd(gi, x2, None, relu=True)
     dx = gi.reshape(ctx.xshape)
+  _join_kernel_grads(forks)
   return (dx, None, None, *grads)
 
 

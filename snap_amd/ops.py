@@ -49,6 +49,8 @@ SIM_CHUNK = 64
 #   USE_PRESPLIT_VOTING / FUSED_TEMPLATE_PACK / PS_RES_INIT / PS_TILE   pre-split GEMM engine (direct-form voting)
 #   SIM_GENERAL_KERNEL  tests: pin the general similarity kernel (the full-chunk kernel is bit-identical)
 #   LATTICE_WINDOW     the refinement lattice scored from one window per point (pose_score_window; same bits)
+#   WGRAD_SIDE_STREAM  backward: a node's kernel-gradient launches run on the second HIP stream next to its
+#                      data-gradient / GroupNorm-VJP chain and are joined before the node returns (same bits)
 # ----------------------------------------------------------------------------------------------------
 _TUNING_DEFAULTS = {
     'OVERLAP_AERIAL': True,
@@ -79,6 +81,7 @@ _TUNING_DEFAULTS = {
     'FUSED_TEMPLATE_PACK': True,
     'SIM_GENERAL_KERNEL': False,
     'LATTICE_WINDOW': True,
+    'WGRAD_SIDE_STREAM': True,
 }
 
 

@@ -151,6 +151,29 @@ def test_train_step_updates_and_decreases_loss():
   assert min(losses[3:]) < losses[0], losses      # same batch, Adam: the NLL goes down
 
 
+@pytest.mark.parametrize('precision', [None, 'bf16'])
+def test_kernel_gradients_on_the_side_stream_same_bits(precision):
+  """ops.Tuning.WGRAD_SIDE_STREAM: the kernel-gradient launches of a node run on the second HIP stream next to
+  its data-gradient chain and are joined before the node returns -- three optimisation steps give the SAME
+  parameters, bit for bit, with and without it (f32 and the bf16 engine: the half-tensor MLP backward)."""
+  from snap_amd import ops
+  outs = []
+  for side in (False, True, True):
+    model, params, batch = _setup(seed=4)
+    state = trainer.TrainState.create(params, rng=0)
+    lr_fn = trainer.make_lr_fn(2e-3, 100)
+    with ops.tuning_scope(WGRAD_SIDE_STREAM=side):
+      for _ in range(3):
+        state, _, logs = trainer.train_step(state, batch, model=model, lr_fn=lr_fn, max_grad_norm=10.0,
+                                            precision=precision)
+    torch.cuda.synchronize()
+    outs.append(([t.clone() for _, t in trainer.flatten_params(state.params)], logs['loss'], logs['l2_grads']))
+  for other in outs[1:]:
+    assert other[1] == outs[0][1] and other[2] == outs[0][2]
+    for a, b in zip(outs[0][0], other[0]):
+      assert torch.equal(a, b)
+
+
 def test_non_finite_gradients_skip_the_update():
   model, params, batch = _setup(seed=3)
   state = trainer.TrainState.create(params)
