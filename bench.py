@@ -809,11 +809,11 @@ def main(argv=None, emit=True):
       loc = variables = batch = None
       dump_env = os.environ.pop('SNAP_BENCH_DUMP', None)     # (the legs must not overwrite the C2 dump)
       for key, leg_args in (
-          ('train_c3', ['--mode', 'train', '--workload', 'c3', '--precision', 'bf16', '--steps', '5', '--warmup', '2']),
+          ('train_c3', ['--mode', 'train', '--workload', 'c3', '--precision', 'bf16', '--steps', '10', '--warmup', '2']),
           # the reference's literal train config: dtype_str = 'float16' + DynamicScale(minimum_scale=256)
-          ('train_c3_fp16', ['--mode', 'train', '--workload', 'c3', '--precision', 'fp16', '--steps', '5', '--warmup', '2']),
+          ('train_c3_fp16', ['--mode', 'train', '--workload', 'c3', '--precision', 'fp16', '--steps', '10', '--warmup', '2']),
           ('c4', ['--workload', 'c4', '--steps', '12', '--warmup', '2']),
-          ('c5', ['--workload', 'c5', '--steps', '8', '--warmup', '2'])):
+          ('c5', ['--workload', 'c5', '--steps', '10', '--warmup', '2'])):
         torch.cuda.empty_cache()
         t1 = time.perf_counter()
         try:
