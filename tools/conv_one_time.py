@@ -1,5 +1,6 @@
 """Average launch time of one layer of tools/conv_bench.LAYERS on one engine (helper of
 conv_ablate_split.py)."""
+import os
 import sys
 
 import torch
