@@ -23,9 +23,10 @@ struct SnapRotSample {
   float w00, w01, w10, w11; // bilinear weights of (i0,j0), (i0,j1), (i1,j0), (i1,j1)
 };
 
-// tfm = (cos, sin, tx, ty) of templates_t_grid for this rotation; (si, sj) = source cell
-SNAP_ROT_DEV SnapRotSample snap_rot_sample(const float* tfm, int si, int sj, int H, int W, float cell,
-                                           const uint8_t* valid) {
+// tfm = (cos, sin, tx, ty) of templates_t_grid for this rotation; (si, sj) = source cell.
+// The geometry alone (ok = inside the grid; the taps' validity not looked at): the taps are clamped into the
+// grid, so a caller may fetch them -- features and validity -- before it knows whether the sample counts.
+SNAP_ROT_DEV SnapRotSample snap_rot_geom(const float* tfm, int si, int sj, int H, int W, float cell) {
   SnapRotSample r;
   const float c = tfm[0], s = tfm[1], tx = tfm[2], ty = tfm[3];
   // cell centre in metres, transformed, back to cell units.
@@ -33,7 +34,7 @@ SNAP_ROT_DEV SnapRotSample snap_rot_sample(const float* tfm, int si, int sj, int
   const float xm = (c * gx - s * gy) + tx;
   const float ym = (s * gx + c * gy) + ty;
   const float u = xm / cell, v = ym / cell;
-  bool ok = (u >= 0.f) && (u < (float)H) && (v >= 0.f) && (v < (float)W);
+  r.ok = (u >= 0.f) && (u < (float)H) && (v >= 0.f) && (v < (float)W);
   const float cu = u - 0.5f, cv = v - 0.5f;
   const float fu = floorf(cu), fv = floorf(cv);
   const float wu1 = cu - fu, wu0 = 1.f - wu1, wv1 = cv - fv, wv0 = 1.f - wv1;
@@ -41,10 +42,15 @@ SNAP_ROT_DEV SnapRotSample snap_rot_sample(const float* tfm, int si, int sj, int
   r.i1 = (int)fminf(fmaxf(fu + 1.f, 0.f), (float)(H - 1));
   r.j0 = (int)fminf(fmaxf(fv, 0.f), (float)(W - 1));
   r.j1 = (int)fminf(fmaxf(fv + 1.f, 0.f), (float)(W - 1));
-  // NaN-mask validity: every tap must be valid, even with zero weight.
-  ok = ok && valid[r.i0 * W + r.j0] && valid[r.i0 * W + r.j1] && valid[r.i1 * W + r.j0] && valid[r.i1 * W + r.j1];
-  r.ok = ok;
   r.w00 = wu0 * wv0; r.w01 = wu0 * wv1; r.w10 = wu1 * wv0; r.w11 = wu1 * wv1;
+  return r;
+}
+
+SNAP_ROT_DEV SnapRotSample snap_rot_sample(const float* tfm, int si, int sj, int H, int W, float cell,
+                                           const uint8_t* valid) {
+  SnapRotSample r = snap_rot_geom(tfm, si, sj, H, W, cell);
+  // NaN-mask validity: every tap must be valid, even with zero weight.
+  r.ok = r.ok && valid[r.i0 * W + r.j0] && valid[r.i0 * W + r.j1] && valid[r.i1 * W + r.j0] && valid[r.i1 * W + r.j1];
   return r;
 }
 

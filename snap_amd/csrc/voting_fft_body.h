@@ -117,6 +117,7 @@ static inline bool make_plan(int N, Plan* pl) {
   return true;
 }
 
+#if defined(VF_EMU) || defined(VF_SCALAR_MATH)     // (VF_SCALAR_MATH: A/B builds of the HIP library)
 VF_DEV float2 cadd(float2 a, float2 b) { float2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
 VF_DEV float2 csub(float2 a, float2 b) { float2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
 VF_DEV float2 cmul(float2 a, float2 b) {            // a * b
@@ -125,17 +126,65 @@ VF_DEV float2 cmul(float2 a, float2 b) {            // a * b
 VF_DEV float2 cmulc(float2 a, float2 b) {           // a * conj(b)
   float2 r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r;
 }
-// two complex products a * conj(b) packed in 16 bytes
-VF_DEV float4 cmulc2(float4 a, float4 b) {
-  float4 r;
-  r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y;
-  r.z = a.z * b.z + a.w * b.w; r.w = a.w * b.z - a.z * b.w;
+// a + (-i) b (forward) / a + i b (inverse), and a - (-i) b / a - i b
+template <bool INV> VF_DEV float2 cadd_rot(float2 a, float2 b) {
+  float2 r;
+  if (INV) { r.x = a.x - b.y; r.y = a.y + b.x; } else { r.x = a.x + b.y; r.y = a.y - b.x; }
   return r;
 }
-// multiply by -i (forward) or +i (inverse)
-template <bool INV> VF_DEV float2 rot90c(float2 a) {
+template <bool INV> VF_DEV float2 csub_rot(float2 a, float2 b) {
   float2 r;
-  if (INV) { r.x = -a.y; r.y = a.x; } else { r.x = a.y; r.y = -a.x; }
+  if (INV) { r.x = a.x + b.y; r.y = a.y - b.x; } else { r.x = a.x - b.y; r.y = a.y + b.x; }
+  return r;
+}
+VF_DEV float2 cscale(float2 a, float s) { float2 r; r.x = s * a.x; r.y = s * a.y; return r; }
+#else
+// The same IEEE operations, two lanes per instruction (v_pk_add_f32 / v_pk_mul_f32 with their op_sel
+// swizzles and per-lane neg modifiers; -ffp-contract=off and no FMA: every product and sum is rounded
+// exactly as in the scalar form above, so the transforms are bit-identical to it).  The per-lane
+// negations and the (re, im) swap of a multiplication by +-i ride on the instruction's source
+// modifiers, which the compiler does not select by itself: a radix-4 butterfly with its three twiddle
+// products is 17 instructions instead of 34.
+typedef float vf_v2 __attribute__((ext_vector_type(2)));
+VF_DEV vf_v2 vf_pk(float2 a) { vf_v2 r = {a.x, a.y}; return r; }
+VF_DEV float2 vf_un(vf_v2 a) { float2 r; r.x = a.x; r.y = a.y; return r; }
+VF_DEV float2 cadd(float2 a, float2 b) { return vf_un(vf_pk(a) + vf_pk(b)); }
+VF_DEV float2 csub(float2 a, float2 b) { return vf_un(vf_pk(a) - vf_pk(b)); }
+VF_DEV float2 cscale(float2 a, float s) { vf_v2 sv = {s, s}; return vf_un(sv * vf_pk(a)); }
+VF_DEV float2 cmul(float2 a, float2 b) {            // a * b = (ax bx - ay by, ax by + ay bx)
+  const vf_v2 av = vf_pk(a), bv = vf_pk(b);
+  const vf_v2 t1 = av.xx * bv;                      // (ax bx, ax by)
+  const vf_v2 t2 = av.yy * bv.yx;                   // (ay by, ay bx)
+  vf_v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));
+  return vf_un(r);
+}
+VF_DEV float2 cmulc(float2 a, float2 b) {           // a * conj(b) = (ax bx + ay by, ay bx - ax by)
+  const vf_v2 av = vf_pk(a), bv = vf_pk(b);
+  const vf_v2 t1 = av.xx * bv;                      // (ax bx, ax by)
+  const vf_v2 t2 = av.yy * bv.yx;                   // (ay by, ay bx)
+  vf_v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(r) : "v"(t1), "v"(t2));
+  return vf_un(r);
+}
+// a + (-i) b = (ax + by, ay - bx) (forward) / a + i b = (ax - by, ay + bx) (inverse)
+template <bool INV> VF_DEV float2 cadd_rot(float2 a, float2 b) {
+  const vf_v2 av = vf_pk(a), bv = vf_pk(b);
+  vf_v2 r;
+  if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+  else     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+  return vf_un(r);
+}
+// a - (-i) b = (ax - by, ay + bx) (forward) / a - i b = (ax + by, ay - bx) (inverse)
+template <bool INV> VF_DEV float2 csub_rot(float2 a, float2 b) { return cadd_rot<!INV>(a, b); }
+#endif
+// two complex products a * conj(b) packed in 16 bytes
+VF_DEV float4 cmulc2(float4 a, float4 b) {
+  float2 a0, a1, b0, b1;
+  a0.x = a.x; a0.y = a.y; a1.x = a.z; a1.y = a.w;
+  b0.x = b.x; b0.y = b.y; b1.x = b.z; b1.y = b.w;
+  const float2 r0 = cmulc(a0, b0), r1 = cmulc(a1, b1);
+  float4 r; r.x = r0.x; r.y = r0.y; r.z = r1.x; r.w = r1.y;
   return r;
 }
 
@@ -146,9 +195,23 @@ template <bool INV>
 VF_DEV void bfly4(float2& x0, float2& x1, float2& x2, float2& x3, bool tw, float2 w1, float2 w2, float2 w3) {
   if (INV && tw) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); x3 = cmulc(x3, w3); }
   const float2 t0 = cadd(x0, x2), u1 = csub(x0, x2), u2 = cadd(x1, x3);
-  const float2 u3 = rot90c<INV>(csub(x1, x3));
-  x0 = cadd(t0, u2); x1 = cadd(u1, u3); x2 = csub(t0, u2); x3 = csub(u1, u3);
+  const float2 d = csub(x1, x3);                    // x1 = u1 + (-+i) d, x3 = u1 - (-+i) d
+  x0 = cadd(t0, u2); x1 = cadd_rot<INV>(u1, d); x2 = csub(t0, u2); x3 = csub_rot<INV>(u1, d);
   if (!INV && tw) { x1 = cmul(x1, w1); x2 = cmul(x2, w2); x3 = cmul(x3, w3); }
+}
+
+// One radix-3 stage butterfly (forward: butterfly, then the twiddles on outputs 1, 2; inverse: conjugate
+// twiddles on inputs 1, 2 first).
+template <bool INV>
+VF_DEV void bfly3(float2& x0, float2& x1, float2& x2, bool tw, float2 w1, float2 w2) {
+  if (INV && tw) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); }
+  const float2 sm = cadd(x1, x2), df = csub(x1, x2);
+  const float2 h = csub(x0, cscale(sm, 0.5f));
+  const float2 e = cscale(df, 0.86602540378443864676f);
+  // y1 = h + (-+ i) e, y2 = h - (-+ i) e   (-+ i (sqrt 3 / 2) (x1 - x2))
+  const float2 y0 = cadd(x0, sm), y1 = cadd_rot<INV>(h, e), y2 = csub_rot<INV>(h, e);
+  x0 = y0; x1 = y1; x2 = y2;
+  if (!INV && tw) { x1 = cmul(x1, w1); x2 = cmul(x2, w2); }
 }
 
 // In-place transform of C interleaved columns, buf[n * C + p].  tw[t] = exp(-2 pi i t / N).
@@ -160,9 +223,10 @@ VF_DEV void bfly4(float2& x0, float2& x1, float2& x2, float2& x3, bool tw, float
 // one barrier, one round of index arithmetic and 15 instead of 24 twiddle loads per 16 elements).
 // N = 768: three passes (3 | 4,4 | 4,4) instead of five.
 // The data must be visible (barrier) on entry; it is on exit.
+// skip_first (forward only): stage 0 has been applied by the caller (stage0_zero_tail below).
 template <int C, bool INV>
-VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int nt) {
-  int ss = 0;
+VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int nt, bool skip_first = false) {
+  int ss = (!INV && skip_first) ? 1 : 0;
   while (ss < pl.nst) {
     const int s = INV ? pl.nst - 1 - ss : ss;                 // the stage this pass starts with
     const int s2 = INV ? s - 1 : s + 1;                       // ... and its partner, if both are radix 4
@@ -238,15 +302,8 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
         float2 w1, w2;
         w1.x = w2.x = 1.f; w1.y = w2.y = 0.f;
         if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; }
-        if (INV && k) { x1 = cmulc(x1, w1); x2 = cmulc(x2, w2); }
-        const float2 sm = cadd(x1, x2), df = csub(x1, x2);
-        float2 h; h.x = x0.x - 0.5f * sm.x; h.y = x0.y - 0.5f * sm.y;
-        const float c3 = 0.86602540378443864676f;
-        float2 e; e.x = c3 * df.x; e.y = c3 * df.y;
-        const float2 g = rot90c<INV>(e);               // -+ i (sqrt 3 / 2) (x1 - x2)
-        float2 y0 = cadd(x0, sm), y1 = cadd(h, g), y2 = csub(h, g);
-        if (!INV && k) { y1 = cmul(y1, w1); y2 = cmul(y2, w2); }
-        b[0] = y0; b[st] = y1; b[2 * st] = y2;
+        bfly3<INV>(x0, x1, x2, k != 0, w1, w2);
+        b[0] = x0; b[st] = x1; b[2 * st] = x2;
       } else {
         float2 x0 = b[0], x1 = b[st];
         float2 w1; w1.x = 1.f; w1.y = 0.f;
@@ -260,6 +317,31 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
     VF_SYNC();
     ss += 1;
   }
+}
+
+// Timing ablations exist only in alt builds (-DVF_ABLATE=<bits>, WRONG results).  Dot launch: 1 = no X1 row
+// load, 2 = no forward transform, 4 = no map-spectrum loads, 8 = no inverse, 16 = no column sums; slow-axis launch
+// of a rotated call: 32 = no tap loads, 64 = no transform, 128 = no store of the half-transformed rows
+#ifndef VF_ABLATE
+#define VF_ABLATE 0
+#endif
+// The first forward stage where its partners are zero padding.  N = 3 * 2^a and n_in <= N / 3 (templates
+// of the map's own size: 256 rows in 768 transform points): the radix-3 butterfly {x[k], x[k + N/3],
+// x[k + 2N/3]} has x1 = x2 = 0, so the thread that STAGES x[k] runs the butterfly on the value it holds
+// and writes the three outputs -- the zero rows are never staged and the stage's own pass over LDS (a
+// read and a write of the whole buffer, one barrier) does not exist.  The same operations on the same
+// operands as that pass, zeros included: bit-identical to it.  `tw` must be visible (barrier) on entry.
+VF_DEV bool stage0_fusable(const Plan& pl, int n_in) {
+  return pl.nst > 1 && pl.radix[0] == 3 && n_in <= pl.N / 3;
+}
+VF_DEV void stage0_zero_tail(float2 x0, int k, const float2* tw, const Plan& pl, float2* y) {
+  float2 x1, x2, w1, w2;
+  x1.x = x1.y = x2.x = x2.y = 0.f;
+  w1.x = w2.x = 1.f; w1.y = w2.y = 0.f;
+  const int t1 = k * pl.tstep[0];
+  if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; }
+  bfly3<false>(x0, x1, x2, k != 0, w1, w2);
+  y[0] = x0; y[1] = x1; y[2] = x2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -291,7 +373,61 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
   for (int t = tid; t < N; t += nt) twl[t] = a.tw[t];
   const int p = tid & (kCols - 1), slot = tid >> kColShift, nslot = nt >> kColShift;
   const int col = bx, batch = by;
-  for (int row = slot; row < N; row += nslot) {
+  const bool fuse0 = stage0_fusable(a.pl, a.n_in);
+  const int M0 = N / 3;
+  if (fuse0) VF_SYNC();                                   // (the staging reads the twiddles)
+  int row_first = slot;
+  if (a.mode == kSlowRotate && fuse0 && !(a.D & 1)) {
+    // Templates sampled on the fly: kRotB rows of the thread at a time, the four taps' features AND validity
+    // bytes of all of them requested before the first is blended (the taps are clamped into the plane, so
+    // nothing waits for the validity verdict: one round trip per kRotB rows instead of two per row).  The
+    // arithmetic per sample is snap_rot_sample / snap_rot_mix: the same bits.
+    constexpr int kRotB = 2;
+    const int r = batch / a.G, g = batch - r * a.G, RQ = a.R >> 2;
+    const int k = r / RQ, r0 = r - k * RQ;
+    const int c = kGroupCh * g + 2 * p;
+    const bool cok = c < a.D && !(VF_ABLATE & 32);
+    const float2 zero2 = {0.f, 0.f};
+    for (; row_first + (kRotB - 1) * nslot < M0; row_first += kRotB * nslot) {
+      SnapRotSample rs[kRotB];
+      float2 t[kRotB][4];
+      uint8_t ok4[kRotB][4];
+#pragma unroll
+      for (int j = 0; j < kRotB; ++j) {
+        const int row = row_first + j * nslot;
+        int si = 0, sj = 0;
+        if (row < a.n_in) snap_rot90_source(k, row, col, a.sH, a.sW, &si, &sj);
+        rs[j] = snap_rot_geom(a.tfm + r0 * 4, si, sj, a.sH, a.sW, a.cell);
+        if (row >= a.n_in) rs[j].ok = false;
+        const int o00 = rs[j].i0 * a.sW + rs[j].j0, o01 = rs[j].i0 * a.sW + rs[j].j1;
+        const int o10 = rs[j].i1 * a.sW + rs[j].j0, o11 = rs[j].i1 * a.sW + rs[j].j1;
+        ok4[j][0] = a.srcb[o00]; ok4[j][1] = a.srcb[o01]; ok4[j][2] = a.srcb[o10]; ok4[j][3] = a.srcb[o11];
+        t[j][0] = t[j][1] = t[j][2] = t[j][3] = zero2;
+        if (cok) {
+          t[j][0] = *reinterpret_cast<const float2*>(a.srcf + (int64_t)o00 * a.D + c);
+          t[j][1] = *reinterpret_cast<const float2*>(a.srcf + (int64_t)o01 * a.D + c);
+          t[j][2] = *reinterpret_cast<const float2*>(a.srcf + (int64_t)o10 * a.D + c);
+          t[j][3] = *reinterpret_cast<const float2*>(a.srcf + (int64_t)o11 * a.D + c);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kRotB; ++j) {
+        const int row = row_first + j * nslot;
+        const bool ok = rs[j].ok && ok4[j][0] && ok4[j][1] && ok4[j][2] && ok4[j][3] && cok;
+        float2 v = zero2;
+        if (ok) {
+          v.x = snap_rot_mix(rs[j], t[j][0].x, t[j][1].x, t[j][2].x, t[j][3].x);
+          v.y = snap_rot_mix(rs[j], t[j][0].y, t[j][1].y, t[j][2].y, t[j][3].y);
+        }
+        float2 y[3];
+        stage0_zero_tail(v, row, twl, a.pl, y);
+        buf[row * kCols + p] = y[0];
+        buf[(row + M0) * kCols + p] = y[1];
+        buf[(row + 2 * M0) * kCols + p] = y[2];
+      }
+    }
+  }
+  for (int row = row_first; row < (fuse0 ? M0 : N); row += nslot) {
     float2 v; v.x = 0.f; v.y = 0.f;
     if (row < a.n_in) {
       if (a.mode == kSlowTemplate || a.mode == kSlowMap) {
@@ -317,7 +453,7 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
         snap_rot90_source(k, row, col, a.sH, a.sW, &si, &sj);
         const SnapRotSample rs = snap_rot_sample(a.tfm + r0 * 4, si, sj, a.sH, a.sW, a.cell, a.srcb);
         const int c = kGroupCh * g + 2 * p;
-        if (rs.ok && c < a.D) {
+        if (rs.ok && c < a.D && !(VF_ABLATE & 32)) {
           const float* f00 = a.srcf + ((int64_t)rs.i0 * a.sW + rs.j0) * a.D + c;
           const float* f01 = a.srcf + ((int64_t)rs.i0 * a.sW + rs.j1) * a.D + c;
           const float* f10 = a.srcf + ((int64_t)rs.i1 * a.sW + rs.j0) * a.D + c;
@@ -350,12 +486,20 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
         }
       }
     }
-    buf[row * kCols + p] = v;
+    if (fuse0) {
+      float2 y[3];
+      stage0_zero_tail(v, row, twl, a.pl, y);
+      buf[row * kCols + p] = y[0];
+      buf[(row + M0) * kCols + p] = y[1];
+      buf[(row + 2 * M0) * kCols + p] = y[2];
+    } else {
+      buf[row * kCols + p] = v;
+    }
   }
   VF_SYNC();
-  fft_lds<kCols, false>(buf, twl, a.pl, tid, nt);
+  if (!(VF_ABLATE & 64)) fft_lds<kCols, false>(buf, twl, a.pl, tid, nt, fuse0);
   float2* d = a.dst + ((int64_t)batch * N * a.ncols + col) * kCols + p;
-  for (int row = slot; row < N; row += nslot) d[(int64_t)row * a.ncols * kCols] = buf[row * kCols + p];
+  for (int row = slot; row < N && !(VF_ABLATE & 128); row += nslot) d[(int64_t)row * a.ncols * kCols] = buf[row * kCols + p];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -387,15 +531,59 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
   if (a.mode == kFastDot)
     for (int t = tid; t < N; t += nt) { sbuf[t].x = 0.f; sbuf[t].y = 0.f; }
   const int k1 = bx, outer = by;
+  float4* b4 = reinterpret_cast<float4*>(buf);
+  const int n4_in = a.n_in * (kCols / 2), n4 = N * (kCols / 2);
+  const bool fuse0 = stage0_fusable(a.pl, a.n_in);
+  const int n4_st = fuse0 ? (N / 3) * (kCols / 2) : n4;      // 16-byte items the staging walks
+  const int n4_m = (N / 3) * (kCols / 2);
+  // the row of the NEXT channel group is requested while this one is transformed (the barriers of these
+  // kernels wait for LDS traffic only): kXPre 16-byte loads per thread stay in flight across the passes
+  constexpr int kXPre = 2;
+  float4 pre[kXPre];
+  {
+    const float4* src0 = reinterpret_cast<const float4*>(a.x1 + (((int64_t)outer * a.gloop) * a.N1 + k1) * a.n_in * kCols);
+#pragma unroll
+    for (int u = 0; u < kXPre; ++u) {
+      const int i = tid + u * nt;
+      pre[u].x = pre[u].y = pre[u].z = pre[u].w = 0.f;
+      if (i < n4_in && i < n4_st && !(VF_ABLATE & 1)) pre[u] = src0[i];
+    }
+  }
+  if (fuse0) VF_SYNC();                                      // (the staging reads the twiddles)
   for (int g = 0; g < a.gloop; ++g) {
     const int64_t batch = (int64_t)outer * a.gloop + g;
     const float4* src = reinterpret_cast<const float4*>(a.x1 + (batch * a.N1 + k1) * a.n_in * kCols);
-    float4* b4 = reinterpret_cast<float4*>(buf);
-    const int n4_in = a.n_in * (kCols / 2), n4 = N * (kCols / 2);
-    for (int i = tid; i < n4; i += nt) {
+    for (int u = 0; tid + u * nt < n4_st; ++u) {
+      const int i = tid + u * nt;
       float4 v; v.x = v.y = v.z = v.w = 0.f;
-      if (i < n4_in) v = src[i];
-      b4[i] = v;
+      if (u < kXPre) {
+        v = u == 0 ? pre[0] : pre[kXPre - 1];                // (kXPre == 2)
+      } else if (i < n4_in && !(VF_ABLATE & 1)) {
+        v = src[i];
+      }
+      if (fuse0) {
+        const int row = i / (kCols / 2);
+        float2 x, y[3];
+        float4 o0, o1, o2;
+        x.x = v.x; x.y = v.y;
+        stage0_zero_tail(x, row, twl, a.pl, y);
+        o0.x = y[0].x; o0.y = y[0].y; o1.x = y[1].x; o1.y = y[1].y; o2.x = y[2].x; o2.y = y[2].y;
+        x.x = v.z; x.y = v.w;
+        stage0_zero_tail(x, row, twl, a.pl, y);
+        o0.z = y[0].x; o0.w = y[0].y; o1.z = y[1].x; o1.w = y[1].y; o2.z = y[2].x; o2.w = y[2].y;
+        b4[i] = o0; b4[i + n4_m] = o1; b4[i + 2 * n4_m] = o2;
+      } else {
+        b4[i] = v;
+      }
+    }
+    if (g + 1 < a.gloop) {
+      const float4* nsrc = reinterpret_cast<const float4*>(a.x1 + ((batch + 1) * a.N1 + k1) * a.n_in * kCols);
+#pragma unroll
+      for (int u = 0; u < kXPre; ++u) {
+        const int i = tid + u * nt;
+        pre[u].x = pre[u].y = pre[u].z = pre[u].w = 0.f;
+        if (i < n4_in && i < n4_st && !(VF_ABLATE & 1)) pre[u] = nsrc[i];
+      }
     }
     // DOT: this row of the map spectrum (98 KB, shared by every rotation: L2 / Infinity-Cache resident
     // after the first) is TOUCHED before the transform -- one dword per 128-byte line, a register each
@@ -412,7 +600,7 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
       for (int line = tid + nt; line < nlines; line += nt) touch += zt[line * 32];   // ... (smaller workgroups: the rest)
     }
     VF_SYNC();
-    fft_lds<kCols, false>(buf, twl, a.pl, tid, nt);
+    if (!(VF_ABLATE & 2) || a.mode != kFastDot) fft_lds<kCols, false>(buf, twl, a.pl, tid, nt, fuse0);
     if (a.mode == kFastStore16) {
       float4* d = reinterpret_cast<float4*>(a.out + (batch * a.N1 + k1) * N * kCols);
       for (int i = tid; i < n4; i += nt) d[i] = b4[i];
@@ -428,7 +616,7 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
         for (int u = 0; u < kZPre; ++u) {
           const int i = i0 + u * nt;
           zreg[u].x = zreg[u].y = zreg[u].z = zreg[u].w = 0.f;
-          if (i < n4) zreg[u] = z4[i];
+          if (i < n4 && !(VF_ABLATE & 4)) zreg[u] = z4[i];
         }
 #pragma unroll
         for (int u = 0; u < kZPre; ++u) {
@@ -438,7 +626,7 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
       }
       VF_KEEP(touch);                                  // the touch loads' only use: after the transform
       VF_SYNC();
-      for (int k2 = tid; k2 < N; k2 += nt) {
+      for (int k2 = tid; k2 < N && !(VF_ABLATE & 16); k2 += nt) {
         float2 acc = sbuf[k2];
 #pragma unroll
         for (int j = 0; j < kCols; ++j) acc = cadd(acc, buf[k2 * kCols + ((j + tid) & (kCols - 1))]);
@@ -450,7 +638,7 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
     VF_SYNC();
   }
   if (a.mode == kFastDot) {
-    fft_lds<1, true>(sbuf, twl, a.pl, tid, nt);
+    if (!(VF_ABLATE & 8)) fft_lds<1, true>(sbuf, twl, a.pl, tid, nt);
     float2* d = a.out + ((int64_t)outer * a.N1 + k1) * a.ld_out;
     for (int t = tid; t < a.nb_out; t += nt) d[t] = sbuf[t];
   } else if (a.mode == kFastMul) {
