@@ -37,24 +37,66 @@ __global__ __launch_bounds__(kNT) void vf_inv_kernel(vfft::InvArgs a) {
                  buf + a.pl.N * vfft::kCols);
 }
 
-// template masks + valid-cell counts of a rotated call (one atomic per wave and quadrant: the counts
-// are integers, the sum is order independent)
-__global__ __launch_bounds__(256) void vf_rot_mask_kernel(vfft::RotSource rs, int H, int W, int R,
-                                                          uint8_t* tvalid, float* tcount) {
-  const int64_t total = (int64_t)(R >> 2) * H * W;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int r0 = 0;
-  bool ok = false;
-  if (idx < total) ok = vfft::rot_mask_body(rs, H, W, R, idx, tvalid, &r0);
-  else r0 = (R >> 2) - 1;
+// Template masks + valid-cell counts of a rotated call: the arithmetic of vfft::rot_mask_body (the CPU emulation's
+// form: one cell per call), a 64 x 64 tile of first-quadrant cells per workgroup.  The verdicts of the tile go through
+// LDS so that all four rot90 copies leave as 64-byte runs -- the copies k = 1, 3 run along si: written by the thread
+// that computed the cell they were one byte per 256-byte row -- and the tile's count is ONE atomic per quadrant (the
+// per-wave form sent 37 k atomics to 36 addresses).  Counts are integers: the sums are order independent.
+constexpr int kMaskTile = 64;
+__global__ __launch_bounds__(256) void vf_rot_mask_kernel(vfft::RotSource rs, int H, int R, uint8_t* tvalid,
+                                                          float* tcount) {
+  __shared__ uint8_t okb[kMaskTile][kMaskTile + 4];
+  __shared__ int wcount[4];
   const int RQ = R >> 2;
-  const int r0_first = __builtin_amdgcn_readfirstlane(r0);
-  if (__all(r0 == r0_first)) {
-    const int n = __popcll(__ballot(ok));
-    if ((threadIdx.x & 63) == 0 && n > 0)
-      for (int k = 0; k < 4; ++k) atomicAdd(tcount + k * RQ + r0_first, (float)n);
-  } else if (ok) {
-    for (int k = 0; k < 4; ++k) atomicAdd(tcount + k * RQ + r0, 1.f);
+  const int r0 = blockIdx.z, si0 = blockIdx.y * kMaskTile, sj0 = blockIdx.x * kMaskTile;
+  const int t = threadIdx.x;
+  int n = 0;
+#pragma unroll 4
+  for (int c = 0; c < kMaskTile * kMaskTile / 256; ++c) {
+    const int li = (c * 256 + t) / kMaskTile, lj = (c * 256 + t) % kMaskTile;
+    const int si = si0 + li, sj = sj0 + lj;
+    bool ok = false;
+    if (si < H && sj < H) {
+      const SnapRotSample g = snap_rot_geom(rs.tfm + r0 * 4, si, sj, H, H, rs.cell);
+      // (the four taps are clamped into the plane: fetched side by side; every tap must be valid, snap_rot_sample)
+      const uint8_t v00 = rs.valid[g.i0 * H + g.j0], v01 = rs.valid[g.i0 * H + g.j1];
+      const uint8_t v10 = rs.valid[g.i1 * H + g.j0], v11 = rs.valid[g.i1 * H + g.j1];
+      ok = g.ok && v00 && v01 && v10 && v11;
+    }
+    okb[li][lj] = ok ? 1 : 0;
+    n += ok ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((t & 63) == 0) wcount[t >> 6] = n;
+  __syncthreads();
+  if (t == 0) {
+    const int total = ((wcount[0] + wcount[1]) + wcount[2]) + wcount[3];
+    if (total > 0)
+      for (int k = 0; k < 4; ++k) atomicAdd(tcount + k * RQ + r0, (float)total);
+  }
+  const int64_t plane = (int64_t)H * H;
+#pragma unroll 4
+  for (int c = 0; c < kMaskTile * kMaskTile / 256; ++c) {
+    const int a = (c * 256 + t) / kMaskTile, b = (c * 256 + t) % kMaskTile;    // b = the fast index of the run
+    // k = 0, 2: runs along sj (li = a, lj = b)
+    {
+      const int si = si0 + a, sj = sj0 + b;
+      if (si < H && sj < H) {
+        const uint8_t v = okb[a][b];
+        tvalid[(int64_t)r0 * plane + (int64_t)si * H + sj] = v;                                   // (di, dj) = (si, sj)
+        tvalid[(int64_t)(2 * RQ + r0) * plane + (int64_t)(H - 1 - si) * H + (H - 1 - sj)] = v;   // (H-1-si, W-1-sj)
+      }
+    }
+    // k = 1, 3: runs along si (lj = a, li = b)
+    {
+      const int si = si0 + b, sj = sj0 + a;
+      if (si < H && sj < H) {
+        const uint8_t v = okb[b][a];
+        tvalid[(int64_t)(RQ + r0) * plane + (int64_t)sj * H + (H - 1 - si)] = v;                  // (sj, H-1-si)
+        tvalid[(int64_t)(3 * RQ + r0) * plane + (int64_t)(H - 1 - sj) * H + si] = v;              // (H-1-sj, si)
+      }
+    }
   }
 }
 
@@ -154,9 +196,9 @@ extern "C" int snap_voting_fft_rotated_f32(const float* feat, const uint8_t* val
   float* tcount = reinterpret_cast<float*>(ws + g.o_tcount);
   if (hipMemsetAsync(tcount, 0, sizeof(float) * R, s) != hipSuccess) return SNAP_ERR_LAUNCH;
   vfft::RotSource rs{feat, valid, tfm, cell_size};
-  const int64_t cells = (int64_t)(R / 4) * H * H;
-  hipLaunchKernelGGL(vf_rot_mask_kernel, dim3((unsigned)snap_cdiv(cells, 256)), dim3(256), 0, s, rs, H, H, R,
-                     tvalid, tcount);
+  const unsigned mtiles = (unsigned)snap_cdiv(H, kMaskTile);
+  hipLaunchKernelGGL(vf_rot_mask_kernel, dim3(mtiles, mtiles, (unsigned)(R / 4)), dim3(256), 0, s, rs, H, R, tvalid,
+                     tcount);
   SNAP_CHECK_LAUNCH();
   HipLaunch L{s};
   if (!vfft::run_voting(g, nullptr, tvalid, map, mvalid, tcount, min_overlap * (float)H * (float)H, 1, ws, scores,
