@@ -9,7 +9,7 @@ R=$PWD
 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_baseline_configs.py -m gpu -q -x -k "voting or template or overlap or fft" 2>&1 | tail -8 > $O/tests.log
 cat $O/tests.log
 for rep in 1 2; do
-for lib in "" snap_amd/lib/alt_vfold/libsnap_hip.so; do
+for lib in "" ${ALTS:-snap_amd/lib/alt_vfold/libsnap_hip.so}; do
   echo "== lib=${lib:-default}"
   SNAP_HIP_LIB=${lib:+$PWD/$lib} timeout 300 python bench.py --workload c4 --steps 12 --warmup 3 --digest 2>/dev/null | tail -1 | python -c "
 import json,sys

@@ -117,6 +117,23 @@ static inline bool make_plan(int N, Plan* pl) {
   return true;
 }
 
+// LDS rows are stored swizzled: logical row n of a C-column buffer lives at row vf_phys<C>(n).  The last fused pass
+// of a transform (spans 16 and 4) has every thread walk the 16 consecutive rows of its block -- 1024 bytes at
+// C = 8 -- so the lanes of a wave, 16 rows apart, met on the same banks (8 lanes per 64-byte row, 8 rows per
+// wave on the same 16 banks; the single-column buffer: 128 bytes apart, 2 banks for 32 lanes).  XOR-ing the
+// row's low bits with bits 4.. of its index (the block number of that pass) spreads neighbouring blocks over
+// the banks; the earlier passes see a lane-uniform XOR of their low bits, a permutation inside a run they
+// already read whole.  A bijection of [0, N) (N = 2^a or 3 * 2^a, a >= 2).  VF_NO_SWIZZLE: A/B builds.
+template <int C> VF_DEV int vf_phys(int n) {
+#ifdef VF_NO_SWIZZLE
+  return n;
+#else
+  return C == 1 ? (n ^ ((n >> 4) & 15)) : (n ^ ((n >> 4) & 3));
+#endif
+}
+// 16-byte item i of the kCols-column buffer (kCols / 2 items per row) -> its swizzled item index
+VF_DEV int vf_phys4(int i) { return vf_phys<kCols>(i / (kCols / 2)) * (kCols / 2) + i % (kCols / 2); }
+
 #if defined(VF_EMU) || defined(VF_SCALAR_MATH)     // (VF_SCALAR_MATH: A/B builds of the HIP library)
 VF_DEV float2 cadd(float2 a, float2 b) { float2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
 VF_DEV float2 csub(float2 a, float2 b) { float2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
@@ -240,12 +257,13 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
       for (int item = tid; item < total; item += nt) {
         const int p = item % C, ti = item / C;
         const int kk = ti & (Mi - 1), blk = ti >> logMi;
-        float2* b = buf + (((blk << (logM + 2)) + kk) * C + p);
+        const int n0 = (blk << (logM + 2)) + kk;
+        float2* b = buf + p;
         float2 v[4][4];                                        // [q' : inner position][m : outer position]
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) v[q][m] = b[(q * Mi + m * M) * C];
+          for (int m = 0; m < 4; ++m) v[q][m] = b[vf_phys<C>(n0 + q * Mi + m * M) * C];
         float2 w1, w2, w3;
         w1.x = w2.x = w3.x = 1.f; w1.y = w2.y = w3.y = 0.f;
         if (!INV) {
@@ -276,7 +294,7 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) b[(q * Mi + m * M) * C] = v[q][m];
+          for (int m = 0; m < 4; ++m) b[vf_phys<C>(n0 + q * Mi + m * M) * C] = v[q][m];
       }
       VF_SYNC();
       ss += 2;
@@ -284,34 +302,37 @@ VF_DEV void fft_lds(float2* buf, const float2* tw, const Plan& pl, int tid, int 
     }
     const int R = pl.radix[s], logM = pl.logM[s], M = 1 << logM, L = pl.L[s], ts = pl.tstep[s];
     const int total = (pl.N / R) * C;
-    const int st = M * C;
     for (int item = tid; item < total; item += nt) {
       const int p = item % C, bi = item / C;
       const int k = bi & (M - 1), blk = bi >> logM;
-      float2* b = buf + ((blk * L + k) * C + p);
+      const int n0 = blk * L + k;
+      float2* b = buf + p;
+      const int a0 = vf_phys<C>(n0) * C, a1 = vf_phys<C>(n0 + M) * C;
       const int t1 = k * ts;
       if (R == 4) {
-        float2 x0 = b[0], x1 = b[st], x2 = b[2 * st], x3 = b[3 * st];
+        const int a2 = vf_phys<C>(n0 + 2 * M) * C, a3 = vf_phys<C>(n0 + 3 * M) * C;
+        float2 x0 = b[a0], x1 = b[a1], x2 = b[a2], x3 = b[a3];
         float2 w1, w2, w3;
         w1.x = w2.x = w3.x = 1.f; w1.y = w2.y = w3.y = 0.f;
         if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; w3 = tw[3 * t1]; }
         bfly4<INV>(x0, x1, x2, x3, k != 0, w1, w2, w3);
-        b[0] = x0; b[st] = x1; b[2 * st] = x2; b[3 * st] = x3;
+        b[a0] = x0; b[a1] = x1; b[a2] = x2; b[a3] = x3;
       } else if (R == 3) {
-        float2 x0 = b[0], x1 = b[st], x2 = b[2 * st];
+        const int a2 = vf_phys<C>(n0 + 2 * M) * C;
+        float2 x0 = b[a0], x1 = b[a1], x2 = b[a2];
         float2 w1, w2;
         w1.x = w2.x = 1.f; w1.y = w2.y = 0.f;
         if (k) { w1 = tw[t1]; w2 = tw[2 * t1]; }
         bfly3<INV>(x0, x1, x2, k != 0, w1, w2);
-        b[0] = x0; b[st] = x1; b[2 * st] = x2;
+        b[a0] = x0; b[a1] = x1; b[a2] = x2;
       } else {
-        float2 x0 = b[0], x1 = b[st];
+        float2 x0 = b[a0], x1 = b[a1];
         float2 w1; w1.x = 1.f; w1.y = 0.f;
         if (k) w1 = tw[t1];
         if (INV && k) x1 = cmulc(x1, w1);
         float2 y0 = cadd(x0, x1), y1 = csub(x0, x1);
         if (!INV && k) y1 = cmul(y1, w1);
-        b[0] = y0; b[st] = y1;
+        b[a0] = y0; b[a1] = y1;
       }
     }
     VF_SYNC();
@@ -380,9 +401,13 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
   if (a.mode == kSlowRotate && fuse0 && !(a.D & 1)) {
     // Templates sampled on the fly: kRotB rows of the thread at a time, the four taps' features AND validity
     // bytes of all of them requested before the first is blended (the taps are clamped into the plane, so
-    // nothing waits for the validity verdict: one round trip per kRotB rows instead of two per row).  The
+    // nothing waits for the validity verdict: one round trip per kRotB rows instead of two per row; 2 rows:
+    // slow-axis launch 0.56 -> 0.46 ms, 4 rows: another 1-2 % of the voting).  The
     // arithmetic per sample is snap_rot_sample / snap_rot_mix: the same bits.
-    constexpr int kRotB = 2;
+#ifndef VF_ROTB
+#define VF_ROTB 4
+#endif
+    constexpr int kRotB = VF_ROTB;
     const int r = batch / a.G, g = batch - r * a.G, RQ = a.R >> 2;
     const int k = r / RQ, r0 = r - k * RQ;
     const int c = kGroupCh * g + 2 * p;
@@ -421,9 +446,9 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
         }
         float2 y[3];
         stage0_zero_tail(v, row, twl, a.pl, y);
-        buf[row * kCols + p] = y[0];
-        buf[(row + M0) * kCols + p] = y[1];
-        buf[(row + 2 * M0) * kCols + p] = y[2];
+        buf[vf_phys<kCols>(row) * kCols + p] = y[0];
+        buf[vf_phys<kCols>(row + M0) * kCols + p] = y[1];
+        buf[vf_phys<kCols>(row + 2 * M0) * kCols + p] = y[2];
       }
     }
   }
@@ -489,17 +514,17 @@ VF_DEV void slow_body(const SlowArgs& a, int bx, int by, int tid, int nt, float2
     if (fuse0) {
       float2 y[3];
       stage0_zero_tail(v, row, twl, a.pl, y);
-      buf[row * kCols + p] = y[0];
-      buf[(row + M0) * kCols + p] = y[1];
-      buf[(row + 2 * M0) * kCols + p] = y[2];
+      buf[vf_phys<kCols>(row) * kCols + p] = y[0];
+      buf[vf_phys<kCols>(row + M0) * kCols + p] = y[1];
+      buf[vf_phys<kCols>(row + 2 * M0) * kCols + p] = y[2];
     } else {
-      buf[row * kCols + p] = v;
+      buf[vf_phys<kCols>(row) * kCols + p] = v;
     }
   }
   VF_SYNC();
   if (!(VF_ABLATE & 64)) fft_lds<kCols, false>(buf, twl, a.pl, tid, nt, fuse0);
   float2* d = a.dst + ((int64_t)batch * N * a.ncols + col) * kCols + p;
-  for (int row = slot; row < N && !(VF_ABLATE & 128); row += nslot) d[(int64_t)row * a.ncols * kCols] = buf[row * kCols + p];
+  for (int row = slot; row < N && !(VF_ABLATE & 128); row += nslot) d[(int64_t)row * a.ncols * kCols] = buf[vf_phys<kCols>(row) * kCols + p];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,9 +596,9 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
         x.x = v.z; x.y = v.w;
         stage0_zero_tail(x, row, twl, a.pl, y);
         o0.z = y[0].x; o0.w = y[0].y; o1.z = y[1].x; o1.w = y[1].y; o2.z = y[2].x; o2.w = y[2].y;
-        b4[i] = o0; b4[i + n4_m] = o1; b4[i + 2 * n4_m] = o2;
+        b4[vf_phys4(i)] = o0; b4[vf_phys4(i + n4_m)] = o1; b4[vf_phys4(i + 2 * n4_m)] = o2;
       } else {
-        b4[i] = v;
+        b4[vf_phys4(i)] = v;
       }
     }
     if (g + 1 < a.gloop) {
@@ -603,9 +628,9 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
     if (!(VF_ABLATE & 2) || a.mode != kFastDot) fft_lds<kCols, false>(buf, twl, a.pl, tid, nt, fuse0);
     if (a.mode == kFastStore16) {
       float4* d = reinterpret_cast<float4*>(a.out + (batch * a.N1 + k1) * N * kCols);
-      for (int i = tid; i < n4; i += nt) d[i] = b4[i];
+      for (int i = tid; i < n4; i += nt) d[i] = b4[vf_phys4(i)];
     } else if (a.mode == kFastStore1) {
-      for (int t = tid; t < N; t += nt) a.out[(int64_t)k1 * N + t] = buf[t * kCols];
+      for (int t = tid; t < N; t += nt) a.out[(int64_t)k1 * N + t] = buf[vf_phys<kCols>(t) * kCols];
     } else if (a.mode == kFastDot) {
       // products Zm * conj(X) in place (kZPre coalesced 16-byte loads in flight per thread), then one
       // thread per k2' sums its 16 pairs (rotated start: the 128-byte row stride would put every lane
@@ -621,30 +646,34 @@ VF_DEV void fast_body(const FastArgs& a, int bx, int by, int tid, int nt, float2
 #pragma unroll
         for (int u = 0; u < kZPre; ++u) {
           const int i = i0 + u * nt;
-          if (i < n4) b4[i] = cmulc2(zreg[u], b4[i]);
+          if (i < n4) { const int ip = vf_phys4(i); b4[ip] = cmulc2(zreg[u], b4[ip]); }
         }
       }
       VF_KEEP(touch);                                  // the touch loads' only use: after the transform
       VF_SYNC();
       for (int k2 = tid; k2 < N && !(VF_ABLATE & 16); k2 += nt) {
-        float2 acc = sbuf[k2];
+        const int ks = vf_phys<1>(k2), kb = vf_phys<kCols>(k2) * kCols;
+        float2 acc = sbuf[ks];
 #pragma unroll
-        for (int j = 0; j < kCols; ++j) acc = cadd(acc, buf[k2 * kCols + ((j + tid) & (kCols - 1))]);
-        sbuf[k2] = acc;
+        for (int j = 0; j < kCols; ++j) acc = cadd(acc, buf[kb + ((j + tid) & (kCols - 1))]);
+        sbuf[ks] = acc;
       }
     } else {
-      for (int i = tid; i < N * kCols; i += nt) buf[i] = cmulc(a.z[(int64_t)k1 * N + (i >> kColShift)], buf[i]);
+      for (int i = tid; i < N * kCols; i += nt) {
+        const int ip = vf_phys<kCols>(i >> kColShift) * kCols + (i & (kCols - 1));
+        buf[ip] = cmulc(a.z[(int64_t)k1 * N + (i >> kColShift)], buf[ip]);
+      }
     }
     VF_SYNC();
   }
   if (a.mode == kFastDot) {
     if (!(VF_ABLATE & 8)) fft_lds<1, true>(sbuf, twl, a.pl, tid, nt);
     float2* d = a.out + ((int64_t)outer * a.N1 + k1) * a.ld_out;
-    for (int t = tid; t < a.nb_out; t += nt) d[t] = sbuf[t];
+    for (int t = tid; t < a.nb_out; t += nt) d[t] = sbuf[vf_phys<1>(t)];
   } else if (a.mode == kFastMul) {
     fft_lds<kCols, true>(buf, twl, a.pl, tid, nt);
     float2* d = a.out + ((int64_t)outer * a.N1 + k1) * a.ld_out * kCols;
-    for (int i = tid; i < a.nb_out * kCols; i += nt) d[i] = buf[i];
+    for (int i = tid; i < a.nb_out * kCols; i += nt) d[i] = buf[vf_phys<kCols>(i >> kColShift) * kCols + (i & (kCols - 1))];
   }
 }
 
@@ -682,11 +711,11 @@ VF_DEV void inv_body(const InvArgs& a, int bx, int by, int tid, int nt, float2* 
     for (int row = slot; row < N; row += nslot) {
       float2 v; v.x = 0.f; v.y = 0.f;
       if (b < a.nb_valid) v = y[(int64_t)row * a.ld];
-      buf[row * kCols + p] = v;
+      buf[vf_phys<kCols>(row) * kCols + p] = v;
     }
   } else {
     const float2* y = a.y + ((int64_t)by * N * a.ld + bx) * kCols + p;
-    for (int row = slot; row < N; row += nslot) buf[row * kCols + p] = y[(int64_t)row * a.ld * kCols];
+    for (int row = slot; row < N; row += nslot) buf[vf_phys<kCols>(row) * kCols + p] = y[(int64_t)row * a.ld * kCols];
   }
   VF_SYNC();
   fft_lds<kCols, true>(buf, twl, a.pl, tid, nt);
@@ -696,7 +725,7 @@ VF_DEV void inv_body(const InvArgs& a, int bx, int by, int tid, int nt, float2* 
       const float tc = a.tcount[r];
       for (int row = slot; row < a.Ho; row += nslot) {
         const int64_t o = ((int64_t)r * a.Ho + row) * a.Wo + b;
-        float v = buf[row * kCols + p].x * a.scale;
+        float v = buf[vf_phys<kCols>(row) * kCols + p].x * a.scale;
         if (a.use_overlap && !a.flags_in[o]) v = -INFINITY;
         a.scores[o] = v / tc;
       }
@@ -705,7 +734,7 @@ VF_DEV void inv_body(const InvArgs& a, int bx, int by, int tid, int nt, float2* 
     const int rp = kCols * by + p, b = bx;
     if (rp < a.R2) {
       for (int row = slot; row < a.Ho; row += nslot) {
-        const float2 c = buf[row * kCols + p];
+        const float2 c = buf[vf_phys<kCols>(row) * kCols + p];
         a.flags_out[((int64_t)rp * a.Ho + row) * a.Wo + b] = rintf(c.x * a.scale) > a.thr ? 1 : 0;
         if (rp + a.R2 < a.R)
           a.flags_out[((int64_t)(rp + a.R2) * a.Ho + row) * a.Wo + b] = rintf(-c.y * a.scale) > a.thr ? 1 : 0;
