@@ -131,7 +131,13 @@ typedef struct SnapConvExtras {
                                  snap_gn_norm_split_f32 / snap_presplit_f32; needs w_split_parts = 2,
                                  prologue NONE, Cin % 16 == 0, no row lists.  Both operands then
                                  travel by LDS-DMA (conv_ps.hip); sizes come from the
-                                 snap_conv2d_presplit_* queries below instead of the plain ones */
+                                 snap_conv2d_presplit_* queries below instead of the plain ones.
+                                 With w_split_parts = 1 (w_bf16 = the ONE-part image of
+                                 snap_conv2d_pack_weights_split_bf16): `x` is a plain bf16 tensor
+                                 [N,H,W,Cin] (Cin_stride == Cin) and the launch is the
+                                 training-precision arithmetic (operands rounded to bf16, f32
+                                 accumulate: the bits of the x_half engine) on the same ring; no
+                                 statistics / split-K / up-sampling epilogue; y_half allowed */
   int32_t ps_tile;            /* ... 0 = automatic, 1 = 128-row tiles, 2 = 256-row tiles (tuning) */
   int32_t ps_res_init;        /* ... 1 = a residual is loaded into the accumulators before the K loop
                                  (r + p1 + p2 + ... instead of (p1 + p2 + ...) + r) */
@@ -314,6 +320,13 @@ int snap_layer_norm_f32(const float* x, const float* gamma, const float* beta, f
                         int64_t M, int32_t C, float eps, void* stream);
 int snap_attention_bf16_f32(const float* qkv, float* out, int32_t B, int32_t N, int32_t H,
                             int32_t D, float scale, void* stream);
+/* The same two with the result written ONLY rounded (RNE) to bf16 (y_bf16 [M, C] / out_bf16 [B, N, H*D]): the
+ * inference path's operands of the dense layers that follow (snap_conv2d_nhwc_ex_f32 with extras->x_presplit = 1,
+ * w_split_parts = 1: both operands by LDS-DMA), which round them to that type anyway -- the same values. */
+int snap_layer_norm_bf16out_f32(const float* x, const float* gamma, const float* beta, void* y_bf16,
+                                int64_t M, int32_t C, float eps, void* stream);
+int snap_attention_bf16out_f32(const float* qkv, void* out_bf16, int32_t B, int32_t N, int32_t H,
+                               int32_t D, float scale, void* stream);
 /* Training path of the ViT pieces.  snap_attention_lse_bf16_f32 also returns lse [B, H, N], the
  * base-2 log-sum-exp of the scaled scores; snap_attention_bwd_bf16_f32 turns (qkv, out, dout,
  * lse) into dqkv (same layout as qkv; delta [B, H, N] is scratch) with two atomic-free kernels

@@ -105,6 +105,8 @@ SIGNATURES = {
     'snap_pack_stacked_templates_split_bf16': (c_int, [ptr, c_int, c_int, c_int, c_int, c_int, ptr, c_size, ptr]),
     'snap_layer_norm_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_attention_bf16_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
+    'snap_layer_norm_bf16out_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr]),
+    'snap_attention_bf16out_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_attention_lse_bf16_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_attention_bwd_bf16_f32': (
         c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
@@ -337,7 +339,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 

@@ -1,7 +1,7 @@
 // Library introspection entry points of the C ABI (include/snap_hip.h).
 #include "common.h"
 
-extern "C" int snap_abi_version(void) { return 21; }
+extern "C" int snap_abi_version(void) { return 22; }
 
 extern "C" const char* snap_build_arch(void) { return "gfx950"; }
 

@@ -58,6 +58,7 @@ struct ConvArgs {
   const void* x_ps;    // pre-split engine (conv_ps.hip): the input as [pixel][Cin/16][hi 16 | lo 16] bf16
   int ps_tile;         // ... 0 = automatic tile, 1 = 128 rows, 2 = 256 rows
   int ps_res_init;     // ... 1 = the residual is loaded into the accumulators before the K loop
+  int ps_parts;        // ... 2 = the two-part image (bf16x3); 1 = x_ps is a plain bf16 matrix, w_bf16 the one-part image (bf16)
   // GroupNorm-VJP statistics in the epilogue (SnapConvExtras.gnb_*; conv_epilogue<..., GNB = true> only)
   const float* gnb_x;
   const float* gnb_mu;

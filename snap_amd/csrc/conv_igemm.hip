@@ -744,8 +744,9 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   if (a.half && (ex->w_split_parts != 0 || presplit || ex->w_split_root)) return SNAP_ERR_UNSUPPORTED;
   a.x_half = nullptr;
   a.y_half = nullptr;
+  const bool ps1 = presplit && ex->w_split_parts == 1;   // the one-part pre-split engine: plain bf16 x, bf16 arithmetic
   if (ex && ex->y_half) {       // half (also / only) output: training-precision engine, no split-K, no statistics
-    if (!a.w_bf16 || ex->w_split_parts != 0 || presplit || ex->w_split_root || gn_partial ||
+    if (!a.w_bf16 || (ex->w_split_parts != 0 && !ps1) || (presplit && !ps1) || ex->w_split_root || gn_partial ||
         (d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD) || d.Cout_stride % 4 != 0 ||
         (reinterpret_cast<uintptr_t>(ex->y_half) & 7))
       return SNAP_ERR_UNSUPPORTED;
@@ -772,6 +773,7 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
   a.x_ps = nullptr;
   a.ps_tile = 0;
   a.ps_res_init = 0;
+  a.ps_parts = 2;
   if (ex && ex->x_half) {     // the input is already bf16 / f16: training-precision engine, both operands by DMA
     if (!a.w_bf16 || ex->w_split_parts != 0 || presplit || ex->w_split_root || d.prologue != SNAP_PRO_NONE ||
         rows_in || d.Cin_stride % 8 != 0 || d.Cin % 8 != 0 || ex->y_half)
@@ -783,8 +785,10 @@ extern "C" int snap_conv2d_nhwc_ex_f32(const SnapConvDesc* desc, const float* x,
     return snapconv::launch_bf16(a, s);
   }
   if (presplit) {                            // both operands pre-split: conv_ps.hip
-    if (!a.w_bf16 || ex->w_split_parts != 2 || ex->w_split_root) return SNAP_ERR_UNSUPPORTED;
-    const size_t need = snap_conv2d_packed_weights_split_bytes(d.KH * d.KW, d.Cin, d.Cout, 2);
+    if (!a.w_bf16 || (ex->w_split_parts != 2 && ex->w_split_parts != 1) || ex->w_split_root) return SNAP_ERR_UNSUPPORTED;
+    if (ps1 && d.Cin_stride != d.Cin) return SNAP_ERR_UNSUPPORTED;
+    a.ps_parts = ex->w_split_parts;
+    const size_t need = snap_conv2d_packed_weights_split_bytes(d.KH * d.KW, d.Cin, d.Cout, ex->w_split_parts);
     if (need == 0) return SNAP_ERR_UNSUPPORTED;
     if (ex->w_bf16_bytes < need) return SNAP_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(a.w_bf16) | reinterpret_cast<uintptr_t>(x)) & 15) return SNAP_ERR_BAD_SHAPE;

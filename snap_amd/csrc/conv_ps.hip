@@ -49,9 +49,13 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // KS = 16-k steps per ring stage (one barrier per stage), NST = ring depth in stages
-template <int BM, int BN, int NT, int KS, int NST, bool RES_INIT, bool DUAL>
+// NS = 2: the two-part pre-split image (f32-grade, three products per MAC).  NS = 1: ONE part -- x is a plain bf16
+// matrix [pixel][Cin] (16 channels = the 32-byte run of a k-step), the weights the one-part image of the same
+// packer: the training-precision arithmetic (operands rounded to bf16, f32 accumulate) with both operands by
+// LDS-DMA through the same ring -- the dense layers of the ViT encoder, whose producers write bf16.
+// OUTH (NS = 1): 1 = the stored values also / only go, rounded to bf16, to a.y_half (conv_epilogue).
+template <int BM, int BN, int NT, int KS, int NST, bool RES_INIT, bool DUAL, int NS = 2, int OUTH = 0>
 __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
-  constexpr int NS = 2;
   constexpr int WR = NT / 128;
   constexpr int TM = BM / (32 * WR), TN = BN / 64;
   static_assert(BM * 2 == NT, "a thread owns one A row and one octet position");
@@ -92,7 +96,7 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
   const int n0 = col_t * BN;
   const int HoWo = d.Ho * d.Wo;
   const int ctiles = a.ctiles;
-  const int64_t pixb = (int64_t)ctiles * 64;      // bytes per pixel of x_ps
+  const int64_t pixb = (int64_t)ctiles * (NS * 32);   // bytes per pixel of x_ps
 
   // ---- this thread's A row ----------------------------------------------------------------
   // Both operands are fetched with BUFFER loads (buffer_load_dwordx4 ... lds): a scalar resource +
@@ -185,11 +189,12 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bool live = ikt + ks < nk_loc;        // (beyond the end: zeros into a slot nobody reads)
-      const int voff = (tap_ok && live) ? r_off + (tap_off + ct * 64) : kOob;
+      const int voff = (tap_ok && live) ? r_off + (tap_off + ct * (NS * 32)) : kOob;
       char* const dst = base + ks * ST1 + wbase;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_t*)dst, 16, voff, 0, 0, 0);
       // (the lo half through the SCALAR offset: an immediate offset would move the LDS address too)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_t*)(dst + A_PART), 16, voff, 32, 0, 0);
+      if constexpr (NS == 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_t*)(dst + A_PART), 16, voff, 32, 0, 0);
       // (branch-free: the loop body stays ONE basic block, so that the issues can be scheduled
       //  between the MFMAs)
       const bool cw = ct + 1 == ctiles;
@@ -298,12 +303,17 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA], bv[j][PB], acc[i][j], 0, 0, 0);
       if (!(SNAP_PS_ABLATE & 8)) {
-        SNAP_PS_PRODUCT(1, 0)
-        if (KS == 1) {
-          if (!(SNAP_PS_ABLATE & 1) && grp == 1) issue(islot);
+        if constexpr (NS == 2) {
+          SNAP_PS_PRODUCT(1, 0)
+          if (KS == 1) {
+            if (!(SNAP_PS_ABLATE & 1) && grp == 1) issue(islot);
+          }
+          SNAP_PS_PRODUCT(0, 1)
+          SNAP_PS_PRODUCT(0, 0)
+        } else {
+          static_assert(NS == 2 || NT == 256 || KS > 1, "one-part 512-thread tiles: two k-steps per stage");
+          SNAP_PS_PRODUCT(0, 0)
         }
-        SNAP_PS_PRODUCT(0, 1)
-        SNAP_PS_PRODUCT(0, 0)
       } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -319,7 +329,7 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
     islot = islot + 1 == NST ? 0 : islot + 1;
   }
   __syncthreads();              // the last stage is read: the ring becomes the epilogue's buffer
-  conv_epilogue<BM, BN, DUAL, NT, RES_INIT>(a, acc, smem, m0, n0, Meff, row_t, split);
+  conv_epilogue<BM, BN, DUAL, NT, RES_INIT, OUTH>(a, acc, smem, m0, n0, Meff, row_t, split);
 }
 
 // workgroups per CU: three of 256 threads (48 KB), two of 512 threads (72 KB), or ONE 256 x 192
@@ -327,6 +337,23 @@ __device__ __forceinline__ void conv_ps_body(const ConvArgs& a) {
 template <int BM, int BN, int NT, int KS, int NST, bool RES_INIT, bool DUAL>
 __global__ __launch_bounds__(NT, NT == 512 ? (BN == 192 ? 2 : 4) : 3) void conv_ps_kernel(const ConvArgs a) {
   conv_ps_body<BM, BN, NT, KS, NST, RES_INIT, DUAL>(a);
+}
+
+// the one-part (bf16) engine: 256 x 128 tiles on 512 threads, two k-steps per stage (the same 24 KB stages and
+// 72 KB ring as the two-part tile), or 128 x 128 on 256 threads
+template <int BM, int BN, int NT, int KS, int NST, int OUTH>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void conv_ps1_kernel(const ConvArgs a) {
+  conv_ps_body<BM, BN, NT, KS, NST, false, false, 1, OUTH>(a);
+}
+
+template <int BM, int BN, int NT, int KS, int NST>
+int launch_variant1(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  if (a.y_half)
+    hipLaunchKernelGGL((conv_ps1_kernel<BM, BN, NT, KS, NST, 1>), grid, dim3(NT), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_ps1_kernel<BM, BN, NT, KS, NST, 0>), grid, dim3(NT), 0, s, a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
 }
 
 template <int BM, int BN, int NT, int KS, int NST>
@@ -404,6 +431,26 @@ int snapconv::launch_ps(ConvArgs a, hipStream_t s) {
   if (!a.x_ps || !a.w_bf16) return SNAP_ERR_NULL;
   if (a.rows_in || a.rows_out || a.row_count) return SNAP_ERR_UNSUPPORTED;
   if (!ps_shape_supported(d)) return SNAP_ERR_UNSUPPORTED;
+  if (a.ps_parts == 1) {
+    // one part: no statistics / split-K / residual pre-load variants (the ViT's dense layers need none)
+    if (a.gn_partial || (d.epilogue & SNAP_EPI_UPSAMPLE2X_ADD)) return SNAP_ERR_UNSUPPORTED;
+    const int64_t t256 = snap_cdiv((int64_t)a.M, 256) * snap_cdiv((int64_t)d.Cout, 128);
+    const bool big = a.ps_tile == 2 || (a.ps_tile == 0 && t256 >= 384);
+    const int bm = big ? 256 : 128;
+    a.ctiles = d.Cin / 16;
+    a.nk = d.KH * d.KW * a.ctiles;
+    a.ncol = (int)snap_cdiv(d.Cout, 128);
+    a.gn_slabs = 0;
+    const int64_t nblocks = snap_cdiv(snap_cdiv((int64_t)a.M, bm), 8) * 8 * a.ncol;
+    if (nblocks > 0x7fffffffLL) return SNAP_ERR_BAD_SHAPE;
+    a.ksplit = 1;
+    a.kpartial = nullptr;
+    a.tiles_per_split = (int)nblocks;
+    a.slabs_per_split = a.nk;
+    const dim3 grid((unsigned)nblocks);
+    return big ? launch_variant1<256, 128, 512, 2, 3>(a, grid, s) : launch_variant1<128, 128, 256, 1, 3>(a, grid, s);
+  }
+  if (a.y_half) return SNAP_ERR_UNSUPPORTED;
   const PsTile t = ps_choose_tile(a.M, d.Cout, a.ps_tile);
   a.ctiles = d.Cin / 16;
   a.nk = d.KH * d.KW * a.ctiles;

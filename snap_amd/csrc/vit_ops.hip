@@ -23,9 +23,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // flax.linen.LayerNorm).  C % 4 == 0, C <= 64 * 4 * LN_MAXQ.
 constexpr int LN_MAXQ = 4;   // float4 per lane: C <= 1024
 
+// HALF: the row goes out rounded (RNE) to bf16 into y_half INSTEAD of y -- the operand of the dense layer that
+// follows, which rounds it to that type anyway (snap_layer_norm_bf16out_f32)
+template <bool HALF>
 __global__ __launch_bounds__(256) void layer_norm_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ y, int64_t M, int C, float eps) {
+    float* __restrict__ y, int64_t M, int C, float eps, __bf16* __restrict__ y_half = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -61,7 +64,12 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-      *reinterpret_cast<f32x4*>(y + m * C + 4 * q) = o;
+      if constexpr (HALF) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4*>(y_half + m * C + 4 * q) = __builtin_convertvector(o, bf16x4);
+      } else {
+        *reinterpret_cast<f32x4*>(y + m * C + 4 * q) = o;
+      }
     }
   }
 }
@@ -76,6 +84,8 @@ constexpr int AT_VS = 136;      // V^T row stride in LDS, bytes (128 + 8: b64 re
 struct AttnArgs {
   const float* qkv;   // [B, N, 3, H, 64]
   float* out;         // [B, N, H * 64]
+  __bf16* out_half;   // non-null: the output rounded (RNE) to bf16 goes HERE instead of `out` (inference: the operand
+                      // of the output projection)
   float* lse;         // optional [B, H, N]: base-2 log-sum-exp of the scaled scores (for the VJP)
   int B, N, H;
   float scale_log2e;  // softmax scale * log2(e)
@@ -241,7 +251,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const int q = q0 + row;
     if (q < a.N) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 68 + 4 * qd);
-      *reinterpret_cast<f32x4*>(a.out + ((int64_t)b * a.N + q) * (a.H * AT_D) + h * AT_D + 4 * qd) = v;
+      if (a.out_half) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4*>(a.out_half + ((int64_t)b * a.N + q) * (a.H * AT_D) + h * AT_D + 4 * qd) =
+            __builtin_convertvector(v, bf16x4);
+      } else {
+        *reinterpret_cast<f32x4*>(a.out + ((int64_t)b * a.N + q) * (a.H * AT_D) + h * AT_D + 4 * qd) = v;
+      }
     }
   }
 }
@@ -255,8 +271,22 @@ extern "C" int snap_layer_norm_f32(const float* x, const float* gamma, const flo
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
       (reinterpret_cast<uintptr_t>(gamma) & 15) || (reinterpret_cast<uintptr_t>(beta) & 15))
     return SNAP_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)snap_cdiv(M, 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, gamma, beta, y, M, C, eps);
+  hipLaunchKernelGGL(layer_norm_kernel<false>, dim3((unsigned)snap_cdiv(M, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, gamma, beta, y, M, C, eps, (__bf16*)nullptr);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
+extern "C" int snap_layer_norm_bf16out_f32(const float* x, const float* gamma, const float* beta, void* y_bf16,
+                                           int64_t M, int32_t C, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y_bf16) return SNAP_ERR_NULL;
+  if (M <= 0 || C <= 0 || C % 4 != 0 || C > 256 * LN_MAXQ) return SNAP_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y_bf16) & 7) ||
+      (reinterpret_cast<uintptr_t>(gamma) & 15) || (reinterpret_cast<uintptr_t>(beta) & 15))
+    return SNAP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(layer_norm_kernel<true>, dim3((unsigned)snap_cdiv(M, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, gamma, beta, (float*)nullptr, M, C, eps,
+                     static_cast<__bf16*>(y_bf16));
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }
@@ -266,17 +296,32 @@ extern "C" int snap_attention_bf16_f32(const float* qkv, float* out, int32_t B, 
   return snap_attention_lse_bf16_f32(qkv, out, nullptr, B, N, H, D, scale, stream);
 }
 
+static int attention_launch(const float* qkv, float* out, void* out_bf16, float* lse, int32_t B, int32_t N, int32_t H,
+                            int32_t D, float scale, void* stream);
+
 extern "C" int snap_attention_lse_bf16_f32(const float* qkv, float* out, float* lse, int32_t B,
                                            int32_t N, int32_t H, int32_t D, float scale,
                                            void* stream) {
-  if (!qkv || !out) return SNAP_ERR_NULL;
+  if (!out) return SNAP_ERR_NULL;
+  return attention_launch(qkv, out, nullptr, lse, B, N, H, D, scale, stream);
+}
+
+extern "C" int snap_attention_bf16out_f32(const float* qkv, void* out_bf16, int32_t B, int32_t N, int32_t H,
+                                          int32_t D, float scale, void* stream) {
+  if (!out_bf16 || (reinterpret_cast<uintptr_t>(out_bf16) & 7)) return out_bf16 ? SNAP_ERR_BAD_SHAPE : SNAP_ERR_NULL;
+  return attention_launch(qkv, nullptr, out_bf16, nullptr, B, N, H, D, scale, stream);
+}
+
+static int attention_launch(const float* qkv, float* out, void* out_bf16, float* lse, int32_t B, int32_t N, int32_t H,
+                            int32_t D, float scale, void* stream) {
+  if (!qkv || (!out && !out_bf16)) return SNAP_ERR_NULL;
   if (B <= 0 || N <= 0 || H <= 0) return SNAP_ERR_BAD_SHAPE;
   if (D != AT_D) return SNAP_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
     return SNAP_ERR_BAD_SHAPE;
   if (B > 65535 || H > 65535) return SNAP_ERR_BAD_SHAPE;
   AttnArgs a;
-  a.qkv = qkv; a.out = out; a.lse = lse; a.B = B; a.N = N; a.H = H;
+  a.qkv = qkv; a.out = out; a.out_half = static_cast<__bf16*>(out_bf16); a.lse = lse; a.B = B; a.N = N; a.H = H;
   a.scale_log2e = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)snap_cdiv(N, 4 * AT_QW), (unsigned)H, (unsigned)B);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -109,21 +109,25 @@ class ViTEncoder(base.Module):
                    prologue=ops.PRO_AFFINE, in_affine=(2.0, -1.0), bias=params['embedding']['bias'])
     N, h, w, _ = x.shape
     x = (x.reshape(N, h * w, C) + self._posemb(params['pos_embedding'], (h, w))).contiguous()
+    # 'bf16' GEMMs: every dense layer's INPUT is produced in bf16 by the kernel in front of it (LayerNorm, attention,
+    # the GELU epilogue of the first MLP layer) -- the values the engine would round to anyway -- so that both GEMM
+    # operands travel by LDS-DMA (conv_ps.hip, one part); the residual stream and qkv stay f32
+    hb = math == 'bf16' and ops.tuning().BF16_PS and C % 16 == 0 and cfg.mlp_dim % 16 == 0
     for i in range(cfg.num_layers):
       blk = params['Transformer'][f'encoderblock_{i}']
       att = blk['MultiHeadDotProductAttention_0']
       wqkv = torch.cat([att[n]['kernel'].reshape(C, C) for n in ('query', 'key', 'value')], dim=1)
       bqkv = torch.cat([att[n]['bias'].reshape(C) for n in ('query', 'key', 'value')])
-      y = ops.layer_norm(x, blk['LayerNorm_0']['scale'], blk['LayerNorm_0']['bias'])
+      y = ops.layer_norm(x, blk['LayerNorm_0']['scale'], blk['LayerNorm_0']['bias'], out_half=hb)
       qkv = ops.dense(y, wqkv.contiguous(), bqkv, math=math).reshape(N, h * w, 3, H, D)
-      a = ops.attention(qkv)
+      a = ops.attention(qkv, out_half=hb)
       x = ops.dense(a, att['out']['kernel'].reshape(C, C), att['out']['bias'], residual=x, math=math)
-      y = ops.layer_norm(x, blk['LayerNorm_1']['scale'], blk['LayerNorm_1']['bias'])
+      y = ops.layer_norm(x, blk['LayerNorm_1']['scale'], blk['LayerNorm_1']['bias'], out_half=hb)
       mlp = blk['MlpBlock_0']
-      y = ops.dense(y, mlp['Dense_0']['kernel'], mlp['Dense_0']['bias'], gelu=True, math=math)
+      y = ops.dense(y, mlp['Dense_0']['kernel'], mlp['Dense_0']['bias'], gelu=True, math=math, out_half=hb)
       x = ops.dense(y, mlp['Dense_1']['kernel'], mlp['Dense_1']['bias'], residual=x, math=math)
     norm = params['Transformer']['encoder_norm']
-    x = ops.layer_norm(x, norm['scale'], norm['bias'])
+    x = ops.layer_norm(x, norm['scale'], norm['bias'], out_half=hb)
     x = ops.dense(x, params['proj']['kernel'], params['proj']['bias'], math=math)
     return x.reshape(N, h, w, self.output_dim)
 

@@ -75,6 +75,7 @@ _TUNING_DEFAULTS = {
     'USE_PRESPLIT_VOTING': True,
     'PS_RES_INIT': True,
     'PS_TILE': 0,
+    'BF16_PS': True,          # a bf16 input (x already in the engine's type) on the one-part pre-split engine (conv_ps.hip NS = 1)
     'USE_FUSED_GN_STATS': True,
     'GN_STATS_BOTH': True,
     'USE_SPLITK': True,
@@ -526,7 +527,7 @@ def conv2d(
     want = 'fp16' if x.dtype == torch.float16 else 'bf16'
     math = want if math is None else math
     if (math != want or prologue != PRO_NONE or rows_in is not None or x.shape[-1] % 8 or w.shape[2] % 8
-        or emit_gn_stats is not None or out_half):
+        or emit_gn_stats is not None):
       raise ValueError('conv2d: a half-precision input takes the matching engine, prologue NONE, whole '
                        'channel octets, no input row list / statistics')
     _chk(x, x.dtype, 'x')
@@ -626,6 +627,15 @@ def conv2d(
   if parts and lib.snap_conv2d_packed_weights_split_bytes(KH * KW, Cin, Cout, parts) == 0:
     math, parts = 'f32', 0     # weight image beyond the split engine's 32-bit offsets (template banks)
   qparts = parts if (Cs % 4 == 0 and Cin >= 4 and not ps) else 0   # (what SnapConvExtras.w_split_parts will say)
+  # a bf16 input whose launch needs nothing but the GEMM + a plain epilogue runs on the ONE-PART pre-split engine
+  # (conv_ps.hip, NS = 1: both operands by LDS-DMA through the three-stage ring, 256 x 128 tiles) -- the same
+  # arithmetic as the training-precision engine (operands rounded to bf16, f32 accumulate)
+  ps1 = bool(xh and x.dtype == torch.bfloat16 and math == 'bf16' and tuning().BF16_PS and Cs == Cin and Cin % 16 == 0
+             and rows_out is None and row_count is None and up_prev is None and gn_bwd_stats is None
+             and out is None and Cout % 4 == 0 and lib.snap_conv2d_presplit_supported(ctypes.byref(d)))
+  if xh and out_half and not ps1:
+    raise ValueError('conv2d: a half-precision input AND output need the one-part pre-split engine (bf16, Cin % 16 == 0, '
+                     'no row lists)')
   ex = None
   partial = partial2 = None
   kws = None
@@ -638,8 +648,8 @@ def conv2d(
     pst = (tuning().PS_TILE if ps_tile is None else int(ps_tile)) if ps else 0
     if ps:
       wbytes = lib.snap_conv2d_presplit_workspace_bytes(ctypes.byref(d), pst) if tuning().USE_SPLITK else 0
-    elif qparts == 2 and lib.snap_conv2d_stationary_kind(ctypes.byref(d), qparts):
-      wbytes = 0        # a stationary-operand kernel takes the launch: it never splits K
+    elif ps1 or (qparts == 2 and lib.snap_conv2d_stationary_kind(ctypes.byref(d), qparts)):
+      wbytes = 0        # a stationary-operand kernel / the one-part pre-split engine takes the launch: it never splits K
     else:
       wbytes = lib.snap_conv2d_workspace_bytes(ctypes.byref(d)) if (tuning().USE_SPLITK and yh is None) else 0
     if wbytes:   # small-M / deep-K layer: split K
@@ -699,6 +709,18 @@ def conv2d(
     ex.w_split_parts = parts
     ex.w_split_root = 1
     family = f'conv_split_{math}'
+  elif ps1:
+    wpk = _packed_weights(w, 'bf16/ps1', 1)
+    if ex is None:
+      ex = _lib.SnapConvExtras(None, None, None, None, 0, 0, None, 0, None, 0)
+    ex.w_bf16 = wpk.data_ptr()
+    ex.w_bf16_bytes = wpk.numel() * 2
+    ex.w_split_parts = 1
+    ex.x_presplit = 1
+    ex.ps_tile = int(tuning().PS_TILE if ps_tile is None else ps_tile)
+    if yh is not None:
+      ex.y_half = yh.data_ptr()
+    family = 'conv_bf16'
   elif math != 'f32' and Cs % 4 == 0 and Cin >= 4:
     wpk = w_img.data if pw else _packed_weights(w, math, parts)
     if ex is None:
@@ -733,7 +755,7 @@ def conv2d(
           if (qparts == 2 and rows_in is None and rows_out is None and row_count is None) else 0)
   with _region(
       family, flops, nbytes,
-      lambda: f'{"PS_" if ps else ("", "RS_", "WS_", "WS_")[kind]}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
+      lambda: f'{"PS_" if ps else "PS1_" if ps1 else ("", "RS_", "WS_", "WS_")[kind]}M{M}{"r" if row_count is not None else ""}_K{KH}x{KW}x{Cin}_N{Cout}'
               f'_s{stride}_p{prologue}_e{epi}',
   ):
     st = lib.snap_conv2d_nhwc_ex_f32(
@@ -1015,12 +1037,19 @@ def stack_templates(tw, S, layout='hwdr'):
   return tws
 
 
-def layer_norm(x, gamma, beta, eps=1e-6):
-  """LayerNorm over the last axis (flax.linen.LayerNorm: biased variance, eps inside the sqrt)."""
+def layer_norm(x, gamma, beta, eps=1e-6, out_half=False):
+  """LayerNorm over the last axis (flax.linen.LayerNorm: biased variance, eps inside the sqrt).
+  out_half: the result ONLY rounded to bf16 (the operand of a 'bf16' dense layer, which rounds it anyway)."""
   lib = _lib.load()
   _f32(x, 'x'); _f32(gamma, 'gamma'); _f32(beta, 'beta')
   C = x.shape[-1]
   M = x.numel() // C
+  if out_half:
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    with _region('layer_norm', 0.0, 6.0 * x.numel()):
+      st = lib.snap_layer_norm_bf16out_f32(_p(x), _p(gamma), _p(beta), _p(y), M, C, float(eps), _stream())
+    _lib.check(st, 'snap_layer_norm_bf16out_f32')
+    return y
   y = torch.empty_like(x)
   with _region('layer_norm', 0.0, 8.0 * x.numel()):
     st = lib.snap_layer_norm_f32(_p(x), _p(gamma), _p(beta), _p(y), M, C, float(eps), _stream())
@@ -1028,16 +1057,25 @@ def layer_norm(x, gamma, beta, eps=1e-6):
   return y
 
 
-def attention(qkv, scale=None, want_lse=False):
+def attention(qkv, scale=None, want_lse=False, out_half=False):
   """Multi-head self-attention on the bf16 matrix cores.  qkv [B, N, 3, H, 64] (fused QKV
   projection output, f32) -> [B, N, H*64] f32 = softmax(scale * Q K^T) V per head.
-  want_lse: also return the base-2 log-sum-exp of the scaled scores [B, H, N] (for the VJP)."""
+  want_lse: also return the base-2 log-sum-exp of the scaled scores [B, H, N] (for the VJP).
+  out_half (inference): the result ONLY rounded to bf16 (the operand of the 'bf16' output projection)."""
   lib = _lib.load()
   _f32(qkv, 'qkv')
   B, N, three, H, D = qkv.shape
   if three != 3:
     raise ValueError('attention: qkv must be [B, N, 3, H, D]')
   scale = D ** -0.5 if scale is None else float(scale)
+  if out_half:
+    if want_lse:
+      raise ValueError('attention: out_half is the inference form (no lse)')
+    out = torch.empty((B, N, H * D), dtype=torch.bfloat16, device=qkv.device)
+    with _region('attention', 4.0 * B * H * N * N * D, 4.0 * qkv.numel() + 2.0 * out.numel()):
+      st = lib.snap_attention_bf16out_f32(_p(qkv), _p(out), B, N, H, D, scale, _stream())
+    _lib.check(st, 'snap_attention_bf16out_f32')
+    return out
   out = torch.empty((B, N, H * D), dtype=torch.float32, device=qkv.device)
   lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
   with _region('attention', 4.0 * B * H * N * N * D, 4.0 * (qkv.numel() + out.numel())):
