@@ -119,16 +119,16 @@ class ViTEncoder(base.Module):
       wqkv = torch.cat([att[n]['kernel'].reshape(C, C) for n in ('query', 'key', 'value')], dim=1)
       bqkv = torch.cat([att[n]['bias'].reshape(C) for n in ('query', 'key', 'value')])
       y = ops.layer_norm(x, blk['LayerNorm_0']['scale'], blk['LayerNorm_0']['bias'], out_half=hb)
-      qkv = ops.dense(y, wqkv.contiguous(), bqkv, math=math).reshape(N, h * w, 3, H, D)
+      qkv = ops.dense(y, wqkv.contiguous(), bqkv, math=math, bf16_ring=hb).reshape(N, h * w, 3, H, D)
       a = ops.attention(qkv, out_half=hb)
-      x = ops.dense(a, att['out']['kernel'].reshape(C, C), att['out']['bias'], residual=x, math=math)
+      x = ops.dense(a, att['out']['kernel'].reshape(C, C), att['out']['bias'], residual=x, math=math, bf16_ring=hb)
       y = ops.layer_norm(x, blk['LayerNorm_1']['scale'], blk['LayerNorm_1']['bias'], out_half=hb)
       mlp = blk['MlpBlock_0']
-      y = ops.dense(y, mlp['Dense_0']['kernel'], mlp['Dense_0']['bias'], gelu=True, math=math, out_half=hb)
-      x = ops.dense(y, mlp['Dense_1']['kernel'], mlp['Dense_1']['bias'], residual=x, math=math)
+      y = ops.dense(y, mlp['Dense_0']['kernel'], mlp['Dense_0']['bias'], gelu=True, math=math, out_half=hb, bf16_ring=hb)
+      x = ops.dense(y, mlp['Dense_1']['kernel'], mlp['Dense_1']['bias'], residual=x, math=math, bf16_ring=hb)
     norm = params['Transformer']['encoder_norm']
     x = ops.layer_norm(x, norm['scale'], norm['bias'], out_half=hb)
-    x = ops.dense(x, params['proj']['kernel'], params['proj']['bias'], math=math)
+    x = ops.dense(x, params['proj']['kernel'], params['proj']['bias'], math=math, bf16_ring=hb)
     return x.reshape(N, h, w, self.output_dim)
 
 

@@ -75,7 +75,7 @@ _TUNING_DEFAULTS = {
     'USE_PRESPLIT_VOTING': True,
     'PS_RES_INIT': True,
     'PS_TILE': 0,
-    'BF16_PS': True,          # a bf16 input (x already in the engine's type) on the one-part pre-split engine (conv_ps.hip NS = 1)
+    'BF16_PS': True,          # conv2d(bf16_ring=True) launches take the one-part pre-split engine (conv_ps.hip NS = 1); False: the x_half engine
     'USE_FUSED_GN_STATS': True,
     'GN_STATS_BOTH': True,
     'USE_SPLITK': True,
@@ -484,7 +484,7 @@ def conv2d(
     gn=None, in_affine=(1.0, 0.0), bias=None, relu=False, residual=None,
     up_prev=None, row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None,
     emit_gn_stats=None, math=None, gelu=False, res_init=None, ps_tile=None, out_half=False, out_stride=None,
-    gn_bwd_stats=None,
+    gn_bwd_stats=None, bf16_ring=False,
 ):
   """NHWC implicit-GEMM conv on the matrix cores.  x [N,H,W,Cs]; w [KH,KW,Cin,Cout] (HWIO).
 
@@ -514,6 +514,11 @@ def conv2d(
   result as its incoming gradient (x_gn [N,Ho,Wo,Cout] is that GroupNorm's input, mode its prologue);
   ``ops_bwd.group_norm_bwd`` finds them on the result (``y._snap_gnb_partial``) and skips its first pass.
   Silently not done where the launch splits K or the shape has no statistics layout.
+  bf16_ring (a bf16 input, math 'bf16', Cin % 16 == 0, no row lists / statistics / split-K): the launch runs on the
+  ONE-PART pre-split engine (conv_ps.hip, NS = 1: both operands by LDS-DMA through the three-stage ring, 256 x 128
+  tiles) -- the arithmetic of the training-precision engine (1 x 1: the same bits), 500-730 instead of 350-560
+  TFLOP/s on large dense layers; it never splits K, so small-M / deep-K launches (the training step's) stay where
+  they are: opt-in per call (the ViT encoder's inference path).  ``Tuning.BF16_PS = False`` turns it off.
   out_stride (with ``out``, a multiple of 4 >= Cout): out's rows hold out_stride floats and the result goes
   to their first Cout (the other columns are not touched); no statistics, residual or up-sampling epilogue.
   Returns y [N,Ho,Wo,Cout] (``out`` itself, [.., out_stride], with out_stride).
@@ -630,7 +635,7 @@ def conv2d(
   # a bf16 input whose launch needs nothing but the GEMM + a plain epilogue runs on the ONE-PART pre-split engine
   # (conv_ps.hip, NS = 1: both operands by LDS-DMA through the three-stage ring, 256 x 128 tiles) -- the same
   # arithmetic as the training-precision engine (operands rounded to bf16, f32 accumulate)
-  ps1 = bool(xh and x.dtype == torch.bfloat16 and math == 'bf16' and tuning().BF16_PS and Cs == Cin and Cin % 16 == 0
+  ps1 = bool(bf16_ring and xh and x.dtype == torch.bfloat16 and math == 'bf16' and tuning().BF16_PS and Cs == Cin and Cin % 16 == 0
              and rows_out is None and row_count is None and up_prev is None and gn_bwd_stats is None
              and out is None and Cout % 4 == 0 and lib.snap_conv2d_presplit_supported(ctypes.byref(d)))
   if xh and out_half and not ps1:
@@ -962,7 +967,7 @@ def packed_rot_image(w, math='bf16'):
 
 def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
           row_mask=None, rows_in=None, rows_out=None, row_count=None, out=None, math=None,
-          gelu=False, residual=None, out_half=False, out_stride=None):
+          gelu=False, residual=None, out_half=False, out_stride=None, bf16_ring=False):
   """x [..., Cs] @ kernel [Cin, Cout] (+bias) through the conv engine (1x1).  out_stride: ``conv2d``."""
   lead = x.shape[:-1]
   M = int(np.prod(lead)) if len(lead) else 1
@@ -979,6 +984,7 @@ def dense(x, kernel, bias=None, *, cin=None, prologue=PRO_NONE, relu=False,
       row_count=row_count, out=None if out is None else out.reshape(1, 1, M, kernel.shape[1]),
       math=math, gelu=gelu,
       residual=None if residual is None else residual.reshape(1, 1, M, kernel.shape[1]), out_half=out_half,
+      bf16_ring=bf16_ring,
   )
   return y.reshape(*lead, kernel.shape[1])
 

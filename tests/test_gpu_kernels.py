@@ -1843,6 +1843,55 @@ def test_attention(B, N, H):
   helpers.report(f'attention vs exact f64 B{B} N{N} H{H}', got, exact, atol=2e-2 * scale, rtol=0)
 
 
+def _dev(t):
+  return t.to(DEV).contiguous()
+
+
+@pytest.mark.parametrize('M,K,N', [(300, 192, 256), (1000, 768, 100), (2500, 32, 2304), (257, 3072, 768), (20, 16, 4)])
+def test_bf16_ring_engine_is_the_half_input_engine_bit_for_bit(M, K, N):
+  """``conv2d(bf16_ring=True)`` (conv_ps.hip, one part: a bf16 input, both operands by LDS-DMA through the ring):
+  a 1 x 1 launch gives the bits of the x_half engine (without its split-K) -- plain, bias + GELU, residual, bf16-only
+  output -- on row / column counts that leave partial tiles; both agree with float64 on the bf16-rounded operands."""
+  x = _dev(rnd((M, K), 220 + M))
+  w = _dev(rnd((K, N), 221, 1 / np.sqrt(K)))
+  b = _dev(rnd((N,), 222))
+  res = _dev(rnd((M, N), 223))
+  xb = x.to(torch.bfloat16)
+  ref = xb.double() @ w.to(torch.bfloat16).double() + b.double()
+  for kw in (dict(), dict(gelu=True), dict(residual=res), dict(relu=True)):
+    ring = ops.dense(xb, w, b, math='bf16', bf16_ring=True, **kw)
+    with ops.tuning_scope(USE_SPLITK=False):                  # (the ring never splits K: the same order of the k-steps)
+      half = ops.dense(xb, w, b, math='bf16', **kw)
+    assert torch.equal(ring, half), (kw, float((ring - half).abs().max()))
+  ring = ops.dense(xb, w, b, math='bf16', bf16_ring=True)
+  helpers.report(f'bf16 ring {M}x{K}x{N}', ring, ref.float(), atol=3e-5 * float(ref.abs().max()) + 1e-6, rtol=0)
+  # the bf16-only output is the f32 output rounded
+  rh = ops.dense(xb, w, b, math='bf16', bf16_ring=True, gelu=True, out_half=True)
+  rf = ops.dense(xb, w, b, math='bf16', bf16_ring=True, gelu=True)
+  assert rh.dtype == torch.bfloat16 and torch.equal(rh, rf.to(torch.bfloat16))
+  with ops.tuning_scope(BF16_PS=False):                       # (the switch: the call falls back to the x_half engine)
+    assert torch.equal(ops.dense(xb, w, b, math='bf16', bf16_ring=True), ops.dense(xb, w, b, math='bf16'))
+
+
+def test_bf16_ring_engine_3x3_conv():
+  """The same engine under a padded 3 x 3 convolution (taps outside the image read zeros through the buffer range
+  check): equal to the x_half engine to summation order."""
+  x = _dev(rnd((3, 13, 11, 64), 230)).to(torch.bfloat16)
+  w = _dev(rnd((3, 3, 64, 96), 231, 1 / 24.0))
+  pad = ((1, 1), (1, 1))
+  ring = ops.conv2d(x, w, padding=pad, math='bf16', bf16_ring=True)
+  half = ops.conv2d(x, w, padding=pad, math='bf16')
+  helpers.report('bf16 ring 3x3', ring, half, atol=2e-5 * float(half.abs().max()), rtol=0)
+
+
+def test_bf16_outputs_of_layer_norm_and_attention_are_the_rounded_f32_outputs():
+  x = _dev(rnd((130, 768), 240) * 1.7 + 0.3)
+  gamma, beta = _dev(rnd((768,), 241) * 0.3 + 1), _dev(rnd((768,), 242) * 0.2)
+  assert torch.equal(ops.layer_norm(x, gamma, beta, out_half=True), ops.layer_norm(x, gamma, beta).to(torch.bfloat16))
+  qkv = _dev(rnd((2, 200, 3, 3, 64), 243))
+  assert torch.equal(ops.attention(qkv, out_half=True), ops.attention(qkv).to(torch.bfloat16))
+
+
 # ----------------------------------------------------------------------------
 # generic grid operators (snap/utils/grids.py:116-153)
 # ----------------------------------------------------------------------------

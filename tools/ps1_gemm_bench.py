@@ -20,18 +20,16 @@ for (K, N) in [(768, 2304), (768, 768), (768, 3072), (3072, 768), (768, 128)]:
   xb = x.to(torch.bfloat16)
   ref = (xb.float() @ w.to(torch.bfloat16).float()) + b
   y0 = ops.dense(x, w, b, math='bf16')
-  y1 = ops.dense(xb, w, b, math='bf16')
-  with ops.tuning_scope(BF16_PS=False):
-    y2 = ops.dense(xb, w, b, math='bf16')
-  yh = ops.dense(xb, w, b, math='bf16', gelu=True, out_half=True)
+  y1 = ops.dense(xb, w, b, math='bf16', bf16_ring=True)
+  y2 = ops.dense(xb, w, b, math='bf16')
+  yh = ops.dense(xb, w, b, math='bf16', gelu=True, out_half=True, bf16_ring=True)
   refh = torch.nn.functional.gelu(ref, approximate='tanh')
   e = lambda a: float((a.float() - ref).abs().max())
   print(f'K={K} N={N}: err f32-in {e(y0):.2e} ps1 {e(y1):.2e} xh {e(y2):.2e} ps1==xh {bool(torch.equal(y1, y2))} gelu-half err {float((yh.float() - refh).abs().max()):.2e}')
   t0 = timeit(lambda: ops.dense(x, w, b, math='bf16'))
-  t1 = timeit(lambda: ops.dense(xb, w, b, math='bf16'))
-  with ops.tuning_scope(BF16_PS=False):
-    t2 = timeit(lambda: ops.dense(xb, w, b, math='bf16'))
-  t3 = timeit(lambda: ops.dense(xb, w, b, math='bf16', residual=y0))
-  t4 = timeit(lambda: ops.dense(xb, w, b, math='bf16', gelu=True, out_half=True))
+  t1 = timeit(lambda: ops.dense(xb, w, b, math='bf16', bf16_ring=True))
+  t2 = timeit(lambda: ops.dense(xb, w, b, math='bf16'))
+  t3 = timeit(lambda: ops.dense(xb, w, b, math='bf16', residual=y0, bf16_ring=True))
+  t4 = timeit(lambda: ops.dense(xb, w, b, math='bf16', gelu=True, out_half=True, bf16_ring=True))
   fl = 2.0 * M * K * N / 1e9
   print(f'   f32-in {t0*1e3:7.1f} us {fl/t0:6.0f} TF | ps1 {t1*1e3:7.1f} us {fl/t1:6.0f} TF | xh {t2*1e3:7.1f} us {fl/t2:6.0f} TF | ps1+res {t3*1e3:7.1f} | ps1 gelu half-out {t4*1e3:7.1f}')
