@@ -327,6 +327,11 @@ int snap_layer_norm_bf16out_f32(const float* x, const float* gamma, const float*
                                 int64_t M, int32_t C, float eps, void* stream);
 int snap_attention_bf16out_f32(const float* qkv, void* out_bf16, int32_t B, int32_t N, int32_t H,
                                int32_t D, float scale, void* stream);
+/* ... and with qkv itself in bf16 (the QKV projection's bf16-only output, y_half): K and V are the values the f32 form
+ * rounds to, moved at half the bytes (the kernel is bound by the L2 traffic of the K / V panels); Q is scaled after
+ * its rounding. */
+int snap_attention_bf16io(const void* qkv_bf16, void* out_bf16, int32_t B, int32_t N, int32_t H, int32_t D,
+                          float scale, void* stream);
 /* Training path of the ViT pieces.  snap_attention_lse_bf16_f32 also returns lse [B, H, N], the
  * base-2 log-sum-exp of the scaled scores; snap_attention_bwd_bf16_f32 turns (qkv, out, dout,
  * lse) into dqkv (same layout as qkv; delta [B, H, N] is scratch) with two atomic-free kernels

@@ -1,12 +1,11 @@
 #!/bin/bash
-# round 6: the one-part pre-split engine under the ViT encoder -- tests, C5 A/B (ops.Tuning BF16_PS), kernel stats
+# round 6: the one-part pre-split engine under the ViT encoder -- tests, C5 A/B (process-default ops.BF16_PS), kernel stats
 set -u
 cd "$(dirname "$0")/.."
 O=gpurun_out/r6vit; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp PYTHONPATH=.
 R=$PWD
-timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_baseline_configs.py tests/test_gpu_kernels.py -m gpu -q -x -k "vit or attention or layer_norm or presplit or dense" 2>&1 | tail -4 | tee $O/tests.log
-python tools/ps1_gemm_bench.py 2>/dev/null | tee $O/gemm.log
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_baseline_configs.py tests/test_gpu_kernels.py -m gpu -q -k "vit or attention or layer_norm or bf16_ring or bf16_outputs or dense" 2>&1 | tail -4 | tee $O/tests.log
 for rep in 1 2; do for ps in 1 0; do
   echo "== BF16_PS=$ps"
   python -c "

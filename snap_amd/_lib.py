@@ -107,6 +107,7 @@ SIGNATURES = {
     'snap_attention_bf16_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_layer_norm_bf16out_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_int, c_float, ptr]),
     'snap_attention_bf16out_f32': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
+    'snap_attention_bf16io': (c_int, [ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_attention_lse_bf16_f32': (c_int, [ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),
     'snap_attention_bwd_bf16_f32': (
         c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_int, c_int, c_int, c_int, c_float, ptr]),

@@ -83,6 +83,7 @@ constexpr int AT_VS = 136;      // V^T row stride in LDS, bytes (128 + 8: b64 re
 
 struct AttnArgs {
   const float* qkv;   // [B, N, 3, H, 64]
+  const __bf16* qkv_h;  // HIN kernels: the same tensor in bf16 (the fused QKV projection's bf16-only output)
   float* out;         // [B, N, H * 64]
   __bf16* out_half;   // non-null: the output rounded (RNE) to bf16 goes HERE instead of `out` (inference: the operand
                       // of the output projection)
@@ -91,6 +92,10 @@ struct AttnArgs {
   float scale_log2e;  // softmax scale * log2(e)
 };
 
+// HIN: qkv arrives in bf16 (a.qkv_h).  K and V are the values the f32 kernel rounds to on its way into LDS -- they
+// travel at half the bytes (a (b, h) panel is re-read by every 128-query workgroup: the kernel is bound by that L2
+// traffic); Q is scaled AFTER its rounding to bf16 (one more rounding than the f32 kernel's bf16(q * scale)).
+template <bool HIN>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (AT_KB * AT_KS + AT_D * AT_VS)];
   char* const Ks0 = smem;
@@ -107,10 +112,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   {
     const int q = min(q0 + l31, a.N - 1);
     const float* qp = base + (int64_t)q * tok_stride;
+    const __bf16* qph = HIN ? a.qkv_h + ((int64_t)b * a.N + q) * tok_stride + (int64_t)h * AT_D : nullptr;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(qp + 16 * s + 8 * lhi);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(qp + 16 * s + 8 * lhi + 4);
+      f32x4 lo, hi;
+      if constexpr (HIN) {
+        const bf16x8 qb = *reinterpret_cast<const bf16x8*>(qph + 16 * s + 8 * lhi);
+        lo = f32x4{(float)qb[0], (float)qb[1], (float)qb[2], (float)qb[3]};
+        hi = f32x4{(float)qb[4], (float)qb[5], (float)qb[6], (float)qb[7]};
+      } else {
+        lo = *reinterpret_cast<const f32x4*>(qp + 16 * s + 8 * lhi);
+        hi = *reinterpret_cast<const f32x4*>(qp + 16 * s + 8 * lhi + 4);
+      }
       const f32x4 l2 = {lo[0] * a.scale_log2e, lo[1] * a.scale_log2e, lo[2] * a.scale_log2e, lo[3] * a.scale_log2e};
       const f32x4 h2 = {hi[0] * a.scale_log2e, hi[1] * a.scale_log2e, hi[2] * a.scale_log2e, hi[3] * a.scale_log2e};
       const bf16x4 bl = __builtin_convertvector(l2, bf16x4), bh = __builtin_convertvector(h2, bf16x4);
@@ -122,27 +135,44 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   const int kq = tid & 15, krow = tid >> 4;        // K: float4 quad of a key row, 16 rows per pass
   const int vq = tid & 15, vg = tid >> 4;          // V: d quad, group of 4 consecutive keys
   f32x4 kr[4], vr[4];
+  bf16x4 krh[4], vrh[4];
   const float* kbase = base + (int64_t)a.H * AT_D;        // K plane
   const float* vbase = base + (int64_t)2 * a.H * AT_D;    // V plane
+  const __bf16* kbase_h = HIN ? a.qkv_h + (int64_t)b * a.N * tok_stride + (int64_t)(a.H + h) * AT_D : nullptr;
+  const __bf16* vbase_h = HIN ? a.qkv_h + (int64_t)b * a.N * tok_stride + (int64_t)(2 * a.H + h) * AT_D : nullptr;
   auto load_block = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int key = min(k0 + krow + 16 * i, a.N - 1);
-      kr[i] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * tok_stride + 4 * kq);
       const int vkey = min(k0 + 4 * vg + i, a.N - 1);
-      vr[i] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)vkey * tok_stride + 4 * vq);
+      if constexpr (HIN) {
+        krh[i] = *reinterpret_cast<const bf16x4*>(kbase_h + (int64_t)key * tok_stride + 4 * kq);
+        vrh[i] = *reinterpret_cast<const bf16x4*>(vbase_h + (int64_t)vkey * tok_stride + 4 * vq);
+      } else {
+        kr[i] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * tok_stride + 4 * kq);
+        vr[i] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)vkey * tok_stride + 4 * vq);
+      }
     }
   };
   auto store_block = [&](int buf) {
     char* ks = Ks0 + buf * (AT_KB * AT_KS);
     char* vs = Vs0 + buf * (AT_D * AT_VS);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<bf16x4*>(ks + (krow + 16 * i) * AT_KS + kq * 8) = __builtin_convertvector(kr[i], bf16x4);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (HIN)
+        *reinterpret_cast<bf16x4*>(ks + (krow + 16 * i) * AT_KS + kq * 8) = krh[i];
+      else
+        *reinterpret_cast<bf16x4*>(ks + (krow + 16 * i) * AT_KS + kq * 8) = __builtin_convertvector(kr[i], bf16x4);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const f32x4 t = {vr[0][e], vr[1][e], vr[2][e], vr[3][e]};   // 4 consecutive keys of channel e
-      *reinterpret_cast<bf16x4*>(vs + (4 * vq + e) * AT_VS + vg * 8) = __builtin_convertvector(t, bf16x4);
+      if constexpr (HIN) {
+        const bf16x4 t = {vrh[0][e], vrh[1][e], vrh[2][e], vrh[3][e]};   // 4 consecutive keys of channel e
+        *reinterpret_cast<bf16x4*>(vs + (4 * vq + e) * AT_VS + vg * 8) = t;
+      } else {
+        const f32x4 t = {vr[0][e], vr[1][e], vr[2][e], vr[3][e]};   // 4 consecutive keys of channel e
+        *reinterpret_cast<bf16x4*>(vs + (4 * vq + e) * AT_VS + vg * 8) = __builtin_convertvector(t, bf16x4);
+      }
     }
   };
 
@@ -312,6 +342,22 @@ extern "C" int snap_attention_bf16out_f32(const float* qkv, void* out_bf16, int3
   return attention_launch(qkv, nullptr, out_bf16, nullptr, B, N, H, D, scale, stream);
 }
 
+extern "C" int snap_attention_bf16io(const void* qkv_bf16, void* out_bf16, int32_t B, int32_t N, int32_t H,
+                                     int32_t D, float scale, void* stream) {
+  if (!qkv_bf16 || !out_bf16) return SNAP_ERR_NULL;
+  if (B <= 0 || N <= 0 || H <= 0 || B > 65535 || H > 65535) return SNAP_ERR_BAD_SHAPE;
+  if (D != AT_D) return SNAP_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(qkv_bf16) & 15) || (reinterpret_cast<uintptr_t>(out_bf16) & 7)) return SNAP_ERR_BAD_SHAPE;
+  AttnArgs a;
+  a.qkv = nullptr; a.qkv_h = static_cast<const __bf16*>(qkv_bf16); a.out = nullptr;
+  a.out_half = static_cast<__bf16*>(out_bf16); a.lse = nullptr; a.B = B; a.N = N; a.H = H;
+  a.scale_log2e = scale * 1.4426950408889634f;
+  const dim3 grid((unsigned)snap_cdiv(N, 4 * AT_QW), (unsigned)H, (unsigned)B);
+  hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  SNAP_CHECK_LAUNCH();
+  return SNAP_OK;
+}
+
 static int attention_launch(const float* qkv, float* out, void* out_bf16, float* lse, int32_t B, int32_t N, int32_t H,
                             int32_t D, float scale, void* stream) {
   if (!qkv || (!out && !out_bf16)) return SNAP_ERR_NULL;
@@ -321,10 +367,10 @@ static int attention_launch(const float* qkv, float* out, void* out_bf16, float*
     return SNAP_ERR_BAD_SHAPE;
   if (B > 65535 || H > 65535) return SNAP_ERR_BAD_SHAPE;
   AttnArgs a;
-  a.qkv = qkv; a.out = out; a.out_half = static_cast<__bf16*>(out_bf16); a.lse = lse; a.B = B; a.N = N; a.H = H;
+  a.qkv = qkv; a.qkv_h = nullptr; a.out = out; a.out_half = static_cast<__bf16*>(out_bf16); a.lse = lse; a.B = B; a.N = N; a.H = H;
   a.scale_log2e = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)snap_cdiv(N, 4 * AT_QW), (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   SNAP_CHECK_LAUNCH();
   return SNAP_OK;
 }

@@ -111,7 +111,8 @@ class ViTEncoder(base.Module):
     x = (x.reshape(N, h * w, C) + self._posemb(params['pos_embedding'], (h, w))).contiguous()
     # 'bf16' GEMMs: every dense layer's INPUT is produced in bf16 by the kernel in front of it (LayerNorm, attention,
     # the GELU epilogue of the first MLP layer) -- the values the engine would round to anyway -- so that both GEMM
-    # operands travel by LDS-DMA (conv_ps.hip, one part); the residual stream and qkv stay f32
+    # operands travel by LDS-DMA (conv_ps.hip, one part); qkv is bf16 too (the attention rounds K / V to it anyway: its
+    # panels move at half the bytes); the residual stream stays f32
     hb = math == 'bf16' and ops.tuning().BF16_PS and C % 16 == 0 and cfg.mlp_dim % 16 == 0
     for i in range(cfg.num_layers):
       blk = params['Transformer'][f'encoderblock_{i}']
@@ -119,7 +120,7 @@ class ViTEncoder(base.Module):
       wqkv = torch.cat([att[n]['kernel'].reshape(C, C) for n in ('query', 'key', 'value')], dim=1)
       bqkv = torch.cat([att[n]['bias'].reshape(C) for n in ('query', 'key', 'value')])
       y = ops.layer_norm(x, blk['LayerNorm_0']['scale'], blk['LayerNorm_0']['bias'], out_half=hb)
-      qkv = ops.dense(y, wqkv.contiguous(), bqkv, math=math, bf16_ring=hb).reshape(N, h * w, 3, H, D)
+      qkv = ops.dense(y, wqkv.contiguous(), bqkv, math=math, bf16_ring=hb, out_half=hb).reshape(N, h * w, 3, H, D)
       a = ops.attention(qkv, out_half=hb)
       x = ops.dense(a, att['out']['kernel'].reshape(C, C), att['out']['bias'], residual=x, math=math, bf16_ring=hb)
       y = ops.layer_norm(x, blk['LayerNorm_1']['scale'], blk['LayerNorm_1']['bias'], out_half=hb)

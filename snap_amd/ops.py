@@ -1069,11 +1069,21 @@ def attention(qkv, scale=None, want_lse=False, out_half=False):
   want_lse: also return the base-2 log-sum-exp of the scaled scores [B, H, N] (for the VJP).
   out_half (inference): the result ONLY rounded to bf16 (the operand of the 'bf16' output projection)."""
   lib = _lib.load()
-  _f32(qkv, 'qkv')
   B, N, three, H, D = qkv.shape
   if three != 3:
     raise ValueError('attention: qkv must be [B, N, 3, H, D]')
   scale = D ** -0.5 if scale is None else float(scale)
+  if qkv.dtype == torch.bfloat16:
+    # the QKV projection's bf16-only output: K / V move at half the bytes (inference; the result in bf16 too)
+    if want_lse or not out_half:
+      raise ValueError('attention: a bf16 qkv is the inference form (out_half=True, no lse)')
+    _chk(qkv, torch.bfloat16, 'qkv')
+    out = torch.empty((B, N, H * D), dtype=torch.bfloat16, device=qkv.device)
+    with _region('attention', 4.0 * B * H * N * N * D, 2.0 * (qkv.numel() + out.numel())):
+      st = lib.snap_attention_bf16io(_p(qkv), _p(out), B, N, H, D, scale, _stream())
+    _lib.check(st, 'snap_attention_bf16io')
+    return out
+  _f32(qkv, 'qkv')
   if out_half:
     if want_lse:
       raise ValueError('attention: out_half is the inference form (no lse)')

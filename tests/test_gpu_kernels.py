@@ -1890,6 +1890,11 @@ def test_bf16_outputs_of_layer_norm_and_attention_are_the_rounded_f32_outputs():
   assert torch.equal(ops.layer_norm(x, gamma, beta, out_half=True), ops.layer_norm(x, gamma, beta).to(torch.bfloat16))
   qkv = _dev(rnd((2, 200, 3, 3, 64), 243))
   assert torch.equal(ops.attention(qkv, out_half=True), ops.attention(qkv).to(torch.bfloat16))
+  # a bf16 qkv: K / V are the values the f32 kernel rounds to; Q is rounded once more (before its scaling)
+  qh = qkv.to(torch.bfloat16)
+  got = ops.attention(qh, out_half=True)
+  want = oracle_ops.attention(qh.float().cpu(), bf16_operands=True)
+  helpers.report('attention bf16 qkv', got.float(), want, atol=8e-3 * float(qkv[:, :, 2].abs().max()), rtol=0)
 
 
 # ----------------------------------------------------------------------------
