@@ -537,7 +537,10 @@ def main(argv=None, emit=True):
   prof = None
   marks = []
   t0 = time.perf_counter()
+  host_enq = []        # host time per step of this loop: the enqueue cost PLUS the launch queue's back-pressure once it is full
+                       # (tools/host_time_probe2.py: the same on an idle GPU = the pure enqueue cost, C2 7.4 ms, C5 8.4, C4 0.44)
   for i in range(args.steps):
+    th0 = time.perf_counter()
     if use_cuda and rank == 0 and i == args.steps - 1:
       if nfl > 1:
         torch.cuda.synchronize(device)  # the profiled step runs ALONE (its events time single launches)
@@ -549,6 +552,8 @@ def main(argv=None, emit=True):
       overlap_prev, ops.OVERLAP_AERIAL = ops.OVERLAP_AERIAL, False
       wgside_prev, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False     # (train: kernel gradients too)
     run_step(i % nfl, 100_000 + i, marks if use_cuda else None)
+    if i < args.steps - 1:
+      host_enq.append(time.perf_counter() - th0)
   ops.set_profiler(None)
   if prof is not None:
     ops.OVERLAP_AERIAL = overlap_prev
@@ -589,6 +594,7 @@ def main(argv=None, emit=True):
             'min': round(min(step_ms), 3), 'median': round(float(np.median(step_ms)), 3),
             'max': round(max(step_ms), 3), 'argmax': int(np.argmax(step_ms)),
         } if step_ms else None,
+        'host_enqueue_ms_per_step': round(1e3 * float(np.median(host_enq)), 3) if host_enq else None,
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,

@@ -131,7 +131,16 @@ def tuning_scope(base=None, **overrides):
     _TUNING_TLS.tuning = prev
 
 
+# the raw handle of torch's current stream on the current device: one C call (torch.cuda.current_stream() builds a
+# Stream object through three layers of device-index resolution: ~9 us per launch, 3-13 ms of a step's host time --
+# a fifth of the C5 step's, which the host bounds)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+  if _raw_stream is not None and _raw_device is not None:
+    return ctypes.c_void_p(_raw_stream(_raw_device()))
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
