@@ -9,5 +9,9 @@ pr.enable()
 bench.main(argv + ['--steps', '20', '--warmup', '2'], emit=False)
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28)
+st = pstats.Stats(pr, stream=s)
+st.sort_stats('tottime').print_stats(28)
 print(s.getvalue()[:6000])
+s2 = io.StringIO()
+pstats.Stats(pr, stream=s2).sort_stats('tottime').print_callers("method 'to' of")
+print(s2.getvalue()[:5000])
