@@ -1420,6 +1420,30 @@ def test_rotate_templates_and_matching(H, R, D, method):
   assert full.shape == (R, 2 * H - 1, 2 * H - 1)
 
 
+@pytest.mark.parametrize('H,R,D', [(100, 8, 16), (86, 12, 32), (64, 4, 8)])
+def test_voting_fft_rotated_entry_equals_the_explicit_templates(H, R, D):
+  """The rotated entry of the frequency-domain voting (templates sampled inside the first transform, masks + counts
+  from the tiled validity pass: 64 x 64 tiles, here with partial tiles and several tiles per side) against the
+  explicit-template entry fed with ``sample_query_templates`` (the stand-alone rotate kernel's templates and masks):
+  the same -inf mask and the same scores."""
+  from snap_amd.models import pose_exhaustive_voting as pev
+  from snap_amd.models import types
+  from snap_amd.utils import grids
+  rng = np.random.default_rng(150 + H)
+  vq = torch.tensor(rng.random((H, H)) > 0.15).to(DEV)
+  fq = (torch.tensor(rng.standard_normal((H, H, D)).astype(np.float32)).to(DEV) * vq[..., None]).contiguous()
+  fm = torch.tensor(rng.standard_normal((H, H, D)).astype(np.float32)).to(DEV)
+  vm = torch.tensor(rng.random((H, H)) > 0.1).to(DEV)
+  g = grids.Grid2D((H, H), 0.25)
+  t, tv = pev.sample_query_templates(fq, vq, R, g)
+  want = pev.template_matching(t, tv, fm, vm, method='fft')
+  got = pev.exhaustive_pose_voting(types.FeaturePlane(fq, vq), types.FeaturePlane(fm, vm), R, g, method='fft')
+  fw, fg = torch.isfinite(want), torch.isfinite(got)
+  assert torch.equal(fw, fg), int((fw != fg).sum())
+  assert 0 < int(fw.sum()) < fw.numel()
+  helpers.report(f'rotated fft entry H={H}', got[fg], want[fw], atol=1e-6 * float(want[fw].abs().max()), rtol=0)
+
+
 @pytest.mark.parametrize('H,R,D,S', [(16, 8, 8, 4), (24, 36, 32, 4), (24, 36, 32, 3), (20, 12, 16, 2)])
 def test_template_matching_shift_stacked(H, R, D, S, monkeypatch):
   """The shift-stacked form of the correlation GEMM (R S^2 filters, stride S) is the direct form
